@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU oracle (oracle/slimm_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py.  Nothing under slimm_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libslimm_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "slimm_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libslimm_oracle.so"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_create.restype = C.c_void_p
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_options.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_char_p]
+        L.orc_db_add_accessions.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p]
+        L.orc_db_add_taxa.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p]
+        L.orc_avg_read_length.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.orc_avg_read_length.restype = C.c_uint32
+        L.orc_reset.argtypes = [C.c_void_p]
+        L.orc_run.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_run.restype = C.c_int
+        L.orc_get_scalars.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_cutoffs.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_ref_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_total_bins.argtypes = [C.c_void_p]
+        L.orc_total_bins.restype = C.c_uint64
+        L.orc_get_bins.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_taxon_count_size.argtypes = [C.c_void_p, C.c_int]
+        L.orc_taxon_count_size.restype = C.c_uint32
+        L.orc_get_taxon_counts.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_children_pairs_size.argtypes = [C.c_void_p, C.c_int]
+        L.orc_children_pairs_size.restype = C.c_uint64
+        L.orc_get_children_pairs.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_text_size.argtypes = [C.c_void_p, C.c_int]
+        L.orc_text_size.restype = C.c_uint64
+        L.orc_get_text.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _blob(strings) -> bytes:
+    return ("\n".join(strings)).encode() + b"\0"
+
+
+@dataclass
+class OracleResult:
+    no_hits: bool
+    scalars: Dict[str, int]
+    cutoffs: Tuple[float, float, float]  # coverage, uniq coverage, expected coverage
+    reads_count: np.ndarray
+    uniq_reads_count: np.ndarray
+    uniq_reads_count2: np.ndarray
+    nbins: np.ndarray
+    nz_cov: np.ndarray
+    nz_uniq_cov: np.ndarray
+    nz_uniq_cov2: np.ndarray
+    valid: np.ndarray
+    abundance: np.ndarray
+    uniq_abundance: np.ndarray
+    cov: np.ndarray  # concatenated, unpadded
+    uniq_cov: np.ndarray
+    uniq_cov2: np.ndarray
+    lca_direct: Dict[int, int]  # taxid -> count after direct LCA hits only
+    lca_direct_children: set  # {(taxid, ref)}
+    taxon_count: Dict[int, int]  # final
+    taxon_children: set
+    profile_tsv: str
+    raw_tsv: str
+    coverage_csv: Tuple[str, str, str]
+    phase_seconds: Tuple[float, float, float]
+
+    def profile_rows(self) -> Dict[str, Tuple[float, int, str]]:
+        return parse_profile(self.profile_tsv)
+
+
+def parse_profile(text: str) -> Dict[str, Tuple[float, int, str]]:
+    """profile TSV -> {taxa_id column: (abundance, read_count, lineage)}; row order is not significant (Q16)."""
+    rows = {}
+    lines = text.strip("\n").split("\n")
+    assert lines[0] == "taxa_level\ttaxa_id\tlinage\tabundance\tread_count", lines[0]
+    for ln in lines[1:]:
+        level, tid, lin, ab, cnt = ln.split("\t")
+        assert tid not in rows, f"duplicate profile row {tid}"
+        rows[tid] = (float(ab), int(cnt), lin)
+    return rows
+
+
+_SCALARS = ["hits", "matches", "uniq_matches", "uniq_hits", "uniq_matches2", "reference_count", "matched_ref_length",
+            "failed_by_cov", "failed_by_uniq_cov", "failed_by_min_read", "n_valid", "bin_width", "min_reads",
+            "profile_count", "profile_failed"]
+
+
+class Oracle:
+    """One `slimm` object of the reference (one database, options; run() = one input file)."""
+
+    def __init__(self, taxonomy, options):
+        L = lib()
+        self.h = C.c_void_p(L.orc_create())
+        L.orc_set_options(self.h, options.bin_width, options.min_reads, options.cov_cut_off,
+                          options.abundance_cut_off, options.rank.encode())
+        lin = np.ascontiguousarray(taxonomy.lineage, dtype=np.uint32)
+        L.orc_db_add_accessions(self.h, len(taxonomy.accessions), _blob(taxonomy.accessions), _p(lin))
+        L.orc_db_add_taxa(self.h, len(taxonomy.tax_name), _p(taxonomy.tax_id), _p(taxonomy.tax_rank),
+                          _blob(taxonomy.tax_name))
+
+    def __del__(self):
+        try:
+            lib().orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def run(self, ref_names, ref_len, records, avg_read_len, want_raw=True, want_cov=False, use_qnames=True,
+            collect_bins=True) -> OracleResult:
+        L = lib()
+        L.orc_reset(self.h)
+        ref_len = np.ascontiguousarray(ref_len, dtype=np.uint32)
+        qblob = _blob(records.qname) if (use_qnames and records.qname is not None) else None
+        ph = np.zeros(3, dtype=np.float64)
+        rc = L.orc_run(self.h, len(ref_names), _blob(ref_names), _p(ref_len), int(avg_read_len), len(records), qblob,
+                       _p(records.read_key), _p(records.flag), _p(records.ref_id), _p(records.begin_pos),
+                       int(want_raw), int(want_cov), _p(ph))
+        R = len(ref_names)
+        sc = np.zeros(15, dtype=np.uint32)
+        L.orc_get_scalars(self.h, _p(sc))
+        cut = np.zeros(3, dtype=np.float32)
+        if rc == 0:
+            L.orc_get_cutoffs(self.h, _p(cut))
+        u = np.zeros((R, 8), dtype=np.uint32)
+        f = np.zeros((R, 2), dtype=np.float32)
+        L.orc_get_ref_stats(self.h, _p(u), _p(f))
+        B = L.orc_total_bins(self.h)
+        bins = []
+        for w in range(3):
+            b = np.zeros(B if collect_bins else 0, dtype=np.uint32)
+            if collect_bins:
+                L.orc_get_bins(self.h, w, _p(b))
+            bins.append(b)
+
+        def counts(stage):
+            n = L.orc_taxon_count_size(self.h, stage)
+            t = np.zeros(n, dtype=np.uint32)
+            c = np.zeros(n, dtype=np.uint32)
+            L.orc_get_taxon_counts(self.h, stage, _p(t), _p(c))
+            return {int(a): int(b) for a, b in zip(t, c)}
+
+        def children(stage):
+            n = L.orc_children_pairs_size(self.h, stage)
+            t = np.zeros(n, dtype=np.uint32)
+            r = np.zeros(n, dtype=np.uint32)
+            L.orc_get_children_pairs(self.h, stage, _p(t), _p(r))
+            return set(zip(t.tolist(), r.tolist()))
+
+        def text(which):
+            n = L.orc_text_size(self.h, which)
+            buf = C.create_string_buffer(n)
+            L.orc_get_text(self.h, which, buf)
+            return buf.raw.decode()
+
+        return OracleResult(
+            no_hits=(rc == 1), scalars={k: int(v) for k, v in zip(_SCALARS, sc)},
+            cutoffs=(float(cut[0]), float(cut[1]), float(cut[2])),
+            reads_count=u[:, 0].copy(), uniq_reads_count=u[:, 1].copy(), uniq_reads_count2=u[:, 2].copy(),
+            nbins=u[:, 3].copy(), nz_cov=u[:, 4].copy(), nz_uniq_cov=u[:, 5].copy(), nz_uniq_cov2=u[:, 6].copy(),
+            valid=u[:, 7].copy(), abundance=f[:, 0].copy(), uniq_abundance=f[:, 1].copy(),
+            cov=bins[0], uniq_cov=bins[1], uniq_cov2=bins[2],
+            lca_direct=counts(0), lca_direct_children=children(0), taxon_count=counts(1), taxon_children=children(1),
+            profile_tsv=text(0), raw_tsv=text(1), coverage_csv=(text(2), text(3), text(4)),
+            phase_seconds=(float(ph[0]), float(ph[1]), float(ph[2])))
+
+
+def run_workload(w, **kw) -> OracleResult:
+    """Run one Workload (slimm_amd.workload.Workload) through a fresh oracle."""
+    return Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, **kw)
+
+
+def avg_read_length(l_seq: np.ndarray, sample: int = 100000) -> int:
+    l_seq = np.ascontiguousarray(l_seq, dtype=np.uint32)
+    return int(lib().orc_avg_read_length(_p(l_seq), l_seq.shape[0], sample))

@@ -1,0 +1,215 @@
+/* ============================================================================
+ * slimm_hip.h -- C ABI of the MI355X-native SLIMM alignment-to-profile path.
+ *
+ * The reference (seqan/slimm) has no plugin/FFI interface; the seam this library replaces is
+ * the trio of `class slimm` member calls made by slimm::get_profiles()
+ * (reference src/slimm.hpp:449 analyze_alignments, :464 filter_alignments,
+ * :485 get_reads_lca_count, :489 write_abundance) and the public members they communicate
+ * through (src/slimm.hpp:103-127).  Each entry point below names the reference code it stands for.
+ *
+ * Conventions: plain pointers and sizes, no C++ types, no exceptions across the boundary.
+ * Every function returning int returns SLIMM_OK (0) or a negative SLIMM_E_* code;
+ * slimm_last_error() gives the text.  A context is NOT thread-safe (the reference object is
+ * single-threaded, one `slimm` per process: src/slimm.hpp:946-958); use one context per GPU.
+ * All `const` host arrays passed in are copied before the call returns; the caller keeps
+ * ownership.  Device work runs on a stream owned by the context; every call that returns
+ * host-visible results has synchronised that stream.
+ * ==========================================================================*/
+#ifndef SLIMM_HIP_H
+#define SLIMM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLIMM_LINEAGE_LEN 8 /* reference src/misc.hpp:4 LINAGE_LENGTH */
+
+enum {
+    SLIMM_OK = 0,
+    SLIMM_E_INVALID = -1,   /* bad argument / call order */
+    SLIMM_E_HIP = -2,       /* HIP runtime error (no GPU, out of memory, ...) */
+    SLIMM_E_REF_RANGE = -3, /* a record names ref_id >= n_refs (undefined behaviour in the reference) */
+    SLIMM_E_RUN_LENGTH = -4,/* one read has more alignment records than the look-back window supports */
+    SLIMM_E_NO_HITS = 1     /* not an error: no mapped record (reference prints a warning and writes nothing, src/slimm.hpp:451-455) */
+};
+
+/* Order of the record stream (SAM @HD SO:/GO: tags).  GROUPED = all records of one read name are
+ * contiguous (mapper output order, `GO:query` / `SO:queryname`); ANY = no assumption (the reference
+ * accepts any order because it groups through a hash map, src/slimm.hpp:204-211) -- the records are
+ * then stably sorted by read identity on the device first. */
+enum { SLIMM_ORDER_GROUPED = 0, SLIMM_ORDER_ANY = 1 };
+
+/* Taxonomic ranks, reference src/misc.hpp:24-35. */
+enum {
+    SLIMM_RANK_STRAIN = 0, SLIMM_RANK_SPECIES, SLIMM_RANK_GENUS, SLIMM_RANK_FAMILY, SLIMM_RANK_ORDER,
+    SLIMM_RANK_CLASS, SLIMM_RANK_PHYLUM, SLIMM_RANK_SUPERKINGDOM, SLIMM_RANK_INTERMEDIATE
+};
+
+typedef struct slimm_ctx slimm_ctx;
+
+/* What slimm::get_profiles() knows before the record loop starts (src/slimm.hpp:409-445) plus
+ * the arg_options the path reads (src/slimm.hpp:49-87). */
+typedef struct {
+    uint32_t n_refs;          /* header contigs, index = BAM refID */
+    const uint32_t* ref_len;  /* [n_refs] contig lengths */
+    const uint32_t* lineage;  /* [n_refs*8] taxids per contig: own, species, genus, family, order, class, phylum,
+                                 superkingdom = db.ac__taxid[accession]; all-zero row for an accession missing from the
+                                 database (src/slimm.hpp:433-442) */
+    uint32_t bin_width;       /* -w; 0 = use avg_read_len (src/slimm.hpp:412-413) */
+    uint32_t avg_read_len;    /* get_avg_read_length() of the input (src/misc.hpp:509-522) */
+    uint32_t min_reads;       /* -mr; 0 = derive 1+(matches-1)/10000 (src/slimm.hpp:458-459); a statistic only */
+    float cov_cut_off;        /* -cc quantile (default 0.95) */
+    float abundance_cut_off;  /* -ac (default 0.01) */
+    const char* rank;         /* -r: "species" (default), "genus", "family", "order", "class", "phylum" */
+    /* db.taxid__name (src/misc.hpp:84): rank and name per taxid; taxids not listed read as (strain, "") like the
+       reference's default-constructed map entry (src/slimm.hpp:565). */
+    uint32_t n_taxa;
+    const uint32_t* tax_id;   /* [n_taxa] */
+    const uint32_t* tax_rank; /* [n_taxa] SLIMM_RANK_* */
+    const char* const* tax_name; /* [n_taxa] NUL-terminated */
+    int device;               /* HIP device ordinal */
+    int record_order;         /* SLIMM_ORDER_* */
+} slimm_config;
+
+/* slimm::slimm(options) + the per-file reference initialisation of get_profiles() (src/slimm.hpp:96-101, 420-445). */
+int slimm_create(const slimm_config* cfg, slimm_ctx** out);
+void slimm_destroy(slimm_ctx* ctx);
+const char* slimm_last_error(const slimm_ctx* ctx); /* ctx may be NULL: error of the last failed slimm_create */
+
+/* slimm::reset() (src/slimm.hpp:167-188): forget records and results, keep configuration, allocations and --
+ * like the reference -- the cached cut-offs (quirk Q8: they survive reset in -d mode). */
+int slimm_reset(slimm_ctx* ctx);
+/* Clears the cached cut-offs as well (a fresh `slimm` object). */
+int slimm_reset_cutoffs(slimm_ctx* ctx);
+
+/* ---- record stream: what the loop of analyze_alignments() reads from each BamAlignmentRecord
+ *      (src/slimm.hpp:194-211): qName identity, flag, rID, beginPos; file order. ------------------
+ * read_key: identity of the qName (equal names <=> equal keys); only the low 62 bits are significant
+ * (the mate number from flag 0x40/0x80 is folded into the two low bits on the device). */
+int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);
+/* Append a batch from host memory (copied to the device before return). */
+int slimm_push_records(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
+                       const uint16_t* flag, uint64_t n);
+/* Use records already resident in device memory, without copying; the arrays must stay valid and unchanged
+ * until slimm_reset().  Replaces anything pushed before. */
+int slimm_set_records_device(slimm_ctx* ctx, const uint64_t* d_read_key, const int32_t* d_ref_id,
+                             const int32_t* d_begin_pos, const uint16_t* d_flag, uint64_t n);
+
+/* ---- phase A: slimm::analyze_alignments() (src/slimm.hpp:191-303) on this context's records:
+ * grouping by read, first-bin per (read, ref), cov / uniq_cov histograms.  Local to this GPU. */
+int slimm_analyze_alignments(slimm_ctx* ctx);
+
+/* Multi-GPU exchange point (no reference counterpart; reads are sharded across ranks):
+ * device buffer [cov | uniq_cov | 16 scalar words] of *n_words uint32 that the caller sums across ranks in place
+ * (one all-reduce) between slimm_analyze_alignments() and slimm_finish_coverage().  The stream is synchronised. */
+int slimm_coverage_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
+
+/* End of phase A: per-reference reads_count / uniq_reads_count / non-zero bin counts
+ * (reference_contig.hpp:84-91,148-155) from the (reduced) bins, and the float statistics of src/slimm.hpp:259-302.
+ * Returns SLIMM_E_NO_HITS when hits_count == 0. */
+int slimm_finish_coverage(slimm_ctx* ctx);
+
+/* Install phase-A per-reference results computed elsewhere, instead of slimm_analyze_alignments() +
+ * slimm_finish_coverage(): for host-only contexts (device = -1, no GPU touched) that run just the scalar host part
+ * of the path -- cut-offs, propagation, profile -- e.g. on a rank that merges results.  uniq_matches is the sum of
+ * uniq_reads_count. */
+int slimm_set_coverage_columns(slimm_ctx* ctx, const uint32_t* reads_count, const uint32_t* uniq_reads_count,
+                               const uint32_t* nz_cov, const uint32_t* nz_uniq_cov, uint32_t hits_count,
+                               uint32_t matches_count);
+
+/* ---- phase B + C(1): slimm::filter_alignments() (src/slimm.hpp:351-392): cut-offs (coverage_cut_off :328-344,
+ * uniq_coverage_cut_off :672-688, get_quantile_cut_off misc.hpp:197-216), valid set, per-read update
+ * (read_stat.hpp:98-114), uniq_cov2 -- fused on the device with the per-read LCA of
+ * get_reads_lca_count() step 1 (src/slimm.hpp:536-557, get_lca :516-531). Local to this GPU. */
+int slimm_filter_alignments(slimm_ctx* ctx);
+
+/* Multi-GPU: the additive partial results of phase B/C(1) of this rank, to be merged across ranks by the caller.
+ *   uniq_reads_count2 [n_refs], lca_count [n_taxa_dense] (sum), level_marks [n_refs] (bitwise OR),
+ *   pairs: (dense taxon << 32 | ref) of reads whose refs agree at no level (set union), scalars[4] (sum). */
+typedef struct {
+    uint32_t n_refs, n_taxa_dense;
+    uint32_t* uniq_reads_count2;
+    uint32_t* lca_count;
+    uint32_t* level_marks;
+    uint64_t* pairs;
+    uint32_t n_pairs;
+    uint32_t scalars[4]; /* [0] uniq_matches_count2 */
+} slimm_partials;
+/* The dense taxon index used by lca_count and pairs: ascending distinct taxids of the lineage table. */
+int slimm_dense_taxa(slimm_ctx* ctx, uint32_t* n, const uint32_t** taxid);
+int slimm_get_partials(slimm_ctx* ctx, slimm_partials* out);       /* pointers stay owned by ctx, valid until reset */
+int slimm_set_partials(slimm_ctx* ctx, const slimm_partials* in);  /* install merged values (copied) */
+
+/* ---- phase C(2,3): the propagation part of slimm::get_reads_lca_count() (src/slimm.hpp:560-610). */
+int slimm_get_reads_lca_count(slimm_ctx* ctx);
+
+/* ---- slimm::write_abundance() (src/slimm.hpp:733-843): the final profile.  The text is identical in format to
+ * the reference's <prefix>_profile.tsv; rows come in ascending taxid order (the reference's order is that of an
+ * unordered_map and carries no meaning).  The buffer is owned by ctx. */
+int slimm_write_abundance(slimm_ctx* ctx, const char** text, uint64_t* len);
+/* Same, written to a file (path = get_tsv_file_name(...) result, computed by the caller). */
+int slimm_write_abundance_file(slimm_ctx* ctx, const char* path);
+
+/* ---- results (the public members of class slimm, src/slimm.hpp:105-127) ---- */
+typedef struct {
+    uint32_t hits_count, matches_count, uniq_matches_count, uniq_hits_count, uniq_matches_count2;
+    uint32_t reference_count, matched_ref_length;
+    uint32_t failed_by_cov, failed_by_uniq_cov, failed_by_min_read, n_valid;
+    uint32_t bin_width, min_reads, avg_read_len;
+    uint32_t profile_count, profile_failed;
+    float coverage_cut_off, uniq_coverage_cut_off, expected_coverage;
+    uint64_t n_records, n_targets; /* records pushed; distinct (read, ref) pairs */
+    uint64_t total_bins;           /* sum over refs of len/bin_width + 1 */
+} slimm_stats;
+int slimm_get_stats(slimm_ctx* ctx, slimm_stats* out);
+
+/* Per-reference columns; any pointer may be NULL.  All arrays [n_refs]. */
+typedef struct {
+    uint32_t* reads_count;
+    uint32_t* uniq_reads_count;
+    uint32_t* uniq_reads_count2;
+    uint32_t* nbins;
+    uint32_t* nz_cov;       /* cov.none_zero_bin_count() */
+    uint32_t* nz_uniq_cov;
+    uint32_t* nz_uniq_cov2;
+    uint8_t* valid;         /* member of valid_ref_ids */
+    float* abundance;       /* src/slimm.hpp:266-279 */
+    float* uniq_abundance;  /* src/slimm.hpp:287-300 */
+} slimm_ref_columns;
+int slimm_get_ref_columns(slimm_ctx* ctx, slimm_ref_columns* out);
+
+/* Coverage bins of every reference, concatenated without padding in refID order (total_bins words).
+ * which: 0 = cov, 1 = uniq_cov, 2 = uniq_cov2 (reference_contig.hpp:110-112). */
+int slimm_get_bins(slimm_ctx* ctx, int which, uint32_t* out);
+
+/* taxon_id__read_count (src/slimm.hpp:126). stage 0: direct LCA hits only (:536-557); 1: final (:560-610). */
+int slimm_taxon_count_size(slimm_ctx* ctx, int stage, uint32_t* n);
+int slimm_get_taxon_counts(slimm_ctx* ctx, int stage, uint32_t* taxid, uint32_t* count);
+/* taxon_id__children (src/slimm.hpp:127) flattened to (taxid, ref) pairs, sorted. */
+int slimm_children_pairs_size(slimm_ctx* ctx, int stage, uint64_t* n);
+int slimm_get_children_pairs(slimm_ctx* ctx, int stage, uint32_t* taxid, uint32_t* ref);
+
+/* ---- measurement ---- */
+/* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
+int slimm_enable_kernel_timing(slimm_ctx* ctx, int on);
+/* Names (static strings) and accumulated milliseconds / launch counts since the last call with reset != 0. */
+int slimm_kernel_times(slimm_ctx* ctx, const char** names, double* ms, uint32_t* launches, uint32_t cap,
+                       uint32_t* n, int reset);
+
+/* ---- host-only helpers (no GPU needed; used by the host driver and testable on CPU) ---- */
+/* get_avg_read_length (src/misc.hpp:509-522). Returns 0 when no record has a sequence (the reference divides by 0). */
+uint32_t slimm_host_avg_read_length(const uint32_t* l_seq, uint64_t n, uint32_t sample_size);
+/* get_quantile_cut_off<float> (src/misc.hpp:197-216), float32, same operation order. */
+float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q);
+/* Bin of one record (src/slimm.hpp:200-201). */
+uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width);
+/* Library build info. */
+const char* slimm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIMM_HIP_H */

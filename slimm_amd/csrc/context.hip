@@ -1,0 +1,859 @@
+// Context, pipeline orchestration and the C ABI (include/slimm_hip.h) of the MI355X SLIMM path.
+//
+// One context = one `slimm` object working on one input file on one GPU (reference src/slimm.hpp:92-165).
+// Device work is queued on a private stream; the only host<->device round trips of a run are
+//   finish_coverage : per-reference {sum, non-zero} of cov / uniq_cov (16 bytes per reference)  -> host cut-offs
+//   filter          : valid mask up (1 byte per reference); uniq2 / LCA counts / child marks down.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/slimm_hip.h"
+#include "host_profile.hpp"
+#include "kernels.h"
+
+namespace {
+
+using namespace slimm;
+
+std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+};
+
+enum KernelId {
+    K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FLAGS, K_BUILD_CSR, K_HIST, K_REF_STATS, K_FILTER_LCA,
+    K_REF_STATS2, K_COUNT
+};
+const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
+                                     "k_flags", "k_build_csr", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2"};
+
+constexpr uint32_t kTailWords = 64;
+
+}  // namespace
+
+struct slimm_ctx {
+    std::unique_ptr<HostProfile> host;
+    std::string err;
+    int device = -1;  // -1: host-only context
+    int order = SLIMM_ORDER_GROUPED;
+    hipStream_t stream = nullptr;
+
+    uint32_t R = 0, T = 0;
+    uint64_t Bp = 0;                   // padded bins per coverage array (multiple of 64)
+    std::vector<uint32_t> bin_off_h;   // [R+1] padded offsets
+
+    // static tables
+    DevBuf<uint32_t> d_ref_len, d_bin_off, d_lin_dense;
+    DevBuf<uint8_t> d_valid;
+    // records
+    DevBuf<uint64_t> in_key;
+    DevBuf<int32_t> in_ref, in_pos;
+    DevBuf<uint16_t> in_flag;
+    DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
+    bool borrowed = false;
+    uint64_t n_pushed = 0;
+    // work arrays
+    DevBuf<uint64_t> c_ident, s_ident;
+    DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist;
+    DevBuf<uint8_t> c_fl;
+    DevBuf<uint32_t> tgt_ref, tgt_gbin, read_off;
+    DevBuf<uint2> tile_cnt;
+    DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
+    DevBuf<uint32_t> counters;   // CNT_WORDS
+    DevBuf<uint32_t> ref_stats;  // [R*4] then [R*4]
+    DevBuf<uint32_t> lca_count, marks;
+    DevBuf<uint64_t> pair_tab, pair_list;
+    uint32_t pair_cap = 0;  // power of two
+    // pinned staging
+    PinBuf<uint32_t> h_stats, h_small, h_lca, h_marks;
+    PinBuf<uint64_t> h_pairs;
+
+    // per-run state
+    bool analyzed = false, covered = false, filtered = false, counted = false, no_hits = false;
+    uint32_t local_V = 0, local_M = 0, local_P = 0;
+    uint32_t n_pairs = 0;
+    std::vector<uint32_t> nz_ucov2;
+    // partials handed out / installed
+    std::vector<uint32_t> part_u2, part_lca, part_marks;
+    std::vector<uint64_t> part_pairs;
+
+    // kernel timing
+    bool timing = false;
+    struct Ev {
+        hipEvent_t a, b;
+        int id;
+    };
+    std::vector<Ev> ev_used, ev_free;
+    double k_ms[K_COUNT] = {0};
+    uint32_t k_n[K_COUNT] = {0};
+
+    uint32_t* cov() { return bins.p; }
+    uint32_t* ucov() { return bins.p + Bp; }
+    uint32_t* tail() { return bins.p + 2 * Bp; }
+    uint32_t* ucov2() { return bins.p + 2 * Bp + kTailWords; }
+};
+
+namespace {
+
+int fail(slimm_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail((c), SLIMM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct KernelTimer {  // brackets one launch (or a group) with events when timing is on
+    slimm_ctx* c;
+    slimm_ctx::Ev ev{};
+    bool on;
+    KernelTimer(slimm_ctx* ctx, int id) : c(ctx), on(ctx->timing) {
+        if (!on) return;
+        if (!c->ev_free.empty()) {
+            ev = c->ev_free.back();
+            c->ev_free.pop_back();
+        } else {
+            (void)hipEventCreate(&ev.a);
+            (void)hipEventCreate(&ev.b);
+        }
+        ev.id = id;
+        (void)hipEventRecord(ev.a, c->stream);
+    }
+    ~KernelTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, c->stream);
+        c->ev_used.push_back(ev);
+    }
+};
+
+void drain_events(slimm_ctx* c) {
+    for (auto& e : c->ev_used) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->k_ms[e.id] += ms;
+            c->k_n[e.id] += 1;
+        }
+        c->ev_free.push_back(e);
+    }
+    c->ev_used.clear();
+}
+
+int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
+    const uint32_t nt = num_tiles(n) + 2;
+    HIP_TRY(c, c->c_ident.ensure(n + 1));
+    HIP_TRY(c, c->c_ref.ensure(n + 1));
+    HIP_TRY(c, c->c_gbin.ensure(n + 1));
+    HIP_TRY(c, c->c_fl.ensure(n + 1));
+    HIP_TRY(c, c->tgt_ref.ensure(n + 1));
+    HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
+    HIP_TRY(c, c->read_off.ensure(static_cast<size_t>(n) + 2));
+    HIP_TRY(c, c->tile_cnt.ensure(nt));
+    if (c->order == SLIMM_ORDER_ANY) {
+        HIP_TRY(c, c->s_ident.ensure(n + 1));
+        HIP_TRY(c, c->s_ref.ensure(n + 1));
+        HIP_TRY(c, c->s_gbin.ensure(n + 1));
+        HIP_TRY(c, c->sort_hist.ensure(256ull * nt));
+    }
+    return SLIMM_OK;
+}
+
+int ensure_pair_table(slimm_ctx* c, uint32_t cap) {
+    if (cap <= c->pair_cap) return SLIMM_OK;
+    HIP_TRY(c, c->pair_tab.ensure(cap));
+    HIP_TRY(c, c->pair_list.ensure(cap / 2 + 1));
+    HIP_TRY(c, c->h_pairs.ensure(cap / 2 + 1));
+    c->pair_cap = cap;
+    return SLIMM_OK;
+}
+
+int check_device_errors(slimm_ctx* c, uint32_t err) {
+    if (err & ERR_REF_RANGE) return fail(c, SLIMM_E_REF_RANGE, "a record names a reference id >= n_refs");
+    if (err & ERR_RUN_LENGTH)
+        return fail(c, SLIMM_E_RUN_LENGTH, "a read has more than 4096 alignment records in one run");
+    return SLIMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* slimm_version(void) { return "slimm_hip 0.1 (gfx950)"; }
+
+const char* slimm_last_error(const slimm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, SLIMM_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->n_refs == 0 || !cfg->ref_len || !cfg->lineage) return fail(nullptr, SLIMM_E_INVALID, "no references");
+    if (cfg->n_refs >= 0x7fffffffu) return fail(nullptr, SLIMM_E_INVALID, "too many references");
+    if (cfg->bin_width == 0 && cfg->avg_read_len == 0)
+        return fail(nullptr, SLIMM_E_INVALID, "bin_width and avg_read_len are both 0 (the reference divides by zero)");
+    HostConfig hc;
+    hc.n_refs = cfg->n_refs;
+    hc.ref_len.assign(cfg->ref_len, cfg->ref_len + cfg->n_refs);
+    hc.lineage.assign(cfg->lineage, cfg->lineage + static_cast<size_t>(cfg->n_refs) * 8);
+    hc.bin_width = cfg->bin_width;
+    hc.avg_read_len = cfg->avg_read_len;
+    hc.min_reads = cfg->min_reads;
+    hc.cov_cut_off = cfg->cov_cut_off;
+    hc.abundance_cut_off = cfg->abundance_cut_off;
+    hc.rank = cfg->rank ? cfg->rank : "species";
+    {
+        uint32_t rk = rank_from_string(hc.rank);
+        if (rk < 1 || rk > 6)  // "strains", "superkingdom" and "all" are broken in the reference (Q14)
+            return fail(nullptr, SLIMM_E_INVALID, "rank must be one of species, genus, family, order, class, phylum");
+    }
+    if (cfg->n_taxa) {
+        if (!cfg->tax_id || !cfg->tax_rank || !cfg->tax_name) return fail(nullptr, SLIMM_E_INVALID, "taxa arrays missing");
+        hc.tax_id.assign(cfg->tax_id, cfg->tax_id + cfg->n_taxa);
+        hc.tax_rank.assign(cfg->tax_rank, cfg->tax_rank + cfg->n_taxa);
+        hc.tax_name.reserve(cfg->n_taxa);
+        for (uint32_t i = 0; i < cfg->n_taxa; ++i) hc.tax_name.emplace_back(cfg->tax_name[i] ? cfg->tax_name[i] : "");
+    }
+    std::unique_ptr<slimm_ctx> c(new slimm_ctx());
+    c->host.reset(new HostProfile(hc));
+    c->R = cfg->n_refs;
+    c->T = c->host->n_taxa_dense();
+    c->device = cfg->device;
+    c->order = cfg->record_order;
+    // padded bin layout: every reference starts on a 16-byte boundary
+    c->bin_off_h.resize(c->R + 1);
+    uint64_t off = 0;
+    for (uint32_t r = 0; r < c->R; ++r) {
+        c->bin_off_h[r] = static_cast<uint32_t>(off);
+        off += (static_cast<uint64_t>(c->host->nbins()[r]) + 3) & ~3ull;
+        if (off >= 0xfffffff0ull) return fail(nullptr, SLIMM_E_INVALID, "more than 2^32 coverage bins; use a larger bin width");
+    }
+    c->bin_off_h[c->R] = static_cast<uint32_t>(off);
+    c->Bp = (off + 63) & ~63ull;
+
+    if (c->device >= 0) {
+        slimm_ctx* cc = c.get();
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0)
+            return fail(nullptr, SLIMM_E_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+        if (c->device >= ndev) return fail(nullptr, SLIMM_E_INVALID, "device %d out of range (%d devices)", c->device, ndev);
+#define HIP_TRY0(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(nullptr, SLIMM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+        HIP_TRY0(hipSetDevice(c->device));
+        HIP_TRY0(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
+        HIP_TRY0(cc->d_ref_len.ensure(c->R));
+        HIP_TRY0(cc->d_bin_off.ensure(c->R + 1));
+        HIP_TRY0(cc->d_lin_dense.ensure(static_cast<size_t>(c->R) * 8));
+        HIP_TRY0(cc->d_valid.ensure(c->R));
+        HIP_TRY0(cc->bins.ensure(3 * c->Bp + kTailWords));
+        HIP_TRY0(cc->counters.ensure(CNT_WORDS));
+        HIP_TRY0(cc->ref_stats.ensure(static_cast<size_t>(c->R) * 8));
+        HIP_TRY0(cc->lca_count.ensure(c->T));
+        HIP_TRY0(cc->marks.ensure(c->R));
+        HIP_TRY0(cc->h_stats.ensure(static_cast<size_t>(c->R) * 8));
+        HIP_TRY0(cc->h_small.ensure(CNT_WORDS + kTailWords));
+        HIP_TRY0(cc->h_lca.ensure(c->T));
+        HIP_TRY0(cc->h_marks.ensure(c->R));
+        HIP_TRY0(hipMemcpy(cc->d_ref_len.p, hc.ref_len.data(), c->R * 4, hipMemcpyHostToDevice));
+        HIP_TRY0(hipMemcpy(cc->d_bin_off.p, c->bin_off_h.data(), (c->R + 1) * 4, hipMemcpyHostToDevice));
+        HIP_TRY0(hipMemcpy(cc->d_lin_dense.p, c->host->lineage_dense().data(), static_cast<size_t>(c->R) * 32,
+                           hipMemcpyHostToDevice));
+#undef HIP_TRY0
+        uint32_t cap = 1u << 16;
+        while (cap < 8ull * c->R && cap < (1u << 30)) cap <<= 1;
+        int rc = ensure_pair_table(cc, cap);
+        if (rc != SLIMM_OK) {
+            g_create_error = cc->err;
+            return rc;
+        }
+    }
+    *out = c.release();
+    return SLIMM_OK;
+}
+
+void slimm_destroy(slimm_ctx* c) {
+    if (!c) return;
+    if (c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        for (auto& e : c->ev_used) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        for (auto& e : c->ev_free) {
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+int slimm_reset(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    c->host->reset();
+    c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
+    c->n_pushed = 0;
+    c->borrowed = false;
+    c->rec = DeviceRecords();
+    c->local_V = c->local_M = c->local_P = 0;
+    c->n_pairs = 0;
+    return SLIMM_OK;
+}
+
+int slimm_reset_cutoffs(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    c->host->reset_cutoffs();
+    return SLIMM_OK;
+}
+
+int slimm_reserve(slimm_ctx* c, uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
+    if (c->borrowed) return fail(c, SLIMM_E_INVALID, "records are borrowed device arrays; reset first");
+    (void)hipSetDevice(c->device);
+    if (n <= c->in_key.cap) return SLIMM_OK;
+    // grow, keeping what was pushed
+    uint64_t cap = std::max<uint64_t>(n, c->in_key.cap * 2);
+    if (cap >= 0x7fffffffull) cap = 0x7ffffffeull;
+    DevBuf<uint64_t> k;
+    DevBuf<int32_t> r, p;
+    DevBuf<uint16_t> f;
+    HIP_TRY(c, k.ensure(cap));
+    HIP_TRY(c, r.ensure(cap));
+    HIP_TRY(c, p.ensure(cap));
+    HIP_TRY(c, f.ensure(cap));
+    if (c->n_pushed) {
+        HIP_TRY(c, hipMemcpyAsync(k.p, c->in_key.p, c->n_pushed * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(r.p, c->in_ref.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(p.p, c->in_pos.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(f.p, c->in_flag.p, c->n_pushed * 2, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    std::swap(c->in_key.p, k.p);
+    std::swap(c->in_key.cap, k.cap);
+    std::swap(c->in_ref.p, r.p);
+    std::swap(c->in_ref.cap, r.cap);
+    std::swap(c->in_pos.p, p.p);
+    std::swap(c->in_pos.cap, p.cap);
+    std::swap(c->in_flag.p, f.p);
+    std::swap(c->in_flag.cap, f.cap);
+    return SLIMM_OK;
+}
+
+int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
+                       uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    int rc = slimm_reserve(c, c->n_pushed + n);
+    if (rc != SLIMM_OK) return rc;
+    const uint64_t o = c->n_pushed;
+    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_flag.p + o, flag, n * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may reuse its buffers on return
+    c->n_pushed += n;
+    c->rec.key = c->in_key.p;
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.flag = c->in_flag.p;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    return SLIMM_OK;
+}
+
+int slimm_set_records_device(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos,
+                             const uint16_t* flag, uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
+    if (n && (!key || !ref || !pos || !flag)) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    c->rec.key = key;
+    c->rec.ref = ref;
+    c->rec.pos = pos;
+    c->rec.flag = flag;
+    c->rec.n = static_cast<uint32_t>(n);
+    c->n_pushed = n;
+    c->borrowed = true;
+    return SLIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ phase A
+int slimm_analyze_alignments(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context: install results with slimm_set_coverage_columns");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "already analysed; reset first");
+    (void)hipSetDevice(c->device);
+    const uint32_t n = c->rec.n;
+    int rc = ensure_work_buffers(c, n);
+    if (rc != SLIMM_OK) return rc;
+    hipStream_t st = c->stream;
+    {
+        KernelTimer t(c, K_MEMSET);
+        HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (2 * c->Bp + kTailWords) * sizeof(uint32_t), st));
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_WORDS * sizeof(uint32_t), st));
+    }
+    const uint32_t nt = num_tiles(n);
+    const HostConfig& hc = c->host->config();
+    {
+        KernelTimer t(c, K_VALID_COUNT);
+        launch_valid_count(st, c->rec, c->R, c->tile_cnt.p, c->counters.p);
+    }
+    {
+        KernelTimer t(c, K_SCAN);
+        launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_V, -1, nullptr);
+    }
+    {
+        KernelTimer t(c, K_COMPACT);
+        launch_compact(st, c->rec, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, hc.avg_read_len / 2, hc.bin_width,
+                       c->c_ident.p, c->c_ref.p, c->c_gbin.p);
+    }
+    if (c->order == SLIMM_ORDER_ANY) {
+        KernelTimer t(c, K_SORT);
+        launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
+                             c->s_gbin.p, c->sort_hist.p);
+    }
+    {
+        KernelTimer t(c, K_FLAGS);
+        launch_flags(st, n, c->c_ident.p, c->c_ref.p, c->counters.p, c->c_fl.p, c->tile_cnt.p);
+    }
+    {
+        KernelTimer t(c, K_SCAN);
+        launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p);
+    }
+    {
+        KernelTimer t(c, K_BUILD_CSR);
+        launch_build_csr(st, n, c->c_fl.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tile_cnt.p, c->tgt_ref.p,
+                         c->tgt_gbin.p, c->read_off.p);
+    }
+    {
+        KernelTimer t(c, K_HIST);
+        launch_hist(st, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->cov(), c->ucov());
+    }
+    launch_publish_tail(st, c->counters.p, c->tail());
+    HIP_TRY(c, hipGetLastError());
+    c->analyzed = true;
+    return SLIMM_OK;
+}
+
+int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
+    if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *d_ptr = c->bins.p;
+    *n_words = 2 * c->Bp + 16;
+    return SLIMM_OK;
+}
+
+int slimm_finish_coverage(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    {
+        KernelTimer t(c, K_REF_STATS);
+        launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_stats.p, c->ref_stats.p, static_cast<size_t>(c->R) * 16, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_small.p, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_small.p + CNT_WORDS, c->tail(), 16 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const uint32_t* cnt = c->h_small.p;
+    const uint32_t* tl = c->h_small.p + CNT_WORDS;
+    int rc = check_device_errors(c, cnt[CNT_ERR] | tl[3]);
+    if (rc != SLIMM_OK) return rc;
+    c->local_V = cnt[CNT_V];
+    c->local_M = cnt[CNT_M];
+    c->local_P = cnt[CNT_P];
+    const uint32_t R = c->R;
+    std::vector<uint32_t> rcnt(R), ucnt(R), nzc(R), nzu(R);
+    for (uint32_t r = 0; r < R; ++r) {
+        rcnt[r] = c->h_stats.p[r * 4 + 0];  // reads_count = sum of cov bins
+        nzc[r] = c->h_stats.p[r * 4 + 1];
+        ucnt[r] = c->h_stats.p[r * 4 + 2];  // uniq_reads_count = sum of uniq_cov bins
+        nzu[r] = c->h_stats.p[r * 4 + 3];
+    }
+    c->host->set_coverage(rcnt.data(), ucnt.data(), nzc.data(), nzu.data(), tl[0], tl[1]);
+    c->covered = true;
+    c->no_hits = (tl[0] == 0);
+    return c->no_hits ? SLIMM_E_NO_HITS : SLIMM_OK;
+}
+
+int slimm_set_coverage_columns(slimm_ctx* c, const uint32_t* reads_count, const uint32_t* uniq_reads_count,
+                               const uint32_t* nz_cov, const uint32_t* nz_uniq_cov, uint32_t hits, uint32_t matches) {
+    if (!c || !reads_count || !uniq_reads_count || !nz_cov || !nz_uniq_cov) return SLIMM_E_INVALID;
+    c->host->set_coverage(reads_count, uniq_reads_count, nz_cov, nz_uniq_cov, hits, matches);
+    c->covered = true;
+    c->no_hits = (hits == 0);
+    return c->no_hits ? SLIMM_E_NO_HITS : SLIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ phase B + C(1)
+int slimm_filter_alignments(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->covered) return fail(c, SLIMM_E_INVALID, "call slimm_finish_coverage first");
+    if (c->no_hits) return SLIMM_E_NO_HITS;
+    HostProfile& h = *c->host;
+    h.compute_valid();
+    if (c->device < 0) {  // host-only: the per-read part arrives through slimm_set_partials
+        c->filtered = true;
+        return SLIMM_OK;
+    }
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const uint32_t R = c->R, T = c->T;
+    HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        {
+            KernelTimer t(c, K_MEMSET);
+            HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
+            HIP_TRY(c, hipMemsetAsync(c->lca_count.p, 0, static_cast<size_t>(T) * 4, st));
+            HIP_TRY(c, hipMemsetAsync(c->marks.p, 0, static_cast<size_t>(R) * 4, st));
+            HIP_TRY(c, hipMemsetAsync(c->pair_tab.p, 0xff, static_cast<size_t>(c->pair_cap) * 8, st));
+            HIP_TRY(c, hipMemsetAsync(c->counters.p + CNT_ERR, 0, 2 * sizeof(uint32_t), st));  // ERR, PAIRS
+        }
+        {
+            KernelTimer t(c, K_FILTER_LCA);
+            launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
+                              c->d_lin_dense.p, c->ucov2(), c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p,
+                              c->pair_cap - 1);
+        }
+        {
+            KernelTimer t(c, K_REF_STATS2);
+            launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, c->ref_stats.p + static_cast<size_t>(R) * 4);
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_stats.p + static_cast<size_t>(R) * 4, c->ref_stats.p + static_cast<size_t>(R) * 4,
+                                  static_cast<size_t>(R) * 16, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_small.p, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_lca.p, c->lca_count.p, static_cast<size_t>(T) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_marks.p, c->marks.p, static_cast<size_t>(R) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        const uint32_t err = c->h_small.p[CNT_ERR];
+        if (err & ERR_PAIR_OVERFLOW) {
+            if (c->pair_cap >= (1u << 30)) return fail(c, SLIMM_E_INVALID, "(taxon, reference) pair set overflow");
+            int rc = ensure_pair_table(c, c->pair_cap * 4);
+            if (rc != SLIMM_OK) return rc;
+            continue;
+        }
+        c->n_pairs = c->h_small.p[CNT_PAIRS];
+        if (c->n_pairs) {
+            HIP_TRY(c, hipMemcpyAsync(c->h_pairs.p, c->pair_list.p, static_cast<size_t>(c->n_pairs) * 8,
+                                      hipMemcpyDeviceToHost, st));
+            HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        break;
+    }
+    c->part_u2.resize(R);
+    c->nz_ucov2.resize(R);
+    const uint32_t* s2 = c->h_stats.p + static_cast<size_t>(R) * 4;
+    for (uint32_t r = 0; r < R; ++r) {
+        c->part_u2[r] = s2[r * 4 + 0];  // uniq_reads_count2 = sum of uniq_cov2 bins
+        c->nz_ucov2[r] = s2[r * 4 + 1];
+    }
+    c->part_lca.assign(c->h_lca.p, c->h_lca.p + T);
+    c->part_marks.assign(c->h_marks.p, c->h_marks.p + R);
+    c->part_pairs.assign(c->h_pairs.p, c->h_pairs.p + c->n_pairs);
+    std::sort(c->part_pairs.begin(), c->part_pairs.end());
+    h.set_partials(c->part_u2.data(), c->part_lca.data(), c->part_marks.data(), c->part_pairs.data(), c->n_pairs);
+    h.set_nz_uniq_cov2(c->nz_ucov2.data());
+    c->filtered = true;
+    return SLIMM_OK;
+}
+
+int slimm_get_partials(slimm_ctx* c, slimm_partials* out) {
+    if (!c || !out) return SLIMM_E_INVALID;
+    if (!c->filtered || c->device < 0) return fail(c, SLIMM_E_INVALID, "no device partials (call slimm_filter_alignments)");
+    out->n_refs = c->R;
+    out->n_taxa_dense = c->T;
+    out->uniq_reads_count2 = c->part_u2.data();
+    out->lca_count = c->part_lca.data();
+    out->level_marks = c->part_marks.data();
+    out->pairs = c->part_pairs.data();
+    out->n_pairs = static_cast<uint32_t>(c->part_pairs.size());
+    out->scalars[0] = c->host->uniq_matches2;
+    out->scalars[1] = out->scalars[2] = out->scalars[3] = 0;
+    return SLIMM_OK;
+}
+
+int slimm_set_partials(slimm_ctx* c, const slimm_partials* in) {
+    if (!c || !in) return SLIMM_E_INVALID;
+    if (!c->filtered) return fail(c, SLIMM_E_INVALID, "call slimm_filter_alignments first");
+    if (in->n_refs != c->R || in->n_taxa_dense != c->T) return fail(c, SLIMM_E_INVALID, "partials shape mismatch");
+    if (!in->uniq_reads_count2 || !in->lca_count || !in->level_marks || (in->n_pairs && !in->pairs))
+        return fail(c, SLIMM_E_INVALID, "null partial array");
+    for (uint32_t k = 0; k < in->n_pairs; ++k)
+        if ((in->pairs[k] >> 32) >= c->T || static_cast<uint32_t>(in->pairs[k]) >= c->R)
+            return fail(c, SLIMM_E_INVALID, "pair %u out of range", k);
+    c->part_u2.assign(in->uniq_reads_count2, in->uniq_reads_count2 + c->R);
+    c->part_lca.assign(in->lca_count, in->lca_count + c->T);
+    c->part_marks.assign(in->level_marks, in->level_marks + c->R);
+    c->part_pairs.assign(in->pairs, in->pairs + in->n_pairs);
+    std::sort(c->part_pairs.begin(), c->part_pairs.end());
+    c->part_pairs.erase(std::unique(c->part_pairs.begin(), c->part_pairs.end()), c->part_pairs.end());
+    c->host->set_partials(c->part_u2.data(), c->part_lca.data(), c->part_marks.data(), c->part_pairs.data(),
+                          static_cast<uint32_t>(c->part_pairs.size()));
+    c->counted = false;
+    return SLIMM_OK;
+}
+
+int slimm_dense_taxa(slimm_ctx* c, uint32_t* n, const uint32_t** taxid) {
+    if (!c || !n) return SLIMM_E_INVALID;
+    *n = c->T;
+    if (taxid) *taxid = c->host->dense_taxid().data();
+    return SLIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ phase C(2,3) + profile
+int slimm_get_reads_lca_count(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->no_hits) return SLIMM_E_NO_HITS;
+    if (!c->filtered || !c->host->have_partials) return fail(c, SLIMM_E_INVALID, "call slimm_filter_alignments first");
+    c->host->propagate();
+    c->counted = true;
+    return SLIMM_OK;
+}
+
+int slimm_write_abundance(slimm_ctx* c, const char** text, uint64_t* len) {
+    if (!c || !text || !len) return SLIMM_E_INVALID;
+    if (c->no_hits) return SLIMM_E_NO_HITS;
+    if (!c->counted) return fail(c, SLIMM_E_INVALID, "call slimm_get_reads_lca_count first");
+    const std::string& s = c->host->write_abundance();
+    *text = s.data();
+    *len = s.size();
+    return SLIMM_OK;
+}
+
+int slimm_write_abundance_file(slimm_ctx* c, const char* path) {
+    const char* text = nullptr;
+    uint64_t len = 0;
+    int rc = slimm_write_abundance(c, &text, &len);
+    if (rc != SLIMM_OK) return rc;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(c, SLIMM_E_INVALID, "cannot open %s for writing", path);
+    size_t w = fwrite(text, 1, len, f);
+    fclose(f);
+    if (w != len) return fail(c, SLIMM_E_INVALID, "short write to %s", path);
+    return SLIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ results
+int slimm_get_stats(slimm_ctx* c, slimm_stats* o) {
+    if (!c || !o) return SLIMM_E_INVALID;
+    HostProfile& h = *c->host;
+    memset(o, 0, sizeof(*o));
+    o->hits_count = h.hits;
+    o->matches_count = h.matches;
+    o->uniq_matches_count = h.uniq_matches;
+    o->uniq_hits_count = h.uniq_hits;
+    o->uniq_matches_count2 = h.uniq_matches2;
+    o->reference_count = h.reference_count;
+    o->matched_ref_length = h.matched_ref_length;
+    o->failed_by_cov = h.failed_by_cov;
+    o->failed_by_uniq_cov = h.failed_by_ucov;
+    o->failed_by_min_read = h.failed_by_min_read;
+    o->n_valid = h.n_valid;
+    o->bin_width = h.bin_width();
+    o->min_reads = h.min_reads;
+    o->avg_read_len = h.config().avg_read_len;
+    o->profile_count = h.profile_count;
+    o->profile_failed = h.profile_failed;
+    if (h.have_coverage && !c->no_hits) {
+        o->coverage_cut_off = h.coverage_cut_off();
+        o->uniq_coverage_cut_off = h.uniq_coverage_cut_off();
+        o->expected_coverage = h.matched_ref_length ? h.expected_coverage() : 0.0f;
+    }
+    o->n_records = c->n_pushed;
+    o->n_targets = c->local_P;
+    o->total_bins = h.total_bins();
+    return SLIMM_OK;
+}
+
+int slimm_get_ref_columns(slimm_ctx* c, slimm_ref_columns* o) {
+    if (!c || !o) return SLIMM_E_INVALID;
+    HostProfile& h = *c->host;
+    const uint32_t R = c->R;
+    if (!h.have_coverage) return fail(c, SLIMM_E_INVALID, "no coverage results yet");
+    auto cp = [&](uint32_t* dst, const std::vector<uint32_t>& src) {
+        if (dst && src.size() == R) memcpy(dst, src.data(), R * 4);
+        else if (dst) memset(dst, 0, R * 4);
+    };
+    cp(o->reads_count, h.reads_count);
+    cp(o->uniq_reads_count, h.uniq_reads_count);
+    cp(o->uniq_reads_count2, h.have_partials ? h.uniq_reads_count2 : std::vector<uint32_t>());
+    cp(o->nbins, h.nbins());
+    cp(o->nz_cov, h.nz_cov);
+    cp(o->nz_uniq_cov, h.nz_ucov);
+    cp(o->nz_uniq_cov2, h.nz_uniq_cov2());
+    if (o->valid) {
+        if (h.have_valid) memcpy(o->valid, h.valid.data(), R);
+        else memset(o->valid, 0, R);
+    }
+    if (o->abundance) memcpy(o->abundance, h.abundance.data(), R * 4);
+    if (o->uniq_abundance) memcpy(o->uniq_abundance, h.uniq_abundance.data(), R * 4);
+    return SLIMM_OK;
+}
+
+int slimm_get_bins(slimm_ctx* c, int which, uint32_t* out) {
+    if (!c || !out || which < 0 || which > 2) return SLIMM_E_INVALID;
+    if (c->device < 0 || !c->analyzed) return fail(c, SLIMM_E_INVALID, "no coverage bins on this context");
+    if (which == 2 && !c->filtered) return fail(c, SLIMM_E_INVALID, "uniq_cov2 needs slimm_filter_alignments");
+    (void)hipSetDevice(c->device);
+    const uint32_t* src = which == 0 ? c->cov() : which == 1 ? c->ucov() : c->ucov2();
+    std::vector<uint32_t> padded(c->Bp);
+    HIP_TRY(c, hipMemcpyAsync(padded.data(), src, c->Bp * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t k = 0;
+    for (uint32_t r = 0; r < c->R; ++r) {
+        uint32_t nb = c->host->nbins()[r];
+        memcpy(out + k, padded.data() + c->bin_off_h[r], static_cast<size_t>(nb) * 4);
+        k += nb;
+    }
+    return SLIMM_OK;
+}
+
+int slimm_taxon_count_size(slimm_ctx* c, int stage, uint32_t* n) {
+    if (!c || !n) return SLIMM_E_INVALID;
+    if (!c->counted) return fail(c, SLIMM_E_INVALID, "call slimm_get_reads_lca_count first");
+    std::vector<uint32_t> t, k;
+    c->host->taxon_counts(stage, t, k);
+    *n = static_cast<uint32_t>(t.size());
+    return SLIMM_OK;
+}
+
+int slimm_get_taxon_counts(slimm_ctx* c, int stage, uint32_t* taxid, uint32_t* count) {
+    if (!c || !taxid || !count) return SLIMM_E_INVALID;
+    if (!c->counted) return fail(c, SLIMM_E_INVALID, "call slimm_get_reads_lca_count first");
+    std::vector<uint32_t> t, k;
+    c->host->taxon_counts(stage, t, k);
+    memcpy(taxid, t.data(), t.size() * 4);
+    memcpy(count, k.data(), k.size() * 4);
+    return SLIMM_OK;
+}
+
+int slimm_children_pairs_size(slimm_ctx* c, int stage, uint64_t* n) {
+    if (!c || !n) return SLIMM_E_INVALID;
+    if (!c->counted) return fail(c, SLIMM_E_INVALID, "call slimm_get_reads_lca_count first");
+    std::vector<uint32_t> t, r;
+    c->host->children_pairs(stage, t, r);
+    *n = t.size();
+    return SLIMM_OK;
+}
+
+int slimm_get_children_pairs(slimm_ctx* c, int stage, uint32_t* taxid, uint32_t* ref) {
+    if (!c || !taxid || !ref) return SLIMM_E_INVALID;
+    if (!c->counted) return fail(c, SLIMM_E_INVALID, "call slimm_get_reads_lca_count first");
+    std::vector<uint32_t> t, r;
+    c->host->children_pairs(stage, t, r);
+    memcpy(taxid, t.data(), t.size() * 4);
+    memcpy(ref, r.data(), r.size() * 4);
+    return SLIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ measurement
+int slimm_enable_kernel_timing(slimm_ctx* c, int on) {
+    if (!c) return SLIMM_E_INVALID;
+    c->timing = on != 0 && c->device >= 0;
+    return SLIMM_OK;
+}
+
+int slimm_kernel_times(slimm_ctx* c, const char** names, double* ms, uint32_t* launches, uint32_t cap, uint32_t* n,
+                       int reset) {
+    if (!c || !n) return SLIMM_E_INVALID;
+    if (c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        drain_events(c);
+    }
+    uint32_t k = 0;
+    for (int i = 0; i < K_COUNT && k < cap; ++i, ++k) {
+        if (names) names[k] = kKernelNames[i];
+        if (ms) ms[k] = c->k_ms[i];
+        if (launches) launches[k] = c->k_n[i];
+    }
+    *n = k;
+    if (reset) {
+        for (int i = 0; i < K_COUNT; ++i) {
+            c->k_ms[i] = 0;
+            c->k_n[i] = 0;
+        }
+    }
+    return SLIMM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ host-only helpers
+uint32_t slimm_host_avg_read_length(const uint32_t* l_seq, uint64_t n, uint32_t sample_size) {  // misc.hpp:509-522
+    uint32_t count = 0, total = 0;
+    for (uint64_t i = 0; i < n && count < sample_size; ++i) {
+        if (l_seq[i] == 0) continue;
+        total += l_seq[i];
+        ++count;
+    }
+    return count ? total / count : 0;
+}
+
+float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q) {
+    return slimm::quantile_cut_off(std::vector<float>(v, v + n), q);
+}
+
+uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width) {
+    uint32_t center = std::min(static_cast<uint32_t>(begin_pos) + (avg_read_len / 2), ref_len);  // slimm.hpp:200
+    return bin_width ? center / bin_width : 0;                                                   // slimm.hpp:201
+}
+
+}  // extern "C"

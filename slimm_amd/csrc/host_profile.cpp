@@ -1,0 +1,446 @@
+// See host_profile.hpp.  Every block cites the reference lines whose arithmetic it reproduces; the
+// data structures are this library's own (dense taxon indices, append-buffer sets), not the reference's.
+#include "host_profile.hpp"
+
+#include <algorithm>
+#include <map>
+#include <numeric>
+#include <sstream>
+#include <unordered_map>
+
+namespace slimm {
+
+static const char* kRankNames[] = {"strain", "species", "genus", "family", "order", "class", "phylum", "superkingdom"};
+static const char* kRankShort[] = {"r", "s", "g", "f", "o", "c", "p", "k"};
+
+uint32_t rank_from_string(const std::string& s) {  // misc.hpp:37-48
+    for (uint32_t i = 0; i < 8; ++i)
+        if (s == kRankNames[i]) return i;
+    return 8;
+}
+std::string rank_long(uint32_t r) { return r < 8 ? kRankNames[r] : "intermidiate"; }  // misc.hpp:51-62
+std::string rank_short(uint32_t r) { return r < 8 ? kRankShort[r] : "i"; }            // misc.hpp:64-75
+
+// misc.hpp:197-216: float32 throughout, sum in input order, ascending sort, partial sums from the top,
+// the `i > 0` guard compared as float like the template does for Type = float.
+float quantile_cut_off(std::vector<float> v, float q) {
+    if (v.empty()) return 0;
+    float total = std::accumulate(v.begin(), v.end(), 0.0f);
+    float sub = 0.0f;
+    std::sort(v.begin(), v.end());
+    uint32_t i = static_cast<uint32_t>(v.size() - 1);
+    while ((float(sub) / total) < q && i > 0.0f) {
+        sub += v[i];
+        --i;
+    }
+    return v[i];
+}
+
+void RefSet::materialise() {
+    if (!dirty) return;
+    std::sort(items.begin(), items.end());
+    items.erase(std::unique(items.begin(), items.end()), items.end());
+    dirty = false;
+}
+
+HostProfile::HostProfile(const HostConfig& cfg) : cfg_(cfg) {
+    const uint32_t R = cfg_.n_refs;
+    if (cfg_.bin_width == 0) cfg_.bin_width = cfg_.avg_read_len;  // slimm.hpp:412-413
+    nbins_.resize(R);
+    total_bins_ = 0;
+    for (uint32_t i = 0; i < R; ++i) {
+        nbins_[i] = cfg_.bin_width ? cfg_.ref_len[i] / cfg_.bin_width + 1 : 0;  // reference_contig.hpp:80
+        total_bins_ += nbins_[i];
+    }
+    // dense taxon index over every taxid the lineage table can produce
+    dense_taxid_ = cfg_.lineage;
+    std::sort(dense_taxid_.begin(), dense_taxid_.end());
+    dense_taxid_.erase(std::unique(dense_taxid_.begin(), dense_taxid_.end()), dense_taxid_.end());
+    lin_dense_.resize(cfg_.lineage.size());
+    for (size_t k = 0; k < cfg_.lineage.size(); ++k)
+        lin_dense_[k] = static_cast<uint32_t>(
+            std::lower_bound(dense_taxid_.begin(), dense_taxid_.end(), cfg_.lineage[k]) - dense_taxid_.begin());
+    if (!dense_taxid_.empty() && dense_taxid_[0] == 0) zero_dense_ = 0;
+    for (uint32_t k = 0; k < cfg_.tax_id.size(); ++k)
+        if (cfg_.tax_id[k] == 0) zero_name_ = cfg_.tax_name[k];
+
+    // db.taxid__name: absent taxid reads as (strain_lv, "") -- the reference's operator[] default (Q6)
+    std::unordered_map<uint32_t, uint32_t> pos;
+    pos.reserve(cfg_.tax_id.size() * 2);
+    for (uint32_t k = 0; k < cfg_.tax_id.size(); ++k) pos[cfg_.tax_id[k]] = k;  // later entries win, like map assignment
+    const uint32_t T = n_taxa_dense();
+    rank_d_.assign(T, 0);
+    name_idx_d_.assign(T, -1);
+    for (uint32_t d = 0; d < T; ++d) {
+        auto it = pos.find(dense_taxid_[d]);
+        if (it != pos.end()) {
+            rank_d_[d] = cfg_.tax_rank[it->second];
+            name_idx_d_[d] = static_cast<int32_t>(it->second);
+        }
+    }
+    // slimm.hpp:498-514 get_considered_ranks
+    if (cfg_.rank == "all") {
+        for (uint32_t i = 8; i > 0; --i) considered_.push_back(i - 1);
+    } else if (cfg_.rank == "superkingdom") {
+        considered_.push_back(rank_from_string(cfg_.rank));
+    } else {
+        considered_.push_back(rank_from_string(cfg_.rank) + 1);
+        considered_.push_back(rank_from_string(cfg_.rank));
+    }
+    reset();
+}
+
+const std::string& HostProfile::name_of_dense(uint32_t d) const {
+    int32_t k = name_idx_d_[d];
+    return k < 0 ? empty_ : cfg_.tax_name[k];
+}
+
+void HostProfile::reset() {  // slimm.hpp:167-188
+    hits = matches = uniq_matches = uniq_hits = uniq_matches2 = 0;
+    reference_count = matched_ref_length = 0;
+    failed_by_cov = failed_by_ucov = failed_by_min_read = n_valid = 0;
+    profile_count = profile_failed = 0;
+    min_reads = cfg_.min_reads;
+    have_coverage = have_valid = have_partials = have_counts = false;
+    profile_.clear();
+}
+
+void HostProfile::reset_cutoffs() { cc_cache_ = ucc_cache_ = 0.0f; }
+
+void HostProfile::set_coverage(const uint32_t* rc, const uint32_t* urc, const uint32_t* nzc, const uint32_t* nzu,
+                               uint32_t hits_, uint32_t matches_) {
+    const uint32_t R = cfg_.n_refs;
+    reads_count.assign(rc, rc + R);
+    uniq_reads_count.assign(urc, urc + R);
+    nz_cov.assign(nzc, nzc + R);
+    nz_ucov.assign(nzu, nzu + R);
+    hits = hits_;
+    matches = matches_;
+    uint32_t u = 0;
+    for (uint32_t i = 0; i < R; ++i) u += uniq_reads_count[i];
+    uniq_matches = u;  // slimm.hpp:225, one per unique read
+    uniq_hits = u;     // slimm.hpp:236
+    // slimm.hpp:259-302
+    abundance.assign(R, 0.0f);
+    uniq_abundance.assign(R, 0.0f);
+    reference_count = 0;
+    matched_ref_length = 0;
+    float total = 0.0f;
+    for (uint32_t i = 0; i < R; ++i) {
+        if (reads_count[i] > 0) {
+            ++reference_count;
+            matched_ref_length += cfg_.ref_len[i];
+            abundance[i] = float(reads_count[i] * 100) / hits;
+            total += abundance[i] / cfg_.ref_len[i];
+        }
+    }
+    for (uint32_t i = 0; i < R; ++i)
+        if (reads_count[i] > 0) abundance[i] = (abundance[i] * 100) / (total * cfg_.ref_len[i]);
+    total = 0.0f;
+    for (uint32_t i = 0; i < R; ++i) {
+        if (uniq_reads_count[i] > 0) {
+            uniq_abundance[i] = float(uniq_reads_count[i] * 100) / uniq_hits;
+            total += uniq_abundance[i] / cfg_.ref_len[i];
+        }
+    }
+    for (uint32_t i = 0; i < R; ++i)
+        if (uniq_reads_count[i] > 0) uniq_abundance[i] = (uniq_abundance[i] * 100) / (total * cfg_.ref_len[i]);
+    // slimm.hpp:458-459
+    if (min_reads == 0 && matches > 0) min_reads = 1 + ((matches - 1) / 10000);
+    have_coverage = true;
+}
+
+float HostProfile::coverage_cut_off() {  // slimm.hpp:328-344
+    if (cc_cache_ == 0.0 && cfg_.cov_cut_off < 1.0) {
+        std::vector<float> v;
+        v.reserve(cfg_.n_refs);
+        for (uint32_t i = 0; i < cfg_.n_refs; ++i)
+            if (uniq_reads_count[i] > 0) v.push_back(float(nz_cov[i]) / nbins_[i]);
+        cc_cache_ = quantile_cut_off(v, cfg_.cov_cut_off);
+    }
+    return cc_cache_;
+}
+
+float HostProfile::uniq_coverage_cut_off() {  // slimm.hpp:672-688
+    if (ucc_cache_ == 0.0 && cfg_.cov_cut_off < 1.0) {
+        std::vector<float> v;
+        v.reserve(cfg_.n_refs);
+        for (uint32_t i = 0; i < cfg_.n_refs; ++i)
+            if (uniq_reads_count[i] > 0) v.push_back(float(nz_ucov[i]) / nbins_[i]);
+        ucc_cache_ = quantile_cut_off(v, cfg_.cov_cut_off);
+    }
+    return ucc_cache_;
+}
+
+float HostProfile::expected_coverage() const {  // slimm.hpp:346-349
+    return float(cfg_.avg_read_len * matches) / matched_ref_length;
+}
+
+void HostProfile::compute_valid() {  // slimm.hpp:353-378
+    const uint32_t R = cfg_.n_refs;
+    valid.assign(R, 0);
+    n_valid = failed_by_cov = failed_by_ucov = failed_by_min_read = 0;
+    // The reference re-evaluates the (cached) cut-off getters inside the loop; their value cannot change while it
+    // runs, so they are read once here.
+    const float cc = coverage_cut_off();
+    const float ucc = uniq_coverage_cut_off();
+    for (uint32_t i = 0; i < R; ++i) {
+        if (reads_count[i] == 0) continue;
+        float cp = float(nz_cov[i]) / nbins_[i];
+        float up = float(nz_ucov[i]) / nbins_[i];
+        if (cp >= cc && up >= ucc) {
+            valid[i] = 1;
+            ++n_valid;
+        } else {
+            if (up < ucc) ++failed_by_ucov;
+            if (reads_count[i] < min_reads) ++failed_by_min_read;
+            if (cp < cc) ++failed_by_cov;
+        }
+    }
+    have_valid = true;
+}
+
+void HostProfile::set_partials(const uint32_t* u2, const uint32_t* lca, const uint32_t* marks, const uint64_t* pairs,
+                               uint32_t n_pairs) {
+    const uint32_t R = cfg_.n_refs, T = n_taxa_dense();
+    uniq_reads_count2.assign(u2, u2 + R);
+    lca_count_.assign(lca, lca + T);
+    marks_.assign(marks, marks + R);
+    pairs_.assign(pairs, pairs + n_pairs);
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < R; ++i) s += uniq_reads_count2[i];
+    uniq_matches2 = s;  // slimm.hpp:387
+    have_partials = true;
+    have_counts = false;
+}
+
+// slimm.hpp:533-611.  Step 1 (per-read LCA, :536-557) arrives from the device as
+//   lca_count_[t]        number of multi-target reads whose LCA is dense taxon t
+//   marks_[ref] bit lv   ref belongs to a read whose refs first agree at level lv  -> children[lineage[ref][lv]] has ref
+//   pairs_               (t << 32 | ref) for reads that agree at no level (Q4)     -> children[t] has ref
+void HostProfile::propagate() {
+    const uint32_t R = cfg_.n_refs, T = n_taxa_dense();
+    count_.assign(T, 0);
+    has_count_.assign(T, 0);
+    kids_.assign(T, RefSet());
+    for (uint32_t t = 0; t < T; ++t) {
+        if (lca_count_[t] != 0) {
+            count_[t] = lca_count_[t];
+            has_count_[t] = 1;
+        }
+    }
+    for (uint32_t r = 0; r < R; ++r) {
+        uint32_t m = marks_[r] & 0xffu;
+        while (m) {
+            uint32_t lv = static_cast<uint32_t>(__builtin_ctz(m));
+            m &= m - 1;
+            kids_[lin_dense_[r * 8 + lv]].add(r);
+        }
+    }
+    for (uint64_t p : pairs_) kids_[static_cast<uint32_t>(p >> 32)].add(static_cast<uint32_t>(p));
+
+    // snapshot of step 1 for the stage-0 getters
+    direct_taxid_.clear();
+    direct_count_.clear();
+    direct_pair_t_.clear();
+    direct_pair_r_.clear();
+    for (uint32_t t = 0; t < T; ++t) {
+        if (has_count_[t]) {
+            direct_taxid_.push_back(dense_taxid_[t]);
+            direct_count_.push_back(count_[t]);
+        }
+        if (kids_[t].present) {
+            kids_[t].materialise();
+            for (uint32_t r : kids_[t].items) {
+                direct_pair_t_.push_back(dense_taxid_[t]);
+                direct_pair_r_.push_back(r);
+            }
+        }
+    }
+
+    // Step 2 (:560-586): every taxon with direct hits hands its count (snapshot value) and its children (live) to the
+    // ranks above its own along the lineage of its smallest child.  The reference walks an unordered_map; any order
+    // gives the same result in a consistent tree.  Here: lower ranks first, then ascending taxid.
+    std::vector<uint32_t> order;
+    for (uint32_t t = 0; t < T; ++t)
+        if (lca_count_[t] != 0) order.push_back(t);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rank_d_[a] < rank_d_[b]; });
+    std::vector<uint32_t> ids;
+    for (uint32_t t : order) {
+        uint32_t rnk = rank_d_[t];
+        RefSet& src = kids_[t];
+        if (!src.present || src.items.empty()) continue;  // cannot happen: a counted LCA taxon has children
+        src.materialise();
+        ids = src.items;
+        const uint32_t* lin = &lin_dense_[static_cast<size_t>(src.mn) * 8];
+        uint32_t c = lca_count_[t];
+        for (uint32_t j = rnk + 1; j < kLineageLen; ++j) {
+            uint32_t u = lin[j];
+            count_[u] += c;
+            has_count_[u] = 1;
+            if (u != t) kids_[u].add_all(ids);
+        }
+    }
+    // Step 3 (:589-610): unique reads of each reference go to lineage slots 1..7 (slot 0 is skipped, Q9), together with
+    // the reference itself and whatever children its slot-0 taxon currently has.
+    for (uint32_t i = 0; i < R; ++i) {
+        uint32_t u2 = uniq_reads_count2[i];
+        if (u2 == 0) continue;
+        const uint32_t* lin = &lin_dense_[static_cast<size_t>(i) * 8];
+        RefSet& s0 = kids_[lin[0]];
+        s0.present = true;  // operator[] creates the entry
+        s0.materialise();
+        ids = s0.items;
+        for (uint32_t j = 1; j < kLineageLen; ++j) {
+            uint32_t u = lin[j];
+            count_[u] += u2;
+            has_count_[u] = 1;
+            kids_[u].add(i);
+            kids_[u].add_all(ids);
+        }
+    }
+    have_counts = true;
+}
+
+void HostProfile::taxon_counts(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& count) {
+    if (stage == 0) {
+        taxid = direct_taxid_;
+        count = direct_count_;
+        return;
+    }
+    taxid.clear();
+    count.clear();
+    for (uint32_t t = 0; t < n_taxa_dense(); ++t)
+        if (has_count_[t]) {
+            taxid.push_back(dense_taxid_[t]);
+            count.push_back(count_[t]);
+        }
+}
+
+void HostProfile::children_pairs(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& ref) {
+    if (stage == 0) {
+        taxid = direct_pair_t_;
+        ref = direct_pair_r_;
+        return;
+    }
+    taxid.clear();
+    ref.clear();
+    for (uint32_t t = 0; t < n_taxa_dense(); ++t) {
+        if (!kids_[t].present) continue;
+        kids_[t].materialise();
+        for (uint32_t r : kids_[t].items) {
+            taxid.push_back(dense_taxid_[t]);
+            ref.push_back(r);
+        }
+    }
+}
+
+// slimm.hpp:690-710
+std::string HostProfile::lineage_string(uint32_t rnk, const uint32_t* lin, bool all_zero) {
+    auto name_at = [&](uint32_t lv) -> std::string {
+        std::string n;
+        if (all_zero) {
+            n = zero_name_;  // db.taxid__name[0]; "" unless the database names taxid 0
+        } else {
+            n = name_of_dense(lin[lv]);
+        }
+        if (n.empty()) n = "unknown_" + rank_long(lv);
+        return n;
+    };
+    std::string s = rank_short(rnk) + "__" + name_at(rnk);
+    for (uint32_t i = rnk + 1; i < kLineageLen; ++i) s = rank_short(i) + "__" + name_at(i) + "|" + s;
+    return s;
+}
+
+// slimm.hpp:733-843
+const std::string& HostProfile::write_abundance() {
+    std::ostringstream out;
+    out << "taxa_level\ttaxa_id\tlinage\tabundance\tread_count\n";
+    const uint32_t T = n_taxa_dense();
+    const uint32_t rnk = considered_.size() > 1 ? considered_[1] : considered_[0];
+    const uint32_t parent_rnk = considered_[0];
+
+    // :747-765 statistics of the upper level
+    std::map<uint32_t, float> parent_abundance;
+    std::map<uint32_t, uint32_t> parent_reads;
+    for (uint32_t t = 0; t < T; ++t) {
+        if (!has_count_[t] || rank_d_[t] != parent_rnk) continue;
+        parent_abundance[t] = float(count_[t]) / (matches)*100;
+        parent_reads[t] = count_[t];
+    }
+
+    uint32_t count = 0, failed = 0, sum_reads = 0;
+    float sum_ab = 0.0f;
+    std::map<uint32_t, float> ab_by_parent;
+    std::map<uint32_t, uint32_t> reads_by_parent;
+    const float cc = coverage_cut_off();
+
+    for (uint32_t t = 0; t < T; ++t) {  // :776-813
+        if (!has_count_[t] || rank_d_[t] != rnk) continue;
+        RefSet& k = kids_[t];
+        k.materialise();
+        uint32_t glen = 0, nchild = 0;
+        for (uint32_t child : k.items) {
+            glen += cfg_.ref_len[child];  // u32 sum, wraps (Q11)
+            ++nchild;
+        }
+        glen = nchild ? glen / nchild : 0;
+        const uint32_t* lin_last = &lin_dense_[static_cast<size_t>(k.mx) * 8];  // lineage of the LAST child (Q12)
+        float cov = float(count_[t] * cfg_.avg_read_len) / glen;                // u32 product, wraps (Q11)
+        float ab = float(count_[t]) / (matches)*100;
+        const std::string& name = name_of_dense(t);
+        uint32_t parent = (parent_rnk < kLineageLen) ? lin_last[parent_rnk] : 0xffffffffu;
+        auto pa = ab_by_parent.find(parent);
+        if (pa != ab_by_parent.end())
+            pa->second += ab;
+        else
+            ab_by_parent[parent] = ab;
+        reads_by_parent[parent] += count_[t];
+        if (ab < cfg_.abundance_cut_off || cov < cc || name.empty()) {  // depth vs fraction (Q10)
+            ++failed;
+            continue;
+        }
+        // get_lineage_string(rank, taxid): lineage of the FIRST child, all zeros for taxid 0 (:712-730)
+        bool zero = dense_taxid_[t] == 0;
+        const uint32_t* lin_first = &lin_dense_[static_cast<size_t>(k.mn) * 8];
+        out << rank_long(rnk) << "\t" << dense_taxid_[t] << "\t" << lineage_string(rnk, lin_first, zero) << "\t";
+        out << ab << "\t" << count_[t] << "\n";
+        sum_ab += ab;
+        sum_reads += count_[t];
+        ++count;
+    }
+
+    for (auto& abp : ab_by_parent) {  // :816-831 unclassified rows per parent
+        uint32_t parent = abp.first;
+        if (parent == 0xffffffffu) continue;
+        float pab = 0.0f;
+        uint32_t prd = 0;
+        auto a = parent_abundance.find(parent);
+        if (a != parent_abundance.end()) pab = a->second;
+        auto b = parent_reads.find(parent);
+        if (b != parent_reads.end()) prd = b->second;
+        float uncl_ab = pab - abp.second;
+        uint32_t uncl_reads = prd - reads_by_parent[parent];
+        std::string name = name_of_dense(parent) + "_unclassified";
+        if (uncl_ab > cfg_.abundance_cut_off && name != "_unclassified") {
+            bool zero = dense_taxid_[parent] == 0;
+            RefSet& k = kids_[parent];
+            if (k.items.empty()) zero = true;  // the reference would throw from .at(); unreachable with a counted parent
+            const uint32_t* lin_first = zero ? nullptr : &lin_dense_[static_cast<size_t>(k.mn) * 8];
+            std::string ls = lineage_string(parent_rnk, lin_first, zero) + "|" + rank_short(rnk) + "__" + name;
+            out << rank_long(rnk) << "\t" << dense_taxid_[parent] << "*\t" << ls << "\t";
+            out << uncl_ab << "\t" << uncl_reads << "\n";
+            sum_reads += uncl_reads;
+            sum_ab += uncl_ab;
+        }
+    }
+
+    out << rank_long(rnk) << "\t" << "0*" << "\t" << lineage_string(rnk, nullptr, true) << "\t";  // :833-835
+    out << 100.0 - sum_ab << "\t" << matches - sum_reads << "\n";
+    profile_count = count;
+    profile_failed = failed;
+    profile_ = out.str();
+    return profile_;
+}
+
+}  // namespace slimm

@@ -1,0 +1,145 @@
+// Host-side scalar glue of the alignment-to-profile path: everything between the integer arrays the
+// HIP kernels produce and the final profile text.  No GPU dependency (plain C++17), so it is unit-testable
+// on a CPU-only machine.
+//
+// What lives here and why:
+//   a6  abundance floats            reference src/slimm.hpp:259-302   (float32, sequential over refs)
+//   a8  quantile cut-offs           src/misc.hpp:197-216, src/slimm.hpp:328-344, 672-688 (float32, order-sensitive)
+//   a9  valid set + failure stats   src/slimm.hpp:353-378
+//   a12 steps 2 and 3 (propagation) src/slimm.hpp:560-610
+//   a13 write_abundance             src/slimm.hpp:690-843
+// These are O(refs) / O(taxa) scalar loops whose float32 operation order decides integer results, so they stay on
+// the host in the reference's order; the kernels only feed them per-reference integers.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace slimm {
+
+constexpr uint32_t kLineageLen = 8;
+
+struct HostConfig {
+    uint32_t n_refs = 0;
+    std::vector<uint32_t> ref_len;   // [R]
+    std::vector<uint32_t> lineage;   // [R*8] taxids
+    uint32_t bin_width = 0, avg_read_len = 0, min_reads = 0;
+    float cov_cut_off = 0.95f, abundance_cut_off = 0.01f;
+    std::string rank = "species";
+    std::vector<uint32_t> tax_id, tax_rank;
+    std::vector<std::string> tax_name;
+};
+
+// Sorted set of reference ids kept as an append buffer: unions append, readers materialise (sort + unique).
+struct RefSet {
+    std::vector<uint32_t> items;
+    uint32_t mn = 0xffffffffu, mx = 0;
+    bool dirty = false;
+    bool present = false;  // an entry exists in taxon_id__children
+    void add(uint32_t r) {
+        items.push_back(r);
+        if (r < mn) mn = r;
+        if (r > mx) mx = r;
+        dirty = true;
+        present = true;
+    }
+    void add_all(const std::vector<uint32_t>& v) {
+        present = true;
+        if (v.empty()) return;
+        items.insert(items.end(), v.begin(), v.end());
+        // v is materialised (sorted) whenever it comes from another RefSet
+        for (uint32_t r : v) {
+            if (r < mn) mn = r;
+            if (r > mx) mx = r;
+        }
+        dirty = true;
+    }
+    void materialise();
+};
+
+class HostProfile {
+public:
+    explicit HostProfile(const HostConfig& cfg);
+
+    // ---- static tables derived from the configuration ----
+    const HostConfig& config() const { return cfg_; }
+    uint32_t n_refs() const { return cfg_.n_refs; }
+    uint32_t n_taxa_dense() const { return static_cast<uint32_t>(dense_taxid_.size()); }
+    const std::vector<uint32_t>& dense_taxid() const { return dense_taxid_; }  // ascending, unique
+    const std::vector<uint32_t>& lineage_dense() const { return lin_dense_; }  // [R*8] indices into dense_taxid
+    const std::vector<uint32_t>& nbins() const { return nbins_; }              // len/W + 1 (reference_contig.hpp:80)
+    uint32_t bin_width() const { return cfg_.bin_width; }
+    uint64_t total_bins() const { return total_bins_; }
+
+    // ---- per-file state ----
+    void reset();          // slimm::reset(): keeps the cut-off caches (Q8)
+    void reset_cutoffs();  // a fresh object
+
+    // phase A results (per reference) -> a6 statistics
+    void set_coverage(const uint32_t* reads_count, const uint32_t* uniq_reads_count, const uint32_t* nz_cov,
+                      const uint32_t* nz_uniq_cov, uint32_t hits, uint32_t matches);
+    // a8 + a9
+    void compute_valid();
+    // phase B/C(1) results
+    void set_partials(const uint32_t* uniq_reads_count2, const uint32_t* lca_count, const uint32_t* level_marks,
+                      const uint64_t* pairs, uint32_t n_pairs);
+    void set_nz_uniq_cov2(const uint32_t* nz) { nz_ucov2_.assign(nz, nz + cfg_.n_refs); }
+    // a12 steps 2,3
+    void propagate();
+    // a13
+    const std::string& write_abundance();
+
+    float coverage_cut_off();
+    float uniq_coverage_cut_off();
+    float expected_coverage() const;
+
+    // results
+    uint32_t hits = 0, matches = 0, uniq_matches = 0, uniq_hits = 0, uniq_matches2 = 0;
+    uint32_t reference_count = 0, matched_ref_length = 0;
+    uint32_t failed_by_cov = 0, failed_by_ucov = 0, failed_by_min_read = 0, n_valid = 0;
+    uint32_t min_reads = 0;
+    uint32_t profile_count = 0, profile_failed = 0;
+    std::vector<uint32_t> reads_count, uniq_reads_count, uniq_reads_count2, nz_cov, nz_ucov;
+    std::vector<uint8_t> valid;
+    std::vector<float> abundance, uniq_abundance;
+    const std::vector<uint32_t>& nz_uniq_cov2() const { return nz_ucov2_; }
+
+    // taxon counts / children.  stage 0 = direct LCA hits, stage 1 = after propagation
+    void taxon_counts(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& count);
+    void children_pairs(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& ref);
+
+    bool have_coverage = false, have_valid = false, have_partials = false, have_counts = false;
+
+private:
+    uint32_t rank_of_dense(uint32_t d) const { return rank_d_[d]; }
+    const std::string& name_of_dense(uint32_t d) const;
+    std::string lineage_string(uint32_t rnk, const uint32_t* lin_dense_row, bool all_zero);
+
+    HostConfig cfg_;
+    std::vector<uint32_t> dense_taxid_, lin_dense_, nbins_, rank_d_;
+    std::vector<int32_t> name_idx_d_;  // index into cfg_.tax_name or -1
+    uint64_t total_bins_ = 0;
+    uint32_t zero_dense_ = 0xffffffffu;  // dense index of taxid 0 if present
+    std::vector<uint32_t> considered_;   // slimm.hpp:498-514
+
+    float cc_cache_ = 0.0f, ucc_cache_ = 0.0f;
+
+    std::vector<uint32_t> nz_ucov2_;
+    // partials
+    std::vector<uint32_t> lca_count_, marks_;
+    std::vector<uint64_t> pairs_;
+    // counts after each stage
+    std::vector<uint32_t> count_;         // [T]
+    std::vector<uint8_t> has_count_;      // [T] membership in taxon_id__read_count
+    std::vector<RefSet> kids_;            // [T]
+    std::vector<uint32_t> direct_taxid_, direct_count_, direct_pair_t_, direct_pair_r_;
+    std::string profile_;
+    std::string empty_, zero_name_;
+};
+
+float quantile_cut_off(std::vector<float> v, float q);
+uint32_t rank_from_string(const std::string& s);
+std::string rank_long(uint32_t r);
+std::string rank_short(uint32_t r);
+
+}  // namespace slimm

@@ -1,0 +1,56 @@
+// Launch interface between the context (context.hip) and the kernels (kernels.hip, radix_sort.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slimm {
+
+// slots of the device counter block (uint32[32])
+enum {
+    CNT_V = 0,      // mapped records of this context = hits_count (src/slimm.hpp:212)
+    CNT_M = 1,      // reads = matches_count (src/slimm.hpp:257)
+    CNT_P = 2,      // distinct (read, ref) pairs = targets
+    CNT_ERR = 3,    // ERR_* bits
+    CNT_PAIRS = 4,  // entries of the no-level-agrees (taxon, ref) set
+    CNT_WORDS = 32
+};
+enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4 };
+
+struct DeviceRecords {
+    const uint64_t* key = nullptr;
+    const int32_t* ref = nullptr;
+    const int32_t* pos = nullptr;
+    const uint16_t* flag = nullptr;
+    uint32_t n = 0;
+};
+
+uint32_t num_tiles(uint32_t n);
+
+void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
+void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
+                       uint32_t* read_off);
+void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
+                    const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
+                    uint32_t* cgbin);
+void launch_flags(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, uint32_t* counters,
+                  uint8_t* fl, uint2* tile_cnt);
+void launch_build_csr(hipStream_t st, uint32_t n_upper, const uint8_t* fl, const uint32_t* cref, const uint32_t* cgbin,
+                      const uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
+                      uint32_t* read_off);
+void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
+                 uint32_t* cov, uint32_t* ucov);
+void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
+                      uint32_t* out);
+void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
+                       const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
+                       uint32_t* ucov2, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list,
+                       uint32_t pair_mask);
+void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
+
+// Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
+// in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and
+// n_upper bounds it for the launch geometry.  hist must hold 256 * (num_tiles(n_upper) + 1) uint32.
+void launch_sort_by_ident(hipStream_t st, uint32_t n_upper, const uint32_t* counters, uint64_t* ident, uint32_t* cref,
+                          uint32_t* cgbin, uint64_t* ident_tmp, uint32_t* cref_tmp, uint32_t* cgbin_tmp, uint32_t* hist);
+
+}  // namespace slimm

@@ -1,0 +1,516 @@
+// HIP kernels of the alignment-to-profile path for gfx950 (MI355X, CDNA4, wave64).
+//
+// The whole path is integer scatter / segmented count / small-table lookup: bounded by HBM bandwidth
+// (and by the L2/fabric atomic rate where bins are hit at random), never by arithmetic -- there is no MFMA work here.
+// Layout (all SoA, 32-bit indices; one context handles < 2^31 records):
+//   records   key u64 | ref i32 | pos i32 | flag u16               (what the reference reads per BamAlignmentRecord)
+//   compact   ident u64 | ref u32 | gbin u32 | fl u8               (mapped records only, file order kept)
+//   targets   tgt_ref u32 (bit31 = first target of its read) | tgt_gbin u32   (CSR over reads: read_off u32[M+1])
+//   bins      cov[Bp] | uniq_cov[Bp] | tail[64] | uniq_cov2[Bp]    (u32; each reference padded to a multiple of 4 bins)
+//
+// Reference semantics implemented here:
+//   a3  record filter + bin + read identity      src/slimm.hpp:194-213        k_valid_count, k_compact
+//   a4  first bin per distinct (read, ref)       src/read_stat.hpp:116-135    k_flags, k_build_csr
+//   a5  cov / uniq_cov histograms                src/slimm.hpp:219-257        k_hist
+//   a7  non-zero bin counts (+ per-ref sums)     src/reference_contig.hpp:84-91   k_ref_stats
+//   a10 per-read filter, uniq_cov2               src/slimm.hpp:380-391, read_stat.hpp:98-114   k_filter_lca
+//   a11 level-scan LCA                           src/slimm.hpp:516-531        k_filter_lca
+//   a12 step 1: per-taxon counts + children      src/slimm.hpp:536-557        k_filter_lca
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace slimm {
+
+constexpr int kBlock = 256;
+constexpr int kItems = 8;
+constexpr int kTile = kBlock * kItems;  // records per workgroup
+constexpr int kWaves = kBlock / 64;
+constexpr uint32_t kLookBackMax = 4096;  // longest supported run of records of one read (SLIMM_E_RUN_LENGTH above it)
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t mask_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ bool record_is_mapped(uint16_t flag, int32_t ref) {
+    return !(flag & 0x4) && ref != -1;  // src/slimm.hpp:197
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_valid_count: mapped records per tile (pass 1 of the compaction).  Flags records naming a reference >= n_refs.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restrict__ flag, const int32_t* __restrict__ ref,
+                                                        uint32_t n, uint32_t n_refs, uint2* __restrict__ tile_cnt,
+                                                        uint32_t* __restrict__ counters) {
+    __shared__ uint32_t s_w[kWaves];
+    const uint32_t base = blockIdx.x * kTile;
+    uint32_t cnt = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        uint32_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) {
+            int32_t r = ref[i];
+            bool v = record_is_mapped(flag[i], r);
+            if (v && static_cast<uint32_t>(r) >= n_refs) {
+                bad = true;
+                v = false;
+            }
+            cnt += v;
+        }
+    }
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_REF_RANGE);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) t += s_w[w];
+        tile_cnt[blockIdx.x] = make_uint2(t, 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_scan_tiles: exclusive scan of the per-tile (x, y) counts by ONE workgroup; totals go to counters[slot_x/slot_y]
+// and to tile_cnt[ntiles].  ntiles = n/2048, so even 10^9 records are < 500k entries: a few microseconds.
+// When read_off != nullptr also writes the CSR sentinel read_off[total_x] = total_y.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cnt, uint32_t ntiles,
+                                                     uint32_t* __restrict__ counters, int slot_x, int slot_y,
+                                                     uint32_t* __restrict__ read_off) {
+    __shared__ uint2 s_part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (ntiles + 1023) / 1024;
+    const uint32_t lo = tid * per;
+    const uint32_t hi = min(lo + per, ntiles);
+    uint2 sum = make_uint2(0u, 0u);
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint2 v = tile_cnt[i];
+        sum.x += v.x;
+        sum.y += v.y;
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint2 add = make_uint2(0u, 0u);
+        if (tid >= off) add = s_part[tid - off];
+        __syncthreads();
+        s_part[tid].x += add.x;
+        s_part[tid].y += add.y;
+        __syncthreads();
+    }
+    uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);  // exclusive prefix of this thread's chunk
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint2 v = tile_cnt[i];
+        tile_cnt[i] = run;
+        run.x += v.x;
+        run.y += v.y;
+    }
+    if (tid == 1023) {
+        uint2 tot = s_part[1023];
+        tile_cnt[ntiles] = tot;
+        counters[slot_x] = tot.x;
+        if (slot_y >= 0) counters[slot_y] = tot.y;
+        if (read_off) read_off[tot.x] = tot.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_compact: pass 2 of the compaction.  Drops unmapped records, folds the mate number into the identity
+// (src/slimm.hpp:204-208: qName + ".1" / ".2"), computes the bin of the record (src/slimm.hpp:200-201) and
+// stores it as a global bin index (bin_off[ref] + bin).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__ key, const int32_t* __restrict__ ref,
+                                                    const int32_t* __restrict__ pos, const uint16_t* __restrict__ flag,
+                                                    uint32_t n, uint32_t n_refs, const uint2* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ ref_len,
+                                                    const uint32_t* __restrict__ bin_off, uint32_t half_read,
+                                                    uint32_t bin_width, uint64_t* __restrict__ ident,
+                                                    uint32_t* __restrict__ cref, uint32_t* __restrict__ cgbin) {
+    __shared__ uint32_t s_w[2][kWaves];
+    const uint32_t base = blockIdx.x * kTile;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t running = tile_off[blockIdx.x].x;
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        uint32_t i = base + k * kBlock + threadIdx.x;
+        bool v = false;
+        int32_t r = -1;
+        uint16_t f = 0;
+        if (i < n) {
+            r = ref[i];
+            f = flag[i];
+            v = record_is_mapped(f, r) && static_cast<uint32_t>(r) < n_refs;
+        }
+        uint64_t m = __ballot(v);
+        uint32_t rank = mask_rank(m);
+        if ((threadIdx.x & 63) == 0) s_w[k & 1][wave] = __popcll(m);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            uint32_t c = s_w[k & 1][w];
+            if (w < static_cast<int>(wave)) before += c;
+            total += c;
+        }
+        if (v) {
+            uint32_t o = running + before + rank;
+            uint32_t mate = (f & 0x40) ? 1u : ((f & 0x80) ? 2u : 0u);
+            ident[o] = (key[i] << 2) | mate;
+            // uint32 wrap-around of int32 + uint32, then clamp to the contig length (Q3)
+            uint32_t center = min(static_cast<uint32_t>(pos[i]) + half_read, ref_len[r]);
+            cref[o] = static_cast<uint32_t>(r);
+            cgbin[o] = bin_off[r] + center / bin_width;
+        }
+        running += total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_flags: for every mapped record, `head` = first record of its read (run of equal identities) and `first` = first
+// record of its (read, ref) pair.  Only `first` records become targets: the reference's add_target() pushes a repeated
+// pair's bin into a by-value copy, so the bin of the FIRST record in file order is the one that counts (Q1).
+// Look-back is over a handful of neighbouring records (cache resident); runs longer than kLookBackMax are rejected.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_flags(const uint64_t* __restrict__ ident, const uint32_t* __restrict__ cref,
+                                                  uint32_t* __restrict__ counters, uint8_t* __restrict__ fl,
+                                                  uint2* __restrict__ tile_cnt) {
+    __shared__ uint2 s_w[kWaves];
+    const uint32_t V = counters[CNT_V];
+    const uint32_t base = blockIdx.x * kTile;
+    uint32_t nh = 0, nf = 0;
+    bool too_long = false;
+    if (base < V) {
+#pragma unroll 2
+        for (int k = 0; k < kItems; ++k) {
+            uint32_t i = base + k * kBlock + threadIdx.x;
+            if (i < V) {
+                uint64_t id = ident[i];
+                uint32_t r = cref[i];
+                bool head = (i == 0) || (ident[i - 1] != id);
+                bool first = true;
+                if (!head) {
+                    uint32_t j = i - 1, steps = 0;
+                    while (true) {
+                        if (cref[j] == r) {
+                            first = false;
+                            break;
+                        }
+                        if (j == 0 || ident[j - 1] != id) break;
+                        --j;
+                        if (++steps > kLookBackMax) {
+                            too_long = true;
+                            break;
+                        }
+                    }
+                }
+                fl[i] = static_cast<uint8_t>((head ? 1 : 0) | (first ? 2 : 0));
+                nh += head;
+                nf += first;
+            }
+        }
+    }
+    nh = wave_sum(nh);
+    nf = wave_sum(nf);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = make_uint2(nh, nf);
+    if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_RUN_LENGTH);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint2 t = make_uint2(0u, 0u);
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            t.x += s_w[w].x;
+            t.y += s_w[w].y;
+        }
+        tile_cnt[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_build_csr: scatter `first` records into the target arrays and `head` records into read_off.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_build_csr(const uint8_t* __restrict__ fl, const uint32_t* __restrict__ cref,
+                                                      const uint32_t* __restrict__ cgbin,
+                                                      const uint32_t* __restrict__ counters,
+                                                      const uint2* __restrict__ tile_off, uint32_t* __restrict__ tgt_ref,
+                                                      uint32_t* __restrict__ tgt_gbin, uint32_t* __restrict__ read_off) {
+    __shared__ uint2 s_w[2][kWaves];
+    const uint32_t V = counters[CNT_V];
+    const uint32_t base = blockIdx.x * kTile;
+    if (base >= V) return;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint2 running = tile_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        uint32_t i = base + k * kBlock + threadIdx.x;
+        uint32_t f = (i < V) ? fl[i] : 0u;
+        bool head = f & 1u, first = f & 2u;
+        uint64_t mh = __ballot(head), mf = __ballot(first);
+        uint32_t rh = mask_rank(mh), rf = mask_rank(mf);
+        if ((threadIdx.x & 63) == 0) s_w[k & 1][wave] = make_uint2(__popcll(mh), __popcll(mf));
+        __syncthreads();
+        uint2 before = make_uint2(0u, 0u), total = make_uint2(0u, 0u);
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            uint2 c = s_w[k & 1][w];
+            if (w < static_cast<int>(wave)) {
+                before.x += c.x;
+                before.y += c.y;
+            }
+            total.x += c.x;
+            total.y += c.y;
+        }
+        if (first) {
+            uint32_t t = running.y + before.y + rf;
+            tgt_ref[t] = cref[i] | (head ? 0x80000000u : 0u);
+            tgt_gbin[t] = cgbin[i];
+            if (head) read_off[running.x + before.x + rh] = t;
+        }
+        running.x += total.x;
+        running.y += total.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_hist: cov[g]++ for every target; uniq_cov[g]++ when the target is the only one of its read
+// (src/slimm.hpp:219-257).  reads_count / uniq_reads_count are NOT counted here: each target adds exactly one to
+// both reads_count[ref] and one bin of ref, so they are the per-reference bin sums k_ref_stats produces.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tgt_ref, const uint32_t* __restrict__ tgt_gbin,
+                                                 const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
+                                                 uint32_t* __restrict__ ucov) {
+    const uint32_t P = counters[CNT_P];
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P; t += stride) {
+        uint32_t g = tgt_gbin[t];
+        bool start = tgt_ref[t] >> 31;
+        bool next_start = (t + 1 == P) || (tgt_ref[t + 1] >> 31);
+        atomicAdd(&cov[g], 1u);
+        if (start && next_start) atomicAdd(&ucov[g], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_ref_stats: one wave per reference streams its (16-byte aligned, zero padded) bin range of up to two arrays and
+// reduces {sum, non-zero count} for each.  out[ref*4 + {0,1,2,3}] = sum_a, nz_a, sum_b, nz_b.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                      const uint32_t* __restrict__ bin_off, uint32_t n_refs,
+                                                      uint32_t* __restrict__ out) {
+    const uint32_t ref = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (ref >= n_refs) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t s = bin_off[ref], e = bin_off[ref + 1];
+    uint32_t sa = 0, za = 0, sb = 0, zb = 0;
+    for (uint32_t i = s + lane * 4; i < e; i += 256) {
+        uint4 v = *reinterpret_cast<const uint4*>(a + i);
+        sa += v.x + v.y + v.z + v.w;
+        za += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+        if (b) {
+            uint4 w = *reinterpret_cast<const uint4*>(b + i);
+            sb += w.x + w.y + w.z + w.w;
+            zb += (w.x != 0) + (w.y != 0) + (w.z != 0) + (w.w != 0);
+        }
+    }
+    sa = wave_sum(sa);
+    za = wave_sum(za);
+    sb = wave_sum(sb);
+    zb = wave_sum(zb);
+    if (lane == 0) *reinterpret_cast<uint4*>(out + static_cast<size_t>(ref) * 4) = make_uint4(sa, za, sb, zb);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_filter_lca: one thread per read.
+//   * keep the targets whose reference is valid (read_stat::update, read_stat.hpp:98-114)
+//   * exactly one left  -> uniq_cov2[g]++   (src/slimm.hpp:383-390)
+//   * more than one     -> level-scan LCA over the dense lineage rows (src/slimm.hpp:516-531): the first level at
+//     which all rows agree (a shared 0 "hole" agrees, Q5); if none, the level-7 entry of the LARGEST reference id --
+//     the reference iterates a std::set and returns the last value it read (Q4).  Then lca_count[t]++ and
+//     children[t] gets every kept reference (src/slimm.hpp:552-555): as a (ref, level) mark bit when a level agrees
+//     (t is lineage[ref][level] for each of them), as a (t, ref) pair in a hash set otherwise.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ void pair_insert(uint64_t key, uint64_t* __restrict__ tab, uint64_t* __restrict__ list, uint32_t mask,
+                            uint32_t* __restrict__ counters) {
+    uint32_t slot = static_cast<uint32_t>(mix64(key)) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        uint64_t cur = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return;
+        if (cur == ~0ull) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot]), ~0ull,
+                                               static_cast<unsigned long long>(key));
+            if (old == ~0ull) {
+                uint32_t k = atomicAdd(&counters[CNT_PAIRS], 1u);
+                if (k <= (mask >> 1))
+                    list[k] = key;
+                else
+                    atomicOr(&counters[CNT_ERR], ERR_PAIR_OVERFLOW);
+                return;
+            }
+            if (old == key) return;
+        }
+        slot = (slot + 1) & mask;
+    }
+    atomicOr(&counters[CNT_ERR], ERR_PAIR_OVERFLOW);
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restrict__ read_off,
+                                                       const uint32_t* __restrict__ tgt_ref,
+                                                       const uint32_t* __restrict__ tgt_gbin,
+                                                       uint32_t* __restrict__ counters, const uint8_t* __restrict__ valid,
+                                                       const uint4* __restrict__ lin4, uint32_t* __restrict__ ucov2,
+                                                       uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
+                                                       uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
+                                                       uint32_t pair_mask) {
+    const uint32_t M = counters[CNT_M];
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t s = read_off[m], e = read_off[m + 1];
+    const bool multi = (e - s) > 1;
+    uint32_t nv = 0, g1 = 0, first_ref = 0, max_ref = 0, eq = 0xffu;
+    uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0;
+    for (uint32_t t = s; t < e; ++t) {
+        uint32_t r = tgt_ref[t] & 0x7fffffffu;
+        if (!valid[r]) continue;
+        if (nv == 0) {
+            g1 = tgt_gbin[t];
+            first_ref = r;
+        }
+        if (multi) {
+            uint4 a = lin4[2 * r], b = lin4[2 * r + 1];
+            if (nv == 0) {
+                a0 = a;
+                b0 = b;
+            } else {
+                uint32_t q = (a.x == a0.x ? 1u : 0u) | (a.y == a0.y ? 2u : 0u) | (a.z == a0.z ? 4u : 0u) |
+                             (a.w == a0.w ? 8u : 0u) | (b.x == b0.x ? 16u : 0u) | (b.y == b0.y ? 32u : 0u) |
+                             (b.z == b0.z ? 64u : 0u) | (b.w == b0.w ? 128u : 0u);
+                eq &= q;
+            }
+        }
+        max_ref = max(max_ref, r);
+        ++nv;
+    }
+    if (nv == 1) {
+        atomicAdd(&ucov2[g1], 1u);
+    } else if (nv > 1) {
+        const uint32_t* lin = reinterpret_cast<const uint32_t*>(lin4);
+        uint32_t taxon;
+        if (eq) {
+            uint32_t lv = __builtin_ctz(eq);
+            taxon = lin[static_cast<size_t>(first_ref) * 8 + lv];
+            for (uint32_t t = s; t < e; ++t) {
+                uint32_t r = tgt_ref[t] & 0x7fffffffu;
+                if (valid[r] && !((marks[r] >> lv) & 1u)) atomicOr(&marks[r], 1u << lv);
+            }
+        } else {
+            taxon = lin[static_cast<size_t>(max_ref) * 8 + 7];
+            for (uint32_t t = s; t < e; ++t) {
+                uint32_t r = tgt_ref[t] & 0x7fffffffu;
+                if (valid[r]) pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
+            }
+        }
+        atomicAdd(&lca_count[taxon], 1u);
+    }
+}
+
+// tail[0..3] = {hits, matches, targets, err}: the additive scalars that travel with the bins through the all-reduce
+__global__ void k_publish_tail(const uint32_t* __restrict__ counters, uint32_t* __restrict__ tail) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        tail[0] = counters[CNT_V];
+        tail[1] = counters[CNT_M];
+        tail[2] = counters[CNT_P];
+        tail[3] = counters[CNT_ERR];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static inline uint32_t tiles_for(uint32_t n) { return (n + kTile - 1) / kTile; }
+
+uint32_t num_tiles(uint32_t n) { return tiles_for(n); }
+
+void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters) {
+    uint32_t nt = tiles_for(in.n);
+    if (nt) hipLaunchKernelGGL(k_valid_count, dim3(nt), dim3(kBlock), 0, st, in.flag, in.ref, in.n, n_refs, tile_cnt, counters);
+}
+
+void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
+                       uint32_t* read_off) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off);
+}
+
+void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
+                    const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
+                    uint32_t* cgbin) {
+    uint32_t nt = tiles_for(in.n);
+    if (nt)
+        hipLaunchKernelGGL(k_compact, dim3(nt), dim3(kBlock), 0, st, in.key, in.ref, in.pos, in.flag, in.n, n_refs, tile_off,
+                           ref_len, bin_off, half_read, bin_width, ident, cref, cgbin);
+}
+
+void launch_flags(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, uint32_t* counters,
+                  uint8_t* fl, uint2* tile_cnt) {
+    uint32_t nt = tiles_for(n_upper);
+    if (nt) hipLaunchKernelGGL(k_flags, dim3(nt), dim3(kBlock), 0, st, ident, cref, counters, fl, tile_cnt);
+}
+
+void launch_build_csr(hipStream_t st, uint32_t n_upper, const uint8_t* fl, const uint32_t* cref, const uint32_t* cgbin,
+                      const uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
+                      uint32_t* read_off) {
+    uint32_t nt = tiles_for(n_upper);
+    if (nt)
+        hipLaunchKernelGGL(k_build_csr, dim3(nt), dim3(kBlock), 0, st, fl, cref, cgbin, counters, tile_off, tgt_ref, tgt_gbin,
+                           read_off);
+}
+
+void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
+                 uint32_t* cov, uint32_t* ucov) {
+    uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
+    if (blocks > 256u * 16u) blocks = 256u * 16u;  // grid-stride beyond 16 workgroups per CU
+    if (blocks) hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_ref, tgt_gbin, counters, cov, ucov);
+}
+
+void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
+                      uint32_t* out) {
+    uint32_t blocks = (n_refs + kWaves - 1) / kWaves;
+    if (blocks) hipLaunchKernelGGL(k_ref_stats, dim3(blocks), dim3(kBlock), 0, st, a, b, bin_off, n_refs, out);
+}
+
+void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
+                       const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
+                       uint32_t* ucov2, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list,
+                       uint32_t pair_mask) {
+    uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
+    if (blocks)
+        hipLaunchKernelGGL(k_filter_lca, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters, valid,
+                           reinterpret_cast<const uint4*>(lin_dense), ucov2, lca_count, marks, pair_tab, pair_list, pair_mask);
+}
+
+void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail) {
+    hipLaunchKernelGGL(k_publish_tail, dim3(1), dim3(64), 0, st, counters, tail);
+}
+
+}  // namespace slimm

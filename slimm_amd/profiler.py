@@ -1,0 +1,231 @@
+"""Python mirror of the reference's `class slimm` (reference src/slimm.hpp:92-165) on top of the C ABI.
+
+Method names and call order are the reference's: `analyze_alignments` -> `filter_alignments` ->
+`get_reads_lca_count` -> `write_abundance` (src/slimm.hpp:449-489); `get_profiles` runs them in that order.
+All compute happens in libslimm_hip.so (HIP kernels + the C++ host glue); this file only moves pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import capi
+from .workload import Options, Records, Taxonomy, Workload
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceArray:
+    """A device pointer + length exposed through __cuda_array_interface__ (lets torch alias library memory)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<i4"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class Slimm:
+    def __init__(self, taxonomy: Taxonomy, options: Options, ref_names: List[str], ref_len: np.ndarray,
+                 avg_read_len: int, device: int = 0, grouped: bool = True, lineage: Optional[np.ndarray] = None):
+        self.L = capi.lib()
+        self.ctx = C.c_void_p()
+        self.ref_names = list(ref_names)
+        self.n_refs = len(ref_names)
+        self._ref_len = np.ascontiguousarray(ref_len, dtype=np.uint32)
+        self._lineage = np.ascontiguousarray(
+            lineage if lineage is not None else taxonomy.lineage_for_header(ref_names), dtype=np.uint32)
+        assert self._lineage.shape == (self.n_refs, 8)
+        names = (C.c_char_p * len(taxonomy.tax_name))(*[n.encode() for n in taxonomy.tax_name])
+        cfg = capi.Config(
+            n_refs=self.n_refs, ref_len=_p(self._ref_len), lineage=_p(self._lineage),
+            bin_width=options.bin_width, avg_read_len=int(avg_read_len), min_reads=options.min_reads,
+            cov_cut_off=options.cov_cut_off, abundance_cut_off=options.abundance_cut_off, rank=options.rank.encode(),
+            n_taxa=len(taxonomy.tax_name), tax_id=_p(taxonomy.tax_id), tax_rank=_p(taxonomy.tax_rank),
+            tax_name=names, device=device, record_order=capi.ORDER_GROUPED if grouped else capi.ORDER_ANY)
+        rc = self.L.slimm_create(C.byref(cfg), C.byref(self.ctx))
+        if rc != capi.OK:
+            msg = self.L.slimm_last_error(None)
+            raise capi.SlimmError(rc, msg.decode() if msg else "")
+        self.device = device
+        self._keepalive = None
+        n = C.c_uint32()
+        tp = C.c_void_p()
+        self._check(self.L.slimm_dense_taxa(self.ctx, C.byref(n), C.byref(tp)))
+        self.n_taxa_dense = n.value
+        self.dense_taxid = np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+
+    @classmethod
+    def for_workload(cls, w: Workload, device: int = 0, grouped: Optional[bool] = None) -> "Slimm":
+        return cls(w.taxonomy, w.options, w.ref_names, w.ref_len, w.avg_read_len, device=device,
+                   grouped=w.grouped if grouped is None else grouped)
+
+    def close(self):
+        if self.ctx:
+            self.L.slimm_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> int:
+        return capi.check(self.ctx, rc)
+
+    # ---- record stream ----
+    def reset(self):
+        self._keepalive = None
+        self._check(self.L.slimm_reset(self.ctx))
+
+    def reset_cutoffs(self):
+        self._check(self.L.slimm_reset_cutoffs(self.ctx))
+
+    def push_records(self, rec: Records, batch: int = 0):
+        n = len(rec)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_push_records(self.ctx, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
+                                                  _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), e - s))
+
+    def set_records_device(self, key, ref, pos, flag):
+        """torch tensors on this context's device: int64/uint64 key, int32 ref, int32 pos, int16/uint16 flag."""
+        n = int(key.shape[0])
+        self._keepalive = (key, ref, pos, flag)
+        self._check(self.L.slimm_set_records_device(self.ctx, C.c_void_p(key.data_ptr()), C.c_void_p(ref.data_ptr()),
+                                                    C.c_void_p(pos.data_ptr()), C.c_void_p(flag.data_ptr()), n))
+
+    # ---- the reference's phases ----
+    def analyze_alignments(self):
+        self._check(self.L.slimm_analyze_alignments(self.ctx))
+
+    def coverage_buffer(self) -> DeviceArray:
+        ptr = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.L.slimm_coverage_buffer(self.ctx, C.byref(ptr), C.byref(n)))
+        return DeviceArray(ptr.value, n.value, "<i4")
+
+    def finish_coverage(self) -> bool:
+        """True when there are mapped records (False = the reference's 'No mapped reads' early return)."""
+        return self._check(self.L.slimm_finish_coverage(self.ctx)) != capi.E_NO_HITS
+
+    def set_coverage_columns(self, reads_count, uniq_reads_count, nz_cov, nz_uniq_cov, hits, matches) -> bool:
+        a = [np.ascontiguousarray(x, dtype=np.uint32) for x in (reads_count, uniq_reads_count, nz_cov, nz_uniq_cov)]
+        return self._check(self.L.slimm_set_coverage_columns(self.ctx, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]),
+                                                             int(hits), int(matches))) != capi.E_NO_HITS
+
+    def filter_alignments(self):
+        self._check(self.L.slimm_filter_alignments(self.ctx))
+
+    def get_partials(self) -> Dict[str, np.ndarray]:
+        p = capi.Partials()
+        self._check(self.L.slimm_get_partials(self.ctx, C.byref(p)))
+
+        def arr(ptr, n, ct, dt):
+            if n == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).copy()
+
+        return {"uniq_reads_count2": arr(p.uniq_reads_count2, p.n_refs, C.c_uint32, np.uint32),
+                "lca_count": arr(p.lca_count, p.n_taxa_dense, C.c_uint32, np.uint32),
+                "level_marks": arr(p.level_marks, p.n_refs, C.c_uint32, np.uint32),
+                "pairs": arr(p.pairs, p.n_pairs, C.c_uint64, np.uint64)}
+
+    def set_partials(self, uniq_reads_count2, lca_count, level_marks, pairs):
+        u2 = np.ascontiguousarray(uniq_reads_count2, dtype=np.uint32)
+        lc = np.ascontiguousarray(lca_count, dtype=np.uint32)
+        mk = np.ascontiguousarray(level_marks, dtype=np.uint32)
+        pr = np.ascontiguousarray(pairs, dtype=np.uint64)
+        p = capi.Partials(n_refs=self.n_refs, n_taxa_dense=self.n_taxa_dense, uniq_reads_count2=_p(u2), lca_count=_p(lc),
+                          level_marks=_p(mk), pairs=_p(pr), n_pairs=int(pr.shape[0]))
+        self._check(self.L.slimm_set_partials(self.ctx, C.byref(p)))
+
+    def get_reads_lca_count(self):
+        self._check(self.L.slimm_get_reads_lca_count(self.ctx))
+
+    def write_abundance(self, path: Optional[str] = None) -> str:
+        if path is not None:
+            self._check(self.L.slimm_write_abundance_file(self.ctx, path.encode()))
+        text = C.c_char_p()
+        n = C.c_uint64()
+        self._check(self.L.slimm_write_abundance(self.ctx, C.byref(text), C.byref(n)))
+        return C.string_at(text, n.value).decode()
+
+    def get_profiles(self, rec: Optional[Records] = None, path: Optional[str] = None) -> Optional[str]:
+        """slimm::get_profiles() minus file I/O (src/slimm.hpp:395-496). None = no mapped reads."""
+        if rec is not None:
+            self.push_records(rec)
+        self.analyze_alignments()
+        if not self.finish_coverage():
+            return None
+        self.filter_alignments()
+        self.get_reads_lca_count()
+        return self.write_abundance(path)
+
+    # ---- results ----
+    def stats(self) -> Dict[str, float]:
+        s = capi.Stats()
+        self._check(self.L.slimm_get_stats(self.ctx, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in capi.Stats._fields_}
+
+    def ref_columns(self) -> Dict[str, np.ndarray]:
+        R = self.n_refs
+        out = {n: np.zeros(R, dtype=np.uint32) for n in ("reads_count", "uniq_reads_count", "uniq_reads_count2", "nbins",
+                                                         "nz_cov", "nz_uniq_cov", "nz_uniq_cov2")}
+        out["valid"] = np.zeros(R, dtype=np.uint8)
+        out["abundance"] = np.zeros(R, dtype=np.float32)
+        out["uniq_abundance"] = np.zeros(R, dtype=np.float32)
+        cols = capi.RefColumns(**{k: _p(v) for k, v in out.items()})
+        self._check(self.L.slimm_get_ref_columns(self.ctx, C.byref(cols)))
+        return out
+
+    def bins(self, which: int) -> np.ndarray:
+        out = np.zeros(int(self.stats()["total_bins"]), dtype=np.uint32)
+        self._check(self.L.slimm_get_bins(self.ctx, which, _p(out)))
+        return out
+
+    def taxon_counts(self, stage: int = 1) -> Dict[int, int]:
+        n = C.c_uint32()
+        self._check(self.L.slimm_taxon_count_size(self.ctx, stage, C.byref(n)))
+        t = np.zeros(n.value, dtype=np.uint32)
+        c = np.zeros(n.value, dtype=np.uint32)
+        self._check(self.L.slimm_get_taxon_counts(self.ctx, stage, _p(t), _p(c)))
+        return {int(a): int(b) for a, b in zip(t, c)}
+
+    def children_pairs(self, stage: int = 1) -> set:
+        n = C.c_uint64()
+        self._check(self.L.slimm_children_pairs_size(self.ctx, stage, C.byref(n)))
+        t = np.zeros(n.value, dtype=np.uint32)
+        r = np.zeros(n.value, dtype=np.uint32)
+        self._check(self.L.slimm_get_children_pairs(self.ctx, stage, _p(t), _p(r)))
+        return set(zip(t.tolist(), r.tolist()))
+
+    # ---- measurement ----
+    def enable_kernel_timing(self, on: bool = True):
+        self._check(self.L.slimm_enable_kernel_timing(self.ctx, int(on)))
+
+    def kernel_times(self, reset: bool = True) -> Dict[str, Tuple[float, int]]:
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        ln = (C.c_uint32 * cap)()
+        n = C.c_uint32()
+        self._check(self.L.slimm_kernel_times(self.ctx, names, ms, ln, cap, C.byref(n), int(reset)))
+        return {names[i].decode(): (ms[i], ln[i]) for i in range(n.value)}
+
+
+def host_quantile_cut_off(v: np.ndarray, q: float) -> float:
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    return float(capi.lib().slimm_host_quantile_cut_off(_p(v), v.shape[0], C.c_float(q)))
+
+
+def host_bin_of(begin_pos: int, avg_read_len: int, ref_len: int, bin_width: int) -> int:
+    return int(capi.lib().slimm_host_bin_of(int(begin_pos), int(avg_read_len), int(ref_len), int(bin_width)))
+
+
+def host_avg_read_length(l_seq: np.ndarray, sample: int = 100000) -> int:
+    l_seq = np.ascontiguousarray(l_seq, dtype=np.uint32)
+    return int(capi.lib().slimm_host_avg_read_length(_p(l_seq), l_seq.shape[0], sample))

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the alignment-to-profile hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): M alignment-records/sec from the decoded-record stream to the final profile.
+A step = one pass of the whole hot path over one batch of synthetic records that are already resident in HBM:
+analyze_alignments -> (all-reduce when N > 1) -> finish_coverage -> filter_alignments -> get_reads_lca_count ->
+write_abundance (profile TSV written to a file by rank 0).  The workload at N = 1 is BASELINE.json configs[1]
+(10 M synthetic 100 bp records, 5 k bacterial refs, mean 3 hits/read, 1000 bp bins); with N ranks every rank holds its
+own 10 M-record shard of the same sample (weak scaling) and the value is total records / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, from HIP events recorded on the library's
+stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the reference algorithm, 1 thread) on a
+bounded prefix of the same record stream.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes(st, n_records, Bp_words):
+    """Algorithmic HBM bytes per launch of each kernel (DESIGN.md section 'Kernels and their rooflines').
+
+    N records, V mapped records, P targets = distinct (read, ref) pairs, M reads, U / U2 unique reads before / after
+    the filter, B coverage bins.  The totals add up to SURVEY.md section 8d's figure (about 40 B/record + 8 B/bin).
+    """
+    N, V, P, M = n_records, st["hits_count"], st["n_targets"], st["matches_count"]
+    U, U2, B = st["uniq_matches_count"], st["uniq_matches_count2"], Bp_words
+    return {
+        "memset_bins": 4 * 3 * B,
+        "k_scan_tiles": 2 * 8 * (N // 2048 + 1),      # per-tile counts in and out
+        "k_valid_count": 6 * N,                       # flag u16 + ref i32
+        "k_compact": 18 * N + 16 * V,                 # read every record once, write ident/ref/gbin
+        "k_flags": 12 * V + 1 * V,                    # ident + ref in, flag byte out (look-back hits cache)
+        "k_build_csr": 9 * V + 8 * P + 4 * M,         # flag + ref + gbin in; targets + read offsets out
+        "k_hist": 8 * P + 8 * P + 8 * U,              # targets in; one 4-byte RMW on cov per target, on uniq_cov per unique
+        "k_ref_stats": 8 * B,                         # one streaming read of cov and uniq_cov
+        "k_filter_lca": 4 * M + 8 * P + 8 * U2,       # offsets + targets in; one RMW on uniq_cov2 per post-filter unique
+        "k_ref_stats2": 4 * B,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="config2")
+    ap.add_argument("--records", type=int, default=0, help="records per rank (default: the config's size)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from slimm_amd.distributed import sharded_profile
+    from slimm_amd.profiler import Slimm
+    from slimm_amd.synth import CONFIGS, make_workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (there is no CPU fallback for the hot path)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = CONFIGS[args.config]
+    n_rec = args.records or cfg.n_records
+    t0 = time.time()
+    w = make_workload(cfg, seed=args.seed + 1000 * rank, n_records=n_rec, sample_seed=args.seed, shard=rank)
+    gen_s = time.time() - t0
+
+    eng = Slimm.for_workload(w, device=local_rank)
+    key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
+    ref = torch.from_numpy(w.records.ref_id).to(dev)
+    pos = torch.from_numpy(w.records.begin_pos).to(dev)
+    flag = torch.from_numpy(w.records.flag.view(np.int16)).to(dev)
+    torch.cuda.synchronize()
+    out_path = os.path.join(tempfile.gettempdir(), f"slimm_bench_profile_{os.getpid()}.tsv")
+
+    def step():
+        eng.reset()
+        eng.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
+        eng.set_records_device(key, ref, pos, flag)
+        return sharded_profile(eng, dev, out_path)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.enable_kernel_timing(True)
+    eng.kernel_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        profile = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = eng.kernel_times(reset=True)
+    eng.enable_kernel_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    st = eng.stats()
+    total_records = n_rec * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_records / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        Bp = int(eng.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
+        model = algorithmic_bytes(st, n_rec, Bp)
+        per_kernel = {}
+        for name, (ms, launches) in ktimes.items():
+            if launches and name in model:
+                per_launch_ms = ms / launches
+                steps_launches = launches / args.steps
+                per_kernel[name] = {"ms_per_launch": per_launch_ms, "launches_per_step": steps_launches,
+                                    "bytes_per_launch": model[name] / max(1.0, steps_launches if name == "memset_bins" else 1.0),
+                                    }
+        # the dominant kernel = most time per step (memsets are DMA fills, not kernels of this library)
+        cand = {k: v for k, v in per_kernel.items() if k != "memset_bins"}
+        dom = max(cand, key=lambda k: cand[k]["ms_per_launch"] * cand[k]["launches_per_step"])
+        d = cand[dom]
+        achieved = d["bytes_per_launch"] / (d["ms_per_launch"] * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
+        kernel_ms = sum(v["ms_per_launch"] * v["launches_per_step"] for v in per_kernel.values())
+        if args.breakdown:
+            print(f"# generate {gen_s:.1f}s; records/rank {n_rec}; V={st['hits_count']} M={st['matches_count']} "
+                  f"P={st['n_targets']} U={st['uniq_matches_count']} U2={st['uniq_matches_count2']} "
+                  f"valid={st['n_valid']} B={st['total_bins']}", file=sys.stderr)
+            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"]):
+                gbs = v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9
+                print(f"# {k:16s} {v['ms_per_launch']*1e3:9.1f} us/launch x{v['launches_per_step']:.0f}  "
+                      f"{v['bytes_per_launch']/1e6:9.1f} MB  {gbs:8.1f} GB/s  {gbs/HBM_PEAK_GBS*100:5.1f}% of HBM peak",
+                      file=sys.stderr)
+            print(f"# device kernels {kernel_ms:.3f} ms of {ms_per_step:.3f} ms per step", file=sys.stderr)
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.binding import Oracle  # the CPU restatement of the reference algorithm (checker / baseline only)
+
+            ns = min(args.cpu_sample, n_rec)
+            sample = w.records.take(np.arange(ns))
+            orc = Oracle(w.taxonomy, w.options)
+            t1 = time.perf_counter()
+            o = orc.run(w.ref_names, w.ref_len, sample, w.avg_read_len, want_raw=False, want_cov=False, use_qnames=False,
+                        collect_bins=False)
+            wall = time.perf_counter() - t1
+            cpu_s = sum(o.phase_seconds)  # the three phases + profile, excluding reference/bin allocation
+            cpu = {"value": round(ns / cpu_s / 1e6, 4), "unit": "M records/s", "cores": 1, "kind": "port",
+                   "sample": f"first {ns} records of the same stream (same refs/DB), phases A+B+C+profile "
+                             f"{cpu_s:.1f}s of {wall:.1f}s wall",
+                   "host": f"{os.cpu_count()} logical cores"}
+
+        line = {
+            "metric": "M alignment-records/sec -> final profile",
+            "value": round(value, 3), "unit": "M records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{list(CONFIGS).index(args.config)}] ({args.config}): "
+                                   f"{n_rec} records/GPU, {cfg.n_refs} refs, mean {cfg.mean_hits} hits/read, "
+                                   f"{cfg.bin_width} bp bins, {cfg.read_len} bp reads",
+                       "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
+                       "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
+                       "record_order": "grouped", "seed": args.seed,
+                       "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "device_kernel_ms_per_step": round(kernel_ms, 4),
+        }
+        print(json.dumps(line))
+        try:
+            os.unlink(out_path)
+        except OSError:
+            pass
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

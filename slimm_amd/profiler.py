@@ -108,6 +108,12 @@ class Slimm:
         self._check(self.L.slimm_coverage_buffer(self.ctx, C.byref(ptr), C.byref(n)))
         return DeviceArray(ptr.value, n.value, "<i4")
 
+    def coverage_tensor(self):
+        """The coverage buffer as an int32 torch tensor aliasing the library's device memory (for the all-reduce)."""
+        import torch
+
+        return torch.as_tensor(self.coverage_buffer(), device=f"cuda:{self.device}")
+
     def finish_coverage(self) -> bool:
         """True when there are mapped records (False = the reference's 'No mapped reads' early return)."""
         return self._check(self.L.slimm_finish_coverage(self.ctx)) != capi.E_NO_HITS

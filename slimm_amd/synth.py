@@ -78,17 +78,21 @@ def synth_taxonomy(n_refs: int, strain_level: bool = False, hole_every: int = 0)
 
 def make_workload(cfg: SynthConfig, seed: int = 1, n_records: Optional[int] = None, shuffled: bool = False,
                   unmapped_frac: float = 0.02, paired_frac: float = 0.30, repeat_frac: float = 0.05,
-                  hole_every: int = 0) -> Workload:
-    rng = np.random.Generator(np.random.PCG64(seed))
+                  hole_every: int = 0, sample_seed: Optional[int] = None, shard: int = 0) -> Workload:
+    """One input file.  `sample_seed` (default: seed) fixes the header, database and sample composition;
+    `seed` fixes the record stream, so several shards of one sample share everything but their reads
+    (`shard` keeps read identities disjoint between them)."""
+    rng_s = np.random.Generator(np.random.PCG64(seed if sample_seed is None else sample_seed))
+    rng = np.random.Generator(np.random.PCG64([seed, 0x5eed]))
     N = int(n_records if n_records is not None else cfg.n_records)
     R = cfg.n_refs
     tax = synth_taxonomy(R, cfg.strain_level, hole_every)
-    ref_len = rng.integers(cfg.len_lo, cfg.len_hi, size=R, dtype=np.int64).astype(np.uint32)
+    ref_len = rng_s.integers(cfg.len_lo, cfg.len_hi, size=R, dtype=np.int64).astype(np.uint32)
     ref_names = [a + ".1" for a in tax.accessions]
 
     # organisms present in the sample, Zipf-like abundances
     n_present = max(4, int(R * cfg.present_frac))
-    present = rng.choice(R, size=n_present, replace=False)
+    present = rng_s.choice(R, size=n_present, replace=False)
     wts = 1.0 / np.arange(1, n_present + 1) ** 0.8
     wts /= wts.sum()
 
@@ -100,7 +104,8 @@ def make_workload(cfg: SynthConfig, seed: int = 1, n_records: Optional[int] = No
     hits[unmapped] = 1
     home = present[rng.choice(n_present, size=n_reads, p=wts)].astype(np.int64)
     # read identity: a bijection of the read index into 62 bits, so distinct reads never share a key
-    key = (np.arange(n_reads, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64((1 << 62) - 1)
+    key = ((np.arange(n_reads, dtype=np.uint64) + np.uint64(shard << 40)) * np.uint64(0x9E3779B97F4A7C15)) \
+        & np.uint64((1 << 62) - 1)
     # mates: a paired read name = two consecutive reads sharing the key, flags 0x41 / 0x81
     mate = np.zeros(n_reads, dtype=np.uint16)
     first_of_pair = (rng.random(n_reads) < paired_frac / 2)

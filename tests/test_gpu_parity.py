@@ -1,0 +1,319 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on a real MI355X.
+
+Bit-exact for every integer (scalars, per-reference columns, every cov / uniq_cov / uniq_cov2 bin, per-taxon counts,
+children sets, profile read counts); relative-abundance floats within 1e-6 (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+from oracle.binding import run_workload
+from slimm_amd import capi
+from slimm_amd.profiler import Slimm
+from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
+from slimm_amd.workload import Options, Records, Workload
+from tests.cases import holes_case, load_golden, records_from_sam, taxonomy_from_lineages, tiny_case
+from tests.helpers import assert_matches_oracle, assert_profiles_match
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(w: Workload, grouped=None, batch=0, expect_hits=True) -> Slimm:
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    s.push_records(w.records, batch=batch)
+    prof = s.get_profiles()
+    assert (prof is not None) == expect_hits
+    return s
+
+
+def check(w: Workload, grouped=None, batch=0, **kw):
+    o = run_workload(w, use_qnames=w.records.qname is not None)
+    s = run_gpu(w, grouped, batch, expect_hits=not o.no_hits)
+    if o.no_hits:
+        assert s.stats()["hits_count"] == 0
+    else:
+        assert_matches_oracle(s, o, **kw)
+    return s, o
+
+
+# ---------------------------------------------------------------- golden micro-cases (reference-observed)
+@pytest.mark.parametrize("name", ["tiny", "holes"])
+def test_golden_micro_cases(name):
+    w, exp, _ = load_golden(name)
+    s, o = check(w)
+    rows = {k: (v[0], v[1]) for k, v in __import__("oracle.binding", fromlist=["parse_profile"]).parse_profile(
+        s.write_abundance()).items()}
+    for k, (ab, cnt) in exp["profile"].items():
+        assert rows[k][1] == cnt and rows[k][0] == pytest.approx(ab, rel=1e-5)
+    st = s.stats()
+    assert (st["hits_count"], st["matches_count"], st["uniq_matches_count"], st["uniq_matches_count2"]) == (
+        exp["hits"], exp["matches"], exp["uniq_matches"], exp["uniq_matches2"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "holes"])
+def test_golden_micro_cases_unordered_path(name):
+    w, _, _ = load_golden(name)
+    check(w, grouped=False)  # same file order, but through the sort path
+
+
+# ---------------------------------------------------------------- quirks
+def _two_ref_case(rows, lens=(1000, 1000), A=50, W=100, lin=None):
+    lin = lin or {"X": [101, 11, 21, 31, 41, 51, 61, 2], "Y": [102, 12, 21, 31, 41, 51, 61, 2]}
+    names = [a + ".1" for a in lin]
+    return Workload(names, np.array(lens, dtype=np.uint32), taxonomy_from_lineages(lin), records_from_sam(rows, names),
+                    avg_read_len=A, options=Options(bin_width=W, cov_cut_off=0.99), name="two")
+
+
+def test_q1_first_position_of_a_pair_wins():
+    rows = [("a", 0, "X.1", 10), ("a", 256, "X.1", 910), ("b", 0, "X.1", 500), ("b", 256, "Y.1", 100),
+            ("b", 256, "X.1", 20), ("b", 256, "Y.1", 800)]
+    s, o = check(_two_ref_case(rows))
+    cov = s.bins(0)
+    assert cov[0] == 1 and cov[9] == 0      # read a: only its first record on X counts
+    assert cov[5] == 1                      # read b on X: first record (POS 500), not the later POS 20
+    assert s.stats()["hits_count"] == 6 and s.stats()["matches_count"] == 2
+
+
+def test_q2_mates_are_different_reads():
+    rows = [("p", 0x41, "X.1", 10), ("p", 0x81, "X.1", 300), ("p", 0x41 | 0x100, "Y.1", 10), ("q", 0, "X.1", 700)]
+    s, o = check(_two_ref_case(rows))
+    assert s.stats()["matches_count"] == 3 and s.stats()["uniq_matches_count"] == 2
+
+
+def test_q3_bin_clamp_and_wrap():
+    rows = [("a", 0, "X.1", 1000), ("b", 0, "X.1", 0), ("c", 0, "X.1", 976), ("d", 0, "Y.1", 1)]
+    s, o = check(_two_ref_case(rows))
+    cov = s.bins(0)
+    assert cov[10] == 2   # POS 1000 and 976: centre >= len clamps to len -> bin len/W
+    assert cov[0] == 1    # POS 0 -> beginPos -1 -> uint32 wrap to A/2 - 1 = 24 -> bin 0
+
+
+def test_q4_q5_lca_fallthrough_and_holes():
+    lin = {"X": [101, 11, 21, 31, 41, 51, 61, 2], "Y": [102, 12, 22, 32, 42, 52, 62, 2157],
+           "H1": [201, 0, 23, 33, 43, 53, 63, 2], "H2": [202, 0, 23, 33, 43, 53, 63, 2]}
+    names = [a + ".1" for a in lin]
+    rows = []
+    for i in range(12):
+        rows += [(f"u{i}", 0, names[i % 4], 1 + 70 * i)]
+    rows += [("x1", 0, "X.1", 100), ("x1", 256, "Y.1", 100), ("x2", 0, "Y.1", 300), ("x2", 256, "X.1", 300),
+             ("h", 0, "H1.1", 200), ("h", 256, "H2.1", 200)]
+    w = Workload(names, np.full(4, 1000, dtype=np.uint32), taxonomy_from_lineages(lin), records_from_sam(rows, names),
+                 avg_read_len=50, options=Options(bin_width=100, cov_cut_off=0.99), name="q4")
+    s, o = check(w)
+    d = s.taxon_counts(0)
+    assert d[2157] == 2   # no level agrees -> lineage[largest ref id][7] (Y is ref 1 > X ref 0)
+    assert d[0] == 1      # shared species hole agrees at level 1 -> taxid 0
+
+
+def test_unknown_accession_gets_zero_lineage():
+    w, _, _ = load_golden("holes")   # NODB.1 is not in the database (Q13)
+    s, o = check(w)
+    assert s.ref_columns()["reads_count"][4] == 11
+
+
+# ---------------------------------------------------------------- seeded synthetic inputs vs the oracle
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_config1_scale(seed):
+    check(make_workload(CONFIGS["config1"], seed=seed))
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_config1_scale_shuffled_records(seed):
+    check(make_workload(CONFIGS["config1"], seed=seed, shuffled=True))
+
+
+def test_config1_with_holes():
+    w = make_workload(CONFIGS["config1"], seed=7, hole_every=3)
+    o = run_workload(w)
+    s = run_gpu(w)
+    # taxid 0's propagated count depends on unordered_map iteration order in the reference (Q17): pin everything up
+    # to and including the direct LCA hits, and the per-reference integers
+    assert s.taxon_counts(0) == o.lca_direct and s.children_pairs(0) == o.lca_direct_children
+    rc = s.ref_columns()
+    assert np.array_equal(rc["uniq_reads_count2"], o.uniq_reads_count2)
+    assert np.array_equal(s.bins(2), o.uniq_cov2)
+
+
+@pytest.mark.parametrize("n,seed", [(300_000, 1), (1_000_000, 2)])
+def test_config2_shape(n, seed):
+    check(make_workload(CONFIGS["config2"], seed=seed, n_records=n))
+
+
+def test_config2_shape_shuffled():
+    check(make_workload(CONFIGS["config2"], seed=3, n_records=400_000, shuffled=True))
+
+
+def test_config3_shape_more_hits():
+    cfg = SynthConfig("c3small", 400_000, 2_000, 8.0)
+    check(make_workload(cfg, seed=4))
+
+
+def test_config5_shape_strain_level_many_hits():
+    cfg = SynthConfig("c5small", 400_000, 3_000, 40.0, strain_level=True)
+    s, o = check(make_workload(cfg, seed=5))
+    assert len(o.lca_direct) > 10  # deep-LCA stress really happened
+
+
+def test_many_cross_superkingdom_reads_use_the_pair_set():
+    # every 4th phylum is archaeal in the synthetic tree; a huge neighbour spread makes reads straddle it
+    cfg = SynthConfig("q4many", 200_000, 10_000, 6.0, present_frac=0.5, len_lo=200_000, len_hi=600_000)
+    w = make_workload(cfg, seed=8)
+    rng = np.random.default_rng(0)
+    m = w.records.ref_id >= 0
+    jump = rng.random(len(w.records)) < 0.2
+    w.records.ref_id[m & jump] = rng.integers(0, cfg.n_refs, size=int((m & jump).sum()), dtype=np.int32)
+    w.records.begin_pos[m & jump] = 1000
+    s, o = check(w)
+    assert s.get_partials()["pairs"].shape[0] > 100
+
+
+def test_batched_push_equals_single_push():
+    w = make_workload(CONFIGS["config1"], seed=11)
+    a = run_gpu(w)
+    b = run_gpu(w, batch=777)
+    assert a.write_abundance() == b.write_abundance()
+    assert np.array_equal(a.bins(0), b.bins(0)) and np.array_equal(a.bins(2), b.bins(2))
+
+
+def test_device_resident_records_and_reset_reuse():
+    import torch
+    w = make_workload(CONFIGS["config2"], seed=12, n_records=200_000)
+    o = run_workload(w, use_qnames=False)
+    s = Slimm.for_workload(w, device=0)
+    dev = torch.device("cuda:0")
+    key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
+    ref = torch.from_numpy(w.records.ref_id).to(dev)
+    pos = torch.from_numpy(w.records.begin_pos).to(dev)
+    flag = torch.from_numpy(w.records.flag.view(np.int16)).to(dev)
+    torch.cuda.synchronize()
+    for _ in range(3):  # the same context, reset between runs (slimm::reset)
+        s.reset()
+        s.reset_cutoffs()
+        s.set_records_device(key, ref, pos, flag)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+
+
+def test_kernel_timing_reports_every_kernel():
+    w = make_workload(CONFIGS["config1"], seed=13)
+    s = Slimm.for_workload(w, device=0)
+    s.enable_kernel_timing(True)
+    s.push_records(w.records)
+    s.get_profiles()
+    t = s.kernel_times()
+    for k in ("k_compact", "k_flags", "k_build_csr", "k_hist", "k_ref_stats", "k_filter_lca"):
+        assert t[k][1] >= 1 and t[k][0] > 0.0, k
+
+
+# ---------------------------------------------------------------- edge cases
+def test_empty_and_all_unmapped_inputs():
+    w = tiny_case()
+    s = Slimm.for_workload(w, device=0)
+    assert s.get_profiles() is None                     # no records at all
+    s.reset()
+    n = 1000
+    rec = Records(np.arange(n, dtype=np.uint64), np.full(n, 4, dtype=np.uint16), np.full(n, -1, dtype=np.int32),
+                  np.full(n, -1, dtype=np.int32))
+    s.push_records(rec)
+    assert s.get_profiles() is None                     # reference: "[WARNING] No mapped reads found"
+    assert s.stats()["hits_count"] == 0
+
+
+def test_mapped_flag_with_invalid_ref_is_skipped_and_unmapped_flag_with_ref_too():
+    rows = [("a", 0, "*", 10), ("b", 4, "X.1", 10), ("c", 0, "X.1", 10), ("d", 0, "Y.1", 10)]
+    s, o = check(_two_ref_case(rows))
+    assert s.stats()["hits_count"] == 2
+
+
+def test_single_record():
+    s, o = check(_two_ref_case([("only", 0, "Y.1", 500)]))
+    assert s.stats()["uniq_matches_count2"] == 1
+
+
+def test_reference_id_out_of_range_is_an_error():
+    w = tiny_case()
+    w.records.ref_id[3] = 99
+    s = Slimm.for_workload(w, device=0)
+    s.push_records(w.records)
+    s.analyze_alignments()
+    with pytest.raises(capi.SlimmError) as e:
+        s.finish_coverage()
+    assert e.value.code == capi.E_REF_RANGE
+
+
+def test_run_longer_than_the_lookback_window_is_an_error_not_a_hang():
+    n = 6000
+    rec = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16),
+                  (np.arange(n) % 5).astype(np.int32), np.full(n, 10, dtype=np.int32))
+    w = tiny_case()
+    s = Slimm.for_workload(w, device=0)
+    s.push_records(rec)
+    s.analyze_alignments()
+    # 6000 records of one read over 5 references: every look-back finds its reference within 5 steps -> fine
+    assert s.finish_coverage()
+    s.reset()
+    rec2 = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16),
+                   np.concatenate([np.zeros(n - 1), [1]]).astype(np.int32), np.full(n, 10, dtype=np.int32))
+    s.push_records(rec2)
+    s.analyze_alignments()
+    with pytest.raises(capi.SlimmError) as e:  # the last record must look back over 5999 records of ref 0
+        s.finish_coverage()
+    assert e.value.code == capi.E_RUN_LENGTH
+
+
+def test_ragged_tile_boundaries():
+    """Record counts around the 2048-record tile size, reads straddling tiles."""
+    base = make_workload(SynthConfig("rag", 9000, 40, 5.0, bin_width=100, len_lo=5_000, len_hi=50_000,
+                                     present_frac=0.5), seed=14)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096, 4097, 8191):
+        w = Workload(base.ref_names, base.ref_len, base.taxonomy, base.records.take(np.arange(n)), base.avg_read_len,
+                     base.options, f"rag{n}")
+        check(w)
+        check(w, grouped=False)
+
+
+# ---------------------------------------------------------------- BASELINE.json full size: size-independent properties
+def _order_preserving_interleave(rec: Records, seed: int) -> Records:
+    """Permute records so reads interleave while the relative order inside each read name is kept."""
+    n = len(rec)
+    rng = np.random.default_rng(seed)
+    pos = rng.permutation(n)
+    a = np.lexsort((np.arange(n), rec.read_key))
+    b = np.lexsort((pos, rec.read_key))
+    newpos = np.empty(n, dtype=np.int64)
+    newpos[a] = pos[b]
+    inv = np.empty(n, dtype=np.int64)
+    inv[newpos] = np.arange(n)
+    return rec.take(inv)
+
+
+def test_full_size_config2_invariants():
+    w = make_workload(CONFIGS["config2"], seed=1)            # 10 M records, 5 k refs
+    s = run_gpu(w)
+    st = s.stats()
+    rc = s.ref_columns()
+    cov, ucov, ucov2 = s.bins(0), s.bins(1), s.bins(2)
+    mapped = int(((w.records.flag & 4) == 0).sum() - ((w.records.ref_id < 0) & ((w.records.flag & 4) == 0)).sum())
+    assert st["hits_count"] == mapped
+    assert int(cov.sum(dtype=np.uint64)) == st["n_targets"] == int(rc["reads_count"].sum(dtype=np.uint64))
+    assert int(ucov.sum(dtype=np.uint64)) == st["uniq_matches_count"] == int(rc["uniq_reads_count"].sum(dtype=np.uint64))
+    assert int(ucov2.sum(dtype=np.uint64)) == st["uniq_matches_count2"]
+    assert np.all(ucov <= cov)
+    off = np.concatenate([[0], np.cumsum(rc["nbins"].astype(np.int64))])
+    assert np.array_equal(np.add.reduceat((cov != 0).astype(np.int64), off[:-1]), rc["nz_cov"])
+    assert np.array_equal(np.add.reduceat(ucov2.astype(np.int64), off[:-1]), rc["uniq_reads_count2"])
+    # reads whose targets all fail the filter vanish; the rest are unique-after-filter or counted at their LCA
+    direct = s.taxon_counts(0)
+    assert st["uniq_matches_count2"] + sum(direct.values()) <= st["matches_count"]
+    assert st["uniq_matches_count2"] >= st["uniq_matches_count"] - int(rc["uniq_reads_count"][rc["valid"] == 0].sum())
+    # profile read counts add up to the matched reads (the `0*` row is the remainder)
+    from oracle.binding import parse_profile
+    rows = parse_profile(s.write_abundance())
+    assert sum(v[1] for v in rows.values()) == st["matches_count"]
+    assert sum(v[0] for v in rows.values()) == pytest.approx(100.0, abs=1e-3)
+    # permutation invariance: interleaving reads (order inside a read kept) + the sort path gives identical results
+    w2 = Workload(w.ref_names, w.ref_len, w.taxonomy, _order_preserving_interleave(w.records, 5), w.avg_read_len,
+                  w.options, "interleaved", grouped=False)
+    s2 = run_gpu(w2)
+    assert np.array_equal(s2.bins(0), cov) and np.array_equal(s2.bins(1), ucov) and np.array_equal(s2.bins(2), ucov2)
+    assert s2.taxon_counts(1) == s.taxon_counts(1) and s2.children_pairs(1) == s.children_pairs(1)
+    assert s2.write_abundance() == s.write_abundance()

@@ -41,6 +41,10 @@ def lib():
         L.orc_run.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_char_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_run.restype = C.c_int
+        L.orc_phase_a.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_phase_a.restype = C.c_int
+        L.orc_phase_b_with_valid.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_scalars.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_cutoffs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_ref_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -145,11 +149,30 @@ class Oracle:
         rc = L.orc_run(self.h, len(ref_names), _blob(ref_names), _p(ref_len), int(avg_read_len), len(records), qblob,
                        _p(records.read_key), _p(records.flag), _p(records.ref_id), _p(records.begin_pos),
                        int(want_raw), int(want_cov), _p(ph))
-        R = len(ref_names)
+        return self._collect(rc, len(ref_names), collect_bins, ph)
+
+    def phase_a(self, ref_names, ref_len, records, avg_read_len) -> OracleResult:
+        """analyze_alignments only (for the multi-rank tests); keyed by read_key."""
+        L = lib()
+        L.orc_reset(self.h)
+        ref_len = np.ascontiguousarray(ref_len, dtype=np.uint32)
+        rc = L.orc_phase_a(self.h, len(ref_names), _blob(ref_names), _p(ref_len), int(avg_read_len), len(records),
+                           _p(records.read_key), _p(records.flag), _p(records.ref_id), _p(records.begin_pos))
+        self._n_refs = len(ref_names)
+        return self._collect(rc, len(ref_names), True, np.zeros(3), cutoffs=False)
+
+    def phase_b_with_valid(self, valid) -> OracleResult:
+        """Per-read filter against an externally decided valid set + direct LCA hits, on this shard's reads."""
+        valid = np.ascontiguousarray(valid, dtype=np.uint8)
+        lib().orc_phase_b_with_valid(self.h, _p(valid))
+        return self._collect(0, self._n_refs, True, np.zeros(3), cutoffs=False)
+
+    def _collect(self, rc, R, collect_bins, ph, cutoffs=True) -> OracleResult:
+        L = lib()
         sc = np.zeros(15, dtype=np.uint32)
         L.orc_get_scalars(self.h, _p(sc))
         cut = np.zeros(3, dtype=np.float32)
-        if rc == 0:
+        if rc == 0 and cutoffs:
             L.orc_get_cutoffs(self.h, _p(cut))
         u = np.zeros((R, 8), dtype=np.uint32)
         f = np.zeros((R, 2), dtype=np.float32)

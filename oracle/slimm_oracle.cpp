@@ -360,6 +360,11 @@ struct Oracle {
 
     // slimm.hpp:351-392
     void filter() {
+        compute_valid();
+        apply_valid();
+    }
+    // slimm.hpp:353-378
+    void compute_valid() {
         uint32_t n = static_cast<uint32_t>(refs.size());
         for (uint32_t i = 0; i < n; ++i) {
             if (refs[i].reads == 0) continue;
@@ -371,6 +376,9 @@ struct Oracle {
                 if (refs[i].cov_pct() < coverage_cut_off()) ++failed_by_cov;
             }
         }
+    }
+    // slimm.hpp:380-391
+    void apply_valid() {
         for (auto it = reads.begin(); it != reads.end(); ++it) {
             it->second.keep_only(valid_refs, ref_len);
             if (it->second.is_uniq()) {
@@ -407,6 +415,11 @@ struct Oracle {
 
     // slimm.hpp:533-611
     void lca_count() {
+        lca_direct();
+        lca_propagate();
+    }
+    // slimm.hpp:536-557
+    void lca_direct() {
         for (auto it = reads.begin(); it != reads.end(); ++it) {
             size_t len = it->second.targets.size();
             if (len > 1) {
@@ -419,7 +432,9 @@ struct Oracle {
         }
         lca_direct_count = taxon_count;
         lca_direct_children = taxon_children;
-
+    }
+    // slimm.hpp:560-610
+    void lca_propagate() {
         std::unordered_map<uint32_t, uint32_t> snapshot = taxon_count;
         uint32_t receiver = 0;
         for (auto tc : snapshot) {
@@ -721,6 +736,27 @@ int orc_run(void* h, uint32_t n_refs, const char* ref_name_blob, const uint32_t*
         phase_seconds[2] = d(t2, t3);
     }
     return 0;
+}
+
+// ---- split phases, for the multi-rank tests: a rank runs phase A on its shard, the caller sums the bins of all
+// ranks, decides the valid set from the sums, and each rank then filters its own reads against that global set.
+int orc_phase_a(void* h, uint32_t n_refs, const char* ref_name_blob, const uint32_t* ref_len, uint32_t avg_read_len,
+                uint64_t n_records, const uint64_t* read_key, const uint16_t* flag, const int32_t* ref_id,
+                const int32_t* begin_pos) {
+    Oracle* o = static_cast<Oracle*>(h);
+    o->init_refs(split_blob(ref_name_blob, n_refs), std::vector<uint32_t>(ref_len, ref_len + n_refs), avg_read_len);
+    for (uint64_t i = 0; i < n_records; ++i) o->feed(std::to_string(read_key[i]), flag[i], ref_id[i], begin_pos[i]);
+    o->finish_analyze();
+    return o->hits == 0 ? 1 : 0;
+}
+// valid[R]: the globally decided valid_ref_ids; runs slimm.hpp:380-391 and :536-557 on this shard's reads only.
+void orc_phase_b_with_valid(void* h, const uint8_t* valid) {
+    Oracle* o = static_cast<Oracle*>(h);
+    o->valid_refs.clear();
+    for (uint32_t i = 0; i < o->refs.size(); ++i)
+        if (valid[i]) o->valid_refs.insert(i);
+    o->apply_valid();
+    o->lca_direct();
 }
 
 // scalars: [hits, matches, uniq_matches, uniq_hits, uniq_matches2, reference_count, matched_ref_length,

@@ -35,7 +35,7 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
 void launch_flags(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, uint32_t* counters,
                   uint8_t* fl, uint2* tile_cnt);
 void launch_build_csr(hipStream_t st, uint32_t n_upper, const uint8_t* fl, const uint32_t* cref, const uint32_t* cgbin,
-                      const uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
+                      uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
                       uint32_t* read_off);
 void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
                  uint32_t* cov, uint32_t* ucov);

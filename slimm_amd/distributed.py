@@ -85,7 +85,7 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
         return None
     engine.filter_alignments()
     merged = merge_partials(engine, device, group)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "needs_set_partials", False):
         engine.set_partials(merged["uniq_reads_count2"], merged["lca_count"], merged["level_marks"], merged["pairs"])
     engine.get_reads_lca_count()
     write_here = path if (not dist.is_initialized() or dist.get_rank(group) == 0) else None

@@ -44,7 +44,7 @@ CONFIGS = {
 def synth_taxonomy(n_refs: int, strain_level: bool = False, hole_every: int = 0):
     """Accessions ACC000000..; lineage columns own, species, genus, family, order, class, phylum, superkingdom.
 
-    A consistent tree: ~2 refs/species, 10/genus, 50/family, 200/order, 1000/class, 2500/phylum; every fourth phylum
+    A consistent tree: ~2 refs/species, 10/genus, 50/family, 200/order, 1000/class, 2000/phylum; every fourth phylum
     is archaeal.  strain_level: 2 contigs per strain and 10 refs per species (LCA at levels 0/1 becomes frequent).
     hole_every > 0 blanks the species slot of every hole_every-th species group (quirk Q5 material).
     """
@@ -58,8 +58,8 @@ def synth_taxonomy(n_refs: int, strain_level: bool = False, hole_every: int = 0)
         200_000 + i // (sp_div * 25),
         100_000 + i // (sp_div * 100),
         50_000 + i // (sp_div * 500),
-        10_000 + i // (sp_div * 1250),
-        np.where((i // (sp_div * 1250)) % 4 == 3, 2157, 2),
+        10_000 + i // (sp_div * 1000),
+        np.where((i // (sp_div * 1000)) % 4 == 3, 2157, 2),
     ], axis=1).astype(np.uint32)
     if hole_every:
         lin[(i // sp_div) % hole_every == hole_every - 1, 1] = 0

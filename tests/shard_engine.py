@@ -1,0 +1,60 @@
+"""A stand-in engine for the multi-rank tests on CPU (no GPU in the test container).
+
+Same method names as slimm_amd.profiler.Slimm.  The per-read work of this rank's shard (phase A, phase B / C(1)) runs
+in the CPU ORACLE; everything the product does on the host (cut-offs, valid set, propagation, profile) runs in the
+product's own host-only context.  This lets world_size-2 gloo tests drive slimm_amd.distributed exactly as bench.py
+does, and check the sharding + the two exchanges.  Test infrastructure only.
+"""
+import numpy as np
+import torch
+
+from oracle.binding import Oracle
+from slimm_amd.profiler import Slimm
+from tests.helpers import partials_from_oracle
+
+
+class OracleShardEngine:
+    needs_set_partials = True  # the host-only context never saw this rank's per-read results
+
+    def __init__(self, w):
+        self.w = w
+        self.orc = Oracle(w.taxonomy, w.options)
+        self.host = Slimm.for_workload(w, device=-1)
+        self.buf = None
+
+    def analyze_alignments(self):
+        w = self.w
+        a = self.orc.phase_a(w.ref_names, w.ref_len, w.records, w.avg_read_len)
+        self.nbins = a.nbins.astype(np.int64)
+        tail = np.zeros(16, dtype=np.uint32)
+        tail[0], tail[1] = a.scalars["hits"], a.scalars["matches"]
+        self.B = int(a.cov.shape[0])
+        self.buf = torch.from_numpy(np.concatenate([a.cov, a.uniq_cov, tail]).view(np.int32).copy())
+
+    def coverage_tensor(self):
+        return self.buf
+
+    def finish_coverage(self):
+        b = self.buf.numpy().view(np.uint32)
+        cov, ucov, tail = b[:self.B], b[self.B:2 * self.B], b[2 * self.B:]
+        off = np.concatenate([[0], np.cumsum(self.nbins)])[:-1]
+        red = lambda x: np.add.reduceat(x.astype(np.uint64), off).astype(np.uint32)  # noqa: E731
+        return self.host.set_coverage_columns(red(cov), red(ucov), red(cov != 0), red(ucov != 0), int(tail[0]), int(tail[1]))
+
+    def filter_alignments(self):
+        self.host.filter_alignments()
+        valid = self.host.ref_columns()["valid"]
+        self.b = self.orc.phase_b_with_valid(valid)
+
+    def get_partials(self):
+        u2, lca, marks, pairs = partials_from_oracle(self.b, self.w.lineage(), self.host.dense_taxid)
+        return {"uniq_reads_count2": u2, "lca_count": lca, "level_marks": marks, "pairs": pairs}
+
+    def set_partials(self, *a):
+        self.host.set_partials(*a)
+
+    def get_reads_lca_count(self):
+        self.host.get_reads_lca_count()
+
+    def write_abundance(self, path=None):
+        return self.host.write_abundance(path)

@@ -1,0 +1,72 @@
+"""world_size-2 tests of the sharded driver (slimm_amd/distributed.py) over gloo on CPU.
+
+Each rank holds a shard of the reads; the result must equal the single-process oracle on the whole stream.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _split_by_read(w, world):
+    """Shards cut so that all records of a read name stay on one rank (hash of the key)."""
+    from slimm_amd.workload import Workload
+
+    owner = (w.records.read_key % np.uint64(world)).astype(np.int64)
+    out = []
+    for r in range(world):
+        idx = np.nonzero(owner == r)[0]
+        out.append(Workload(w.ref_names, w.ref_len, w.taxonomy, w.records.take(idx), w.avg_read_len, w.options,
+                            f"{w.name}-shard{r}"))
+    return out
+
+
+def _worker(rank, world, port, case, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.binding import run_workload
+        from slimm_amd.distributed import sharded_profile
+        from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
+        from tests.helpers import assert_matches_oracle
+        from tests.shard_engine import OracleShardEngine
+
+        if case == "config1":
+            w = make_workload(CONFIGS["config1"], seed=21)
+        elif case == "cross":
+            cfg = SynthConfig("x", 60_000, 10_000, 5.0, present_frac=0.3, len_lo=20_000, len_hi=60_000)
+            w = make_workload(cfg, seed=22)
+            rng = np.random.default_rng(1)
+            m = (w.records.ref_id >= 0) & (rng.random(len(w.records)) < 0.2)
+            w.records.ref_id[m] = rng.integers(0, cfg.n_refs, size=int(m.sum()), dtype=np.int32)
+            w.records.begin_pos[m] = 100
+        else:
+            w = make_workload(CONFIGS["config2"], seed=23, n_records=150_000)
+        shard = _split_by_read(w, world)[rank]
+        eng = OracleShardEngine(shard)
+        text = sharded_profile(eng, None, os.path.join(tmp, "profile.tsv"))
+        whole = run_workload(w, use_qnames=False, collect_bins=False)
+        assert text is not None
+        assert_matches_oracle(eng.host, whole, bins=False)
+        if rank == 0:
+            assert open(os.path.join(tmp, "profile.tsv")).read() == text
+        if case == "cross":
+            assert len(eng.get_partials()["pairs"]) > 0
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["config1", "config2", "cross"])
+def test_two_ranks_equal_single_process(case):
+    port = 29500 + (os.getpid() % 2000) + {"config1": 0, "config2": 1, "cross": 2}[case]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, port, case, tmp), nprocs=2, join=True)

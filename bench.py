@@ -46,7 +46,11 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "k_compact": 18 * N + 16 * V,                 # read every record once, write ident/ref/gbin
         "k_flags": 12 * V + 1 * V,                    # ident + ref in, flag byte out (look-back hits cache)
         "k_build_csr": 9 * V + 8 * P + 4 * M,         # flag + ref + gbin in; targets + read offsets out
-        "k_hist": 8 * P + 8 * P + 8 * U,              # targets in; one 4-byte RMW on cov per target, on uniq_cov per unique
+        "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
+        "k_tile_count": 4 * P,                        # gbin in
+        "k_tile_scan": 12 * (B // 8192 + 1),
+        "k_tile_scatter": 8 * P + 2 * P,              # gbin + ref in, 16-bit bucket entries out
+        "k_tile_hist": 2 * P + 8 * B,                 # bucket in, finished cov + uniq_cov tiles out (replaces the zero-fill)
         "k_ref_stats": 8 * B,                         # one streaming read of cov and uniq_cov
         "k_filter_lca": 4 * M + 8 * P + 8 * U2,       # offsets + targets in; one RMW on uniq_cov2 per post-filter unique
         "k_ref_stats2": 4 * B,

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -63,10 +64,11 @@ struct PinBuf {
 
 enum KernelId {
     K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FLAGS, K_BUILD_CSR, K_HIST, K_REF_STATS, K_FILTER_LCA,
-    K_REF_STATS2, K_COUNT
+    K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_COUNT
 };
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
-                                     "k_flags", "k_build_csr", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2"};
+                                     "k_flags", "k_build_csr", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
+                                     "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist"};
 
 constexpr uint32_t kTailWords = 64;
 
@@ -99,6 +101,10 @@ struct slimm_ctx {
     DevBuf<uint8_t> c_fl;
     DevBuf<uint32_t> tgt_ref, tgt_gbin, read_off;
     DevBuf<uint2> tile_cnt;
+    DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
+    DevBuf<uint32_t> tile_count, tile_base, tile_cursor;
+    uint32_t ntiles = 0;
+    bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
     DevBuf<uint32_t> counters;   // CNT_WORDS
     DevBuf<uint32_t> ref_stats;  // [R*4] then [R*4]
@@ -200,6 +206,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->read_off.ensure(static_cast<size_t>(n) + 2));
     HIP_TRY(c, c->tile_cnt.ensure(nt));
+    if (c->use_tiles) HIP_TRY(c, c->bucket.ensure(n + 1));
     if (c->order == SLIMM_ORDER_ANY) {
         HIP_TRY(c, c->s_ident.ensure(n + 1));
         HIP_TRY(c, c->s_ref.ensure(n + 1));
@@ -277,7 +284,8 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         if (off >= 0xfffffff0ull) return fail(nullptr, SLIMM_E_INVALID, "more than 2^32 coverage bins; use a larger bin width");
     }
     c->bin_off_h[c->R] = static_cast<uint32_t>(off);
-    c->Bp = (off + 63) & ~63ull;
+    c->Bp = (off + kTileBins - 1) & ~static_cast<uint64_t>(kTileBins - 1);
+    c->ntiles = static_cast<uint32_t>(c->Bp >> kTileShift);
 
     if (c->device >= 0) {
         slimm_ctx* cc = c.get();
@@ -311,6 +319,13 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(hipMemcpy(cc->d_lin_dense.p, c->host->lineage_dense().data(), static_cast<size_t>(c->R) * 32,
                            hipMemcpyHostToDevice));
 #undef HIP_TRY0
+        const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
+        cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles) == 0;
+        if (cc->use_tiles) {
+            if (cc->tile_count.ensure(c->ntiles + 1) != hipSuccess || cc->tile_base.ensure(c->ntiles + 1) != hipSuccess ||
+                cc->tile_cursor.ensure(c->ntiles + 1) != hipSuccess)
+                return fail(nullptr, SLIMM_E_HIP, "out of device memory for tile tables");
+        }
         uint32_t cap = 1u << 16;
         while (cap < 8ull * c->R && cap < (1u << 30)) cap <<= 1;
         int rc = ensure_pair_table(cc, cap);
@@ -446,7 +461,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     hipStream_t st = c->stream;
     {
         KernelTimer t(c, K_MEMSET);
-        HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (2 * c->Bp + kTailWords) * sizeof(uint32_t), st));
+        if (c->use_tiles)  // the tile kernel writes every cov / uniq_cov word itself
+            HIP_TRY(c, hipMemsetAsync(c->tail(), 0, kTailWords * sizeof(uint32_t), st));
+        else
+            HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (2 * c->Bp + kTailWords) * sizeof(uint32_t), st));
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_WORDS * sizeof(uint32_t), st));
     }
     const uint32_t nt = num_tiles(n);
@@ -482,7 +500,26 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         launch_build_csr(st, n, c->c_fl.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tile_cnt.p, c->tgt_ref.p,
                          c->tgt_gbin.p, c->read_off.p);
     }
-    {
+    if (c->use_tiles) {
+        const uint32_t grid = 512;  // two persistent workgroups per CU
+        {
+            KernelTimer t(c, K_TILE_COUNT);
+            launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, c->tile_count.p);
+        }
+        {
+            KernelTimer t(c, K_TILE_SCAN);
+            launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p);
+        }
+        {
+            KernelTimer t(c, K_TILE_SCATTER);
+            launch_tile_scatter(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->tile_base.p,
+                                c->tile_cursor.p, c->bucket.p);
+        }
+        {
+            KernelTimer t(c, K_TILE_HIST);
+            launch_tile_hist(st, c->ntiles, c->bucket.p, c->tile_base.p, c->cov(), c->ucov());
+        }
+    } else {
         KernelTimer t(c, K_HIST);
         launch_hist(st, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->cov(), c->ucov());
     }

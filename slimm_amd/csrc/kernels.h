@@ -47,6 +47,20 @@ void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_of
                        uint32_t pair_mask);
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
 
+// ---- LDS-privatised coverage histograms (tile_hist.hip) ----
+constexpr uint32_t kTileShift = 13;
+constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 32 KiB of LDS in k_tile_hist
+constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
+int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_gbin, const uint32_t* counters,
+                       uint32_t* tile_count);
+void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
+                      uint32_t* tile_cursor);
+void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* tgt_gbin,
+                         const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint16_t* bucket);
+void launch_tile_hist(hipStream_t st, uint32_t ntiles, const uint16_t* bucket, const uint32_t* tile_base, uint32_t* cov,
+                      uint32_t* ucov);
+
 // Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and
 // n_upper bounds it for the launch geometry.  hist must hold 256 * (num_tiles(n_upper) + 1) uint32.

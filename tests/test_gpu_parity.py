@@ -166,6 +166,13 @@ def test_many_cross_superkingdom_reads_use_the_pair_set():
     assert s.get_partials()["pairs"].shape[0] > 100
 
 
+def test_direct_atomic_fallback_path(monkeypatch):
+    """The global-atomic histogram (used when there are too many bin tiles for LDS) must agree too."""
+    monkeypatch.setenv("SLIMM_DIRECT_ATOMICS", "1")
+    check(make_workload(CONFIGS["config2"], seed=15, n_records=200_000))
+    check(make_workload(CONFIGS["config1"], seed=16))
+
+
 def test_batched_push_equals_single_push():
     w = make_workload(CONFIGS["config1"], seed=11)
     a = run_gpu(w)

@@ -103,6 +103,7 @@ struct slimm_ctx {
     DevBuf<uint2> tile_cnt;
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor;
+    DevBuf<uint4> tile_items;
     uint32_t ntiles = 0;
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
@@ -206,7 +207,10 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->read_off.ensure(static_cast<size_t>(n) + 2));
     HIP_TRY(c, c->tile_cnt.ensure(nt));
-    if (c->use_tiles) HIP_TRY(c, c->bucket.ensure(n + 1));
+    if (c->use_tiles) {
+        HIP_TRY(c, c->bucket.ensure(n + 1));
+        HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles, n) + 1));
+    }
     if (c->order == SLIMM_ORDER_ANY) {
         HIP_TRY(c, c->s_ident.ensure(n + 1));
         HIP_TRY(c, c->s_ref.ensure(n + 1));
@@ -508,7 +512,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_TILE_SCAN);
-            launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p);
+            launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                             c->counters.p);
         }
         {
             KernelTimer t(c, K_TILE_SCATTER);
@@ -517,7 +522,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_TILE_HIST);
-            launch_tile_hist(st, c->ntiles, c->bucket.p, c->tile_base.p, c->cov(), c->ucov());
+            launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
+                             c->ucov());
         }
     } else {
         KernelTimer t(c, K_HIST);

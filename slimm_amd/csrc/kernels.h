@@ -12,6 +12,7 @@ enum {
     CNT_P = 2,      // distinct (read, ref) pairs = targets
     CNT_ERR = 3,    // ERR_* bits
     CNT_PAIRS = 4,  // entries of the no-level-agrees (taxon, ref) set
+    CNT_ITEMS = 5,  // work items of k_tile_hist
     CNT_WORDS = 32
 };
 enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4 };
@@ -54,12 +55,14 @@ constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile
 int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_gbin, const uint32_t* counters,
                        uint32_t* tile_count);
+constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
+uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
-                      uint32_t* tile_cursor);
+                      uint32_t* tile_cursor, uint4* items, uint32_t* counters);
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* tgt_gbin,
                          const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint16_t* bucket);
-void launch_tile_hist(hipStream_t st, uint32_t ntiles, const uint16_t* bucket, const uint32_t* tile_base, uint32_t* cov,
-                      uint32_t* ucov);
+void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
+                      const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov);
 
 // Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and

@@ -21,13 +21,13 @@
 
 namespace slimm {
 
-constexpr int kTBlock = 256;
+constexpr int kTBlock = 512;
 constexpr uint32_t kTileMask = kTileBins - 1;
 
-// slice of the targets owned by workgroup b of g: [lo, hi), 256-aligned so loads stay coalesced
+// slice of the targets owned by workgroup b of g: [lo, hi), 2048-aligned so the unrolled loads stay coalesced
 __device__ __forceinline__ void slice_of(uint32_t P, uint32_t b, uint32_t g, uint32_t& lo, uint32_t& hi) {
     uint32_t chunk = (P + g - 1) / g;
-    chunk = (chunk + 255u) & ~255u;
+    chunk = (chunk + 2047u) & ~2047u;
     uint64_t l = static_cast<uint64_t>(b) * chunk;
     uint64_t h = l + chunk;
     lo = l < P ? static_cast<uint32_t>(l) : P;
@@ -43,7 +43,17 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
     __syncthreads();
     uint32_t lo, hi;
     slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += kTBlock) atomicAdd(&s_hist[tgt_gbin[t] >> kTileShift], 1u);
+    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
+        uint32_t g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t t = t0 + u * kTBlock + threadIdx.x;
+            g[u] = (t < hi) ? tgt_gbin[t] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g[u] != 0xffffffffu) atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
         uint32_t h = s_hist[i];
@@ -51,31 +61,50 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
     }
 }
 
-// exclusive scan of tile_count[0..ntiles) -> tile_base[0..ntiles], tile_base[ntiles] = total; zeroes tile_cursor
+// One workgroup: exclusive scan tile_count -> tile_base (tile_base[ntiles] = total), zero tile_cursor, and cut every
+// tile's bucket into work items of at most kTileSub entries for k_tile_hist: items[k] = {tile, lo, hi, pieces of tile}.
+// A tile with no entry still gets one item (its finished tile is all zeros and has to be written).
 __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
-                                                    uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor) {
-    __shared__ uint32_t s_part[1024];
+                                                    uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
+                                                    uint4* __restrict__ items, uint32_t* __restrict__ counters) {
+    __shared__ uint2 s_part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (ntiles + 1023) / 1024;
     const uint32_t lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
-    uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += tile_count[i];
+    uint2 sum = make_uint2(0u, 0u);
+    for (uint32_t i = lo; i < hi; ++i) {
+        uint32_t c = tile_count[i];
+        sum.x += c;
+        sum.y += c ? (c + kTileSub - 1) / kTileSub : 1u;
+    }
     s_part[tid] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t add = (tid >= off) ? s_part[tid - off] : 0u;
+        uint2 add = make_uint2(0u, 0u);
+        if (tid >= off) add = s_part[tid - off];
         __syncthreads();
-        s_part[tid] += add;
+        s_part[tid].x += add.x;
+        s_part[tid].y += add.y;
         __syncthreads();
     }
-    uint32_t run = s_part[tid] - sum;
+    uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
     for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t v = tile_count[i];
-        tile_base[i] = run;
+        uint32_t c = tile_count[i];
+        uint32_t pieces = c ? (c + kTileSub - 1) / kTileSub : 1u;
+        tile_base[i] = run.x;
         tile_cursor[i] = 0;
-        run += v;
+        for (uint32_t k = 0; k < pieces; ++k) {
+            uint32_t a = run.x + k * kTileSub;
+            uint32_t b = min(a + kTileSub, run.x + c);
+            items[run.y + k] = make_uint4(i, a, b, pieces);
+        }
+        run.x += c;
+        run.y += pieces;
     }
-    if (tid == 1023) tile_base[ntiles] = s_part[1023];
+    if (tid == 1023) {
+        tile_base[ntiles] = s_part[1023].x;
+        counters[CNT_ITEMS] = s_part[1023].y;
+    }
 }
 
 __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ tgt_ref,
@@ -90,7 +119,17 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
     __syncthreads();
     uint32_t lo, hi;
     slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += kTBlock) atomicAdd(&s_hist[tgt_gbin[t] >> kTileShift], 1u);
+    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
+        uint32_t g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t t = t0 + u * kTBlock + threadIdx.x;
+            g[u] = (t < hi) ? tgt_gbin[t] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g[u] != 0xffffffffu) atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+    }
     __syncthreads();
     // reserve [base, base + h) of each non-empty tile's bucket for this workgroup; s_hist becomes the write cursor
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
@@ -98,40 +137,91 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
         if (h) s_hist[i] = tile_base[i] + atomicAdd(&tile_cursor[i], h);
     }
     __syncthreads();
-    for (uint32_t t = lo + threadIdx.x; t < hi; t += kTBlock) {
-        uint32_t g = tgt_gbin[t];
-        bool start = tgt_ref[t] >> 31;
-        bool next_start = (t + 1 == P) || (tgt_ref[t + 1] >> 31);
-        uint32_t pos = atomicAdd(&s_hist[g >> kTileShift], 1u);
-        bucket[pos] = static_cast<uint16_t>((g & kTileMask) | ((start && next_start) ? kTileBins : 0u));
+    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
+        uint32_t g[4], r0[4], r1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t t = t0 + u * kTBlock + threadIdx.x;
+            bool live = t < hi;
+            g[u] = live ? tgt_gbin[t] : 0xffffffffu;
+            r0[u] = live ? tgt_ref[t] : 0u;
+            r1[u] = (live && t + 1 < P) ? tgt_ref[t + 1] : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (g[u] == 0xffffffffu) continue;
+            bool uniq = (r0[u] >> 31) && (r1[u] >> 31);  // first target of its read and the next target starts a read
+            uint32_t pos = atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+            bucket[pos] = static_cast<uint16_t>((g[u] & kTileMask) | (uniq ? kTileBins : 0u));
+        }
     }
 }
 
-__global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ bucket,
-                                                   const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ cov,
+// tiles cut into several work items are accumulated with (contiguous) global atomics, so they start from zero
+__global__ __launch_bounds__(256) void k_tile_zero_split(const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ cov,
+                                                         uint32_t* __restrict__ ucov) {
+    const uint32_t tile = blockIdx.x;
+    if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) return;
+    uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
+    uint4* ou = reinterpret_cast<uint4*>(ucov + static_cast<size_t>(tile) * kTileBins);
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 256) {
+        oc[i] = z;
+        ou[i] = z;
+    }
+}
+
+__global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
+                                                   const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov) {
     __shared__ uint32_t s_cov[kTileBins];
     __shared__ uint32_t s_ucov[kTileBins];
-    const uint32_t tile = blockIdx.x;
-    for (uint32_t i = threadIdx.x; i < kTileBins; i += 512) {
-        s_cov[i] = 0;
-        s_ucov[i] = 0;
+    if (blockIdx.x >= counters[CNT_ITEMS]) return;
+    const uint4 it = items[blockIdx.x];
+    const uint32_t tile = it.x, lo = it.y, hi = it.z;
+    const bool whole = it.w == 1;
+    {
+        uint4* zc = reinterpret_cast<uint4*>(s_cov);
+        uint4* zu = reinterpret_cast<uint4*>(s_ucov);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+            zc[i] = z;
+            zu[i] = z;
+        }
     }
     __syncthreads();
-    const uint32_t lo = tile_base[tile], hi = tile_base[tile + 1];
-    for (uint32_t e = lo + threadIdx.x; e < hi; e += 512) {
-        uint32_t v = bucket[e];
-        atomicAdd(&s_cov[v & kTileMask], 1u);
-        if (v & kTileBins) atomicAdd(&s_ucov[v & kTileMask], 1u);
+    for (uint32_t e0 = lo; e0 < hi; e0 += 4 * 512) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t e = e0 + u * 512 + threadIdx.x;
+            v[u] = (e < hi) ? bucket[e] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (v[u] == 0xffffffffu) continue;
+            atomicAdd(&s_cov[v[u] & kTileMask], 1u);
+            if (v[u] & kTileBins) atomicAdd(&s_ucov[v[u] & kTileMask], 1u);
+        }
     }
     __syncthreads();
-    uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
-    uint4* ou = reinterpret_cast<uint4*>(ucov + static_cast<size_t>(tile) * kTileBins);
-    const uint4* sc = reinterpret_cast<const uint4*>(s_cov);
-    const uint4* su = reinterpret_cast<const uint4*>(s_ucov);
-    for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
-        oc[i] = sc[i];
-        ou[i] = su[i];
+    uint32_t* gc = cov + static_cast<size_t>(tile) * kTileBins;
+    uint32_t* gu = ucov + static_cast<size_t>(tile) * kTileBins;
+    if (whole) {
+        uint4* oc = reinterpret_cast<uint4*>(gc);
+        uint4* ou = reinterpret_cast<uint4*>(gu);
+        const uint4* sc = reinterpret_cast<const uint4*>(s_cov);
+        const uint4* su = reinterpret_cast<const uint4*>(s_ucov);
+        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+            oc[i] = sc[i];
+            ou[i] = su[i];
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < kTileBins; i += 512) {
+            uint32_t a = s_cov[i], b = s_ucov[i];
+            if (a) atomicAdd(&gc[i], a);
+            if (b) atomicAdd(&gu[i], b);
+        }
     }
 }
 
@@ -156,8 +246,8 @@ void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uin
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
-                      uint32_t* tile_cursor) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor);
+                      uint32_t* tile_cursor, uint4* items, uint32_t* counters) {
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters);
 }
 
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* tgt_gbin,
@@ -166,9 +256,13 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const u
                        counters, ntiles, tile_base, tile_cursor, bucket);
 }
 
-void launch_tile_hist(hipStream_t st, uint32_t ntiles, const uint16_t* bucket, const uint32_t* tile_base, uint32_t* cov,
-                      uint32_t* ucov) {
-    hipLaunchKernelGGL(k_tile_hist, dim3(ntiles), dim3(512), 0, st, bucket, tile_base, cov, ucov);
+uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }
+
+void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
+                      const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov) {
+    hipLaunchKernelGGL(k_tile_zero_split, dim3(ntiles), dim3(256), 0, st, tile_base, cov, ucov);
+    hipLaunchKernelGGL(k_tile_hist, dim3(tile_items_upper(ntiles, n_upper)), dim3(512), 0, st, bucket, items, counters, cov,
+                       ucov);
 }
 
 }  // namespace slimm

@@ -42,10 +42,10 @@ def algorithmic_bytes(st, n_records, Bp_words):
     return {
         "memset_bins": 4 * 3 * B,
         "k_scan_tiles": 2 * 8 * (N // 2048 + 1),      # per-tile counts in and out
-        "k_valid_count": 6 * N,                       # flag u16 + ref i32
-        "k_compact": 18 * N + 16 * V,                 # read every record once, write ident/ref/gbin
-        "k_flags": 12 * V + 1 * V,                    # ident + ref in, flag byte out (look-back hits cache)
-        "k_build_csr": 9 * V + 8 * P + 4 * M,         # flag + ref + gbin in; targets + read offsets out
+        "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
+        "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
+        "k_runs": 14 * N + 1 * N,                     # key + ref + flag in (look-back is an LDS walk), flag byte out
+        "k_emit": 1 * N + 8 * P + 8 * P + 4 * M,      # flag byte in; ref + pos of the firsts in; targets + read offsets out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
         "k_tile_count": 4 * P,                        # gbin in
         "k_tile_scan": 12 * (B // 8192 + 1),
@@ -107,11 +107,13 @@ def main():
     torch.cuda.synchronize()
     out_path = os.path.join(tempfile.gettempdir(), f"slimm_bench_profile_{os.getpid()}.tsv")
 
+    phase_times = {} if args.breakdown else None
+
     def step():
         eng.reset()
         eng.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
         eng.set_records_device(key, ref, pos, flag)
-        return sharded_profile(eng, dev, out_path)
+        return sharded_profile(eng, dev, out_path, phase_times=phase_times)
 
     def barrier():
         if world > 1:
@@ -122,6 +124,8 @@ def main():
         step()
     eng.enable_kernel_timing(True)
     eng.kernel_times(reset=True)
+    if phase_times is not None:
+        phase_times.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -170,6 +174,8 @@ def main():
                       f"{v['bytes_per_launch']/1e6:9.1f} MB  {gbs:8.1f} GB/s  {gbs/HBM_PEAK_GBS*100:5.1f}% of HBM peak",
                       file=sys.stderr)
             print(f"# device kernels {kernel_ms:.3f} ms of {ms_per_step:.3f} ms per step", file=sys.stderr)
+            for k, v in phase_times.items():
+                print(f"# host wall {k:28s} {v / args.steps * 1e6:9.1f} us/step", file=sys.stderr)
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

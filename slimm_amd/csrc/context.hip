@@ -67,7 +67,7 @@ enum KernelId {
     K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_COUNT
 };
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
-                                     "k_flags", "k_build_csr", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
+                                     "k_runs", "k_emit", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist"};
 
 constexpr uint32_t kTailWords = 64;
@@ -199,9 +199,6 @@ void drain_events(slimm_ctx* c) {
 
 int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     const uint32_t nt = num_tiles(n) + 2;
-    HIP_TRY(c, c->c_ident.ensure(n + 1));
-    HIP_TRY(c, c->c_ref.ensure(n + 1));
-    HIP_TRY(c, c->c_gbin.ensure(n + 1));
     HIP_TRY(c, c->c_fl.ensure(n + 1));
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
@@ -212,6 +209,9 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
         HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles, n) + 1));
     }
     if (c->order == SLIMM_ORDER_ANY) {
+        HIP_TRY(c, c->c_ident.ensure(n + 1));
+        HIP_TRY(c, c->c_ref.ensure(n + 1));
+        HIP_TRY(c, c->c_gbin.ensure(n + 1));
         HIP_TRY(c, c->s_ident.ensure(n + 1));
         HIP_TRY(c, c->s_ref.ensure(n + 1));
         HIP_TRY(c, c->s_gbin.ensure(n + 1));
@@ -248,7 +248,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     if (!cfg || !out) return fail(nullptr, SLIMM_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->n_refs == 0 || !cfg->ref_len || !cfg->lineage) return fail(nullptr, SLIMM_E_INVALID, "no references");
-    if (cfg->n_refs >= 0x7fffffffu) return fail(nullptr, SLIMM_E_INVALID, "too many references");
+    if (cfg->n_refs >= (1u << 28)) return fail(nullptr, SLIMM_E_INVALID, "too many references (limit 2^28)");
     if (cfg->bin_width == 0 && cfg->avg_read_len == 0)
         return fail(nullptr, SLIMM_E_INVALID, "bin_width and avg_read_len are both 0 (the reference divides by zero)");
     HostConfig hc;
@@ -473,36 +473,56 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     }
     const uint32_t nt = num_tiles(n);
     const HostConfig& hc = c->host->config();
-    {
-        KernelTimer t(c, K_VALID_COUNT);
-        launch_valid_count(st, c->rec, c->R, c->tile_cnt.p, c->counters.p);
-    }
-    {
-        KernelTimer t(c, K_SCAN);
-        launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_V, -1, nullptr);
-    }
-    {
-        KernelTimer t(c, K_COMPACT);
-        launch_compact(st, c->rec, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, hc.avg_read_len / 2, hc.bin_width,
-                       c->c_ident.p, c->c_ref.p, c->c_gbin.p);
-    }
+    const uint32_t half_read = hc.avg_read_len / 2;
     if (c->order == SLIMM_ORDER_ANY) {
-        KernelTimer t(c, K_SORT);
-        launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
-                             c->s_gbin.p, c->sort_hist.p);
-    }
-    {
-        KernelTimer t(c, K_FLAGS);
-        launch_flags(st, n, c->c_ident.p, c->c_ref.p, c->counters.p, c->c_fl.p, c->tile_cnt.p);
-    }
-    {
-        KernelTimer t(c, K_SCAN);
-        launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p);
-    }
-    {
-        KernelTimer t(c, K_BUILD_CSR);
-        launch_build_csr(st, n, c->c_fl.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tile_cnt.p, c->tgt_ref.p,
-                         c->tgt_gbin.p, c->read_off.p);
+        // compaction of the mapped records, then a stable sort by read identity makes every read a contiguous run
+        {
+            KernelTimer t(c, K_VALID_COUNT);
+            launch_valid_count(st, c->rec, c->R, c->tile_cnt.p, c->counters.p);
+        }
+        {
+            KernelTimer t(c, K_SCAN);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_V, -1, nullptr);
+        }
+        {
+            KernelTimer t(c, K_COMPACT);
+            launch_compact(st, c->rec, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width,
+                           c->c_ident.p, c->c_ref.p, c->c_gbin.p);
+        }
+        {
+            KernelTimer t(c, K_SORT);
+            launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
+                                 c->s_gbin.p, c->sort_hist.p);
+        }
+        {
+            KernelTimer t(c, K_FLAGS);
+            launch_runs_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->c_fl.p, c->tile_cnt.p);
+        }
+        {
+            KernelTimer t(c, K_SCAN);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p);
+        }
+        {
+            KernelTimer t(c, K_BUILD_CSR);
+            launch_emit_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->c_fl.p, c->counters.p, c->tile_cnt.p,
+                               c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p);
+        }
+    } else {
+        // grouped input: classify and emit straight from the caller's record arrays
+        {
+            KernelTimer t(c, K_FLAGS);
+            launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
+                            c->c_fl.p, c->tile_cnt.p);
+        }
+        {
+            KernelTimer t(c, K_SCAN);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p);
+        }
+        {
+            KernelTimer t(c, K_BUILD_CSR);
+            launch_emit_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->c_fl.p,
+                            c->counters.p, c->tile_cnt.p, c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p);
+        }
     }
     if (c->use_tiles) {
         const uint32_t grid = 512;  // two persistent workgroups per CU

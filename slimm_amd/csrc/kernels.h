@@ -33,11 +33,18 @@ void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
-void launch_flags(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, uint32_t* counters,
-                  uint8_t* fl, uint2* tile_cnt);
-void launch_build_csr(hipStream_t st, uint32_t n_upper, const uint8_t* fl, const uint32_t* cref, const uint32_t* cgbin,
-                      uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
-                      uint32_t* read_off);
+// runs.hip: record classification + CSR emission, on the raw records (grouped input) or on the sorted compact stream
+void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
+                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
+                     uint2* tile_cnt);
+void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
+                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, const uint8_t* fl, uint32_t* counters,
+                     const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off);
+void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
+                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt);
+void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
+                        const uint8_t* fl, uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
+                        uint32_t* read_off);
 void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
                  uint32_t* cov, uint32_t* ucov);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,

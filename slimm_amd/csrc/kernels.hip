@@ -9,9 +9,10 @@
 //   bins      cov[Bp] | uniq_cov[Bp] | tail[64] | uniq_cov2[Bp]    (u32; each reference padded to a multiple of 4 bins)
 //
 // Reference semantics implemented here:
-//   a3  record filter + bin + read identity      src/slimm.hpp:194-213        k_valid_count, k_compact
-//   a4  first bin per distinct (read, ref)       src/read_stat.hpp:116-135    k_flags, k_build_csr
-//   a5  cov / uniq_cov histograms                src/slimm.hpp:219-257        k_hist
+//   a3  record filter + bin + read identity      src/slimm.hpp:194-213        k_runs / k_emit on the raw records;
+//                                                                              k_valid_count, k_compact feed the sort path
+//   a4  first bin per distinct (read, ref)       src/read_stat.hpp:116-135    k_runs, k_emit (runs.hip)
+//   a5  cov / uniq_cov histograms                src/slimm.hpp:219-257        tile_hist.hip (k_hist = fallback)
 //   a7  non-zero bin counts (+ per-ref sums)     src/reference_contig.hpp:84-91   k_ref_stats
 //   a10 per-read filter, uniq_cov2               src/slimm.hpp:380-391, read_stat.hpp:98-114   k_filter_lca
 //   a11 level-scan LCA                           src/slimm.hpp:516-531        k_filter_lca
@@ -27,7 +28,6 @@ constexpr int kBlock = 256;
 constexpr int kItems = 8;
 constexpr int kTile = kBlock * kItems;  // records per workgroup
 constexpr int kWaves = kBlock / 64;
-constexpr uint32_t kLookBackMax = 4096;  // longest supported run of records of one read (SLIMM_E_RUN_LENGTH above it)
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -177,167 +177,6 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
         }
         running += total;
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_flags: classify every mapped record inside its qName run (contiguous records with the same key).
-//   head  = first record of its read.  A read is qName + mate number (src/slimm.hpp:204-208), and a mapper interleaves
-//           the records of the two mates of a pair, so one qName run can hold up to three reads (mate 0, 1, 2).
-//   first = first record of its (read, ref) pair.  Only `first` records become targets: the reference's add_target()
-//           pushes a repeated pair's bin into a by-value copy, so the bin of the FIRST record in file order counts (Q1).
-// Flag byte: bit0 head | bit1 first | bits2-3 mate | bit4 first record of the qName run | bit5 an earlier record of the
-// run has a larger mate number (k_build_csr then has to look at the run to order reads by mate).
-// Look-back walks a handful of neighbouring records (cache resident); runs longer than kLookBackMax are rejected.
-// ---------------------------------------------------------------------------------------------------------
-enum { FL_HEAD = 1, FL_FIRST = 2, FL_MATE_SHIFT = 2, FL_RUN_START = 16, FL_GREATER_BEFORE = 32 };
-
-__global__ __launch_bounds__(kBlock) void k_flags(const uint64_t* __restrict__ ident, const uint32_t* __restrict__ cref,
-                                                  uint32_t* __restrict__ counters, uint8_t* __restrict__ fl,
-                                                  uint2* __restrict__ tile_cnt) {
-    __shared__ uint2 s_w[kWaves];
-    const uint32_t V = counters[CNT_V];
-    const uint32_t base = blockIdx.x * kTile;
-    uint32_t nh = 0, nf = 0;
-    bool too_long = false;
-    if (base < V) {
-#pragma unroll 2
-        for (int k = 0; k < kItems; ++k) {
-            uint32_t i = base + k * kBlock + threadIdx.x;
-            if (i < V) {
-                const uint64_t id = ident[i];
-                const uint64_t key = id >> 2;
-                const uint32_t mate = static_cast<uint32_t>(id) & 3u;
-                const uint32_t r = cref[i];
-                bool head = true, first = true, greater_before = false;
-                const bool run_start = (i == 0) || ((ident[i - 1] >> 2) != key);
-                if (!run_start) {
-                    uint32_t j = i - 1, steps = 0;
-                    while (true) {
-                        const uint64_t idj = ident[j];
-                        if ((idj >> 2) != key) break;
-                        if (idj == id) {
-                            head = false;
-                            if (cref[j] == r) {
-                                first = false;
-                                break;
-                            }
-                        } else if ((static_cast<uint32_t>(idj) & 3u) > mate) {
-                            greater_before = true;
-                        }
-                        if (j == 0) break;
-                        --j;
-                        if (++steps > kLookBackMax) {
-                            too_long = true;
-                            break;
-                        }
-                    }
-                }
-                fl[i] = static_cast<uint8_t>((head ? FL_HEAD : 0) | (first ? FL_FIRST : 0) | (mate << FL_MATE_SHIFT) |
-                                             (run_start ? FL_RUN_START : 0) | (greater_before ? FL_GREATER_BEFORE : 0));
-                nh += head;
-                nf += first;
-            }
-        }
-    }
-    nh = wave_sum(nh);
-    nf = wave_sum(nf);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = make_uint2(nh, nf);
-    if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_RUN_LENGTH);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint2 t = make_uint2(0u, 0u);
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            t.x += s_w[w].x;
-            t.y += s_w[w].y;
-        }
-        tile_cnt[blockIdx.x] = t;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_build_csr: scatter `first` records into the target arrays and `head` records into read_off, so that the targets
-// of one read are contiguous and in file order.  Inside a qName run the reads are laid out by ascending mate number;
-// when mates interleave in the file (bit5, or a non-zero mate with smaller mates after it) the scan position of a
-// record is corrected by the number of out-of-order heads / firsts around it in its run.
-// ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kRunWalkMax = 1u << 20;
-
-__global__ __launch_bounds__(kBlock) void k_build_csr(const uint8_t* __restrict__ fl, const uint32_t* __restrict__ cref,
-                                                      const uint32_t* __restrict__ cgbin,
-                                                      uint32_t* __restrict__ counters,
-                                                      const uint2* __restrict__ tile_off, uint32_t* __restrict__ tgt_ref,
-                                                      uint32_t* __restrict__ tgt_gbin, uint32_t* __restrict__ read_off) {
-    __shared__ uint2 s_w[2][kWaves];
-    const uint32_t V = counters[CNT_V];
-    const uint32_t base = blockIdx.x * kTile;
-    if (base >= V) return;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint2 running = tile_off[blockIdx.x];
-    bool too_long = false;
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        uint32_t i = base + k * kBlock + threadIdx.x;
-        uint32_t f = (i < V) ? fl[i] : 0u;
-        bool head = f & FL_HEAD, first = f & FL_FIRST;
-        uint64_t mh = __ballot(head), mf = __ballot(first);
-        uint32_t rh = mask_rank(mh), rf = mask_rank(mf);
-        if ((threadIdx.x & 63) == 0) s_w[k & 1][wave] = make_uint2(__popcll(mh), __popcll(mf));
-        __syncthreads();
-        uint2 before = make_uint2(0u, 0u), total = make_uint2(0u, 0u);
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            uint2 c = s_w[k & 1][w];
-            if (w < static_cast<int>(wave)) {
-                before.x += c.x;
-                before.y += c.y;
-            }
-            total.x += c.x;
-            total.y += c.y;
-        }
-        if (first) {
-            const uint32_t mate = (f >> FL_MATE_SHIFT) & 3u;
-            uint32_t t = running.y + before.y + rf;
-            uint32_t m = running.x + before.x + rh;
-            if ((f & FL_GREATER_BEFORE) && !(f & FL_RUN_START)) {  // earlier records of the run with a larger mate
-                uint32_t j = i, steps = 0;
-                do {
-                    --j;
-                    uint32_t g = fl[j];
-                    if (((g >> FL_MATE_SHIFT) & 3u) > mate) {
-                        t -= (g & FL_FIRST) ? 1u : 0u;
-                        m -= (g & FL_HEAD) ? 1u : 0u;
-                    }
-                    if (g & FL_RUN_START) break;
-                    if (++steps > kRunWalkMax) {
-                        too_long = true;
-                        break;
-                    }
-                } while (j > 0);
-            }
-            if (mate > 0) {  // later records of the run with a smaller mate
-                uint32_t steps = 0;
-                for (uint32_t j = i + 1; j < V; ++j) {
-                    uint32_t g = fl[j];
-                    if (g & FL_RUN_START) break;
-                    if (((g >> FL_MATE_SHIFT) & 3u) < mate) {
-                        t += (g & FL_FIRST) ? 1u : 0u;
-                        m += (g & FL_HEAD) ? 1u : 0u;
-                    }
-                    if (++steps > kRunWalkMax) {
-                        too_long = true;
-                        break;
-                    }
-                }
-            }
-            tgt_ref[t] = cref[i] | (head ? 0x80000000u : 0u);
-            tgt_gbin[t] = cgbin[i];
-            if (head) read_off[m] = t;
-        }
-        running.x += total.x;
-        running.y += total.y;
-    }
-    if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_RUN_LENGTH);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -525,21 +364,6 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
     if (nt)
         hipLaunchKernelGGL(k_compact, dim3(nt), dim3(kBlock), 0, st, in.key, in.ref, in.pos, in.flag, in.n, n_refs, tile_off,
                            ref_len, bin_off, half_read, bin_width, ident, cref, cgbin);
-}
-
-void launch_flags(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, uint32_t* counters,
-                  uint8_t* fl, uint2* tile_cnt) {
-    uint32_t nt = tiles_for(n_upper);
-    if (nt) hipLaunchKernelGGL(k_flags, dim3(nt), dim3(kBlock), 0, st, ident, cref, counters, fl, tile_cnt);
-}
-
-void launch_build_csr(hipStream_t st, uint32_t n_upper, const uint8_t* fl, const uint32_t* cref, const uint32_t* cgbin,
-                      uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
-                      uint32_t* read_off) {
-    uint32_t nt = tiles_for(n_upper);
-    if (nt)
-        hipLaunchKernelGGL(k_build_csr, dim3(nt), dim3(kBlock), 0, st, fl, cref, cgbin, counters, tile_off, tgt_ref, tgt_gbin,
-                           read_off);
 }
 
 void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,

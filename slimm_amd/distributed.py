@@ -25,11 +25,12 @@ def _device_of(t: torch.Tensor):
 
 def allreduce_coverage(engine, group=None):
     """The single large collective: sum [cov | uniq_cov | scalar tail] across ranks, in place."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return None  # single process: nothing to exchange, the library keeps its stream running
     buf = engine.coverage_tensor()  # int32 view of the library's device buffer (two's complement sum == uint32 sum)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        if buf.is_cuda:
-            torch.cuda.synchronize(buf.device)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if buf.is_cuda:
+        torch.cuda.synchronize(buf.device)
     return buf
 
 
@@ -73,20 +74,38 @@ def merge_partials(engine, device: Optional[torch.device] = None, group=None):
     return {"uniq_reads_count2": u2, "lca_count": lca, "level_marks": mk, "pairs": pairs}
 
 
-def sharded_profile(engine, device: Optional[torch.device] = None, path: Optional[str] = None, group=None):
+def sharded_profile(engine, device: Optional[torch.device] = None, path: Optional[str] = None, group=None,
+                    phase_times: Optional[dict] = None):
     """slimm::get_profiles() (reference src/slimm.hpp:395-496) over a record stream sharded across ranks.
 
     `engine` already holds this rank's records.  Returns the profile text (identical on every rank) or None when no
     rank has a mapped record.
     """
+    import time
+
+    def lap(name, t0):
+        if phase_times is not None:
+            phase_times[name] = phase_times.get(name, 0.0) + (time.perf_counter() - t0)
+        return time.perf_counter()
+
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    t = time.perf_counter()
     engine.analyze_alignments()
+    t = lap("analyze_alignments(launch)", t)
     allreduce_coverage(engine, group)
+    t = lap("allreduce_coverage", t)
     if not engine.finish_coverage():
         return None
+    t = lap("finish_coverage", t)
     engine.filter_alignments()
-    merged = merge_partials(engine, device, group)
-    if (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "needs_set_partials", False):
+    t = lap("filter_alignments", t)
+    if multi or getattr(engine, "needs_set_partials", False):
+        merged = merge_partials(engine, device, group)
         engine.set_partials(merged["uniq_reads_count2"], merged["lca_count"], merged["level_marks"], merged["pairs"])
+        t = lap("merge_partials", t)
     engine.get_reads_lca_count()
+    t = lap("get_reads_lca_count", t)
     write_here = path if (not dist.is_initialized() or dist.get_rank(group) == 0) else None
-    return engine.write_abundance(write_here)
+    out = engine.write_abundance(write_here)
+    lap("write_abundance", t)
+    return out

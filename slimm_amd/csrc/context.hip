@@ -101,6 +101,7 @@ struct slimm_ctx {
     DevBuf<uint8_t> c_fl;
     DevBuf<uint32_t> tgt_ref, tgt_gbin, read_off;
     DevBuf<uint2> tile_cnt;
+    DevBuf<uint32_t> tile_valid;
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor;
     DevBuf<uint4> tile_items;
@@ -204,6 +205,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->read_off.ensure(static_cast<size_t>(n) + 2));
     HIP_TRY(c, c->tile_cnt.ensure(nt));
+    HIP_TRY(c, c->tile_valid.ensure(nt));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles, n) + 1));
@@ -512,11 +514,11 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_FLAGS);
             launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
-                            c->c_fl.p, c->tile_cnt.p);
+                            c->c_fl.p, c->tile_cnt.p, c->tile_valid.p);
         }
         {
             KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, c->tile_valid.p, CNT_V);
         }
         {
             KernelTimer t(c, K_BUILD_CSR);

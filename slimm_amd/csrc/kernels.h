@@ -29,14 +29,14 @@ uint32_t num_tiles(uint32_t n);
 
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off);
+                       uint32_t* read_off, const uint32_t* extra = nullptr, int slot_extra = -1);
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
 // runs.hip: record classification + CSR emission, on the raw records (grouped input) or on the sorted compact stream
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt);
+                     uint2* tile_cnt, uint32_t* tile_valid);
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, const uint8_t* fl, uint32_t* counters,
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off);

@@ -89,19 +89,25 @@ __global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restri
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cnt, uint32_t ntiles,
                                                      uint32_t* __restrict__ counters, int slot_x, int slot_y,
-                                                     uint32_t* __restrict__ read_off) {
+                                                     uint32_t* __restrict__ read_off, const uint32_t* __restrict__ extra,
+                                                     int slot_extra) {
     __shared__ uint2 s_part[1024];
+    __shared__ uint32_t s_extra[16];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (ntiles + 1023) / 1024;
     const uint32_t lo = tid * per;
     const uint32_t hi = min(lo + per, ntiles);
     uint2 sum = make_uint2(0u, 0u);
+    uint32_t ex = 0;
     for (uint32_t i = lo; i < hi; ++i) {
         uint2 v = tile_cnt[i];
         sum.x += v.x;
         sum.y += v.y;
+        if (extra) ex += extra[i];
     }
     s_part[tid] = sum;
+    ex = wave_sum(ex);
+    if ((tid & 63) == 0) s_extra[tid >> 6] = ex;
     __syncthreads();
     // Hillis-Steele inclusive scan over 1024 partials
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -125,6 +131,11 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cn
         counters[slot_x] = tot.x;
         if (slot_y >= 0) counters[slot_y] = tot.y;
         if (read_off) read_off[tot.x] = tot.y;
+        if (extra) {
+            uint32_t e = 0;
+            for (int w = 0; w < 16; ++w) e += s_extra[w];
+            counters[slot_extra] = e;
+        }
     }
 }
 
@@ -353,8 +364,9 @@ void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs
 }
 
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off);
+                       uint32_t* read_off, const uint32_t* extra, int slot_extra) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off, extra,
+                       slot_extra);
 }
 
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,

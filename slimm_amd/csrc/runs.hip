@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
 
 template <typename Acc>
 __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __restrict__ counters, uint8_t* __restrict__ fl,
-                                                  uint2* __restrict__ tile_cnt) {
+                                                  uint2* __restrict__ tile_cnt, uint32_t* __restrict__ tile_valid) {
     __shared__ uint32_t s_meta[kRTile + kHalo];
     __shared__ uint2 s_w[kRWaves];
     __shared__ uint32_t s_v[kRWaves];
@@ -120,27 +120,48 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
                 bool head = true, first = true, greater_before = false;
                 if (!(me & M_RUN)) {
                     const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
-                    uint32_t j = i, steps = 0;
-                    while (true) {
-                        --j;  // record 0 starts a run, so j never underflows
-                        bool dummy = false;
-                        const uint32_t m = (j >= lds_lo) ? s_meta[j - lds_lo] : full_meta(acc, j, dummy);
+                    // hot loop: walk back through LDS until the run start or a record of the same (read, ref)
+                    const uint32_t* p = &s_meta[i - lds_lo];
+                    bool open = true;  // run start not seen yet
+                    while (p != s_meta) {
+                        const uint32_t m = *--p;
                         if (m & M_VALID) {
                             const uint32_t mt = (m >> 28) & 3u;
                             if ((m & M_IDENT) == my_ident) {
                                 head = false;
                                 first = false;
+                                open = false;
                                 break;
                             }
-                            if (mt == my_mate)
-                                head = false;
-                            else if (mt > my_mate)
-                                greater_before = true;
+                            head = head && (mt != my_mate);
+                            greater_before = greater_before || (mt > my_mate);
                         }
-                        if (m & M_RUN) break;
-                        if (++steps > kLookBackMax) {
-                            too_long = true;
+                        if (m & M_RUN) {
+                            open = false;
                             break;
+                        }
+                    }
+                    if (open) {  // the run reaches back beyond the halo: continue in global memory (rare)
+                        uint32_t j = lds_lo, steps = 0;
+                        while (j > 0) {
+                            --j;
+                            bool dummy = false;
+                            const uint32_t m = full_meta(acc, j, dummy);
+                            if (m & M_VALID) {
+                                const uint32_t mt = (m >> 28) & 3u;
+                                if ((m & M_IDENT) == my_ident) {
+                                    head = false;
+                                    first = false;
+                                    break;
+                                }
+                                head = head && (mt != my_mate);
+                                greater_before = greater_before || (mt > my_mate);
+                            }
+                            if (m & M_RUN) break;
+                            if (++steps > kLookBackMax) {
+                                too_long = true;
+                                break;
+                            }
                         }
                     }
                 }
@@ -155,11 +176,11 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
     nh = r_wave_sum(nh);
     nf = r_wave_sum(nf);
     nv = r_wave_sum(nv);
+    const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
     if ((threadIdx.x & 63) == 0) {
         s_w[threadIdx.x >> 6] = make_uint2(nh, nf);
         s_v[threadIdx.x >> 6] = nv;
-        uint32_t e = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
-        if (e) atomicOr(&counters[CNT_ERR], e);
+        if (err) atomicOr(&counters[CNT_ERR], err);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -172,7 +193,7 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
             v += s_v[w];
         }
         tile_cnt[blockIdx.x] = t;
-        if (Acc::kCountsMapped && v) atomicAdd(&counters[CNT_V], v);  // hits_count (src/slimm.hpp:212)
+        if (Acc::kCountsMapped) tile_valid[blockIdx.x] = v;  // summed into hits_count by k_scan_tiles (src/slimm.hpp:212)
     }
 }
 
@@ -257,7 +278,8 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         running.x += total.x;
         running.y += total.y;
     }
-    if (__any(too_long) && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_RUN_LENGTH);
+    const bool any_long = __any(too_long);
+    if (any_long && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_RUN_LENGTH);
 }
 
 static inline uint32_t rtiles(uint32_t n) { return (n + kRTile - 1) / kRTile; }
@@ -280,11 +302,11 @@ static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint3
 
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt) {
+                     uint2* tile_cnt, uint32_t* tile_valid) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
     hipLaunchKernelGGL(k_runs<RawRecords>, dim3(nt), dim3(kRBlock), 0, st,
-                       make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt);
+                       make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt, tile_valid);
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
@@ -302,7 +324,8 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     const uint32_t nt = rtiles(n_upper);
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
-    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt);
+    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt,
+                       static_cast<uint32_t*>(nullptr));
 }
 
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

@@ -248,21 +248,21 @@ def test_reference_id_out_of_range_is_an_error():
 
 
 def test_run_longer_than_the_lookback_window_is_an_error_not_a_hang():
-    n = 6000
+    n = 20000
     rec = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16),
                   (np.arange(n) % 5).astype(np.int32), np.full(n, 10, dtype=np.int32))
     w = tiny_case()
     s = Slimm.for_workload(w, device=0)
     s.push_records(rec)
     s.analyze_alignments()
-    # 6000 records of one read over 5 references: every look-back finds its reference within 5 steps -> fine
+    # 20000 records of one read over 5 references: every look-back finds its reference within 5 steps -> fine
     assert s.finish_coverage()
     s.reset()
     rec2 = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16),
                    np.concatenate([np.zeros(n - 1), [1]]).astype(np.int32), np.full(n, 10, dtype=np.int32))
     s.push_records(rec2)
     s.analyze_alignments()
-    with pytest.raises(capi.SlimmError) as e:  # the last record must look back over 5999 records of ref 0
+    with pytest.raises(capi.SlimmError) as e:  # the last record must look back over 19999 records of ref 0
         s.finish_coverage()
     assert e.value.code == capi.E_RUN_LENGTH
 

@@ -281,6 +281,11 @@ __device__ void pair_insert(uint64_t key, uint64_t* __restrict__ tab, uint64_t* 
     atomicOr(&counters[CNT_ERR], ERR_PAIR_OVERFLOW);
 }
 
+__device__ __forceinline__ uint32_t row_eq_mask(const uint4& a, const uint4& b, const uint4& a0, const uint4& b0) {
+    return (a.x == a0.x ? 1u : 0u) | (a.y == a0.y ? 2u : 0u) | (a.z == a0.z ? 4u : 0u) | (a.w == a0.w ? 8u : 0u) |
+           (b.x == b0.x ? 16u : 0u) | (b.y == b0.y ? 32u : 0u) | (b.z == b0.z ? 64u : 0u) | (b.w == b0.w ? 128u : 0u);
+}
+
 __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restrict__ read_off,
                                                        const uint32_t* __restrict__ tgt_ref,
                                                        const uint32_t* __restrict__ tgt_gbin,
@@ -294,46 +299,59 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
     if (m >= M) return;
     const uint32_t s = read_off[m], e = read_off[m + 1];
     const bool multi = (e - s) > 1;
-    uint32_t nv = 0, g1 = 0, first_ref = 0, max_ref = 0, eq = 0xffu;
+    uint32_t nv = 0, first_t = 0, first_ref = 0, max_ref = 0, eq = 0xffu;
     uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0;
-    for (uint32_t t = s; t < e; ++t) {
-        uint32_t r = tgt_ref[t] & 0x7fffffffu;
-        if (!valid[r]) continue;
-        if (nv == 0) {
-            g1 = tgt_gbin[t];
-            first_ref = r;
-        }
+    // four targets per trip: their ref / valid / lineage-row loads are independent, so they overlap in flight
+    for (uint32_t c = s; c < e; c += 4) {
+        uint32_t r[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (c + k < e) ? (tgt_ref[c + k] & 0x7fffffffu) : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ok[k] = (r[k] != 0xffffffffu) && valid[r[k]];
+        uint4 ra[4], rb[4];
         if (multi) {
-            uint4 a = lin4[2 * r], b = lin4[2 * r + 1];
-            if (nv == 0) {
-                a0 = a;
-                b0 = b;
-            } else {
-                uint32_t q = (a.x == a0.x ? 1u : 0u) | (a.y == a0.y ? 2u : 0u) | (a.z == a0.z ? 4u : 0u) |
-                             (a.w == a0.w ? 8u : 0u) | (b.x == b0.x ? 16u : 0u) | (b.y == b0.y ? 32u : 0u) |
-                             (b.z == b0.z ? 64u : 0u) | (b.w == b0.w ? 128u : 0u);
-                eq &= q;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (ok[k]) {
+                    ra[k] = lin4[2 * r[k]];
+                    rb[k] = lin4[2 * r[k] + 1];
+                }
             }
         }
-        max_ref = max(max_ref, r);
-        ++nv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            if (nv == 0) {
+                first_t = c + k;
+                first_ref = r[k];
+                if (multi) {
+                    a0 = ra[k];
+                    b0 = rb[k];
+                }
+            } else {
+                eq &= row_eq_mask(ra[k], rb[k], a0, b0);
+            }
+            max_ref = max(max_ref, r[k]);
+            ++nv;
+        }
     }
     if (nv == 1) {
-        atomicAdd(&ucov2[g1], 1u);
+        atomicAdd(&ucov2[tgt_gbin[first_t]], 1u);
     } else if (nv > 1) {
         const uint32_t* lin = reinterpret_cast<const uint32_t*>(lin4);
         uint32_t taxon;
         if (eq) {
-            uint32_t lv = __builtin_ctz(eq);
+            const uint32_t lv = __builtin_ctz(eq);
             taxon = lin[static_cast<size_t>(first_ref) * 8 + lv];
             for (uint32_t t = s; t < e; ++t) {
-                uint32_t r = tgt_ref[t] & 0x7fffffffu;
+                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
                 if (valid[r] && !((marks[r] >> lv) & 1u)) atomicOr(&marks[r], 1u << lv);
             }
         } else {
             taxon = lin[static_cast<size_t>(max_ref) * 8 + 7];
             for (uint32_t t = s; t < e; ++t) {
-                uint32_t r = tgt_ref[t] & 0x7fffffffu;
+                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
                 if (valid[r]) pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
             }
         }

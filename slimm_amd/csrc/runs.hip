@@ -109,68 +109,61 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
         const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
         for (uint32_t i = lds_lo + threadIdx.x; i < lds_hi; i += kRBlock) s_meta[i - lds_lo] = full_meta(acc, i, bad);
         __syncthreads();
-#pragma unroll 2
         for (int k = 0; k < kRItems; ++k) {
             const uint32_t i = base + k * kRBlock + threadIdx.x;
-            if (i >= N) continue;
-            const uint32_t me = s_meta[i - lds_lo];
-            uint32_t f = ((me >> 28) & 3u) << FL_MATE_SHIFT;
-            if (me & M_RUN) f |= FL_RUN_START;
-            if (me & M_VALID) {
-                bool head = true, first = true, greater_before = false;
-                if (!(me & M_RUN)) {
-                    const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
-                    // hot loop: walk back through LDS until the run start or a record of the same (read, ref)
-                    const uint32_t* p = &s_meta[i - lds_lo];
-                    bool open = true;  // run start not seen yet
-                    while (p != s_meta) {
-                        const uint32_t m = *--p;
-                        if (m & M_VALID) {
-                            const uint32_t mt = (m >> 28) & 3u;
-                            if ((m & M_IDENT) == my_ident) {
-                                head = false;
-                                first = false;
-                                open = false;
-                                break;
-                            }
-                            head = head && (mt != my_mate);
-                            greater_before = greater_before || (mt > my_mate);
-                        }
-                        if (m & M_RUN) {
-                            open = false;
+            const bool live = i < N;
+            const uint32_t li = live ? i - lds_lo : 0u;
+            const uint32_t me = live ? s_meta[li] : M_RUN;  // dead lanes: not mapped, never walk
+            const bool valid = me & M_VALID;
+            const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
+            bool head = true, first = true, greater_before = false;
+            // Look-back through LDS, one distance per trip for the whole wave: a wave-uniform loop with a predicated
+            // body (per-lane break/continue costs far more scalar branch instructions than the compares themselves).
+            bool active = valid && !(me & M_RUN);
+            bool open = false;  // ran out of staged records before the run start
+            for (uint32_t d = 1; __ballot(active) != 0ull; ++d) {
+                const bool in = active && d <= li;
+                const uint32_t m = s_meta[in ? li - d : 0u];
+                const bool v = in && (m & M_VALID);
+                const uint32_t mt = (m >> 28) & 3u;
+                const bool same = v && ((m & M_IDENT) == my_ident);
+                head = head && !(v && mt == my_mate);
+                first = first && !same;
+                greater_before = greater_before || (v && mt > my_mate);
+                open = open || (active && !in);
+                active = in && !same && !(m & M_RUN);
+            }
+            if (open) {  // the run reaches back beyond the halo: continue in global memory (rare)
+                uint32_t j = lds_lo, steps = 0;
+                while (j > 0) {
+                    --j;
+                    bool dummy = false;
+                    const uint32_t m = full_meta(acc, j, dummy);
+                    if (m & M_VALID) {
+                        const uint32_t mt = (m >> 28) & 3u;
+                        if ((m & M_IDENT) == my_ident) {
+                            head = false;
+                            first = false;
                             break;
                         }
+                        head = head && (mt != my_mate);
+                        greater_before = greater_before || (mt > my_mate);
                     }
-                    if (open) {  // the run reaches back beyond the halo: continue in global memory (rare)
-                        uint32_t j = lds_lo, steps = 0;
-                        while (j > 0) {
-                            --j;
-                            bool dummy = false;
-                            const uint32_t m = full_meta(acc, j, dummy);
-                            if (m & M_VALID) {
-                                const uint32_t mt = (m >> 28) & 3u;
-                                if ((m & M_IDENT) == my_ident) {
-                                    head = false;
-                                    first = false;
-                                    break;
-                                }
-                                head = head && (mt != my_mate);
-                                greater_before = greater_before || (mt > my_mate);
-                            }
-                            if (m & M_RUN) break;
-                            if (++steps > kLookBackMax) {
-                                too_long = true;
-                                break;
-                            }
-                        }
+                    if (m & M_RUN) break;
+                    if (++steps > kLookBackMax) {
+                        too_long = true;
+                        break;
                     }
                 }
-                f |= (head ? FL_HEAD : 0) | (first ? FL_FIRST : 0) | (greater_before ? FL_GREATER_BEFORE : 0);
-                nh += head;
-                nf += first;
-                nv += 1;
             }
-            fl[i] = static_cast<uint8_t>(f);
+            head = head && valid;
+            first = first && valid;
+            uint32_t f = (my_mate << FL_MATE_SHIFT) | ((me & M_RUN) ? FL_RUN_START : 0u) | (head ? FL_HEAD : 0u) |
+                         (first ? FL_FIRST : 0u) | ((valid && greater_before) ? FL_GREATER_BEFORE : 0u);
+            nh += head;
+            nf += first;
+            nv += valid;
+            if (live) fl[i] = static_cast<uint8_t>(f);
         }
     }
     nh = r_wave_sum(nh);
@@ -234,15 +227,29 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
             total.x += c.x;
             total.y += c.y;
         }
-        if (first) {
-            const uint32_t mate = (f >> FL_MATE_SHIFT) & 3u;
-            uint32_t t = running.y + before.y + rf;
-            uint32_t m = running.x + before.x + rh;
-            if ((f & FL_GREATER_BEFORE) && !(f & FL_RUN_START)) {  // earlier records of the run with a larger mate
-                uint32_t j = i, steps = 0;
-                do {
+        const uint32_t mate = (f >> FL_MATE_SHIFT) & 3u;
+        const uint32_t li = (i < N) ? i - lds_lo : 0u;
+        uint32_t t = running.y + before.y + rf;
+        uint32_t m = running.x + before.x + rh;
+        // Reads of one qName run are laid out by ascending mate.  Both corrections are wave-uniform loops over the
+        // distance with predicated bodies; runs leaving the staged window finish in global memory (rare).
+        {   // earlier records of the run with a larger mate sit AFTER this one in the target order
+            bool act = first && (f & FL_GREATER_BEFORE) && !(f & FL_RUN_START);
+            bool open = false;
+            for (uint32_t d = 1; __ballot(act) != 0ull; ++d) {
+                const bool in = act && d <= li;
+                const uint32_t g = s_fl[in ? li - d : 0u];
+                const bool bigger = in && ((g >> FL_MATE_SHIFT) & 3u) > mate;
+                t -= (bigger && (g & FL_FIRST)) ? 1u : 0u;
+                m -= (bigger && (g & FL_HEAD)) ? 1u : 0u;
+                open = open || (act && !in);
+                act = in && !(g & FL_RUN_START);
+            }
+            if (open) {
+                uint32_t j = lds_lo, steps = 0;
+                while (j > 0) {
                     --j;
-                    const uint32_t g = (j >= lds_lo) ? s_fl[j - lds_lo] : fl[j];
+                    const uint32_t g = fl[j];
                     if (((g >> FL_MATE_SHIFT) & 3u) > mate) {
                         t -= (g & FL_FIRST) ? 1u : 0u;
                         m -= (g & FL_HEAD) ? 1u : 0u;
@@ -252,12 +259,26 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
                         too_long = true;
                         break;
                     }
-                } while (j > 0);
+                }
             }
-            if (mate > 0) {  // later records of the run with a smaller mate
+        }
+        {   // later records of the run with a smaller mate sit BEFORE this one
+            bool act = first && mate > 0;
+            bool open = false;
+            for (uint32_t d = 1; __ballot(act) != 0ull; ++d) {
+                const bool in = act && (i + d) < lds_hi;
+                const uint32_t g = s_fl[in ? li + d : 0u];
+                const bool stop = in && (g & FL_RUN_START);
+                const bool smaller = in && !stop && ((g >> FL_MATE_SHIFT) & 3u) < mate;
+                t += (smaller && (g & FL_FIRST)) ? 1u : 0u;
+                m += (smaller && (g & FL_HEAD)) ? 1u : 0u;
+                open = open || (act && !in && (i + d) < N);
+                act = in && !stop;
+            }
+            if (open) {
                 uint32_t steps = 0;
-                for (uint32_t j = i + 1; j < N; ++j) {
-                    const uint32_t g = (j < lds_hi) ? s_fl[j - lds_lo] : fl[j];
+                for (uint32_t j = lds_hi; j < N; ++j) {
+                    const uint32_t g = fl[j];
                     if (g & FL_RUN_START) break;
                     if (((g >> FL_MATE_SHIFT) & 3u) < mate) {
                         t += (g & FL_FIRST) ? 1u : 0u;
@@ -269,6 +290,8 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
                     }
                 }
             }
+        }
+        if (first) {
             bool dummy = false;
             const uint32_t r = acc.meta_of(i, dummy) & 0x0fffffffu;
             tgt_ref[t] = r | (head ? 0x80000000u : 0u);

@@ -51,8 +51,12 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "k_tile_scan": 12 * (B // 8192 + 1),
         "k_tile_scatter": 8 * P + 2 * P,              # gbin + ref in, 16-bit bucket entries out
         "k_tile_hist": 2 * P + 8 * B,                 # bucket in, finished cov + uniq_cov tiles out (replaces the zero-fill)
+        "k_tile_count2": 4 * M,                       # per-read bin (or marker) in
+        "k_tile_scan2": 12 * (B // 8192 + 1),
+        "k_tile_scatter2": 4 * M + 2 * U2,
+        "k_tile_hist2": 2 * U2 + 4 * B,               # finished uniq_cov2 tiles out (replaces its zero-fill)
         "k_ref_stats": 8 * B,                         # one streaming read of cov and uniq_cov
-        "k_filter_lca": 4 * M + 8 * P + 8 * U2,       # offsets + targets in; one RMW on uniq_cov2 per post-filter unique
+        "k_filter_lca": 4 * M + 8 * P + 4 * M,        # offsets + targets in; per-read unique bin out
         "k_ref_stats2": 4 * B,
     }
 

@@ -64,11 +64,13 @@ struct PinBuf {
 
 enum KernelId {
     K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FLAGS, K_BUILD_CSR, K_HIST, K_REF_STATS, K_FILTER_LCA,
-    K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_COUNT
+    K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_TILE_COUNT2, K_TILE_SCAN2, K_TILE_SCATTER2,
+    K_TILE_HIST2, K_COUNT
 };
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
                                      "k_runs", "k_emit", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
-                                     "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist"};
+                                     "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",
+                                     "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2"};
 
 constexpr uint32_t kTailWords = 64;
 
@@ -105,6 +107,7 @@ struct slimm_ctx {
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor;
     DevBuf<uint4> tile_items;
+    DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
@@ -209,6 +212,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles, n) + 1));
+        HIP_TRY(c, c->uniq_gbin.ensure(n + 1));
     }
     if (c->order == SLIMM_ORDER_ANY) {
         HIP_TRY(c, c->c_ident.ensure(n + 1));
@@ -530,7 +534,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, c->tile_count.p);
+            launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p);
         }
         {
             KernelTimer t(c, K_TILE_SCAN);
@@ -539,7 +543,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_TILE_SCATTER);
-            launch_tile_scatter(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->tile_base.p,
+            launch_tile_scatter(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
                                 c->tile_cursor.p, c->bucket.p);
         }
         {
@@ -628,7 +632,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
     for (int attempt = 0; attempt < 8; ++attempt) {
         {
             KernelTimer t(c, K_MEMSET);
-            HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
+            if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
             HIP_TRY(c, hipMemsetAsync(c->lca_count.p, 0, static_cast<size_t>(T) * 4, st));
             HIP_TRY(c, hipMemsetAsync(c->marks.p, 0, static_cast<size_t>(R) * 4, st));
             HIP_TRY(c, hipMemsetAsync(c->pair_tab.p, 0xff, static_cast<size_t>(c->pair_cap) * 8, st));
@@ -637,8 +641,31 @@ int slimm_filter_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_FILTER_LCA);
             launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
-                              c->d_lin_dense.p, c->ucov2(), c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p,
-                              c->pair_cap - 1);
+                              c->d_lin_dense.p, c->use_tiles ? nullptr : c->ucov2(),
+                              c->use_tiles ? c->uniq_gbin.p : nullptr, c->lca_count.p, c->marks.p, c->pair_tab.p,
+                              c->pair_list.p, c->pair_cap - 1);
+        }
+        if (c->use_tiles) {  // uniq_cov2 from the per-read bins, through the same LDS tile histogram as phase A
+            const uint32_t grid = 512;
+            {
+                KernelTimer t(c, K_TILE_COUNT2);
+                launch_tile_count(st, grid, c->ntiles, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p);
+            }
+            {
+                KernelTimer t(c, K_TILE_SCAN2);
+                launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                                 c->counters.p);
+            }
+            {
+                KernelTimer t(c, K_TILE_SCATTER2);
+                launch_tile_scatter(st, grid, c->ntiles, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_base.p,
+                                    c->tile_cursor.p, c->bucket.p);
+            }
+            {
+                KernelTimer t(c, K_TILE_HIST2);
+                launch_tile_hist(st, c->ntiles, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
+                                 c->ucov2(), nullptr);
+            }
         }
         {
             KernelTimer t(c, K_REF_STATS2);

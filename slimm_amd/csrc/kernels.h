@@ -49,10 +49,12 @@ void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, cons
                  uint32_t* cov, uint32_t* ucov);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
                       uint32_t* out);
+// ucov2 != nullptr: uniq_cov2[g]++ with a global atomic per unique-after-filter read (fallback);
+// uniq_gbin != nullptr: the bin of such a read (or 0xffffffff) is stored per read for the tile histogram instead.
 void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                        const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
-                       uint32_t* ucov2, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list,
-                       uint32_t pair_mask);
+                       uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
+                       uint64_t* pair_list, uint32_t pair_mask);
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----
@@ -60,14 +62,15 @@ constexpr uint32_t kTileShift = 13;
 constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 32 KiB of LDS in k_tile_hist
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
 int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_gbin, const uint32_t* counters,
-                       uint32_t* tile_count);
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
+                       int count_slot, uint32_t* tile_count);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters);
-void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* tgt_gbin,
-                         const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint16_t* bucket);
+void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
+                         const uint32_t* counters, int count_slot, const uint32_t* tile_base, uint32_t* tile_cursor,
+                         uint16_t* bucket);
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov);
 

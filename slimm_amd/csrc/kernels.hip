@@ -291,6 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
                                                        const uint32_t* __restrict__ tgt_gbin,
                                                        uint32_t* __restrict__ counters, const uint8_t* __restrict__ valid,
                                                        const uint4* __restrict__ lin4, uint32_t* __restrict__ ucov2,
+                                                       uint32_t* __restrict__ uniq_gbin,
                                                        uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
                                                        uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
                                                        uint32_t pair_mask) {
@@ -336,8 +337,9 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
             ++nv;
         }
     }
+    if (uniq_gbin) uniq_gbin[m] = (nv == 1) ? tgt_gbin[first_t] : 0xffffffffu;
     if (nv == 1) {
-        atomicAdd(&ucov2[tgt_gbin[first_t]], 1u);
+        if (ucov2) atomicAdd(&ucov2[tgt_gbin[first_t]], 1u);
     } else if (nv > 1) {
         const uint32_t* lin = reinterpret_cast<const uint32_t*>(lin4);
         uint32_t taxon;
@@ -411,12 +413,13 @@ void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, cons
 
 void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                        const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
-                       uint32_t* ucov2, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list,
-                       uint32_t pair_mask) {
+                       uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
+                       uint64_t* pair_list, uint32_t pair_mask) {
     uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
     if (blocks)
         hipLaunchKernelGGL(k_filter_lca, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters, valid,
-                           reinterpret_cast<const uint4*>(lin_dense), ucov2, lca_count, marks, pair_tab, pair_list, pair_mask);
+                           reinterpret_cast<const uint4*>(lin_dense), ucov2, uniq_gbin, lca_count, marks, pair_tab, pair_list,
+                           pair_mask);
 }
 
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail) {

@@ -35,10 +35,10 @@ __device__ __forceinline__ void slice_of(uint32_t P, uint32_t b, uint32_t g, uin
 }
 
 __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ tgt_gbin,
-                                                        const uint32_t* __restrict__ counters, uint32_t ntiles,
-                                                        uint32_t* __restrict__ tile_count) {
+                                                        const uint32_t* __restrict__ counters, int count_slot,
+                                                        uint32_t ntiles, uint32_t* __restrict__ tile_count) {
     extern __shared__ uint32_t s_hist[];
-    const uint32_t P = counters[CNT_P];
+    const uint32_t P = counters[count_slot];
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
     uint32_t lo, hi;
@@ -107,14 +107,15 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
     }
 }
 
+template <bool kWithRef>
 __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ tgt_ref,
                                                           const uint32_t* __restrict__ tgt_gbin,
-                                                          const uint32_t* __restrict__ counters, uint32_t ntiles,
-                                                          const uint32_t* __restrict__ tile_base,
+                                                          const uint32_t* __restrict__ counters, int count_slot,
+                                                          uint32_t ntiles, const uint32_t* __restrict__ tile_base,
                                                           uint32_t* __restrict__ tile_cursor,
                                                           uint16_t* __restrict__ bucket) {
     extern __shared__ uint32_t s_hist[];
-    const uint32_t P = counters[CNT_P];
+    const uint32_t P = counters[count_slot];
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
     uint32_t lo, hi;
@@ -144,8 +145,12 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
             uint32_t t = t0 + u * kTBlock + threadIdx.x;
             bool live = t < hi;
             g[u] = live ? tgt_gbin[t] : 0xffffffffu;
-            r0[u] = live ? tgt_ref[t] : 0u;
-            r1[u] = (live && t + 1 < P) ? tgt_ref[t + 1] : 0x80000000u;
+            if (kWithRef) {
+                r0[u] = live ? tgt_ref[t] : 0u;
+                r1[u] = (live && t + 1 < P) ? tgt_ref[t + 1] : 0x80000000u;
+            } else {
+                r0[u] = r1[u] = 0u;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
 }
 
 // tiles cut into several work items are accumulated with (contiguous) global atomics, so they start from zero
+template <bool kTwo>
 __global__ __launch_bounds__(256) void k_tile_zero_split(const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ cov,
                                                          uint32_t* __restrict__ ucov) {
     const uint32_t tile = blockIdx.x;
@@ -167,15 +173,16 @@ __global__ __launch_bounds__(256) void k_tile_zero_split(const uint32_t* __restr
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 256) {
         oc[i] = z;
-        ou[i] = z;
+        if (kTwo) ou[i] = z;
     }
 }
 
+template <bool kTwo>
 __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
                                                    const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov) {
     __shared__ uint32_t s_cov[kTileBins];
-    __shared__ uint32_t s_ucov[kTileBins];
+    __shared__ uint32_t s_ucov[kTwo ? kTileBins : 4];
     if (blockIdx.x >= counters[CNT_ITEMS]) return;
     const uint4 it = items[blockIdx.x];
     const uint32_t tile = it.x, lo = it.y, hi = it.z;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         const uint4 z = make_uint4(0, 0, 0, 0);
         for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
             zc[i] = z;
-            zu[i] = z;
+            if (kTwo) zu[i] = z;
         }
     }
     __syncthreads();
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         for (int u = 0; u < 4; ++u) {
             if (v[u] == 0xffffffffu) continue;
             atomicAdd(&s_cov[v[u] & kTileMask], 1u);
-            if (v[u] & kTileBins) atomicAdd(&s_ucov[v[u] & kTileMask], 1u);
+            if (kTwo && (v[u] & kTileBins)) atomicAdd(&s_ucov[v[u] & kTileMask], 1u);
         }
     }
     __syncthreads();
@@ -214,13 +221,16 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         const uint4* su = reinterpret_cast<const uint4*>(s_ucov);
         for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
             oc[i] = sc[i];
-            ou[i] = su[i];
+            if (kTwo) ou[i] = su[i];
         }
     } else {
         for (uint32_t i = threadIdx.x; i < kTileBins; i += 512) {
-            uint32_t a = s_cov[i], b = s_ucov[i];
+            uint32_t a = s_cov[i];
             if (a) atomicAdd(&gc[i], a);
-            if (b) atomicAdd(&gu[i], b);
+            if (kTwo) {
+                uint32_t b2 = s_ucov[i];
+                if (b2) atomicAdd(&gu[i], b2);
+            }
         }
     }
 }
@@ -232,17 +242,20 @@ int tile_hist_setup(uint32_t ntiles) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_count), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(bytes)) != hipSuccess)
         return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(bytes)) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
+        return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
         return -1;
     return 0;
 }
 
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_gbin, const uint32_t* counters,
-                       uint32_t* tile_count) {
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
+                       int count_slot, uint32_t* tile_count) {
     (void)hipMemsetAsync(tile_count, 0, static_cast<size_t>(ntiles) * 4, st);
-    hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, tgt_gbin, counters,
-                       ntiles, tile_count);
+    hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, gbin, counters,
+                       count_slot, ntiles, tile_count);
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
@@ -250,19 +263,31 @@ void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_coun
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters);
 }
 
-void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* tgt_gbin,
-                         const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint16_t* bucket) {
-    hipLaunchKernelGGL(k_tile_scatter, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, tgt_ref, tgt_gbin,
-                       counters, ntiles, tile_base, tile_cursor, bucket);
+void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
+                         const uint32_t* counters, int count_slot, const uint32_t* tile_base, uint32_t* tile_cursor,
+                         uint16_t* bucket) {
+    const size_t lds = static_cast<size_t>(ntiles) * 4;
+    if (tgt_ref)
+        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
+                           ntiles, tile_base, tile_cursor, bucket);
+    else
+        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
+                           ntiles, tile_base, tile_cursor, bucket);
 }
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }
 
+// cov + ucov (ucov != nullptr: bit 13 of a bucket entry selects uniq_cov as well) or a single array
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov) {
-    hipLaunchKernelGGL(k_tile_zero_split, dim3(ntiles), dim3(256), 0, st, tile_base, cov, ucov);
-    hipLaunchKernelGGL(k_tile_hist, dim3(tile_items_upper(ntiles, n_upper)), dim3(512), 0, st, bucket, items, counters, cov,
-                       ucov);
+    const uint32_t grid = tile_items_upper(ntiles, n_upper);
+    if (ucov) {
+        hipLaunchKernelGGL(k_tile_zero_split<true>, dim3(ntiles), dim3(256), 0, st, tile_base, cov, ucov);
+        hipLaunchKernelGGL(k_tile_hist<true>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov);
+    } else {
+        hipLaunchKernelGGL(k_tile_zero_split<false>, dim3(ntiles), dim3(256), 0, st, tile_base, cov, cov);
+        hipLaunchKernelGGL(k_tile_hist<false>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov);
+    }
 }
 
 }  // namespace slimm

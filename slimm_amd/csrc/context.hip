@@ -90,6 +90,10 @@ struct slimm_ctx {
     // static tables
     DevBuf<uint32_t> d_ref_len, d_bin_off, d_lin_dense;
     DevBuf<uint8_t> d_valid;
+    DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
+    DevBuf<uint32_t> d_level_taxon;
+    PinBuf<uint4> h_rows16;
+    bool use_rows16 = false;
     // records
     DevBuf<uint64_t> in_key;
     DevBuf<int32_t> in_ref, in_pos;
@@ -329,6 +333,15 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(hipMemcpy(cc->d_lin_dense.p, c->host->lineage_dense().data(), static_cast<size_t>(c->R) * 32,
                            hipMemcpyHostToDevice));
 #undef HIP_TRY0
+        const char* wide_rows = getenv("SLIMM_WIDE_ROWS");
+        cc->use_rows16 = c->host->rows16_ok() && !(wide_rows && wide_rows[0] == '1');
+        if (cc->use_rows16) {
+            const std::vector<uint32_t>& lt = c->host->level_taxon();
+            if (cc->d_rows16.ensure(c->R) != hipSuccess || cc->h_rows16.ensure(c->R) != hipSuccess ||
+                cc->d_level_taxon.ensure(lt.size() + 1) != hipSuccess ||
+                hipMemcpy(cc->d_level_taxon.p, lt.data(), lt.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
+        }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
         cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles) == 0;
         if (cc->use_tiles) {
@@ -628,7 +641,18 @@ int slimm_filter_alignments(slimm_ctx* c) {
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     const uint32_t R = c->R, T = c->T;
-    HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
+    if (c->use_rows16) {
+        const uint16_t* li = h.level_index().data();
+        for (uint32_t r = 0; r < R; ++r) {
+            const uint16_t* q = li + static_cast<size_t>(r) * 8;
+            const uint32_t v = h.valid[r] ? 0x8000u : 0u;
+            c->h_rows16.p[r] = make_uint4(q[0] | (uint32_t(q[1]) << 16), q[2] | (uint32_t(q[3]) << 16),
+                                          q[4] | (uint32_t(q[5]) << 16), q[6] | ((uint32_t(q[7]) | v) << 16));
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_rows16.p, c->h_rows16.p, static_cast<size_t>(R) * 16, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
+    }
     for (int attempt = 0; attempt < 8; ++attempt) {
         {
             KernelTimer t(c, K_MEMSET);
@@ -640,10 +664,16 @@ int slimm_filter_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_FILTER_LCA);
-            launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
-                              c->d_lin_dense.p, c->use_tiles ? nullptr : c->ucov2(),
-                              c->use_tiles ? c->uniq_gbin.p : nullptr, c->lca_count.p, c->marks.p, c->pair_tab.p,
-                              c->pair_list.p, c->pair_cap - 1);
+            if (c->use_rows16)
+                launch_filter_lca16(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p,
+                                    c->d_rows16.p, c->d_level_taxon.p, h.level_offset(),
+                                    c->use_tiles ? nullptr : c->ucov2(), c->use_tiles ? c->uniq_gbin.p : nullptr,
+                                    c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p, c->pair_cap - 1);
+            else
+                launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
+                                  c->d_lin_dense.p, c->use_tiles ? nullptr : c->ucov2(),
+                                  c->use_tiles ? c->uniq_gbin.p : nullptr, c->lca_count.p, c->marks.p, c->pair_tab.p,
+                                  c->pair_list.p, c->pair_cap - 1);
         }
         if (c->use_tiles) {  // uniq_cov2 from the per-read bins, through the same LDS tile histogram as phase A
             const uint32_t grid = 512;

@@ -5,7 +5,7 @@
 #include <algorithm>
 #include <map>
 #include <numeric>
-#include <sstream>
+#include <cstdio>
 #include <unordered_map>
 
 namespace slimm {
@@ -64,6 +64,25 @@ HostProfile::HostProfile(const HostConfig& cfg) : cfg_(cfg) {
     for (uint32_t k = 0; k < cfg_.tax_id.size(); ++k)
         if (cfg_.tax_id[k] == 0) zero_name_ = cfg_.tax_name[k];
 
+    // per-level dense indices for the 16-byte device rows
+    rows16_ok_ = true;
+    lvl_idx_.assign(static_cast<size_t>(R) * 8, 0);
+    lvl_taxon_.clear();
+    for (uint32_t lv = 0; lv < kLineageLen; ++lv) {
+        std::vector<uint32_t> vals(R);
+        for (uint32_t r = 0; r < R; ++r) vals[r] = lin_dense_[static_cast<size_t>(r) * 8 + lv];
+        std::sort(vals.begin(), vals.end());
+        vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+        lvl_off_[lv] = static_cast<uint32_t>(lvl_taxon_.size());
+        if (vals.size() > (lv == 7 ? 32767u : 65535u)) rows16_ok_ = false;
+        if (rows16_ok_)
+            for (uint32_t r = 0; r < R; ++r)
+                lvl_idx_[static_cast<size_t>(r) * 8 + lv] = static_cast<uint16_t>(
+                    std::lower_bound(vals.begin(), vals.end(), lin_dense_[static_cast<size_t>(r) * 8 + lv]) - vals.begin());
+        lvl_taxon_.insert(lvl_taxon_.end(), vals.begin(), vals.end());
+    }
+    lvl_off_[8] = static_cast<uint32_t>(lvl_taxon_.size());
+
     // db.taxid__name: absent taxid reads as (strain_lv, "") -- the reference's operator[] default (Q6)
     std::unordered_map<uint32_t, uint32_t> pos;
     pos.reserve(cfg_.tax_id.size() * 2);
@@ -103,6 +122,7 @@ void HostProfile::reset() {  // slimm.hpp:167-188
     min_reads = cfg_.min_reads;
     have_coverage = have_valid = have_partials = have_counts = false;
     profile_.clear();
+    profile_ready_ = false;
 }
 
 void HostProfile::reset_cutoffs() { cc_cache_ = ucc_cache_ = 0.0f; }
@@ -300,6 +320,7 @@ void HostProfile::propagate() {
         }
     }
     have_counts = true;
+    profile_ready_ = false;
 }
 
 void HostProfile::taxon_counts(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& count) {
@@ -347,15 +368,35 @@ std::string HostProfile::lineage_string(uint32_t rnk, const uint32_t* lin, bool 
         if (n.empty()) n = "unknown_" + rank_long(lv);
         return n;
     };
-    std::string s = rank_short(rnk) + "__" + name_at(rnk);
-    for (uint32_t i = rnk + 1; i < kLineageLen; ++i) s = rank_short(i) + "__" + name_at(i) + "|" + s;
+    std::string s;
+    s.reserve(256);
+    for (uint32_t i = kLineageLen; i-- > rnk;) {  // the reference prepends rank by rank; same text, built front to back
+        s += rank_short(i);
+        s += "__";
+        s += name_at(i);
+        if (i != rnk) s += '|';
+    }
     return s;
 }
 
 // slimm.hpp:733-843
+// Number formatting: the reference streams floats / doubles into an ofstream with default flags, i.e. "%.6g".
+static void put_g(std::string& out, double v) {
+    char buf[40];
+    int n = snprintf(buf, sizeof(buf), "%.6g", v);
+    out.append(buf, static_cast<size_t>(n));
+}
+static void put_u(std::string& out, uint32_t v) {
+    char buf[16];
+    int n = snprintf(buf, sizeof(buf), "%u", v);
+    out.append(buf, static_cast<size_t>(n));
+}
+
 const std::string& HostProfile::write_abundance() {
-    std::ostringstream out;
-    out << "taxa_level\ttaxa_id\tlinage\tabundance\tread_count\n";
+    if (profile_ready_) return profile_;
+    std::string out;
+    out.reserve(8192);
+    out += "taxa_level\ttaxa_id\tlinage\tabundance\tread_count\n";
     const uint32_t T = n_taxa_dense();
     const uint32_t rnk = considered_.size() > 1 ? considered_[1] : considered_[0];
     const uint32_t parent_rnk = considered_[0];
@@ -403,8 +444,16 @@ const std::string& HostProfile::write_abundance() {
         // get_lineage_string(rank, taxid): lineage of the FIRST child, all zeros for taxid 0 (:712-730)
         bool zero = dense_taxid_[t] == 0;
         const uint32_t* lin_first = &lin_dense_[static_cast<size_t>(k.mn) * 8];
-        out << rank_long(rnk) << "\t" << dense_taxid_[t] << "\t" << lineage_string(rnk, lin_first, zero) << "\t";
-        out << ab << "\t" << count_[t] << "\n";
+        out += rank_long(rnk);
+        out += '\t';
+        put_u(out, dense_taxid_[t]);
+        out += '\t';
+        out += lineage_string(rnk, lin_first, zero);
+        out += '\t';
+        put_g(out, ab);
+        out += '\t';
+        put_u(out, count_[t]);
+        out += '\n';
         sum_ab += ab;
         sum_reads += count_[t];
         ++count;
@@ -428,18 +477,33 @@ const std::string& HostProfile::write_abundance() {
             if (k.items.empty()) zero = true;  // the reference would throw from .at(); unreachable with a counted parent
             const uint32_t* lin_first = zero ? nullptr : &lin_dense_[static_cast<size_t>(k.mn) * 8];
             std::string ls = lineage_string(parent_rnk, lin_first, zero) + "|" + rank_short(rnk) + "__" + name;
-            out << rank_long(rnk) << "\t" << dense_taxid_[parent] << "*\t" << ls << "\t";
-            out << uncl_ab << "\t" << uncl_reads << "\n";
+            out += rank_long(rnk);
+            out += '\t';
+            put_u(out, dense_taxid_[parent]);
+            out += "*\t";
+            out += ls;
+            out += '\t';
+            put_g(out, uncl_ab);
+            out += '\t';
+            put_u(out, uncl_reads);
+            out += '\n';
             sum_reads += uncl_reads;
             sum_ab += uncl_ab;
         }
     }
 
-    out << rank_long(rnk) << "\t" << "0*" << "\t" << lineage_string(rnk, nullptr, true) << "\t";  // :833-835
-    out << 100.0 - sum_ab << "\t" << matches - sum_reads << "\n";
+    out += rank_long(rnk);  // :833-835
+    out += "\t0*\t";
+    out += lineage_string(rnk, nullptr, true);
+    out += '\t';
+    put_g(out, 100.0 - sum_ab);
+    out += '\t';
+    put_u(out, matches - sum_reads);
+    out += '\n';
     profile_count = count;
     profile_failed = failed;
-    profile_ = out.str();
+    profile_.swap(out);
+    profile_ready_ = true;
     return profile_;
 }
 

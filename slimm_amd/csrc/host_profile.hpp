@@ -68,6 +68,12 @@ public:
     const std::vector<uint32_t>& dense_taxid() const { return dense_taxid_; }  // ascending, unique
     const std::vector<uint32_t>& lineage_dense() const { return lin_dense_; }  // [R*8] indices into dense_taxid
     const std::vector<uint32_t>& nbins() const { return nbins_; }              // len/W + 1 (reference_contig.hpp:80)
+    // Compact lineage rows for the device LCA: per level a dense 16-bit index (level 7: 15 bits, the top bit is the
+    // per-run valid flag).  rows16_ok() is false when a level has too many distinct taxids for that.
+    bool rows16_ok() const { return rows16_ok_; }
+    const std::vector<uint16_t>& level_index() const { return lvl_idx_; }      // [R*8]
+    const std::vector<uint32_t>& level_taxon() const { return lvl_taxon_; }    // concatenated per level: dense taxon
+    const uint32_t* level_offset() const { return lvl_off_; }                  // [9]
     uint32_t bin_width() const { return cfg_.bin_width; }
     uint64_t total_bins() const { return total_bins_; }
 
@@ -117,6 +123,10 @@ private:
 
     HostConfig cfg_;
     std::vector<uint32_t> dense_taxid_, lin_dense_, nbins_, rank_d_;
+    std::vector<uint16_t> lvl_idx_;
+    std::vector<uint32_t> lvl_taxon_;
+    uint32_t lvl_off_[9] = {0};
+    bool rows16_ok_ = false;
     std::vector<int32_t> name_idx_d_;  // index into cfg_.tax_name or -1
     uint64_t total_bins_ = 0;
     uint32_t zero_dense_ = 0xffffffffu;  // dense index of taxid 0 if present
@@ -134,6 +144,7 @@ private:
     std::vector<RefSet> kids_;            // [T]
     std::vector<uint32_t> direct_taxid_, direct_count_, direct_pair_t_, direct_pair_r_;
     std::string profile_;
+    bool profile_ready_ = false;
     std::string empty_, zero_name_;
 };
 

@@ -55,6 +55,11 @@ void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_of
                        const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
                        uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
                        uint64_t* pair_list, uint32_t pair_mask);
+// 16-byte rows (per-level 16-bit indices + valid bit); level_off is a host array of 8 offsets into level_taxon
+void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
+                         const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
+                         const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
+                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask);
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----

@@ -361,6 +361,91 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_filter_lca16: the same per-read work on 16-byte lineage rows: eight per-level 16-bit indices, with the run's valid
+// flag in the top bit of the level-7 half-word.  One 16-byte gather per target replaces a byte gather (valid[]) plus
+// two 16-byte gathers (32-byte rows): the kernel is bound by the number of distinct cache lines its gathers touch.
+//   row.x = lvl0 | lvl1 << 16, row.y = lvl2 | lvl3 << 16, row.z = lvl4 | lvl5 << 16, row.w = lvl6 | (valid << 15 | lvl7) << 16
+// level_taxon[level_off[lv] + idx] gives the dense taxon of a (level, index).
+// ---------------------------------------------------------------------------------------------------------
+struct LevelOffsets {
+    uint32_t off[8];
+};
+
+__device__ __forceinline__ uint32_t row16_eq_mask(const uint4& a, const uint4& b) {
+    const uint32_t dx = a.x ^ b.x, dy = a.y ^ b.y, dz = a.z ^ b.z, dw = a.w ^ b.w;
+    return ((dx & 0xffffu) ? 0u : 1u) | ((dx >> 16) ? 0u : 2u) | ((dy & 0xffffu) ? 0u : 4u) | ((dy >> 16) ? 0u : 8u) |
+           ((dz & 0xffffu) ? 0u : 16u) | ((dz >> 16) ? 0u : 32u) | ((dw & 0xffffu) ? 0u : 64u) | ((dw >> 16) ? 0u : 128u);
+}
+
+__device__ __forceinline__ uint32_t row16_level(const uint4& a, uint32_t lv) {
+    const uint32_t w = (lv < 2) ? a.x : (lv < 4) ? a.y : (lv < 6) ? a.z : a.w;
+    const uint32_t h = (lv & 1u) ? (w >> 16) : (w & 0xffffu);
+    return (lv == 7) ? (h & 0x7fffu) : h;
+}
+
+__global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restrict__ read_off,
+                                                         const uint32_t* __restrict__ tgt_ref,
+                                                         const uint32_t* __restrict__ tgt_gbin,
+                                                         uint32_t* __restrict__ counters, const uint4* __restrict__ rows16,
+                                                         const uint32_t* __restrict__ level_taxon, const LevelOffsets lo,
+                                                         uint32_t* __restrict__ ucov2, uint32_t* __restrict__ uniq_gbin,
+                                                         uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
+                                                         uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
+                                                         uint32_t pair_mask) {
+    const uint32_t M = counters[CNT_M];
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t s = read_off[m], e = read_off[m + 1];
+    uint32_t nv = 0, first_t = 0, max_ref = 0, w_max = 0, eq = 0xffu;
+    uint4 a0 = make_uint4(0, 0, 0, 0);
+    for (uint32_t c = s; c < e; c += 4) {
+        uint32_t r[4];
+        uint4 row[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (c + k < e) ? (tgt_ref[c + k] & 0x7fffffffu) : 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) row[k] = (r[k] != 0xffffffffu) ? rows16[r[k]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!(row[k].w >> 31)) continue;  // not a valid reference (or past the end)
+            if (nv == 0) {
+                first_t = c + k;
+                a0 = row[k];
+            } else {
+                eq &= row16_eq_mask(row[k], a0);
+            }
+            if (r[k] >= max_ref) {
+                max_ref = r[k];
+                w_max = row[k].w;
+            }
+            ++nv;
+        }
+    }
+    if (uniq_gbin) uniq_gbin[m] = (nv == 1) ? tgt_gbin[first_t] : 0xffffffffu;
+    if (nv == 1) {
+        if (ucov2) atomicAdd(&ucov2[tgt_gbin[first_t]], 1u);
+    } else if (nv > 1) {
+        uint32_t taxon;
+        if (eq) {
+            const uint32_t lv = __builtin_ctz(eq);
+            taxon = level_taxon[lo.off[lv] + row16_level(a0, lv)];
+            for (uint32_t t = s; t < e; ++t) {
+                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
+                if ((rows16[r].w >> 31) && !((marks[r] >> lv) & 1u)) atomicOr(&marks[r], 1u << lv);
+            }
+        } else {
+            taxon = level_taxon[lo.off[7] + ((w_max >> 16) & 0x7fffu)];
+            for (uint32_t t = s; t < e; ++t) {
+                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
+                if (rows16[r].w >> 31)
+                    pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
+            }
+        }
+        atomicAdd(&lca_count[taxon], 1u);
+    }
+}
+
 // tail[0..3] = {hits, matches, targets, err}: the additive scalars that travel with the bins through the all-reduce
 __global__ void k_publish_tail(const uint32_t* __restrict__ counters, uint32_t* __restrict__ tail) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -420,6 +505,19 @@ void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_of
         hipLaunchKernelGGL(k_filter_lca, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters, valid,
                            reinterpret_cast<const uint4*>(lin_dense), ucov2, uniq_gbin, lca_count, marks, pair_tab, pair_list,
                            pair_mask);
+}
+
+void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
+                         const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
+                         const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
+                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask) {
+    uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
+    LevelOffsets lo;
+    for (int i = 0; i < 8; ++i) lo.off[i] = level_off[i];
+    if (blocks)
+        hipLaunchKernelGGL(k_filter_lca16, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters,
+                           reinterpret_cast<const uint4*>(rows16), level_taxon, lo, ucov2, uniq_gbin, lca_count, marks,
+                           pair_tab, pair_list, pair_mask);
 }
 
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail) {

@@ -173,6 +173,14 @@ def test_direct_atomic_fallback_path(monkeypatch):
     check(make_workload(CONFIGS["config1"], seed=16))
 
 
+def test_wide_lineage_rows_fallback_path(monkeypatch):
+    """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
+    monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")
+    check(make_workload(CONFIGS["config2"], seed=17, n_records=200_000))
+    w, _, _ = load_golden("holes")
+    check(w)
+
+
 def test_batched_push_equals_single_push():
     w = make_workload(CONFIGS["config1"], seed=11)
     a = run_gpu(w)

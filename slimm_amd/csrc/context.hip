@@ -113,6 +113,7 @@ struct slimm_ctx {
     DevBuf<uint4> tile_items;
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
+    uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
     DevBuf<uint32_t> counters;   // CNT_WORDS
@@ -147,6 +148,7 @@ struct slimm_ctx {
     uint32_t* ucov() { return bins.p + Bp; }
     uint32_t* tail() { return bins.p + 2 * Bp; }
     uint32_t* ucov2() { return bins.p + 2 * Bp + kTailWords; }
+    uint32_t* lca_tiles() { return bins.p + 3 * Bp + kTailWords; }  // [Tpad] right behind uniq_cov2: one index space
 };
 
 namespace {
@@ -215,7 +217,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tile_valid.ensure(nt));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
-        HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles, n) + 1));
+        HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles2, n) + 1));
         HIP_TRY(c, c->uniq_gbin.ensure(n + 1));
     }
     if (c->order == SLIMM_ORDER_ANY) {
@@ -300,6 +302,9 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     c->bin_off_h[c->R] = static_cast<uint32_t>(off);
     c->Bp = (off + kTileBins - 1) & ~static_cast<uint64_t>(kTileBins - 1);
     c->ntiles = static_cast<uint32_t>(c->Bp >> kTileShift);
+    c->Tpad = (c->T + kTileBins - 1) & ~(kTileBins - 1);
+    c->ntiles2 = c->ntiles + (c->Tpad >> kTileShift);
+    if (c->Bp + c->Tpad >= 0xfffffff0ull) return fail(nullptr, SLIMM_E_INVALID, "more than 2^32 coverage bins; use a larger bin width");
 
     if (c->device >= 0) {
         slimm_ctx* cc = c.get();
@@ -319,7 +324,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->d_bin_off.ensure(c->R + 1));
         HIP_TRY0(cc->d_lin_dense.ensure(static_cast<size_t>(c->R) * 8));
         HIP_TRY0(cc->d_valid.ensure(c->R));
-        HIP_TRY0(cc->bins.ensure(3 * c->Bp + kTailWords));
+        HIP_TRY0(cc->bins.ensure(3 * c->Bp + kTailWords + c->Tpad));
         HIP_TRY0(cc->counters.ensure(CNT_WORDS));
         HIP_TRY0(cc->ref_stats.ensure(static_cast<size_t>(c->R) * 8));
         HIP_TRY0(cc->lca_count.ensure(c->T));
@@ -343,10 +348,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
         }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
-        cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles) == 0;
+        cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles2) == 0;
         if (cc->use_tiles) {
-            if (cc->tile_count.ensure(c->ntiles + 1) != hipSuccess || cc->tile_base.ensure(c->ntiles + 1) != hipSuccess ||
-                cc->tile_cursor.ensure(c->ntiles + 1) != hipSuccess)
+            if (cc->tile_count.ensure(c->ntiles2 + 1) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
+                cc->tile_cursor.ensure(c->ntiles2 + 1) != hipSuccess)
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for tile tables");
         }
         uint32_t cap = 1u << 16;
@@ -657,7 +662,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_MEMSET);
             if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
-            HIP_TRY(c, hipMemsetAsync(c->lca_count.p, 0, static_cast<size_t>(T) * 4, st));
+            if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->lca_count.p, 0, static_cast<size_t>(T) * 4, st));
             HIP_TRY(c, hipMemsetAsync(c->marks.p, 0, static_cast<size_t>(R) * 4, st));
             HIP_TRY(c, hipMemsetAsync(c->pair_tab.p, 0xff, static_cast<size_t>(c->pair_cap) * 8, st));
             HIP_TRY(c, hipMemsetAsync(c->counters.p + CNT_ERR, 0, 2 * sizeof(uint32_t), st));  // ERR, PAIRS
@@ -668,32 +673,33 @@ int slimm_filter_alignments(slimm_ctx* c) {
                 launch_filter_lca16(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p,
                                     c->d_rows16.p, c->d_level_taxon.p, h.level_offset(),
                                     c->use_tiles ? nullptr : c->ucov2(), c->use_tiles ? c->uniq_gbin.p : nullptr,
-                                    c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p, c->pair_cap - 1);
+                                    c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p, c->pair_cap - 1,
+                                    static_cast<uint32_t>(c->Bp));
             else
                 launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
                                   c->d_lin_dense.p, c->use_tiles ? nullptr : c->ucov2(),
                                   c->use_tiles ? c->uniq_gbin.p : nullptr, c->lca_count.p, c->marks.p, c->pair_tab.p,
-                                  c->pair_list.p, c->pair_cap - 1);
+                                  c->pair_list.p, c->pair_cap - 1, static_cast<uint32_t>(c->Bp));
         }
-        if (c->use_tiles) {  // uniq_cov2 from the per-read bins, through the same LDS tile histogram as phase A
+        if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
             const uint32_t grid = 512;
             {
                 KernelTimer t(c, K_TILE_COUNT2);
-                launch_tile_count(st, grid, c->ntiles, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p);
+                launch_tile_count(st, grid, c->ntiles2, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p);
             }
             {
                 KernelTimer t(c, K_TILE_SCAN2);
-                launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
                                  c->counters.p);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
-                launch_tile_scatter(st, grid, c->ntiles, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_base.p,
+                launch_tile_scatter(st, grid, c->ntiles2, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_base.p,
                                     c->tile_cursor.p, c->bucket.p);
             }
             {
                 KernelTimer t(c, K_TILE_HIST2);
-                launch_tile_hist(st, c->ntiles, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
+                launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
                                  c->ucov2(), nullptr);
             }
         }
@@ -704,7 +710,8 @@ int slimm_filter_alignments(slimm_ctx* c) {
         HIP_TRY(c, hipMemcpyAsync(c->h_stats.p + static_cast<size_t>(R) * 4, c->ref_stats.p + static_cast<size_t>(R) * 4,
                                   static_cast<size_t>(R) * 16, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(c->h_small.p, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(c->h_lca.p, c->lca_count.p, static_cast<size_t>(T) * 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(c->h_lca.p, c->use_tiles ? c->lca_tiles() : c->lca_count.p, static_cast<size_t>(T) * 4,
+                                  hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(c->h_marks.p, c->marks.p, static_cast<size_t>(R) * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         const uint32_t err = c->h_small.p[CNT_ERR];

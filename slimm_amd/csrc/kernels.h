@@ -49,17 +49,19 @@ void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, cons
                  uint32_t* cov, uint32_t* ucov);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
                       uint32_t* out);
-// ucov2 != nullptr: uniq_cov2[g]++ with a global atomic per unique-after-filter read (fallback);
-// uniq_gbin != nullptr: the bin of such a read (or 0xffffffff) is stored per read for the tile histogram instead.
+// ucov2 != nullptr: global atomics -- uniq_cov2[g]++ per unique-after-filter read, lca_count[t]++ per LCA read (fallback);
+// uniq_gbin != nullptr: one selector per read instead (its uniq_cov2 bin, taxon_base + its LCA taxon, or 0xffffffff),
+// counted afterwards by the tile histogram over the index space [uniq_cov2 bins | taxa].
 void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                        const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
                        uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
-                       uint64_t* pair_list, uint32_t pair_mask);
+                       uint64_t* pair_list, uint32_t pair_mask, uint32_t taxon_base);
 // 16-byte rows (per-level 16-bit indices + valid bit); level_off is a host array of 8 offsets into level_taxon
 void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                          const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
                          const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
-                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask);
+                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
+                         uint32_t taxon_base);
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----

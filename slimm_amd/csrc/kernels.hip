@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
                                                        uint32_t* __restrict__ uniq_gbin,
                                                        uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
                                                        uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
-                                                       uint32_t pair_mask) {
+                                                       uint32_t pair_mask, uint32_t taxon_base) {
     const uint32_t M = counters[CNT_M];
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     if (m >= M) return;
@@ -337,9 +337,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
             ++nv;
         }
     }
-    if (uniq_gbin) uniq_gbin[m] = (nv == 1) ? tgt_gbin[first_t] : 0xffffffffu;
+    uint32_t sel = 0xffffffffu;  // what this read adds one to: a uniq_cov2 bin, an LCA taxon counter, or nothing
     if (nv == 1) {
-        if (ucov2) atomicAdd(&ucov2[tgt_gbin[first_t]], 1u);
+        sel = tgt_gbin[first_t];
+        if (ucov2) atomicAdd(&ucov2[sel], 1u);
     } else if (nv > 1) {
         const uint32_t* lin = reinterpret_cast<const uint32_t*>(lin4);
         uint32_t taxon;
@@ -357,8 +358,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
                 if (valid[r]) pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
             }
         }
-        atomicAdd(&lca_count[taxon], 1u);
+        if (uniq_gbin)
+            sel = taxon_base + taxon;  // counted by the tile histogram: hot taxa make global atomics serialise
+        else
+            atomicAdd(&lca_count[taxon], 1u);
     }
+    if (uniq_gbin) uniq_gbin[m] = sel;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
                                                          uint32_t* __restrict__ ucov2, uint32_t* __restrict__ uniq_gbin,
                                                          uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
                                                          uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
-                                                         uint32_t pair_mask) {
+                                                         uint32_t pair_mask, uint32_t taxon_base) {
     const uint32_t M = counters[CNT_M];
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     if (m >= M) return;
@@ -422,9 +427,10 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
             ++nv;
         }
     }
-    if (uniq_gbin) uniq_gbin[m] = (nv == 1) ? tgt_gbin[first_t] : 0xffffffffu;
+    uint32_t sel = 0xffffffffu;  // what this read adds one to: a uniq_cov2 bin, an LCA taxon counter, or nothing
     if (nv == 1) {
-        if (ucov2) atomicAdd(&ucov2[tgt_gbin[first_t]], 1u);
+        sel = tgt_gbin[first_t];
+        if (ucov2) atomicAdd(&ucov2[sel], 1u);
     } else if (nv > 1) {
         uint32_t taxon;
         if (eq) {
@@ -442,8 +448,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
                     pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
             }
         }
-        atomicAdd(&lca_count[taxon], 1u);
+        if (uniq_gbin)
+            sel = taxon_base + taxon;  // counted by the tile histogram: hot taxa make global atomics serialise
+        else
+            atomicAdd(&lca_count[taxon], 1u);
     }
+    if (uniq_gbin) uniq_gbin[m] = sel;
 }
 
 // tail[0..3] = {hits, matches, targets, err}: the additive scalars that travel with the bins through the all-reduce
@@ -499,25 +509,26 @@ void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, cons
 void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                        const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
                        uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
-                       uint64_t* pair_list, uint32_t pair_mask) {
+                       uint64_t* pair_list, uint32_t pair_mask, uint32_t taxon_base) {
     uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
     if (blocks)
         hipLaunchKernelGGL(k_filter_lca, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters, valid,
                            reinterpret_cast<const uint4*>(lin_dense), ucov2, uniq_gbin, lca_count, marks, pair_tab, pair_list,
-                           pair_mask);
+                           pair_mask, taxon_base);
 }
 
 void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                          const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
                          const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
-                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask) {
+                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
+                         uint32_t taxon_base) {
     uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
     LevelOffsets lo;
     for (int i = 0; i < 8; ++i) lo.off[i] = level_off[i];
     if (blocks)
         hipLaunchKernelGGL(k_filter_lca16, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters,
                            reinterpret_cast<const uint4*>(rows16), level_taxon, lo, ucov2, uniq_gbin, lca_count, marks,
-                           pair_tab, pair_list, pair_mask);
+                           pair_tab, pair_list, pair_mask, taxon_base);
 }
 
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail) {

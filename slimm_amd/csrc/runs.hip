@@ -97,7 +97,7 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
 template <typename Acc>
 __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __restrict__ counters, uint8_t* __restrict__ fl,
                                                   uint2* __restrict__ tile_cnt, uint32_t* __restrict__ tile_valid) {
-    __shared__ uint32_t s_meta[kRTile + kHalo + kRBlock];
+    __shared__ uint32_t s_meta[kRTile + kHalo];
     __shared__ uint2 s_w[kRWaves];
     __shared__ uint32_t s_v[kRWaves];
     const uint32_t N = acc.count(counters);
@@ -107,107 +107,70 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
     if (base < N) {
         const uint32_t lds_lo = base >= kHalo ? base - kHalo : 0u;
         const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
-        const uint32_t lane = threadIdx.x & 63u;
-        // ---- stage the meta words: all global loads of the tile are issued before the first one is consumed ----
-        constexpr int kFill = (kRTile + kHalo + kRBlock - 1) / kRBlock;  // 9 slices of 256 records
-        uint64_t key[kFill], kprev0[kFill];
-        uint32_t meta[kFill];
-#pragma unroll
-        for (int k = 0; k < kFill; ++k) {
-            const uint32_t i = lds_lo + k * kRBlock + threadIdx.x;
-            const bool live = i < lds_hi;
-            key[k] = live ? acc.key_of(i) : 0ull;
-            meta[k] = live ? acc.meta_of(i, bad) : 0u;
-            // the predecessor's key comes from the neighbouring lane; lane 0 of each wave fetches its own
-            kprev0[k] = (live && lane == 0 && i > 0) ? acc.key_of(i - 1) : 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < kFill; ++k) {
-            const uint32_t i = lds_lo + k * kRBlock + threadIdx.x;
-            uint64_t prev = __shfl_up(key[k], 1, 64);
-            if (lane == 0) prev = kprev0[k];
-            if (i == 0 || key[k] != prev) meta[k] |= M_RUN;
-            if (i < lds_hi) s_meta[i - lds_lo] = meta[k];
-        }
+        for (uint32_t i = lds_lo + threadIdx.x; i < lds_hi; i += kRBlock) s_meta[i - lds_lo] = full_meta(acc, i, bad);
         __syncthreads();
-        // ---- classify: look-back through LDS, one distance per trip for the whole wave (wave-uniform loop with a
-        // predicated body), four 256-record slices interleaved so four independent LDS reads are in flight per trip ----
-        constexpr int kIlp = 4;
-#pragma unroll 1
-        for (int k0 = 0; k0 < kRItems; k0 += kIlp) {
-            uint32_t li[kIlp], me[kIlp], my_ident[kIlp], my_mate[kIlp];
-            bool live[kIlp], valid[kIlp], head[kIlp], first[kIlp], gb[kIlp], active[kIlp], open[kIlp];
-            bool any_active = false;
-#pragma unroll
-            for (int u = 0; u < kIlp; ++u) {
-                const uint32_t i = base + (k0 + u) * kRBlock + threadIdx.x;
-                live[u] = i < N;
-                li[u] = live[u] ? i - lds_lo : 0u;
-                me[u] = live[u] ? s_meta[li[u]] : M_RUN;  // dead lanes: not mapped, never walk
-                valid[u] = me[u] & M_VALID;
-                my_ident[u] = me[u] & M_IDENT;
-                my_mate[u] = (me[u] >> 28) & 3u;
-                head[u] = first[u] = true;
-                gb[u] = open[u] = false;
-                active[u] = valid[u] && !(me[u] & M_RUN);
-                any_active = any_active || active[u];
+        for (int k = 0; k < kRItems; ++k) {
+            const uint32_t i = base + k * kRBlock + threadIdx.x;
+            const bool live = i < N;
+            const uint32_t li = live ? i - lds_lo : 0u;
+            const uint32_t me = live ? s_meta[li] : M_RUN;  // dead lanes: not mapped, never walk
+            const bool valid = me & M_VALID;
+            const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
+            // Look-back through LDS, one distance per trip for the whole wave.  The per-lane state lives in VGPRs as
+            // 0/1 integers and is updated with plain integer arithmetic: C++ bools would become 64-bit lane masks in
+            // SGPRs, and the CU's single scalar ALU -- shared by all four SIMDs -- was the measured bottleneck
+            // (62 M SALU instructions per launch at config 2).
+            uint32_t act = (valid && !(me & M_RUN)) ? 1u : 0u;
+            uint32_t headb = 1u, firstb = 1u, gbb = 0u, openb = 0u;
+            for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
+                const uint32_t diff = li - d;                         // negative (bit 31) once d > li
+                const uint32_t inn = act & ((~diff) >> 31);           // still inside the staged window
+                const uint32_t m = s_meta[diff & (0u - inn)];
+                const uint32_t v = inn & (m >> 31);                   // a mapped record of this run
+                const uint32_t x = (m ^ me) & M_IDENT;                // 0 <=> same read and same reference
+                const uint32_t same = v & (((x | (0u - x)) >> 31) ^ 1u);
+                const uint32_t xm = x >> 28;                          // 0 <=> same mate
+                const uint32_t eqm = ((xm | (0u - xm)) >> 31) ^ 1u;
+                const uint32_t gt = (my_mate - ((m >> 28) & 3u)) >> 31;  // its mate is larger than mine
+                headb &= ~(v & eqm);
+                firstb &= ~same;
+                gbb |= v & gt;
+                openb |= act & (inn ^ 1u);
+                act = inn & (same ^ 1u) & (((m >> 30) & 1u) ^ 1u);    // stop at a duplicate or at the run start
             }
-            for (uint32_t d = 1; __ballot(any_active) != 0ull; ++d) {
-                uint32_t m[kIlp];
-                bool in[kIlp];
-#pragma unroll
-                for (int u = 0; u < kIlp; ++u) {
-                    in[u] = active[u] && d <= li[u];
-                    m[u] = s_meta[in[u] ? li[u] - d : 0u];
-                }
-                any_active = false;
-#pragma unroll
-                for (int u = 0; u < kIlp; ++u) {
-                    const bool v = in[u] && (m[u] & M_VALID);
-                    const uint32_t mt = (m[u] >> 28) & 3u;
-                    const bool same = v && ((m[u] & M_IDENT) == my_ident[u]);
-                    head[u] = head[u] && !(v && mt == my_mate[u]);
-                    first[u] = first[u] && !same;
-                    gb[u] = gb[u] || (v && mt > my_mate[u]);
-                    open[u] = open[u] || (active[u] && !in[u]);
-                    active[u] = in[u] && !same && !(m[u] & M_RUN);
-                    any_active = any_active || active[u];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < kIlp; ++u) {
-                if (open[u]) {  // the run reaches back beyond the halo: continue in global memory (rare)
-                    uint32_t j = lds_lo, steps = 0;
-                    while (j > 0) {
-                        --j;
-                        bool dummy = false;
-                        const uint32_t m = full_meta(acc, j, dummy);
-                        if (m & M_VALID) {
-                            const uint32_t mt = (m >> 28) & 3u;
-                            if ((m & M_IDENT) == my_ident[u]) {
-                                head[u] = false;
-                                first[u] = false;
-                                break;
-                            }
-                            head[u] = head[u] && (mt != my_mate[u]);
-                            gb[u] = gb[u] || (mt > my_mate[u]);
-                        }
-                        if (m & M_RUN) break;
-                        if (++steps > kLookBackMax) {
-                            too_long = true;
+            bool head = headb & 1u, first = firstb & 1u, greater_before = gbb & 1u;
+            const bool open = openb & 1u;  // ran out of staged records before the run start
+            if (open) {  // the run reaches back beyond the halo: continue in global memory (rare)
+                uint32_t j = lds_lo, steps = 0;
+                while (j > 0) {
+                    --j;
+                    bool dummy = false;
+                    const uint32_t m = full_meta(acc, j, dummy);
+                    if (m & M_VALID) {
+                        const uint32_t mt = (m >> 28) & 3u;
+                        if ((m & M_IDENT) == my_ident) {
+                            head = false;
+                            first = false;
                             break;
                         }
+                        head = head && (mt != my_mate);
+                        greater_before = greater_before || (mt > my_mate);
+                    }
+                    if (m & M_RUN) break;
+                    if (++steps > kLookBackMax) {
+                        too_long = true;
+                        break;
                     }
                 }
-                const bool h = head[u] && valid[u], f1 = first[u] && valid[u];
-                const uint32_t f = (my_mate[u] << FL_MATE_SHIFT) | ((me[u] & M_RUN) ? FL_RUN_START : 0u) |
-                                   (h ? FL_HEAD : 0u) | (f1 ? FL_FIRST : 0u) |
-                                   ((valid[u] && gb[u]) ? FL_GREATER_BEFORE : 0u);
-                nh += h;
-                nf += f1;
-                nv += valid[u];
-                if (live[u]) fl[base + (k0 + u) * kRBlock + threadIdx.x] = static_cast<uint8_t>(f);
             }
+            head = head && valid;
+            first = first && valid;
+            uint32_t f = (my_mate << FL_MATE_SHIFT) | ((me & M_RUN) ? FL_RUN_START : 0u) | (head ? FL_HEAD : 0u) |
+                         (first ? FL_FIRST : 0u) | ((valid && greater_before) ? FL_GREATER_BEFORE : 0u);
+            nh += head;
+            nf += first;
+            nv += valid;
+            if (live) fl[i] = static_cast<uint8_t>(f);
         }
     }
     nh = r_wave_sum(nh);
@@ -277,19 +240,21 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         uint32_t m = running.x + before.x + rh;
         // Reads of one qName run are laid out by ascending mate.  Both corrections are wave-uniform loops over the
         // distance with predicated bodies; runs leaving the staged window finish in global memory (rare).
+        // (integer 0/1 lane state in VGPRs instead of bools: see k_runs)
         {   // earlier records of the run with a larger mate sit AFTER this one in the target order
-            bool act = first && (f & FL_GREATER_BEFORE) && !(f & FL_RUN_START);
-            bool open = false;
-            for (uint32_t d = 1; __ballot(act) != 0ull; ++d) {
-                const bool in = act && d <= li;
-                const uint32_t g = s_fl[in ? li - d : 0u];
-                const bool bigger = in && ((g >> FL_MATE_SHIFT) & 3u) > mate;
-                t -= (bigger && (g & FL_FIRST)) ? 1u : 0u;
-                m -= (bigger && (g & FL_HEAD)) ? 1u : 0u;
-                open = open || (act && !in);
-                act = in && !(g & FL_RUN_START);
+            uint32_t act = (first && (f & FL_GREATER_BEFORE) && !(f & FL_RUN_START)) ? 1u : 0u;
+            uint32_t openb = 0u;
+            for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
+                const uint32_t diff = li - d;
+                const uint32_t inn = act & ((~diff) >> 31);
+                const uint32_t g = s_fl[diff & (0u - inn)];
+                const uint32_t bigger = inn & ((mate - ((g >> FL_MATE_SHIFT) & 3u)) >> 31);  // its mate > mine
+                t -= bigger & (g >> 1);   // FL_FIRST is bit 1
+                m -= bigger & g;          // FL_HEAD is bit 0
+                openb |= act & (inn ^ 1u);
+                act = inn & (((g >> 4) & 1u) ^ 1u);  // stop at the run start (bit 4)
             }
-            if (open) {
+            if (openb & 1u) {
                 uint32_t j = lds_lo, steps = 0;
                 while (j > 0) {
                     --j;
@@ -307,19 +272,21 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
             }
         }
         {   // later records of the run with a smaller mate sit BEFORE this one
-            bool act = first && mate > 0;
-            bool open = false;
-            for (uint32_t d = 1; __ballot(act) != 0ull; ++d) {
-                const bool in = act && (i + d) < lds_hi;
-                const uint32_t g = s_fl[in ? li + d : 0u];
-                const bool stop = in && (g & FL_RUN_START);
-                const bool smaller = in && !stop && ((g >> FL_MATE_SHIFT) & 3u) < mate;
-                t += (smaller && (g & FL_FIRST)) ? 1u : 0u;
-                m += (smaller && (g & FL_HEAD)) ? 1u : 0u;
-                open = open || (act && !in && (i + d) < N);
-                act = in && !stop;
+            const uint32_t room = lds_hi - lds_lo;  // staged records
+            uint32_t act = (first && mate > 0) ? 1u : 0u;
+            uint32_t openb = 0u;
+            for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
+                const uint32_t j = li + d;
+                const uint32_t inn = act & ((j - room) >> 31);           // j < room
+                const uint32_t g = s_fl[j & (0u - inn)];
+                const uint32_t go = inn & (((g >> 4) & 1u) ^ 1u);        // not a run start: still my run
+                const uint32_t smaller = go & ((((g >> FL_MATE_SHIFT) & 3u) - mate) >> 31);  // its mate < mine
+                t += smaller & (g >> 1);
+                m += smaller & g;
+                openb |= act & (inn ^ 1u) & (((lds_lo + j) - N) >> 31);  // window ended, the stream did not
+                act = go;
             }
-            if (open) {
+            if (openb & 1u) {
                 uint32_t steps = 0;
                 for (uint32_t j = lds_hi; j < N; ++j) {
                     const uint32_t g = fl[j];

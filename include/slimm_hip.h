@@ -85,6 +85,11 @@ int slimm_reset(slimm_ctx* ctx);
 /* Clears the cached cut-offs as well (a fresh `slimm` object). */
 int slimm_reset_cutoffs(slimm_ctx* ctx);
 
+/* The cached cut-offs (src/slimm.hpp:155-156).  In the reference's -d mode one `slimm` object serves all files, so
+ * files 2+ reuse file 1's cut-offs (Q8); a host that creates one context per file carries them over with these. */
+int slimm_get_cutoff_cache(slimm_ctx* ctx, float* coverage_cut_off, float* uniq_coverage_cut_off);
+int slimm_set_cutoff_cache(slimm_ctx* ctx, float coverage_cut_off, float uniq_coverage_cut_off);
+
 /* ---- record stream: what the loop of analyze_alignments() reads from each BamAlignmentRecord
  *      (src/slimm.hpp:194-211): qName identity, flag, rID, beginPos; file order. ------------------
  * read_key: identity of the qName (equal names <=> equal keys); only the low 62 bits are significant

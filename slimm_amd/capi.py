@@ -69,6 +69,8 @@ SYMBOLS = [
     ("slimm_last_error", C.c_char_p, [_P]),
     ("slimm_reset", C.c_int, [_P]),
     ("slimm_reset_cutoffs", C.c_int, [_P]),
+    ("slimm_get_cutoff_cache", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("slimm_set_cutoff_cache", C.c_int, [_P, C.c_float, C.c_float]),
     ("slimm_reserve", C.c_int, [_P, C.c_uint64]),
     ("slimm_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_set_records_device", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),

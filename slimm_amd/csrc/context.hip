@@ -402,6 +402,18 @@ int slimm_reset_cutoffs(slimm_ctx* c) {
     return SLIMM_OK;
 }
 
+int slimm_get_cutoff_cache(slimm_ctx* c, float* cc, float* ucc) {
+    if (!c || !cc || !ucc) return SLIMM_E_INVALID;
+    c->host->get_cutoff_cache(*cc, *ucc);
+    return SLIMM_OK;
+}
+
+int slimm_set_cutoff_cache(slimm_ctx* c, float cc, float ucc) {
+    if (!c) return SLIMM_E_INVALID;
+    c->host->set_cutoff_cache(cc, ucc);
+    return SLIMM_OK;
+}
+
 int slimm_reserve(slimm_ctx* c, uint64_t n) {
     if (!c) return SLIMM_E_INVALID;
     if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");

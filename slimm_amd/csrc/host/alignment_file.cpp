@@ -1,0 +1,324 @@
+#include "alignment_file.hpp"
+
+#include <zlib.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <unordered_map>
+
+namespace slimm {
+
+// wyhash-style 64-bit mix of the name bytes, folded to 62 bits
+uint64_t hash_read_name(const char* s, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdULL);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, s + i, 8);
+        h ^= w;
+        h *= 0xff51afd7ed558ccdULL;
+        h ^= h >> 32;
+    }
+    uint64_t tail = 0;
+    memcpy(&tail, s + i, n - i);
+    h ^= tail;
+    h *= 0xc4ceb9fe1a85ec53ULL;
+    h ^= h >> 29;
+    h *= 0xff51afd7ed558ccdULL;
+    h ^= h >> 32;
+    return h >> 2;
+}
+
+AlignmentFile::~AlignmentFile() { close(); }
+
+void AlignmentFile::close() {
+    if (fp_) fclose(fp_);
+    fp_ = nullptr;
+}
+
+static uint32_t rd_u32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
+static uint16_t rd_u16(const uint8_t* p) { return static_cast<uint16_t>(p[0] | (p[1] << 8)); }
+
+bool AlignmentFile::open(const std::string& path) {
+    close();
+    ref_names_.clear();
+    ref_len_.clear();
+    sam_index_.clear();
+    buf_.clear();
+    pos_ = 0;
+    eof_ = false;
+    have_pending_ = false;
+    order_ = SortOrder::Unknown;
+    fp_ = fopen(path.c_str(), "rb");
+    if (!fp_) {
+        err_ = "Could not open " + path + "!";
+        return false;
+    }
+    unsigned char magic[2] = {0, 0};
+    size_t got = fread(magic, 1, 2, fp_);
+    rewind(fp_);
+    bam_ = (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+    bool ok = bam_ ? read_bam_header() : read_sam_header();
+    if (!ok && err_.empty()) err_ = "bad header in " + path;
+    return ok;
+}
+
+// ---- BGZF ------------------------------------------------------------------------------------------------------
+bool AlignmentFile::inflate_block() {
+    uint8_t hdr[12];
+    size_t got = fread(hdr, 1, 12, fp_);
+    if (got == 0) {
+        eof_ = true;
+        return false;
+    }
+    if (got != 12 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
+        err_ = "not a BGZF block";
+        return false;
+    }
+    uint16_t xlen = rd_u16(hdr + 10);
+    std::vector<uint8_t> extra(xlen);
+    if (fread(extra.data(), 1, xlen, fp_) != xlen) {
+        err_ = "truncated BGZF header";
+        return false;
+    }
+    int bsize = -1;
+    for (size_t o = 0; o + 4 <= extra.size();) {
+        uint16_t slen = rd_u16(&extra[o + 2]);
+        if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) bsize = rd_u16(&extra[o + 4]);
+        o += 4 + slen;
+    }
+    if (bsize < 0) {
+        err_ = "BGZF block without BC field";
+        return false;
+    }
+    size_t clen = static_cast<size_t>(bsize) + 1 - 12 - xlen;  // deflate data + crc32 + isize
+    if (clen < 8) {
+        err_ = "bad BGZF block size";
+        return false;
+    }
+    cbuf_.resize(clen);
+    if (fread(cbuf_.data(), 1, clen, fp_) != clen) {
+        err_ = "truncated BGZF block";
+        return false;
+    }
+    uint32_t isize = rd_u32(&cbuf_[clen - 4]);
+    if (isize == 0) return true;  // empty block (the EOF marker)
+    // drop consumed bytes now and then so the window does not grow without bound
+    if (pos_ > (1u << 20)) {
+        buf_.erase(buf_.begin(), buf_.begin() + static_cast<long>(pos_));
+        pos_ = 0;
+    }
+    size_t old = buf_.size();
+    buf_.resize(old + isize);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) {
+        err_ = "zlib init failed";
+        return false;
+    }
+    zs.next_in = cbuf_.data();
+    zs.avail_in = static_cast<uInt>(clen - 8);
+    zs.next_out = buf_.data() + old;
+    zs.avail_out = isize;
+    int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) {
+        err_ = "corrupt BGZF block";
+        return false;
+    }
+    if (crc32(crc32(0L, Z_NULL, 0), buf_.data() + old, isize) != rd_u32(&cbuf_[clen - 8])) {
+        err_ = "BGZF CRC mismatch";
+        return false;
+    }
+    return true;
+}
+
+bool AlignmentFile::fill(size_t need) {
+    while (buf_.size() - pos_ < need) {
+        if (!inflate_block()) return false;
+    }
+    return true;
+}
+
+void AlignmentFile::parse_hd_line(const std::string& line) {
+    // @HD ... SO:<order> GO:<grouping>
+    size_t so = line.find("\tSO:");
+    if (so != std::string::npos) {
+        std::string v = line.substr(so + 4, line.find_first_of("\t\r\n", so + 4) - (so + 4));
+        if (v == "queryname") order_ = SortOrder::QueryName;
+        else if (v == "coordinate") order_ = SortOrder::Coordinate;
+        else if (v == "unsorted") order_ = SortOrder::Unsorted;
+    }
+    size_t go = line.find("\tGO:");
+    if (go != std::string::npos) {
+        std::string v = line.substr(go + 4, line.find_first_of("\t\r\n", go + 4) - (go + 4));
+        if (v == "query" && order_ != SortOrder::QueryName) order_ = SortOrder::QueryGrouped;
+    }
+}
+
+bool AlignmentFile::read_bam_header() {
+    if (!fill(12)) return false;
+    if (memcmp(&buf_[pos_], "BAM\1", 4) != 0) {
+        err_ = "missing BAM magic";
+        return false;
+    }
+    uint32_t l_text = rd_u32(&buf_[pos_ + 4]);
+    pos_ += 8;
+    if (!fill(l_text + 4)) return false;
+    std::string text(reinterpret_cast<const char*>(&buf_[pos_]), l_text);
+    pos_ += l_text;
+    if (text.compare(0, 3, "@HD") == 0) parse_hd_line(text.substr(0, text.find('\n')));
+    uint32_t n_ref = rd_u32(&buf_[pos_]);
+    pos_ += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (!fill(4)) return false;
+        uint32_t l_name = rd_u32(&buf_[pos_]);
+        pos_ += 4;
+        if (!fill(l_name + 4)) return false;
+        ref_names_.emplace_back(reinterpret_cast<const char*>(&buf_[pos_]), l_name ? l_name - 1 : 0);
+        pos_ += l_name;
+        ref_len_.push_back(rd_u32(&buf_[pos_]));
+        pos_ += 4;
+    }
+    return true;
+}
+
+// ---- SAM text --------------------------------------------------------------------------------------------------
+bool AlignmentFile::next_sam_line(std::string& line) {
+    line.clear();
+    while (true) {
+        if (pos_ >= buf_.size()) {
+            buf_.resize(1 << 20);
+            size_t got = fread(buf_.data(), 1, buf_.size(), fp_);
+            buf_.resize(got);
+            pos_ = 0;
+            if (got == 0) {
+                eof_ = true;
+                return !line.empty();
+            }
+        }
+        const uint8_t* b = buf_.data() + pos_;
+        const uint8_t* e = static_cast<const uint8_t*>(memchr(b, '\n', buf_.size() - pos_));
+        if (e) {
+            line.append(reinterpret_cast<const char*>(b), e - b);
+            pos_ += static_cast<size_t>(e - b) + 1;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            return true;
+        }
+        line.append(reinterpret_cast<const char*>(b), buf_.size() - pos_);
+        pos_ = buf_.size();
+    }
+}
+
+bool AlignmentFile::read_sam_header() {
+    std::string line;
+    while (next_sam_line(line)) {
+        if (line.empty()) continue;
+        if (line[0] != '@') {
+            pending_line_ = line;
+            have_pending_ = true;
+            break;
+        }
+        if (line.compare(0, 3, "@HD") == 0) parse_hd_line(line);
+        if (line.compare(0, 3, "@SQ") == 0) {
+            std::string name;
+            uint32_t len = 0;
+            size_t p = 3;
+            while (p < line.size()) {
+                size_t q = line.find('\t', p + 1);
+                if (q == std::string::npos) q = line.size();
+                if (line.compare(p + 1, 3, "SN:") == 0) name = line.substr(p + 4, q - p - 4);
+                if (line.compare(p + 1, 3, "LN:") == 0) len = static_cast<uint32_t>(strtoul(line.c_str() + p + 4, nullptr, 10));
+                p = q;
+            }
+            ref_names_.push_back(name);
+            ref_len_.push_back(len);
+        }
+    }
+    return true;
+}
+
+long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_names) {
+    long n = 0;
+    if (bam_) {
+        while (static_cast<size_t>(n) < max_records) {
+            if (!fill(4)) {
+                if (eof_ && buf_.size() == pos_) break;
+                return err_.empty() ? n : -1;
+            }
+            uint32_t bs = rd_u32(&buf_[pos_]);
+            if (bs < 32) {
+                err_ = "bad BAM record size";
+                return -1;
+            }
+            if (!fill(4 + static_cast<size_t>(bs))) {
+                err_ = "truncated BAM record";
+                return -1;
+            }
+            const uint8_t* r = &buf_[pos_ + 4];
+            int32_t ref_id = static_cast<int32_t>(rd_u32(r));
+            int32_t pos = static_cast<int32_t>(rd_u32(r + 4));
+            uint8_t l_read_name = r[8];
+            uint16_t flag = rd_u16(r + 14);
+            uint32_t l_seq = rd_u32(r + 16);
+            const char* name = reinterpret_cast<const char*>(r + 32);
+            size_t nlen = l_read_name ? l_read_name - 1u : 0u;
+            if (32u + l_read_name > bs) {
+                err_ = "bad BAM read name length";
+                return -1;
+            }
+            out.read_key.push_back(hash_read_name(name, nlen));
+            out.ref_id.push_back(ref_id);
+            out.begin_pos.push_back(pos);
+            out.flag.push_back(flag);
+            out.l_seq.push_back(l_seq);
+            if (keep_names) out.qname.emplace_back(name, nlen);
+            pos_ += 4 + static_cast<size_t>(bs);
+            ++n;
+        }
+        return n;
+    }
+    // SAM: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL ...
+    if (sam_index_.empty() && !ref_names_.empty()) {
+        sam_index_.reserve(ref_names_.size() * 2);
+        for (size_t i = 0; i < ref_names_.size(); ++i) sam_index_.emplace(ref_names_[i], static_cast<int32_t>(i));
+    }
+    const std::unordered_map<std::string, int32_t>& index = sam_index_;
+    std::string line;
+    while (static_cast<size_t>(n) < max_records) {
+        if (have_pending_) {
+            line.swap(pending_line_);
+            have_pending_ = false;
+        } else if (!next_sam_line(line)) {
+            break;
+        }
+        if (line.empty() || line[0] == '@') continue;
+        size_t f[11];
+        size_t nf = 0, p = 0;
+        f[nf++] = 0;
+        while (nf < 11 && (p = line.find('\t', p)) != std::string::npos) f[nf++] = ++p;
+        if (nf < 10) {
+            err_ = "SAM line with fewer than 10 fields";
+            return -1;
+        }
+        auto field = [&](size_t k) { return line.substr(f[k], (k + 1 < nf ? f[k + 1] - 1 : line.size()) - f[k]); };
+        std::string qn = field(0), rn = field(2), seq = field(9);
+        uint16_t flag = static_cast<uint16_t>(strtoul(line.c_str() + f[1], nullptr, 10));
+        long pos1 = strtol(line.c_str() + f[3], nullptr, 10);
+        int32_t ref_id = -1;
+        if (rn != "*") {
+            auto it = index.find(rn);
+            if (it != index.end()) ref_id = it->second;
+        }
+        out.read_key.push_back(hash_read_name(qn.data(), qn.size()));
+        out.ref_id.push_back(ref_id);
+        out.begin_pos.push_back(static_cast<int32_t>(pos1 - 1));  // SAM POS is 1-based; 0 ("unavailable") becomes -1
+        out.flag.push_back(flag);
+        out.l_seq.push_back(seq == "*" ? 0u : static_cast<uint32_t>(seq.size()));
+        if (keep_names) out.qname.push_back(qn);
+        ++n;
+    }
+    return n;
+}
+
+}  // namespace slimm

@@ -1,0 +1,521 @@
+// `slimm [OPTIONS] DB.sldb IN` -- the reference's command line (reference src/slimm.cpp:60-204) on top of the C ABI.
+//
+// Same options, defaults and output files as the reference; the per-file driver follows slimm::get_profiles()
+// (reference src/slimm.hpp:395-496) step for step, with the three hot phases running on the MI355X through
+// include/slimm_hip.h.  Extra options (no reference counterpart): --device N, --query-grouped, --any-order,
+// --dump-records (decode only, for reader tests on machines without a GPU).
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <numeric>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/slimm_hip.h"
+#include "alignment_file.hpp"
+#include "sldb.hpp"
+
+namespace {
+
+using namespace slimm;
+
+struct Options {  // arg_options, reference src/slimm.hpp:49-87
+    float cov_cut_off = 0.95f, abundance_cut_off = 0.01f;
+    uint32_t bin_width = 0, min_reads = 0;
+    bool verbose = false, is_directory = false, raw_output = false, coverage_output = false;
+    std::string rank = "species", input_path, output_prefix, database_path;
+    // extensions
+    int device = 0;
+    int order = -1;  // -1: from the @HD line
+    bool dump_records = false;
+};
+
+const char* kRankList[] = {"strains", "species", "genus", "family", "order", "class", "phylum", "superkingdom"};
+
+// ---- reference src/file_helper.hpp:88-123 ----
+std::string get_file_name(const std::string& s) { return s.substr(s.find_last_of("/\\") + 1); }
+std::string get_directory(const std::string& s) { return s.substr(0, s.find_last_of("/\\")); }
+std::string get_tsv_file_name(const std::string& prefix, const std::string& input) {
+    std::string dir = get_directory(prefix), file = get_file_name(prefix);
+    if (file.empty()) {
+        file = get_file_name(input);
+        auto ends = [&](const char* ext) {
+            size_t p = file.find(ext);
+            return p != std::string::npos && p == file.find_last_of(".");
+        };
+        if (ends(".sam") || ends(".bam")) file.replace(file.find_last_of("."), 4, "");
+    }
+    return dir + "/" + file;  // with no '/' in the prefix `dir` is the whole prefix (Q15)
+}
+std::string get_tsv_file_name(const std::string& prefix, const std::string& input, const std::string& suffix) {
+    return get_tsv_file_name(prefix, input) + suffix + ".tsv";
+}
+std::vector<std::string> get_bam_files_in_directory(const std::string& directory) {  // src/file_helper.hpp:51-86
+    std::vector<std::string> out;
+    DIR* dir = opendir(directory.c_str());
+    if (!dir) return out;
+    while (dirent* ent = readdir(dir)) {
+        const std::string name = ent->d_name, full = directory + "/" + name;
+        if (name.empty() || name[0] == '.') continue;
+        struct stat st;
+        if (stat(full.c_str(), &st) == -1 || (st.st_mode & S_IFDIR)) continue;
+        if (full.find(".sam") == full.find_last_of(".") || full.find(".bam") == full.find_last_of(".")) out.push_back(full);
+    }
+    closedir(dir);
+    return out;
+}
+
+std::string get_accession_id(const std::string& name) {  // src/misc.hpp:415-422
+    size_t i = 0;
+    while (i < name.size()) {
+        unsigned char c = static_cast<unsigned char>(name[i]);
+        if (c == '.' || c == '|' || c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f') break;
+        ++i;
+    }
+    return name.substr(0, i);
+}
+
+struct Lap {  // Timer<> of src/timer.hpp: whole seconds
+    std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now(), lap_start = start;
+    long lap() {
+        auto now = std::chrono::steady_clock::now();
+        long s = std::chrono::duration_cast<std::chrono::seconds>(now - lap_start).count();
+        lap_start = now;
+        return s;
+    }
+    long elapsed() const {
+        return std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - start).count();
+    }
+};
+
+void usage() {
+    std::cerr << "slimm - Species Level Identification of Microbes from Metagenomes (MI355X path)\n"
+                 "usage: slimm [OPTIONS] \"DB\" \"IN\"\n"
+                 "  -o,  --output-prefix PREFIX   output path prefix (default: IN)\n"
+                 "  -w,  --bin-width INT          width of a single bin in nucleotides (default 0 = average read length)\n"
+                 "  -mr, --min-reads INT          minimum number of matching reads to consider a reference present\n"
+                 "  -r,  --rank STRING            strains|species|genus|family|order|class|phylum|superkingdom (default species)\n"
+                 "  -cc, --cov-cut-off DOUBLE     quantile of coverages used as cut-off, in [0, 1] (default 0.95)\n"
+                 "  -ac, --abundance-cut-off DOUBLE  do not report abundances below this, in [0, 10] (default 0.01)\n"
+                 "  -d,  --directory              IN is a directory of SAM/BAM files\n"
+                 "  -ro, --raw-output             write raw reference statistics\n"
+                 "  -co, --coverage-output        write raw coverage statistics\n"
+                 "  -v,  --verbose\n"
+                 "       --device N | --query-grouped | --any-order | --dump-records\n";
+}
+
+// 0 ok, 1 error, 2 help
+int parse(int argc, char** argv, Options& o) {
+    std::vector<std::string> pos;
+    bool have_prefix = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto value = [&](std::string& dst) {
+            if (i + 1 >= argc) {
+                std::cerr << "slimm: option " << a << " needs a value\n";
+                return false;
+            }
+            dst = argv[++i];
+            return true;
+        };
+        std::string v;
+        if (a == "-h" || a == "--help") {
+            usage();
+            return 2;
+        } else if (a == "-o" || a == "--output-prefix") {
+            if (!value(o.output_prefix)) return 1;
+            have_prefix = true;
+        } else if (a == "-w" || a == "--bin-width") {
+            if (!value(v)) return 1;
+            o.bin_width = static_cast<uint32_t>(strtoul(v.c_str(), nullptr, 10));
+        } else if (a == "-mr" || a == "--min-reads") {
+            if (!value(v)) return 1;
+            o.min_reads = static_cast<uint32_t>(strtoul(v.c_str(), nullptr, 10));
+        } else if (a == "-r" || a == "--rank") {
+            if (!value(o.rank)) return 1;
+            if (std::find_if(std::begin(kRankList), std::end(kRankList), [&](const char* r) { return o.rank == r; }) ==
+                std::end(kRankList)) {
+                std::cerr << "slimm: invalid rank '" << o.rank << "'\n";
+                return 1;
+            }
+        } else if (a == "-cc" || a == "--cov-cut-off") {
+            if (!value(v)) return 1;
+            double d = strtod(v.c_str(), nullptr);
+            if (d < 0.0 || d > 1.0) {
+                std::cerr << "slimm: cov-cut-off must be in [0, 1]\n";
+                return 1;
+            }
+            o.cov_cut_off = static_cast<float>(d);
+        } else if (a == "-ac" || a == "--abundance-cut-off") {
+            if (!value(v)) return 1;
+            double d = strtod(v.c_str(), nullptr);
+            if (d < 0.0 || d > 10.0) {
+                std::cerr << "slimm: abundance-cut-off must be in [0, 10]\n";
+                return 1;
+            }
+            o.abundance_cut_off = static_cast<float>(d);
+        } else if (a == "-d" || a == "--directory") {
+            o.is_directory = true;
+        } else if (a == "-ro" || a == "--raw-output") {
+            o.raw_output = true;
+        } else if (a == "-co" || a == "--coverage-output") {
+            o.coverage_output = true;
+        } else if (a == "-v" || a == "--verbose") {
+            o.verbose = true;
+        } else if (a == "--device") {
+            if (!value(v)) return 1;
+            o.device = atoi(v.c_str());
+        } else if (a == "--query-grouped") {
+            o.order = SLIMM_ORDER_GROUPED;
+        } else if (a == "--any-order") {
+            o.order = SLIMM_ORDER_ANY;
+        } else if (a == "--dump-records") {
+            o.dump_records = true;
+        } else if (!a.empty() && a[0] == '-' && a.size() > 1) {
+            std::cerr << "slimm: unknown option " << a << "\n";
+            return 1;
+        } else {
+            pos.push_back(a);
+        }
+    }
+    if (o.dump_records && pos.size() == 1) {
+        o.input_path = pos[0];
+        return 0;
+    }
+    if (pos.size() != 2) {
+        usage();
+        return 1;
+    }
+    o.database_path = pos[0];
+    o.input_path = pos[1];
+    if (o.database_path.size() < 5 || o.database_path.substr(o.database_path.size() - 5) != ".sldb") {
+        std::cerr << "slimm: the database must be a .sldb file\n";
+        return 1;
+    }
+    if (!have_prefix) o.output_prefix = o.input_path;  // src/slimm.cpp:175-177
+    return 0;
+}
+
+int dump_records(const Options& o) {
+    AlignmentFile f;
+    if (!f.open(o.input_path)) {
+        std::cerr << f.error() << "\n";
+        return 1;
+    }
+    std::cout << "#format\t" << (f.is_bam() ? "BAM" : "SAM") << "\torder\t" << static_cast<int>(f.sort_order()) << "\n";
+    for (size_t i = 0; i < f.ref_names().size(); ++i) std::cout << "@\t" << f.ref_names()[i] << "\t" << f.ref_lengths()[i] << "\n";
+    RecordBatch b;
+    long n;
+    while ((n = f.read_batch(b, 1 << 16, true)) > 0) {
+        for (size_t i = 0; i < b.size(); ++i)
+            std::cout << b.qname[i] << "\t" << b.flag[i] << "\t" << b.ref_id[i] << "\t" << b.begin_pos[i] << "\t" << b.l_seq[i]
+                      << "\t" << b.read_key[i] << "\n";
+        b.clear();
+    }
+    if (n < 0) {
+        std::cerr << f.error() << "\n";
+        return 1;
+    }
+    return 0;
+}
+
+struct Session {  // what the one `slimm` object of the reference keeps across files
+    Options options;
+    SlimmDatabase db;
+    std::vector<std::string> input_paths;
+    float cc_cache = 0.0f, ucc_cache = 0.0f;  // src/slimm.hpp:155-156: never cleared by reset() (Q8)
+    uint32_t total_hits = 0;
+};
+
+#define CHECK(ctx, call)                                                            \
+    do {                                                                            \
+        int rc_ = (call);                                                           \
+        if (rc_ < 0) {                                                              \
+            std::cerr << "slimm: " << #call << ": " << slimm_last_error(ctx) << "\n"; \
+            if (ctx) slimm_destroy(ctx);                                            \
+            return false;                                                           \
+        }                                                                           \
+    } while (0)
+
+float depth_of(const uint32_t* bins, uint32_t n, uint32_t nz) {  // reference_contig.hpp:188-207 + misc.hpp:285-289
+    if (nz == 0) return 0.0f;
+    float s = 0.0f;
+    for (uint32_t i = 0; i < n; ++i) s += float(bins[i]);
+    return s / n;
+}
+
+// slimm::get_profiles() for one file (src/slimm.hpp:395-496)
+bool get_profiles(Session& S, size_t file_index) {
+    Options& options = S.options;
+    const std::string path = S.input_paths[file_index];
+    Lap watch;
+    std::cerr << "\nReading " << file_index + 1 << " of " << S.input_paths.size() << " files ... (" << get_file_name(path) << ")\n"
+              << "=================================================================\n";
+    AlignmentFile bam;
+    if (!bam.open(path)) {  // src/misc.hpp:500-504: message, skip the file
+        std::cerr << bam.error() << "\n";
+        return true;
+    }
+    // average read length from a sample of 100k records with a sequence (src/misc.hpp:509-522)
+    uint32_t avg_read_length = 0;
+    {
+        RecordBatch b;
+        uint32_t count = 0, total = 0;
+        while (count < 100000) {
+            b.clear();
+            long n = bam.read_batch(b, 4096);
+            if (n <= 0) break;
+            for (size_t i = 0; i < b.size() && count < 100000; ++i) {
+                if (b.l_seq[i] == 0) continue;
+                total += b.l_seq[i];
+                ++count;
+            }
+        }
+        if (count == 0) {
+            std::cerr << "[ERROR] no record with a sequence in " << path << " (the reference divides by zero here)\n";
+            return false;
+        }
+        avg_read_length = total / count;
+    }
+    if (options.bin_width == 0) options.bin_width = avg_read_length;  // :412-413, persists across files
+    bam.close();
+    if (!bam.open(path)) return true;
+
+    std::cerr << "Intializing coverages for all reference genome ... ";
+    const uint32_t R = static_cast<uint32_t>(bam.ref_names().size());
+    std::vector<std::string> accession(R);
+    std::vector<uint32_t> taxa_id(R, 0), lineage(static_cast<size_t>(R) * 8, 0);
+    for (uint32_t i = 0; i < R; ++i) {  // :430-445
+        accession[i] = get_accession_id(bam.ref_names()[i]);
+        auto it = S.db.ac_taxid.find(accession[i]);
+        if (it != S.db.ac_taxid.end()) {
+            taxa_id[i] = it->second.empty() ? 0 : it->second[0];
+            for (size_t k = 0; k < 8 && k < it->second.size(); ++k) lineage[static_cast<size_t>(i) * 8 + k] = it->second[k];
+        } else {
+            S.db.ac_taxid[accession[i]] = std::vector<uint32_t>(8, 0);  // Q13
+        }
+    }
+    std::vector<uint32_t> tax_id, tax_rank;
+    std::vector<const char*> tax_name;
+    tax_id.reserve(S.db.taxid_name.size());
+    for (auto& kv : S.db.taxid_name) {
+        tax_id.push_back(kv.first);
+        tax_rank.push_back(kv.second.first);
+        tax_name.push_back(kv.second.second.c_str());
+    }
+    slimm_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.n_refs = R;
+    cfg.ref_len = bam.ref_lengths().data();
+    cfg.lineage = lineage.data();
+    cfg.bin_width = options.bin_width;
+    cfg.avg_read_len = avg_read_length;
+    cfg.min_reads = options.min_reads;
+    cfg.cov_cut_off = options.cov_cut_off;
+    cfg.abundance_cut_off = options.abundance_cut_off;
+    cfg.rank = options.rank.c_str();
+    cfg.n_taxa = static_cast<uint32_t>(tax_id.size());
+    cfg.tax_id = tax_id.data();
+    cfg.tax_rank = tax_rank.data();
+    cfg.tax_name = tax_name.data();
+    cfg.device = options.device;
+    if (options.order >= 0)
+        cfg.record_order = options.order;
+    else  // only a header that promises name grouping is trusted; anything else is sorted on the device
+        cfg.record_order = (bam.sort_order() == SortOrder::QueryName || bam.sort_order() == SortOrder::QueryGrouped)
+                               ? SLIMM_ORDER_GROUPED
+                               : SLIMM_ORDER_ANY;
+    slimm_ctx* ctx = nullptr;
+    if (slimm_create(&cfg, &ctx) != SLIMM_OK) {
+        std::cerr << "slimm: " << slimm_last_error(nullptr) << "\n";
+        return false;
+    }
+    CHECK(ctx, slimm_set_cutoff_cache(ctx, S.cc_cache, S.ucc_cache));
+    std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+
+    std::cerr << "Analysing alignments, reads and references ....... ";
+    {
+        RecordBatch b;
+        long n;
+        while ((n = bam.read_batch(b, 1 << 20)) > 0) {
+            CHECK(ctx, slimm_push_records(ctx, b.read_key.data(), b.ref_id.data(), b.begin_pos.data(), b.flag.data(), b.size()));
+            b.clear();
+        }
+        if (n < 0) {
+            std::cerr << bam.error() << "\n";
+            slimm_destroy(ctx);
+            return false;
+        }
+    }
+    CHECK(ctx, slimm_analyze_alignments(ctx));
+    int rc = slimm_finish_coverage(ctx);
+    if (rc < 0) {
+        std::cerr << "slimm: " << slimm_last_error(ctx) << "\n";
+        slimm_destroy(ctx);
+        return false;
+    }
+    std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    slimm_stats st;
+    slimm_get_stats(ctx, &st);
+    S.total_hits += st.hits_count;
+    if (rc == SLIMM_E_NO_HITS) {
+        std::cerr << "[WARNING] No mapped reads found in BAM file!" << std::endl;
+        slimm_destroy(ctx);
+        return true;
+    }
+    if (options.min_reads == 0) options.min_reads = st.min_reads;  // :458-459, persists across files
+    if (options.verbose) {                                         // print_matches_stat :621-630
+        std::cerr << "  " << st.hits_count << " records processed." << std::endl;
+        std::cerr << "    " << st.matches_count << " matching reads" << std::endl;
+        std::cerr << "    " << st.uniq_matches_count << " uniquily matching reads" << std::endl;
+        std::cerr << "  references with reads = " << st.reference_count << std::endl;
+        std::cerr << "  expected bins coverage = " << st.expected_coverage << std::endl;
+        std::cerr << "  bins coverage cut-off = " << st.coverage_cut_off << " (" << options.cov_cut_off << " quantile)\n";
+        std::cerr << "  uniq bins coverage cut-off = " << st.uniq_coverage_cut_off << " (" << options.cov_cut_off << " quantile)\n\n";
+    }
+
+    std::cerr << "Filtering unlikely sequences ..................... ";
+    CHECK(ctx, slimm_filter_alignments(ctx));
+    std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    slimm_get_stats(ctx, &st);
+    if (options.verbose) {  // print_filter_stat :613-619
+        std::cerr << "  " << st.n_valid << " passed the threshould coverage.\n";
+        std::cerr << "  " << st.failed_by_cov << " ref's couldn't pass the coverage threshould.\n";
+        std::cerr << "  " << st.failed_by_uniq_cov << " ref's couldn't pass the uniq coverage threshould.\n";
+        std::cerr << "  uniquily matching reads increased from " << st.uniq_matches_count << " to " << st.uniq_matches_count2 << "\n\n";
+    }
+
+    std::vector<uint32_t> reads(R), uniq(R), uniq2(R), nbins(R), nz(R), nzu(R), nzu2(R);
+    std::vector<uint8_t> valid(R);
+    std::vector<float> ab(R), uab(R);
+    std::vector<uint32_t> cov, ucov, ucov2;
+    if (options.raw_output || options.coverage_output) {
+        slimm_ref_columns cols = {reads.data(), uniq.data(), uniq2.data(), nbins.data(), nz.data(),
+                                  nzu.data(),   nzu2.data(), valid.data(), ab.data(),    uab.data()};
+        CHECK(ctx, slimm_get_ref_columns(ctx, &cols));
+        cov.resize(st.total_bins);
+        ucov.resize(st.total_bins);
+        ucov2.resize(st.total_bins);
+        CHECK(ctx, slimm_get_bins(ctx, 0, cov.data()));
+        CHECK(ctx, slimm_get_bins(ctx, 1, ucov.data()));
+        CHECK(ctx, slimm_get_bins(ctx, 2, ucov2.data()));
+    }
+    auto name_of = [&](uint32_t taxid) -> std::string {
+        auto it = S.db.taxid_name.find(taxid);
+        return it == S.db.taxid_name.end() ? std::string() : it->second.second;
+    };
+    if (options.raw_output) {  // write_raw_stat :883-943
+        std::cerr << "Writing features to a file ....................... ";
+        std::ofstream o(get_tsv_file_name(options.output_prefix, path, "_raw"));
+        o << "accesion\ttaxaid\tname\treads_count\tabundance\tuniq1_abundance\tuniq2_abundance\tgenome_length\t"
+             "uniq1_reads_count\tuniq2_reads_count\tbins_count\tbins_count(>0)\tuniq1_bins_count(>0)\t"
+             "uniq2_bins_count(>0)\tcoverage_depth\tuniq1_coverage_depth\tuniq2_coverage_depth\tcoverage(%)\t"
+             "uniq1_coverage(%)\tuniq2_coverage(%)\n";
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < R; ++i) {
+            std::string nm = name_of(taxa_id[i]);
+            if (nm.empty()) nm = "no_name_found";
+            const uint32_t nb = nbins[i];
+            o << accession[i] << "\t" << taxa_id[i] << "\t" << nm << "\t" << reads[i] << "\t" << ab[i] << "\t" << uab[i] << "\t"
+              << 0.0f << "\t" << bam.ref_lengths()[i] << "\t" << uniq[i] << "\t" << uniq2[i] << "\t" << nb << "\t" << nz[i] << "\t"
+              << nzu[i] << "\t" << nzu2[i] << "\t" << depth_of(&cov[off], nb, nz[i]) << "\t" << depth_of(&ucov[off], nb, nzu[i])
+              << "\t" << depth_of(&ucov2[off], nb, nzu2[i]) << "\t" << float(nz[i]) / nb << "\t" << float(nzu[i]) / nb << "\t"
+              << float(nzu2[i]) / nb << "\n";
+            off += nb;
+        }
+        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    }
+    if (options.coverage_output) {  // write_coverage :846-881
+        std::cerr << "Writing coverage profiles to a file ....................... ";
+        std::ofstream a(get_tsv_file_name(options.output_prefix, path, "_coverage"));
+        std::ofstream b(get_tsv_file_name(options.output_prefix, path, "_uniq_coverage"));
+        std::ofstream c(get_tsv_file_name(options.output_prefix, path, "_uniq_coverage2"));
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < R; ++i) {
+            const uint32_t nb = nbins[i];
+            if (valid[i]) {
+                a << accession[i];
+                b << accession[i];
+                c << accession[i];
+                for (int k = 0; k < 8; ++k) {
+                    std::string nm = name_of(lineage[static_cast<size_t>(i) * 8 + k]);
+                    a << "," << nm;
+                    b << "," << nm;
+                    c << "," << nm;
+                }
+                for (uint32_t k = 0; k < nb; ++k) {
+                    a << "," << cov[off + k];
+                    b << "," << ucov[off + k];
+                    c << "," << ucov2[off + k];
+                }
+                a << "\n";
+                b << "\n";
+                c << "\n";
+            }
+            off += nb;
+        }
+        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    }
+
+    std::cerr << "Assigning reads to Least Common Ancestor (LCA) ... ";
+    CHECK(ctx, slimm_get_reads_lca_count(ctx));
+    std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+
+    std::cerr << "Writing taxnomic profile(s) ...................... ";
+    CHECK(ctx, slimm_write_abundance_file(ctx, get_tsv_file_name(options.output_prefix, path, "_profile").c_str()));
+    if (options.verbose) {
+        slimm_get_stats(ctx, &st);
+        std::cerr << "\n" << std::setw(4) << st.profile_count << std::setw(15) << (options.rank) << " (" << st.profile_failed
+                  << " bellow cutoff i.e. " << options.abundance_cut_off << ")";
+        std::cerr << "\n.................................................. ";
+    }
+    std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
+    CHECK(ctx, slimm_get_cutoff_cache(ctx, &S.cc_cache, &S.ucc_cache));
+    slimm_destroy(ctx);
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Session S;
+    int pr = parse(argc, argv, S.options);
+    if (pr == 2) return 0;
+    if (pr != 0) return 1;
+    if (S.options.dump_records) return dump_records(S.options);
+    Lap watch;
+    // slimm::slimm(): collect_bam_files + load_slimm_database (src/slimm.hpp:96-101, 306-326)
+    if (S.options.is_directory) {
+        S.input_paths = get_bam_files_in_directory(S.options.input_path);
+        if (S.options.verbose)
+            std::cerr << S.input_paths.size() << " SAM/BAM Files found under the directory: " << S.options.input_path << "!\n";
+    } else if (access(S.options.input_path.c_str(), 0) == 0) {
+        S.input_paths.push_back(S.options.input_path);
+    } else {
+        std::cerr << S.options.input_path << " is not a file use -d option for a directory.\n";
+        return 1;
+    }
+    std::string err;
+    if (!load_slimm_database(S.options.database_path, S.db, err)) {
+        std::cerr << "slimm: " << err << "\n";
+        return 1;
+    }
+    for (size_t n = 0; n < S.input_paths.size(); ++n)
+        if (!get_profiles(S, n)) return 1;
+    std::cerr << "\n*****************************************************************\n";
+    std::cerr << S.total_hits << " SAM/BAM alignment records are proccessed.\n";
+    std::cerr << "Taxonomic profiles are written to: \n   " << get_directory(S.options.output_prefix) << "\n";
+    std::cerr << "Total time elapsed: " << watch.elapsed() << " secs\n";
+    return 0;
+}

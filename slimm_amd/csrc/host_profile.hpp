@@ -80,6 +80,8 @@ public:
     // ---- per-file state ----
     void reset();          // slimm::reset(): keeps the cut-off caches (Q8)
     void reset_cutoffs();  // a fresh object
+    void get_cutoff_cache(float& cc, float& ucc) const { cc = cc_cache_; ucc = ucc_cache_; }
+    void set_cutoff_cache(float cc, float ucc) { cc_cache_ = cc; ucc_cache_ = ucc; }
 
     // phase A results (per reference) -> a6 statistics
     void set_coverage(const uint32_t* reads_count, const uint32_t* uniq_reads_count, const uint32_t* nz_cov,

@@ -1,0 +1,75 @@
+"""Independent Python writers of SAM, BAM (BGZF) and .sldb files for testing the C++ readers.
+
+Written from the SAM/BAM specification and SURVEY.md Appendix B; they share no code with
+slimm_amd/csrc/host/alignment_file.cpp or sldb.cpp.  Test infrastructure only.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+
+def qnames_of(records):
+    if records.qname is not None:
+        return list(records.qname)
+    return [f"r{int(k)}" for k in records.read_key]
+
+
+def sam_header(ref_names, ref_len, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
+    lines = [hd] if hd else []
+    lines += [f"@SQ\tSN:{n}\tLN:{int(l)}" for n, l in zip(ref_names, ref_len)]
+    return "\n".join(lines) + "\n"
+
+
+def write_sam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
+    q = qnames_of(records)
+    seq = "A" * read_len
+    with open(path, "w") as f:
+        f.write(sam_header(ref_names, ref_len, hd))
+        for i in range(len(records)):
+            r = int(records.ref_id[i])
+            rn = ref_names[r] if r >= 0 else "*"
+            f.write(f"{q[i]}\t{int(records.flag[i])}\t{rn}\t{int(records.begin_pos[i]) + 1}\t255\t{read_len}M\t*\t0\t0\t{seq}\t*\n")
+
+
+def _bgzf_block(data: bytes) -> bytes:
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(data) + co.flush()
+    bsize = len(comp) + 25  # 12 header + 6 extra + 8 trailer - 1
+    return (b"\x1f\x8b\x08\x04" + b"\x00\x00\x00\x00" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+            + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
+
+
+def write_bam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
+    q = qnames_of(records)
+    text = sam_header(ref_names, ref_len, hd).encode()
+    out = bytearray()
+    out += b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names))
+    for n, l in zip(ref_names, ref_len):
+        nb = n.encode() + b"\x00"
+        out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", int(l))
+    seq = bytes([0x11] * ((read_len + 1) // 2))
+    qual = bytes([0xff] * read_len)
+    cigar = struct.pack("<I", (read_len << 4) | 0)
+    for i in range(len(records)):
+        name = q[i].encode() + b"\x00"
+        body = struct.pack("<iiBBHHHIiii", int(records.ref_id[i]), int(records.begin_pos[i]), len(name), 255, 4680, 1,
+                           int(records.flag[i]), read_len, -1, -1, 0) + name + cigar + seq + qual
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as f:
+        for s in range(0, len(out), 0xff00):
+            f.write(_bgzf_block(bytes(out[s:s + 0xff00])))
+        f.write(_bgzf_block(b""))  # EOF marker
+
+
+def write_sldb(path, taxonomy):
+    """cereal binary layout of slimm_database."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(taxonomy.accessions)))
+        for acc, lin in zip(taxonomy.accessions, taxonomy.lineage):
+            a = acc.encode()
+            f.write(struct.pack("<Q", len(a)) + a + struct.pack("<Q", 8) + np.asarray(lin, dtype="<u4").tobytes())
+        f.write(struct.pack("<Q", len(taxonomy.tax_name)))
+        for t, r, n in zip(taxonomy.tax_id, taxonomy.tax_rank, taxonomy.tax_name):
+            b = n.encode()
+            f.write(struct.pack("<IIQ", int(t), int(r), len(b)) + b)

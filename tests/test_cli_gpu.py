@@ -1,0 +1,116 @@
+"""The `slimm` command line end to end on a real MI355X: SAM / BAM + .sldb in, the reference's output files out,
+compared with the CPU oracle's text outputs (same formats as the reference writers)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.binding import Oracle, parse_profile
+from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
+from slimm_amd.workload import Records, Workload
+from tests.bam_io import qnames_of, write_bam, write_sam, write_sldb
+from tests.cases import holes_case, tiny_case
+from tests.helpers import assert_profiles_match
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "slimm_amd", "slimm")
+
+
+def with_names(w: Workload) -> Workload:
+    r = w.records
+    return Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, qnames_of(r)),
+                    w.avg_read_len, w.options, w.name)
+
+
+def run_cli(args):
+    r = subprocess.run([CLI] + args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stderr
+
+
+def check_outputs(outdir, stem, o, coverage=True):
+    assert_profiles_match(open(os.path.join(outdir, stem + "_profile.tsv")).read(), o.profile_tsv)
+    assert open(os.path.join(outdir, stem + "_raw.tsv")).read() == o.raw_tsv
+    if coverage:
+        for suffix, want in zip(("_coverage", "_uniq_coverage", "_uniq_coverage2"), o.coverage_csv):
+            assert open(os.path.join(outdir, stem + suffix + ".tsv")).read() == want, suffix
+
+
+@pytest.mark.parametrize("fmt", ["sam", "bam"])
+@pytest.mark.parametrize("mk", [tiny_case, holes_case, lambda: make_workload(CONFIGS["config1"], seed=41)])
+def test_cli_matches_oracle_outputs(tmp_path, fmt, mk):
+    w = with_names(mk())
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / ("sample." + fmt))
+    (write_sam if fmt == "sam" else write_bam)(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", "-v", db, inp])
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    check_outputs(out, "sample", o)
+    assert f"{o.scalars['hits']} records processed." in err
+    assert f"{o.scalars['matches']} matching reads" in err
+    assert f"{o.scalars['n_valid']} passed the threshould coverage." in err
+
+
+def test_cli_default_bin_width_unsorted_header_and_rank(tmp_path):
+    # no -w: bin width = average read length; header without a grouping promise -> the device sort path; -r genus
+    w = with_names(make_workload(SynthConfig("c", 30_000, 60, 3.0, bin_width=0, read_len=75, len_lo=20_000, len_hi=60_000,
+                                             present_frac=0.4), seed=42))
+    w.options.rank = "genus"
+    w.options.cov_cut_off = 0.9
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "reads.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=75, hd="@HD\tVN:1.6\tSO:unsorted")
+    out = str(tmp_path / "o") + "/"
+    os.makedirs(out)
+    run_cli(["-o", out, "-r", "genus", "-cc", "0.9", "-ro", db, inp])
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, 75, want_raw=True)
+    assert o.scalars["bin_width"] == 75
+    check_outputs(out, "reads", o, coverage=False)
+
+
+def test_cli_directory_mode_leaks_cutoffs_like_the_reference(tmp_path):
+    """-d: one `slimm` object for all files; cut-offs, bin width and min_reads of file 1 are reused (Q8)."""
+    base = with_names(make_workload(CONFIGS["config1"], seed=43))
+    n = len(base.records)
+    parts = [base.records.take(np.arange(0, n // 2)), base.records.take(np.arange(n // 2, n))]
+    d = tmp_path / "in"
+    d.mkdir()
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, base.taxonomy)
+    for k, rec in enumerate(parts):
+        write_sam(str(d / f"part{k}.sam"), base.ref_names, base.ref_len, rec, read_len=base.avg_read_len)
+    out = str(tmp_path / "o") + "/"
+    os.makedirs(out)
+    err = run_cli(["-d", "-w", "100", "-o", out, "-ro", "-v", db, str(d)])
+    order = re.findall(r"Reading \d+ of 2 files \.\.\. \((part\d)\.sam\)", err)
+    assert sorted(order) == ["part0", "part1"]
+    orc = Oracle(base.taxonomy, base.options)  # the same object for both files, in the order the tool used
+    for stem in order:
+        o = orc.run(base.ref_names, base.ref_len, parts[int(stem[-1])], base.avg_read_len, want_raw=True)
+        check_outputs(out, stem, o, coverage=False)
+
+
+def test_cli_no_mapped_reads_and_bad_input(tmp_path):
+    w = with_names(tiny_case())
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "none.sam")
+    rec = w.records.take(np.arange(3))
+    rec.flag[:] = 4
+    write_sam(inp, w.ref_names, w.ref_len, rec, read_len=50)
+    out = str(tmp_path / "o") + "/"
+    os.makedirs(out)
+    err = run_cli(["-w", "100", "-o", out, db, inp])
+    assert "No mapped reads found" in err and not os.path.exists(os.path.join(out, "none_profile.tsv"))
+    r = subprocess.run([CLI, db, str(tmp_path / "missing.bam")], capture_output=True, text=True)
+    assert r.returncode == 1 and "is not a file use -d option" in r.stderr
+    r = subprocess.run([CLI, "-r", "kingdom", db, inp], capture_output=True, text=True)
+    assert r.returncode == 1

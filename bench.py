@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--exchange", default="summary", choices=["summary", "bins"],
+                    help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps, or all-reduce of the bins")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the multi-rank code path (process group, collectives) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -93,8 +97,9 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = CONFIGS[args.config]
@@ -104,6 +109,7 @@ def main():
     gen_s = time.time() - t0
 
     eng = Slimm.for_workload(w, device=local_rank)
+    eng.force_exchange = args.force_exchange
     key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
     ref = torch.from_numpy(w.records.ref_id).to(dev)
     pos = torch.from_numpy(w.records.begin_pos).to(dev)
@@ -117,10 +123,10 @@ def main():
         eng.reset()
         eng.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
         eng.set_records_device(key, ref, pos, flag)
-        return sharded_profile(eng, dev, out_path, phase_times=phase_times)
+        return sharded_profile(eng, dev, out_path, phase_times=phase_times, exchange=args.exchange)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +144,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = eng.kernel_times(reset=True)
     eng.enable_kernel_timing(False)
-    if world > 1:
+    if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -208,7 +214,8 @@ def main():
                                    f"{cfg.bin_width} bp bins, {cfg.read_len} bp reads",
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
                        "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
-                       "record_order": "grouped", "seed": args.seed,
+                       "record_order": "grouped", "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
+                       "exchange": (args.exchange if (world > 1 or args.force_exchange) else "none"),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -219,7 +226,7 @@ def main():
             os.unlink(out_path)
         except OSError:
             pass
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

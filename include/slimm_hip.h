@@ -112,6 +112,15 @@ int slimm_analyze_alignments(slimm_ctx* ctx);
  * (one all-reduce) between slimm_analyze_alignments() and slimm_finish_coverage().  The stream is synchronised. */
 int slimm_coverage_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
 
+/* Leaner exchange for the same point, used by default by slimm_amd/distributed.py: the cut-offs only need per-reference
+ * SUMS of cov / uniq_cov (additive) and per-reference counts of NON-ZERO bins (popcount of the OR of every rank's
+ * "bin != 0" bitmap).  slimm_coverage_summary() builds [sums | 16 scalars | cov bits | uniq_cov bits] for this rank in
+ * device memory (*n_words uint32, about 1/16 of the bins); the caller all-gathers the summaries of all ranks into one
+ * device buffer (rank-major, contiguous) and hands it to slimm_finish_coverage_merged(), which replaces
+ * slimm_finish_coverage().  cov / uniq_cov then stay per-rank partial sums (slimm_get_bins returns this rank's share). */
+int slimm_coverage_summary(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
+int slimm_finish_coverage_merged(slimm_ctx* ctx, const void* d_gathered, uint32_t n_ranks);
+
 /* End of phase A: per-reference reads_count / uniq_reads_count / non-zero bin counts
  * (reference_contig.hpp:84-91,148-155) from the (reduced) bins, and the float statistics of src/slimm.hpp:259-302.
  * Returns SLIMM_E_NO_HITS when hits_count == 0. */

@@ -118,6 +118,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
     DevBuf<uint32_t> counters;   // CNT_WORDS
     DevBuf<uint32_t> ref_stats;  // [R*4] then [R*4]
+    DevBuf<uint32_t> summary;    // multi-GPU: [4R sums | 16 scalars | cov bits | uniq_cov bits]
     DevBuf<uint32_t> lca_count, marks;
     DevBuf<uint64_t> pair_tab, pair_list;
     uint32_t pair_cap = 0;  // power of two
@@ -601,18 +602,14 @@ int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     return SLIMM_OK;
 }
 
-int slimm_finish_coverage(slimm_ctx* c) {
-    if (!c) return SLIMM_E_INVALID;
-    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
-    (void)hipSetDevice(c->device);
+namespace {
+// shared end of phase A: ref_stats[R*4] = {reads_count, nz_cov, uniq_reads_count, nz_uniq_cov} and `tail_src` (16 words:
+// hits, matches, targets, err) are final on the device; bring them to the host and derive the a6 statistics
+int finish_from_device_stats(slimm_ctx* c, const uint32_t* tail_src) {
     hipStream_t st = c->stream;
-    {
-        KernelTimer t(c, K_REF_STATS);
-        launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p);
-    }
     HIP_TRY(c, hipMemcpyAsync(c->h_stats.p, c->ref_stats.p, static_cast<size_t>(c->R) * 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipMemcpyAsync(c->h_small.p, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(c->h_small.p + CNT_WORDS, c->tail(), 16 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_small.p + CNT_WORDS, tail_src, 16 * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
     const uint32_t* cnt = c->h_small.p;
     const uint32_t* tl = c->h_small.p + CNT_WORDS;
@@ -633,6 +630,55 @@ int slimm_finish_coverage(slimm_ctx* c) {
     c->covered = true;
     c->no_hits = (tl[0] == 0);
     return c->no_hits ? SLIMM_E_NO_HITS : SLIMM_OK;
+}
+}  // namespace
+
+int slimm_finish_coverage(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    (void)hipSetDevice(c->device);
+    {
+        KernelTimer t(c, K_REF_STATS);
+        launch_ref_stats(c->stream, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p);
+    }
+    return finish_from_device_stats(c, c->tail());
+}
+
+int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
+    if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    (void)hipSetDevice(c->device);
+    const uint64_t bits_words = c->Bp / 32;
+    const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
+    HIP_TRY(c, c->summary.ensure(W));
+    hipStream_t st = c->stream;
+    {
+        KernelTimer t(c, K_REF_STATS);
+        launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->summary.p);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->summary.p + 4ull * c->R, c->tail(), 16 * 4, hipMemcpyDeviceToDevice, st));
+    launch_nonzero_bits(st, c->cov(), c->Bp, c->summary.p + 4ull * c->R + 16);
+    launch_nonzero_bits(st, c->ucov(), c->Bp, c->summary.p + 4ull * c->R + 16 + bits_words);
+    HIP_TRY(c, hipStreamSynchronize(st));
+    *d_ptr = c->summary.p;
+    *n_words = W;
+    return SLIMM_OK;
+}
+
+int slimm_finish_coverage_merged(slimm_ctx* c, const void* d_gathered, uint32_t n_ranks) {
+    if (!c || !d_gathered || n_ranks == 0) return SLIMM_E_INVALID;
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    (void)hipSetDevice(c->device);
+    const uint64_t bits_words = c->Bp / 32;
+    const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
+    HIP_TRY(c, c->summary.ensure(W));  // its scalar slot doubles as the merged tail
+    uint32_t* merged_tail = c->summary.p + 4ull * c->R;
+    if (d_gathered == c->summary.p && n_ranks > 1) return fail(c, SLIMM_E_INVALID, "gathered buffer aliases the local summary");
+    // a single-rank "gather" may alias the local summary: the merged tail is then written over its own input, which the
+    // kernel reads before writing (one thread per scalar)
+    launch_merge_summary(c->stream, static_cast<const uint32_t*>(d_gathered), W, n_ranks, c->d_bin_off.p, c->R, 4ull * c->R + 16,
+                         4ull * c->R + 16 + bits_words, c->ref_stats.p, merged_tail);
+    return finish_from_device_stats(c, merged_tail);
 }
 
 int slimm_set_coverage_columns(slimm_ctx* c, const uint32_t* reads_count, const uint32_t* uniq_reads_count,

@@ -62,6 +62,11 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
                          const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
                          uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
                          uint32_t taxon_base);
+// multi-GPU coverage summary: "bin != 0" bitmaps and their merge (sums over ranks, popcount of the OR per reference)
+void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits);
+void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,
+                          const uint32_t* bin_off, uint32_t n_refs, uint64_t bits_off_cov, uint64_t bits_off_ucov,
+                          uint32_t* out_stats, uint32_t* out_tail);
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace slimm {
@@ -533,6 +535,93 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
 
 void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail) {
     hipLaunchKernelGGL(k_publish_tail, dim3(1), dim3(64), 0, st, counters, tail);
+}
+
+}  // namespace slimm
+
+// =========================================================================================================
+// Multi-GPU coverage summary (no reference counterpart: the reference is one process).
+// What the cut-offs need from the other ranks is small: per-reference SUMS of cov / uniq_cov (additive) and per-reference
+// counts of NON-ZERO bins, i.e. popcounts of the OR of every rank's "bin != 0" bitmap.  One bit per bin travels instead
+// of one 32-bit word: 1/32 of the all-reduce volume, and an all-gather instead of a ring all-reduce.
+//   summary = [ per-ref {sum_cov, -, sum_ucov, -} (4R words) | tail (16 words) | cov bits (Bp/32) | uniq_cov bits (Bp/32) ]
+// =========================================================================================================
+namespace slimm {
+
+__global__ __launch_bounds__(256) void k_nonzero_bits(const uint32_t* __restrict__ bins, uint64_t n_words64,
+                                                      uint64_t* __restrict__ bits) {
+    // one wave per 64 bins: the ballot of (bin != 0) IS the bitmap word
+    const uint64_t w = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t stride = (static_cast<uint64_t>(gridDim.x) * 256) >> 6;
+    for (uint64_t k = w; k < n_words64; k += stride) {
+        const uint64_t m = __ballot(bins[k * 64 + lane] != 0u);
+        if (lane == 0) bits[k] = m;
+    }
+}
+
+__device__ __forceinline__ uint32_t or_over_ranks(const uint32_t* __restrict__ gathered, uint64_t rank_stride,
+                                                  uint32_t n_ranks, uint64_t word) {
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < n_ranks; ++k) v |= gathered[k * rank_stride + word];
+    return v;
+}
+
+// one wave per reference: sums over ranks, popcount of the OR-ed bitmaps over the reference's (padded) bin range
+__global__ __launch_bounds__(256) void k_merge_summary(const uint32_t* __restrict__ gathered, uint64_t rank_stride,
+                                                       uint32_t n_ranks, const uint32_t* __restrict__ bin_off,
+                                                       uint32_t n_refs, uint64_t bits_off_cov, uint64_t bits_off_ucov,
+                                                       uint32_t* __restrict__ out_stats, uint32_t* __restrict__ out_tail) {
+    const uint32_t ref = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (ref == 0 && lane < 16) {  // additive scalars; slot 3 holds error bits and is OR-ed
+        uint32_t s = 0, o = 0;
+        for (uint32_t k = 0; k < n_ranks; ++k) {
+            const uint32_t v = gathered[k * rank_stride + 4ull * n_refs + lane];
+            s += v;
+            o |= v;
+        }
+        out_tail[lane] = (lane == 3) ? o : s;
+    }
+    if (ref >= n_refs) return;
+    const uint32_t s = bin_off[ref], e = bin_off[ref + 1];
+    uint32_t nz_a = 0, nz_b = 0;
+    if (e > s) {
+        const uint32_t w0 = s >> 5, w1 = (e - 1) >> 5;
+        for (uint32_t w = w0 + lane; w <= w1; w += 64) {
+            uint32_t mask = 0xffffffffu;
+            if (w == w0) mask &= 0xffffffffu << (s & 31u);
+            if (w == w1) mask &= 0xffffffffu >> (31u - ((e - 1) & 31u));
+            nz_a += __popc(or_over_ranks(gathered, rank_stride, n_ranks, bits_off_cov + w) & mask);
+            nz_b += __popc(or_over_ranks(gathered, rank_stride, n_ranks, bits_off_ucov + w) & mask);
+        }
+    }
+    nz_a = wave_sum(nz_a);
+    nz_b = wave_sum(nz_b);
+    if (lane == 0) {
+        uint32_t sa = 0, sb = 0;
+        for (uint32_t k = 0; k < n_ranks; ++k) {
+            sa += gathered[k * rank_stride + 4ull * ref + 0];
+            sb += gathered[k * rank_stride + 4ull * ref + 2];
+        }
+        *reinterpret_cast<uint4*>(out_stats + 4ull * ref) = make_uint4(sa, nz_a, sb, nz_b);
+    }
+}
+
+void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits) {
+    const uint64_t n64 = n_bins / 64;  // n_bins is a multiple of the tile size
+    uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n64 + 3) / 4, 4096));
+    if (blocks)
+        hipLaunchKernelGGL(k_nonzero_bits, dim3(blocks), dim3(256), 0, st, bins, n64, reinterpret_cast<uint64_t*>(bits));
+}
+
+void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,
+                          const uint32_t* bin_off, uint32_t n_refs, uint64_t bits_off_cov, uint64_t bits_off_ucov,
+                          uint32_t* out_stats, uint32_t* out_tail) {
+    uint32_t blocks = (n_refs + 3) / 4;
+    if (blocks)
+        hipLaunchKernelGGL(k_merge_summary, dim3(blocks), dim3(256), 0, st, gathered, rank_stride, n_ranks, bin_off, n_refs,
+                           bits_off_cov, bits_off_ucov, out_stats, out_tail);
 }
 
 }  // namespace slimm

@@ -1,11 +1,12 @@
 """One-process-per-GPU sharding of the alignment-to-profile path.
 
 The record stream is partitioned BY READ (all records of a read on one rank: splitting a read would break the
-first-bin rule Q1 and the unique/multi classification).  Each rank runs phase A on its shard; the integer coverage
-bins are summed with ONE all-reduce (RCCL over xGMI when the backend is "nccl"); every rank then derives identical
-non-zero-bin counts, cut-offs and valid set, runs phase B / C(1) on its own reads, and the small additive partial
-results (uniq_reads_count2, per-taxon LCA counts, child marks, no-agreement pairs) are merged by a second, tiny
-exchange.  The reference has no counterpart (single process, single thread).
+first-bin rule Q1 and the unique/multi classification).  Each rank runs phase A on its shard; ONE collective (RCCL
+over xGMI when the backend is "nccl") then gives every rank what the cut-offs need from the others -- by default an
+all-gather of per-reference sums plus one bit per bin, optionally the all-reduce of the integer bins themselves; every
+rank derives identical non-zero-bin counts, cut-offs and valid set, runs phase B / C(1) on its own reads, and the small
+additive partial results (uniq_reads_count2, per-taxon LCA counts, child marks, no-agreement pairs) are merged by a
+second, tiny exchange.  The reference has no counterpart (single process, single thread).
 
 The functions take an `engine` with the method names of `slimm_amd.profiler.Slimm`; the collectives are plain
 `torch.distributed` calls, so the same code runs over gloo on CPU in the tests.
@@ -19,26 +20,41 @@ import torch
 import torch.distributed as dist
 
 
-def _device_of(t: torch.Tensor):
-    return t.device
+def exchange_coverage(engine, group=None, mode: str = "summary") -> bool:
+    """The exchange between phase A and the cut-offs; returns engine.finish_coverage*()'s answer.
 
-
-def allreduce_coverage(engine, group=None):
-    """The single large collective: sum [cov | uniq_cov | scalar tail] across ranks, in place."""
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
-        return None  # single process: nothing to exchange, the library keeps its stream running
-    buf = engine.coverage_tensor()  # int32 view of the library's device buffer (two's complement sum == uint32 sum)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    if buf.is_cuda:
-        torch.cuda.synchronize(buf.device)
-    return buf
+    mode "summary" (default): ONE all-gather of each rank's [per-reference sums | scalars | 'bin != 0' bitmaps]
+        (about 1/16 of the bins buffer); every rank then sums / ORs the gathered pieces on its own GPU.
+    mode "bins": ONE all-reduce(SUM) over [cov | uniq_cov | scalars] in place -- needed only when the caller wants the
+        global coverage arrays themselves (the reference's -co output); 16 x more bytes on the wire.
+    """
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi and not getattr(engine, "force_exchange", False):
+        return engine.finish_coverage()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if mode == "bins":
+        buf = engine.coverage_tensor()
+        if multi:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            if buf.is_cuda:
+                torch.cuda.synchronize(buf.device)
+        return engine.finish_coverage()
+    mine = engine.coverage_summary_tensor()
+    gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+    if multi:
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+    else:
+        gathered.copy_(mine)
+    if gathered.is_cuda:
+        torch.cuda.synchronize(gathered.device)
+    return engine.finish_coverage_merged(gathered, world)
 
 
 def merge_partials(engine, device: Optional[torch.device] = None, group=None):
     """Second, small exchange: sums, ORs (as sums of 0/1 flags) and a set union of the per-rank partial results."""
     p = engine.get_partials()
     if not (dist.is_initialized() and dist.get_world_size(group) > 1):
-        return p
+        return p  # nothing to merge with
     world = dist.get_world_size(group)
     dev = device or torch.device("cpu")
     R = p["uniq_reads_count2"].shape[0]
@@ -75,7 +91,7 @@ def merge_partials(engine, device: Optional[torch.device] = None, group=None):
 
 
 def sharded_profile(engine, device: Optional[torch.device] = None, path: Optional[str] = None, group=None,
-                    phase_times: Optional[dict] = None):
+                    phase_times: Optional[dict] = None, exchange: str = "summary"):
     """slimm::get_profiles() (reference src/slimm.hpp:395-496) over a record stream sharded across ranks.
 
     `engine` already holds this rank's records.  Returns the profile text (identical on every rank) or None when no
@@ -88,15 +104,14 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
             phase_times[name] = phase_times.get(name, 0.0) + (time.perf_counter() - t0)
         return time.perf_counter()
 
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "force_exchange", False)
     t = time.perf_counter()
     engine.analyze_alignments()
     t = lap("analyze_alignments(launch)", t)
-    allreduce_coverage(engine, group)
-    t = lap("allreduce_coverage", t)
-    if not engine.finish_coverage():
+    have_hits = exchange_coverage(engine, group, exchange)
+    t = lap("exchange + finish_coverage", t)
+    if not have_hits:
         return None
-    t = lap("finish_coverage", t)
     engine.filter_alignments()
     t = lap("filter_alignments", t)
     if multi or getattr(engine, "needs_set_partials", False):

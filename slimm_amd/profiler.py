@@ -114,6 +114,21 @@ class Slimm:
 
         return torch.as_tensor(self.coverage_buffer(), device=f"cuda:{self.device}")
 
+    def coverage_summary_tensor(self):
+        """[per-ref sums | scalars | 'bin != 0' bitmaps] of this rank as an int32 tensor aliasing library memory."""
+        import torch
+
+        ptr = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.L.slimm_coverage_summary(self.ctx, C.byref(ptr), C.byref(n)))
+        return torch.as_tensor(DeviceArray(ptr.value, n.value, "<i4"), device=f"cuda:{self.device}")
+
+    def finish_coverage_merged(self, gathered, n_ranks: int) -> bool:
+        """`gathered`: int32 device tensor holding the summaries of all ranks back to back (all_gather output)."""
+        self._merged_keepalive = gathered
+        rc = self._check(self.L.slimm_finish_coverage_merged(self.ctx, C.c_void_p(gathered.data_ptr()), int(n_ranks)))
+        return rc != capi.E_NO_HITS
+
     def finish_coverage(self) -> bool:
         """True when there are mapped records (False = the reference's 'No mapped reads' early return)."""
         return self._check(self.L.slimm_finish_coverage(self.ctx)) != capi.E_NO_HITS

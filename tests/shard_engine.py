@@ -34,6 +34,31 @@ class OracleShardEngine:
     def coverage_tensor(self):
         return self.buf
 
+    def coverage_summary_tensor(self):
+        b = self.buf.numpy().view(np.uint32)
+        cov, ucov, tail = b[:self.B], b[self.B:2 * self.B], b[2 * self.B:]
+        off = np.concatenate([[0], np.cumsum(self.nbins)])[:-1]
+        sums = np.stack([np.add.reduceat(cov.astype(np.uint64), off), np.add.reduceat(ucov.astype(np.uint64), off)],
+                        axis=1).astype(np.uint32).reshape(-1)
+        bits = np.concatenate([np.packbits(cov != 0, bitorder="little"), np.packbits(ucov != 0, bitorder="little")])
+        pad = (-bits.shape[0]) % 4
+        self._nbits_bytes = (self.B + 7) // 8
+        words = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)]).view(np.uint32)
+        return torch.from_numpy(np.concatenate([sums, tail[:16], words]).view(np.int32).copy())
+
+    def finish_coverage_merged(self, gathered, n_ranks):
+        g = gathered.numpy().view(np.uint32).reshape(n_ranks, -1)
+        R = self.nbins.shape[0]
+        sums = g[:, :2 * R].astype(np.uint64).sum(axis=0).astype(np.uint32).reshape(R, 2)
+        tail = g[:, 2 * R:2 * R + 16].astype(np.uint64).sum(axis=0)
+        bits = np.bitwise_or.reduce(g[:, 2 * R + 16:], axis=0).view(np.uint8)
+        nb = self._nbits_bytes
+        nzc = np.unpackbits(bits[:nb], bitorder="little")[:self.B]
+        nzu = np.unpackbits(bits[nb:2 * nb], bitorder="little")[:self.B]
+        off = np.concatenate([[0], np.cumsum(self.nbins)])[:-1]
+        red = lambda x: np.add.reduceat(x.astype(np.uint64), off).astype(np.uint32)  # noqa: E731
+        return self.host.set_coverage_columns(sums[:, 0], sums[:, 1], red(nzc), red(nzu), int(tail[0]), int(tail[1]))
+
     def finish_coverage(self):
         b = self.buf.numpy().view(np.uint32)
         cov, ucov, tail = b[:self.B], b[self.B:2 * self.B], b[2 * self.B:]

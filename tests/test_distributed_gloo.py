@@ -27,7 +27,7 @@ def _split_by_read(w, world):
     return out
 
 
-def _worker(rank, world, port, case, tmp):
+def _worker(rank, world, port, case, tmp, exchange="summary"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -52,7 +52,7 @@ def _worker(rank, world, port, case, tmp):
             w = make_workload(CONFIGS["config2"], seed=23, n_records=150_000)
         shard = _split_by_read(w, world)[rank]
         eng = OracleShardEngine(shard)
-        text = sharded_profile(eng, None, os.path.join(tmp, "profile.tsv"))
+        text = sharded_profile(eng, None, os.path.join(tmp, "profile.tsv"), exchange=exchange)
         whole = run_workload(w, use_qnames=False, collect_bins=False)
         assert text is not None
         assert_matches_oracle(eng.host, whole, bins=False)
@@ -65,8 +65,9 @@ def _worker(rank, world, port, case, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", ["config1", "config2", "cross"])
-def test_two_ranks_equal_single_process(case):
-    port = 29500 + (os.getpid() % 2000) + {"config1": 0, "config2": 1, "cross": 2}[case]
+@pytest.mark.parametrize("case,exchange", [("config1", "summary"), ("config2", "summary"), ("cross", "summary"),
+                                           ("config1", "bins")])
+def test_two_ranks_equal_single_process(case, exchange):
+    port = 29500 + (os.getpid() % 2000) + {"config1": 0, "config2": 1, "cross": 2}[case] + (3 if exchange == "bins" else 0)
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(2, port, case, tmp), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, case, tmp, exchange), nprocs=2, join=True)

@@ -208,6 +208,48 @@ def test_device_resident_records_and_reset_reuse():
         assert_matches_oracle(s, o)
 
 
+def test_two_shards_on_one_gpu_through_the_summary_exchange():
+    """Two contexts stand in for two ranks: their coverage summaries are concatenated like an all-gather would."""
+    import torch
+    w = make_workload(CONFIGS["config2"], seed=18, n_records=300_000)
+    o = run_workload(w, use_qnames=False)
+    owner = (w.records.read_key % np.uint64(2)).astype(np.int64)
+    engines = []
+    for r in range(2):
+        s = Slimm.for_workload(w, device=0)
+        s.push_records(w.records.take(np.nonzero(owner == r)[0]))
+        s.analyze_alignments()
+        engines.append(s)
+    gathered = torch.cat([e.coverage_summary_tensor().clone() for e in engines])
+    torch.cuda.synchronize()
+    parts = []
+    for e in engines:
+        assert e.finish_coverage_merged(gathered, 2)
+        e.filter_alignments()
+        parts.append(e.get_partials())
+    marks = parts[0]["level_marks"] | parts[1]["level_marks"]
+    pairs = np.unique(np.concatenate([parts[0]["pairs"], parts[1]["pairs"]]))
+    engines[0].set_partials(parts[0]["uniq_reads_count2"] + parts[1]["uniq_reads_count2"],
+                            parts[0]["lca_count"] + parts[1]["lca_count"], marks, pairs)
+    engines[0].get_reads_lca_count()
+    assert_matches_oracle(engines[0], o, bins=False)
+    # per-rank coverage arrays are partial sums of the whole
+    assert np.array_equal(engines[0].bins(0) + engines[1].bins(0), o.cov)
+    assert np.array_equal(engines[0].bins(2) + engines[1].bins(2), o.uniq_cov2)
+
+
+def test_single_rank_through_the_exchange_code_path():
+    from slimm_amd.distributed import sharded_profile
+    w = make_workload(CONFIGS["config1"], seed=19)
+    o = run_workload(w)
+    for mode in ("summary", "bins"):
+        s = Slimm.for_workload(w, device=0)
+        s.force_exchange = True
+        s.push_records(w.records)
+        assert sharded_profile(s, None, None, exchange=mode) is not None
+        assert_matches_oracle(s, o)
+
+
 def test_kernel_timing_reports_every_kernel():
     w = make_workload(CONFIGS["config1"], seed=13)
     s = Slimm.for_workload(w, device=0)

@@ -34,14 +34,14 @@ def exchange_coverage(engine, group=None, mode: str = "summary") -> bool:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if mode == "bins":
         buf = engine.coverage_tensor()
-        if multi:
+        if dist.is_initialized():
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
             if buf.is_cuda:
                 torch.cuda.synchronize(buf.device)
         return engine.finish_coverage()
     mine = engine.coverage_summary_tensor()
     gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-    if multi:
+    if dist.is_initialized():
         dist.all_gather_into_tensor(gathered, mine, group=group)
     else:
         gathered.copy_(mine)
@@ -53,7 +53,7 @@ def exchange_coverage(engine, group=None, mode: str = "summary") -> bool:
 def merge_partials(engine, device: Optional[torch.device] = None, group=None):
     """Second, small exchange: sums, ORs (as sums of 0/1 flags) and a set union of the per-rank partial results."""
     p = engine.get_partials()
-    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+    if not dist.is_initialized():
         return p  # nothing to merge with
     world = dist.get_world_size(group)
     dev = device or torch.device("cpu")

@@ -40,7 +40,7 @@ def algorithmic_bytes(st, n_records, Bp_words):
     N, V, P, M = n_records, st["hits_count"], st["n_targets"], st["matches_count"]
     U, U2, B = st["uniq_matches_count"], st["uniq_matches_count2"], Bp_words
     return {
-        "memset_bins": 4 * 3 * B,
+        "memset_bins": 4 * (B // 8192 + 5200),       # counters, tail, tile counters, child marks (bins are written whole by the tile kernels)
         "k_scan_tiles": 2 * 8 * (N // 2048 + 1),      # per-tile counts in and out
         "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
         "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin

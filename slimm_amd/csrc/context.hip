@@ -131,6 +131,7 @@ struct slimm_ctx {
     uint32_t local_V = 0, local_M = 0, local_P = 0;
     uint32_t n_pairs = 0;
     std::vector<uint32_t> nz_ucov2;
+    std::vector<uint32_t> col[4];  // per-reference columns handed to the host glue
     // partials handed out / installed
     std::vector<uint32_t> part_u2, part_lca, part_marks;
     std::vector<uint64_t> part_pairs;
@@ -145,6 +146,10 @@ struct slimm_ctx {
     double k_ms[K_COUNT] = {0};
     uint32_t k_n[K_COUNT] = {0};
 
+    // packed result blocks: A = [4R stats | 32 counters | 16 tail], B = [4R stats2 | 32 counters | R marks | T lca]
+    size_t statsA_words() const { return 4ull * R + 64; }
+    size_t statsB_words() const { return 5ull * R + 32 + T; }
+    bool pair_clean = false;  // the (taxon, ref) hash set holds only empty slots
     uint32_t* cov() { return bins.p; }
     uint32_t* ucov() { return bins.p + Bp; }
     uint32_t* tail() { return bins.p + 2 * Bp; }
@@ -327,10 +332,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->d_valid.ensure(c->R));
         HIP_TRY0(cc->bins.ensure(3 * c->Bp + kTailWords + c->Tpad));
         HIP_TRY0(cc->counters.ensure(CNT_WORDS));
-        HIP_TRY0(cc->ref_stats.ensure(static_cast<size_t>(c->R) * 8));
+        HIP_TRY0(cc->ref_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->lca_count.ensure(c->T));
         HIP_TRY0(cc->marks.ensure(c->R));
-        HIP_TRY0(cc->h_stats.ensure(static_cast<size_t>(c->R) * 8));
+        HIP_TRY0(cc->h_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->h_small.ensure(CNT_WORDS + kTailWords));
         HIP_TRY0(cc->h_lca.ensure(c->T));
         HIP_TRY0(cc->h_marks.ensure(c->R));
@@ -502,11 +507,18 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     hipStream_t st = c->stream;
     {
         KernelTimer t(c, K_MEMSET);
-        if (c->use_tiles)  // the tile kernel writes every cov / uniq_cov word itself
-            HIP_TRY(c, hipMemsetAsync(c->tail(), 0, kTailWords * sizeof(uint32_t), st));
-        else
-            HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, (2 * c->Bp + kTailWords) * sizeof(uint32_t), st));
-        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, CNT_WORDS * sizeof(uint32_t), st));
+        if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)
+            HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, 2 * c->Bp * sizeof(uint32_t), st));
+        ZeroArgs z;
+        z.p[0] = c->counters.p;
+        z.n[0] = CNT_WORDS;
+        z.p[1] = c->tail();
+        z.n[1] = kTailWords;
+        if (c->use_tiles) {
+            z.p[2] = c->tile_count.p;
+            z.n[2] = c->ntiles2 + 1;
+        }
+        launch_zero(st, z);
     }
     const uint32_t nt = num_tiles(n);
     const HostConfig& hc = c->host->config();
@@ -537,7 +549,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, nullptr, -1, c->tail());
         }
         {
             KernelTimer t(c, K_BUILD_CSR);
@@ -553,7 +565,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, c->tile_valid.p, CNT_V);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, c->tile_valid.p, CNT_V,
+                              c->tail());
         }
         {
             KernelTimer t(c, K_BUILD_CSR);
@@ -575,7 +588,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_TILE_SCATTER);
             launch_tile_scatter(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
-                                c->tile_cursor.p, c->bucket.p);
+                                c->tile_cursor.p, c->bucket.p, c->cov(), c->ucov());
         }
         {
             KernelTimer t(c, K_TILE_HIST);
@@ -586,7 +599,6 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         KernelTimer t(c, K_HIST);
         launch_hist(st, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->cov(), c->ucov());
     }
-    launch_publish_tail(st, c->counters.p, c->tail());
     HIP_TRY(c, hipGetLastError());
     c->analyzed = true;
     return SLIMM_OK;
@@ -603,23 +615,29 @@ int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
 }
 
 namespace {
-// shared end of phase A: ref_stats[R*4] = {reads_count, nz_cov, uniq_reads_count, nz_uniq_cov} and `tail_src` (16 words:
-// hits, matches, targets, err) are final on the device; bring them to the host and derive the a6 statistics
-int finish_from_device_stats(slimm_ctx* c, const uint32_t* tail_src) {
+// shared end of phase A: the packed block A = [4R: {reads_count, nz_cov, uniq_reads_count, nz_uniq_cov} | 32 counters |
+// 16 tail (hits, matches, targets, err)] is final on the device; one copy brings it to the host
+int finish_from_device_stats(slimm_ctx* c) {
     hipStream_t st = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->h_stats.p, c->ref_stats.p, static_cast<size_t>(c->R) * 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(c->h_small.p, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(c, hipMemcpyAsync(c->h_small.p + CNT_WORDS, tail_src, 16 * 4, hipMemcpyDeviceToHost, st));
+    const size_t R4 = 4ull * c->R;
+    HIP_TRY(c, hipMemcpyAsync(c->h_stats.p, c->ref_stats.p, (R4 + 48) * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(c, hipStreamSynchronize(st));
-    const uint32_t* cnt = c->h_small.p;
-    const uint32_t* tl = c->h_small.p + CNT_WORDS;
+    const uint32_t* cnt = c->h_stats.p + R4;
+    const uint32_t* tl = c->h_stats.p + R4 + 32;
     int rc = check_device_errors(c, cnt[CNT_ERR] | tl[3]);
     if (rc != SLIMM_OK) return rc;
     c->local_V = cnt[CNT_V];
     c->local_M = cnt[CNT_M];
     c->local_P = cnt[CNT_P];
     const uint32_t R = c->R;
-    std::vector<uint32_t> rcnt(R), ucnt(R), nzc(R), nzu(R);
+    std::vector<uint32_t>& rcnt = c->col[0];
+    std::vector<uint32_t>& ucnt = c->col[1];
+    std::vector<uint32_t>& nzc = c->col[2];
+    std::vector<uint32_t>& nzu = c->col[3];
+    rcnt.resize(R);
+    ucnt.resize(R);
+    nzc.resize(R);
+    nzu.resize(R);
     for (uint32_t r = 0; r < R; ++r) {
         rcnt[r] = c->h_stats.p[r * 4 + 0];  // reads_count = sum of cov bins
         nzc[r] = c->h_stats.p[r * 4 + 1];
@@ -639,9 +657,14 @@ int slimm_finish_coverage(slimm_ctx* c) {
     (void)hipSetDevice(c->device);
     {
         KernelTimer t(c, K_REF_STATS);
-        launch_ref_stats(c->stream, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p);
+        PackArgs pk;
+        pk.src[0] = c->counters.p;
+        pk.n[0] = 32;
+        pk.src[1] = c->tail();
+        pk.n[1] = 16;
+        launch_ref_stats(c->stream, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p, &pk);
     }
-    return finish_from_device_stats(c, c->tail());
+    return finish_from_device_stats(c);
 }
 
 int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
@@ -654,9 +677,11 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     hipStream_t st = c->stream;
     {
         KernelTimer t(c, K_REF_STATS);
-        launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->summary.p);
+        PackArgs pk;
+        pk.src[0] = c->tail();
+        pk.n[0] = 16;
+        launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->summary.p, &pk);
     }
-    HIP_TRY(c, hipMemcpyAsync(c->summary.p + 4ull * c->R, c->tail(), 16 * 4, hipMemcpyDeviceToDevice, st));
     launch_nonzero_bits(st, c->cov(), c->Bp, c->summary.p + 4ull * c->R + 16);
     launch_nonzero_bits(st, c->ucov(), c->Bp, c->summary.p + 4ull * c->R + 16 + bits_words);
     HIP_TRY(c, hipStreamSynchronize(st));
@@ -671,14 +696,10 @@ int slimm_finish_coverage_merged(slimm_ctx* c, const void* d_gathered, uint32_t 
     (void)hipSetDevice(c->device);
     const uint64_t bits_words = c->Bp / 32;
     const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
-    HIP_TRY(c, c->summary.ensure(W));  // its scalar slot doubles as the merged tail
-    uint32_t* merged_tail = c->summary.p + 4ull * c->R;
-    if (d_gathered == c->summary.p && n_ranks > 1) return fail(c, SLIMM_E_INVALID, "gathered buffer aliases the local summary");
-    // a single-rank "gather" may alias the local summary: the merged tail is then written over its own input, which the
-    // kernel reads before writing (one thread per scalar)
+    // merged statistics, this rank's counters and the merged scalars land in the packed block A
     launch_merge_summary(c->stream, static_cast<const uint32_t*>(d_gathered), W, n_ranks, c->d_bin_off.p, c->R, 4ull * c->R + 16,
-                         4ull * c->R + 16 + bits_words, c->ref_stats.p, merged_tail);
-    return finish_from_device_stats(c, merged_tail);
+                         4ull * c->R + 16 + bits_words, c->ref_stats.p, c->counters.p);
+    return finish_from_device_stats(c);
 }
 
 int slimm_set_coverage_columns(slimm_ctx* c, const uint32_t* reads_count, const uint32_t* uniq_reads_count,
@@ -716,14 +737,28 @@ int slimm_filter_alignments(slimm_ctx* c) {
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
     }
+    uint32_t* const blockB = c->ref_stats.p + c->statsA_words();
     for (int attempt = 0; attempt < 8; ++attempt) {
         {
             KernelTimer t(c, K_MEMSET);
             if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
-            if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->lca_count.p, 0, static_cast<size_t>(T) * 4, st));
-            HIP_TRY(c, hipMemsetAsync(c->marks.p, 0, static_cast<size_t>(R) * 4, st));
-            HIP_TRY(c, hipMemsetAsync(c->pair_tab.p, 0xff, static_cast<size_t>(c->pair_cap) * 8, st));
-            HIP_TRY(c, hipMemsetAsync(c->counters.p + CNT_ERR, 0, 2 * sizeof(uint32_t), st));  // ERR, PAIRS
+            ZeroArgs z;
+            z.p[0] = c->marks.p;
+            z.n[0] = R;
+            z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
+            z.n[1] = 2;
+            if (c->use_tiles) {
+                z.p[2] = c->tile_count.p;
+                z.n[2] = c->ntiles2 + 1;
+            } else {
+                z.p[2] = c->lca_count.p;
+                z.n[2] = T;
+            }
+            if (!c->pair_clean) {
+                z.p64 = c->pair_tab.p;
+                z.n64 = c->pair_cap;
+            }
+            launch_zero(st, z);
         }
         {
             KernelTimer t(c, K_FILTER_LCA);
@@ -753,7 +788,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
                 launch_tile_scatter(st, grid, c->ntiles2, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_base.p,
-                                    c->tile_cursor.p, c->bucket.p);
+                                    c->tile_cursor.p, c->bucket.p, c->ucov2(), nullptr);
             }
             {
                 KernelTimer t(c, K_TILE_HIST2);
@@ -763,23 +798,29 @@ int slimm_filter_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_REF_STATS2);
-            launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, c->ref_stats.p + static_cast<size_t>(R) * 4);
+            PackArgs pk;
+            pk.src[0] = c->counters.p;
+            pk.n[0] = 32;
+            pk.src[1] = c->marks.p;
+            pk.n[1] = R;
+            pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
+            pk.n[2] = T;
+            launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, blockB, &pk);
         }
-        HIP_TRY(c, hipMemcpyAsync(c->h_stats.p + static_cast<size_t>(R) * 4, c->ref_stats.p + static_cast<size_t>(R) * 4,
-                                  static_cast<size_t>(R) * 16, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(c->h_small.p, c->counters.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(c->h_lca.p, c->use_tiles ? c->lca_tiles() : c->lca_count.p, static_cast<size_t>(T) * 4,
-                                  hipMemcpyDeviceToHost, st));
-        HIP_TRY(c, hipMemcpyAsync(c->h_marks.p, c->marks.p, static_cast<size_t>(R) * 4, hipMemcpyDeviceToHost, st));
+        uint32_t* const hB = c->h_stats.p + c->statsA_words();
+        HIP_TRY(c, hipMemcpyAsync(hB, blockB, c->statsB_words() * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
-        const uint32_t err = c->h_small.p[CNT_ERR];
+        const uint32_t* h_cnt = hB + 4ull * R;
+        const uint32_t err = h_cnt[CNT_ERR];
         if (err & ERR_PAIR_OVERFLOW) {
             if (c->pair_cap >= (1u << 30)) return fail(c, SLIMM_E_INVALID, "(taxon, reference) pair set overflow");
             int rc = ensure_pair_table(c, c->pair_cap * 4);
             if (rc != SLIMM_OK) return rc;
+            c->pair_clean = false;
             continue;
         }
-        c->n_pairs = c->h_small.p[CNT_PAIRS];
+        c->n_pairs = h_cnt[CNT_PAIRS];
+        c->pair_clean = (c->n_pairs == 0);
         if (c->n_pairs) {
             HIP_TRY(c, hipMemcpyAsync(c->h_pairs.p, c->pair_list.p, static_cast<size_t>(c->n_pairs) * 8,
                                       hipMemcpyDeviceToHost, st));
@@ -789,13 +830,13 @@ int slimm_filter_alignments(slimm_ctx* c) {
     }
     c->part_u2.resize(R);
     c->nz_ucov2.resize(R);
-    const uint32_t* s2 = c->h_stats.p + static_cast<size_t>(R) * 4;
+    const uint32_t* s2 = c->h_stats.p + c->statsA_words();
     for (uint32_t r = 0; r < R; ++r) {
         c->part_u2[r] = s2[r * 4 + 0];  // uniq_reads_count2 = sum of uniq_cov2 bins
         c->nz_ucov2[r] = s2[r * 4 + 1];
     }
-    c->part_lca.assign(c->h_lca.p, c->h_lca.p + T);
-    c->part_marks.assign(c->h_marks.p, c->h_marks.p + R);
+    c->part_marks.assign(s2 + 4ull * R + 32, s2 + 5ull * R + 32);
+    c->part_lca.assign(s2 + 5ull * R + 32, s2 + 5ull * R + 32 + T);
     c->part_pairs.assign(c->h_pairs.p, c->h_pairs.p + c->n_pairs);
     std::sort(c->part_pairs.begin(), c->part_pairs.end());
     h.set_partials(c->part_u2.data(), c->part_lca.data(), c->part_marks.data(), c->part_pairs.data(), c->n_pairs);

@@ -3,7 +3,6 @@
 #include "host_profile.hpp"
 
 #include <algorithm>
-#include <map>
 #include <numeric>
 #include <cstdio>
 #include <unordered_map>
@@ -240,11 +239,29 @@ void HostProfile::set_partials(const uint32_t* u2, const uint32_t* lca, const ui
 //   pairs_               (t << 32 | ref) for reads that agree at no level (Q4)     -> children[t] has ref
 void HostProfile::propagate() {
     const uint32_t R = cfg_.n_refs, T = n_taxa_dense();
-    count_.assign(T, 0);
-    has_count_.assign(T, 0);
-    kids_.assign(T, RefSet());
+    if (count_.size() != T) {
+        count_.assign(T, 0);
+        has_count_.assign(T, 0);
+        kids_.assign(T, RefSet());
+    } else {  // reuse the allocations of the previous file: only what was touched is cleared
+        for (uint32_t t : touched_) {
+            count_[t] = 0;
+            has_count_[t] = 0;
+            RefSet& k = kids_[t];
+            k.items.clear();
+            k.mn = 0xffffffffu;
+            k.mx = 0;
+            k.dirty = false;
+            k.present = false;
+        }
+    }
+    touched_.clear();
+    auto touch = [&](uint32_t t) {
+        if (!has_count_[t] && !kids_[t].present) touched_.push_back(t);
+    };
     for (uint32_t t = 0; t < T; ++t) {
         if (lca_count_[t] != 0) {
+            touch(t);
             count_[t] = lca_count_[t];
             has_count_[t] = 1;
         }
@@ -254,28 +271,15 @@ void HostProfile::propagate() {
         while (m) {
             uint32_t lv = static_cast<uint32_t>(__builtin_ctz(m));
             m &= m - 1;
-            kids_[lin_dense_[r * 8 + lv]].add(r);
+            const uint32_t t = lin_dense_[r * 8 + lv];
+            touch(t);
+            kids_[t].add(r);
         }
     }
-    for (uint64_t p : pairs_) kids_[static_cast<uint32_t>(p >> 32)].add(static_cast<uint32_t>(p));
-
-    // snapshot of step 1 for the stage-0 getters
-    direct_taxid_.clear();
-    direct_count_.clear();
-    direct_pair_t_.clear();
-    direct_pair_r_.clear();
-    for (uint32_t t = 0; t < T; ++t) {
-        if (has_count_[t]) {
-            direct_taxid_.push_back(dense_taxid_[t]);
-            direct_count_.push_back(count_[t]);
-        }
-        if (kids_[t].present) {
-            kids_[t].materialise();
-            for (uint32_t r : kids_[t].items) {
-                direct_pair_t_.push_back(dense_taxid_[t]);
-                direct_pair_r_.push_back(r);
-            }
-        }
+    for (uint64_t p : pairs_) {
+        const uint32_t t = static_cast<uint32_t>(p >> 32);
+        touch(t);
+        kids_[t].add(static_cast<uint32_t>(p));
     }
 
     // Step 2 (:560-586): every taxon with direct hits hands its count (snapshot value) and its children (live) to the
@@ -296,6 +300,7 @@ void HostProfile::propagate() {
         uint32_t c = lca_count_[t];
         for (uint32_t j = rnk + 1; j < kLineageLen; ++j) {
             uint32_t u = lin[j];
+            touch(u);
             count_[u] += c;
             has_count_[u] = 1;
             if (u != t) kids_[u].add_all(ids);
@@ -307,12 +312,14 @@ void HostProfile::propagate() {
         uint32_t u2 = uniq_reads_count2[i];
         if (u2 == 0) continue;
         const uint32_t* lin = &lin_dense_[static_cast<size_t>(i) * 8];
+        touch(lin[0]);
         RefSet& s0 = kids_[lin[0]];
         s0.present = true;  // operator[] creates the entry
         s0.materialise();
         ids = s0.items;
         for (uint32_t j = 1; j < kLineageLen; ++j) {
             uint32_t u = lin[j];
+            touch(u);
             count_[u] += u2;
             has_count_[u] = 1;
             kids_[u].add(i);
@@ -324,28 +331,38 @@ void HostProfile::propagate() {
 }
 
 void HostProfile::taxon_counts(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& count) {
-    if (stage == 0) {
-        taxid = direct_taxid_;
-        count = direct_count_;
-        return;
-    }
     taxid.clear();
     count.clear();
-    for (uint32_t t = 0; t < n_taxa_dense(); ++t)
-        if (has_count_[t]) {
+    const uint32_t T = n_taxa_dense();
+    for (uint32_t t = 0; t < T; ++t) {
+        if (stage == 0 ? (lca_count_[t] != 0) : (has_count_[t] != 0)) {
             taxid.push_back(dense_taxid_[t]);
-            count.push_back(count_[t]);
+            count.push_back(stage == 0 ? lca_count_[t] : count_[t]);
         }
+    }
 }
 
 void HostProfile::children_pairs(int stage, std::vector<uint32_t>& taxid, std::vector<uint32_t>& ref) {
-    if (stage == 0) {
-        taxid = direct_pair_t_;
-        ref = direct_pair_r_;
-        return;
-    }
     taxid.clear();
     ref.clear();
+    if (stage == 0) {  // rebuilt from what the device reported: (ref, level) marks and no-agreement pairs
+        std::vector<uint64_t> pr(pairs_);
+        for (uint32_t r = 0; r < cfg_.n_refs; ++r) {
+            uint32_t m = marks_[r] & 0xffu;
+            while (m) {
+                uint32_t lv = static_cast<uint32_t>(__builtin_ctz(m));
+                m &= m - 1;
+                pr.push_back((static_cast<uint64_t>(lin_dense_[r * 8 + lv]) << 32) | r);
+            }
+        }
+        std::sort(pr.begin(), pr.end());
+        pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+        for (uint64_t p : pr) {
+            taxid.push_back(dense_taxid_[static_cast<uint32_t>(p >> 32)]);
+            ref.push_back(static_cast<uint32_t>(p));
+        }
+        return;
+    }
     for (uint32_t t = 0; t < n_taxa_dense(); ++t) {
         if (!kids_[t].present) continue;
         kids_[t].materialise();
@@ -356,30 +373,22 @@ void HostProfile::children_pairs(int stage, std::vector<uint32_t>& taxid, std::v
     }
 }
 
-// slimm.hpp:690-710
-std::string HostProfile::lineage_string(uint32_t rnk, const uint32_t* lin, bool all_zero) {
-    auto name_at = [&](uint32_t lv) -> std::string {
-        std::string n;
-        if (all_zero) {
-            n = zero_name_;  // db.taxid__name[0]; "" unless the database names taxid 0
-        } else {
-            n = name_of_dense(lin[lv]);
-        }
-        if (n.empty()) n = "unknown_" + rank_long(lv);
-        return n;
-    };
-    std::string s;
-    s.reserve(256);
+// slimm.hpp:690-710: k__..|p__..|...|<rank>__name, missing names -> unknown_<rank>
+void HostProfile::append_lineage(std::string& s, uint32_t rnk, const uint32_t* lin, bool all_zero) {
     for (uint32_t i = kLineageLen; i-- > rnk;) {  // the reference prepends rank by rank; same text, built front to back
-        s += rank_short(i);
+        s += kRankShort[i < 8 ? i : 0];
         s += "__";
-        s += name_at(i);
+        const std::string& n = all_zero ? zero_name_ : name_of_dense(lin[i]);  // db.taxid__name[0] for the zero lineage
+        if (n.empty()) {
+            s += "unknown_";
+            s += kRankNames[i < 8 ? i : 0];
+        } else {
+            s += n;
+        }
         if (i != rnk) s += '|';
     }
-    return s;
 }
 
-// slimm.hpp:733-843
 // Number formatting: the reference streams floats / doubles into an ofstream with default flags, i.e. "%.6g".
 static void put_g(std::string& out, double v) {
     char buf[40];
@@ -392,32 +401,45 @@ static void put_u(std::string& out, uint32_t v) {
     out.append(buf, static_cast<size_t>(n));
 }
 
+// slimm.hpp:733-843
 const std::string& HostProfile::write_abundance() {
     if (profile_ready_) return profile_;
     std::string out;
-    out.reserve(8192);
+    out.reserve(16384);
     out += "taxa_level\ttaxa_id\tlinage\tabundance\tread_count\n";
     const uint32_t T = n_taxa_dense();
     const uint32_t rnk = considered_.size() > 1 ? considered_[1] : considered_[0];
     const uint32_t parent_rnk = considered_[0];
+    const char* rank_name = rnk < 8 ? kRankNames[rnk] : "intermidiate";
 
-    // :747-765 statistics of the upper level
-    std::map<uint32_t, float> parent_abundance;
-    std::map<uint32_t, uint32_t> parent_reads;
-    for (uint32_t t = 0; t < T; ++t) {
-        if (!has_count_[t] || rank_d_[t] != parent_rnk) continue;
-        parent_abundance[t] = float(count_[t]) / (matches)*100;
-        parent_reads[t] = count_[t];
+    // per-parent accumulators on the dense taxon index (the reference uses four unordered_maps keyed by taxid);
+    // only taxa with an entry in taxon_id__read_count can matter, so the walks go over `touched_`
+    if (pa_ab_.size() != T) {
+        pa_ab_.assign(T, 0.0f);
+        sum_ab_.assign(T, 0.0f);
+        pa_rd_.assign(T, 0u);
+        sum_rd_.assign(T, 0u);
+        pa_seen_.assign(T, 0);
+    }
+    std::vector<uint32_t>& order = order_scratch_;
+    order.clear();
+    for (uint32_t t : touched_)
+        if (has_count_[t]) order.push_back(t);
+    std::sort(order.begin(), order.end());  // rows in ascending taxid order
+    parents_scratch_.clear();
+
+    for (uint32_t t : order) {  // :747-765 statistics of the upper level
+        if (rank_d_[t] != parent_rnk) continue;
+        pa_ab_[t] = float(count_[t]) / (matches)*100;
+        pa_rd_[t] = count_[t];
     }
 
     uint32_t count = 0, failed = 0, sum_reads = 0;
     float sum_ab = 0.0f;
-    std::map<uint32_t, float> ab_by_parent;
-    std::map<uint32_t, uint32_t> reads_by_parent;
     const float cc = coverage_cut_off();
 
-    for (uint32_t t = 0; t < T; ++t) {  // :776-813
-        if (!has_count_[t] || rank_d_[t] != rnk) continue;
+    for (uint32_t t : order) {  // :776-813
+        if (rank_d_[t] != rnk) continue;
         RefSet& k = kids_[t];
         k.materialise();
         uint32_t glen = 0, nchild = 0;
@@ -430,25 +452,27 @@ const std::string& HostProfile::write_abundance() {
         float cov = float(count_[t] * cfg_.avg_read_len) / glen;                // u32 product, wraps (Q11)
         float ab = float(count_[t]) / (matches)*100;
         const std::string& name = name_of_dense(t);
-        uint32_t parent = (parent_rnk < kLineageLen) ? lin_last[parent_rnk] : 0xffffffffu;
-        auto pa = ab_by_parent.find(parent);
-        if (pa != ab_by_parent.end())
-            pa->second += ab;
-        else
-            ab_by_parent[parent] = ab;
-        reads_by_parent[parent] += count_[t];
+        if (parent_rnk < kLineageLen) {
+            const uint32_t parent = lin_last[parent_rnk];
+            if (!pa_seen_[parent]) {
+                pa_seen_[parent] = 1;
+                parents_scratch_.push_back(parent);
+            }
+            sum_ab_[parent] += ab;
+            sum_rd_[parent] += count_[t];
+        }
         if (ab < cfg_.abundance_cut_off || cov < cc || name.empty()) {  // depth vs fraction (Q10)
             ++failed;
             continue;
         }
         // get_lineage_string(rank, taxid): lineage of the FIRST child, all zeros for taxid 0 (:712-730)
-        bool zero = dense_taxid_[t] == 0;
+        const bool zero = dense_taxid_[t] == 0;
         const uint32_t* lin_first = &lin_dense_[static_cast<size_t>(k.mn) * 8];
-        out += rank_long(rnk);
+        out += rank_name;
         out += '\t';
         put_u(out, dense_taxid_[t]);
         out += '\t';
-        out += lineage_string(rnk, lin_first, zero);
+        append_lineage(out, rnk, lin_first, zero);
         out += '\t';
         put_g(out, ab);
         out += '\t';
@@ -459,30 +483,27 @@ const std::string& HostProfile::write_abundance() {
         ++count;
     }
 
-    for (auto& abp : ab_by_parent) {  // :816-831 unclassified rows per parent
-        uint32_t parent = abp.first;
-        if (parent == 0xffffffffu) continue;
-        float pab = 0.0f;
-        uint32_t prd = 0;
-        auto a = parent_abundance.find(parent);
-        if (a != parent_abundance.end()) pab = a->second;
-        auto b = parent_reads.find(parent);
-        if (b != parent_reads.end()) prd = b->second;
-        float uncl_ab = pab - abp.second;
-        uint32_t uncl_reads = prd - reads_by_parent[parent];
-        std::string name = name_of_dense(parent) + "_unclassified";
-        if (uncl_ab > cfg_.abundance_cut_off && name != "_unclassified") {
+    std::sort(parents_scratch_.begin(), parents_scratch_.end());
+    for (uint32_t parent : parents_scratch_) {  // :816-831 unclassified rows per parent
+        // a parent that is not a counted taxon of the parent rank reads as 0 from the reference's maps
+        const float uncl_ab = pa_ab_[parent] - sum_ab_[parent];
+        const uint32_t uncl_reads = pa_rd_[parent] - sum_rd_[parent];
+        const std::string& pname = name_of_dense(parent);
+        if (uncl_ab > cfg_.abundance_cut_off && !pname.empty()) {  // name + "_unclassified" != "_unclassified"
             bool zero = dense_taxid_[parent] == 0;
             RefSet& k = kids_[parent];
             if (k.items.empty()) zero = true;  // the reference would throw from .at(); unreachable with a counted parent
             const uint32_t* lin_first = zero ? nullptr : &lin_dense_[static_cast<size_t>(k.mn) * 8];
-            std::string ls = lineage_string(parent_rnk, lin_first, zero) + "|" + rank_short(rnk) + "__" + name;
-            out += rank_long(rnk);
+            out += rank_name;
             out += '\t';
             put_u(out, dense_taxid_[parent]);
             out += "*\t";
-            out += ls;
-            out += '\t';
+            append_lineage(out, parent_rnk, lin_first, zero);
+            out += '|';
+            out += kRankShort[rnk < 8 ? rnk : 0];
+            out += "__";
+            out += pname;
+            out += "_unclassified\t";
             put_g(out, uncl_ab);
             out += '\t';
             put_u(out, uncl_reads);
@@ -491,10 +512,20 @@ const std::string& HostProfile::write_abundance() {
             sum_ab += uncl_ab;
         }
     }
+    // leave the accumulators clean for the next file
+    for (uint32_t t : order) {
+        pa_ab_[t] = 0.0f;
+        pa_rd_[t] = 0u;
+    }
+    for (uint32_t parent : parents_scratch_) {
+        sum_ab_[parent] = 0.0f;
+        sum_rd_[parent] = 0u;
+        pa_seen_[parent] = 0;
+    }
 
-    out += rank_long(rnk);  // :833-835
+    out += rank_name;  // :833-835
     out += "\t0*\t";
-    out += lineage_string(rnk, nullptr, true);
+    append_lineage(out, rnk, nullptr, true);
     out += '\t';
     put_g(out, 100.0 - sum_ab);
     out += '\t';

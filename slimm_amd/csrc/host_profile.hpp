@@ -121,7 +121,7 @@ public:
 private:
     uint32_t rank_of_dense(uint32_t d) const { return rank_d_[d]; }
     const std::string& name_of_dense(uint32_t d) const;
-    std::string lineage_string(uint32_t rnk, const uint32_t* lin_dense_row, bool all_zero);
+    void append_lineage(std::string& out, uint32_t rnk, const uint32_t* lin_dense_row, bool all_zero);
 
     HostConfig cfg_;
     std::vector<uint32_t> dense_taxid_, lin_dense_, nbins_, rank_d_;
@@ -144,7 +144,10 @@ private:
     std::vector<uint32_t> count_;         // [T]
     std::vector<uint8_t> has_count_;      // [T] membership in taxon_id__read_count
     std::vector<RefSet> kids_;            // [T]
-    std::vector<uint32_t> direct_taxid_, direct_count_, direct_pair_t_, direct_pair_r_;
+    std::vector<float> pa_ab_, sum_ab_;   // write_abundance scratch, dense taxon index, kept zeroed between calls
+    std::vector<uint32_t> pa_rd_, sum_rd_, order_scratch_, parents_scratch_;
+    std::vector<uint8_t> pa_seen_;
+    std::vector<uint32_t> touched_;       // taxa whose count / children entry exists (cleared cheaply on the next file)
     std::string profile_;
     bool profile_ready_ = false;
     std::string empty_, zero_name_;

@@ -17,6 +17,18 @@ enum {
 };
 enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4 };
 
+struct PackArgs {  // small arrays appended behind the per-reference statistics by k_ref_stats
+    const uint32_t* src[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n[4] = {0, 0, 0, 0};
+};
+struct ZeroArgs {  // arrays cleared by one k_zero launch; p64 is filled with ~0 (the empty key of the pair set)
+    uint32_t* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t n[5] = {0, 0, 0, 0, 0};
+    uint64_t* p64 = nullptr;
+    uint32_t n64 = 0;
+};
+void launch_zero(hipStream_t st, const ZeroArgs& z);
+
 struct DeviceRecords {
     const uint64_t* key = nullptr;
     const int32_t* ref = nullptr;
@@ -29,7 +41,7 @@ uint32_t num_tiles(uint32_t n);
 
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off, const uint32_t* extra = nullptr, int slot_extra = -1);
+                       uint32_t* read_off, const uint32_t* extra = nullptr, int slot_extra = -1, uint32_t* tail = nullptr);
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
@@ -48,7 +60,7 @@ void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
 void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
                  uint32_t* cov, uint32_t* ucov);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
-                      uint32_t* out);
+                      uint32_t* out, const PackArgs* pack = nullptr);
 // ucov2 != nullptr: global atomics -- uniq_cov2[g]++ per unique-after-filter read, lca_count[t]++ per LCA read (fallback);
 // uniq_gbin != nullptr: one selector per read instead (its uniq_cov2 bin, taxon_base + its LCA taxon, or 0xffffffff),
 // counted afterwards by the tile histogram over the index space [uniq_cov2 bins | taxa].
@@ -66,23 +78,24 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
 void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits);
 void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,
                           const uint32_t* bin_off, uint32_t n_refs, uint64_t bits_off_cov, uint64_t bits_off_ucov,
-                          uint32_t* out_stats, uint32_t* out_tail);
-void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail);
+                          uint32_t* out_stats, const uint32_t* counters);
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----
 constexpr uint32_t kTileShift = 13;
 constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 32 KiB of LDS in k_tile_hist
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
 int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
+// tile_count must be zero on entry (k_zero)
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
                        int count_slot, uint32_t* tile_count);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters);
+// also zeroes the tiles (of cov, and of ucov when given) that k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
                          const uint32_t* counters, int count_slot, const uint32_t* tile_base, uint32_t* tile_cursor,
-                         uint16_t* bucket);
+                         uint16_t* bucket, uint32_t* cov, uint32_t* ucov);
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov);
 

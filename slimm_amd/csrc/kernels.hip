@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restri
 __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cnt, uint32_t ntiles,
                                                      uint32_t* __restrict__ counters, int slot_x, int slot_y,
                                                      uint32_t* __restrict__ read_off, const uint32_t* __restrict__ extra,
-                                                     int slot_extra) {
+                                                     int slot_extra, uint32_t* __restrict__ tail) {
     __shared__ uint2 s_part[1024];
     __shared__ uint32_t s_extra[16];
     const uint32_t tid = threadIdx.x;
@@ -133,10 +133,17 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cn
         counters[slot_x] = tot.x;
         if (slot_y >= 0) counters[slot_y] = tot.y;
         if (read_off) read_off[tot.x] = tot.y;
+        uint32_t v = counters[CNT_V];
         if (extra) {
             uint32_t e = 0;
             for (int w = 0; w < 16; ++w) e += s_extra[w];
             counters[slot_extra] = e;
+            if (slot_extra == CNT_V) v = e;
+        }
+        if (tail) {  // the additive scalars that travel with the bins through the multi-GPU exchange
+            tail[0] = v;       // hits
+            tail[1] = tot.x;   // matches (reads)
+            tail[2] = tot.y;   // targets
         }
     }
 }
@@ -217,7 +224,17 @@ __global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tg
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                       const uint32_t* __restrict__ bin_off, uint32_t n_refs,
-                                                      uint32_t* __restrict__ out) {
+                                                      uint32_t* __restrict__ out, const PackArgs pack) {
+    // ride-along: gather the small result arrays behind the statistics so that ONE copy brings everything to the host
+    {
+        const uint32_t gid = blockIdx.x * kBlock + threadIdx.x, gsz = gridDim.x * kBlock;
+        uint32_t* dst = out + 4ull * n_refs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            for (uint32_t i = gid; i < pack.n[k]; i += gsz) dst[i] = pack.src[k][i];
+            dst += pack.n[k];
+        }
+    }
     const uint32_t ref = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (ref >= n_refs) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -458,16 +475,6 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
     if (uniq_gbin) uniq_gbin[m] = sel;
 }
 
-// tail[0..3] = {hits, matches, targets, err}: the additive scalars that travel with the bins through the all-reduce
-__global__ void k_publish_tail(const uint32_t* __restrict__ counters, uint32_t* __restrict__ tail) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        tail[0] = counters[CNT_V];
-        tail[1] = counters[CNT_M];
-        tail[2] = counters[CNT_P];
-        tail[3] = counters[CNT_ERR];
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
@@ -481,9 +488,9 @@ void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs
 }
 
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off, const uint32_t* extra, int slot_extra) {
+                       uint32_t* read_off, const uint32_t* extra, int slot_extra, uint32_t* tail) {
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off, extra,
-                       slot_extra);
+                       slot_extra, tail);
 }
 
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
@@ -503,9 +510,28 @@ void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, cons
 }
 
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
-                      uint32_t* out) {
+                      uint32_t* out, const PackArgs* pack) {
     uint32_t blocks = (n_refs + kWaves - 1) / kWaves;
-    if (blocks) hipLaunchKernelGGL(k_ref_stats, dim3(blocks), dim3(kBlock), 0, st, a, b, bin_off, n_refs, out);
+    PackArgs none;
+    if (blocks)
+        hipLaunchKernelGGL(k_ref_stats, dim3(blocks), dim3(kBlock), 0, st, a, b, bin_off, n_refs, out, pack ? *pack : none);
+}
+
+// several small arrays cleared by one launch (each hipMemsetAsync is a launch of its own)
+__global__ __launch_bounds__(256) void k_zero(const ZeroArgs z) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        for (uint32_t i = gid; i < z.n[k]; i += gsz) z.p[k][i] = 0u;
+    for (uint32_t i = gid; i < z.n64; i += gsz) z.p64[i] = ~0ull;
+}
+
+void launch_zero(hipStream_t st, const ZeroArgs& z) {
+    uint32_t most = z.n64;
+    for (int k = 0; k < 5; ++k) most = most > z.n[k] ? most : z.n[k];
+    uint32_t blocks = (most + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks) hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, st, z);
 }
 
 void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
@@ -531,10 +557,6 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
         hipLaunchKernelGGL(k_filter_lca16, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters,
                            reinterpret_cast<const uint4*>(rows16), level_taxon, lo, ucov2, uniq_gbin, lca_count, marks,
                            pair_tab, pair_list, pair_mask, taxon_base);
-}
-
-void launch_publish_tail(hipStream_t st, const uint32_t* counters, uint32_t* tail) {
-    hipLaunchKernelGGL(k_publish_tail, dim3(1), dim3(64), 0, st, counters, tail);
 }
 
 }  // namespace slimm
@@ -571,9 +593,12 @@ __device__ __forceinline__ uint32_t or_over_ranks(const uint32_t* __restrict__ g
 __global__ __launch_bounds__(256) void k_merge_summary(const uint32_t* __restrict__ gathered, uint64_t rank_stride,
                                                        uint32_t n_ranks, const uint32_t* __restrict__ bin_off,
                                                        uint32_t n_refs, uint64_t bits_off_cov, uint64_t bits_off_ucov,
-                                                       uint32_t* __restrict__ out_stats, uint32_t* __restrict__ out_tail) {
+                                                       uint32_t* __restrict__ out_stats,
+                                                       const uint32_t* __restrict__ counters) {
     const uint32_t ref = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* const out_tail = out_stats + 4ull * n_refs + 32;       // packed block A: [4R stats | 32 counters | 16 tail]
+    if (ref == 0 && lane < 32) out_stats[4ull * n_refs + lane] = counters[lane];
     if (ref == 0 && lane < 16) {  // additive scalars; slot 3 holds error bits and is OR-ed
         uint32_t s = 0, o = 0;
         for (uint32_t k = 0; k < n_ranks; ++k) {
@@ -617,11 +642,11 @@ void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, 
 
 void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,
                           const uint32_t* bin_off, uint32_t n_refs, uint64_t bits_off_cov, uint64_t bits_off_ucov,
-                          uint32_t* out_stats, uint32_t* out_tail) {
+                          uint32_t* out_stats, const uint32_t* counters) {
     uint32_t blocks = (n_refs + 3) / 4;
     if (blocks)
         hipLaunchKernelGGL(k_merge_summary, dim3(blocks), dim3(256), 0, st, gathered, rank_stride, n_ranks, bin_off, n_refs,
-                           bits_off_cov, bits_off_ucov, out_stats, out_tail);
+                           bits_off_cov, bits_off_ucov, out_stats, counters);
 }
 
 }  // namespace slimm

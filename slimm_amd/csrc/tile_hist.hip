@@ -9,7 +9,7 @@
 //   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slice of the targets, merged into
 //                   tile_count[] with one (contiguous, non-returning) global atomic per non-empty tile
 //   k_tile_scan     exclusive scan tile_count -> tile_base (one workgroup; <= 36 K tiles)
-//   k_tile_scatter  same slices; reserves a range per (workgroup, tile) with one returning atomic on tile_cursor[],
+//   k_tile_scatter  zeroes the tiles that will be accumulated with atomics; same slices; reserves a range per (workgroup, tile) with one returning atomic on tile_cursor[],
 //                   then writes each target as a 16-bit word (13-bit bin-in-tile | unique bit) into its bucket
 //   k_tile_hist     one workgroup per tile: LDS cov[8192] + uniq_cov[8192], bucket in, finished tile out
 //
@@ -113,9 +113,21 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
                                                           const uint32_t* __restrict__ counters, int count_slot,
                                                           uint32_t ntiles, const uint32_t* __restrict__ tile_base,
                                                           uint32_t* __restrict__ tile_cursor,
-                                                          uint16_t* __restrict__ bucket) {
+                                                          uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
+                                                          uint32_t* __restrict__ ucov) {
     extern __shared__ uint32_t s_hist[];
     const uint32_t P = counters[count_slot];
+    // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) continue;
+        uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
+        uint4* ou = reinterpret_cast<uint4*>((ucov ? ucov : cov) + static_cast<size_t>(tile) * kTileBins);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += kTBlock) {
+            oc[i] = z;
+            if (ucov) ou[i] = z;
+        }
+    }
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
     uint32_t lo, hi;
@@ -159,21 +171,6 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
             uint32_t pos = atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
             bucket[pos] = static_cast<uint16_t>((g[u] & kTileMask) | (uniq ? kTileBins : 0u));
         }
-    }
-}
-
-// tiles cut into several work items are accumulated with (contiguous) global atomics, so they start from zero
-template <bool kTwo>
-__global__ __launch_bounds__(256) void k_tile_zero_split(const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ cov,
-                                                         uint32_t* __restrict__ ucov) {
-    const uint32_t tile = blockIdx.x;
-    if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) return;
-    uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
-    uint4* ou = reinterpret_cast<uint4*>(ucov + static_cast<size_t>(tile) * kTileBins);
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 256) {
-        oc[i] = z;
-        if (kTwo) ou[i] = z;
     }
 }
 
@@ -253,7 +250,6 @@ int tile_hist_setup(uint32_t ntiles) {
 
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
                        int count_slot, uint32_t* tile_count) {
-    (void)hipMemsetAsync(tile_count, 0, static_cast<size_t>(ntiles) * 4, st);
     hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, gbin, counters,
                        count_slot, ntiles, tile_count);
 }
@@ -265,14 +261,14 @@ void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_coun
 
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
                          const uint32_t* counters, int count_slot, const uint32_t* tile_base, uint32_t* tile_cursor,
-                         uint16_t* bucket) {
+                         uint16_t* bucket, uint32_t* cov, uint32_t* ucov) {
     const size_t lds = static_cast<size_t>(ntiles) * 4;
     if (tgt_ref)
         hipLaunchKernelGGL(k_tile_scatter<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                           ntiles, tile_base, tile_cursor, bucket);
+                           ntiles, tile_base, tile_cursor, bucket, cov, ucov);
     else
         hipLaunchKernelGGL(k_tile_scatter<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                           ntiles, tile_base, tile_cursor, bucket);
+                           ntiles, tile_base, tile_cursor, bucket, cov, ucov);
 }
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }
@@ -281,13 +277,10 @@ uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov) {
     const uint32_t grid = tile_items_upper(ntiles, n_upper);
-    if (ucov) {
-        hipLaunchKernelGGL(k_tile_zero_split<true>, dim3(ntiles), dim3(256), 0, st, tile_base, cov, ucov);
+    if (ucov)
         hipLaunchKernelGGL(k_tile_hist<true>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov);
-    } else {
-        hipLaunchKernelGGL(k_tile_zero_split<false>, dim3(ntiles), dim3(256), 0, st, tile_base, cov, cov);
+    else
         hipLaunchKernelGGL(k_tile_hist<false>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov);
-    }
 }
 
 }  // namespace slimm

@@ -61,6 +61,23 @@ def algorithmic_bytes(st, n_records, Bp_words):
     }
 
 
+def pmc_traffic_bytes(kernel_name, records_per_gpu):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh run on
+    MI355X with the default workload; FETCH_SIZE and WRITE_SIZE collected in separate passes, unit KB).  gfx950
+    correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-byte requests as 64 bytes, i.e. half of a
+    coalesced stream -- calibrated here on k_ref_stats, whose 16 B/lane loads read exactly 8 B per bin (ratio 2.03) --
+    so fetched bytes = 2 * FETCH_SIZE; WRITE_SIZE is exact.  None when no profile matches."""
+    path = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_summary.json")
+    if records_per_gpu != 10_000_000 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    for k, v in d.items():
+        if k.split("<")[0] == kernel_name and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,7 +188,9 @@ def main():
         d = cand[dom]
         achieved = d["bytes_per_launch"] / (d["ms_per_launch"] * 1e-3) / 1e9
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc_traffic_bytes(dom, n_rec) if args.config == "config2" else None,
+                    "traffic_source": "profiles/round1/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes)",
                     "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
         kernel_ms = sum(v["ms_per_launch"] * v["launches_per_step"] for v in per_kernel.values())
         if args.breakdown:

@@ -1,0 +1,21 @@
+# HBM traffic of every kernel from the TCC counters, in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/pmc_traffic; mkdir -p $OUT; cd /tmp
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/err_f.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/err_w.txt
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>$OUT/err_r.txt
+python3 - <<PY
+import csv, collections, glob, json
+res=collections.defaultdict(dict)
+for tag in ("fetch","write","req"):
+    try: rows=list(csv.DictReader(open("$OUT/%s_counter_collection.csv"%tag)))
+    except Exception as e: print("missing",tag,e); continue
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
+    for r in rows:
+        k=r["Kernel_Name"].split("(")[0].replace("void slimm::","").replace("slimm::","")
+        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    for k,v in agg.items():
+        if k.startswith("__amd"): continue
+        for a,b in v.items(): res[k][a]=b/len(n[k])
+json.dump(res, open("$OUT/summary.json","w"), indent=1)
+for k,v in res.items(): print(k, {a:round(b,1) for a,b in v.items()})
+PY

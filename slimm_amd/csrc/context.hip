@@ -110,7 +110,8 @@ struct slimm_ctx {
     DevBuf<uint32_t> tile_valid;
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor;
-    DevBuf<uint4> tile_items;
+    DevBuf<uint4> tile_items, part_items;
+    DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
@@ -225,6 +226,9 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles2, n) + 1));
         HIP_TRY(c, c->uniq_gbin.ensure(n + 1));
+        HIP_TRY(c, c->mid.ensure(n + 1));
+        HIP_TRY(c, c->part_items.ensure(part_items_upper(c->ntiles2, n) + 1));
+        HIP_TRY(c, c->sup_cursor.ensure(kMaxSuper));
     }
     if (c->order == SLIMM_ORDER_ANY) {
         HIP_TRY(c, c->c_ident.ensure(n + 1));
@@ -583,12 +587,13 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_TILE_SCAN);
             launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                             c->counters.p);
+                             c->counters.p, c->part_items.p, c->sup_cursor.p);
         }
         {
             KernelTimer t(c, K_TILE_SCATTER);
-            launch_tile_scatter(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
-                                c->tile_cursor.p, c->bucket.p, c->cov(), c->ucov());
+            launch_tile_scatter(st, grid, c->ntiles, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
+                                c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(),
+                                c->ucov());
         }
         {
             KernelTimer t(c, K_TILE_HIST);
@@ -783,12 +788,13 @@ int slimm_filter_alignments(slimm_ctx* c) {
             {
                 KernelTimer t(c, K_TILE_SCAN2);
                 launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                 c->counters.p);
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
-                launch_tile_scatter(st, grid, c->ntiles2, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_base.p,
-                                    c->tile_cursor.p, c->bucket.p, c->ucov2(), nullptr);
+                launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M,
+                                    c->tile_base.p, c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p,
+                                    c->bucket.p, c->ucov2(), nullptr);
             }
             {
                 KernelTimer t(c, K_TILE_HIST2);

@@ -93,42 +93,48 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cn
                                                      uint32_t* __restrict__ counters, int slot_x, int slot_y,
                                                      uint32_t* __restrict__ read_off, const uint32_t* __restrict__ extra,
                                                      int slot_extra, uint32_t* __restrict__ tail) {
-    __shared__ uint2 s_part[1024];
+    // coalesced chunks of 1024 entries with a running carry: wave scan by shuffles, wave totals through LDS
+    __shared__ uint2 s_wave[16];
     __shared__ uint32_t s_extra[16];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (ntiles + 1023) / 1024;
-    const uint32_t lo = tid * per;
-    const uint32_t hi = min(lo + per, ntiles);
-    uint2 sum = make_uint2(0u, 0u);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint2 carry = make_uint2(0u, 0u);
     uint32_t ex = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint2 v = tile_cnt[i];
-        sum.x += v.x;
-        sum.y += v.y;
-        if (extra) ex += extra[i];
+    for (uint32_t c0 = 0; c0 < ntiles; c0 += 1024) {
+        const uint32_t i = c0 + tid;
+        uint2 v = (i < ntiles) ? tile_cnt[i] : make_uint2(0u, 0u);
+        if (extra && i < ntiles) ex += extra[i];
+        uint2 inc = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
+            if (lane >= static_cast<uint32_t>(o)) {
+                inc.x += ax;
+                inc.y += ay;
+            }
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint2 before = carry, total = make_uint2(0u, 0u);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint2 t = s_wave[w];
+            if (w < static_cast<int>(wave)) {
+                before.x += t.x;
+                before.y += t.y;
+            }
+            total.x += t.x;
+            total.y += t.y;
+        }
+        if (i < ntiles) tile_cnt[i] = make_uint2(before.x + inc.x - v.x, before.y + inc.y - v.y);
+        carry.x += total.x;
+        carry.y += total.y;
+        __syncthreads();
     }
-    s_part[tid] = sum;
     ex = wave_sum(ex);
-    if ((tid & 63) == 0) s_extra[tid >> 6] = ex;
+    if (lane == 0) s_extra[wave] = ex;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint2 add = make_uint2(0u, 0u);
-        if (tid >= off) add = s_part[tid - off];
-        __syncthreads();
-        s_part[tid].x += add.x;
-        s_part[tid].y += add.y;
-        __syncthreads();
-    }
-    uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);  // exclusive prefix of this thread's chunk
-    for (uint32_t i = lo; i < hi; ++i) {
-        uint2 v = tile_cnt[i];
-        tile_cnt[i] = run;
-        run.x += v.x;
-        run.y += v.y;
-    }
-    if (tid == 1023) {
-        uint2 tot = s_part[1023];
+    if (tid == 0) {
+        const uint2 tot = carry;
         tile_cnt[ntiles] = tot;
         counters[slot_x] = tot.x;
         if (slot_y >= 0) counters[slot_y] = tot.y;

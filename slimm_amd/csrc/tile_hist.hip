@@ -9,8 +9,13 @@
 //   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slice of the targets, merged into
 //                   tile_count[] with one (contiguous, non-returning) global atomic per non-empty tile
 //   k_tile_scan     exclusive scan tile_count -> tile_base (one workgroup; <= 36 K tiles)
-//   k_tile_scatter  zeroes the tiles that will be accumulated with atomics; same slices; reserves a range per (workgroup, tile) with one returning atomic on tile_cursor[],
-//                   then writes each target as a 16-bit word (13-bit bin-in-tile | unique bit) into its bucket
+//   k_part_super    same slices; level 1 of the bucketing: targets go to their SUPER tile (256 tiles = 2 M bins) as
+//                   32-bit words (21-bit bin-in-super | unique bit).  <= ~100 destinations per workgroup, so every
+//                   workgroup writes runs of hundreds of bytes.  Also zeroes the tiles that k_tile_hist will
+//                   accumulate with atomics.
+//   k_part_tile     level 2: work items of <= 32 K entries of one super tile are split into its 256 tiles as 16-bit
+//                   words (13-bit bin-in-tile | unique bit).  (A one-level scatter into thousands of tiles wrote
+//                   2-byte stores all over memory: 123 MB of write traffic for 16 MB of payload at config 2.)
 //   k_tile_hist     one workgroup per tile: LDS cov[8192] + uniq_cov[8192], bucket in, finished tile out
 //
 // Reference semantics: src/slimm.hpp:219-257 (cov[bin]++ per target; uniq_cov[bin]++ when the read has one target).
@@ -66,7 +71,8 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
 // A tile with no entry still gets one item (its finished tile is all zeros and has to be written).
 __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
                                                     uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
-                                                    uint4* __restrict__ items, uint32_t* __restrict__ counters) {
+                                                    uint4* __restrict__ items, uint32_t* __restrict__ counters,
+                                                    uint4* __restrict__ items2, uint32_t* __restrict__ sup_cursor) {
     __shared__ uint2 s_part[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (ntiles + 1023) / 1024;
@@ -105,18 +111,30 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
         tile_base[ntiles] = s_part[1023].x;
         counters[CNT_ITEMS] = s_part[1023].y;
     }
+    __syncthreads();  // tile_base is complete (same workgroup, same CU)
+    if (tid == 0) {   // work items of k_part_tile: <= kPartSub entries of one super tile each
+        const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
+        uint32_t n2 = 0;
+        for (uint32_t sp = 0; sp < nsup; ++sp) {
+            sup_cursor[sp] = 0;
+            const uint32_t a = tile_base[sp * kSuperTiles];
+            const uint32_t b = tile_base[min((sp + 1) * kSuperTiles, ntiles)];
+            for (uint32_t q = a; q < b; q += kPartSub) items2[n2++] = make_uint4(sp, q, min(q + kPartSub, b), 0u);
+        }
+        counters[CNT_ITEMS2] = n2;
+    }
 }
 
 template <bool kWithRef>
-__global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ tgt_ref,
-                                                          const uint32_t* __restrict__ tgt_gbin,
-                                                          const uint32_t* __restrict__ counters, int count_slot,
-                                                          uint32_t ntiles, const uint32_t* __restrict__ tile_base,
-                                                          uint32_t* __restrict__ tile_cursor,
-                                                          uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
-                                                          uint32_t* __restrict__ ucov) {
-    extern __shared__ uint32_t s_hist[];
+__global__ __launch_bounds__(kTBlock) void k_part_super(const uint32_t* __restrict__ tgt_ref,
+                                                        const uint32_t* __restrict__ tgt_gbin,
+                                                        const uint32_t* __restrict__ counters, int count_slot,
+                                                        uint32_t ntiles, const uint32_t* __restrict__ tile_base,
+                                                        uint32_t* __restrict__ sup_cursor, uint32_t* __restrict__ mid,
+                                                        uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
+    __shared__ uint32_t s_cur[kMaxSuper];
     const uint32_t P = counters[count_slot];
+    const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
     // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) continue;
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
             if (ucov) ou[i] = z;
         }
     }
-    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) s_cur[i] = 0;
     __syncthreads();
     uint32_t lo, hi;
     slice_of(P, blockIdx.x, gridDim.x, lo, hi);
@@ -141,13 +159,13 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (g[u] != 0xffffffffu) atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+            if (g[u] != 0xffffffffu) atomicAdd(&s_cur[g[u] >> kSuperShift], 1u);
     }
     __syncthreads();
-    // reserve [base, base + h) of each non-empty tile's bucket for this workgroup; s_hist becomes the write cursor
-    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
-        uint32_t h = s_hist[i];
-        if (h) s_hist[i] = tile_base[i] + atomicAdd(&tile_cursor[i], h);
+    // reserve [base, base + h) of each non-empty super tile's range for this workgroup; s_cur becomes the write cursor
+    for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) {
+        uint32_t h = s_cur[i];
+        if (h) s_cur[i] = tile_base[i * kSuperTiles] + atomicAdd(&sup_cursor[i], h);
     }
     __syncthreads();
     for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
@@ -168,8 +186,54 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
         for (int u = 0; u < 4; ++u) {
             if (g[u] == 0xffffffffu) continue;
             bool uniq = (r0[u] >> 31) && (r1[u] >> 31);  // first target of its read and the next target starts a read
-            uint32_t pos = atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
-            bucket[pos] = static_cast<uint16_t>((g[u] & kTileMask) | (uniq ? kTileBins : 0u));
+            uint32_t pos = atomicAdd(&s_cur[g[u] >> kSuperShift], 1u);
+            mid[pos] = (g[u] & kSuperMask) | (uniq ? (1u << kSuperShift) : 0u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kTBlock) void k_part_tile(const uint32_t* __restrict__ mid, const uint4* __restrict__ items2,
+                                                       const uint32_t* __restrict__ counters,
+                                                       const uint32_t* __restrict__ tile_base,
+                                                       uint32_t* __restrict__ tile_cursor, uint32_t ntiles,
+                                                       uint16_t* __restrict__ bucket) {
+    __shared__ uint32_t s_cur[kSuperTiles];
+    if (blockIdx.x >= counters[CNT_ITEMS2]) return;
+    const uint4 it = items2[blockIdx.x];
+    const uint32_t sup = it.x, lo = it.y, hi = it.z;
+    const uint32_t tile0 = sup * kSuperTiles;
+    if (threadIdx.x < kSuperTiles) s_cur[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kTBlock) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t e = e0 + u * kTBlock + threadIdx.x;
+            v[u] = (e < hi) ? mid[e] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != 0xffffffffu) atomicAdd(&s_cur[(v[u] & kSuperMask) >> kTileShift], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kSuperTiles) {
+        const uint32_t h = s_cur[threadIdx.x], tile = tile0 + threadIdx.x;
+        if (h && tile < ntiles) s_cur[threadIdx.x] = tile_base[tile] + atomicAdd(&tile_cursor[tile], h);
+    }
+    __syncthreads();
+    for (uint32_t e0 = lo; e0 < hi; e0 += 4 * kTBlock) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t e = e0 + u * kTBlock + threadIdx.x;
+            v[u] = (e < hi) ? mid[e] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (v[u] == 0xffffffffu) continue;
+            const uint32_t local = v[u] & kSuperMask;
+            uint32_t pos = atomicAdd(&s_cur[local >> kTileShift], 1u);
+            bucket[pos] = static_cast<uint16_t>((local & kTileMask) | (((v[u] >> kSuperShift) & 1u) ? kTileBins : 0u));
         }
     }
 }
@@ -239,12 +303,7 @@ int tile_hist_setup(uint32_t ntiles) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_count), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(bytes)) != hipSuccess)
         return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
-        return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
-        return -1;
+    if ((ntiles + kSuperTiles - 1) / kSuperTiles > kMaxSuper) return -1;
     return 0;
 }
 
@@ -255,20 +314,27 @@ void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uin
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
-                      uint32_t* tile_cursor, uint4* items, uint32_t* counters) {
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters);
+                      uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor) {
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters,
+                       items2, sup_cursor);
 }
 
-void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
-                         const uint32_t* counters, int count_slot, const uint32_t* tile_base, uint32_t* tile_cursor,
-                         uint16_t* bucket, uint32_t* cov, uint32_t* ucov) {
-    const size_t lds = static_cast<size_t>(ntiles) * 4;
+uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
+    return (ntiles + kSuperTiles - 1) / kSuperTiles + n_upper / kPartSub + 1;
+}
+
+void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
+                         const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
+                         uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
+                         uint32_t* cov, uint32_t* ucov) {
     if (tgt_ref)
-        hipLaunchKernelGGL(k_tile_scatter<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                           ntiles, tile_base, tile_cursor, bucket, cov, ucov);
+        hipLaunchKernelGGL(k_part_super<true>, dim3(grid), dim3(kTBlock), 0, st, tgt_ref, gbin, counters, count_slot, ntiles,
+                           tile_base, sup_cursor, mid, cov, ucov);
     else
-        hipLaunchKernelGGL(k_tile_scatter<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                           ntiles, tile_base, tile_cursor, bucket, cov, ucov);
+        hipLaunchKernelGGL(k_part_super<false>, dim3(grid), dim3(kTBlock), 0, st, tgt_ref, gbin, counters, count_slot, ntiles,
+                           tile_base, sup_cursor, mid, cov, ucov);
+    hipLaunchKernelGGL(k_part_tile, dim3(part_items_upper(ntiles, n_upper)), dim3(kTBlock), 0, st, mid, items2, counters,
+                       tile_base, tile_cursor, ntiles, bucket);
 }
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }

@@ -115,6 +115,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
+    bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
     DevBuf<uint32_t> counters;   // CNT_WORDS
@@ -359,6 +360,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
         cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles2) == 0;
+        {
+            const char* tl = getenv("SLIMM_TWO_LEVEL");  // default: by size (measured: one level 87 us vs 90 us at 2.4 K
+            cc->two_level = tl ? (tl[0] == '1') : (c->ntiles2 > 4096);  // tiles, 996 us vs 603 us at 9.8 K tiles)
+        }
         if (cc->use_tiles) {
             if (cc->tile_count.ensure(c->ntiles2 + 1) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
                 cc->tile_cursor.ensure(c->ntiles2 + 1) != hipSuccess)
@@ -593,7 +598,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             KernelTimer t(c, K_TILE_SCATTER);
             launch_tile_scatter(st, grid, c->ntiles, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
                                 c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(),
-                                c->ucov());
+                                c->ucov(), c->two_level);
         }
         {
             KernelTimer t(c, K_TILE_HIST);
@@ -794,7 +799,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
                 KernelTimer t(c, K_TILE_SCATTER2);
                 launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M,
                                     c->tile_base.p, c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p,
-                                    c->bucket.p, c->ucov2(), nullptr);
+                                    c->bucket.p, c->ucov2(), nullptr, c->two_level);
             }
             {
                 KernelTimer t(c, K_TILE_HIST2);

@@ -90,21 +90,21 @@ int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this m
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
                        int count_slot, uint32_t* tile_count);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
-constexpr uint32_t kSuperTiles = 256;                   // tiles per super tile (level 1 of the bucketing)
-constexpr uint32_t kSuperShift = kTileShift + 8;        // 2 M bins per super tile
+constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
+constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile
 constexpr uint32_t kSuperMask = (1u << kSuperShift) - 1;
-constexpr uint32_t kMaxSuper = 2048;                    // super tiles an LDS cursor array holds (4 G bins)
+constexpr uint32_t kMaxSuper = 8192;                    // super tiles an LDS cursor array holds (4 G bins)
 constexpr uint32_t kPartSub = 32768;                    // entries per k_part_tile work item
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper);
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor);
-// two-level bucketing (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
+// bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
                          const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
                          uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
-                         uint32_t* cov, uint32_t* ucov);
+                         uint32_t* cov, uint32_t* ucov, bool two_level);
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov);
 

@@ -111,17 +111,92 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
         tile_base[ntiles] = s_part[1023].x;
         counters[CNT_ITEMS] = s_part[1023].y;
     }
+    __shared__ uint32_t s_n2;
+    if (tid == 0) s_n2 = 0;
+    __threadfence_block();
     __syncthreads();  // tile_base is complete (same workgroup, same CU)
-    if (tid == 0) {   // work items of k_part_tile: <= kPartSub entries of one super tile each
-        const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
-        uint32_t n2 = 0;
-        for (uint32_t sp = 0; sp < nsup; ++sp) {
-            sup_cursor[sp] = 0;
-            const uint32_t a = tile_base[sp * kSuperTiles];
-            const uint32_t b = tile_base[min((sp + 1) * kSuperTiles, ntiles)];
-            for (uint32_t q = a; q < b; q += kPartSub) items2[n2++] = make_uint4(sp, q, min(q + kPartSub, b), 0u);
+    // work items of k_part_tile: <= kPartSub entries of one super tile each (their order does not matter)
+    const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
+    for (uint32_t sp = tid; sp < nsup; sp += 1024) {
+        sup_cursor[sp] = 0;
+        const uint32_t a = tile_base[sp * kSuperTiles];
+        const uint32_t b = tile_base[min((sp + 1) * kSuperTiles, ntiles)];
+        const uint32_t pieces = (b - a + kPartSub - 1) / kPartSub;
+        if (pieces) {
+            uint32_t slot = atomicAdd(&s_n2, pieces);
+            for (uint32_t q = a; q < b; q += kPartSub) items2[slot++] = make_uint4(sp, q, min(q + kPartSub, b), 0u);
         }
-        counters[CNT_ITEMS2] = n2;
+    }
+    __syncthreads();
+    if (tid == 0) counters[CNT_ITEMS2] = s_n2;
+}
+
+template <bool kWithRef>
+__global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ tgt_ref,
+                                                          const uint32_t* __restrict__ tgt_gbin,
+                                                          const uint32_t* __restrict__ counters, int count_slot,
+                                                          uint32_t ntiles, const uint32_t* __restrict__ tile_base,
+                                                          uint32_t* __restrict__ tile_cursor,
+                                                          uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
+                                                          uint32_t* __restrict__ ucov) {
+    extern __shared__ uint32_t s_hist[];
+    const uint32_t P = counters[count_slot];
+    // (one-level variant, used while the tile-id histogram fits LDS comfortably: fewer passes, but 2-byte stores scattered
+    // over thousands of buckets)
+    // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) continue;
+        uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
+        uint4* ou = reinterpret_cast<uint4*>((ucov ? ucov : cov) + static_cast<size_t>(tile) * kTileBins);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += kTBlock) {
+            oc[i] = z;
+            if (ucov) ou[i] = z;
+        }
+    }
+    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
+    __syncthreads();
+    uint32_t lo, hi;
+    slice_of(P, blockIdx.x, gridDim.x, lo, hi);
+    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
+        uint32_t g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t t = t0 + u * kTBlock + threadIdx.x;
+            g[u] = (t < hi) ? tgt_gbin[t] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (g[u] != 0xffffffffu) atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+    }
+    __syncthreads();
+    // reserve [base, base + h) of each non-empty tile's bucket for this workgroup; s_hist becomes the write cursor
+    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
+        uint32_t h = s_hist[i];
+        if (h) s_hist[i] = tile_base[i] + atomicAdd(&tile_cursor[i], h);
+    }
+    __syncthreads();
+    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
+        uint32_t g[4], r0[4], r1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t t = t0 + u * kTBlock + threadIdx.x;
+            bool live = t < hi;
+            g[u] = live ? tgt_gbin[t] : 0xffffffffu;
+            if (kWithRef) {
+                r0[u] = live ? tgt_ref[t] : 0u;
+                r1[u] = (live && t + 1 < P) ? tgt_ref[t + 1] : 0x80000000u;
+            } else {
+                r0[u] = r1[u] = 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (g[u] == 0xffffffffu) continue;
+            bool uniq = (r0[u] >> 31) && (r1[u] >> 31);  // first target of its read and the next target starts a read
+            uint32_t pos = atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+            bucket[pos] = static_cast<uint16_t>((g[u] & kTileMask) | (uniq ? kTileBins : 0u));
+        }
     }
 }
 
@@ -304,6 +379,12 @@ int tile_hist_setup(uint32_t ntiles) {
                             static_cast<int>(bytes)) != hipSuccess)
         return -1;
     if ((ntiles + kSuperTiles - 1) / kSuperTiles > kMaxSuper) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
+        return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
+        return -1;
     return 0;
 }
 
@@ -326,7 +407,17 @@ uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
                          const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
                          uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
-                         uint32_t* cov, uint32_t* ucov) {
+                         uint32_t* cov, uint32_t* ucov, bool two_level) {
+    if (!two_level) {
+        const size_t lds = static_cast<size_t>(ntiles) * 4;
+        if (tgt_ref)
+            hipLaunchKernelGGL(k_tile_scatter<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
+                               ntiles, tile_base, tile_cursor, bucket, cov, ucov);
+        else
+            hipLaunchKernelGGL(k_tile_scatter<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters,
+                               count_slot, ntiles, tile_base, tile_cursor, bucket, cov, ucov);
+        return;
+    }
     if (tgt_ref)
         hipLaunchKernelGGL(k_part_super<true>, dim3(grid), dim3(kTBlock), 0, st, tgt_ref, gbin, counters, count_slot, ntiles,
                            tile_base, sup_cursor, mid, cov, ucov);

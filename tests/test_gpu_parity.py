@@ -173,6 +173,13 @@ def test_direct_atomic_fallback_path(monkeypatch):
     check(make_workload(CONFIGS["config1"], seed=16))
 
 
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_both_bucketing_variants(monkeypatch, two):
+    monkeypatch.setenv("SLIMM_TWO_LEVEL", two)
+    check(make_workload(CONFIGS["config2"], seed=20, n_records=300_000))
+    check(make_workload(CONFIGS["config1"], seed=21))
+
+
 def test_wide_lineage_rows_fallback_path(monkeypatch):
     """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
     monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")

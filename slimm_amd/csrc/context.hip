@@ -271,7 +271,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     if (!cfg || !out) return fail(nullptr, SLIMM_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->n_refs == 0 || !cfg->ref_len || !cfg->lineage) return fail(nullptr, SLIMM_E_INVALID, "no references");
-    if (cfg->n_refs >= (1u << 28)) return fail(nullptr, SLIMM_E_INVALID, "too many references (limit 2^28)");
+    if (cfg->n_refs >= (1u << 28) - 1) return fail(nullptr, SLIMM_E_INVALID, "too many references (limit 2^28 - 2)");
     if (cfg->bin_width == 0 && cfg->avg_read_len == 0)
         return fail(nullptr, SLIMM_E_INVALID, "bin_width and avg_read_len are both 0 (the reference divides by zero)");
     HostConfig hc;

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace slimm {
@@ -197,6 +199,190 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_runs_hash: the same classification in O(1) per record.  The look-back of k_runs costs O(records of the read) per
+// record and a whole wave waits for its longest run -- fine at 3 hits per read, the dominant cost at 40 (BASELINE
+// config 5: 4.2 ms of a 9.7 ms file).  Here every mapped record of the staged window puts
+//     (run, mate, ref)  and  (run, mate, ANY)
+// into an LDS hash table with atomicMin(record index); afterwards `first` <=> the minimum of its (run, mate, ref) entry
+// is the record itself, `head` <=> likewise for (run, mate, ANY), and "an earlier record of the run has a larger mate"
+// <=> the minimum of a larger mate's ANY entry is smaller than the record's index.  `run` is the window index of the
+// run's first record (block-wide max-scan of the run-start flags).  Records whose run starts before the staged window
+// (512 records of back halo) fall back to the global look-back walk.
+// One 64-bit LDS word per entry: (run 12 bits | mate 2 | ref 28) << 12 | window index.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHBlock = 512;
+constexpr uint32_t kHHalo = 512;
+constexpr uint32_t kHWin = kRTile + kHHalo;        // 2560 staged records
+constexpr uint32_t kHSlots = 8192;                 // >= 2 entries per staged record at load <= 0.63
+constexpr uint32_t kRefAny = 0x0fffffffu;          // not a reference id: slimm_create keeps n_refs below 2^28 - 1
+constexpr uint64_t kEmptySlot = ~0ull;
+
+__device__ __forceinline__ uint32_t hash_slot(uint64_t key) {
+    key ^= key >> 23;
+    key *= 0x2127599bf4325c37ULL;
+    key ^= key >> 29;
+    return static_cast<uint32_t>(key) & (kHSlots - 1);
+}
+
+// insert (key, idx) keeping the minimum idx; returns the slot
+__device__ __forceinline__ uint32_t hash_put_min(uint64_t* tab, uint64_t key, uint32_t idx) {
+    const uint64_t val = (key << 12) | idx;
+    uint32_t s = hash_slot(key);
+    while (true) {
+        uint64_t cur = tab[s];
+        if (cur == kEmptySlot) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[s]),
+                                                     static_cast<unsigned long long>(kEmptySlot),
+                                                     static_cast<unsigned long long>(val));
+            if (old == kEmptySlot) return s;
+            cur = old;
+        }
+        if ((cur >> 12) == key) {
+            atomicMin(reinterpret_cast<unsigned long long*>(&tab[s]), static_cast<unsigned long long>(val));
+            return s;
+        }
+        s = (s + 1) & (kHSlots - 1);
+    }
+}
+
+// minimum idx stored for key, or 0xffffffff when the key is absent
+__device__ __forceinline__ uint32_t hash_get_min(const uint64_t* tab, uint64_t key) {
+    uint32_t s = hash_slot(key);
+    while (true) {
+        const uint64_t cur = tab[s];
+        if (cur == kEmptySlot) return 0xffffffffu;
+        if ((cur >> 12) == key) return static_cast<uint32_t>(cur) & 0xfffu;
+        s = (s + 1) & (kHSlots - 1);
+    }
+}
+
+template <typename Acc>
+__global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t* __restrict__ counters,
+                                                       uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
+                                                       uint32_t* __restrict__ tile_valid) {
+    __shared__ uint64_t s_tab[kHSlots];
+    __shared__ uint32_t s_meta[kHWin];
+    __shared__ uint16_t s_rs[kHWin];     // window index of the run's first record + 1; 0 = starts before the window
+    __shared__ uint32_t s_wmax[kHBlock / 64];
+    __shared__ uint2 s_w[kHBlock / 64];
+    __shared__ uint32_t s_v[kHBlock / 64];
+    const uint32_t N = acc.count(counters);
+    const uint32_t base = blockIdx.x * kRTile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t nh = 0, nf = 0, nv = 0;
+    bool bad = false, too_long = false;
+    if (base < N) {
+        const uint32_t lds_lo = base >= kHHalo ? base - kHHalo : 0u;
+        const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
+        const uint32_t wn = lds_hi - lds_lo;  // staged records
+        for (uint32_t i = tid; i < kHSlots; i += kHBlock) s_tab[i] = kEmptySlot;
+        for (uint32_t i = lds_lo + tid; i < lds_hi; i += kHBlock) s_meta[i - lds_lo] = full_meta(acc, i, bad);
+        __syncthreads();
+        // run start of every staged record: inclusive max-scan of (run-start ? index + 1 : 0), 512 records per trip
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < wn; c0 += kHBlock) {
+            const uint32_t j = c0 + tid;
+            uint32_t v = (j < wn && (s_meta[j] & M_RUN)) ? j + 1 : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t a = __shfl_up(v, o, 64);
+                if (lane >= static_cast<uint32_t>(o)) v = max(v, a);
+            }
+            if (lane == 63) s_wmax[wave] = v;
+            __syncthreads();
+            uint32_t before = carry, total = carry;
+#pragma unroll
+            for (int w = 0; w < kHBlock / 64; ++w) {
+                const uint32_t t = s_wmax[w];
+                if (w < static_cast<int>(wave)) before = max(before, t);
+                total = max(total, t);
+            }
+            if (j < wn) s_rs[j] = static_cast<uint16_t>(max(v, before));
+            carry = total;
+            __syncthreads();
+        }
+        // every mapped staged record (halo included: it holds the predecessors) enters the table twice
+        for (uint32_t j = tid; j < wn; j += kHBlock) {
+            const uint32_t me = s_meta[j], rs = s_rs[j];
+            if ((me & M_VALID) && rs) {
+                const uint64_t run = static_cast<uint64_t>(rs - 1) << 30;
+                hash_put_min(s_tab, run | (me & M_IDENT), j);
+                hash_put_min(s_tab, run | (me & 0x30000000u) | kRefAny, j);
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < kRTile / kHBlock; ++k) {
+            const uint32_t i = base + k * kHBlock + tid;
+            if (i >= N) continue;
+            const uint32_t j = i - lds_lo;
+            const uint32_t me = s_meta[j], rs = s_rs[j];
+            const bool valid = me & M_VALID;
+            const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
+            bool head = valid, first = valid, greater_before = false;
+            if (valid && !(me & M_RUN)) {
+                if (rs) {
+                    const uint64_t run = static_cast<uint64_t>(rs - 1) << 30;
+                    first = hash_get_min(s_tab, run | my_ident) == j;
+                    head = hash_get_min(s_tab, run | (me & 0x30000000u) | kRefAny) == j;
+                    for (uint32_t m2 = my_mate + 1; m2 < 3; ++m2)
+                        greater_before = greater_before || hash_get_min(s_tab, run | (m2 << 28) | kRefAny) < j;
+                } else {  // the run starts before the staged window: walk back through global memory (rare)
+                    uint32_t q = i, steps = 0;
+                    while (q > 0) {
+                        --q;
+                        bool dummy = false;
+                        const uint32_t m = (q >= lds_lo) ? s_meta[q - lds_lo] : full_meta(acc, q, dummy);
+                        if (m & M_VALID) {
+                            const uint32_t mt = (m >> 28) & 3u;
+                            if ((m & M_IDENT) == my_ident) {
+                                head = false;
+                                first = false;
+                                break;
+                            }
+                            head = head && (mt != my_mate);
+                            greater_before = greater_before || (mt > my_mate);
+                        }
+                        if (m & M_RUN) break;
+                        if (++steps > kLookBackMax + kHHalo) {
+                            too_long = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            const uint32_t f = (my_mate << FL_MATE_SHIFT) | ((me & M_RUN) ? FL_RUN_START : 0u) | (head ? FL_HEAD : 0u) |
+                               (first ? FL_FIRST : 0u) | ((valid && greater_before) ? FL_GREATER_BEFORE : 0u);
+            nh += head;
+            nf += first;
+            nv += valid;
+            fl[i] = static_cast<uint8_t>(f);
+        }
+    }
+    nh = r_wave_sum(nh);
+    nf = r_wave_sum(nf);
+    nv = r_wave_sum(nv);
+    const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
+    if (lane == 0) {
+        s_w[wave] = make_uint2(nh, nf);
+        s_v[wave] = nv;
+        if (err) atomicOr(&counters[CNT_ERR], err);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint2 t = make_uint2(0u, 0u);
+        uint32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < kHBlock / 64; ++w) {
+            t.x += s_w[w].x;
+            t.y += s_w[w].y;
+            v += s_v[w];
+        }
+        tile_cnt[blockIdx.x] = t;
+        if (Acc::kCountsMapped) tile_valid[blockIdx.x] = v;
+    }
+}
+
 template <typename Acc>
 __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* __restrict__ fl,
                                                   uint32_t* __restrict__ counters, const uint2* __restrict__ tile_off,
@@ -318,6 +504,12 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
 
 static inline uint32_t rtiles(uint32_t n) { return (n + kRTile - 1) / kRTile; }
 
+// SLIMM_WALK_RUNS=1 selects the look-back classification (k_runs) instead of the hash table (k_runs_hash)
+static bool use_hash_runs() {
+    const char* e = getenv("SLIMM_WALK_RUNS");
+    return !(e && e[0] == '1');
+}
+
 static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len, const uint32_t* bin_off,
                            uint32_t half_read, uint32_t bin_width) {
     RawRecords a;
@@ -339,8 +531,12 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
                      uint2* tile_cnt, uint32_t* tile_valid) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
-    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(nt), dim3(kRBlock), 0, st,
-                       make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt, tile_valid);
+    if (use_hash_runs())
+        hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(nt), dim3(kHBlock), 0, st,
+                           make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt, tile_valid);
+    else
+        hipLaunchKernelGGL(k_runs<RawRecords>, dim3(nt), dim3(kRBlock), 0, st,
+                           make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt, tile_valid);
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
@@ -358,8 +554,12 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     const uint32_t nt = rtiles(n_upper);
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
-    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt,
-                       static_cast<uint32_t*>(nullptr));
+    if (use_hash_runs())
+        hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(nt), dim3(kHBlock), 0, st, a, counters, fl, tile_cnt,
+                           static_cast<uint32_t*>(nullptr));
+    else
+        hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt,
+                           static_cast<uint32_t*>(nullptr));
 }
 
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

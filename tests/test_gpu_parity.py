@@ -173,6 +173,23 @@ def test_direct_atomic_fallback_path(monkeypatch):
     check(make_workload(CONFIGS["config1"], seed=16))
 
 
+def test_lookback_classification_variant(monkeypatch):
+    """k_runs (look-back walk) instead of k_runs_hash: both must agree with the oracle."""
+    monkeypatch.setenv("SLIMM_WALK_RUNS", "1")
+    check(make_workload(CONFIGS["config2"], seed=22, n_records=300_000))
+    check(make_workload(SynthConfig("c5w", 200_000, 3_000, 40.0, strain_level=True), seed=23))
+    w, _, _ = load_golden("tiny")
+    check(w)
+    check(w, grouped=False)
+
+
+def test_runs_longer_than_the_staged_window():
+    """Reads with hundreds of records: runs cross tile boundaries and outgrow the 512-record halo (global fallback)."""
+    cfg = SynthConfig("long", 400_000, 4_000, 300.0, strain_level=True, present_frac=0.2)
+    s, o = check(make_workload(cfg, seed=24))
+    assert o.scalars["hits"] / o.scalars["matches"] > 100
+
+
 @pytest.mark.parametrize("two", ["0", "1"])
 def test_both_bucketing_variants(monkeypatch, two):
     monkeypatch.setenv("SLIMM_TWO_LEVEL", two)

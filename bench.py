@@ -42,6 +42,7 @@ def algorithmic_bytes(st, n_records, Bp_words):
     return {
         "memset_bins": 4 * (B // 8192 + 5200),       # counters, tail, tile counters, child marks (bins are written whole by the tile kernels)
         "k_scan_tiles": 2 * 8 * (N // 2048 + 1),      # per-tile counts in and out
+        "sort_by_ident": 8 * (2 * 16 * V + 8 * V),   # (sort path only) 8 passes: keys+payload in and out, keys again for the histogram
         "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
         "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
         "k_runs": 14 * N + 1 * N,                     # key + ref + flag in (look-back is an LDS walk), flag byte out
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--record-order", default="grouped", choices=["grouped", "any"],
+                    help="'any' sends the same records through the device sort path (record_order = SLIMM_ORDER_ANY)")
     ap.add_argument("--exchange", default="summary", choices=["summary", "bins"],
                     help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps, or all-reduce of the bins")
     ap.add_argument("--force-exchange", action="store_true",
@@ -125,7 +128,7 @@ def main():
     w = make_workload(cfg, seed=args.seed + 1000 * rank, n_records=n_rec, sample_seed=args.seed, shard=rank)
     gen_s = time.time() - t0
 
-    eng = Slimm.for_workload(w, device=local_rank)
+    eng = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))
     eng.force_exchange = args.force_exchange
     key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
     ref = torch.from_numpy(w.records.ref_id).to(dev)
@@ -233,7 +236,7 @@ def main():
                                    f"{cfg.bin_width} bp bins, {cfg.read_len} bp reads",
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
                        "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
-                       "record_order": "grouped", "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
+                       "record_order": args.record_order, "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
                        "exchange": (args.exchange if (world > 1 or args.force_exchange) else "none"),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,

@@ -14,6 +14,7 @@ enum {
     CNT_PAIRS = 4,  // entries of the no-level-agrees (taxon, ref) set
     CNT_ITEMS = 5,  // work items of k_tile_hist
     CNT_ITEMS2 = 6, // work items of k_part_tile
+    CNT_MODE = 7,   // classification kernel picked on the device: 0 = look-back walk (k_runs), 1 = hash table (k_runs_hash)
     CNT_WORDS = 32
 };
 enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4 };

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
     __shared__ uint32_t s_meta[kRTile + kHalo];
     __shared__ uint2 s_w[kRWaves];
     __shared__ uint32_t s_v[kRWaves];
+    if (counters[CNT_MODE] != 0u) return;  // k_pick_runs chose the hash-table kernel for this stream
     const uint32_t N = acc.count(counters);
     const uint32_t base = blockIdx.x * kRTile;
     uint32_t nh = 0, nf = 0, nv = 0;
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t* 
     __shared__ uint32_t s_wmax[kHBlock / 64];
     __shared__ uint2 s_w[kHBlock / 64];
     __shared__ uint32_t s_v[kHBlock / 64];
+    if (counters[CNT_MODE] != 1u) return;  // k_pick_runs chose the look-back kernel for this stream
     const uint32_t N = acc.count(counters);
     const uint32_t base = blockIdx.x * kRTile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -380,6 +382,33 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t* 
         }
         tile_cnt[blockIdx.x] = t;
         if (Acc::kCountsMapped) tile_valid[blockIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_pick_runs: which classification kernel suits this stream?  Samples the first records, measures records per qName
+// run, and writes the choice to counters[CNT_MODE]; both kernels are launched and the one not chosen returns at once.
+// Measured per 10 M records: look-back 100 us at 3 records/run, 152 at 8, 417 at 42; hash table 318 / - / 222.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPickSample = 65536;
+constexpr uint32_t kPickHashAbove = 24;  // records per run
+
+template <typename Acc>
+__global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __restrict__ counters, int force) {
+    __shared__ uint32_t s_runs[16];
+    const uint32_t N = acc.count(counters);
+    const uint32_t S = min(N, kPickSample);
+    uint32_t runs = 0;
+    for (uint32_t i = threadIdx.x; i < S; i += 1024) runs += (i == 0 || acc.key_of(i) != acc.key_of(i - 1)) ? 1u : 0u;
+    runs = r_wave_sum(runs);
+    if ((threadIdx.x & 63) == 0) s_runs[threadIdx.x >> 6] = runs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += s_runs[w];
+        uint32_t mode = (t != 0 && S / t > kPickHashAbove) ? 1u : 0u;
+        if (force >= 0) mode = static_cast<uint32_t>(force);
+        counters[CNT_MODE] = mode;
     }
 }
 
@@ -504,10 +533,11 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
 
 static inline uint32_t rtiles(uint32_t n) { return (n + kRTile - 1) / kRTile; }
 
-// SLIMM_WALK_RUNS=1 selects the look-back classification (k_runs) instead of the hash table (k_runs_hash)
-static bool use_hash_runs() {
-    const char* e = getenv("SLIMM_WALK_RUNS");
-    return !(e && e[0] == '1');
+// SLIMM_RUNS_KERNEL=walk|hash overrides the choice k_pick_runs makes on the device (for tests and A/B timing)
+static int forced_runs_mode() {
+    const char* e = getenv("SLIMM_RUNS_KERNEL");
+    if (!e) return -1;
+    return e[0] == 'h' ? 1 : (e[0] == 'w' ? 0 : -1);
 }
 
 static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len, const uint32_t* bin_off,
@@ -531,12 +561,10 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
                      uint2* tile_cnt, uint32_t* tile_valid) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
-    if (use_hash_runs())
-        hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(nt), dim3(kHBlock), 0, st,
-                           make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt, tile_valid);
-    else
-        hipLaunchKernelGGL(k_runs<RawRecords>, dim3(nt), dim3(kRBlock), 0, st,
-                           make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), counters, fl, tile_cnt, tile_valid);
+    const RawRecords a = make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width);
+    hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
+    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt, tile_valid);
+    hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(nt), dim3(kHBlock), 0, st, a, counters, fl, tile_cnt, tile_valid);
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
@@ -554,12 +582,11 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     const uint32_t nt = rtiles(n_upper);
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
-    if (use_hash_runs())
-        hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(nt), dim3(kHBlock), 0, st, a, counters, fl, tile_cnt,
-                           static_cast<uint32_t*>(nullptr));
-    else
-        hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt,
-                           static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
+    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt,
+                       static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(nt), dim3(kHBlock), 0, st, a, counters, fl, tile_cnt,
+                       static_cast<uint32_t*>(nullptr));
 }
 
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

@@ -173,9 +173,11 @@ def test_direct_atomic_fallback_path(monkeypatch):
     check(make_workload(CONFIGS["config1"], seed=16))
 
 
-def test_lookback_classification_variant(monkeypatch):
-    """k_runs (look-back walk) instead of k_runs_hash: both must agree with the oracle."""
-    monkeypatch.setenv("SLIMM_WALK_RUNS", "1")
+@pytest.mark.parametrize("kernel", ["walk", "hash"])
+def test_both_classification_kernels(monkeypatch, kernel):
+    """k_runs (look-back walk) and k_runs_hash (LDS hash table) are picked on the device by records per read;
+    forced here, both must agree with the oracle on shallow and deep multi-mapping."""
+    monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
     check(make_workload(CONFIGS["config2"], seed=22, n_records=300_000))
     check(make_workload(SynthConfig("c5w", 200_000, 3_000, 40.0, strain_level=True), seed=23))
     w, _, _ = load_golden("tiny")

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -97,14 +98,16 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
 }
 
 template <typename Acc>
-__global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __restrict__ counters, uint8_t* __restrict__ fl,
-                                                  uint2* __restrict__ tile_cnt, uint32_t* __restrict__ tile_valid) {
+__global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
+                                                  uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
+                                                  uint32_t* __restrict__ tile_valid) {
     __shared__ uint32_t s_meta[kRTile + kHalo];
     __shared__ uint2 s_w[kRWaves];
     __shared__ uint32_t s_v[kRWaves];
     if (counters[CNT_MODE] != 0u) return;  // k_pick_runs chose the hash-table kernel for this stream
     const uint32_t N = acc.count(counters);
-    const uint32_t base = blockIdx.x * kRTile;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // grid-stride over tiles: the launch stays
+    const uint32_t base = tile * kRTile;                                  // small, so not being chosen costs nothing
     uint32_t nh = 0, nf = 0, nv = 0;
     bool bad = false, too_long = false;
     if (base < N) {
@@ -195,8 +198,10 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t* __res
             t.y += s_w[w].y;
             v += s_v[w];
         }
-        tile_cnt[blockIdx.x] = t;
-        if (Acc::kCountsMapped) tile_valid[blockIdx.x] = v;  // summed into hits_count by k_scan_tiles (src/slimm.hpp:212)
+        tile_cnt[tile] = t;
+        if (Acc::kCountsMapped) tile_valid[tile] = v;  // summed into hits_count by k_scan_tiles (src/slimm.hpp:212)
+    }
+    __syncthreads();  // LDS is reused by the next tile
     }
 }
 
@@ -259,7 +264,7 @@ __device__ __forceinline__ uint32_t hash_get_min(const uint64_t* tab, uint64_t k
 }
 
 template <typename Acc>
-__global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t* __restrict__ counters,
+__global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
                                                        uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
                                                        uint32_t* __restrict__ tile_valid) {
     __shared__ uint64_t s_tab[kHSlots];
@@ -270,8 +275,9 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t* 
     __shared__ uint32_t s_v[kHBlock / 64];
     if (counters[CNT_MODE] != 1u) return;  // k_pick_runs chose the look-back kernel for this stream
     const uint32_t N = acc.count(counters);
-    const uint32_t base = blockIdx.x * kRTile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t base = tile * kRTile;
     uint32_t nh = 0, nf = 0, nv = 0;
     bool bad = false, too_long = false;
     if (base < N) {
@@ -380,8 +386,10 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t* 
             t.y += s_w[w].y;
             v += s_v[w];
         }
-        tile_cnt[blockIdx.x] = t;
-        if (Acc::kCountsMapped) tile_valid[blockIdx.x] = v;
+        tile_cnt[tile] = t;
+        if (Acc::kCountsMapped) tile_valid[tile] = v;
+    }
+    __syncthreads();  // LDS is reused by the next tile
     }
 }
 
@@ -563,8 +571,10 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
     if (!nt) return;
     const RawRecords a = make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width);
     hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
-    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt, tile_valid);
-    hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(nt), dim3(kHBlock), 0, st, a, counters, fl, tile_cnt, tile_valid);
+    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, 2048u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
+                       tile_valid);
+    hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl, tile_cnt,
+                       tile_valid);
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
@@ -583,10 +593,10 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
     hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
-    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, counters, fl, tile_cnt,
+    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, 2048u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
                        static_cast<uint32_t*>(nullptr));
-    hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(nt), dim3(kHBlock), 0, st, a, counters, fl, tile_cnt,
-                       static_cast<uint32_t*>(nullptr));
+    hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
+                       tile_cnt, static_cast<uint32_t*>(nullptr));
 }
 
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

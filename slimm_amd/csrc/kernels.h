@@ -14,6 +14,7 @@ enum {
     CNT_PAIRS = 4,  // entries of the no-level-agrees (taxon, ref) set
     CNT_ITEMS = 5,  // work items of k_tile_hist
     CNT_ITEMS2 = 6, // work items of k_part_tile
+    CNT_ANYGB = 8,  // some record follows a record of the same qName run with a larger mate number (mates interleave)
     CNT_MODE = 7,   // classification kernel picked on the device: 0 = look-back walk (k_runs), 1 = hash table (k_runs_hash)
     CNT_WORDS = 32
 };

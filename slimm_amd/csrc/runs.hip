@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t ntiles
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // grid-stride over tiles: the launch stays
     const uint32_t base = tile * kRTile;                                  // small, so not being chosen costs nothing
     uint32_t nh = 0, nf = 0, nv = 0;
-    bool bad = false, too_long = false;
+    bool bad = false, too_long = false, any_gb = false;
     if (base < N) {
         const uint32_t lds_lo = base >= kHalo ? base - kHalo : 0u;
         const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t ntiles
             }
             head = head && valid;
             first = first && valid;
+            any_gb = any_gb || (valid && greater_before);
             uint32_t f = (my_mate << FL_MATE_SHIFT) | ((me & M_RUN) ? FL_RUN_START : 0u) | (head ? FL_HEAD : 0u) |
                          (first ? FL_FIRST : 0u) | ((valid && greater_before) ? FL_GREATER_BEFORE : 0u);
             nh += head;
@@ -183,10 +184,12 @@ __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t ntiles
     nf = r_wave_sum(nf);
     nv = r_wave_sum(nv);
     const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
+    const bool wave_gb = __any(any_gb);
     if ((threadIdx.x & 63) == 0) {
         s_w[threadIdx.x >> 6] = make_uint2(nh, nf);
         s_v[threadIdx.x >> 6] = nv;
         if (err) atomicOr(&counters[CNT_ERR], err);
+        if (wave_gb && counters[CNT_ANYGB] == 0u) atomicOr(&counters[CNT_ANYGB], 1u);  // mates interleave in this stream
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t base = tile * kRTile;
     uint32_t nh = 0, nf = 0, nv = 0;
-    bool bad = false, too_long = false;
+    bool bad = false, too_long = false, any_gb = false;
     if (base < N) {
         const uint32_t lds_lo = base >= kHHalo ? base - kHHalo : 0u;
         const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
@@ -364,6 +367,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
             nh += head;
             nf += first;
             nv += valid;
+            any_gb = any_gb || (valid && greater_before);
             fl[i] = static_cast<uint8_t>(f);
         }
     }
@@ -371,10 +375,12 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
     nf = r_wave_sum(nf);
     nv = r_wave_sum(nv);
     const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
+    const bool wave_gb = __any(any_gb);
     if (lane == 0) {
         s_w[wave] = make_uint2(nh, nf);
         s_v[wave] = nv;
         if (err) atomicOr(&counters[CNT_ERR], err);
+        if (wave_gb && counters[CNT_ANYGB] == 0u) atomicOr(&counters[CNT_ANYGB], 1u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
 // run, and writes the choice to counters[CNT_MODE]; both kernels are launched and the one not chosen returns at once.
 // Measured per 10 M records: look-back 100 us at 3 records/run, 152 at 8, 417 at 42; hash table 318 / - / 222.
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kPickSample = 65536;
+constexpr uint32_t kPickSample = 8192;
 constexpr uint32_t kPickHashAbove = 24;  // records per run
 
 template <typename Acc>
@@ -437,6 +443,9 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
     __syncthreads();
     uint2 running = tile_off[blockIdx.x];
     bool too_long = false;
+    // A later record with a smaller mate exists only where some record carries the larger-mate-before flag; when no
+    // record of the whole stream does (unpaired data, or mates not interleaved), the forward look is skipped.
+    const bool mates_interleave = counters[CNT_ANYGB] != 0u;
 #pragma unroll
     for (int k = 0; k < kRItems; ++k) {
         const uint32_t i = base + k * kRBlock + threadIdx.x;
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         }
         {   // later records of the run with a smaller mate sit BEFORE this one
             const uint32_t room = lds_hi - lds_lo;  // staged records
-            uint32_t act = (first && mate > 0) ? 1u : 0u;
+            uint32_t act = (first && mate > 0 && mates_interleave) ? 1u : 0u;
             uint32_t openb = 0u;
             for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
                 const uint32_t j = li + d;
@@ -571,7 +580,7 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
     if (!nt) return;
     const RawRecords a = make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width);
     hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
-    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, 2048u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
+    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
                        tile_valid);
     hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl, tile_cnt,
                        tile_valid);
@@ -593,7 +602,7 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
     hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
-    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, 2048u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
+    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
                        static_cast<uint32_t*>(nullptr));
     hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
                        tile_cnt, static_cast<uint32_t*>(nullptr));

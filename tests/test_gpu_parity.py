@@ -185,6 +185,34 @@ def test_both_classification_kernels(monkeypatch, kernel):
     check(w, grouped=False)
 
 
+def _interleave_mates(w: Workload) -> Workload:
+    """Reorder every qName run so the records of its two mates alternate (bowtie2 -k style output)."""
+    rec = w.records
+    n = len(rec)
+    run_id = np.concatenate([[0], np.cumsum(rec.read_key[1:] != rec.read_key[:-1])])
+    mate = np.where(rec.flag & 0x40, 1, np.where(rec.flag & 0x80, 2, 0))
+    # rank of a record among the records of its (run, mate), then order by (run, rank, mate)
+    order0 = np.lexsort((np.arange(n), mate, run_id))
+    rk = np.empty(n, dtype=np.int64)
+    grp = run_id[order0] * 4 + mate[order0]
+    start = np.concatenate([[True], grp[1:] != grp[:-1]])
+    first_idx = np.maximum.accumulate(np.where(start, np.arange(n), 0))
+    rk[order0] = np.arange(n) - first_idx
+    order = np.lexsort((mate, rk, run_id))
+    return Workload(w.ref_names, w.ref_len, w.taxonomy, rec.take(order), w.avg_read_len, w.options, w.name + "-interleaved")
+
+
+@pytest.mark.parametrize("kernel", ["walk", "hash"])
+def test_interleaved_mates(monkeypatch, kernel):
+    monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
+    w = _interleave_mates(make_workload(SynthConfig("pairs", 200_000, 2_000, 6.0), seed=25, paired_frac=0.9))
+    mate = np.where(w.records.flag & 0x40, 1, np.where(w.records.flag & 0x80, 2, 0))
+    same = w.records.read_key[1:] == w.records.read_key[:-1]
+    assert int((same & (mate[1:] < mate[:-1])).sum()) > 1000   # mates really interleave
+    check(w)
+    check(w, grouped=False)
+
+
 def test_runs_longer_than_the_staged_window():
     """Reads with hundreds of records: runs cross tile boundaries and outgrow the 512-record halo (global fallback)."""
     cfg = SynthConfig("long", 400_000, 4_000, 300.0, strain_level=True, present_frac=0.2)

@@ -313,16 +313,26 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
             carry = total;
             __syncthreads();
         }
-        // every mapped staged record (halo included: it holds the predecessors) enters the table twice
+        // every mapped staged record (halo included: it holds the predecessors) enters the table: always with its
+        // (run, mate, ref); with (run, mate, ANY) only when the record before it is not a mapped record of the same
+        // run and mate -- the first record of a (run, mate) always qualifies, and a read's dozens of consecutive
+        // records no longer hammer one LDS word
+        bool paired = false;
         for (uint32_t j = tid; j < wn; j += kHBlock) {
             const uint32_t me = s_meta[j], rs = s_rs[j];
             if ((me & M_VALID) && rs) {
                 const uint64_t run = static_cast<uint64_t>(rs - 1) << 30;
                 hash_put_min(s_tab, run | (me & M_IDENT), j);
-                hash_put_min(s_tab, run | (me & 0x30000000u) | kRefAny, j);
+                bool lead = true;
+                if (j > 0 && !(me & M_RUN)) {
+                    const uint32_t pm = s_meta[j - 1];
+                    lead = !((pm & M_VALID) && ((pm ^ me) & 0x30000000u) == 0u);
+                }
+                if (lead) hash_put_min(s_tab, run | (me & 0x30000000u) | kRefAny, j);
+                paired = paired || (me & 0x30000000u);
             }
         }
-        __syncthreads();
+        const bool any_paired = __syncthreads_or(paired);  // no mate numbers in the window: nothing can precede with a larger one
         for (int k = 0; k < kRTile / kHBlock; ++k) {
             const uint32_t i = base + k * kHBlock + tid;
             if (i >= N) continue;
@@ -336,8 +346,9 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
                     const uint64_t run = static_cast<uint64_t>(rs - 1) << 30;
                     first = hash_get_min(s_tab, run | my_ident) == j;
                     head = hash_get_min(s_tab, run | (me & 0x30000000u) | kRefAny) == j;
-                    for (uint32_t m2 = my_mate + 1; m2 < 3; ++m2)
-                        greater_before = greater_before || hash_get_min(s_tab, run | (m2 << 28) | kRefAny) < j;
+                    if (any_paired)
+                        for (uint32_t m2 = my_mate + 1; m2 < 3; ++m2)
+                            greater_before = greater_before || hash_get_min(s_tab, run | (m2 << 28) | kRefAny) < j;
                 } else {  // the run starts before the staged window: walk back through global memory (rare)
                     uint32_t q = i, steps = 0;
                     while (q > 0) {

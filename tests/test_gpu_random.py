@@ -1,0 +1,114 @@
+"""Randomised small inputs against the oracle on the GPU: dense collisions of read names, references, mates, unmapped
+records in the middle of a read, duplicate (read, ref) pairs, holes-free but otherwise arbitrary lineages, tiny and
+long contigs -- through both record orders and both classification kernels."""
+import numpy as np
+import pytest
+
+from oracle.binding import run_workload
+from slimm_amd.profiler import Slimm
+from slimm_amd.workload import Options, Records, Taxonomy, Workload
+from tests.helpers import assert_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(seed: int) -> Workload:
+    rng = np.random.default_rng(seed)
+    R = int(rng.integers(1, 40))
+    # a consistent random tree: each level groups the level below
+    lin = np.zeros((R, 8), dtype=np.uint32)
+    grp = np.arange(R)
+    base = 1000
+    lin[:, 0] = 10_000 + np.arange(R)
+    if rng.random() < 0.3:                      # several contigs of one strain
+        lin[:, 0] = 10_000 + np.arange(R) // 2
+    for lv in range(1, 8):
+        grp = grp // int(rng.integers(1, 4))
+        lin[:, lv] = base * (lv + 1) + grp
+    if rng.random() < 0.5:                      # species-level accessions: own taxid == species taxid
+        sel = rng.random(R) < 0.3
+        lin[sel, 0] = lin[sel, 1]
+    tid, rk = [], []
+    for lv in range(7, -1, -1):
+        for t in np.unique(lin[:, lv]):
+            if lv == 0 and (lin[lin[:, 0] == t, 1] == t).any():
+                continue
+            tid.append(int(t))
+            rk.append(lv)
+    keep = {}
+    for t, r in zip(tid, rk):
+        keep[t] = r
+    tids = sorted(keep)
+    names = [f"n{t}" if rng.random() > 0.03 else "" for t in tids]   # a few unnamed taxa
+    accs = [f"A{i}" for i in range(R)]
+    if R > 3 and rng.random() < 0.3:
+        accs_db = accs[:-1]                      # last contig missing from the database (Q13)
+        lin_db = lin[:-1]
+    else:
+        accs_db, lin_db = accs, lin
+    tax = Taxonomy(accs_db, lin_db, np.array(tids, dtype=np.uint32), np.array([keep[t] for t in tids], dtype=np.uint32), names)
+    ref_len = rng.integers(1, 3000, size=R).astype(np.uint32)
+    A = int(rng.integers(2, 120))
+    W = int(rng.choice([0, 1, 7, 50, 100, 1000]))
+    n_reads = int(rng.integers(1, 400))
+    rows_key, rows_flag, rows_ref, rows_pos = [], [], [], []
+    for q in range(n_reads):
+        h = int(rng.geometric(0.35))
+        paired = rng.random() < 0.3
+        for _ in range(h):
+            f = 0
+            if paired:
+                f |= 0x40 if rng.random() < 0.5 else 0x80
+            if rng.random() < 0.05:
+                f |= 0x4
+            if rng.random() < 0.3:
+                f |= 0x100
+            r = int(rng.integers(0, R)) if rng.random() > 0.03 else -1
+            if rng.random() < 0.5 and rows_ref and rows_key[-1] == q and rows_ref[-1] >= 0:
+                r = rows_ref[-1] if rng.random() < 0.4 else min(R - 1, rows_ref[-1] + 1)
+            p = int(rng.integers(-1, int(ref_len[max(r, 0)]) + 5))
+            rows_key.append(q)
+            rows_flag.append(f)
+            rows_ref.append(r)
+            rows_pos.append(p)
+    key = (np.array(rows_key, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64((1 << 62) - 1)
+    rec = Records(key, np.array(rows_flag, dtype=np.uint16), np.array(rows_ref, dtype=np.int32),
+                  np.array(rows_pos, dtype=np.int32))
+    opts = Options(bin_width=W, cov_cut_off=float(rng.choice([0.5, 0.9, 0.95, 0.99])),
+                   abundance_cut_off=float(rng.choice([0.0, 0.01, 1.0])), rank=str(rng.choice(["species", "genus", "family"])))
+    return Workload([a + ".1" for a in accs], ref_len, tax, rec, A, opts, f"rand{seed}")
+
+
+def _run(w, grouped):
+    o = run_workload(w, use_qnames=False)
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    s.push_records(w.records)
+    prof = s.get_profiles()
+    if o.no_hits:
+        assert prof is None
+    else:
+        assert_matches_oracle(s, o)
+
+
+@pytest.mark.parametrize("kernel", ["walk", "hash"])
+def test_random_small_inputs(monkeypatch, kernel):
+    monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
+    for seed in range(120):
+        w = random_case(seed)
+        try:
+            _run(w, True)
+            _run(w, False)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {e}") from e
+
+
+def test_random_shuffled_inputs():
+    """Arbitrary record order (file order decides first bins, so the oracle sees the same shuffled stream)."""
+    for seed in range(200, 260):
+        w = random_case(seed)
+        perm = np.random.default_rng(seed).permutation(len(w.records))
+        w.records = w.records.take(perm)
+        try:
+            _run(w, False)
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {e}") from e

@@ -62,7 +62,7 @@ public:
 
 private:
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)
-    bool inflate_block();             // one BGZF block -> buf_
+    bool inflate_batch();             // the next few hundred BGZF blocks -> buf_, inflated on several threads
     bool read_bam_header();
     bool read_sam_header();
     bool next_sam_line(std::string& line);
@@ -78,6 +78,12 @@ private:
     std::vector<uint8_t> buf_;
     size_t pos_ = 0;
     std::vector<uint8_t> cbuf_;
+    struct Block {
+        size_t coff, clen, ooff;  // compressed bytes in cbuf_, output offset in buf_
+        uint32_t isize, crc;
+    };
+    std::vector<Block> blocks_;
+    unsigned threads_ = 1;
     std::string pending_line_;  // first alignment line met while reading a SAM header
     bool have_pending_ = false;
     std::unordered_map<std::string, int32_t> sam_index_;  // RNAME -> refID

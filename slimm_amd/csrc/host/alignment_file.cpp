@@ -279,42 +279,73 @@ bool AlignmentFile::read_sam_header() {
 long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_names) {
     long n = 0;
     if (bam_) {
-        while (static_cast<size_t>(n) < max_records) {
-            if (!fill(4)) {
-                if (eof_ && buf_.size() == pos_) break;
-                return err_.empty() ? n : -1;
+        // pass 1 (sequential, one load per record): where the records start; pass 2 (parallel): decode + hash the names
+        std::vector<size_t> offs;
+        offs.reserve(std::min<size_t>(max_records, 1u << 20));
+        while (offs.size() < max_records) {
+            // inflating more moves the window, which would invalidate the offsets collected so far: decode those first
+            if (buf_.size() - pos_ < 4) {
+                if (!offs.empty()) break;
+                if (!fill(4)) {
+                    if (!err_.empty()) return -1;
+                    if (buf_.size() != pos_) {
+                        err_ = "truncated BAM record";
+                        return -1;
+                    }
+                    break;  // clean end of file
+                }
             }
-            uint32_t bs = rd_u32(&buf_[pos_]);
+            const uint32_t bs = rd_u32(&buf_[pos_]);
             if (bs < 32) {
                 err_ = "bad BAM record size";
                 return -1;
             }
-            if (!fill(4 + static_cast<size_t>(bs))) {
-                err_ = "truncated BAM record";
-                return -1;
+            if (buf_.size() - pos_ < 4 + static_cast<size_t>(bs)) {
+                if (!offs.empty()) break;
+                if (!fill(4 + static_cast<size_t>(bs))) {
+                    if (err_.empty()) err_ = "truncated BAM record";
+                    return -1;
+                }
             }
-            const uint8_t* r = &buf_[pos_ + 4];
-            int32_t ref_id = static_cast<int32_t>(rd_u32(r));
-            int32_t pos = static_cast<int32_t>(rd_u32(r + 4));
-            uint8_t l_read_name = r[8];
-            uint16_t flag = rd_u16(r + 14);
-            uint32_t l_seq = rd_u32(r + 16);
-            const char* name = reinterpret_cast<const char*>(r + 32);
-            size_t nlen = l_read_name ? l_read_name - 1u : 0u;
-            if (32u + l_read_name > bs) {
+            if (32u + buf_[pos_ + 4 + 8] > bs) {
                 err_ = "bad BAM read name length";
                 return -1;
             }
-            out.read_key.push_back(hash_read_name(name, nlen));
-            out.ref_id.push_back(ref_id);
-            out.begin_pos.push_back(pos);
-            out.flag.push_back(flag);
-            out.l_seq.push_back(l_seq);
-            if (keep_names) out.qname.emplace_back(name, nlen);
+            offs.push_back(pos_);
             pos_ += 4 + static_cast<size_t>(bs);
-            ++n;
         }
-        return n;
+        const size_t cnt = offs.size(), base = out.read_key.size();
+        out.read_key.resize(base + cnt);
+        out.ref_id.resize(base + cnt);
+        out.begin_pos.resize(base + cnt);
+        out.flag.resize(base + cnt);
+        out.l_seq.resize(base + cnt);
+        if (keep_names) out.qname.resize(base + cnt);
+        auto decode = [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) {
+                const uint8_t* r = &buf_[offs[k] + 4];
+                const uint8_t l_read_name = r[8];
+                const char* name = reinterpret_cast<const char*>(r + 32);
+                const size_t nlen = l_read_name ? l_read_name - 1u : 0u;
+                out.read_key[base + k] = hash_read_name(name, nlen);
+                out.ref_id[base + k] = static_cast<int32_t>(rd_u32(r));
+                out.begin_pos[base + k] = static_cast<int32_t>(rd_u32(r + 4));
+                out.flag[base + k] = rd_u16(r + 14);
+                out.l_seq[base + k] = rd_u32(r + 16);
+                if (keep_names) out.qname[base + k].assign(name, nlen);
+            }
+        };
+        const unsigned nthreads = cnt >= 65536 ? std::min<unsigned>(threads_, 16u) : 1u;
+        if (nthreads <= 1) {
+            decode(0, cnt);
+        } else {
+            std::vector<std::thread> pool;
+            const size_t per = (cnt + nthreads - 1) / nthreads;
+            for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(decode, std::min(cnt, t * per), std::min(cnt, (t + 1) * per));
+            decode(0, std::min(cnt, per));
+            for (auto& th : pool) th.join();
+        }
+        return static_cast<long>(cnt);
     }
     // SAM: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL ...
     if (sam_index_.empty() && !ref_names_.empty()) {

@@ -93,7 +93,7 @@ bool inflate_one(const uint8_t* src, size_t clen, uint8_t* dst, uint32_t isize, 
 }  // namespace
 
 bool AlignmentFile::inflate_batch() {
-    constexpr size_t kBatchBytes = 32u << 20;  // compressed bytes per batch
+    constexpr size_t kBatchBytes = 4u << 20;  // compressed bytes per batch
     cbuf_.clear();
     blocks_.clear();
     // drop consumed bytes so the window does not grow without bound

@@ -45,7 +45,9 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "sort_by_ident": 8 * (2 * 16 * V + 8 * V),   # (sort path only) 8 passes: keys+payload in and out, keys again for the histogram
         "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
         "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
+        "k_pick_runs": 8 * 8192,                      # samples the first records to choose the classification kernel
         "k_runs": 14 * N + 1 * N,                     # key + ref + flag in (look-back is an LDS walk), flag byte out
+        "k_runs_hash": 14 * N + 1 * N,                # same bytes; whichever of the two was not picked returns at once
         "k_emit": 1 * N + 8 * P + 8 * P + 4 * M,      # flag byte in; ref + pos of the firsts in; targets + read offsets out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
         "k_tile_count": 4 * P,                        # gbin in
@@ -186,7 +188,7 @@ def main():
                                     "bytes_per_launch": model[name] / max(1.0, steps_launches if name == "memset_bins" else 1.0),
                                     }
         # the dominant kernel = most time per step (memsets are DMA fills, not kernels of this library)
-        cand = {k: v for k, v in per_kernel.items() if k != "memset_bins"}
+        cand = {k: v for k, v in per_kernel.items() if k not in ("memset_bins", "k_pick_runs")}
         dom = max(cand, key=lambda k: cand[k]["ms_per_launch"] * cand[k]["launches_per_step"])
         d = cand[dom]
         achieved = d["bytes_per_launch"] / (d["ms_per_launch"] * 1e-3) / 1e9

@@ -65,12 +65,13 @@ struct PinBuf {
 enum KernelId {
     K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FLAGS, K_BUILD_CSR, K_HIST, K_REF_STATS, K_FILTER_LCA,
     K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_TILE_COUNT2, K_TILE_SCAN2, K_TILE_SCATTER2,
-    K_TILE_HIST2, K_COUNT
+    K_TILE_HIST2, K_PICK, K_RUNS_HASH, K_COUNT
 };
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
                                      "k_runs", "k_emit", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",
-                                     "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2"};
+                                     "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2",
+                                     "k_pick_runs", "k_runs_hash"};
 
 constexpr uint32_t kTailWords = 64;
 
@@ -552,9 +553,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
                                  c->s_gbin.p, c->sort_hist.p);
         }
-        {
-            KernelTimer t(c, K_FLAGS);
-            launch_runs_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->c_fl.p, c->tile_cnt.p);
+        const int ids[3] = {K_PICK, K_FLAGS, K_RUNS_HASH};
+        for (int part = 0; part < 3; ++part) {
+            KernelTimer t(c, ids[part]);
+            launch_runs_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->c_fl.p, c->tile_cnt.p, part);
         }
         {
             KernelTimer t(c, K_SCAN);
@@ -567,10 +569,11 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
     } else {
         // grouped input: classify and emit straight from the caller's record arrays
-        {
-            KernelTimer t(c, K_FLAGS);
+        const int ids[3] = {K_PICK, K_FLAGS, K_RUNS_HASH};
+        for (int part = 0; part < 3; ++part) {
+            KernelTimer t(c, ids[part]);
             launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
-                            c->c_fl.p, c->tile_cnt.p, c->tile_valid.p);
+                            c->c_fl.p, c->tile_cnt.p, c->tile_valid.p, part);
         }
         {
             KernelTimer t(c, K_SCAN);

@@ -48,15 +48,17 @@ void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
-// runs.hip: record classification + CSR emission, on the raw records (grouped input) or on the sorted compact stream
+// runs.hip: record classification + CSR emission, on the raw records (grouped input) or on the sorted compact stream.
+// part 0 = k_pick_runs (chooses the kernel on the device), 1 = k_runs (look-back), 2 = k_runs_hash; all three are
+// launched, the classification kernel that was not chosen returns immediately.
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt, uint32_t* tile_valid);
+                     uint2* tile_cnt, uint32_t* tile_valid, int part);
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, const uint8_t* fl, uint32_t* counters,
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off);
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt);
+                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part);
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
                         const uint8_t* fl, uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
                         uint32_t* read_off);

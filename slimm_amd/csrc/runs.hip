@@ -586,15 +586,18 @@ static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint3
 
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt, uint32_t* tile_valid) {
+                     uint2* tile_cnt, uint32_t* tile_valid, int part) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
     const RawRecords a = make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width);
-    hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
-    hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
-                       tile_valid);
-    hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl, tile_cnt,
-                       tile_valid);
+    if (part == 0)
+        hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
+    else if (part == 1)
+        hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl,
+                           tile_cnt, tile_valid);
+    else
+        hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
+                           tile_cnt, tile_valid);
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
@@ -608,15 +611,18 @@ void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
 }
 
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt) {
+                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part) {
     const uint32_t nt = rtiles(n_upper);
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
-    hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
-    hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl, tile_cnt,
-                       static_cast<uint32_t*>(nullptr));
-    hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
-                       tile_cnt, static_cast<uint32_t*>(nullptr));
+    if (part == 0)
+        hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
+    else if (part == 1)
+        hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl,
+                           tile_cnt, static_cast<uint32_t*>(nullptr));
+    else
+        hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
+                           tile_cnt, static_cast<uint32_t*>(nullptr));
 }
 
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

@@ -1,0 +1,60 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the host code that does not need a GPU: the SAM/BAM/.sldb readers (good, truncated and
+# corrupted inputs, 1 and 8 decode threads) and the host profile stages.  GPU sanitizers are not available on the pool,
+# so this is the CPU-build sanitizer pass.  Usage: scripts/sanitize_host.sh [workdir]
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+W="${1:-/tmp/slimm_sanitize}"
+mkdir -p "$W"
+FLAGS="-std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer"
+g++ $FLAGS "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
+    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -o "$W/san_readers"
+g++ $FLAGS "$ROOT/tests/native/host_profile_bench.cpp" "$ROOT/slimm_amd/csrc/host_profile.cpp" -o "$W/san_profile"
+# ThreadSanitizer over the parallel BGZF inflate / record decode
+g++ -std=c++17 -g -O1 -fsanitize=thread "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
+    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -o "$W/tsan_readers"
+cd "$ROOT"
+python - "$W" <<'PY'
+import os, subprocess, sys
+sys.path.insert(0, os.getcwd())
+from slimm_amd.synth import CONFIGS, make_workload
+from tests.bam_io import write_bam, write_sam, write_sldb
+from tests.cases import tiny_case, holes_case
+d = sys.argv[1]
+files = []
+cases = [tiny_case(), holes_case(), make_workload(CONFIGS["config1"], seed=3),
+         make_workload(CONFIGS["config2"], seed=4, n_records=150_000)]
+for i, w in enumerate(cases):
+    for fmt, wr in (("sam", write_sam), ("bam", write_bam)):
+        p = f"{d}/c{i}.{fmt}"
+        wr(p, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+        files.append(p)
+    p = f"{d}/c{i}.sldb"
+    write_sldb(p, w.taxonomy)
+    files.append(p)
+data = open(f"{d}/c2.bam", "rb").read()
+open(f"{d}/trunc.bam", "wb").write(data[:len(data) // 3])
+bad = bytearray(data); bad[200] ^= 0xff
+open(f"{d}/flip.bam", "wb").write(bytes(bad))
+open(f"{d}/short.sldb", "wb").write(open(f"{d}/c2.sldb", "rb").read()[:100])
+open(f"{d}/garbage.sam", "w").write("@SQ\tSN:x\tLN:10\nr1\t0\tx\n")
+files += [f"{d}/trunc.bam", f"{d}/flip.bam", f"{d}/short.sldb", f"{d}/garbage.sam"]
+bad = 0
+for thr in ("1", "8"):
+    r = subprocess.run([f"{d}/san_readers"] + files, capture_output=True, text=True,
+                       env=dict(os.environ, SLIMM_DECODE_THREADS=thr))
+    print(r.stdout)
+    if r.returncode or r.stderr.strip():
+        bad += 1; print("SANITIZER OUTPUT:\n" + r.stderr)
+r = subprocess.run([f"{d}/tsan_readers", f"{d}/c3.bam", f"{d}/c2.bam", f"{d}/trunc.bam"], capture_output=True, text=True,
+                   env=dict(os.environ, SLIMM_DECODE_THREADS="8"))
+print(r.stdout)
+if r.returncode or r.stderr.strip():
+    bad += 1; print("THREAD SANITIZER OUTPUT:\n" + r.stderr)
+r = subprocess.run([f"{d}/san_profile"], capture_output=True, text=True)
+print(r.stdout)
+if r.returncode or r.stderr.strip():
+    bad += 1; print("SANITIZER OUTPUT:\n" + r.stderr)
+print("sanitizer findings:", bad)
+sys.exit(1 if bad else 0)
+PY

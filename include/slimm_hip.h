@@ -209,6 +209,9 @@ int slimm_get_children_pairs(slimm_ctx* ctx, int stage, uint32_t* taxid, uint32_
 /* ---- measurement ---- */
 /* When enabled, every kernel launch is bracketed by HIP events on the context's stream. */
 int slimm_enable_kernel_timing(slimm_ctx* ctx, int on);
+/* Restrict the bracketing to one kernel (a name slimm_kernel_times reports); NULL or "" = all kernels again.  Events
+ * cost a few microseconds of stream idle time each, so a throughput run times only the kernel it reports on. */
+int slimm_time_only_kernel(slimm_ctx* ctx, const char* name);
 /* Names (static strings) and accumulated milliseconds / launch counts since the last call with reset != 0. */
 int slimm_kernel_times(slimm_ctx* ctx, const char** names, double* ms, uint32_t* launches, uint32_t cap,
                        uint32_t* n, int reset);

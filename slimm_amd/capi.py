@@ -95,6 +95,7 @@ SYMBOLS = [
     ("slimm_children_pairs_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),
     ("slimm_get_children_pairs", C.c_int, [_P, C.c_int, _P, _P]),
     ("slimm_enable_kernel_timing", C.c_int, [_P, C.c_int]),
+    ("slimm_time_only_kernel", C.c_int, [_P, C.c_char_p]),
     ("slimm_kernel_times", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
                                      C.c_uint32, C.POINTER(C.c_uint32), C.c_int]),
     ("slimm_host_avg_read_length", C.c_uint32, [_P, C.c_uint64, C.c_uint32]),

@@ -141,6 +141,7 @@ struct slimm_ctx {
 
     // kernel timing
     bool timing = false;
+    int timing_only = -1;  // >= 0: bracket only this kernel id (keeps the event overhead out of the other launches)
     struct Ev {
         hipEvent_t a, b;
         int id;
@@ -185,7 +186,7 @@ struct KernelTimer {  // brackets one launch (or a group) with events when timin
     slimm_ctx* c;
     slimm_ctx::Ev ev{};
     bool on;
-    KernelTimer(slimm_ctx* ctx, int id) : c(ctx), on(ctx->timing) {
+    KernelTimer(slimm_ctx* ctx, int id) : c(ctx), on(ctx->timing && (ctx->timing_only < 0 || ctx->timing_only == id)) {
         if (!on) return;
         if (!c->ev_free.empty()) {
             ev = c->ev_free.back();
@@ -1053,6 +1054,20 @@ int slimm_enable_kernel_timing(slimm_ctx* c, int on) {
     if (!c) return SLIMM_E_INVALID;
     c->timing = on != 0 && c->device >= 0;
     return SLIMM_OK;
+}
+
+int slimm_time_only_kernel(slimm_ctx* c, const char* name) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!name || !*name) {
+        c->timing_only = -1;
+        return SLIMM_OK;
+    }
+    for (int i = 0; i < K_COUNT; ++i)
+        if (std::strcmp(name, kKernelNames[i]) == 0) {
+            c->timing_only = i;
+            return SLIMM_OK;
+        }
+    return fail(c, SLIMM_E_INVALID, "slimm_time_only_kernel: unknown kernel '%s'", name);
 }
 
 int slimm_kernel_times(slimm_ctx* c, const char** names, double* ms, uint32_t* launches, uint32_t cap, uint32_t* n,

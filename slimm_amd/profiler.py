@@ -228,6 +228,9 @@ class Slimm:
     def enable_kernel_timing(self, on: bool = True):
         self._check(self.L.slimm_enable_kernel_timing(self.ctx, int(on)))
 
+    def time_only_kernel(self, name: Optional[str]):
+        self._check(self.L.slimm_time_only_kernel(self.ctx, name.encode() if name else None))
+
     def kernel_times(self, reset: bool = True) -> Dict[str, Tuple[float, int]]:
         cap = 32
         names = (C.c_char_p * cap)()

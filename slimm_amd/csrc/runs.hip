@@ -21,8 +21,20 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#ifndef EXP
+#define EXP 0
+#endif
 
 namespace slimm {
+
+#if EXP == 9
+__device__ unsigned long long g_prof[8 * 32768];  // [tile-wave][phase]
+#define PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define PROF_ADD(slot, a, b) if (lane == 0) g_prof[(tile * 4 + (threadIdx.x >> 6)) * 8 + slot] = (b) - (a)
+#else
+#define PROF_T(x)
+#define PROF_ADD(slot, a, b)
+#endif
 
 constexpr int kRBlock = 256;
 constexpr int kRItems = 8;
@@ -70,6 +82,40 @@ struct RawRecords {
         }
         return mapped ? (M_VALID | (mate << 28) | static_cast<uint32_t>(r)) : (mate << 28);
     }
+    // the loads of one record without any arithmetic or branch in between (so that several records' loads can be in
+    // flight at once) and the meta word from them
+    struct Raw {
+        uint64_t key;
+        uint32_t flag;
+        int32_t ref;
+    };
+    __device__ Raw load(uint32_t i) const { return Raw{key[i], flag[i], ref[i]}; }
+    __device__ uint64_t raw_key(uint32_t i) const { return key[i]; }
+    __device__ static bool same_run(uint64_t a, uint64_t b) { return ((a ^ b) << 2) == 0ull; }
+    __device__ static uint64_t key_bits(const Raw& r) { return r.key; }
+    __device__ uint32_t meta(const Raw& r, bool& bad) const {
+        const uint32_t mate = (r.flag & 0x40) ? 1u : ((r.flag & 0x80) ? 2u : 0u);
+        bool mapped = !(r.flag & 0x4) && r.ref != -1;
+        if (mapped && static_cast<uint32_t>(r.ref) >= n_refs) {
+            bad = true;
+            mapped = false;
+        }
+        return mapped ? (M_VALID | (mate << 28) | static_cast<uint32_t>(r.ref)) : (mate << 28);
+    }
+    // k_emit: what a `first` record contributes, in two load levels that can each be batched over several records
+    struct Hit {
+        int32_t ref, pos;
+    };
+    __device__ Hit hit(uint32_t i) const { return Hit{ref[i], pos[i]}; }
+    __device__ uint32_t hit_ref(const Hit& h) const { return min(static_cast<uint32_t>(h.ref), n_refs - 1u); }
+    struct Geo {
+        uint32_t len, off;
+    };
+    __device__ Geo geo(uint32_t r) const { return Geo{ref_len[r], bin_off[r]}; }
+    __device__ uint32_t gbin(const Hit& h, const Geo& g) const {
+        // uint32 wrap-around of int32 + uint32, then clamp to the contig length (src/slimm.hpp:200-201, Q3)
+        return g.off + min(static_cast<uint32_t>(h.pos) + half_read, g.len) / bin_width;
+    }
     __device__ uint32_t gbin_of(uint32_t i, uint32_t r) const {
         // uint32 wrap-around of int32 + uint32, then clamp to the contig length (src/slimm.hpp:200-201, Q3)
         const uint32_t center = min(static_cast<uint32_t>(pos[i]) + half_read, ref_len[r]);
@@ -87,6 +133,25 @@ struct SortedRecords {
     __device__ uint32_t meta_of(uint32_t i, bool&) const {
         return M_VALID | ((static_cast<uint32_t>(ident[i]) & 3u) << 28) | cref[i];
     }
+    struct Raw {
+        uint64_t key;
+        uint32_t ref;
+    };
+    __device__ Raw load(uint32_t i) const { return Raw{ident[i], cref[i]}; }
+    __device__ uint64_t raw_key(uint32_t i) const { return ident[i]; }
+    __device__ static bool same_run(uint64_t a, uint64_t b) { return ((a ^ b) >> 2) == 0ull; }
+    __device__ static uint64_t key_bits(const Raw& r) { return r.key; }
+    __device__ uint32_t meta(const Raw& r, bool&) const {
+        return M_VALID | ((static_cast<uint32_t>(r.key) & 3u) << 28) | r.ref;
+    }
+    struct Hit {
+        uint32_t ref, gbin;
+    };
+    __device__ Hit hit(uint32_t i) const { return Hit{cref[i], cgbin[i]}; }
+    __device__ uint32_t hit_ref(const Hit& h) const { return h.ref; }
+    struct Geo {};
+    __device__ Geo geo(uint32_t) const { return Geo{}; }
+    __device__ uint32_t gbin(const Hit& h, const Geo&) const { return h.gbin; }
     __device__ uint32_t gbin_of(uint32_t i, uint32_t) const { return cgbin[i]; }
 };
 
@@ -97,94 +162,240 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
     return m;
 }
 
+// Per 64-record segment of the staged window: what a record right behind the segment inherits from it.
+//   bits 0-2   mates of the mapped records between the segment's last run start (or its first record) and its end
+//   bits 8-27  number of records in that stretch
+//   bit 31     the segment holds a run start (otherwise the stretch continues into the segment before)
+// k_runs works through a tile in passes of kQTile records (each with its own halo): half the registers of a
+// whole-tile pass, so more workgroups are resident and their load and classify phases overlap
+#ifndef SLIMM_Q_ITEMS
+#define SLIMM_Q_ITEMS 4
+#endif
+constexpr int kQItems = SLIMM_Q_ITEMS;
+constexpr int kQTile = kRBlock * kQItems;
+constexpr uint32_t kSegs = (kQTile + kHalo) / 64;
+constexpr uint32_t SEG_START = 0x80000000u;
+
 template <typename Acc>
 __global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
                                                   uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
                                                   uint32_t* __restrict__ tile_valid) {
-    __shared__ uint32_t s_meta[kRTile + kHalo];
+    __shared__ uint32_t s_meta[kQTile + kHalo];
+    __shared__ uint32_t s_flw[kQTile / 4];  // the pass's flag bytes, written out coalesced
+    __shared__ uint32_t s_seg[kSegs];       // segment summaries, then (in place) the carry into each segment
+    __shared__ uint64_t s_last[kSegs + 2];  // key of the last record of each segment
     __shared__ uint2 s_w[kRWaves];
     __shared__ uint32_t s_v[kRWaves];
     if (counters[CNT_MODE] != 0u) return;  // k_pick_runs chose the hash-table kernel for this stream
+    uint8_t* s_fl = reinterpret_cast<uint8_t*>(s_flw);
     const uint32_t N = acc.count(counters);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;          // lanes before mine
+    const uint64_t le_mask = lt_mask | (1ull << lane);       // ... and mine
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {  // grid-stride over tiles: the launch stays
-    const uint32_t base = tile * kRTile;                                  // small, so not being chosen costs nothing
-    uint32_t nh = 0, nf = 0, nv = 0;
-    bool bad = false, too_long = false, any_gb = false;
-    if (base < N) {
+    uint32_t nh = 0, nf = 0, nv = 0, any_gb = 0;                          // small, so not being chosen costs nothing
+    bool bad = false, too_long = false;
+    for (uint32_t base = tile * kRTile; base < min((tile + 1u) * kRTile, N); base += kQTile) {
         const uint32_t lds_lo = base >= kHalo ? base - kHalo : 0u;
-        const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
-        for (uint32_t i = lds_lo + threadIdx.x; i < lds_hi; i += kRBlock) s_meta[i - lds_lo] = full_meta(acc, i, bad);
-        __syncthreads();
-        for (int k = 0; k < kRItems; ++k) {
-            const uint32_t i = base + k * kRBlock + threadIdx.x;
-            const bool live = i < N;
-            const uint32_t li = live ? i - lds_lo : 0u;
-            const uint32_t me = live ? s_meta[li] : M_RUN;  // dead lanes: not mapped, never walk
-            const bool valid = me & M_VALID;
-            const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
-            // Look-back through LDS, one distance per trip for the whole wave.  The per-lane state lives in VGPRs as
-            // 0/1 integers and is updated with plain integer arithmetic: C++ bools would become 64-bit lane masks in
-            // SGPRs, and the CU's single scalar ALU -- shared by all four SIMDs -- was the measured bottleneck
-            // (62 M SALU instructions per launch at config 2).
-            uint32_t act = (valid && !(me & M_RUN)) ? 1u : 0u;
-            uint32_t headb = 1u, firstb = 1u, gbb = 0u, openb = 0u;
-            for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
-                const uint32_t diff = li - d;                         // negative (bit 31) once d > li
-                const uint32_t inn = act & ((~diff) >> 31);           // still inside the staged window
-                const uint32_t m = s_meta[diff & (0u - inn)];
-                const uint32_t v = inn & (m >> 31);                   // a mapped record of this run
-                const uint32_t x = (m ^ me) & M_IDENT;                // 0 <=> same read and same reference
-                const uint32_t same = v & (((x | (0u - x)) >> 31) ^ 1u);
-                const uint32_t xm = x >> 28;                          // 0 <=> same mate
-                const uint32_t eqm = ((xm | (0u - xm)) >> 31) ^ 1u;
-                const uint32_t gt = (my_mate - ((m >> 28) & 3u)) >> 31;  // its mate is larger than mine
-                headb &= ~(v & eqm);
-                firstb &= ~same;
-                gbb |= v & gt;
-                openb |= act & (inn ^ 1u);
-                act = inn & (same ^ 1u) & (((m >> 30) & 1u) ^ 1u);    // stop at a duplicate or at the run start
+        const uint32_t lds_hi = min(base + static_cast<uint32_t>(kQTile), N);
+        const uint32_t off = base - lds_lo, n_here = lds_hi - base, W = lds_hi - lds_lo;
+        const uint32_t nseg = (W + 63u) >> 6;
+        // 1. stage {mapped, run start, mate, ref} of the window (tile + halo before it) and summarise each segment.
+        //    All loads of a thread (9 records x {key, previous key, flag, ref}) go out back to back, with clamped
+        //    indices instead of bounds branches: a branch per record made every load round trip a serial step
+        //    (two per record, 18 per tile), and that latency chain -- not bandwidth -- set the kernel's time.
+        PROF_T(t0);
+        {
+            typename Acc::Raw raw[kQItems + 1];
+#pragma unroll
+            for (int k = 0; k <= kQItems; ++k) raw[k] = acc.load(min(lds_lo + k * kRBlock + threadIdx.x, N - 1u));
+            // the key of the record before the window (every thread the same address: one request)
+            const uint64_t before = acc.raw_key(lds_lo ? lds_lo - 1u : 0u);
+            // The previous record's key comes from the neighbouring lane (DPP shift), for lane 0 from the last lane
+            // of the wave before through LDS.  (Loading key[i - 1] as well -- 512-byte wave loads 8 bytes off their
+            // alignment -- cost 35 of the kernel's 90 us.)
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k <= kQItems; ++k) s_last[k * kRWaves + wave] = Acc::key_bits(raw[k]);
             }
-            bool head = headb & 1u, first = firstb & 1u, greater_before = gbb & 1u;
-            const bool open = openb & 1u;  // ran out of staged records before the run start
-            if (open) {  // the run reaches back beyond the halo: continue in global memory (rare)
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k <= kQItems; ++k) {
+                const uint32_t j = k * kRBlock + threadIdx.x;   // window index; segment j >> 6 is this wave's, whole
+                if ((j & ~63u) < W) {                           // wave-uniform
+                    const uint64_t mine = Acc::key_bits(raw[k]);
+                    const uint32_t seg = j >> 6;
+                    const uint64_t carry_key = seg ? s_last[seg - 1u] : before;  // s_last is indexed by segment
+                    const uint32_t plo = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key),
+                                                                     static_cast<uint32_t>(mine), 0x138, 0xf, 0xf, false);
+                    const uint32_t phi = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key >> 32),
+                                                                     static_cast<uint32_t>(mine >> 32), 0x138, 0xf, 0xf,
+                                                                     false);
+                    const uint64_t prev = (static_cast<uint64_t>(phi) << 32) | plo;
+                    uint32_t m = 0u;
+                    if (j < W) {
+                        m = acc.meta(raw[k], bad);
+                        if (lds_lo + j == 0u || !Acc::same_run(mine, prev)) m |= M_RUN;
+                        s_meta[j] = m;
+                    }
+                    const uint64_t starts = __ballot((m >> 30) & 1u);
+                    const bool mapped = m >> 31;
+                    const uint32_t mate = (m >> 28) & 3u;
+                    const uint64_t tail = starts ? ~((1ull << (63 - __builtin_clzll(starts))) - 1ull) : ~0ull;
+                    const uint32_t seen = ((__ballot(mapped && mate == 0u) & tail) ? 1u : 0u) |
+                                          ((__ballot(mapped && mate == 1u) & tail) ? 2u : 0u) |
+                                          ((__ballot(mapped && mate == 2u) & tail) ? 4u : 0u);
+                    if (lane == 0)
+                        s_seg[seg] = seen | (static_cast<uint32_t>(__popcll(tail)) << 8) | (starts ? SEG_START : 0u);
+                }
+            }
+        }
+        PROF_T(t1);
+        __syncthreads();
+        PROF_T(t2);
+        // 2. carry into each segment: mates seen and records since the run start, looking back over whole segments
+        uint32_t carry = 0;
+        if (threadIdx.x < nseg) {
+            uint32_t seen = 0, len = 0, open = 1;
+            for (int p = static_cast<int>(threadIdx.x) - 1; p >= 0; --p) {
+                const uint32_t sm = s_seg[p];
+                seen |= sm & 7u;
+                len += (sm >> 8) & 0xfffffu;
+                if (sm & SEG_START) {
+                    open = 0;
+                    break;
+                }
+            }
+            if (threadIdx.x == 0 && lds_lo == 0) open = 0;  // nothing before the first record of the stream
+            carry = seen | (len << 8) | (open << 31);
+        }
+        __syncthreads();
+        if (threadIdx.x < nseg) s_seg[threadIdx.x] = carry;
+        __syncthreads();
+        PROF_T(t3);
+        // 3. classify.  head / larger-mate-before come from the ballots of the record's own segment plus the carry;
+        //    only the duplicate test (same read AND same reference earlier in the run: Q1) walks back through LDS.
+        //    The walk handles the thread's 8 records in ONE loop over the distance -- 8 independent LDS reads per
+        //    trip, so their latency overlaps -- and the trip count is known up front (distance to the run start).
+        //    (The first version walked per record for all three answers, ~30 vector instructions per trip behind a
+        //    serial LDS read each, and was bound by exactly that.)
+        uint32_t me_[kQItems], wl_[kQItems], st_[kQItems];  // meta word, walk length, {head, gb, open} bits
+#pragma unroll
+        for (int k = 0; k < kQItems; ++k) {
+            const uint32_t lpos = k * kRBlock + threadIdx.x;
+            const uint32_t li = off + lpos;
+            const uint32_t me = lpos < n_here ? s_meta[li] : M_RUN;  // past the end: not mapped, a run of its own
+            const uint32_t valid = me >> 31, my_mate = (me >> 28) & 3u;
+            const uint64_t starts = __ballot((me >> 30) & 1u);
+            const uint64_t v0 = __ballot(valid && my_mate == 0u), v1 = __ballot(valid && my_mate == 1u),
+                           v2 = __ballot(valid && my_mate == 2u);
+            const uint64_t ps = starts & le_mask;           // run starts at or before me in this segment
+            const uint32_t from = ps ? 63u - static_cast<uint32_t>(__builtin_clzll(ps)) : 0u;
+            const uint64_t bit_from = 1ull << from;
+            // a mapped record with mate m in [from, lane)  <=>  (v_m & lanes before me) >= bit(from)
+            uint32_t seen = ((v0 & lt_mask) >= bit_from ? 1u : 0u) | ((v1 & lt_mask) >= bit_from ? 2u : 0u) |
+                            ((v2 & lt_mask) >= bit_from ? 4u : 0u);
+            uint32_t len = lane - from, open = 0u;
+            if (!ps) {  // my run starts in an earlier segment
+                const uint32_t c = s_seg[li >> 6];
+                seen |= c & 7u;
+                len += (c >> 8) & 0xfffffu;
+                open = c >> 31;
+            }
+            const uint32_t head = valid & (((seen >> my_mate) & 1u) ^ 1u);
+            const uint32_t gb = valid & ((seen >> (my_mate + 1u)) != 0u ? 1u : 0u);
+            me_[k] = me;
+            wl_[k] = valid ? min(len, li) : 0u;  // compare with this many records before me (all staged unless open)
+            st_[k] = head | (gb << 1) | ((open & valid) << 2);
+        }
+        PROF_T(t4);
+        uint32_t dup_[kQItems];  // minimum over the walked records of (their word ^ mine) & compared bits: 0 <=> duplicate
+        {
+            uint32_t longest = 0u;
+            uint32_t a4[kQItems], w4[kQItems];  // byte offsets: my slot in s_meta, walk length
+#pragma unroll
+            for (int k = 0; k < kQItems; ++k) {
+                longest = max(longest, wl_[k]);
+                dup_[k] = 0xffffffffu;
+                a4[k] = (off + k * kRBlock + threadIdx.x) * 4u;
+                w4[k] = wl_[k] * 4u;
+            }
+            const char* meta_bytes = reinterpret_cast<const char*>(s_meta);
+            for (uint32_t d = 1; __ballot(d <= longest) != 0ull; ++d) {
+#pragma unroll
+                for (int k = 0; k < kQItems; ++k) {
+                    // past my run: the same record (the run start) again, harmless
+                    const uint32_t m = *reinterpret_cast<const uint32_t*>(meta_bytes + (a4[k] - min(d * 4u, w4[k])));
+                    dup_[k] = min(dup_[k], (m ^ me_[k]) & (M_VALID | M_IDENT));
+                }
+            }
+        }
+        PROF_T(t5);
+#pragma unroll
+        for (int k = 0; k < kQItems; ++k) {
+            const uint32_t lpos = k * kRBlock + threadIdx.x;
+            const uint32_t me = me_[k], valid = me >> 31, my_mate = (me >> 28) & 3u;
+            uint32_t head = st_[k] & 1u, gb = (st_[k] >> 1) & 1u;
+            uint32_t first = valid & ((wl_[k] != 0u && dup_[k] == 0u) ? 0u : 1u);
+            if (st_[k] & 4u) {  // the run reaches back beyond the halo: go on in global memory (rare)
+                const uint32_t my_ident = me & M_IDENT;
                 uint32_t j = lds_lo, steps = 0;
-                while (j > 0) {
+                while (j > 0 && first) {
                     --j;
                     bool dummy = false;
-                    const uint32_t m = full_meta(acc, j, dummy);
-                    if (m & M_VALID) {
-                        const uint32_t mt = (m >> 28) & 3u;
-                        if ((m & M_IDENT) == my_ident) {
-                            head = false;
-                            first = false;
+                    const uint32_t mg = full_meta(acc, j, dummy);
+                    if (mg & M_VALID) {
+                        const uint32_t mt = (mg >> 28) & 3u;
+                        if ((mg & M_IDENT) == my_ident) {
+                            head = 0u;
+                            first = 0u;
                             break;
                         }
-                        head = head && (mt != my_mate);
-                        greater_before = greater_before || (mt > my_mate);
+                        if (mt == my_mate) head = 0u;
+                        if (mt > my_mate) gb = 1u;
                     }
-                    if (m & M_RUN) break;
+                    if (mg & M_RUN) break;
                     if (++steps > kLookBackMax) {
                         too_long = true;
                         break;
                     }
                 }
             }
-            head = head && valid;
-            first = first && valid;
-            any_gb = any_gb || (valid && greater_before);
-            uint32_t f = (my_mate << FL_MATE_SHIFT) | ((me & M_RUN) ? FL_RUN_START : 0u) | (head ? FL_HEAD : 0u) |
-                         (first ? FL_FIRST : 0u) | ((valid && greater_before) ? FL_GREATER_BEFORE : 0u);
+            head &= first;  // a duplicate of an earlier record is never a head (that record has its mate)
+            gb &= first;    // k_emit reads the flag of `first` records only
+            if (lpos < n_here)
+                s_fl[lpos] = static_cast<uint8_t>((my_mate << FL_MATE_SHIFT) | (((me >> 30) & 1u) << 4) | head |
+                                                  (first << 1) | (gb << 5));
             nh += head;
             nf += first;
             nv += valid;
-            if (live) fl[i] = static_cast<uint8_t>(f);
+            any_gb |= gb;
         }
+        PROF_T(t6);
+        PROF_ADD(0, t0, t1);
+        PROF_ADD(1, t1, t2);
+        PROF_ADD(2, t2, t3);
+        PROF_ADD(3, t3, t4);
+        PROF_ADD(4, t4, t5);
+        PROF_ADD(5, t5, t6);
+        PROF_ADD(6, t0, t0 + 1);
+        PROF_ADD(7, 0, t0);
+        __syncthreads();
+        if (n_here == static_cast<uint32_t>(kQTile)) {  // kQItems flag bytes per thread in one store
+            if (kQItems == 8)
+                reinterpret_cast<uint2*>(fl + base)[threadIdx.x] = reinterpret_cast<const uint2*>(s_flw)[threadIdx.x];
+            else
+                reinterpret_cast<uint32_t*>(fl + base)[threadIdx.x] = s_flw[threadIdx.x];
+        } else {
+            for (uint32_t j = threadIdx.x; j < n_here; j += kRBlock) fl[base + j] = s_fl[j];
+        }
+        __syncthreads();  // LDS is reused by the next pass
     }
     nh = r_wave_sum(nh);
     nf = r_wave_sum(nf);
     nv = r_wave_sum(nv);
     const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
-    const bool wave_gb = __any(any_gb);
+    const bool wave_gb = __any(any_gb != 0u);
     if ((threadIdx.x & 63) == 0) {
         s_w[threadIdx.x >> 6] = make_uint2(nh, nf);
         s_v[threadIdx.x >> 6] = nv;
@@ -450,7 +661,25 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lds_lo = base >= kHalo ? base - kHalo : 0u;
     const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile) + kHalo, N);
-    for (uint32_t i = lds_lo + threadIdx.x; i < lds_hi; i += kRBlock) s_fl[i - lds_lo] = fl[i];
+    // All global loads of the tile go out up front, with clamped indices instead of bounds branches (a load inside a
+    // per-record branch is a serial round trip; see k_runs): the flag bytes of the window, then reference / position of
+    // the thread's 8 records, then the contig geometry those references point at.
+    {
+        uint8_t fb[kRItems + 1];
+#pragma unroll
+        for (int k = 0; k <= kRItems; ++k) fb[k] = fl[min(lds_lo + k * kRBlock + threadIdx.x, N - 1u)];
+#pragma unroll
+        for (int k = 0; k <= kRItems; ++k) {
+            const uint32_t j = k * kRBlock + threadIdx.x;
+            if (j < lds_hi - lds_lo) s_fl[j] = fb[k];
+        }
+    }
+    typename Acc::Hit hit[kRItems];
+#pragma unroll
+    for (int k = 0; k < kRItems; ++k) hit[k] = acc.hit(min(base + k * kRBlock + threadIdx.x, N - 1u));
+    typename Acc::Geo geo[kRItems];
+#pragma unroll
+    for (int k = 0; k < kRItems; ++k) geo[k] = acc.geo(acc.hit_ref(hit[k]));
     __syncthreads();
     uint2 running = tile_off[blockIdx.x];
     bool too_long = false;
@@ -545,11 +774,9 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
                 }
             }
         }
-        if (first) {
-            bool dummy = false;
-            const uint32_t r = acc.meta_of(i, dummy) & 0x0fffffffu;
-            tgt_ref[t] = r | (head ? 0x80000000u : 0u);
-            tgt_gbin[t] = acc.gbin_of(i, r);
+        if (first) {  // a first record is mapped, so its reference is in range (k_runs checked)
+            tgt_ref[t] = acc.hit_ref(hit[k]) | (head ? 0x80000000u : 0u);
+            tgt_gbin[t] = acc.gbin(hit[k], geo[k]);
             if (head) read_off[m] = t;
         }
         running.x += total.x;
@@ -566,6 +793,13 @@ static int forced_runs_mode() {
     const char* e = getenv("SLIMM_RUNS_KERNEL");
     if (!e) return -1;
     return e[0] == 'h' ? 1 : (e[0] == 'w' ? 0 : -1);
+}
+
+// grid of k_runs (grid-stride over tiles beyond it)
+static uint32_t runs_grid() {
+    const char* e = getenv("SLIMM_RUNS_GRID");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? static_cast<uint32_t>(v) : 16384u;
 }
 
 static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len, const uint32_t* bin_off,
@@ -593,7 +827,7 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
     if (part == 0)
         hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
     else if (part == 1)
-        hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl,
+        hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, runs_grid())), dim3(kRBlock), 0, st, a, nt, counters, fl,
                            tile_cnt, tile_valid);
     else
         hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
@@ -618,7 +852,7 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     if (part == 0)
         hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
     else if (part == 1)
-        hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, 16384u)), dim3(kRBlock), 0, st, a, nt, counters, fl,
+        hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, runs_grid())), dim3(kRBlock), 0, st, a, nt, counters, fl,
                            tile_cnt, static_cast<uint32_t*>(nullptr));
     else
         hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
@@ -636,3 +870,10 @@ void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
 }
 
 }  // namespace slimm
+
+#if EXP == 9
+extern "C" int slimm_debug_prof(unsigned long long* out, int n) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof), sizeof(unsigned long long) * n);
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

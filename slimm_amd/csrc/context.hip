@@ -90,6 +90,7 @@ struct slimm_ctx {
 
     // static tables
     DevBuf<uint32_t> d_ref_len, d_bin_off, d_lin_dense;
+    DevBuf<uint2> d_geo;              // {contig length, first bin} per reference: one gather in k_emit
     DevBuf<uint8_t> d_valid;
     DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
     DevBuf<uint32_t> d_level_taxon;
@@ -348,6 +349,12 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->h_marks.ensure(c->R));
         HIP_TRY0(hipMemcpy(cc->d_ref_len.p, hc.ref_len.data(), c->R * 4, hipMemcpyHostToDevice));
         HIP_TRY0(hipMemcpy(cc->d_bin_off.p, c->bin_off_h.data(), (c->R + 1) * 4, hipMemcpyHostToDevice));
+        {
+            std::vector<uint2> geo(c->R);
+            for (uint32_t i = 0; i < c->R; ++i) geo[i] = make_uint2(hc.ref_len[i], static_cast<uint32_t>(c->bin_off_h[i]));
+            HIP_TRY0(cc->d_geo.ensure(c->R));
+            HIP_TRY0(hipMemcpy(cc->d_geo.p, geo.data(), c->R * sizeof(uint2), hipMemcpyHostToDevice));
+        }
         HIP_TRY0(hipMemcpy(cc->d_lin_dense.p, c->host->lineage_dense().data(), static_cast<size_t>(c->R) * 32,
                            hipMemcpyHostToDevice));
 #undef HIP_TRY0
@@ -583,7 +590,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_BUILD_CSR);
-            launch_emit_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->c_fl.p,
+            launch_emit_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, c->d_geo.p, half_read, hc.bin_width, c->c_fl.p,
                             c->counters.p, c->tile_cnt.p, c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p);
         }
     }

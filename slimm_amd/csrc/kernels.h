@@ -55,7 +55,8 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
                      uint2* tile_cnt, uint32_t* tile_valid, int part);
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
-                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, const uint8_t* fl, uint32_t* counters,
+                     const uint32_t* bin_off, const uint2* geo, uint32_t half_read, uint32_t bin_width, const uint8_t* fl,
+                     uint32_t* counters,
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off);
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
                         uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part);

@@ -67,6 +67,7 @@ struct RawRecords {
     uint32_t n, n_refs;
     const uint32_t* ref_len;
     const uint32_t* bin_off;
+    const uint2* geo_tab;  // {contig length, first bin} per reference (k_emit)
     uint32_t half_read, bin_width;
     static constexpr bool kCountsMapped = true;
     __device__ uint32_t count(const uint32_t*) const { return n; }
@@ -111,7 +112,10 @@ struct RawRecords {
     struct Geo {
         uint32_t len, off;
     };
-    __device__ Geo geo(uint32_t r) const { return Geo{ref_len[r], bin_off[r]}; }
+    __device__ Geo geo(uint32_t r) const {  // one 8-byte gather: divergent loads are paid per lane, not per byte
+        const uint2 g = geo_tab[r];
+        return Geo{g.x, g.y};
+    }
     __device__ uint32_t gbin(const Hit& h, const Geo& g) const {
         // uint32 wrap-around of int32 + uint32, then clamp to the contig length (src/slimm.hpp:200-201, Q3)
         return g.off + min(static_cast<uint32_t>(h.pos) + half_read, g.len) / bin_width;
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
                                                   uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
                                                   uint32_t* __restrict__ read_off) {
     __shared__ uint8_t s_fl[kHalo + kRTile + kHalo];
-    __shared__ uint2 s_w[2][kRWaves];
+    __shared__ uint2 s_w[kRItems][kRWaves];
     const uint32_t N = acc.count(counters);
     const uint32_t base = blockIdx.x * kRTile;
     if (base >= N) return;
@@ -686,6 +690,15 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
     // A later record with a smaller mate exists only where some record carries the larger-mate-before flag; when no
     // record of the whole stream does (unpaired data, or mates not interleaved), the forward look is skipped.
     const bool mates_interleave = counters[CNT_ANYGB] != 0u;
+    // heads / firsts of every 64-record segment (one barrier for the whole tile, then per-thread running sums)
+#pragma unroll
+    for (int k = 0; k < kRItems; ++k) {
+        const uint32_t i = base + k * kRBlock + threadIdx.x;
+        const uint32_t f = (i < N) ? s_fl[i - lds_lo] : 0u;
+        const uint64_t mh = __ballot(f & FL_HEAD), mf = __ballot(f & FL_FIRST);
+        if ((threadIdx.x & 63) == 0) s_w[k][wave] = make_uint2(__popcll(mh), __popcll(mf));
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kRItems; ++k) {
         const uint32_t i = base + k * kRBlock + threadIdx.x;
@@ -693,12 +706,10 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         const bool head = f & FL_HEAD, first = f & FL_FIRST;
         const uint64_t mh = __ballot(head), mf = __ballot(first);
         const uint32_t rh = r_mask_rank(mh), rf = r_mask_rank(mf);
-        if ((threadIdx.x & 63) == 0) s_w[k & 1][wave] = make_uint2(__popcll(mh), __popcll(mf));
-        __syncthreads();
         uint2 before = make_uint2(0u, 0u), total = make_uint2(0u, 0u);
 #pragma unroll
         for (int w = 0; w < kRWaves; ++w) {
-            const uint2 c = s_w[k & 1][w];
+            const uint2 c = s_w[k][w];
             if (w < static_cast<int>(wave)) {
                 before.x += c.x;
                 before.y += c.y;
@@ -803,7 +814,7 @@ static uint32_t runs_grid() {
 }
 
 static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len, const uint32_t* bin_off,
-                           uint32_t half_read, uint32_t bin_width) {
+                           uint32_t half_read, uint32_t bin_width, const uint2* geo = nullptr) {
     RawRecords a;
     a.key = in.key;
     a.ref = in.ref;
@@ -813,6 +824,7 @@ static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint3
     a.n_refs = n_refs;
     a.ref_len = ref_len;
     a.bin_off = bin_off;
+    a.geo_tab = geo;
     a.half_read = half_read;
     a.bin_width = bin_width;
     return a;
@@ -835,12 +847,13 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
-                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, const uint8_t* fl, uint32_t* counters,
+                     const uint32_t* bin_off, const uint2* geo, uint32_t half_read, uint32_t bin_width, const uint8_t* fl,
+                     uint32_t* counters,
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
     hipLaunchKernelGGL(k_emit<RawRecords>, dim3(nt), dim3(kRBlock), 0, st,
-                       make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width), fl, counters, tile_off, tgt_ref,
+                       make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width, geo), fl, counters, tile_off, tgt_ref,
                        tgt_gbin, read_off);
 }
 

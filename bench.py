@@ -48,7 +48,7 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "k_pick_runs": 8 * 8192,                      # samples the first records to choose the classification kernel
         "k_runs": 14 * N + 1 * N,                     # key + ref + flag in (look-back is an LDS walk), flag byte out
         "k_runs_hash": 14 * N + 1 * N,                # same bytes; whichever of the two was not picked returns at once
-        "k_emit": 1 * N + 8 * P + 8 * P + 4 * M,      # flag byte in; ref + pos of the firsts in; targets + read offsets out
+        "k_emit": 1 * N + 8 * N + 8 * P + 4 * M,      # flag byte + ref + pos of every record in; targets + read offsets out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
         "k_tile_count": 4 * P,                        # gbin in
         "k_tile_scan": 12 * (B // 8192 + 1),
@@ -58,7 +58,9 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "k_tile_scan2": 12 * (B // 8192 + 1),
         "k_tile_scatter2": 4 * M + 2 * U2,
         "k_tile_hist2": 2 * U2 + 4 * B,               # finished uniq_cov2 tiles out (replaces its zero-fill)
-        "k_ref_stats": 8 * B,                         # one streaming read of cov and uniq_cov
+        "k_ref_stats": 8 * B,                         # (multi-GPU bins exchange / fallback) one streaming read of cov and uniq_cov
+        "k_pack": 4 * 2 * 48,                         # counters + scalars copied behind the statistics k_tile_hist accumulated
+        "k_pack2": 4 * 2 * (32 + 5000 + 9000),        # counters, child marks, per-taxon counts
         "k_filter_lca": 4 * M + 8 * P + 4 * M,        # offsets + targets in; per-read unique bin out
         "k_ref_stats2": 4 * B,
     }

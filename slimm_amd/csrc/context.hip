@@ -65,13 +65,13 @@ struct PinBuf {
 enum KernelId {
     K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FLAGS, K_BUILD_CSR, K_HIST, K_REF_STATS, K_FILTER_LCA,
     K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_TILE_COUNT2, K_TILE_SCAN2, K_TILE_SCATTER2,
-    K_TILE_HIST2, K_PICK, K_RUNS_HASH, K_COUNT
+    K_TILE_HIST2, K_PICK, K_RUNS_HASH, K_PACK, K_PACK2, K_COUNT
 };
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
                                      "k_runs", "k_emit", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",
                                      "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2",
-                                     "k_pick_runs", "k_runs_hash"};
+                                     "k_pick_runs", "k_runs_hash", "k_pack", "k_pack2"};
 
 constexpr uint32_t kTailWords = 64;
 
@@ -90,6 +90,7 @@ struct slimm_ctx {
 
     // static tables
     DevBuf<uint32_t> d_ref_len, d_bin_off, d_lin_dense;
+    DevBuf<uint32_t> d_tile_ref0;     // per bin tile: first reference overlapping it (fused statistics)
     DevBuf<uint2> d_geo;              // {contig length, first bin} per reference: one gather in k_emit
     DevBuf<uint8_t> d_valid;
     DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
@@ -111,13 +112,15 @@ struct slimm_ctx {
     DevBuf<uint2> tile_cnt;
     DevBuf<uint32_t> tile_valid;
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
-    DevBuf<uint32_t> tile_count, tile_base, tile_cursor;
+    DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;
     DevBuf<uint4> tile_items, part_items;
     DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
+    bool statsA_final = false;  // k_pack has added the non-zero counts of the split tiles to the fused statistics
+    bool bins_exposed = false;  // the caller holds the coverage buffer (may have merged other ranks' bins into it)
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
     DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
     DevBuf<uint32_t> counters;   // CNT_WORDS
@@ -375,7 +378,18 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         }
         if (cc->use_tiles) {
             if (cc->tile_count.ensure(c->ntiles2 + 1) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
-                cc->tile_cursor.ensure(c->ntiles2 + 1) != hipSuccess)
+                cc->tile_cursor.ensure(c->ntiles2 + 1) != hipSuccess || cc->split_tiles.ensure(c->ntiles2 + 1) != hipSuccess)
+                return fail(nullptr, SLIMM_E_HIP, "out of device memory for tile tables");
+            std::vector<uint32_t> ref0(c->ntiles2 + 1, c->R);
+            uint32_t r = 0;
+            for (uint32_t t = 0; t < c->ntiles2; ++t) {
+                const uint64_t t0 = static_cast<uint64_t>(t) * kTileBins;
+                if (t0 >= c->bin_off_h[c->R]) break;
+                while (r + 1 < c->R && c->bin_off_h[r + 1] <= t0) ++r;
+                ref0[t] = r;
+            }
+            if (cc->d_tile_ref0.ensure(ref0.size()) != hipSuccess ||
+                hipMemcpy(cc->d_tile_ref0.p, ref0.data(), ref0.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for tile tables");
         }
         uint32_t cap = 1u << 16;
@@ -535,9 +549,13 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         if (c->use_tiles) {
             z.p[2] = c->tile_count.p;
             z.n[2] = c->ntiles2 + 1;
+            z.p[3] = c->ref_stats.p;  // per-reference statistics accumulated by k_tile_hist
+            z.n[3] = 4 * c->R;
         }
         launch_zero(st, z);
     }
+    c->bins_exposed = false;
+    c->statsA_final = false;
     const uint32_t nt = num_tiles(n);
     const HostConfig& hc = c->host->config();
     const uint32_t half_read = hc.avg_read_len / 2;
@@ -603,7 +621,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_TILE_SCAN);
             launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                             c->counters.p, c->part_items.p, c->sup_cursor.p);
+                             c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p);
         }
         {
             KernelTimer t(c, K_TILE_SCATTER);
@@ -614,7 +632,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_TILE_HIST);
             launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
-                             c->ucov());
+                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p);
         }
     } else {
         KernelTimer t(c, K_HIST);
@@ -630,6 +648,7 @@ int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
     (void)hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->bins_exposed = true;  // the statistics k_tile_hist accumulated describe the local bins only
     *d_ptr = c->bins.p;
     *n_words = 2 * c->Bp + 16;
     return SLIMM_OK;
@@ -676,13 +695,18 @@ int slimm_finish_coverage(slimm_ctx* c) {
     if (!c) return SLIMM_E_INVALID;
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
     (void)hipSetDevice(c->device);
-    {
+    PackArgs pk;
+    pk.src[0] = c->counters.p;
+    pk.n[0] = 32;
+    pk.src[1] = c->tail();
+    pk.n[1] = 16;
+    if (c->use_tiles && !c->bins_exposed) {  // k_tile_hist left the per-reference statistics in place
+        KernelTimer t(c, K_PACK);
+        launch_pack(c->stream, c->ref_stats.p + 4ull * c->R, pk, c->split_tiles.p, c->counters.p, c->cov(), c->ucov(),
+                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p);
+        c->statsA_final = true;
+    } else {
         KernelTimer t(c, K_REF_STATS);
-        PackArgs pk;
-        pk.src[0] = c->counters.p;
-        pk.n[0] = 32;
-        pk.src[1] = c->tail();
-        pk.n[1] = 16;
         launch_ref_stats(c->stream, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p, &pk);
     }
     return finish_from_device_stats(c);
@@ -696,7 +720,20 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
     HIP_TRY(c, c->summary.ensure(W));
     hipStream_t st = c->stream;
-    {
+    if (c->use_tiles && !c->bins_exposed) {
+        KernelTimer t(c, K_PACK);
+        PackArgs pk;
+        pk.src[0] = c->ref_stats.p;
+        pk.n[0] = 4 * c->R;
+        pk.src[1] = c->tail();
+        pk.n[1] = 16;
+        if (!c->statsA_final) {  // first finish the statistics in place, then copy them
+            launch_pack(st, c->summary.p, PackArgs(), c->split_tiles.p, c->counters.p, c->cov(), c->ucov(), c->d_bin_off.p,
+                        c->R, c->d_tile_ref0.p, c->ref_stats.p);
+            c->statsA_final = true;
+        }
+        launch_pack(st, c->summary.p, pk);
+    } else {
         KernelTimer t(c, K_REF_STATS);
         PackArgs pk;
         pk.src[0] = c->tail();
@@ -771,6 +808,8 @@ int slimm_filter_alignments(slimm_ctx* c) {
             if (c->use_tiles) {
                 z.p[2] = c->tile_count.p;
                 z.n[2] = c->ntiles2 + 1;
+                z.p[3] = blockB;  // per-reference statistics of uniq_cov2, accumulated by k_tile_hist
+                z.n[3] = 4 * R;
             } else {
                 z.p[2] = c->lca_count.p;
                 z.n[2] = T;
@@ -804,7 +843,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             {
                 KernelTimer t(c, K_TILE_SCAN2);
                 launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                 c->counters.p, c->part_items.p, c->sup_cursor.p);
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
@@ -815,11 +854,10 @@ int slimm_filter_alignments(slimm_ctx* c) {
             {
                 KernelTimer t(c, K_TILE_HIST2);
                 launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
-                                 c->ucov2(), nullptr);
+                                 c->ucov2(), nullptr, c->d_bin_off.p, R, c->d_tile_ref0.p, blockB);
             }
         }
         {
-            KernelTimer t(c, K_REF_STATS2);
             PackArgs pk;
             pk.src[0] = c->counters.p;
             pk.n[0] = 32;
@@ -827,7 +865,14 @@ int slimm_filter_alignments(slimm_ctx* c) {
             pk.n[1] = R;
             pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
             pk.n[2] = T;
-            launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, blockB, &pk);
+            if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place
+                KernelTimer t(c, K_PACK2);
+                launch_pack(st, blockB + 4ull * R, pk, c->split_tiles.p, c->counters.p, c->ucov2(), nullptr,
+                            c->d_bin_off.p, R, c->d_tile_ref0.p, blockB);
+            } else {
+                KernelTimer t(c, K_REF_STATS2);
+                launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, blockB, &pk);
+            }
         }
         uint32_t* const hB = c->h_stats.p + c->statsA_words();
         HIP_TRY(c, hipMemcpyAsync(hB, blockB, c->statsB_words() * 4, hipMemcpyDeviceToHost, st));

@@ -16,9 +16,23 @@ enum {
     CNT_ITEMS2 = 6, // work items of k_part_tile
     CNT_ANYGB = 8,  // some record follows a record of the same qName run with a larger mate number (mates interleave)
     CNT_MODE = 7,   // classification kernel picked on the device: 0 = look-back walk (k_runs), 1 = hash table (k_runs_hash)
+    CNT_SPLIT = 9,  // bin tiles cut into several k_tile_hist work items (their non-zero counts are finished by k_pack)
     CNT_WORDS = 32
 };
 enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4 };
+
+#if defined(__HIPCC__)
+// Sum over the 64 lanes of a wave with DPP adds (no LDS round trips as with ds_bpermute shuffles); every lane gets it.
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);   // row_shr:8  -> lane 15 of every row: row total
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
 
 struct PackArgs {  // small arrays appended behind the per-reference statistics by k_ref_stats
     const uint32_t* src[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -103,15 +117,26 @@ constexpr uint32_t kPartSub = 32768;                    // entries per k_part_ti
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper);
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
-                      uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor);
+                      uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
+                      uint32_t* split_tiles);
 // bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
                          const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
                          uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
                          uint32_t* cov, uint32_t* ucov, bool two_level);
+// stats != nullptr: k_tile_hist also accumulates the per-reference statistics {sum a, non-zero a, sum b, non-zero b}
+// (stats[ref * 4 ..], zeroed by the caller) of the finished arrays; tile_ref0[tile] = first reference overlapping the
+// tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
-                      const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov);
+                      const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
+                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats);
+// small arrays copied back to back to dst; with stats != nullptr also the non-zero bin counts of the tiles k_tile_hist
+// accumulated in pieces (split_tiles[0 .. counters[CNT_SPLIT])), read back from the finished arrays a / b
+void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint32_t* split_tiles = nullptr,
+                 const uint32_t* counters = nullptr, const uint32_t* a = nullptr, const uint32_t* b = nullptr,
+                 const uint32_t* bin_off = nullptr, uint32_t n_refs = 0, const uint32_t* tile_ref0 = nullptr,
+                 uint32_t* stats = nullptr);
 
 // Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and

@@ -311,7 +311,7 @@ def test_kernel_timing_reports_every_kernel():
     s.push_records(w.records)
     s.get_profiles()
     t = s.kernel_times()
-    for k in ("k_runs", "k_emit", "k_tile_hist", "k_ref_stats", "k_filter_lca"):
+    for k in ("k_runs", "k_emit", "k_tile_hist", "k_pack", "k_filter_lca", "k_tile_hist2", "k_pack2"):
         assert t[k][1] >= 1 and t[k][0] > 0.0, k
 
 

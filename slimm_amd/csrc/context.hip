@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -166,6 +167,24 @@ struct slimm_ctx {
 };
 
 namespace {
+
+// SLIMM_HOST_TRACE=1: wall-clock marks of the host steps between the two device phases, on stderr
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char* what;
+    explicit HostTrace(const char* w) : on(false), what(w) {
+        static const bool enabled = getenv("SLIMM_HOST_TRACE") != nullptr;
+        on = enabled;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void mark(const char* step) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host] %s: %s %.1f us\n", what, step, std::chrono::duration<double, std::micro>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 int fail(slimm_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -345,7 +364,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->counters.ensure(CNT_WORDS));
         HIP_TRY0(cc->ref_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->lca_count.ensure(c->T));
-        HIP_TRY0(cc->marks.ensure(c->R));
+        HIP_TRY0(cc->marks.ensure(static_cast<size_t>(c->R) * kMarkReps));
         HIP_TRY0(cc->h_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->h_small.ensure(CNT_WORDS + kTailWords));
         HIP_TRY0(cc->h_lca.ensure(c->T));
@@ -660,8 +679,11 @@ namespace {
 int finish_from_device_stats(slimm_ctx* c) {
     hipStream_t st = c->stream;
     const size_t R4 = 4ull * c->R;
+    HostTrace tr("finish_coverage");
     HIP_TRY(c, hipMemcpyAsync(c->h_stats.p, c->ref_stats.p, (R4 + 48) * 4, hipMemcpyDeviceToHost, st));
+    tr.mark("memcpyAsync call");
     HIP_TRY(c, hipStreamSynchronize(st));
+    tr.mark("stream sync (device phase A + copy)");
     const uint32_t* cnt = c->h_stats.p + R4;
     const uint32_t* tl = c->h_stats.p + R4 + 32;
     int rc = check_device_errors(c, cnt[CNT_ERR] | tl[3]);
@@ -685,6 +707,7 @@ int finish_from_device_stats(slimm_ctx* c) {
         nzu[r] = c->h_stats.p[r * 4 + 3];
     }
     c->host->set_coverage(rcnt.data(), ucnt.data(), nzc.data(), nzu.data(), tl[0], tl[1]);
+    tr.mark("columns + set_coverage");
     c->covered = true;
     c->no_hits = (tl[0] == 0);
     return c->no_hits ? SLIMM_E_NO_HITS : SLIMM_OK;
@@ -775,7 +798,9 @@ int slimm_filter_alignments(slimm_ctx* c) {
     if (!c->covered) return fail(c, SLIMM_E_INVALID, "call slimm_finish_coverage first");
     if (c->no_hits) return SLIMM_E_NO_HITS;
     HostProfile& h = *c->host;
+    HostTrace tr("filter_alignments");
     h.compute_valid();
+    tr.mark("compute_valid");
     if (c->device < 0) {  // host-only: the per-read part arrives through slimm_set_partials
         c->filtered = true;
         return SLIMM_OK;
@@ -791,7 +816,9 @@ int slimm_filter_alignments(slimm_ctx* c) {
             c->h_rows16.p[r] = make_uint4(q[0] | (uint32_t(q[1]) << 16), q[2] | (uint32_t(q[3]) << 16),
                                           q[4] | (uint32_t(q[5]) << 16), q[6] | ((uint32_t(q[7]) | v) << 16));
         }
+        tr.mark("rows16 build");
         HIP_TRY(c, hipMemcpyAsync(c->d_rows16.p, c->h_rows16.p, static_cast<size_t>(R) * 16, hipMemcpyHostToDevice, st));
+        tr.mark("rows16 H2D call");
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
     }
@@ -802,7 +829,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
             ZeroArgs z;
             z.p[0] = c->marks.p;
-            z.n[0] = R;
+            z.n[0] = R * (c->use_rows16 ? kMarkReps : 1u);
             z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
             z.n[1] = 2;
             if (c->use_tiles) {
@@ -827,7 +854,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
                                     c->d_rows16.p, c->d_level_taxon.p, h.level_offset(),
                                     c->use_tiles ? nullptr : c->ucov2(), c->use_tiles ? c->uniq_gbin.p : nullptr,
                                     c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p, c->pair_cap - 1,
-                                    static_cast<uint32_t>(c->Bp));
+                                    static_cast<uint32_t>(c->Bp), R);
             else
                 launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
                                   c->d_lin_dense.p, c->use_tiles ? nullptr : c->ucov2(),
@@ -863,6 +890,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             pk.n[0] = 32;
             pk.src[1] = c->marks.p;
             pk.n[1] = R;
+            pk.reps[1] = c->use_rows16 ? kMarkReps : 1u;  // k_filter_lca16 spreads the marks over copies
             pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
             pk.n[2] = T;
             if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place
@@ -875,8 +903,10 @@ int slimm_filter_alignments(slimm_ctx* c) {
             }
         }
         uint32_t* const hB = c->h_stats.p + c->statsA_words();
+        tr.mark("phase B launches");
         HIP_TRY(c, hipMemcpyAsync(hB, blockB, c->statsB_words() * 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
+        tr.mark("stream sync (device phase B + copy)");
         const uint32_t* h_cnt = hB + 4ull * R;
         const uint32_t err = h_cnt[CNT_ERR];
         if (err & ERR_PAIR_OVERFLOW) {
@@ -908,6 +938,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
     std::sort(c->part_pairs.begin(), c->part_pairs.end());
     h.set_partials(c->part_u2.data(), c->part_lca.data(), c->part_marks.data(), c->part_pairs.data(), c->n_pairs);
     h.set_nz_uniq_cov2(c->nz_ucov2.data());
+    tr.mark("partials to host profile");
     c->filtered = true;
     return SLIMM_OK;
 }

@@ -34,10 +34,12 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
 }
 #endif
 
-struct PackArgs {  // small arrays appended behind the per-reference statistics by k_ref_stats
+struct PackArgs {  // small arrays appended behind the per-reference statistics (k_pack, k_ref_stats)
     const uint32_t* src[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t n[4] = {0, 0, 0, 0};
+    uint32_t reps[4] = {1, 1, 1, 1};  // src[k] holds reps[k] copies of n[k] words each; their bitwise OR is packed
 };
+constexpr uint32_t kMarkReps = 16;  // copies of the level-mark words (k_filter_lca16 spreads its atomicOr over them)
 struct ZeroArgs {  // arrays cleared by one k_zero launch; p64 is filled with ~0 (the empty key of the pair set)
     uint32_t* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t n[5] = {0, 0, 0, 0, 0};
@@ -93,7 +95,7 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
                          const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
                          const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
                          uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
-                         uint32_t taxon_base);
+                         uint32_t taxon_base, uint32_t n_refs);
 // multi-GPU coverage summary: "bin != 0" bitmaps and their merge (sums over ranks, popcount of the OR per reference)
 void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits);
 void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,

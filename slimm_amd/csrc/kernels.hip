@@ -237,7 +237,12 @@ __global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict
         uint32_t* dst = out + 4ull * n_refs;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            for (uint32_t i = gid; i < pack.n[k]; i += gsz) dst[i] = pack.src[k][i];
+            for (uint32_t i = gid; i < pack.n[k]; i += gsz) {
+                uint32_t v = 0;
+#pragma unroll 16
+                for (uint32_t rep = 0; rep < pack.reps[k]; ++rep) v |= pack.src[k][static_cast<size_t>(rep) * pack.n[k] + i];
+                dst[i] = v;
+            }
             dst += pack.n[k];
         }
     }
@@ -420,12 +425,16 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
                                                          uint32_t* __restrict__ counters, const uint4* __restrict__ rows16,
                                                          const uint32_t* __restrict__ level_taxon, const LevelOffsets lo,
                                                          uint32_t* __restrict__ ucov2, uint32_t* __restrict__ uniq_gbin,
-                                                         uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
+                                                         uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks_all,
                                                          uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
-                                                         uint32_t pair_mask, uint32_t taxon_base) {
+                                                         uint32_t pair_mask, uint32_t taxon_base, uint32_t n_refs) {
     const uint32_t M = counters[CNT_M];
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     if (m >= M) return;
+    // Level marks are one bit per (reference, level) and most reads hit the same few references: while the bits are
+    // still unset, thousands of lanes atomicOr the same words (a third of this kernel's time with one copy).  Every
+    // workgroup therefore marks one of kMarkReps copies; k_pack ORs the copies together.
+    uint32_t* __restrict__ marks = marks_all + static_cast<size_t>(blockIdx.x & (kMarkReps - 1u)) * n_refs;
     const uint32_t s = read_off[m], e = read_off[m + 1];
     uint32_t nv = 0, first_g = 0, max_ref = 0, w_max = 0, eq = 0xffu;
     uint4 a0 = make_uint4(0, 0, 0, 0);
@@ -561,14 +570,14 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
                          const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
                          const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
                          uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
-                         uint32_t taxon_base) {
+                         uint32_t taxon_base, uint32_t n_refs) {
     uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
     LevelOffsets lo;
     for (int i = 0; i < 8; ++i) lo.off[i] = level_off[i];
     if (blocks)
         hipLaunchKernelGGL(k_filter_lca16, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters,
                            reinterpret_cast<const uint4*>(rows16), level_taxon, lo, ucov2, uniq_gbin, lca_count, marks,
-                           pair_tab, pair_list, pair_mask, taxon_base);
+                           pair_tab, pair_list, pair_mask, taxon_base, n_refs);
 }
 
 }  // namespace slimm

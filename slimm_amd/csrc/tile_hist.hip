@@ -153,6 +153,97 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
     }
 }
 
+// One chunk of the one-level bucketing: kQ * 2048 targets starting at c0 (kWhole: all of them inside [c0, hi), so no
+// bounds test sits between the loads -- a branch there makes every load wait for the one before).  The chunk stays in
+// registers: count per tile in LDS, reserve the chunk's stretch of every bucket with one returning atomic per tile (all
+// of a thread's atomics issued before any is waited for), scatter from registers.
+template <bool kWithRef, int kQ, bool kWhole>
+__device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_ref, const uint32_t* __restrict__ tgt_gbin,
+                                              uint32_t c0, uint32_t hi, uint32_t P, uint32_t ntiles,
+                                              const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
+                                              uint16_t* __restrict__ bucket, uint32_t* s_hist) {
+    constexpr int kMaxTilesPerThread = 8;  // one-level bucketing is used up to 4096 tiles
+    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
+    uint4 g[kQ];
+    uint32_t uniq = 0;  // bit 4 q + j: target j of word q is the only target of its read
+    if (kWhole) {
+        uint4 r[kQ];
+        uint32_t nxt[kQ];
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const uint32_t t = c0 + (q * kTBlock + threadIdx.x) * 4;
+            g[q] = *reinterpret_cast<const uint4*>(tgt_gbin + t);
+            if (kWithRef) {
+                r[q] = *reinterpret_cast<const uint4*>(tgt_ref + t);
+                nxt[q] = tgt_ref[min(t + 4, P - 1u)];
+            }
+        }
+        if (kWithRef) {
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const uint32_t t = c0 + (q * kTBlock + threadIdx.x) * 4;
+                const uint32_t s0 = r[q].x >> 31, s1 = r[q].y >> 31, s2 = r[q].z >> 31, s3 = r[q].w >> 31;
+                const uint32_t s4 = (t + 4 < P) ? (nxt[q] >> 31) : 1u;  // the end of the stream ends the read
+                uniq |= ((s0 & s1) | ((s1 & s2) << 1) | ((s2 & s3) << 2) | ((s3 & s4) << 3)) << (4 * q);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kQ; ++q) {
+            const uint32_t t = c0 + (q * kTBlock + threadIdx.x) * 4;
+            uint32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool live = t + j < hi;
+                v[j] = live ? tgt_gbin[t + j] : 0xffffffffu;
+                if (kWithRef && live) {
+                    const uint32_t a = tgt_ref[t + j] >> 31;
+                    const uint32_t n = (t + j + 1 < P) ? (tgt_ref[t + j + 1] >> 31) : 1u;
+                    uniq |= (a & n) << (4 * q + j);
+                }
+            }
+            g[q] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+        if (g[q].x != 0xffffffffu) atomicAdd(&s_hist[g[q].x >> kTileShift], 1u);
+        if (g[q].y != 0xffffffffu) atomicAdd(&s_hist[g[q].y >> kTileShift], 1u);
+        if (g[q].z != 0xffffffffu) atomicAdd(&s_hist[g[q].z >> kTileShift], 1u);
+        if (g[q].w != 0xffffffffu) atomicAdd(&s_hist[g[q].w >> kTileShift], 1u);
+    }
+    __syncthreads();
+    {   // s_hist becomes the write cursor of this chunk in every tile's bucket
+        uint32_t got[kMaxTilesPerThread];
+#pragma unroll
+        for (int j = 0; j < kMaxTilesPerThread; ++j) {
+            const uint32_t i = j * kTBlock + threadIdx.x;
+            const uint32_t h = i < ntiles ? s_hist[i] : 0u;
+            got[j] = h ? atomicAdd(&tile_cursor[i], h) + tile_base[i] : 0u;  // tiles this chunk does not touch: no atomic
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxTilesPerThread; ++j) {
+            const uint32_t i = j * kTBlock + threadIdx.x;
+            if (i < ntiles) s_hist[i] = got[j];
+        }
+        for (uint32_t i = kMaxTilesPerThread * kTBlock + threadIdx.x; i < ntiles; i += kTBlock)  // (beyond 4096 tiles)
+            s_hist[i] = atomicAdd(&tile_cursor[i], s_hist[i]) + tile_base[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) {
+        const uint32_t v[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (v[j] == 0xffffffffu) continue;
+            const uint32_t pos = atomicAdd(&s_hist[v[j] >> kTileShift], 1u);
+            bucket[pos] = static_cast<uint16_t>((v[j] & kTileMask) | (((uniq >> (4 * q + j)) & 1u) ? kTileBins : 0u));
+        }
+    }
+    __syncthreads();  // s_hist is cleared by the next chunk
+}
+
 template <bool kWithRef>
 __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ tgt_ref,
                                                           const uint32_t* __restrict__ tgt_gbin,
@@ -176,50 +267,27 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
             if (ucov) ou[i] = z;
         }
     }
-    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
-    __syncthreads();
     uint32_t lo, hi;
     slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
-        uint32_t g[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t t = t0 + u * kTBlock + threadIdx.x;
-            g[u] = (t < hi) ? tgt_gbin[t] : 0xffffffffu;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (g[u] != 0xffffffffu) atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
+    // whole chunks of 16 K, then 8 K / 4 K / 2 K (slices are 2048-aligned), then the ragged end of the last slice
+    constexpr uint32_t kUnit = kTBlock * 4;  // targets per 16-byte word of every thread
+    uint32_t c0 = lo;
+    for (; c0 + 8 * kUnit <= hi; c0 += 8 * kUnit)
+        scatter_chunk<kWithRef, 8, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+    if (c0 + 4 * kUnit <= hi) {
+        scatter_chunk<kWithRef, 4, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        c0 += 4 * kUnit;
     }
-    __syncthreads();
-    // reserve [base, base + h) of each non-empty tile's bucket for this workgroup; s_hist becomes the write cursor
-    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
-        uint32_t h = s_hist[i];
-        if (h) s_hist[i] = tile_base[i] + atomicAdd(&tile_cursor[i], h);
+    if (c0 + 2 * kUnit <= hi) {
+        scatter_chunk<kWithRef, 2, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        c0 += 2 * kUnit;
     }
-    __syncthreads();
-    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
-        uint32_t g[4], r0[4], r1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t t = t0 + u * kTBlock + threadIdx.x;
-            bool live = t < hi;
-            g[u] = live ? tgt_gbin[t] : 0xffffffffu;
-            if (kWithRef) {
-                r0[u] = live ? tgt_ref[t] : 0u;
-                r1[u] = (live && t + 1 < P) ? tgt_ref[t + 1] : 0x80000000u;
-            } else {
-                r0[u] = r1[u] = 0u;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (g[u] == 0xffffffffu) continue;
-            bool uniq = (r0[u] >> 31) && (r1[u] >> 31);  // first target of its read and the next target starts a read
-            uint32_t pos = atomicAdd(&s_hist[g[u] >> kTileShift], 1u);
-            bucket[pos] = static_cast<uint16_t>((g[u] & kTileMask) | (uniq ? kTileBins : 0u));
-        }
+    if (c0 + kUnit <= hi) {
+        scatter_chunk<kWithRef, 1, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        c0 += kUnit;
     }
+    if (c0 < hi)
+        scatter_chunk<kWithRef, 1, false>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
 }
 
 template <bool kWithRef>

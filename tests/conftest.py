@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch ships its own HIP runtime and libslimm_hip.so links the system one; whichever loads first serves both (same
+    # SONAME).  Load torch's first, as bench.py and smoke() do, so that tests using torch tensors next to the library do
+    # not depend on which test happened to run first.
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 def gpu_available() -> bool:

@@ -119,6 +119,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
+    uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
     bool statsA_final = false;  // k_pack has added the non-zero counts of the split tiles to the fused statistics
     bool bins_exposed = false;  // the caller holds the coverage buffer (may have merged other ranks' bins into it)
@@ -396,8 +397,11 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
             cc->two_level = tl ? (tl[0] == '1') : (c->ntiles2 > 4096);  // tiles, 996 us vs 603 us at 9.8 K tiles)
         }
         if (cc->use_tiles) {
-            if (cc->tile_count.ensure(c->ntiles2 + 1) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
-                cc->tile_cursor.ensure(c->ntiles2 + 1) != hipSuccess || cc->split_tiles.ensure(c->ntiles2 + 1) != hipSuccess)
+            cc->treps = cc->two_level ? 1u : kTileReps;
+            cc->tstride = c->ntiles2 + 1;
+            const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
+            if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
+                cc->tile_cursor.ensure(rep_words) != hipSuccess || cc->split_tiles.ensure(c->ntiles2 + 1) != hipSuccess)
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for tile tables");
             std::vector<uint32_t> ref0(c->ntiles2 + 1, c->R);
             uint32_t r = 0;
@@ -567,7 +571,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         z.n[1] = kTailWords;
         if (c->use_tiles) {
             z.p[2] = c->tile_count.p;
-            z.n[2] = c->ntiles2 + 1;
+            z.n[2] = c->treps * c->tstride;
             z.p[3] = c->ref_stats.p;  // per-reference statistics accumulated by k_tile_hist
             z.n[3] = 4 * c->R;
         }
@@ -635,18 +639,18 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p);
+            launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p, c->treps, c->tstride);
         }
         {
             KernelTimer t(c, K_TILE_SCAN);
             launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                             c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p);
+                             c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride);
         }
         {
             KernelTimer t(c, K_TILE_SCATTER);
             launch_tile_scatter(st, grid, c->ntiles, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
                                 c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(),
-                                c->ucov(), c->two_level);
+                                c->ucov(), c->two_level, c->tile_count.p, c->treps, c->tstride);
         }
         {
             KernelTimer t(c, K_TILE_HIST);
@@ -834,7 +838,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             z.n[1] = 2;
             if (c->use_tiles) {
                 z.p[2] = c->tile_count.p;
-                z.n[2] = c->ntiles2 + 1;
+                z.n[2] = c->treps * c->tstride;
                 z.p[3] = blockB;  // per-reference statistics of uniq_cov2, accumulated by k_tile_hist
                 z.n[3] = 4 * R;
             } else {
@@ -865,18 +869,19 @@ int slimm_filter_alignments(slimm_ctx* c) {
             const uint32_t grid = 512;
             {
                 KernelTimer t(c, K_TILE_COUNT2);
-                launch_tile_count(st, grid, c->ntiles2, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p);
+                launch_tile_count(st, grid, c->ntiles2, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p, c->treps,
+                                  c->tstride);
             }
             {
                 KernelTimer t(c, K_TILE_SCAN2);
                 launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p);
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
                 launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M,
                                     c->tile_base.p, c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p,
-                                    c->bucket.p, c->ucov2(), nullptr, c->two_level);
+                                    c->bucket.p, c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
             }
             {
                 KernelTimer t(c, K_TILE_HIST2);

@@ -107,9 +107,12 @@ constexpr uint32_t kTileShift = 13;
 constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 32 KiB of LDS in k_tile_hist
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
 int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
-// tile_count must be zero on entry (k_zero)
+// tile_count: `reps` copies of rep_stride words, zero on entry (k_zero); workgroup b adds to copy b % reps.
+// k_tile_scan sums the copies into tile_base and turns every copy into the start of its stretch inside the buckets,
+// which k_tile_scatter (same grid) then fills through the copy's own cursors: 1/reps of the same-address atomics.
+constexpr uint32_t kTileReps = 8;
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
-                       int count_slot, uint32_t* tile_count);
+                       int count_slot, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
 constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
 constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile
@@ -118,15 +121,16 @@ constexpr uint32_t kMaxSuper = 8192;                    // super tiles an LDS cu
 constexpr uint32_t kPartSub = 32768;                    // entries per k_part_tile work item
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper);
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
-void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
+void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles);
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride);
 // bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
                          const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
                          uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
-                         uint32_t* cov, uint32_t* ucov, bool two_level);
+                         uint32_t* cov, uint32_t* ucov, bool two_level, const uint32_t* rep_base, uint32_t reps,
+                         uint32_t rep_stride);
 // stats != nullptr: k_tile_hist also accumulates the per-reference statistics {sum a, non-zero a, sum b, non-zero b}
 // (stats[ref * 4 ..], zeroed by the caller) of the finished arrays; tile_ref0[tile] = first reference overlapping the
 // tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts

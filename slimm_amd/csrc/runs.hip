@@ -172,6 +172,9 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
 //   bit 31     the segment holds a run start (otherwise the stretch continues into the segment before)
 // k_runs works through a tile in passes of kQTile records (each with its own halo): half the registers of a
 // whole-tile pass, so more workgroups are resident and their load and classify phases overlap
+#ifndef SLIMM_RUNS_MINBLOCKS
+#define SLIMM_RUNS_MINBLOCKS 3  // workgroups per CU the register allocation aims for
+#endif
 #ifndef SLIMM_Q_ITEMS
 #define SLIMM_Q_ITEMS 4
 #endif
@@ -181,7 +184,7 @@ constexpr uint32_t kSegs = (kQTile + kHalo) / 64;
 constexpr uint32_t SEG_START = 0x80000000u;
 
 template <typename Acc>
-__global__ __launch_bounds__(kRBlock) void k_runs(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
+__global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
                                                   uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
                                                   uint32_t* __restrict__ tile_valid) {
     __shared__ uint32_t s_meta[kQTile + kHalo];

@@ -43,9 +43,13 @@ __device__ __forceinline__ void slice_of(uint32_t P, uint32_t b, uint32_t g, uin
 
 __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ tgt_gbin,
                                                         const uint32_t* __restrict__ counters, int count_slot,
-                                                        uint32_t ntiles, uint32_t* __restrict__ tile_count) {
+                                                        uint32_t ntiles, uint32_t* __restrict__ tile_count_all,
+                                                        uint32_t reps, uint32_t rep_stride) {
     extern __shared__ uint32_t s_hist[];
     const uint32_t P = counters[count_slot];
+    // 512 workgroups adding to the same 2.4 K counters serialise in the memory-side atomic units: every workgroup adds to
+    // one of `reps` copies instead, and k_tile_scan sums the copies
+    uint32_t* __restrict__ tile_count = tile_count_all + static_cast<size_t>(blockIdx.x % reps) * rep_stride;
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
     uint32_t lo, hi;
@@ -83,21 +87,39 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
 // One workgroup: exclusive scan tile_count -> tile_base (tile_base[ntiles] = total), zero tile_cursor, and cut every
 // tile's bucket into work items of at most kTileSub entries for k_tile_hist: items[k] = {tile, lo, hi, pieces of tile}.
 // A tile with no entry still gets one item (its finished tile is all zeros and has to be written).
-__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ tile_count, uint32_t ntiles,
+__global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_count, uint32_t ntiles,
                                                     uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
                                                     uint4* __restrict__ items, uint32_t* __restrict__ counters,
                                                     uint4* __restrict__ items2, uint32_t* __restrict__ sup_cursor,
-                                                    uint32_t* __restrict__ split_tiles) {
+                                                    uint32_t* __restrict__ split_tiles, uint32_t reps,
+                                                    uint32_t rep_stride) {
     __shared__ uint2 s_part[1024];
     __shared__ uint32_t s_nsplit;
+    __shared__ uint32_t s_cnt[4096];  // (one-level bucketing: <= 4096 tiles) a tile's total over the copies, then its base
     if (threadIdx.x == 0) s_nsplit = 0;
-    __syncthreads();
     const uint32_t tid = threadIdx.x;
+    const bool staged = ntiles <= 4096;  // otherwise reps == 1 (two-level bucketing) and the counts are read in place
+    if (staged) {
+        for (uint32_t i = tid; i < ntiles; i += 1024) {  // coalesced, the copies' loads independent of each other
+            uint32_t c = 0;
+            if (reps == kTileReps) {
+                uint32_t v[kTileReps];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) c += v[rep];
+            } else {
+                for (uint32_t rep = 0; rep < reps; ++rep) c += tile_count[static_cast<size_t>(rep) * rep_stride + i];
+            }
+            s_cnt[i] = c;
+        }
+    }
+    __syncthreads();
     const uint32_t per = (ntiles + 1023) / 1024;
     const uint32_t lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
     uint2 sum = make_uint2(0u, 0u);
     for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t c = tile_count[i];
+        const uint32_t c = staged ? s_cnt[i] : tile_count[i];
         sum.x += c;
         sum.y += c ? (c + kTileSub - 1) / kTileSub : 1u;
     }
@@ -113,10 +135,15 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
     }
     uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
     for (uint32_t i = lo; i < hi; ++i) {
-        uint32_t c = tile_count[i];
-        uint32_t pieces = c ? (c + kTileSub - 1) / kTileSub : 1u;
+        const uint32_t c = staged ? s_cnt[i] : tile_count[i];
+        const uint32_t pieces = c ? (c + kTileSub - 1) / kTileSub : 1u;
         tile_base[i] = run.x;
-        tile_cursor[i] = 0;
+        if (staged) {
+            s_cnt[i] = run.x;
+        } else {
+            tile_count[i] = run.x;
+            tile_cursor[i] = 0;
+        }
         if (pieces > 1) split_tiles[atomicAdd(&s_nsplit, 1u)] = i;
         for (uint32_t k = 0; k < pieces; ++k) {
             uint32_t a = run.x + k * kTileSub;
@@ -125,6 +152,32 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
         }
         run.x += c;
         run.y += pieces;
+    }
+    __syncthreads();
+    if (staged) {  // the copies of a tile's count become the start of every copy's stretch inside the tile's bucket
+        for (uint32_t i = tid; i < ntiles; i += 1024) {
+            uint32_t at = s_cnt[i];
+            if (reps == kTileReps) {
+                uint32_t v[kTileReps];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) {
+                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
+                    tile_count[k] = at;
+                    tile_cursor[k] = 0;
+                    at += v[rep];
+                }
+            } else {
+                for (uint32_t rep = 0; rep < reps; ++rep) {
+                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
+                    const uint32_t cr = tile_count[k];
+                    tile_count[k] = at;
+                    tile_cursor[k] = 0;
+                    at += cr;
+                }
+            }
+        }
     }
     if (tid == 1023) {
         tile_base[ntiles] = s_part[1023].x;
@@ -162,6 +215,7 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
                                               uint32_t c0, uint32_t hi, uint32_t P, uint32_t ntiles,
                                               const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
                                               uint16_t* __restrict__ bucket, uint32_t* s_hist) {
+    // (tile_base / tile_cursor: this workgroup's copy -- start of the copy's stretch in every bucket, and its cursor)
     constexpr int kMaxTilesPerThread = 8;  // one-level bucketing is used up to 4096 tiles
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     uint4 g[kQ];
@@ -249,11 +303,16 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
                                                           const uint32_t* __restrict__ tgt_gbin,
                                                           const uint32_t* __restrict__ counters, int count_slot,
                                                           uint32_t ntiles, const uint32_t* __restrict__ tile_base,
-                                                          uint32_t* __restrict__ tile_cursor,
+                                                          uint32_t* __restrict__ tile_cursor_all,
                                                           uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
-                                                          uint32_t* __restrict__ ucov) {
+                                                          uint32_t* __restrict__ ucov,
+                                                          const uint32_t* __restrict__ rep_base_all, uint32_t reps,
+                                                          uint32_t rep_stride) {
     extern __shared__ uint32_t s_hist[];
     const uint32_t P = counters[count_slot];
+    const size_t rep_off = static_cast<size_t>(blockIdx.x % reps) * rep_stride;
+    uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
+    const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
     // (one-level variant, used while the tile-id histogram fits LDS comfortably: fewer passes, but 2-byte stores scattered
     // over thousands of buckets)
     // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
@@ -273,21 +332,21 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
     constexpr uint32_t kUnit = kTBlock * 4;  // targets per 16-byte word of every thread
     uint32_t c0 = lo;
     for (; c0 + 8 * kUnit <= hi; c0 += 8 * kUnit)
-        scatter_chunk<kWithRef, 8, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        scatter_chunk<kWithRef, 8, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
     if (c0 + 4 * kUnit <= hi) {
-        scatter_chunk<kWithRef, 4, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        scatter_chunk<kWithRef, 4, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
         c0 += 4 * kUnit;
     }
     if (c0 + 2 * kUnit <= hi) {
-        scatter_chunk<kWithRef, 2, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        scatter_chunk<kWithRef, 2, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
         c0 += 2 * kUnit;
     }
     if (c0 + kUnit <= hi) {
-        scatter_chunk<kWithRef, 1, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        scatter_chunk<kWithRef, 1, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
         c0 += kUnit;
     }
     if (c0 < hi)
-        scatter_chunk<kWithRef, 1, false>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, tile_base, tile_cursor, bucket, s_hist);
+        scatter_chunk<kWithRef, 1, false>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
 }
 
 template <bool kWithRef>
@@ -614,16 +673,16 @@ int tile_hist_setup(uint32_t ntiles) {
 }
 
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
-                       int count_slot, uint32_t* tile_count) {
+                       int count_slot, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
     hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, gbin, counters,
-                       count_slot, ntiles, tile_count);
+                       count_slot, ntiles, tile_count, reps, rep_stride);
 }
 
-void launch_tile_scan(hipStream_t st, uint32_t ntiles, const uint32_t* tile_count, uint32_t* tile_base,
+void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles) {
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters,
-                       items2, sup_cursor, split_tiles);
+                       items2, sup_cursor, split_tiles, reps, rep_stride);
 }
 
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
@@ -633,15 +692,16 @@ uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
                          const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
                          uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
-                         uint32_t* cov, uint32_t* ucov, bool two_level) {
+                         uint32_t* cov, uint32_t* ucov, bool two_level, const uint32_t* rep_base, uint32_t reps,
+                         uint32_t rep_stride) {
     if (!two_level) {
         const size_t lds = static_cast<size_t>(ntiles) * 4;
         if (tgt_ref)
             hipLaunchKernelGGL(k_tile_scatter<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                               ntiles, tile_base, tile_cursor, bucket, cov, ucov);
+                               ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
         else
             hipLaunchKernelGGL(k_tile_scatter<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters,
-                               count_slot, ntiles, tile_base, tile_cursor, bucket, cov, ucov);
+                               count_slot, ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
         return;
     }
     if (tgt_ref)

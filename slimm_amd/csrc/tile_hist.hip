@@ -28,6 +28,15 @@
 
 namespace slimm {
 
+#if defined(EXP) && EXP == 8
+__device__ unsigned long long g_prof_t[8 * 4096];  // [workgroup-wave][phase]
+#define TPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define TPROF_ADD(slot, a, b) if ((threadIdx.x & 63) == 0) g_prof_t[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + slot] += (b) - (a)
+#else
+#define TPROF_T(x)
+#define TPROF_ADD(slot, a, b)
+#endif
+
 constexpr int kTBlock = 512;
 constexpr uint32_t kTileMask = kTileBins - 1;
 
@@ -217,6 +226,7 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
                                               uint16_t* __restrict__ bucket, uint32_t* s_hist) {
     // (tile_base / tile_cursor: this workgroup's copy -- start of the copy's stretch in every bucket, and its cursor)
     constexpr int kMaxTilesPerThread = 8;  // one-level bucketing is used up to 4096 tiles
+    TPROF_T(p0);
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     uint4 g[kQ];
     uint32_t uniq = 0;  // bit 4 q + j: target j of word q is the only target of its read
@@ -260,6 +270,7 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
         }
     }
     __syncthreads();
+    TPROF_T(p1);
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
         if (g[q].x != 0xffffffffu) atomicAdd(&s_hist[g[q].x >> kTileShift], 1u);
@@ -268,6 +279,7 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
         if (g[q].w != 0xffffffffu) atomicAdd(&s_hist[g[q].w >> kTileShift], 1u);
     }
     __syncthreads();
+    TPROF_T(p2);
     {   // s_hist becomes the write cursor of this chunk in every tile's bucket
         uint32_t got[kMaxTilesPerThread];
 #pragma unroll
@@ -285,6 +297,7 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
             s_hist[i] = atomicAdd(&tile_cursor[i], s_hist[i]) + tile_base[i];
     }
     __syncthreads();
+    TPROF_T(p3);
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
         const uint32_t v[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
@@ -295,7 +308,14 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
             bucket[pos] = static_cast<uint16_t>((v[j] & kTileMask) | (((uniq >> (4 * q + j)) & 1u) ? kTileBins : 0u));
         }
     }
+    TPROF_T(p4);
     __syncthreads();  // s_hist is cleared by the next chunk
+    TPROF_T(p5);
+    TPROF_ADD(0, p0, p1);
+    TPROF_ADD(1, p1, p2);
+    TPROF_ADD(2, p2, p3);
+    TPROF_ADD(3, p3, p4);
+    TPROF_ADD(4, p4, p5);
 }
 
 template <bool kWithRef>
@@ -731,3 +751,14 @@ void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const u
 }
 
 }  // namespace slimm
+
+#if defined(EXP) && EXP == 8
+extern "C" int slimm_debug_prof_tiles(unsigned long long* out, int n, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_t), sizeof(unsigned long long) * n);
+    if (reset) {
+        static unsigned long long z[8 * 4096];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_t), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

@@ -157,6 +157,17 @@ int slimm_dense_taxa(slimm_ctx* ctx, uint32_t* n, const uint32_t** taxid);
 int slimm_get_partials(slimm_ctx* ctx, slimm_partials* out);       /* pointers stay owned by ctx, valid until reset */
 int slimm_set_partials(slimm_ctx* ctx, const slimm_partials* in);  /* install merged values (copied) */
 
+/* Multi-GPU, device-side merge of the additive partial results (faster than get/set_partials through the host).
+ * After slimm_filter_alignments: a device buffer of n_words 32-bit words
+ *   [n_refs uniq_reads_count2 | n_taxa_dense LCA counts | 2 n_refs level marks, one 8-bit field per level | 1 pair count]
+ * that the ranks sum in place (ncclAllReduce(ncclSum, ncclInt32) from C++, torch.distributed.all_reduce on a tensor
+ * aliasing it); at most 255 ranks, so that no field carries into the next.  slimm_install_merged_partials then copies
+ * it back and installs it.  *total_pairs = (taxon, reference) pairs over all ranks (src/slimm.hpp:551-556, the
+ * no-level-agrees case): when it is not zero, gather every rank's pairs (slimm_get_partials) and install the union with
+ * slimm_set_partials. */
+int slimm_partials_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
+int slimm_install_merged_partials(slimm_ctx* ctx, uint32_t* total_pairs);
+
 /* ---- phase C(2,3): the propagation part of slimm::get_reads_lca_count() (src/slimm.hpp:560-610). */
 int slimm_get_reads_lca_count(slimm_ctx* ctx);
 

@@ -84,6 +84,8 @@ SYMBOLS = [
     ("slimm_dense_taxa", C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(_P)]),
     ("slimm_get_partials", C.c_int, [_P, C.POINTER(Partials)]),
     ("slimm_set_partials", C.c_int, [_P, C.POINTER(Partials)]),
+    ("slimm_partials_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("slimm_install_merged_partials", C.c_int, [_P, C.POINTER(C.c_uint32)]),
     ("slimm_get_reads_lca_count", C.c_int, [_P]),
     ("slimm_write_abundance", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]),
     ("slimm_write_abundance_file", C.c_int, [_P, C.c_char_p]),

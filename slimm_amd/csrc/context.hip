@@ -129,6 +129,8 @@ struct slimm_ctx {
     DevBuf<uint32_t> ref_stats;  // [R*4] then [R*4]
     DevBuf<uint32_t> summary;    // multi-GPU: [4R sums | 16 scalars | cov bits | uniq_cov bits]
     DevBuf<uint32_t> lca_count, marks;
+    DevBuf<uint32_t> d_partials;  // multi-GPU: the additive partial results, summed across ranks in place
+    PinBuf<uint32_t> h_partials;
     DevBuf<uint64_t> pair_tab, pair_list;
     uint32_t pair_cap = 0;  // power of two
     // pinned staging
@@ -945,6 +947,51 @@ int slimm_filter_alignments(slimm_ctx* c) {
     h.set_nz_uniq_cov2(c->nz_ucov2.data());
     tr.mark("partials to host profile");
     c->filtered = true;
+    return SLIMM_OK;
+}
+
+int slimm_partials_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
+    if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
+    if (!c->filtered || c->device < 0) return fail(c, SLIMM_E_INVALID, "no device partials (call slimm_filter_alignments)");
+    (void)hipSetDevice(c->device);
+    const uint64_t W = 3ull * c->R + c->T + 1;
+    HIP_TRY(c, c->d_partials.ensure(W));
+    launch_partials_pack(c->stream, c->ref_stats.p + c->statsA_words(), c->R, c->T, c->d_partials.p);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *d_ptr = c->d_partials.p;
+    *n_words = W;
+    return SLIMM_OK;
+}
+
+int slimm_install_merged_partials(slimm_ctx* c, uint32_t* total_pairs) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->filtered || c->device < 0 || !c->d_partials.p)
+        return fail(c, SLIMM_E_INVALID, "call slimm_partials_buffer first");
+    (void)hipSetDevice(c->device);
+    const uint32_t R = c->R, T = c->T;
+    const uint64_t W = 3ull * R + T + 1;
+    HIP_TRY(c, c->h_partials.ensure(W));
+    HIP_TRY(c, hipMemcpyAsync(c->h_partials.p, c->d_partials.p, W * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t* h = c->h_partials.p;
+    c->part_u2.assign(h, h + R);
+    c->part_lca.assign(h + R, h + R + T);
+    c->part_marks.resize(R);
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t lo = h[R + T + 2 * r], hi = h[R + T + 2 * r + 1];
+        uint32_t m = 0;
+        for (uint32_t lv = 0; lv < 4; ++lv) {
+            if ((lo >> (8 * lv)) & 0xffu) m |= 1u << lv;
+            if ((hi >> (8 * lv)) & 0xffu) m |= 1u << (4 + lv);
+        }
+        c->part_marks[r] = m;
+    }
+    if (total_pairs) *total_pairs = h[3ull * R + T];
+    // the (taxon, reference) pairs of the other ranks are not in here: when the total is not this rank's own count the
+    // caller gathers them and installs everything with slimm_set_partials
+    c->host->set_partials(c->part_u2.data(), c->part_lca.data(), c->part_marks.data(), c->part_pairs.data(),
+                          static_cast<uint32_t>(c->part_pairs.size()));
+    c->counted = false;
     return SLIMM_OK;
 }
 

@@ -96,6 +96,8 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
                          const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
                          uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
                          uint32_t taxon_base, uint32_t n_refs);
+// multi-GPU: [R uniq_reads_count2 | T LCA counts | 2R level marks in 8-bit fields | 1 pair count] from result block B
+void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out);
 // multi-GPU coverage summary: "bin != 0" bitmaps and their merge (sums over ranks, popcount of the OR per reference)
 void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits);
 void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,

@@ -555,6 +555,31 @@ void launch_zero(hipStream_t st, const ZeroArgs& z) {
     if (blocks) hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, st, z);
 }
 
+// Multi-GPU: this rank's additive partial results as one int32 buffer that ranks SUM in place:
+//   [R uniq_reads_count2 | T per-taxon LCA counts | 2R level marks, one 8-bit field per level | 1 number of pairs]
+// (a sum over at most 255 ranks cannot carry between the fields, so "field != 0" afterwards is the OR of the marks)
+__global__ __launch_bounds__(256) void k_partials_pack(const uint32_t* __restrict__ block_b, uint32_t R, uint32_t T,
+                                                       uint32_t* __restrict__ out) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    const uint32_t* cnt = block_b + 4ull * R;
+    const uint32_t* marks = cnt + 32;
+    const uint32_t* lca = marks + R;
+    for (uint32_t r = gid; r < R; r += gsz) {
+        out[r] = block_b[4ull * r];
+        const uint32_t m = marks[r];
+        out[R + T + 2 * r] = (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21);
+        out[R + T + 2 * r + 1] = ((m >> 4) & 1u) | ((m & 32u) << 3) | ((m & 64u) << 10) | ((m & 128u) << 17);
+    }
+    for (uint32_t t = gid; t < T; t += gsz) out[R + t] = lca[t];
+    if (gid == 0) out[3ull * R + T] = cnt[CNT_PAIRS];
+}
+
+void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out) {
+    const uint32_t n = R > T ? R : T;
+    hipLaunchKernelGGL(k_partials_pack, dim3(std::min<uint32_t>(256u, (n + 255u) / 256u + 1u)), dim3(256), 0, st, block_b, R, T,
+                       out);
+}
+
 void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
                        const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
                        uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,

@@ -50,43 +50,77 @@ def exchange_coverage(engine, group=None, mode: str = "summary") -> bool:
     return engine.finish_coverage_merged(gathered, world)
 
 
+# level marks travel as one int64 per reference with one 8-bit field per level: a SUM over up to 255 ranks cannot carry
+# from one field into the next, so "field != 0" after the all-reduce is the OR of the ranks' bits
+_SPREAD = np.array([sum(((m >> lv) & 1) << (8 * lv) for lv in range(8)) for m in range(256)], dtype=np.int64)
+
+
+def _gather_pairs(pairs: np.ndarray, total_pairs: int, dev, group) -> np.ndarray:
+    """Union of every rank's (taxon << 32 | reference) pairs; total_pairs (the same on every rank) bounds the buffers."""
+    world = dist.get_world_size(group)
+    n_local = int(pairs.shape[0])
+    mine = torch.full((total_pairs + 1,), -1, dtype=torch.int64, device=dev)
+    mine[0] = n_local
+    if n_local:
+        mine[1:1 + n_local] = torch.from_numpy(pairs.view(np.int64)).to(dev)
+    gathered = torch.empty(world * (total_pairs + 1), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    g = gathered.cpu().numpy().reshape(world, total_pairs + 1)
+    return np.unique(np.concatenate([g[k, 1:1 + int(g[k, 0])] for k in range(world)]).view(np.uint64))
+
+
+def merge_partials_on_device(engine, group=None) -> bool:
+    """The second exchange without a host detour, for engines that expose their partial results as a device tensor
+    (`partials_tensor` / `install_merged_partials`, i.e. the HIP library): ONE all-reduce(SUM) in place, one copy back.
+    Returns False when the engine has no such tensor (the caller then merges through the host)."""
+    if not hasattr(engine, "partials_tensor") or not dist.is_initialized():
+        return False
+    if dist.get_world_size(group) > 255:
+        raise ValueError("level marks travel in 8-bit fields: at most 255 ranks")
+    t = engine.partials_tensor()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+    total_pairs = engine.install_merged_partials()
+    if total_pairs > 0:  # rare (Q4: reads whose references agree at no level); the same decision on every rank
+        p = engine.get_partials()
+        pairs = _gather_pairs(p["pairs"], total_pairs, t.device, group)
+        engine.set_partials(p["uniq_reads_count2"], p["lca_count"], p["level_marks"], pairs)
+    return True
+
+
 def merge_partials(engine, device: Optional[torch.device] = None, group=None):
-    """Second, small exchange: sums, ORs (as sums of 0/1 flags) and a set union of the per-rank partial results."""
+    """Second, small exchange through host arrays: ONE all-reduce(SUM) of [uniq_reads_count2 | per-taxon LCA counts |
+    level marks | number of no-agreement pairs]; the pairs themselves (rare: reads whose references agree at no level,
+    Q4) follow in an all-gather only when some rank has any."""
     p = engine.get_partials()
     if not dist.is_initialized():
         return p  # nothing to merge with
     world = dist.get_world_size(group)
+    if world > 255:
+        raise ValueError("merge_partials packs level marks into 8-bit fields: at most 255 ranks")
     dev = device or torch.device("cpu")
     R = p["uniq_reads_count2"].shape[0]
     T = p["lca_count"].shape[0]
-    marks = p["level_marks"].astype(np.uint32)
-    flags = ((marks[:, None] >> np.arange(8, dtype=np.uint32)[None, :]) & 1).astype(np.int32).reshape(-1)
-    packed = np.concatenate([p["uniq_reads_count2"].view(np.int32), p["lca_count"].view(np.int32), flags,
-                             np.array([p["pairs"].shape[0]], dtype=np.int32)])
-    t = torch.from_numpy(packed).to(dev)
     npairs_local = int(p["pairs"].shape[0])
-    mx = torch.tensor([npairs_local], dtype=torch.int64, device=dev)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    packed = np.empty(2 * R + T + 1, dtype=np.int64)
+    packed[:R] = p["uniq_reads_count2"]
+    packed[R:R + T] = p["lca_count"]
+    packed[R + T:2 * R + T] = _SPREAD[p["level_marks"] & 0xff]
+    packed[-1] = npairs_local
+    t = torch.from_numpy(packed).to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    cap = int(mx.item())
-    pairs = p["pairs"]
-    if cap > 0:
-        mine = torch.full((cap + 1,), -1, dtype=torch.int64, device=dev)
-        mine[0] = npairs_local
-        if npairs_local:
-            mine[1:1 + npairs_local] = torch.from_numpy(pairs.view(np.int64)).to(dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=group)
-        parts = []
-        for g in gathered:
-            g = g.cpu().numpy()
-            parts.append(g[1:1 + int(g[0])])
-        pairs = np.unique(np.concatenate(parts).view(np.uint64))
     out = t.cpu().numpy()
-    u2 = out[:R].view(np.uint32).copy()
-    lca = out[R:R + T].view(np.uint32).copy()
-    fl = out[R + T:R + T + 8 * R].reshape(R, 8) > 0
-    mk = (fl.astype(np.uint32) << np.arange(8, dtype=np.uint32)[None, :]).sum(axis=1).astype(np.uint32)
+    pairs = p["pairs"]
+    total_pairs = int(out[-1])
+    if total_pairs > 0:  # every rank sees the same total, so every rank takes this branch
+        pairs = _gather_pairs(pairs, total_pairs, dev, group)
+    u2 = out[:R].astype(np.uint32)
+    lca = out[R:R + T].astype(np.uint32)
+    sp = out[R + T:2 * R + T]
+    mk = np.zeros(R, dtype=np.uint32)
+    for lv in range(8):
+        mk |= (((sp >> (8 * lv)) & 0xff) != 0).astype(np.uint32) << np.uint32(lv)
     return {"uniq_reads_count2": u2, "lca_count": lca, "level_marks": mk, "pairs": pairs}
 
 
@@ -115,8 +149,9 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
     engine.filter_alignments()
     t = lap("filter_alignments", t)
     if multi or getattr(engine, "needs_set_partials", False):
-        merged = merge_partials(engine, device, group)
-        engine.set_partials(merged["uniq_reads_count2"], merged["lca_count"], merged["level_marks"], merged["pairs"])
+        if not merge_partials_on_device(engine, group):
+            merged = merge_partials(engine, device, group)
+            engine.set_partials(merged["uniq_reads_count2"], merged["lca_count"], merged["level_marks"], merged["pairs"])
         t = lap("merge_partials", t)
     engine.get_reads_lca_count()
     t = lap("get_reads_lca_count", t)

@@ -155,6 +155,22 @@ class Slimm:
                 "level_marks": arr(p.level_marks, p.n_refs, C.c_uint32, np.uint32),
                 "pairs": arr(p.pairs, p.n_pairs, C.c_uint64, np.uint64)}
 
+    def partials_tensor(self):
+        """This rank's additive partial results ([uniq_reads_count2 | LCA counts | level marks | pair count]) as an int32
+        tensor aliasing library memory: all_reduce(SUM) it in place, then call install_merged_partials()."""
+        import torch
+
+        ptr = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.L.slimm_partials_buffer(self.ctx, C.byref(ptr), C.byref(n)))
+        return torch.as_tensor(DeviceArray(ptr.value, n.value, "<i4"), device=f"cuda:{self.device}")
+
+    def install_merged_partials(self) -> int:
+        """Installs the (summed) partials buffer; returns the number of (taxon, reference) pairs over all ranks."""
+        total = C.c_uint32()
+        self._check(self.L.slimm_install_merged_partials(self.ctx, C.byref(total)))
+        return int(total.value)
+
     def set_partials(self, uniq_reads_count2, lca_count, level_marks, pairs):
         u2 = np.ascontiguousarray(uniq_reads_count2, dtype=np.uint32)
         lc = np.ascontiguousarray(lca_count, dtype=np.uint32)

@@ -292,6 +292,51 @@ def test_two_shards_on_one_gpu_through_the_summary_exchange():
     assert np.array_equal(engines[0].bins(2) + engines[1].bins(2), o.uniq_cov2)
 
 
+@pytest.mark.parametrize("with_pairs", [False, True])
+def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs):
+    """The second exchange on the device: the two contexts' partials buffers are summed like an all-reduce would."""
+    import torch
+    if with_pairs:   # reads straddling superkingdoms agree at no level (Q4): (taxon, ref) pairs
+        cfg = SynthConfig("q4shards", 150_000, 10_000, 6.0, present_frac=0.5, len_lo=200_000, len_hi=600_000)
+        w = make_workload(cfg, seed=23)
+        rng = np.random.default_rng(1)
+        m = w.records.ref_id >= 0
+        jump = rng.random(len(w.records)) < 0.2
+        w.records.ref_id[m & jump] = rng.integers(0, cfg.n_refs, size=int((m & jump).sum()), dtype=np.int32)
+        w.records.begin_pos[m & jump] = 1000
+    else:
+        w = make_workload(CONFIGS["config2"], seed=22, n_records=300_000)
+    o = run_workload(w, use_qnames=False)
+    owner = (w.records.read_key % np.uint64(2)).astype(np.int64)
+    engines = []
+    for r in range(2):
+        s = Slimm.for_workload(w, device=0)
+        s.push_records(w.records.take(np.nonzero(owner == r)[0]))
+        s.analyze_alignments()
+        engines.append(s)
+    gathered = torch.cat([e.coverage_summary_tensor().clone() for e in engines])
+    torch.cuda.synchronize()
+    for e in engines:
+        assert e.finish_coverage_merged(gathered, 2)
+        e.filter_alignments()
+    tensors = [e.partials_tensor() for e in engines]
+    total = tensors[0] + tensors[1]
+    for t in tensors:
+        t.copy_(total)
+    torch.cuda.synchronize()
+    totals = [e.install_merged_partials() for e in engines]
+    assert totals[0] == totals[1]
+    local = [e.get_partials() for e in engines]
+    assert totals[0] == sum(p["pairs"].shape[0] for p in local)
+    assert (totals[0] > 0) == with_pairs
+    pairs = np.unique(np.concatenate([p["pairs"] for p in local]))
+    for e, p in zip(engines, local):
+        if totals[0]:
+            e.set_partials(p["uniq_reads_count2"], p["lca_count"], p["level_marks"], pairs)
+        e.get_reads_lca_count()
+        assert_matches_oracle(e, o, bins=False)
+
+
 def test_single_rank_through_the_exchange_code_path():
     from slimm_amd.distributed import sharded_profile
     w = make_workload(CONFIGS["config1"], seed=19)

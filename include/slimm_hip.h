@@ -112,6 +112,10 @@ int slimm_analyze_alignments(slimm_ctx* ctx);
  * (one all-reduce) between slimm_analyze_alignments() and slimm_finish_coverage().  The stream is synchronised. */
 int slimm_coverage_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
 
+/* Multi-GPU, optional: announce before slimm_analyze_alignments that slimm_coverage_summary will be called, so that
+ * the histogram kernels write the 'bin != 0' bitmaps while the finished tiles are still in LDS (otherwise
+ * slimm_coverage_summary streams both coverage arrays once more to build them). */
+int slimm_prepare_summary(slimm_ctx* ctx, int on);
 /* Leaner exchange for the same point, used by default by slimm_amd/distributed.py: the cut-offs only need per-reference
  * SUMS of cov / uniq_cov (additive) and per-reference counts of NON-ZERO bins (popcount of the OR of every rank's
  * "bin != 0" bitmap).  slimm_coverage_summary() builds [sums | 16 scalars | cov bits | uniq_cov bits] for this rank in

@@ -121,6 +121,8 @@ struct slimm_ctx {
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
     uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
+    bool summary_bits = false;  // k_tile_hist also writes the 'bin != 0' bitmaps of the coverage summary (multi-GPU)
+    bool summary_has_bits = false;
     bool statsA_final = false;  // k_pack has added the non-zero counts of the split tiles to the fused statistics
     bool bins_exposed = false;  // the caller holds the coverage buffer (may have merged other ranks' bins into it)
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
@@ -656,8 +658,18 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_TILE_HIST);
+            uint64_t* bits_a = nullptr;
+            uint64_t* bits_b = nullptr;
+            c->summary_has_bits = false;
+            if (c->summary_bits) {
+                const uint64_t bits_words = c->Bp / 32;
+                HIP_TRY(c, c->summary.ensure(4ull * c->R + 16 + 2 * bits_words));
+                bits_a = reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16);
+                bits_b = reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16 + bits_words);
+                c->summary_has_bits = true;
+            }
             launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
-                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p);
+                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, bits_a, bits_b);
         }
     } else {
         KernelTimer t(c, K_HIST);
@@ -731,14 +743,22 @@ int slimm_finish_coverage(slimm_ctx* c) {
     pk.n[1] = 16;
     if (c->use_tiles && !c->bins_exposed) {  // k_tile_hist left the per-reference statistics in place
         KernelTimer t(c, K_PACK);
+        uint64_t* bits_a = c->summary_has_bits ? reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16) : nullptr;
         launch_pack(c->stream, c->ref_stats.p + 4ull * c->R, pk, c->split_tiles.p, c->counters.p, c->cov(), c->ucov(),
-                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p);
+                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p, bits_a,
+                    bits_a ? bits_a + c->Bp / 64 : nullptr);
         c->statsA_final = true;
     } else {
         KernelTimer t(c, K_REF_STATS);
         launch_ref_stats(c->stream, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->ref_stats.p, &pk);
     }
     return finish_from_device_stats(c);
+}
+
+int slimm_prepare_summary(slimm_ctx* c, int on) {
+    if (!c) return SLIMM_E_INVALID;
+    c->summary_bits = on != 0 && c->device >= 0 && c->use_tiles;
+    return SLIMM_OK;
 }
 
 int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
@@ -749,6 +769,7 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
     HIP_TRY(c, c->summary.ensure(W));
     hipStream_t st = c->stream;
+    bool have_bits = false;  // k_tile_hist / k_pack already wrote the bitmaps into the summary buffer
     if (c->use_tiles && !c->bins_exposed) {
         KernelTimer t(c, K_PACK);
         PackArgs pk;
@@ -756,12 +777,14 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
         pk.n[0] = 4 * c->R;
         pk.src[1] = c->tail();
         pk.n[1] = 16;
-        if (!c->statsA_final) {  // first finish the statistics in place, then copy them
+        if (!c->statsA_final) {  // first finish the statistics (and bitmaps) of the split tiles in place, then copy
+            uint64_t* bits_a = c->summary_has_bits ? reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16) : nullptr;
             launch_pack(st, c->summary.p, PackArgs(), c->split_tiles.p, c->counters.p, c->cov(), c->ucov(), c->d_bin_off.p,
-                        c->R, c->d_tile_ref0.p, c->ref_stats.p);
+                        c->R, c->d_tile_ref0.p, c->ref_stats.p, bits_a, bits_a ? bits_a + bits_words / 2 : nullptr);
             c->statsA_final = true;
         }
         launch_pack(st, c->summary.p, pk);
+        have_bits = c->summary_has_bits;
     } else {
         KernelTimer t(c, K_REF_STATS);
         PackArgs pk;
@@ -769,8 +792,10 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
         pk.n[0] = 16;
         launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->summary.p, &pk);
     }
-    launch_nonzero_bits(st, c->cov(), c->Bp, c->summary.p + 4ull * c->R + 16);
-    launch_nonzero_bits(st, c->ucov(), c->Bp, c->summary.p + 4ull * c->R + 16 + bits_words);
+    if (!have_bits) {
+        launch_nonzero_bits(st, c->cov(), c->Bp, c->summary.p + 4ull * c->R + 16);
+        launch_nonzero_bits(st, c->ucov(), c->Bp, c->summary.p + 4ull * c->R + 16 + bits_words);
+    }
     HIP_TRY(c, hipStreamSynchronize(st));
     *d_ptr = c->summary.p;
     *n_words = W;

@@ -138,13 +138,14 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
 // tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
-                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats);
+                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, uint64_t* bits_a = nullptr,
+                      uint64_t* bits_b = nullptr);  // bits: also the 'bin != 0' bitmaps of the two arrays
 // small arrays copied back to back to dst; with stats != nullptr also the non-zero bin counts of the tiles k_tile_hist
 // accumulated in pieces (split_tiles[0 .. counters[CNT_SPLIT])), read back from the finished arrays a / b
 void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint32_t* split_tiles = nullptr,
                  const uint32_t* counters = nullptr, const uint32_t* a = nullptr, const uint32_t* b = nullptr,
                  const uint32_t* bin_off = nullptr, uint32_t n_refs = 0, const uint32_t* tile_ref0 = nullptr,
-                 uint32_t* stats = nullptr);
+                 uint32_t* stats = nullptr, uint64_t* bits_a = nullptr, uint64_t* bits_b = nullptr);
 
 // Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and

@@ -140,6 +140,8 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
 
     multi = (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "force_exchange", False)
     t = time.perf_counter()
+    if hasattr(engine, "prepare_summary"):
+        engine.prepare_summary(multi and exchange == "summary")
     engine.analyze_alignments()
     t = lap("analyze_alignments(launch)", t)
     have_hits = exchange_coverage(engine, group, exchange)

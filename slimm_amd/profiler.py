@@ -114,6 +114,10 @@ class Slimm:
 
         return torch.as_tensor(self.coverage_buffer(), device=f"cuda:{self.device}")
 
+    def prepare_summary(self, on: bool = True):
+        """Multi-GPU: have phase A write the coverage-summary bitmaps as a by-product (call before analyze_alignments)."""
+        self._check(self.L.slimm_prepare_summary(self.ctx, int(on)))
+
     def coverage_summary_tensor(self):
         """[per-ref sums | scalars | 'bin != 0' bitmaps] of this rank as an int32 tensor aliasing library memory."""
         import torch

@@ -49,3 +49,29 @@ def test_layout_fallback_paths(monkeypatch, cfg, env):
 
 def test_layout_any_order():
     _check(MIXED, seed=7, grouped=False)
+
+
+@pytest.mark.parametrize("cfg", [HOT_TILE, TINY_REFS], ids=lambda c: c.name)
+@pytest.mark.parametrize("prepared", [True, False])
+def test_layout_through_the_summary_exchange(cfg, prepared):
+    """Coverage summary (per-reference sums + 'bin != 0' bitmaps) of these layouts, with the bitmaps written by the
+    histogram kernels (split tiles finished by k_pack) and by the separate bitmap kernels."""
+    import torch
+    w = make_workload(cfg, seed=9)
+    o = run_workload(w, use_qnames=False)
+    s = Slimm.for_workload(w, device=0)
+    s.prepare_summary(prepared)
+    s.push_records(w.records)
+    s.analyze_alignments()
+    mine = s.coverage_summary_tensor()
+    R = len(w.ref_len)
+    Bp = (mine.numel() - 4 * R - 16) * 32 // 2
+    words = mine.cpu().numpy().view(np.uint32)
+    for which, arr in ((0, o.cov), (1, o.uniq_cov)):
+        bits = np.unpackbits(words[4 * R + 16 + which * (Bp // 32):4 * R + 16 + (which + 1) * (Bp // 32)].view(np.uint8),
+                             bitorder="little")
+        assert int(bits.sum()) == int((arr != 0).sum())
+    assert s.finish_coverage_merged(mine.clone(), 1)
+    s.filter_alignments()
+    s.get_reads_lca_count()
+    assert_matches_oracle(s, o)

@@ -311,6 +311,7 @@ def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs):
     engines = []
     for r in range(2):
         s = Slimm.for_workload(w, device=0)
+        s.prepare_summary(True)   # bitmaps written by the histogram kernels (the other test leaves this off)
         s.push_records(w.records.take(np.nonzero(owner == r)[0]))
         s.analyze_alignments()
         engines.append(s)

@@ -86,8 +86,8 @@ def pmc_traffic_bytes(kernel_name, records_per_gpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="config2")
     ap.add_argument("--records", type=int, default=0, help="records per rank (default: the config's size)")
     ap.add_argument("--seed", type=int, default=1)

@@ -144,7 +144,6 @@ struct slimm_ctx {
     uint32_t local_V = 0, local_M = 0, local_P = 0;
     uint32_t n_pairs = 0;
     std::vector<uint32_t> nz_ucov2;
-    std::vector<uint32_t> col[4];  // per-reference columns handed to the host glue
     // partials handed out / installed
     std::vector<uint32_t> part_u2, part_lca, part_marks;
     std::vector<uint64_t> part_pairs;
@@ -709,22 +708,9 @@ int finish_from_device_stats(slimm_ctx* c) {
     c->local_V = cnt[CNT_V];
     c->local_M = cnt[CNT_M];
     c->local_P = cnt[CNT_P];
-    const uint32_t R = c->R;
-    std::vector<uint32_t>& rcnt = c->col[0];
-    std::vector<uint32_t>& ucnt = c->col[1];
-    std::vector<uint32_t>& nzc = c->col[2];
-    std::vector<uint32_t>& nzu = c->col[3];
-    rcnt.resize(R);
-    ucnt.resize(R);
-    nzc.resize(R);
-    nzu.resize(R);
-    for (uint32_t r = 0; r < R; ++r) {
-        rcnt[r] = c->h_stats.p[r * 4 + 0];  // reads_count = sum of cov bins
-        nzc[r] = c->h_stats.p[r * 4 + 1];
-        ucnt[r] = c->h_stats.p[r * 4 + 2];  // uniq_reads_count = sum of uniq_cov bins
-        nzu[r] = c->h_stats.p[r * 4 + 3];
-    }
-    c->host->set_coverage(rcnt.data(), ucnt.data(), nzc.data(), nzu.data(), tl[0], tl[1]);
+    // packed rows {reads_count = sum of cov bins, non-zero cov, uniq_reads_count = sum of uniq_cov bins, non-zero uniq_cov}
+    const uint32_t* st4 = c->h_stats.p;
+    c->host->set_coverage_strided(st4 + 0, st4 + 2, st4 + 1, st4 + 3, 4, tl[0], tl[1]);
     tr.mark("columns + set_coverage");
     c->covered = true;
     c->no_hits = (tl[0] == 0);

@@ -128,23 +128,36 @@ void HostProfile::reset_cutoffs() { cc_cache_ = ucc_cache_ = 0.0f; }
 
 void HostProfile::set_coverage(const uint32_t* rc, const uint32_t* urc, const uint32_t* nzc, const uint32_t* nzu,
                                uint32_t hits_, uint32_t matches_) {
+    set_coverage_strided(rc, urc, nzc, nzu, 1, hits_, matches_);
+}
+
+// The four per-reference columns with a common stride (4: the device's packed {reads, non-zero cov, unique reads,
+// non-zero uniq_cov} rows, read in place).
+void HostProfile::set_coverage_strided(const uint32_t* rc, const uint32_t* urc, const uint32_t* nzc, const uint32_t* nzu,
+                                       size_t stride, uint32_t hits_, uint32_t matches_) {
     const uint32_t R = cfg_.n_refs;
-    reads_count.assign(rc, rc + R);
-    uniq_reads_count.assign(urc, urc + R);
-    nz_cov.assign(nzc, nzc + R);
-    nz_ucov.assign(nzu, nzu + R);
+    reads_count.resize(R);
+    uniq_reads_count.resize(R);
+    nz_cov.resize(R);
+    nz_ucov.resize(R);
     hits = hits_;
     matches = matches_;
     uint32_t u = 0;
-    for (uint32_t i = 0; i < R; ++i) u += uniq_reads_count[i];
+    for (uint32_t i = 0; i < R; ++i) {
+        reads_count[i] = rc[i * stride];
+        uniq_reads_count[i] = urc[i * stride];
+        nz_cov[i] = nzc[i * stride];
+        nz_ucov[i] = nzu[i * stride];
+        u += uniq_reads_count[i];
+    }
     uniq_matches = u;  // slimm.hpp:225, one per unique read
     uniq_hits = u;     // slimm.hpp:236
-    // slimm.hpp:259-302
+    // slimm.hpp:259-302 (two passes per abundance: the float sums run over the references in index order)
     abundance.assign(R, 0.0f);
     uniq_abundance.assign(R, 0.0f);
     reference_count = 0;
     matched_ref_length = 0;
-    float total = 0.0f;
+    float total = 0.0f, utotal = 0.0f;
     for (uint32_t i = 0; i < R; ++i) {
         if (reads_count[i] > 0) {
             ++reference_count;
@@ -152,18 +165,15 @@ void HostProfile::set_coverage(const uint32_t* rc, const uint32_t* urc, const ui
             abundance[i] = float(reads_count[i] * 100) / hits;
             total += abundance[i] / cfg_.ref_len[i];
         }
-    }
-    for (uint32_t i = 0; i < R; ++i)
-        if (reads_count[i] > 0) abundance[i] = (abundance[i] * 100) / (total * cfg_.ref_len[i]);
-    total = 0.0f;
-    for (uint32_t i = 0; i < R; ++i) {
         if (uniq_reads_count[i] > 0) {
             uniq_abundance[i] = float(uniq_reads_count[i] * 100) / uniq_hits;
-            total += uniq_abundance[i] / cfg_.ref_len[i];
+            utotal += uniq_abundance[i] / cfg_.ref_len[i];
         }
     }
-    for (uint32_t i = 0; i < R; ++i)
-        if (uniq_reads_count[i] > 0) uniq_abundance[i] = (uniq_abundance[i] * 100) / (total * cfg_.ref_len[i]);
+    for (uint32_t i = 0; i < R; ++i) {
+        if (reads_count[i] > 0) abundance[i] = (abundance[i] * 100) / (total * cfg_.ref_len[i]);
+        if (uniq_reads_count[i] > 0) uniq_abundance[i] = (uniq_abundance[i] * 100) / (utotal * cfg_.ref_len[i]);
+    }
     // slimm.hpp:458-459
     if (min_reads == 0 && matches > 0) min_reads = 1 + ((matches - 1) / 10000);
     have_coverage = true;

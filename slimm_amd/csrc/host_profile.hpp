@@ -86,6 +86,8 @@ public:
     // phase A results (per reference) -> a6 statistics
     void set_coverage(const uint32_t* reads_count, const uint32_t* uniq_reads_count, const uint32_t* nz_cov,
                       const uint32_t* nz_uniq_cov, uint32_t hits, uint32_t matches);
+    void set_coverage_strided(const uint32_t* reads_count, const uint32_t* uniq_reads_count, const uint32_t* nz_cov,
+                              const uint32_t* nz_uniq_cov, size_t stride, uint32_t hits, uint32_t matches);
     // a8 + a9
     void compute_valid();
     // phase B/C(1) results

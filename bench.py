@@ -96,8 +96,9 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--record-order", default="grouped", choices=["grouped", "any"],
                     help="'any' sends the same records through the device sort path (record_order = SLIMM_ORDER_ANY)")
-    ap.add_argument("--exchange", default="summary", choices=["summary", "bins"],
-                    help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps, or all-reduce of the bins")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "summary", "sliced", "bins"],
+                    help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps (summary), all-to-all of "
+                         "bitmap slices + small all-reduce (sliced), all-reduce of the bins; auto = summary up to 2 ranks")
     ap.add_argument("--kernel-timing", choices=("dominant", "all"), default="dominant",
                     help="HIP events in the timed steps: around the dominant kernel only (default) or around every launch")
     ap.add_argument("--force-exchange", action="store_true",
@@ -107,7 +108,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from slimm_amd.distributed import sharded_profile
+    from slimm_amd.distributed import resolve_exchange, sharded_profile
     from slimm_amd.profiler import Slimm
     from slimm_amd.synth import CONFIGS, make_workload
 
@@ -264,7 +265,7 @@ def main():
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
                        "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
                        "record_order": args.record_order, "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
-                       "exchange": (args.exchange if (world > 1 or args.force_exchange) else "none"),
+                       "exchange": (resolve_exchange(eng, args.exchange, world) if (world > 1 or args.force_exchange) else "none"),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -114,8 +114,10 @@ int slimm_coverage_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
 
 /* Multi-GPU, optional: announce before slimm_analyze_alignments that slimm_coverage_summary will be called, so that
  * the histogram kernels write the 'bin != 0' bitmaps while the finished tiles are still in LDS (otherwise
- * slimm_coverage_summary streams both coverage arrays once more to build them). */
-int slimm_prepare_summary(slimm_ctx* ctx, int on);
+ * slimm_coverage_summary streams both coverage arrays once more to build them).  n_slices: 0 = off; 1 = one
+ * [cov bits | uniq_cov bits] block (all-gather form, below); n > 1 = the bitmaps cut into n slices of bin tiles, slice j
+ * = [cov bits | uniq_cov bits] of rank j's share, for the all-to-all form. */
+int slimm_prepare_summary(slimm_ctx* ctx, uint32_t n_slices);
 /* Leaner exchange for the same point, used by default by slimm_amd/distributed.py: the cut-offs only need per-reference
  * SUMS of cov / uniq_cov (additive) and per-reference counts of NON-ZERO bins (popcount of the OR of every rank's
  * "bin != 0" bitmap).  slimm_coverage_summary() builds [sums | 16 scalars | cov bits | uniq_cov bits] for this rank in
@@ -124,6 +126,16 @@ int slimm_prepare_summary(slimm_ctx* ctx, int on);
  * slimm_finish_coverage().  cov / uniq_cov then stay per-rank partial sums (slimm_get_bins returns this rank's share). */
 int slimm_coverage_summary(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
 int slimm_finish_coverage_merged(slimm_ctx* ctx, const void* d_gathered, uint32_t n_ranks);
+/* All-to-all form of the same exchange for many ranks (each rank receives 1/n of every other rank's bitmaps instead of
+ * all of them).  With slimm_prepare_summary(ctx, n) in effect the buffer of slimm_coverage_summary is
+ * [4 n_refs + 16 words | n chunks of equal size]; send chunk j to rank j (ncclAllToAll / all_to_all_single) and hand the
+ * n received chunks to slimm_merge_summary_slices: it ORs them, counts the non-zero bins of this rank's slice per
+ * reference and returns a device vector of 4 n_refs + 16 words [own sums, partial non-zero counts | own scalars] that
+ * the ranks sum in place (all-reduce, int32).  slimm_finish_coverage_reduced then takes the place of
+ * slimm_finish_coverage. */
+int slimm_merge_summary_slices(slimm_ctx* ctx, const void* d_received, uint32_t n_ranks, uint32_t my_rank, void** d_vec,
+                               uint64_t* n_words);
+int slimm_finish_coverage_reduced(slimm_ctx* ctx);
 
 /* End of phase A: per-reference reads_count / uniq_reads_count / non-zero bin counts
  * (reference_contig.hpp:84-91,148-155) from the (reduced) bins, and the float statistics of src/slimm.hpp:259-302.

@@ -76,9 +76,11 @@ SYMBOLS = [
     ("slimm_set_records_device", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_analyze_alignments", C.c_int, [_P]),
     ("slimm_coverage_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
-    ("slimm_prepare_summary", C.c_int, [_P, C.c_int]),
+    ("slimm_prepare_summary", C.c_int, [_P, C.c_uint32]),
     ("slimm_coverage_summary", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("slimm_finish_coverage_merged", C.c_int, [_P, _P, C.c_uint32]),
+    ("slimm_merge_summary_slices", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    ("slimm_finish_coverage_reduced", C.c_int, [_P]),
     ("slimm_finish_coverage", C.c_int, [_P]),
     ("slimm_set_coverage_columns", C.c_int, [_P, _P, _P, _P, _P, C.c_uint32, C.c_uint32]),
     ("slimm_filter_alignments", C.c_int, [_P]),

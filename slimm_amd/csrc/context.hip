@@ -121,8 +121,24 @@ struct slimm_ctx {
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
     uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
-    bool summary_bits = false;  // k_tile_hist also writes the 'bin != 0' bitmaps of the coverage summary (multi-GPU)
-    bool summary_has_bits = false;
+    // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
+    // 1: bitmaps written by k_tile_hist as [cov | uniq_cov], n > 1: in n slices of tiles for the all-to-all exchange
+    uint32_t summary_slices = 0;
+    bool summary_has_bits = false;   // the bitmaps of this analysis are in `summary` already
+    uint32_t summary_layout = 0xffffffffu;  // n_slices the buffer was last zeroed for
+    DevBuf<uint32_t> d_sum_vec;      // all-to-all form: [4R | 16] additive vector, all-reduced in place
+    uint32_t slice_tiles() const { return summary_slices > 1 ? (ntiles + summary_slices - 1) / summary_slices : ntiles; }
+    uint64_t slice_words() const { return static_cast<uint64_t>(slice_tiles()) * (kTileBins / 32); }  // per array
+    uint64_t summary_words() const { return 4ull * R + 16 + 2ull * std::max<uint32_t>(summary_slices, 1u) * slice_words(); }
+    BitsLayout bits_layout() {
+        BitsLayout b;
+        if (summary_has_bits) {
+            b.base = reinterpret_cast<uint64_t*>(summary.p + 4ull * R + 16);
+            b.tps = slice_tiles();
+            b.slice_w64 = slice_words() / 2;
+        }
+        return b;
+    }
     bool statsA_final = false;  // k_pack has added the non-zero counts of the split tiles to the fused statistics
     bool bins_exposed = false;  // the caller holds the coverage buffer (may have merged other ranks' bins into it)
     bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
@@ -657,18 +673,17 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_TILE_HIST);
-            uint64_t* bits_a = nullptr;
-            uint64_t* bits_b = nullptr;
             c->summary_has_bits = false;
-            if (c->summary_bits) {
-                const uint64_t bits_words = c->Bp / 32;
-                HIP_TRY(c, c->summary.ensure(4ull * c->R + 16 + 2 * bits_words));
-                bits_a = reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16);
-                bits_b = reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16 + bits_words);
+            if (c->summary_slices) {
+                const bool fresh = c->summary.cap < c->summary_words() || c->summary_layout != c->summary_slices;
+                HIP_TRY(c, c->summary.ensure(c->summary_words()));
+                if (fresh)  // the padding behind the last tile of the last slice is never written: zero it once per layout
+                    HIP_TRY(c, hipMemsetAsync(c->summary.p, 0, c->summary_words() * 4, st));
+                c->summary_layout = c->summary_slices;
                 c->summary_has_bits = true;
             }
             launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
-                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, bits_a, bits_b);
+                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout());
         }
     } else {
         KernelTimer t(c, K_HIST);
@@ -729,10 +744,8 @@ int slimm_finish_coverage(slimm_ctx* c) {
     pk.n[1] = 16;
     if (c->use_tiles && !c->bins_exposed) {  // k_tile_hist left the per-reference statistics in place
         KernelTimer t(c, K_PACK);
-        uint64_t* bits_a = c->summary_has_bits ? reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16) : nullptr;
         launch_pack(c->stream, c->ref_stats.p + 4ull * c->R, pk, c->split_tiles.p, c->counters.p, c->cov(), c->ucov(),
-                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p, bits_a,
-                    bits_a ? bits_a + c->Bp / 64 : nullptr);
+                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p, c->bits_layout());
         c->statsA_final = true;
     } else {
         KernelTimer t(c, K_REF_STATS);
@@ -741,9 +754,10 @@ int slimm_finish_coverage(slimm_ctx* c) {
     return finish_from_device_stats(c);
 }
 
-int slimm_prepare_summary(slimm_ctx* c, int on) {
+int slimm_prepare_summary(slimm_ctx* c, uint32_t n_slices) {
     if (!c) return SLIMM_E_INVALID;
-    c->summary_bits = on != 0 && c->device >= 0 && c->use_tiles;
+    if (n_slices > 1 && !c->use_tiles) return fail(c, SLIMM_E_INVALID, "sliced summaries need the tile histogram path");
+    c->summary_slices = (c->device >= 0 && c->use_tiles) ? n_slices : 0;
     return SLIMM_OK;
 }
 
@@ -751,8 +765,10 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
     (void)hipSetDevice(c->device);
+    if (c->summary_slices > 1 && (!c->summary_has_bits || c->bins_exposed))
+        return fail(c, SLIMM_E_INVALID, "sliced summary: call slimm_prepare_summary before slimm_analyze_alignments");
     const uint64_t bits_words = c->Bp / 32;
-    const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
+    const uint64_t W = c->summary_words();
     HIP_TRY(c, c->summary.ensure(W));
     hipStream_t st = c->stream;
     bool have_bits = false;  // k_tile_hist / k_pack already wrote the bitmaps into the summary buffer
@@ -764,9 +780,8 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
         pk.src[1] = c->tail();
         pk.n[1] = 16;
         if (!c->statsA_final) {  // first finish the statistics (and bitmaps) of the split tiles in place, then copy
-            uint64_t* bits_a = c->summary_has_bits ? reinterpret_cast<uint64_t*>(c->summary.p + 4ull * c->R + 16) : nullptr;
             launch_pack(st, c->summary.p, PackArgs(), c->split_tiles.p, c->counters.p, c->cov(), c->ucov(), c->d_bin_off.p,
-                        c->R, c->d_tile_ref0.p, c->ref_stats.p, bits_a, bits_a ? bits_a + bits_words / 2 : nullptr);
+                        c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout());
             c->statsA_final = true;
         }
         launch_pack(st, c->summary.p, pk);
@@ -788,10 +803,49 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     return SLIMM_OK;
 }
 
+int slimm_merge_summary_slices(slimm_ctx* c, const void* d_recv, uint32_t n_ranks, uint32_t my_rank, void** d_vec,
+                               uint64_t* n_words) {
+    if (!c || !d_recv || !d_vec || !n_words) return SLIMM_E_INVALID;
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    if (n_ranks < 1 || n_ranks != std::max<uint32_t>(c->summary_slices, 1u) || my_rank >= n_ranks || !c->summary_has_bits)
+        return fail(c, SLIMM_E_INVALID, "slimm_merge_summary_slices: slimm_prepare_summary(ctx, n_ranks) was not in effect");
+    (void)hipSetDevice(c->device);
+    const uint64_t W = 4ull * c->R + 16;
+    HIP_TRY(c, c->d_sum_vec.ensure(W));
+    const uint64_t lo_tile = static_cast<uint64_t>(my_rank) * c->slice_tiles();
+    const uint64_t hi_tile = std::min<uint64_t>(lo_tile + c->slice_tiles(), c->ntiles);
+    const uint32_t lo_bin = static_cast<uint32_t>(std::min<uint64_t>(lo_tile, c->ntiles) * kTileBins);
+    const uint32_t hi_bin = static_cast<uint32_t>(std::max<uint64_t>(hi_tile, std::min<uint64_t>(lo_tile, c->ntiles)) * kTileBins);
+    // own sums and scalars come from the summary buffer (slimm_coverage_summary filled it)
+    launch_merge_slices(c->stream, static_cast<const uint32_t*>(d_recv), n_ranks, c->slice_words(), lo_bin, hi_bin,
+                        c->d_bin_off.p, c->R, c->summary.p, c->summary.p + 4ull * c->R, c->d_sum_vec.p);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *d_vec = c->d_sum_vec.p;
+    *n_words = W;
+    return SLIMM_OK;
+}
+
+int slimm_finish_coverage_reduced(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->analyzed || !c->d_sum_vec.p) return fail(c, SLIMM_E_INVALID, "call slimm_merge_summary_slices first");
+    (void)hipSetDevice(c->device);
+    // packed block A = [4R merged statistics | 32 counters of this rank | 16 merged scalars]
+    PackArgs pk;
+    pk.src[0] = c->d_sum_vec.p;
+    pk.n[0] = 4 * c->R;
+    pk.src[1] = c->counters.p;
+    pk.n[1] = 32;
+    pk.src[2] = c->d_sum_vec.p + 4ull * c->R;
+    pk.n[2] = 16;
+    launch_pack(c->stream, c->ref_stats.p, pk);
+    return finish_from_device_stats(c);
+}
+
 int slimm_finish_coverage_merged(slimm_ctx* c, const void* d_gathered, uint32_t n_ranks) {
     if (!c || !d_gathered || n_ranks == 0) return SLIMM_E_INVALID;
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
     (void)hipSetDevice(c->device);
+    if (c->summary_slices > 1) return fail(c, SLIMM_E_INVALID, "sliced summaries are merged with slimm_merge_summary_slices");
     const uint64_t bits_words = c->Bp / 32;
     const uint64_t W = 4ull * c->R + 16 + 2 * bits_words;
     // merged statistics, this rank's counters and the merged scalars land in the packed block A

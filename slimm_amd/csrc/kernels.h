@@ -98,6 +98,12 @@ void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_
                          uint32_t taxon_base, uint32_t n_refs);
 // multi-GPU: [R uniq_reads_count2 | T LCA counts | 2R level marks in 8-bit fields | 1 pair count] from result block B
 void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out);
+// multi-GPU, all-to-all form: this rank received every rank's bitmaps of ITS slice ([n_ranks][2][slice_words] 32-bit
+// words, bins lo_bin .. hi_bin); vec = [4R: own sums in slots 0 / 2, popcount of the OR-ed bitmaps inside the slice in
+// slots 1 / 3 | 16 own scalars]: additive over the ranks, so one all-reduce(SUM) completes it
+void launch_merge_slices(hipStream_t st, const uint32_t* recv, uint32_t n_ranks, uint64_t slice_words, uint32_t lo_bin,
+                         uint32_t hi_bin, const uint32_t* bin_off, uint32_t n_refs, const uint32_t* own_stats,
+                         const uint32_t* own_tail, uint32_t* vec);
 // multi-GPU coverage summary: "bin != 0" bitmaps and their merge (sums over ranks, popcount of the OR per reference)
 void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits);
 void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t rank_stride, uint32_t n_ranks,
@@ -133,19 +139,27 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
                          uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
                          uint32_t* cov, uint32_t* ucov, bool two_level, const uint32_t* rep_base, uint32_t reps,
                          uint32_t rep_stride);
+// where k_tile_hist / k_pack put the 'bin != 0' bitmaps of the multi-GPU coverage summary: the tiles are cut into slices
+// of `tps` tiles (one slice per rank for the all-to-all exchange, a single slice otherwise) and slice j holds
+// [array 0 bits | array 1 bits] of its tiles back to back
+struct BitsLayout {
+    uint64_t* base = nullptr;   // nullptr: no bitmaps
+    uint32_t tps = 1;           // tiles per slice
+    uint64_t slice_w64 = 0;     // 64-bit words of one array in one slice = tps * 128
+};
 // stats != nullptr: k_tile_hist also accumulates the per-reference statistics {sum a, non-zero a, sum b, non-zero b}
 // (stats[ref * 4 ..], zeroed by the caller) of the finished arrays; tile_ref0[tile] = first reference overlapping the
 // tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
-                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, uint64_t* bits_a = nullptr,
-                      uint64_t* bits_b = nullptr);  // bits: also the 'bin != 0' bitmaps of the two arrays
+                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,
+                      const BitsLayout& bits = BitsLayout());  // bits: also the 'bin != 0' bitmaps of the two arrays
 // small arrays copied back to back to dst; with stats != nullptr also the non-zero bin counts of the tiles k_tile_hist
 // accumulated in pieces (split_tiles[0 .. counters[CNT_SPLIT])), read back from the finished arrays a / b
 void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint32_t* split_tiles = nullptr,
                  const uint32_t* counters = nullptr, const uint32_t* a = nullptr, const uint32_t* b = nullptr,
                  const uint32_t* bin_off = nullptr, uint32_t n_refs = 0, const uint32_t* tile_ref0 = nullptr,
-                 uint32_t* stats = nullptr, uint64_t* bits_a = nullptr, uint64_t* bits_b = nullptr);
+                 uint32_t* stats = nullptr, const BitsLayout& bits = BitsLayout());
 
 // Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and

@@ -679,6 +679,50 @@ __global__ __launch_bounds__(256) void k_merge_summary(const uint32_t* __restric
     }
 }
 
+// one wave per reference; see launch_merge_slices in kernels.h
+__global__ __launch_bounds__(256) void k_merge_slices(const uint32_t* __restrict__ recv, uint32_t n_ranks,
+                                                      uint64_t slice_words, uint32_t lo_bin, uint32_t hi_bin,
+                                                      const uint32_t* __restrict__ bin_off, uint32_t n_refs,
+                                                      const uint32_t* __restrict__ own_stats,
+                                                      const uint32_t* __restrict__ own_tail, uint32_t* __restrict__ vec) {
+    const uint32_t ref = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (ref == 0 && lane < 16) vec[4ull * n_refs + lane] = own_tail[lane];
+    if (ref >= n_refs) return;
+    const uint32_t s = max(bin_off[ref], lo_bin), e = min(bin_off[ref + 1], hi_bin);
+    uint32_t nz_a = 0, nz_b = 0;
+    if (e > s) {
+        const uint32_t w0 = s >> 5, w1 = (e - 1) >> 5, wl = lo_bin >> 5;  // lo_bin is a multiple of the tile size
+        for (uint32_t w = w0 + lane; w <= w1; w += 64) {
+            uint32_t mask = 0xffffffffu;
+            if (w == w0) mask &= 0xffffffffu << (s & 31u);
+            if (w == w1) mask &= 0xffffffffu >> (31u - ((e - 1) & 31u));
+            uint32_t a = 0, b = 0;
+            for (uint32_t k = 0; k < n_ranks; ++k) {
+                const uint32_t* chunk = recv + static_cast<uint64_t>(k) * 2 * slice_words;
+                a |= chunk[w - wl];
+                b |= chunk[slice_words + (w - wl)];
+            }
+            nz_a += __popc(a & mask);
+            nz_b += __popc(b & mask);
+        }
+    }
+    nz_a = wave_sum(nz_a);
+    nz_b = wave_sum(nz_b);
+    if (lane == 0)
+        *reinterpret_cast<uint4*>(vec + 4ull * ref) =
+            make_uint4(own_stats[4ull * ref + 0], nz_a, own_stats[4ull * ref + 2], nz_b);
+}
+
+void launch_merge_slices(hipStream_t st, const uint32_t* recv, uint32_t n_ranks, uint64_t slice_words, uint32_t lo_bin,
+                         uint32_t hi_bin, const uint32_t* bin_off, uint32_t n_refs, const uint32_t* own_stats,
+                         const uint32_t* own_tail, uint32_t* vec) {
+    const uint32_t blocks = (n_refs + 3) / 4;
+    if (blocks)
+        hipLaunchKernelGGL(k_merge_slices, dim3(blocks), dim3(256), 0, st, recv, n_ranks, slice_words, lo_bin, hi_bin, bin_off,
+                           n_refs, own_stats, own_tail, vec);
+}
+
 void launch_nonzero_bits(hipStream_t st, const uint32_t* bins, uint64_t n_bins, uint32_t* bits) {
     const uint64_t n64 = n_bins / 64;  // n_bins is a multiple of the tile size
     uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((n64 + 3) / 4, 4096));

@@ -486,14 +486,18 @@ __global__ __launch_bounds__(kTBlock) void k_part_tile(const uint32_t* __restric
 // uniq_reads_count are): every wave owns one eighth of the tile, walks the references overlapping it (their offsets
 // are staged in LDS) and adds its partial results to stats[ref * 4 + {0: sum a, 1: non-zero a, 2: sum b, 3: non-zero b}].
 // A few dozen atomics per tile replace a kernel that streamed both arrays again (31 + 22 us at config 2).
-// 'bin != 0' bitmap words of the tile held in LDS (multi-GPU coverage summary): one ballot per 64 bins
-__device__ __forceinline__ void tile_nonzero_bits(const uint32_t* s_a, uint32_t tile, uint64_t* __restrict__ bits) {
+// 'bin != 0' bitmap words of the tile held in LDS (multi-GPU coverage summary): one ballot per 64 bins.  The bitmap
+// region is laid out for the exchange: the tiles are cut into slices of `tps` tiles (one slice per rank for the
+// all-to-all form, a single slice otherwise) and slice j holds [array 0 bits | array 1 bits] of its tiles.
+__device__ __forceinline__ void tile_nonzero_bits(const uint32_t* s_a, uint32_t tile, const BitsLayout& bl, uint32_t array) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t* dst = bl.base + (static_cast<uint64_t>(tile / bl.tps) * 2 + array) * bl.slice_w64 +
+                    static_cast<uint64_t>(tile % bl.tps) * (kTileBins / 64);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t i = wave * 1024 + j * 64;
         const uint64_t m = __ballot(s_a[i + lane] != 0u);
-        if (lane == 0) bits[(static_cast<size_t>(tile) * kTileBins + i) >> 6] = m;
+        if (lane == 0) dst[i >> 6] = m;
     }
 }
 
@@ -565,8 +569,7 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
                                                    const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov, const uint32_t* __restrict__ bin_off,
                                                    uint32_t n_refs, const uint32_t* __restrict__ tile_ref0,
-                                                   uint32_t* __restrict__ stats, uint64_t* __restrict__ bits_a,
-                                                   uint64_t* __restrict__ bits_b) {
+                                                   uint32_t* __restrict__ stats, const BitsLayout bits) {
     __shared__ uint32_t s_cov[kTileBins];
     __shared__ uint32_t s_ucov[kTwo ? kTileBins : 4];
     __shared__ uint32_t s_off[kStatRefs + 1];  // bin offsets of the references overlapping this tile (and one more)
@@ -617,9 +620,9 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
             if (kTwo) ou[i] = su[i];
         }
         if (stats) tile_ref_stats<kTwo>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
-        if (bits_a) {
-            tile_nonzero_bits(s_cov, tile, bits_a);
-            if (kTwo) tile_nonzero_bits(s_ucov, tile, bits_b);
+        if (bits.base) {
+            tile_nonzero_bits(s_cov, tile, bits, 0);
+            if (kTwo) tile_nonzero_bits(s_ucov, tile, bits, 1);
         }
         return;
     }
@@ -644,8 +647,7 @@ __global__ __launch_bounds__(512) void k_pack(uint32_t* __restrict__ dst, const 
                                               const uint32_t* __restrict__ counters, const uint32_t* __restrict__ a,
                                               const uint32_t* __restrict__ b, const uint32_t* __restrict__ bin_off,
                                               uint32_t n_refs, const uint32_t* __restrict__ tile_ref0,
-                                              uint32_t* __restrict__ stats, uint64_t* __restrict__ bits_a,
-                                              uint64_t* __restrict__ bits_b) {
+                                              uint32_t* __restrict__ stats, const BitsLayout bits) {
     __shared__ uint32_t s_a[kTileBins];
     __shared__ uint32_t s_b[kTwo ? kTileBins : 4];
     __shared__ uint32_t s_off[kStatRefs + 1];
@@ -677,23 +679,23 @@ __global__ __launch_bounds__(512) void k_pack(uint32_t* __restrict__ dst, const 
         }
         __syncthreads();
         tile_ref_stats<kTwo>(s_a, s_b, tile, s_off, r0, bin_off, n_refs, stats, false, true);
-        if (bits_a) {
-            tile_nonzero_bits(s_a, tile, bits_a);
-            if (kTwo) tile_nonzero_bits(s_b, tile, bits_b);
+        if (bits.base) {
+            tile_nonzero_bits(s_a, tile, bits, 0);
+            if (kTwo) tile_nonzero_bits(s_b, tile, bits, 1);
         }
     }
 }
 
 void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint32_t* split_tiles, const uint32_t* counters,
                  const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs, const uint32_t* tile_ref0,
-                 uint32_t* stats, uint64_t* bits_a, uint64_t* bits_b) {
+                 uint32_t* stats, const BitsLayout& bits) {
     const uint32_t blocks = 256;
     if (b)
         hipLaunchKernelGGL(k_pack<true>, dim3(blocks), dim3(512), 0, st, dst, pack, split_tiles, counters, a, b, bin_off,
-                           n_refs, tile_ref0, stats, bits_a, bits_b);
+                           n_refs, tile_ref0, stats, bits);
     else
         hipLaunchKernelGGL(k_pack<false>, dim3(blocks), dim3(512), 0, st, dst, pack, split_tiles, counters, a, a, bin_off,
-                           n_refs, tile_ref0, stats, bits_a, bits_b);
+                           n_refs, tile_ref0, stats, bits);
 }
 
 int tile_hist_setup(uint32_t ntiles) {
@@ -761,14 +763,14 @@ uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n
 // stats != nullptr: also accumulate the per-reference statistics (zeroed by the caller) of the finished arrays
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
-                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, uint64_t* bits_a, uint64_t* bits_b) {
+                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, const BitsLayout& bits) {
     const uint32_t grid = tile_items_upper(ntiles, n_upper);
     if (ucov)
         hipLaunchKernelGGL(k_tile_hist<true>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
-                           n_refs, tile_ref0, stats, bits_a, bits_b);
+                           n_refs, tile_ref0, stats, bits);
     else
         hipLaunchKernelGGL(k_tile_hist<false>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov, bin_off,
-                           n_refs, tile_ref0, stats, bits_a, bits_b);
+                           n_refs, tile_ref0, stats, bits);
 }
 
 }  // namespace slimm

@@ -20,11 +20,23 @@ import torch
 import torch.distributed as dist
 
 
-def exchange_coverage(engine, group=None, mode: str = "summary") -> bool:
+def resolve_exchange(engine, mode: str, world: int) -> str:
+    """What "auto" means for this engine and world size; other modes pass through."""
+    if mode == "auto":
+        return "sliced" if (world > 2 and hasattr(engine, "merge_summary_slices")) else "summary"
+    return mode
+
+
+def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
     """The exchange between phase A and the cut-offs; returns engine.finish_coverage*()'s answer.
 
     mode "summary" (default): ONE all-gather of each rank's [per-reference sums | scalars | 'bin != 0' bitmaps]
         (about 1/16 of the bins buffer); every rank then sums / ORs the gathered pieces on its own GPU.
+    mode "sliced": the same information for many ranks: an all-to-all in which every rank receives only ITS slice
+        (1/world) of every other rank's bitmaps, ORs them and counts non-zero bins per reference inside the slice, then
+        ONE small all-reduce(SUM) of [per-reference sums, partial non-zero counts | scalars].  An all-gather delivers
+        (world - 1) x 5 MB to every rank at config 2, the all-to-all (world - 1) / world x 5 MB.
+    mode "auto": "summary" up to 2 ranks, "sliced" above (engines without sliced support: "summary").
     mode "bins": ONE all-reduce(SUM) over [cov | uniq_cov | scalars] in place -- needed only when the caller wants the
         global coverage arrays themselves (the reference's -co output); 16 x more bytes on the wire.
     """
@@ -39,6 +51,23 @@ def exchange_coverage(engine, group=None, mode: str = "summary") -> bool:
             if buf.is_cuda:
                 torch.cuda.synchronize(buf.device)
         return engine.finish_coverage()
+    if resolve_exchange(engine, mode, world) == "sliced":
+        mine = engine.coverage_summary_tensor()
+        head = engine.summary_head_words()
+        chunks = mine[head:]
+        received = torch.empty_like(chunks)
+        if dist.is_initialized():
+            dist.all_to_all_single(received, chunks, group=group)
+        else:
+            received.copy_(chunks)
+        if received.is_cuda:
+            torch.cuda.synchronize(received.device)
+        vec = engine.merge_summary_slices(received, world, dist.get_rank(group) if dist.is_initialized() else 0)
+        if dist.is_initialized():
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+        if vec.is_cuda:
+            torch.cuda.synchronize(vec.device)
+        return engine.finish_coverage_reduced()
     mine = engine.coverage_summary_tensor()
     gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
     if dist.is_initialized():
@@ -125,7 +154,7 @@ def merge_partials(engine, device: Optional[torch.device] = None, group=None):
 
 
 def sharded_profile(engine, device: Optional[torch.device] = None, path: Optional[str] = None, group=None,
-                    phase_times: Optional[dict] = None, exchange: str = "summary"):
+                    phase_times: Optional[dict] = None, exchange: str = "auto"):
     """slimm::get_profiles() (reference src/slimm.hpp:395-496) over a record stream sharded across ranks.
 
     `engine` already holds this rank's records.  Returns the profile text (identical on every rank) or None when no
@@ -141,7 +170,9 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
     multi = (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "force_exchange", False)
     t = time.perf_counter()
     if hasattr(engine, "prepare_summary"):
-        engine.prepare_summary(multi and exchange == "summary")
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        how = resolve_exchange(engine, exchange, world) if multi else "none"
+        engine.prepare_summary(world if how == "sliced" else (1 if how == "summary" else 0))
     engine.analyze_alignments()
     t = lap("analyze_alignments(launch)", t)
     have_hits = exchange_coverage(engine, group, exchange)

@@ -114,9 +114,29 @@ class Slimm:
 
         return torch.as_tensor(self.coverage_buffer(), device=f"cuda:{self.device}")
 
-    def prepare_summary(self, on: bool = True):
-        """Multi-GPU: have phase A write the coverage-summary bitmaps as a by-product (call before analyze_alignments)."""
-        self._check(self.L.slimm_prepare_summary(self.ctx, int(on)))
+    def prepare_summary(self, n_slices: int = 1):
+        """Multi-GPU: have phase A write the coverage-summary bitmaps as a by-product (call before analyze_alignments).
+        0 = off, 1 = all-gather layout, n > 1 = n slices for the all-to-all exchange."""
+        self._check(self.L.slimm_prepare_summary(self.ctx, int(n_slices)))
+
+    def summary_head_words(self) -> int:
+        """Words of a coverage summary before its bitmap chunks."""
+        return 4 * self.n_refs + 16
+
+    def merge_summary_slices(self, received, n_ranks: int, rank: int):
+        """`received`: int32 device tensor with every rank's bitmap chunk for this rank's slice (all_to_all output).
+        Returns the additive [4R | 16] vector (aliasing library memory) to all_reduce(SUM) in place."""
+        import torch
+
+        self._slices_keepalive = received
+        ptr = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.L.slimm_merge_summary_slices(self.ctx, C.c_void_p(received.data_ptr()), int(n_ranks), int(rank),
+                                                      C.byref(ptr), C.byref(n)))
+        return torch.as_tensor(DeviceArray(ptr.value, n.value, "<i4"), device=f"cuda:{self.device}")
+
+    def finish_coverage_reduced(self) -> bool:
+        return self._check(self.L.slimm_finish_coverage_reduced(self.ctx)) != capi.E_NO_HITS
 
     def coverage_summary_tensor(self):
         """[per-ref sums | scalars | 'bin != 0' bitmaps] of this rank as an int32 tensor aliasing library memory."""

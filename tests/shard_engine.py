@@ -35,6 +35,8 @@ class OracleShardEngine:
         return self.buf
 
     def coverage_summary_tensor(self):
+        if getattr(self, "n_slices", 1) > 1:
+            return self._sliced_summary()
         b = self.buf.numpy().view(np.uint32)
         cov, ucov, tail = b[:self.B], b[self.B:2 * self.B], b[2 * self.B:]
         off = np.concatenate([[0], np.cumsum(self.nbins)])[:-1]
@@ -45,6 +47,62 @@ class OracleShardEngine:
         self._nbits_bytes = (self.B + 7) // 8
         words = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)]).view(np.uint32)
         return torch.from_numpy(np.concatenate([sums, tail[:16], words]).view(np.int32).copy())
+
+    # ---- all-to-all ("sliced") form: the bins are cut into n equal slices of whole 32-bit bitmap words ----
+    def prepare_summary(self, n_slices=1):
+        self.n_slices = int(n_slices)
+
+    def summary_head_words(self):
+        return 2 * self.nbins.shape[0] + 16
+
+    def _slice_words(self):
+        words = (self.B + 31) // 32
+        return (words + self.n_slices - 1) // self.n_slices
+
+    def _sliced_summary(self):
+        b = self.buf.numpy().view(np.uint32)
+        cov, ucov, tail = b[:self.B], b[self.B:2 * self.B], b[2 * self.B:]
+        off = np.concatenate([[0], np.cumsum(self.nbins)])[:-1]
+        sums = np.stack([np.add.reduceat(cov.astype(np.uint64), off), np.add.reduceat(ucov.astype(np.uint64), off)],
+                        axis=1).astype(np.uint32).reshape(-1)
+        sw = self._slice_words()
+        total_bits = sw * self.n_slices * 32
+
+        def words(x):
+            bits = np.zeros(total_bits, dtype=np.uint8)
+            bits[:self.B] = x != 0
+            return np.packbits(bits, bitorder="little").view(np.uint32).reshape(self.n_slices, sw)
+
+        chunks = np.concatenate([words(cov), words(ucov)], axis=1).reshape(-1)   # slice j: [cov words | ucov words]
+        self._own_head = np.concatenate([sums, tail[:16]])
+        return torch.from_numpy(np.concatenate([self._own_head, chunks]).view(np.int32).copy())
+
+    def merge_summary_slices(self, received, n_ranks, rank):
+        sw = self._slice_words()
+        g = received.numpy().view(np.uint32).reshape(n_ranks, 2, sw)
+        ored = np.bitwise_or.reduce(g, axis=0)
+        R = self.nbins.shape[0]
+        lo = rank * sw * 32
+        off = np.concatenate([[0], np.cumsum(self.nbins)])
+        vec = np.zeros(4 * R + 16, dtype=np.uint32)
+        vec[0:4 * R:4] = self._own_head[0:2 * R:2]
+        vec[2:4 * R:4] = self._own_head[1:2 * R:2]
+        vec[4 * R:] = self._own_head[2 * R:]
+        for a in range(2):
+            bits = np.unpackbits(ored[a].view(np.uint8), bitorder="little")
+            full = np.zeros(max(self.B, lo + bits.shape[0]), dtype=np.uint8)
+            full[lo:lo + bits.shape[0]] = bits                     # this rank's slice only, at its place
+            nz = np.add.reduceat(full[:self.B].astype(np.uint64), off[:-1]).astype(np.uint32)
+            nz[self.nbins == 0] = 0
+            vec[1 + 2 * a:4 * R:4] = nz
+        self._vec = torch.from_numpy(vec.view(np.int32).copy())
+        return self._vec
+
+    def finish_coverage_reduced(self):
+        v = self._vec.numpy().view(np.uint32)
+        R = self.nbins.shape[0]
+        return self.host.set_coverage_columns(v[0:4 * R:4], v[2:4 * R:4], v[1:4 * R:4], v[3:4 * R:4],
+                                              int(v[4 * R]), int(v[4 * R + 1]))
 
     def finish_coverage_merged(self, gathered, n_ranks):
         g = gathered.numpy().view(np.uint32).reshape(n_ranks, -1)

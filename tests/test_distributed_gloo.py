@@ -66,8 +66,16 @@ def _worker(rank, world, port, case, tmp, exchange="summary"):
 
 
 @pytest.mark.parametrize("case,exchange", [("config1", "summary"), ("config2", "summary"), ("cross", "summary"),
-                                           ("config1", "bins")])
+                                           ("config1", "bins"), ("config2", "sliced")])
 def test_two_ranks_equal_single_process(case, exchange):
-    port = 29500 + (os.getpid() % 2000) + {"config1": 0, "config2": 1, "cross": 2}[case] + (3 if exchange == "bins" else 0)
+    port = (29500 + (os.getpid() % 2000) + {"config1": 0, "config2": 1, "cross": 2}[case]
+            + {"summary": 0, "bins": 3, "sliced": 4}[exchange])
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, port, case, tmp, exchange), nprocs=2, join=True)
+
+
+def test_three_ranks_auto_exchange_is_sliced():
+    """world_size 3: "auto" picks the all-to-all form; slices of unequal fill (the bins do not divide by 3)."""
+    port = 29500 + (os.getpid() % 2000) + 9
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(3, port, "config2", tmp, "auto"), nprocs=3, join=True)

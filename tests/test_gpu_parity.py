@@ -338,11 +338,52 @@ def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs):
         assert_matches_oracle(e, o, bins=False)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_shards_on_one_gpu_through_the_sliced_exchange(world):
+    """`world` contexts stand in for ranks: the bitmap chunks are routed like an all-to-all would, the additive vectors
+    summed like an all-reduce (the bin tiles do not divide evenly by 3: the last slice is partly padding)."""
+    import torch
+    w = make_workload(CONFIGS["config2"], seed=27, n_records=300_000)
+    o = run_workload(w, use_qnames=False)
+    owner = (w.records.read_key % np.uint64(world)).astype(np.int64)
+    engines, summaries = [], []
+    for r in range(world):
+        s = Slimm.for_workload(w, device=0)
+        s.prepare_summary(world)
+        s.push_records(w.records.take(np.nonzero(owner == r)[0]))
+        s.analyze_alignments()
+        engines.append(s)
+        summaries.append(s.coverage_summary_tensor().clone())
+    head = engines[0].summary_head_words()
+    chunk = (summaries[0].numel() - head) // world
+    vecs = []
+    for j, e in enumerate(engines):
+        received = torch.cat([summaries[i][head + j * chunk:head + (j + 1) * chunk] for i in range(world)])
+        vecs.append(e.merge_summary_slices(received, world, j))
+    total = torch.stack([v.clone() for v in vecs]).sum(dim=0).to(torch.int32)
+    for v in vecs:
+        v.copy_(total)
+    torch.cuda.synchronize()
+    parts = []
+    for e in engines:
+        assert e.finish_coverage_reduced()
+        e.filter_alignments()
+        parts.append(e.get_partials())
+    rc = engines[0].ref_columns()
+    assert np.array_equal(rc["nz_cov"], o.nz_cov) and np.array_equal(rc["reads_count"], o.reads_count)
+    assert np.array_equal(rc["nz_uniq_cov"], o.nz_uniq_cov) and np.array_equal(rc["uniq_reads_count"], o.uniq_reads_count)
+    marks = np.bitwise_or.reduce([p["level_marks"] for p in parts])
+    pairs = np.unique(np.concatenate([p["pairs"] for p in parts]))
+    engines[0].set_partials(sum(p["uniq_reads_count2"] for p in parts), sum(p["lca_count"] for p in parts), marks, pairs)
+    engines[0].get_reads_lca_count()
+    assert_matches_oracle(engines[0], o, bins=False)
+
+
 def test_single_rank_through_the_exchange_code_path():
     from slimm_amd.distributed import sharded_profile
     w = make_workload(CONFIGS["config1"], seed=19)
     o = run_workload(w)
-    for mode in ("summary", "bins"):
+    for mode in ("summary", "sliced", "bins"):
         s = Slimm.for_workload(w, device=0)
         s.force_exchange = True
         s.push_records(w.records)

@@ -663,7 +663,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_TILE_SCAN);
             launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                             c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride);
+                             c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
+                             c->two_level);
         }
         {
             KernelTimer t(c, K_TILE_SCATTER);
@@ -942,7 +943,8 @@ int slimm_filter_alignments(slimm_ctx* c) {
             {
                 KernelTimer t(c, K_TILE_SCAN2);
                 launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride);
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
+                             c->two_level);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);

@@ -131,7 +131,7 @@ uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper);
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride);
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level);
 // bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,

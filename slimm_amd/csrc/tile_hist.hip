@@ -101,22 +101,25 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
                                                     uint4* __restrict__ items, uint32_t* __restrict__ counters,
                                                     uint4* __restrict__ items2, uint32_t* __restrict__ sup_cursor,
                                                     uint32_t* __restrict__ split_tiles, uint32_t reps,
-                                                    uint32_t rep_stride) {
+                                                    uint32_t rep_stride, int two_level) {
     __shared__ uint2 s_part[1024];
     __shared__ uint32_t s_nsplit;
     __shared__ uint32_t s_cnt[4096];  // (one-level bucketing: <= 4096 tiles) a tile's total over the copies, then its base
     if (threadIdx.x == 0) s_nsplit = 0;
     const uint32_t tid = threadIdx.x;
     const bool staged = ntiles <= 4096;  // otherwise reps == 1 (two-level bucketing) and the counts are read in place
+    uint32_t keep[4][kTileReps];  // (staged, reps == kTileReps) the copies of this thread's up to 4 tiles, for stage 3
     if (staged) {
-        for (uint32_t i = tid; i < ntiles; i += 1024) {  // coalesced, the copies' loads independent of each other
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // coalesced, the copies' loads independent of each other
+            const uint32_t i = tid + q * 1024;
+            if (i >= ntiles) break;
             uint32_t c = 0;
             if (reps == kTileReps) {
-                uint32_t v[kTileReps];
 #pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) keep[q][rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
 #pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) c += v[rep];
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) c += keep[q][rep];
             } else {
                 for (uint32_t rep = 0; rep < reps; ++rep) c += tile_count[static_cast<size_t>(rep) * rep_stride + i];
             }
@@ -164,18 +167,18 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
     }
     __syncthreads();
     if (staged) {  // the copies of a tile's count become the start of every copy's stretch inside the tile's bucket
-        for (uint32_t i = tid; i < ntiles; i += 1024) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t i = tid + q * 1024;
+            if (i >= ntiles) break;
             uint32_t at = s_cnt[i];
             if (reps == kTileReps) {
-                uint32_t v[kTileReps];
-#pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
 #pragma unroll
                 for (uint32_t rep = 0; rep < kTileReps; ++rep) {
                     const size_t k = static_cast<size_t>(rep) * rep_stride + i;
                     tile_count[k] = at;
                     tile_cursor[k] = 0;
-                    at += v[rep];
+                    at += keep[q][rep];
                 }
             } else {
                 for (uint32_t rep = 0; rep < reps; ++rep) {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
     __threadfence_block();
     __syncthreads();  // tile_base is complete (same workgroup, same CU)
     // work items of k_part_tile: <= kPartSub entries of one super tile each (their order does not matter)
-    const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
+    const uint32_t nsup = two_level ? (ntiles + kSuperTiles - 1) / kSuperTiles : 0u;  // (one-level bucketing: none)
     for (uint32_t sp = tid; sp < nsup; sp += 1024) {
         sup_cursor[sp] = 0;
         const uint32_t a = tile_base[sp * kSuperTiles];
@@ -723,9 +726,9 @@ void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uin
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride) {
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters,
-                       items2, sup_cursor, split_tiles, reps, rep_stride);
+                       items2, sup_cursor, split_tiles, reps, rep_stride, two_level ? 1 : 0);
 }
 
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {

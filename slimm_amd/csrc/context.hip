@@ -713,8 +713,8 @@ int finish_from_device_stats(slimm_ctx* c) {
     hipStream_t st = c->stream;
     const size_t R4 = 4ull * c->R;
     HostTrace tr("finish_coverage");
-    HIP_TRY(c, hipMemcpyAsync(c->h_stats.p, c->ref_stats.p, (R4 + 48) * 4, hipMemcpyDeviceToHost, st));
-    tr.mark("memcpyAsync call");
+    launch_copy_out(st, c->h_stats.p, c->ref_stats.p, static_cast<uint32_t>(R4 + 48));  // pinned memory is host-mapped
+    tr.mark("copy-out launch");
     HIP_TRY(c, hipStreamSynchronize(st));
     tr.mark("stream sync (device phase A + copy)");
     const uint32_t* cnt = c->h_stats.p + R4;
@@ -889,7 +889,9 @@ int slimm_filter_alignments(slimm_ctx* c) {
                                           q[4] | (uint32_t(q[5]) << 16), q[6] | ((uint32_t(q[7]) | v) << 16));
         }
         tr.mark("rows16 build");
-        HIP_TRY(c, hipMemcpyAsync(c->d_rows16.p, c->h_rows16.p, static_cast<size_t>(R) * 16, hipMemcpyHostToDevice, st));
+        // (a kernel reading the pinned rows, like the copy-outs; measured equal to the H2D DMA here)
+        launch_copy_out(st, reinterpret_cast<uint32_t*>(c->d_rows16.p), reinterpret_cast<const uint32_t*>(c->h_rows16.p),
+                        R * 4u);
         tr.mark("rows16 H2D call");
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
@@ -978,7 +980,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
         }
         uint32_t* const hB = c->h_stats.p + c->statsA_words();
         tr.mark("phase B launches");
-        HIP_TRY(c, hipMemcpyAsync(hB, blockB, c->statsB_words() * 4, hipMemcpyDeviceToHost, st));
+        launch_copy_out(st, hB, blockB, static_cast<uint32_t>(c->statsB_words()));
         HIP_TRY(c, hipStreamSynchronize(st));
         tr.mark("stream sync (device phase B + copy)");
         const uint32_t* h_cnt = hB + 4ull * R;

@@ -47,6 +47,8 @@ struct ZeroArgs {  // arrays cleared by one k_zero launch; p64 is filled with ~0
     uint32_t n64 = 0;
 };
 void launch_zero(hipStream_t st, const ZeroArgs& z);
+// n words from device memory to host-mapped pinned memory (16-byte aligned both) by a kernel instead of the DMA engine
+void launch_copy_out(hipStream_t st, uint32_t* dst_host, const uint32_t* src, uint32_t n);
 
 struct DeviceRecords {
     const uint64_t* key = nullptr;

@@ -538,6 +538,22 @@ void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, cons
         hipLaunchKernelGGL(k_ref_stats, dim3(blocks), dim3(kBlock), 0, st, a, b, bin_off, n_refs, out, pack ? *pack : none);
 }
 
+// Result block to pinned host memory by a kernel: a hipMemcpyAsync goes through the DMA engine, whose start-up latency
+// (11 us between the last kernel and the copy, rocprofv3 trace) is longer than this whole kernel for a few hundred KB.
+__global__ __launch_bounds__(256) void k_copy_out(uint32_t* __restrict__ dst_host, const uint32_t* __restrict__ src,
+                                                  uint32_t n) {
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    const uint32_t n4 = n >> 2;
+    for (uint32_t i = gid; i < n4; i += gsz)
+        reinterpret_cast<uint4*>(dst_host)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (uint32_t i = (n4 << 2) + gid; i < n; i += gsz) dst_host[i] = src[i];
+}
+
+void launch_copy_out(hipStream_t st, uint32_t* dst_host, const uint32_t* src, uint32_t n) {
+    const uint32_t blocks = std::min<uint32_t>(64u, (n / 4 + 255u) / 256u + 1u);
+    hipLaunchKernelGGL(k_copy_out, dim3(blocks), dim3(256), 0, st, dst_host, src, n);
+}
+
 // several small arrays cleared by one launch (each hipMemsetAsync is a launch of its own)
 __global__ __launch_bounds__(256) void k_zero(const ZeroArgs z) {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;

@@ -187,6 +187,11 @@ int slimm_install_merged_partials(slimm_ctx* ctx, uint32_t* total_pairs);
 /* ---- phase C(2,3): the propagation part of slimm::get_reads_lca_count() (src/slimm.hpp:560-610). */
 int slimm_get_reads_lca_count(slimm_ctx* ctx);
 
+/* The per-file body of slimm::get_profiles() (src/slimm.hpp:447-489) on one GPU in one call:
+ * slimm_analyze_alignments, slimm_finish_coverage, slimm_filter_alignments, slimm_get_reads_lca_count and, when path is
+ * not NULL, slimm_write_abundance_file.  Returns SLIMM_E_NO_HITS (nothing written) when no record is mapped. */
+int slimm_get_profiles(slimm_ctx* ctx, const char* path);
+
 /* ---- slimm::write_abundance() (src/slimm.hpp:733-843): the final profile.  The text is identical in format to
  * the reference's <prefix>_profile.tsv; rows come in ascending taxid order (the reference's order is that of an
  * unordered_map and carries no meaning).  The buffer is owned by ctx. */

@@ -90,6 +90,7 @@ SYMBOLS = [
     ("slimm_partials_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("slimm_install_merged_partials", C.c_int, [_P, C.POINTER(C.c_uint32)]),
     ("slimm_get_reads_lca_count", C.c_int, [_P]),
+    ("slimm_get_profiles", C.c_int, [_P, C.c_char_p]),
     ("slimm_write_abundance", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64)]),
     ("slimm_write_abundance_file", C.c_int, [_P, C.c_char_p]),
     ("slimm_get_stats", C.c_int, [_P, C.POINTER(Stats)]),

@@ -1117,6 +1117,18 @@ int slimm_get_reads_lca_count(slimm_ctx* c) {
     return SLIMM_OK;
 }
 
+int slimm_get_profiles(slimm_ctx* c, const char* path) {  // src/slimm.hpp:447-489, one file on one GPU
+    int rc = slimm_analyze_alignments(c);
+    if (rc != SLIMM_OK) return rc;
+    rc = slimm_finish_coverage(c);
+    if (rc != SLIMM_OK) return rc;  // SLIMM_E_NO_HITS: "[WARNING] No mapped reads found" (:451-455), nothing written
+    rc = slimm_filter_alignments(c);
+    if (rc != SLIMM_OK) return rc;
+    rc = slimm_get_reads_lca_count(c);
+    if (rc != SLIMM_OK) return rc;
+    return path ? slimm_write_abundance_file(c, path) : SLIMM_OK;
+}
+
 int slimm_write_abundance(slimm_ctx* c, const char** text, uint64_t* len) {
     if (!c || !text || !len) return SLIMM_E_INVALID;
     if (c->no_hits) return SLIMM_E_NO_HITS;

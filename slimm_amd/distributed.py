@@ -169,6 +169,10 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
 
     multi = (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "force_exchange", False)
     t = time.perf_counter()
+    if not multi and phase_times is None and hasattr(engine, "get_profiles") and not getattr(engine, "needs_set_partials", False):
+        if hasattr(engine, "prepare_summary"):
+            engine.prepare_summary(0)
+        return engine.get_profiles(path=path)  # one rank, nothing to exchange: the library's single call
     if hasattr(engine, "prepare_summary"):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         how = resolve_exchange(engine, exchange, world) if multi else "none"

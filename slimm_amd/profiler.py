@@ -219,12 +219,9 @@ class Slimm:
         """slimm::get_profiles() minus file I/O (src/slimm.hpp:395-496). None = no mapped reads."""
         if rec is not None:
             self.push_records(rec)
-        self.analyze_alignments()
-        if not self.finish_coverage():
+        if self._check(self.L.slimm_get_profiles(self.ctx, path.encode() if path else None)) == capi.E_NO_HITS:
             return None
-        self.filter_alignments()
-        self.get_reads_lca_count()
-        return self.write_abundance(path)
+        return self.write_abundance(None)
 
     # ---- results ----
     def stats(self) -> Dict[str, float]:

@@ -403,6 +403,14 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restric
 //   row.x = lvl0 | lvl1 << 16, row.y = lvl2 | lvl3 << 16, row.z = lvl4 | lvl5 << 16, row.w = lvl6 | (valid << 15 | lvl7) << 16
 // level_taxon[level_off[lv] + idx] gives the dense taxon of a (level, index).
 // ---------------------------------------------------------------------------------------------------------
+#if defined(EXP) && EXP == 7
+__device__ unsigned long long g_prof_f[8];
+#define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define FPROF_ADD(slot, a, b) if ((threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_prof_f[slot], (b) - (a))
+#else
+#define FPROF_T(x)
+#define FPROF_ADD(slot, a, b)
+#endif
 struct LevelOffsets {
     uint32_t off[8];
 };
@@ -435,25 +443,32 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
     // still unset, thousands of lanes atomicOr the same words (a third of this kernel's time with one copy).  Every
     // workgroup therefore marks one of kMarkReps copies; k_pack ORs the copies together.
     uint32_t* __restrict__ marks = marks_all + static_cast<size_t>(blockIdx.x & (kMarkReps - 1u)) * n_refs;
+    FPROF_T(q0);
     const uint32_t s = read_off[m], e = read_off[m + 1];
     uint32_t nv = 0, first_g = 0, max_ref = 0, w_max = 0, eq = 0xffu;
     uint4 a0 = make_uint4(0, 0, 0, 0);
     constexpr int kChunk = 4;  // targets per trip (8 measured slower: more predicated loads than longer reads save)
+    uint32_t r0[kChunk], vmask0 = 0;  // the first kChunk targets (all of them for most reads) stay in registers
     for (uint32_t c = s; c < e; c += kChunk) {
         uint32_t r[kChunk], g[kChunk];
         uint4 row[kChunk];
         // the bins travel with the reference ids (same addresses, no extra dependent load at the end)
 #pragma unroll
-        for (int k = 0; k < kChunk; ++k) {
-            const bool in = c + k < e;
-            r[k] = in ? (tgt_ref[c + k] & 0x7fffffffu) : 0xffffffffu;
-            g[k] = in ? tgt_gbin[c + k] : 0u;
+        for (int k = 0; k < kChunk; ++k) {  // clamped instead of bounds-tested: the loads of a trip go out together
+            const uint32_t t = min(c + k, e - 1u);
+            r[k] = tgt_ref[t] & 0x7fffffffu;
+            g[k] = tgt_gbin[t];
         }
 #pragma unroll
-        for (int k = 0; k < kChunk; ++k) row[k] = (r[k] != 0xffffffffu) ? rows16[r[k]] : make_uint4(0, 0, 0, 0);
+        for (int k = 0; k < kChunk; ++k) row[k] = rows16[r[k]];
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
-            if (!(row[k].w >> 31)) continue;  // not a valid reference (or past the end)
+            const bool ok = (c + k < e) && (row[k].w >> 31);  // inside the read and a valid reference
+            if (c == s) {
+                r0[k] = r[k];
+                vmask0 |= ok ? (1u << k) : 0u;
+            }
+            if (!ok) continue;
             if (nv == 0) {
                 first_g = g[k];
                 a0 = row[k];
@@ -467,6 +482,7 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
             ++nv;
         }
     }
+    FPROF_T(q1);
     uint32_t sel = 0xffffffffu;  // what this read adds one to: a uniq_cov2 bin, an LCA taxon counter, or nothing
     if (nv == 1) {
         sel = first_g;
@@ -476,13 +492,24 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
         if (eq) {
             const uint32_t lv = __builtin_ctz(eq);
             taxon = level_taxon[lo.off[lv] + row16_level(a0, lv)];
-            for (uint32_t t = s; t < e; ++t) {
+            // mark words of the first chunk's references: the gathers go out together, then the (rare) atomics
+            uint32_t mk[kChunk];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) mk[k] = marks[((vmask0 >> k) & 1u) ? r0[k] : r0[0]];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                if (((vmask0 >> k) & 1u) && !((mk[k] >> lv) & 1u)) atomicOr(&marks[r0[k]], 1u << lv);
+            for (uint32_t t = s + kChunk; t < e; ++t) {
                 const uint32_t r = tgt_ref[t] & 0x7fffffffu;
                 if ((rows16[r].w >> 31) && !((marks[r] >> lv) & 1u)) atomicOr(&marks[r], 1u << lv);
             }
         } else {
             taxon = level_taxon[lo.off[7] + ((w_max >> 16) & 0x7fffu)];
-            for (uint32_t t = s; t < e; ++t) {
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k)
+                if ((vmask0 >> k) & 1u)
+                    pair_insert((static_cast<uint64_t>(taxon) << 32) | r0[k], pair_tab, pair_list, pair_mask, counters);
+            for (uint32_t t = s + kChunk; t < e; ++t) {
                 const uint32_t r = tgt_ref[t] & 0x7fffffffu;
                 if (rows16[r].w >> 31)
                     pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
@@ -493,7 +520,13 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
         else
             atomicAdd(&lca_count[taxon], 1u);
     }
+    FPROF_T(q2);
     if (uniq_gbin) uniq_gbin[m] = sel;
+    FPROF_T(q3);
+    FPROF_ADD(0, q0, q1);
+    FPROF_ADD(1, q1, q2);
+    FPROF_ADD(2, q2, q3);
+    FPROF_ADD(3, q0, q0 + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -756,3 +789,14 @@ void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t ran
 }
 
 }  // namespace slimm
+
+#if defined(EXP) && EXP == 7
+extern "C" int slimm_debug_prof_filter(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_f), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_f), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

@@ -491,6 +491,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
     __shared__ uint64_t s_tab[kHSlots];
     __shared__ uint32_t s_meta[kHWin];
     __shared__ uint16_t s_rs[kHWin];     // window index of the run's first record + 1; 0 = starts before the window
+    __shared__ uint64_t s_last[kHWin / 64];  // key of the last record of each 64-record segment (staging)
     __shared__ uint32_t s_wmax[kHBlock / 64];
     __shared__ uint2 s_w[kHBlock / 64];
     __shared__ uint32_t s_v[kHBlock / 64];
@@ -506,7 +507,37 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
         const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
         const uint32_t wn = lds_hi - lds_lo;  // staged records
         for (uint32_t i = tid; i < kHSlots; i += kHBlock) s_tab[i] = kEmptySlot;
-        for (uint32_t i = lds_lo + tid; i < lds_hi; i += kHBlock) s_meta[i - lds_lo] = full_meta(acc, i, bad);
+        {   // stage the window like k_runs: all loads up front with clamped indices, previous key by DPP lane shift
+            constexpr int kSlots = kHWin / kHBlock;  // 5 records per thread
+            typename Acc::Raw raw[kSlots];
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) raw[k] = acc.load(min(lds_lo + k * kHBlock + tid, N - 1u));
+            const uint64_t before = acc.raw_key(lds_lo ? lds_lo - 1u : 0u);
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < kSlots; ++k) s_last[k * (kHBlock / 64) + wave] = Acc::key_bits(raw[k]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) {
+                const uint32_t j = k * kHBlock + tid;
+                if ((j & ~63u) < wn) {  // wave-uniform
+                    const uint64_t mine = Acc::key_bits(raw[k]);
+                    const uint32_t seg = j >> 6;
+                    const uint64_t carry_key = seg ? s_last[seg - 1u] : before;
+                    const uint32_t plo = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key),
+                                                                     static_cast<uint32_t>(mine), 0x138, 0xf, 0xf, false);
+                    const uint32_t phi = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key >> 32),
+                                                                     static_cast<uint32_t>(mine >> 32), 0x138, 0xf, 0xf,
+                                                                     false);
+                    if (j < wn) {
+                        uint32_t m = acc.meta(raw[k], bad);
+                        if (lds_lo + j == 0u || !Acc::same_run(mine, (static_cast<uint64_t>(phi) << 32) | plo)) m |= M_RUN;
+                        s_meta[j] = m;
+                    }
+                }
+            }
+        }
         __syncthreads();
         // run start of every staged record: inclusive max-scan of (run-start ? index + 1 : 0), 512 records per trip
         uint32_t carry = 0;

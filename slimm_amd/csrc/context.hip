@@ -584,8 +584,6 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)
             HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, 2 * c->Bp * sizeof(uint32_t), st));
         ZeroArgs z;
-        z.p[0] = c->counters.p;
-        z.n[0] = CNT_WORDS;
         z.p[1] = c->tail();
         z.n[1] = kTailWords;
         if (c->use_tiles) {
@@ -594,7 +592,13 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             z.p[3] = c->ref_stats.p;  // per-reference statistics accumulated by k_tile_hist
             z.n[3] = 4 * c->R;
         }
-        launch_zero(st, z);
+        if (c->order == SLIMM_ORDER_GROUPED) {  // the same launch clears the counters and picks the classification kernel
+            launch_zero_pick_raw(st, z, c->rec, c->counters.p);
+        } else {
+            z.p[0] = c->counters.p;
+            z.n[0] = CNT_WORDS;
+            launch_zero(st, z);
+        }
     }
     c->bins_exposed = false;
     c->statsA_final = false;
@@ -638,7 +642,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     } else {
         // grouped input: classify and emit straight from the caller's record arrays
         const int ids[3] = {K_PICK, K_FLAGS, K_RUNS_HASH};
-        for (int part = 0; part < 3; ++part) {
+        for (int part = 1; part < 3; ++part) {  // (part 0, the pick, rode along with the clearing kernel)
             KernelTimer t(c, ids[part]);
             launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
                             c->c_fl.p, c->tile_cnt.p, c->tile_valid.p, part);
@@ -880,6 +884,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     const uint32_t R = c->R, T = c->T;
+    bool rows_ride_along = false;
     if (c->use_rows16) {
         const uint16_t* li = h.level_index().data();
         for (uint32_t r = 0; r < R; ++r) {
@@ -889,9 +894,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
                                           q[4] | (uint32_t(q[5]) << 16), q[6] | ((uint32_t(q[7]) | v) << 16));
         }
         tr.mark("rows16 build");
-        // (a kernel reading the pinned rows, like the copy-outs; measured equal to the H2D DMA here)
-        launch_copy_out(st, reinterpret_cast<uint32_t*>(c->d_rows16.p), reinterpret_cast<const uint32_t*>(c->h_rows16.p),
-                        R * 4u);
+        rows_ride_along = true;  // copied by the clearing kernel below (pinned host memory is device-readable)
         tr.mark("rows16 H2D call");
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
@@ -918,6 +921,11 @@ int slimm_filter_alignments(slimm_ctx* c) {
             if (!c->pair_clean) {
                 z.p64 = c->pair_tab.p;
                 z.n64 = c->pair_cap;
+            }
+            if (rows_ride_along && attempt == 0) {
+                z.cp_dst = reinterpret_cast<uint32_t*>(c->d_rows16.p);
+                z.cp_src = reinterpret_cast<const uint32_t*>(c->h_rows16.p);
+                z.cp_n = R * 4u;
             }
             launch_zero(st, z);
         }

@@ -45,6 +45,9 @@ struct ZeroArgs {  // arrays cleared by one k_zero launch; p64 is filled with ~0
     uint32_t n[5] = {0, 0, 0, 0, 0};
     uint64_t* p64 = nullptr;
     uint32_t n64 = 0;
+    uint32_t* cp_dst = nullptr;        // optional ride-along copy of cp_n words (16-byte aligned), e.g. pinned host -> device
+    const uint32_t* cp_src = nullptr;
+    uint32_t cp_n = 0;
 };
 void launch_zero(hipStream_t st, const ZeroArgs& z);
 // n words from device memory to host-mapped pinned memory (16-byte aligned both) by a kernel instead of the DMA engine
@@ -69,6 +72,9 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
 // runs.hip: record classification + CSR emission, on the raw records (grouped input) or on the sorted compact stream.
 // part 0 = k_pick_runs (chooses the kernel on the device), 1 = k_runs (look-back), 2 = k_runs_hash; all three are
 // launched, the classification kernel that was not chosen returns immediately.
+// k_zero and k_pick_runs in one launch (grouped input): z must not contain the counters, which workgroup 0 clears itself
+// before it writes the chosen kernel to counters[CNT_MODE]
+void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters);
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
                      uint2* tile_cnt, uint32_t* tile_valid, int part);

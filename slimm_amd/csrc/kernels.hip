@@ -594,10 +594,13 @@ __global__ __launch_bounds__(256) void k_zero(const ZeroArgs z) {
     for (int k = 0; k < 5; ++k)
         for (uint32_t i = gid; i < z.n[k]; i += gsz) z.p[k][i] = 0u;
     for (uint32_t i = gid; i < z.n64; i += gsz) z.p64[i] = ~0ull;
+    const uint32_t n4 = z.cp_n >> 2;
+    for (uint32_t i = gid; i < n4; i += gsz) reinterpret_cast<uint4*>(z.cp_dst)[i] = reinterpret_cast<const uint4*>(z.cp_src)[i];
+    for (uint32_t i = (n4 << 2) + gid; i < z.cp_n; i += gsz) z.cp_dst[i] = z.cp_src[i];
 }
 
 void launch_zero(hipStream_t st, const ZeroArgs& z) {
-    uint32_t most = z.n64;
+    uint32_t most = std::max(z.n64, z.cp_n / 4);
     for (int k = 0; k < 5; ++k) most = most > z.n[k] ? most : z.n[k];
     uint32_t blocks = (most + 255) / 256;
     if (blocks > 1024) blocks = 1024;

@@ -686,6 +686,52 @@ __global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __r
     }
 }
 
+// k_zero + k_pick_runs in one launch: every workgroup clears its share of the arrays; workgroup 0 clears the counters,
+// then samples the first records and writes the choice.  (Two single-purpose launches cost ~6 us each in launch and
+// drain latency.)
+template <typename Acc>
+__global__ __launch_bounds__(256) void k_zero_pick(const ZeroArgs z, const Acc acc, uint32_t* __restrict__ counters,
+                                                   int force) {
+    __shared__ uint32_t s_runs[4];
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        for (uint32_t i = gid; i < z.n[k]; i += gsz) z.p[k][i] = 0u;
+    for (uint32_t i = gid; i < z.n64; i += gsz) z.p64[i] = ~0ull;
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x < CNT_WORDS) counters[threadIdx.x] = 0u;
+    const uint32_t N = acc.count(counters);  // (raw records: a kernel argument, not a counter)
+    const uint32_t S = min(N, kPickSample);
+    if (S == 0) {
+        if (threadIdx.x == 0) counters[CNT_MODE] = force >= 0 ? static_cast<uint32_t>(force) : 0u;
+        return;
+    }
+    uint32_t runs = 0;
+    for (uint32_t i0 = 0; i0 < S; i0 += 8 * 256) {  // 8 records per thread and trip, their loads issued together
+        uint64_t a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = min(i0 + u * 256 + threadIdx.x, S - 1u);
+            a[u] = acc.key_of(i);
+            b[u] = acc.key_of(i ? i - 1u : 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u * 256 + threadIdx.x;
+            runs += (i < S && (i == 0 || a[u] != b[u])) ? 1u : 0u;
+        }
+    }
+    runs = r_wave_sum(runs);
+    if ((threadIdx.x & 63) == 0) s_runs[threadIdx.x >> 6] = runs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_runs[0] + s_runs[1] + s_runs[2] + s_runs[3];
+        uint32_t mode = (t != 0 && S / t > kPickHashAbove) ? 1u : 0u;
+        if (force >= 0) mode = static_cast<uint32_t>(force);
+        counters[CNT_MODE] = mode;
+    }
+}
+
 template <typename Acc>
 __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* __restrict__ fl,
                                                   uint32_t* __restrict__ counters, const uint2* __restrict__ tile_off,
@@ -862,6 +908,14 @@ static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint3
     a.half_read = half_read;
     a.bin_width = bin_width;
     return a;
+}
+
+void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters) {
+    uint32_t most = z.n64;
+    for (int k = 0; k < 5; ++k) most = most > z.n[k] ? most : z.n[k];
+    const uint32_t blocks = std::min<uint32_t>(1024u, (most + 255u) / 256u + 1u);
+    const RawRecords a = make_raw(in, 0, nullptr, nullptr, 0, 1);
+    hipLaunchKernelGGL(k_zero_pick<RawRecords>, dim3(blocks), dim3(256), 0, st, z, a, counters, forced_runs_mode());
 }
 
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,

@@ -13,7 +13,8 @@
 //                                                                              k_valid_count, k_compact feed the sort path
 //   a4  first bin per distinct (read, ref)       src/read_stat.hpp:116-135    k_runs, k_emit (runs.hip)
 //   a5  cov / uniq_cov histograms                src/slimm.hpp:219-257        tile_hist.hip (k_hist = fallback)
-//   a7  non-zero bin counts (+ per-ref sums)     src/reference_contig.hpp:84-91   k_ref_stats
+//   a7  non-zero bin counts (+ per-ref sums)     src/reference_contig.hpp:84-91   k_tile_hist (tile_hist.hip); k_ref_stats
+//                                                                              after a bins merge / on the fallback path
 //   a10 per-read filter, uniq_cov2               src/slimm.hpp:380-391, read_stat.hpp:98-114   k_filter_lca
 //   a11 level-scan LCA                           src/slimm.hpp:516-531        k_filter_lca
 //   a12 step 1: per-taxon counts + children      src/slimm.hpp:536-557        k_filter_lca
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
 // ---------------------------------------------------------------------------------------------------------
 // k_hist: cov[g]++ for every target; uniq_cov[g]++ when the target is the only one of its read
 // (src/slimm.hpp:219-257).  reads_count / uniq_reads_count are NOT counted here: each target adds exactly one to
-// both reads_count[ref] and one bin of ref, so they are the per-reference bin sums k_ref_stats produces.
+// both reads_count[ref] and one bin of ref, so they are the per-reference bin sums (k_tile_hist / k_ref_stats).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tgt_ref, const uint32_t* __restrict__ tgt_gbin,
                                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,

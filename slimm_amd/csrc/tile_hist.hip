@@ -6,17 +6,19 @@
 // one workgroup per tile accumulates its bucket in LDS and writes the finished tile with coalesced 16-byte stores.
 // The tile write-back also replaces the zero-fill of cov / uniq_cov.
 //
-//   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slice of the targets, merged into
-//                   tile_count[] with one (contiguous, non-returning) global atomic per non-empty tile
-//   k_tile_scan     exclusive scan tile_count -> tile_base (one workgroup; <= 36 K tiles)
-//   k_part_super    same slices; level 1 of the bucketing: targets go to their SUPER tile (256 tiles = 2 M bins) as
-//                   32-bit words (21-bit bin-in-super | unique bit).  <= ~100 destinations per workgroup, so every
-//                   workgroup writes runs of hundreds of bytes.  Also zeroes the tiles that k_tile_hist will
-//                   accumulate with atomics.
-//   k_part_tile     level 2: work items of <= 32 K entries of one super tile are split into its 256 tiles as 16-bit
-//                   words (13-bit bin-in-tile | unique bit).  (A one-level scatter into thousands of tiles wrote
-//                   2-byte stores all over memory: 123 MB of write traffic for 16 MB of payload at config 2.)
-//   k_tile_hist     one workgroup per tile: LDS cov[8192] + uniq_cov[8192], bucket in, finished tile out
+//   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slice of the targets, added to one
+//                   of 8 copies of tile_count[] with one non-returning global atomic per non-empty tile
+//   k_tile_scan     one workgroup: sums the copies, exclusive scan -> tile_base, turns every copy into the start of its
+//                   stretch inside the buckets, cuts buckets into work items of <= 16 K entries, lists the split tiles
+//   k_tile_scatter  same slices, one level: 16 K-target chunks held in registers; LDS count, one returning atomic per
+//                   tile and chunk on the copy's cursor, 16-bit entries (13-bit bin-in-tile | unique bit) out.  Also
+//                   zeroes the tiles that k_tile_hist will accumulate with atomics.  (<= 4096 tiles)
+//   k_part_super    two levels, level 1: targets go to their SUPER tile (64 tiles = 512 K bins) as 32-bit words
+//                   (19-bit bin-in-super | unique bit): few destinations per workgroup, long runs
+//   k_part_tile     level 2: work items of <= 32 K entries of one super tile are split into its 64 tiles
+//   k_tile_hist     one workgroup per work item: LDS cov[8192] + uniq_cov[8192], bucket in, finished tile out, plus the
+//                   per-reference {sum, non-zero} statistics of the tile and (multi-GPU) its 'bin != 0' bitmaps
+//   k_pack          small result arrays behind the statistics; non-zero counts / bitmaps of the split tiles
 //
 // Reference semantics: src/slimm.hpp:219-257 (cov[bin]++ per target; uniq_cov[bin]++ when the read has one target).
 #include <hip/hip_runtime.h>

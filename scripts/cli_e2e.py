@@ -49,12 +49,13 @@ print(f"BAM: {n} records, {len(raw)/1e6:.0f} MB raw, {os.path.getsize(bam)/1e6:.
 db = os.path.join(tmp, "db.sldb"); write_sldb(db, w.taxonomy)
 cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimm_amd", "slimm")
 os.makedirs(os.path.join(tmp, "out"))
-for threads in (1, 8, 32):
-    env = dict(os.environ, SLIMM_DECODE_THREADS=str(threads))
+for threads in (32, 64):
+    env = dict(os.environ, SLIMM_DECODE_THREADS=str(threads), SLIMM_CLI_TRACE="1")
     t0 = time.time()
     r = subprocess.run([cli, "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True, env=env)
     dt_ = time.time() - t0
     assert r.returncode == 0, r.stderr[-1000:]
+    print("\n".join(l[l.index("[trace]"):] for l in r.stderr.splitlines() if "[trace]" in l))
     print(f"slimm DB BAM with {threads:2d} decode threads: {dt_:.2f} s wall -> {n/dt_/1e6:.2f} M records/s (process start, two passes over the "
           f"file, GPU path, profile)", flush=True)
 print(open(os.path.join(tmp, "out", "sample_profile.tsv")).read()[:300])

@@ -62,6 +62,9 @@ public:
 
 private:
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)
+    // record starts in buf_[pos_, end): appended to offs, at most max_records; returns false on a malformed record
+    bool find_records(size_t end, size_t max_records, std::vector<size_t>& offs, size_t& new_pos);
+    bool plausible_record(size_t o, size_t end, int depth) const;
     bool inflate_batch();             // the next few hundred BGZF blocks -> buf_, inflated on several threads
     bool read_bam_header();
     bool read_sam_header();
@@ -75,9 +78,28 @@ private:
     std::vector<uint32_t> ref_len_;
     SortOrder order_ = SortOrder::Unknown;
     // decoded byte window (BAM) / raw text window (SAM)
-    std::vector<uint8_t> buf_;
+    // byte buffers whose resize() does not zero-fill: every byte is overwritten by fread / inflate right away
+    template <typename T>
+    struct NoInit {
+        using value_type = T;
+        NoInit() = default;
+        template <typename U>
+        NoInit(const NoInit<U>&) {}
+        T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+        void deallocate(T* p, size_t) { ::operator delete(p); }
+        template <typename U, typename... A>
+        void construct(U* p, A&&... a) {
+            if (sizeof...(A) > 0) ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+        }
+        template <typename U>
+        bool operator==(const NoInit<U>&) const { return true; }
+        template <typename U>
+        bool operator!=(const NoInit<U>&) const { return false; }
+    };
+    using Bytes = std::vector<uint8_t, NoInit<uint8_t>>;
+    Bytes buf_;
     size_t pos_ = 0;
-    std::vector<uint8_t> cbuf_;
+    Bytes cbuf_;
     struct Block {
         size_t coff, clen, ooff;  // compressed bytes in cbuf_, output offset in buf_
         uint32_t isize, crc;

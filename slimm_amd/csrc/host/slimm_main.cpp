@@ -216,7 +216,7 @@ int dump_records(const Options& o) {
     for (size_t i = 0; i < f.ref_names().size(); ++i) std::cout << "@\t" << f.ref_names()[i] << "\t" << f.ref_lengths()[i] << "\n";
     RecordBatch b;
     long n;
-    while ((n = f.read_batch(b, 1 << 16, true)) > 0) {
+    while ((n = f.read_batch(b, 1 << 20, true)) > 0) {
         for (size_t i = 0; i < b.size(); ++i)
             std::cout << b.qname[i] << "\t" << b.flag[i] << "\t" << b.ref_id[i] << "\t" << b.begin_pos[i] << "\t" << b.l_seq[i]
                       << "\t" << b.read_key[i] << "\n";
@@ -254,11 +254,24 @@ float depth_of(const uint32_t* bins, uint32_t n, uint32_t nz) {  // reference_co
     return s / n;
 }
 
+// SLIMM_CLI_TRACE=1: millisecond marks of the per-file stages on stderr (the reference's own timer prints whole seconds)
+struct Trace {
+    bool on = getenv("SLIMM_CLI_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[trace] %-34s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 // slimm::get_profiles() for one file (src/slimm.hpp:395-496)
 bool get_profiles(Session& S, size_t file_index) {
     Options& options = S.options;
     const std::string path = S.input_paths[file_index];
     Lap watch;
+    Trace trace;
     std::cerr << "\nReading " << file_index + 1 << " of " << S.input_paths.size() << " files ... (" << get_file_name(path) << ")\n"
               << "=================================================================\n";
     AlignmentFile bam;
@@ -288,6 +301,7 @@ bool get_profiles(Session& S, size_t file_index) {
         avg_read_length = total / count;
     }
     if (options.bin_width == 0) options.bin_width = avg_read_length;  // :412-413, persists across files
+    trace.mark("open + read-length sample");
     bam.close();
     if (!bam.open(path)) return true;
 
@@ -341,16 +355,26 @@ bool get_profiles(Session& S, size_t file_index) {
         return false;
     }
     CHECK(ctx, slimm_set_cutoff_cache(ctx, S.cc_cache, S.ucc_cache));
+    trace.mark("lineage table + slimm_create");
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;
 
     std::cerr << "Analysing alignments, reads and references ....... ";
     {
         RecordBatch b;
         long n;
+        double decode_ms = 0, push_ms = 0;
+        auto t0 = std::chrono::steady_clock::now();
         while ((n = bam.read_batch(b, 1 << 20)) > 0) {
+            auto t1 = std::chrono::steady_clock::now();
             CHECK(ctx, slimm_push_records(ctx, b.read_key.data(), b.ref_id.data(), b.begin_pos.data(), b.flag.data(), b.size()));
             b.clear();
+            auto t2 = std::chrono::steady_clock::now();
+            decode_ms += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            push_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
+            t0 = t2;
         }
+        if (trace.on) fprintf(stderr, "[trace] decode %.2f ms, push to device %.2f ms\n", decode_ms, push_ms);
+        trace.mark("read + decode + push");
         if (n < 0) {
             std::cerr << bam.error() << "\n";
             slimm_destroy(ctx);
@@ -364,6 +388,7 @@ bool get_profiles(Session& S, size_t file_index) {
         slimm_destroy(ctx);
         return false;
     }
+    trace.mark("analyze_alignments + finish_coverage");
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;
     slimm_stats st;
     slimm_get_stats(ctx, &st);
@@ -480,6 +505,7 @@ bool get_profiles(Session& S, size_t file_index) {
         std::cerr << "\n.................................................. ";
     }
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    trace.mark("filter + LCA + outputs");
     std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
     CHECK(ctx, slimm_get_cutoff_cache(ctx, &S.cc_cache, &S.ucc_cache));
     slimm_destroy(ctx);
@@ -507,10 +533,12 @@ int main(int argc, char** argv) {
         return 1;
     }
     std::string err;
+    Trace trace;
     if (!load_slimm_database(S.options.database_path, S.db, err)) {
         std::cerr << "slimm: " << err << "\n";
         return 1;
     }
+    trace.mark("load .sldb");
     for (size_t n = 0; n < S.input_paths.size(); ++n)
         if (!get_profiles(S, n)) return 1;
     std::cerr << "\n*****************************************************************\n";

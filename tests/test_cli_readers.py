@@ -55,6 +55,48 @@ def test_bam_spanning_many_bgzf_blocks(tmp_path):
     assert [int(r[3]) for r in recs] == w.records.begin_pos.tolist()
 
 
+def test_bam_with_irregular_records_is_split_correctly_by_the_parallel_reader(tmp_path, monkeypatch):
+    """Record starts are found chunk-wise in parallel from guessed first records (verified against the chunk before).
+    Irregular records -- names of 1..60 bytes, 0..3 CIGAR operations, reads of 0..400 bases, auxiliary bytes that
+    contain whole fake record headers -- must come out exactly as a sequential walk would give them."""
+    import struct
+    from tests.bam_io import _bgzf_block, sam_header
+    rng = np.random.default_rng(5)
+    n, nref = 60_000, 7
+    ref_names = [f"ref{i}" for i in range(nref)]
+    ref_len = [100_000 + i for i in range(nref)]
+    text = sam_header(ref_names, np.array(ref_len), "@HD\tVN:1.6\tSO:unsorted").encode()
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", nref))
+    for nm, l in zip(ref_names, ref_len):
+        b = nm.encode() + b"\0"
+        out += struct.pack("<i", len(b)) + b + struct.pack("<i", l)
+    expect = []
+    fake = struct.pack("<iiiBBHHHIiii", 200, 1, 5, 4, 0, 0, 1, 0, 50, -1, -1, 0) + b"abc\0"   # looks like a record start
+    for i in range(n):
+        name = ("r%d_" % i + "x" * int(rng.integers(0, 50)))[:int(rng.integers(1, 60))].encode() + b"\0"
+        ncig = int(rng.integers(0, 4))
+        lseq = int(rng.choice([0, 1, 35, 100, 151, 400]))
+        ref = int(rng.integers(-1, nref))
+        pos = int(rng.integers(-1, 90_000))
+        flag = int(rng.choice([0, 4, 16, 65, 129, 256, 2048]))
+        aux = (fake * int(rng.integers(0, 3))) + bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))
+        body = (struct.pack("<iiBBHHHIiii", ref, pos, len(name), 30, 4680, ncig, flag, lseq, -1, -1, 0) + name
+                + struct.pack("<%dI" % ncig, *([(10 << 4)] * ncig)) + bytes((lseq + 1) // 2) + bytes(lseq) + aux)
+        out += struct.pack("<i", len(body)) + body
+        expect.append((name[:-1].decode(), flag, ref, pos, lseq))
+    p = str(tmp_path / "irregular.bam")
+    with open(p, "wb") as f:
+        for s0 in range(0, len(out), 0xff00):
+            f.write(_bgzf_block(bytes(out[s0:s0 + 0xff00])))
+        f.write(_bgzf_block(b""))
+    for threads in ("1", "8"):
+        monkeypatch.setenv("SLIMM_DECODE_THREADS", threads)
+        _, refs, recs = dump(p)
+        assert len(recs) == n
+        got = [(r[0], int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in recs]
+        assert got == expect
+
+
 def test_sort_order_tag_and_errors(tmp_path):
     w = tiny_case()
     p = str(tmp_path / "q.sam")

@@ -412,11 +412,13 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
         cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles2) == 0;
         {
-            const char* tl = getenv("SLIMM_TWO_LEVEL");  // default: by size (measured: one level 87 us vs 90 us at 2.4 K
-            cc->two_level = tl ? (tl[0] == '1') : (c->ntiles2 > 4096);  // tiles, 996 us vs 603 us at 9.8 K tiles)
+            // default by size: with the register-resident scatter chunks one level wins up to ~10 K tiles (config 3:
+            // 494 vs 601 us) and is level with two at 24 K (config 5: 430 vs 396 us)
+            const char* tl = getenv("SLIMM_TWO_LEVEL");
+            cc->two_level = tl ? (tl[0] == '1') : (c->ntiles2 > 16384);
         }
         if (cc->use_tiles) {
-            cc->treps = cc->two_level ? 1u : kTileReps;
+            cc->treps = (cc->two_level || c->ntiles2 > 4096) ? 1u : kTileReps;  // (k_tile_scan stages the copies of <= 4096 tiles)
             cc->tstride = c->ntiles2 + 1;
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||

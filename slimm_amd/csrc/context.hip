@@ -418,7 +418,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
             cc->two_level = tl ? (tl[0] == '1') : (c->ntiles2 > 16384);
         }
         if (cc->use_tiles) {
-            cc->treps = (cc->two_level || c->ntiles2 > 4096) ? 1u : kTileReps;  // (k_tile_scan stages the copies of <= 4096 tiles)
+            cc->treps = (cc->two_level || c->ntiles2 > 16384) ? 1u : kTileReps;  // (k_tile_scan stages the copies of <= 16 K tiles)
             cc->tstride = c->ntiles2 + 1;
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||

@@ -41,6 +41,7 @@ __device__ unsigned long long g_prof_t[8 * 4096];  // [workgroup-wave][phase]
 
 constexpr int kTBlock = 512;
 constexpr uint32_t kTileMask = kTileBins - 1;
+constexpr uint32_t kScanStaged = 16384;  // tiles whose counts k_tile_scan stages in LDS (the one-level bucketing range)
 
 // slice of the targets owned by workgroup b of g: [lo, hi), 2048-aligned so the unrolled loads stay coalesced
 __device__ __forceinline__ void slice_of(uint32_t P, uint32_t b, uint32_t g, uint32_t& lo, uint32_t& hi) {
@@ -106,12 +107,27 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
                                                     uint32_t rep_stride, int two_level) {
     __shared__ uint2 s_part[1024];
     __shared__ uint32_t s_nsplit;
-    __shared__ uint32_t s_cnt[4096];  // (one-level bucketing: <= 4096 tiles) a tile's total over the copies, then its base
+    __shared__ uint32_t s_cnt[kScanStaged];  // (<= 16 K tiles) a tile's total over the copies, then its base
     if (threadIdx.x == 0) s_nsplit = 0;
     const uint32_t tid = threadIdx.x;
-    const bool staged = ntiles <= 4096;  // otherwise reps == 1 (two-level bucketing) and the counts are read in place
+    const bool staged = ntiles <= kScanStaged;  // otherwise reps == 1 (two-level bucketing) and the counts are read in place
+    const bool kept = ntiles <= 4096;           // the copies of <= 4 tiles per thread stay in registers between the stages
     uint32_t keep[4][kTileReps];  // (staged, reps == kTileReps) the copies of this thread's up to 4 tiles, for stage 3
-    if (staged) {
+    if (staged && !kept) {
+        for (uint32_t i = tid; i < ntiles; i += 1024) {
+            uint32_t c = 0;
+            if (reps == kTileReps) {
+                uint32_t v[kTileReps];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) c += v[rep];
+            } else {
+                for (uint32_t rep = 0; rep < reps; ++rep) c += tile_count[static_cast<size_t>(rep) * rep_stride + i];
+            }
+            s_cnt[i] = c;
+        }
+    } else if (staged) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // coalesced, the copies' loads independent of each other
             const uint32_t i = tid + q * 1024;
@@ -168,7 +184,31 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
         run.y += pieces;
     }
     __syncthreads();
-    if (staged) {  // the copies of a tile's count become the start of every copy's stretch inside the tile's bucket
+    if (staged && !kept) {
+        for (uint32_t i = tid; i < ntiles; i += 1024) {
+            uint32_t at = s_cnt[i];
+            if (reps == kTileReps) {
+                uint32_t v[kTileReps];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+#pragma unroll
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) {
+                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
+                    tile_count[k] = at;
+                    tile_cursor[k] = 0;
+                    at += v[rep];
+                }
+            } else {
+                for (uint32_t rep = 0; rep < reps; ++rep) {
+                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
+                    const uint32_t cr = tile_count[k];
+                    tile_count[k] = at;
+                    tile_cursor[k] = 0;
+                    at += cr;
+                }
+            }
+        }
+    } else if (staged) {  // the copies of a tile's count become the start of every copy's stretch inside the tile's bucket
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t i = tid + q * 1024;
@@ -230,7 +270,7 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
                                               const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
                                               uint16_t* __restrict__ bucket, uint32_t* s_hist) {
     // (tile_base / tile_cursor: this workgroup's copy -- start of the copy's stretch in every bucket, and its cursor)
-    constexpr int kMaxTilesPerThread = 8;  // one-level bucketing is used up to 4096 tiles
+    constexpr int kMaxTilesPerThread = 8;  // tiles per thread whose reservations are in flight together
     TPROF_T(p0);
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     uint4 g[kQ];
@@ -285,21 +325,21 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
     }
     __syncthreads();
     TPROF_T(p2);
-    {   // s_hist becomes the write cursor of this chunk in every tile's bucket
+    // s_hist becomes the write cursor of this chunk in every tile's bucket: 8 tiles per thread and trip, the trip's
+    // returning atomics all issued before any is waited for
+    for (uint32_t i0 = 0; i0 < ntiles; i0 += kMaxTilesPerThread * kTBlock) {
         uint32_t got[kMaxTilesPerThread];
 #pragma unroll
         for (int j = 0; j < kMaxTilesPerThread; ++j) {
-            const uint32_t i = j * kTBlock + threadIdx.x;
+            const uint32_t i = i0 + j * kTBlock + threadIdx.x;
             const uint32_t h = i < ntiles ? s_hist[i] : 0u;
             got[j] = h ? atomicAdd(&tile_cursor[i], h) + tile_base[i] : 0u;  // tiles this chunk does not touch: no atomic
         }
 #pragma unroll
         for (int j = 0; j < kMaxTilesPerThread; ++j) {
-            const uint32_t i = j * kTBlock + threadIdx.x;
+            const uint32_t i = i0 + j * kTBlock + threadIdx.x;
             if (i < ntiles) s_hist[i] = got[j];
         }
-        for (uint32_t i = kMaxTilesPerThread * kTBlock + threadIdx.x; i < ntiles; i += kTBlock)  // (beyond 4096 tiles)
-            s_hist[i] = atomicAdd(&tile_cursor[i], s_hist[i]) + tile_base[i];
     }
     __syncthreads();
     TPROF_T(p3);

@@ -814,7 +814,9 @@ int slimm_merge_summary_slices(slimm_ctx* c, const void* d_recv, uint32_t n_rank
                                uint64_t* n_words) {
     if (!c || !d_recv || !d_vec || !n_words) return SLIMM_E_INVALID;
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
-    if (n_ranks < 1 || n_ranks != std::max<uint32_t>(c->summary_slices, 1u) || my_rank >= n_ranks || !c->summary_has_bits)
+    // (one rank: the unsliced summary of slimm_coverage_summary is its own single slice, however its bitmaps were made)
+    if (n_ranks < 1 || n_ranks != std::max<uint32_t>(c->summary_slices, 1u) || my_rank >= n_ranks ||
+        (!c->summary_has_bits && n_ranks > 1) || !c->summary.p)
         return fail(c, SLIMM_E_INVALID, "slimm_merge_summary_slices: slimm_prepare_summary(ctx, n_ranks) was not in effect");
     (void)hipSetDevice(c->device);
     const uint64_t W = 4ull * c->R + 16;

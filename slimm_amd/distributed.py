@@ -176,7 +176,14 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
     if hasattr(engine, "prepare_summary"):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         how = resolve_exchange(engine, exchange, world) if multi else "none"
-        engine.prepare_summary(world if how == "sliced" else (1 if how == "summary" else 0))
+        if how == "sliced":
+            try:
+                engine.prepare_summary(world)
+            except Exception:  # the engine cannot slice (e.g. the direct-atomics fallback): same answer on every rank
+                how = exchange = "summary"
+        if how != "sliced":
+            engine.prepare_summary(1 if how == "summary" else 0)
+        exchange = how if multi else exchange
     engine.analyze_alignments()
     t = lap("analyze_alignments(launch)", t)
     have_hits = exchange_coverage(engine, group, exchange)

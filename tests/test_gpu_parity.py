@@ -391,6 +391,23 @@ def test_single_rank_through_the_exchange_code_path():
         assert_matches_oracle(s, o)
 
 
+def test_sliced_exchange_on_the_direct_atomics_fallback(monkeypatch):
+    """The direct-atomics fallback has no tile kernels to lay the bitmaps out in slices.  One rank: the unsliced summary
+    (bitmaps from the separate kernels) is its own single slice.  More ranks: slimm_prepare_summary(n > 1) refuses and
+    the driver takes the all-gather form (the same decision on every rank: it depends on the configuration only)."""
+    from slimm_amd.distributed import sharded_profile
+    monkeypatch.setenv("SLIMM_DIRECT_ATOMICS", "1")
+    w = make_workload(CONFIGS["config1"], seed=29)
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0)
+    s.force_exchange = True
+    s.push_records(w.records)
+    assert sharded_profile(s, None, None, exchange="sliced") is not None
+    assert_matches_oracle(s, o)
+    with pytest.raises(Exception):
+        s.prepare_summary(4)
+
+
 def test_kernel_timing_reports_every_kernel():
     w = make_workload(CONFIGS["config1"], seed=13)
     s = Slimm.for_workload(w, device=0)

@@ -3,7 +3,9 @@
 // One context = one `slimm` object working on one input file on one GPU (reference src/slimm.hpp:92-165).
 // Device work is queued on a private stream; the only host<->device round trips of a run are
 //   finish_coverage : per-reference {sum, non-zero} of cov / uniq_cov (16 bytes per reference)  -> host cut-offs
-//   filter          : valid mask up (1 byte per reference); uniq2 / LCA counts / child marks down.
+//   filter          : lineage rows with the valid bit up (16 bytes per reference); uniq2 / LCA counts / child marks down
+// both through pinned host memory that a copy kernel reads / writes (no DMA-engine start-up latency).
+// Multi-GPU entry points (coverage summary in all-gather or all-to-all form, device-side partials merge) are further down.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

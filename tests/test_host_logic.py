@@ -3,6 +3,8 @@
 A host-only context (device = -1) is fed the per-reference / per-taxon integers the kernels would produce -- here taken
 from the oracle -- and everything downstream must equal the oracle.  No GPU call is made.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -126,3 +128,28 @@ def test_no_hits_and_bad_config():
     w.options.rank = "superkingdom"  # broken in the reference (Q14): rejected
     with pytest.raises(capi.SlimmError):
         Slimm.for_workload(w, device=-1)
+
+
+def test_collect_profiles_merges_samples(tmp_path):
+    """scripts/collect_profiles.py: one row per taxon, one column pair per sample, zeros for
+    taxa a sample does not have."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "collect_profiles", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts",
+                                         "collect_profiles.py"))
+    cp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cp)
+    head = "taxa_level\ttaxa_id\tlinage\tabundance\tread_count\n"
+    a = tmp_path / "a_profile.tsv"
+    b = tmp_path / "b_profile.tsv"
+    a.write_text(head + "species\t10\tk__K|s__x\t60.5\t605\nspecies\t0*\tk__|s__\t39.5\t395\n")
+    b.write_text(head + "species\t10\tk__K|s__x\t10\t1\nspecies\t11\tk__K|s__y\t80\t8\nspecies\t0*\tk__|s__\t10\t1\n")
+    out = tmp_path / "merged.tsv"
+    assert cp.main(["-o", str(out), str(a), str(b)]) == 0
+    lines = out.read_text().rstrip("\n").split("\n")
+    assert lines[0].split("\t") == ["taxa_level", "taxa_id", "linage", "a_abundance", "b_abundance", "a_read_count",
+                                     "b_read_count"]
+    rows = {tuple(l.split("\t")[:2]): l.split("\t")[3:] for l in lines[1:]}
+    assert rows[("species", "10")] == ["60.5", "10", "605", "1"]
+    assert rows[("species", "11")] == ["0", "80", "0", "8"]
+    assert lines[1].split("\t")[1] == "10"          # sorted by the first sample's abundance, descending

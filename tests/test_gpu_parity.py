@@ -408,6 +408,31 @@ def test_sliced_exchange_on_the_direct_atomics_fallback(monkeypatch):
         s.prepare_summary(4)
 
 
+def test_contexts_release_their_device_memory():
+    """Create / run / destroy in a loop: free device memory must not drift (every DevBuf and stream is released)."""
+    import gc
+    import torch
+    w = make_workload(CONFIGS["config2"], seed=33, n_records=200_000)
+
+    def one_pass():
+        s = Slimm.for_workload(w, device=0)
+        s.prepare_summary(2)
+        s.push_records(w.records)
+        assert s.get_profiles() is not None
+        s.close()
+
+    one_pass()
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        one_pass()
+    gc.collect()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < 64 << 20, (free0, free1)   # (allocator granularity, not a per-context leak)
+
+
 def test_kernel_timing_reports_every_kernel():
     w = make_workload(CONFIGS["config1"], seed=13)
     s = Slimm.for_workload(w, device=0)

@@ -121,6 +121,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
+    bool fused_scan = false;                            // k_tile_scan runs inside the one-level bucketing kernel
     uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
     // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
@@ -422,6 +423,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         if (cc->use_tiles) {
             cc->treps = (cc->two_level || c->ntiles2 > 16384) ? 1u : kTileReps;  // (k_tile_scan stages the copies of <= 16 K tiles)
             cc->tstride = c->ntiles2 + 1;
+            {
+                const char* fs = getenv("SLIMM_FUSED_SCAN");
+                cc->fused_scan = !cc->two_level && cc->treps == kTileReps && c->ntiles2 <= kFusedScanTiles && !(fs && fs[0] == '0');
+            }
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
                 cc->tile_cursor.ensure(rep_words) != hipSuccess || cc->split_tiles.ensure(c->ntiles2 + 1) != hipSuccess)
@@ -595,6 +600,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             z.n[2] = c->treps * c->tstride;
             z.p[3] = c->ref_stats.p;  // per-reference statistics accumulated by k_tile_hist
             z.n[3] = 4 * c->R;
+            if (c->fused_scan) {      // (otherwise k_tile_scan clears the cursors)
+                z.p[4] = c->tile_cursor.p;
+                z.n[4] = c->treps * c->tstride;
+            }
         }
         if (c->order == SLIMM_ORDER_GROUPED) {  // the same launch clears the counters and picks the classification kernel
             launch_zero_pick_raw(st, z, c->rec, c->counters.p);
@@ -668,17 +677,24 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             KernelTimer t(c, K_TILE_COUNT);
             launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p, c->treps, c->tstride);
         }
-        {
-            KernelTimer t(c, K_TILE_SCAN);
-            launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                             c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                             c->two_level);
-        }
-        {
+        if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER);
-            launch_tile_scatter(st, grid, c->ntiles, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
-                                c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(),
-                                c->ucov(), c->two_level, c->tile_count.p, c->treps, c->tstride);
+            launch_tile_scatter_fused(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p,
+                                      c->tile_cursor.p, c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p,
+                                      c->split_tiles.p);
+        } else {
+            {
+                KernelTimer t(c, K_TILE_SCAN);
+                launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
+                                 c->two_level);
+            }
+            {
+                KernelTimer t(c, K_TILE_SCATTER);
+                launch_tile_scatter(st, grid, c->ntiles, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
+                                    c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(),
+                                    c->ucov(), c->two_level, c->tile_count.p, c->treps, c->tstride);
+            }
         }
         {
             KernelTimer t(c, K_TILE_HIST);
@@ -920,6 +936,10 @@ int slimm_filter_alignments(slimm_ctx* c) {
                 z.n[2] = c->treps * c->tstride;
                 z.p[3] = blockB;  // per-reference statistics of uniq_cov2, accumulated by k_tile_hist
                 z.n[3] = 4 * R;
+                if (c->fused_scan) {
+                    z.p[4] = c->tile_cursor.p;
+                    z.n[4] = c->treps * c->tstride;
+                }
             } else {
                 z.p[2] = c->lca_count.p;
                 z.n[2] = T;
@@ -956,17 +976,24 @@ int slimm_filter_alignments(slimm_ctx* c) {
                 launch_tile_count(st, grid, c->ntiles2, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p, c->treps,
                                   c->tstride);
             }
-            {
-                KernelTimer t(c, K_TILE_SCAN2);
-                launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                             c->two_level);
-            }
-            {
+            if (c->fused_scan) {
                 KernelTimer t(c, K_TILE_SCATTER2);
-                launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M,
-                                    c->tile_base.p, c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p,
-                                    c->bucket.p, c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
+                launch_tile_scatter_fused(st, grid, c->ntiles2, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p,
+                                          c->tile_cursor.p, c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p,
+                                          c->split_tiles.p);
+            } else {
+                {
+                    KernelTimer t(c, K_TILE_SCAN2);
+                    launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                                     c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
+                                 c->two_level);
+                }
+                {
+                    KernelTimer t(c, K_TILE_SCATTER2);
+                    launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M,
+                                        c->tile_base.p, c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p,
+                                        c->bucket.p, c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
+                }
             }
             {
                 KernelTimer t(c, K_TILE_HIST2);

@@ -158,6 +158,13 @@ struct BitsLayout {
 // stats != nullptr: k_tile_hist also accumulates the per-reference statistics {sum a, non-zero a, sum b, non-zero b}
 // (stats[ref * 4 ..], zeroed by the caller) of the finished arrays; tile_ref0[tile] = first reference overlapping the
 // tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts
+// one-level bucketing with k_tile_scan folded in (<= 4096 tiles, kTileReps copies of the counters): after
+// launch_tile_count, with tile_cursor zero; also writes k_tile_hist's work items, the split-tile list and their counts
+constexpr uint32_t kFusedScanTiles = 4096;
+void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
+                               uint32_t* counters, int count_slot, const uint32_t* tile_count, uint32_t* tile_cursor,
+                               uint16_t* bucket, uint32_t* cov, uint32_t* ucov, uint32_t rep_stride, uint4* items,
+                               uint32_t* split_tiles);
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
                       uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,

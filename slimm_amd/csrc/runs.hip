@@ -427,22 +427,18 @@ __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Ac
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_runs_hash: the same classification in O(1) per record.  The look-back of k_runs costs O(records of the read) per
-// record and a whole wave waits for its longest run -- fine at 3 hits per read, the dominant cost at 40 (BASELINE
-// config 5: 4.2 ms of a 9.7 ms file).  Here every mapped record of the staged window puts
-//     (run, mate, ref)  and  (run, mate, ANY)
-// into an LDS hash table with atomicMin(record index); afterwards `first` <=> the minimum of its (run, mate, ref) entry
-// is the record itself, `head` <=> likewise for (run, mate, ANY), and "an earlier record of the run has a larger mate"
-// <=> the minimum of a larger mate's ANY entry is smaller than the record's index.  `run` is the window index of the
-// run's first record (block-wide max-scan of the run-start flags).  Records whose run starts before the staged window
-// (512 records of back halo) fall back to the global look-back walk.
-// One 64-bit LDS word per entry: (run 12 bits | mate 2 | ref 28) << 12 | window index.
+// k_runs_hash: the same classification with an O(1) duplicate test.  The duplicate walk of k_runs costs O(records of
+// the read) per record and a whole wave waits for its longest run -- fine at 3-8 hits per read, the dominant cost at 40
+// (BASELINE config 5).  Here `head` and `larger mate before` come from the same segment ballots + carries as in k_runs,
+// and every mapped record of the staged window puts ONE key, (run start, mate, ref), into an LDS hash table with
+// atomicMin(window index): `first` <=> the minimum of its key is the record itself.  Records whose run starts before the
+// staged window (512 records of back halo) fall back to the global look-back walk.
+// One 64-bit LDS word per entry: (run start 12 bits | mate 2 | ref 28) << 12 | window index.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kHBlock = 512;
 constexpr uint32_t kHHalo = 512;
 constexpr uint32_t kHWin = kRTile + kHHalo;        // 2560 staged records
-constexpr uint32_t kHSlots = 8192;                 // >= 2 entries per staged record at load <= 0.63
-constexpr uint32_t kRefAny = 0x0fffffffu;          // not a reference id: slimm_create keeps n_refs below 2^28 - 1
+constexpr uint32_t kHSlots = 8192;                 // one entry per mapped staged record: load <= 0.32
 constexpr uint64_t kEmptySlot = ~0ull;
 
 __device__ __forceinline__ uint32_t hash_slot(uint64_t key) {
@@ -488,34 +484,40 @@ template <typename Acc>
 __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
                                                        uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
                                                        uint32_t* __restrict__ tile_valid) {
+    constexpr int kSlots = kHWin / kHBlock;       // 5 staged records per thread
+    constexpr uint32_t kHSegs = kHWin / 64;       // 40 segments
+    constexpr int kHWaves = kHBlock / 64;
     __shared__ uint64_t s_tab[kHSlots];
     __shared__ uint32_t s_meta[kHWin];
-    __shared__ uint16_t s_rs[kHWin];     // window index of the run's first record + 1; 0 = starts before the window
-    __shared__ uint64_t s_last[kHWin / 64];  // key of the last record of each 64-record segment (staging)
-    __shared__ uint32_t s_wmax[kHBlock / 64];
-    __shared__ uint2 s_w[kHBlock / 64];
-    __shared__ uint32_t s_v[kHBlock / 64];
+    __shared__ uint32_t s_seg[kHSegs];            // segment summaries, then the carry into each segment (as in k_runs)
+    __shared__ uint64_t s_last[kHSegs];           // key of the last record of each segment (staging)
+    __shared__ uint2 s_w[kHWaves];
+    __shared__ uint32_t s_v[kHWaves];
     if (counters[CNT_MODE] != 1u) return;  // k_pick_runs chose the look-back kernel for this stream
     const uint32_t N = acc.count(counters);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint64_t le_mask = lt_mask | (1ull << lane);
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const uint32_t base = tile * kRTile;
-    uint32_t nh = 0, nf = 0, nv = 0;
-    bool bad = false, too_long = false, any_gb = false;
+    uint32_t nh = 0, nf = 0, nv = 0, any_gb = 0;
+    bool bad = false, too_long = false;
     if (base < N) {
         const uint32_t lds_lo = base >= kHHalo ? base - kHHalo : 0u;
         const uint32_t lds_hi = min(base + static_cast<uint32_t>(kRTile), N);
-        const uint32_t wn = lds_hi - lds_lo;  // staged records
+        const uint32_t off = base - lds_lo, wn = lds_hi - lds_lo;  // staged records
+        const uint32_t nseg = (wn + 63u) >> 6;
         for (uint32_t i = tid; i < kHSlots; i += kHBlock) s_tab[i] = kEmptySlot;
-        {   // stage the window like k_runs: all loads up front with clamped indices, previous key by DPP lane shift
-            constexpr int kSlots = kHWin / kHBlock;  // 5 records per thread
+        // 1. stage the window like k_runs (all loads up front with clamped indices, previous key by DPP lane shift) and
+        //    summarise every 64-record segment
+        {
             typename Acc::Raw raw[kSlots];
 #pragma unroll
             for (int k = 0; k < kSlots; ++k) raw[k] = acc.load(min(lds_lo + k * kHBlock + tid, N - 1u));
             const uint64_t before = acc.raw_key(lds_lo ? lds_lo - 1u : 0u);
             if (lane == 63) {
 #pragma unroll
-                for (int k = 0; k < kSlots; ++k) s_last[k * (kHBlock / 64) + wave] = Acc::key_bits(raw[k]);
+                for (int k = 0; k < kSlots; ++k) s_last[k * kHWaves + wave] = Acc::key_bits(raw[k]);
             }
             __syncthreads();
 #pragma unroll
@@ -530,75 +532,93 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
                     const uint32_t phi = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key >> 32),
                                                                      static_cast<uint32_t>(mine >> 32), 0x138, 0xf, 0xf,
                                                                      false);
+                    uint32_t m = 0u;
                     if (j < wn) {
-                        uint32_t m = acc.meta(raw[k], bad);
+                        m = acc.meta(raw[k], bad);
                         if (lds_lo + j == 0u || !Acc::same_run(mine, (static_cast<uint64_t>(phi) << 32) | plo)) m |= M_RUN;
                         s_meta[j] = m;
                     }
+                    const uint64_t starts = __ballot((m >> 30) & 1u);
+                    const bool mapped = m >> 31;
+                    const uint32_t mate = (m >> 28) & 3u;
+                    const uint64_t tail = starts ? ~((1ull << (63 - __builtin_clzll(starts))) - 1ull) : ~0ull;
+                    const uint32_t seen = ((__ballot(mapped && mate == 0u) & tail) ? 1u : 0u) |
+                                          ((__ballot(mapped && mate == 1u) & tail) ? 2u : 0u) |
+                                          ((__ballot(mapped && mate == 2u) & tail) ? 4u : 0u);
+                    if (lane == 0)
+                        s_seg[seg] = seen | (static_cast<uint32_t>(__popcll(tail)) << 8) | (starts ? SEG_START : 0u);
                 }
             }
         }
         __syncthreads();
-        // run start of every staged record: inclusive max-scan of (run-start ? index + 1 : 0), 512 records per trip
+        // 2. carry into each segment (mates seen and records since the run start), as in k_runs
         uint32_t carry = 0;
-        for (uint32_t c0 = 0; c0 < wn; c0 += kHBlock) {
-            const uint32_t j = c0 + tid;
-            uint32_t v = (j < wn && (s_meta[j] & M_RUN)) ? j + 1 : 0u;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t a = __shfl_up(v, o, 64);
-                if (lane >= static_cast<uint32_t>(o)) v = max(v, a);
-            }
-            if (lane == 63) s_wmax[wave] = v;
-            __syncthreads();
-            uint32_t before = carry, total = carry;
-#pragma unroll
-            for (int w = 0; w < kHBlock / 64; ++w) {
-                const uint32_t t = s_wmax[w];
-                if (w < static_cast<int>(wave)) before = max(before, t);
-                total = max(total, t);
-            }
-            if (j < wn) s_rs[j] = static_cast<uint16_t>(max(v, before));
-            carry = total;
-            __syncthreads();
-        }
-        // every mapped staged record (halo included: it holds the predecessors) enters the table: always with its
-        // (run, mate, ref); with (run, mate, ANY) only when the record before it is not a mapped record of the same
-        // run and mate -- the first record of a (run, mate) always qualifies, and a read's dozens of consecutive
-        // records no longer hammer one LDS word
-        bool paired = false;
-        for (uint32_t j = tid; j < wn; j += kHBlock) {
-            const uint32_t me = s_meta[j], rs = s_rs[j];
-            if ((me & M_VALID) && rs) {
-                const uint64_t run = static_cast<uint64_t>(rs - 1) << 30;
-                hash_put_min(s_tab, run | (me & M_IDENT), j);
-                bool lead = true;
-                if (j > 0 && !(me & M_RUN)) {
-                    const uint32_t pm = s_meta[j - 1];
-                    lead = !((pm & M_VALID) && ((pm ^ me) & 0x30000000u) == 0u);
+        if (tid < nseg) {
+            uint32_t seen = 0, len = 0, open = 1;
+            for (int p = static_cast<int>(tid) - 1; p >= 0; --p) {
+                const uint32_t sm = s_seg[p];
+                seen |= sm & 7u;
+                len += (sm >> 8) & 0xfffffu;
+                if (sm & SEG_START) {
+                    open = 0;
+                    break;
                 }
-                if (lead) hash_put_min(s_tab, run | (me & 0x30000000u) | kRefAny, j);
-                paired = paired || (me & 0x30000000u);
             }
+            if (tid == 0 && lds_lo == 0) open = 0;
+            carry = seen | (len << 8) | (open << 31);
         }
-        const bool any_paired = __syncthreads_or(paired);  // no mate numbers in the window: nothing can precede with a larger one
-        for (int k = 0; k < kRTile / kHBlock; ++k) {
-            const uint32_t i = base + k * kHBlock + tid;
-            if (i >= N) continue;
-            const uint32_t j = i - lds_lo;
-            const uint32_t me = s_meta[j], rs = s_rs[j];
-            const bool valid = me & M_VALID;
-            const uint32_t my_ident = me & M_IDENT, my_mate = (me >> 28) & 3u;
-            bool head = valid, first = valid, greater_before = false;
+        __syncthreads();
+        if (tid < nseg) s_seg[tid] = carry;
+        __syncthreads();
+        // 3. head / larger-mate-before from the ballots of the record's segment plus the carry (k_runs); every mapped
+        //    staged record whose run starts inside the window enters the table once, keyed (run start, mate, ref), with
+        //    atomicMin(window index): `first` <=> the minimum of the key is the record itself.  (The first version also
+        //    kept (run, mate, ANY) entries to answer the head / larger-mate questions: three table operations more per
+        //    record, the bulk of its time.)
+        uint32_t me_[kSlots], st_[kSlots], rs_[kSlots];  // meta word; {head, gb, open} bits; window index of the run start
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const uint32_t j = k * kHBlock + tid;
+            const bool live = j < wn;
+            const uint32_t me = live ? s_meta[j] : M_RUN;
+            const uint32_t valid = me >> 31, my_mate = (me >> 28) & 3u;
+            const uint64_t starts = __ballot((me >> 30) & 1u);
+            const uint64_t v0 = __ballot(valid && my_mate == 0u), v1 = __ballot(valid && my_mate == 1u),
+                           v2 = __ballot(valid && my_mate == 2u);
+            const uint64_t ps = starts & le_mask;
+            const uint32_t from = ps ? 63u - static_cast<uint32_t>(__builtin_clzll(ps)) : 0u;
+            const uint64_t bit_from = 1ull << from;
+            uint32_t seen = ((v0 & lt_mask) >= bit_from ? 1u : 0u) | ((v1 & lt_mask) >= bit_from ? 2u : 0u) |
+                            ((v2 & lt_mask) >= bit_from ? 4u : 0u);
+            uint32_t len = lane - from, open = 0u;
+            if (!ps && live) {
+                const uint32_t c = s_seg[j >> 6];
+                seen |= c & 7u;
+                len += (c >> 8) & 0xfffffu;
+                open = c >> 31;
+            }
+            const uint32_t head = valid & (((seen >> my_mate) & 1u) ^ 1u);
+            const uint32_t gb = valid & ((seen >> (my_mate + 1u)) != 0u ? 1u : 0u);
+            me_[k] = me;
+            rs_[k] = j - min(len, j);
+            st_[k] = head | (gb << 1) | ((open & valid) << 2);
+            if (valid && !open)
+                hash_put_min(s_tab, (static_cast<uint64_t>(rs_[k]) << 30) | (me & M_IDENT), j);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) {
+            const uint32_t j = k * kHBlock + tid;
+            if (j < off || j >= wn) continue;  // halo records belong to the tile before; slots past the end
+            const uint32_t i = lds_lo + j;
+            const uint32_t me = me_[k], valid = me >> 31, my_mate = (me >> 28) & 3u, my_ident = me & M_IDENT;
+            uint32_t head = st_[k] & 1u, gb = (st_[k] >> 1) & 1u, first = valid;
             if (valid && !(me & M_RUN)) {
-                if (rs) {
-                    const uint64_t run = static_cast<uint64_t>(rs - 1) << 30;
-                    first = hash_get_min(s_tab, run | my_ident) == j;
-                    head = hash_get_min(s_tab, run | (me & 0x30000000u) | kRefAny) == j;
-                    if (any_paired)
-                        for (uint32_t m2 = my_mate + 1; m2 < 3; ++m2)
-                            greater_before = greater_before || hash_get_min(s_tab, run | (m2 << 28) | kRefAny) < j;
+                if (!(st_[k] & 4u)) {
+                    first = hash_get_min(s_tab, (static_cast<uint64_t>(rs_[k]) << 30) | my_ident) == j ? 1u : 0u;
                 } else {  // the run starts before the staged window: walk back through global memory (rare)
+                    head = 1u;
+                    gb = 0u;
                     uint32_t q = i, steps = 0;
                     while (q > 0) {
                         --q;
@@ -607,12 +627,12 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
                         if (m & M_VALID) {
                             const uint32_t mt = (m >> 28) & 3u;
                             if ((m & M_IDENT) == my_ident) {
-                                head = false;
-                                first = false;
+                                head = 0u;
+                                first = 0u;
                                 break;
                             }
-                            head = head && (mt != my_mate);
-                            greater_before = greater_before || (mt > my_mate);
+                            if (mt == my_mate) head = 0u;
+                            if (mt > my_mate) gb = 1u;
                         }
                         if (m & M_RUN) break;
                         if (++steps > kLookBackMax + kHHalo) {
@@ -622,12 +642,14 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
                     }
                 }
             }
+            head &= first;
+            gb &= first;
             const uint32_t f = (my_mate << FL_MATE_SHIFT) | ((me & M_RUN) ? FL_RUN_START : 0u) | (head ? FL_HEAD : 0u) |
-                               (first ? FL_FIRST : 0u) | ((valid && greater_before) ? FL_GREATER_BEFORE : 0u);
+                               (first ? FL_FIRST : 0u) | (gb ? FL_GREATER_BEFORE : 0u);
             nh += head;
             nf += first;
             nv += valid;
-            any_gb = any_gb || (valid && greater_before);
+            any_gb |= gb;
             fl[i] = static_cast<uint8_t>(f);
         }
     }
@@ -635,7 +657,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
     nf = r_wave_sum(nf);
     nv = r_wave_sum(nv);
     const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
-    const bool wave_gb = __any(any_gb);
+    const bool wave_gb = __any(any_gb != 0u);
     if (lane == 0) {
         s_w[wave] = make_uint2(nh, nf);
         s_v[wave] = nv;
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
         uint2 t = make_uint2(0u, 0u);
         uint32_t v = 0;
 #pragma unroll
-        for (int w = 0; w < kHBlock / 64; ++w) {
+        for (int w = 0; w < kHWaves; ++w) {
             t.x += s_w[w].x;
             t.y += s_w[w].y;
             v += s_v[w];
@@ -662,10 +684,10 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
 // ---------------------------------------------------------------------------------------------------------
 // k_pick_runs: which classification kernel suits this stream?  Samples the first records, measures records per qName
 // run, and writes the choice to counters[CNT_MODE]; both kernels are launched and the one not chosen returns at once.
-// Measured per 10 M records: look-back 100 us at 3 records/run, 152 at 8, 417 at 42; hash table 318 / - / 222.
+// Measured per 10 M records: look-back 82 us at 3 records/run, 100 at 10, 249 at 42; hash table ~125 at any depth.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPickSample = 8192;
-constexpr uint32_t kPickHashAbove = 24;  // records per run
+constexpr uint32_t kPickHashAbove = 16;  // records per run
 
 template <typename Acc>
 __global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __restrict__ counters, int force) {

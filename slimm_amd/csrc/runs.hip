@@ -166,10 +166,93 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
     return m;
 }
 
-// Per 64-record segment of the staged window: what a record right behind the segment inherits from it.
+// ---------------------------------------------------------------------------------------------------------
+// Pieces shared by k_runs and k_runs_hash.  The staged window is cut into 64-record segments (one wave instruction
+// each).  Per segment, what a record right behind it inherits:
 //   bits 0-2   mates of the mapped records between the segment's last run start (or its first record) and its end
 //   bits 8-27  number of records in that stretch
 //   bit 31     the segment holds a run start (otherwise the stretch continues into the segment before)
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t SEG_START = 0x80000000u;
+
+// summary word of the segment whose 64 meta words the wave holds (m = 0 for slots past the window)
+__device__ __forceinline__ uint32_t segment_summary(uint32_t m) {
+    const uint64_t starts = __ballot((m >> 30) & 1u);
+    const bool mapped = m >> 31;
+    const uint32_t mate = (m >> 28) & 3u;
+    const uint64_t tail = starts ? ~((1ull << (63 - __builtin_clzll(starts))) - 1ull) : ~0ull;
+    const uint32_t seen = ((__ballot(mapped && mate == 0u) & tail) ? 1u : 0u) |
+                          ((__ballot(mapped && mate == 1u) & tail) ? 2u : 0u) |
+                          ((__ballot(mapped && mate == 2u) & tail) ? 4u : 0u);
+    return seen | (static_cast<uint32_t>(__popcll(tail)) << 8) | (starts ? SEG_START : 0u);
+}
+
+// The previous record's key for every lane of a wave holding 64 consecutive keys: the neighbouring lane's (DPP wave
+// shift), lane 0 gets carry_key (the last key of the segment before).  (Loading key[i - 1] as well -- 512-byte wave
+// loads 8 bytes off their alignment -- cost 35 of k_runs' 90 us.)
+__device__ __forceinline__ uint64_t previous_key(uint64_t mine, uint64_t carry_key) {
+    const uint32_t plo = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key), static_cast<uint32_t>(mine), 0x138,
+                                                     0xf, 0xf, false);
+    const uint32_t phi = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key >> 32),
+                                                     static_cast<uint32_t>(mine >> 32), 0x138, 0xf, 0xf, false);
+    return (static_cast<uint64_t>(phi) << 32) | plo;
+}
+
+// Turns the segment summaries s_seg[0 .. nseg) into the carry INTO each segment (mates seen and records since the run
+// start, looking back over whole segments; bit 31: the run starts before the window).  All threads of the workgroup call.
+__device__ __forceinline__ void segment_carries(uint32_t* s_seg, uint32_t nseg, bool stream_start) {
+    uint32_t carry = 0;
+    if (threadIdx.x < nseg) {
+        uint32_t seen = 0, len = 0, open = 1;
+        for (int p = static_cast<int>(threadIdx.x) - 1; p >= 0; --p) {
+            const uint32_t sm = s_seg[p];
+            seen |= sm & 7u;
+            len += (sm >> 8) & 0xfffffu;
+            if (sm & SEG_START) {
+                open = 0;
+                break;
+            }
+        }
+        if (threadIdx.x == 0 && stream_start) open = 0;  // nothing before the first record of the stream
+        carry = seen | (len << 8) | (open << 31);
+    }
+    __syncthreads();
+    if (threadIdx.x < nseg) s_seg[threadIdx.x] = carry;
+    __syncthreads();
+}
+
+// Per record, from the ballots of its own segment plus the carry: is it the first mapped record of its (run, mate)
+// (head), did a mapped record with a larger mate precede it in the run (gb), how many records precede it in the run
+// (len), and does the run start before the window (open).  `head` and `gb` are "was there a mapped record with mate m
+// since the run start": three ballots, a clz and a 64-bit compare instead of a walk.
+struct RunScan {
+    uint32_t head, gb, len, open;
+};
+__device__ __forceinline__ RunScan run_scan(uint32_t me, uint32_t seg_carry, bool use_carry, uint32_t lane, uint64_t lt_mask,
+                                            uint64_t le_mask) {
+    const uint32_t valid = me >> 31, my_mate = (me >> 28) & 3u;
+    const uint64_t starts = __ballot((me >> 30) & 1u);
+    const uint64_t v0 = __ballot(valid && my_mate == 0u), v1 = __ballot(valid && my_mate == 1u),
+                   v2 = __ballot(valid && my_mate == 2u);
+    const uint64_t ps = starts & le_mask;  // run starts at or before me in this segment
+    const uint32_t from = ps ? 63u - static_cast<uint32_t>(__builtin_clzll(ps)) : 0u;
+    const uint64_t bit_from = 1ull << from;
+    // a mapped record with mate m in [from, lane)  <=>  (v_m & lanes before me) >= bit(from)
+    uint32_t seen = ((v0 & lt_mask) >= bit_from ? 1u : 0u) | ((v1 & lt_mask) >= bit_from ? 2u : 0u) |
+                    ((v2 & lt_mask) >= bit_from ? 4u : 0u);
+    RunScan r;
+    r.len = lane - from;
+    r.open = 0u;
+    if (!ps && use_carry) {  // my run starts in an earlier segment
+        seen |= seg_carry & 7u;
+        r.len += (seg_carry >> 8) & 0xfffffu;
+        r.open = (seg_carry >> 31) & valid;
+    }
+    r.head = valid & (((seen >> my_mate) & 1u) ^ 1u);
+    r.gb = valid & ((seen >> (my_mate + 1u)) != 0u ? 1u : 0u);
+    return r;
+}
+
 // k_runs works through a tile in passes of kQTile records (each with its own halo): half the registers of a
 // whole-tile pass, so more workgroups are resident and their load and classify phases overlap
 #ifndef SLIMM_RUNS_MINBLOCKS
@@ -181,7 +264,6 @@ __device__ __forceinline__ uint32_t full_meta(const Acc& acc, uint32_t i, bool& 
 constexpr int kQItems = SLIMM_Q_ITEMS;
 constexpr int kQTile = kRBlock * kQItems;
 constexpr uint32_t kSegs = (kQTile + kHalo) / 64;
-constexpr uint32_t SEG_START = 0x80000000u;
 
 template <typename Acc>
 __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
@@ -232,28 +314,15 @@ __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Ac
                 if ((j & ~63u) < W) {                           // wave-uniform
                     const uint64_t mine = Acc::key_bits(raw[k]);
                     const uint32_t seg = j >> 6;
-                    const uint64_t carry_key = seg ? s_last[seg - 1u] : before;  // s_last is indexed by segment
-                    const uint32_t plo = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key),
-                                                                     static_cast<uint32_t>(mine), 0x138, 0xf, 0xf, false);
-                    const uint32_t phi = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key >> 32),
-                                                                     static_cast<uint32_t>(mine >> 32), 0x138, 0xf, 0xf,
-                                                                     false);
-                    const uint64_t prev = (static_cast<uint64_t>(phi) << 32) | plo;
+                    const uint64_t prev = previous_key(mine, seg ? s_last[seg - 1u] : before);  // s_last: by segment
                     uint32_t m = 0u;
                     if (j < W) {
                         m = acc.meta(raw[k], bad);
                         if (lds_lo + j == 0u || !Acc::same_run(mine, prev)) m |= M_RUN;
                         s_meta[j] = m;
                     }
-                    const uint64_t starts = __ballot((m >> 30) & 1u);
-                    const bool mapped = m >> 31;
-                    const uint32_t mate = (m >> 28) & 3u;
-                    const uint64_t tail = starts ? ~((1ull << (63 - __builtin_clzll(starts))) - 1ull) : ~0ull;
-                    const uint32_t seen = ((__ballot(mapped && mate == 0u) & tail) ? 1u : 0u) |
-                                          ((__ballot(mapped && mate == 1u) & tail) ? 2u : 0u) |
-                                          ((__ballot(mapped && mate == 2u) & tail) ? 4u : 0u);
-                    if (lane == 0)
-                        s_seg[seg] = seen | (static_cast<uint32_t>(__popcll(tail)) << 8) | (starts ? SEG_START : 0u);
+                    const uint32_t summary = segment_summary(m);
+                    if (lane == 0) s_seg[seg] = summary;
                 }
             }
         }
@@ -261,24 +330,7 @@ __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Ac
         __syncthreads();
         PROF_T(t2);
         // 2. carry into each segment: mates seen and records since the run start, looking back over whole segments
-        uint32_t carry = 0;
-        if (threadIdx.x < nseg) {
-            uint32_t seen = 0, len = 0, open = 1;
-            for (int p = static_cast<int>(threadIdx.x) - 1; p >= 0; --p) {
-                const uint32_t sm = s_seg[p];
-                seen |= sm & 7u;
-                len += (sm >> 8) & 0xfffffu;
-                if (sm & SEG_START) {
-                    open = 0;
-                    break;
-                }
-            }
-            if (threadIdx.x == 0 && lds_lo == 0) open = 0;  // nothing before the first record of the stream
-            carry = seen | (len << 8) | (open << 31);
-        }
-        __syncthreads();
-        if (threadIdx.x < nseg) s_seg[threadIdx.x] = carry;
-        __syncthreads();
+        segment_carries(s_seg, nseg, lds_lo == 0);
         PROF_T(t3);
         // 3. classify.  head / larger-mate-before come from the ballots of the record's own segment plus the carry;
         //    only the duplicate test (same read AND same reference earlier in the run: Q1) walks back through LDS.
@@ -292,28 +344,10 @@ __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Ac
             const uint32_t lpos = k * kRBlock + threadIdx.x;
             const uint32_t li = off + lpos;
             const uint32_t me = lpos < n_here ? s_meta[li] : M_RUN;  // past the end: not mapped, a run of its own
-            const uint32_t valid = me >> 31, my_mate = (me >> 28) & 3u;
-            const uint64_t starts = __ballot((me >> 30) & 1u);
-            const uint64_t v0 = __ballot(valid && my_mate == 0u), v1 = __ballot(valid && my_mate == 1u),
-                           v2 = __ballot(valid && my_mate == 2u);
-            const uint64_t ps = starts & le_mask;           // run starts at or before me in this segment
-            const uint32_t from = ps ? 63u - static_cast<uint32_t>(__builtin_clzll(ps)) : 0u;
-            const uint64_t bit_from = 1ull << from;
-            // a mapped record with mate m in [from, lane)  <=>  (v_m & lanes before me) >= bit(from)
-            uint32_t seen = ((v0 & lt_mask) >= bit_from ? 1u : 0u) | ((v1 & lt_mask) >= bit_from ? 2u : 0u) |
-                            ((v2 & lt_mask) >= bit_from ? 4u : 0u);
-            uint32_t len = lane - from, open = 0u;
-            if (!ps) {  // my run starts in an earlier segment
-                const uint32_t c = s_seg[li >> 6];
-                seen |= c & 7u;
-                len += (c >> 8) & 0xfffffu;
-                open = c >> 31;
-            }
-            const uint32_t head = valid & (((seen >> my_mate) & 1u) ^ 1u);
-            const uint32_t gb = valid & ((seen >> (my_mate + 1u)) != 0u ? 1u : 0u);
+            const RunScan rs = run_scan(me, s_seg[li >> 6], true, lane, lt_mask, le_mask);
             me_[k] = me;
-            wl_[k] = valid ? min(len, li) : 0u;  // compare with this many records before me (all staged unless open)
-            st_[k] = head | (gb << 1) | ((open & valid) << 2);
+            wl_[k] = (me >> 31) ? min(rs.len, li) : 0u;  // compare with this many records before me (all staged unless open)
+            st_[k] = rs.head | (rs.gb << 1) | (rs.open << 2);
         }
         PROF_T(t4);
         uint32_t dup_[kQItems];  // minimum over the walked records of (their word ^ mine) & compared bits: 0 <=> duplicate
@@ -526,50 +560,21 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
                 if ((j & ~63u) < wn) {  // wave-uniform
                     const uint64_t mine = Acc::key_bits(raw[k]);
                     const uint32_t seg = j >> 6;
-                    const uint64_t carry_key = seg ? s_last[seg - 1u] : before;
-                    const uint32_t plo = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key),
-                                                                     static_cast<uint32_t>(mine), 0x138, 0xf, 0xf, false);
-                    const uint32_t phi = __builtin_amdgcn_update_dpp(static_cast<uint32_t>(carry_key >> 32),
-                                                                     static_cast<uint32_t>(mine >> 32), 0x138, 0xf, 0xf,
-                                                                     false);
+                    const uint64_t prev = previous_key(mine, seg ? s_last[seg - 1u] : before);
                     uint32_t m = 0u;
                     if (j < wn) {
                         m = acc.meta(raw[k], bad);
-                        if (lds_lo + j == 0u || !Acc::same_run(mine, (static_cast<uint64_t>(phi) << 32) | plo)) m |= M_RUN;
+                        if (lds_lo + j == 0u || !Acc::same_run(mine, prev)) m |= M_RUN;
                         s_meta[j] = m;
                     }
-                    const uint64_t starts = __ballot((m >> 30) & 1u);
-                    const bool mapped = m >> 31;
-                    const uint32_t mate = (m >> 28) & 3u;
-                    const uint64_t tail = starts ? ~((1ull << (63 - __builtin_clzll(starts))) - 1ull) : ~0ull;
-                    const uint32_t seen = ((__ballot(mapped && mate == 0u) & tail) ? 1u : 0u) |
-                                          ((__ballot(mapped && mate == 1u) & tail) ? 2u : 0u) |
-                                          ((__ballot(mapped && mate == 2u) & tail) ? 4u : 0u);
-                    if (lane == 0)
-                        s_seg[seg] = seen | (static_cast<uint32_t>(__popcll(tail)) << 8) | (starts ? SEG_START : 0u);
+                    const uint32_t summary = segment_summary(m);
+                    if (lane == 0) s_seg[seg] = summary;
                 }
             }
         }
         __syncthreads();
-        // 2. carry into each segment (mates seen and records since the run start), as in k_runs
-        uint32_t carry = 0;
-        if (tid < nseg) {
-            uint32_t seen = 0, len = 0, open = 1;
-            for (int p = static_cast<int>(tid) - 1; p >= 0; --p) {
-                const uint32_t sm = s_seg[p];
-                seen |= sm & 7u;
-                len += (sm >> 8) & 0xfffffu;
-                if (sm & SEG_START) {
-                    open = 0;
-                    break;
-                }
-            }
-            if (tid == 0 && lds_lo == 0) open = 0;
-            carry = seen | (len << 8) | (open << 31);
-        }
-        __syncthreads();
-        if (tid < nseg) s_seg[tid] = carry;
-        __syncthreads();
+        // 2. carry into each segment (mates seen and records since the run start)
+        segment_carries(s_seg, nseg, lds_lo == 0);
         // 3. head / larger-mate-before from the ballots of the record's segment plus the carry (k_runs); every mapped
         //    staged record whose run starts inside the window enters the table once, keyed (run start, mate, ref), with
         //    atomicMin(window index): `first` <=> the minimum of the key is the record itself.  (The first version also
@@ -581,27 +586,11 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
             const uint32_t j = k * kHBlock + tid;
             const bool live = j < wn;
             const uint32_t me = live ? s_meta[j] : M_RUN;
-            const uint32_t valid = me >> 31, my_mate = (me >> 28) & 3u;
-            const uint64_t starts = __ballot((me >> 30) & 1u);
-            const uint64_t v0 = __ballot(valid && my_mate == 0u), v1 = __ballot(valid && my_mate == 1u),
-                           v2 = __ballot(valid && my_mate == 2u);
-            const uint64_t ps = starts & le_mask;
-            const uint32_t from = ps ? 63u - static_cast<uint32_t>(__builtin_clzll(ps)) : 0u;
-            const uint64_t bit_from = 1ull << from;
-            uint32_t seen = ((v0 & lt_mask) >= bit_from ? 1u : 0u) | ((v1 & lt_mask) >= bit_from ? 2u : 0u) |
-                            ((v2 & lt_mask) >= bit_from ? 4u : 0u);
-            uint32_t len = lane - from, open = 0u;
-            if (!ps && live) {
-                const uint32_t c = s_seg[j >> 6];
-                seen |= c & 7u;
-                len += (c >> 8) & 0xfffffu;
-                open = c >> 31;
-            }
-            const uint32_t head = valid & (((seen >> my_mate) & 1u) ^ 1u);
-            const uint32_t gb = valid & ((seen >> (my_mate + 1u)) != 0u ? 1u : 0u);
+            const RunScan rs = run_scan(me, live ? s_seg[j >> 6] : 0u, live, lane, lt_mask, le_mask);
+            const uint32_t valid = me >> 31, open = rs.open;
             me_[k] = me;
-            rs_[k] = j - min(len, j);
-            st_[k] = head | (gb << 1) | ((open & valid) << 2);
+            rs_[k] = j - min(rs.len, j);
+            st_[k] = rs.head | (rs.gb << 1) | (rs.open << 2);
             if (valid && !open)
                 hash_put_min(s_tab, (static_cast<uint64_t>(rs_[k]) << 30) | (me & M_IDENT), j);
         }

@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
         AlignmentFile f;
         if (!f.open(p)) { printf("%s: %s\n", p.c_str(), f.error().c_str()); continue; }
         RecordBatch b; long n, tot = 0;
-        while ((n = f.read_batch(b, 10000, true)) > 0) { tot += n; b.clear(); }
+        while ((n = f.read_batch(b, 1 << 20, true)) > 0) { tot += n; b.clear(); }  // large requests: the parallel record walk
         printf("%s: refs=%zu records=%ld rc=%ld %s\n", p.c_str(), f.ref_names().size(), tot, n, f.error().c_str());
     }
 }

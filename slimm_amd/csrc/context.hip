@@ -113,6 +113,7 @@ struct slimm_ctx {
     DevBuf<uint8_t> c_fl;
     DevBuf<uint32_t> tgt_ref, tgt_gbin, read_off;
     DevBuf<uint2> tile_cnt;
+    DevBuf<uint4> scan_sums;  // chunk sums of the multi-workgroup tile scan
     DevBuf<uint32_t> tile_valid;
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;
@@ -270,6 +271,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->read_off.ensure(static_cast<size_t>(n) + 2));
     HIP_TRY(c, c->tile_cnt.ensure(nt));
+    HIP_TRY(c, c->scan_sums.ensure(kScanMaxChunks));
     HIP_TRY(c, c->tile_valid.ensure(nt));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
@@ -626,7 +628,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_V, -1, nullptr);
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_V, -1, nullptr, nullptr, -1, nullptr, c->scan_sums.p);
         }
         {
             KernelTimer t(c, K_COMPACT);
@@ -645,7 +647,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, nullptr, -1, c->tail());
+            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, nullptr, -1, c->tail(),
+                              c->scan_sums.p);
         }
         {
             KernelTimer t(c, K_BUILD_CSR);
@@ -663,7 +666,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_SCAN);
             launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, c->tile_valid.p, CNT_V,
-                              c->tail());
+                              c->tail(), c->scan_sums.p);
         }
         {
             KernelTimer t(c, K_BUILD_CSR);

@@ -64,8 +64,10 @@ struct DeviceRecords {
 uint32_t num_tiles(uint32_t n);
 
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
+constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off, const uint32_t* extra = nullptr, int slot_extra = -1, uint32_t* tail = nullptr);
+                       uint32_t* read_off, const uint32_t* extra = nullptr, int slot_extra = -1, uint32_t* tail = nullptr,
+                       uint4* sums = nullptr);
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);

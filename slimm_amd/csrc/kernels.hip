@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -86,24 +87,68 @@ __global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_scan_tiles: exclusive scan of the per-tile (x, y) counts by ONE workgroup; totals go to counters[slot_x/slot_y]
-// and to tile_cnt[ntiles].  ntiles = n/2048, so even 10^9 records are < 500k entries: a few microseconds.
+// k_scan_tiles: exclusive scan of the per-tile (x, y) counts; totals go to counters[slot_x/slot_y] and to
+// tile_cnt[ntiles].  Up to 32 K tiles (64 M records) ONE workgroup does it in ~10 us; beyond that the tiles are cut
+// into chunks of kScanChunk, k_scan_sums reduces every chunk, and the workgroups of k_scan_tiles start from the sum of
+// the chunks before theirs (one workgroup needed 0.86 ms for the 488 K tiles of 10^9 records).
 // When read_off != nullptr also writes the CSR sentinel read_off[total_x] = total_y.
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanChunk = 8192;  // tiles per workgroup of the chunked scan (SLIMM_SCAN_CHUNK overrides, for tests)
+
+__global__ __launch_bounds__(1024) void k_scan_sums(const uint2* __restrict__ tile_cnt, uint32_t ntiles,
+                                                    const uint32_t* __restrict__ extra, uint4* __restrict__ sums,
+                                                    uint32_t chunk) {
+    __shared__ uint4 s_w[16];
+    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, ntiles);
+    uint32_t x = 0, y = 0, e = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        const uint2 v = tile_cnt[i];
+        x += v.x;
+        y += v.y;
+        if (extra) e += extra[i];
+    }
+    x = wave_sum(x);
+    y = wave_sum(y);
+    e = wave_sum(e);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = make_uint4(x, y, e, 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint4 t = make_uint4(0u, 0u, 0u, 0u);
+        for (int w = 0; w < 16; ++w) {
+            t.x += s_w[w].x;
+            t.y += s_w[w].y;
+            t.z += s_w[w].z;
+        }
+        sums[blockIdx.x] = t;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cnt, uint32_t ntiles,
                                                      uint32_t* __restrict__ counters, int slot_x, int slot_y,
                                                      uint32_t* __restrict__ read_off, const uint32_t* __restrict__ extra,
-                                                     int slot_extra, uint32_t* __restrict__ tail) {
+                                                     int slot_extra, uint32_t* __restrict__ tail,
+                                                     const uint4* __restrict__ sums, uint32_t chunk) {
     // coalesced chunks of 1024 entries with a running carry: wave scan by shuffles, wave totals through LDS
     __shared__ uint2 s_wave[16];
     __shared__ uint32_t s_extra[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // one workgroup: the whole range; several: my chunk, starting from the totals of the chunks before it
+    const uint32_t lo = gridDim.x > 1 ? blockIdx.x * chunk : 0u;
+    const uint32_t hi = gridDim.x > 1 ? min(lo + chunk, ntiles) : ntiles;
     uint2 carry = make_uint2(0u, 0u);
-    uint32_t ex = 0;
-    for (uint32_t c0 = 0; c0 < ntiles; c0 += 1024) {
+    uint32_t ex = 0, ex_before = 0;
+    if (gridDim.x > 1) {
+        for (uint32_t g = 0; g < blockIdx.x; ++g) {  // (uniform loads, at most a few dozen chunks)
+            const uint4 t = sums[g];
+            carry.x += t.x;
+            carry.y += t.y;
+            ex_before += t.z;
+        }
+    }
+    for (uint32_t c0 = lo; c0 < hi; c0 += 1024) {
         const uint32_t i = c0 + tid;
-        uint2 v = (i < ntiles) ? tile_cnt[i] : make_uint2(0u, 0u);
-        if (extra && i < ntiles) ex += extra[i];
+        uint2 v = (i < hi) ? tile_cnt[i] : make_uint2(0u, 0u);
+        if (extra && i < hi) ex += extra[i];
         uint2 inc = v;  // inclusive scan inside the wave
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -126,11 +171,12 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cn
             total.x += t.x;
             total.y += t.y;
         }
-        if (i < ntiles) tile_cnt[i] = make_uint2(before.x + inc.x - v.x, before.y + inc.y - v.y);
+        if (i < hi) tile_cnt[i] = make_uint2(before.x + inc.x - v.x, before.y + inc.y - v.y);
         carry.x += total.x;
         carry.y += total.y;
         __syncthreads();
     }
+    if (blockIdx.x + 1 != gridDim.x) return;  // the workgroup of the last chunk publishes the totals
     ex = wave_sum(ex);
     if (lane == 0) s_extra[wave] = ex;
     __syncthreads();
@@ -142,7 +188,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cn
         if (read_off) read_off[tot.x] = tot.y;
         uint32_t v = counters[CNT_V];
         if (extra) {
-            uint32_t e = 0;
+            uint32_t e = ex_before;
             for (int w = 0; w < 16; ++w) e += s_extra[w];
             counters[slot_extra] = e;
             if (slot_extra == CNT_V) v = e;
@@ -543,9 +589,19 @@ void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs
 }
 
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off, const uint32_t* extra, int slot_extra, uint32_t* tail) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off, extra,
-                       slot_extra, tail);
+                       uint32_t* read_off, const uint32_t* extra, int slot_extra, uint32_t* tail, uint4* sums) {
+    uint32_t grid = 1, chunk = kScanChunk, above = 32768;
+    if (const char* e = getenv("SLIMM_SCAN_CHUNK")) {  // tests: chunked scan on small inputs
+        chunk = std::max<uint32_t>(1u, static_cast<uint32_t>(atol(e)));
+        above = chunk;
+    }
+    chunk = std::max(chunk, (ntiles + kScanMaxChunks - 1) / kScanMaxChunks);  // sums holds kScanMaxChunks entries
+    if (sums && ntiles > above) {
+        grid = (ntiles + chunk - 1) / chunk;
+        hipLaunchKernelGGL(k_scan_sums, dim3(grid), dim3(1024), 0, st, tile_cnt, ntiles, extra, sums, chunk);
+    }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(grid), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off, extra,
+                       slot_extra, tail, sums, chunk);
 }
 
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,

@@ -359,6 +359,7 @@ def test_shards_on_one_gpu_through_the_sliced_exchange(world):
     vecs = []
     for j, e in enumerate(engines):
         received = torch.cat([summaries[i][head + j * chunk:head + (j + 1) * chunk] for i in range(world)])
+        torch.cuda.synchronize()   # torch's stream wrote `received`; the library reads it on its own stream
         vecs.append(e.merge_summary_slices(received, world, j))
     total = torch.stack([v.clone() for v in vecs]).sum(dim=0).to(torch.int32)
     for v in vecs:
@@ -431,6 +432,15 @@ def test_contexts_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) < 64 << 20, (free0, free1)   # (allocator granularity, not a per-context leak)
+
+
+def test_chunked_tile_scan(monkeypatch):
+    """Above 32 K record tiles (64 M records) the tile scan runs on several workgroups; forced here on small inputs with
+    chunks of 16 tiles (the last chunk ragged), through both record orders."""
+    monkeypatch.setenv("SLIMM_SCAN_CHUNK", "16")
+    w = make_workload(CONFIGS["config2"], seed=35, n_records=250_000)   # 123 tiles -> 8 chunks
+    check(w)
+    check(w, grouped=False)
 
 
 def test_kernel_timing_reports_every_kernel():

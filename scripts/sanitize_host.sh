@@ -10,6 +10,7 @@ FLAGS="-std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer"
 g++ $FLAGS "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
     "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -o "$W/san_readers"
 g++ $FLAGS "$ROOT/tests/native/host_profile_bench.cpp" "$ROOT/slimm_amd/csrc/host_profile.cpp" -o "$W/san_profile"
+g++ $FLAGS "$ROOT/slimm_amd/csrc/host/slimm_build_main.cpp" "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -o "$W/san_build"
 # ThreadSanitizer over the parallel BGZF inflate / record decode
 g++ -std=c++17 -g -O1 -fsanitize=thread "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
     "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -o "$W/tsan_readers"
@@ -55,6 +56,32 @@ r = subprocess.run([f"{d}/san_profile"], capture_output=True, text=True)
 print(r.stdout)
 if r.returncode or r.stderr.strip():
     bad += 1; print("SANITIZER OUTPUT:\n" + r.stderr)
+# slimm_build: well-formed dumps (plain and gzip'ed FASTA, tiny batches), then cut and garbled ones
+import pathlib
+from slimm_amd.synth import synth_taxonomy
+from tests.ncbi_dumps import write_dumps
+for k, (gz, batch) in enumerate([(False, "1000000"), (True, "7")]):
+    t = pathlib.Path(d) / f"dumps{k}"
+    t.mkdir(exist_ok=True)
+    dd = write_dumps(t, synth_taxonomy(400, strain_level=bool(k), hole_every=3), gz_fasta=gz)
+    runs = [dd]
+    if k == 0:
+        cut = dict(dd)
+        for key in ("nodes", "names"):
+            b = open(dd[key], "rb").read()
+            open(dd[key] + ".cut", "wb").write(b[:len(b) // 2 + 3])
+            cut[key] = dd[key] + ".cut"
+        open(f"{t}/junk.a2t", "wb").write(b"\t\t\t\n\n\xff\xfe\t1\nACC000001\nACC000002\t\t99999999999999999999\n" + os.urandom(4096))
+        cut["acc"] = [f"{t}/junk.a2t"] + dd["acc"]
+        open(f"{t}/junk.fa", "wb").write(b">\n>>|\n@x\n" + os.urandom(2048) + b"\n>ACC000003.1 z")
+        runs += [cut, dict(cut, fasta=f"{t}/junk.fa")]
+    for rr in runs:
+        r = subprocess.run([f"{d}/san_build", "-nm", rr["names"], "-nd", rr["nodes"], "-o", f"{t}/o.sldb", "-b", batch, rr["fasta"]]
+                           + rr["acc"], capture_output=True, text=True, errors="replace")
+        noise = [l for l in r.stderr.splitlines() if not l.startswith(("[MSG]", "[WARNING!]", "[VERBOSE"))]
+        if r.returncode or noise:
+            bad += 1; print("SANITIZER OUTPUT (slimm_build):\n" + r.stderr)
+print("slimm_build under sanitizers: done")
 print("sanitizer findings:", bad)
 sys.exit(1 if bad else 0)
 PY

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../../include/slimm_hip.h"
+#include "accession.hpp"
 #include "alignment_file.hpp"
 #include "sldb.hpp"
 
@@ -73,16 +74,6 @@ std::vector<std::string> get_bam_files_in_directory(const std::string& directory
     }
     closedir(dir);
     return out;
-}
-
-std::string get_accession_id(const std::string& name) {  // src/misc.hpp:415-422
-    size_t i = 0;
-    while (i < name.size()) {
-        unsigned char c = static_cast<unsigned char>(name[i]);
-        if (c == '.' || c == '|' || c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f') break;
-        ++i;
-    }
-    return name.substr(0, i);
 }
 
 struct Lap {  // Timer<> of src/timer.hpp: whole seconds

@@ -73,3 +73,33 @@ def write_sldb(path, taxonomy):
         for t, r, n in zip(taxonomy.tax_id, taxonomy.tax_rank, taxonomy.tax_name):
             b = n.encode()
             f.write(struct.pack("<IIQ", int(t), int(r), len(b)) + b)
+
+
+def read_sldb(path):
+    """Inverse of write_sldb: ({accession: [taxids]}, {taxid: (rank, name)}), entries in file order."""
+    with open(path, "rb") as f:
+        b = f.read()
+    o = 0
+
+    def u64():
+        nonlocal o
+        v = struct.unpack_from("<Q", b, o)[0]
+        o += 8
+        return v
+
+    ac, tn = {}, {}
+    for _ in range(u64()):
+        n = u64()
+        a = b[o:o + n].decode()
+        o += n
+        c = u64()
+        ac[a] = list(struct.unpack_from("<%dI" % c, b, o))
+        o += 4 * c
+    for _ in range(u64()):
+        t, r = struct.unpack_from("<II", b, o)
+        o += 8
+        n = u64()
+        tn[t] = (r, b[o:o + n].decode())
+        o += n
+    assert o == len(b)
+    return ac, tn

@@ -114,3 +114,21 @@ def test_cli_no_mapped_reads_and_bad_input(tmp_path):
     assert r.returncode == 1 and "is not a file use -d option" in r.stderr
     r = subprocess.run([CLI, "-r", "kingdom", db, inp], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def test_cli_on_a_database_made_by_slimm_build(tmp_path):
+    # the whole tool chain of the reference: slimm_build (NCBI dumps + FASTA -> .sldb) then slimm (BAM + .sldb -> profile)
+    from tests.ncbi_dumps import write_dumps
+    w = with_names(make_workload(CONFIGS["config1"], seed=44))
+    d = write_dumps(tmp_path, w.taxonomy, versioned_ids=False)
+    db = str(tmp_path / "built.sldb")
+    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm_build"), "-nm", d["names"], "-nd", d["nodes"], "-o", db, "-b", "97",
+                        d["fasta"], *d["acc"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    inp = str(tmp_path / "sample.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp])
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    check_outputs(out, "sample", o)

@@ -1,0 +1,133 @@
+"""slimm_build (reference src/slimm_build.cpp) against the plain-Python restatement in
+oracle/build_db.py and against the synthetic taxonomy its inputs were derived from.  Host only: no GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import build_db
+from slimm_amd.synth import synth_taxonomy
+from tests.bam_io import read_sldb
+from tests.ncbi_dumps import write_dumps
+
+BUILDER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimm_amd", "slimm_build")
+
+
+def run_builder(d, out, *extra, check=True):
+    cmd = [BUILDER, "-nm", d["names"], "-nd", d["nodes"], "-o", out, *extra, d["fasta"], *d["acc"]]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    if check:
+        assert r.returncode == 0, r.stderr
+    return r
+
+
+def expected_from(tax):
+    ac = {a: [int(x) for x in row] for a, row in zip(tax.accessions, tax.lineage)}
+    tn = {int(t): (int(r), n) for t, r, n in zip(tax.tax_id, tax.tax_rank, tax.tax_name)}
+    return ac, tn
+
+
+@pytest.mark.parametrize("strain_level,holes,gz,batch", [(False, 0, False, 1000000), (True, 0, True, 37),
+                                                           (False, 3, False, 1), (True, 4, False, 500)])
+def test_builder_matches_oracle_and_taxonomy(tmp_path, strain_level, holes, gz, batch):
+    tax = synth_taxonomy(300, strain_level=strain_level, hole_every=holes)
+    d = write_dumps(tmp_path, tax, gz_fasta=gz)
+    out = str(tmp_path / "db.sldb")
+    run_builder(d, out, "-b", str(batch))
+    ac, tn = read_sldb(out)
+    o_ac, o_tn, missed = build_db.build(d["fasta"], d["acc"], d["nodes"], d["names"], batch=batch)
+    assert missed == []
+    assert ac == o_ac and tn == o_tn                       # the restatement of the reference
+    e_ac, e_tn = expected_from(tax)                        # and what the inputs were made from
+    assert ac == e_ac
+    assert tn == e_tn
+    assert not os.path.exists(str(tmp_path / "db.missed"))
+
+
+def test_species_level_accession_is_recorded_as_species(tmp_path):
+    # an accession whose own taxid IS a species node: lineage[0] == lineage[1], the (strain, name) entry is overwritten
+    # with (species, name) -- reference src/slimm_build.cpp:329 then :338-342
+    tax = synth_taxonomy(20)
+    tax.lineage[:, 0] = tax.lineage[:, 1]
+    keep = ~np.isin(tax.tax_rank, [0])
+    tax.tax_id, tax.tax_rank = tax.tax_id[keep], tax.tax_rank[keep]
+    tax.tax_name = [n for n, k in zip(tax.tax_name, keep) if k]
+    d = write_dumps(tmp_path, tax)
+    out = str(tmp_path / "db.sldb")
+    run_builder(d, out)
+    ac, tn = read_sldb(out)
+    assert (ac, tn) == expected_from(tax)
+    assert all(l[0] == l[1] for l in ac.values())
+    assert all(tn[l[0]][0] == 1 for l in ac.values())
+    assert (ac, tn) == build_db.build(d["fasta"], d["acc"], d["nodes"], d["names"])[:2]
+
+
+def test_batches_first_batch_wins_last_line_in_a_batch_wins(tmp_path):
+    (tmp_path / "r.fa").write_text(">A1.2 x\nAC\n>B1|y\nGT\n>C1\nAA\n>D1 never mapped\nCC\n")
+    (tmp_path / "nodes.dmp").write_text("".join(f"{t}\t|\t{p}\t|\t{r}\t|\n" for t, p, r in
+                                                [(1, 1, "no rank"), (10, 1, "superkingdom"), (20, 10, "genus"),
+                                                 (30, 20, "species"), (31, 20, "species"), (32, 30, "no rank")]))
+    (tmp_path / "names.dmp").write_text("".join(f"{t}\t|\tname{t}\t|\t\t|\tscientific name\t|\n" for t in (1, 10, 20, 30, 31, 32)))
+    # batch of 3 lines: [header, A1->30, A1->31] -> A1 = 31 (last of the batch);  [B1->30, C1->32, B1->31] -> B1 = 31;
+    # [A1->32, C1->30] both already placed -> ignored;  the header line carries taxid 0 into the map under "accession"
+    (tmp_path / "m.a2t").write_text("accession\taccession.version\ttaxid\tgi\n"
+                                    "A1\tA1.2\t30\t1\nA1\tA1.2\t31\t1\nB1\tB1.1\t30\t1\nC1\tC1.1\t32\t1\nB1\tB1.1\t31\t1\n"
+                                    "A1\tA1.2\t32\t1\nC1\tC1.1\t30\t1\n")
+    d = {"fasta": str(tmp_path / "r.fa"), "nodes": str(tmp_path / "nodes.dmp"), "names": str(tmp_path / "names.dmp"),
+         "acc": [str(tmp_path / "m.a2t")]}
+    out = str(tmp_path / "o.sldb")
+    r = run_builder(d, out, "-b", "3", "-v")
+    ac, tn = read_sldb(out)
+    assert ac == {"A1": [31, 31, 20, 0, 0, 0, 0, 10], "B1": [31, 31, 20, 0, 0, 0, 0, 10], "C1": [32, 30, 20, 0, 0, 0, 0, 10]}
+    assert tn == {31: (1, "name31"), 32: (0, "name32"), 30: (1, "name30"), 20: (2, "name20"), 10: (7, "name10")}
+    o_ac, o_tn, missed = build_db.build(d["fasta"], d["acc"], d["nodes"], d["names"], batch=3)
+    assert (ac, tn) == (o_ac, o_tn) and missed == ["D1"]
+    assert (tmp_path / "o.missed").read_text() == "D1\n"    # reference src/slimm_build.cpp:200-219
+    assert "1 accessions (D1, ...) were not mapped to taxaid" in r.stderr
+    assert "[VERBOSE MSG] mapping file: [1/1]" in r.stderr
+    # one batch holding everything: the last line of every accession wins instead
+    run_builder(d, out, "-b", "100")
+    ac2, _ = read_sldb(out)
+    assert [ac2[k][0] for k in ("A1", "B1", "C1")] == [32, 31, 30]
+    assert ac2 == build_db.build(d["fasta"], d["acc"], d["nodes"], d["names"], batch=100)[0]
+
+
+def test_fastq_ids_and_unknown_taxid(tmp_path):
+    (tmp_path / "r.fq").write_text("@Q1.1 d\nACGT\n+\n@@@@\n@Q2\nAC\nGT\n+Q2\n!!\n@!\n")
+    (tmp_path / "nodes.dmp").write_text("1\t|\t1\t|\tno rank\t|\n")
+    (tmp_path / "names.dmp").write_text("1\t|\troot\t|\t\t|\tscientific name\t|\n")
+    (tmp_path / "m").write_text("Q1\tQ1.1\t777\t0\nQ2\tQ2.1\t1\t0\n")
+    d = {"fasta": str(tmp_path / "r.fq"), "nodes": str(tmp_path / "nodes.dmp"), "names": str(tmp_path / "names.dmp"),
+         "acc": [str(tmp_path / "m")]}
+    out = str(tmp_path / "o.sldb")
+    run_builder(d, out)
+    ac, tn = read_sldb(out)
+    assert ac == {"Q1": [777, 0, 0, 0, 0, 0, 0, 0], "Q2": [1, 0, 0, 0, 0, 0, 0, 0]}
+    assert tn == {777: (0, ""), 1: (0, "root")}             # a taxid nodes.dmp does not know: empty name, no lineage
+
+
+def test_command_line_errors(tmp_path):
+    tax = synth_taxonomy(4)
+    d = write_dumps(tmp_path, tax)
+    assert run_builder(d, str(tmp_path / "db.bin"), check=False).returncode == 1          # must end in .sldb
+    r = subprocess.run([BUILDER, "-nd", d["nodes"], d["fasta"], d["acc"][0]], capture_output=True, text=True)
+    assert r.returncode == 1 and "required" in r.stderr
+    r = subprocess.run([BUILDER, "-nm", d["names"], "-nd", d["nodes"], d["fasta"]], capture_output=True, text=True)
+    assert r.returncode == 1
+    bad = dict(d, fasta=str(tmp_path / "nope.fa"))
+    r = run_builder(bad, str(tmp_path / "x.sldb"), check=False)
+    assert r.returncode == 1 and "Unable to open contigs File" in r.stderr
+    assert subprocess.run([BUILDER, "--help"], capture_output=True).returncode == 0
+
+
+def test_database_round_trips_through_the_products_reader(tmp_path):
+    # the same entries as the independent Python writer the CLI tests feed to `slimm`
+    tax = synth_taxonomy(50, hole_every=5)
+    d = write_dumps(tmp_path, tax)
+    out = str(tmp_path / "db.sldb")
+    run_builder(d, out)
+    from tests.bam_io import write_sldb
+    ref = str(tmp_path / "ref.sldb")
+    write_sldb(ref, tax)
+    assert read_sldb(out) == read_sldb(ref)

@@ -585,11 +585,16 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     if (!c) return SLIMM_E_INVALID;
     if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context: install results with slimm_set_coverage_columns");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "already analysed; reset first");
+    HostTrace tr("analyze_alignments");
     (void)hipSetDevice(c->device);
     const uint32_t n = c->rec.n;
     int rc = ensure_work_buffers(c, n);
     if (rc != SLIMM_OK) return rc;
+    tr.mark("set device + buffers");
     hipStream_t st = c->stream;
+    const bool no_fused_emit = getenv("SLIMM_NO_FUSED_EMIT") != nullptr;  // tests: the scan-kernel path
+    const bool fused_emit = c->order == SLIMM_ORDER_GROUPED && num_tiles(n) > 0 && num_tiles(n) <= kFusedEmitTiles &&
+                            !no_fused_emit;
     {
         KernelTimer t(c, K_MEMSET);
         if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)
@@ -608,6 +613,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             }
         }
         if (c->order == SLIMM_ORDER_GROUPED) {  // the same launch clears the counters and picks the classification kernel
+            if (fused_emit) {  // chunk sums of the per-tile counts, in place of a scan launch
+                z.p[0] = reinterpret_cast<uint32_t*>(c->scan_sums.p);
+                z.n[0] = 4u * ((num_tiles(n) + 63u) / 64u);
+            }
             launch_zero_pick_raw(st, z, c->rec, c->counters.p);
         } else {
             z.p[0] = c->counters.p;
@@ -661,9 +670,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         for (int part = 1; part < 3; ++part) {  // (part 0, the pick, rode along with the clearing kernel)
             KernelTimer t(c, ids[part]);
             launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
-                            c->c_fl.p, c->tile_cnt.p, c->tile_valid.p, part);
+                            c->c_fl.p, c->tile_cnt.p, c->tile_valid.p, part,
+                            fused_emit ? reinterpret_cast<uint32_t*>(c->scan_sums.p) : nullptr);
         }
-        {
+        if (!fused_emit) {
             KernelTimer t(c, K_SCAN);
             launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, c->tile_valid.p, CNT_V,
                               c->tail(), c->scan_sums.p);
@@ -671,7 +681,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_BUILD_CSR);
             launch_emit_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, c->d_geo.p, half_read, hc.bin_width, c->c_fl.p,
-                            c->counters.p, c->tile_cnt.p, c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p);
+                            c->counters.p, c->tile_cnt.p, c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p,
+                            fused_emit ? reinterpret_cast<const uint32_t*>(c->scan_sums.p) : nullptr,
+                            fused_emit ? c->tail() : nullptr);
         }
     }
     if (c->use_tiles) {
@@ -719,6 +731,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     }
     HIP_TRY(c, hipGetLastError());
     c->analyzed = true;
+    tr.mark("phase A launches");
     return SLIMM_OK;
 }
 
@@ -1156,7 +1169,9 @@ int slimm_get_reads_lca_count(slimm_ctx* c) {
     if (!c) return SLIMM_E_INVALID;
     if (c->no_hits) return SLIMM_E_NO_HITS;
     if (!c->filtered || !c->host->have_partials) return fail(c, SLIMM_E_INVALID, "call slimm_filter_alignments first");
+    HostTrace tr("get_reads_lca_count");
     c->host->propagate();
+    tr.mark("propagate");
     c->counted = true;
     return SLIMM_OK;
 }
@@ -1186,12 +1201,15 @@ int slimm_write_abundance(slimm_ctx* c, const char** text, uint64_t* len) {
 int slimm_write_abundance_file(slimm_ctx* c, const char* path) {
     const char* text = nullptr;
     uint64_t len = 0;
+    HostTrace tr("write_abundance_file");
     int rc = slimm_write_abundance(c, &text, &len);
     if (rc != SLIMM_OK) return rc;
+    tr.mark("profile text");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(c, SLIMM_E_INVALID, "cannot open %s for writing", path);
     size_t w = fwrite(text, 1, len, f);
     fclose(f);
+    tr.mark("open + write + close");
     if (w != len) return fail(c, SLIMM_E_INVALID, "short write to %s", path);
     return SLIMM_OK;
 }
@@ -1248,6 +1266,7 @@ int slimm_get_ref_columns(slimm_ctx* c, slimm_ref_columns* o) {
         if (h.have_valid) memcpy(o->valid, h.valid.data(), R);
         else memset(o->valid, 0, R);
     }
+    if (o->abundance || o->uniq_abundance) h.abundances();
     if (o->abundance) memcpy(o->abundance, h.abundance.data(), R * 4);
     if (o->uniq_abundance) memcpy(o->uniq_abundance, h.uniq_abundance.data(), R * 4);
     return SLIMM_OK;

@@ -111,7 +111,8 @@ public:
     uint32_t profile_count = 0, profile_failed = 0;
     std::vector<uint32_t> reads_count, uniq_reads_count, uniq_reads_count2, nz_cov, nz_ucov;
     std::vector<uint8_t> valid;
-    std::vector<float> abundance, uniq_abundance;
+    std::vector<float> abundance, uniq_abundance;  // valid after abundances()
+    void abundances();
     const std::vector<uint32_t>& nz_uniq_cov2() const { return nz_ucov2_; }
 
     // taxon counts / children.  stage 0 = direct LCA hits, stage 1 = after propagation
@@ -152,6 +153,7 @@ private:
     std::vector<uint32_t> touched_;       // taxa whose count / children entry exists (cleared cheaply on the next file)
     std::string profile_;
     bool profile_ready_ = false;
+    bool abundance_ready_ = false;
     std::string empty_, zero_name_;
 };
 

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restri
 // the chunks before theirs (one workgroup needed 0.86 ms for the 488 K tiles of 10^9 records).
 // When read_off != nullptr also writes the CSR sentinel read_off[total_x] = total_y.
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanRegs = 16;    // entries per thread of the one-pass scan
 constexpr uint32_t kScanChunk = 8192;  // tiles per workgroup of the chunked scan (SLIMM_SCAN_CHUNK overrides, for tests)
 
 __global__ __launch_bounds__(1024) void k_scan_sums(const uint2* __restrict__ tile_cnt, uint32_t ntiles,
@@ -145,7 +146,58 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cn
             ex_before += t.z;
         }
     }
-    for (uint32_t c0 = lo; c0 < hi; c0 += 1024) {
+    const bool one_pass = gridDim.x == 1 && ntiles > 0 && ntiles <= 1024u * kScanRegs;
+    if (one_pass) {
+        // The usual case (up to 16 K tiles = 16 M records): every thread takes `per` consecutive entries into registers
+        // with all its loads in flight together, scans them, and ONE workgroup scan of the thread totals follows --
+        // a loop of 1024-entry chunks pays a load round trip and two barriers per chunk (10 us at 9.8 K tiles).
+        const uint32_t per = (ntiles + 1023u) >> 10, base = tid * per;
+        uint2 v[kScanRegs];
+        uint2 mine = make_uint2(0u, 0u);
+#pragma unroll
+        for (uint32_t k = 0; k < kScanRegs; ++k) {
+            const uint32_t i = base + k;
+            const bool in = k < per && i < ntiles;
+            const uint32_t ic = min(i, ntiles - 1u);  // clamped: a load behind a per-element branch is a round trip of its own
+            const uint2 t = tile_cnt[ic];
+            const uint32_t e = extra ? extra[ic] : 0u;
+            v[k] = in ? t : make_uint2(0u, 0u);
+            if (in) ex += e;
+            mine.x += v[k].x;
+            mine.y += v[k].y;
+        }
+        uint2 inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
+            if (lane >= static_cast<uint32_t>(o)) {
+                inc.x += ax;
+                inc.y += ay;
+            }
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint2 run = make_uint2(inc.x - mine.x, inc.y - mine.y);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint2 t = s_wave[w];
+            if (w < static_cast<int>(wave)) {
+                run.x += t.x;
+                run.y += t.y;
+            }
+            carry.x += t.x;
+            carry.y += t.y;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kScanRegs; ++k) {
+            const uint32_t i = base + k;
+            if (k < per && i < ntiles) tile_cnt[i] = run;
+            run.x += v[k].x;
+            run.y += v[k].y;
+        }
+        __syncthreads();
+    }
+    for (uint32_t c0 = lo; c0 < hi && !one_pass; c0 += 1024) {
         const uint32_t i = c0 + tid;
         uint2 v = (i < hi) ? tile_cnt[i] : make_uint2(0u, 0u);
         if (extra && i < hi) ex += extra[i];

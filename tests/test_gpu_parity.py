@@ -438,9 +438,22 @@ def test_chunked_tile_scan(monkeypatch):
     """Above 32 K record tiles (64 M records) the tile scan runs on several workgroups; forced here on small inputs with
     chunks of 16 tiles (the last chunk ragged), through both record orders."""
     monkeypatch.setenv("SLIMM_SCAN_CHUNK", "16")
+    monkeypatch.setenv("SLIMM_NO_FUSED_EMIT", "1")    # grouped input up to 16 K tiles needs no scan kernel otherwise
     w = make_workload(CONFIGS["config2"], seed=35, n_records=250_000)   # 123 tiles -> 8 chunks
     check(w)
     check(w, grouped=False)
+
+
+@pytest.mark.parametrize("n_records", [2048 * 64, 2048 * 64 + 1, 2048 * 129 - 5, 1_500_000])
+def test_tile_offsets_from_chunk_sums(n_records, monkeypatch):
+    """Grouped input of up to 16 K tiles: k_emit derives its offsets from per-chunk sums (64 tiles per chunk) instead of a
+    scan launch; chunk boundaries exact, one past, ragged, and many chunks -- and the same answers with the scan kernel."""
+    w = make_workload(CONFIGS["config2"], seed=36, n_records=n_records)
+    check(w)                                          # chunk sums by the idle hash launch
+    monkeypatch.setenv("SLIMM_RUNS_KERNEL", "hash")
+    check(w)                                          # chunk sums by atomics of the hash kernel
+    monkeypatch.setenv("SLIMM_NO_FUSED_EMIT", "1")
+    check(w)
 
 
 def test_kernel_timing_reports_every_kernel():

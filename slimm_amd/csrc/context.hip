@@ -6,7 +6,10 @@
 //   filter          : lineage rows with the valid bit up (16 bytes per reference); uniq2 / LCA counts / child marks down
 // both through pinned host memory that a copy kernel reads / writes (no DMA-engine start-up latency).
 // Multi-GPU entry points (coverage summary in all-gather or all-to-all form, device-side partials merge) are further down.
+#include <cerrno>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -99,6 +102,8 @@ struct slimm_ctx {
     DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
     DevBuf<uint32_t> d_level_taxon;
     PinBuf<uint4> h_rows16;
+    bool rows16_base_ready = false;    // h_rows16 holds the static part of every row
+    std::vector<uint32_t> rows16_prev; // references whose valid bit is set in h_rows16
     bool use_rows16 = false;
     // records
     DevBuf<uint64_t> in_key;
@@ -924,13 +929,21 @@ int slimm_filter_alignments(slimm_ctx* c) {
     const uint32_t R = c->R, T = c->T;
     bool rows_ride_along = false;
     if (c->use_rows16) {
-        const uint16_t* li = h.level_index().data();
-        for (uint32_t r = 0; r < R; ++r) {
-            const uint16_t* q = li + static_cast<size_t>(r) * 8;
-            const uint32_t v = h.valid[r] ? 0x8000u : 0u;
-            c->h_rows16.p[r] = make_uint4(q[0] | (uint32_t(q[1]) << 16), q[2] | (uint32_t(q[3]) << 16),
-                                          q[4] | (uint32_t(q[5]) << 16), q[6] | ((uint32_t(q[7]) | v) << 16));
+        // the rows are static except for the valid bit (bit 31 of .w): built once, then only the bits of the previous
+        // file's valid references are cleared and this file's are set
+        if (!c->rows16_base_ready) {
+            const uint16_t* li = h.level_index().data();
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint16_t* q = li + static_cast<size_t>(r) * 8;
+                c->h_rows16.p[r] = make_uint4(q[0] | (uint32_t(q[1]) << 16), q[2] | (uint32_t(q[3]) << 16),
+                                              q[4] | (uint32_t(q[5]) << 16), q[6] | (uint32_t(q[7]) << 16));
+            }
+            c->rows16_base_ready = true;
+            c->rows16_prev.clear();
         }
+        for (uint32_t r : c->rows16_prev) c->h_rows16.p[r].w &= 0x7fffffffu;
+        c->rows16_prev = h.valid_list();
+        for (uint32_t r : c->rows16_prev) c->h_rows16.p[r].w |= 0x80000000u;
         tr.mark("rows16 build");
         rows_ride_along = true;  // copied by the clearing kernel below (pinned host memory is device-readable)
         tr.mark("rows16 H2D call");
@@ -1205,12 +1218,19 @@ int slimm_write_abundance_file(slimm_ctx* c, const char* path) {
     int rc = slimm_write_abundance(c, &text, &len);
     if (rc != SLIMM_OK) return rc;
     tr.mark("profile text");
-    FILE* f = fopen(path, "wb");
-    if (!f) return fail(c, SLIMM_E_INVALID, "cannot open %s for writing", path);
-    size_t w = fwrite(text, 1, len, f);
-    fclose(f);
+    // (plain descriptors: three system calls, no stdio buffer to allocate and flush for a few KB written once)
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return fail(c, SLIMM_E_INVALID, "cannot open %s for writing", path);
+    uint64_t w = 0;
+    while (w < len) {
+        const ssize_t k = write(fd, text + w, len - w);
+        if (k < 0 && errno == EINTR) continue;
+        if (k <= 0) break;
+        w += static_cast<uint64_t>(k);
+    }
+    const bool closed = close(fd) == 0;
     tr.mark("open + write + close");
-    if (w != len) return fail(c, SLIMM_E_INVALID, "short write to %s", path);
+    if (w != len || !closed) return fail(c, SLIMM_E_INVALID, "short write to %s", path);
     return SLIMM_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <charconv>
 #include <numeric>
 #include <cstdio>
+#include <cstring>
 #include <unordered_map>
 
 namespace slimm {
@@ -20,6 +21,23 @@ uint32_t rank_from_string(const std::string& s) {  // misc.hpp:37-48
 }
 std::string rank_long(uint32_t r) { return r < 8 ? kRankNames[r] : "intermidiate"; }  // misc.hpp:51-62
 std::string rank_short(uint32_t r) { return r < 8 ? kRankShort[r] : "i"; }            // misc.hpp:64-75
+
+// f(i) for every non-zero a[i], ascending.  The per-file arrays are a few thousand words with a few dozen non-zeros; a
+// plain `if (a[i])` loop over them cost ~1 ns per word, which was most of the host time between and after the two
+// device phases.
+template <typename F>
+static inline void for_each_nonzero(const uint32_t* a, uint32_t n, F f) {
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x[4];
+        memcpy(x, a + i, 32);
+        if ((x[0] | x[1] | x[2] | x[3]) == 0) continue;
+        for (uint32_t k = 0; k < 8; ++k)
+            if (a[i + k]) f(i + k);
+    }
+    for (; i < n; ++i)
+        if (a[i]) f(i);
+}
 
 // misc.hpp:197-216: float32 throughout, sum in input order, ascending sort, partial sums from the top,
 // the `i > 0` guard compared as float like the template does for Type = float.
@@ -137,14 +155,26 @@ void HostProfile::set_coverage(const uint32_t* rc, const uint32_t* urc, const ui
 void HostProfile::set_coverage_strided(const uint32_t* rc, const uint32_t* urc, const uint32_t* nzc, const uint32_t* nzu,
                                        size_t stride, uint32_t hits_, uint32_t matches_) {
     const uint32_t R = cfg_.n_refs;
-    reads_count.resize(R);
-    uniq_reads_count.resize(R);
-    nz_cov.resize(R);
-    nz_ucov.resize(R);
+    reads_count.assign(R, 0u);
+    uniq_reads_count.assign(R, 0u);
+    nz_cov.assign(R, 0u);
+    nz_ucov.assign(R, 0u);
     hits = hits_;
     matches = matches_;
+    // references with anything to say (typically a few per cent): every later pass over the references walks this list
+    active_.clear();
+    if (stride == 4 && nzc == rc + 1 && urc == rc + 2 && nzu == rc + 3) {  // the device's 16-byte rows
+        for (uint32_t i = 0; i < R; ++i) {
+            uint64_t w[2];
+            memcpy(w, rc + 4ull * i, 16);
+            if (w[0] | w[1]) active_.push_back(i);
+        }
+    } else {
+        for (uint32_t i = 0; i < R; ++i)
+            if (rc[i * stride] | urc[i * stride] | nzc[i * stride] | nzu[i * stride]) active_.push_back(i);
+    }
     uint32_t u = 0;
-    for (uint32_t i = 0; i < R; ++i) {
+    for (uint32_t i : active_) {
         reads_count[i] = rc[i * stride];
         uniq_reads_count[i] = urc[i * stride];
         nz_cov[i] = nzc[i * stride];
@@ -157,7 +187,7 @@ void HostProfile::set_coverage_strided(const uint32_t* rc, const uint32_t* urc, 
     // profile, only by the raw-output columns) are computed by abundances() when first asked for
     reference_count = 0;
     matched_ref_length = 0;
-    for (uint32_t i = 0; i < R; ++i) {
+    for (uint32_t i : active_) {
         if (reads_count[i] > 0) {
             ++reference_count;
             matched_ref_length += cfg_.ref_len[i];
@@ -176,7 +206,7 @@ void HostProfile::abundances() {
     abundance.assign(R, 0.0f);
     uniq_abundance.assign(R, 0.0f);
     float total = 0.0f, utotal = 0.0f;
-    for (uint32_t i = 0; i < R; ++i) {
+    for (uint32_t i : active_) {  // ascending reference index, like the reference's loops
         if (reads_count[i] > 0) {
             abundance[i] = float(reads_count[i] * 100) / hits;
             total += abundance[i] / cfg_.ref_len[i];
@@ -186,7 +216,7 @@ void HostProfile::abundances() {
             utotal += uniq_abundance[i] / cfg_.ref_len[i];
         }
     }
-    for (uint32_t i = 0; i < R; ++i) {
+    for (uint32_t i : active_) {
         if (reads_count[i] > 0) abundance[i] = (abundance[i] * 100) / (total * cfg_.ref_len[i]);
         if (uniq_reads_count[i] > 0) uniq_abundance[i] = (uniq_abundance[i] * 100) / (utotal * cfg_.ref_len[i]);
     }
@@ -196,8 +226,8 @@ void HostProfile::abundances() {
 float HostProfile::coverage_cut_off() {  // slimm.hpp:328-344
     if (cc_cache_ == 0.0 && cfg_.cov_cut_off < 1.0) {
         std::vector<float> v;
-        v.reserve(cfg_.n_refs);
-        for (uint32_t i = 0; i < cfg_.n_refs; ++i)
+        v.reserve(active_.size());
+        for (uint32_t i : active_)
             if (uniq_reads_count[i] > 0) v.push_back(float(nz_cov[i]) / nbins_[i]);
         cc_cache_ = quantile_cut_off(v, cfg_.cov_cut_off);
     }
@@ -207,8 +237,8 @@ float HostProfile::coverage_cut_off() {  // slimm.hpp:328-344
 float HostProfile::uniq_coverage_cut_off() {  // slimm.hpp:672-688
     if (ucc_cache_ == 0.0 && cfg_.cov_cut_off < 1.0) {
         std::vector<float> v;
-        v.reserve(cfg_.n_refs);
-        for (uint32_t i = 0; i < cfg_.n_refs; ++i)
+        v.reserve(active_.size());
+        for (uint32_t i : active_)
             if (uniq_reads_count[i] > 0) v.push_back(float(nz_ucov[i]) / nbins_[i]);
         ucc_cache_ = quantile_cut_off(v, cfg_.cov_cut_off);
     }
@@ -227,12 +257,30 @@ void HostProfile::compute_valid() {  // slimm.hpp:353-378
     // runs, so they are read once here.
     const float cc = coverage_cut_off();
     const float ucc = uniq_coverage_cut_off();
-    for (uint32_t i = 0; i < R; ++i) {
+    valid_list_.clear();
+    // the two quotients of every reference in one dense, branch-free loop the compiler turns into packed divisions
+    // (4000 scalar divisions inside the branchy loop below were 10 of this function's 18 us)
+    cov_frac_.resize(R);
+    ucov_frac_.resize(R);
+    {
+        const uint32_t* nzc = nz_cov.data();
+        const uint32_t* nzu = nz_ucov.data();
+        const uint32_t* nb = nbins_.data();
+        float* cf = cov_frac_.data();
+        float* uf = ucov_frac_.data();
+        for (uint32_t i = 0; i < R; ++i) {
+            const float b = float(nb[i]);
+            cf[i] = float(nzc[i]) / b;
+            uf[i] = float(nzu[i]) / b;
+        }
+    }
+    for (uint32_t i : active_) {
         if (reads_count[i] == 0) continue;
-        float cp = float(nz_cov[i]) / nbins_[i];
-        float up = float(nz_ucov[i]) / nbins_[i];
+        const float cp = cov_frac_[i];
+        const float up = ucov_frac_[i];
         if (cp >= cc && up >= ucc) {
             valid[i] = 1;
+            valid_list_.push_back(i);
             ++n_valid;
         } else {
             if (up < ucc) ++failed_by_ucov;
@@ -283,14 +331,15 @@ void HostProfile::propagate() {
     auto touch = [&](uint32_t t) {
         if (!has_count_[t] && !kids_[t].present) touched_.push_back(t);
     };
-    for (uint32_t t = 0; t < T; ++t) {
-        if (lca_count_[t] != 0) {
-            touch(t);
-            count_[t] = lca_count_[t];
-            has_count_[t] = 1;
-        }
-    }
-    for (uint32_t r = 0; r < R; ++r) {
+    std::vector<uint32_t>& order = order_scratch_;  // taxa with direct hits, ascending
+    order.clear();
+    for_each_nonzero(lca_count_.data(), T, [&](uint32_t t) {
+        touch(t);
+        count_[t] = lca_count_[t];
+        has_count_[t] = 1;
+        order.push_back(t);
+    });
+    for_each_nonzero(marks_.data(), R, [&](uint32_t r) {
         uint32_t m = marks_[r] & 0xffu;
         while (m) {
             uint32_t lv = static_cast<uint32_t>(__builtin_ctz(m));
@@ -299,7 +348,7 @@ void HostProfile::propagate() {
             touch(t);
             kids_[t].add(r);
         }
-    }
+    });
     for (uint64_t p : pairs_) {
         const uint32_t t = static_cast<uint32_t>(p >> 32);
         touch(t);
@@ -309,9 +358,6 @@ void HostProfile::propagate() {
     // Step 2 (:560-586): every taxon with direct hits hands its count (snapshot value) and its children (live) to the
     // ranks above its own along the lineage of its smallest child.  The reference walks an unordered_map; any order
     // gives the same result in a consistent tree.  Here: lower ranks first, then ascending taxid.
-    std::vector<uint32_t> order;
-    for (uint32_t t = 0; t < T; ++t)
-        if (lca_count_[t] != 0) order.push_back(t);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rank_d_[a] < rank_d_[b]; });
     std::vector<uint32_t> ids;
     for (uint32_t t : order) {
@@ -332,9 +378,8 @@ void HostProfile::propagate() {
     }
     // Step 3 (:589-610): unique reads of each reference go to lineage slots 1..7 (slot 0 is skipped, Q9), together with
     // the reference itself and whatever children its slot-0 taxon currently has.
-    for (uint32_t i = 0; i < R; ++i) {
-        uint32_t u2 = uniq_reads_count2[i];
-        if (u2 == 0) continue;
+    for_each_nonzero(uniq_reads_count2.data(), R, [&](uint32_t i) {
+        const uint32_t u2 = uniq_reads_count2[i];
         const uint32_t* lin = &lin_dense_[static_cast<size_t>(i) * 8];
         touch(lin[0]);
         RefSet& s0 = kids_[lin[0]];
@@ -349,7 +394,7 @@ void HostProfile::propagate() {
             kids_[u].add(i);
             kids_[u].add_all(ids);
         }
-    }
+    });
     have_counts = true;
     profile_ready_ = false;
 }

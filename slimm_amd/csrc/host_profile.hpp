@@ -111,6 +111,7 @@ public:
     uint32_t profile_count = 0, profile_failed = 0;
     std::vector<uint32_t> reads_count, uniq_reads_count, uniq_reads_count2, nz_cov, nz_ucov;
     std::vector<uint8_t> valid;
+    const std::vector<uint32_t>& valid_list() const { return valid_list_; }  // the set bits of `valid`, ascending
     std::vector<float> abundance, uniq_abundance;  // valid after abundances()
     void abundances();
     const std::vector<uint32_t>& nz_uniq_cov2() const { return nz_ucov2_; }
@@ -140,6 +141,9 @@ private:
     float cc_cache_ = 0.0f, ucc_cache_ = 0.0f;
 
     std::vector<uint32_t> nz_ucov2_;
+    std::vector<uint32_t> active_;      // references with a non-zero statistic, ascending (set_coverage)
+    std::vector<uint32_t> valid_list_;
+    std::vector<float> cov_frac_, ucov_frac_;  // compute_valid scratch
     // partials
     std::vector<uint32_t> lca_count_, marks_;
     std::vector<uint64_t> pairs_;

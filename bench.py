@@ -92,7 +92,8 @@ def main():
     ap.add_argument("--records", type=int, default=0, help="records per rank (default: the config's size)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
+                    help="records of the same stream the single-threaded CPU restatement is timed on (default: all)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--record-order", default="grouped", choices=["grouped", "any"],
                     help="'any' sends the same records through the device sort path (record_order = SLIMM_ORDER_ANY)")
@@ -213,6 +214,12 @@ def main():
                 per_kernel[name] = {"ms_per_launch": per_launch_ms, "launches_per_step": steps_launches,
                                     "bytes_per_launch": model[name] / max(1.0, steps_launches if name == "memset_bins" else 1.0),
                                     }
+        # of the two classification kernels the one the device did not pick returns at once (k_runs_hash then only sums
+        # the per-tile counts by chunk): its bytes are those counts, not the records
+        pair = [k for k in ("k_runs", "k_runs_hash") if k in per_kernel]
+        if len(pair) == 2:
+            idle = min(pair, key=lambda k: per_kernel[k]["ms_per_launch"])
+            per_kernel[idle]["bytes_per_launch"] = 12 * (n_rec // 2048 + 1)
         # the dominant kernel = most time per step (memsets are DMA fills, not kernels of this library)
         cand = {k: v for k, v in per_kernel.items() if k not in ("memset_bins", "k_pick_runs")}
         dom = max(cand, key=lambda k: cand[k]["ms_per_launch"] * cand[k]["launches_per_step"])

@@ -53,6 +53,10 @@ __device__ __forceinline__ uint32_t r_mask_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
+// Lane mask of a predicate.  HIP's __ballot(int) takes an integer: a bool expression is first turned into 0 / 1 in a VGPR
+// and then compared with zero again (two vector instructions per ballot that the compare producing the bool already paid
+// for); the builtin takes the i1 directly.
+__device__ __forceinline__ uint64_t r_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t r_wave_sum(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -177,13 +181,14 @@ constexpr uint32_t SEG_START = 0x80000000u;
 
 // summary word of the segment whose 64 meta words the wave holds (m = 0 for slots past the window)
 __device__ __forceinline__ uint32_t segment_summary(uint32_t m) {
-    const uint64_t starts = __ballot((m >> 30) & 1u);
-    const bool mapped = m >> 31;
-    const uint32_t mate = (m >> 28) & 3u;
+    const uint64_t starts = r_ballot(((m >> 30) & 1u) != 0u);
+    // "mapped and mate == k" as ONE compare each ({mapped, mate} = bits 31, 29-28): the ballot of a compare is the
+    // compare; the ballot of `a && b` is both compares, an and, a 0/1 select and a third compare
+    const uint32_t vm = m & (M_VALID | (3u << 28));
     const uint64_t tail = starts ? ~((1ull << (63 - __builtin_clzll(starts))) - 1ull) : ~0ull;
-    const uint32_t seen = ((__ballot(mapped && mate == 0u) & tail) ? 1u : 0u) |
-                          ((__ballot(mapped && mate == 1u) & tail) ? 2u : 0u) |
-                          ((__ballot(mapped && mate == 2u) & tail) ? 4u : 0u);
+    const uint32_t seen = ((r_ballot(vm == M_VALID) & tail) ? 1u : 0u) |
+                          ((r_ballot(vm == (M_VALID | (1u << 28))) & tail) ? 2u : 0u) |
+                          ((r_ballot(vm == (M_VALID | (2u << 28))) & tail) ? 4u : 0u);
     return seen | (static_cast<uint32_t>(__popcll(tail)) << 8) | (starts ? SEG_START : 0u);
 }
 
@@ -231,9 +236,10 @@ struct RunScan {
 __device__ __forceinline__ RunScan run_scan(uint32_t me, uint32_t seg_carry, bool use_carry, uint32_t lane, uint64_t lt_mask,
                                             uint64_t le_mask) {
     const uint32_t valid = me >> 31, my_mate = (me >> 28) & 3u;
-    const uint64_t starts = __ballot((me >> 30) & 1u);
-    const uint64_t v0 = __ballot(valid && my_mate == 0u), v1 = __ballot(valid && my_mate == 1u),
-                   v2 = __ballot(valid && my_mate == 2u);
+    const uint64_t starts = r_ballot(((me >> 30) & 1u) != 0u);
+    const uint32_t vm = me & (M_VALID | (3u << 28));  // (one compare per ballot: see segment_summary)
+    const uint64_t v0 = r_ballot(vm == M_VALID), v1 = r_ballot(vm == (M_VALID | (1u << 28))),
+                   v2 = r_ballot(vm == (M_VALID | (2u << 28)));
     const uint64_t ps = starts & le_mask;  // run starts at or before me in this segment
     const uint32_t from = ps ? 63u - static_cast<uint32_t>(__builtin_clzll(ps)) : 0u;
     const uint64_t bit_from = 1ull << from;
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Ac
                 w4[k] = wl_[k] * 4u;
             }
             const char* meta_bytes = reinterpret_cast<const char*>(s_meta);
-            for (uint32_t d = 1; __ballot(d <= longest) != 0ull; ++d) {
+            for (uint32_t d = 1; r_ballot(d <= longest) != 0ull; ++d) {
 #pragma unroll
                 for (int k = 0; k < kQItems; ++k) {
                     // past my run: the same record (the run start) again, harmless
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
     for (int k = 0; k < kRItems; ++k) {
         const uint32_t i = base + k * kRBlock + threadIdx.x;
         const uint32_t f = (i < N) ? s_fl[i - lds_lo] : 0u;
-        const uint64_t mh = __ballot(f & FL_HEAD), mf = __ballot(f & FL_FIRST);
+        const uint64_t mh = r_ballot((f & FL_HEAD) != 0u), mf = r_ballot((f & FL_FIRST) != 0u);
         if ((threadIdx.x & 63) == 0) s_w[k][wave] = make_uint2(__popcll(mh), __popcll(mf));
     }
     __syncthreads();
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         const uint32_t i = base + k * kRBlock + threadIdx.x;
         const uint32_t f = (i < N) ? s_fl[i - lds_lo] : 0u;
         const bool head = f & FL_HEAD, first = f & FL_FIRST;
-        const uint64_t mh = __ballot(head), mf = __ballot(first);
+        const uint64_t mh = r_ballot(head), mf = r_ballot(first);
         const uint32_t rh = r_mask_rank(mh), rf = r_mask_rank(mf);
         uint2 before = make_uint2(0u, 0u), total = make_uint2(0u, 0u);
 #pragma unroll
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         {   // earlier records of the run with a larger mate sit AFTER this one in the target order
             uint32_t act = (first && (f & FL_GREATER_BEFORE) && !(f & FL_RUN_START)) ? 1u : 0u;
             uint32_t openb = 0u;
-            for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
+            for (uint32_t d = 1; r_ballot(act != 0u) != 0ull; ++d) {
                 const uint32_t diff = li - d;
                 const uint32_t inn = act & ((~diff) >> 31);
                 const uint32_t g = s_fl[diff & (0u - inn)];
@@ -937,7 +943,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
             const uint32_t room = lds_hi - lds_lo;  // staged records
             uint32_t act = (first && mate > 0 && mates_interleave) ? 1u : 0u;
             uint32_t openb = 0u;
-            for (uint32_t d = 1; __ballot(act != 0u) != 0ull; ++d) {
+            for (uint32_t d = 1; r_ballot(act != 0u) != 0ull; ++d) {
                 const uint32_t j = li + d;
                 const uint32_t inn = act & ((j - room) >> 31);           // j < room
                 const uint32_t g = s_fl[j & (0u - inn)];

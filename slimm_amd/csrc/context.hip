@@ -394,7 +394,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->counters.ensure(CNT_WORDS));
         HIP_TRY0(cc->ref_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->lca_count.ensure(c->T));
-        HIP_TRY0(cc->marks.ensure(static_cast<size_t>(c->R) * kMarkReps));
+        HIP_TRY0(cc->marks.ensure(static_cast<size_t>(c->R) * (kMarkBytes / 4)));
         HIP_TRY0(cc->h_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->h_small.ensure(CNT_WORDS + kTailWords));
         HIP_TRY0(cc->h_lca.ensure(c->T));
@@ -957,7 +957,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
             ZeroArgs z;
             z.p[0] = c->marks.p;
-            z.n[0] = R * (c->use_rows16 ? kMarkReps : 1u);
+            z.n[0] = R * (c->use_rows16 ? kMarkBytes / 4 : 1u);
             z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
             z.n[1] = 2;
             if (c->use_tiles) {
@@ -1036,7 +1036,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             pk.n[0] = 32;
             pk.src[1] = c->marks.p;
             pk.n[1] = R;
-            pk.reps[1] = c->use_rows16 ? kMarkReps : 1u;  // k_filter_lca16 spreads the marks over copies
+            pk.reps[1] = c->use_rows16 ? kPackBytes8 : 1u;  // k_filter_lca16 sets one byte per (reference, level)
             pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
             pk.n[2] = T;
             if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place

@@ -38,8 +38,27 @@ struct PackArgs {  // small arrays appended behind the per-reference statistics 
     const uint32_t* src[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t n[4] = {0, 0, 0, 0};
     uint32_t reps[4] = {1, 1, 1, 1};  // src[k] holds reps[k] copies of n[k] words each; their bitwise OR is packed
+                                      // kPackBytes8: src[k] holds 8 bytes per output word, bit l = (byte l != 0)
 };
-constexpr uint32_t kMarkReps = 16;  // copies of the level-mark words (k_filter_lca16 spreads its atomicOr over them)
+constexpr uint32_t kPackBytes8 = 0xffffffffu;
+#ifdef __HIPCC__
+// word i of packed array k (k_pack, k_ref_stats)
+__device__ __forceinline__ uint32_t packed_word(const PackArgs& pack, int k, uint32_t i) {
+    uint32_t v = 0;
+    if (pack.reps[k] == kPackBytes8) {
+        const uint2 b = reinterpret_cast<const uint2*>(pack.src[k])[i];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            v |= ((b.x >> (8 * l)) & 0xffu) ? (1u << l) : 0u;
+            v |= ((b.y >> (8 * l)) & 0xffu) ? (16u << l) : 0u;
+        }
+    } else {
+        for (uint32_t rep = 0; rep < pack.reps[k]; ++rep) v |= pack.src[k][static_cast<size_t>(rep) * pack.n[k] + i];
+    }
+    return v;
+}
+#endif
+constexpr uint32_t kMarkBytes = 8;  // level marks of k_filter_lca16: one byte per (reference, level)
 struct ZeroArgs {  // arrays cleared by one k_zero launch; p64 is filled with ~0 (the empty key of the pair set)
     uint32_t* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t n[5] = {0, 0, 0, 0, 0};

@@ -336,12 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict
         uint32_t* dst = out + 4ull * n_refs;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            for (uint32_t i = gid; i < pack.n[k]; i += gsz) {
-                uint32_t v = 0;
-#pragma unroll 16
-                for (uint32_t rep = 0; rep < pack.reps[k]; ++rep) v |= pack.src[k][static_cast<size_t>(rep) * pack.n[k] + i];
-                dst[i] = v;
-            }
+            for (uint32_t i = gid; i < pack.n[k]; i += gsz) dst[i] = packed_word(pack, k, i);
             dst += pack.n[k];
         }
     }
@@ -538,10 +533,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
     const uint32_t M = counters[CNT_M];
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     if (m >= M) return;
-    // Level marks are one bit per (reference, level) and most reads hit the same few references: while the bits are
-    // still unset, thousands of lanes atomicOr the same words (a third of this kernel's time with one copy).  Every
-    // workgroup therefore marks one of kMarkReps copies; k_pack ORs the copies together.
-    uint32_t* __restrict__ marks = marks_all + static_cast<size_t>(blockIdx.x & (kMarkReps - 1u)) * n_refs;
+    // Level marks: one BYTE per (reference, level), set by a plain store.  Most reads hit the same few references; bits
+    // in a word meant atomicOr (memory-side: thousands of lanes on the same words while a bit is not yet visible, and a
+    // workgroup retires only when its atomics have come back) or, to avoid those, a read of the word first -- a fourth
+    // dependent round trip per read.  A byte store of 1 is idempotent, needs no read, and leaves no atomic outstanding;
+    // k_pack folds the 8 bytes of a reference into its mark word.
+    uint8_t* __restrict__ marks = reinterpret_cast<uint8_t*>(marks_all);
     FPROF_T(q0);
     const uint32_t s = read_off[m], e = read_off[m + 1];
     uint32_t nv = 0, first_g = 0, max_ref = 0, w_max = 0, eq = 0xffu;
@@ -591,16 +588,12 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
         if (eq) {
             const uint32_t lv = __builtin_ctz(eq);
             taxon = level_taxon[lo.off[lv] + row16_level(a0, lv)];
-            // mark words of the first chunk's references: the gathers go out together, then the (rare) atomics
-            uint32_t mk[kChunk];
-#pragma unroll
-            for (int k = 0; k < kChunk; ++k) mk[k] = marks[((vmask0 >> k) & 1u) ? r0[k] : r0[0]];
 #pragma unroll
             for (int k = 0; k < kChunk; ++k)
-                if (((vmask0 >> k) & 1u) && !((mk[k] >> lv) & 1u)) atomicOr(&marks[r0[k]], 1u << lv);
+                if ((vmask0 >> k) & 1u) marks[r0[k] * 8u + lv] = 1;
             for (uint32_t t = s + kChunk; t < e; ++t) {
                 const uint32_t r = tgt_ref[t] & 0x7fffffffu;
-                if ((rows16[r].w >> 31) && !((marks[r] >> lv) & 1u)) atomicOr(&marks[r], 1u << lv);
+                if (rows16[r].w >> 31) marks[r * 8u + lv] = 1;
             }
         } else {
             taxon = level_taxon[lo.off[7] + ((w_max >> 16) & 0x7fffu)];

@@ -846,12 +846,7 @@ __global__ __launch_bounds__(512) void k_pack(uint32_t* __restrict__ dst, const 
         const uint32_t gid = blockIdx.x * 512 + threadIdx.x, gsz = gridDim.x * 512;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            for (uint32_t i = gid; i < pack.n[k]; i += gsz) {
-                uint32_t v = 0;
-#pragma unroll 16
-                for (uint32_t rep = 0; rep < pack.reps[k]; ++rep) v |= pack.src[k][static_cast<size_t>(rep) * pack.n[k] + i];
-                dst[i] = v;
-            }
+            for (uint32_t i = gid; i < pack.n[k]; i += gsz) dst[i] = packed_word(pack, k, i);
             dst += pack.n[k];
         }
     }

@@ -806,11 +806,13 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         uint4* ou = reinterpret_cast<uint4*>(gu);
         const uint4* sc = reinterpret_cast<const uint4*>(s_cov);
         const uint4* su = reinterpret_cast<const uint4*>(s_ucov);
+        // the statistics' atomics first: they come back from the memory side in ~2 us, and a workgroup retires only when
+        // they have -- issued before the 64 KB of tile stores they are back by the time those are
+        if (stats) tile_ref_stats<kTwo>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
         for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
             oc[i] = sc[i];
             if (kTwo) ou[i] = su[i];
         }
-        if (stats) tile_ref_stats<kTwo>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
         if (bits.base) {
             tile_nonzero_bits(s_cov, tile, bits, 0);
             if (kTwo) tile_nonzero_bits(s_ucov, tile, bits, 1);

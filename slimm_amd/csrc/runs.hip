@@ -73,7 +73,17 @@ struct RawRecords {
     const uint32_t* bin_off;
     const uint2* geo_tab;  // {contig length, first bin} per reference (k_emit)
     uint32_t half_read, bin_width;
+    uint32_t bw_magic;  // floor((2^32 - 1) / bin_width), see div_bin_width
     static constexpr bool kCountsMapped = true;
+    // n / bin_width for a divisor known on the host: the quotient estimate mulhi(n, floor((2^32 - 1) / d)) is the true
+    // quotient or one less (n * M / 2^32 lies in (n / d - 1, n / d]), so one correction makes it exact.  The compiler's
+    // general u32 division refines a float reciprocal and corrects twice: ~30 full-rate-equivalent vector instructions
+    // per record (five of them quarter-rate multiplies), a quarter of k_emit's vector work.
+    __device__ uint32_t div_bin_width(uint32_t n) const {
+        const uint32_t q = __umulhi(n, bw_magic);
+        const uint32_t r = n - q * bin_width;
+        return q + (r >= bin_width ? 1u : 0u);
+    }
     __device__ uint32_t count(const uint32_t*) const { return n; }
     __device__ uint64_t key_of(uint32_t i) const { return key[i] << 2; }  // only the low 62 bits are significant
     __device__ uint32_t meta_of(uint32_t i, bool& bad) const {
@@ -122,12 +132,12 @@ struct RawRecords {
     }
     __device__ uint32_t gbin(const Hit& h, const Geo& g) const {
         // uint32 wrap-around of int32 + uint32, then clamp to the contig length (src/slimm.hpp:200-201, Q3)
-        return g.off + min(static_cast<uint32_t>(h.pos) + half_read, g.len) / bin_width;
+        return g.off + div_bin_width(min(static_cast<uint32_t>(h.pos) + half_read, g.len));
     }
     __device__ uint32_t gbin_of(uint32_t i, uint32_t r) const {
         // uint32 wrap-around of int32 + uint32, then clamp to the contig length (src/slimm.hpp:200-201, Q3)
         const uint32_t center = min(static_cast<uint32_t>(pos[i]) + half_read, ref_len[r]);
-        return bin_off[r] + center / bin_width;
+        return bin_off[r] + div_bin_width(center);
     }
 };
 
@@ -1012,6 +1022,7 @@ static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint3
     a.geo_tab = geo;
     a.half_read = half_read;
     a.bin_width = bin_width;
+    a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
     return a;
 }
 

@@ -22,6 +22,7 @@
 //
 // Reference semantics: src/slimm.hpp:219-257 (cov[bin]++ per target; uniq_cov[bin]++ when the read has one target).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include <algorithm>
@@ -148,11 +149,19 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
     const uint32_t per = (ntiles + 1023) / 1024;
     const uint32_t lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
     uint2 sum = make_uint2(0u, 0u);
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t c = staged ? s_cnt[i] : tile_count[i];
-        sum.x += c;
-        sum.y += c ? (c + kTileSub - 1) / kTileSub : 1u;
-    }
+    // (the two sources as compile-time cases: `staged ? s_cnt[i] : tile_count[i]` selects between an LDS and a global
+    // pointer and compiles to flat loads, serial ones in these per-thread loops)
+    auto sum_counts = [&](auto from_lds) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t c = decltype(from_lds)::value ? s_cnt[i] : tile_count[i];
+            sum.x += c;
+            sum.y += c ? (c + kTileSub - 1) / kTileSub : 1u;
+        }
+    };
+    if (staged)
+        sum_counts(std::true_type{});
+    else
+        sum_counts(std::false_type{});
     s_part[tid] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -164,11 +173,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
         __syncthreads();
     }
     uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
+    auto emit_items = [&](auto from_lds) {
     for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t c = staged ? s_cnt[i] : tile_count[i];
+        const uint32_t c = decltype(from_lds)::value ? s_cnt[i] : tile_count[i];
         const uint32_t pieces = c ? (c + kTileSub - 1) / kTileSub : 1u;
         tile_base[i] = run.x;
-        if (staged) {
+        if (decltype(from_lds)::value) {
             s_cnt[i] = run.x;
         } else {
             tile_count[i] = run.x;
@@ -183,6 +193,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
         run.x += c;
         run.y += pieces;
     }
+    };
+    if (staged)
+        emit_items(std::true_type{});
+    else
+        emit_items(std::false_type{});
     __syncthreads();
     if (staged && !kept) {
         for (uint32_t i = tid; i < ntiles; i += 1024) {
@@ -720,12 +735,8 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
         if (k + 1 == staged && staged == kStatRefs)  // more references than staged: continue in global memory
             while (r0 + k + 1 < n_refs && bin_off[r0 + k + 1] <= t0) ++k;
     }
-    for (; r0 + k < n_refs; ++k) {
-        const uint32_t r = r0 + k;
-        const uint32_t s = k < kStatRefs ? s_off[k] : bin_off[r];
-        if (s >= t1) break;
-        const uint32_t e = k + 1 <= kStatRefs ? s_off[k + 1] : bin_off[r + 1];
-        if (e <= t0) continue;
+    // statistics of reference r, whose bins [s, e) overlap my part
+    auto one_ref = [&](uint32_t r, uint32_t s, uint32_t e) {
         const uint32_t a0 = max(s, t0) - tile0, a1 = min(e, t1) - tile0;  // multiples of 4 (offsets are 16-byte aligned)
         uint32_t sa = 0, za = 0, sb = 0, zb = 0;
         for (uint32_t i = a0 + lane * 4; i < a1; i += 256) {
@@ -752,6 +763,22 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
             if (kTwo && want_sum && sb) atomicAdd(o4 + 2, sb);
             if (kTwo && want_nz && zb) atomicAdd(o4 + 3, zb);
         }
+    };
+    // Two loops, one over the offsets staged in LDS and one (rare: more than kStatRefs references in a tile) over global
+    // memory: `k < kStatRefs ? s_off[k] : bin_off[r]` in ONE loop selects between an LDS and a global pointer and
+    // compiles to flat loads on the critical path of every iteration.
+    const uint32_t staged = min(kStatRefs, n_refs - r0);
+    for (; k < staged; ++k) {
+        const uint32_t s = s_off[k];
+        if (s >= t1) return;
+        const uint32_t e = s_off[k + 1];
+        if (e > t0) one_ref(r0 + k, s, e);
+    }
+    for (; r0 + k < n_refs; ++k) {
+        const uint32_t s = bin_off[r0 + k];
+        if (s >= t1) break;
+        const uint32_t e = bin_off[r0 + k + 1];
+        if (e > t0) one_ref(r0 + k, s, e);
     }
 }
 

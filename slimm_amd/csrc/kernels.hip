@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restri
 
 // ---------------------------------------------------------------------------------------------------------
 // k_scan_tiles: exclusive scan of the per-tile (x, y) counts; totals go to counters[slot_x/slot_y] and to
-// tile_cnt[ntiles].  Up to 32 K tiles (64 M records) ONE workgroup does it in ~10 us; beyond that the tiles are cut
+// tile_cnt[ntiles].  Up to 16 K tiles (32 M records) ONE workgroup does it in one pass over registers; beyond that the tiles are cut
 // into chunks of kScanChunk, k_scan_sums reduces every chunk, and the workgroups of k_scan_tiles start from the sum of
 // the chunks before theirs (one workgroup needed 0.86 ms for the 488 K tiles of 10^9 records).
 // When read_off != nullptr also writes the CSR sentinel read_off[total_x] = total_y.
@@ -635,7 +635,9 @@ void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs
 
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
                        uint32_t* read_off, const uint32_t* extra, int slot_extra, uint32_t* tail, uint4* sums) {
-    uint32_t grid = 1, chunk = kScanChunk, above = 32768;
+    // one workgroup up to the range of its one-pass register path; its loop over 1024-entry pieces beyond that costs
+    // ~5 us per piece (93 us at 16 385 tiles, 161 us at 24 K) against ~15 us for the two launches of the chunked scan
+    uint32_t grid = 1, chunk = kScanChunk, above = 1024u * kScanRegs;
     if (const char* e = getenv("SLIMM_SCAN_CHUNK")) {  // tests: chunked scan on small inputs
         chunk = std::max<uint32_t>(1u, static_cast<uint32_t>(atol(e)));
         above = chunk;

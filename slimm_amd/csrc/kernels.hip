@@ -555,8 +555,11 @@ __global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restr
             r[k] = tgt_ref[t] & 0x7fffffffu;
             g[k] = tgt_gbin[t];
         }
+        // slots past the read's last target all gather row 0: lanes with the same address cost the texture addresser one
+        // line together, a clamped index (the read's own last row again) one line per lane -- and with 2.6 targets per
+        // read half the slots are such
 #pragma unroll
-        for (int k = 0; k < kChunk; ++k) row[k] = rows16[r[k]];
+        for (int k = 0; k < kChunk; ++k) row[k] = rows16[(c + k < e) ? r[k] : 0u];
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
             const bool ok = (c + k < e) && (row[k].w >> 31);  // inside the read and a valid reference

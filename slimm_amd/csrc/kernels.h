@@ -152,7 +152,10 @@ int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this m
 // tile_count: `reps` copies of rep_stride words, zero on entry (k_zero); workgroup b adds to copy b % reps.
 // k_tile_scan sums the copies into tile_base and turns every copy into the start of its stretch inside the buckets,
 // which k_tile_scatter (same grid) then fills through the copy's own cursors: 1/reps of the same-address atomics.
-constexpr uint32_t kTileReps = 8;
+#ifndef SLIMM_TILE_REPS
+#define SLIMM_TILE_REPS 8
+#endif
+constexpr uint32_t kTileReps = SLIMM_TILE_REPS;
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
                        int count_slot, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item

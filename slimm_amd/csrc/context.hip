@@ -600,6 +600,11 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     const bool no_fused_emit = getenv("SLIMM_NO_FUSED_EMIT") != nullptr;  // tests: the scan-kernel path
     const bool fused_emit = c->order == SLIMM_ORDER_GROUPED && num_tiles(n) > 0 && num_tiles(n) <= kFusedEmitTiles &&
                             !no_fused_emit;
+    uint32_t emit_shift = emit_chunk_shift(num_tiles(n));
+    if (const char* e = getenv("SLIMM_EMIT_CHUNK_SHIFT")) {  // tests: larger chunks on small inputs
+        const long v = atol(e);
+        if (v >= static_cast<long>(emit_shift) && v <= 8) emit_shift = static_cast<uint32_t>(v);
+    }
     {
         KernelTimer t(c, K_MEMSET);
         if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)
@@ -620,7 +625,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         if (c->order == SLIMM_ORDER_GROUPED) {  // the same launch clears the counters and picks the classification kernel
             if (fused_emit) {  // chunk sums of the per-tile counts, in place of a scan launch
                 z.p[0] = reinterpret_cast<uint32_t*>(c->scan_sums.p);
-                z.n[0] = 4u * ((num_tiles(n) + 63u) / 64u);
+                z.n[0] = 4u * (((num_tiles(n) - 1u) >> emit_shift) + 1u);
             }
             launch_zero_pick_raw(st, z, c->rec, c->counters.p);
         } else {
@@ -676,7 +681,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             KernelTimer t(c, ids[part]);
             launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
                             c->c_fl.p, c->tile_cnt.p, c->tile_valid.p, part,
-                            fused_emit ? reinterpret_cast<uint32_t*>(c->scan_sums.p) : nullptr);
+                            fused_emit ? reinterpret_cast<uint32_t*>(c->scan_sums.p) : nullptr, emit_shift);
         }
         if (!fused_emit) {
             KernelTimer t(c, K_SCAN);
@@ -688,7 +693,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             launch_emit_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, c->d_geo.p, half_read, hc.bin_width, c->c_fl.p,
                             c->counters.p, c->tile_cnt.p, c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p,
                             fused_emit ? reinterpret_cast<const uint32_t*>(c->scan_sums.p) : nullptr,
-                            fused_emit ? c->tail() : nullptr);
+                            fused_emit ? c->tail() : nullptr, emit_shift);
         }
     }
     if (c->use_tiles) {

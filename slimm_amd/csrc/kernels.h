@@ -98,16 +98,19 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
 void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters);
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt, uint32_t* tile_valid, int part, uint32_t* chunk_acc = nullptr);
+                     uint2* tile_cnt, uint32_t* tile_valid, int part, uint32_t* chunk_acc = nullptr,
+                     uint32_t chunk_shift = 6);
 // chunk_acc != nullptr (streams of up to kFusedEmitTiles tiles): the second classification launch leaves the sums of every
-// 64 tiles' counts in chunk_acc[4 * chunk ..] (zeroed by the caller), tile_off holds the per-tile COUNTS, and k_emit
+// (1 << chunk_shift) tiles' counts in chunk_acc[4 * chunk ..] (zeroed by the caller), tile_off holds the per-tile COUNTS, and k_emit
 // derives its offsets and publishes the totals (counters, read_off sentinel, tail) itself -- no k_scan_tiles launch
-constexpr uint32_t kFusedEmitTiles = 16384;
+constexpr uint32_t kFusedEmitTiles = 65536;
+// tiles per chunk as a shift: at most 256 chunks
+inline uint32_t emit_chunk_shift(uint32_t ntiles) { return ntiles <= 16384 ? 6u : (ntiles <= 32768 ? 7u : 8u); }
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, const uint2* geo, uint32_t half_read, uint32_t bin_width, const uint8_t* fl,
                      uint32_t* counters,
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off,
-                     const uint32_t* chunk_acc = nullptr, uint32_t* tail = nullptr);
+                     const uint32_t* chunk_acc = nullptr, uint32_t* tail = nullptr, uint32_t chunk_shift = 6);
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
                         uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part);
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

@@ -270,16 +270,16 @@ __device__ __forceinline__ RunScan run_scan(uint32_t me, uint32_t seg_carry, boo
 }
 
 // Tile offsets without a scan kernel (streams of up to kFusedEmitTiles tiles): the per-tile (heads, firsts, mapped) counts
-// are summed by chunk of kEmitChunk tiles, and a k_emit workgroup gets its offset as the chunk sums before its chunk plus
+// are summed by chunk of 64 - 256 tiles, and a k_emit workgroup gets its offset as the chunk sums before its chunk plus
 // the tile counts before it inside the chunk: at most 256 + 63 loads, all L2 hits.  Of the two classification kernels one
 // returns at once; when that is k_runs_hash (launched second) its idle launch computes the chunk sums from k_runs'
 // counts, and when k_runs_hash does the classifying it adds each tile's counts to its chunk with three atomics.
 // (Atomics at the end of k_runs' one-tile workgroups held every workgroup ~2 us longer: 81 -> 96 us.  k_scan_tiles
 // as a launch of its own was 9 us of a 520 us file, half of it the dependent-dispatch overhead every launch pays.)
-constexpr uint32_t kEmitChunk = 64;
+// (chunks of 64, 128 or 256 tiles -- 1 << chunk_shift -- so that there are at most 256 of them up to 64 K tiles)
 template <typename Acc>
-__device__ __forceinline__ void add_chunk_sums(uint32_t* chunk_acc, uint32_t tile, uint2 t, uint32_t v) {
-    uint32_t* a = chunk_acc + (tile / kEmitChunk) * 4u;
+__device__ __forceinline__ void add_chunk_sums(uint32_t* chunk_acc, uint32_t chunk_shift, uint32_t tile, uint2 t, uint32_t v) {
+    uint32_t* a = chunk_acc + (tile >> chunk_shift) * 4u;
     atomicAdd(a, t.x);
     atomicAdd(a + 1, t.y);
     if (Acc::kCountsMapped) atomicAdd(a + 2, v);
@@ -549,7 +549,8 @@ __device__ __forceinline__ uint32_t hash_get_min(const uint64_t* tab, uint64_t k
 template <typename Acc>
 __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
                                                        uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
-                                                       uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ chunk_acc) {
+                                                       uint32_t* __restrict__ tile_valid, uint32_t* __restrict__ chunk_acc,
+                                                       uint32_t chunk_shift) {
     constexpr int kSlots = kHWin / kHBlock;       // 5 staged records per thread
     constexpr uint32_t kHSegs = kHWin / 64;       // 40 segments
     constexpr int kHWaves = kHBlock / 64;
@@ -561,18 +562,32 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
     __shared__ uint32_t s_v[kHWaves];
     if (counters[CNT_MODE] != 1u) {  // k_pick_runs chose the look-back kernel for this stream: k_runs has classified it
         // ... and this launch, which would otherwise return at once, sums its per-tile counts by chunk for k_emit
-        if (chunk_acc && threadIdx.x < 64u && blockIdx.x * kEmitChunk < ntiles) {
-            const uint32_t t = blockIdx.x * kEmitChunk + threadIdx.x, tc = min(t, ntiles - 1u);
+        const uint32_t chunk = 1u << chunk_shift;  // <= 256 tiles: the first four waves, one tile per thread
+        if (chunk_acc && (blockIdx.x << chunk_shift) < ntiles) {
+            const uint32_t t = (blockIdx.x << chunk_shift) + threadIdx.x, tc = min(t, ntiles - 1u);
             uint2 c = tile_cnt[tc];
             uint32_t v = Acc::kCountsMapped ? tile_valid[tc] : 0u;
-            if (t >= ntiles) {
+            if (t >= ntiles || threadIdx.x >= chunk) {
                 c = make_uint2(0u, 0u);
                 v = 0u;
             }
             c.x = r_wave_sum(c.x);
             c.y = r_wave_sum(c.y);
             v = r_wave_sum(v);
-            if (threadIdx.x == 0) *reinterpret_cast<uint4*>(chunk_acc + blockIdx.x * 4u) = make_uint4(c.x, c.y, v, 0u);
+            if ((threadIdx.x & 63u) == 0u) {
+                s_w[threadIdx.x >> 6] = c;
+                s_v[threadIdx.x >> 6] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint4 sum = make_uint4(0u, 0u, 0u, 0u);
+                for (uint32_t w = 0; w < (chunk + 63u) / 64u; ++w) {
+                    sum.x += s_w[w].x;
+                    sum.y += s_w[w].y;
+                    sum.z += s_v[w];
+                }
+                *reinterpret_cast<uint4*>(chunk_acc + blockIdx.x * 4u) = sum;
+            }
         }
         return;
     }
@@ -713,7 +728,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
         }
         tile_cnt[tile] = t;
         if (Acc::kCountsMapped) tile_valid[tile] = v;
-        if (chunk_acc) add_chunk_sums<Acc>(chunk_acc, tile, t, v);
+        if (chunk_acc) add_chunk_sums<Acc>(chunk_acc, chunk_shift, tile, t, v);
     }
     __syncthreads();  // LDS is reused by the next tile
     }
@@ -797,7 +812,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
                                                   uint32_t* __restrict__ counters, const uint2* __restrict__ tile_off,
                                                   uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
                                                   uint32_t* __restrict__ read_off, const uint32_t* __restrict__ chunk_acc,
-                                                  uint32_t* __restrict__ tail) {
+                                                  uint32_t* __restrict__ tail, uint32_t chunk_shift) {
     __shared__ uint8_t s_fl[kHalo + kRTile + kHalo];
     __shared__ uint2 s_w[kRItems][kRWaves];
     __shared__ uint2 s_pre[kRWaves];
@@ -806,10 +821,10 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
     if (base >= N) return;
     const uint32_t wave = threadIdx.x >> 6;
     if (chunk_acc) {  // my offset from the chunk sums and my chunk's tile counts (tile_off holds COUNTS here, not offsets)
-        const uint32_t c = blockIdx.x / kEmitChunk, in_chunk = blockIdx.x - c * kEmitChunk;
+        const uint32_t c = blockIdx.x >> chunk_shift, in_chunk = blockIdx.x - (c << chunk_shift);  // both < kRBlock
         uint2 p = make_uint2(0u, 0u);
         const uint2 cs = *reinterpret_cast<const uint2*>(chunk_acc + min(threadIdx.x, c ? c - 1u : 0u) * 4u);
-        const uint2 ts = tile_off[c * kEmitChunk + min(threadIdx.x, in_chunk ? in_chunk - 1u : 0u)];
+        const uint2 ts = tile_off[(c << chunk_shift) + min(threadIdx.x, in_chunk ? in_chunk - 1u : 0u)];
         if (threadIdx.x < c) p = cs;
         if (threadIdx.x < in_chunk) {
             p.x += ts.x;
@@ -819,7 +834,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         p.y = r_wave_sum(p.y);
         if ((threadIdx.x & 63) == 0) s_pre[wave] = p;
         if (blockIdx.x == 0) {  // totals for the kernels and the host after this one
-            const uint32_t nchunks = (gridDim.x + kEmitChunk - 1u) / kEmitChunk;  // <= kRBlock
+            const uint32_t nchunks = (gridDim.x + (1u << chunk_shift) - 1u) >> chunk_shift;  // <= kRBlock
             uint4 q = *reinterpret_cast<const uint4*>(chunk_acc + min(threadIdx.x, nchunks - 1u) * 4u);
             if (threadIdx.x >= nchunks) q = make_uint4(0u, 0u, 0u, 0u);
             __shared__ uint4 s_tot[kRWaves];
@@ -1036,7 +1051,7 @@ void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords
 
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt, uint32_t* tile_valid, int part, uint32_t* chunk_acc) {
+                     uint2* tile_cnt, uint32_t* tile_valid, int part, uint32_t* chunk_acc, uint32_t chunk_shift) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
     const RawRecords a = make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width);
@@ -1047,19 +1062,19 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
                            tile_cnt, tile_valid);
     else
         hipLaunchKernelGGL(k_runs_hash<RawRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
-                           tile_cnt, tile_valid, chunk_acc);
+                           tile_cnt, tile_valid, chunk_acc, chunk_shift);
 }
 
 void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, const uint2* geo, uint32_t half_read, uint32_t bin_width, const uint8_t* fl,
                      uint32_t* counters,
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off,
-                     const uint32_t* chunk_acc, uint32_t* tail) {
+                     const uint32_t* chunk_acc, uint32_t* tail, uint32_t chunk_shift) {
     const uint32_t nt = rtiles(in.n);
     if (!nt) return;
     hipLaunchKernelGGL(k_emit<RawRecords>, dim3(nt), dim3(kRBlock), 0, st,
                        make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width, geo), fl, counters, tile_off, tgt_ref,
-                       tgt_gbin, read_off, chunk_acc, tail);
+                       tgt_gbin, read_off, chunk_acc, tail, chunk_shift);
 }
 
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
@@ -1074,7 +1089,7 @@ void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
                            tile_cnt, static_cast<uint32_t*>(nullptr));
     else
         hipLaunchKernelGGL(k_runs_hash<SortedRecords>, dim3(std::min(nt, 512u)), dim3(kHBlock), 0, st, a, nt, counters, fl,
-                           tile_cnt, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr));
+                           tile_cnt, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 6u);
 }
 
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
@@ -1084,7 +1099,7 @@ void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident,
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
     hipLaunchKernelGGL(k_emit<SortedRecords>, dim3(nt), dim3(kRBlock), 0, st, a, fl, counters, tile_off, tgt_ref, tgt_gbin,
-                       read_off, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr));
+                       read_off, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 6u);
 }
 
 }  // namespace slimm

@@ -446,10 +446,17 @@ def test_chunked_tile_scan(monkeypatch):
 
 @pytest.mark.parametrize("n_records", [2048 * 64, 2048 * 64 + 1, 2048 * 129 - 5, 1_500_000])
 def test_tile_offsets_from_chunk_sums(n_records, monkeypatch):
-    """Grouped input of up to 16 K tiles: k_emit derives its offsets from per-chunk sums (64 tiles per chunk) instead of a
-    scan launch; chunk boundaries exact, one past, ragged, and many chunks -- and the same answers with the scan kernel."""
+    """Grouped input of up to 64 K tiles: k_emit derives its offsets from per-chunk sums (64 - 256 tiles per chunk) instead
+    of a scan launch; chunk boundaries exact, one past, ragged, and many chunks -- and the same answers with the scan kernel."""
     w = make_workload(CONFIGS["config2"], seed=36, n_records=n_records)
     check(w)                                          # chunk sums by the idle hash launch
+    for shift in ("7", "8"):                          # the chunk sizes of 16 K - 64 K tiles, on this small input
+        monkeypatch.setenv("SLIMM_EMIT_CHUNK_SHIFT", shift)
+        check(w)
+        monkeypatch.setenv("SLIMM_RUNS_KERNEL", "hash")
+        check(w)
+        monkeypatch.delenv("SLIMM_RUNS_KERNEL")
+    monkeypatch.delenv("SLIMM_EMIT_CHUNK_SHIFT")
     monkeypatch.setenv("SLIMM_RUNS_KERNEL", "hash")
     check(w)                                          # chunk sums by atomics of the hash kernel
     monkeypatch.setenv("SLIMM_NO_FUSED_EMIT", "1")

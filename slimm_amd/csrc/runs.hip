@@ -739,7 +739,7 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
 // run, and writes the choice to counters[CNT_MODE]; both kernels are launched and the one not chosen returns at once.
 // Measured per 10 M records: look-back 82 us at 3 records/run, 100 at 10, 249 at 42; hash table ~125 at any depth.
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kPickSample = 8192;
+constexpr uint32_t kPickSample = 2048;  // one trip of k_zero_pick (8 records per thread); 8192 cost 3 us more per file
 constexpr uint32_t kPickHashAbove = 16;  // records per run
 
 template <typename Acc>

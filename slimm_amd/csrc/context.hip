@@ -1076,19 +1076,12 @@ int slimm_filter_alignments(slimm_ctx* c) {
         }
         break;
     }
-    c->part_u2.resize(R);
-    c->nz_ucov2.resize(R);
+    // the packed rows {uniq_reads_count2 = sum of uniq_cov2 bins, non-zero uniq_cov2 bins, -, -}, the level marks and the
+    // per-taxon LCA counts go to the host profile straight from the pinned block
     const uint32_t* s2 = c->h_stats.p + c->statsA_words();
-    for (uint32_t r = 0; r < R; ++r) {
-        c->part_u2[r] = s2[r * 4 + 0];  // uniq_reads_count2 = sum of uniq_cov2 bins
-        c->nz_ucov2[r] = s2[r * 4 + 1];
-    }
-    c->part_marks.assign(s2 + 4ull * R + 32, s2 + 5ull * R + 32);
-    c->part_lca.assign(s2 + 5ull * R + 32, s2 + 5ull * R + 32 + T);
     c->part_pairs.assign(c->h_pairs.p, c->h_pairs.p + c->n_pairs);
     std::sort(c->part_pairs.begin(), c->part_pairs.end());
-    h.set_partials(c->part_u2.data(), c->part_lca.data(), c->part_marks.data(), c->part_pairs.data(), c->n_pairs);
-    h.set_nz_uniq_cov2(c->nz_ucov2.data());
+    h.set_partials_rows(s2, 4, s2 + 5ull * R + 32, s2 + 4ull * R + 32, c->part_pairs.data(), c->n_pairs);
     tr.mark("partials to host profile");
     c->filtered = true;
     return SLIMM_OK;
@@ -1144,11 +1137,13 @@ int slimm_get_partials(slimm_ctx* c, slimm_partials* out) {
     if (!c->filtered || c->device < 0) return fail(c, SLIMM_E_INVALID, "no device partials (call slimm_filter_alignments)");
     out->n_refs = c->R;
     out->n_taxa_dense = c->T;
-    out->uniq_reads_count2 = c->part_u2.data();
-    out->lca_count = c->part_lca.data();
-    out->level_marks = c->part_marks.data();
-    out->pairs = c->part_pairs.data();
-    out->n_pairs = static_cast<uint32_t>(c->part_pairs.size());
+    const HostProfile& hp = *c->host;  // (what the last filter / install / set call handed to the host profile)
+    out->uniq_reads_count2 = const_cast<uint32_t*>(hp.uniq_reads_count2.data());  // (read-only views; the struct is
+                                                                                   // shared with slimm_set_partials)
+    out->lca_count = const_cast<uint32_t*>(hp.lca_count().data());
+    out->level_marks = const_cast<uint32_t*>(hp.level_marks().data());
+    out->pairs = const_cast<uint64_t*>(hp.pairs().data());
+    out->n_pairs = static_cast<uint32_t>(hp.pairs().size());
     out->scalars[0] = c->host->uniq_matches2;
     out->scalars[1] = out->scalars[2] = out->scalars[3] = 0;
     return SLIMM_OK;

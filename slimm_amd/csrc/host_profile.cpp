@@ -293,8 +293,24 @@ void HostProfile::compute_valid() {  // slimm.hpp:353-378
 
 void HostProfile::set_partials(const uint32_t* u2, const uint32_t* lca, const uint32_t* marks, const uint64_t* pairs,
                                uint32_t n_pairs) {
+    set_partials_rows(u2, 1, lca, marks, pairs, n_pairs);
+}
+
+// the same with uniq_reads_count2[r] = u2[r * stride] (the device's packed rows, read in place) and, for stride > 1,
+// the non-zero uniq_cov2 counts in the next column
+void HostProfile::set_partials_rows(const uint32_t* u2, size_t stride, const uint32_t* lca, const uint32_t* marks,
+                                    const uint64_t* pairs, uint32_t n_pairs) {
     const uint32_t R = cfg_.n_refs, T = n_taxa_dense();
-    uniq_reads_count2.assign(u2, u2 + R);
+    if (stride == 1) {
+        uniq_reads_count2.assign(u2, u2 + R);
+    } else {
+        uniq_reads_count2.resize(R);
+        nz_ucov2_.resize(R);
+        for (uint32_t i = 0; i < R; ++i) {
+            uniq_reads_count2[i] = u2[i * stride];
+            nz_ucov2_[i] = u2[i * stride + 1];
+        }
+    }
     lca_count_.assign(lca, lca + T);
     marks_.assign(marks, marks + R);
     pairs_.assign(pairs, pairs + n_pairs);

@@ -93,7 +93,12 @@ public:
     // phase B/C(1) results
     void set_partials(const uint32_t* uniq_reads_count2, const uint32_t* lca_count, const uint32_t* level_marks,
                       const uint64_t* pairs, uint32_t n_pairs);
+    void set_partials_rows(const uint32_t* u2_rows, size_t stride, const uint32_t* lca_count, const uint32_t* level_marks,
+                           const uint64_t* pairs, uint32_t n_pairs);
     void set_nz_uniq_cov2(const uint32_t* nz) { nz_ucov2_.assign(nz, nz + cfg_.n_refs); }
+    const std::vector<uint32_t>& lca_count() const { return lca_count_; }
+    const std::vector<uint32_t>& level_marks() const { return marks_; }
+    const std::vector<uint64_t>& pairs() const { return pairs_; }
     // a12 steps 2,3
     void propagate();
     // a13

@@ -131,3 +131,56 @@ def test_database_round_trips_through_the_products_reader(tmp_path):
     ref = str(tmp_path / "ref.sldb")
     write_sldb(ref, tax)
     assert read_sldb(out) == read_sldb(ref)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_builder_matches_oracle_on_random_dumps(tmp_path, seed):
+    """Random trees (repeated and missing ranks along a path, nodes without names, taxids nobody defines), accessions
+    repeated inside and across mapping files with different taxids, odd batch sizes: the C++ tool and the line-by-line
+    restatement of the reference must agree on every entry."""
+    rng = np.random.default_rng(seed)
+    ranks = ["no rank", "clade", "strain", "species", "genus", "family", "order", "class", "phylum", "superkingdom",
+             "subspecies", "species group"]
+    n_nodes = int(rng.integers(30, 400))
+    ids = [1] + sorted(set(int(x) for x in rng.integers(2, 5000, size=n_nodes)))
+    parent = {1: 1}
+    for k, t in enumerate(ids[1:], start=1):
+        parent[t] = ids[int(rng.integers(0, k))]            # a tree: the parent comes earlier in the list
+    with open(tmp_path / "nodes.dmp", "w") as f:
+        for t in rng.permutation(ids):
+            t = int(t)
+            if t != 1 and rng.random() < 0.03:
+                continue                                    # a node the dump does not define: the walk stops there
+            f.write(f"{t}\t|\t{parent[t]}\t|\t{ranks[int(rng.integers(0, len(ranks)))]}\t|\tXX\t|\t0\t|\n")
+    with open(tmp_path / "names.dmp", "w") as f:
+        for t in ids:
+            if rng.random() < 0.1:
+                continue                                    # no scientific name: empty string in the database
+            f.write(f"{t}\t|\tsyn {t}\t|\t\t|\tsynonym\t|\n{t}\t|\tName of {t}\t|\t\t|\tscientific name\t|\n")
+    accs = [f"AC{k:05d}" for k in range(int(rng.integers(5, 120)))]
+    with open(tmp_path / "r.fa", "w") as f:
+        for a in accs:
+            sep = [".1 desc", "|x|y", " z", "\tq", ""][int(rng.integers(0, 5))]
+            f.write(f">{a}{sep}\nACGT\n")
+    paths = []
+    for k in range(int(rng.integers(1, 4))):
+        p = str(tmp_path / f"m{k}.a2t")
+        with open(p, "w") as f:
+            if rng.random() < 0.7:
+                f.write("accession\taccession.version\ttaxid\tgi\n")
+            for _ in range(int(rng.integers(0, 300))):
+                a = accs[int(rng.integers(0, len(accs)))] if rng.random() < 0.6 else f"ZZ{int(rng.integers(0, 999)):03d}"
+                t = ids[int(rng.integers(0, len(ids)))] if rng.random() < 0.9 else int(rng.integers(6000, 7000))
+                f.write(f"{a}\t{a}.1\t{t}\t0\n")
+        paths.append(p)
+    d = {"fasta": str(tmp_path / "r.fa"), "nodes": str(tmp_path / "nodes.dmp"), "names": str(tmp_path / "names.dmp"),
+         "acc": paths}
+    batch = int(rng.choice([1, 2, 7, 50, 1000000]))
+    out = str(tmp_path / "o.sldb")
+    run_builder(d, out, "-b", str(batch))
+    ac, tn = read_sldb(out)
+    o_ac, o_tn, missed = build_db.build(d["fasta"], d["acc"], d["nodes"], d["names"], batch=batch)
+    assert ac == o_ac
+    assert tn == o_tn
+    missed_file = tmp_path / "o.missed"
+    assert (missed_file.read_text().split() if missed_file.exists() else []) == missed

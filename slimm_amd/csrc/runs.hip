@@ -909,6 +909,22 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         if ((threadIdx.x & 63) == 0) s_w[k][wave] = make_uint2(__popcll(mh), __popcll(mf));
     }
     __syncthreads();
+    // exclusive scan of the 32 (item, wave) counts by 32 lanes, once (every thread adding up its item's four counts with
+    // selects cost 16 vector instructions per record slot: this kernel's vector ALUs are busy 2/3 of the time)
+    if (threadIdx.x < kRItems * kRWaves) {
+        const uint2 c = s_w[threadIdx.x / kRWaves][threadIdx.x % kRWaves];
+        uint2 inc = c;
+#pragma unroll
+        for (int o = 1; o < kRItems * kRWaves; o <<= 1) {
+            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
+            if (threadIdx.x >= static_cast<uint32_t>(o)) {
+                inc.x += ax;
+                inc.y += ay;
+            }
+        }
+        s_w[threadIdx.x / kRWaves][threadIdx.x % kRWaves] = make_uint2(inc.x - c.x, inc.y - c.y);
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kRItems; ++k) {
         const uint32_t i = base + k * kRBlock + threadIdx.x;
@@ -916,17 +932,7 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
         const bool head = f & FL_HEAD, first = f & FL_FIRST;
         const uint64_t mh = r_ballot(head), mf = r_ballot(first);
         const uint32_t rh = r_mask_rank(mh), rf = r_mask_rank(mf);
-        uint2 before = make_uint2(0u, 0u), total = make_uint2(0u, 0u);
-#pragma unroll
-        for (int w = 0; w < kRWaves; ++w) {
-            const uint2 c = s_w[k][w];
-            if (w < static_cast<int>(wave)) {
-                before.x += c.x;
-                before.y += c.y;
-            }
-            total.x += c.x;
-            total.y += c.y;
-        }
+        const uint2 before = s_w[k][wave];  // heads / firsts of the tile before this wave's 64 records of item k
         const uint32_t mate = (f >> FL_MATE_SHIFT) & 3u;
         const uint32_t li = (i < N) ? i - lds_lo : 0u;
         uint32_t t = running.y + before.y + rf;
@@ -1000,8 +1006,6 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
             tgt_gbin[t] = acc.gbin(hit[k], geo[k]);
             if (head) read_off[m] = t;
         }
-        running.x += total.x;
-        running.y += total.y;
     }
     const bool any_long = __any(too_long);
     if (any_long && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_RUN_LENGTH);

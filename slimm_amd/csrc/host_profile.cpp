@@ -459,6 +459,16 @@ void HostProfile::children_pairs(int stage, std::vector<uint32_t>& taxid, std::v
 }
 
 // slimm.hpp:690-710: k__..|p__..|...|<rank>__name, missing names -> unknown_<rank>
+// The lineage text of a reference's row down to rank rnk depends on the database only: built once per (reference, rank)
+// and kept for the following files (40 profile rows x 7 name lookups and appends were a third of the profile text's time).
+void HostProfile::append_lineage_of_ref(std::string& s, uint32_t rnk, uint32_t ref) {
+    std::vector<std::string>& cache = lineage_text_[rnk < 9 ? rnk : 8];
+    if (cache.empty()) cache.resize(cfg_.n_refs);
+    std::string& t = cache[ref];
+    if (t.empty()) append_lineage(t, rnk, &lin_dense_[static_cast<size_t>(ref) * 8], false);
+    s += t;
+}
+
 void HostProfile::append_lineage(std::string& s, uint32_t rnk, const uint32_t* lin, bool all_zero) {
     for (uint32_t i = kLineageLen; i-- > rnk;) {  // the reference prepends rank by rank; same text, built front to back
         s += kRankShort[i < 8 ? i : 0];
@@ -559,7 +569,10 @@ const std::string& HostProfile::write_abundance() {
         out += '\t';
         put_u(out, dense_taxid_[t]);
         out += '\t';
-        append_lineage(out, rnk, lin_first, zero);
+        if (zero)
+            append_lineage(out, rnk, lin_first, true);
+        else
+            append_lineage_of_ref(out, rnk, k.mn);
         out += '\t';
         put_g(out, ab);
         out += '\t';
@@ -585,7 +598,10 @@ const std::string& HostProfile::write_abundance() {
             out += '\t';
             put_u(out, dense_taxid_[parent]);
             out += "*\t";
-            append_lineage(out, parent_rnk, lin_first, zero);
+            if (zero)
+                append_lineage(out, parent_rnk, lin_first, true);
+            else
+                append_lineage_of_ref(out, parent_rnk, k.mn);
             out += '|';
             out += kRankShort[rnk < 8 ? rnk : 0];
             out += "__";

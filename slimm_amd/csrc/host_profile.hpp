@@ -131,6 +131,8 @@ private:
     uint32_t rank_of_dense(uint32_t d) const { return rank_d_[d]; }
     const std::string& name_of_dense(uint32_t d) const;
     void append_lineage(std::string& out, uint32_t rnk, const uint32_t* lin_dense_row, bool all_zero);
+    void append_lineage_of_ref(std::string& out, uint32_t rnk, uint32_t ref);
+    std::vector<std::string> lineage_text_[9];  // [rank][reference]: lineage text, filled on first use
 
     HostConfig cfg_;
     std::vector<uint32_t> dense_taxid_, lin_dense_, nbins_, rank_d_;

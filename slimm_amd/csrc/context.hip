@@ -1108,7 +1108,7 @@ int slimm_install_merged_partials(slimm_ctx* c, uint32_t* total_pairs) {
     const uint32_t R = c->R, T = c->T;
     const uint64_t W = 3ull * R + T + 1;
     HIP_TRY(c, c->h_partials.ensure(W));
-    HIP_TRY(c, hipMemcpyAsync(c->h_partials.p, c->d_partials.p, W * 4, hipMemcpyDeviceToHost, c->stream));
+    launch_copy_out(c->stream, c->h_partials.p, c->d_partials.p, static_cast<uint32_t>(W));  // (a kernel, not the DMA engine)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t* h = c->h_partials.p;
     c->part_u2.assign(h, h + R);

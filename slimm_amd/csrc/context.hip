@@ -627,7 +627,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                 z.p[0] = reinterpret_cast<uint32_t*>(c->scan_sums.p);
                 z.n[0] = 4u * (((num_tiles(n) - 1u) >> emit_shift) + 1u);
             }
-            launch_zero_pick_raw(st, z, c->rec, c->counters.p);
+            launch_zero_pick_raw(st, z, c->rec, c->counters.p, c->R);
         } else {
             z.p[0] = c->counters.p;
             z.n[0] = CNT_WORDS;
@@ -662,7 +662,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const int ids[3] = {K_PICK, K_FLAGS, K_RUNS_HASH};
         for (int part = 0; part < 3; ++part) {
             KernelTimer t(c, ids[part]);
-            launch_runs_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->c_fl.p, c->tile_cnt.p, part);
+            launch_runs_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->c_fl.p, c->tile_cnt.p, part,
+                               c->R);
         }
         {
             KernelTimer t(c, K_SCAN);

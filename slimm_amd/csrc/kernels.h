@@ -15,7 +15,7 @@ enum {
     CNT_ITEMS = 5,  // work items of k_tile_hist
     CNT_ITEMS2 = 6, // work items of k_part_tile
     CNT_ANYGB = 8,  // some record follows a record of the same qName run with a larger mate number (mates interleave)
-    CNT_MODE = 7,   // classification kernel picked on the device: 0 = look-back walk (k_runs), 1 = hash table (k_runs_hash)
+    CNT_MODE = 7,   // classification picked on the device: 0 = look-back walk, 2 = tagged-word walk (both k_runs), 1 = hash table (k_runs_hash)
     CNT_SPLIT = 9,  // bin tiles cut into several k_tile_hist work items (their non-zero counts are finished by k_pack)
     CNT_WORDS = 32
 };
@@ -95,7 +95,7 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
 // launched, the classification kernel that was not chosen returns immediately.
 // k_zero and k_pick_runs in one launch (grouped input): z must not contain the counters, which workgroup 0 clears itself
 // before it writes the chosen kernel to counters[CNT_MODE]
-void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters);
+void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters, uint32_t n_refs);
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
                      const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
                      uint2* tile_cnt, uint32_t* tile_valid, int part, uint32_t* chunk_acc = nullptr,
@@ -112,7 +112,7 @@ void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
                      const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off,
                      const uint32_t* chunk_acc = nullptr, uint32_t* tail = nullptr, uint32_t chunk_shift = 6);
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part);
+                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part, uint32_t n_refs);
 void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
                         const uint8_t* fl, uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
                         uint32_t* read_off);

@@ -298,16 +298,15 @@ constexpr int kQTile = kRBlock * kQItems;
 constexpr uint32_t kSegs = (kQTile + kHalo) / 64;
 
 template <typename Acc>
-__global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Acc acc, uint32_t ntiles, uint32_t* __restrict__ counters,
-                                                  uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
-                                                  uint32_t* __restrict__ tile_valid) {
+__device__ __forceinline__ void runs_walk(const Acc& acc, uint32_t ntiles, uint32_t* __restrict__ counters,
+                                          uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
+                                          uint32_t* __restrict__ tile_valid) {
     __shared__ uint32_t s_meta[kQTile + kHalo];
     __shared__ uint32_t s_flw[kQTile / 4];  // the pass's flag bytes, written out coalesced
     __shared__ uint32_t s_seg[kSegs];       // segment summaries, then (in place) the carry into each segment
     __shared__ uint64_t s_last[kSegs + 2];  // key of the last record of each segment
     __shared__ uint2 s_w[kRWaves];
     __shared__ uint32_t s_v[kRWaves];
-    if (counters[CNT_MODE] != 0u) return;  // k_pick_runs chose the hash-table kernel for this stream
     uint8_t* s_fl = reinterpret_cast<uint8_t*>(s_flw);
     const uint32_t N = acc.count(counters);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -490,6 +489,229 @@ __global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Ac
     }
     __syncthreads();  // LDS is reused by the next tile
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_runs_t: k_runs for streams with longer qName runs (about 5 - 16 records per run) and fewer than 2^18 references.
+//
+// k_runs' duplicate walk costs 23 vector instructions per step for a thread's four records (clamped address, LDS read,
+// xor, mask, min) and runs to the longest run of the wave: 250 of 800 instructions per pass at 3 hits per read, 700 of
+// 1200 at 8.  Here the LDS word a walk compares carries the window position of the record's RUN START above {mapped,
+// mate, reference}:
+//     bits 31-21 run start | bit 20 mapped | bits 19-18 mate | bits 17-0 reference
+// so "same read and same reference earlier in my run" is plain equality with my own word: records before my run's start
+// belong to runs that start earlier, the walk needs no clamp (it may read past the window's first word into a zeroed
+// guard, which never equals a mapped word) and no mask -- 8 instructions per step.  The run start is known only after
+// the segment carries, so the tagged words are written in the second stage, which therefore also covers the halo (a
+// fifth record for half the waves) behind one more barrier: ~75 instructions more per pass, which the shorter walk
+// does not earn back at 3 hits per read (112 vs 83 us at config 2).  Both stages use ONE record-to-thread mapping
+// (window index off + k * 256 + thread, plus the halo for the first 128 threads), so the second stage takes the
+// record's word from registers.  Everything else (flags, slow path for runs reaching back beyond the halo, outputs) is
+// k_runs'.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kTagRefBits = 18;
+constexpr uint32_t kTagGuard = kQTile + kHalo + 4;  // zero words below the window: the unclamped walk may read them
+
+__device__ __forceinline__ uint32_t tagged_word(uint32_t m, uint32_t run_start) {
+    return (m & ((1u << kTagRefBits) - 1u)) | ((m >> 10) & 0xc0000u) | ((m >> 11) & 0x100000u) | (run_start << 21);
+}
+
+template <typename Acc>
+__device__ __forceinline__ void runs_tagged(const Acc& acc, uint32_t ntiles, uint32_t* __restrict__ counters,
+                                            uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
+                                            uint32_t* __restrict__ tile_valid) {
+    __shared__ uint32_t s_tagw[kTagGuard + kQTile + kHalo];
+    __shared__ uint32_t s_flw[kQTile / 4];
+    __shared__ uint32_t s_seg[kSegs];
+    __shared__ uint64_t s_last[kSegs + 2];
+    __shared__ uint2 s_w[kRWaves];
+    __shared__ uint32_t s_v[kRWaves];
+    uint8_t* s_fl = reinterpret_cast<uint8_t*>(s_flw);
+    uint32_t* const s_tag = s_tagw + kTagGuard;
+    for (uint32_t i = threadIdx.x; i < kTagGuard; i += kRBlock) s_tagw[i] = 0u;  // (first read after several barriers)
+    const uint32_t N = acc.count(counters);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint64_t le_mask = lt_mask | (1ull << lane);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint32_t nh = 0, nf = 0, nv = 0, any_gb = 0;
+    bool bad = false, too_long = false;
+    for (uint32_t base = tile * kRTile; base < min((tile + 1u) * kRTile, N); base += kQTile) {
+        const uint32_t lds_lo = base >= kHalo ? base - kHalo : 0u;
+        const uint32_t lds_hi = min(base + static_cast<uint32_t>(kQTile), N);
+        const uint32_t off = base - lds_lo, n_here = lds_hi - base, W = lds_hi - lds_lo;
+        const uint32_t nseg = (W + 63u) >> 6;
+        const bool halo_mine = threadIdx.x < off;  // off is 0 or 128: waves 0 and 1 also take the halo's two segments
+        // 1. meta word of every record of the window and its segment's summary (slot kQItems = the halo)
+        uint32_t m_[kQItems + 1];
+        {
+            typename Acc::Raw raw[kQItems + 1];
+#pragma unroll
+            for (int k = 0; k < kQItems; ++k) raw[k] = acc.load(min(base + k * kRBlock + threadIdx.x, N - 1u));
+            raw[kQItems] = acc.load(min(lds_lo + threadIdx.x, N - 1u));
+            const uint64_t before = acc.raw_key(lds_lo ? lds_lo - 1u : 0u);
+            if (lane == 63) {
+#pragma unroll
+                for (int k = 0; k < kQItems; ++k) s_last[(off >> 6) + k * kRWaves + wave] = Acc::key_bits(raw[k]);
+                if (halo_mine) s_last[wave] = Acc::key_bits(raw[kQItems]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k <= kQItems; ++k) {
+                const uint32_t j = k < kQItems ? off + k * kRBlock + threadIdx.x : threadIdx.x;  // window index
+                const bool active = k < kQItems ? (j & ~63u) < W : halo_mine;                      // wave-uniform
+                uint32_t m = 0u;
+                if (active) {
+                    const uint64_t mine = Acc::key_bits(raw[k]);
+                    const uint32_t seg = j >> 6;
+                    const uint64_t prev = previous_key(mine, seg ? s_last[seg - 1u] : before);
+                    if (j < W) {
+                        m = acc.meta(raw[k], bad);
+                        if (lds_lo + j == 0u || !Acc::same_run(mine, prev)) m |= M_RUN;
+                    }
+                    const uint32_t summary = segment_summary(m);
+                    if (lane == 0) s_seg[seg] = summary;
+                }
+                m_[k] = m;
+            }
+        }
+        __syncthreads();
+        // 2. carry into each segment
+        segment_carries(s_seg, nseg, lds_lo == 0);
+        // 3. head / larger-mate-before / distance to the run start from the ballots and the carry; the tagged word
+        uint32_t me_[kQItems], wl_[kQItems], st_[kQItems];
+#pragma unroll
+        for (int k = 0; k <= kQItems; ++k) {
+            const uint32_t j = k < kQItems ? off + k * kRBlock + threadIdx.x : threadIdx.x;
+            const bool active = k < kQItems ? (j & ~63u) < W : halo_mine;
+            uint32_t t = 0u, wl = 0u, st = 0u;
+            if (active) {
+                const uint32_t me = m_[k];
+                const RunScan rs = run_scan(me, s_seg[j >> 6], true, lane, lt_mask, le_mask);
+                t = tagged_word(me, j - rs.len);  // (a run reaching back beyond the window: position 0)
+                if (j < W) s_tag[j] = t;
+                wl = (me >> 31) ? min(rs.len, j) : 0u;
+                st = rs.head | (rs.gb << 1) | (rs.open << 2);
+            }
+            if (k < kQItems) {
+                me_[k] = t;
+                wl_[k] = wl;
+                st_[k] = st;
+            }
+        }
+        __syncthreads();
+        // 4. duplicate walk: four steps per trip, equality with my own tagged word
+        uint32_t dup_[kQItems];
+        {
+            uint32_t longest = 0u;
+            uint32_t b_[kQItems];  // byte offset into s_tagw (an offset, not a pointer: pointer arrays decay to flat addressing)
+#pragma unroll
+            for (int k = 0; k < kQItems; ++k) {
+                longest = max(longest, wl_[k]);
+                dup_[k] = 0xffffffffu;
+                b_[k] = (kTagGuard + off + k * kRBlock + threadIdx.x) * 4u;
+            }
+            const char* tag_bytes = reinterpret_cast<const char*>(s_tagw);
+            for (uint32_t d = 0; r_ballot(d < longest) != 0ull; d += 4) {
+#pragma unroll
+                for (int k = 0; k < kQItems; ++k) {
+                    b_[k] -= 16u;
+                    const uint32_t* q = reinterpret_cast<const uint32_t*>(tag_bytes + b_[k]);
+                    const uint32_t x0 = q[3] ^ me_[k], x1 = q[2] ^ me_[k], x2 = q[1] ^ me_[k], x3 = q[0] ^ me_[k];
+                    dup_[k] = min(min(dup_[k], min(x0, x1)), min(x2, x3));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kQItems; ++k) {
+            const uint32_t lpos = k * kRBlock + threadIdx.x;
+            const uint32_t me = m_[k], valid = me >> 31, my_mate = (me >> 28) & 3u;
+            uint32_t head = st_[k] & 1u, gb = (st_[k] >> 1) & 1u;
+            uint32_t first = valid & (dup_[k] != 0u ? 1u : 0u);  // (no walk: dup_ stayed all ones)
+            if (st_[k] & 4u) {  // the run reaches back beyond the halo: go on in global memory (rare)
+                const uint32_t my_ident = me & M_IDENT;
+                uint32_t j = lds_lo, steps = 0;
+                while (j > 0 && first) {
+                    --j;
+                    bool dummy = false;
+                    const uint32_t mg = full_meta(acc, j, dummy);
+                    if (mg & M_VALID) {
+                        const uint32_t mt = (mg >> 28) & 3u;
+                        if ((mg & M_IDENT) == my_ident) {
+                            head = 0u;
+                            first = 0u;
+                            break;
+                        }
+                        if (mt == my_mate) head = 0u;
+                        if (mt > my_mate) gb = 1u;
+                    }
+                    if (mg & M_RUN) break;
+                    if (++steps > kLookBackMax) {
+                        too_long = true;
+                        break;
+                    }
+                }
+            }
+            head &= first;
+            gb &= first;
+            if (lpos < n_here)
+                s_fl[lpos] = static_cast<uint8_t>((my_mate << FL_MATE_SHIFT) | (((me >> 30) & 1u) << 4) | head |
+                                                  (first << 1) | (gb << 5));
+            nh += head;
+            nf += first;
+            nv += valid;
+            any_gb |= gb;
+        }
+        __syncthreads();
+        if (n_here == static_cast<uint32_t>(kQTile)) {
+            if (kQItems == 8)
+                reinterpret_cast<uint2*>(fl + base)[threadIdx.x] = reinterpret_cast<const uint2*>(s_flw)[threadIdx.x];
+            else
+                reinterpret_cast<uint32_t*>(fl + base)[threadIdx.x] = s_flw[threadIdx.x];
+        } else {
+            for (uint32_t j = threadIdx.x; j < n_here; j += kRBlock) fl[base + j] = s_fl[j];
+        }
+        __syncthreads();  // LDS is reused by the next pass
+    }
+    nh = r_wave_sum(nh);
+    nf = r_wave_sum(nf);
+    nv = r_wave_sum(nv);
+    const uint32_t err = (__any(bad) ? ERR_REF_RANGE : 0u) | (__any(too_long) ? ERR_RUN_LENGTH : 0u);
+    const bool wave_gb = __any(any_gb != 0u);
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = make_uint2(nh, nf);
+        s_v[threadIdx.x >> 6] = nv;
+        if (err) atomicOr(&counters[CNT_ERR], err);
+        if (wave_gb && counters[CNT_ANYGB] == 0u) atomicOr(&counters[CNT_ANYGB], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint2 t = make_uint2(0u, 0u);
+        uint32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < kRWaves; ++w) {
+            t.x += s_w[w].x;
+            t.y += s_w[w].y;
+            v += s_v[w];
+        }
+        tile_cnt[tile] = t;
+        if (Acc::kCountsMapped) tile_valid[tile] = v;
+    }
+    __syncthreads();
+    }
+}
+
+// The look-back classification launch: the plain walk (mode 0) or the tagged-word walk (mode 2), as picked on the device.
+template <typename Acc>
+__global__ __launch_bounds__(kRBlock, SLIMM_RUNS_MINBLOCKS) void k_runs(const Acc acc, uint32_t ntiles,
+                                                                         uint32_t* __restrict__ counters,
+                                                                         uint8_t* __restrict__ fl, uint2* __restrict__ tile_cnt,
+                                                                         uint32_t* __restrict__ tile_valid) {
+    const uint32_t mode = counters[CNT_MODE];
+    if (mode == 0u)
+        runs_walk(acc, ntiles, counters, fl, tile_cnt, tile_valid);
+    else if (mode == 2u)
+        runs_tagged(acc, ntiles, counters, fl, tile_cnt, tile_valid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -740,10 +962,21 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
 // Measured per 10 M records: look-back 82 us at 3 records/run, 100 at 10, 249 at 42; hash table ~125 at any depth.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPickSample = 2048;  // one trip of k_zero_pick (8 records per thread); 8192 cost 3 us more per file
-constexpr uint32_t kPickHashAbove = 16;  // records per run
+constexpr uint32_t kPickHashAbove = 16;  // records per qName run above which the hash-table kernel is picked
+constexpr uint32_t kPickTagAbove = 6;    // ... and the tagged-word walk (3.7 at config 2: plain walk; 9.7 at config 3)
+__device__ __forceinline__ uint32_t pick_mode(uint32_t sample, uint32_t runs, uint32_t tag_ok, int force) {
+    uint32_t mode = 0u;
+    if (runs != 0u) {
+        const uint32_t per_run = sample / runs;
+        mode = per_run > kPickHashAbove ? 1u : ((tag_ok && per_run >= kPickTagAbove) ? 2u : 0u);
+    }
+    if (force >= 0) mode = (force == 2 && !tag_ok) ? 0u : static_cast<uint32_t>(force);
+    return mode;
+}
 
 template <typename Acc>
-__global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __restrict__ counters, int force) {
+__global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __restrict__ counters, int force,
+                                                    uint32_t tag_ok) {
     __shared__ uint32_t s_runs[16];
     const uint32_t N = acc.count(counters);
     const uint32_t S = min(N, kPickSample);
@@ -755,9 +988,7 @@ __global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __r
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int w = 0; w < 16; ++w) t += s_runs[w];
-        uint32_t mode = (t != 0 && S / t > kPickHashAbove) ? 1u : 0u;
-        if (force >= 0) mode = static_cast<uint32_t>(force);
-        counters[CNT_MODE] = mode;
+        counters[CNT_MODE] = pick_mode(S, t, tag_ok, force);
     }
 }
 
@@ -766,7 +997,7 @@ __global__ __launch_bounds__(1024) void k_pick_runs(const Acc acc, uint32_t* __r
 // drain latency.)
 template <typename Acc>
 __global__ __launch_bounds__(256) void k_zero_pick(const ZeroArgs z, const Acc acc, uint32_t* __restrict__ counters,
-                                                   int force) {
+                                                   int force, uint32_t tag_ok) {
     __shared__ uint32_t s_runs[4];
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
 #pragma unroll
@@ -778,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_zero_pick(const ZeroArgs z, const Acc a
     const uint32_t N = acc.count(counters);  // (raw records: a kernel argument, not a counter)
     const uint32_t S = min(N, kPickSample);
     if (S == 0) {
-        if (threadIdx.x == 0) counters[CNT_MODE] = force >= 0 ? static_cast<uint32_t>(force) : 0u;
+        if (threadIdx.x == 0) counters[CNT_MODE] = pick_mode(0u, 0u, tag_ok, force);
         return;
     }
     uint32_t runs = 0;
@@ -801,9 +1032,7 @@ __global__ __launch_bounds__(256) void k_zero_pick(const ZeroArgs z, const Acc a
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t t = s_runs[0] + s_runs[1] + s_runs[2] + s_runs[3];
-        uint32_t mode = (t != 0 && S / t > kPickHashAbove) ? 1u : 0u;
-        if (force >= 0) mode = static_cast<uint32_t>(force);
-        counters[CNT_MODE] = mode;
+        counters[CNT_MODE] = pick_mode(S, t, tag_ok, force);
     }
 }
 
@@ -1014,10 +1243,17 @@ __global__ __launch_bounds__(kRBlock) void k_emit(const Acc acc, const uint8_t* 
 static inline uint32_t rtiles(uint32_t n) { return (n + kRTile - 1) / kRTile; }
 
 // SLIMM_RUNS_KERNEL=walk|hash overrides the choice k_pick_runs makes on the device (for tests and A/B timing)
+// the tagged-word walk needs reference ids below 2^18; SLIMM_RUNS_TAGGED=0 takes it out of the choice
+static uint32_t tagged_ok(uint32_t n_refs) {
+    if (n_refs >= (1u << kTagRefBits)) return 0u;
+    const char* e = getenv("SLIMM_RUNS_TAGGED");
+    return (e && e[0] == '0') ? 0u : 1u;
+}
+
 static int forced_runs_mode() {
     const char* e = getenv("SLIMM_RUNS_KERNEL");
     if (!e) return -1;
-    return e[0] == 'h' ? 1 : (e[0] == 'w' ? 0 : -1);
+    return e[0] == 'h' ? 1 : (e[0] == 'w' ? 0 : (e[0] == 't' ? 2 : -1));
 }
 
 // grid of k_runs (grid-stride over tiles beyond it)
@@ -1045,12 +1281,13 @@ static RawRecords make_raw(const DeviceRecords& in, uint32_t n_refs, const uint3
     return a;
 }
 
-void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters) {
+void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters, uint32_t n_refs) {
     uint32_t most = z.n64;
     for (int k = 0; k < 5; ++k) most = most > z.n[k] ? most : z.n[k];
     const uint32_t blocks = std::min<uint32_t>(1024u, (most + 255u) / 256u + 1u);
     const RawRecords a = make_raw(in, 0, nullptr, nullptr, 0, 1);
-    hipLaunchKernelGGL(k_zero_pick<RawRecords>, dim3(blocks), dim3(256), 0, st, z, a, counters, forced_runs_mode());
+    hipLaunchKernelGGL(k_zero_pick<RawRecords>, dim3(blocks), dim3(256), 0, st, z, a, counters, forced_runs_mode(),
+                       tagged_ok(n_refs));
 }
 
 void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
@@ -1060,7 +1297,8 @@ void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
     if (!nt) return;
     const RawRecords a = make_raw(in, n_refs, ref_len, bin_off, half_read, bin_width);
     if (part == 0)
-        hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
+        hipLaunchKernelGGL(k_pick_runs<RawRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode(),
+                           tagged_ok(n_refs));
     else if (part == 1)
         hipLaunchKernelGGL(k_runs<RawRecords>, dim3(std::min(nt, runs_grid())), dim3(kRBlock), 0, st, a, nt, counters, fl,
                            tile_cnt, tile_valid);
@@ -1082,12 +1320,13 @@ void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, c
 }
 
 void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part) {
+                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part, uint32_t n_refs) {
     const uint32_t nt = rtiles(n_upper);
     if (!nt) return;
     SortedRecords a{ident, cref, cgbin};
     if (part == 0)
-        hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode());
+        hipLaunchKernelGGL(k_pick_runs<SortedRecords>, dim3(1), dim3(1024), 0, st, a, counters, forced_runs_mode(),
+                           tagged_ok(n_refs));
     else if (part == 1)
         hipLaunchKernelGGL(k_runs<SortedRecords>, dim3(std::min(nt, runs_grid())), dim3(kRBlock), 0, st, a, nt, counters, fl,
                            tile_cnt, static_cast<uint32_t*>(nullptr));

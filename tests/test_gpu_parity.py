@@ -173,7 +173,7 @@ def test_direct_atomic_fallback_path(monkeypatch):
     check(make_workload(CONFIGS["config1"], seed=16))
 
 
-@pytest.mark.parametrize("kernel", ["walk", "hash"])
+@pytest.mark.parametrize("kernel", ["walk", "tagged", "hash"])
 def test_both_classification_kernels(monkeypatch, kernel):
     """k_runs (look-back walk) and k_runs_hash (LDS hash table) are picked on the device by records per read;
     forced here, both must agree with the oracle on shallow and deep multi-mapping."""
@@ -202,7 +202,7 @@ def _interleave_mates(w: Workload) -> Workload:
     return Workload(w.ref_names, w.ref_len, w.taxonomy, rec.take(order), w.avg_read_len, w.options, w.name + "-interleaved")
 
 
-@pytest.mark.parametrize("kernel", ["walk", "hash"])
+@pytest.mark.parametrize("kernel", ["walk", "tagged", "hash"])
 def test_interleaved_mates(monkeypatch, kernel):
     monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
     w = _interleave_mates(make_workload(SynthConfig("pairs", 200_000, 2_000, 6.0), seed=25, paired_frac=0.9))
@@ -587,3 +587,13 @@ def test_full_size_config2_invariants():
     assert np.array_equal(s2.bins(0), cov) and np.array_equal(s2.bins(1), ucov) and np.array_equal(s2.bins(2), ucov2)
     assert s2.taxon_counts(1) == s.taxon_counts(1) and s2.children_pairs(1) == s.children_pairs(1)
     assert s2.write_abundance() == s.write_abundance()
+
+
+@pytest.mark.parametrize("hits", [6.0, 9.0, 14.0])
+def test_medium_depth_streams_take_the_tagged_walk(hits):
+    """6 - 16 records per qName run: the device picks the tagged-word walk by itself (k_runs, mode 2); runs cross pass and
+    tile boundaries, mates interleave."""
+    w = make_workload(SynthConfig("mid", 300_000, 300, hits, bin_width=200, len_lo=20_000, len_hi=200_000,
+                                  strain_level=True), seed=51)
+    check(w)
+    check(w, grouped=False)

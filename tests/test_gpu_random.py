@@ -90,7 +90,7 @@ def _run(w, grouped):
         assert_matches_oracle(s, o)
 
 
-@pytest.mark.parametrize("kernel", ["walk", "hash"])
+@pytest.mark.parametrize("kernel", ["walk", "tagged", "hash"])
 def test_random_small_inputs(monkeypatch, kernel):
     monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
     for seed in range(120):

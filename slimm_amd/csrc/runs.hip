@@ -963,7 +963,8 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPickSample = 2048;  // one trip of k_zero_pick (8 records per thread); 8192 cost 3 us more per file
 constexpr uint32_t kPickHashAbove = 16;  // records per qName run above which the hash-table kernel is picked
-constexpr uint32_t kPickTagAbove = 6;    // ... and the tagged-word walk (3.7 at config 2: plain walk; 9.7 at config 3)
+constexpr uint32_t kPickTagAbove = 0;    // ... and the tagged-word walk: it wins at every depth (scripts/exp_walk_crossover.py:
+                                         // 72 vs 81 us at 3 hits per read, 100 vs 144 at 12); the plain walk serves >= 2^18 references
 __device__ __forceinline__ uint32_t pick_mode(uint32_t sample, uint32_t runs, uint32_t tag_ok, int force) {
     uint32_t mode = 0u;
     if (runs != 0u) {

@@ -962,14 +962,18 @@ __global__ __launch_bounds__(kHBlock) void k_runs_hash(const Acc acc, uint32_t n
 // Measured per 10 M records: look-back 82 us at 3 records/run, 100 at 10, 249 at 42; hash table ~125 at any depth.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPickSample = 2048;  // one trip of k_zero_pick (8 records per thread); 8192 cost 3 us more per file
-constexpr uint32_t kPickHashAbove = 16;  // records per qName run above which the hash-table kernel is picked
+constexpr uint32_t kPickHashAbove = 16;  // records per qName run above which the hash-table kernel beats the plain walk
+constexpr uint32_t kPickHashAboveTagged = 28;  // ... and the tagged-word walk (125 vs 148 us at 24 per run, level at 29)
 constexpr uint32_t kPickTagAbove = 0;    // ... and the tagged-word walk: it wins at every depth (scripts/exp_walk_crossover.py:
                                          // 72 vs 81 us at 3 hits per read, 100 vs 144 at 12); the plain walk serves >= 2^18 references
 __device__ __forceinline__ uint32_t pick_mode(uint32_t sample, uint32_t runs, uint32_t tag_ok, int force) {
     uint32_t mode = 0u;
     if (runs != 0u) {
         const uint32_t per_run = sample / runs;
-        mode = per_run > kPickHashAbove ? 1u : ((tag_ok && per_run >= kPickTagAbove) ? 2u : 0u);
+        if (tag_ok && per_run >= kPickTagAbove)
+            mode = per_run > kPickHashAboveTagged ? 1u : 2u;
+        else
+            mode = per_run > kPickHashAbove ? 1u : 0u;
     }
     if (force >= 0) mode = (force == 2 && !tag_ok) ? 0u : static_cast<uint32_t>(force);
     return mode;

@@ -492,22 +492,22 @@ __device__ __forceinline__ void runs_walk(const Acc& acc, uint32_t ntiles, uint3
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_runs_t: k_runs for streams with longer qName runs (about 5 - 16 records per run) and fewer than 2^18 references.
+// runs_tagged: the body of k_runs for databases of fewer than 2^18 references (every BASELINE config).
 //
-// k_runs' duplicate walk costs 23 vector instructions per step for a thread's four records (clamped address, LDS read,
-// xor, mask, min) and runs to the longest run of the wave: 250 of 800 instructions per pass at 3 hits per read, 700 of
-// 1200 at 8.  Here the LDS word a walk compares carries the window position of the record's RUN START above {mapped,
+// The plain walk (runs_walk) costs 23 vector instructions per step for a thread's four records (clamped address, LDS
+// read, xor, mask, min) and runs to the longest run of the wave: 250 of 800 instructions per pass at 3 hits per read, 700
+// of 1200 at 8.  Here the LDS word a walk compares carries the window position of the record's RUN START above {mapped,
 // mate, reference}:
 //     bits 31-21 run start | bit 20 mapped | bits 19-18 mate | bits 17-0 reference
 // so "same read and same reference earlier in my run" is plain equality with my own word: records before my run's start
 // belong to runs that start earlier, the walk needs no clamp (it may read past the window's first word into a zeroed
 // guard, which never equals a mapped word) and no mask -- 8 instructions per step.  The run start is known only after
 // the segment carries, so the tagged words are written in the second stage, which therefore also covers the halo (a
-// fifth record for half the waves) behind one more barrier: ~75 instructions more per pass, which the shorter walk
-// does not earn back at 3 hits per read (112 vs 83 us at config 2).  Both stages use ONE record-to-thread mapping
-// (window index off + k * 256 + thread, plus the halo for the first 128 threads), so the second stage takes the
-// record's word from registers.  Everything else (flags, slow path for runs reaching back beyond the halo, outputs) is
-// k_runs'.
+// fifth record for half the waves) behind one more barrier.  Both stages use ONE record-to-thread mapping (window index
+// off + k * 256 + thread, plus the halo for the first 128 threads), so the second stage takes the record's word from
+// registers and ballots again (a first version handed the ballots over through LDS and lost: 112 vs 83 us).  Measured
+// (scripts/exp_walk_crossover.py, 10 M records): 72 vs 81 us at 3 hits per read, 88 vs 116 at 8, 125 vs 191 at 20.
+// Everything else (flags, slow path for runs reaching back beyond the halo, outputs) is runs_walk's.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t kTagRefBits = 18;
 constexpr uint32_t kTagGuard = kQTile + kHalo + 4;  // zero words below the window: the unclamped walk may read them

@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="records of the same stream the single-threaded CPU restatement is timed on (default: all)")
+    ap.add_argument("--no-bins", action="store_true",
+                    help="do not materialise the coverage arrays in HBM (slimm_keep_bins(0): their statistics are taken from "
+                         "the finished tiles in LDS either way; what `slimm` does without -co)")
     ap.add_argument("--cpu-passes", type=int, default=2, help="passes of the CPU restatement over that sample (2 = ~14 s)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--record-order", default="grouped", choices=["grouped", "any"],
@@ -139,6 +142,8 @@ def main():
 
     eng = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))
     eng.force_exchange = args.force_exchange
+    if args.no_bins:
+        eng.keep_bins(False)
     key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
     ref = torch.from_numpy(w.records.ref_id).to(dev)
     pos = torch.from_numpy(w.records.begin_pos).to(dev)
@@ -205,7 +210,10 @@ def main():
     value = total_records / (elapsed / args.steps) / 1e6
 
     if rank == 0:
-        Bp = int(eng.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
+        if args.no_bins:
+            Bp = int(st["total_bins"])  # (the padded count is a property of the buffer, which is not exposed here)
+        else:
+            Bp = int(eng.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
         model = algorithmic_bytes(st, n_rec, Bp)
         per_kernel = {}
         for name, (ms, launches) in ktimes.items():
@@ -275,7 +283,8 @@ def main():
                                    f"{cfg.bin_width} bp bins, {cfg.read_len} bp reads",
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
                        "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
-                       "record_order": args.record_order, "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
+                       "record_order": args.record_order, "coverage_arrays": "not materialised" if args.no_bins else "in HBM",
+                       "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
                        "exchange": (resolve_exchange(eng, args.exchange, world) if (world > 1 or args.force_exchange) else "none"),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,

@@ -118,6 +118,13 @@ int slimm_coverage_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
  * [cov bits | uniq_cov bits] block (all-gather form, below); n > 1 = the bitmaps cut into n slices of bin tiles, slice j
  * = [cov bits | uniq_cov bits] of rank j's share, for the all-to-all form. */
 int slimm_prepare_summary(slimm_ctx* ctx, uint32_t n_slices);
+
+/* The coverage arrays (cov, uniq_cov, uniq_cov2: reference src/reference_contig.hpp:70-72) are intermediate results of
+ * the path: the profile needs their per-reference sums and non-zero bin counts, which the tile kernels take from every
+ * finished tile while it is in LDS.  on = 0 before slimm_analyze_alignments: the finished tiles are not written to HBM
+ * (only what the reference's -co output, slimm_get_bins and slimm_coverage_buffer would read); those calls then fail
+ * with SLIMM_E_INVALID.  Default: on = 1. */
+int slimm_keep_bins(slimm_ctx* ctx, int on);
 /* Leaner exchange for the same point, used by default by slimm_amd/distributed.py: the cut-offs only need per-reference
  * SUMS of cov / uniq_cov (additive) and per-reference counts of NON-ZERO bins (popcount of the OR of every rank's
  * "bin != 0" bitmap).  slimm_coverage_summary() builds [sums | 16 scalars | cov bits | uniq_cov bits] for this rank in

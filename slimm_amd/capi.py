@@ -77,6 +77,7 @@ SYMBOLS = [
     ("slimm_analyze_alignments", C.c_int, [_P]),
     ("slimm_coverage_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("slimm_prepare_summary", C.c_int, [_P, C.c_uint32]),
+    ("slimm_keep_bins", C.c_int, [_P, C.c_int]),
     ("slimm_coverage_summary", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     ("slimm_finish_coverage_merged", C.c_int, [_P, _P, C.c_uint32]),
     ("slimm_merge_summary_slices", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64)]),

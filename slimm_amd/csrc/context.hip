@@ -122,6 +122,8 @@ struct slimm_ctx {
     DevBuf<uint32_t> tile_valid;
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;
+    bool keep_bins = true;       // materialise cov / uniq_cov / uniq_cov2 in HBM (slimm_keep_bins)
+    bool binsA_stored = false, binsB_stored = false;
     DevBuf<uint4> tile_items, part_items;
     DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
     DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
@@ -734,11 +736,14 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                 c->summary_has_bits = true;
             }
             launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
-                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout());
+                             c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout(),
+                             c->keep_bins ? 0u : c->ntiles);
+            c->binsA_stored = c->keep_bins;
         }
     } else {
         KernelTimer t(c, K_HIST);
         launch_hist(st, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->cov(), c->ucov());
+        c->binsA_stored = true;
     }
     HIP_TRY(c, hipGetLastError());
     c->analyzed = true;
@@ -749,6 +754,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
 int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    if (!c->binsA_stored) return fail(c, SLIMM_E_INVALID, "the coverage arrays were not kept (slimm_keep_bins)");
     (void)hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->bins_exposed = true;  // the statistics k_tile_hist accumulated describe the local bins only
@@ -806,6 +812,13 @@ int slimm_finish_coverage(slimm_ctx* c) {
     return finish_from_device_stats(c);
 }
 
+int slimm_keep_bins(slimm_ctx* c, int on) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "slimm_keep_bins: before slimm_analyze_alignments");
+    c->keep_bins = on != 0;
+    return SLIMM_OK;
+}
+
 int slimm_prepare_summary(slimm_ctx* c, uint32_t n_slices) {
     if (!c) return SLIMM_E_INVALID;
     if (n_slices > 1 && !c->use_tiles) return fail(c, SLIMM_E_INVALID, "sliced summaries need the tile histogram path");
@@ -845,6 +858,8 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
         pk.n[0] = 16;
         launch_ref_stats(st, c->cov(), c->ucov(), c->d_bin_off.p, c->R, c->summary.p, &pk);
     }
+    if (!have_bits && !c->binsA_stored)
+        return fail(c, SLIMM_E_INVALID, "no bit maps and no coverage arrays: call slimm_prepare_summary or slimm_keep_bins");
     if (!have_bits) {
         launch_nonzero_bits(st, c->cov(), c->Bp, c->summary.p + 4ull * c->R + 16);
         launch_nonzero_bits(st, c->ucov(), c->Bp, c->summary.p + 4ull * c->R + 16 + bits_words);
@@ -1033,7 +1048,9 @@ int slimm_filter_alignments(slimm_ctx* c) {
             {
                 KernelTimer t(c, K_TILE_HIST2);
                 launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
-                                 c->ucov2(), nullptr, c->d_bin_off.p, R, c->d_tile_ref0.p, blockB);
+                                 c->ucov2(), nullptr, c->d_bin_off.p, R, c->d_tile_ref0.p, blockB, BitsLayout(),
+                                 // (the tiles behind the bins hold the per-taxon LCA counts k_pack reads back)
+                                 c->keep_bins ? 0u : static_cast<uint32_t>(c->Bp / kTileBins));
             }
         }
         {
@@ -1084,6 +1101,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
     std::sort(c->part_pairs.begin(), c->part_pairs.end());
     h.set_partials_rows(s2, 4, s2 + 5ull * R + 32, s2 + 4ull * R + 32, c->part_pairs.data(), c->n_pairs);
     tr.mark("partials to host profile");
+    c->binsB_stored = !c->use_tiles || c->keep_bins;
     c->filtered = true;
     return SLIMM_OK;
 }
@@ -1297,6 +1315,8 @@ int slimm_get_bins(slimm_ctx* c, int which, uint32_t* out) {
     if (!c || !out || which < 0 || which > 2) return SLIMM_E_INVALID;
     if (c->device < 0 || !c->analyzed) return fail(c, SLIMM_E_INVALID, "no coverage bins on this context");
     if (which == 2 && !c->filtered) return fail(c, SLIMM_E_INVALID, "uniq_cov2 needs slimm_filter_alignments");
+    if (which < 2 ? !c->binsA_stored : !c->binsB_stored)
+        return fail(c, SLIMM_E_INVALID, "the coverage arrays were not kept (slimm_keep_bins)");
     (void)hipSetDevice(c->device);
     const uint32_t* src = which == 0 ? c->cov() : which == 1 ? c->ucov() : c->ucov2();
     std::vector<uint32_t> padded(c->Bp);

@@ -346,6 +346,7 @@ bool get_profiles(Session& S, size_t file_index) {
         return false;
     }
     CHECK(ctx, slimm_set_cutoff_cache(ctx, S.cc_cache, S.ucc_cache));
+    slimm_keep_bins(ctx, (S.options.raw_output || S.options.coverage_output) ? 1 : 0);  // (only -ro / -co read the arrays back)
     trace.mark("lineage table + slimm_create");
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;
 

@@ -200,7 +200,8 @@ void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, c
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
                       uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,
-                      const BitsLayout& bits = BitsLayout());  // bits: also the 'bin != 0' bitmaps of the two arrays
+                      const BitsLayout& bits = BitsLayout(), uint32_t store_from = 0);  // bits: also the 'bin != 0' bitmaps of the
+                      // two arrays; finished tiles below store_from are not written out (their statistics are still taken)
 // small arrays copied back to back to dst; with stats != nullptr also the non-zero bin counts of the tiles k_tile_hist
 // accumulated in pieces (split_tiles[0 .. counters[CNT_SPLIT])), read back from the finished arrays a / b
 void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint32_t* split_tiles = nullptr,

@@ -787,7 +787,7 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
                                                    const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov, const uint32_t* __restrict__ bin_off,
                                                    uint32_t n_refs, const uint32_t* __restrict__ tile_ref0,
-                                                   uint32_t* __restrict__ stats, const BitsLayout bits) {
+                                                   uint32_t* __restrict__ stats, const BitsLayout bits, uint32_t store_from) {
     __shared__ uint32_t s_cov[kTileBins];
     __shared__ uint32_t s_ucov[kTwo ? kTileBins : 4];
     __shared__ uint32_t s_off[kStatRefs + 1];  // bin offsets of the references overlapping this tile (and one more)
@@ -836,9 +836,14 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         // the statistics' atomics first: they come back from the memory side in ~2 us, and a workgroup retires only when
         // they have -- issued before the 64 KB of tile stores they are back by the time those are
         if (stats) tile_ref_stats<kTwo>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
-        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
-            oc[i] = sc[i];
-            if (kTwo) ou[i] = su[i];
+        // tiles below store_from: the caller only wants what is derived from the finished tile while it is in LDS
+        // (statistics, bit maps); the coverage arrays themselves are not materialised (tiles cut into pieces still are:
+        // they are summed in global memory)
+        if (tile >= store_from) {
+            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+                oc[i] = sc[i];
+                if (kTwo) ou[i] = su[i];
+            }
         }
         if (bits.base) {
             tile_nonzero_bits(s_cov, tile, bits, 0);
@@ -993,14 +998,14 @@ uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n
 // stats != nullptr: also accumulate the per-reference statistics (zeroed by the caller) of the finished arrays
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
-                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, const BitsLayout& bits) {
+                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, const BitsLayout& bits, uint32_t store_from) {
     const uint32_t grid = tile_items_upper(ntiles, n_upper);
     if (ucov)
         hipLaunchKernelGGL(k_tile_hist<true>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
-                           n_refs, tile_ref0, stats, bits);
+                           n_refs, tile_ref0, stats, bits, store_from);
     else
         hipLaunchKernelGGL(k_tile_hist<false>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov, bin_off,
-                           n_refs, tile_ref0, stats, bits);
+                           n_refs, tile_ref0, stats, bits, store_from);
 }
 
 }  // namespace slimm

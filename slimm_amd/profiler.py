@@ -114,6 +114,10 @@ class Slimm:
 
         return torch.as_tensor(self.coverage_buffer(), device=f"cuda:{self.device}")
 
+    def keep_bins(self, on: bool = True):
+        """Whether the coverage arrays are materialised in HBM (needed by bins() and coverage_tensor(); default yes)."""
+        self._check(self.L.slimm_keep_bins(self.ctx, 1 if on else 0))
+
     def prepare_summary(self, n_slices: int = 1):
         """Multi-GPU: have phase A write the coverage-summary bitmaps as a by-product (call before analyze_alignments).
         0 = off, 1 = all-gather layout, n > 1 = n slices for the all-to-all exchange."""

@@ -17,17 +17,21 @@ from tests.helpers import assert_matches_oracle, assert_profiles_match
 pytestmark = pytest.mark.gpu
 
 
-def run_gpu(w: Workload, grouped=None, batch=0, expect_hits=True) -> Slimm:
+def run_gpu(w: Workload, grouped=None, batch=0, expect_hits=True, keep_bins=True) -> Slimm:
     s = Slimm.for_workload(w, device=0, grouped=grouped)
+    if not keep_bins:
+        s.keep_bins(False)
     s.push_records(w.records, batch=batch)
     prof = s.get_profiles()
     assert (prof is not None) == expect_hits
     return s
 
 
-def check(w: Workload, grouped=None, batch=0, **kw):
+def check(w: Workload, grouped=None, batch=0, keep_bins=True, **kw):
     o = run_workload(w, use_qnames=w.records.qname is not None)
-    s = run_gpu(w, grouped, batch, expect_hits=not o.no_hits)
+    s = run_gpu(w, grouped, batch, expect_hits=not o.no_hits, keep_bins=keep_bins)
+    if not keep_bins:
+        kw["bins"] = False
     if o.no_hits:
         assert s.stats()["hits_count"] == 0
     else:
@@ -597,3 +601,24 @@ def test_medium_depth_streams_take_the_tagged_walk(hits):
                                   strain_level=True), seed=51)
     check(w)
     check(w, grouped=False)
+
+
+@pytest.mark.parametrize("mk", [tiny_case, holes_case, lambda: make_workload(CONFIGS["config1"], seed=61),
+                                lambda: make_workload(CONFIGS["config2"], seed=62, n_records=400_000),
+                                lambda: make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000,
+                                                                  len_hi=900_000, present_frac=0.3), seed=63)])
+def test_without_materialised_coverage_arrays(mk):
+    """slimm_keep_bins(0): the tile kernels take sums, non-zero counts and per-taxon counts from the finished tiles in LDS
+    and do not write them to HBM (tiles cut into pieces still are) -- every result but the arrays themselves is the
+    same, and asking for the arrays is an error."""
+    w = mk()
+    s, o = check(w, keep_bins=False)
+    rc = s.ref_columns()
+    assert np.array_equal(rc["nz_uniq_cov2"], o.nz_uniq_cov2)
+    with pytest.raises(capi.SlimmError):
+        s.bins(0)
+    with pytest.raises(capi.SlimmError):
+        s.bins(2)
+    with pytest.raises(capi.SlimmError):
+        s.coverage_tensor()
+    check(w, grouped=False, keep_bins=False)

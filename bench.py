@@ -106,6 +106,14 @@ def main():
                          "bitmap slices + small all-reduce (sliced), all-reduce of the bins; auto = summary up to 2 ranks")
     ap.add_argument("--kernel-timing", choices=("dominant", "all"), default="dominant",
                     help="HIP events in the timed steps: around the dominant kernel only (default) or around every launch")
+    ap.add_argument("--no-config3", action="store_true",
+                    help="skip the second measurement on BASELINE.json configs[2] (100 M records, 20 k refs: the "
+                         "designated HBM-roofline run), which adds ~15 s at N = 1")
+    ap.add_argument("--config3-steps", type=int, default=5)
+    ap.add_argument("--config3-records", type=int, default=0, help="records of that run (default: all 100 M)")
+    ap.add_argument("--push-batch", type=int, default=1 << 20, help="records per slimm_push_records call")
+    ap.add_argument("--push-steps", type=int, default=3,
+                    help="steps of the push-inclusive measurement (records start in host memory; 0 = skip)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-rank code path (process group, collectives) even with one rank")
     args = ap.parse_args()
@@ -209,37 +217,41 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_records / (elapsed / args.steps) / 1e6
 
-    if rank == 0:
+    def roofline_from(engine, stats, n_records, kt, steps, traffic_for=None):
+        """The roofline object of the dominant kernel + the per-kernel table, from HIP-event times `kt`
+        ({kernel: (ms, launches)} over `steps` steps)."""
         if args.no_bins:
-            Bp = int(st["total_bins"])  # (the padded count is a property of the buffer, which is not exposed here)
+            Bp = int(stats["total_bins"])  # (the padded count is a property of the buffer, which is not exposed here)
         else:
-            Bp = int(eng.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
-        model = algorithmic_bytes(st, n_rec, Bp)
+            Bp = int(engine.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
+        model = algorithmic_bytes(stats, n_records, Bp)
         per_kernel = {}
-        for name, (ms, launches) in ktimes.items():
+        for name, (ms, launches) in kt.items():
             if launches and name in model:
-                per_launch_ms = ms / launches
-                steps_launches = launches / args.steps
-                per_kernel[name] = {"ms_per_launch": per_launch_ms, "launches_per_step": steps_launches,
-                                    "bytes_per_launch": model[name] / max(1.0, steps_launches if name == "memset_bins" else 1.0),
-                                    }
+                steps_launches = launches / steps
+                per_kernel[name] = {"ms_per_launch": ms / launches, "launches_per_step": steps_launches,
+                                    "bytes_per_launch": model[name] / max(1.0, steps_launches if name == "memset_bins" else 1.0)}
         # of the two classification kernels the one the device did not pick returns at once (k_runs_hash then only sums
         # the per-tile counts by chunk): its bytes are those counts, not the records
         pair = [k for k in ("k_runs", "k_runs_hash") if k in per_kernel]
         if len(pair) == 2:
             idle = min(pair, key=lambda k: per_kernel[k]["ms_per_launch"])
-            per_kernel[idle]["bytes_per_launch"] = 12 * (n_rec // 2048 + 1)
+            per_kernel[idle]["bytes_per_launch"] = 12 * (n_records // 2048 + 1)
         # the dominant kernel = most time per step (memsets are DMA fills, not kernels of this library)
         cand = {k: v for k, v in per_kernel.items() if k not in ("memset_bins", "k_pick_runs")}
         dom = max(cand, key=lambda k: cand[k]["ms_per_launch"] * cand[k]["launches_per_step"])
         d = cand[dom]
         achieved = d["bytes_per_launch"] / (d["ms_per_launch"] * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc_traffic_bytes(dom, n_rec) if args.config == "config2" else None,
-                    "traffic_source": "profiles/round1/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes)",
-                    "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
+        roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic_bytes(dom, n_records) if traffic_for == "config2" else None,
+                "traffic_source": "profiles/round1/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes)",
+                "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
         kernel_ms = sum(v["ms_per_launch"] * v["launches_per_step"] for v in per_kernel.values())
+        return roof, per_kernel, kernel_ms
+
+    if rank == 0:
+        roofline, per_kernel, kernel_ms = roofline_from(eng, st, n_rec, ktimes, args.steps, traffic_for=args.config)
         if args.breakdown:
             print(f"# generate {gen_s:.1f}s; records/rank {n_rec}; V={st['hits_count']} M={st['matches_count']} "
                   f"P={st['n_targets']} U={st['uniq_matches_count']} U2={st['uniq_matches_count2']} "
@@ -252,6 +264,83 @@ def main():
             print(f"# device kernels {kernel_ms:.3f} ms of {ms_per_step:.3f} ms per step", file=sys.stderr)
             for k, v in phase_times.items():
                 print(f"# host wall {k:28s} {v / args.steps * 1e6:9.1f} us/step", file=sys.stderr)
+
+        # ---- push-inclusive rate: the clock starts before the first record leaves host
+        # memory and stops when the profile file is written.  Never `value`: PCIe, not the path, bounds it.
+        with_push = None
+        if world == 1 and args.push_steps > 0 and not args.force_exchange:
+            rec = w.records
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(args.push_steps + 1):   # the first pass sizes the library's own record buffers
+                eng.reset()
+                eng.reset_cutoffs()
+                t1 = time.perf_counter()
+                eng.push_records(rec, batch=args.push_batch)
+                eng.get_profiles(path=out_path)
+                dt = time.perf_counter() - t1
+                best = dt if best is None else min(best, dt)
+            with_push = {"value": round(n_rec / best / 1e6, 3), "unit": "M records/s", "ms_per_step": round(best * 1e3, 4),
+                         "what": f"first slimm_push_records (host arrays, batches of {args.push_batch}) to profile file "
+                                 f"written, best of {args.push_steps}; 18 B/record over PCIe",
+                         "gb_per_s_over_pcie": round(18.0 * n_rec / best / 1e9, 2)}
+
+        # ---- BASELINE.json configs[2]: the designated HBM-roofline run (100 M records, 20 k refs, mean 8 hits/read)
+        roof3 = None
+        if world == 1 and not args.no_config3 and args.config == "config2" and not args.force_exchange:
+            cfg3 = CONFIGS["config3"]
+            w3 = make_workload(cfg3, seed=args.seed, n_records=args.config3_records or cfg3.n_records)
+            n3 = len(w3.records)
+            eng3 = Slimm.for_workload(w3, device=local_rank, grouped=True)
+            if args.no_bins:
+                eng3.keep_bins(False)
+            k3 = torch.from_numpy(w3.records.read_key.view(np.int64)).to(dev)
+            r3 = torch.from_numpy(w3.records.ref_id).to(dev)
+            p3 = torch.from_numpy(w3.records.begin_pos).to(dev)
+            f3 = torch.from_numpy(w3.records.flag.view(np.int16)).to(dev)
+            torch.cuda.synchronize()
+
+            def step3():
+                eng3.reset()
+                eng3.reset_cutoffs()
+                eng3.set_records_device(k3, r3, p3, f3)
+                return eng3.get_profiles(path=out_path)
+
+            eng3.enable_kernel_timing(True)
+            step3()                                   # cold step: allocations
+            eng3.kernel_times(reset=True)
+            step3()                                   # survey: every launch bracketed
+            survey3 = eng3.kernel_times(reset=True)
+            cand3 = {k: ms for k, (ms, n) in survey3.items() if n and k not in ("memset_bins", "k_pick_runs")}
+            dom3 = max(cand3, key=cand3.get)
+            eng3.time_only_kernel(dom3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.config3_steps):
+                step3()
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t1
+            live3 = eng3.kernel_times(reset=True)
+            kt3 = {k: (ms * args.config3_steps, n * args.config3_steps) for k, (ms, n) in survey3.items()}
+            kt3[dom3] = live3[dom3]
+            st3 = eng3.stats()
+            roof3, pk3, kms3 = roofline_from(eng3, st3, n3, kt3, args.config3_steps)
+            roof3.pop("traffic_source", None)
+            roof3.update({"workload": f"BASELINE.json configs[2] (config3): {n3} records, {cfg3.n_refs} refs, mean "
+                                      f"{cfg3.mean_hits} hits/read, {cfg3.bin_width} bp bins; records resident in HBM "
+                                      f"before the timed region",
+                          "steps": args.config3_steps, "ms_per_step": round(el3 / args.config3_steps * 1e3, 4),
+                          "value": round(n3 / (el3 / args.config3_steps) / 1e6, 3), "unit_value": "M records/s",
+                          "device_kernel_ms_per_step": round(kms3, 4),
+                          "reads": st3["matches_count"], "targets": st3["n_targets"], "bins": st3["total_bins"]})
+            if args.breakdown:
+                print(f"# config3: {n3} records, {el3 / args.config3_steps * 1e3:.3f} ms/step", file=sys.stderr)
+                for k, v in sorted(pk3.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"]):
+                    gbs = v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9
+                    print(f"# c3 {k:16s} {v['ms_per_launch']*1e3:9.1f} us/launch x{v['launches_per_step']:.0f}  "
+                          f"{v['bytes_per_launch']/1e6:9.1f} MB  {gbs:8.1f} GB/s  {gbs/HBM_PEAK_GBS*100:5.1f}% of HBM peak",
+                          file=sys.stderr)
+            eng3.close()
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -284,10 +373,13 @@ def main():
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
                        "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
                        "record_order": args.record_order, "coverage_arrays": "not materialised" if args.no_bins else "in HBM",
+                       "records": "resident in HBM before the timed region (value_with_push starts in host memory)",
                        "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
                        "exchange": (resolve_exchange(eng, args.exchange, world) if (world > 1 or args.force_exchange) else "none"),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,
+            "roofline_config3": roof3,
+            "value_with_push": with_push,
             "cpu_baseline": cpu,
             "device_kernel_ms_per_step": round(kernel_ms, 4),
             "kernel_timing": ("HIP events around " + (f"{dom_name} only in the timed steps (other kernels: warm-up survey)"

@@ -59,7 +59,9 @@ class _Stream:
             k += 1
         if k == j:
             self.ok = False
-            return old
+            # the sentry fails (value untouched) when only white space is left; num_get stores 0 when what follows is
+            # not a number (C++11)
+            return old if i >= len(self.s) else 0
         self.i = k
         return min(int(self.s[j:k]), 0xFFFFFFFF)
 

@@ -184,6 +184,16 @@ bool parse_u32(const char* p, const char* end, uint32_t& out) {
     return true;
 }
 
+// `stream >> value` of a std::stringstream positioned at p (C++11 libstdc++, what the reference's
+// `linestream >> taxid` does, src/slimm_build.cpp:189): white space is skipped first; when the text ends there the
+// sentry fails and the value is left alone; otherwise num_get runs, and a field that does not start a number
+// stores 0 (LWG 23 / C++11), an overflowing one stores the maximum.
+void stream_extract_u32(const char* p, const char* end, uint32_t& out) {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\v' || *p == '\f' || *p == '\n')) ++p;
+    if (p >= end) return;
+    if (!parse_u32(p, end, out)) out = 0;
+}
+
 // up to `want` tab-separated fields of a line
 size_t split_tabs(const char* p, size_t n, const char** f, size_t* fl, size_t want) {
     size_t k = 0;
@@ -277,7 +287,8 @@ bool get_taxid_from_accession(SlimmDatabase& db, std::set<std::string>& accessio
         bool more = true;
         while (more) {
             hits.clear();
-            uint32_t taxid = 0, lines = 0;  // `taxid` survives a line without a number (the header line), :180-189
+            uint32_t taxid = 0, lines = 0;  // `taxid` survives a line that ends before its third column; a third
+                                            // column that is not a number (the header line) stores 0, :180-189
             const char* p;
             size_t n;
             std::string ac;
@@ -285,7 +296,7 @@ bool get_taxid_from_accession(SlimmDatabase& db, std::set<std::string>& accessio
                 const char* f[3];
                 size_t fl[3];
                 size_t k = split_tabs(p, n, f, fl, 3);
-                if (k == 3) parse_u32(f[2], p + n, taxid);
+                if (k == 3) stream_extract_u32(f[2], p + n, taxid);
                 ac.assign(f[0], fl[0]);
                 if (accessions.count(ac)) hits[ac] = taxid;
                 if (++lines >= o.batch) break;

@@ -560,21 +560,35 @@ def _order_preserving_interleave(rec: Records, seed: int) -> Records:
     return rec.take(inv)
 
 
-def test_full_size_config2_invariants():
-    w = make_workload(CONFIGS["config2"], seed=1)            # 10 M records, 5 k refs
-    s = run_gpu(w)
+def _full_size_invariants(w: Workload, s: Slimm, permutation: bool):
+    """Size-independent properties of one finished run (nothing here needs the oracle, which would take minutes)."""
     st = s.stats()
     rc = s.ref_columns()
     cov, ucov, ucov2 = s.bins(0), s.bins(1), s.bins(2)
-    mapped = int(((w.records.flag & 4) == 0).sum() - ((w.records.ref_id < 0) & ((w.records.flag & 4) == 0)).sum())
-    assert st["hits_count"] == mapped
+    mapped = int((((w.records.flag & 4) == 0) & (w.records.ref_id >= 0)).sum())
+    assert st["hits_count"] == mapped % 2**32                      # uint32 like the reference's counter (Q11)
     assert int(cov.sum(dtype=np.uint64)) == st["n_targets"] == int(rc["reads_count"].sum(dtype=np.uint64))
     assert int(ucov.sum(dtype=np.uint64)) == st["uniq_matches_count"] == int(rc["uniq_reads_count"].sum(dtype=np.uint64))
-    assert int(ucov2.sum(dtype=np.uint64)) == st["uniq_matches_count2"]
+    assert int(ucov2.sum(dtype=np.uint64)) == st["uniq_matches_count2"] == int(rc["uniq_reads_count2"].sum(dtype=np.uint64))
     assert np.all(ucov <= cov)
     off = np.concatenate([[0], np.cumsum(rc["nbins"].astype(np.int64))])
     assert np.array_equal(np.add.reduceat((cov != 0).astype(np.int64), off[:-1]), rc["nz_cov"])
+    assert np.array_equal(np.add.reduceat((ucov != 0).astype(np.int64), off[:-1]), rc["nz_uniq_cov"])
+    assert np.array_equal(np.add.reduceat(cov.astype(np.int64), off[:-1]), rc["reads_count"])
+    assert np.array_equal(np.add.reduceat(ucov.astype(np.int64), off[:-1]), rc["uniq_reads_count"])
     assert np.array_equal(np.add.reduceat(ucov2.astype(np.int64), off[:-1]), rc["uniq_reads_count2"])
+    assert np.array_equal(np.add.reduceat((ucov2 != 0).astype(np.int64), off[:-1]), rc["nz_uniq_cov2"])
+    # every target of an invalid reference is dropped by the filter: nothing of it may reach uniq_cov2
+    assert not np.any(rc["uniq_reads_count2"][rc["valid"] == 0])
+    # an independent count of the reads: distinct (qName, mate) among the mapped records (src/slimm.hpp:204-211)
+    m =((w.records.flag & 4) == 0) & (w.records.ref_id >= 0)
+    mate = np.where(w.records.flag[m] & 0x40, 1, np.where(w.records.flag[m] & 0x80, 2, 0)).astype(np.uint64)
+    ident = (w.records.read_key[m] << np.uint64(2)) | mate
+    n_reads = int(np.unique(ident).shape[0])
+    assert st["matches_count"] == n_reads % 2**32
+    # an independent count of the targets: distinct (read, reference) pairs
+    pair_hash = ident * np.uint64(0x9E3779B97F4A7C15) + w.records.ref_id[m].astype(np.uint64)
+    assert abs(int(np.unique(pair_hash).shape[0]) - st["n_targets"]) <= 2   # (64-bit mixing: collisions are ~1e-3 events)
     # reads whose targets all fail the filter vanish; the rest are unique-after-filter or counted at their LCA
     direct = s.taxon_counts(0)
     assert st["uniq_matches_count2"] + sum(direct.values()) <= st["matches_count"]
@@ -584,13 +598,45 @@ def test_full_size_config2_invariants():
     rows = parse_profile(s.write_abundance())
     assert sum(v[1] for v in rows.values()) == st["matches_count"]
     assert sum(v[0] for v in rows.values()) == pytest.approx(100.0, abs=1e-3)
-    # permutation invariance: interleaving reads (order inside a read kept) + the sort path gives identical results
-    w2 = Workload(w.ref_names, w.ref_len, w.taxonomy, _order_preserving_interleave(w.records, 5), w.avg_read_len,
-                  w.options, "interleaved", grouped=False)
-    s2 = run_gpu(w2)
-    assert np.array_equal(s2.bins(0), cov) and np.array_equal(s2.bins(1), ucov) and np.array_equal(s2.bins(2), ucov2)
-    assert s2.taxon_counts(1) == s.taxon_counts(1) and s2.children_pairs(1) == s.children_pairs(1)
-    assert s2.write_abundance() == s.write_abundance()
+    if permutation:
+        # permutation invariance: interleaving reads (order inside a read kept) + the sort path gives identical results
+        w2 = Workload(w.ref_names, w.ref_len, w.taxonomy, _order_preserving_interleave(w.records, 5), w.avg_read_len,
+                      w.options, "interleaved", grouped=False)
+        s2 = run_gpu(w2)
+        assert np.array_equal(s2.bins(0), cov) and np.array_equal(s2.bins(1), ucov) and np.array_equal(s2.bins(2), ucov2)
+        assert s2.taxon_counts(1) == s.taxon_counts(1) and s2.children_pairs(1) == s.children_pairs(1)
+        assert s2.write_abundance() == s.write_abundance()
+    return st
+
+
+def test_full_size_config2_invariants():
+    w = make_workload(CONFIGS["config2"], seed=1)            # 10 M records, 5 k refs
+    _full_size_invariants(w, run_gpu(w), permutation=True)
+
+
+def test_full_size_config3_invariants():
+    """BASELINE.json configs[2] at full size: 100 M records, 20 k references, mean 8 hits per read."""
+    w = make_workload(CONFIGS["config3"], seed=1)
+    st = _full_size_invariants(w, run_gpu(w), permutation=False)
+    assert st["n_records"] == 100_000_000 and st["total_bins"] > 60_000_000
+
+
+def test_full_size_config5_invariants():
+    """BASELINE.json configs[4] at full size: 100 M records, 50 k strain-level references, mean 40 hits per read
+    (the hash classification, two-level bucketing and deep-LCA paths at their real sizes)."""
+    w = make_workload(CONFIGS["config5"], seed=1)
+    s = run_gpu(w)
+    st = _full_size_invariants(w, s, permutation=False)
+    assert st["n_records"] == 100_000_000 and st["total_bins"] > 150_000_000
+    assert len(s.taxon_counts(0)) > 100   # strain-level database: LCAs at levels 0 / 1 are frequent
+
+
+@pytest.mark.parametrize("name,n", [("config3", 3_000_000), ("config5", 2_000_000), ("config4", 2_000_000)])
+def test_prefix_of_the_big_configs_with_their_full_reference_sets(name, n):
+    """The first n records of configs[2] / [4] / [3] with ALL 20 k / 50 k references of the configuration (the big-table
+    paths: > 4096 bin tiles -> separate tile scan, > 16 K tiles -> two-level bucketing, wide per-level indices)
+    compared with the oracle bit for bit."""
+    check(make_workload(CONFIGS[name], seed=2, n_records=n))
 
 
 @pytest.mark.parametrize("hits", [6.0, 9.0, 14.0])

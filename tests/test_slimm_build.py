@@ -184,3 +184,23 @@ def test_builder_matches_oracle_on_random_dumps(tmp_path, seed):
     assert tn == o_tn
     missed_file = tmp_path / "o.missed"
     assert (missed_file.read_text().split() if missed_file.exists() else []) == missed
+
+
+def test_mapping_lines_without_a_number_follow_the_stream_semantics_of_the_reference(tmp_path):
+    """`linestream >> taxid` (reference src/slimm_build.cpp:189, C++11 libstdc++): a third column that is not a number
+    stores 0; a line that ends before its third column leaves the previous line's taxid in place."""
+    (tmp_path / "r.fa").write_text(">A1.1\nAC\n>B1.1\nGT\n>C1.1\nAA\n")
+    (tmp_path / "nodes.dmp").write_text("".join(f"{t}\t|\t{p}\t|\t{r}\t|\n" for t, p, r in
+                                                [(1, 1, "no rank"), (10, 1, "superkingdom"), (30, 10, "species")]))
+    (tmp_path / "names.dmp").write_text("".join(f"{t}\t|\tname{t}\t|\t\t|\tscientific name\t|\n" for t in (1, 10, 30)))
+    # A1: taxid column "n/a" -> 0.  B1 then carries C1's 30?  No: B1's line is short, so it keeps the taxid of the line
+    # BEFORE it (X9 -> 30).  C1: only white space in the third column -> also the previous value (30).
+    (tmp_path / "m.a2t").write_text("A1\tA1.1\tn/a\t1\nX9\tX9.1\t30\t1\nB1\tB1.1\nC1\tC1.1\t  \n")
+    d = {"fasta": str(tmp_path / "r.fa"), "nodes": str(tmp_path / "nodes.dmp"), "names": str(tmp_path / "names.dmp"),
+         "acc": [str(tmp_path / "m.a2t")]}
+    out = str(tmp_path / "o.sldb")
+    run_builder(d, out)
+    ac, tn = read_sldb(out)
+    assert ac["A1"][0] == 0 and ac["B1"][0] == 30 and ac["C1"][0] == 30
+    o_ac, o_tn, missed = build_db.build(d["fasta"], d["acc"], d["nodes"], d["names"])
+    assert (ac, tn) == (o_ac, o_tn) and missed == []

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
                                                         const uint32_t* __restrict__ counters, int count_slot,
                                                         uint32_t ntiles, uint32_t* __restrict__ tile_count_all,
                                                         uint32_t reps, uint32_t rep_stride) {
-    extern __shared__ uint32_t s_hist[];
+    HIP_DYNAMIC_SHARED(uint32_t, s_hist)
     const uint32_t P = counters[count_slot];
     // 512 workgroups adding to the same 2.4 K counters serialise in the memory-side atomic units: every workgroup adds to
     // one of `reps` copies instead, and k_tile_scan sums the copies
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
                                                           uint32_t* __restrict__ ucov,
                                                           const uint32_t* __restrict__ rep_base_all, uint32_t reps,
                                                           uint32_t rep_stride) {
-    extern __shared__ uint32_t s_hist[];
+    HIP_DYNAMIC_SHARED(uint32_t, s_hist)
     const uint32_t P = counters[count_slot];
     const size_t rep_off = static_cast<size_t>(blockIdx.x % reps) * rep_stride;
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
                                                                 uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
                                                                 uint32_t* __restrict__ ucov, uint32_t rep_stride,
                                                                 uint4* __restrict__ items, uint32_t* __restrict__ split_tiles) {
-    extern __shared__ uint32_t s_hist[];             // [ntiles] chunk histogram / cursors (scatter_chunk)
+    HIP_DYNAMIC_SHARED(uint32_t, s_hist)             // [ntiles] chunk histogram / cursors (scatter_chunk)
     __shared__ uint32_t s_base[kFusedTiles + 1];     // tile totals, then their exclusive scan (= tile_base)
     __shared__ uint32_t s_mine[kFusedTiles];         // start of this workgroup's copy inside every tile's bucket
     __shared__ uint32_t s_wtot[8];

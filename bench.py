@@ -45,14 +45,12 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "sort_by_ident": 8 * (2 * 16 * V + 8 * V),   # (sort path only) 8 passes: keys+payload in and out, keys again for the histogram
         "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
         "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
-        "k_pick_runs": 8 * 8192,                      # samples the first records to choose the classification kernel
-        "k_runs": 14 * N + 1 * N,                     # key + ref + flag in (look-back is an LDS walk), flag byte out
-        "k_runs_hash": 14 * N + 1 * N,                # same bytes; whichever of the two was not picked returns at once
-        "k_emit": 1 * N + 8 * N + 8 * P + 4 * M,      # flag byte + ref + pos of every record in; targets + read offsets out
+        "k_front": 18 * N + 8 * P + 16 * (N // 1024 + 1),  # every record once (key 8 + ref 4 + pos 4 + flag 2 bytes); targets (ref word
+                                                      # + bin word) and the slot descriptors out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
         "k_tile_count": 4 * P,                        # gbin in
         "k_tile_scan": 12 * (B // 8192 + 1),
-        "k_tile_scatter": 8 * P + 2 * P,              # gbin + ref in, 16-bit bucket entries out
+        "k_tile_scatter": 4 * P + 2 * P,              # bin words in (the unique bit rides in bit 31), 16-bit bucket entries out
         "k_tile_hist": 2 * P + 8 * B,                 # bucket in, finished cov + uniq_cov tiles out (replaces the zero-fill)
         "k_tile_count2": 4 * M,                       # per-read bin (or marker) in
         "k_tile_scan2": 12 * (B // 8192 + 1),
@@ -61,7 +59,7 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "k_ref_stats": 8 * B,                         # (multi-GPU bins exchange / fallback) one streaming read of cov and uniq_cov
         "k_pack": 4 * 2 * 48,                         # counters + scalars copied behind the statistics k_tile_hist accumulated
         "k_pack2": 4 * 2 * (32 + 5000 + 9000),        # counters, child marks, per-taxon counts
-        "k_filter_lca": 4 * M + 8 * P + 4 * M,        # offsets + targets in; per-read unique bin out
+        "k_filter": 8 * P + 4 * M,                    # targets in (lineage rows are cache resident); one selector per read out
         "k_ref_stats2": 4 * B,
     }
 

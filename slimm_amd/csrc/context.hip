@@ -69,15 +69,15 @@ struct PinBuf {
 };
 
 enum KernelId {
-    K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FLAGS, K_BUILD_CSR, K_HIST, K_REF_STATS, K_FILTER_LCA,
+    K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FRONT, K_HIST, K_REF_STATS, K_FILTER,
     K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_TILE_COUNT2, K_TILE_SCAN2, K_TILE_SCATTER2,
-    K_TILE_HIST2, K_PICK, K_RUNS_HASH, K_PACK, K_PACK2, K_COUNT
+    K_TILE_HIST2, K_PACK, K_PACK2, K_COUNT
 };
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
-                                     "k_runs", "k_emit", "k_hist", "k_ref_stats", "k_filter_lca", "k_ref_stats2",
+                                     "k_front", "k_hist", "k_ref_stats", "k_filter", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",
                                      "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2",
-                                     "k_pick_runs", "k_runs_hash", "k_pack", "k_pack2"};
+                                     "k_pack", "k_pack2"};
 
 constexpr uint32_t kTailWords = 64;
 
@@ -115,18 +115,17 @@ struct slimm_ctx {
     // work arrays
     DevBuf<uint64_t> c_ident, s_ident;
     DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist;
-    DevBuf<uint8_t> c_fl;
-    DevBuf<uint32_t> tgt_ref, tgt_gbin, read_off;
-    DevBuf<uint2> tile_cnt;
-    DevBuf<uint4> scan_sums;  // chunk sums of the multi-workgroup tile scan
-    DevBuf<uint32_t> tile_valid;
+    DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
+    DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
+    DevBuf<uint2> tile_cnt;              // (record_order = ANY: mapped records per tile of the compaction)
+    DevBuf<uint4> scan_sums;             // chunk sums of the multi-workgroup tile scan
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;
     bool keep_bins = true;       // materialise cov / uniq_cov / uniq_cov2 in HBM (slimm_keep_bins)
     bool binsA_stored = false, binsB_stored = false;
     DevBuf<uint4> tile_items, part_items;
     DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
-    DevBuf<uint32_t> uniq_gbin;                         // per read: bin of its single valid target, or 0xffffffff
+    DevBuf<uint32_t> sel;                               // per read (slot.x + k): its uniq_cov2 bin, Bp + LCA taxon, or 0xffffffff
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
     bool fused_scan = false;                            // k_tile_scan runs inside the one-level bucketing kernel
@@ -273,22 +272,20 @@ void drain_events(slimm_ctx* c) {
 
 int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     const uint32_t nt = num_tiles(n) + 2;
-    HIP_TRY(c, c->c_fl.ensure(n + 1));
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
-    HIP_TRY(c, c->read_off.ensure(static_cast<size_t>(n) + 2));
-    HIP_TRY(c, c->tile_cnt.ensure(nt));
-    HIP_TRY(c, c->scan_sums.ensure(kScanMaxChunks));
-    HIP_TRY(c, c->tile_valid.ensure(nt));
+    HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
+    HIP_TRY(c, c->sel.ensure(n + 1));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles2, n) + 1));
-        HIP_TRY(c, c->uniq_gbin.ensure(n + 1));
         HIP_TRY(c, c->mid.ensure(n + 1));
         HIP_TRY(c, c->part_items.ensure(part_items_upper(c->ntiles2, n) + 1));
         HIP_TRY(c, c->sup_cursor.ensure(kMaxSuper));
     }
     if (c->order == SLIMM_ORDER_ANY) {
+        HIP_TRY(c, c->tile_cnt.ensure(nt));
+        HIP_TRY(c, c->scan_sums.ensure(kScanMaxChunks));
         HIP_TRY(c, c->c_ident.ensure(n + 1));
         HIP_TRY(c, c->c_ref.ensure(n + 1));
         HIP_TRY(c, c->c_gbin.ensure(n + 1));
@@ -311,8 +308,6 @@ int ensure_pair_table(slimm_ctx* c, uint32_t cap) {
 
 int check_device_errors(slimm_ctx* c, uint32_t err) {
     if (err & ERR_REF_RANGE) return fail(c, SLIMM_E_REF_RANGE, "a record names a reference id >= n_refs");
-    if (err & ERR_RUN_LENGTH)
-        return fail(c, SLIMM_E_RUN_LENGTH, "a read has more than 4096 alignment records in one run");
     return SLIMM_OK;
 }
 
@@ -328,7 +323,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     if (!cfg || !out) return fail(nullptr, SLIMM_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->n_refs == 0 || !cfg->ref_len || !cfg->lineage) return fail(nullptr, SLIMM_E_INVALID, "no references");
-    if (cfg->n_refs >= (1u << 28) - 1) return fail(nullptr, SLIMM_E_INVALID, "too many references (limit 2^28 - 2)");
+    if (cfg->n_refs > kMaxRefs) return fail(nullptr, SLIMM_E_INVALID, "too many references (limit 2^26 - 1)");
     if (cfg->bin_width == 0 && cfg->avg_read_len == 0)
         return fail(nullptr, SLIMM_E_INVALID, "bin_width and avg_read_len are both 0 (the reference divides by zero)");
     HostConfig hc;
@@ -365,14 +360,14 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     for (uint32_t r = 0; r < c->R; ++r) {
         c->bin_off_h[r] = static_cast<uint32_t>(off);
         off += (static_cast<uint64_t>(c->host->nbins()[r]) + 3) & ~3ull;
-        if (off >= 0xfffffff0ull) return fail(nullptr, SLIMM_E_INVALID, "more than 2^32 coverage bins; use a larger bin width");
+        if (off >= kMaxBins) return fail(nullptr, SLIMM_E_INVALID, "more than 2^31 coverage bins; use a larger bin width");
     }
     c->bin_off_h[c->R] = static_cast<uint32_t>(off);
     c->Bp = (off + kTileBins - 1) & ~static_cast<uint64_t>(kTileBins - 1);
     c->ntiles = static_cast<uint32_t>(c->Bp >> kTileShift);
     c->Tpad = (c->T + kTileBins - 1) & ~(kTileBins - 1);
     c->ntiles2 = c->ntiles + (c->Tpad >> kTileShift);
-    if (c->Bp + c->Tpad >= 0xfffffff0ull) return fail(nullptr, SLIMM_E_INVALID, "more than 2^32 coverage bins; use a larger bin width");
+    if (c->Bp + c->Tpad >= kMaxBins) return fail(nullptr, SLIMM_E_INVALID, "more than 2^31 coverage bins; use a larger bin width");
 
     if (c->device >= 0) {
         slimm_ctx* cc = c.get();
@@ -599,19 +594,13 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     if (rc != SLIMM_OK) return rc;
     tr.mark("set device + buffers");
     hipStream_t st = c->stream;
-    const bool no_fused_emit = getenv("SLIMM_NO_FUSED_EMIT") != nullptr;  // tests: the scan-kernel path
-    const bool fused_emit = c->order == SLIMM_ORDER_GROUPED && num_tiles(n) > 0 && num_tiles(n) <= kFusedEmitTiles &&
-                            !no_fused_emit;
-    uint32_t emit_shift = emit_chunk_shift(num_tiles(n));
-    if (const char* e = getenv("SLIMM_EMIT_CHUNK_SHIFT")) {  // tests: larger chunks on small inputs
-        const long v = atol(e);
-        if (v >= static_cast<long>(emit_shift) && v <= 8) emit_shift = static_cast<uint32_t>(v);
-    }
     {
         KernelTimer t(c, K_MEMSET);
         if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)
             HIP_TRY(c, hipMemsetAsync(c->bins.p, 0, 2 * c->Bp * sizeof(uint32_t), st));
         ZeroArgs z;
+        z.p[0] = c->counters.p;
+        z.n[0] = CNT_WORDS;
         z.p[1] = c->tail();
         z.n[1] = kTailWords;
         if (c->use_tiles) {
@@ -624,23 +613,14 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                 z.n[4] = c->treps * c->tstride;
             }
         }
-        if (c->order == SLIMM_ORDER_GROUPED) {  // the same launch clears the counters and picks the classification kernel
-            if (fused_emit) {  // chunk sums of the per-tile counts, in place of a scan launch
-                z.p[0] = reinterpret_cast<uint32_t*>(c->scan_sums.p);
-                z.n[0] = 4u * (((num_tiles(n) - 1u) >> emit_shift) + 1u);
-            }
-            launch_zero_pick_raw(st, z, c->rec, c->counters.p, c->R);
-        } else {
-            z.p[0] = c->counters.p;
-            z.n[0] = CNT_WORDS;
-            launch_zero(st, z);
-        }
+        launch_zero(st, z);
     }
     c->bins_exposed = false;
     c->statsA_final = false;
     const uint32_t nt = num_tiles(n);
     const HostConfig& hc = c->host->config();
     const uint32_t half_read = hc.avg_read_len / 2;
+    const uint32_t nslots = front_slots(n);
     if (c->order == SLIMM_ORDER_ANY) {
         // compaction of the mapped records, then a stable sort by read identity makes every read a contiguous run
         {
@@ -661,55 +641,32 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
                                  c->s_gbin.p, c->sort_hist.p);
         }
-        const int ids[3] = {K_PICK, K_FLAGS, K_RUNS_HASH};
-        for (int part = 0; part < 3; ++part) {
-            KernelTimer t(c, ids[part]);
-            launch_runs_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->c_fl.p, c->tile_cnt.p, part,
-                               c->R);
-        }
         {
-            KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, nullptr, -1, c->tail(),
-                              c->scan_sums.p);
-        }
-        {
-            KernelTimer t(c, K_BUILD_CSR);
-            launch_emit_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->c_fl.p, c->counters.p, c->tile_cnt.p,
-                               c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p);
+            KernelTimer t(c, K_FRONT);
+            launch_front_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
+                                c->slots.p);
         }
     } else {
-        // grouped input: classify and emit straight from the caller's record arrays
-        const int ids[3] = {K_PICK, K_FLAGS, K_RUNS_HASH};
-        for (int part = 1; part < 3; ++part) {  // (part 0, the pick, rode along with the clearing kernel)
-            KernelTimer t(c, ids[part]);
-            launch_runs_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width, c->counters.p,
-                            c->c_fl.p, c->tile_cnt.p, c->tile_valid.p, part,
-                            fused_emit ? reinterpret_cast<uint32_t*>(c->scan_sums.p) : nullptr, emit_shift);
-        }
-        if (!fused_emit) {
-            KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_M, CNT_P, c->read_off.p, c->tile_valid.p, CNT_V,
-                              c->tail(), c->scan_sums.p);
-        }
-        {
-            KernelTimer t(c, K_BUILD_CSR);
-            launch_emit_raw(st, c->rec, c->R, c->d_ref_len.p, c->d_bin_off.p, c->d_geo.p, half_read, hc.bin_width, c->c_fl.p,
-                            c->counters.p, c->tile_cnt.p, c->tgt_ref.p, c->tgt_gbin.p, c->read_off.p,
-                            fused_emit ? reinterpret_cast<const uint32_t*>(c->scan_sums.p) : nullptr,
-                            fused_emit ? c->tail() : nullptr, emit_shift);
-        }
+        // grouped input: one pass straight over the caller's record arrays
+        KernelTimer t(c, K_FRONT);
+        launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
+                         c->slots.p);
     }
+    SlotValues targets;
+    targets.vals = c->tgt_gbin.p;
+    targets.slots = c->slots.p;
+    targets.nslots = nslots;
+    targets.per_read = false;
     if (c->use_tiles) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p, c->treps, c->tstride);
+            launch_tile_count(st, grid, c->ntiles, targets, c->counters.p, c->tail(), c->tile_count.p, c->treps, c->tstride);
         }
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER);
-            launch_tile_scatter_fused(st, grid, c->ntiles, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_count.p,
-                                      c->tile_cursor.p, c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p,
-                                      c->split_tiles.p);
+            launch_tile_scatter_fused(st, grid, c->ntiles, targets, c->counters.p, c->tile_count.p, c->tile_cursor.p,
+                                      c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p, c->split_tiles.p);
         } else {
             {
                 KernelTimer t(c, K_TILE_SCAN);
@@ -719,9 +676,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER);
-                launch_tile_scatter(st, grid, c->ntiles, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, CNT_P, c->tile_base.p,
-                                    c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(),
-                                    c->ucov(), c->two_level, c->tile_count.p, c->treps, c->tstride);
+                launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
+                                    c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
+                                    c->two_level, c->tile_count.p, c->treps, c->tstride);
             }
         }
         {
@@ -742,7 +699,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
     } else {
         KernelTimer t(c, K_HIST);
-        launch_hist(st, n, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->cov(), c->ucov());
+        launch_hist(st, c->tgt_gbin.p, c->slots.p, nslots, c->counters.p, c->tail(), c->cov(), c->ucov());
         c->binsA_stored = true;
     }
     HIP_TRY(c, hipGetLastError());
@@ -978,7 +935,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
             ZeroArgs z;
             z.p[0] = c->marks.p;
-            z.n[0] = R * (c->use_rows16 ? kMarkBytes / 4 : 1u);
+            z.n[0] = R * (kMarkBytes / 4);  // one byte per (reference, level)
             z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
             z.n[1] = 2;
             if (c->use_tiles) {
@@ -1005,32 +962,51 @@ int slimm_filter_alignments(slimm_ctx* c) {
             }
             launch_zero(st, z);
         }
+        const uint32_t nslots = front_slots(c->rec.n);
         {
-            KernelTimer t(c, K_FILTER_LCA);
-            if (c->use_rows16)
-                launch_filter_lca16(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p,
-                                    c->d_rows16.p, c->d_level_taxon.p, h.level_offset(),
-                                    c->use_tiles ? nullptr : c->ucov2(), c->use_tiles ? c->uniq_gbin.p : nullptr,
-                                    c->lca_count.p, c->marks.p, c->pair_tab.p, c->pair_list.p, c->pair_cap - 1,
-                                    static_cast<uint32_t>(c->Bp), R);
-            else
-                launch_filter_lca(st, c->local_M, c->read_off.p, c->tgt_ref.p, c->tgt_gbin.p, c->counters.p, c->d_valid.p,
-                                  c->d_lin_dense.p, c->use_tiles ? nullptr : c->ucov2(),
-                                  c->use_tiles ? c->uniq_gbin.p : nullptr, c->lca_count.p, c->marks.p, c->pair_tab.p,
-                                  c->pair_list.p, c->pair_cap - 1, static_cast<uint32_t>(c->Bp));
+            KernelTimer t(c, K_FILTER);
+            FilterArgs fa;
+            fa.tgt_ref = c->tgt_ref.p;
+            fa.tgt_gbin = c->tgt_gbin.p;
+            fa.slots = c->slots.p;
+            fa.nslots = nslots;
+            if (c->use_rows16) {
+                fa.rows16 = c->d_rows16.p;
+                fa.level_taxon = c->d_level_taxon.p;
+                fa.level_off = h.level_offset();
+            } else {
+                fa.lin_dense = c->d_lin_dense.p;
+                fa.valid = c->d_valid.p;
+            }
+            fa.sel = c->sel.p;
+            fa.marks = c->marks.p;
+            fa.pair_tab = c->pair_tab.p;
+            fa.pair_list = c->pair_list.p;
+            fa.pair_mask = c->pair_cap - 1;
+            fa.taxon_base = static_cast<uint32_t>(c->Bp);
+            fa.counters = c->counters.p;
+            launch_filter(st, fa);
+        }
+        SlotValues selectors;
+        selectors.vals = c->sel.p;
+        selectors.slots = c->slots.p;
+        selectors.nslots = nslots;
+        selectors.per_read = true;
+        if (!c->use_tiles) {
+            KernelTimer t(c, K_HIST);
+            launch_sel_atomics(st, c->sel.p, c->slots.p, nslots, static_cast<uint32_t>(c->Bp), c->ucov2(), c->lca_count.p);
         }
         if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
             const uint32_t grid = 512;
             {
                 KernelTimer t(c, K_TILE_COUNT2);
-                launch_tile_count(st, grid, c->ntiles2, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p, c->treps,
+                launch_tile_count(st, grid, c->ntiles2, selectors, c->counters.p, nullptr, c->tile_count.p, c->treps,
                                   c->tstride);
             }
             if (c->fused_scan) {
                 KernelTimer t(c, K_TILE_SCATTER2);
-                launch_tile_scatter_fused(st, grid, c->ntiles2, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M, c->tile_count.p,
-                                          c->tile_cursor.p, c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p,
-                                          c->split_tiles.p);
+                launch_tile_scatter_fused(st, grid, c->ntiles2, selectors, c->counters.p, c->tile_count.p, c->tile_cursor.p,
+                                          c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p, c->split_tiles.p);
             } else {
                 {
                     KernelTimer t(c, K_TILE_SCAN2);
@@ -1040,9 +1016,9 @@ int slimm_filter_alignments(slimm_ctx* c) {
                 }
                 {
                     KernelTimer t(c, K_TILE_SCATTER2);
-                    launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, nullptr, c->uniq_gbin.p, c->counters.p, CNT_M,
-                                        c->tile_base.p, c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p,
-                                        c->bucket.p, c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
+                    launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
+                                        c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
+                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
                 }
             }
             {
@@ -1059,7 +1035,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             pk.n[0] = 32;
             pk.src[1] = c->marks.p;
             pk.n[1] = R;
-            pk.reps[1] = c->use_rows16 ? kPackBytes8 : 1u;  // k_filter_lca16 sets one byte per (reference, level)
+            pk.reps[1] = kPackBytes8;  // k_filter sets one byte per (reference, level)
             pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
             pk.n[2] = T;
             if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place

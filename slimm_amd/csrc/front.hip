@@ -1,0 +1,568 @@
+// Front end of phase A (gfx950, wave64): ONE pass over the record stream, from the records to the per-read target lists.
+//
+// Reference semantics: src/slimm.hpp:194-213 (record filter, bin, read identity = qName + mate number) and
+// src/read_stat.hpp:116-135 (add_target keeps the bin of the FIRST record of a (read, reference) pair: quirk Q1);
+// the unique bit is the `reads.size() == 1` test of src/slimm.hpp:224-237.
+//
+// Shape.  A wave owns slots of kSlotRecs consecutive records and walks through a slot in windows of 64 records that
+// always START AT A qName RUN START and are cut behind the window's last complete run, so every window holds whole
+// runs only: nothing about a read has to be carried from one window, wave or workgroup to the next -- no halo, no LDS,
+// no barrier, no scan over tiles.  (The records behind the last complete run are loaded again by the next window: 4 %
+// of the loads at 3 records per run, 12 % at 8.)  Inside a window everything is lane-mask arithmetic:
+//   run / segment starts   ballots of "key or mate differs from the lane before" (DPP wave shift)
+//   first of (read, ref)   Q1: a tagged word {segment start, reference} is shifted along the lanes one step at a time
+//                          and compared with the lane's own; the trip count is the window's longest segment
+//   head of a read         "first mapped lane at or after each segment start": ONE 64-bit scalar add -- the carry
+//                          of ~mapped + starts ripples from every start to the first mapped lane behind it
+//   unique reads           a head is unique iff the next target is a head again: the same carry trick on the
+//                          bit-reversed masks finds the target in front of every non-head target
+// and the targets are written compacted behind the slot's first run start (rank = popcount of the lanes below).  A slot's
+// targets therefore sit at [start, start + nf) with start = index of its first run start and nf <= the records the slot
+// is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.
+//
+// Three paths per window, chosen by wave-uniform tests:
+//   fast     the mate numbers of every run are non-decreasing (mapper output "all of mate 1, then all of mate 2",
+//            unpaired data): a read is a contiguous segment
+//   general  mates interleave inside a run: per-lane walks over the run (lane shuffles), targets of a run reordered by
+//            mate so that reads stay contiguous
+//   long     a run of 64 records or more: chunks of 64, every chunk compared with all chunks before it by lane
+//            rotation (quadratic in the run length, without any limit on it), one pass per mate number when the run's
+//            mates interleave
+//
+// Output (all 32-bit):
+//   tgt_ref [p]  reference id | bit 31: first target of its read
+//   tgt_gbin[p]  global bin (bin_off[ref] + bin) | bit 31: the read has exactly one target (src/slimm.hpp:224)
+//   slots   [s]  {start, targets, reads, mapped records} of slot s
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace slimm {
+
+namespace {
+
+constexpr uint32_t kTagShift = 26;                       // reference ids are below 2^26 (slimm_create checks)
+constexpr uint32_t kRefField = (1u << kTagShift) - 1u;   // ... so this value names no reference
+constexpr uint32_t kNoMatch = 0xffffffffu;               // shifted in at lane 0: equals no tagged word
+
+__device__ __forceinline__ uint32_t f_lane() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint32_t f_rank(uint64_t mask) {  // set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+__device__ __forceinline__ uint64_t f_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool f_bit(uint64_t wave_uniform_mask) {  // this lane's bit: one v_cndmask on the SGPR pair
+    return __builtin_amdgcn_inverse_ballot_w64(wave_uniform_mask);
+}
+// the value of the lane before (lane 0 gets `lane0`)
+__device__ __forceinline__ uint32_t f_shr1(uint32_t v, uint32_t lane0) {
+    return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t f_ror1(uint32_t v) {  // lane i gets lane i - 1, lane 0 gets lane 63
+    return __builtin_amdgcn_update_dpp(v, v, 0x13c, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t f_below(uint32_t n) {  // lanes 0 .. n-1 (n <= 64)
+    return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+}
+// "first bit of `bits` at or after every bit of `starts`, looking no further than the next stop": adding `starts` to a
+// word that is one where nothing is to be found lets the carry ripple from each start up to the first zero, which is the
+// lane looked for (or the stop lane, which `& bits` removes again when it is no hit)
+__device__ __forceinline__ uint64_t f_first_after(uint64_t starts, uint64_t bits, uint64_t stops) {
+    const uint64_t ones = ~bits & ~stops;
+    return (ones + starts) & ~ones & bits;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// record sources: the caller's arrays (grouped input) or the compacted, identity-sorted stream (record_order = ANY)
+// ---------------------------------------------------------------------------------------------------------
+struct FrontRaw {
+    const uint64_t* key;
+    const int32_t* ref;
+    const int32_t* pos;
+    const uint16_t* flag;
+    const uint2* geo;  // {contig length, first bin} per reference
+    uint32_t n, n_refs, half_read, bin_width, bw_magic;
+    static constexpr bool kCountsMapped = true;   // hits_count (src/slimm.hpp:212) is counted here
+    __device__ uint32_t count(const uint32_t*) const { return n; }
+    struct Rec {
+        uint32_t klo, khi;  // qName identity (its top two bits are not significant and are cleared)
+        uint32_t mate, ref, aux;
+        bool mapped;
+    };
+    __device__ Rec load(uint32_t i, bool& bad) const {
+        const uint64_t k = key[i];
+        const uint32_t f = flag[i];
+        const int32_t r = ref[i];
+        Rec o;
+        o.klo = static_cast<uint32_t>(k);
+        o.khi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
+        o.mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);                    // src/slimm.hpp:205-208
+        o.mapped = !(f & 0x4u) && r != -1;                                       // src/slimm.hpp:197
+        if (o.mapped && static_cast<uint32_t>(r) >= n_refs) {
+            bad = true;
+            o.mapped = false;
+        }
+        o.ref = static_cast<uint32_t>(r);
+        o.aux = static_cast<uint32_t>(pos[i]);
+        return o;
+    }
+    __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
+        const uint64_t k = key[i];
+        lo = static_cast<uint32_t>(k);
+        hi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
+    }
+    // what the duplicate test of the long-run path needs of an earlier chunk
+    __device__ void mate_ref(uint32_t i, uint32_t& mate, uint32_t& r, bool& mapped) const {
+        const uint32_t f = flag[i];
+        const int32_t rr = ref[i];
+        mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);
+        mapped = !(f & 0x4u) && rr != -1 && static_cast<uint32_t>(rr) < n_refs;
+        r = static_cast<uint32_t>(rr);
+    }
+    // n / bin_width with a host-computed reciprocal: mulhi(n, floor((2^32 - 1) / d)) is the quotient or one less
+    __device__ uint32_t div_bin_width(uint32_t v) const {
+        const uint32_t q = __umulhi(v, bw_magic);
+        const uint32_t r = v - q * bin_width;
+        return q + (r >= bin_width ? 1u : 0u);
+    }
+    // bin of the record: uint32 wrap-around of int32 + uint32, then the clamp to the contig length
+    // (src/slimm.hpp:200-201, quirk Q3); one 8-byte gather for the contig's geometry
+    __device__ uint32_t gbin(uint32_t r, uint32_t aux) const {
+        const uint2 g = geo[r];
+        return g.y + div_bin_width(min(aux + half_read, g.x));
+    }
+};
+
+struct FrontSorted {
+    const uint64_t* ident;  // key << 2 | mate
+    const uint32_t* cref;
+    const uint32_t* cgbin;
+    static constexpr bool kCountsMapped = false;  // the compaction counted the mapped records
+    __device__ uint32_t count(const uint32_t* counters) const { return counters[CNT_V]; }
+    struct Rec {
+        uint32_t klo, khi;
+        uint32_t mate, ref, aux;
+        bool mapped;
+    };
+    __device__ Rec load(uint32_t i, bool&) const {
+        const uint64_t k = ident[i];
+        Rec o;
+        o.mate = static_cast<uint32_t>(k) & 3u;
+        o.klo = static_cast<uint32_t>(k) & ~3u;
+        o.khi = static_cast<uint32_t>(k >> 32);
+        o.mapped = true;
+        o.ref = cref[i];
+        o.aux = cgbin[i];
+        return o;
+    }
+    __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
+        const uint64_t k = ident[i];
+        lo = static_cast<uint32_t>(k) & ~3u;
+        hi = static_cast<uint32_t>(k >> 32);
+    }
+    __device__ void mate_ref(uint32_t i, uint32_t& mate, uint32_t& r, bool& mapped) const {
+        mate = static_cast<uint32_t>(ident[i]) & 3u;
+        r = cref[i];
+        mapped = true;
+    }
+    __device__ uint32_t gbin(uint32_t, uint32_t aux) const { return aux; }
+};
+
+namespace {
+
+struct SlotOut {  // where the slot's targets go and what it has counted so far (all wave-uniform)
+    uint32_t base;            // index of the slot's first run start = position of its first target
+    uint32_t nf, nh, nv;      // targets, reads, mapped records
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// fast path: lanes [lo, X) of the window hold whole runs whose mates never decrease
+// ---------------------------------------------------------------------------------------------------------
+template <typename Acc>
+__device__ __forceinline__ void window_fast(const Acc& acc, const typename Acc::Rec& rec, uint32_t lane, uint64_t PR,
+                                            uint64_t SS, uint64_t V, uint32_t X, SlotOut& so,
+                                            uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
+    const bool in_pr = f_bit(PR);
+    const bool use = rec.mapped && in_pr;
+    // segment start of this lane: the highest start at or below it
+    const uint64_t le = (2ull << lane) - 1ull;
+    const uint32_t from = 63u - static_cast<uint32_t>(__builtin_clzll((SS & le) | 1ull));
+    const uint32_t T = use ? ((from << kTagShift) | rec.ref) : ((lane << kTagShift) | kRefField);
+    const uint32_t dist = use ? lane - from : 0u;
+    // Q1: an earlier lane of my segment with my reference?  Four steps per trip; the trip count follows the longest
+    // segment of THIS window
+    uint32_t Ts = T, differ = kNoMatch;  // minimum over the steps of (shifted ^ mine): 0 <=> a duplicate
+    for (uint32_t d = 1; f_ballot(dist >= d) != 0ull; d += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Ts = f_shr1(Ts, kNoMatch);
+            differ = min(differ, Ts ^ T);
+        }
+    }
+    const bool first = use && differ != 0u;
+    const uint64_t F = f_ballot(first);
+    // heads: the first mapped lane of every segment; the last lane of a segment stops the carry of its start
+    const uint64_t last_lane = 1ull << (X - 1u);
+    const uint64_t H = f_first_after(SS, V, (SS >> 1) | last_lane);
+    // unique reads: a head whose NEXT target is a head again (or there is none in the window: the next run's first
+    // target is a head).  In bit-reversed order "the target in front of g" is "the first target above g".
+    const uint64_t G = F & ~H;
+    const uint64_t Fr = __builtin_bitreverse64(F), Gr = __builtin_bitreverse64(G);
+    const uint64_t NU = __builtin_bitreverse64((~Fr + (Gr << 1)) & Fr);
+    const uint64_t U = H & ~NU;
+    if (first) {
+        const uint32_t p = so.base + so.nf + f_rank(F);
+        tgt_ref[p] = rec.ref | (f_bit(H) ? 0x80000000u : 0u);
+        tgt_gbin[p] = acc.gbin(rec.ref, rec.aux) | (f_bit(U) ? 0x80000000u : 0u);
+    }
+    so.nf += static_cast<uint32_t>(__popcll(F));
+    so.nh += static_cast<uint32_t>(__popcll(H));
+    so.nv += static_cast<uint32_t>(__popcll(V));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// general path: mates interleave inside some run of the window.  Per-lane walks over the run by lane shuffles; the
+// targets of a run are written ordered by (mate, file order), so a read's targets stay contiguous.
+// ---------------------------------------------------------------------------------------------------------
+template <typename Acc>
+__device__ __forceinline__ void window_general(const Acc& acc, const typename Acc::Rec& rec, uint32_t lane, uint64_t PR,
+                                               uint64_t RS, uint64_t V, SlotOut& so, uint32_t* __restrict__ tgt_ref,
+                                               uint32_t* __restrict__ tgt_gbin) {
+    const bool in_pr = f_bit(PR);
+    const bool use = rec.mapped && in_pr;
+    const uint64_t le = (2ull << lane) - 1ull;
+    const uint64_t runs = RS & PR;
+    const uint32_t run_from = 63u - static_cast<uint32_t>(__builtin_clzll((runs & le) | 1ull));
+    const uint64_t above = runs & ~le;  // run starts behind this lane
+    const uint32_t pr_end = 64u - static_cast<uint32_t>(__builtin_clzll(PR));
+    const uint32_t run_to = above ? static_cast<uint32_t>(__builtin_ctzll(above)) : pr_end;  // one past my run's last lane
+    const uint32_t W = use ? ((rec.mate << 28) | rec.ref) : (0xc0000000u | lane);  // mate 3: equals nobody's
+    // backward over the run: first of its (mate, ref)?  head of its mate?
+    const uint32_t back = in_pr ? lane - run_from : 0u;
+    bool dup = false, mate_seen = false;
+    for (uint32_t d = 1; f_ballot(back >= d) != 0ull; ++d) {
+        const uint32_t o = __shfl(W, static_cast<int>((lane - d) & 63u), 64);
+        const bool mine = back >= d;
+        dup = dup || (mine && o == W);
+        mate_seen = mate_seen || (mine && (o >> 28) == (W >> 28));
+    }
+    const bool first = use && !dup;
+    const bool head = use && !mate_seen;
+    // per target: targets of my run with a smaller mate (they go in front of me), targets of my own mate before me,
+    // targets of my own mate at all (unique <=> 1)
+    const uint32_t WF = first ? (W >> 28) : 3u;  // mate of a target, 3 for lanes that are none
+    const uint32_t span = in_pr ? run_to - run_from : 0u;
+    uint32_t smaller = 0, same_before = 0, same_total = 0;
+    for (uint32_t d = 0; f_ballot(span > d) != 0ull; ++d) {
+        const uint32_t j = run_from + d;  // lane d of my run
+        const uint32_t o = __shfl(WF, static_cast<int>(j & 63u), 64);
+        const bool mine = span > d && o != 3u && first;
+        smaller += (mine && o < WF) ? 1u : 0u;
+        same_total += (mine && o == WF) ? 1u : 0u;
+        same_before += (mine && o == WF && j < lane) ? 1u : 0u;
+    }
+    const uint64_t F = f_ballot(first);
+    const uint64_t H = f_ballot(head);
+    if (first) {
+        // targets of the runs before mine in this window, then my place inside my run
+        const uint32_t before_run = static_cast<uint32_t>(__popcll(F & ((1ull << run_from) - 1ull)));
+        const uint32_t p = so.base + so.nf + before_run + smaller + same_before;
+        tgt_ref[p] = rec.ref | (head ? 0x80000000u : 0u);
+        tgt_gbin[p] = acc.gbin(rec.ref, rec.aux) | ((head && same_total == 1u) ? 0x80000000u : 0u);
+    }
+    so.nf += static_cast<uint32_t>(__popcll(F));
+    so.nh += static_cast<uint32_t>(__popcll(H));
+    so.nv += static_cast<uint32_t>(__popcll(V));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// long path: the run starting at `pos` has 64 records or more.  Chunks of 64 records; a chunk's records are compared
+// with the chunk's earlier lanes (shift) and with every earlier chunk of the run (64 rotations each).  Returns the index
+// of the record behind the run.
+// ---------------------------------------------------------------------------------------------------------
+template <typename Acc>
+__device__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, SlotOut& so,
+                             uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
+    // 1. where the run ends, whether its mates ever decrease, which mates it has
+    uint32_t klo0, khi0;
+    acc.key_at(pos, klo0, khi0);
+    uint32_t end = pos;
+    bool decreasing = false;
+    uint32_t last_mate = 0;
+    while (true) {
+        const uint32_t i = end + lane;
+        const bool live = i < N;
+        bool b = false;
+        const typename Acc::Rec r = acc.load(live ? i : N - 1u, b);
+        const uint64_t same = f_ballot(live && r.klo == klo0 && r.khi == khi0);
+        const uint32_t n_same = static_cast<uint32_t>(__builtin_ctzll(~same | (1ull << 63)));  // lanes before the first other key
+        const bool whole = (~same) == 0ull;
+        const uint32_t n_in = whole ? 64u : n_same;
+        const uint32_t mprev = f_shr1(r.mate, last_mate);
+        decreasing = decreasing || (f_ballot(r.mate < mprev) & f_below(n_in)) != 0ull;
+        if (n_in) last_mate = __builtin_amdgcn_readlane(r.mate, n_in - 1u);
+        end += n_in;
+        if (!whole) break;
+    }
+    // 2. one pass for all mates when they never decrease (reads are contiguous), one pass per mate otherwise
+    uint32_t nv_run = 0;
+    for (uint32_t pass = 0; pass < (decreasing ? 3u : 1u); ++pass) {
+        uint32_t head_seen = 0;                        // bit m: a mapped record with mate m came by
+        uint32_t n_first[3] = {0u, 0u, 0u};            // targets per mate
+        uint32_t head_p[3] = {0u, 0u, 0u}, head_g[3] = {0u, 0u, 0u};  // where each mate's head went, its bin word
+        for (uint32_t cb = pos; cb < end; cb += 64u) {
+            const uint32_t i = cb + lane;
+            const bool in_run = i < end;
+            const typename Acc::Rec r = acc.load(in_run ? i : end - 1u, bad);
+            const bool use = in_run && r.mapped && (!decreasing || r.mate == pass);
+            const uint32_t T = use ? ((r.mate << 28) | r.ref) : (0xc0000000u | lane);
+            if (pass == 0) nv_run += static_cast<uint32_t>(__popcll(f_ballot(in_run && r.mapped)));
+            uint32_t differ = kNoMatch;
+            {   // earlier lanes of this chunk
+                uint32_t Ts = T;
+                for (uint32_t d = 1; d < 64u; ++d) {
+                    Ts = f_shr1(Ts, kNoMatch);
+                    differ = min(differ, Ts ^ T);
+                }
+            }
+            for (uint32_t eb = pos; eb < cb; eb += 64u) {  // every earlier chunk, all rotations
+                uint32_t mt, rf;
+                bool mp;
+                acc.mate_ref(eb + lane, mt, rf, mp);
+                uint32_t Te = mp ? ((mt << 28) | rf) : 0xe0000000u;
+                for (uint32_t d = 0; d < 64u; ++d) {
+                    differ = min(differ, Te ^ T);
+                    Te = f_ror1(Te);
+                }
+            }
+            const bool first = use && differ != 0u;
+            const uint64_t F = f_ballot(first);
+            // heads: per mate the first mapped lane, unless an earlier chunk had one
+            uint64_t H = 0;
+#pragma unroll
+            for (uint32_t m = 0; m < 3u; ++m) {
+                const uint64_t Vm = f_ballot(use && r.mate == m);
+                if (Vm && !((head_seen >> m) & 1u)) {
+                    H |= 1ull << __builtin_ctzll(Vm);
+                    head_seen |= 1u << m;
+                }
+                n_first[m] += static_cast<uint32_t>(__popcll(f_ballot(first && r.mate == m)));
+            }
+            const bool head = f_bit(H);
+            const uint32_t p = so.base + so.nf + f_rank(F);
+            const uint32_t g = first ? acc.gbin(r.ref, r.aux) : 0u;
+            if (first) {
+                tgt_ref[p] = r.ref | (head ? 0x80000000u : 0u);
+                if (!head) tgt_gbin[p] = g;  // a head's bin word waits for the end of the run (unique or not)
+            }
+            uint64_t Hm = H;
+            while (Hm) {
+                const uint32_t hl = static_cast<uint32_t>(__builtin_ctzll(Hm));
+                Hm &= Hm - 1ull;
+                const uint32_t m = __builtin_amdgcn_readlane(r.mate, hl);
+                head_p[m] = __builtin_amdgcn_readlane(p, hl);
+                head_g[m] = __builtin_amdgcn_readlane(g, hl);
+            }
+            so.nf += static_cast<uint32_t>(__popcll(F));
+            so.nh += static_cast<uint32_t>(__popcll(H));
+        }
+#pragma unroll
+        for (uint32_t m = 0; m < 3u; ++m)
+            if (((head_seen >> m) & 1u) && lane == 0u) tgt_gbin[head_p[m]] = head_g[m] | (n_first[m] == 1u ? 0x80000000u : 0u);
+    }
+    so.nv += nv_run;
+    return end;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// k_front: every wave walks TWO slots at a time (two independent streams): a stream's next window depends on the keys
+// of the current one, so one stream per wave has one window of loads in flight and the kernel would be bound by the
+// latency of that chain; with two the loads of one stream are in flight under the arithmetic of the other.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Stream {       // all wave-uniform
+    uint32_t slot;    // slot being walked (>= nslots: the stream has run out of work)
+    uint32_t pos, end;
+    SlotOut so;
+    bool anchored;    // pos is known to be a run start
+    bool have_start;
+};
+
+template <typename Acc>
+struct Window {       // what a stream has in flight: the 64 records at pos and the key in front of them
+    typename Acc::Rec rec;
+    uint32_t plo, phi;
+};
+
+__device__ __forceinline__ void stream_begin(Stream& st, uint32_t slot, uint32_t N) {
+    st.slot = slot;
+    st.pos = slot * kSlotRecs;
+    st.end = min(st.pos + kSlotRecs, N);
+    st.so = SlotOut{st.pos, 0u, 0u, 0u};
+    st.anchored = false;
+    st.have_start = false;
+}
+
+template <typename Acc>
+__device__ __forceinline__ void stream_load(const Acc& acc, const Stream& st, uint32_t N, uint32_t lane, Window<Acc>& w,
+                                            bool& bad) {
+    w.rec = acc.load(min(st.pos + lane, N - 1u), bad);
+    w.plo = w.phi = 0u;
+    if (!st.anchored && st.pos > 0u) acc.key_at(st.pos - 1u, w.plo, w.phi);  // (one address for the whole wave)
+}
+
+// one window of one stream; advances st.pos
+template <typename Acc>
+__device__ __forceinline__ void stream_step(const Acc& acc, Stream& st, const Window<Acc>& w, uint32_t N, uint32_t lane,
+                                            uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
+    const typename Acc::Rec& rec = w.rec;
+    const uint32_t pos = st.pos;
+    const uint32_t n_live = min(64u, N - pos);
+    const uint64_t LIVE = f_below(n_live);
+    // run starts: the key differs from the lane before; lane 0 looks at the record in front of the window
+    const uint32_t qlo = f_shr1(rec.klo, w.plo), qhi = f_shr1(rec.khi, w.phi);
+    uint64_t RS = f_ballot(((rec.klo ^ qlo) | (rec.khi ^ qhi)) != 0u) & LIVE;
+    if (st.anchored || pos == 0u) RS |= 1ull;
+    if (RS == 0ull) {  // the whole window continues a run of the slot before
+        st.pos = pos + 64u;
+        return;
+    }
+    const uint32_t lo = static_cast<uint32_t>(__builtin_ctzll(RS));
+    if (pos + lo >= st.end) {  // the first run start at or behind pos belongs to the next slot
+        st.pos = st.end;
+        return;
+    }
+    // complete runs end at the last run start of the window -- or at the end of the stream
+    const bool at_end = pos + 64u >= N;
+    uint32_t X = at_end ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(RS));
+    if (st.end - pos < 64u) {  // runs starting at or behind the slot's end are the next slot's
+        const uint64_t beyond = RS & ~f_below(st.end - pos);
+        if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
+    }
+    if (X <= lo) {  // the run starting at lane `lo` does not end inside this window
+        if (lo > 0u) {  // look again from its start
+            st.pos = pos + lo;
+            st.anchored = true;
+            return;
+        }
+        if (!st.have_start) {
+            st.so.base = pos;
+            st.have_start = true;
+        }
+        st.pos = long_run(acc, pos, N, lane, st.so, tgt_ref, tgt_gbin, bad);
+        st.anchored = true;
+        return;
+    }
+    if (!st.have_start) {
+        st.so.base = pos + lo;
+        st.have_start = true;
+    }
+    const uint64_t PR = f_below(X) & ~f_below(lo);
+    const uint32_t mprev = f_shr1(rec.mate, 0u);
+    const uint64_t MC = f_ballot(rec.mate != mprev);
+    const uint64_t V = f_ballot(rec.mapped) & PR;
+    const uint64_t dec = f_ballot(rec.mate < mprev) & ~RS & PR;
+    if (dec == 0ull)
+        window_fast(acc, rec, lane, PR, (RS | MC) & PR, V, X, st.so, tgt_ref, tgt_gbin);
+    else
+        window_general(acc, rec, lane, PR, RS, V, st.so, tgt_ref, tgt_gbin);
+    st.pos = pos + X;
+    st.anchored = true;
+}
+
+}  // namespace
+
+template <typename Acc>
+__global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
+                                                       uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
+                                                       uint4* __restrict__ slots) {
+    const uint32_t N = acc.count(counters);
+    const uint32_t lane = f_lane();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kFrontBlock / 64);
+    const uint32_t my_wave = blockIdx.x * (kFrontBlock / 64) + wave;
+    uint32_t tot_f = 0, tot_h = 0, tot_v = 0;
+    bool bad = false;
+    Stream st[2];
+    stream_begin(st[0], my_wave, N);
+    stream_begin(st[1], my_wave + n_waves, N);
+    uint32_t next_slot = my_wave + 2u * n_waves;
+    while (st[0].slot < nslots || st[1].slot < nslots) {
+        Window<Acc> w[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (st[k].slot < nslots && st[k].pos < st[k].end) stream_load(acc, st[k], N, lane, w[k], bad);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (st[k].slot >= nslots) continue;
+            if (st[k].pos < st[k].end) stream_step(acc, st[k], w[k], N, lane, tgt_ref, tgt_gbin, bad);
+            if (st[k].pos >= st[k].end) {  // the slot is done (or was empty): publish it, take the next one
+                if (lane == 0u) slots[st[k].slot] = make_uint4(st[k].so.base, st[k].so.nf, st[k].so.nh, st[k].so.nv);
+                tot_f += st[k].so.nf;
+                tot_h += st[k].so.nh;
+                tot_v += st[k].so.nv;
+                stream_begin(st[k], next_slot, N);
+                next_slot += n_waves;
+            }
+        }
+    }
+    if (lane == 0u) {
+        if (tot_h) atomicAdd(&counters[CNT_M], tot_h);
+        if (tot_f) atomicAdd(&counters[CNT_P], tot_f);
+        if (Acc::kCountsMapped && tot_v) atomicAdd(&counters[CNT_V], tot_v);
+    }
+    if (__any(bad) && lane == 0u) atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_REF_RANGE));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+uint32_t front_slots(uint32_t n_records) { return (n_records + kSlotRecs - 1u) / kSlotRecs; }
+
+static uint32_t front_grid(uint32_t nslots) {
+    // two slots per wave and trip; at most 8 workgroups of 256 threads per CU (256 CUs)
+    const uint32_t waves = (nslots + 1u) / 2u;
+    const uint32_t blocks = (waves + (kFrontBlock / 64) - 1u) / (kFrontBlock / 64);
+    return std::max(1u, std::min(blocks, 2048u));
+}
+
+void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
+                      uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots) {
+    const uint32_t ns = front_slots(in.n);
+    if (!ns) return;
+    FrontRaw a;
+    a.key = in.key;
+    a.ref = in.ref;
+    a.pos = in.pos;
+    a.flag = in.flag;
+    a.geo = geo;
+    a.n = in.n;
+    a.n_refs = n_refs;
+    a.half_read = half_read;
+    a.bin_width = bin_width;
+    a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
+    hipLaunchKernelGGL(k_front<FrontRaw>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref, tgt_gbin,
+                       slots);
+}
+
+void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots) {
+    const uint32_t ns = front_slots(n_upper);
+    if (!ns) return;
+    FrontSorted a{ident, cref, cgbin};
+    hipLaunchKernelGGL(k_front<FrontSorted>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
+                       tgt_gbin, slots);
+}
+
+}  // namespace slimm

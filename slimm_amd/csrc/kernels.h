@@ -82,6 +82,19 @@ struct DeviceRecords {
 
 uint32_t num_tiles(uint32_t n);
 
+// ---- front.hip: the single-pass front end of phase A ----
+// A slot = kSlotRecs consecutive records; its targets (the runs that START in it) lie compacted at
+// [slot.x, slot.x + slot.y) of tgt_ref / tgt_gbin; slot.z = reads (targets with bit 31 of tgt_ref), slot.w = mapped records
+constexpr uint32_t kSlotRecs = 1024;
+constexpr int kFrontBlock = 256;
+constexpr uint32_t kMaxRefs = (1u << 26) - 1u;      // reference ids fit 26 bits (tagged words of the duplicate test)
+constexpr uint32_t kMaxBins = 0x7ffffff0u;          // global bin indices fit 31 bits (bit 31 of tgt_gbin: unique read)
+uint32_t front_slots(uint32_t n_records);
+void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
+                      uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots);
+void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots);
+
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
@@ -90,49 +103,36 @@ void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
-// runs.hip: record classification + CSR emission, on the raw records (grouped input) or on the sorted compact stream.
-// part 0 = k_pick_runs (chooses the kernel on the device), 1 = k_runs (look-back), 2 = k_runs_hash; all three are
-// launched, the classification kernel that was not chosen returns immediately.
-// k_zero and k_pick_runs in one launch (grouped input): z must not contain the counters, which workgroup 0 clears itself
-// before it writes the chosen kernel to counters[CNT_MODE]
-void launch_zero_pick_raw(hipStream_t st, const ZeroArgs& z, const DeviceRecords& in, uint32_t* counters, uint32_t n_refs);
-void launch_runs_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
-                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint32_t* counters, uint8_t* fl,
-                     uint2* tile_cnt, uint32_t* tile_valid, int part, uint32_t* chunk_acc = nullptr,
-                     uint32_t chunk_shift = 6);
-// chunk_acc != nullptr (streams of up to kFusedEmitTiles tiles): the second classification launch leaves the sums of every
-// (1 << chunk_shift) tiles' counts in chunk_acc[4 * chunk ..] (zeroed by the caller), tile_off holds the per-tile COUNTS, and k_emit
-// derives its offsets and publishes the totals (counters, read_off sentinel, tail) itself -- no k_scan_tiles launch
-constexpr uint32_t kFusedEmitTiles = 65536;
-// tiles per chunk as a shift: at most 256 chunks
-inline uint32_t emit_chunk_shift(uint32_t ntiles) { return ntiles <= 16384 ? 6u : (ntiles <= 32768 ? 7u : 8u); }
-void launch_emit_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint32_t* ref_len,
-                     const uint32_t* bin_off, const uint2* geo, uint32_t half_read, uint32_t bin_width, const uint8_t* fl,
-                     uint32_t* counters,
-                     const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint32_t* read_off,
-                     const uint32_t* chunk_acc = nullptr, uint32_t* tail = nullptr, uint32_t chunk_shift = 6);
-void launch_runs_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                        uint32_t* counters, uint8_t* fl, uint2* tile_cnt, int part, uint32_t n_refs);
-void launch_emit_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                        const uint8_t* fl, uint32_t* counters, const uint2* tile_off, uint32_t* tgt_ref, uint32_t* tgt_gbin,
-                        uint32_t* read_off);
-void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
-                 uint32_t* cov, uint32_t* ucov);
+// the direct-atomics fallback of the coverage histograms (too many bins for the LDS tile tables)
+void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, const uint32_t* counters,
+                 uint32_t* tail, uint32_t* cov, uint32_t* ucov);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
                       uint32_t* out, const PackArgs* pack = nullptr);
-// ucov2 != nullptr: global atomics -- uniq_cov2[g]++ per unique-after-filter read, lca_count[t]++ per LCA read (fallback);
-// uniq_gbin != nullptr: one selector per read instead (its uniq_cov2 bin, taxon_base + its LCA taxon, or 0xffffffff),
-// counted afterwards by the tile histogram over the index space [uniq_cov2 bins | taxa].
-void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
-                       const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
-                       uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
-                       uint64_t* pair_list, uint32_t pair_mask, uint32_t taxon_base);
-// 16-byte rows (per-level 16-bit indices + valid bit); level_off is a host array of 8 offsets into level_taxon
-void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
-                         const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
-                         const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
-                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
-                         uint32_t taxon_base, uint32_t n_refs);
+// phase B + C(1): one selector per read into sel[] (indexed like the slots' reads: slot.x + k): its uniq_cov2 bin,
+// taxon_base + its LCA taxon, or 0xffffffff; level marks as one byte per (reference, level); (taxon, reference) pairs
+// of the reads whose references agree at no level.  rows16 != nullptr: 16-byte lineage rows (level_off: host array of 8
+// offsets into level_taxon); otherwise 32-byte rows lin_dense + the byte array valid.
+struct FilterArgs {
+    const uint32_t* tgt_ref = nullptr;
+    const uint32_t* tgt_gbin = nullptr;
+    const uint4* slots = nullptr;
+    uint32_t nslots = 0;
+    const void* rows16 = nullptr;
+    const uint32_t* level_taxon = nullptr;
+    const uint32_t* level_off = nullptr;
+    const uint32_t* lin_dense = nullptr;
+    const uint8_t* valid = nullptr;
+    uint32_t* sel = nullptr;
+    uint32_t* marks = nullptr;
+    uint64_t* pair_tab = nullptr;
+    uint64_t* pair_list = nullptr;
+    uint32_t pair_mask = 0, taxon_base = 0;
+    uint32_t* counters = nullptr;
+};
+void launch_filter(hipStream_t st, const FilterArgs& a);
+// direct-atomics fallback: count the selectors with global atomics instead of the second tile histogram
+void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
+                        uint32_t* ucov2, uint32_t* lca_count);
 // multi-GPU: [R uniq_reads_count2 | T LCA counts | 2R level marks in 8-bit fields | 1 pair count] from result block B
 void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out);
 // multi-GPU, all-to-all form: this rank received every rank's bitmaps of ITS slice ([n_ranks][2][slice_words] 32-bit
@@ -159,8 +159,17 @@ int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this m
 #define SLIMM_TILE_REPS 8
 #endif
 constexpr uint32_t kTileReps = SLIMM_TILE_REPS;
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
-                       int count_slot, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
+// the values the bucketing kernels read: one per target (tgt_gbin: bit 31 = unique read) or one per read (the selectors
+// of phase B: 0xffffffff = none), lying in the slots front.hip wrote
+struct SlotValues {
+    const uint32_t* vals = nullptr;
+    const uint4* slots = nullptr;
+    uint32_t nslots = 0;
+    bool per_read = false;
+};
+// tail != nullptr: workgroup 0 also copies the totals {mapped records, reads, targets} there (multi-GPU scalars)
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* counters,
+                       uint32_t* tail, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
 constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
 constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile
@@ -174,11 +183,10 @@ void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uin
                       uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level);
 // bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
-void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
-                         const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
-                         uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
-                         uint32_t* cov, uint32_t* ucov, bool two_level, const uint32_t* rep_base, uint32_t reps,
-                         uint32_t rep_stride);
+void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const SlotValues& in,
+                         const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
+                         const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
+                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride);
 // where k_tile_hist / k_pack put the 'bin != 0' bitmaps of the multi-GPU coverage summary: the tiles are cut into slices
 // of `tps` tiles (one slice per rank for the all-to-all exchange, a single slice otherwise) and slice j holds
 // [array 0 bits | array 1 bits] of its tiles back to back
@@ -192,11 +200,10 @@ struct BitsLayout {
 // tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts
 // one-level bucketing with k_tile_scan folded in (<= 4096 tiles, kTileReps copies of the counters): after
 // launch_tile_count, with tile_cursor zero; also writes k_tile_hist's work items, the split-tile list and their counts
-constexpr uint32_t kFusedScanTiles = 4096;
-void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
-                               uint32_t* counters, int count_slot, const uint32_t* tile_count, uint32_t* tile_cursor,
-                               uint16_t* bucket, uint32_t* cov, uint32_t* ucov, uint32_t rep_stride, uint4* items,
-                               uint32_t* split_tiles);
+constexpr uint32_t kFusedScanTiles = 4064;  // (4096 table entries less the room three small arrays take: tile_hist.hip)
+void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
+                               const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
+                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles);
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
                       uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,

@@ -305,21 +305,29 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_hist: cov[g]++ for every target; uniq_cov[g]++ when the target is the only one of its read
-// (src/slimm.hpp:219-257).  reads_count / uniq_reads_count are NOT counted here: each target adds exactly one to
-// both reads_count[ref] and one bin of ref, so they are the per-reference bin sums (k_tile_hist / k_ref_stats).
+// k_hist: cov[g]++ for every target; uniq_cov[g]++ when the target is the only one of its read (bit 31 of tgt_gbin)
+// (src/slimm.hpp:219-257).  The direct-atomics fallback for bin counts too large for the LDS tile tables.
+// reads_count / uniq_reads_count are NOT counted here: each target adds exactly one to both reads_count[ref] and one bin
+// of ref, so they are the per-reference bin sums (k_tile_hist / k_ref_stats).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tgt_ref, const uint32_t* __restrict__ tgt_gbin,
-                                                 const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
+__global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tgt_gbin, const uint4* __restrict__ slots,
+                                                 uint32_t nslots, const uint32_t* __restrict__ counters,
+                                                 uint32_t* __restrict__ tail, uint32_t* __restrict__ cov,
                                                  uint32_t* __restrict__ ucov) {
-    const uint32_t P = counters[CNT_P];
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t t = blockIdx.x * kBlock + threadIdx.x; t < P; t += stride) {
-        uint32_t g = tgt_gbin[t];
-        bool start = tgt_ref[t] >> 31;
-        bool next_start = (t + 1 == P) || (tgt_ref[t + 1] >> 31);
-        atomicAdd(&cov[g], 1u);
-        if (start && next_start) atomicAdd(&ucov[g], 1u);
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {
+        tail[0] = counters[CNT_V];
+        tail[1] = counters[CNT_M];
+        tail[2] = counters[CNT_P];
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t s = wave; s < nslots; s += n_waves) {
+        const uint4 d = slots[s];
+        for (uint32_t o = lane; o < d.y; o += 64u) {
+            const uint32_t g = tgt_gbin[d.x + o];
+            atomicAdd(&cov[g & 0x7fffffffu], 1u);
+            if (g >> 31) atomicAdd(&ucov[g & 0x7fffffffu], 1u);
+        }
     }
 }
 
@@ -363,14 +371,22 @@ __global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_filter_lca: one thread per read.
+// k_filter: phase B + C(1) per read, ONE LANE PER TARGET.
 //   * keep the targets whose reference is valid (read_stat::update, read_stat.hpp:98-114)
-//   * exactly one left  -> uniq_cov2[g]++   (src/slimm.hpp:383-390)
-//   * more than one     -> level-scan LCA over the dense lineage rows (src/slimm.hpp:516-531): the first level at
-//     which all rows agree (a shared 0 "hole" agrees, Q5); if none, the level-7 entry of the LARGEST reference id --
-//     the reference iterates a std::set and returns the last value it read (Q4).  Then lca_count[t]++ and
-//     children[t] gets every kept reference (src/slimm.hpp:552-555): as a (ref, level) mark bit when a level agrees
-//     (t is lineage[ref][level] for each of them), as a (t, ref) pair in a hash set otherwise.
+//   * exactly one left  -> the read's selector is that target's bin: uniq_cov2[g]++   (src/slimm.hpp:383-390)
+//   * more than one     -> level-scan LCA over the lineage rows (src/slimm.hpp:516-531): the first level at which all
+//     rows agree (a shared 0 "hole" agrees, Q5); if none, the level-7 entry of the LARGEST reference id -- the reference
+//     iterates a std::set and returns the last value it read (Q4).  The selector is the taxon (counted by the second tile
+//     histogram: lca_count[t]++), and children[t] gets every kept reference (src/slimm.hpp:552-555): as a (reference,
+//     level) mark when a level agrees (t is lineage[ref][level] for each of them), as a (t, ref) pair in a hash set
+//     otherwise.
+// A wave walks the slots of the front end (front.hip) in windows of 64 targets that start at a read's first target and
+// are cut behind the window's last complete read, like the front end's windows over runs: the target words arrive by
+// two coalesced loads, the lineage rows by ONE 16-byte gather per target -- two dependent levels instead of the three
+// of a thread per read (offsets, targets, rows).  Per read the work is lane-mask arithmetic on the ballots of "head"
+// and "valid": first / second valid lane of every read by carry chains (f_first_after, below), the reads they belong
+// to by the same chains on the bit-reversed masks.  Only reads that keep several targets (8 % at config 2) get more:
+// a scalar loop over them compares the rows of their valid lanes with the first one's, level by level.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
@@ -395,233 +411,259 @@ __device__ void pair_insert(uint64_t key, uint64_t* __restrict__ tab, uint64_t* 
                 if (k <= (mask >> 1))
                     list[k] = key;
                 else
-                    atomicOr(&counters[CNT_ERR], ERR_PAIR_OVERFLOW);
+                    atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_PAIR_OVERFLOW));
                 return;
             }
             if (old == key) return;
         }
         slot = (slot + 1) & mask;
     }
-    atomicOr(&counters[CNT_ERR], ERR_PAIR_OVERFLOW);
+    atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_PAIR_OVERFLOW));
 }
 
-__device__ __forceinline__ uint32_t row_eq_mask(const uint4& a, const uint4& b, const uint4& a0, const uint4& b0) {
-    return (a.x == a0.x ? 1u : 0u) | (a.y == a0.y ? 2u : 0u) | (a.z == a0.z ? 4u : 0u) | (a.w == a0.w ? 8u : 0u) |
-           (b.x == b0.x ? 16u : 0u) | (b.y == b0.y ? 32u : 0u) | (b.z == b0.z ? 64u : 0u) | (b.w == b0.w ? 128u : 0u);
-}
-
-__global__ __launch_bounds__(kBlock) void k_filter_lca(const uint32_t* __restrict__ read_off,
-                                                       const uint32_t* __restrict__ tgt_ref,
-                                                       const uint32_t* __restrict__ tgt_gbin,
-                                                       uint32_t* __restrict__ counters, const uint8_t* __restrict__ valid,
-                                                       const uint4* __restrict__ lin4, uint32_t* __restrict__ ucov2,
-                                                       uint32_t* __restrict__ uniq_gbin,
-                                                       uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks,
-                                                       uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
-                                                       uint32_t pair_mask, uint32_t taxon_base) {
-    const uint32_t M = counters[CNT_M];
-    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
-    if (m >= M) return;
-    const uint32_t s = read_off[m], e = read_off[m + 1];
-    const bool multi = (e - s) > 1;
-    uint32_t nv = 0, first_t = 0, first_ref = 0, max_ref = 0, eq = 0xffu;
-    uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0;
-    // four targets per trip: their ref / valid / lineage-row loads are independent, so they overlap in flight
-    for (uint32_t c = s; c < e; c += 4) {
-        uint32_t r[4];
-        bool ok[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = (c + k < e) ? (tgt_ref[c + k] & 0x7fffffffu) : 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) ok[k] = (r[k] != 0xffffffffu) && valid[r[k]];
-        uint4 ra[4], rb[4];
-        if (multi) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (ok[k]) {
-                    ra[k] = lin4[2 * r[k]];
-                    rb[k] = lin4[2 * r[k] + 1];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) continue;
-            if (nv == 0) {
-                first_t = c + k;
-                first_ref = r[k];
-                if (multi) {
-                    a0 = ra[k];
-                    b0 = rb[k];
-                }
-            } else {
-                eq &= row_eq_mask(ra[k], rb[k], a0, b0);
-            }
-            max_ref = max(max_ref, r[k]);
-            ++nv;
-        }
-    }
-    uint32_t sel = 0xffffffffu;  // what this read adds one to: a uniq_cov2 bin, an LCA taxon counter, or nothing
-    if (nv == 1) {
-        sel = tgt_gbin[first_t];
-        if (ucov2) atomicAdd(&ucov2[sel], 1u);
-    } else if (nv > 1) {
-        const uint32_t* lin = reinterpret_cast<const uint32_t*>(lin4);
-        uint32_t taxon;
-        if (eq) {
-            const uint32_t lv = __builtin_ctz(eq);
-            taxon = lin[static_cast<size_t>(first_ref) * 8 + lv];
-            for (uint32_t t = s; t < e; ++t) {
-                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
-                if (valid[r] && !((marks[r] >> lv) & 1u)) atomicOr(&marks[r], 1u << lv);
-            }
-        } else {
-            taxon = lin[static_cast<size_t>(max_ref) * 8 + 7];
-            for (uint32_t t = s; t < e; ++t) {
-                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
-                if (valid[r]) pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
-            }
-        }
-        if (uniq_gbin)
-            sel = taxon_base + taxon;  // counted by the tile histogram: hot taxa make global atomics serialise
-        else
-            atomicAdd(&lca_count[taxon], 1u);
-    }
-    if (uniq_gbin) uniq_gbin[m] = sel;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_filter_lca16: the same per-read work on 16-byte lineage rows: eight per-level 16-bit indices, with the run's valid
-// flag in the top bit of the level-7 half-word.  One 16-byte gather per target replaces a byte gather (valid[]) plus
-// two 16-byte gathers (32-byte rows): the kernel is bound by the number of distinct cache lines its gathers touch.
-//   row.x = lvl0 | lvl1 << 16, row.y = lvl2 | lvl3 << 16, row.z = lvl4 | lvl5 << 16, row.w = lvl6 | (valid << 15 | lvl7) << 16
-// level_taxon[level_off[lv] + idx] gives the dense taxon of a (level, index).
-// ---------------------------------------------------------------------------------------------------------
-#if defined(EXP) && EXP == 7
-__device__ unsigned long long g_prof_f[8];
-#define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
-#define FPROF_ADD(slot, a, b) if ((threadIdx.x & 63) == 0 && (blockIdx.x & 31) == 0) atomicAdd(&g_prof_f[slot], (b) - (a))
-#else
-#define FPROF_T(x)
-#define FPROF_ADD(slot, a, b)
-#endif
 struct LevelOffsets {
     uint32_t off[8];
 };
 
-__device__ __forceinline__ uint32_t row16_eq_mask(const uint4& a, const uint4& b) {
-    const uint32_t dx = a.x ^ b.x, dy = a.y ^ b.y, dz = a.z ^ b.z, dw = a.w ^ b.w;
-    return ((dx & 0xffffu) ? 0u : 1u) | ((dx >> 16) ? 0u : 2u) | ((dy & 0xffffu) ? 0u : 4u) | ((dy >> 16) ? 0u : 8u) |
-           ((dz & 0xffffu) ? 0u : 16u) | ((dz >> 16) ? 0u : 32u) | ((dw & 0xffffu) ? 0u : 64u) | ((dw >> 16) ? 0u : 128u);
+// 16-byte lineage rows: eight per-level 16-bit indices, the reference's valid flag in the top bit of the level-7
+// half-word; level_taxon[off[lv] + idx] is the dense taxon of a (level, index)
+struct Rows16 {
+    const uint4* rows;
+    const uint32_t* level_taxon;
+    LevelOffsets lo;
+    struct Row {
+        uint4 q;
+    };
+    __device__ Row load(uint32_t ref) const { return Row{rows[ref]}; }
+    __device__ static bool valid(const Row& r) { return (r.q.w >> 31) != 0u; }
+    __device__ static void fields(const Row& r, uint32_t (&f)[8]) {
+        f[0] = r.q.x & 0xffffu;
+        f[1] = r.q.x >> 16;
+        f[2] = r.q.y & 0xffffu;
+        f[3] = r.q.y >> 16;
+        f[4] = r.q.z & 0xffffu;
+        f[5] = r.q.z >> 16;
+        f[6] = r.q.w & 0xffffu;
+        f[7] = (r.q.w >> 16) & 0x7fffu;
+    }
+    __device__ uint32_t taxon(uint32_t lv, uint32_t field) const { return level_taxon[lo.off[lv] + field]; }
+};
+// 32-byte rows (databases with more than 65535 taxa on one level): eight dense taxon indices, validity in a byte array
+struct Rows32 {
+    const uint4* lin4;
+    const uint8_t* valid_of;
+    struct Row {
+        uint4 a, b;
+        bool ok;
+    };
+    __device__ Row load(uint32_t ref) const { return Row{lin4[2 * ref], lin4[2 * ref + 1], valid_of[ref] != 0}; }
+    __device__ static bool valid(const Row& r) { return r.ok; }
+    __device__ static void fields(const Row& r, uint32_t (&f)[8]) {
+        f[0] = r.a.x;
+        f[1] = r.a.y;
+        f[2] = r.a.z;
+        f[3] = r.a.w;
+        f[4] = r.b.x;
+        f[5] = r.b.y;
+        f[6] = r.b.z;
+        f[7] = r.b.w;
+    }
+    __device__ uint32_t taxon(uint32_t, uint32_t field) const { return field; }
+};
+
+namespace {
+
+__device__ __forceinline__ uint64_t k_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool k_bit(uint64_t wave_uniform_mask) { return __builtin_amdgcn_inverse_ballot_w64(wave_uniform_mask); }
+__device__ __forceinline__ uint64_t k_below(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
+// first bit of `bits` at or after every bit of `starts`, looking no further than the next stop (see front.hip)
+__device__ __forceinline__ uint64_t k_first_after(uint64_t starts, uint64_t bits, uint64_t stops) {
+    const uint64_t ones = ~bits & ~stops;
+    return (ones + starts) & ~ones & bits;
+}
+// the bit of `heads` at or below every bit of `bits` (every bit has one): the same carry chain on the reversed masks
+__device__ __forceinline__ uint64_t k_head_of(uint64_t bits, uint64_t heads) {
+    const uint64_t br = __builtin_bitreverse64(bits), hr = __builtin_bitreverse64(heads);
+    return __builtin_bitreverse64((~hr + br) & hr);
 }
 
-__device__ __forceinline__ uint32_t row16_level(const uint4& a, uint32_t lv) {
-    const uint32_t w = (lv < 2) ? a.x : (lv < 4) ? a.y : (lv < 6) ? a.z : a.w;
-    const uint32_t h = (lv & 1u) ? (w >> 16) : (w & 0xffffu);
-    return (lv == 7) ? (h & 0x7fffu) : h;
+struct FilterOut {
+    uint32_t* sel;                 // one selector per read: a uniq_cov2 bin, taxon_base + taxon, or 0xffffffff
+    uint8_t* marks;                // one byte per (reference, level)
+    uint64_t* pair_tab;
+    uint64_t* pair_list;
+    uint32_t pair_mask, taxon_base;
+    uint32_t* counters;
+};
+
+// what is known about one read's valid targets so far (all wave-uniform)
+struct ReadAcc {
+    uint32_t nv;        // valid targets
+    uint32_t first_g;   // bin word of the first of them
+    uint32_t a0[8];     // its row
+    uint32_t eq;        // bit lv: every valid row so far agrees with a0 at level lv
+    uint32_t max_ref, max_f7;  // largest valid reference and its level-7 field
+};
+
+// adds the valid lanes `Vs` (of one read) of the wave's current 64 targets
+template <typename Rows>
+__device__ __forceinline__ void read_add(ReadAcc& acc, uint64_t Vs, uint32_t ref, uint32_t g, const uint32_t (&f)[8]) {
+    if (!Vs) return;
+    if (acc.nv == 0u) {
+        const uint32_t fl = static_cast<uint32_t>(__builtin_ctzll(Vs));
+        acc.first_g = __builtin_amdgcn_readlane(g, fl);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc.a0[l] = __builtin_amdgcn_readlane(f[l], fl);
+    }
+    acc.nv += static_cast<uint32_t>(__popcll(Vs));
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+        if (k_ballot(f[l] != acc.a0[l]) & Vs) acc.eq &= ~(1u << l);
+    // the largest reference among the lanes (needed only when no level agrees, Q4; cheap enough to keep)
+    uint64_t rest = Vs;
+    while (rest) {
+        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(rest));
+        rest &= rest - 1ull;
+        const uint32_t r = __builtin_amdgcn_readlane(ref, l);
+        if (r >= acc.max_ref) {
+            acc.max_ref = r;
+            acc.max_f7 = __builtin_amdgcn_readlane(f[7], l);
+        }
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void k_filter_lca16(const uint32_t* __restrict__ read_off,
-                                                         const uint32_t* __restrict__ tgt_ref,
+// LCA of a read with several valid targets; *lv = the agreeing level (8: none, Q4)
+template <typename Rows>
+__device__ __forceinline__ uint32_t read_taxon(const Rows& rows, const ReadAcc& acc, uint32_t* lv) {
+    if (acc.eq) {
+        *lv = static_cast<uint32_t>(__builtin_ctz(acc.eq));
+        return rows.taxon(*lv, acc.a0[*lv]);
+    }
+    *lv = 8u;
+    return rows.taxon(7u, acc.max_f7);
+}
+
+// children[taxon] gets the valid lanes' references: a level mark, or a (taxon, reference) pair when no level agreed
+__device__ __forceinline__ void read_children(const FilterOut& out, bool mine, uint32_t ref, uint32_t lv, uint32_t taxon) {
+    if (!mine) return;
+    if (lv < 8u)
+        out.marks[ref * kMarkBytes + lv] = 1;  // a plain, idempotent byte store (no read of the word, no atomic)
+    else
+        pair_insert((static_cast<uint64_t>(taxon) << 32) | ref, out.pair_tab, out.pair_list, out.pair_mask, out.counters);
+}
+
+}  // namespace
+
+constexpr int kFilterBlock = 256;
+
+template <typename Rows>
+__global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,
-                                                         uint32_t* __restrict__ counters, const uint4* __restrict__ rows16,
-                                                         const uint32_t* __restrict__ level_taxon, const LevelOffsets lo,
-                                                         uint32_t* __restrict__ ucov2, uint32_t* __restrict__ uniq_gbin,
-                                                         uint32_t* __restrict__ lca_count, uint32_t* __restrict__ marks_all,
-                                                         uint64_t* __restrict__ pair_tab, uint64_t* __restrict__ pair_list,
-                                                         uint32_t pair_mask, uint32_t taxon_base, uint32_t n_refs) {
-    const uint32_t M = counters[CNT_M];
-    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
-    if (m >= M) return;
-    // Level marks: one BYTE per (reference, level), set by a plain store.  Most reads hit the same few references; bits
-    // in a word meant atomicOr (memory-side: thousands of lanes on the same words while a bit is not yet visible, and a
-    // workgroup retires only when its atomics have come back) or, to avoid those, a read of the word first -- a fourth
-    // dependent round trip per read.  A byte store of 1 is idempotent, needs no read, and leaves no atomic outstanding;
-    // k_pack folds the 8 bytes of a reference into its mark word.
-    uint8_t* __restrict__ marks = reinterpret_cast<uint8_t*>(marks_all);
-    FPROF_T(q0);
-    const uint32_t s = read_off[m], e = read_off[m + 1];
-    uint32_t nv = 0, first_g = 0, max_ref = 0, w_max = 0, eq = 0xffu;
-    uint4 a0 = make_uint4(0, 0, 0, 0);
-    constexpr int kChunk = 4;  // targets per trip (8 measured slower: more predicated loads than longer reads save)
-    uint32_t r0[kChunk], vmask0 = 0;  // the first kChunk targets (all of them for most reads) stay in registers
-    for (uint32_t c = s; c < e; c += kChunk) {
-        uint32_t r[kChunk], g[kChunk];
-        uint4 row[kChunk];
-        // the bins travel with the reference ids (same addresses, no extra dependent load at the end)
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k) {  // clamped instead of bounds-tested: the loads of a trip go out together
-            const uint32_t t = min(c + k, e - 1u);
-            r[k] = tgt_ref[t] & 0x7fffffffu;
-            g[k] = tgt_gbin[t];
-        }
-        // slots past the read's last target all gather row 0: lanes with the same address cost the texture addresser one
-        // line together, a clamped index (the read's own last row again) one line per lane -- and with 2.6 targets per
-        // read half the slots are such
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k) row[k] = rows16[(c + k < e) ? r[k] : 0u];
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k) {
-            const bool ok = (c + k < e) && (row[k].w >> 31);  // inside the read and a valid reference
-            if (c == s) {
-                r0[k] = r[k];
-                vmask0 |= ok ? (1u << k) : 0u;
+                                                         const uint4* __restrict__ slots, uint32_t nslots, const Rows rows,
+                                                         const FilterOut out) {
+    const uint32_t lane = lane_id();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (kFilterBlock / 64);
+    for (uint32_t slot = blockIdx.x * (kFilterBlock / 64) + wave; slot < nslots; slot += n_waves) {
+        const uint4 d = slots[slot];
+        uint32_t pos = d.x;
+        const uint32_t endp = d.x + d.y;
+        uint32_t reads_done = 0;  // selectors of this slot written so far
+        while (pos < endp) {
+            const uint32_t n_live = min(64u, endp - pos);
+            const uint64_t LIVE = k_below(n_live);
+            const bool live = lane < n_live;
+            const uint32_t w = live ? tgt_ref[pos + lane] : 0u;
+            const uint32_t g = live ? tgt_gbin[pos + lane] : 0u;
+            const uint64_t HB = k_ballot((w >> 31) != 0u) & LIVE;  // (bit 0 is set: a window starts at a read's first target)
+            const bool at_end = pos + 64u >= endp;
+            const uint32_t X = at_end ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(HB));
+            const uint32_t ref = w & 0x7fffffffu;
+            if (X == 0u) {
+                // ---- a read with 64 targets or more: walk it in chunks, then once more for its children
+                ReadAcc acc;
+                acc.nv = 0;
+                acc.eq = 0xffu;
+                acc.max_ref = 0;
+                acc.max_f7 = 0;
+                acc.first_g = 0;
+                uint32_t e = pos;  // end of the read
+                while (true) {
+                    const bool lv_ = e + lane < endp;
+                    const uint32_t ww = lv_ ? tgt_ref[e + lane] : 0x80000000u;
+                    const uint32_t gg = lv_ ? tgt_gbin[e + lane] : 0u;
+                    uint64_t heads = k_ballot((ww >> 31) != 0u);
+                    if (e == pos) heads &= ~1ull;
+                    const uint32_t n_in = heads ? static_cast<uint32_t>(__builtin_ctzll(heads)) : 64u;
+                    const typename Rows::Row row = rows.load(lane < n_in ? (ww & 0x7fffffffu) : 0u);
+                    uint32_t f[8];
+                    Rows::fields(row, f);
+                    read_add<Rows>(acc, k_ballot(Rows::valid(row)) & k_below(n_in), ww & 0x7fffffffu, gg, f);
+                    e += n_in;
+                    if (n_in < 64u) break;
+                }
+                uint32_t sel = 0xffffffffu;
+                if (acc.nv == 1u) {
+                    sel = acc.first_g & 0x7fffffffu;
+                } else if (acc.nv > 1u) {
+                    uint32_t lv;
+                    const uint32_t taxon = read_taxon(rows, acc, &lv);
+                    sel = out.taxon_base + taxon;
+                    for (uint32_t c = pos; c < e; c += 64u) {
+                        const bool in = c + lane < e;
+                        const uint32_t rr = in ? (tgt_ref[c + lane] & 0x7fffffffu) : 0u;
+                        const typename Rows::Row row = rows.load(rr);
+                        read_children(out, in && Rows::valid(row), rr, lv, taxon);
+                    }
+                }
+                if (lane == 0u) out.sel[d.x + reads_done] = sel;
+                reads_done += 1u;
+                pos = e;
+                continue;
             }
-            if (!ok) continue;
-            if (nv == 0) {
-                first_g = g[k];
-                a0 = row[k];
-            } else {
-                eq &= row16_eq_mask(row[k], a0);
+            const uint64_t PR = k_below(X);
+            const uint64_t H = HB & PR;
+            const typename Rows::Row row = rows.load(k_bit(PR) ? ref : 0u);
+            const uint64_t VB = k_ballot(Rows::valid(row)) & PR;
+            const uint64_t stops = (H >> 1) | (1ull << (X - 1u));
+            const uint64_t FV = k_first_after(H, VB, stops);              // first valid target of every read
+            const uint64_t SV = k_first_after(H, VB & ~FV, stops);        // second one, where there is one
+            const uint64_t HF = k_head_of(FV, H);                         // reads with a valid target
+            const uint64_t HM = k_head_of(SV, H);                         // reads with several
+            const uint64_t single = FV & ~k_first_after(HM, FV, stops);   // the one valid target of the reads with one
+            const uint64_t empty = H & ~HF;                               // reads that lost every target
+            // index of this lane's read among the slot's reads
+            const uint32_t ridx = d.x + reads_done + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
+            if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
+            if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
+            if (HM) {
+                uint32_t f[8];
+                Rows::fields(row, f);
+                uint64_t todo = HM;
+                while (todo) {
+                    const uint32_t h = static_cast<uint32_t>(__builtin_ctzll(todo));
+                    todo &= todo - 1ull;
+                    const uint64_t later = H & ~k_below(h + 1u);
+                    const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
+                    const uint64_t Vs = VB & k_below(nxt) & ~k_below(h);
+                    ReadAcc acc;
+                    acc.nv = 0;
+                    acc.eq = 0xffu;
+                    acc.max_ref = 0;
+                    acc.max_f7 = 0;
+                    acc.first_g = 0;
+                    read_add<Rows>(acc, Vs, ref, g, f);
+                    uint32_t lv;
+                    const uint32_t taxon = read_taxon(rows, acc, &lv);
+                    read_children(out, k_bit(Vs), ref, lv, taxon);
+                    if (lane == 0u)
+                        out.sel[d.x + reads_done + static_cast<uint32_t>(__popcll(H & k_below(h)))] = out.taxon_base + taxon;
+                }
             }
-            if (r[k] >= max_ref) {
-                max_ref = r[k];
-                w_max = row[k].w;
-            }
-            ++nv;
+            reads_done += static_cast<uint32_t>(__popcll(H));
+            pos += X;
         }
     }
-    FPROF_T(q1);
-    uint32_t sel = 0xffffffffu;  // what this read adds one to: a uniq_cov2 bin, an LCA taxon counter, or nothing
-    if (nv == 1) {
-        sel = first_g;
-        if (ucov2) atomicAdd(&ucov2[sel], 1u);
-    } else if (nv > 1) {
-        uint32_t taxon;
-        if (eq) {
-            const uint32_t lv = __builtin_ctz(eq);
-            taxon = level_taxon[lo.off[lv] + row16_level(a0, lv)];
-#pragma unroll
-            for (int k = 0; k < kChunk; ++k)
-                if ((vmask0 >> k) & 1u) marks[r0[k] * 8u + lv] = 1;
-            for (uint32_t t = s + kChunk; t < e; ++t) {
-                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
-                if (rows16[r].w >> 31) marks[r * 8u + lv] = 1;
-            }
-        } else {
-            taxon = level_taxon[lo.off[7] + ((w_max >> 16) & 0x7fffu)];
-#pragma unroll
-            for (int k = 0; k < kChunk; ++k)
-                if ((vmask0 >> k) & 1u)
-                    pair_insert((static_cast<uint64_t>(taxon) << 32) | r0[k], pair_tab, pair_list, pair_mask, counters);
-            for (uint32_t t = s + kChunk; t < e; ++t) {
-                const uint32_t r = tgt_ref[t] & 0x7fffffffu;
-                if (rows16[r].w >> 31)
-                    pair_insert((static_cast<uint64_t>(taxon) << 32) | r, pair_tab, pair_list, pair_mask, counters);
-            }
-        }
-        if (uniq_gbin)
-            sel = taxon_base + taxon;  // counted by the tile histogram: hot taxa make global atomics serialise
-        else
-            atomicAdd(&lca_count[taxon], 1u);
-    }
-    FPROF_T(q2);
-    if (uniq_gbin) uniq_gbin[m] = sel;
-    FPROF_T(q3);
-    FPROF_ADD(0, q0, q1);
-    FPROF_ADD(1, q1, q2);
-    FPROF_ADD(2, q2, q3);
-    FPROF_ADD(3, q0, q0 + 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -663,11 +705,10 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
                            ref_len, bin_off, half_read, bin_width, ident, cref, cgbin);
 }
 
-void launch_hist(hipStream_t st, uint32_t n_upper, const uint32_t* tgt_ref, const uint32_t* tgt_gbin, const uint32_t* counters,
-                 uint32_t* cov, uint32_t* ucov) {
-    uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
-    if (blocks > 256u * 16u) blocks = 256u * 16u;  // grid-stride beyond 16 workgroups per CU
-    if (blocks) hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_ref, tgt_gbin, counters, cov, ucov);
+void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, const uint32_t* counters,
+                 uint32_t* tail, uint32_t* cov, uint32_t* ucov) {
+    uint32_t blocks = std::max(1u, std::min((nslots + kWaves - 1) / kWaves, 256u * 16u));
+    hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_gbin, slots, nslots, counters, tail, cov, ucov);
 }
 
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
@@ -739,29 +780,61 @@ void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, u
                        out);
 }
 
-void launch_filter_lca(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
-                       const uint32_t* tgt_gbin, uint32_t* counters, const uint8_t* valid, const uint32_t* lin_dense,
-                       uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count, uint32_t* marks, uint64_t* pair_tab,
-                       uint64_t* pair_list, uint32_t pair_mask, uint32_t taxon_base) {
-    uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
-    if (blocks)
-        hipLaunchKernelGGL(k_filter_lca, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters, valid,
-                           reinterpret_cast<const uint4*>(lin_dense), ucov2, uniq_gbin, lca_count, marks, pair_tab, pair_list,
-                           pair_mask, taxon_base);
+// the selectors counted with global atomics (direct-atomics fallback: no tile histogram): uniq_cov2[g]++ per read that
+// kept one target, lca_count[t]++ per read counted at its LCA
+__global__ __launch_bounds__(kBlock) void k_sel_atomics(const uint32_t* __restrict__ sel, const uint4* __restrict__ slots,
+                                                        uint32_t nslots, uint32_t taxon_base, uint32_t* __restrict__ ucov2,
+                                                        uint32_t* __restrict__ lca_count) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
+    for (uint32_t s = wave; s < nslots; s += n_waves) {
+        const uint4 d = slots[s];
+        for (uint32_t o = lane; o < d.z; o += 64u) {
+            const uint32_t v = sel[d.x + o];
+            if (v == 0xffffffffu) continue;
+            if (v < taxon_base)
+                atomicAdd(&ucov2[v], 1u);
+            else
+                atomicAdd(&lca_count[v - taxon_base], 1u);
+        }
+    }
 }
 
-void launch_filter_lca16(hipStream_t st, uint32_t n_upper, const uint32_t* read_off, const uint32_t* tgt_ref,
-                         const uint32_t* tgt_gbin, uint32_t* counters, const void* rows16, const uint32_t* level_taxon,
-                         const uint32_t* level_off, uint32_t* ucov2, uint32_t* uniq_gbin, uint32_t* lca_count,
-                         uint32_t* marks, uint64_t* pair_tab, uint64_t* pair_list, uint32_t pair_mask,
-                         uint32_t taxon_base, uint32_t n_refs) {
-    uint32_t blocks = (n_upper + kBlock - 1) / kBlock;
-    LevelOffsets lo;
-    for (int i = 0; i < 8; ++i) lo.off[i] = level_off[i];
-    if (blocks)
-        hipLaunchKernelGGL(k_filter_lca16, dim3(blocks), dim3(kBlock), 0, st, read_off, tgt_ref, tgt_gbin, counters,
-                           reinterpret_cast<const uint4*>(rows16), level_taxon, lo, ucov2, uniq_gbin, lca_count, marks,
-                           pair_tab, pair_list, pair_mask, taxon_base, n_refs);
+void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
+                        uint32_t* ucov2, uint32_t* lca_count) {
+    uint32_t blocks = std::max(1u, std::min((nslots + kWaves - 1) / kWaves, 256u * 16u));
+    hipLaunchKernelGGL(k_sel_atomics, dim3(blocks), dim3(kBlock), 0, st, sel, slots, nslots, taxon_base, ucov2, lca_count);
+}
+
+static uint32_t filter_grid(uint32_t nslots) {
+    const uint32_t blocks = (nslots + (kFilterBlock / 64) - 1u) / (kFilterBlock / 64);
+    return std::max(1u, std::min(blocks, 2048u));
+}
+
+void launch_filter(hipStream_t st, const FilterArgs& a) {
+    if (!a.nslots) return;
+    FilterOut out;
+    out.sel = a.sel;
+    out.marks = reinterpret_cast<uint8_t*>(a.marks);
+    out.pair_tab = a.pair_tab;
+    out.pair_list = a.pair_list;
+    out.pair_mask = a.pair_mask;
+    out.taxon_base = a.taxon_base;
+    out.counters = a.counters;
+    if (a.rows16) {
+        Rows16 r;
+        r.rows = reinterpret_cast<const uint4*>(a.rows16);
+        r.level_taxon = a.level_taxon;
+        for (int i = 0; i < 8; ++i) r.lo.off[i] = a.level_off[i];
+        hipLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
+                           a.slots, a.nslots, r, out);
+    } else {
+        Rows32 r;
+        r.lin4 = reinterpret_cast<const uint4*>(a.lin_dense);
+        r.valid_of = a.valid;
+        hipLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
+                           a.slots, a.nslots, r, out);
+    }
 }
 
 }  // namespace slimm

@@ -6,13 +6,14 @@
 // one workgroup per tile accumulates its bucket in LDS and writes the finished tile with coalesced 16-byte stores.
 // The tile write-back also replaces the zero-fill of cov / uniq_cov.
 //
-//   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slice of the targets, added to one
-//                   of 8 copies of tile_count[] with one non-returning global atomic per non-empty tile
+//   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slots of targets (front.hip), added
+//                   to one of 8 copies of tile_count[] with one non-returning global atomic per non-empty tile
 //   k_tile_scan     one workgroup: sums the copies, exclusive scan -> tile_base, turns every copy into the start of its
 //                   stretch inside the buckets, cuts buckets into work items of <= 16 K entries, lists the split tiles
-//   k_tile_scatter  same slices, one level: 16 K-target chunks held in registers; LDS count, one returning atomic per
-//                   tile and chunk on the copy's cursor, 16-bit entries (13-bit bin-in-tile | unique bit) out.  Also
-//                   zeroes the tiles that k_tile_hist will accumulate with atomics.  (<= 4096 tiles)
+//   k_tile_scatter  same slots, one level: rounds of 8 K values held in registers; LDS count, one returning atomic per
+//                   tile and round on the copy's cursor, 16-bit entries (13-bit bin-in-tile | unique bit) out -- up to
+//                   4096 tiles (k_tile_scatter_fused) ordered by tile in LDS first, so that a tile's run leaves as
+//                   consecutive stores.  Also zeroes the tiles that k_tile_hist will accumulate with atomics.
 //   k_part_super    two levels, level 1: targets go to their SUPER tile (64 tiles = 512 K bins) as 32-bit words
 //                   (19-bit bin-in-super | unique bit): few destinations per workgroup, long runs
 //   k_part_tile     level 2: work items of <= 32 K entries of one super tile are split into its 64 tiles
@@ -44,51 +45,82 @@ constexpr int kTBlock = 512;
 constexpr uint32_t kTileMask = kTileBins - 1;
 constexpr uint32_t kScanStaged = 16384;  // tiles whose counts k_tile_scan stages in LDS (the one-level bucketing range)
 
-// slice of the targets owned by workgroup b of g: [lo, hi), 2048-aligned so the unrolled loads stay coalesced
-__device__ __forceinline__ void slice_of(uint32_t P, uint32_t b, uint32_t g, uint32_t& lo, uint32_t& hi) {
-    uint32_t chunk = (P + g - 1) / g;
-    chunk = (chunk + 2047u) & ~2047u;
-    uint64_t l = static_cast<uint64_t>(b) * chunk;
-    uint64_t h = l + chunk;
-    lo = l < P ? static_cast<uint32_t>(l) : P;
-    hi = h < P ? static_cast<uint32_t>(h) : P;
+// The bucketing kernels read values that lie in slots (front.hip): slot s holds its entries compacted at
+// [slots[s].x, slots[s].x + n) with n = slots[s].y (one value per target) or slots[s].z (one value per read).
+// Workgroup b of g owns a contiguous range of slots -- the SAME range in the count and in the scatter kernel, whose
+// counter copies pair up by workgroup -- and its waves take the slots of that range round robin, 64 entries at a time.
+struct SlotWalk {  // all wave-uniform
+    const uint4* slots;
+    uint32_t s, s_end;        // next slot of this wave, end of the workgroup's range
+    uint32_t base, left;      // entries of the current slot not yet handed out: [base, base + left)
+    bool per_read;
+};
+
+__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read) {
+    const uint32_t per_wg = (nslots + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = min(blockIdx.x * per_wg, nslots);
+    SlotWalk w;
+    w.slots = slots;
+    w.s = lo + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.s_end = min(lo + per_wg, nslots);
+    w.base = 0;
+    w.left = 0;
+    w.per_read = per_read;
+    return w;
 }
 
-__global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ tgt_gbin,
-                                                        const uint32_t* __restrict__ counters, int count_slot,
-                                                        uint32_t ntiles, uint32_t* __restrict__ tile_count_all,
-                                                        uint32_t reps, uint32_t rep_stride) {
+// the next (up to) 64 entries: returns their count (0: the wave has no more), *base = index of the first
+__device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
+    while (w.left == 0u) {
+        if (w.s >= w.s_end) return 0u;
+        const uint4 d = w.slots[w.s];  // (a scalar load: one address for the wave)
+        w.s += kTBlock / 64;
+        w.base = d.x;
+        w.left = w.per_read ? d.z : d.y;
+    }
+    const uint32_t n = min(w.left, 64u);
+    *base = w.base;
+    w.base += n;
+    w.left -= n;
+    return n;
+}
+
+// tile of a value: bit 31 (unique read) is no part of the bin index; 0xffffffff = nothing to count (a read without
+// a selector)
+__device__ __forceinline__ uint32_t tile_of(uint32_t v) { return (v & 0x7fffffffu) >> kTileShift; }
+
+__global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
+                                                        uint32_t nslots, int per_read, uint32_t ntiles,
+                                                        uint32_t* __restrict__ tile_count_all, uint32_t reps,
+                                                        uint32_t rep_stride, const uint32_t* __restrict__ counters,
+                                                        uint32_t* __restrict__ tail) {
     HIP_DYNAMIC_SHARED(uint32_t, s_hist)
-    const uint32_t P = counters[count_slot];
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {  // the additive scalars that travel with the bins (multi-GPU)
+        tail[0] = counters[CNT_V];
+        tail[1] = counters[CNT_M];
+        tail[2] = counters[CNT_P];
+    }
     // 512 workgroups adding to the same 2.4 K counters serialise in the memory-side atomic units: every workgroup adds to
     // one of `reps` copies instead, and k_tile_scan sums the copies
     uint32_t* __restrict__ tile_count = tile_count_all + static_cast<size_t>(blockIdx.x % reps) * rep_stride;
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
-    uint32_t lo, hi;
-    slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    // 16-byte loads (4 targets per lane, 2 in flight): slices are 2048-aligned, so only the last one has a ragged end
-    for (uint32_t t0 = lo; t0 < hi; t0 += 8 * kTBlock) {
-        uint4 g[2];
+    const uint32_t lane = threadIdx.x & 63u;
+    SlotWalk w = slot_walk(slots, nslots, per_read != 0);
+    while (true) {  // four pieces per trip, their loads in flight together
+        uint32_t v[4];
+        bool any = false;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t t = t0 + (u * kTBlock + threadIdx.x) * 4;
-            if (t + 4 <= hi) {
-                g[u] = *reinterpret_cast<const uint4*>(tgt_gbin + t);
-            } else {
-                g[u].x = t < hi ? tgt_gbin[t] : 0xffffffffu;
-                g[u].y = t + 1 < hi ? tgt_gbin[t + 1] : 0xffffffffu;
-                g[u].z = t + 2 < hi ? tgt_gbin[t + 2] : 0xffffffffu;
-                g[u].w = 0xffffffffu;
-            }
+        for (int u = 0; u < 4; ++u) {
+            uint32_t base = 0;
+            const uint32_t n = slot_next(w, &base);
+            any = any || n != 0u;
+            v[u] = lane < n ? vals[base + lane] : 0xffffffffu;
         }
+        if (!any) break;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (g[u].x != 0xffffffffu) atomicAdd(&s_hist[g[u].x >> kTileShift], 1u);
-            if (g[u].y != 0xffffffffu) atomicAdd(&s_hist[g[u].y >> kTileShift], 1u);
-            if (g[u].z != 0xffffffffu) atomicAdd(&s_hist[g[u].z >> kTileShift], 1u);
-            if (g[u].w != 0xffffffffu) atomicAdd(&s_hist[g[u].w >> kTileShift], 1u);
-        }
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != 0xffffffffu) atomicAdd(&s_hist[tile_of(v[u])], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
@@ -275,80 +307,104 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
     }
 }
 
-// One chunk of the one-level bucketing: kQ * 2048 targets starting at c0 (kWhole: all of them inside [c0, hi), so no
-// bounds test sits between the loads -- a branch there makes every load wait for the one before).  The chunk stays in
-// registers: count per tile in LDS, reserve the chunk's stretch of every bucket with one returning atomic per tile (all
-// of a thread's atomics issued before any is waited for), scatter from registers.
-template <bool kWithRef, int kQ, bool kWhole>
-__device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_ref, const uint32_t* __restrict__ tgt_gbin,
-                                              uint32_t c0, uint32_t hi, uint32_t P, uint32_t ntiles,
-                                              const uint32_t* __restrict__ tile_base, uint32_t* __restrict__ tile_cursor,
-                                              uint16_t* __restrict__ bucket, uint32_t* s_hist) {
-    // (tile_base / tile_cursor: this workgroup's copy -- start of the copy's stretch in every bucket, and its cursor)
+// ---------------------------------------------------------------------------------------------------------
+// Bucketing rounds.  In one round every wave of the workgroup takes kRoundPieces pieces of 64 values from its slots
+// into registers (at most kRoundCap values per workgroup and round).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kRoundPieces = 16;
+constexpr uint32_t kTileSlots = 4096;  // entries of the ordered round's tile tables (= kFusedTiles)
+constexpr uint32_t kRoundCap = (kTBlock / 64) * kRoundPieces * 64;  // 8192 values per round
+
+// loads the round's values (0xffffffff where there is none); returns whether this wave got any
+__device__ __forceinline__ bool round_load(SlotWalk& w, const uint32_t* __restrict__ vals, uint32_t lane,
+                                           uint32_t (&v)[kRoundPieces]) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kRoundPieces; ++k) {
+        uint32_t base = 0;
+        const uint32_t n = slot_next(w, &base);
+        any = any || n != 0u;
+        v[k] = lane < n ? vals[base + lane] : 0xffffffffu;
+    }
+    return any;
+}
+
+// bucket entry of a value: 13-bit bin inside its tile | the unique bit
+__device__ __forceinline__ uint32_t entry_of(uint32_t v) { return (v & kTileMask) | ((v >> 31) << kTileShift); }
+
+// One round of the one-level bucketing with the values ORDERED BY TILE in LDS before they leave (<= 4096 tiles).
+// Scattered 2-byte stores straight from registers were one L2 write request per value (8.2 M requests per file, ~half of
+// the old kernel's time); here a value's place inside the round is rank-inside-its-tile (the returned count of the LDS
+// histogram add) + the tile's offset (a scan of that histogram), the values are staged in that order, and consecutive
+// lanes then store consecutive bucket positions of the same tile: one request per (tile, round) run.
+//   s_cnt   [4096]  values per tile in this round; then: global position of the tile's run minus its place in the stage
+//   s_loff  [4096]  exclusive scan of s_cnt
+//   s_stage [8192]  tile << 14 | entry, in tile order
+// mine[t] = start of this workgroup's counter copy inside tile t's bucket, cursor[t] = the copy's fill (global atomics).
+__device__ __forceinline__ uint32_t block_excl_scan_4096(uint32_t* s, uint32_t* s_wtot);
+
+__device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRoundPieces], uint32_t ntiles,
+                                                      const uint32_t* s_mine, uint32_t* __restrict__ tile_cursor,
+                                                      uint16_t* __restrict__ bucket, uint32_t* s_cnt, uint32_t* s_loff,
+                                                      uint32_t* s_stage, uint32_t* s_wtot) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < kTileSlots; i += kTBlock) s_cnt[i] = 0;
+    __syncthreads();
+    uint32_t r[kRoundPieces];
+#pragma unroll
+    for (int k = 0; k < kRoundPieces; ++k) r[k] = v[k] != 0xffffffffu ? atomicAdd(&s_cnt[tile_of(v[k])], 1u) : 0u;
+    __syncthreads();
+    // this round's stretch of every touched tile's bucket: one returning atomic per tile, all of a thread's issued
+    // before the scan so that they are back when it is done
+    uint32_t got[kTileSlots / kTBlock];
+#pragma unroll
+    for (uint32_t j = 0; j < kTileSlots / kTBlock; ++j) {
+        const uint32_t i = j * kTBlock + tid;
+        const uint32_t h = s_cnt[i];
+        s_loff[i] = h;
+        got[j] = (h && i < ntiles) ? atomicAdd(&tile_cursor[i], h) + s_mine[i] : 0u;
+    }
+    __syncthreads();
+    const uint32_t total = block_excl_scan_4096(s_loff, s_wtot);
+#pragma unroll
+    for (uint32_t j = 0; j < kTileSlots / kTBlock; ++j) {
+        const uint32_t i = j * kTBlock + tid;
+        s_cnt[i] = got[j] - s_loff[i];
+    }
+#pragma unroll
+    for (int k = 0; k < kRoundPieces; ++k) {
+        if (v[k] == 0xffffffffu) continue;
+        const uint32_t t = tile_of(v[k]);
+        s_stage[s_loff[t] + r[k]] = (t << 14) | entry_of(v[k]);
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < total; j += kTBlock) {
+        const uint32_t e = s_stage[j];
+        bucket[s_cnt[e >> 14] + j] = static_cast<uint16_t>(e & 0x3fffu);
+    }
+    __syncthreads();  // the next round clears s_cnt and refills the stage
+}
+
+// One round of the one-level bucketing straight from registers (more than 4096 tiles: the tile tables of the ordered
+// form no longer fit LDS beside a stage).  s_hist[ntiles]: the round's histogram, then the write cursors.
+__device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kRoundPieces], uint32_t ntiles,
+                                                     const uint32_t* __restrict__ tile_base,
+                                                     uint32_t* __restrict__ tile_cursor, uint16_t* __restrict__ bucket,
+                                                     uint32_t* s_hist) {
     constexpr int kMaxTilesPerThread = 8;  // tiles per thread whose reservations are in flight together
-    TPROF_T(p0);
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
-    uint4 g[kQ];
-    uint32_t uniq = 0;  // bit 4 q + j: target j of word q is the only target of its read
-    if (kWhole) {
-        uint4 r[kQ];
-        uint32_t nxt[kQ];
-#pragma unroll
-        for (int q = 0; q < kQ; ++q) {
-            const uint32_t t = c0 + (q * kTBlock + threadIdx.x) * 4;
-            g[q] = *reinterpret_cast<const uint4*>(tgt_gbin + t);
-            if (kWithRef) {
-                r[q] = *reinterpret_cast<const uint4*>(tgt_ref + t);
-                nxt[q] = tgt_ref[min(t + 4, P - 1u)];
-            }
-        }
-        if (kWithRef) {
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) {
-                const uint32_t t = c0 + (q * kTBlock + threadIdx.x) * 4;
-                const uint32_t s0 = r[q].x >> 31, s1 = r[q].y >> 31, s2 = r[q].z >> 31, s3 = r[q].w >> 31;
-                const uint32_t s4 = (t + 4 < P) ? (nxt[q] >> 31) : 1u;  // the end of the stream ends the read
-                uniq |= ((s0 & s1) | ((s1 & s2) << 1) | ((s2 & s3) << 2) | ((s3 & s4) << 3)) << (4 * q);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int q = 0; q < kQ; ++q) {
-            const uint32_t t = c0 + (q * kTBlock + threadIdx.x) * 4;
-            uint32_t v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool live = t + j < hi;
-                v[j] = live ? tgt_gbin[t + j] : 0xffffffffu;
-                if (kWithRef && live) {
-                    const uint32_t a = tgt_ref[t + j] >> 31;
-                    const uint32_t n = (t + j + 1 < P) ? (tgt_ref[t + j + 1] >> 31) : 1u;
-                    uniq |= (a & n) << (4 * q + j);
-                }
-            }
-            g[q] = make_uint4(v[0], v[1], v[2], v[3]);
-        }
-    }
     __syncthreads();
-    TPROF_T(p1);
 #pragma unroll
-    for (int q = 0; q < kQ; ++q) {
-        if (g[q].x != 0xffffffffu) atomicAdd(&s_hist[g[q].x >> kTileShift], 1u);
-        if (g[q].y != 0xffffffffu) atomicAdd(&s_hist[g[q].y >> kTileShift], 1u);
-        if (g[q].z != 0xffffffffu) atomicAdd(&s_hist[g[q].z >> kTileShift], 1u);
-        if (g[q].w != 0xffffffffu) atomicAdd(&s_hist[g[q].w >> kTileShift], 1u);
-    }
+    for (int k = 0; k < kRoundPieces; ++k)
+        if (v[k] != 0xffffffffu) atomicAdd(&s_hist[tile_of(v[k])], 1u);
     __syncthreads();
-    TPROF_T(p2);
-    // s_hist becomes the write cursor of this chunk in every tile's bucket: 8 tiles per thread and trip, the trip's
-    // returning atomics all issued before any is waited for
     for (uint32_t i0 = 0; i0 < ntiles; i0 += kMaxTilesPerThread * kTBlock) {
         uint32_t got[kMaxTilesPerThread];
 #pragma unroll
         for (int j = 0; j < kMaxTilesPerThread; ++j) {
             const uint32_t i = i0 + j * kTBlock + threadIdx.x;
             const uint32_t h = i < ntiles ? s_hist[i] : 0u;
-            got[j] = h ? atomicAdd(&tile_cursor[i], h) + tile_base[i] : 0u;  // tiles this chunk does not touch: no atomic
+            got[j] = h ? atomicAdd(&tile_cursor[i], h) + tile_base[i] : 0u;  // tiles this round does not touch: no atomic
         }
 #pragma unroll
         for (int j = 0; j < kMaxTilesPerThread; ++j) {
@@ -357,45 +413,36 @@ __device__ __forceinline__ void scatter_chunk(const uint32_t* __restrict__ tgt_r
         }
     }
     __syncthreads();
-    TPROF_T(p3);
 #pragma unroll
-    for (int q = 0; q < kQ; ++q) {
-        const uint32_t v[4] = {g[q].x, g[q].y, g[q].z, g[q].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (v[j] == 0xffffffffu) continue;
-            const uint32_t pos = atomicAdd(&s_hist[v[j] >> kTileShift], 1u);
-            bucket[pos] = static_cast<uint16_t>((v[j] & kTileMask) | (((uniq >> (4 * q + j)) & 1u) ? kTileBins : 0u));
-        }
+    for (int k = 0; k < kRoundPieces; ++k) {
+        if (v[k] == 0xffffffffu) continue;
+        const uint32_t pos = atomicAdd(&s_hist[tile_of(v[k])], 1u);
+        bucket[pos] = static_cast<uint16_t>(entry_of(v[k]));
     }
-    TPROF_T(p4);
-    __syncthreads();  // s_hist is cleared by the next chunk
-    TPROF_T(p5);
-    TPROF_ADD(0, p0, p1);
-    TPROF_ADD(1, p1, p2);
-    TPROF_ADD(2, p2, p3);
-    TPROF_ADD(3, p3, p4);
-    TPROF_ADD(4, p4, p5);
+    __syncthreads();  // s_hist is cleared by the next round
 }
 
-template <bool kWithRef>
-__global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ tgt_ref,
-                                                          const uint32_t* __restrict__ tgt_gbin,
-                                                          const uint32_t* __restrict__ counters, int count_slot,
-                                                          uint32_t ntiles, const uint32_t* __restrict__ tile_base,
-                                                          uint32_t* __restrict__ tile_cursor_all,
-                                                          uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
-                                                          uint32_t* __restrict__ ucov,
-                                                          const uint32_t* __restrict__ rep_base_all, uint32_t reps,
-                                                          uint32_t rep_stride) {
-    HIP_DYNAMIC_SHARED(uint32_t, s_hist)
-    const uint32_t P = counters[count_slot];
-    const size_t rep_off = static_cast<size_t>(blockIdx.x % reps) * rep_stride;
-    uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
-    const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
-    // (one-level variant, used while the tile-id histogram fits LDS comfortably: fewer passes, but 2-byte stores scattered
-    // over thousands of buckets)
-    // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
+// rounds until no wave of the workgroup has values left (s_more: one flag per wave)
+template <typename Body>
+__device__ __forceinline__ void bucketing_rounds(SlotWalk& walk, const uint32_t* __restrict__ vals, uint32_t* s_more,
+                                                 Body body) {
+    while (true) {
+        uint32_t v[kRoundPieces];
+        const bool mine = round_load(walk, vals, threadIdx.x & 63u, v);
+        if ((threadIdx.x & 63u) == 0) s_more[threadIdx.x >> 6] = mine ? 1u : 0u;
+        __syncthreads();
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < kTBlock / 64; ++w) any |= s_more[w];
+        __syncthreads();
+        if (!any) break;
+        body(v);
+    }
+}
+
+// tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them first
+__device__ __forceinline__ void zero_split_tiles(const uint32_t* tile_base, uint32_t ntiles, uint32_t* __restrict__ cov,
+                                                 uint32_t* __restrict__ ucov) {
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) continue;
         uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
@@ -406,32 +453,31 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
             if (ucov) ou[i] = z;
         }
     }
-    uint32_t lo, hi;
-    slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    // whole chunks of 16 K, then 8 K / 4 K / 2 K (slices are 2048-aligned), then the ragged end of the last slice
-    constexpr uint32_t kUnit = kTBlock * 4;  // targets per 16-byte word of every thread
-    uint32_t c0 = lo;
-    for (; c0 + 8 * kUnit <= hi; c0 += 8 * kUnit)
-        scatter_chunk<kWithRef, 8, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
-    if (c0 + 4 * kUnit <= hi) {
-        scatter_chunk<kWithRef, 4, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
-        c0 += 4 * kUnit;
-    }
-    if (c0 + 2 * kUnit <= hi) {
-        scatter_chunk<kWithRef, 2, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
-        c0 += 2 * kUnit;
-    }
-    if (c0 + kUnit <= hi) {
-        scatter_chunk<kWithRef, 1, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
-        c0 += kUnit;
-    }
-    if (c0 < hi)
-        scatter_chunk<kWithRef, 1, false>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, rep_base, tile_cursor, bucket, s_hist);
+}
+
+__global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
+                                                          uint32_t nslots, int per_read, uint32_t ntiles,
+                                                          const uint32_t* __restrict__ tile_base,
+                                                          uint32_t* __restrict__ tile_cursor_all,
+                                                          uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
+                                                          uint32_t* __restrict__ ucov,
+                                                          const uint32_t* __restrict__ rep_base_all, uint32_t reps,
+                                                          uint32_t rep_stride) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_hist)
+    __shared__ uint32_t s_more[kTBlock / 64];
+    const size_t rep_off = static_cast<size_t>(blockIdx.x % reps) * rep_stride;
+    uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
+    const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
+    zero_split_tiles(tile_base, ntiles, cov, ucov);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
+    bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
+        scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
+    });
 }
 
 // Exclusive scan of s[0 .. kFusedTiles) in place by the 512 threads of a workgroup (8 consecutive elements per thread,
 // wave prefix by DPP-free shuffles, 8 wave totals through s_wtot); returns the grand total to every thread.
-constexpr uint32_t kFusedTiles = 4096;  // tiles the fused scan handles: 8 per thread
+constexpr uint32_t kFusedTiles = 4096;  // slots of the fused scan: 8 per thread (kFusedScanTiles of them may hold tiles)
 __device__ __forceinline__ uint32_t block_excl_scan_4096(uint32_t* s, uint32_t* s_wtot) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t v[8], sum = 0;
@@ -469,21 +515,27 @@ __device__ __forceinline__ uint32_t block_excl_scan_4096(uint32_t* s, uint32_t* 
 // counts and scans them itself (78 KB of L2 reads and ~2 us per workgroup) instead of waiting for a single-workgroup
 // kernel (10 us per launch, twice per file); workgroup 0 also cuts the buckets into k_tile_hist's work items and lists
 // the split tiles.  tile_cursor must be zero on entry (k_zero).
-template <bool kWithRef>
-__global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* __restrict__ tgt_ref,
-                                                                const uint32_t* __restrict__ tgt_gbin,
-                                                                uint32_t* __restrict__ counters, int count_slot,
+__global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* __restrict__ vals,
+                                                                const uint4* __restrict__ slots, uint32_t nslots,
+                                                                int per_read, uint32_t* __restrict__ counters,
                                                                 uint32_t ntiles, const uint32_t* __restrict__ tile_count_all,
                                                                 uint32_t* __restrict__ tile_cursor_all,
                                                                 uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
                                                                 uint32_t* __restrict__ ucov, uint32_t rep_stride,
                                                                 uint4* __restrict__ items, uint32_t* __restrict__ split_tiles) {
-    HIP_DYNAMIC_SHARED(uint32_t, s_hist)             // [ntiles] chunk histogram / cursors (scatter_chunk)
-    __shared__ uint32_t s_base[kFusedTiles + 1];     // tile totals, then their exclusive scan (= tile_base)
+    // 80 KiB of LDS to the byte, so that two workgroups share a CU: the three small arrays live in the tail of s_mine,
+    // whose entries from ntiles on are never read (the launcher admits at most kFusedScanTiles = 4064 tiles)
+    __shared__ uint32_t s_stage[kRoundCap];          // the ordered round's stage; before the rounds: the tile totals and
+                                                     // their exclusive scan (= tile_base), kFusedTiles + 1 words
     __shared__ uint32_t s_mine[kFusedTiles];         // start of this workgroup's copy inside every tile's bucket
-    __shared__ uint32_t s_wtot[8];
-    __shared__ uint32_t s_nsplit;
-    const uint32_t P = counters[count_slot];
+    __shared__ uint32_t s_cnt[kFusedTiles];          // (scatter_round_ordered) / pieces per tile (workgroup 0's work items)
+    __shared__ uint32_t s_loff[kFusedTiles];
+    static_assert(kRoundCap >= kFusedTiles + 1, "the stage doubles as the tile_base table");
+    static_assert(kFusedScanTiles + 32 <= kFusedTiles, "room for the small arrays behind the last tile");
+    uint32_t* const s_wtot = s_mine + kFusedTiles - 32;       // [8]
+    uint32_t* const s_more = s_mine + kFusedTiles - 24;       // [kTBlock / 64]
+    uint32_t& s_nsplit = s_mine[kFusedTiles - 16];
+    uint32_t* const s_base = s_stage;
     const uint32_t tid = threadIdx.x;
     const uint32_t my_rep = blockIdx.x % kTileReps;
     if (tid == 0) s_nsplit = 0;
@@ -502,7 +554,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
             }
         }
         s_base[i] = c;
-        s_mine[i] = mine;
+        if (i < ntiles) s_mine[i] = mine;
     }
     __syncthreads();
     const uint32_t total = block_excl_scan_4096(s_base, s_wtot);
@@ -510,12 +562,12 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const uint32_t i = q * kTBlock + tid;
-        s_mine[i] += s_base[i];
+        if (i < ntiles) s_mine[i] += s_base[i];
     }
     __syncthreads();
     // (tiles beyond ntiles have count 0: their base is the grand total, so base[i + 1] - base[i] is right for every i < ntiles)
     if (blockIdx.x == 0) {  // work items of k_tile_hist: <= kTileSub entries of one tile each; an empty tile still gets one
-        uint32_t* s_piece = s_hist;  // (free until the first chunk) pieces per tile, then their exclusive scan
+        uint32_t* s_piece = s_cnt;  // (free until the first round) pieces per tile, then their exclusive scan
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const uint32_t i = q * kTBlock + tid;
@@ -539,107 +591,50 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
             counters[CNT_ITEMS2] = 0;
             counters[CNT_SPLIT] = s_nsplit;
         }
-        __syncthreads();  // s_hist is handed to the chunks
     }
-    // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (s_base[tile + 1] - s_base[tile] <= kTileSub) continue;
-        uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
-        uint4* ou = reinterpret_cast<uint4*>((ucov ? ucov : cov) + static_cast<size_t>(tile) * kTileBins);
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = tid; i < kTileBins / 4; i += kTBlock) {
-            oc[i] = z;
-            if (ucov) ou[i] = z;
-        }
-    }
+    zero_split_tiles(s_base, ntiles, cov, ucov);
+    __syncthreads();  // the stage (s_base) and s_cnt are handed to the rounds
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + static_cast<size_t>(my_rep) * rep_stride;
-    uint32_t lo, hi;
-    slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    constexpr uint32_t kUnit = kTBlock * 4;
-    uint32_t c0 = lo;
-    for (; c0 + 8 * kUnit <= hi; c0 += 8 * kUnit)
-        scatter_chunk<kWithRef, 8, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, s_mine, tile_cursor, bucket, s_hist);
-    if (c0 + 4 * kUnit <= hi) {
-        scatter_chunk<kWithRef, 4, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, s_mine, tile_cursor, bucket, s_hist);
-        c0 += 4 * kUnit;
-    }
-    if (c0 + 2 * kUnit <= hi) {
-        scatter_chunk<kWithRef, 2, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, s_mine, tile_cursor, bucket, s_hist);
-        c0 += 2 * kUnit;
-    }
-    if (c0 + kUnit <= hi) {
-        scatter_chunk<kWithRef, 1, true>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, s_mine, tile_cursor, bucket, s_hist);
-        c0 += kUnit;
-    }
-    if (c0 < hi)
-        scatter_chunk<kWithRef, 1, false>(tgt_ref, tgt_gbin, c0, hi, P, ntiles, s_mine, tile_cursor, bucket, s_hist);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
+    bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
+        scatter_round_ordered(v, ntiles, s_mine, tile_cursor, bucket, s_cnt, s_loff, s_stage, s_wtot);
+    });
 }
 
-template <bool kWithRef>
-__global__ __launch_bounds__(kTBlock) void k_part_super(const uint32_t* __restrict__ tgt_ref,
-                                                        const uint32_t* __restrict__ tgt_gbin,
-                                                        const uint32_t* __restrict__ counters, int count_slot,
-                                                        uint32_t ntiles, const uint32_t* __restrict__ tile_base,
+// two levels, level 1: values go to their SUPER tile (64 tiles = 512 K bins) as 32-bit words (19-bit bin-in-super |
+// unique bit): few destinations per workgroup, long runs
+__global__ __launch_bounds__(kTBlock) void k_part_super(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
+                                                        uint32_t nslots, int per_read, uint32_t ntiles,
+                                                        const uint32_t* __restrict__ tile_base,
                                                         uint32_t* __restrict__ sup_cursor, uint32_t* __restrict__ mid,
                                                         uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
     __shared__ uint32_t s_cur[kMaxSuper];
-    const uint32_t P = counters[count_slot];
+    __shared__ uint32_t s_more[kTBlock / 64];
     const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
-    // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them here
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) continue;
-        uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
-        uint4* ou = reinterpret_cast<uint4*>((ucov ? ucov : cov) + static_cast<size_t>(tile) * kTileBins);
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += kTBlock) {
-            oc[i] = z;
-            if (ucov) ou[i] = z;
-        }
-    }
-    for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) s_cur[i] = 0;
-    __syncthreads();
-    uint32_t lo, hi;
-    slice_of(P, blockIdx.x, gridDim.x, lo, hi);
-    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
-        uint32_t g[4];
+    zero_split_tiles(tile_base, ntiles, cov, ucov);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
+    bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
+        for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) s_cur[i] = 0;
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t t = t0 + u * kTBlock + threadIdx.x;
-            g[u] = (t < hi) ? tgt_gbin[t] : 0xffffffffu;
+        for (int k = 0; k < kRoundPieces; ++k)
+            if (v[k] != 0xffffffffu) atomicAdd(&s_cur[(v[k] & 0x7fffffffu) >> kSuperShift], 1u);
+        __syncthreads();
+        // reserve [base, base + h) of each non-empty super tile's range for this round; s_cur becomes the write cursor
+        for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) {
+            const uint32_t h = s_cur[i];
+            if (h) s_cur[i] = tile_base[i * kSuperTiles] + atomicAdd(&sup_cursor[i], h);
         }
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (g[u] != 0xffffffffu) atomicAdd(&s_cur[g[u] >> kSuperShift], 1u);
-    }
-    __syncthreads();
-    // reserve [base, base + h) of each non-empty super tile's range for this workgroup; s_cur becomes the write cursor
-    for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) {
-        uint32_t h = s_cur[i];
-        if (h) s_cur[i] = tile_base[i * kSuperTiles] + atomicAdd(&sup_cursor[i], h);
-    }
-    __syncthreads();
-    for (uint32_t t0 = lo; t0 < hi; t0 += 4 * kTBlock) {
-        uint32_t g[4], r0[4], r1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t t = t0 + u * kTBlock + threadIdx.x;
-            bool live = t < hi;
-            g[u] = live ? tgt_gbin[t] : 0xffffffffu;
-            if (kWithRef) {
-                r0[u] = live ? tgt_ref[t] : 0u;
-                r1[u] = (live && t + 1 < P) ? tgt_ref[t + 1] : 0x80000000u;
-            } else {
-                r0[u] = r1[u] = 0u;
-            }
+        for (int k = 0; k < kRoundPieces; ++k) {
+            if (v[k] == 0xffffffffu) continue;
+            const uint32_t g = v[k] & 0x7fffffffu;
+            const uint32_t pos = atomicAdd(&s_cur[g >> kSuperShift], 1u);
+            mid[pos] = (g & kSuperMask) | ((v[k] >> 31) << kSuperShift);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (g[u] == 0xffffffffu) continue;
-            bool uniq = (r0[u] >> 31) && (r1[u] >> 31);  // first target of its read and the next target starts a read
-            uint32_t pos = atomicAdd(&s_cur[g[u] >> kSuperShift], 1u);
-            mid[pos] = (g[u] & kSuperMask) | (uniq ? (1u << kSuperShift) : 0u);
-        }
-    }
+        __syncthreads();
+    });
 }
 
 __global__ __launch_bounds__(kTBlock) void k_part_tile(const uint32_t* __restrict__ mid, const uint4* __restrict__ items2,
@@ -926,19 +921,16 @@ int tile_hist_setup(uint32_t ntiles) {
                             static_cast<int>(bytes)) != hipSuccess)
         return -1;
     if ((ntiles + kSuperTiles - 1) / kSuperTiles > kMaxSuper) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
-        return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(bytes)) != hipSuccess)
         return -1;
     return 0;
 }
 
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* gbin, const uint32_t* counters,
-                       int count_slot, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
-    hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, gbin, counters,
-                       count_slot, ntiles, tile_count, reps, rep_stride);
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* counters,
+                       uint32_t* tail, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
+    hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots,
+                       in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, counters, tail);
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
@@ -952,44 +944,30 @@ uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
     return (ntiles + kSuperTiles - 1) / kSuperTiles + n_upper / kPartSub + 1;
 }
 
-void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const uint32_t* tgt_ref,
-                         const uint32_t* gbin, const uint32_t* counters, int count_slot, const uint32_t* tile_base,
-                         uint32_t* tile_cursor, uint32_t* sup_cursor, const uint4* items2, uint32_t* mid, uint16_t* bucket,
-                         uint32_t* cov, uint32_t* ucov, bool two_level, const uint32_t* rep_base, uint32_t reps,
-                         uint32_t rep_stride) {
+void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const SlotValues& in,
+                         const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
+                         const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
+                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride) {
     if (!two_level) {
         const size_t lds = static_cast<size_t>(ntiles) * 4;
-        if (tgt_ref)
-            hipLaunchKernelGGL(k_tile_scatter<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                               ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
-        else
-            hipLaunchKernelGGL(k_tile_scatter<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters,
-                               count_slot, ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
+        hipLaunchKernelGGL(k_tile_scatter, dim3(grid), dim3(kTBlock), lds, st, in.vals, in.slots, in.nslots,
+                           in.per_read ? 1 : 0, ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
         return;
     }
-    if (tgt_ref)
-        hipLaunchKernelGGL(k_part_super<true>, dim3(grid), dim3(kTBlock), 0, st, tgt_ref, gbin, counters, count_slot, ntiles,
-                           tile_base, sup_cursor, mid, cov, ucov);
-    else
-        hipLaunchKernelGGL(k_part_super<false>, dim3(grid), dim3(kTBlock), 0, st, tgt_ref, gbin, counters, count_slot, ntiles,
-                           tile_base, sup_cursor, mid, cov, ucov);
+    hipLaunchKernelGGL(k_part_super, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots, in.per_read ? 1 : 0,
+                       ntiles, tile_base, sup_cursor, mid, cov, ucov);
     hipLaunchKernelGGL(k_part_tile, dim3(part_items_upper(ntiles, n_upper)), dim3(kTBlock), 0, st, mid, items2, counters,
                        tile_base, tile_cursor, ntiles, bucket);
 }
 
 // count -> scan -> scatter of the one-level bucketing with the scan inside the scatter kernel (<= 4096 tiles, copies of
 // the counters / cursors in use); tile_cursor must be zero.  counters is written (work item and split-tile counts).
-void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const uint32_t* tgt_ref, const uint32_t* gbin,
-                               uint32_t* counters, int count_slot, const uint32_t* tile_count, uint32_t* tile_cursor,
-                               uint16_t* bucket, uint32_t* cov, uint32_t* ucov, uint32_t rep_stride, uint4* items,
-                               uint32_t* split_tiles) {
-    const size_t lds = static_cast<size_t>(kFusedTiles) * 4;  // the block scan works on 4096 slots
-    if (tgt_ref)
-        hipLaunchKernelGGL(k_tile_scatter_fused<true>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters, count_slot,
-                           ntiles, tile_count, tile_cursor, bucket, cov, ucov, rep_stride, items, split_tiles);
-    else
-        hipLaunchKernelGGL(k_tile_scatter_fused<false>, dim3(grid), dim3(kTBlock), lds, st, tgt_ref, gbin, counters,
-                           count_slot, ntiles, tile_count, tile_cursor, bucket, cov, ucov, rep_stride, items, split_tiles);
+void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
+                               const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
+                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles) {
+    hipLaunchKernelGGL(k_tile_scatter_fused, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots,
+                       in.per_read ? 1 : 0, counters, ntiles, tile_count, tile_cursor, bucket, cov, ucov, rep_stride, items,
+                       split_tiles);
 }
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }

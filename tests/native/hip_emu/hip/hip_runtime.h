@@ -154,6 +154,14 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
     const uint32_t below = l <= 32 ? 0u : ((1u << (l - 32)) - 1u);
     return add + static_cast<uint32_t>(__builtin_popcount(mask & below));
 }
+// the lane's bit of a wave-uniform mask: a v_cndmask on the GPU, no exchange between lanes (so it may sit inside
+// divergent code, which the lock-step model cannot order against collectives outside the branch)
+static inline bool __builtin_amdgcn_inverse_ballot_w64(uint64_t mask) { return (mask >> ::hipemu::g_lane) & 1u; }
+static inline uint64_t __builtin_bitreverse64(uint64_t v) {
+    uint64_t r = 0;
+    for (int i = 0; i < 64; ++i) r |= ((v >> i) & 1ull) << (63 - i);
+    return r;
+}
 static inline uint32_t __builtin_amdgcn_readlane(uint32_t v, uint32_t lane) {
     const uint64_t* a = ::hipemu::wave_exchange(v);
     return static_cast<uint32_t>(a[lane & 63u]);

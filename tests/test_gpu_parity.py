@@ -177,11 +177,9 @@ def test_direct_atomic_fallback_path(monkeypatch):
     check(make_workload(CONFIGS["config1"], seed=16))
 
 
-@pytest.mark.parametrize("kernel", ["walk", "tagged", "hash"])
-def test_both_classification_kernels(monkeypatch, kernel):
-    """k_runs (look-back walk) and k_runs_hash (LDS hash table) are picked on the device by records per read;
-    forced here, both must agree with the oracle on shallow and deep multi-mapping."""
-    monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
+def test_shallow_and_deep_multi_mapping():
+    """The front end's three window paths against the oracle: runs of a few records (fast windows), and runs of 40 records
+    on average, a third of which exceed 64 records (the chunked long-run path)."""
     check(make_workload(CONFIGS["config2"], seed=22, n_records=300_000))
     check(make_workload(SynthConfig("c5w", 200_000, 3_000, 40.0, strain_level=True), seed=23))
     w, _, _ = load_golden("tiny")
@@ -206,10 +204,11 @@ def _interleave_mates(w: Workload) -> Workload:
     return Workload(w.ref_names, w.ref_len, w.taxonomy, rec.take(order), w.avg_read_len, w.options, w.name + "-interleaved")
 
 
-@pytest.mark.parametrize("kernel", ["walk", "tagged", "hash"])
-def test_interleaved_mates(monkeypatch, kernel):
-    monkeypatch.setenv("SLIMM_RUNS_KERNEL", kernel)
-    w = _interleave_mates(make_workload(SynthConfig("pairs", 200_000, 2_000, 6.0), seed=25, paired_frac=0.9))
+@pytest.mark.parametrize("hits", [6.0, 45.0])
+def test_interleaved_mates(hits):
+    """Mates alternating inside a qName run: the general window path (targets of a run reordered by mate), and at 45 hits
+    per read the long-run path with one pass per mate number."""
+    w = _interleave_mates(make_workload(SynthConfig("pairs", 200_000, 2_000, hits), seed=25, paired_frac=0.9))
     mate = np.where(w.records.flag & 0x40, 1, np.where(w.records.flag & 0x80, 2, 0))
     same = w.records.read_key[1:] == w.records.read_key[:-1]
     assert int((same & (mate[1:] < mate[:-1])).sum()) > 1000   # mates really interleave
@@ -217,8 +216,8 @@ def test_interleaved_mates(monkeypatch, kernel):
     check(w, grouped=False)
 
 
-def test_runs_longer_than_the_staged_window():
-    """Reads with hundreds of records: runs cross tile boundaries and outgrow the 512-record halo (global fallback)."""
+def test_runs_of_hundreds_of_records():
+    """Reads with hundreds of records: runs cross many slots; every chunk of a run is compared with all chunks before it."""
     cfg = SynthConfig("long", 400_000, 4_000, 300.0, strain_level=True, present_frac=0.2)
     s, o = check(make_workload(cfg, seed=24))
     assert o.scalars["hits"] / o.scalars["matches"] > 100
@@ -439,31 +438,18 @@ def test_contexts_release_their_device_memory():
 
 
 def test_chunked_tile_scan(monkeypatch):
-    """Above 32 K record tiles (64 M records) the tile scan runs on several workgroups; forced here on small inputs with
-    chunks of 16 tiles (the last chunk ragged), through both record orders."""
+    """Above 16 K record tiles the tile scan of the compaction (record_order = ANY) runs on several workgroups; forced here
+    on a small input with chunks of 16 tiles (the last chunk ragged)."""
     monkeypatch.setenv("SLIMM_SCAN_CHUNK", "16")
-    monkeypatch.setenv("SLIMM_NO_FUSED_EMIT", "1")    # grouped input up to 16 K tiles needs no scan kernel otherwise
     w = make_workload(CONFIGS["config2"], seed=35, n_records=250_000)   # 123 tiles -> 8 chunks
-    check(w)
     check(w, grouped=False)
 
 
-@pytest.mark.parametrize("n_records", [2048 * 64, 2048 * 64 + 1, 2048 * 129 - 5, 1_500_000])
-def test_tile_offsets_from_chunk_sums(n_records, monkeypatch):
-    """Grouped input of up to 64 K tiles: k_emit derives its offsets from per-chunk sums (64 - 256 tiles per chunk) instead
-    of a scan launch; chunk boundaries exact, one past, ragged, and many chunks -- and the same answers with the scan kernel."""
+@pytest.mark.parametrize("n_records", [1024 * 64, 1024 * 64 + 1, 1024 * 129 - 5, 1_500_000])
+def test_slot_boundaries(n_records):
+    """Record counts at, one past and short of whole slots (1024 records), and many slots: runs straddle slot boundaries,
+    the last slot is ragged."""
     w = make_workload(CONFIGS["config2"], seed=36, n_records=n_records)
-    check(w)                                          # chunk sums by the idle hash launch
-    for shift in ("7", "8"):                          # the chunk sizes of 16 K - 64 K tiles, on this small input
-        monkeypatch.setenv("SLIMM_EMIT_CHUNK_SHIFT", shift)
-        check(w)
-        monkeypatch.setenv("SLIMM_RUNS_KERNEL", "hash")
-        check(w)
-        monkeypatch.delenv("SLIMM_RUNS_KERNEL")
-    monkeypatch.delenv("SLIMM_EMIT_CHUNK_SHIFT")
-    monkeypatch.setenv("SLIMM_RUNS_KERNEL", "hash")
-    check(w)                                          # chunk sums by atomics of the hash kernel
-    monkeypatch.setenv("SLIMM_NO_FUSED_EMIT", "1")
     check(w)
 
 
@@ -474,7 +460,7 @@ def test_kernel_timing_reports_every_kernel():
     s.push_records(w.records)
     s.get_profiles()
     t = s.kernel_times()
-    for k in ("k_runs", "k_emit", "k_tile_hist", "k_pack", "k_filter_lca", "k_tile_hist2", "k_pack2"):
+    for k in ("k_front", "k_tile_hist", "k_pack", "k_filter", "k_tile_hist2", "k_pack2"):
         assert t[k][1] >= 1 and t[k][0] > 0.0, k
 
 
@@ -514,24 +500,23 @@ def test_reference_id_out_of_range_is_an_error():
     assert e.value.code == capi.E_REF_RANGE
 
 
-def test_run_longer_than_the_lookback_window_is_an_error_not_a_hang():
+def test_a_read_with_tens_of_thousands_of_records_is_no_error():
+    """The reference has no limit on the alignments of one read (src/read_stat.hpp:116-135).  20000 records of ONE read:
+    over 5 references (every record but the first five is a repeat), and with the very last record on a new reference --
+    it has to be compared with all 19999 records before it."""
     n = 20000
-    rec = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16),
-                  (np.arange(n) % 5).astype(np.int32), np.full(n, 10, dtype=np.int32))
-    w = tiny_case()
-    s = Slimm.for_workload(w, device=0)
-    s.push_records(rec)
-    s.analyze_alignments()
-    # 20000 records of one read over 5 references: every look-back finds its reference within 5 steps -> fine
-    assert s.finish_coverage()
-    s.reset()
-    rec2 = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16),
-                   np.concatenate([np.zeros(n - 1), [1]]).astype(np.int32), np.full(n, 10, dtype=np.int32))
-    s.push_records(rec2)
-    s.analyze_alignments()
-    with pytest.raises(capi.SlimmError) as e:  # the last record must look back over 19999 records of ref 0
-        s.finish_coverage()
-    assert e.value.code == capi.E_RUN_LENGTH
+    base = tiny_case()
+    for refs in ((np.arange(n) % 5).astype(np.int32), np.concatenate([np.zeros(n - 1), [1]]).astype(np.int32)):
+        rec = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16), refs, np.full(n, 10, dtype=np.int32))
+        w = Workload(base.ref_names, base.ref_len, base.taxonomy, rec, base.avg_read_len, base.options, "one-read")
+        s, o = check(w)
+        assert s.stats()["matches_count"] == 1 and s.stats()["hits_count"] == n
+    # ... and the same read with its two mates alternating (one pass per mate number over the run)
+    flag = np.where(np.arange(n) % 2 == 0, 0x41, 0x81).astype(np.uint16)
+    rec = Records(np.zeros(n, dtype=np.uint64), flag, (np.arange(n) % 5).astype(np.int32), np.full(n, 10, dtype=np.int32))
+    w = Workload(base.ref_names, base.ref_len, base.taxonomy, rec, base.avg_read_len, base.options, "one-pair")
+    s, o = check(w)
+    assert s.stats()["matches_count"] == 2
 
 
 def test_ragged_tile_boundaries():
@@ -639,10 +624,9 @@ def test_prefix_of_the_big_configs_with_their_full_reference_sets(name, n):
     check(make_workload(CONFIGS[name], seed=2, n_records=n))
 
 
-@pytest.mark.parametrize("hits", [6.0, 9.0, 14.0])
-def test_medium_depth_streams_take_the_tagged_walk(hits):
-    """6 - 16 records per qName run: the device picks the tagged-word walk by itself (k_runs, mode 2); runs cross pass and
-    tile boundaries, mates interleave."""
+@pytest.mark.parametrize("hits", [6.0, 9.0, 14.0, 25.0])
+def test_medium_depth_streams(hits):
+    """6 - 25 records per qName run: windows of a few runs each, a growing share of runs of 64 records or more."""
     w = make_workload(SynthConfig("mid", 300_000, 300, hits, bin_width=200, len_lo=20_000, len_hi=200_000,
                                   strain_level=True), seed=51)
     check(w)

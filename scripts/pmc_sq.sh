@@ -1,0 +1,18 @@
+# SQ instruction / wait counters of every kernel (one rocprofv3 --pmc pass), for a bench configuration: scripts/pmc_sq.sh TAG [bench args]
+TAG=${1:-sq}; shift
+export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT -o a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config3 --push-steps 0 "$@" > /dev/null 2>$OUT/err_a.txt
+python3 - <<PY
+import csv, collections, glob
+for f in sorted(glob.glob("$OUT/*_counter_collection.csv")):
+    rows=list(csv.DictReader(open(f)))
+    agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
+    for r in rows:
+        k=r["Kernel_Name"].split("(")[0].replace("void slimm::","").replace("slimm::","")[:28]
+        agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
+    with open("$OUT/summary.txt","w") as o:
+        for k,v in agg.items():
+            if k.startswith("__amd"): continue
+            line=f"{k} {len(n[k])} " + str({a:round(b/len(n[k])) for a,b in sorted(v.items())})
+            print(line); o.write(line+"\n")
+PY

@@ -117,6 +117,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist;
     DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
     DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
+    DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
     DevBuf<uint2> tile_cnt;              // (record_order = ANY: mapped records per tile of the compaction)
     DevBuf<uint4> scan_sums;             // chunk sums of the multi-workgroup tile scan
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
@@ -275,6 +276,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
+    HIP_TRY(c, c->wcut.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
     HIP_TRY(c, c->sel.ensure(n + 1));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
@@ -644,13 +646,13 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_FRONT);
             launch_front_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                                c->slots.p);
+                                c->slots.p, c->wcut.p);
         }
     } else {
         // grouped input: one pass straight over the caller's record arrays
         KernelTimer t(c, K_FRONT);
         launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                         c->slots.p);
+                         c->slots.p, c->wcut.p);
     }
     SlotValues targets;
     targets.vals = c->tgt_gbin.p;
@@ -969,6 +971,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             fa.tgt_ref = c->tgt_ref.p;
             fa.tgt_gbin = c->tgt_gbin.p;
             fa.slots = c->slots.p;
+            fa.wcut = c->wcut.p;
             fa.nslots = nslots;
             if (c->use_rows16) {
                 fa.rows16 = c->d_rows16.p;

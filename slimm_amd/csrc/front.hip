@@ -4,21 +4,26 @@
 // src/read_stat.hpp:116-135 (add_target keeps the bin of the FIRST record of a (read, reference) pair: quirk Q1);
 // the unique bit is the `reads.size() == 1` test of src/slimm.hpp:224-237.
 //
-// Shape.  A wave owns slots of kSlotRecs consecutive records and walks through a slot in windows of 64 records that
-// always START AT A qName RUN START and are cut behind the window's last complete run, so every window holds whole
-// runs only: nothing about a read has to be carried from one window, wave or workgroup to the next -- no halo, no LDS,
-// no barrier, no scan over tiles.  (The records behind the last complete run are loaded again by the next window: 4 %
-// of the loads at 3 records per run, 12 % at 8.)  Inside a window everything is lane-mask arithmetic:
-//   run / segment starts   ballots of "key or mate differs from the lane before" (DPP wave shift)
-//   first of (read, ref)   Q1: a tagged word {segment start, reference} is shifted along the lanes one step at a time
-//                          and compared with the lane's own; the trip count is the window's longest segment
-//   head of a read         "first mapped lane at or after each segment start": ONE 64-bit scalar add -- the carry
-//                          of ~mapped + starts ripples from every start to the first mapped lane behind it
-//   unique reads           a head is unique iff the next target is a head again: the same carry trick on the
-//                          bit-reversed masks finds the target in front of every non-head target
-// and the targets are written compacted behind the slot's first run start (rank = popcount of the lanes below).  A slot's
-// targets therefore sit at [start, start + nf) with start = index of its first run start and nf <= the records the slot
-// is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.
+// Shape.  A wave owns slots of kSlotRecs consecutive records.  Per slot:
+//   1. the run-start bitmap of the slot: its keys (all blocks of 64 in flight together) are compared with the key of the
+//      lane before (DPP wave shift); one ballot per block.  The keys are not needed again.
+//   2. the slot is cut into WINDOWS of up to 64 records that start at a qName run start and end behind the last run that
+//      is complete inside them -- scalar arithmetic on the bitmap, so the cuts are known before any other field of the
+//      records has been loaded, and the {flag, reference, position} loads of the next window are in flight while the
+//      current one is classified.  Every window holds whole runs only: nothing about a read is ever carried from one
+//      window, wave or workgroup to the next -- no halo, no LDS, no barrier, no scan over tiles.
+//   3. inside a window everything is lane-mask arithmetic:
+//        segment starts       run starts | "mate differs from the lane before"
+//        first of (read, ref) Q1: a tagged word {segment start, reference} is shifted along the lanes one step at a time
+//                             and compared with the lane's own; the trip count is the window's longest segment
+//        head of a read       "first mapped lane at or after each segment start": ONE 64-bit scalar add -- the carry
+//                             of ~mapped + starts ripples from every start to the first mapped lane behind it
+//        unique reads         a head is unique iff the next target is a head again: the same carry trick on the
+//                             bit-reversed masks finds the target in front of every non-head target
+//      and the targets are written compacted behind the slot's first run start (rank = popcount of the lanes below).
+// A slot's targets therefore sit at [start, start + nf) with start = index of its first run start and nf <= the records
+// the slot is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.  The windows'
+// first targets / reads are listed per slot (wcut) so that k_filter can take them up independently of each other.
 //
 // Three paths per window, chosen by wave-uniform tests:
 //   fast     the mate numbers of every run are non-decreasing (mapper output "all of mate 1, then all of mate 2",
@@ -33,6 +38,8 @@
 //   tgt_ref [p]  reference id | bit 31: first target of its read
 //   tgt_gbin[p]  global bin (bin_off[ref] + bin) | bit 31: the read has exactly one target (src/slimm.hpp:224)
 //   slots   [s]  {start, targets, reads, mapped records} of slot s
+//   wcut    [s * kSlotWindows + i]  {targets, reads} of slot s in front of its window i; the last entry of a slot's row
+//                holds the number of windows, the entry behind the last window the slot's totals
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,6 +55,8 @@ namespace {
 constexpr uint32_t kTagShift = 26;                       // reference ids are below 2^26 (slimm_create checks)
 constexpr uint32_t kRefField = (1u << kTagShift) - 1u;   // ... so this value names no reference
 constexpr uint32_t kNoMatch = 0xffffffffu;               // shifted in at lane 0: equals no tagged word
+constexpr uint32_t kSlotBlocks = kSlotRecs / 64 + 1;     // key blocks of a slot's bitmap: one more than the slot, so
+                                                         // that a window starting in the slot's last record is covered
 
 __device__ __forceinline__ uint32_t f_lane() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -83,6 +92,11 @@ __device__ __forceinline__ uint64_t f_first_after(uint64_t starts, uint64_t bits
 // ---------------------------------------------------------------------------------------------------------
 // record sources: the caller's arrays (grouped input) or the compacted, identity-sorted stream (record_order = ANY)
 // ---------------------------------------------------------------------------------------------------------
+struct FrontRec {  // what a window needs of a record besides its place in a run
+    uint32_t mate, ref, aux;
+    bool mapped;
+};
+
 struct FrontRaw {
     const uint64_t* key;
     const int32_t* ref;
@@ -92,18 +106,16 @@ struct FrontRaw {
     uint32_t n, n_refs, half_read, bin_width, bw_magic;
     static constexpr bool kCountsMapped = true;   // hits_count (src/slimm.hpp:212) is counted here
     __device__ uint32_t count(const uint32_t*) const { return n; }
-    struct Rec {
-        uint32_t klo, khi;  // qName identity (its top two bits are not significant and are cleared)
-        uint32_t mate, ref, aux;
-        bool mapped;
-    };
-    __device__ Rec load(uint32_t i, bool& bad) const {
+    // qName identity (the top two bits of the key are not significant)
+    __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
         const uint64_t k = key[i];
+        lo = static_cast<uint32_t>(k);
+        hi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
+    }
+    __device__ FrontRec rec(uint32_t i, bool& bad) const {
         const uint32_t f = flag[i];
         const int32_t r = ref[i];
-        Rec o;
-        o.klo = static_cast<uint32_t>(k);
-        o.khi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
+        FrontRec o;
         o.mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);                    // src/slimm.hpp:205-208
         o.mapped = !(f & 0x4u) && r != -1;                                       // src/slimm.hpp:197
         if (o.mapped && static_cast<uint32_t>(r) >= n_refs) {
@@ -113,19 +125,6 @@ struct FrontRaw {
         o.ref = static_cast<uint32_t>(r);
         o.aux = static_cast<uint32_t>(pos[i]);
         return o;
-    }
-    __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
-        const uint64_t k = key[i];
-        lo = static_cast<uint32_t>(k);
-        hi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
-    }
-    // what the duplicate test of the long-run path needs of an earlier chunk
-    __device__ void mate_ref(uint32_t i, uint32_t& mate, uint32_t& r, bool& mapped) const {
-        const uint32_t f = flag[i];
-        const int32_t rr = ref[i];
-        mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);
-        mapped = !(f & 0x4u) && rr != -1 && static_cast<uint32_t>(rr) < n_refs;
-        r = static_cast<uint32_t>(rr);
     }
     // n / bin_width with a host-computed reciprocal: mulhi(n, floor((2^32 - 1) / d)) is the quotient or one less
     __device__ uint32_t div_bin_width(uint32_t v) const {
@@ -147,31 +146,18 @@ struct FrontSorted {
     const uint32_t* cgbin;
     static constexpr bool kCountsMapped = false;  // the compaction counted the mapped records
     __device__ uint32_t count(const uint32_t* counters) const { return counters[CNT_V]; }
-    struct Rec {
-        uint32_t klo, khi;
-        uint32_t mate, ref, aux;
-        bool mapped;
-    };
-    __device__ Rec load(uint32_t i, bool&) const {
-        const uint64_t k = ident[i];
-        Rec o;
-        o.mate = static_cast<uint32_t>(k) & 3u;
-        o.klo = static_cast<uint32_t>(k) & ~3u;
-        o.khi = static_cast<uint32_t>(k >> 32);
-        o.mapped = true;
-        o.ref = cref[i];
-        o.aux = cgbin[i];
-        return o;
-    }
     __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
         const uint64_t k = ident[i];
         lo = static_cast<uint32_t>(k) & ~3u;
         hi = static_cast<uint32_t>(k >> 32);
     }
-    __device__ void mate_ref(uint32_t i, uint32_t& mate, uint32_t& r, bool& mapped) const {
-        mate = static_cast<uint32_t>(ident[i]) & 3u;
-        r = cref[i];
-        mapped = true;
+    __device__ FrontRec rec(uint32_t i, bool&) const {
+        FrontRec o;
+        o.mate = reinterpret_cast<const uint32_t*>(ident)[2 * static_cast<size_t>(i)] & 3u;
+        o.mapped = true;
+        o.ref = cref[i];
+        o.aux = cgbin[i];
+        return o;
     }
     __device__ uint32_t gbin(uint32_t, uint32_t aux) const { return aux; }
 };
@@ -184,14 +170,14 @@ struct SlotOut {  // where the slot's targets go and what it has counted so far 
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// fast path: lanes [lo, X) of the window hold whole runs whose mates never decrease
+// fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  SS = segment starts (run starts and
+// mate changes), V = mapped lanes, both inside [0, X).
 // ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
-__device__ __forceinline__ void window_fast(const Acc& acc, const typename Acc::Rec& rec, uint32_t lane, uint64_t PR,
-                                            uint64_t SS, uint64_t V, uint32_t X, SlotOut& so,
-                                            uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
-    const bool in_pr = f_bit(PR);
-    const bool use = rec.mapped && in_pr;
+__device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec, uint32_t lane, uint64_t SS, uint64_t V,
+                                            uint32_t X, SlotOut& so, uint32_t* __restrict__ tgt_ref,
+                                            uint32_t* __restrict__ tgt_gbin) {
+    const bool use = f_bit(V);
     // segment start of this lane: the highest start at or below it
     const uint64_t le = (2ull << lane) - 1ull;
     const uint32_t from = 63u - static_cast<uint32_t>(__builtin_clzll((SS & le) | 1ull));
@@ -210,18 +196,16 @@ __device__ __forceinline__ void window_fast(const Acc& acc, const typename Acc::
     const bool first = use && differ != 0u;
     const uint64_t F = f_ballot(first);
     // heads: the first mapped lane of every segment; the last lane of a segment stops the carry of its start
-    const uint64_t last_lane = 1ull << (X - 1u);
-    const uint64_t H = f_first_after(SS, V, (SS >> 1) | last_lane);
+    const uint64_t H = f_first_after(SS, V, (SS >> 1) | (1ull << (X - 1u)));
     // unique reads: a head whose NEXT target is a head again (or there is none in the window: the next run's first
     // target is a head).  In bit-reversed order "the target in front of g" is "the first target above g".
-    const uint64_t G = F & ~H;
-    const uint64_t Fr = __builtin_bitreverse64(F), Gr = __builtin_bitreverse64(G);
-    const uint64_t NU = __builtin_bitreverse64((~Fr + (Gr << 1)) & Fr);
-    const uint64_t U = H & ~NU;
+    const uint64_t Fr = __builtin_bitreverse64(F), Gr = __builtin_bitreverse64(F & ~H);
+    const uint64_t U = H & ~__builtin_bitreverse64((~Fr + (Gr << 1)) & Fr);
+    const bool hbit = f_bit(H), ubit = f_bit(U);
     if (first) {
         const uint32_t p = so.base + so.nf + f_rank(F);
-        tgt_ref[p] = rec.ref | (f_bit(H) ? 0x80000000u : 0u);
-        tgt_gbin[p] = acc.gbin(rec.ref, rec.aux) | (f_bit(U) ? 0x80000000u : 0u);
+        tgt_ref[p] = rec.ref | (hbit ? 0x80000000u : 0u);
+        tgt_gbin[p] = acc.gbin(rec.ref, rec.aux) | (ubit ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -233,17 +217,15 @@ __device__ __forceinline__ void window_fast(const Acc& acc, const typename Acc::
 // targets of a run are written ordered by (mate, file order), so a read's targets stay contiguous.
 // ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
-__device__ __forceinline__ void window_general(const Acc& acc, const typename Acc::Rec& rec, uint32_t lane, uint64_t PR,
-                                               uint64_t RS, uint64_t V, SlotOut& so, uint32_t* __restrict__ tgt_ref,
-                                               uint32_t* __restrict__ tgt_gbin) {
-    const bool in_pr = f_bit(PR);
-    const bool use = rec.mapped && in_pr;
+__device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& rec, uint32_t lane, uint64_t RS, uint64_t V,
+                                            uint32_t X, SlotOut& so, uint32_t* __restrict__ tgt_ref,
+                                            uint32_t* __restrict__ tgt_gbin) {
+    const bool in_pr = lane < X;
+    const bool use = f_bit(V);
     const uint64_t le = (2ull << lane) - 1ull;
-    const uint64_t runs = RS & PR;
-    const uint32_t run_from = 63u - static_cast<uint32_t>(__builtin_clzll((runs & le) | 1ull));
-    const uint64_t above = runs & ~le;  // run starts behind this lane
-    const uint32_t pr_end = 64u - static_cast<uint32_t>(__builtin_clzll(PR));
-    const uint32_t run_to = above ? static_cast<uint32_t>(__builtin_ctzll(above)) : pr_end;  // one past my run's last lane
+    const uint32_t run_from = 63u - static_cast<uint32_t>(__builtin_clzll((RS & le) | 1ull));
+    const uint64_t above = RS & ~le;  // run starts behind this lane
+    const uint32_t run_to = above ? static_cast<uint32_t>(__builtin_ctzll(above)) : X;  // one past my run's last lane
     const uint32_t W = use ? ((rec.mate << 28) | rec.ref) : (0xc0000000u | lane);  // mate 3: equals nobody's
     // backward over the run: first of its (mate, ref)?  head of its mate?
     const uint32_t back = in_pr ? lane - run_from : 0u;
@@ -289,9 +271,9 @@ __device__ __forceinline__ void window_general(const Acc& acc, const typename Ac
 // of the record behind the run.
 // ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
-__device__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, SlotOut& so,
-                             uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
-    // 1. where the run ends, whether its mates ever decrease, which mates it has
+__device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, SlotOut& so,
+                                          uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
+    // 1. where the run ends, whether its mates ever decrease
     uint32_t klo0, khi0;
     acc.key_at(pos, klo0, khi0);
     uint32_t end = pos;
@@ -301,8 +283,10 @@ __device__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t 
         const uint32_t i = end + lane;
         const bool live = i < N;
         bool b = false;
-        const typename Acc::Rec r = acc.load(live ? i : N - 1u, b);
-        const uint64_t same = f_ballot(live && r.klo == klo0 && r.khi == khi0);
+        uint32_t klo, khi;
+        acc.key_at(live ? i : N - 1u, klo, khi);
+        const FrontRec r = acc.rec(live ? i : N - 1u, b);
+        const uint64_t same = f_ballot(live && klo == klo0 && khi == khi0);
         const uint32_t n_same = static_cast<uint32_t>(__builtin_ctzll(~same | (1ull << 63)));  // lanes before the first other key
         const bool whole = (~same) == 0ull;
         const uint32_t n_in = whole ? 64u : n_same;
@@ -321,7 +305,7 @@ __device__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t 
         for (uint32_t cb = pos; cb < end; cb += 64u) {
             const uint32_t i = cb + lane;
             const bool in_run = i < end;
-            const typename Acc::Rec r = acc.load(in_run ? i : end - 1u, bad);
+            const FrontRec r = acc.rec(in_run ? i : end - 1u, bad);
             const bool use = in_run && r.mapped && (!decreasing || r.mate == pass);
             const uint32_t T = use ? ((r.mate << 28) | r.ref) : (0xc0000000u | lane);
             if (pass == 0) nv_run += static_cast<uint32_t>(__popcll(f_ballot(in_run && r.mapped)));
@@ -334,10 +318,9 @@ __device__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t 
                 }
             }
             for (uint32_t eb = pos; eb < cb; eb += 64u) {  // every earlier chunk, all rotations
-                uint32_t mt, rf;
-                bool mp;
-                acc.mate_ref(eb + lane, mt, rf, mp);
-                uint32_t Te = mp ? ((mt << 28) | rf) : 0xe0000000u;
+                bool b = false;
+                const FrontRec e = acc.rec(eb + lane, b);
+                uint32_t Te = e.mapped ? ((e.mate << 28) | e.ref) : 0xe0000000u;
                 for (uint32_t d = 0; d < 64u; ++d) {
                     differ = min(differ, Te ^ T);
                     Te = f_ror1(Te);
@@ -382,140 +365,144 @@ __device__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t 
     return end;
 }
 
-}  // namespace
-
-// ---------------------------------------------------------------------------------------------------------
-// k_front: every wave walks TWO slots at a time (two independent streams): a stream's next window depends on the keys
-// of the current one, so one stream per wave has one window of loads in flight and the kernel would be bound by the
-// latency of that chain; with two the loads of one stream are in flight under the arithmetic of the other.
-// ---------------------------------------------------------------------------------------------------------
-namespace {
-
-struct Stream {       // all wave-uniform
-    uint32_t slot;    // slot being walked (>= nslots: the stream has run out of work)
-    uint32_t pos, end;
-    SlotOut so;
-    bool anchored;    // pos is known to be a run start
-    bool have_start;
-};
-
-template <typename Acc>
-struct Window {       // what a stream has in flight: the 64 records at pos and the key in front of them
-    typename Acc::Rec rec;
-    uint32_t plo, phi;
-};
-
-__device__ __forceinline__ void stream_begin(Stream& st, uint32_t slot, uint32_t N) {
-    st.slot = slot;
-    st.pos = slot * kSlotRecs;
-    st.end = min(st.pos + kSlotRecs, N);
-    st.so = SlotOut{st.pos, 0u, 0u, 0u};
-    st.anchored = false;
-    st.have_start = false;
+// 64 bits of the slot's run-start bitmap from bit `off` on (lane j of bm_lo / bm_hi holds block j)
+__device__ __forceinline__ uint64_t bitmap_window(uint32_t bm_lo, uint32_t bm_hi, uint32_t off) {
+    const uint32_t q = off >> 6, sh = off & 63u;
+    const uint64_t a = (static_cast<uint64_t>(__builtin_amdgcn_readlane(bm_hi, q)) << 32) | __builtin_amdgcn_readlane(bm_lo, q);
+    const uint64_t b = (static_cast<uint64_t>(__builtin_amdgcn_readlane(bm_hi, q + 1u)) << 32) |
+                       __builtin_amdgcn_readlane(bm_lo, q + 1u);
+    return sh ? ((a >> sh) | (b << (64u - sh))) : a;
 }
 
-template <typename Acc>
-__device__ __forceinline__ void stream_load(const Acc& acc, const Stream& st, uint32_t N, uint32_t lane, Window<Acc>& w,
-                                            bool& bad) {
-    w.rec = acc.load(min(st.pos + lane, N - 1u), bad);
-    w.plo = w.phi = 0u;
-    if (!st.anchored && st.pos > 0u) acc.key_at(st.pos - 1u, w.plo, w.phi);  // (one address for the whole wave)
-}
+struct Cut {   // a window: records [off, off + X) of the slot; X = 0: a run of 64 records or more starts at off
+    uint32_t off, X;
+    uint64_t RS;  // run starts of the 64 records from off on
+};
 
-// one window of one stream; advances st.pos
-template <typename Acc>
-__device__ __forceinline__ void stream_step(const Acc& acc, Stream& st, const Window<Acc>& w, uint32_t N, uint32_t lane,
-                                            uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
-    const typename Acc::Rec& rec = w.rec;
-    const uint32_t pos = st.pos;
-    const uint32_t n_live = min(64u, N - pos);
-    const uint64_t LIVE = f_below(n_live);
-    // run starts: the key differs from the lane before; lane 0 looks at the record in front of the window
-    const uint32_t qlo = f_shr1(rec.klo, w.plo), qhi = f_shr1(rec.khi, w.phi);
-    uint64_t RS = f_ballot(((rec.klo ^ qlo) | (rec.khi ^ qhi)) != 0u) & LIVE;
-    if (st.anchored || pos == 0u) RS |= 1ull;
-    if (RS == 0ull) {  // the whole window continues a run of the slot before
-        st.pos = pos + 64u;
-        return;
-    }
-    const uint32_t lo = static_cast<uint32_t>(__builtin_ctzll(RS));
-    if (pos + lo >= st.end) {  // the first run start at or behind pos belongs to the next slot
-        st.pos = st.end;
-        return;
-    }
+// the window starting at the run start `off` (< kSlotRecs) of the slot that begins at record B
+__device__ __forceinline__ Cut cut_at(uint32_t bm_lo, uint32_t bm_hi, uint32_t B, uint32_t off, uint32_t N) {
+    Cut c;
+    c.off = off;
+    c.RS = bitmap_window(bm_lo, bm_hi, off);
+    const uint32_t pos = B + off;
     // complete runs end at the last run start of the window -- or at the end of the stream
-    const bool at_end = pos + 64u >= N;
-    uint32_t X = at_end ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(RS));
-    if (st.end - pos < 64u) {  // runs starting at or behind the slot's end are the next slot's
-        const uint64_t beyond = RS & ~f_below(st.end - pos);
+    uint32_t X = pos + 64u >= N ? N - pos : 63u - static_cast<uint32_t>(__builtin_clzll(c.RS | 1ull));
+    if (kSlotRecs - off < 64u) {  // runs starting at or behind the slot's end are the next slot's
+        const uint64_t beyond = c.RS & ~f_below(kSlotRecs - off);
         if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
     }
-    if (X <= lo) {  // the run starting at lane `lo` does not end inside this window
-        if (lo > 0u) {  // look again from its start
-            st.pos = pos + lo;
-            st.anchored = true;
-            return;
-        }
-        if (!st.have_start) {
-            st.so.base = pos;
-            st.have_start = true;
-        }
-        st.pos = long_run(acc, pos, N, lane, st.so, tgt_ref, tgt_gbin, bad);
-        st.anchored = true;
-        return;
-    }
-    if (!st.have_start) {
-        st.so.base = pos + lo;
-        st.have_start = true;
-    }
-    const uint64_t PR = f_below(X) & ~f_below(lo);
-    const uint32_t mprev = f_shr1(rec.mate, 0u);
-    const uint64_t MC = f_ballot(rec.mate != mprev);
-    const uint64_t V = f_ballot(rec.mapped) & PR;
-    const uint64_t dec = f_ballot(rec.mate < mprev) & ~RS & PR;
-    if (dec == 0ull)
-        window_fast(acc, rec, lane, PR, (RS | MC) & PR, V, X, st.so, tgt_ref, tgt_gbin);
-    else
-        window_general(acc, rec, lane, PR, RS, V, st.so, tgt_ref, tgt_gbin);
-    st.pos = pos + X;
-    st.anchored = true;
+    c.X = X;
+    return c;
 }
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// k_front
+// ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
 __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
-                                                       uint4* __restrict__ slots) {
+                                                       uint4* __restrict__ slots, uint2* __restrict__ wcut) {
     const uint32_t N = acc.count(counters);
     const uint32_t lane = f_lane();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFrontBlock / 64);
-    const uint32_t my_wave = blockIdx.x * (kFrontBlock / 64) + wave;
     uint32_t tot_f = 0, tot_h = 0, tot_v = 0;
     bool bad = false;
-    Stream st[2];
-    stream_begin(st[0], my_wave, N);
-    stream_begin(st[1], my_wave + n_waves, N);
-    uint32_t next_slot = my_wave + 2u * n_waves;
-    while (st[0].slot < nslots || st[1].slot < nslots) {
-        Window<Acc> w[2];
+    for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
+        const uint32_t B = slot * kSlotRecs;
+        uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
+        SlotOut so{B, 0u, 0u, 0u};
+        uint32_t nw = 0;
+        if (B < N) {
+            // ---- 1. run starts of records [B, B + 64 * kSlotBlocks): lane j of bm_lo / bm_hi gets block j's ballot
+            uint32_t bm_lo = 0, bm_hi = 0;
+            {
+                uint32_t klo[kSlotBlocks], khi[kSlotBlocks];
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (st[k].slot < nslots && st[k].pos < st[k].end) stream_load(acc, st[k], N, lane, w[k], bad);
+                for (uint32_t j = 0; j < kSlotBlocks; ++j) acc.key_at(min(B + 64u * j + lane, N - 1u), klo[j], khi[j]);
+                uint32_t plo = 0, phi = 0;  // the key in front of the block (one address for the whole wave)
+                if (B > 0u) acc.key_at(B - 1u, plo, phi);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (st[k].slot >= nslots) continue;
-            if (st[k].pos < st[k].end) stream_step(acc, st[k], w[k], N, lane, tgt_ref, tgt_gbin, bad);
-            if (st[k].pos >= st[k].end) {  // the slot is done (or was empty): publish it, take the next one
-                if (lane == 0u) slots[st[k].slot] = make_uint4(st[k].so.base, st[k].so.nf, st[k].so.nh, st[k].so.nv);
-                tot_f += st[k].so.nf;
-                tot_h += st[k].so.nh;
-                tot_v += st[k].so.nv;
-                stream_begin(st[k], next_slot, N);
-                next_slot += n_waves;
+                for (uint32_t j = 0; j < kSlotBlocks; ++j) {
+                    const uint32_t qlo = f_shr1(klo[j], plo), qhi = f_shr1(khi[j], phi);
+                    uint64_t rs = f_ballot(((klo[j] ^ qlo) | (khi[j] ^ qhi)) != 0u);
+                    if (B == 0u && j == 0u) rs |= 1ull;  // the first record of the stream starts a run
+                    const uint32_t first = B + 64u * j;
+                    rs &= first < N ? f_below(min(64u, N - first)) : 0ull;  // no records behind the stream's end
+                    bm_lo = lane == j ? static_cast<uint32_t>(rs) : bm_lo;
+                    bm_hi = lane == j ? static_cast<uint32_t>(rs >> 32) : bm_hi;
+                    plo = __builtin_amdgcn_readlane(klo[j], 63);
+                    phi = __builtin_amdgcn_readlane(khi[j], 63);
+                }
+            }
+            // ---- 2. the slot's first run start
+            uint32_t off = kSlotRecs;
+            {
+                const uint64_t any = f_ballot(lane < kSlotRecs / 64 && (bm_lo | bm_hi) != 0u);
+                if (any) {
+                    const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(any));
+                    const uint64_t w = (static_cast<uint64_t>(__builtin_amdgcn_readlane(bm_hi, q)) << 32) |
+                                       __builtin_amdgcn_readlane(bm_lo, q);
+                    off = 64u * q + static_cast<uint32_t>(__builtin_ctzll(w));
+                }
+            }
+            so.base = B + min(off, kSlotRecs);
+            // ---- 3. windows: the loads of the next one are in flight while the current one is classified
+            bool have = off < kSlotRecs;
+            Cut cur{};
+            FrontRec rec{};
+            if (have) {
+                cur = cut_at(bm_lo, bm_hi, B, off, N);
+                if (cur.X) rec = acc.rec(min(B + off + lane, N - 1u), bad);
+            }
+            while (have) {
+                if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
+                    if (lane == 0u) cuts[nw] = make_uint2(so.nf, so.nh);  // records; beyond that the list's last window
+                    ++nw;                                                  // simply takes the rest of the slot)
+                }
+                uint32_t noff;
+                bool nhave = false;
+                Cut nxt{};
+                FrontRec nrec{};
+                if (cur.X) {
+                    noff = cur.off + cur.X;
+                    nhave = noff < kSlotRecs && B + noff < N;
+                    if (nhave) {
+                        nxt = cut_at(bm_lo, bm_hi, B, noff, N);
+                        if (nxt.X) nrec = acc.rec(min(B + noff + lane, N - 1u), bad);
+                    }
+                    const uint64_t PR = f_below(cur.X);
+                    const uint64_t RS = cur.RS & PR;
+                    const uint32_t mprev = f_shr1(rec.mate, 0u);
+                    const uint64_t V = f_ballot(rec.mapped) & PR;
+                    const uint64_t dec = f_ballot(rec.mate < mprev) & ~RS & PR;
+                    if (dec == 0ull)
+                        window_fast(acc, rec, lane, (RS | f_ballot(rec.mate != mprev)) & PR, V, cur.X, so, tgt_ref, tgt_gbin);
+                    else
+                        window_general(acc, rec, lane, RS, V, cur.X, so, tgt_ref, tgt_gbin);
+                } else {
+                    noff = long_run(acc, B + cur.off, N, lane, so, tgt_ref, tgt_gbin, bad) - B;
+                    nhave = noff < kSlotRecs && B + noff < N;
+                    if (nhave) {
+                        nxt = cut_at(bm_lo, bm_hi, B, noff, N);
+                        if (nxt.X) nrec = acc.rec(min(B + noff + lane, N - 1u), bad);
+                    }
+                }
+                have = nhave;
+                cur = nxt;
+                rec = nrec;
             }
         }
+        if (lane == 0u) {
+            slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
+            cuts[nw] = make_uint2(so.nf, so.nh);
+            cuts[kSlotWindows - 1u] = make_uint2(nw, 0u);
+        }
+        tot_f += so.nf;
+        tot_h += so.nh;
+        tot_v += so.nv;
     }
     if (lane == 0u) {
         if (tot_h) atomicAdd(&counters[CNT_M], tot_h);
@@ -531,14 +518,14 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
 uint32_t front_slots(uint32_t n_records) { return (n_records + kSlotRecs - 1u) / kSlotRecs; }
 
 static uint32_t front_grid(uint32_t nslots) {
-    // two slots per wave and trip; at most 8 workgroups of 256 threads per CU (256 CUs)
-    const uint32_t waves = (nslots + 1u) / 2u;
-    const uint32_t blocks = (waves + (kFrontBlock / 64) - 1u) / (kFrontBlock / 64);
+    // one slot per wave and trip; at most 8 workgroups of 256 threads per CU (256 CUs)
+    const uint32_t blocks = (nslots + (kFrontBlock / 64) - 1u) / (kFrontBlock / 64);
     return std::max(1u, std::min(blocks, 2048u));
 }
 
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
-                      uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots) {
+                      uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
+                      uint2* wcut) {
     const uint32_t ns = front_slots(in.n);
     if (!ns) return;
     FrontRaw a;
@@ -553,16 +540,16 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.bin_width = bin_width;
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
     hipLaunchKernelGGL(k_front<FrontRaw>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref, tgt_gbin,
-                       slots);
+                       slots, wcut);
 }
 
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots) {
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut) {
     const uint32_t ns = front_slots(n_upper);
     if (!ns) return;
     FrontSorted a{ident, cref, cgbin};
     hipLaunchKernelGGL(k_front<FrontSorted>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                       tgt_gbin, slots);
+                       tgt_gbin, slots, wcut);
 }
 
 }  // namespace slimm

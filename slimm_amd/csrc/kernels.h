@@ -86,14 +86,20 @@ uint32_t num_tiles(uint32_t n);
 // A slot = kSlotRecs consecutive records; its targets (the runs that START in it) lie compacted at
 // [slot.x, slot.x + slot.y) of tgt_ref / tgt_gbin; slot.z = reads (targets with bit 31 of tgt_ref), slot.w = mapped records
 constexpr uint32_t kSlotRecs = 1024;
+// The front end works through a slot in windows of whole qName runs (<= 64 records, or one run of 64 records or more);
+// wcut[s * kSlotWindows + i] = {targets, reads} of slot s in front of its window i, the entry behind the last window
+// holds the slot's totals and wcut[s * kSlotWindows + kSlotWindows - 1].x the number of windows.  The targets of a
+// window are whole reads: k_filter takes the windows up independently of each other.
+constexpr uint32_t kSlotWindows = 2 * (kSlotRecs / 64) + 6;
 constexpr int kFrontBlock = 256;
 constexpr uint32_t kMaxRefs = (1u << 26) - 1u;      // reference ids fit 26 bits (tagged words of the duplicate test)
 constexpr uint32_t kMaxBins = 0x7ffffff0u;          // global bin indices fit 31 bits (bit 31 of tgt_gbin: unique read)
 uint32_t front_slots(uint32_t n_records);
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
-                      uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots);
+                      uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
+                      uint2* wcut);
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots);
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut);
 
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
@@ -116,6 +122,7 @@ struct FilterArgs {
     const uint32_t* tgt_ref = nullptr;
     const uint32_t* tgt_gbin = nullptr;
     const uint4* slots = nullptr;
+    const uint2* wcut = nullptr;
     uint32_t nslots = 0;
     const void* rows16 = nullptr;
     const uint32_t* level_taxon = nullptr;

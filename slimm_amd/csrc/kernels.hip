@@ -502,12 +502,33 @@ struct ReadAcc {
     uint32_t first_g;   // bin word of the first of them
     uint32_t a0[8];     // its row
     uint32_t eq;        // bit lv: every valid row so far agrees with a0 at level lv
-    uint32_t max_ref, max_f7;  // largest valid reference and its level-7 field
+    uint32_t max_ref, max_f7;  // largest valid reference and its level-7 field (Q4)
 };
 
+__device__ __forceinline__ void read_clear(ReadAcc& acc) {
+    acc.nv = 0;
+    acc.first_g = 0;
+    acc.eq = 0xffu;
+    acc.max_ref = 0;
+    acc.max_f7 = 0;
+}
+
+// the largest reference among the lanes `Vs` and its level-7 field (needed only when no level agrees, Q4)
+__device__ __forceinline__ void read_max(ReadAcc& acc, uint64_t Vs, uint32_t ref, uint32_t f7) {
+    uint64_t rest = Vs;
+    while (rest) {
+        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(rest));
+        rest &= rest - 1ull;
+        const uint32_t r = __builtin_amdgcn_readlane(ref, l);
+        if (r >= acc.max_ref) {
+            acc.max_ref = r;
+            acc.max_f7 = __builtin_amdgcn_readlane(f7, l);
+        }
+    }
+}
+
 // adds the valid lanes `Vs` (of one read) of the wave's current 64 targets
-template <typename Rows>
-__device__ __forceinline__ void read_add(ReadAcc& acc, uint64_t Vs, uint32_t ref, uint32_t g, const uint32_t (&f)[8]) {
+__device__ __forceinline__ void read_add(ReadAcc& acc, uint64_t Vs, uint32_t g, const uint32_t (&f)[8]) {
     if (!Vs) return;
     if (acc.nv == 0u) {
         const uint32_t fl = static_cast<uint32_t>(__builtin_ctzll(Vs));
@@ -519,17 +540,6 @@ __device__ __forceinline__ void read_add(ReadAcc& acc, uint64_t Vs, uint32_t ref
 #pragma unroll
     for (int l = 0; l < 8; ++l)
         if (k_ballot(f[l] != acc.a0[l]) & Vs) acc.eq &= ~(1u << l);
-    // the largest reference among the lanes (needed only when no level agrees, Q4; cheap enough to keep)
-    uint64_t rest = Vs;
-    while (rest) {
-        const uint32_t l = static_cast<uint32_t>(__builtin_ctzll(rest));
-        rest &= rest - 1ull;
-        const uint32_t r = __builtin_amdgcn_readlane(ref, l);
-        if (r >= acc.max_ref) {
-            acc.max_ref = r;
-            acc.max_f7 = __builtin_amdgcn_readlane(f[7], l);
-        }
-    }
 }
 
 // LCA of a read with several valid targets; *lv = the agreeing level (8: none, Q4)
@@ -552,116 +562,175 @@ __device__ __forceinline__ void read_children(const FilterOut& out, bool mine, u
         pair_insert((static_cast<uint64_t>(taxon) << 32) | ref, out.pair_tab, out.pair_list, out.pair_mask, out.counters);
 }
 
+// One window of up to 64 targets that are whole reads: lanes [0, X); w / g = the target words, row = the lineage rows
+// of the lanes' references, sel_base = index of the window's first read among the selectors.
+template <typename Rows>
+__device__ __forceinline__ void filter_window(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
+                                              uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
+    const uint64_t PR = k_below(X);
+    const uint64_t H = k_ballot((w >> 31) != 0u) & PR;  // (bit 0 is set: a window starts at a read's first target)
+    const uint32_t ref = w & 0x7fffffffu;
+    const uint64_t VB = k_ballot(Rows::valid(row)) & PR;
+    const uint64_t stops = (H >> 1) | (1ull << (X - 1u));
+    const uint64_t FV = k_first_after(H, VB, stops);              // first valid target of every read
+    const uint64_t SV = k_first_after(H, VB & ~FV, stops);        // second one, where there is one
+    const uint64_t HF = k_head_of(FV, H);                         // reads with a valid target
+    const uint64_t HM = k_head_of(SV, H);                         // reads with several
+    const uint64_t single = FV & ~k_first_after(HM, FV, stops);   // the one valid target of the reads with one
+    const uint64_t empty = H & ~HF;                               // reads that lost every target
+    // index of this lane's read among the selectors
+    const uint32_t ridx = sel_base + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
+    if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
+    if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
+    if (HM) {
+        uint32_t f[8];
+        Rows::fields(row, f);
+        uint64_t todo = HM;
+        while (todo) {
+            const uint32_t h = static_cast<uint32_t>(__builtin_ctzll(todo));
+            todo &= todo - 1ull;
+            const uint64_t later = H & ~k_below(h + 1u);
+            const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
+            const uint64_t Vs = VB & k_below(nxt) & ~k_below(h);
+            ReadAcc acc;
+            read_clear(acc);
+            read_add(acc, Vs, g, f);
+            if (!acc.eq) read_max(acc, Vs, ref, f[7]);
+            uint32_t lv;
+            const uint32_t taxon = read_taxon(rows, acc, &lv);
+            read_children(out, k_bit(Vs), ref, lv, taxon);
+            if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(h)))] = out.taxon_base + taxon;
+        }
+    }
+}
+
+// The targets [pos, endp) -- whole reads, any number of them, reads of 64 targets and more among them -- one window
+// after the other (what a run of 64 records or more leaves behind, front.hip).
+template <typename Rows>
+__device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& out, const uint32_t* __restrict__ tgt_ref,
+                                         const uint32_t* __restrict__ tgt_gbin, uint32_t lane, uint32_t pos, uint32_t endp,
+                                         uint32_t sel_base) {
+    while (pos < endp) {
+        const uint32_t n_live = min(64u, endp - pos);
+        const bool live = lane < n_live;
+        const uint32_t w = live ? tgt_ref[pos + lane] : 0u;
+        const uint32_t g = live ? tgt_gbin[pos + lane] : 0u;
+        const uint64_t HB = k_ballot((w >> 31) != 0u) & k_below(n_live);
+        const uint32_t X = pos + 64u >= endp ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(HB | 1ull));
+        if (X != 0u) {
+            const typename Rows::Row row = rows.load(lane < X ? (w & 0x7fffffffu) : 0u);
+            filter_window(rows, out, lane, X, w, g, row, sel_base);
+            sel_base += static_cast<uint32_t>(__popcll(HB & k_below(X)));
+            pos += X;
+            continue;
+        }
+        // ---- a read with 64 targets or more: walk it in chunks, then once more for its children
+        ReadAcc acc;
+        read_clear(acc);
+        uint32_t e = pos;  // end of the read
+        while (true) {
+            const bool in = e + lane < endp;
+            const uint32_t ww = in ? tgt_ref[e + lane] : 0x80000000u;
+            const uint32_t gg = in ? tgt_gbin[e + lane] : 0u;
+            uint64_t heads = k_ballot((ww >> 31) != 0u);
+            if (e == pos) heads &= ~1ull;
+            const uint32_t n_in = heads ? static_cast<uint32_t>(__builtin_ctzll(heads)) : 64u;
+            const uint32_t rr = ww & 0x7fffffffu;
+            const typename Rows::Row row = rows.load(lane < n_in ? rr : 0u);
+            uint32_t f[8];
+            Rows::fields(row, f);
+            const uint64_t Vs = k_ballot(Rows::valid(row)) & k_below(n_in);
+            read_add(acc, Vs, gg, f);
+            read_max(acc, Vs, rr, f[7]);
+            e += n_in;
+            if (n_in < 64u) break;
+        }
+        uint32_t sel = 0xffffffffu;
+        if (acc.nv == 1u) {
+            sel = acc.first_g & 0x7fffffffu;
+        } else if (acc.nv > 1u) {
+            uint32_t lv;
+            const uint32_t taxon = read_taxon(rows, acc, &lv);
+            sel = out.taxon_base + taxon;
+            for (uint32_t c = pos; c < e; c += 64u) {
+                const bool in = c + lane < e;
+                const uint32_t rr = in ? (tgt_ref[c + lane] & 0x7fffffffu) : 0u;
+                const typename Rows::Row row = rows.load(rr);
+                read_children(out, in && Rows::valid(row), rr, lv, taxon);
+            }
+        }
+        if (lane == 0u) out.sel[sel_base] = sel;
+        sel_base += 1u;
+        pos = e;
+    }
+}
+
 }  // namespace
 
 constexpr int kFilterBlock = 256;
 
+// A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
+// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other and
+// three are in flight per wave: the target words of window i + 2 are being loaded and the lineage rows of window i + 1
+// gathered while window i is worked on.
 template <typename Rows>
 __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,
-                                                         const uint4* __restrict__ slots, uint32_t nslots, const Rows rows,
-                                                         const FilterOut out) {
+                                                         const uint4* __restrict__ slots, const uint2* __restrict__ wcut,
+                                                         uint32_t nslots, const Rows rows, const FilterOut out) {
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFilterBlock / 64);
     for (uint32_t slot = blockIdx.x * (kFilterBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint4 d = slots[slot];
-        uint32_t pos = d.x;
-        const uint32_t endp = d.x + d.y;
-        uint32_t reads_done = 0;  // selectors of this slot written so far
-        while (pos < endp) {
-            const uint32_t n_live = min(64u, endp - pos);
-            const uint64_t LIVE = k_below(n_live);
-            const bool live = lane < n_live;
-            const uint32_t w = live ? tgt_ref[pos + lane] : 0u;
-            const uint32_t g = live ? tgt_gbin[pos + lane] : 0u;
-            const uint64_t HB = k_ballot((w >> 31) != 0u) & LIVE;  // (bit 0 is set: a window starts at a read's first target)
-            const bool at_end = pos + 64u >= endp;
-            const uint32_t X = at_end ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(HB));
-            const uint32_t ref = w & 0x7fffffffu;
-            if (X == 0u) {
-                // ---- a read with 64 targets or more: walk it in chunks, then once more for its children
-                ReadAcc acc;
-                acc.nv = 0;
-                acc.eq = 0xffu;
-                acc.max_ref = 0;
-                acc.max_f7 = 0;
-                acc.first_g = 0;
-                uint32_t e = pos;  // end of the read
-                while (true) {
-                    const bool lv_ = e + lane < endp;
-                    const uint32_t ww = lv_ ? tgt_ref[e + lane] : 0x80000000u;
-                    const uint32_t gg = lv_ ? tgt_gbin[e + lane] : 0u;
-                    uint64_t heads = k_ballot((ww >> 31) != 0u);
-                    if (e == pos) heads &= ~1ull;
-                    const uint32_t n_in = heads ? static_cast<uint32_t>(__builtin_ctzll(heads)) : 64u;
-                    const typename Rows::Row row = rows.load(lane < n_in ? (ww & 0x7fffffffu) : 0u);
-                    uint32_t f[8];
-                    Rows::fields(row, f);
-                    read_add<Rows>(acc, k_ballot(Rows::valid(row)) & k_below(n_in), ww & 0x7fffffffu, gg, f);
-                    e += n_in;
-                    if (n_in < 64u) break;
+        if (d.y == 0u) continue;
+        const uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
+        const uint32_t nw = cuts[kSlotWindows - 1u].x;
+        const uint2 ce = lane <= nw ? cuts[lane] : make_uint2(0u, 0u);  // lane i: {targets, reads} in front of window i
+        // stage A (target words loaded), stage B (+ rows gathered) of the two windows behind the one being loaded
+        uint32_t a_w = 0, a_g = 0, a_cnt = 0, a_sel = 0;
+        uint32_t b_w = 0, b_g = 0, b_cnt = 0, b_sel = 0;
+        typename Rows::Row b_row{};
+        bool spans = false;  // some window holds more than 64 targets
+        for (uint32_t i = 0; i < nw + 2u; ++i) {
+            // window i: load its target words
+            uint32_t n_w = 0, n_g = 0, n_cnt = 0, n_sel = 0;
+            if (i < nw) {
+                const uint32_t t0 = __builtin_amdgcn_readlane(ce.x, i), t1 = __builtin_amdgcn_readlane(ce.x, i + 1u);
+                n_cnt = t1 - t0;
+                n_sel = d.x + __builtin_amdgcn_readlane(ce.y, i);
+                if (n_cnt > 64u) {
+                    spans = true;
+                    n_cnt = 0;
                 }
-                uint32_t sel = 0xffffffffu;
-                if (acc.nv == 1u) {
-                    sel = acc.first_g & 0x7fffffffu;
-                } else if (acc.nv > 1u) {
-                    uint32_t lv;
-                    const uint32_t taxon = read_taxon(rows, acc, &lv);
-                    sel = out.taxon_base + taxon;
-                    for (uint32_t c = pos; c < e; c += 64u) {
-                        const bool in = c + lane < e;
-                        const uint32_t rr = in ? (tgt_ref[c + lane] & 0x7fffffffu) : 0u;
-                        const typename Rows::Row row = rows.load(rr);
-                        read_children(out, in && Rows::valid(row), rr, lv, taxon);
-                    }
-                }
-                if (lane == 0u) out.sel[d.x + reads_done] = sel;
-                reads_done += 1u;
-                pos = e;
-                continue;
-            }
-            const uint64_t PR = k_below(X);
-            const uint64_t H = HB & PR;
-            const typename Rows::Row row = rows.load(k_bit(PR) ? ref : 0u);
-            const uint64_t VB = k_ballot(Rows::valid(row)) & PR;
-            const uint64_t stops = (H >> 1) | (1ull << (X - 1u));
-            const uint64_t FV = k_first_after(H, VB, stops);              // first valid target of every read
-            const uint64_t SV = k_first_after(H, VB & ~FV, stops);        // second one, where there is one
-            const uint64_t HF = k_head_of(FV, H);                         // reads with a valid target
-            const uint64_t HM = k_head_of(SV, H);                         // reads with several
-            const uint64_t single = FV & ~k_first_after(HM, FV, stops);   // the one valid target of the reads with one
-            const uint64_t empty = H & ~HF;                               // reads that lost every target
-            // index of this lane's read among the slot's reads
-            const uint32_t ridx = d.x + reads_done + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
-            if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
-            if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
-            if (HM) {
-                uint32_t f[8];
-                Rows::fields(row, f);
-                uint64_t todo = HM;
-                while (todo) {
-                    const uint32_t h = static_cast<uint32_t>(__builtin_ctzll(todo));
-                    todo &= todo - 1ull;
-                    const uint64_t later = H & ~k_below(h + 1u);
-                    const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
-                    const uint64_t Vs = VB & k_below(nxt) & ~k_below(h);
-                    ReadAcc acc;
-                    acc.nv = 0;
-                    acc.eq = 0xffu;
-                    acc.max_ref = 0;
-                    acc.max_f7 = 0;
-                    acc.first_g = 0;
-                    read_add<Rows>(acc, Vs, ref, g, f);
-                    uint32_t lv;
-                    const uint32_t taxon = read_taxon(rows, acc, &lv);
-                    read_children(out, k_bit(Vs), ref, lv, taxon);
-                    if (lane == 0u)
-                        out.sel[d.x + reads_done + static_cast<uint32_t>(__popcll(H & k_below(h)))] = out.taxon_base + taxon;
+                if (n_cnt) {
+                    const uint32_t t = d.x + t0 + min(lane, n_cnt - 1u);
+                    n_w = tgt_ref[t];
+                    n_g = tgt_gbin[t];
                 }
             }
-            reads_done += static_cast<uint32_t>(__popcll(H));
-            pos += X;
+            // window i - 1: gather its rows
+            typename Rows::Row n_row{};
+            if (a_cnt) n_row = rows.load(lane < a_cnt ? (a_w & 0x7fffffffu) : 0u);
+            // window i - 2: work
+            if (b_cnt) filter_window(rows, out, lane, b_cnt, b_w, b_g, b_row, b_sel);
+            b_w = a_w;
+            b_g = a_g;
+            b_cnt = a_cnt;
+            b_sel = a_sel;
+            b_row = n_row;
+            a_w = n_w;
+            a_g = n_g;
+            a_cnt = n_cnt;
+            a_sel = n_sel;
+        }
+        if (spans) {
+            for (uint32_t i = 0; i < nw; ++i) {
+                const uint32_t t0 = __builtin_amdgcn_readlane(ce.x, i), t1 = __builtin_amdgcn_readlane(ce.x, i + 1u);
+                if (t1 - t0 > 64u)
+                    filter_span(rows, out, tgt_ref, tgt_gbin, lane, d.x + t0, d.x + t1,
+                                d.x + __builtin_amdgcn_readlane(ce.y, i));
+            }
         }
     }
 }
@@ -827,13 +896,13 @@ void launch_filter(hipStream_t st, const FilterArgs& a) {
         r.level_taxon = a.level_taxon;
         for (int i = 0; i < 8; ++i) r.lo.off[i] = a.level_off[i];
         hipLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
-                           a.slots, a.nslots, r, out);
+                           a.slots, a.wcut, a.nslots, r, out);
     } else {
         Rows32 r;
         r.lin4 = reinterpret_cast<const uint4*>(a.lin_dense);
         r.valid_of = a.valid;
         hipLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
-                           a.slots, a.nslots, r, out);
+                           a.slots, a.wcut, a.nslots, r, out);
     }
 }
 

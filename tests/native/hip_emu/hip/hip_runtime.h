@@ -25,6 +25,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __HIP_MEMORY_SCOPE_AGENT 0
@@ -165,6 +166,10 @@ static inline uint64_t __builtin_bitreverse64(uint64_t v) {
 static inline uint32_t __builtin_amdgcn_readlane(uint32_t v, uint32_t lane) {
     const uint64_t* a = ::hipemu::wave_exchange(v);
     return static_cast<uint32_t>(a[lane & 63u]);
+}
+// v_writelane: lane `lane` of the result is `value` (wave-uniform), the other lanes keep `old`; no exchange
+static inline uint32_t __builtin_amdgcn_writelane(uint32_t value, uint32_t lane, uint32_t old) {
+    return ::hipemu::g_lane == (lane & 63u) ? value : old;
 }
 static inline uint32_t __builtin_amdgcn_readfirstlane(uint32_t v) {
     uint64_t live = 0;

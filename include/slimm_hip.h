@@ -238,6 +238,14 @@ int slimm_get_ref_columns(slimm_ctx* ctx, slimm_ref_columns* out);
  * which: 0 = cov, 1 = uniq_cov, 2 = uniq_cov2 (reference_contig.hpp:110-112). */
 int slimm_get_bins(slimm_ctx* ctx, int which, uint32_t* out);
 
+/* The reads' target lists after phase A (the reference's `reads[*].targets`, src/read_stat.hpp:46-59, 61-74): one entry
+ * per distinct (read, reference) pair, the targets of a read contiguous, reads in the order the device emitted them.
+ *   ref[i]   reference id | bit 31: first target of its read
+ *   gbin[i]  bin of the pair's first record, counted over all references (bins of the references before it included,
+ *            every reference padded to a multiple of 4 bins) | bit 31: the read has this one target only
+ * Call with ref = gbin = NULL to get the number of entries in *n; otherwise cap entries are available and *n are written. */
+int slimm_get_read_targets(slimm_ctx* ctx, uint32_t* ref, uint32_t* gbin, uint64_t cap, uint64_t* n);
+
 /* taxon_id__read_count (src/slimm.hpp:126). stage 0: direct LCA hits only (:536-557); 1: final (:560-610). */
 int slimm_taxon_count_size(slimm_ctx* ctx, int stage, uint32_t* n);
 int slimm_get_taxon_counts(slimm_ctx* ctx, int stage, uint32_t* taxid, uint32_t* count);

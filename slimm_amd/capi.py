@@ -97,6 +97,7 @@ SYMBOLS = [
     ("slimm_get_stats", C.c_int, [_P, C.POINTER(Stats)]),
     ("slimm_get_ref_columns", C.c_int, [_P, C.POINTER(RefColumns)]),
     ("slimm_get_bins", C.c_int, [_P, C.c_int, _P]),
+    ("slimm_get_read_targets", C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("slimm_taxon_count_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint32)]),
     ("slimm_get_taxon_counts", C.c_int, [_P, C.c_int, _P, _P]),
     ("slimm_children_pairs_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64)]),

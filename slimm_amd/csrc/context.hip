@@ -1310,6 +1310,31 @@ int slimm_get_bins(slimm_ctx* c, int which, uint32_t* out) {
     return SLIMM_OK;
 }
 
+int slimm_get_read_targets(slimm_ctx* c, uint32_t* ref, uint32_t* gbin, uint64_t cap, uint64_t* n) {
+    if (!c || !n) return SLIMM_E_INVALID;
+    if (c->device < 0 || !c->analyzed) return fail(c, SLIMM_E_INVALID, "no targets on this context (call slimm_analyze_alignments)");
+    (void)hipSetDevice(c->device);
+    const uint32_t ns = front_slots(c->rec.n);
+    std::vector<uint4> sl(ns);
+    if (ns) HIP_TRY(c, hipMemcpyAsync(sl.data(), c->slots.p, ns * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint64_t total = 0;
+    for (const uint4& d : sl) total += d.y;
+    *n = total;
+    if (!ref && !gbin) return SLIMM_OK;
+    if (cap < total) return fail(c, SLIMM_E_INVALID, "slimm_get_read_targets: %llu entries, room for %llu",
+                                 static_cast<unsigned long long>(total), static_cast<unsigned long long>(cap));
+    uint64_t o = 0;
+    for (const uint4& d : sl) {  // (a slot's targets are contiguous; runs of slots are too when nothing was dropped)
+        if (!d.y) continue;
+        if (ref) HIP_TRY(c, hipMemcpyAsync(ref + o, c->tgt_ref.p + d.x, d.y * 4ull, hipMemcpyDeviceToHost, c->stream));
+        if (gbin) HIP_TRY(c, hipMemcpyAsync(gbin + o, c->tgt_gbin.p + d.x, d.y * 4ull, hipMemcpyDeviceToHost, c->stream));
+        o += d.y;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SLIMM_OK;
+}
+
 int slimm_taxon_count_size(slimm_ctx* c, int stage, uint32_t* n) {
     if (!c || !n) return SLIMM_E_INVALID;
     if (!c->counted) return fail(c, SLIMM_E_INVALID, "call slimm_get_reads_lca_count first");

@@ -76,6 +76,13 @@ __device__ __forceinline__ uint32_t f_shr1(uint32_t v, uint32_t lane0) {
 __device__ __forceinline__ uint32_t f_ror1(uint32_t v) {  // lane i gets lane i - 1, lane 0 gets lane 63
     return __builtin_amdgcn_update_dpp(v, v, 0x13c, 0xf, 0xf, false);
 }
+// the 64-bit value lane `l` holds in (lo, hi).  (__builtin_amdgcn_readlane returns a signed int: unless the low half
+// goes through uint32_t, its bit 31 smears over the high half.)
+__device__ __forceinline__ uint64_t f_read64(uint32_t lo, uint32_t hi, uint32_t l) {
+    const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readlane(lo, l));
+    const uint32_t b = static_cast<uint32_t>(__builtin_amdgcn_readlane(hi, l));
+    return (static_cast<uint64_t>(b) << 32) | a;
+}
 __device__ __forceinline__ uint64_t f_below(uint32_t n) {  // lanes 0 .. n-1 (n <= 64)
     return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
 }
@@ -368,9 +375,7 @@ __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint3
 // 64 bits of the slot's run-start bitmap from bit `off` on (lane j of bm_lo / bm_hi holds block j)
 __device__ __forceinline__ uint64_t bitmap_window(uint32_t bm_lo, uint32_t bm_hi, uint32_t off) {
     const uint32_t q = off >> 6, sh = off & 63u;
-    const uint64_t a = (static_cast<uint64_t>(__builtin_amdgcn_readlane(bm_hi, q)) << 32) | __builtin_amdgcn_readlane(bm_lo, q);
-    const uint64_t b = (static_cast<uint64_t>(__builtin_amdgcn_readlane(bm_hi, q + 1u)) << 32) |
-                       __builtin_amdgcn_readlane(bm_lo, q + 1u);
+    const uint64_t a = f_read64(bm_lo, bm_hi, q), b = f_read64(bm_lo, bm_hi, q + 1u);
     return sh ? ((a >> sh) | (b << (64u - sh))) : a;
 }
 
@@ -443,8 +448,7 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
                 const uint64_t any = f_ballot(lane < kSlotRecs / 64 && (bm_lo | bm_hi) != 0u);
                 if (any) {
                     const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(any));
-                    const uint64_t w = (static_cast<uint64_t>(__builtin_amdgcn_readlane(bm_hi, q)) << 32) |
-                                       __builtin_amdgcn_readlane(bm_lo, q);
+                    const uint64_t w = f_read64(bm_lo, bm_hi, q);
                     off = 64u * q + static_cast<uint32_t>(__builtin_ctzll(w));
                 }
             }

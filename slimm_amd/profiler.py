@@ -249,6 +249,15 @@ class Slimm:
         self._check(self.L.slimm_get_bins(self.ctx, which, _p(out)))
         return out
 
+    def read_targets(self):
+        """The reads' target lists after analyze_alignments: (ref | head bit, global bin | unique bit), both uint32."""
+        n = C.c_uint64()
+        self._check(self.L.slimm_get_read_targets(self.ctx, None, None, 0, C.byref(n)))
+        ref = np.zeros(n.value, dtype=np.uint32)
+        gbin = np.zeros(n.value, dtype=np.uint32)
+        self._check(self.L.slimm_get_read_targets(self.ctx, _p(ref), _p(gbin), n.value, C.byref(n)))
+        return ref, gbin
+
     def taxon_counts(self, stage: int = 1) -> Dict[int, int]:
         n = C.c_uint32()
         self._check(self.L.slimm_taxon_count_size(self.ctx, stage, C.byref(n)))

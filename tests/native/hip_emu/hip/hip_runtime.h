@@ -211,10 +211,9 @@ static inline T __shfl_xor(T v, int m, int width = 64) {
     return hipemu_shfl_from(v, static_cast<int>(::hipemu::g_lane) ^ m, true);
 }
 // DPP move: dst = (source lane valid and enabled) ? src[source lane] : (bound_ctrl ? 0 : old)
-static inline uint32_t __builtin_amdgcn_update_dpp(uint32_t old, uint32_t src, int ctrl, int row_mask, int bank_mask,
-                                                   bool bound_ctrl) {
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     uint64_t live = 0;
-    const uint64_t* a = ::hipemu::wave_exchange(src, &live);
+    const uint64_t* a = ::hipemu::wave_exchange(static_cast<uint32_t>(src), &live);
     const int l = static_cast<int>(::hipemu::g_lane);
     const int row = l >> 4, in_row = l & 15;
     if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
@@ -250,8 +249,8 @@ static inline uint32_t __builtin_amdgcn_update_dpp(uint32_t old, uint32_t src, i
         std::fprintf(stderr, "hip_emu: DPP control 0x%x not modelled\n", ctrl);
         std::abort();
     }
-    if (s < 0 || !((live >> s) & 1u)) return bound_ctrl ? 0u : old;
-    return static_cast<uint32_t>(a[s]);
+    if (s < 0 || !((live >> s) & 1u)) return bound_ctrl ? 0 : old;
+    return static_cast<int>(static_cast<uint32_t>(a[s]));
 }
 static inline uint32_t __builtin_amdgcn_ds_bpermute(int byte_addr, uint32_t v) {
     uint64_t live = 0;

@@ -8,10 +8,12 @@
 //   1. the run-start bitmap of the slot: its keys (all blocks of 64 in flight together) are compared with the key of the
 //      lane before (DPP wave shift); one ballot per block.  The keys are not needed again.
 //   2. the slot is cut into WINDOWS of up to 64 records that start at a qName run start and end behind the last run that
-//      is complete inside them -- scalar arithmetic on the bitmap, so the cuts are known before any other field of the
-//      records has been loaded, and the {flag, reference, position} loads of the next window are in flight while the
-//      current one is classified.  Every window holds whole runs only: nothing about a read is ever carried from one
-//      window, wave or workgroup to the next -- no halo, no LDS, no barrier, no scan over tiles.
+//      is complete inside them -- scalar arithmetic on the bitmap, so every cut of the slot is known before any other
+//      field of the records has been loaded.  Every window holds whole runs only: nothing about a read is ever carried
+//      from one window, wave or workgroup to the next -- no halo, no LDS, no barrier, no scan over tiles -- and a
+//      window's targets are written compacted BEHIND THE WINDOW'S OWN FIRST RECORD (it has no more targets than
+//      records), so not even a running count links the windows: their {flag, reference, position} loads run three
+//      windows ahead of the arithmetic, the gather of the contigs' geometry one.
 //   3. inside a window everything is lane-mask arithmetic:
 //        segment starts       run starts | "mate differs from the lane before"
 //        first of (read, ref) Q1: a tagged word {segment start, reference} is shifted along the lanes one step at a time
@@ -20,10 +22,8 @@
 //                             of ~mapped + starts ripples from every start to the first mapped lane behind it
 //        unique reads         a head is unique iff the next target is a head again: the same carry trick on the
 //                             bit-reversed masks finds the target in front of every non-head target
-//      and the targets are written compacted behind the slot's first run start (rank = popcount of the lanes below).
-// A slot's targets therefore sit at [start, start + nf) with start = index of its first run start and nf <= the records
-// the slot is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.  The windows'
-// first targets / reads are listed per slot (wcut) so that k_filter can take them up independently of each other.
+// The consumers walk the windows (win[]): no prefix sum over the stream is ever needed, and every window is a piece of
+// work of its own for them, too.
 //
 // Three paths per window, chosen by wave-uniform tests:
 //   fast     the mate numbers of every run are non-decreasing (mapper output "all of mate 1, then all of mate 2",
@@ -37,9 +37,8 @@
 // Output (all 32-bit):
 //   tgt_ref [p]  reference id | bit 31: first target of its read
 //   tgt_gbin[p]  global bin (bin_off[ref] + bin) | bit 31: the read has exactly one target (src/slimm.hpp:224)
-//   slots   [s]  {start, targets, reads, mapped records} of slot s
-//   wcut    [s * kSlotWindows + i]  {targets, reads} of slot s in front of its window i; the last entry of a slot's row
-//                holds the number of windows, the entry behind the last window the slot's totals
+//   win  [s * kSlotWindows + i]  window i of slot s: {index of its first record = of its first target, targets, reads, 0}
+//   slots[s]     {windows, targets, reads, mapped records} of slot s
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -103,6 +102,9 @@ struct FrontRec {  // what a window needs of a record besides its place in a run
     uint32_t mate, ref, aux;
     bool mapped;
 };
+struct FrontRaw3 {  // the three words a window loads per record, as they come from memory
+    uint32_t a, b, c;
+};
 
 struct FrontRaw {
     const uint64_t* key;
@@ -119,20 +121,25 @@ struct FrontRaw {
         lo = static_cast<uint32_t>(k);
         hi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
     }
-    __device__ FrontRec rec(uint32_t i, bool& bad) const {
-        const uint32_t f = flag[i];
-        const int32_t r = ref[i];
+    __device__ FrontRaw3 raw(uint32_t i) const {
+        return FrontRaw3{flag[i], static_cast<uint32_t>(ref[i]), static_cast<uint32_t>(pos[i])};
+    }
+    __device__ FrontRec decode(const FrontRaw3& w, bool& bad) const {
         FrontRec o;
-        o.mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);                    // src/slimm.hpp:205-208
-        o.mapped = !(f & 0x4u) && r != -1;                                       // src/slimm.hpp:197
-        if (o.mapped && static_cast<uint32_t>(r) >= n_refs) {
+        o.mate = (w.a & 0x40u) ? 1u : ((w.a & 0x80u) ? 2u : 0u);                // src/slimm.hpp:205-208
+        o.mapped = !(w.a & 0x4u) && w.b != 0xffffffffu;                          // src/slimm.hpp:197
+        if (o.mapped && w.b >= n_refs) {
             bad = true;
             o.mapped = false;
         }
-        o.ref = static_cast<uint32_t>(r);
-        o.aux = static_cast<uint32_t>(pos[i]);
+        o.ref = w.b;
+        o.aux = w.c;
         return o;
     }
+    __device__ FrontRec rec(uint32_t i, bool& bad) const { return decode(raw(i), bad); }
+    // the contig's {length, first bin}: one 8-byte gather, issued a window ahead of its use (lanes whose reference is
+    // no index of the table gather row 0)
+    __device__ uint2 geo_of(const FrontRaw3& w) const { return geo[w.b < n_refs ? w.b : 0u]; }
     // n / bin_width with a host-computed reciprocal: mulhi(n, floor((2^32 - 1) / d)) is the quotient or one less
     __device__ uint32_t div_bin_width(uint32_t v) const {
         const uint32_t q = __umulhi(v, bw_magic);
@@ -140,10 +147,9 @@ struct FrontRaw {
         return q + (r >= bin_width ? 1u : 0u);
     }
     // bin of the record: uint32 wrap-around of int32 + uint32, then the clamp to the contig length
-    // (src/slimm.hpp:200-201, quirk Q3); one 8-byte gather for the contig's geometry
-    __device__ uint32_t gbin(uint32_t r, uint32_t aux) const {
-        const uint2 g = geo[r];
-        return g.y + div_bin_width(min(aux + half_read, g.x));
+    // (src/slimm.hpp:200-201, quirk Q3)
+    __device__ uint32_t gbin(const FrontRec& r, const uint2& g) const {
+        return g.y + div_bin_width(min(r.aux + half_read, g.x));
     }
 };
 
@@ -158,21 +164,19 @@ struct FrontSorted {
         lo = static_cast<uint32_t>(k) & ~3u;
         hi = static_cast<uint32_t>(k >> 32);
     }
-    __device__ FrontRec rec(uint32_t i, bool&) const {
-        FrontRec o;
-        o.mate = reinterpret_cast<const uint32_t*>(ident)[2 * static_cast<size_t>(i)] & 3u;
-        o.mapped = true;
-        o.ref = cref[i];
-        o.aux = cgbin[i];
-        return o;
+    __device__ FrontRaw3 raw(uint32_t i) const {
+        return FrontRaw3{reinterpret_cast<const uint32_t*>(ident)[2 * static_cast<size_t>(i)], cref[i], cgbin[i]};
     }
-    __device__ uint32_t gbin(uint32_t, uint32_t aux) const { return aux; }
+    __device__ FrontRec decode(const FrontRaw3& w, bool&) const { return FrontRec{w.a & 3u, w.b, w.c, true}; }
+    __device__ FrontRec rec(uint32_t i, bool& bad) const { return decode(raw(i), bad); }
+    __device__ uint2 geo_of(const FrontRaw3&) const { return make_uint2(0u, 0u); }
+    __device__ uint32_t gbin(const FrontRec& r, const uint2&) const { return r.aux; }
 };
 
 namespace {
 
-struct SlotOut {  // where the slot's targets go and what it has counted so far (all wave-uniform)
-    uint32_t base;            // index of the slot's first run start = position of its first target
+struct WinOut {  // where a window's targets go and what it has counted (all wave-uniform)
+    uint32_t base;            // index of the window's first record = position of its first target
     uint32_t nf, nh, nv;      // targets, reads, mapped records
 };
 
@@ -181,8 +185,8 @@ struct SlotOut {  // where the slot's targets go and what it has counted so far 
 // mate changes), V = mapped lanes, both inside [0, X).
 // ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
-__device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec, uint32_t lane, uint64_t SS, uint64_t V,
-                                            uint32_t X, SlotOut& so, uint32_t* __restrict__ tgt_ref,
+__device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec, const uint2& geo, uint32_t lane, uint64_t SS,
+                                            uint64_t V, uint32_t X, WinOut& so, uint32_t* __restrict__ tgt_ref,
                                             uint32_t* __restrict__ tgt_gbin) {
     const bool use = f_bit(V);
     // segment start of this lane: the highest start at or below it
@@ -212,7 +216,7 @@ __device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec,
     if (first) {
         const uint32_t p = so.base + so.nf + f_rank(F);
         tgt_ref[p] = rec.ref | (hbit ? 0x80000000u : 0u);
-        tgt_gbin[p] = acc.gbin(rec.ref, rec.aux) | (ubit ? 0x80000000u : 0u);
+        tgt_gbin[p] = acc.gbin(rec, geo) | (ubit ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -224,9 +228,9 @@ __device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec,
 // targets of a run are written ordered by (mate, file order), so a read's targets stay contiguous.
 // ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
-__device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& rec, uint32_t lane, uint64_t RS, uint64_t V,
-                                            uint32_t X, SlotOut& so, uint32_t* __restrict__ tgt_ref,
-                                            uint32_t* __restrict__ tgt_gbin) {
+__device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& rec, const uint2& geo, uint32_t lane,
+                                               uint64_t RS, uint64_t V, uint32_t X, WinOut& so,
+                                               uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
     const bool in_pr = lane < X;
     const bool use = f_bit(V);
     const uint64_t le = (2ull << lane) - 1ull;
@@ -265,7 +269,7 @@ __device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& r
         const uint32_t before_run = static_cast<uint32_t>(__popcll(F & ((1ull << run_from) - 1ull)));
         const uint32_t p = so.base + so.nf + before_run + smaller + same_before;
         tgt_ref[p] = rec.ref | (head ? 0x80000000u : 0u);
-        tgt_gbin[p] = acc.gbin(rec.ref, rec.aux) | ((head && same_total == 1u) ? 0x80000000u : 0u);
+        tgt_gbin[p] = acc.gbin(rec, geo) | ((head && same_total == 1u) ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -278,7 +282,7 @@ __device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& r
 // of the record behind the run.
 // ---------------------------------------------------------------------------------------------------------
 template <typename Acc>
-__device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, SlotOut& so,
+__device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, WinOut& so,
                                           uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
     // 1. where the run ends, whether its mates ever decrease
     uint32_t klo0, khi0;
@@ -348,7 +352,8 @@ __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint3
             }
             const bool head = f_bit(H);
             const uint32_t p = so.base + so.nf + f_rank(F);
-            const uint32_t g = first ? acc.gbin(r.ref, r.aux) : 0u;
+            const FrontRaw3 rw{0u, first ? r.ref : 0u, 0u};
+            const uint32_t g = first ? acc.gbin(r, acc.geo_of(rw)) : 0u;
             if (first) {
                 tgt_ref[p] = r.ref | (head ? 0x80000000u : 0u);
                 if (!head) tgt_gbin[p] = g;  // a head's bin word waits for the end of the run (unique or not)
@@ -379,25 +384,17 @@ __device__ __forceinline__ uint64_t bitmap_window(uint32_t bm_lo, uint32_t bm_hi
     return sh ? ((a >> sh) | (b << (64u - sh))) : a;
 }
 
-struct Cut {   // a window: records [off, off + X) of the slot; X = 0: a run of 64 records or more starts at off
-    uint32_t off, X;
-    uint64_t RS;  // run starts of the 64 records from off on
-};
-
-// the window starting at the run start `off` (< kSlotRecs) of the slot that begins at record B
-__device__ __forceinline__ Cut cut_at(uint32_t bm_lo, uint32_t bm_hi, uint32_t B, uint32_t off, uint32_t N) {
-    Cut c;
-    c.off = off;
-    c.RS = bitmap_window(bm_lo, bm_hi, off);
-    const uint32_t pos = B + off;
-    // complete runs end at the last run start of the window -- or at the end of the stream
-    uint32_t X = pos + 64u >= N ? N - pos : 63u - static_cast<uint32_t>(__builtin_clzll(c.RS | 1ull));
-    if (kSlotRecs - off < 64u) {  // runs starting at or behind the slot's end are the next slot's
-        const uint64_t beyond = c.RS & ~f_below(kSlotRecs - off);
-        if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
-    }
-    c.X = X;
-    return c;
+// first run start of the slot's bitmap at or behind bit `off` (< 64 * kSlotBlocks), 64 * kSlotBlocks when there is none
+__device__ __forceinline__ uint32_t bitmap_next(uint32_t bm_lo, uint32_t bm_hi, uint32_t lane, uint32_t off) {
+    const uint32_t q0 = off >> 6;
+    uint64_t mine = (static_cast<uint64_t>(bm_hi) << 32) | bm_lo;   // this lane's block
+    if (lane == q0) mine &= ~f_below(off & 63u);
+    const uint64_t any = f_ballot(lane >= q0 && lane < kSlotBlocks && mine != 0ull);
+    if (!any) return 64u * kSlotBlocks;
+    const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(any));
+    uint64_t w = f_read64(bm_lo, bm_hi, q);
+    if (q == q0) w &= ~f_below(off & 63u);
+    return 64u * q + static_cast<uint32_t>(__builtin_ctzll(w));
 }
 
 }  // namespace
@@ -408,7 +405,7 @@ __device__ __forceinline__ Cut cut_at(uint32_t bm_lo, uint32_t bm_hi, uint32_t B
 template <typename Acc>
 __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
-                                                       uint4* __restrict__ slots, uint2* __restrict__ wcut) {
+                                                       uint4* __restrict__ slots, uint4* __restrict__ win) {
     const uint32_t N = acc.count(counters);
     const uint32_t lane = f_lane();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -417,9 +414,8 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
     bool bad = false;
     for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint32_t B = slot * kSlotRecs;
-        uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
-        SlotOut so{B, 0u, 0u, 0u};
-        uint32_t nw = 0;
+        uint4* const wins = win + static_cast<size_t>(slot) * kSlotWindows;
+        uint32_t nw = 0, slot_f = 0, slot_h = 0, slot_v = 0;
         if (B < N) {
             // ---- 1. run starts of records [B, B + 64 * kSlotBlocks): lane j of bm_lo / bm_hi gets block j's ballot
             uint32_t bm_lo = 0, bm_hi = 0;
@@ -438,75 +434,77 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
                     rs &= first < N ? f_below(min(64u, N - first)) : 0ull;  // no records behind the stream's end
                     bm_lo = lane == j ? static_cast<uint32_t>(rs) : bm_lo;
                     bm_hi = lane == j ? static_cast<uint32_t>(rs >> 32) : bm_hi;
-                    plo = __builtin_amdgcn_readlane(klo[j], 63);
-                    phi = __builtin_amdgcn_readlane(khi[j], 63);
+                    plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(klo[j], 63));
+                    phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(khi[j], 63));
                 }
             }
-            // ---- 2. the slot's first run start
-            uint32_t off = kSlotRecs;
+            // ---- 2. the cuts: lane i of c_off / c_x = window i's first record (relative to B) and length; length 0 = a
+            //         run of 64 records or more starts there
+            uint32_t c_off = 0, c_x = 0;
             {
-                const uint64_t any = f_ballot(lane < kSlotRecs / 64 && (bm_lo | bm_hi) != 0u);
-                if (any) {
-                    const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(any));
-                    const uint64_t w = f_read64(bm_lo, bm_hi, q);
-                    off = 64u * q + static_cast<uint32_t>(__builtin_ctzll(w));
-                }
-            }
-            so.base = B + min(off, kSlotRecs);
-            // ---- 3. windows: the loads of the next one are in flight while the current one is classified
-            bool have = off < kSlotRecs;
-            Cut cur{};
-            FrontRec rec{};
-            if (have) {
-                cur = cut_at(bm_lo, bm_hi, B, off, N);
-                if (cur.X) rec = acc.rec(min(B + off + lane, N - 1u), bad);
-            }
-            while (have) {
-                if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
-                    if (lane == 0u) cuts[nw] = make_uint2(so.nf, so.nh);  // records; beyond that the list's last window
-                    ++nw;                                                  // simply takes the rest of the slot)
-                }
-                uint32_t noff;
-                bool nhave = false;
-                Cut nxt{};
-                FrontRec nrec{};
-                if (cur.X) {
-                    noff = cur.off + cur.X;
-                    nhave = noff < kSlotRecs && B + noff < N;
-                    if (nhave) {
-                        nxt = cut_at(bm_lo, bm_hi, B, noff, N);
-                        if (nxt.X) nrec = acc.rec(min(B + noff + lane, N - 1u), bad);
+                uint32_t off = bitmap_next(bm_lo, bm_hi, lane, 0u);
+                while (off < kSlotRecs && nw < kSlotWindows) {
+                    const uint64_t RS = bitmap_window(bm_lo, bm_hi, off);
+                    const uint32_t pos = B + off;
+                    // complete runs end at the last run start of the window -- or at the end of the stream
+                    uint32_t X = pos + 64u >= N ? N - pos : 63u - static_cast<uint32_t>(__builtin_clzll(RS | 1ull));
+                    if (kSlotRecs - off < 64u) {  // runs starting at or behind the slot's end are the next slot's
+                        const uint64_t beyond = RS & ~f_below(kSlotRecs - off);
+                        if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
                     }
-                    const uint64_t PR = f_below(cur.X);
-                    const uint64_t RS = cur.RS & PR;
+                    c_off = lane == nw ? off : c_off;
+                    c_x = lane == nw ? X : c_x;
+                    ++nw;
+                    // (two windows in a row cover at least 64 records, so a slot has at most 2 * kSlotRecs / 64 + 2 of
+                    // them; kSlotWindows leaves room to spare)
+                    off = X ? off + X : bitmap_next(bm_lo, bm_hi, lane, off + 1u);  // behind a long run: the next run start
+                }
+            }
+            // ---- 3. the windows.  Loads run three windows ahead (q1 .. q3), the geometry gather one (g1).
+            auto issue = [&](uint32_t i, FrontRaw3& q) {
+                if (i < nw && __builtin_amdgcn_readlane(c_x, i) != 0)
+                    q = acc.raw(min(B + static_cast<uint32_t>(__builtin_amdgcn_readlane(c_off, i)) + lane, N - 1u));
+            };
+            FrontRaw3 q0{}, q1{}, q2{}, q3{};
+            uint2 g0 = make_uint2(0u, 0u), g1 = make_uint2(0u, 0u);
+            issue(0u, q0);
+            issue(1u, q1);
+            issue(2u, q2);
+            if (nw && __builtin_amdgcn_readlane(c_x, 0) != 0) g0 = acc.geo_of(q0);
+            for (uint32_t i = 0; i < nw; ++i) {
+                issue(i + 3u, q3);
+                if (i + 1u < nw && __builtin_amdgcn_readlane(c_x, i + 1u) != 0) g1 = acc.geo_of(q1);
+                const uint32_t off = static_cast<uint32_t>(__builtin_amdgcn_readlane(c_off, i));
+                const uint32_t X = static_cast<uint32_t>(__builtin_amdgcn_readlane(c_x, i));
+                WinOut so{B + off, 0u, 0u, 0u};
+                if (X) {
+                    const FrontRec rec = acc.decode(q0, bad);
+                    const uint64_t PR = f_below(X);
+                    const uint64_t RS = bitmap_window(bm_lo, bm_hi, off) & PR;
                     const uint32_t mprev = f_shr1(rec.mate, 0u);
                     const uint64_t V = f_ballot(rec.mapped) & PR;
                     const uint64_t dec = f_ballot(rec.mate < mprev) & ~RS & PR;
                     if (dec == 0ull)
-                        window_fast(acc, rec, lane, (RS | f_ballot(rec.mate != mprev)) & PR, V, cur.X, so, tgt_ref, tgt_gbin);
+                        window_fast(acc, rec, g0, lane, (RS | f_ballot(rec.mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin);
                     else
-                        window_general(acc, rec, lane, RS, V, cur.X, so, tgt_ref, tgt_gbin);
+                        window_general(acc, rec, g0, lane, RS, V, X, so, tgt_ref, tgt_gbin);
                 } else {
-                    noff = long_run(acc, B + cur.off, N, lane, so, tgt_ref, tgt_gbin, bad) - B;
-                    nhave = noff < kSlotRecs && B + noff < N;
-                    if (nhave) {
-                        nxt = cut_at(bm_lo, bm_hi, B, noff, N);
-                        if (nxt.X) nrec = acc.rec(min(B + noff + lane, N - 1u), bad);
-                    }
+                    (void)long_run(acc, B + off, N, lane, so, tgt_ref, tgt_gbin, bad);
                 }
-                have = nhave;
-                cur = nxt;
-                rec = nrec;
+                if (lane == 0u) wins[i] = make_uint4(so.base, so.nf, so.nh, 0u);
+                slot_f += so.nf;
+                slot_h += so.nh;
+                slot_v += so.nv;
+                q0 = q1;
+                q1 = q2;
+                q2 = q3;
+                g0 = g1;
             }
         }
-        if (lane == 0u) {
-            slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
-            cuts[nw] = make_uint2(so.nf, so.nh);
-            cuts[kSlotWindows - 1u] = make_uint2(nw, 0u);
-        }
-        tot_f += so.nf;
-        tot_h += so.nh;
-        tot_v += so.nv;
+        if (lane == 0u) slots[slot] = make_uint4(nw, slot_f, slot_h, slot_v);
+        tot_f += slot_f;
+        tot_h += slot_h;
+        tot_v += slot_v;
     }
     if (lane == 0u) {
         if (tot_h) atomicAdd(&counters[CNT_M], tot_h);
@@ -529,7 +527,7 @@ static uint32_t front_grid(uint32_t nslots) {
 
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint2* wcut) {
+                      uint4* win) {
     const uint32_t ns = front_slots(in.n);
     if (!ns) return;
     FrontRaw a;
@@ -544,16 +542,16 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.bin_width = bin_width;
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
     hipLaunchKernelGGL(k_front<FrontRaw>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref, tgt_gbin,
-                       slots, wcut);
+                       slots, win);
 }
 
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut) {
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint4* win) {
     const uint32_t ns = front_slots(n_upper);
     if (!ns) return;
     FrontSorted a{ident, cref, cgbin};
     hipLaunchKernelGGL(k_front<FrontSorted>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                       tgt_gbin, slots, wcut);
+                       tgt_gbin, slots, win);
 }
 
 }  // namespace slimm

@@ -116,8 +116,8 @@ struct slimm_ctx {
     DevBuf<uint64_t> c_ident, s_ident;
     DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist;
     DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
-    DevBuf<uint4> slots;                 // per kSlotRecs records: {windows, targets, reads, mapped records}
-    DevBuf<uint4> win;                   // per slot kSlotWindows windows: {first target, targets, reads, 0} (kernels.h)
+    DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
+    DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
     DevBuf<uint2> tile_cnt;              // (record_order = ANY: mapped records per tile of the compaction)
     DevBuf<uint4> scan_sums;             // chunk sums of the multi-workgroup tile scan
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
@@ -276,7 +276,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
-    HIP_TRY(c, c->win.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
+    HIP_TRY(c, c->wcut.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
     HIP_TRY(c, c->sel.ensure(n + 1));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
@@ -646,18 +646,17 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_FRONT);
             launch_front_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                                c->slots.p, c->win.p);
+                                c->slots.p, c->wcut.p);
         }
     } else {
         // grouped input: one pass straight over the caller's record arrays
         KernelTimer t(c, K_FRONT);
         launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                         c->slots.p, c->win.p);
+                         c->slots.p, c->wcut.p);
     }
     SlotValues targets;
     targets.vals = c->tgt_gbin.p;
     targets.slots = c->slots.p;
-    targets.win = c->win.p;
     targets.nslots = nslots;
     targets.per_read = false;
     if (c->use_tiles) {
@@ -702,7 +701,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
     } else {
         KernelTimer t(c, K_HIST);
-        launch_hist(st, c->tgt_gbin.p, c->slots.p, c->win.p, nslots, c->counters.p, c->tail(), c->cov(), c->ucov());
+        launch_hist(st, c->tgt_gbin.p, c->slots.p, nslots, c->counters.p, c->tail(), c->cov(), c->ucov());
         c->binsA_stored = true;
     }
     HIP_TRY(c, hipGetLastError());
@@ -972,7 +971,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             fa.tgt_ref = c->tgt_ref.p;
             fa.tgt_gbin = c->tgt_gbin.p;
             fa.slots = c->slots.p;
-            fa.win = c->win.p;
+            fa.wcut = c->wcut.p;
             fa.nslots = nslots;
             if (c->use_rows16) {
                 fa.rows16 = c->d_rows16.p;
@@ -994,13 +993,11 @@ int slimm_filter_alignments(slimm_ctx* c) {
         SlotValues selectors;
         selectors.vals = c->sel.p;
         selectors.slots = c->slots.p;
-        selectors.win = c->win.p;
         selectors.nslots = nslots;
         selectors.per_read = true;
         if (!c->use_tiles) {
             KernelTimer t(c, K_HIST);
-            launch_sel_atomics(st, c->sel.p, c->slots.p, c->win.p, nslots, static_cast<uint32_t>(c->Bp), c->ucov2(),
-                               c->lca_count.p);
+            launch_sel_atomics(st, c->sel.p, c->slots.p, nslots, static_cast<uint32_t>(c->Bp), c->ucov2(), c->lca_count.p);
         }
         if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
             const uint32_t grid = 512;
@@ -1318,11 +1315,8 @@ int slimm_get_read_targets(slimm_ctx* c, uint32_t* ref, uint32_t* gbin, uint64_t
     if (c->device < 0 || !c->analyzed) return fail(c, SLIMM_E_INVALID, "no targets on this context (call slimm_analyze_alignments)");
     (void)hipSetDevice(c->device);
     const uint32_t ns = front_slots(c->rec.n);
-    std::vector<uint4> sl(ns), wn(static_cast<size_t>(ns) * kSlotWindows);
-    if (ns) {
-        HIP_TRY(c, hipMemcpyAsync(sl.data(), c->slots.p, ns * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(wn.data(), c->win.p, wn.size() * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
-    }
+    std::vector<uint4> sl(ns);
+    if (ns) HIP_TRY(c, hipMemcpyAsync(sl.data(), c->slots.p, ns * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint64_t total = 0;
     for (const uint4& d : sl) total += d.y;
@@ -1331,14 +1325,11 @@ int slimm_get_read_targets(slimm_ctx* c, uint32_t* ref, uint32_t* gbin, uint64_t
     if (cap < total) return fail(c, SLIMM_E_INVALID, "slimm_get_read_targets: %llu entries, room for %llu",
                                  static_cast<unsigned long long>(total), static_cast<unsigned long long>(cap));
     uint64_t o = 0;
-    for (uint32_t s = 0; s < ns; ++s) {
-        for (uint32_t i = 0; i < sl[s].x; ++i) {  // (a window's targets are contiguous)
-            const uint4& d = wn[static_cast<size_t>(s) * kSlotWindows + i];
-            if (!d.y) continue;
-            if (ref) HIP_TRY(c, hipMemcpyAsync(ref + o, c->tgt_ref.p + d.x, d.y * 4ull, hipMemcpyDeviceToHost, c->stream));
-            if (gbin) HIP_TRY(c, hipMemcpyAsync(gbin + o, c->tgt_gbin.p + d.x, d.y * 4ull, hipMemcpyDeviceToHost, c->stream));
-            o += d.y;
-        }
+    for (const uint4& d : sl) {  // (a slot's targets are contiguous; runs of slots are too when nothing was dropped)
+        if (!d.y) continue;
+        if (ref) HIP_TRY(c, hipMemcpyAsync(ref + o, c->tgt_ref.p + d.x, d.y * 4ull, hipMemcpyDeviceToHost, c->stream));
+        if (gbin) HIP_TRY(c, hipMemcpyAsync(gbin + o, c->tgt_gbin.p + d.x, d.y * 4ull, hipMemcpyDeviceToHost, c->stream));
+        o += d.y;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SLIMM_OK;

@@ -5,16 +5,16 @@
 // the unique bit is the `reads.size() == 1` test of src/slimm.hpp:224-237.
 //
 // Shape.  A wave owns slots of kSlotRecs consecutive records.  Per slot:
-//   1. the run-start bitmap of the slot: its keys (all blocks of 64 in flight together) are compared with the key of the
-//      lane before (DPP wave shift); one ballot per block.  The keys are not needed again.
-//   2. the slot is cut into WINDOWS of up to 64 records that start at a qName run start and end behind the last run that
-//      is complete inside them -- scalar arithmetic on the bitmap, so every cut of the slot is known before any other
-//      field of the records has been loaded.  Every window holds whole runs only: nothing about a read is ever carried
-//      from one window, wave or workgroup to the next -- no halo, no LDS, no barrier, no scan over tiles -- and a
-//      window's targets are written compacted BEHIND THE WINDOW'S OWN FIRST RECORD (it has no more targets than
-//      records), so not even a running count links the windows: their {flag, reference, position} loads run three
-//      windows ahead of the arithmetic, the gather of the contigs' geometry one.
-//   3. inside a window everything is lane-mask arithmetic:
+//   1. STAGE: the slot's records are loaded block by block (64 records, six blocks in flight together), the bin of every
+//      record is computed (one 8-byte gather of its contig's geometry) and two words per record -- {reference, mate,
+//      mapped} and the bin -- go to the wave's own stretch of LDS; comparing every key with the key of the lane before
+//      (DPP wave shift, one ballot per block) gives the slot's run-start bitmap.  This is the only part of the kernel
+//      that waits for memory, and everything it loads is in flight at once.
+//   2. CUT: the slot is cut into WINDOWS of up to 64 records that start at a qName run start and end behind the last run
+//      that is complete inside them -- scalar arithmetic on the bitmap.  Every window holds whole runs only: nothing
+//      about a read is ever carried from one window, wave or workgroup to the next -- no halo, no barrier, no scan over
+//      tiles.
+//   3. CLASSIFY: per window the staged words come back from LDS and everything is lane-mask arithmetic:
 //        segment starts       run starts | "mate differs from the lane before"
 //        first of (read, ref) Q1: a tagged word {segment start, reference} is shifted along the lanes one step at a time
 //                             and compared with the lane's own; the trip count is the window's longest segment
@@ -22,8 +22,10 @@
 //                             of ~mapped + starts ripples from every start to the first mapped lane behind it
 //        unique reads         a head is unique iff the next target is a head again: the same carry trick on the
 //                             bit-reversed masks finds the target in front of every non-head target
-// The consumers walk the windows (win[]): no prefix sum over the stream is ever needed, and every window is a piece of
-// work of its own for them, too.
+//      and the targets are written compacted behind the slot's first run start (rank = popcount of the lanes below).
+// A slot's targets therefore sit at [start, start + nf) with start = index of its first run start and nf <= the records
+// the slot is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.  The windows'
+// first targets / reads are listed per slot (wcut) so that k_filter can take them up independently of each other.
 //
 // Three paths per window, chosen by wave-uniform tests:
 //   fast     the mate numbers of every run are non-decreasing (mapper output "all of mate 1, then all of mate 2",
@@ -37,8 +39,9 @@
 // Output (all 32-bit):
 //   tgt_ref [p]  reference id | bit 31: first target of its read
 //   tgt_gbin[p]  global bin (bin_off[ref] + bin) | bit 31: the read has exactly one target (src/slimm.hpp:224)
-//   win  [s * kSlotWindows + i]  window i of slot s: {index of its first record = of its first target, targets, reads, 0}
-//   slots[s]     {windows, targets, reads, mapped records} of slot s
+//   slots   [s]  {start, targets, reads, mapped records} of slot s
+//   wcut    [s * kSlotWindows + i]  {targets, reads} of slot s in front of its window i; the last entry of a slot's row
+//                holds the number of windows, the entry behind the last window the slot's totals
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -137,8 +140,7 @@ struct FrontRaw {
         return o;
     }
     __device__ FrontRec rec(uint32_t i, bool& bad) const { return decode(raw(i), bad); }
-    // the contig's {length, first bin}: one 8-byte gather, issued a window ahead of its use (lanes whose reference is
-    // no index of the table gather row 0)
+    // the contig's {length, first bin}: one 8-byte gather (lanes whose reference is no index of the table gather row 0)
     __device__ uint2 geo_of(const FrontRaw3& w) const { return geo[w.b < n_refs ? w.b : 0u]; }
     // n / bin_width with a host-computed reciprocal: mulhi(n, floor((2^32 - 1) / d)) is the quotient or one less
     __device__ uint32_t div_bin_width(uint32_t v) const {
@@ -175,19 +177,30 @@ struct FrontSorted {
 
 namespace {
 
-struct WinOut {  // where a window's targets go and what it has counted (all wave-uniform)
-    uint32_t base;            // index of the window's first record = position of its first target
+struct WinOut {  // where the slot's targets go and what it has counted so far (all wave-uniform)
+    uint32_t base;            // index of the slot's first run start = position of its first target
     uint32_t nf, nh, nv;      // targets, reads, mapped records
 };
+
+// the two words staged per record
+constexpr uint32_t kStMateShift = 26, kStMapped = 1u << 28;
+__device__ __forceinline__ uint32_t stage_word(const FrontRec& r) {
+    return (r.ref & kRefField) | (r.mate << kStMateShift) | (r.mapped ? kStMapped : 0u);
+}
+struct Staged {  // a record as the windows see it
+    uint32_t mate, ref, gbin;
+    bool mapped;
+};
+__device__ __forceinline__ Staged unstage(uint32_t w1, uint32_t w2) {
+    return Staged{(w1 >> kStMateShift) & 3u, w1 & kRefField, w2, (w1 & kStMapped) != 0u};
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  SS = segment starts (run starts and
 // mate changes), V = mapped lanes, both inside [0, X).
 // ---------------------------------------------------------------------------------------------------------
-template <typename Acc>
-__device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec, const uint2& geo, uint32_t lane, uint64_t SS,
-                                            uint64_t V, uint32_t X, WinOut& so, uint32_t* __restrict__ tgt_ref,
-                                            uint32_t* __restrict__ tgt_gbin) {
+__device__ __forceinline__ void window_fast(const Staged& rec, uint32_t lane, uint64_t SS, uint64_t V, uint32_t X, WinOut& so,
+                                            uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
     const bool use = f_bit(V);
     // segment start of this lane: the highest start at or below it
     const uint64_t le = (2ull << lane) - 1ull;
@@ -216,7 +229,7 @@ __device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec,
     if (first) {
         const uint32_t p = so.base + so.nf + f_rank(F);
         tgt_ref[p] = rec.ref | (hbit ? 0x80000000u : 0u);
-        tgt_gbin[p] = acc.gbin(rec, geo) | (ubit ? 0x80000000u : 0u);
+        tgt_gbin[p] = rec.gbin | (ubit ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -227,10 +240,9 @@ __device__ __forceinline__ void window_fast(const Acc& acc, const FrontRec& rec,
 // general path: mates interleave inside some run of the window.  Per-lane walks over the run by lane shuffles; the
 // targets of a run are written ordered by (mate, file order), so a read's targets stay contiguous.
 // ---------------------------------------------------------------------------------------------------------
-template <typename Acc>
-__device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& rec, const uint2& geo, uint32_t lane,
-                                               uint64_t RS, uint64_t V, uint32_t X, WinOut& so,
-                                               uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
+__device__ __forceinline__ void window_general(const Staged& rec, uint32_t lane, uint64_t RS, uint64_t V, uint32_t X,
+                                               WinOut& so, uint32_t* __restrict__ tgt_ref,
+                                               uint32_t* __restrict__ tgt_gbin) {
     const bool in_pr = lane < X;
     const bool use = f_bit(V);
     const uint64_t le = (2ull << lane) - 1ull;
@@ -269,7 +281,7 @@ __device__ __forceinline__ void window_general(const Acc& acc, const FrontRec& r
         const uint32_t before_run = static_cast<uint32_t>(__popcll(F & ((1ull << run_from) - 1ull)));
         const uint32_t p = so.base + so.nf + before_run + smaller + same_before;
         tgt_ref[p] = rec.ref | (head ? 0x80000000u : 0u);
-        tgt_gbin[p] = acc.gbin(rec, geo) | ((head && same_total == 1u) ? 0x80000000u : 0u);
+        tgt_gbin[p] = rec.gbin | ((head && same_total == 1u) ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -402,109 +414,110 @@ __device__ __forceinline__ uint32_t bitmap_next(uint32_t bm_lo, uint32_t bm_hi, 
 // ---------------------------------------------------------------------------------------------------------
 // k_front
 // ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kStageRecs = 64u * kSlotBlocks;   // records staged per slot (the slot and 64 more)
+constexpr uint32_t kStageGroup = 6;                  // blocks whose loads are in flight together
+
 template <typename Acc>
 __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
-                                                       uint4* __restrict__ slots, uint4* __restrict__ win) {
+                                                       uint4* __restrict__ slots, uint2* __restrict__ wcut) {
+    __shared__ uint32_t s_stage[kFrontBlock / 64][2][kStageRecs];
     const uint32_t N = acc.count(counters);
     const uint32_t lane = f_lane();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFrontBlock / 64);
+    uint32_t* const st1 = s_stage[wave][0];
+    uint32_t* const st2 = s_stage[wave][1];
     uint32_t tot_f = 0, tot_h = 0, tot_v = 0;
     bool bad = false;
     for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint32_t B = slot * kSlotRecs;
-        uint4* const wins = win + static_cast<size_t>(slot) * kSlotWindows;
-        uint32_t nw = 0, slot_f = 0, slot_h = 0, slot_v = 0;
+        uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
+        WinOut so{B, 0u, 0u, 0u};
+        uint32_t nw = 0;
         if (B < N) {
-            // ---- 1. run starts of records [B, B + 64 * kSlotBlocks): lane j of bm_lo / bm_hi gets block j's ballot
+            // ---- 1. stage records [B, B + kStageRecs) and their run starts: lane j of bm_lo / bm_hi gets block j's ballot
             uint32_t bm_lo = 0, bm_hi = 0;
             {
-                uint32_t klo[kSlotBlocks], khi[kSlotBlocks];
-#pragma unroll
-                for (uint32_t j = 0; j < kSlotBlocks; ++j) acc.key_at(min(B + 64u * j + lane, N - 1u), klo[j], khi[j]);
                 uint32_t plo = 0, phi = 0;  // the key in front of the block (one address for the whole wave)
                 if (B > 0u) acc.key_at(B - 1u, plo, phi);
 #pragma unroll
-                for (uint32_t j = 0; j < kSlotBlocks; ++j) {
-                    const uint32_t qlo = f_shr1(klo[j], plo), qhi = f_shr1(khi[j], phi);
-                    uint64_t rs = f_ballot(((klo[j] ^ qlo) | (khi[j] ^ qhi)) != 0u);
-                    if (B == 0u && j == 0u) rs |= 1ull;  // the first record of the stream starts a run
-                    const uint32_t first = B + 64u * j;
-                    rs &= first < N ? f_below(min(64u, N - first)) : 0ull;  // no records behind the stream's end
-                    bm_lo = lane == j ? static_cast<uint32_t>(rs) : bm_lo;
-                    bm_hi = lane == j ? static_cast<uint32_t>(rs >> 32) : bm_hi;
-                    plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(klo[j], 63));
-                    phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(khi[j], 63));
-                }
-            }
-            // ---- 2. the cuts: lane i of c_off / c_x = window i's first record (relative to B) and length; length 0 = a
-            //         run of 64 records or more starts there
-            uint32_t c_off = 0, c_x = 0;
-            {
-                uint32_t off = bitmap_next(bm_lo, bm_hi, lane, 0u);
-                while (off < kSlotRecs && nw < kSlotWindows) {
-                    const uint64_t RS = bitmap_window(bm_lo, bm_hi, off);
-                    const uint32_t pos = B + off;
-                    // complete runs end at the last run start of the window -- or at the end of the stream
-                    uint32_t X = pos + 64u >= N ? N - pos : 63u - static_cast<uint32_t>(__builtin_clzll(RS | 1ull));
-                    if (kSlotRecs - off < 64u) {  // runs starting at or behind the slot's end are the next slot's
-                        const uint64_t beyond = RS & ~f_below(kSlotRecs - off);
-                        if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
+                for (uint32_t j0 = 0; j0 < kSlotBlocks; j0 += kStageGroup) {
+                    uint32_t klo[kStageGroup], khi[kStageGroup];
+                    FrontRaw3 raw[kStageGroup];
+                    uint2 geo[kStageGroup];
+#pragma unroll
+                    for (uint32_t u = 0; u < kStageGroup; ++u) {
+                        if (j0 + u >= kSlotBlocks) break;
+                        const uint32_t i = min(B + 64u * (j0 + u) + lane, N - 1u);
+                        acc.key_at(i, klo[u], khi[u]);
+                        raw[u] = acc.raw(i);
                     }
-                    c_off = lane == nw ? off : c_off;
-                    c_x = lane == nw ? X : c_x;
-                    ++nw;
-                    // (two windows in a row cover at least 64 records, so a slot has at most 2 * kSlotRecs / 64 + 2 of
-                    // them; kSlotWindows leaves room to spare)
-                    off = X ? off + X : bitmap_next(bm_lo, bm_hi, lane, off + 1u);  // behind a long run: the next run start
+#pragma unroll
+                    for (uint32_t u = 0; u < kStageGroup; ++u) {
+                        if (j0 + u >= kSlotBlocks) break;
+                        geo[u] = acc.geo_of(raw[u]);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kStageGroup; ++u) {
+                        const uint32_t j = j0 + u;
+                        if (j >= kSlotBlocks) break;
+                        const FrontRec r = acc.decode(raw[u], bad);
+                        st1[64u * j + lane] = stage_word(r);
+                        st2[64u * j + lane] = acc.gbin(r, geo[u]);
+                        const uint32_t qlo = f_shr1(klo[u], plo), qhi = f_shr1(khi[u], phi);
+                        uint64_t rs = f_ballot(((klo[u] ^ qlo) | (khi[u] ^ qhi)) != 0u);
+                        if (B == 0u && j == 0u) rs |= 1ull;  // the first record of the stream starts a run
+                        const uint32_t first = B + 64u * j;
+                        rs &= first < N ? f_below(min(64u, N - first)) : 0ull;  // no records behind the stream's end
+                        bm_lo = lane == j ? static_cast<uint32_t>(rs) : bm_lo;
+                        bm_hi = lane == j ? static_cast<uint32_t>(rs >> 32) : bm_hi;
+                        plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(klo[u], 63));
+                        phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(khi[u], 63));
+                    }
                 }
             }
-            // ---- 3. the windows.  Loads run three windows ahead (q1 .. q3), the geometry gather one (g1).
-            auto issue = [&](uint32_t i, FrontRaw3& q) {
-                if (i < nw && __builtin_amdgcn_readlane(c_x, i) != 0)
-                    q = acc.raw(min(B + static_cast<uint32_t>(__builtin_amdgcn_readlane(c_off, i)) + lane, N - 1u));
-            };
-            FrontRaw3 q0{}, q1{}, q2{}, q3{};
-            uint2 g0 = make_uint2(0u, 0u), g1 = make_uint2(0u, 0u);
-            issue(0u, q0);
-            issue(1u, q1);
-            issue(2u, q2);
-            if (nw && __builtin_amdgcn_readlane(c_x, 0) != 0) g0 = acc.geo_of(q0);
-            for (uint32_t i = 0; i < nw; ++i) {
-                issue(i + 3u, q3);
-                if (i + 1u < nw && __builtin_amdgcn_readlane(c_x, i + 1u) != 0) g1 = acc.geo_of(q1);
-                const uint32_t off = static_cast<uint32_t>(__builtin_amdgcn_readlane(c_off, i));
-                const uint32_t X = static_cast<uint32_t>(__builtin_amdgcn_readlane(c_x, i));
-                WinOut so{B + off, 0u, 0u, 0u};
+            // ---- 2 + 3. windows: cut at the bitmap, classified from the staged words
+            uint32_t off = bitmap_next(bm_lo, bm_hi, lane, 0u);
+            so.base = B + min(off, kSlotRecs);
+            while (off < kSlotRecs) {
+                if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
+                    if (lane == 0u) cuts[nw] = make_uint2(so.nf, so.nh);  // records; beyond that the list's last window
+                    ++nw;                                                  // simply takes the rest of the slot)
+                }
+                const uint64_t RSw = bitmap_window(bm_lo, bm_hi, off);
+                const uint32_t pos = B + off;
+                // complete runs end at the last run start of the window -- or at the end of the stream
+                uint32_t X = pos + 64u >= N ? N - pos : 63u - static_cast<uint32_t>(__builtin_clzll(RSw | 1ull));
+                if (kSlotRecs - off < 64u) {  // runs starting at or behind the slot's end are the next slot's
+                    const uint64_t beyond = RSw & ~f_below(kSlotRecs - off);
+                    if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
+                }
                 if (X) {
-                    const FrontRec rec = acc.decode(q0, bad);
+                    const Staged rec = unstage(st1[off + lane], st2[off + lane]);
                     const uint64_t PR = f_below(X);
-                    const uint64_t RS = bitmap_window(bm_lo, bm_hi, off) & PR;
+                    const uint64_t RS = RSw & PR;
                     const uint32_t mprev = f_shr1(rec.mate, 0u);
                     const uint64_t V = f_ballot(rec.mapped) & PR;
-                    const uint64_t dec = f_ballot(rec.mate < mprev) & ~RS & PR;
-                    if (dec == 0ull)
-                        window_fast(acc, rec, g0, lane, (RS | f_ballot(rec.mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin);
+                    if ((f_ballot(rec.mate < mprev) & ~RS & PR) == 0ull)
+                        window_fast(rec, lane, (RS | f_ballot(rec.mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin);
                     else
-                        window_general(acc, rec, g0, lane, RS, V, X, so, tgt_ref, tgt_gbin);
-                } else {
-                    (void)long_run(acc, B + off, N, lane, so, tgt_ref, tgt_gbin, bad);
+                        window_general(rec, lane, RS, V, X, so, tgt_ref, tgt_gbin);
+                    off += X;
+                } else {  // a run of 64 records or more: from global memory, at its own pace
+                    const uint32_t end = long_run(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad);
+                    off = end - B < kStageRecs ? bitmap_next(bm_lo, bm_hi, lane, end - B) : kStageRecs;
                 }
-                if (lane == 0u) wins[i] = make_uint4(so.base, so.nf, so.nh, 0u);
-                slot_f += so.nf;
-                slot_h += so.nh;
-                slot_v += so.nv;
-                q0 = q1;
-                q1 = q2;
-                q2 = q3;
-                g0 = g1;
             }
         }
-        if (lane == 0u) slots[slot] = make_uint4(nw, slot_f, slot_h, slot_v);
-        tot_f += slot_f;
-        tot_h += slot_h;
-        tot_v += slot_v;
+        if (lane == 0u) {
+            slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
+            cuts[nw] = make_uint2(so.nf, so.nh);
+            cuts[kSlotWindows - 1u] = make_uint2(nw, 0u);
+        }
+        tot_f += so.nf;
+        tot_h += so.nh;
+        tot_v += so.nv;
     }
     if (lane == 0u) {
         if (tot_h) atomicAdd(&counters[CNT_M], tot_h);
@@ -527,7 +540,7 @@ static uint32_t front_grid(uint32_t nslots) {
 
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint4* win) {
+                      uint2* wcut) {
     const uint32_t ns = front_slots(in.n);
     if (!ns) return;
     FrontRaw a;
@@ -542,16 +555,16 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.bin_width = bin_width;
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
     hipLaunchKernelGGL(k_front<FrontRaw>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref, tgt_gbin,
-                       slots, win);
+                       slots, wcut);
 }
 
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint4* win) {
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut) {
     const uint32_t ns = front_slots(n_upper);
     if (!ns) return;
     FrontSorted a{ident, cref, cgbin};
     hipLaunchKernelGGL(k_front<FrontSorted>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                       tgt_gbin, slots, win);
+                       tgt_gbin, slots, wcut);
 }
 
 }  // namespace slimm

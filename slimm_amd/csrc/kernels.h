@@ -83,21 +83,23 @@ struct DeviceRecords {
 uint32_t num_tiles(uint32_t n);
 
 // ---- front.hip: the single-pass front end of phase A ----
-// A slot = kSlotRecs consecutive records.  The front end works through it in WINDOWS of whole qName runs (<= 64 records,
-// or one run of 64 records or more); window i of slot s is win[s * kSlotWindows + i] = {p, targets, reads, 0}: its
-// targets lie compacted at [p, p + targets) of tgt_ref / tgt_gbin (p = index of the window's first record), per-read
-// values (the selectors of phase B) at [p, p + reads).  slots[s] = {windows, targets, reads, mapped records}.
+// A slot = kSlotRecs consecutive records; its targets (the runs that START in it) lie compacted at
+// [slot.x, slot.x + slot.y) of tgt_ref / tgt_gbin; slot.z = reads (targets with bit 31 of tgt_ref), slot.w = mapped records
 constexpr uint32_t kSlotRecs = 1024;
-constexpr uint32_t kSlotWindows = 2 * (kSlotRecs / 64) + 6;  // two windows in a row cover >= 64 records
+// The front end works through a slot in windows of whole qName runs (<= 64 records, or one run of 64 records or more);
+// wcut[s * kSlotWindows + i] = {targets, reads} of slot s in front of its window i, the entry behind the last window
+// holds the slot's totals and wcut[s * kSlotWindows + kSlotWindows - 1].x the number of windows.  The targets of a
+// window are whole reads: k_filter takes the windows up independently of each other.
+constexpr uint32_t kSlotWindows = 2 * (kSlotRecs / 64) + 6;
 constexpr int kFrontBlock = 256;
 constexpr uint32_t kMaxRefs = (1u << 26) - 1u;      // reference ids fit 26 bits (tagged words of the duplicate test)
 constexpr uint32_t kMaxBins = 0x7ffffff0u;          // global bin indices fit 31 bits (bit 31 of tgt_gbin: unique read)
 uint32_t front_slots(uint32_t n_records);
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint4* win);
+                      uint2* wcut);
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint4* win);
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut);
 
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
@@ -108,8 +110,8 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
 // the direct-atomics fallback of the coverage histograms (too many bins for the LDS tile tables)
-void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, const uint4* win, uint32_t nslots,
-                 const uint32_t* counters, uint32_t* tail, uint32_t* cov, uint32_t* ucov);
+void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, const uint32_t* counters,
+                 uint32_t* tail, uint32_t* cov, uint32_t* ucov);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
                       uint32_t* out, const PackArgs* pack = nullptr);
 // phase B + C(1): one selector per read into sel[] (indexed like the slots' reads: slot.x + k): its uniq_cov2 bin,
@@ -120,7 +122,7 @@ struct FilterArgs {
     const uint32_t* tgt_ref = nullptr;
     const uint32_t* tgt_gbin = nullptr;
     const uint4* slots = nullptr;
-    const uint4* win = nullptr;
+    const uint2* wcut = nullptr;
     uint32_t nslots = 0;
     const void* rows16 = nullptr;
     const uint32_t* level_taxon = nullptr;
@@ -136,8 +138,8 @@ struct FilterArgs {
 };
 void launch_filter(hipStream_t st, const FilterArgs& a);
 // direct-atomics fallback: count the selectors with global atomics instead of the second tile histogram
-void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, const uint4* win, uint32_t nslots,
-                        uint32_t taxon_base, uint32_t* ucov2, uint32_t* lca_count);
+void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
+                        uint32_t* ucov2, uint32_t* lca_count);
 // multi-GPU: [R uniq_reads_count2 | T LCA counts | 2R level marks in 8-bit fields | 1 pair count] from result block B
 void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out);
 // multi-GPU, all-to-all form: this rank received every rank's bitmaps of ITS slice ([n_ranks][2][slice_words] 32-bit
@@ -165,11 +167,10 @@ int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this m
 #endif
 constexpr uint32_t kTileReps = SLIMM_TILE_REPS;
 // the values the bucketing kernels read: one per target (tgt_gbin: bit 31 = unique read) or one per read (the selectors
-// of phase B: 0xffffffff = none), lying in the windows front.hip wrote
+// of phase B: 0xffffffff = none), lying in the slots front.hip wrote
 struct SlotValues {
     const uint32_t* vals = nullptr;
     const uint4* slots = nullptr;
-    const uint4* win = nullptr;
     uint32_t nslots = 0;
     bool per_read = false;
 };

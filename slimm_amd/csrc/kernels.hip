@@ -311,9 +311,9 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
 // of ref, so they are the per-reference bin sums (k_tile_hist / k_ref_stats).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tgt_gbin, const uint4* __restrict__ slots,
-                                                 const uint4* __restrict__ win, uint32_t nslots,
-                                                 const uint32_t* __restrict__ counters, uint32_t* __restrict__ tail,
-                                                 uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
+                                                 uint32_t nslots, const uint32_t* __restrict__ counters,
+                                                 uint32_t* __restrict__ tail, uint32_t* __restrict__ cov,
+                                                 uint32_t* __restrict__ ucov) {
     if (tail && blockIdx.x == 0 && threadIdx.x == 0) {
         tail[0] = counters[CNT_V];
         tail[1] = counters[CNT_M];
@@ -322,14 +322,11 @@ __global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tg
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
     for (uint32_t s = wave; s < nslots; s += n_waves) {
-        const uint32_t nw = slots[s].x;
-        for (uint32_t i = 0; i < nw; ++i) {
-            const uint4 d = win[static_cast<size_t>(s) * kSlotWindows + i];
-            for (uint32_t o = lane; o < d.y; o += 64u) {
-                const uint32_t g = tgt_gbin[d.x + o];
-                atomicAdd(&cov[g & 0x7fffffffu], 1u);
-                if (g >> 31) atomicAdd(&ucov[g & 0x7fffffffu], 1u);
-            }
+        const uint4 d = slots[s];
+        for (uint32_t o = lane; o < d.y; o += 64u) {
+            const uint32_t g = tgt_gbin[d.x + o];
+            atomicAdd(&cov[g & 0x7fffffffu], 1u);
+            if (g >> 31) atomicAdd(&ucov[g & 0x7fffffffu], 1u);
         }
     }
 }
@@ -672,65 +669,59 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 
 constexpr int kFilterBlock = 256;
 
-// A wave takes a slot of the front end and works through its windows (win[]): every window's targets are whole reads,
-// at most 64 of them unless a run of 64 records or more left them, at a place of their own, so the windows are
-// independent of each other and three are in flight per wave: the target words of window i + 2 are being loaded and the
-// lineage rows of window i + 1 gathered while window i is worked on.
+// A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
+// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Four
+// at a time: the target words of all four are loaded together, then their lineage rows gathered together, then the four
+// are worked on -- two memory round trips per four windows instead of two per window.  (No branch around the loads:
+// with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
+// waits for and waits for all of them.)
+constexpr int kFilterBatch = 4;
 template <typename Rows>
 __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,
-                                                         const uint4* __restrict__ slots, const uint4* __restrict__ win,
+                                                         const uint4* __restrict__ slots, const uint2* __restrict__ wcut,
                                                          uint32_t nslots, const Rows rows, const FilterOut out) {
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFilterBlock / 64);
     for (uint32_t slot = blockIdx.x * (kFilterBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint4 d = slots[slot];
-        const uint32_t nw = d.x;
         if (d.y == 0u) continue;
-        const uint4 e = win[static_cast<size_t>(slot) * kSlotWindows + min(lane, kSlotWindows - 1u)];  // lane i: window i
-        const uint32_t e_base = e.x, e_cnt = lane < nw ? e.y : 0u;
-        // stage A (target words loaded), stage B (+ rows gathered) of the two windows behind the one being loaded
-        uint32_t a_w = 0, a_g = 0, a_cnt = 0, a_base = 0;
-        uint32_t b_w = 0, b_g = 0, b_cnt = 0, b_base = 0;
-        typename Rows::Row b_row{};
+        const uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
+        const uint32_t nw = cuts[kSlotWindows - 1u].x;
+        const uint2 ce = cuts[min(lane, nw)];  // lane i: {targets, reads} in front of window i; lanes >= nw: the totals
         bool spans = false;  // some window holds more than 64 targets
-        for (uint32_t i = 0; i < nw + 2u; ++i) {
-            // window i: load its target words
-            uint32_t n_w = 0, n_g = 0, n_cnt = 0, n_base = 0;
-            if (i < nw) {
-                n_cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(e_cnt, i));
-                n_base = static_cast<uint32_t>(__builtin_amdgcn_readlane(e_base, i));
-                if (n_cnt > 64u) {
+        for (uint32_t i0 = 0; i0 < nw; i0 += kFilterBatch) {
+            uint32_t w[kFilterBatch], g[kFilterBatch], cnt[kFilterBatch], selb[kFilterBatch];
+            typename Rows::Row row[kFilterBatch];
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) {
+                const uint32_t i = i0 + u;  // (lanes behind the last window hold the totals: windows of no targets)
+                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, i & 63u));
+                const uint32_t t1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, (i + 1u) & 63u));
+                cnt[u] = i < nw ? t1 - t0 : 0u;
+                selb[u] = d.x + static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.y, i & 63u));
+                if (cnt[u] > 64u) {
                     spans = true;
-                    n_cnt = 0;
+                    cnt[u] = 0;
                 }
-                if (n_cnt) {
-                    const uint32_t t = n_base + min(lane, n_cnt - 1u);
-                    n_w = tgt_ref[t];
-                    n_g = tgt_gbin[t];
-                }
+                const uint32_t t = d.x + min(t0 + lane, d.y - 1u);
+                w[u] = tgt_ref[t];
+                g[u] = tgt_gbin[t];
             }
-            // window i - 1: gather its rows
-            typename Rows::Row n_row{};
-            if (a_cnt) n_row = rows.load(lane < a_cnt ? (a_w & 0x7fffffffu) : 0u);
-            // window i - 2: work
-            if (b_cnt) filter_window(rows, out, lane, b_cnt, b_w, b_g, b_row, b_base);
-            b_w = a_w;
-            b_g = a_g;
-            b_cnt = a_cnt;
-            b_base = a_base;
-            b_row = n_row;
-            a_w = n_w;
-            a_g = n_g;
-            a_cnt = n_cnt;
-            a_base = n_base;
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) row[u] = rows.load(lane < cnt[u] ? (w[u] & 0x7fffffffu) : 0u);
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u)
+                if (cnt[u]) filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], selb[u]);
         }
         if (spans) {
             for (uint32_t i = 0; i < nw; ++i) {
-                const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readlane(e_cnt, i));
-                const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(e_base, i));
-                if (cnt > 64u) filter_span(rows, out, tgt_ref, tgt_gbin, lane, base, base + cnt, base);
+                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, i));
+                const uint32_t t1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, i + 1u));
+                if (t1 - t0 > 64u)
+                    filter_span(rows, out, tgt_ref, tgt_gbin, lane, d.x + t0, d.x + t1,
+                                d.x + static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.y, i)));
             }
         }
     }
@@ -775,10 +766,10 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
                            ref_len, bin_off, half_read, bin_width, ident, cref, cgbin);
 }
 
-void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, const uint4* win, uint32_t nslots,
-                 const uint32_t* counters, uint32_t* tail, uint32_t* cov, uint32_t* ucov) {
+void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, const uint32_t* counters,
+                 uint32_t* tail, uint32_t* cov, uint32_t* ucov) {
     uint32_t blocks = std::max(1u, std::min((nslots + kWaves - 1) / kWaves, 256u * 16u));
-    hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_gbin, slots, win, nslots, counters, tail, cov, ucov);
+    hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_gbin, slots, nslots, counters, tail, cov, ucov);
 }
 
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
@@ -853,31 +844,27 @@ void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, u
 // the selectors counted with global atomics (direct-atomics fallback: no tile histogram): uniq_cov2[g]++ per read that
 // kept one target, lca_count[t]++ per read counted at its LCA
 __global__ __launch_bounds__(kBlock) void k_sel_atomics(const uint32_t* __restrict__ sel, const uint4* __restrict__ slots,
-                                                        const uint4* __restrict__ win, uint32_t nslots, uint32_t taxon_base,
-                                                        uint32_t* __restrict__ ucov2, uint32_t* __restrict__ lca_count) {
+                                                        uint32_t nslots, uint32_t taxon_base, uint32_t* __restrict__ ucov2,
+                                                        uint32_t* __restrict__ lca_count) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
     for (uint32_t s = wave; s < nslots; s += n_waves) {
-        const uint32_t nw = slots[s].x;
-        for (uint32_t i = 0; i < nw; ++i) {
-            const uint4 d = win[static_cast<size_t>(s) * kSlotWindows + i];
-            for (uint32_t o = lane; o < d.z; o += 64u) {
-                const uint32_t v = sel[d.x + o];
-                if (v == 0xffffffffu) continue;
-                if (v < taxon_base)
-                    atomicAdd(&ucov2[v], 1u);
-                else
-                    atomicAdd(&lca_count[v - taxon_base], 1u);
-            }
+        const uint4 d = slots[s];
+        for (uint32_t o = lane; o < d.z; o += 64u) {
+            const uint32_t v = sel[d.x + o];
+            if (v == 0xffffffffu) continue;
+            if (v < taxon_base)
+                atomicAdd(&ucov2[v], 1u);
+            else
+                atomicAdd(&lca_count[v - taxon_base], 1u);
         }
     }
 }
 
-void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, const uint4* win, uint32_t nslots,
-                        uint32_t taxon_base, uint32_t* ucov2, uint32_t* lca_count) {
+void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
+                        uint32_t* ucov2, uint32_t* lca_count) {
     uint32_t blocks = std::max(1u, std::min((nslots + kWaves - 1) / kWaves, 256u * 16u));
-    hipLaunchKernelGGL(k_sel_atomics, dim3(blocks), dim3(kBlock), 0, st, sel, slots, win, nslots, taxon_base, ucov2,
-                       lca_count);
+    hipLaunchKernelGGL(k_sel_atomics, dim3(blocks), dim3(kBlock), 0, st, sel, slots, nslots, taxon_base, ucov2, lca_count);
 }
 
 static uint32_t filter_grid(uint32_t nslots) {
@@ -901,13 +888,13 @@ void launch_filter(hipStream_t st, const FilterArgs& a) {
         r.level_taxon = a.level_taxon;
         for (int i = 0; i < 8; ++i) r.lo.off[i] = a.level_off[i];
         hipLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
-                           a.slots, a.win, a.nslots, r, out);
+                           a.slots, a.wcut, a.nslots, r, out);
     } else {
         Rows32 r;
         r.lin4 = reinterpret_cast<const uint4*>(a.lin_dense);
         r.valid_of = a.valid;
         hipLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
-                           a.slots, a.win, a.nslots, r, out);
+                           a.slots, a.wcut, a.nslots, r, out);
     }
 }
 

@@ -45,33 +45,24 @@ constexpr int kTBlock = 512;
 constexpr uint32_t kTileMask = kTileBins - 1;
 constexpr uint32_t kScanStaged = 16384;  // tiles whose counts k_tile_scan stages in LDS (the one-level bucketing range)
 
-// The bucketing kernels read values that lie in the windows of the front end (front.hip): window i of slot s holds its
-// entries compacted at [w.x, w.x + n) with w = win[s * kSlotWindows + i] and n = w.y (one value per target) or w.z (one
-// value per read).  Workgroup b of g owns a contiguous range of slots -- the SAME range in the count and in the scatter
-// kernel, whose counter copies pair up by workgroup -- and its waves take the slots of that range round robin, 64 entries
-// at a time.
-struct SlotWalk {  // wave-uniform but for the two lane arrays
+// The bucketing kernels read values that lie in slots (front.hip): slot s holds its entries compacted at
+// [slots[s].x, slots[s].x + n) with n = slots[s].y (one value per target) or slots[s].z (one value per read).
+// Workgroup b of g owns a contiguous range of slots -- the SAME range in the count and in the scatter kernel, whose
+// counter copies pair up by workgroup -- and its waves take the slots of that range round robin, 64 entries at a time.
+struct SlotWalk {  // all wave-uniform
     const uint4* slots;
-    const uint4* win;
     uint32_t s, s_end;        // next slot of this wave, end of the workgroup's range
-    uint32_t nw, wi;          // windows of the current slot, next one
-    uint32_t e_base, e_cnt;   // lane i: first entry and number of entries of the current slot's window i
-    uint32_t base, left;      // entries of the current window not yet handed out: [base, base + left)
+    uint32_t base, left;      // entries of the current slot not yet handed out: [base, base + left)
     bool per_read;
 };
 
-__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, const uint4* win, uint32_t nslots, bool per_read) {
+__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read) {
     const uint32_t per_wg = (nslots + gridDim.x - 1) / gridDim.x;
     const uint32_t lo = min(blockIdx.x * per_wg, nslots);
     SlotWalk w;
     w.slots = slots;
-    w.win = win;
     w.s = lo + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.s_end = min(lo + per_wg, nslots);
-    w.nw = 0;
-    w.wi = 0;
-    w.e_base = 0;
-    w.e_cnt = 0;
     w.base = 0;
     w.left = 0;
     w.per_read = per_read;
@@ -81,20 +72,11 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, const uint4* w
 // the next (up to) 64 entries: returns their count (0: the wave has no more), *base = index of the first
 __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
     while (w.left == 0u) {
-        if (w.wi < w.nw) {
-            w.base = static_cast<uint32_t>(__builtin_amdgcn_readlane(w.e_base, w.wi));
-            w.left = static_cast<uint32_t>(__builtin_amdgcn_readlane(w.e_cnt, w.wi));
-            ++w.wi;
-            continue;
-        }
         if (w.s >= w.s_end) return 0u;
-        w.nw = w.slots[w.s].x;  // (a scalar load: one address for the wave)
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint4 e = w.win[static_cast<size_t>(w.s) * kSlotWindows + min(lane, kSlotWindows - 1u)];
-        w.e_base = e.x;
-        w.e_cnt = lane < w.nw ? (w.per_read ? e.z : e.y) : 0u;
-        w.wi = 0;
+        const uint4 d = w.slots[w.s];  // (a scalar load: one address for the wave)
         w.s += kTBlock / 64;
+        w.base = d.x;
+        w.left = w.per_read ? d.z : d.y;
     }
     const uint32_t n = min(w.left, 64u);
     *base = w.base;
@@ -108,8 +90,7 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
 __device__ __forceinline__ uint32_t tile_of(uint32_t v) { return (v & 0x7fffffffu) >> kTileShift; }
 
 __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
-                                                        const uint4* __restrict__ win, uint32_t nslots, int per_read,
-                                                        uint32_t ntiles,
+                                                        uint32_t nslots, int per_read, uint32_t ntiles,
                                                         uint32_t* __restrict__ tile_count_all, uint32_t reps,
                                                         uint32_t rep_stride, const uint32_t* __restrict__ counters,
                                                         uint32_t* __restrict__ tail) {
@@ -125,7 +106,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    SlotWalk w = slot_walk(slots, win, nslots, per_read != 0);
+    SlotWalk w = slot_walk(slots, nslots, per_read != 0);
     while (true) {  // four pieces per trip, their loads in flight together
         uint32_t v[4];
         bool any = false;
@@ -475,8 +456,7 @@ __device__ __forceinline__ void zero_split_tiles(const uint32_t* tile_base, uint
 }
 
 __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
-                                                          const uint4* __restrict__ win, uint32_t nslots, int per_read,
-                                                          uint32_t ntiles,
+                                                          uint32_t nslots, int per_read, uint32_t ntiles,
                                                           const uint32_t* __restrict__ tile_base,
                                                           uint32_t* __restrict__ tile_cursor_all,
                                                           uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
@@ -489,7 +469,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
     const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
     zero_split_tiles(tile_base, ntiles, cov, ucov);
-    SlotWalk walk = slot_walk(slots, win, nslots, per_read != 0);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
     bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
     });
@@ -536,8 +516,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_4096(uint32_t* s, uint32_t* 
 // kernel (10 us per launch, twice per file); workgroup 0 also cuts the buckets into k_tile_hist's work items and lists
 // the split tiles.  tile_cursor must be zero on entry (k_zero).
 __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* __restrict__ vals,
-                                                                const uint4* __restrict__ slots,
-                                                                const uint4* __restrict__ win, uint32_t nslots,
+                                                                const uint4* __restrict__ slots, uint32_t nslots,
                                                                 int per_read, uint32_t* __restrict__ counters,
                                                                 uint32_t ntiles, const uint32_t* __restrict__ tile_count_all,
                                                                 uint32_t* __restrict__ tile_cursor_all,
@@ -616,7 +595,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     zero_split_tiles(s_base, ntiles, cov, ucov);
     __syncthreads();  // the stage (s_base) and s_cnt are handed to the rounds
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + static_cast<size_t>(my_rep) * rep_stride;
-    SlotWalk walk = slot_walk(slots, win, nslots, per_read != 0);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
     bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
         scatter_round_ordered(v, ntiles, s_mine, tile_cursor, bucket, s_cnt, s_loff, s_stage, s_wtot);
     });
@@ -625,8 +604,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
 // two levels, level 1: values go to their SUPER tile (64 tiles = 512 K bins) as 32-bit words (19-bit bin-in-super |
 // unique bit): few destinations per workgroup, long runs
 __global__ __launch_bounds__(kTBlock) void k_part_super(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
-                                                        const uint4* __restrict__ win, uint32_t nslots, int per_read,
-                                                        uint32_t ntiles,
+                                                        uint32_t nslots, int per_read, uint32_t ntiles,
                                                         const uint32_t* __restrict__ tile_base,
                                                         uint32_t* __restrict__ sup_cursor, uint32_t* __restrict__ mid,
                                                         uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
@@ -634,7 +612,7 @@ __global__ __launch_bounds__(kTBlock) void k_part_super(const uint32_t* __restri
     __shared__ uint32_t s_more[kTBlock / 64];
     const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
     zero_split_tiles(tile_base, ntiles, cov, ucov);
-    SlotWalk walk = slot_walk(slots, win, nslots, per_read != 0);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
     bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
         for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) s_cur[i] = 0;
         __syncthreads();
@@ -952,7 +930,7 @@ int tile_hist_setup(uint32_t ntiles) {
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* counters,
                        uint32_t* tail, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
     hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots,
-                       in.win, in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, counters, tail);
+                       in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, counters, tail);
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
@@ -972,11 +950,11 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
                          const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride) {
     if (!two_level) {
         const size_t lds = static_cast<size_t>(ntiles) * 4;
-        hipLaunchKernelGGL(k_tile_scatter, dim3(grid), dim3(kTBlock), lds, st, in.vals, in.slots, in.win, in.nslots,
+        hipLaunchKernelGGL(k_tile_scatter, dim3(grid), dim3(kTBlock), lds, st, in.vals, in.slots, in.nslots,
                            in.per_read ? 1 : 0, ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
         return;
     }
-    hipLaunchKernelGGL(k_part_super, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.win, in.nslots, in.per_read ? 1 : 0,
+    hipLaunchKernelGGL(k_part_super, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots, in.per_read ? 1 : 0,
                        ntiles, tile_base, sup_cursor, mid, cov, ucov);
     hipLaunchKernelGGL(k_part_tile, dim3(part_items_upper(ntiles, n_upper)), dim3(kTBlock), 0, st, mid, items2, counters,
                        tile_base, tile_cursor, ntiles, bucket);
@@ -987,7 +965,7 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
 void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
                                const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
                                uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles) {
-    hipLaunchKernelGGL(k_tile_scatter_fused, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.win, in.nslots,
+    hipLaunchKernelGGL(k_tile_scatter_fused, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots,
                        in.per_read ? 1 : 0, counters, ntiles, tile_count, tile_cursor, bucket, cov, ucov, rep_stride, items,
                        split_tiles);
 }

@@ -118,6 +118,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
     DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
     DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
+    DevBuf<uint4> tot_part;              // per workgroup of k_tile_count: totals of its slots (kernels.h: Totals)
     DevBuf<uint2> tile_cnt;              // (record_order = ANY: mapped records per tile of the compaction)
     DevBuf<uint4> scan_sums;             // chunk sums of the multi-workgroup tile scan
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
@@ -277,6 +278,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
     HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
     HIP_TRY(c, c->wcut.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
+    HIP_TRY(c, c->tot_part.ensure(512));
     HIP_TRY(c, c->sel.ensure(n + 1));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
@@ -663,18 +665,22 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, targets, c->counters.p, c->tail(), c->tile_count.p, c->treps, c->tstride);
+            launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride);
         }
+        Totals tot;
+        tot.part = c->tot_part.p;
+        tot.nparts = grid;
+        tot.tail = c->tail();
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER);
             launch_tile_scatter_fused(st, grid, c->ntiles, targets, c->counters.p, c->tile_count.p, c->tile_cursor.p,
-                                      c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p, c->split_tiles.p);
+                                      c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p, c->split_tiles.p, tot);
         } else {
             {
                 KernelTimer t(c, K_TILE_SCAN);
                 launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
                                  c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                                 c->two_level);
+                                 c->two_level, tot);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER);
@@ -701,7 +707,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
     } else {
         KernelTimer t(c, K_HIST);
-        launch_hist(st, c->tgt_gbin.p, c->slots.p, nslots, c->counters.p, c->tail(), c->cov(), c->ucov());
+        launch_hist(st, c->tgt_gbin.p, c->slots.p, nslots, c->counters.p, c->tail(), c->cov(), c->ucov(),
+                    c->order != SLIMM_ORDER_ANY);
         c->binsA_stored = true;
     }
     HIP_TRY(c, hipGetLastError());
@@ -1003,7 +1010,7 @@ int slimm_filter_alignments(slimm_ctx* c) {
             const uint32_t grid = 512;
             {
                 KernelTimer t(c, K_TILE_COUNT2);
-                launch_tile_count(st, grid, c->ntiles2, selectors, c->counters.p, nullptr, c->tile_count.p, c->treps,
+                launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps,
                                   c->tstride);
             }
             if (c->fused_scan) {

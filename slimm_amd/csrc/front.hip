@@ -428,7 +428,6 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
     const uint32_t n_waves = gridDim.x * (kFrontBlock / 64);
     uint32_t* const st1 = s_stage[wave][0];
     uint32_t* const st2 = s_stage[wave][1];
-    uint32_t tot_f = 0, tot_h = 0, tot_v = 0;
     bool bad = false;
     for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint32_t B = slot * kSlotRecs;
@@ -453,11 +452,14 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
                         acc.key_at(i, klo[u], khi[u]);
                         raw[u] = acc.raw(i);
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // (all the group's loads before the first use of one: left to itself
+                                                        // the scheduler pairs every load with its use, a round trip each)
 #pragma unroll
                     for (uint32_t u = 0; u < kStageGroup; ++u) {
                         if (j0 + u >= kSlotBlocks) break;
                         geo[u] = acc.geo_of(raw[u]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (uint32_t u = 0; u < kStageGroup; ++u) {
                         const uint32_t j = j0 + u;
@@ -477,7 +479,10 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
                     }
                 }
             }
-            // ---- 2 + 3. windows: cut at the bitmap, classified from the staged words
+            // ---- 2 + 3. windows: cut at the bitmap, classified from the staged words.  (Every load has landed by now; said
+            // aloud, so that the compiler does not make each window wait for the stores of the window before it on behalf
+            // of a register some load of the staging loop once wrote.)
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
             uint32_t off = bitmap_next(bm_lo, bm_hi, lane, 0u);
             so.base = B + min(off, kSlotRecs);
             while (off < kSlotRecs) {
@@ -506,6 +511,7 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
                     off += X;
                 } else {  // a run of 64 records or more: from global memory, at its own pace
                     const uint32_t end = long_run(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
                     off = end - B < kStageRecs ? bitmap_next(bm_lo, bm_hi, lane, end - B) : kStageRecs;
                 }
             }
@@ -515,15 +521,9 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
             cuts[nw] = make_uint2(so.nf, so.nh);
             cuts[kSlotWindows - 1u] = make_uint2(nw, 0u);
         }
-        tot_f += so.nf;
-        tot_h += so.nh;
-        tot_v += so.nv;
     }
-    if (lane == 0u) {
-        if (tot_h) atomicAdd(&counters[CNT_M], tot_h);
-        if (tot_f) atomicAdd(&counters[CNT_P], tot_f);
-        if (Acc::kCountsMapped && tot_v) atomicAdd(&counters[CNT_V], tot_v);
-    }
+    // (No totals here: thousands of waves adding to the same three counters are as many memory-side atomics in a row,
+    // ~40 ns each -- 0.3 ms at the end of a 0.1 ms kernel.  The first consumer of the slots sums their counts.)
     if (__any(bad) && lane == 0u) atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_REF_RANGE));
 }
 

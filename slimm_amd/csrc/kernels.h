@@ -110,8 +110,10 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
                     uint32_t* cgbin);
 // the direct-atomics fallback of the coverage histograms (too many bins for the LDS tile tables)
-void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, const uint32_t* counters,
-                 uint32_t* tail, uint32_t* cov, uint32_t* ucov);
+// (also adds the stream's totals to counters[CNT_M / CNT_P] -- and [CNT_V] when count_mapped: the compaction of the
+// sort path has counted the mapped records already -- and to tail[0..2]; all zero on entry)
+void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, uint32_t* counters,
+                 uint32_t* tail, uint32_t* cov, uint32_t* ucov, bool count_mapped);
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,
                       uint32_t* out, const PackArgs* pack = nullptr);
 // phase B + C(1): one selector per read into sel[] (indexed like the slots' reads: slot.x + k): its uniq_cov2 bin,
@@ -174,9 +176,17 @@ struct SlotValues {
     uint32_t nslots = 0;
     bool per_read = false;
 };
-// tail != nullptr: workgroup 0 also copies the totals {mapped records, reads, targets} there (multi-GPU scalars)
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* counters,
-                       uint32_t* tail, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
+// The front end leaves the totals of the stream {mapped records, reads, targets} to its consumers (thousands of waves
+// adding to three counters would be as many memory-side atomics in a row): launch_tile_count with part != nullptr
+// writes one partial sum per workgroup (part[grid]), and the scan that follows (launch_tile_scan or
+// launch_tile_scatter_fused, given the same part) adds them up into counters[CNT_V / CNT_M / CNT_P] and tail[0..2].
+struct Totals {
+    const uint4* part = nullptr;
+    uint32_t nparts = 0;
+    uint32_t* tail = nullptr;  // may be null
+};
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
+                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
 constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
 constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile
@@ -187,7 +197,8 @@ uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper);
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level);
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level,
+                      const Totals& tot = Totals());
 // bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const SlotValues& in,
@@ -210,7 +221,8 @@ struct BitsLayout {
 constexpr uint32_t kFusedScanTiles = 4064;  // (4096 table entries less the room three small arrays take: tile_hist.hip)
 void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
                                const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
-                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles);
+                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles,
+                               const Totals& tot = Totals());
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
                       uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,

@@ -311,23 +311,37 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
 // of ref, so they are the per-reference bin sums (k_tile_hist / k_ref_stats).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_hist(const uint32_t* __restrict__ tgt_gbin, const uint4* __restrict__ slots,
-                                                 uint32_t nslots, const uint32_t* __restrict__ counters,
+                                                 uint32_t nslots, uint32_t* __restrict__ counters,
                                                  uint32_t* __restrict__ tail, uint32_t* __restrict__ cov,
-                                                 uint32_t* __restrict__ ucov) {
-    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {
-        tail[0] = counters[CNT_V];
-        tail[1] = counters[CNT_M];
-        tail[2] = counters[CNT_P];
-    }
+                                                 uint32_t* __restrict__ ucov, int count_mapped) {
+    __shared__ uint32_t s_tot[3];
+    if (threadIdx.x < 3) s_tot[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
+    uint32_t sum_f = 0, sum_h = 0, sum_v = 0;
     for (uint32_t s = wave; s < nslots; s += n_waves) {
         const uint4 d = slots[s];
+        sum_f += d.y;
+        sum_h += d.z;
+        sum_v += d.w;
         for (uint32_t o = lane; o < d.y; o += 64u) {
             const uint32_t g = tgt_gbin[d.x + o];
             atomicAdd(&cov[g & 0x7fffffffu], 1u);
             if (g >> 31) atomicAdd(&ucov[g & 0x7fffffffu], 1u);
         }
+    }
+    // the stream's totals (the front end leaves them to the consumer of its slots): one set of atomics per workgroup
+    if (lane == 0u) {
+        atomicAdd(&s_tot[0], sum_v);
+        atomicAdd(&s_tot[1], sum_h);
+        atomicAdd(&s_tot[2], sum_f);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && s_tot[threadIdx.x]) {
+        const int slot = threadIdx.x == 0 ? CNT_V : threadIdx.x == 1 ? CNT_M : CNT_P;
+        if (threadIdx.x != 0 || count_mapped) atomicAdd(&counters[slot], s_tot[threadIdx.x]);
+        if (tail) atomicAdd(&tail[threadIdx.x], s_tot[threadIdx.x]);
     }
 }
 
@@ -766,10 +780,11 @@ void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, co
                            ref_len, bin_off, half_read, bin_width, ident, cref, cgbin);
 }
 
-void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, const uint32_t* counters,
-                 uint32_t* tail, uint32_t* cov, uint32_t* ucov) {
+void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, uint32_t* counters,
+                 uint32_t* tail, uint32_t* cov, uint32_t* ucov, bool count_mapped) {
     uint32_t blocks = std::max(1u, std::min((nslots + kWaves - 1) / kWaves, 256u * 16u));
-    hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_gbin, slots, nslots, counters, tail, cov, ucov);
+    hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(kBlock), 0, st, tgt_gbin, slots, nslots, counters, tail, cov, ucov,
+                       count_mapped ? 1 : 0);
 }
 
 void launch_ref_stats(hipStream_t st, const uint32_t* a, const uint32_t* b, const uint32_t* bin_off, uint32_t n_refs,

@@ -53,6 +53,7 @@ struct SlotWalk {  // all wave-uniform
     const uint4* slots;
     uint32_t s, s_end;        // next slot of this wave, end of the workgroup's range
     uint32_t base, left;      // entries of the current slot not yet handed out: [base, base + left)
+    uint32_t sum_f, sum_h, sum_v;  // targets, reads and mapped records of the slots taken so far
     bool per_read;
 };
 
@@ -65,6 +66,7 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslot
     w.s_end = min(lo + per_wg, nslots);
     w.base = 0;
     w.left = 0;
+    w.sum_f = w.sum_h = w.sum_v = 0;
     w.per_read = per_read;
     return w;
 }
@@ -77,6 +79,9 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
         w.s += kTBlock / 64;
         w.base = d.x;
         w.left = w.per_read ? d.z : d.y;
+        w.sum_f += d.y;
+        w.sum_h += d.z;
+        w.sum_v += d.w;
     }
     const uint32_t n = min(w.left, 64u);
     *base = w.base;
@@ -92,14 +97,10 @@ __device__ __forceinline__ uint32_t tile_of(uint32_t v) { return (v & 0x7fffffff
 __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
                                                         uint32_t nslots, int per_read, uint32_t ntiles,
                                                         uint32_t* __restrict__ tile_count_all, uint32_t reps,
-                                                        uint32_t rep_stride, const uint32_t* __restrict__ counters,
-                                                        uint32_t* __restrict__ tail) {
+                                                        uint32_t rep_stride, uint4* __restrict__ part) {
     HIP_DYNAMIC_SHARED(uint32_t, s_hist)
-    if (tail && blockIdx.x == 0 && threadIdx.x == 0) {  // the additive scalars that travel with the bins (multi-GPU)
-        tail[0] = counters[CNT_V];
-        tail[1] = counters[CNT_M];
-        tail[2] = counters[CNT_P];
-    }
+    __shared__ uint32_t s_sum[3];
+    if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
     // 512 workgroups adding to the same 2.4 K counters serialise in the memory-side atomic units: every workgroup adds to
     // one of `reps` copies instead, and k_tile_scan sums the copies
     uint32_t* __restrict__ tile_count = tile_count_all + static_cast<size_t>(blockIdx.x % reps) * rep_stride;
@@ -122,10 +123,45 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
         for (int u = 0; u < 4; ++u)
             if (v[u] != 0xffffffffu) atomicAdd(&s_hist[tile_of(v[u])], 1u);
     }
+    if (part && lane == 0u) {  // the totals of this workgroup's slots (the front end leaves them to its first consumer)
+        atomicAdd(&s_sum[0], w.sum_v);
+        atomicAdd(&s_sum[1], w.sum_h);
+        atomicAdd(&s_sum[2], w.sum_f);
+    }
     __syncthreads();
+    if (part && threadIdx.x == 0) part[blockIdx.x] = make_uint4(s_sum[0], s_sum[1], s_sum[2], 0u);
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
         uint32_t h = s_hist[i];
         if (h) atomicAdd(&tile_count[i], h);
+    }
+}
+
+// the totals {mapped records, reads, targets} of the stream from the per-workgroup sums k_tile_count left: into the
+// counter block (from where they reach the host) and the scalars that travel with the bins (multi-GPU)
+__device__ __forceinline__ void publish_totals(const uint4* __restrict__ part, uint32_t nparts, uint32_t* __restrict__ counters,
+                                               uint32_t* __restrict__ tail, uint32_t* s_tot) {
+    if (threadIdx.x < 3) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t v = 0, h = 0, f = 0;
+    for (uint32_t i = threadIdx.x; i < nparts; i += blockDim.x) {
+        const uint4 p = part[i];
+        v += p.x;
+        h += p.y;
+        f += p.z;
+    }
+    if (v) atomicAdd(&s_tot[0], v);
+    if (h) atomicAdd(&s_tot[1], h);
+    if (f) atomicAdd(&s_tot[2], f);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        counters[CNT_V] = s_tot[0];
+        counters[CNT_M] = s_tot[1];
+        counters[CNT_P] = s_tot[2];
+        if (tail) {
+            tail[0] = s_tot[0];
+            tail[1] = s_tot[1];
+            tail[2] = s_tot[2];
+        }
     }
 }
 
@@ -137,9 +173,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
                                                     uint4* __restrict__ items, uint32_t* __restrict__ counters,
                                                     uint4* __restrict__ items2, uint32_t* __restrict__ sup_cursor,
                                                     uint32_t* __restrict__ split_tiles, uint32_t reps,
-                                                    uint32_t rep_stride, int two_level) {
+                                                    uint32_t rep_stride, int two_level, const uint4* __restrict__ part,
+                                                    uint32_t nparts, uint32_t* __restrict__ tail) {
     __shared__ uint2 s_part[1024];
     __shared__ uint32_t s_nsplit;
+    __shared__ uint32_t s_tot[3];
+    if (part) publish_totals(part, nparts, counters, tail, s_tot);
     __shared__ uint32_t s_cnt[kScanStaged];  // (<= 16 K tiles) a tile's total over the copies, then its base
     if (threadIdx.x == 0) s_nsplit = 0;
     const uint32_t tid = threadIdx.x;
@@ -522,7 +561,9 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
                                                                 uint32_t* __restrict__ tile_cursor_all,
                                                                 uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
                                                                 uint32_t* __restrict__ ucov, uint32_t rep_stride,
-                                                                uint4* __restrict__ items, uint32_t* __restrict__ split_tiles) {
+                                                                uint4* __restrict__ items, uint32_t* __restrict__ split_tiles,
+                                                                const uint4* __restrict__ part, uint32_t nparts,
+                                                                uint32_t* __restrict__ tail) {
     // 80 KiB of LDS to the byte, so that two workgroups share a CU: the three small arrays live in the tail of s_mine,
     // whose entries from ntiles on are never read (the launcher admits at most kFusedScanTiles = 4064 tiles)
     __shared__ uint32_t s_stage[kRoundCap];          // the ordered round's stage; before the rounds: the tile totals and
@@ -567,6 +608,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     __syncthreads();
     // (tiles beyond ntiles have count 0: their base is the grand total, so base[i + 1] - base[i] is right for every i < ntiles)
     if (blockIdx.x == 0) {  // work items of k_tile_hist: <= kTileSub entries of one tile each; an empty tile still gets one
+        if (part) publish_totals(part, nparts, counters, tail, s_loff);  // (s_loff is free until the first round)
         uint32_t* s_piece = s_cnt;  // (free until the first round) pieces per tile, then their exclusive scan
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -927,17 +969,17 @@ int tile_hist_setup(uint32_t ntiles) {
     return 0;
 }
 
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* counters,
-                       uint32_t* tail, uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
+void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
+                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
     hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots,
-                       in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, counters, tail);
+                       in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, part);
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level) {
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level, const Totals& tot) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters,
-                       items2, sup_cursor, split_tiles, reps, rep_stride, two_level ? 1 : 0);
+                       items2, sup_cursor, split_tiles, reps, rep_stride, two_level ? 1 : 0, tot.part, tot.nparts, tot.tail);
 }
 
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
@@ -964,10 +1006,11 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
 // the counters / cursors in use); tile_cursor must be zero.  counters is written (work item and split-tile counts).
 void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
                                const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
-                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles) {
+                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles,
+                               const Totals& tot) {
     hipLaunchKernelGGL(k_tile_scatter_fused, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots,
                        in.per_read ? 1 : 0, counters, ntiles, tile_count, tile_cursor, bucket, cov, ucov, rep_stride, items,
-                       split_tiles);
+                       split_tiles, tot.part, tot.nparts, tot.tail);
 }
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }

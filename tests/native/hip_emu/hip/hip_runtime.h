@@ -126,6 +126,8 @@ static inline void __syncthreads() { ::hipemu::block_barrier(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 static inline void __builtin_amdgcn_fence(int, const char*) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
 
 // ------------------------------------------------------------------------------------------------ wave collectives
 static inline uint64_t __builtin_amdgcn_ballot_w64(bool p) {

@@ -100,7 +100,8 @@ struct slimm_ctx {
     DevBuf<uint2> d_geo;              // {contig length, first bin} per reference: one gather in k_emit
     DevBuf<uint8_t> d_valid;
     DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
-    DevBuf<uint32_t> d_level_taxon;
+    DevBuf<uint32_t> d_level_taxon;    // [(level << taxon_shift) | index] -> dense taxon
+    uint32_t taxon_shift = 0;
     PinBuf<uint4> h_rows16;
     bool rows16_base_ready = false;    // h_rows16 holds the static part of every row
     std::vector<uint32_t> rows16_prev; // references whose valid bit is set in h_rows16
@@ -414,10 +415,20 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         const char* wide_rows = getenv("SLIMM_WIDE_ROWS");
         cc->use_rows16 = c->host->rows16_ok() && !(wide_rows && wide_rows[0] == '1');
         if (cc->use_rows16) {
+            // the dense taxon of a (level, index): one table with a power-of-two stride per level, so that a lane turns
+            // its (level, index) into an address with one shift-or
             const std::vector<uint32_t>& lt = c->host->level_taxon();
+            const uint32_t* off = c->host->level_offset();
+            uint32_t widest = 1;
+            for (int l = 0; l < 8; ++l) widest = std::max(widest, off[l + 1] - off[l]);
+            cc->taxon_shift = 0;
+            while ((1u << cc->taxon_shift) < widest) ++cc->taxon_shift;
+            std::vector<uint32_t> flat(static_cast<size_t>(8) << cc->taxon_shift, 0u);
+            for (int l = 0; l < 8; ++l)
+                for (uint32_t i = off[l]; i < off[l + 1]; ++i) flat[(static_cast<size_t>(l) << cc->taxon_shift) + (i - off[l])] = lt[i];
             if (cc->d_rows16.ensure(c->R) != hipSuccess || cc->h_rows16.ensure(c->R) != hipSuccess ||
-                cc->d_level_taxon.ensure(lt.size() + 1) != hipSuccess ||
-                hipMemcpy(cc->d_level_taxon.p, lt.data(), lt.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                cc->d_level_taxon.ensure(flat.size()) != hipSuccess ||
+                hipMemcpy(cc->d_level_taxon.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
         }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
@@ -982,8 +993,8 @@ int slimm_filter_alignments(slimm_ctx* c) {
             fa.nslots = nslots;
             if (c->use_rows16) {
                 fa.rows16 = c->d_rows16.p;
-                fa.level_taxon = c->d_level_taxon.p;
-                fa.level_off = h.level_offset();
+                fa.taxon_flat = c->d_level_taxon.p;
+                fa.taxon_shift = c->taxon_shift;
             } else {
                 fa.lin_dense = c->d_lin_dense.p;
                 fa.valid = c->d_valid.p;

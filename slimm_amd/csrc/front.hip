@@ -54,11 +54,14 @@ namespace slimm {
 
 namespace {
 
-constexpr uint32_t kTagShift = 26;                       // reference ids are below 2^26 (slimm_create checks)
-constexpr uint32_t kRefField = (1u << kTagShift) - 1u;   // ... so this value names no reference
+constexpr uint32_t kTagShift = 26;                       // a staged record's low 26 bits: reference + 1 (slimm_create
+constexpr uint32_t kRefField = (1u << kTagShift) - 1u;   // keeps n_refs <= 2^26 - 2), all ones for an unmapped record
 constexpr uint32_t kNoMatch = 0xffffffffu;               // shifted in at lane 0: equals no tagged word
-constexpr uint32_t kSlotBlocks = kSlotRecs / 64 + 1;     // key blocks of a slot's bitmap: one more than the slot, so
-                                                         // that a window starting in the slot's last record is covered
+constexpr uint32_t kStMateShift = 26;                    // ... bits 26-27: mate number
+constexpr uint32_t kStRunStart = 1u << 31;               // ... bit 31: the record starts a qName run
+constexpr uint32_t kSlotBlocks = kSlotRecs / 64 + 1;     // blocks of 64 records staged per slot: one more than the slot,
+                                                         // so that a window starting in the slot's last record is covered
+static_assert(kMaxRefs < kRefField, "reference + 1 must stay below the unmapped marker");
 
 __device__ __forceinline__ uint32_t f_lane() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -75,15 +78,12 @@ __device__ __forceinline__ bool f_bit(uint64_t wave_uniform_mask) {  // this lan
 __device__ __forceinline__ uint32_t f_shr1(uint32_t v, uint32_t lane0) {
     return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
 }
+// the value of the lane before, zero at lane 0 (the form the compiler folds into the instruction that uses it)
+__device__ __forceinline__ uint32_t f_shr1z(uint32_t v) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0x138, 0xf, 0xf, true);
+}
 __device__ __forceinline__ uint32_t f_ror1(uint32_t v) {  // lane i gets lane i - 1, lane 0 gets lane 63
     return __builtin_amdgcn_update_dpp(v, v, 0x13c, 0xf, 0xf, false);
-}
-// the 64-bit value lane `l` holds in (lo, hi).  (__builtin_amdgcn_readlane returns a signed int: unless the low half
-// goes through uint32_t, its bit 31 smears over the high half.)
-__device__ __forceinline__ uint64_t f_read64(uint32_t lo, uint32_t hi, uint32_t l) {
-    const uint32_t a = static_cast<uint32_t>(__builtin_amdgcn_readlane(lo, l));
-    const uint32_t b = static_cast<uint32_t>(__builtin_amdgcn_readlane(hi, l));
-    return (static_cast<uint64_t>(b) << 32) | a;
 }
 __device__ __forceinline__ uint64_t f_below(uint32_t n) {  // lanes 0 .. n-1 (n <= 64)
     return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
@@ -108,6 +108,15 @@ struct FrontRec {  // what a window needs of a record besides its place in a run
 struct FrontRaw3 {  // the three words a window loads per record, as they come from memory
     uint32_t a, b, c;
 };
+struct FrontLoaded {  // a record as the staging loop loads it: key halves and the three words
+    uint32_t klo, khi, a, b, c;
+};
+// element `byte_off / sizeof(T)` behind a wave-uniform pointer: a scalar base and ONE 32-bit lane offset per load
+// instead of a 64-bit address computed per lane and array
+template <typename T>
+__device__ __forceinline__ T f_load_at(const T* uniform_base, uint32_t byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
+}
 
 struct FrontRaw {
     const uint64_t* key;
@@ -126,6 +135,38 @@ struct FrontRaw {
     }
     __device__ FrontRaw3 raw(uint32_t i) const {
         return FrontRaw3{flag[i], static_cast<uint32_t>(ref[i]), static_cast<uint32_t>(pos[i])};
+    }
+    // ---- the staging loop's view: record base + rel (base wave-uniform)
+    __device__ void load(uint32_t base, uint32_t rel, FrontLoaded& o) const {
+        const uint2 k = f_load_at(reinterpret_cast<const uint2*>(key) + base, rel * 8u);
+        o.klo = k.x;
+        o.khi = k.y;  // (nothing but loads here: key_fix below, once the whole group is on its way)
+        o.a = f_load_at(flag + base, rel * 2u);
+        o.b = static_cast<uint32_t>(f_load_at(ref + base, rel * 4u));
+        o.c = static_cast<uint32_t>(f_load_at(pos + base, rel * 4u));
+    }
+    __device__ void load_key(uint32_t base, uint32_t rel, uint32_t& lo, uint32_t& hi) const {
+        const uint2 k = f_load_at(reinterpret_cast<const uint2*>(key) + base, rel * 8u);
+        lo = k.x;
+        hi = k.y;
+    }
+    __device__ static void key_fix(uint32_t&, uint32_t& hi) { hi &= 0x3fffffffu; }  // qName identity: 62 bits
+    __device__ static void no_key(uint32_t& lo, uint32_t& hi) {  // differs from every key (bit 62 is not significant)
+        lo = 0u;
+        hi = 0x40000000u;
+    }
+    __device__ uint2 geo_at(const FrontLoaded& w) const { return f_load_at(geo, (w.b < n_refs ? w.b : 0u) * 8u); }
+    // field = reference + 1 of a mapped record (src/slimm.hpp:197), kRefField otherwise; mate: src/slimm.hpp:205-208
+    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, bool& bad) const {
+        const bool aligned = (w.a & 0x4u) == 0u;
+        const uint32_t r1 = w.b + 1u;
+        bad = bad || (aligned && r1 > n_refs);  // neither -1 nor a reference
+        field = (aligned && w.b < n_refs) ? r1 : kRefField;
+        const uint32_t c = (w.a >> 6) & 3u;     // first-in-pair wins over last-in-pair
+        mate = c == 3u ? 1u : c;
+    }
+    __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2& g) const {
+        return g.y + div_bin_width(min(w.c + half_read, g.x));
     }
     __device__ FrontRec decode(const FrontRaw3& w, bool& bad) const {
         FrontRec o;
@@ -173,6 +214,30 @@ struct FrontSorted {
     __device__ FrontRec rec(uint32_t i, bool& bad) const { return decode(raw(i), bad); }
     __device__ uint2 geo_of(const FrontRaw3&) const { return make_uint2(0u, 0u); }
     __device__ uint32_t gbin(const FrontRec& r, const uint2&) const { return r.aux; }
+    __device__ void load(uint32_t base, uint32_t rel, FrontLoaded& o) const {
+        const uint2 k = f_load_at(reinterpret_cast<const uint2*>(ident) + base, rel * 8u);
+        o.klo = k.x;
+        o.khi = k.y;
+        o.a = k.x;
+        o.b = f_load_at(cref + base, rel * 4u);
+        o.c = f_load_at(cgbin + base, rel * 4u);
+    }
+    __device__ void load_key(uint32_t base, uint32_t rel, uint32_t& lo, uint32_t& hi) const {
+        const uint2 k = f_load_at(reinterpret_cast<const uint2*>(ident) + base, rel * 8u);
+        lo = k.x;
+        hi = k.y;
+    }
+    __device__ static void key_fix(uint32_t& lo, uint32_t&) { lo &= ~3u; }  // (the mate number rides in the low bits)
+    __device__ static void no_key(uint32_t& lo, uint32_t& hi) {  // (the low two bits of every key's low word are clear)
+        lo = 1u;
+        hi = 0u;
+    }
+    __device__ uint2 geo_at(const FrontLoaded&) const { return make_uint2(0u, 0u); }
+    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, bool&) const {
+        field = w.b + 1u;
+        mate = w.a & 3u;
+    }
+    __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2&) const { return w.c; }
 };
 
 namespace {
@@ -182,54 +247,48 @@ struct WinOut {  // where the slot's targets go and what it has counted so far (
     uint32_t nf, nh, nv;      // targets, reads, mapped records
 };
 
-// the two words staged per record
-constexpr uint32_t kStMateShift = 26, kStMapped = 1u << 28;
-__device__ __forceinline__ uint32_t stage_word(const FrontRec& r) {
-    return (r.ref & kRefField) | (r.mate << kStMateShift) | (r.mapped ? kStMapped : 0u);
-}
-struct Staged {  // a record as the windows see it
+// a record as the general path sees it
+struct Staged {
     uint32_t mate, ref, gbin;
     bool mapped;
 };
-__device__ __forceinline__ Staged unstage(uint32_t w1, uint32_t w2) {
-    return Staged{(w1 >> kStMateShift) & 3u, w1 & kRefField, w2, (w1 & kStMapped) != 0u};
-}
 
 // ---------------------------------------------------------------------------------------------------------
-// fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  SS = segment starts (run starts and
-// mate changes), V = mapped lanes, both inside [0, X).
+// fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  field = the staged reference field,
+// SS = segment starts (run starts and mate changes), V = mapped lanes, both inside [0, X).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void window_fast(const Staged& rec, uint32_t lane, uint64_t SS, uint64_t V, uint32_t X, WinOut& so,
-                                            uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
-    const bool use = f_bit(V);
-    // segment start of this lane: the highest start at or below it
-    const uint64_t le = (2ull << lane) - 1ull;
-    const uint32_t from = 63u - static_cast<uint32_t>(__builtin_clzll((SS & le) | 1ull));
-    const uint32_t T = use ? ((from << kTagShift) | rec.ref) : ((lane << kTagShift) | kRefField);
-    const uint32_t dist = use ? lane - from : 0u;
-    // Q1: an earlier lane of my segment with my reference?  Four steps per trip; the trip count follows the longest
-    // segment of THIS window
-    uint32_t Ts = T, differ = kNoMatch;  // minimum over the steps of (shifted ^ mine): 0 <=> a duplicate
-    for (uint32_t d = 1; f_ballot(dist >= d) != 0ull; d += 4) {
+__device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint32_t lane, uint64_t SS, uint64_t V, uint32_t X,
+                                            WinOut& so, uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
+    // Q1: an earlier lane of my segment with my reference?  T = {segment number, field} is never zero and equal only
+    // inside a segment; x_d[i] = T[i - d] ^ T[i] (T of the lanes in front of lane 0 taken as zero) follows from
+    // x_{d+1}[i] = x_d[i - 1] ^ x_1[i]: ONE xor with a lane shift per step.  A lane is a duplicate iff some x_d is zero.
+    // Steps beyond a lane's own segment compare it with other segments' words -- never equal, so nothing guards them;
+    // the trip count follows the longest segment of THIS window (scalar: D = lanes at least d behind their start).
+    const uint32_t T = (f_rank(SS >> 1) << kTagShift) | field;
+    const uint32_t x1 = f_shr1z(T) ^ T;
+    uint32_t x = x1, differ = x1;
+    const uint64_t N0 = ~SS & f_below(X);
+    uint64_t D = N0 & (N0 << 1);
+    while (D) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            Ts = f_shr1(Ts, kNoMatch);
-            differ = min(differ, Ts ^ T);
+            x = f_shr1z(x) ^ x1;
+            differ = min(differ, x);
+            D &= D << 1;
         }
     }
-    const bool first = use && differ != 0u;
-    const uint64_t F = f_ballot(first);
+    const uint64_t F = f_ballot(differ != 0u) & V;
     // heads: the first mapped lane of every segment; the last lane of a segment stops the carry of its start
     const uint64_t H = f_first_after(SS, V, (SS >> 1) | (1ull << (X - 1u)));
     // unique reads: a head whose NEXT target is a head again (or there is none in the window: the next run's first
     // target is a head).  In bit-reversed order "the target in front of g" is "the first target above g".
     const uint64_t Fr = __builtin_bitreverse64(F), Gr = __builtin_bitreverse64(F & ~H);
     const uint64_t U = H & ~__builtin_bitreverse64((~Fr + (Gr << 1)) & Fr);
-    const bool hbit = f_bit(H), ubit = f_bit(U);
-    if (first) {
-        const uint32_t p = so.base + so.nf + f_rank(F);
-        tgt_ref[p] = rec.ref | (hbit ? 0x80000000u : 0u);
-        tgt_gbin[p] = rec.gbin | (ubit ? 0x80000000u : 0u);
+    if (f_bit(F)) {
+        const uint32_t at = so.base + so.nf;  // (wave-uniform: a scalar base per array, one lane offset for both)
+        const uint32_t r4 = f_rank(F) * 4u;
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tgt_ref + at) + r4) = (field - 1u) | (f_bit(H) ? 0x80000000u : 0u);
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tgt_gbin + at) + r4) = gbin | (f_bit(U) ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -389,24 +448,85 @@ __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint3
     return end;
 }
 
-// 64 bits of the slot's run-start bitmap from bit `off` on (lane j of bm_lo / bm_hi holds block j)
-__device__ __forceinline__ uint64_t bitmap_window(uint32_t bm_lo, uint32_t bm_hi, uint32_t off) {
-    const uint32_t q = off >> 6, sh = off & 63u;
-    const uint64_t a = f_read64(bm_lo, bm_hi, q), b = f_read64(bm_lo, bm_hi, q + 1u);
-    return sh ? ((a >> sh) | (b << (64u - sh))) : a;
+constexpr uint32_t kStageRecs = 64u * kSlotBlocks;   // records staged per slot (the slot and 64 more)
+constexpr uint32_t kStageGroup = 6;                  // blocks whose loads are in flight together
+
+// first run start among the staged records at or behind `from`; kStageRecs when there is none
+__device__ __forceinline__ uint32_t next_run_start(const uint32_t* st1, uint32_t lane, uint32_t from) {
+    for (uint32_t o = from; o < kStageRecs; o += 64u) {
+        const uint32_t i = o + lane;
+        const uint32_t w = i < kStageRecs ? st1[i] : 0u;
+        const uint64_t m = f_ballot(static_cast<int32_t>(w) < 0);
+        if (m) return o + static_cast<uint32_t>(__builtin_ctzll(m));
+    }
+    return kStageRecs;
 }
 
-// first run start of the slot's bitmap at or behind bit `off` (< 64 * kSlotBlocks), 64 * kSlotBlocks when there is none
-__device__ __forceinline__ uint32_t bitmap_next(uint32_t bm_lo, uint32_t bm_hi, uint32_t lane, uint32_t off) {
-    const uint32_t q0 = off >> 6;
-    uint64_t mine = (static_cast<uint64_t>(bm_hi) << 32) | bm_lo;   // this lane's block
-    if (lane == q0) mine &= ~f_below(off & 63u);
-    const uint64_t any = f_ballot(lane >= q0 && lane < kSlotBlocks && mine != 0ull);
-    if (!any) return 64u * kSlotBlocks;
-    const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(any));
-    uint64_t w = f_read64(bm_lo, bm_hi, q);
-    if (q == q0) w &= ~f_below(off & 63u);
-    return 64u * q + static_cast<uint32_t>(__builtin_ctzll(w));
+// STAGE: records [B, B + kStageRecs) of the stream as two words each in the wave's stretch of LDS --
+//   st1: reference + 1 (kRefField: not mapped) | mate << 26 | run start << 31,  st2: global bin.
+// kClamp: the stream ends inside the stretch (its last slots only): lanes behind the end load the last record again and
+// stage "not mapped, no run start".
+template <bool kClamp, typename Acc>
+__device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t N, uint32_t lane, uint32_t* st1, uint32_t* st2,
+                                           bool& bad) {
+    // The key in front of every record: the lane before's (DPP), for lane 0 the last key of the block before -- and for
+    // the stretch's first block a second load of the keys, one record down, issued with the others.  (The key of record
+    // B - 1 alone, loaded up front, would be a round trip of its own per slot.)
+    uint32_t plo = 0, phi = 0, q0lo, q0hi;
+    {
+        const uint32_t pb = B > 0u ? B - 1u : 0u;                        // B == 0: lane 0 is given no_key below,
+        uint32_t rel = (B == 0u && lane != 0u) ? lane - 1u : lane;       // lane i gets key[i - 1]
+        if (kClamp) rel = min(rel, N - 1u - pb);
+        acc.load_key(pb, rel, q0lo, q0hi);
+    }
+#pragma unroll
+    for (uint32_t j0 = 0; j0 < kSlotBlocks; j0 += kStageGroup) {
+        FrontLoaded rec[kStageGroup];
+        uint2 geo[kStageGroup];
+#pragma unroll
+        for (uint32_t u = 0; u < kStageGroup; ++u) {
+            if (j0 + u >= kSlotBlocks) break;
+            // (the block's first record as the scalar base, the lane as the offset: the same three offset registers
+            // serve every block of every slot)
+            const uint32_t blk = kClamp ? min(B + 64u * (j0 + u), N - 1u) : B + 64u * (j0 + u);
+            acc.load(blk, kClamp ? min(lane, N - 1u - blk) : lane, rec[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (all the group's loads before the first use of one: left to itself the
+                                            // scheduler pairs every load with its use, a round trip each)
+#pragma unroll
+        for (uint32_t u = 0; u < kStageGroup; ++u) {
+            if (j0 + u >= kSlotBlocks) break;
+            geo[u] = acc.geo_at(rec[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t u = 0; u < kStageGroup; ++u) {
+            const uint32_t j = j0 + u;
+            if (j >= kSlotBlocks) break;
+            uint32_t field, mate;
+            acc.fields(rec[u], field, mate, bad);
+            Acc::key_fix(rec[u].klo, rec[u].khi);
+            const uint32_t g = acc.gbin_of(rec[u], geo[u]);
+            const uint64_t k = (static_cast<uint64_t>(rec[u].khi) << 32) | rec[u].klo;
+            uint32_t qlo, qhi;
+            if (j == 0u) {
+                qlo = q0lo;
+                qhi = q0hi;
+                Acc::key_fix(qlo, qhi);
+                if (B == 0u && lane == 0u) Acc::no_key(qlo, qhi);  // the first record of the stream starts a run
+            } else {
+                qlo = f_shr1(rec[u].klo, plo);
+                qhi = f_shr1(rec[u].khi, phi);
+            }
+            const uint64_t q = (static_cast<uint64_t>(qhi) << 32) | qlo;
+            uint32_t w = field | (mate << kStMateShift) | (k != q ? kStRunStart : 0u);
+            if (kClamp && 64u * j + lane >= N - B) w = kRefField;
+            st1[64u * j + lane] = w;
+            st2[64u * j + lane] = g;
+            plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].klo, 63));
+            phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].khi, 63));
+        }
+    }
 }
 
 }  // namespace
@@ -414,11 +534,8 @@ __device__ __forceinline__ uint32_t bitmap_next(uint32_t bm_lo, uint32_t bm_hi, 
 // ---------------------------------------------------------------------------------------------------------
 // k_front
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kStageRecs = 64u * kSlotBlocks;   // records staged per slot (the slot and 64 more)
-constexpr uint32_t kStageGroup = 6;                  // blocks whose loads are in flight together
-
 template <typename Acc>
-__global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
+__global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
                                                        uint4* __restrict__ slots, uint2* __restrict__ wcut) {
     __shared__ uint32_t s_stage[kFrontBlock / 64][2][kStageRecs];
@@ -435,62 +552,24 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
         WinOut so{B, 0u, 0u, 0u};
         uint32_t nw = 0;
         if (B < N) {
-            // ---- 1. stage records [B, B + kStageRecs) and their run starts: lane j of bm_lo / bm_hi gets block j's ballot
-            uint32_t bm_lo = 0, bm_hi = 0;
-            {
-                uint32_t plo = 0, phi = 0;  // the key in front of the block (one address for the whole wave)
-                if (B > 0u) acc.key_at(B - 1u, plo, phi);
-#pragma unroll
-                for (uint32_t j0 = 0; j0 < kSlotBlocks; j0 += kStageGroup) {
-                    uint32_t klo[kStageGroup], khi[kStageGroup];
-                    FrontRaw3 raw[kStageGroup];
-                    uint2 geo[kStageGroup];
-#pragma unroll
-                    for (uint32_t u = 0; u < kStageGroup; ++u) {
-                        if (j0 + u >= kSlotBlocks) break;
-                        const uint32_t i = min(B + 64u * (j0 + u) + lane, N - 1u);
-                        acc.key_at(i, klo[u], khi[u]);
-                        raw[u] = acc.raw(i);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // (all the group's loads before the first use of one: left to itself
-                                                        // the scheduler pairs every load with its use, a round trip each)
-#pragma unroll
-                    for (uint32_t u = 0; u < kStageGroup; ++u) {
-                        if (j0 + u >= kSlotBlocks) break;
-                        geo[u] = acc.geo_of(raw[u]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (uint32_t u = 0; u < kStageGroup; ++u) {
-                        const uint32_t j = j0 + u;
-                        if (j >= kSlotBlocks) break;
-                        const FrontRec r = acc.decode(raw[u], bad);
-                        st1[64u * j + lane] = stage_word(r);
-                        st2[64u * j + lane] = acc.gbin(r, geo[u]);
-                        const uint32_t qlo = f_shr1(klo[u], plo), qhi = f_shr1(khi[u], phi);
-                        uint64_t rs = f_ballot(((klo[u] ^ qlo) | (khi[u] ^ qhi)) != 0u);
-                        if (B == 0u && j == 0u) rs |= 1ull;  // the first record of the stream starts a run
-                        const uint32_t first = B + 64u * j;
-                        rs &= first < N ? f_below(min(64u, N - first)) : 0ull;  // no records behind the stream's end
-                        bm_lo = lane == j ? static_cast<uint32_t>(rs) : bm_lo;
-                        bm_hi = lane == j ? static_cast<uint32_t>(rs >> 32) : bm_hi;
-                        plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(klo[u], 63));
-                        phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(khi[u], 63));
-                    }
-                }
-            }
-            // ---- 2 + 3. windows: cut at the bitmap, classified from the staged words.  (Every load has landed by now; said
-            // aloud, so that the compiler does not make each window wait for the stores of the window before it on behalf
-            // of a register some load of the staging loop once wrote.)
+            // ---- 1. stage (the only part that waits for memory; everything a group loads is in flight at once)
+            if (N - B >= kStageRecs)
+                stage_slot<false>(acc, B, N, lane, st1, st2, bad);
+            else
+                stage_slot<true>(acc, B, N, lane, st1, st2, bad);
+            // ---- 2 + 3. windows: cut at the staged run starts, classified from the staged words.  (Every load has
+            // landed by now; said aloud, so that the compiler does not make each window wait for the stores of the
+            // window before it on behalf of a register some load of the staging loop once wrote.)
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-            uint32_t off = bitmap_next(bm_lo, bm_hi, lane, 0u);
+            uint32_t off = next_run_start(st1, lane, 0u);
             so.base = B + min(off, kSlotRecs);
             while (off < kSlotRecs) {
                 if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
                     if (lane == 0u) cuts[nw] = make_uint2(so.nf, so.nh);  // records; beyond that the list's last window
                     ++nw;                                                  // simply takes the rest of the slot)
                 }
-                const uint64_t RSw = bitmap_window(bm_lo, bm_hi, off);
+                const uint32_t w1 = st1[off + lane], w2 = st2[off + lane];
+                const uint64_t RSw = f_ballot(static_cast<int32_t>(w1) < 0);  // (bit 0 is set: a window starts a run)
                 const uint32_t pos = B + off;
                 // complete runs end at the last run start of the window -- or at the end of the stream
                 uint32_t X = pos + 64u >= N ? N - pos : 63u - static_cast<uint32_t>(__builtin_clzll(RSw | 1ull));
@@ -499,20 +578,20 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
                     if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
                 }
                 if (X) {
-                    const Staged rec = unstage(st1[off + lane], st2[off + lane]);
+                    const uint32_t field = w1 & kRefField, mate = (w1 >> kStMateShift) & 3u;
                     const uint64_t PR = f_below(X);
                     const uint64_t RS = RSw & PR;
-                    const uint32_t mprev = f_shr1(rec.mate, 0u);
-                    const uint64_t V = f_ballot(rec.mapped) & PR;
-                    if ((f_ballot(rec.mate < mprev) & ~RS & PR) == 0ull)
-                        window_fast(rec, lane, (RS | f_ballot(rec.mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin);
+                    const uint32_t mprev = f_shr1z(mate);
+                    const uint64_t V = f_ballot(field != kRefField) & PR;
+                    if ((f_ballot(mate < mprev) & ~RS & PR) == 0ull)
+                        window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin);
                     else
-                        window_general(rec, lane, RS, V, X, so, tgt_ref, tgt_gbin);
+                        window_general(Staged{mate, field - 1u, w2, f_bit(V)}, lane, RS, V, X, so, tgt_ref, tgt_gbin);
                     off += X;
                 } else {  // a run of 64 records or more: from global memory, at its own pace
                     const uint32_t end = long_run(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad);
                     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
-                    off = end - B < kStageRecs ? bitmap_next(bm_lo, bm_hi, lane, end - B) : kStageRecs;
+                    off = end - B < kStageRecs ? next_run_start(st1, lane, end - B) : kStageRecs;
                 }
             }
         }
@@ -533,9 +612,11 @@ __global__ __launch_bounds__(kFrontBlock) void k_front(const Acc acc, uint32_t n
 uint32_t front_slots(uint32_t n_records) { return (n_records + kSlotRecs - 1u) / kSlotRecs; }
 
 static uint32_t front_grid(uint32_t nslots) {
-    // one slot per wave and trip; at most 8 workgroups of 256 threads per CU (256 CUs)
+    // One slot per wave, however many workgroups that makes: the dispatcher hands the next workgroup to whichever CU
+    // retires one.  (A grid capped at what is resident at once, its waves striding over the slots, gives some waves
+    // one slot more than others -- at 2.4 slots per resident wave that is 3 rounds for the price of 2.4.)
     const uint32_t blocks = (nslots + (kFrontBlock / 64) - 1u) / (kFrontBlock / 64);
-    return std::max(1u, std::min(blocks, 2048u));
+    return std::max(1u, blocks);
 }
 
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,

@@ -92,7 +92,7 @@ constexpr uint32_t kSlotRecs = 1024;
 // window are whole reads: k_filter takes the windows up independently of each other.
 constexpr uint32_t kSlotWindows = 2 * (kSlotRecs / 64) + 6;
 constexpr int kFrontBlock = 256;
-constexpr uint32_t kMaxRefs = (1u << 26) - 1u;      // reference ids fit 26 bits (tagged words of the duplicate test)
+constexpr uint32_t kMaxRefs = (1u << 26) - 2u;      // reference id + 1 fits 26 bits and is not all ones (front.hip)
 constexpr uint32_t kMaxBins = 0x7ffffff0u;          // global bin indices fit 31 bits (bit 31 of tgt_gbin: unique read)
 uint32_t front_slots(uint32_t n_records);
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
@@ -127,8 +127,8 @@ struct FilterArgs {
     const uint2* wcut = nullptr;
     uint32_t nslots = 0;
     const void* rows16 = nullptr;
-    const uint32_t* level_taxon = nullptr;
-    const uint32_t* level_off = nullptr;
+    const uint32_t* taxon_flat = nullptr;  // rows16: dense taxon of (level, index) at [(level << taxon_shift) | index]
+    uint32_t taxon_shift = 0;
     const uint32_t* lin_dense = nullptr;
     const uint8_t* valid = nullptr;
     uint32_t* sel = nullptr;

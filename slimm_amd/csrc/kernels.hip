@@ -435,16 +435,12 @@ __device__ void pair_insert(uint64_t key, uint64_t* __restrict__ tab, uint64_t* 
     atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_PAIR_OVERFLOW));
 }
 
-struct LevelOffsets {
-    uint32_t off[8];
-};
-
 // 16-byte lineage rows: eight per-level 16-bit indices, the reference's valid flag in the top bit of the level-7
-// half-word; level_taxon[off[lv] + idx] is the dense taxon of a (level, index)
+// half-word; taxon_flat[(lv << shift) | idx] is the dense taxon of a (level, index)
 struct Rows16 {
     const uint4* rows;
-    const uint32_t* level_taxon;
-    LevelOffsets lo;
+    const uint32_t* taxon_flat;
+    uint32_t shift;
     struct Row {
         uint4 q;
     };
@@ -460,7 +456,28 @@ struct Rows16 {
         f[6] = r.q.w & 0xffffu;
         f[7] = (r.q.w >> 16) & 0x7fffu;
     }
-    __device__ uint32_t taxon(uint32_t lv, uint32_t field) const { return level_taxon[lo.off[lv] + field]; }
+    // the row lane `byte_addr / 4` holds
+    __device__ static Row from_lane(const Row& r, uint32_t byte_addr) {
+        return Row{make_uint4(__builtin_amdgcn_ds_bpermute(byte_addr, r.q.x), __builtin_amdgcn_ds_bpermute(byte_addr, r.q.y),
+                              __builtin_amdgcn_ds_bpermute(byte_addr, r.q.z), __builtin_amdgcn_ds_bpermute(byte_addr, r.q.w))};
+    }
+    // the levels at which two rows of VALID references differ
+    __device__ static void differ(const Row& a, const Row& b, bool (&ne)[8]) {
+        const uint32_t d[4] = {a.q.x ^ b.q.x, a.q.y ^ b.q.y, a.q.z ^ b.q.z, a.q.w ^ b.q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ne[2 * k] = static_cast<uint16_t>(d[k]) != 0;
+            ne[2 * k + 1] = d[k] > 0xffffu;
+        }
+    }
+    // the field of level lv (a per-lane value below 8)
+    __device__ static uint32_t field(const Row& r, uint32_t lv) {
+        const uint64_t lo = (static_cast<uint64_t>(r.q.y) << 32) | r.q.x;
+        const uint64_t hi = (static_cast<uint64_t>(r.q.w & 0x7fffffffu) << 32) | r.q.z;
+        return static_cast<uint32_t>((lv < 4u ? lo : hi) >> ((lv & 3u) * 16u)) & 0xffffu;
+    }
+    __device__ uint32_t taxon_index(uint32_t lv, uint32_t field) const { return (lv << shift) | field; }
+    __device__ uint32_t taxon_at(uint32_t index) const { return taxon_flat[index]; }
 };
 // 32-byte rows (databases with more than 65535 taxa on one level): eight dense taxon indices, validity in a byte array
 struct Rows32 {
@@ -482,7 +499,35 @@ struct Rows32 {
         f[6] = r.b.z;
         f[7] = r.b.w;
     }
-    __device__ uint32_t taxon(uint32_t, uint32_t field) const { return field; }
+    __device__ static Row from_lane(const Row& r, uint32_t byte_addr) {
+        Row o;
+        o.a = make_uint4(__builtin_amdgcn_ds_bpermute(byte_addr, r.a.x), __builtin_amdgcn_ds_bpermute(byte_addr, r.a.y),
+                         __builtin_amdgcn_ds_bpermute(byte_addr, r.a.z), __builtin_amdgcn_ds_bpermute(byte_addr, r.a.w));
+        o.b = make_uint4(__builtin_amdgcn_ds_bpermute(byte_addr, r.b.x), __builtin_amdgcn_ds_bpermute(byte_addr, r.b.y),
+                         __builtin_amdgcn_ds_bpermute(byte_addr, r.b.z), __builtin_amdgcn_ds_bpermute(byte_addr, r.b.w));
+        o.ok = true;
+        return o;
+    }
+    __device__ static void differ(const Row& p, const Row& q, bool (&ne)[8]) {
+        ne[0] = p.a.x != q.a.x;
+        ne[1] = p.a.y != q.a.y;
+        ne[2] = p.a.z != q.a.z;
+        ne[3] = p.a.w != q.a.w;
+        ne[4] = p.b.x != q.b.x;
+        ne[5] = p.b.y != q.b.y;
+        ne[6] = p.b.z != q.b.z;
+        ne[7] = p.b.w != q.b.w;
+    }
+    __device__ static uint32_t field(const Row& r, uint32_t lv) {
+        uint32_t f[8];
+        fields(r, f);
+        uint32_t v = f[0];
+#pragma unroll
+        for (uint32_t l = 1; l < 8; ++l) v = lv == l ? f[l] : v;
+        return v;
+    }
+    __device__ uint32_t taxon_index(uint32_t, uint32_t field) const { return field; }
+    __device__ uint32_t taxon_at(uint32_t index) const { return index; }
 };
 
 namespace {
@@ -561,10 +606,10 @@ template <typename Rows>
 __device__ __forceinline__ uint32_t read_taxon(const Rows& rows, const ReadAcc& acc, uint32_t* lv) {
     if (acc.eq) {
         *lv = static_cast<uint32_t>(__builtin_ctz(acc.eq));
-        return rows.taxon(*lv, acc.a0[*lv]);
+        return rows.taxon_at(rows.taxon_index(*lv, acc.a0[*lv]));
     }
     *lv = 8u;
-    return rows.taxon(7u, acc.max_f7);
+    return rows.taxon_at(rows.taxon_index(7u, acc.max_f7));
 }
 
 // children[taxon] gets the valid lanes' references: a level mark, or a (taxon, reference) pair when no level agreed
@@ -578,9 +623,20 @@ __device__ __forceinline__ void read_children(const FilterOut& out, bool mine, u
 
 // One window of up to 64 targets that are whole reads: lanes [0, X); w / g = the target words, row = the lineage rows
 // of the lanes' references, sel_base = index of the window's first read among the selectors.
+// Everything per read is lane-mask arithmetic; the reads that keep several targets (8 % at config 2, most of them at
+// config 5) are worked on all at once as well: every valid lane fetches the row of its read's FIRST valid lane (a lane
+// permute), per level one ballot says which lanes differ from it, and the first valid lane of each read -- its owner --
+// finds the first level at which no lane between itself and the next read's head does.  The owners' taxa are ONE gather
+// per window, left to the caller (Lookup) so that the gathers of a batch of windows are in flight together.
+struct Lookup {
+    uint32_t index;  // taxon_at(index) + taxon_base is the selector ...
+    uint32_t ridx;   // ... of read ridx
+    bool want;
+};
+
 template <typename Rows>
-__device__ __forceinline__ void filter_window(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
-                                              uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
+__device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
+                                                uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
     const uint64_t PR = k_below(X);
     const uint64_t H = k_ballot((w >> 31) != 0u) & PR;  // (bit 0 is set: a window starts at a read's first target)
     const uint32_t ref = w & 0x7fffffffu;
@@ -596,26 +652,58 @@ __device__ __forceinline__ void filter_window(const Rows& rows, const FilterOut&
     const uint32_t ridx = sel_base + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
     if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
     if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
+    Lookup lk{0u, ridx, false};
     if (HM) {
-        uint32_t f[8];
-        Rows::fields(row, f);
-        uint64_t todo = HM;
-        while (todo) {
-            const uint32_t h = static_cast<uint32_t>(__builtin_ctzll(todo));
-            todo &= todo - 1ull;
-            const uint64_t later = H & ~k_below(h + 1u);
-            const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
-            const uint64_t Vs = VB & k_below(nxt) & ~k_below(h);
-            ReadAcc acc;
-            read_clear(acc);
-            read_add(acc, Vs, g, f);
-            if (!acc.eq) read_max(acc, Vs, ref, f[7]);
-            uint32_t lv;
-            const uint32_t taxon = read_taxon(rows, acc, &lv);
-            read_children(out, k_bit(Vs), ref, lv, taxon);
-            if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(h)))] = out.taxon_base + taxon;
+        const uint64_t le = (2ull << lane) - 1ull;  // the lanes up to and including this one
+        const uint64_t OW = FV & ~single;           // owners: the first valid lane of every read with several
+        // the first valid lane of this lane's read (for the valid lanes): the highest bit of FV at or below it
+        const uint32_t fvl = 63u - static_cast<uint32_t>(__builtin_clzll((FV & le) | 1ull));
+        const typename Rows::Row first = Rows::from_lane(row, fvl << 2);
+        bool ne[8];
+        Rows::differ(row, first, ne);
+        // the lanes above this one that still belong to its read: those below the next head
+        const uint64_t Hn = H & ~le;
+        const uint64_t mine = ~le & ~Hn & (Hn - 1ull) & PR;
+        uint32_t lv = 8u;  // src/slimm.hpp:516-531: the first level (from the leaves) on which all valid targets agree
+#pragma unroll
+        for (int l = 7; l >= 0; --l) {
+            const uint64_t D = k_ballot(ne[l]) & VB;
+            lv = (D & mine) == 0ull ? static_cast<uint32_t>(l) : lv;
+        }
+        const uint64_t Q4 = k_ballot(lv == 8u) & OW;  // no level agrees (quirk Q4): rare, one read at a time below
+        lk.want = k_bit(OW & ~Q4);
+        lk.index = rows.taxon_index(lv & 7u, Rows::field(row, lv & 7u));
+        // children[taxon] gets the valid targets' references (src/slimm.hpp:536-557): a (reference, level) mark
+        const uint32_t lv_read = __builtin_amdgcn_ds_bpermute(fvl << 2, lv);
+        if (k_bit(VB & ~single) && lv_read < 8u) out.marks[ref * kMarkBytes + lv_read] = 1;  // plain, idempotent byte store
+        if (Q4) {
+            uint32_t f[8];
+            Rows::fields(row, f);
+            uint64_t todo = Q4;
+            while (todo) {
+                const uint32_t o = static_cast<uint32_t>(__builtin_ctzll(todo));
+                todo &= todo - 1ull;
+                const uint64_t later = H & ~k_below(o + 1u);
+                const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
+                const uint64_t Vs = VB & k_below(nxt) & ~k_below(o);
+                ReadAcc acc;
+                read_clear(acc);
+                read_max(acc, Vs, ref, f[7]);
+                const uint32_t taxon = rows.taxon_at(rows.taxon_index(7u, acc.max_f7));
+                read_children(out, k_bit(Vs), ref, 8u, taxon);
+                if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(o + 1u))) - 1u] = out.taxon_base + taxon;
+            }
         }
     }
+    return lk;
+}
+
+// ... and the same with the owners' taxa looked up at once (the windows of filter_span, one at a time)
+template <typename Rows>
+__device__ __forceinline__ void filter_window_now(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
+                                                  uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
+    const Lookup lk = filter_window(rows, out, lane, X, w, g, row, sel_base);
+    if (lk.want) out.sel[lk.ridx] = out.taxon_base + rows.taxon_at(lk.index);
 }
 
 // The targets [pos, endp) -- whole reads, any number of them, reads of 64 targets and more among them -- one window
@@ -633,7 +721,7 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
         const uint32_t X = pos + 64u >= endp ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(HB | 1ull));
         if (X != 0u) {
             const typename Rows::Row row = rows.load(lane < X ? (w & 0x7fffffffu) : 0u);
-            filter_window(rows, out, lane, X, w, g, row, sel_base);
+            filter_window_now(rows, out, lane, X, w, g, row, sel_base);
             sel_base += static_cast<uint32_t>(__popcll(HB & k_below(X)));
             pos += X;
             continue;
@@ -725,9 +813,18 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
             }
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) row[u] = rows.load(lane < cnt[u] ? (w[u] & 0x7fffffffu) : 0u);
+            Lookup lk[kFilterBatch];
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) {
+                lk[u] = Lookup{0u, 0u, false};
+                if (cnt[u]) lk[u] = filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], selb[u]);
+            }
+            uint32_t taxon[kFilterBatch];
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) taxon[u] = rows.taxon_at(lk[u].want ? lk[u].index : 0u);
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u)
-                if (cnt[u]) filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], selb[u]);
+                if (lk[u].want) out.sel[lk[u].ridx] = out.taxon_base + taxon[u];
         }
         if (spans) {
             for (uint32_t i = 0; i < nw; ++i) {
@@ -883,8 +980,9 @@ void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots,
 }
 
 static uint32_t filter_grid(uint32_t nslots) {
+    // one slot per wave (front.hip: front_grid)
     const uint32_t blocks = (nslots + (kFilterBlock / 64) - 1u) / (kFilterBlock / 64);
-    return std::max(1u, std::min(blocks, 2048u));
+    return std::max(1u, blocks);
 }
 
 void launch_filter(hipStream_t st, const FilterArgs& a) {
@@ -900,8 +998,8 @@ void launch_filter(hipStream_t st, const FilterArgs& a) {
     if (a.rows16) {
         Rows16 r;
         r.rows = reinterpret_cast<const uint4*>(a.rows16);
-        r.level_taxon = a.level_taxon;
-        for (int i = 0; i < 8; ++i) r.lo.off[i] = a.level_off[i];
+        r.taxon_flat = a.taxon_flat;
+        r.shift = a.taxon_shift;
         hipLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
                            a.slots, a.wcut, a.nslots, r, out);
     } else {

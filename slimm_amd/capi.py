@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslimm_hip.so")
+# (SLIMM_HIP_LIB: another build of the same library, for tuning experiments -- scripts/build_variant.sh)
+LIB_PATH = os.environ.get("SLIMM_HIP_LIB") or os.path.join(_HERE, "libslimm_hip.so")
 
 OK = 0
 E_INVALID = -1

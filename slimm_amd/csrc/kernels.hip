@@ -772,12 +772,13 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 constexpr int kFilterBlock = 256;
 
 // A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
-// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Four
-// at a time: the target words of all four are loaded together, then their lineage rows gathered together, then the four
-// are worked on -- two memory round trips per four windows instead of two per window.  (No branch around the loads:
+// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Eight
+// at a time: the target words of all eight are loaded together, then their lineage rows gathered together, then the eight
+// are worked on, then the taxa of their reads with several targets looked up together -- three memory round trips per
+// eight windows (measured: 4 -> 8 windows per trip is worth 5 % at config 2, 7 % at config 3).  (No branch around the loads:
 // with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
 // waits for and waits for all of them.)
-constexpr int kFilterBatch = 4;
+constexpr int kFilterBatch = 8;
 template <typename Rows>
 __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,

@@ -98,6 +98,22 @@ int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);
 /* Append a batch from host memory (copied to the device before return). */
 int slimm_push_records(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
                        const uint16_t* flag, uint64_t n);
+/* Streamed ingest.  slimm_push_records_async enqueues the copies on the context's copy stream and returns at once:
+ * the arrays must stay unchanged until slimm_push_wait() returns (page-locked arrays are read by the DMA engine
+ * directly; pageable ones still work, at the speed of the runtime's own staging).  slimm_analyze_alignments() is
+ * ordered behind the copies on the device (an event), so the host never waits for PCIe: it decodes the next batch, or
+ * drives another context's phases, meanwhile. */
+int slimm_push_records_async(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
+                             const uint16_t* flag, uint64_t n);
+int slimm_push_wait(slimm_ctx* ctx);
+/* Two page-locked staging sets owned by the context, for producers that decode records piecemeal (the BAM reader of
+ * the slimm command): fill set `which` (0 or 1; at least `capacity` records each), hand it over with
+ * slimm_push_staged_async(ctx, which, n) and fill the other one meanwhile; slimm_staging_buffers / slimm_staging_wait
+ * block until the set's last copy has left it. */
+int slimm_staging_buffers(slimm_ctx* ctx, uint32_t which, uint64_t capacity, uint64_t** read_key, int32_t** ref_id,
+                          int32_t** begin_pos, uint16_t** flag);
+int slimm_push_staged_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
+int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
 /* Use records already resident in device memory, without copying; the arrays must stay valid and unchanged
  * until slimm_reset().  Replaces anything pushed before. */
 int slimm_set_records_device(slimm_ctx* ctx, const uint64_t* d_read_key, const int32_t* d_ref_id,
@@ -271,6 +287,9 @@ float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q);
 /* Bin of one record (src/slimm.hpp:200-201). */
 uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width);
 /* Library build info. */
+/* Starts the HIP runtime on `device` (what the first slimm_create of a process would otherwise pay, 0.1 - 0.3 s): for
+ * hosts that call it from a thread of their own while they load their database and open their input. */
+int slimm_warm_up(int device);
 const char* slimm_version(void);
 
 #ifdef __cplusplus

@@ -74,6 +74,13 @@ SYMBOLS = [
     ("slimm_set_cutoff_cache", C.c_int, [_P, C.c_float, C.c_float]),
     ("slimm_reserve", C.c_int, [_P, C.c_uint64]),
     ("slimm_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
+    ("slimm_warm_up", C.c_int, [C.c_int]),
+    ("slimm_push_records_async", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
+    ("slimm_push_wait", C.c_int, [_P]),
+    ("slimm_staging_buffers", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                        C.POINTER(_P)]),
+    ("slimm_push_staged_async", C.c_int, [_P, C.c_uint32, C.c_uint64]),
+    ("slimm_staging_wait", C.c_int, [_P, C.c_uint32]),
     ("slimm_set_records_device", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_analyze_alignments", C.c_int, [_P]),
     ("slimm_coverage_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),

@@ -89,6 +89,18 @@ struct slimm_ctx {
     int device = -1;  // -1: host-only context
     int order = SLIMM_ORDER_GROUPED;
     hipStream_t stream = nullptr;
+    // streamed ingest (slimm_push_records_async): host -> device copies on a stream of their own, ordered before phase A
+    // by an event (never by the host); two page-locked staging sets for callers that produce records piecemeal
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;
+    bool copy_pending = false;
+    struct Staging {
+        PinBuf<uint64_t> key;
+        PinBuf<int32_t> ref, pos;
+        PinBuf<uint16_t> flag;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    } staging[2];
 
     uint32_t R = 0, T = 0;
     uint64_t Bp = 0;                   // padded bins per coverage array (multiple of 64)
@@ -320,6 +332,15 @@ int check_device_errors(slimm_ctx* c, uint32_t err) {
 
 extern "C" {
 
+// The first HIP call of a process pays for the runtime's start-up (0.1 - 0.3 s); a host that has other work to do first
+// (loading its database, opening its input) calls this from a thread of its own meanwhile.
+int slimm_warm_up(int device) {
+    if (device < 0) return SLIMM_OK;
+    if (hipSetDevice(device) != hipSuccess) return SLIMM_E_HIP;
+    if (hipFree(nullptr) != hipSuccess) return SLIMM_E_HIP;
+    return SLIMM_OK;
+}
+
 const char* slimm_version(void) { return "slimm_hip 0.1 (gfx950)"; }
 
 const char* slimm_last_error(const slimm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -388,6 +409,9 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     } while (0)
         HIP_TRY0(hipSetDevice(c->device));
         HIP_TRY0(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
+        HIP_TRY0(hipStreamCreateWithFlags(&cc->copy_stream, hipStreamNonBlocking));
+        HIP_TRY0(hipEventCreateWithFlags(&cc->copy_done, hipEventDisableTiming));
+        for (auto& sg : cc->staging) HIP_TRY0(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
         HIP_TRY0(cc->d_ref_len.ensure(c->R));
         HIP_TRY0(cc->d_bin_off.ensure(c->R + 1));
         HIP_TRY0(cc->d_lin_dense.ensure(static_cast<size_t>(c->R) * 8));
@@ -487,6 +511,13 @@ void slimm_destroy(slimm_ctx* c) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
         }
+        if (c->copy_stream) {
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamDestroy(c->copy_stream);
+        }
+        if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+        for (auto& sg : c->staging)
+            if (sg.done) (void)hipEventDestroy(sg.done);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -494,6 +525,12 @@ void slimm_destroy(slimm_ctx* c) {
 
 int slimm_reset(slimm_ctx* c) {
     if (!c) return SLIMM_E_INVALID;
+    if (c->copy_pending) {  // copies still on their way would land in the next file's records
+        (void)hipSetDevice(c->device);
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        c->copy_pending = false;
+        for (auto& sg : c->staging) sg.pending = false;
+    }
     c->host->reset();
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;
@@ -529,7 +566,8 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
     if (c->borrowed) return fail(c, SLIMM_E_INVALID, "records are borrowed device arrays; reset first");
     (void)hipSetDevice(c->device);
     if (n <= c->in_key.cap) return SLIMM_OK;
-    // grow, keeping what was pushed
+    // grow, keeping what was pushed (copies on their way included)
+    if (c->copy_pending) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     uint64_t cap = std::max<uint64_t>(n, c->in_key.cap * 2);
     if (cap >= 0x7fffffffull) cap = 0x7ffffffeull;
     DevBuf<uint64_t> k;
@@ -580,6 +618,87 @@ int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     return SLIMM_OK;
 }
 
+// Streamed ingest: the copies go to a stream of their own and the call returns at once; phase A is ordered behind them
+// by an event on the device, never by the host.  With page-locked arrays (the staging sets below, or the caller's own)
+// the DMA engine reads them directly while the host decodes the next batch and the compute stream works on the file
+// before.
+int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
+                             uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    int rc = slimm_reserve(c, c->n_pushed + n);
+    if (rc != SLIMM_OK) return rc;
+    const uint64_t o = c->n_pushed;
+    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_flag.p + o, flag, n * 2, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
+    c->copy_pending = true;
+    c->n_pushed += n;
+    c->rec.key = c->in_key.p;
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.flag = c->in_flag.p;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    return SLIMM_OK;
+}
+
+int slimm_push_wait(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->copy_pending) return SLIMM_OK;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipEventSynchronize(c->copy_done));
+    c->copy_pending = false;
+    for (auto& sg : c->staging) sg.pending = false;
+    return SLIMM_OK;
+}
+
+int slimm_staging_buffers(slimm_ctx* c, uint32_t which, uint64_t capacity, uint64_t** key, int32_t** ref, int32_t** pos,
+                          uint16_t** flag) {
+    if (!c || which > 1 || !key || !ref || !pos || !flag) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    (void)hipSetDevice(c->device);
+    slimm_ctx::Staging& sg = c->staging[which];
+    if (sg.pending) {  // the set is being read by a copy: it is the caller's again when that has finished
+        HIP_TRY(c, hipEventSynchronize(sg.done));
+        sg.pending = false;
+    }
+    HIP_TRY(c, sg.key.ensure(capacity));
+    HIP_TRY(c, sg.ref.ensure(capacity));
+    HIP_TRY(c, sg.pos.ensure(capacity));
+    HIP_TRY(c, sg.flag.ensure(capacity));
+    *key = sg.key.p;
+    *ref = sg.ref.p;
+    *pos = sg.pos.p;
+    *flag = sg.flag.p;
+    return SLIMM_OK;
+}
+
+int slimm_push_staged_async(slimm_ctx* c, uint32_t which, uint64_t n) {
+    if (!c || which > 1) return SLIMM_E_INVALID;
+    slimm_ctx::Staging& sg = c->staging[which];
+    if (n > sg.key.cap) return fail(c, SLIMM_E_INVALID, "more records than the staging set holds");
+    if (n == 0) return SLIMM_OK;
+    int rc = slimm_push_records_async(c, sg.key.p, sg.ref.p, sg.pos.p, sg.flag.p, n);
+    if (rc != SLIMM_OK) return rc;
+    HIP_TRY(c, hipEventRecord(sg.done, c->copy_stream));
+    sg.pending = true;
+    return SLIMM_OK;
+}
+
+int slimm_staging_wait(slimm_ctx* c, uint32_t which) {
+    if (!c || which > 1) return SLIMM_E_INVALID;
+    slimm_ctx::Staging& sg = c->staging[which];
+    if (!sg.pending) return SLIMM_OK;
+    (void)hipSetDevice(c->device);
+    HIP_TRY(c, hipEventSynchronize(sg.done));
+    sg.pending = false;
+    return SLIMM_OK;
+}
+
 int slimm_set_records_device(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos,
                              const uint16_t* flag, uint64_t n) {
     if (!c) return SLIMM_E_INVALID;
@@ -609,6 +728,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     if (rc != SLIMM_OK) return rc;
     tr.mark("set device + buffers");
     hipStream_t st = c->stream;
+    if (c->copy_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->copy_done, 0));  // streamed ingest: device-side ordering
     {
         KernelTimer t(c, K_MEMSET);
         if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)

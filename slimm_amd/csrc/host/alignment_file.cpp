@@ -404,40 +404,94 @@ bool AlignmentFile::find_records(size_t end, size_t max_records, std::vector<siz
     return true;
 }
 
+// BAM: the starts of the next (at most max_records) records in the decoded window; 0 at a clean end of file, -1 + err_
+long AlignmentFile::bam_record_starts(size_t max_records, std::vector<size_t>& offs) {
+    // the window must hold at least one complete record (or the file is at its end)
+    for (;;) {
+        const size_t avail = buf_.size() - pos_;
+        size_t need = 4;
+        if (avail >= 4) {
+            const uint32_t bs = rd_u32(&buf_[pos_]);
+            if (bs < 32) {
+                err_ = "bad BAM record size";
+                return -1;
+            }
+            if (avail >= 4 + static_cast<size_t>(bs)) break;
+            need = 4 + static_cast<size_t>(bs);
+        }
+        if (!fill(need)) {
+            if (!err_.empty()) return -1;
+            if (buf_.size() != pos_) {
+                err_ = "truncated BAM record";
+                return -1;
+            }
+            return 0;  // clean end of file
+        }
+    }
+    // where the records start (chunks of the window in parallel)
+    offs.clear();
+    size_t new_pos = pos_;
+    if (!find_records(buf_.size(), max_records, offs, new_pos)) return -1;
+    if (offs.empty()) {
+        err_ = "bad BAM record";
+        return -1;
+    }
+    pos_ = new_pos;
+    return static_cast<long>(offs.size());
+}
+
+// decode(lo, hi) over [0, cnt) on the reader's threads
+template <typename F>
+void AlignmentFile::decode_parallel(size_t cnt, F decode) {
+    const unsigned nthreads = cnt >= 65536 ? std::min<unsigned>(threads_, 16u) : 1u;
+    if (nthreads <= 1) {
+        decode(0, cnt);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (cnt + nthreads - 1) / nthreads;
+    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(decode, std::min(cnt, t * per), std::min(cnt, (t + 1) * per));
+    decode(0, std::min(cnt, per));
+    for (auto& th : pool) th.join();
+}
+
+// The four record fields of the hot path straight into the caller's arrays (the page-locked staging sets of
+// slimm_staging_buffers: the DMA engine reads what the decode threads wrote, no copy in between).
+long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records) {
+    if (!bam_) {  // SAM text: through a batch (parsing dominates by far)
+        RecordBatch b;
+        const long n = read_batch(b, max_records);
+        for (long i = 0; i < n; ++i) {
+            read_key[i] = b.read_key[i];
+            ref_id[i] = b.ref_id[i];
+            begin_pos[i] = b.begin_pos[i];
+            flag[i] = b.flag[i];
+        }
+        return n;
+    }
+    std::vector<size_t> offs;
+    const long cnt = bam_record_starts(max_records, offs);
+    if (cnt <= 0) return cnt;
+    decode_parallel(static_cast<size_t>(cnt), [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) {
+            const uint8_t* r = &buf_[offs[k] + 4];
+            const uint8_t l_read_name = r[8];
+            read_key[k] = hash_read_name(reinterpret_cast<const char*>(r + 32), l_read_name ? l_read_name - 1u : 0u);
+            ref_id[k] = static_cast<int32_t>(rd_u32(r));
+            begin_pos[k] = static_cast<int32_t>(rd_u32(r + 4));
+            flag[k] = rd_u16(r + 14);
+        }
+    });
+    return cnt;
+}
+
 long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_names) {
     long n = 0;
     if (bam_) {
-        // the window must hold at least one complete record (or the file is at its end)
-        for (;;) {
-            const size_t avail = buf_.size() - pos_;
-            size_t need = 4;
-            if (avail >= 4) {
-                const uint32_t bs = rd_u32(&buf_[pos_]);
-                if (bs < 32) {
-                    err_ = "bad BAM record size";
-                    return -1;
-                }
-                if (avail >= 4 + static_cast<size_t>(bs)) break;
-                need = 4 + static_cast<size_t>(bs);
-            }
-            if (!fill(need)) {
-                if (!err_.empty()) return -1;
-                if (buf_.size() != pos_) {
-                    err_ = "truncated BAM record";
-                    return -1;
-                }
-                return 0;  // clean end of file
-            }
-        }
-        // pass 1: where the records start (chunks of the window in parallel); pass 2 (parallel): decode + hash the names
         std::vector<size_t> offs;
-        size_t new_pos = pos_;
-        if (!find_records(buf_.size(), max_records, offs, new_pos)) return -1;
-        if (offs.empty()) {
-            err_ = "bad BAM record";
-            return -1;
-        }
-        pos_ = new_pos;
+        const long got = bam_record_starts(max_records, offs);
+        if (got <= 0) return got;
+        // decode + hash the names (parallel)
         const size_t cnt = offs.size(), base = out.read_key.size();
         out.read_key.resize(base + cnt);
         out.ref_id.resize(base + cnt);
@@ -445,7 +499,7 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
         out.flag.resize(base + cnt);
         out.l_seq.resize(base + cnt);
         if (keep_names) out.qname.resize(base + cnt);
-        auto decode = [&](size_t lo, size_t hi) {
+        decode_parallel(cnt, [&](size_t lo, size_t hi) {
             for (size_t k = lo; k < hi; ++k) {
                 const uint8_t* r = &buf_[offs[k] + 4];
                 const uint8_t l_read_name = r[8];
@@ -458,17 +512,7 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
                 out.l_seq[base + k] = rd_u32(r + 16);
                 if (keep_names) out.qname[base + k].assign(name, nlen);
             }
-        };
-        const unsigned nthreads = cnt >= 65536 ? std::min<unsigned>(threads_, 16u) : 1u;
-        if (nthreads <= 1) {
-            decode(0, cnt);
-        } else {
-            std::vector<std::thread> pool;
-            const size_t per = (cnt + nthreads - 1) / nthreads;
-            for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(decode, std::min(cnt, t * per), std::min(cnt, (t + 1) * per));
-            decode(0, std::min(cnt, per));
-            for (auto& th : pool) th.join();
-        }
+        });
         return static_cast<long>(cnt);
     }
     // SAM: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL ...

@@ -59,9 +59,14 @@ public:
 
     // Appends up to max_records records to `out`; returns the number appended (0 at end of file), -1 on a format error.
     long read_batch(RecordBatch& out, size_t max_records, bool keep_names = false);
+    // The same for the four fields of the hot path, written straight into the caller's arrays (room for max_records).
+    long read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records);
 
 private:
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)
+    long bam_record_starts(size_t max_records, std::vector<size_t>& offs);
+    template <typename F>
+    void decode_parallel(size_t cnt, F decode);
     // record starts in buf_[pos_, end): appended to offs, at most max_records; returns false on a malformed record
     bool find_records(size_t end, size_t max_records, std::vector<size_t>& offs, size_t& new_pos);
     bool plausible_record(size_t o, size_t end, int depth) const;

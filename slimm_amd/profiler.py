@@ -91,6 +91,43 @@ class Slimm:
             self._check(self.L.slimm_push_records(self.ctx, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
                                                   _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), e - s))
 
+    def staging(self, which: int, capacity: int):
+        """The context's page-locked staging set `which` (0 / 1) as numpy arrays (key u64, ref i32, pos i32, flag u16)."""
+        import numpy as np
+
+        ptr = [C.c_void_p() for _ in range(4)]
+        self._check(self.L.slimm_staging_buffers(self.ctx, which, capacity, *[C.byref(q) for q in ptr]))
+        out = []
+        for q, (ct, dt) in zip(ptr, ((C.c_uint64, np.uint64), (C.c_int32, np.int32), (C.c_int32, np.int32),
+                                     (C.c_uint16, np.uint16))):
+            out.append(np.ctypeslib.as_array(C.cast(q, C.POINTER(ct)), shape=(capacity,)).view(dt))
+        return tuple(out)
+
+    def push_records_streamed(self, rec: Records, batch: int = 1 << 20):
+        """slimm_push_staged_async over the two staging sets: batch k is copied into one set (the producer's work: a
+        BAM decoder writes there directly) while the DMA engine reads the other; returns without waiting for PCIe."""
+        n = len(rec)
+        sets = [self.staging(0, batch), self.staging(1, batch)]
+        for i, s in enumerate(range(0, n, batch)):
+            e = min(n, s + batch)
+            which = i & 1
+            self._check(self.L.slimm_staging_wait(self.ctx, which))
+            k, r, p, f = sets[which]
+            k[: e - s] = rec.read_key[s:e]
+            r[: e - s] = rec.ref_id[s:e]
+            p[: e - s] = rec.begin_pos[s:e]
+            f[: e - s] = rec.flag[s:e]
+            self._check(self.L.slimm_push_staged_async(self.ctx, which, e - s))
+
+    def push_records_async(self, key, ref, pos, flag):
+        """slimm_push_records_async on numpy arrays (page-locked ones are read by the DMA engine directly); keep them
+        unchanged until push_wait()."""
+        self._keepalive = (key, ref, pos, flag)
+        self._check(self.L.slimm_push_records_async(self.ctx, _p(key), _p(ref), _p(pos), _p(flag), len(key)))
+
+    def push_wait(self):
+        self._check(self.L.slimm_push_wait(self.ctx))
+
     def set_records_device(self, key, ref, pos, flag):
         """torch tensors on this context's device: int64/uint64 key, int32 ref, int32 pos, int16/uint16 flag."""
         n = int(key.shape[0])

@@ -652,3 +652,36 @@ def test_without_materialised_coverage_arrays(mk):
     with pytest.raises(capi.SlimmError):
         s.coverage_tensor()
     check(w, grouped=False, keep_bins=False)
+
+
+# ---------------------------------------------------------------- streamed ingest (slimm_push_records_async)
+@pytest.mark.parametrize("batch", [1000, 4096, 1 << 20])
+def test_streamed_ingest_through_the_staging_sets(batch):
+    """Records handed over through the two page-locked staging sets (ragged last batch, sets reused many times), phase A
+    ordered behind the copies on the device: the same results as the synchronous push."""
+    w = make_workload(CONFIGS["config1"], seed=5)
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0)
+    s.push_records_streamed(w.records, batch=batch)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    # the context is reusable: a second file through the asynchronous form on caller-owned arrays
+    s.reset()
+    r = w.records
+    s.push_records_async(r.read_key, r.ref_id, r.begin_pos, r.flag)
+    s.push_wait()
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+
+
+def test_reset_with_copies_on_their_way():
+    w = make_workload(CONFIGS["config1"], seed=6)
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0)
+    r = w.records
+    half = len(r) // 2
+    s.push_records_async(r.read_key[:half], r.ref_id[:half], r.begin_pos[:half], r.flag[:half])
+    s.reset()                       # waits for the copies; nothing of them is left
+    s.push_records_streamed(r, batch=3000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)

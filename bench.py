@@ -112,6 +112,11 @@ def main():
     ap.add_argument("--push-batch", type=int, default=1 << 20, help="records per slimm_push_records call")
     ap.add_argument("--push-steps", type=int, default=3,
                     help="steps of the push-inclusive measurement (records start in host memory; 0 = skip)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: ONE seeded stream of --records (default: the config's) records in 10 M-record "
+                         "chunks, rank r generates and keeps chunks [r C / N, (r + 1) C / N) -- cuts at read boundaries "
+                         "(slimm_amd/partition.py); implied by --config config4")
+    ap.add_argument("--chunk-records", type=int, default=10_000_000, help="records per chunk of the strong-scaling stream")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-rank code path (process group, collectives) even with one rank")
     args = ap.parse_args()
@@ -141,19 +146,49 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = CONFIGS[args.config]
-    n_rec = args.records or cfg.n_records
+    strong = args.strong or args.config == "config4"
     t0 = time.time()
-    w = make_workload(cfg, seed=args.seed + 1000 * rank, n_records=n_rec, sample_seed=args.seed, shard=rank)
+    if strong:
+        # ONE stream for every N: chunk c is make_workload(seed + 1000 c, shard = c) of the same sample, a grouped file
+        # of whole reads; the stream is the chunks in order, and rank r owns a contiguous range of them.  A rank
+        # generates only what it keeps, chunk by chunk straight into HBM.
+        from slimm_amd.partition import chunk_owner
+
+        n_stream = args.records or cfg.n_records
+        n_chunks = max(1, (n_stream + args.chunk_records - 1) // args.chunk_records)
+        mine = chunk_owner(n_chunks, world)[rank]
+        parts = {"key": [], "ref": [], "pos": [], "flag": []}
+        w = None
+        for c in mine:
+            wc = make_workload(cfg, seed=args.seed + 1000 * c, n_records=min(args.chunk_records, n_stream - c * args.chunk_records),
+                               sample_seed=args.seed, shard=c)
+            parts["key"].append(torch.from_numpy(wc.records.read_key.view(np.int64)).to(dev))
+            parts["ref"].append(torch.from_numpy(wc.records.ref_id).to(dev))
+            parts["pos"].append(torch.from_numpy(wc.records.begin_pos).to(dev))
+            parts["flag"].append(torch.from_numpy(wc.records.flag.view(np.int16)).to(dev))
+            if w is None:
+                w = wc          # header, database, options (the same for every chunk) + the sample for the CPU baseline
+        if w is None:           # more ranks than chunks: this rank has no records, but takes part in the exchange
+            w = make_workload(cfg, seed=args.seed, n_records=1000, sample_seed=args.seed, shard=0)
+            z = lambda dt: torch.zeros(0, dtype=dt, device=dev)
+            key, ref, pos, flag = z(torch.int64), z(torch.int32), z(torch.int32), z(torch.int16)
+        else:
+            key, ref, pos, flag = (torch.cat(parts[k]) for k in ("key", "ref", "pos", "flag"))
+        del parts
+        n_rec = int(key.shape[0])
+    else:
+        n_rec = args.records or cfg.n_records
+        w = make_workload(cfg, seed=args.seed + 1000 * rank, n_records=n_rec, sample_seed=args.seed, shard=rank)
+        key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
+        ref = torch.from_numpy(w.records.ref_id).to(dev)
+        pos = torch.from_numpy(w.records.begin_pos).to(dev)
+        flag = torch.from_numpy(w.records.flag.view(np.int16)).to(dev)
     gen_s = time.time() - t0
 
     eng = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))
     eng.force_exchange = args.force_exchange
     if args.no_bins:
         eng.keep_bins(False)
-    key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
-    ref = torch.from_numpy(w.records.ref_id).to(dev)
-    pos = torch.from_numpy(w.records.begin_pos).to(dev)
-    flag = torch.from_numpy(w.records.flag.view(np.int16)).to(dev)
     torch.cuda.synchronize()
     out_path = os.path.join(tempfile.gettempdir(), f"slimm_bench_profile_{os.getpid()}.tsv")
 
@@ -212,6 +247,10 @@ def main():
 
     st = eng.stats()
     total_records = n_rec * world
+    if strong and dist.is_initialized():
+        tot = torch.tensor([n_rec], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_records = int(tot.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = total_records / (elapsed / args.steps) / 1e6
 
@@ -266,7 +305,7 @@ def main():
         # ---- push-inclusive rate: the clock starts before the first record leaves host
         # memory and stops when the profile file is written.  Never `value`: PCIe, not the path, bounds it.
         with_push = None
-        if world == 1 and args.push_steps > 0 and not args.force_exchange:
+        if world == 1 and args.push_steps > 0 and not args.force_exchange and not strong:
             # Streamed ingest (slimm_push_records_async): the records sit in page-locked host memory (where a decoder
             # would have written them), the copies of file k + 1 run on the copy stream while file k is profiled on
             # another context -- the -d directory mode of the slimm command.  One "step" = one file: clock from the
@@ -316,7 +355,7 @@ def main():
 
         # ---- BASELINE.json configs[2]: the designated HBM-roofline run (100 M records, 20 k refs, mean 8 hits/read)
         roof3 = None
-        if world == 1 and not args.no_config3 and args.config == "config2" and not args.force_exchange:
+        if world == 1 and not args.no_config3 and args.config == "config2" and not args.force_exchange and not strong:
             cfg3 = CONFIGS["config3"]
             w3 = make_workload(cfg3, seed=args.seed, n_records=args.config3_records or cfg3.n_records)
             n3 = len(w3.records)
@@ -394,7 +433,7 @@ def main():
         line = {
             "metric": "M alignment-records/sec -> final profile",
             "value": round(value, 3), "unit": "M records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[{list(CONFIGS).index(args.config)}] ({args.config}): "
                                    f"{n_rec} records/GPU, {cfg.n_refs} refs, mean {cfg.mean_hits} hits/read, "
@@ -404,6 +443,8 @@ def main():
                        "record_order": args.record_order, "coverage_arrays": "not materialised" if args.no_bins else "in HBM",
                        "records": "resident in HBM before the timed region (value_with_push starts in host memory)",
                        "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
+                       "stream": (f"one seeded stream of {total_records} records in chunks of {args.chunk_records}, "
+                                  f"contiguous chunk ranges per rank") if strong else "one seeded shard per rank",
                        "exchange": (resolve_exchange(eng, args.exchange, world) if (world > 1 or args.force_exchange) else "none"),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,

@@ -123,6 +123,14 @@ int slimm_set_records_device(slimm_ctx* ctx, const uint64_t* d_read_key, const i
  * grouping by read, first-bin per (read, ref), cov / uniq_cov histograms.  Local to this GPU. */
 int slimm_analyze_alignments(slimm_ctx* ctx);
 
+/* Stream-ordered exchange.  The context's kernels run on one HIP stream (slimm_get_stream: a hipStream_t).  By default
+ * every function that hands out a device buffer for a collective synchronises that stream first, so that any stream
+ * may read the buffer.  A caller that enqueues its collectives ON the context's stream (ncclAllGather(..., stream),
+ * torch.cuda.ExternalStream) turns that off with slimm_set_stream_ordered(ctx, 1): buffers are then valid in stream
+ * order only, and between slimm_analyze_alignments and the cut-offs the host never waits for the device. */
+int slimm_get_stream(slimm_ctx* ctx, void** hip_stream);
+int slimm_set_stream_ordered(slimm_ctx* ctx, int on);
+
 /* Multi-GPU exchange point (no reference counterpart; reads are sharded across ranks):
  * device buffer [cov | uniq_cov | 16 scalar words] of *n_words uint32 that the caller sums across ranks in place
  * (one all-reduce) between slimm_analyze_alignments() and slimm_finish_coverage().  The stream is synchronised. */

@@ -75,6 +75,8 @@ SYMBOLS = [
     ("slimm_reserve", C.c_int, [_P, C.c_uint64]),
     ("slimm_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_warm_up", C.c_int, [C.c_int]),
+    ("slimm_get_stream", C.c_int, [_P, C.POINTER(_P)]),
+    ("slimm_set_stream_ordered", C.c_int, [_P, C.c_int]),
     ("slimm_push_records_async", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_push_wait", C.c_int, [_P]),
     ("slimm_staging_buffers", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),

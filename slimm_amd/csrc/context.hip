@@ -94,6 +94,7 @@ struct slimm_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
     bool copy_pending = false;
+    bool stream_ordered = false;  // slimm_set_stream_ordered: the caller enqueues its collectives on `stream`
     struct Staging {
         PinBuf<uint64_t> key;
         PinBuf<int32_t> ref, pos;
@@ -848,12 +849,25 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     return SLIMM_OK;
 }
 
+int slimm_get_stream(slimm_ctx* c, void** hip_stream) {
+    if (!c || !hip_stream) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no stream");
+    *hip_stream = c->stream;
+    return SLIMM_OK;
+}
+
+int slimm_set_stream_ordered(slimm_ctx* c, int on) {
+    if (!c) return SLIMM_E_INVALID;
+    c->stream_ordered = on != 0;
+    return SLIMM_OK;
+}
+
 int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
     if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
     if (!c->binsA_stored) return fail(c, SLIMM_E_INVALID, "the coverage arrays were not kept (slimm_keep_bins)");
     (void)hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->stream_ordered) HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->bins_exposed = true;  // the statistics k_tile_hist accumulated describe the local bins only
     *d_ptr = c->bins.p;
     *n_words = 2 * c->Bp + 16;
@@ -961,7 +975,7 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
         launch_nonzero_bits(st, c->cov(), c->Bp, c->summary.p + 4ull * c->R + 16);
         launch_nonzero_bits(st, c->ucov(), c->Bp, c->summary.p + 4ull * c->R + 16 + bits_words);
     }
-    HIP_TRY(c, hipStreamSynchronize(st));
+    if (!c->stream_ordered) HIP_TRY(c, hipStreamSynchronize(st));
     *d_ptr = c->summary.p;
     *n_words = W;
     return SLIMM_OK;
@@ -985,7 +999,7 @@ int slimm_merge_summary_slices(slimm_ctx* c, const void* d_recv, uint32_t n_rank
     // own sums and scalars come from the summary buffer (slimm_coverage_summary filled it)
     launch_merge_slices(c->stream, static_cast<const uint32_t*>(d_recv), n_ranks, c->slice_words(), lo_bin, hi_bin,
                         c->d_bin_off.p, c->R, c->summary.p, c->summary.p + 4ull * c->R, c->d_sum_vec.p);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->stream_ordered) HIP_TRY(c, hipStreamSynchronize(c->stream));
     *d_vec = c->d_sum_vec.p;
     *n_words = W;
     return SLIMM_OK;
@@ -1230,7 +1244,7 @@ int slimm_partials_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     const uint64_t W = 3ull * c->R + c->T + 1;
     HIP_TRY(c, c->d_partials.ensure(W));
     launch_partials_pack(c->stream, c->ref_stats.p + c->statsA_words(), c->R, c->T, c->d_partials.p);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!c->stream_ordered) HIP_TRY(c, hipStreamSynchronize(c->stream));
     *d_ptr = c->d_partials.p;
     *n_words = W;
     return SLIMM_OK;

@@ -13,6 +13,7 @@ The functions take an `engine` with the method names of `slimm_amd.profiler.Slim
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import numpy as np
@@ -25,6 +26,20 @@ def resolve_exchange(engine, mode: str, world: int) -> str:
     if mode == "auto":
         return "sliced" if (world > 2 and hasattr(engine, "merge_summary_slices")) else "summary"
     return mode
+
+
+def _engine_stream(engine):
+    """(context manager, ordered): engines that expose their HIP stream (Slimm.torch_stream) get their collectives
+    enqueued there -- ProcessGroupNCCL orders its own stream against the current one with events, so the library's
+    kernels, the collective and the library's next kernels run back to back without the host waiting in between."""
+    if hasattr(engine, "torch_stream") and torch.cuda.is_available():
+        return torch.cuda.stream(engine.torch_stream()), True
+    return contextlib.nullcontext(), False
+
+
+def _fence(t, ordered: bool):
+    if t.is_cuda and not ordered:
+        torch.cuda.synchronize(t.device)
 
 
 def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
@@ -44,39 +59,37 @@ def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
     if not multi and not getattr(engine, "force_exchange", False):
         return engine.finish_coverage()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if mode == "bins":
-        buf = engine.coverage_tensor()
-        if dist.is_initialized():
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            if buf.is_cuda:
-                torch.cuda.synchronize(buf.device)
-        return engine.finish_coverage()
-    if resolve_exchange(engine, mode, world) == "sliced":
+    on_stream, ordered = _engine_stream(engine)
+    with on_stream:
+        if mode == "bins":
+            buf = engine.coverage_tensor()
+            if dist.is_initialized():
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                _fence(buf, ordered)
+            return engine.finish_coverage()
+        if resolve_exchange(engine, mode, world) == "sliced":
+            mine = engine.coverage_summary_tensor()
+            head = engine.summary_head_words()
+            chunks = mine[head:]
+            received = torch.empty_like(chunks)
+            if dist.is_initialized():
+                dist.all_to_all_single(received, chunks, group=group)
+            else:
+                received.copy_(chunks)
+            _fence(received, ordered)
+            vec = engine.merge_summary_slices(received, world, dist.get_rank(group) if dist.is_initialized() else 0)
+            if dist.is_initialized():
+                dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+            _fence(vec, ordered)
+            return engine.finish_coverage_reduced()
         mine = engine.coverage_summary_tensor()
-        head = engine.summary_head_words()
-        chunks = mine[head:]
-        received = torch.empty_like(chunks)
+        gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
         if dist.is_initialized():
-            dist.all_to_all_single(received, chunks, group=group)
+            dist.all_gather_into_tensor(gathered, mine, group=group)
         else:
-            received.copy_(chunks)
-        if received.is_cuda:
-            torch.cuda.synchronize(received.device)
-        vec = engine.merge_summary_slices(received, world, dist.get_rank(group) if dist.is_initialized() else 0)
-        if dist.is_initialized():
-            dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
-        if vec.is_cuda:
-            torch.cuda.synchronize(vec.device)
-        return engine.finish_coverage_reduced()
-    mine = engine.coverage_summary_tensor()
-    gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-    if dist.is_initialized():
-        dist.all_gather_into_tensor(gathered, mine, group=group)
-    else:
-        gathered.copy_(mine)
-    if gathered.is_cuda:
-        torch.cuda.synchronize(gathered.device)
-    return engine.finish_coverage_merged(gathered, world)
+            gathered.copy_(mine)
+        _fence(gathered, ordered)
+        return engine.finish_coverage_merged(gathered, world)
 
 
 # level marks travel as one int64 per reference with one 8-bit field per level: a SUM over up to 255 ranks cannot carry
@@ -106,11 +119,12 @@ def merge_partials_on_device(engine, group=None) -> bool:
         return False
     if dist.get_world_size(group) > 255:
         raise ValueError("level marks travel in 8-bit fields: at most 255 ranks")
-    t = engine.partials_tensor()
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    if t.is_cuda:
-        torch.cuda.synchronize(t.device)
-    total_pairs = engine.install_merged_partials()
+    on_stream, ordered = _engine_stream(engine)
+    with on_stream:
+        t = engine.partials_tensor()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _fence(t, ordered)
+        total_pairs = engine.install_merged_partials()
     if total_pairs > 0:  # rare (Q4: reads whose references agree at no level); the same decision on every rank
         p = engine.get_partials()
         pairs = _gather_pairs(p["pairs"], total_pairs, t.device, group)

@@ -145,6 +145,20 @@ class Slimm:
         self._check(self.L.slimm_coverage_buffer(self.ctx, C.byref(ptr), C.byref(n)))
         return DeviceArray(ptr.value, n.value, "<i4")
 
+    def torch_stream(self):
+        """The HIP stream the context's kernels run on, as a torch.cuda.ExternalStream.  Asking for it switches the
+        context to stream-ordered buffers (slimm_set_stream_ordered): collectives issued under
+        `torch.cuda.stream(engine.torch_stream())` are ordered with the library's kernels on the device and no
+        torch.cuda.synchronize is needed between them (slimm_amd/distributed.py does exactly that)."""
+        import torch
+
+        if getattr(self, "_ext_stream", None) is None:
+            p = C.c_void_p()
+            self._check(self.L.slimm_get_stream(self.ctx, C.byref(p)))
+            self._ext_stream = torch.cuda.ExternalStream(p.value, device=f"cuda:{self.device}")
+            self._check(self.L.slimm_set_stream_ordered(self.ctx, 1))
+        return self._ext_stream
+
     def coverage_tensor(self):
         """The coverage buffer as an int32 torch tensor aliasing the library's device memory (for the all-reduce)."""
         import torch

@@ -27,7 +27,7 @@ def _split_by_read(w, world):
     return out
 
 
-def _worker(rank, world, port, case, tmp, exchange="summary"):
+def _worker(rank, world, port, case, tmp, exchange="summary", cuts="hash"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -50,7 +50,15 @@ def _worker(rank, world, port, case, tmp, exchange="summary"):
             w.records.begin_pos[m] = 100
         else:
             w = make_workload(CONFIGS["config2"], seed=23, n_records=150_000)
-        shard = _split_by_read(w, world)[rank]
+        if cuts == "contiguous":   # the partitioner of the library: slices of the grouped file cut at qName runs
+            from slimm_amd.partition import shard_records
+            from slimm_amd.workload import Workload
+
+            rec, still_grouped = shard_records(w.records, rank, world, grouped=True)
+            assert still_grouped
+            shard = Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, f"{w.name}-cut{rank}")
+        else:
+            shard = _split_by_read(w, world)[rank]
         eng = OracleShardEngine(shard)
         text = sharded_profile(eng, None, os.path.join(tmp, "profile.tsv"), exchange=exchange)
         whole = run_workload(w, use_qnames=False, collect_bins=False)
@@ -72,6 +80,14 @@ def test_two_ranks_equal_single_process(case, exchange):
             + {"summary": 0, "bins": 3, "sliced": 4}[exchange])
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(2, port, case, tmp, exchange), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("case", ["config1", "config2"])
+def test_two_ranks_on_contiguous_cuts_of_the_file(case):
+    """slimm_amd/partition.py: rank r keeps records [c_r, c_r+1) of the grouped stream, cut at qName-run boundaries."""
+    port = 29500 + (os.getpid() % 2000) + 20 + {"config1": 0, "config2": 1}[case]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, port, case, tmp, "summary", "contiguous"), nprocs=2, join=True)
 
 
 def test_three_ranks_auto_exchange_is_sliced():

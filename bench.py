@@ -143,6 +143,9 @@ def main():
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # (stdout carries ONE line: RCCL's version banner, printed at NCCL_DEBUG=VERSION / INFO, goes nowhere near it)
+        os.environ["NCCL_DEBUG"] = os.environ.get("SLIMM_NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # (RCCL logs to stdout by default)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = CONFIGS[args.config]
@@ -430,6 +433,28 @@ def main():
                              f"A+B+C+profile {cpu_s:.1f}s of {wall:.1f}s wall",
                    "host": f"{os.cpu_count()} logical cores"}
 
+        # ---- the same host's cores, all of them: the dense multi-threaded restatement of phases A, B and the per-read
+        # LCA (oracle/slimm_dense_mt.cpp, checked against the oracle in tests/test_dense_mt.py).  A reported baseline
+        # like cpu_baseline -- the reference itself is single-threaded -- never a code path of the product.
+        cpu_mt = None
+        if world == 1 and not args.no_cpu_baseline and not strong:
+            from oracle.binding import dense_mt_run
+
+            threads = os.cpu_count() or 1
+            best = None
+            t_all = time.perf_counter()
+            for _ in range(3):
+                d = dense_mt_run(w, threads=threads)
+                sec = sum(d["seconds"])
+                best = sec if best is None else min(best, sec)
+            agree = (d["hits"], d["matches"], d["uniq_matches"], d["uniq_matches2"]) == (
+                st["hits_count"], st["matches_count"], st["uniq_matches_count"], st["uniq_matches_count2"])
+            cpu_mt = {"value": round(len(w.records) / best / 1e6, 3), "unit": "M records/s", "cores": threads, "kind": "port",
+                      "sample": f"best of 3 passes over all {len(w.records)} records of the same stream on {threads} threads: "
+                                f"phases A + B + per-read LCA {best * 1e3:.1f} ms (array allocation and the scalar profile "
+                                f"tail excluded), {time.perf_counter() - t_all:.1f} s wall for the three",
+                      "scalars_equal_gpu": bool(agree)}
+
         line = {
             "metric": "M alignment-records/sec -> final profile",
             "value": round(value, 3), "unit": "M records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -451,6 +476,7 @@ def main():
             "roofline_config3": roof3,
             "value_with_push": with_push,
             "cpu_baseline": cpu,
+            "cpu_baseline_mt": cpu_mt,
             "device_kernel_ms_per_step": round(kernel_ms, 4),
             "kernel_timing": ("HIP events around " + (f"{dom_name} only in the timed steps (other kernels: warm-up survey)"
                                                       if dom_name else "every launch in the timed steps")),

@@ -225,3 +225,52 @@ def run_workload(w, **kw) -> OracleResult:
 def avg_read_length(l_seq: np.ndarray, sample: int = 100000) -> int:
     l_seq = np.ascontiguousarray(l_seq, dtype=np.uint32)
     return int(lib().orc_avg_read_length(_p(l_seq), l_seq.shape[0], sample))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the all-core dense restatement (oracle/slimm_dense_mt.cpp): bench.py's cpu_baseline_mt leg, checked against the
+# oracle above in tests/test_dense_mt.py
+_mt_lib = None
+
+
+def dense_mt_lib():
+    global _mt_lib
+    if _mt_lib is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libslimm_dense_mt.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C oracle`")
+        L = C.CDLL(path)
+        L.dmt_run.restype = C.c_int
+        L.dmt_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                              C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_uint32, C.c_void_p, C.c_void_p]
+        _mt_lib = L
+    return _mt_lib
+
+
+def dense_mt_run(w, records=None, threads: int = 0) -> dict:
+    """Phases A, B and the direct LCA counts of workload `w` (records grouped by read name) on `threads` host threads
+    (0 = all).  Returns per-reference columns, scalars, {taxid: count} and the three phase times."""
+    rec = w.records if records is None else records
+    R = len(w.ref_names)
+    lineage = np.ascontiguousarray(w.taxonomy.lineage_for_header(w.ref_names), dtype=np.uint32)
+    ref_len = np.ascontiguousarray(w.ref_len, dtype=np.uint32)
+    cols = np.zeros((R, 5), dtype=np.uint32)
+    sc = np.zeros(8, dtype=np.uint64)
+    cap = 1 << 20
+    tx = np.zeros(cap, dtype=np.uint32)
+    cn = np.zeros(cap, dtype=np.uint32)
+    n_lca = C.c_uint32(0)
+    sec = np.zeros(3, dtype=np.float64)
+    threads = threads or (os.cpu_count() or 1)
+    rc = dense_mt_lib().dmt_run(_p(rec.read_key), _p(rec.flag), _p(rec.ref_id), _p(rec.begin_pos), len(rec), R, _p(ref_len),
+                                _p(lineage), int(w.avg_read_len), int(w.options.bin_width), float(w.options.cov_cut_off),
+                                int(threads), _p(cols), _p(sc), _p(tx), _p(cn), cap, C.byref(n_lca), _p(sec))
+    if rc < 0:
+        raise RuntimeError("dmt_run: bad arguments")
+    k = min(int(n_lca.value), cap)
+    return {"no_hits": rc == 1, "reads_count": cols[:, 0].copy(), "uniq_reads_count": cols[:, 1].copy(),
+            "nz_cov": cols[:, 2].copy(), "nz_uniq_cov": cols[:, 3].copy(), "uniq_reads_count2": cols[:, 4].copy(),
+            "hits": int(sc[0]), "matches": int(sc[1]), "uniq_matches": int(sc[2]), "uniq_matches2": int(sc[3]),
+            "n_valid": int(sc[4]), "total_bins": int(sc[5]), "lca_direct": {int(a): int(b) for a, b in zip(tx[:k], cn[:k])},
+            "seconds": tuple(float(x) for x in sec), "threads": int(threads)}

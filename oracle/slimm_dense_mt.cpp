@@ -1,0 +1,276 @@
+// ============================================================================
+// slimm_dense_mt.cpp -- TEST INFRASTRUCTURE / CPU BASELINE ONLY.  NOT PART OF THE PRODUCT.
+//
+// What a careful all-core CPU implementation of SLIMM's alignment-to-profile hot path looks like: the reference's
+// algorithm (src/slimm.hpp:194-303 analyze_alignments, :328-392 cut-offs + filter_alignments, :516-557 LCA of the reads
+// that keep several references; src/read_stat.hpp:98-135) restated over DENSE integer arrays and run on every host
+// core, where slimm_oracle.cpp follows the reference container by container on one thread.  It is the fair "what
+// would the host do" number of bench.py's cpu_baseline_mt leg: the reference itself is single-threaded, so this is
+// faster than anything the reference does, by design.  Checked against slimm_oracle.cpp in tests/test_dense_mt.py.
+// Only tests/ and bench.py's cpu_baseline legs may load it; the product (slimm_amd/, libslimm_hip.so) never does.
+//
+// PARITY PIN STATUS: as slimm_oracle.cpp (PARITY UNPINNED beyond the two known-answer micro-cases of SURVEY.md
+// Appendix C; the reference cannot be built in this image).
+//
+// Input: records grouped by read name (all records of a qName adjacent -- mapper output), as the product's
+// SLIMM_ORDER_GROUPED.  Threads take contiguous slices of the stream cut at qName-run boundaries; histogram bins and
+// per-reference counters are shared arrays updated with relaxed atomic adds; per-taxon LCA counts are per-thread maps
+// merged at the end.  Scope: phases A, B and C(1) -- everything that touches records or reads.  The scalar tail of
+// the path (propagation up the lineages, abundances, the profile file: a few thousand taxa, < 1 ms on the oracle) is
+// not repeated here.
+// ============================================================================
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+constexpr uint64_t kKeyMask = (1ull << 62) - 1;
+
+struct Target {
+    uint32_t ref, gbin;
+};
+
+// what phase A leaves behind per thread for phase B: the reads' target lists, back to back
+struct Shard {
+    std::vector<Target> targets;
+    std::vector<uint32_t> read_end;  // end of every read's targets in `targets`
+    uint64_t hits = 0, reads = 0, uniq_reads = 0, uniq_reads2 = 0;
+    std::unordered_map<uint32_t, uint32_t> lca;
+};
+
+inline uint32_t mate_of(uint16_t flag) { return (flag & 0x40) ? 1u : ((flag & 0x80) ? 2u : 0u); }  // slimm.hpp:205-208
+
+// misc.hpp:197-216 get_quantile_cut_off<float>
+float quantile_cut_off(std::vector<float> v, float q) {
+    if (v.empty()) return 0;
+    float total = std::accumulate(v.begin(), v.end(), 0.0f);
+    float sub = 0.0f;
+    std::sort(v.begin(), v.end());
+    uint32_t i = static_cast<uint32_t>(v.size() - 1);
+    while ((float(sub) / total) < q && i > 0.0f) {
+        sub += v[i];
+        --i;
+    }
+    return v[i];
+}
+
+inline void add32(uint32_t* p, uint32_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+template <typename F>
+void parallel(unsigned n_threads, F f) {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(f, t);
+    f(0u);
+    for (auto& th : pool) th.join();
+}
+
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+// ref_cols [R * 5]: reads_count, uniq_reads_count, nz_cov, nz_uniq_cov, uniq_reads_count2
+// scalars  [8]    : hits, matches, uniq_matches, uniq_matches2, n_valid, total bins, 0, 0
+// lca      up to lca_cap (taxid, count) pairs of the reads that keep several references (src/slimm.hpp:536-557)
+// seconds  [3]    : phase A (records -> histograms + statistics), cut-offs + phase B, LCA merge
+// returns 0, 1 when no record is mapped (the reference's early return), -1 on bad arguments
+int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
+            const uint32_t* ref_len, const uint32_t* lineage /*[n_refs * 8]*/, uint32_t avg_read_len, uint32_t bin_width,
+            float cov_cut_off, uint32_t n_threads, uint32_t* ref_cols, uint64_t* scalars, uint32_t* lca_taxid,
+            uint32_t* lca_count, uint32_t lca_cap, uint32_t* n_lca, double* seconds) {
+    if (!n_refs || !ref_len || !lineage || !ref_cols || !scalars || !seconds) return -1;
+    if (bin_width == 0) bin_width = avg_read_len;  // slimm.hpp:412-413
+    if (bin_width == 0) return -1;
+    n_threads = std::max(1u, n_threads);
+    const uint32_t R = n_refs;
+    const uint32_t half = avg_read_len / 2;
+    // bins of every reference back to back (reference_contig.hpp:80: len / width + 1 bins)
+    std::vector<uint64_t> bin_off(R + 1, 0);
+    for (uint32_t r = 0; r < R; ++r) bin_off[r + 1] = bin_off[r] + ref_len[r] / bin_width + 1;
+    const uint64_t B = bin_off[R];
+    std::vector<uint32_t> cov(B, 0), ucov(B, 0), ucov2(B, 0);
+    std::vector<uint32_t> reads_count(R, 0), uniq_count(R, 0), uniq_count2(R, 0), nz_cov(R, 0), nz_ucov(R, 0);
+    std::vector<Shard> shard(n_threads);
+    // contiguous cuts at qName-run boundaries
+    std::vector<uint64_t> cut(n_threads + 1, n);
+    cut[0] = 0;
+    for (unsigned t = 1; t < n_threads; ++t) {
+        uint64_t c = n * t / n_threads;
+        while (c > 0 && c < n && ((key[c] ^ key[c - 1]) & kKeyMask) == 0) ++c;
+        cut[t] = std::max(c, cut[t - 1]);
+    }
+
+    // ---------------------------------------------------------------- phase A (slimm.hpp:194-257)
+    auto t0 = std::chrono::steady_clock::now();
+    parallel(n_threads, [&](unsigned t) {
+        Shard& s = shard[t];
+        const uint64_t lo = cut[t], hi = cut[t + 1];
+        s.targets.reserve((hi - lo) + 16);
+        s.read_end.reserve((hi - lo) / 2 + 16);
+        std::vector<Target> tmp[3];  // the targets of the run's up to three reads (mate 0 / 1 / 2), in file order
+        uint64_t i = lo;
+        while (i < hi) {
+            uint64_t e = i + 1;
+            while (e < hi && ((key[e] ^ key[i]) & kKeyMask) == 0) ++e;
+            for (auto& v : tmp) v.clear();
+            for (uint64_t k = i; k < e; ++k) {
+                if ((flag[k] & 0x4) || ref[k] == -1) continue;  // slimm.hpp:197
+                ++s.hits;
+                const uint32_t r = static_cast<uint32_t>(ref[k]);
+                if (r >= R) continue;  // (the product reports SLIMM_E_REF_RANGE; the streams of the bench hold none)
+                const uint32_t center = std::min(static_cast<uint32_t>(pos[k]) + half, ref_len[r]);  // slimm.hpp:200 (Q3)
+                std::vector<Target>& tg = tmp[mate_of(flag[k])];
+                bool seen = false;  // read_stat.hpp:116-135: the first record of a (read, reference) pair decides (Q1)
+                for (const Target& x : tg)
+                    if (x.ref == r) {
+                        seen = true;
+                        break;
+                    }
+                if (!seen) tg.push_back(Target{r, static_cast<uint32_t>(bin_off[r] + center / bin_width)});
+            }
+            for (auto& tg : tmp) {
+                if (tg.empty()) continue;
+                ++s.reads;
+                const bool uniq = tg.size() == 1;  // slimm.hpp:224
+                if (uniq) {
+                    ++s.uniq_reads;
+                    add32(&uniq_count[tg[0].ref], 1u);
+                    add32(&ucov[tg[0].gbin], 1u);
+                }
+                for (const Target& x : tg) {
+                    add32(&reads_count[x.ref], 1u);
+                    add32(&cov[x.gbin], 1u);
+                    s.targets.push_back(x);
+                }
+                s.read_end.push_back(static_cast<uint32_t>(s.targets.size()));
+            }
+            i = e;
+        }
+    });
+    uint64_t hits = 0, matches = 0, uniq_matches = 0;
+    for (const Shard& s : shard) {
+        hits += s.hits;
+        matches += s.reads;
+        uniq_matches += s.uniq_reads;
+    }
+    // non-zero bins per reference (reference_contig.hpp:84-91)
+    std::atomic<uint32_t> next_ref{0};
+    parallel(n_threads, [&](unsigned) {
+        for (uint32_t r0; (r0 = next_ref.fetch_add(64)) < R;)
+            for (uint32_t r = r0; r < std::min(R, r0 + 64); ++r) {
+                uint32_t a = 0, b = 0;
+                for (uint64_t g = bin_off[r]; g < bin_off[r + 1]; ++g) {
+                    a += cov[g] != 0;
+                    b += ucov[g] != 0;
+                }
+                nz_cov[r] = a;
+                nz_ucov[r] = b;
+            }
+    });
+    seconds[0] = seconds_since(t0);
+    scalars[0] = static_cast<uint32_t>(hits);
+    scalars[1] = static_cast<uint32_t>(matches);
+    scalars[2] = static_cast<uint32_t>(uniq_matches);
+    scalars[5] = B;
+    for (uint32_t r = 0; r < R; ++r) {
+        ref_cols[r * 5 + 0] = reads_count[r];
+        ref_cols[r * 5 + 1] = uniq_count[r];
+        ref_cols[r * 5 + 2] = nz_cov[r];
+        ref_cols[r * 5 + 3] = nz_ucov[r];
+    }
+    if (hits == 0) return 1;
+
+    // ---------------------------------------------------------------- cut-offs + phase B (slimm.hpp:328-392, 672-688)
+    t0 = std::chrono::steady_clock::now();
+    float cc = 0.0f, ucc = 0.0f;
+    if (cov_cut_off < 1.0f) {
+        std::vector<float> a, b;
+        for (uint32_t r = 0; r < R; ++r)
+            if (uniq_count[r] > 0) {
+                const uint32_t nb = static_cast<uint32_t>(bin_off[r + 1] - bin_off[r]);
+                a.push_back(float(nz_cov[r]) / nb);
+                b.push_back(float(nz_ucov[r]) / nb);
+            }
+        cc = quantile_cut_off(a, cov_cut_off);
+        ucc = quantile_cut_off(b, cov_cut_off);
+    }
+    std::vector<uint8_t> valid(R, 0);
+    uint32_t n_valid = 0;
+    for (uint32_t r = 0; r < R; ++r) {
+        if (reads_count[r] == 0) continue;
+        const uint32_t nb = static_cast<uint32_t>(bin_off[r + 1] - bin_off[r]);
+        if (float(nz_cov[r]) / nb >= cc && float(nz_ucov[r]) / nb >= ucc) {
+            valid[r] = 1;
+            ++n_valid;
+        }
+    }
+    parallel(n_threads, [&](unsigned t) {
+        Shard& s = shard[t];
+        uint32_t b = 0;
+        std::vector<uint32_t> ids;
+        for (uint32_t e : s.read_end) {
+            ids.clear();
+            uint32_t first_g = 0;
+            for (uint32_t k = b; k < e; ++k)
+                if (valid[s.targets[k].ref]) {
+                    if (ids.empty()) first_g = s.targets[k].gbin;
+                    ids.push_back(s.targets[k].ref);
+                }
+            b = e;
+            if (ids.size() == 1) {  // slimm.hpp:384-389
+                ++s.uniq_reads2;
+                add32(&uniq_count2[ids[0]], 1u);
+                add32(&ucov2[first_g], 1u);
+            } else if (ids.size() > 1) {  // slimm.hpp:516-531, 536-557: level scan; no agreeing level -> the last value read (Q4)
+                std::sort(ids.begin(), ids.end());
+                uint32_t taxon = 1;
+                for (uint32_t lv = 0; lv < 8; ++lv) {
+                    bool same = true;
+                    const uint32_t first = lineage[static_cast<size_t>(ids[0]) * 8 + lv];
+                    for (uint32_t id : ids) {
+                        taxon = lineage[static_cast<size_t>(id) * 8 + lv];
+                        same = same && taxon == first;
+                    }
+                    if (same) break;
+                }
+                ++s.lca[taxon];
+            }
+        }
+    });
+    seconds[1] = seconds_since(t0);
+
+    // ---------------------------------------------------------------- merge of the per-thread LCA counts
+    t0 = std::chrono::steady_clock::now();
+    std::unordered_map<uint32_t, uint32_t> lca;
+    uint64_t uniq_matches2 = 0;
+    for (const Shard& s : shard) {
+        uniq_matches2 += s.uniq_reads2;
+        for (const auto& kv : s.lca) lca[kv.first] += kv.second;
+    }
+    seconds[2] = seconds_since(t0);
+    scalars[3] = static_cast<uint32_t>(uniq_matches2);
+    scalars[4] = n_valid;
+    for (uint32_t r = 0; r < R; ++r) ref_cols[r * 5 + 4] = uniq_count2[r];
+    uint32_t k = 0;
+    for (const auto& kv : lca) {
+        if (k < lca_cap && lca_taxid && lca_count) {
+            lca_taxid[k] = kv.first;
+            lca_count[k] = kv.second;
+        }
+        ++k;
+    }
+    if (n_lca) *n_lca = k;
+    return 0;
+}
+
+}  // extern "C"

@@ -71,7 +71,8 @@ def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
             mine = engine.coverage_summary_tensor()
             head = engine.summary_head_words()
             chunks = mine[head:]
-            received = torch.empty_like(chunks)
+            received = (engine.scratch("received", chunks.numel(), chunks) if hasattr(engine, "scratch")
+                        else torch.empty_like(chunks))
             if dist.is_initialized():
                 dist.all_to_all_single(received, chunks, group=group)
             else:
@@ -83,7 +84,8 @@ def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
             _fence(vec, ordered)
             return engine.finish_coverage_reduced()
         mine = engine.coverage_summary_tensor()
-        gathered = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        gathered = (engine.scratch("gathered", world * mine.numel(), mine) if hasattr(engine, "scratch")
+                    else torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device))
         if dist.is_initialized():
             dist.all_gather_into_tensor(gathered, mine, group=group)
         else:

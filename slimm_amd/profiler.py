@@ -23,6 +23,7 @@ class DeviceArray:
     """A device pointer + length exposed through __cuda_array_interface__ (lets torch alias library memory)."""
 
     def __init__(self, ptr: int, n: int, typestr: str = "<i4"):
+        self.ptr, self.n = ptr, n
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
@@ -145,6 +146,29 @@ class Slimm:
         self._check(self.L.slimm_coverage_buffer(self.ctx, C.byref(ptr), C.byref(n)))
         return DeviceArray(ptr.value, n.value, "<i4")
 
+    def _alias(self, name: str, ptr: int, n: int):
+        """int32 torch tensor over n words of library memory at ptr; the wrapper is kept per buffer (building one from
+        __cuda_array_interface__ costs tens of microseconds, which the per-file exchange would pay three times)."""
+        import torch
+
+        cache = self.__dict__.setdefault("_alias_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != (ptr, n):
+            hit = ((ptr, n), torch.as_tensor(DeviceArray(ptr, n, "<i4"), device=f"cuda:{self.device}"))
+            cache[name] = hit
+        return hit[1]
+
+    def scratch(self, name: str, numel: int, like):
+        """A reusable device tensor of the exchange (receive buffers), allocated once per size."""
+        import torch
+
+        cache = self.__dict__.setdefault("_scratch_cache", {})
+        t = cache.get(name)
+        if t is None or t.numel() != numel or t.dtype != like.dtype or t.device != like.device:
+            t = torch.empty(numel, dtype=like.dtype, device=like.device)
+            cache[name] = t
+        return t
+
     def torch_stream(self):
         """The HIP stream the context's kernels run on, as a torch.cuda.ExternalStream.  Asking for it switches the
         context to stream-ordered buffers (slimm_set_stream_ordered): collectives issued under
@@ -163,7 +187,8 @@ class Slimm:
         """The coverage buffer as an int32 torch tensor aliasing the library's device memory (for the all-reduce)."""
         import torch
 
-        return torch.as_tensor(self.coverage_buffer(), device=f"cuda:{self.device}")
+        b = self.coverage_buffer()
+        return self._alias("coverage", b.ptr, b.n)
 
     def keep_bins(self, on: bool = True):
         """Whether the coverage arrays are materialised in HBM (needed by bins() and coverage_tensor(); default yes)."""
@@ -188,7 +213,7 @@ class Slimm:
         n = C.c_uint64()
         self._check(self.L.slimm_merge_summary_slices(self.ctx, C.c_void_p(received.data_ptr()), int(n_ranks), int(rank),
                                                       C.byref(ptr), C.byref(n)))
-        return torch.as_tensor(DeviceArray(ptr.value, n.value, "<i4"), device=f"cuda:{self.device}")
+        return self._alias("sum_vec", ptr.value, n.value)
 
     def finish_coverage_reduced(self) -> bool:
         return self._check(self.L.slimm_finish_coverage_reduced(self.ctx)) != capi.E_NO_HITS
@@ -200,7 +225,7 @@ class Slimm:
         ptr = C.c_void_p()
         n = C.c_uint64()
         self._check(self.L.slimm_coverage_summary(self.ctx, C.byref(ptr), C.byref(n)))
-        return torch.as_tensor(DeviceArray(ptr.value, n.value, "<i4"), device=f"cuda:{self.device}")
+        return self._alias("summary", ptr.value, n.value)
 
     def finish_coverage_merged(self, gathered, n_ranks: int) -> bool:
         """`gathered`: int32 device tensor holding the summaries of all ranks back to back (all_gather output)."""
@@ -242,7 +267,7 @@ class Slimm:
         ptr = C.c_void_p()
         n = C.c_uint64()
         self._check(self.L.slimm_partials_buffer(self.ctx, C.byref(ptr), C.byref(n)))
-        return torch.as_tensor(DeviceArray(ptr.value, n.value, "<i4"), device=f"cuda:{self.device}")
+        return self._alias("partials", ptr.value, n.value)
 
     def install_merged_partials(self) -> int:
         """Installs the (summed) partials buffer; returns the number of (taxon, reference) pairs over all ranks."""

@@ -13,9 +13,9 @@
 // Appendix C; the reference cannot be built in this image).
 //
 // Input: records grouped by read name (all records of a qName adjacent -- mapper output), as the product's
-// SLIMM_ORDER_GROUPED.  Threads take contiguous slices of the stream cut at qName-run boundaries; histogram bins and
-// per-reference counters are shared arrays updated with relaxed atomic adds; per-taxon LCA counts are per-thread maps
-// merged at the end.  Scope: phases A, B and C(1) -- everything that touches records or reads.  The scalar tail of
+// SLIMM_ORDER_GROUPED.  Threads take contiguous slices of the stream cut at qName-run boundaries; histogram bins are
+// shared arrays updated with relaxed atomic adds; per-reference counters and per-taxon LCA counts are private to a
+// thread and merged at the end (the few abundant references of a sample would be one contended cache line otherwise).  Scope: phases A, B and C(1) -- everything that touches records or reads.  The scalar tail of
 // the path (propagation up the lineages, abundances, the profile file: a few thousand taxa, < 1 ms on the oracle) is
 // not repeated here.
 // ============================================================================
@@ -38,9 +38,12 @@ struct Target {
 };
 
 // what phase A leaves behind per thread for phase B: the reads' target lists, back to back
-struct Shard {
+struct alignas(128) Shard {  // (a cache line pair of its own: the threads' counters never share one)
     std::vector<Target> targets;
     std::vector<uint32_t> read_end;  // end of every read's targets in `targets`
+    // per-reference counters are private to the thread and summed afterwards: the few abundant references of a sample
+    // would otherwise be one contended cache line for all threads
+    std::vector<uint32_t> reads_count, uniq_count, uniq_count2;
     uint64_t hits = 0, reads = 0, uniq_reads = 0, uniq_reads2 = 0;
     std::unordered_map<uint32_t, uint32_t> lca;
 };
@@ -117,6 +120,10 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
         const uint64_t lo = cut[t], hi = cut[t + 1];
         s.targets.reserve((hi - lo) + 16);
         s.read_end.reserve((hi - lo) / 2 + 16);
+        s.reads_count.assign(R, 0);
+        s.uniq_count.assign(R, 0);
+        s.uniq_count2.assign(R, 0);
+        uint64_t n_hits = 0, n_reads = 0, n_uniq = 0;
         std::vector<Target> tmp[3];  // the targets of the run's up to three reads (mate 0 / 1 / 2), in file order
         uint64_t i = lo;
         while (i < hi) {
@@ -125,7 +132,7 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
             for (auto& v : tmp) v.clear();
             for (uint64_t k = i; k < e; ++k) {
                 if ((flag[k] & 0x4) || ref[k] == -1) continue;  // slimm.hpp:197
-                ++s.hits;
+                ++n_hits;
                 const uint32_t r = static_cast<uint32_t>(ref[k]);
                 if (r >= R) continue;  // (the product reports SLIMM_E_REF_RANGE; the streams of the bench hold none)
                 const uint32_t center = std::min(static_cast<uint32_t>(pos[k]) + half, ref_len[r]);  // slimm.hpp:200 (Q3)
@@ -140,15 +147,15 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
             }
             for (auto& tg : tmp) {
                 if (tg.empty()) continue;
-                ++s.reads;
+                ++n_reads;
                 const bool uniq = tg.size() == 1;  // slimm.hpp:224
                 if (uniq) {
-                    ++s.uniq_reads;
-                    add32(&uniq_count[tg[0].ref], 1u);
+                    ++n_uniq;
+                    ++s.uniq_count[tg[0].ref];
                     add32(&ucov[tg[0].gbin], 1u);
                 }
                 for (const Target& x : tg) {
-                    add32(&reads_count[x.ref], 1u);
+                    ++s.reads_count[x.ref];
                     add32(&cov[x.gbin], 1u);
                     s.targets.push_back(x);
                 }
@@ -156,6 +163,9 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
             }
             i = e;
         }
+        s.hits = n_hits;
+        s.reads = n_reads;
+        s.uniq_reads = n_uniq;
     });
     uint64_t hits = 0, matches = 0, uniq_matches = 0;
     for (const Shard& s : shard) {
@@ -175,6 +185,13 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
                 }
                 nz_cov[r] = a;
                 nz_ucov[r] = b;
+                uint32_t rc = 0, uc = 0;
+                for (const Shard& s : shard) {
+                    rc += s.reads_count[r];
+                    uc += s.uniq_count[r];
+                }
+                reads_count[r] = rc;
+                uniq_count[r] = uc;
             }
     });
     seconds[0] = seconds_since(t0);
@@ -217,6 +234,7 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
     parallel(n_threads, [&](unsigned t) {
         Shard& s = shard[t];
         uint32_t b = 0;
+        uint64_t n_uniq2 = 0;
         std::vector<uint32_t> ids;
         for (uint32_t e : s.read_end) {
             ids.clear();
@@ -228,8 +246,8 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
                 }
             b = e;
             if (ids.size() == 1) {  // slimm.hpp:384-389
-                ++s.uniq_reads2;
-                add32(&uniq_count2[ids[0]], 1u);
+                ++n_uniq2;
+                ++s.uniq_count2[ids[0]];
                 add32(&ucov2[first_g], 1u);
             } else if (ids.size() > 1) {  // slimm.hpp:516-531, 536-557: level scan; no agreeing level -> the last value read (Q4)
                 std::sort(ids.begin(), ids.end());
@@ -246,6 +264,7 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
                 ++s.lca[taxon];
             }
         }
+        s.uniq_reads2 = n_uniq2;
     });
     seconds[1] = seconds_since(t0);
 
@@ -256,6 +275,7 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
     for (const Shard& s : shard) {
         uniq_matches2 += s.uniq_reads2;
         for (const auto& kv : s.lca) lca[kv.first] += kv.second;
+        for (uint32_t r = 0; r < R; ++r) uniq_count2[r] += s.uniq_count2[r];
     }
     seconds[2] = seconds_since(t0);
     scalars[3] = static_cast<uint32_t>(uniq_matches2);

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 
@@ -51,6 +52,7 @@ bool AlignmentFile::open(const std::string& path) {
     pos_ = 0;
     eof_ = false;
     have_pending_ = false;
+    have_last_ = false;
     {
         const char* e = getenv("SLIMM_DECODE_THREADS");
         unsigned hw = std::thread::hardware_concurrency();
@@ -455,6 +457,67 @@ void AlignmentFile::decode_parallel(size_t cnt, F decode) {
     for (auto& th : pool) th.join();
 }
 
+// Exact read identity for adjacent records (what grouped input needs): a record whose name differs from the record
+// before it never shares its key, whatever the hash says.  Keys are 62-bit hashes of the names; two DIFFERENT names
+// with one hash next to each other in a name-grouped file would be taken for one read.  Every record whose key equals
+// its predecessor's has its name compared with the predecessor's (a memcmp inside a run); on a mismatch the run gets
+// the next free key.  (Names that collide far apart in an unsorted file are not seen here: 2^-62 per pair.)
+void AlignmentFile::separate_adjacent_names(uint64_t* key, const std::vector<size_t>& offs) {
+    const size_t cnt = offs.size();
+    if (!cnt) return;
+    constexpr uint64_t kMask = (1ull << 62) - 1;
+    auto name_of = [&](size_t k, size_t& len) {
+        const uint8_t* r = &buf_[offs[k] + 4];
+        len = r[8] ? r[8] - 1u : 0u;
+        return reinterpret_cast<const char*>(r + 32);
+    };
+    auto same_name = [&](size_t a, size_t b) {
+        size_t la, lb;
+        const char* pa = name_of(a, la);
+        const char* pb = name_of(b, lb);
+        return la == lb && memcmp(pa, pb, la) == 0;
+    };
+    std::vector<size_t> clash;  // records that start a new name under their predecessor's key
+    std::mutex mu;
+    decode_parallel(cnt, [&](size_t lo, size_t hi) {
+        for (size_t k = std::max<size_t>(lo, 1); k < hi; ++k)
+            if (key[k] == key[k - 1] && !same_name(k, k - 1)) {
+                std::lock_guard<std::mutex> g(mu);
+                clash.push_back(k);
+            }
+    });
+    // the batch's first record against the last record of the batch before
+    size_t l0;
+    const char* n0 = name_of(0, l0);
+    const bool continues = have_last_ && last_name_.size() == l0 && memcmp(last_name_.data(), n0, l0) == 0;
+    if (have_last_ && (continues ? key[0] != last_key_ : key[0] == last_key_)) clash.push_back(0);
+    std::sort(clash.begin(), clash.end());
+    for (size_t q = 0; q < clash.size(); ++q) {
+        const size_t k = clash[q];
+        uint64_t fresh;
+        if (k == 0 && continues) {
+            fresh = last_key_;  // the run goes on under the key it was given in the batch before
+        } else {
+            const uint64_t before = k ? key[k - 1] : last_key_;
+            if (key[k] != before) continue;  // (an earlier move took its predecessor out of the way)
+            fresh = (key[k] + 1) & kMask;
+            while (fresh == before) fresh = (fresh + 1) & kMask;
+        }
+        size_t e = k + 1;
+        while (e < cnt && same_name(e, k)) ++e;
+        for (size_t j = k; j < e; ++j) key[j] = fresh;
+        // the name behind the run must not run into the fresh key either
+        if (e < cnt && key[e] == fresh && (q + 1 >= clash.size() || clash[q + 1] != e)) {
+            clash.insert(clash.begin() + static_cast<long>(q) + 1, e);
+        }
+    }
+    size_t ll;
+    const char* ln = name_of(cnt - 1, ll);
+    last_name_.assign(ln, ll);
+    last_key_ = key[cnt - 1];
+    have_last_ = true;
+}
+
 // The four record fields of the hot path straight into the caller's arrays (the page-locked staging sets of
 // slimm_staging_buffers: the DMA engine reads what the decode threads wrote, no copy in between).
 long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records) {
@@ -482,6 +545,7 @@ long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begi
             flag[k] = rd_u16(r + 14);
         }
     });
+    separate_adjacent_names(read_key, offs);
     return cnt;
 }
 
@@ -513,6 +577,7 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
                 if (keep_names) out.qname[base + k].assign(name, nlen);
             }
         });
+        separate_adjacent_names(out.read_key.data() + base, offs);
         return static_cast<long>(cnt);
     }
     // SAM: QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL ...
@@ -547,7 +612,17 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
             auto it = index.find(rn);
             if (it != index.end()) ref_id = it->second;
         }
-        out.read_key.push_back(hash_read_name(qn.data(), qn.size()));
+        uint64_t key = hash_read_name(qn.data(), qn.size());
+        if (have_last_) {  // (separate_adjacent_names, one record at a time)
+            if (qn == last_name_)
+                key = last_key_;
+            else if (key == last_key_)
+                key = (key + 1) & ((1ull << 62) - 1);
+        }
+        last_name_ = qn;
+        last_key_ = key;
+        have_last_ = true;
+        out.read_key.push_back(key);
         out.ref_id.push_back(ref_id);
         out.begin_pos.push_back(static_cast<int32_t>(pos1 - 1));  // SAM POS is 1-based; 0 ("unavailable") becomes -1
         out.flag.push_back(flag);

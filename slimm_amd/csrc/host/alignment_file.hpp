@@ -36,8 +36,9 @@ struct RecordBatch {
 
 enum class SortOrder { Unknown, Unsorted, QueryName, Coordinate, QueryGrouped };
 
-// 62-bit identity of a read name (equal names <=> equal keys, up to hash collisions: ~0.04 % odds of ANY collision
-// among 125 M reads).
+// 62-bit identity of a read name.  The reader makes it exact where grouped input needs it to be: a record whose name
+// differs from its predecessor's never gets the predecessor's key (separate_adjacent_names).  Names colliding far
+// apart in a file that is NOT grouped by name remain possible (~0.04 % odds of any such pair among 125 M reads).
 uint64_t hash_read_name(const char* s, size_t n);
 
 class AlignmentFile {
@@ -67,6 +68,10 @@ private:
     long bam_record_starts(size_t max_records, std::vector<size_t>& offs);
     template <typename F>
     void decode_parallel(size_t cnt, F decode);
+    void separate_adjacent_names(uint64_t* key, const std::vector<size_t>& offs);
+    std::string last_name_;   // name and key of the last record handed out (separate_adjacent_names)
+    uint64_t last_key_ = 0;
+    bool have_last_ = false;
     // record starts in buf_[pos_, end): appended to offs, at most max_records; returns false on a malformed record
     bool find_records(size_t end, size_t max_records, std::vector<size_t>& offs, size_t& new_pos);
     bool plausible_record(size_t o, size_t end, int depth) const;

@@ -132,3 +132,35 @@ def test_cli_on_a_database_made_by_slimm_build(tmp_path):
     run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp])
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
     check_outputs(out, "sample", o)
+
+
+def test_cli_two_names_with_one_hash_are_two_reads(tmp_path):
+    """two different read names whose 62-bit hashes are equal, next to each other in a
+    name-grouped file.  The oracle keys reads by the names themselves; the command line must agree with it (its reader
+    compares the names of adjacent records with equal keys and moves the second name to a key of its own)."""
+    from tests.test_cli_readers import colliding_names
+
+    a, b = colliding_names()
+    w = with_names(make_workload(CONFIGS["config1"], seed=43))
+    r = w.records
+    q = list(r.qname)
+    # give the two names to two ADJACENT multi-record reads (all records of each)
+    starts = [i for i in range(len(q)) if i == 0 or q[i] != q[i - 1]]
+    runs = [(s, e) for s, e in zip(starts, starts[1:] + [len(q)])]
+    k = next(i for i in range(len(runs) - 1) if runs[i][1] - runs[i][0] >= 2 and runs[i + 1][1] - runs[i + 1][0] >= 2
+             and (r.ref_id[runs[i][0]:runs[i][1]] >= 0).all() and (r.ref_id[runs[i + 1][0]:runs[i + 1][1]] >= 0).all())
+    for (s, e), nm in zip((runs[k], runs[k + 1]), (a, b)):
+        for i in range(s, e):
+            q[i] = nm
+    w = Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, q), w.avg_read_len,
+                 w.options, w.name)
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "sample.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", "-v", db, inp])
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    check_outputs(out, "sample", o)
+    assert f"{o.scalars['matches']} matching reads" in err

@@ -114,3 +114,64 @@ def test_sort_order_tag_and_errors(tmp_path):
     assert r.returncode != 0
     r = subprocess.run([CLI, "--dump-records", str(tmp_path / "missing.bam")], capture_output=True, text=True)
     assert r.returncode != 0 and "Could not open" in r.stderr
+
+
+# ---------------------------------------------------------------- name-hash collisions
+_M64 = (1 << 64) - 1
+
+
+def _hash_state(words, n):
+    """hash_read_name of alignment_file.cpp up to (not including) its tail step, for whole 8-byte words."""
+    h = 0x9E3779B97F4A7C15 ^ ((n * 0xff51afd7ed558ccd) & _M64)
+    for w in words:
+        h ^= w
+        h = (h * 0xff51afd7ed558ccd) & _M64
+        h ^= h >> 32
+    return h
+
+
+def colliding_names():
+    """Two different printable 16-byte names with the same hash: every step of the hash is a bijection of its state, so
+    after two words the states are equal iff (state_1 ^ word_2) are -- the second word of one name is chosen to cancel
+    the difference the first words made."""
+    import itertools
+    import struct
+
+    a = b"readAAAAcollideX"
+    wa = struct.unpack("<2Q", a)
+    sa = _hash_state(wa[:1], 16)
+    for tag in itertools.product(b"BCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", repeat=4):
+        first = b"read" + bytes(tag)
+        (wb0,) = struct.unpack("<Q", first)
+        sb = _hash_state([wb0], 16)
+        wb1 = wa[1] ^ sa ^ sb
+        second = struct.pack("<Q", wb1)
+        if all(33 <= c < 127 for c in second):
+            b = first + second
+            assert b != a
+            return a.decode(), b.decode()
+    raise AssertionError("no printable partner found")
+
+
+@pytest.mark.parametrize("writer", [write_sam, write_bam])
+def test_adjacent_names_with_equal_hashes_stay_two_reads(tmp_path, writer):
+    """Name-grouped input: the reader compares the NAMES of adjacent records whenever their keys are equal, so two
+    different names can never be taken for one read (the key of the second one is moved to the next free value)."""
+    from slimm_amd.workload import Records
+
+    a, b = colliding_names()
+    w = tiny_case()
+    names = ["before", a, a, b, b, b, a, "after"]    # ... and the same name coming back later gets its own hash again
+    n = len(names)
+    rec = Records(np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint16), np.zeros(n, dtype=np.int32),
+                  np.arange(n, dtype=np.int32) * 10, names)
+    p = str(tmp_path / ("c." + ("sam" if writer is write_sam else "bam")))
+    writer(p, w.ref_names, w.ref_len, rec, read_len=50)
+    _, _, recs = dump(p)
+    assert [r[0] for r in recs] == names
+    keys = [r[5] for r in recs]
+    assert keys[1] == keys[2] and keys[3] == keys[4] == keys[5]
+    assert keys[2] != keys[3] and keys[5] != keys[6]
+    assert len({keys[0], keys[1], keys[3], keys[7]}) == 4
+    # without the name comparison the two names WOULD share a key: the construction is a real collision
+    assert int(keys[3]) == (int(keys[1]) + 1) % (1 << 62) and keys[6] == keys[1]

@@ -32,7 +32,8 @@ enum {
     SLIMM_E_INVALID = -1,   /* bad argument / call order */
     SLIMM_E_HIP = -2,       /* HIP runtime error (no GPU, out of memory, ...) */
     SLIMM_E_REF_RANGE = -3, /* a record names ref_id >= n_refs (undefined behaviour in the reference) */
-    SLIMM_E_RUN_LENGTH = -4,/* one read has more alignment records than the look-back window supports */
+    SLIMM_E_RUN_LENGTH = -4,/* (not returned any more: a read may have any number of alignment records; the value is
+                               kept so that the codes after it do not move) */
     SLIMM_E_NO_HITS = 1     /* not an error: no mapped record (reference prints a warning and writes nothing, src/slimm.hpp:451-455) */
 };
 
@@ -93,7 +94,11 @@ int slimm_set_cutoff_cache(slimm_ctx* ctx, float coverage_cut_off, float uniq_co
 /* ---- record stream: what the loop of analyze_alignments() reads from each BamAlignmentRecord
  *      (src/slimm.hpp:194-211): qName identity, flag, rID, beginPos; file order. ------------------
  * read_key: identity of the qName (equal names <=> equal keys); only the low 62 bits are significant
- * (the mate number from flag 0x40/0x80 is folded into the two low bits on the device). */
+ * (the mate number from flag 0x40/0x80 is folded into the two low bits on the device).  The library compares
+ * keys, never names: "equal names <=> equal keys" is the caller's promise.  GROUPED streams only ever compare
+ * ADJACENT records, so a producer that hashes names can make the promise exact by comparing every name with the
+ * one before it (the slimm command's reader does: host/alignment_file.cpp, separate_adjacent_names); for ANY order
+ * a 62-bit hash leaves ~n^2 / 2^63 odds of two different names meeting. */
 int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);
 /* Append a batch from host memory (copied to the device before return). */
 int slimm_push_records(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,

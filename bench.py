@@ -70,8 +70,9 @@ def pmc_traffic_bytes(kernel_name, records_per_gpu):
     correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-byte requests as 64 bytes, i.e. half of a
     coalesced stream -- calibrated here on k_ref_stats, whose 16 B/lane loads read exactly 8 B per bin (ratio 2.03) --
     so fetched bytes = 2 * FETCH_SIZE; WRITE_SIZE is exact.  None when no profile matches."""
-    path = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_summary.json")
-    if records_per_gpu != 10_000_000 or not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic_summary.json") for r in ("round2", "round1"))
+                 if os.path.exists(q)), None)
+    if records_per_gpu != 10_000_000 or path is None:
         return None
     with open(path) as f:
         d = json.load(f)
@@ -285,7 +286,7 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic_bytes(dom, n_records) if traffic_for == "config2" else None,
-                "traffic_source": "profiles/round1/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes)",
+                "traffic_source": "profiles/round2/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes)",
                 "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
         kernel_ms = sum(v["ms_per_launch"] * v["launches_per_step"] for v in per_kernel.values())
         return roof, per_kernel, kernel_ms

@@ -1,12 +1,12 @@
 # rocprofv3 kernel trace + stats of the default bench; summary goes to gpurun_out/<tag>/
 TAG=${1:-trace}
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/$TAG; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config3 --push-steps 0 > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$R/gpurun_out/$TAG/t_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'k_runs' in r['Kernel_Name']]
+idx=[i for i,r in enumerate(rows) if 'k_front' in r['Kernel_Name']]
 s=idx[-1]; prev=None; busy=0; first=None; last=None
 for r in rows[s-2:]:
     st=int(r['Start_Timestamp']); en=int(r['End_Timestamp'])

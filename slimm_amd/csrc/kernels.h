@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// "This value is in a vector register HERE": an empty asm statement that takes and returns it.  It costs nothing and
+// gives a loaded value a use the compiler can neither move nor remove -- without one, a read-only load whose only uses
+// sit in a conditional block is sunk into that block, and the loads a kernel issued together come back one at a time.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SLIMM_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define SLIMM_PIN_VGPR(x) (void)(x)
+#endif
+
 namespace slimm {
 
 // slots of the device counter block (uint32[32])

@@ -636,11 +636,12 @@ struct Lookup {
 
 template <typename Rows>
 __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
-                                                uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
+                                                uint32_t g, const typename Rows::Row& row, uint64_t valid_lanes,
+                                                uint32_t sel_base) {
     const uint64_t PR = k_below(X);
     const uint64_t H = k_ballot((w >> 31) != 0u) & PR;  // (bit 0 is set: a window starts at a read's first target)
     const uint32_t ref = w & 0x7fffffffu;
-    const uint64_t VB = k_ballot(Rows::valid(row)) & PR;
+    const uint64_t VB = valid_lanes & PR;               // valid_lanes = k_ballot(Rows::valid(row)), taken by the caller
     const uint64_t stops = (H >> 1) | (1ull << (X - 1u));
     const uint64_t FV = k_first_after(H, VB, stops);              // first valid target of every read
     const uint64_t SV = k_first_after(H, VB & ~FV, stops);        // second one, where there is one
@@ -702,7 +703,7 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
 template <typename Rows>
 __device__ __forceinline__ void filter_window_now(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
                                                   uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
-    const Lookup lk = filter_window(rows, out, lane, X, w, g, row, sel_base);
+    const Lookup lk = filter_window(rows, out, lane, X, w, g, row, k_ballot(Rows::valid(row)), sel_base);
     if (lk.want) out.sel[lk.ridx] = out.taxon_base + rows.taxon_at(lk.index);
 }
 
@@ -772,13 +773,13 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 constexpr int kFilterBlock = 256;
 
 // A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
-// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Eight
-// at a time: the target words of all eight are loaded together, then their lineage rows gathered together, then the eight
+// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Six
+// at a time: the target words of all six are loaded together, then their lineage rows gathered together, then the six
 // are worked on, then the taxa of their reads with several targets looked up together -- three memory round trips per
-// eight windows (measured: 4 -> 8 windows per trip is worth 5 % at config 2, 7 % at config 3).  (No branch around the loads:
+// six windows (a slot has ~17: three full trips; 4, 8 and 12 per trip measure 65 / 64 / 70 us against 61).  (No branch around the loads:
 // with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
 // waits for and waits for all of them.)
-constexpr int kFilterBatch = 8;
+constexpr int kFilterBatch = 6;
 template <typename Rows>
 __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,
@@ -812,17 +813,31 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
                 w[u] = tgt_ref[t];
                 g[u] = tgt_gbin[t];
             }
+            __builtin_amdgcn_sched_barrier(0);  // (every load of the stage before the first use of one)
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) row[u] = rows.load(lane < cnt[u] ? (w[u] & 0x7fffffffu) : 0u);
+            __builtin_amdgcn_sched_barrier(0);
+            // Every loaded value gets a use HERE, in the straight-line code behind its stage: a (restrict, read-only) load
+            // whose only uses sit in a conditional block further down is sunk into that block by the compiler -- which
+            // turns "three round trips per eight windows" back into three per window.
+            uint64_t vb[kFilterBatch];
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) {
+                SLIMM_PIN_VGPR(g[u]);
+                vb[u] = k_ballot(Rows::valid(row[u]));
+            }
             Lookup lk[kFilterBatch];
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) {
                 lk[u] = Lookup{0u, 0u, false};
-                if (cnt[u]) lk[u] = filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], selb[u]);
+                if (cnt[u]) lk[u] = filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], vb[u], selb[u]);
             }
             uint32_t taxon[kFilterBatch];
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) taxon[u] = rows.taxon_at(lk[u].want ? lk[u].index : 0u);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) SLIMM_PIN_VGPR(taxon[u]);  // (a use in straight-line code, as above)
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u)
                 if (lk[u].want) out.sel[lk[u].ridx] = out.taxon_base + taxon[u];

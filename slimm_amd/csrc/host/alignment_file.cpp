@@ -6,6 +6,8 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -13,6 +15,81 @@
 namespace slimm {
 
 // wyhash-style 64-bit mix of the name bytes, folded to 62 bits
+// The reader's worker threads: started once per file and handed one job after the other.  A batch of a million
+// records goes through four parallel stages of a few milliseconds each (inflate, record starts, decode, name check);
+// starting and joining 32 threads for every one of them cost about as much as the work.
+class AlignmentFile::Workers {
+public:
+    explicit Workers(unsigned n_threads) {
+        for (unsigned t = 1; t < n_threads; ++t) pool_.emplace_back([this] { loop(); });
+    }
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : pool_) t.join();
+    }
+    unsigned size() const { return static_cast<unsigned>(pool_.size()) + 1u; }
+    // fn(i) for every i in [0, count), on the workers and the calling thread; returns when all are done
+    void run(unsigned count, const std::function<void(unsigned)>& fn) {
+        if (count == 0) return;
+        if (count == 1 || pool_.empty()) {
+            for (unsigned i = 0; i < count; ++i) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_.store(&fn);
+            count_.store(count);
+            next_.store(0, std::memory_order_relaxed);
+            left_ = count;
+            ++generation_;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return left_ == 0; });
+        count_.store(0);  // (stragglers find nothing to do)
+    }
+
+private:
+    void work() {
+        unsigned finished = 0;
+        for (unsigned i; (i = next_.fetch_add(1)) < count_.load();) {
+            (*fn_.load())(i);
+            ++finished;
+        }
+        if (finished) {
+            std::lock_guard<std::mutex> g(mu_);
+            left_ -= finished;
+            if (left_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                wake_.wait(g, [&] { return quit_ || generation_ != seen; });
+                if (quit_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+    std::vector<std::thread> pool_;
+    std::mutex mu_;
+    std::condition_variable wake_, done_;
+    // (a worker on its way out of the job before may already pick up items of the next one: fn_ and count_ are atomics)
+    std::atomic<const std::function<void(unsigned)>*> fn_{nullptr};
+    std::atomic<unsigned> next_{0}, count_{0};
+    unsigned left_ = 0;
+    uint64_t generation_ = 0;
+    bool quit_ = false;
+};
+
 uint64_t hash_read_name(const char* s, size_t n) {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdULL);
     size_t i = 0;
@@ -33,11 +110,13 @@ uint64_t hash_read_name(const char* s, size_t n) {
     return h >> 2;
 }
 
+AlignmentFile::AlignmentFile() = default;
 AlignmentFile::~AlignmentFile() { close(); }
 
 void AlignmentFile::close() {
     if (fp_) fclose(fp_);
     fp_ = nullptr;
+    workers_.reset();
 }
 
 static uint32_t rd_u32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
@@ -56,8 +135,9 @@ bool AlignmentFile::open(const std::string& path) {
     {
         const char* e = getenv("SLIMM_DECODE_THREADS");
         unsigned hw = std::thread::hardware_concurrency();
-        threads_ = e ? static_cast<unsigned>(std::max(1, atoi(e))) : std::max(1u, std::min(hw ? hw : 1u, 32u));
+        threads_ = e ? static_cast<unsigned>(std::max(1, atoi(e))) : std::max(1u, std::min(hw ? hw : 1u, 64u));
     }
+    workers_.reset(new Workers(threads_));
     order_ = SortOrder::Unknown;
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) {
@@ -95,7 +175,7 @@ bool inflate_one(const uint8_t* src, size_t clen, uint8_t* dst, uint32_t isize, 
 }  // namespace
 
 bool AlignmentFile::inflate_batch() {
-    constexpr size_t kBatchBytes = 4u << 20;  // compressed bytes per batch
+    constexpr size_t kBatchBytes = 16u << 20;  // compressed bytes per batch
     cbuf_.clear();
     blocks_.clear();
     // drop consumed bytes so the window does not grow without bound
@@ -161,11 +241,7 @@ bool AlignmentFile::inflate_batch() {
             if (!inflate_one(cbuf_.data() + b.coff, b.clen, buf_.data() + b.ooff, b.isize, b.crc)) ok = false;
         }
     };
-    unsigned nthreads = std::min<unsigned>(threads_, static_cast<unsigned>(blocks_.size()));
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    workers_->run(std::min<unsigned>(threads_, static_cast<unsigned>(blocks_.size())), [&](unsigned) { work(); });
     if (!ok) {
         err_ = "corrupt BGZF block (inflate or CRC failed)";
         return false;
@@ -371,12 +447,7 @@ bool AlignmentFile::find_records(size_t end, size_t max_records, std::vector<siz
         k.offs.reserve((k.hi - k.lo) / 128);
         walk(from, k.hi, k.offs, k.stop, k.bad);
     };
-    {
-        std::vector<std::thread> pool;
-        for (unsigned c = 1; c < nchunks; ++c) pool.emplace_back(work, c);
-        work(0);
-        for (auto& th : pool) th.join();
-    }
+    workers_->run(nchunks, work);
     size_t cur = pos_;  // where the next record starts, according to the verified walk so far
     bool window_done = false;
     for (unsigned c = 0; c < nchunks && !window_done; ++c) {
@@ -445,16 +516,13 @@ long AlignmentFile::bam_record_starts(size_t max_records, std::vector<size_t>& o
 // decode(lo, hi) over [0, cnt) on the reader's threads
 template <typename F>
 void AlignmentFile::decode_parallel(size_t cnt, F decode) {
-    const unsigned nthreads = cnt >= 65536 ? std::min<unsigned>(threads_, 16u) : 1u;
+    const unsigned nthreads = cnt >= 65536 ? threads_ : 1u;
     if (nthreads <= 1) {
         decode(0, cnt);
         return;
     }
-    std::vector<std::thread> pool;
     const size_t per = (cnt + nthreads - 1) / nthreads;
-    for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(decode, std::min(cnt, t * per), std::min(cnt, (t + 1) * per));
-    decode(0, std::min(cnt, per));
-    for (auto& th : pool) th.join();
+    workers_->run(nthreads, [&](unsigned t) { decode(std::min(cnt, t * per), std::min(cnt, (t + 1) * per)); });
 }
 
 // Exact read identity for adjacent records (what grouped input needs): a record whose name differs from the record

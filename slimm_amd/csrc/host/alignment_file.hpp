@@ -10,6 +10,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -43,7 +44,7 @@ uint64_t hash_read_name(const char* s, size_t n);
 
 class AlignmentFile {
 public:
-    AlignmentFile() = default;
+    AlignmentFile();
     ~AlignmentFile();
     AlignmentFile(const AlignmentFile&) = delete;
     AlignmentFile& operator=(const AlignmentFile&) = delete;
@@ -116,6 +117,8 @@ private:
     };
     std::vector<Block> blocks_;
     unsigned threads_ = 1;
+    class Workers;  // the decode threads, started once per file
+    std::unique_ptr<Workers> workers_;
     std::string pending_line_;  // first alignment line met while reading a SAM header
     bool have_pending_ = false;
     std::unordered_map<std::string, int32_t> sam_index_;  // RNAME -> refID

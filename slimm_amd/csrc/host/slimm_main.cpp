@@ -12,10 +12,14 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <sstream>
 #include <string>
@@ -258,6 +262,113 @@ struct Trace {
     }
 };
 
+// The record stream of one file, decoded on a thread of its own from the moment the file is open: while the main thread
+// builds the lineage table and creates the context (the HIP runtime's start-up included), batches pile up in host
+// memory; once the context exists they are pushed in order and the decoder switches to the context's page-locked
+// staging sets, which the DMA engine reads while the next batch is decoded (slimm_push_staged_async).
+struct RecordPump {
+    static constexpr uint64_t kBatch = 1 << 20;   // records per batch
+    static constexpr size_t kMaxQueued = 64;      // batches held in host memory before the decoder waits for the context
+    struct Batch {
+        std::unique_ptr<uint64_t[]> key{new uint64_t[kBatch]};
+        std::unique_ptr<int32_t[]> ref{new int32_t[kBatch]}, pos{new int32_t[kBatch]};
+        std::unique_ptr<uint16_t[]> flag{new uint16_t[kBatch]};
+        uint64_t n = 0;
+    };
+    AlignmentFile& bam;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Batch> queued;
+    slimm_ctx* ctx = nullptr;  // set by attach(): from then on the decoder pushes by itself
+    bool failed = false;       // a push failed (slimm_last_error says why)
+    long read_rc = 0;          // the reader's last answer: 0 = end of file, -1 = format error
+    double decode_ms = 0, wait_ms = 0;
+    std::thread th;
+
+    explicit RecordPump(AlignmentFile& f) : bam(f), th([this] { run(); }) {}
+    ~RecordPump() {
+        if (th.joinable()) {
+            {
+                std::lock_guard<std::mutex> g(mu);
+                failed = true;  // (an early return of the caller: let the decoder out of its wait)
+            }
+            cv.notify_all();
+            th.join();
+        }
+    }
+    static double ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    }
+    void run() {
+        uint32_t which = 0;
+        for (;;) {
+            slimm_ctx* c;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                if (failed) return;
+                c = ctx;
+            }
+            if (c) {  // straight into a staging set
+                uint64_t* key;
+                int32_t *ref, *pos;
+                uint16_t* flag;
+                auto t0 = std::chrono::steady_clock::now();
+                if (slimm_staging_buffers(c, which, kBatch, &key, &ref, &pos, &flag) < 0) break;  // (waits for the set's last copy)
+                auto t1 = std::chrono::steady_clock::now();
+                const long n = bam.read_into(key, ref, pos, flag, kBatch);
+                auto t2 = std::chrono::steady_clock::now();
+                wait_ms += ms(t0, t1);
+                decode_ms += ms(t1, t2);
+                if (n <= 0) {
+                    read_rc = n;
+                    return;
+                }
+                if (slimm_push_staged_async(c, which, static_cast<uint64_t>(n)) < 0) break;
+                which ^= 1u;
+                continue;
+            }
+            Batch b;
+            auto t1 = std::chrono::steady_clock::now();
+            const long n = bam.read_into(b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), kBatch);
+            decode_ms += ms(t1, std::chrono::steady_clock::now());
+            if (n <= 0) {
+                read_rc = n;
+                return;
+            }
+            b.n = static_cast<uint64_t>(n);
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return ctx || failed || queued.size() < kMaxQueued; });
+            if (failed) return;
+            if (ctx) {  // attached meanwhile: everything queued before has been pushed, this batch follows
+                if (slimm_push_records(ctx, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) break;
+            } else {
+                queued.push_back(std::move(b));
+            }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        failed = true;
+    }
+    // pushes what was decoded so far and hands the context to the decoder; false when a push failed
+    bool attach(slimm_ctx* c) {
+        std::unique_lock<std::mutex> g(mu);
+        for (Batch& b : queued)
+            if (slimm_push_records(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) {
+                failed = true;
+                cv.notify_all();
+                return false;
+            }
+        queued.clear();
+        ctx = c;
+        cv.notify_all();
+        return true;
+    }
+    // waits for the end of the file; false on a failed push
+    bool finish() {
+        th.join();
+        return !failed;
+    }
+};
+
 // slimm::get_profiles() for one file (src/slimm.hpp:395-496)
 bool get_profiles(Session& S, size_t file_index) {
     Options& options = S.options;
@@ -296,6 +407,7 @@ bool get_profiles(Session& S, size_t file_index) {
     trace.mark("open + read-length sample");
     bam.close();
     if (!bam.open(path)) return true;
+    RecordPump pump(bam);  // decoding starts now; the records are claimed further down, when the context exists
 
     std::cerr << "Intializing coverages for all reference genome ... ";
     const uint32_t R = static_cast<uint32_t>(bam.ref_names().size());
@@ -353,30 +465,17 @@ bool get_profiles(Session& S, size_t file_index) {
 
     std::cerr << "Analysing alignments, reads and references ....... ";
     {
-        // streamed ingest: the decode threads write batch k + 1 into one page-locked staging set while the DMA engine
-        // reads batch k from the other (slimm_push_staged_async returns at once)
-        const uint64_t kBatch = 1 << 20;
-        long n = 0;
-        uint32_t which = 0;
-        double decode_ms = 0, push_ms = 0;
-        for (;;) {
-            uint64_t* key;
-            int32_t *ref, *pos;
-            uint16_t* flag;
-            auto t0 = std::chrono::steady_clock::now();
-            CHECK(ctx, slimm_staging_buffers(ctx, which, kBatch, &key, &ref, &pos, &flag));  // (waits for the set's last copy)
-            auto t1 = std::chrono::steady_clock::now();
-            n = bam.read_into(key, ref, pos, flag, kBatch);
-            if (n <= 0) break;
-            auto t2 = std::chrono::steady_clock::now();
-            CHECK(ctx, slimm_push_staged_async(ctx, which, static_cast<uint64_t>(n)));
-            which ^= 1u;
-            auto t3 = std::chrono::steady_clock::now();
-            decode_ms += std::chrono::duration<double, std::milli>(t2 - t1).count();
-            push_ms += std::chrono::duration<double, std::milli>(t1 - t0).count() + std::chrono::duration<double, std::milli>(t3 - t2).count();
+        const bool pushed = pump.attach(ctx) && pump.finish();
+        if (trace.on)
+            fprintf(stderr, "[trace] decode %.2f ms (on its own thread, from the moment the file was open), waiting for staging sets %.2f ms\n",
+                    pump.decode_ms, pump.wait_ms);
+        trace.mark("rest of read + decode + push");
+        if (!pushed) {
+            std::cerr << "slimm: pushing records: " << slimm_last_error(ctx) << "\n";
+            slimm_destroy(ctx);
+            return false;
         }
-        if (trace.on) fprintf(stderr, "[trace] decode %.2f ms, waiting for / enqueueing copies %.2f ms\n", decode_ms, push_ms);
-        trace.mark("read + decode + push");
+        const long n = pump.read_rc;
         if (n < 0) {
             std::cerr << bam.error() << "\n";
             slimm_destroy(ctx);

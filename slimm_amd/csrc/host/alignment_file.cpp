@@ -6,8 +6,10 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -111,12 +113,27 @@ uint64_t hash_read_name(const char* s, size_t n) {
 }
 
 AlignmentFile::AlignmentFile() = default;
+
+namespace {
+struct StageClock {  // SLIMM_CLI_TRACE=1: where the reader's time goes, printed when the file is closed
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double& into;
+    explicit StageClock(double& acc) : into(acc) {}
+    ~StageClock() { into += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
 AlignmentFile::~AlignmentFile() { close(); }
 
 void AlignmentFile::close() {
+    if (fp_ && getenv("SLIMM_CLI_TRACE") && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0)
+        fprintf(stderr, "[trace] reader: read + parse blocks %.1f ms, inflate %.1f ms, record starts %.1f ms, decode + hash %.1f ms, "
+                        "name check %.1f ms (%u threads)\n", ms_read_, ms_inflate_, ms_find_, ms_decode_, ms_names_, threads_);
+    ms_read_ = ms_inflate_ = ms_find_ = ms_decode_ = ms_names_ = 0;
+    stop_prefetch();
     if (fp_) fclose(fp_);
     fp_ = nullptr;
     workers_.reset();
+    inflaters_.reset();
 }
 
 static uint32_t rd_u32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24); }
@@ -138,6 +155,11 @@ bool AlignmentFile::open(const std::string& path) {
         threads_ = e ? static_cast<unsigned>(std::max(1, atoi(e))) : std::max(1u, std::min(hw ? hw : 1u, 64u));
     }
     workers_.reset(new Workers(threads_));
+    inflaters_.reset(new Workers(threads_));  // (the prefetch thread's own: its jobs run beside the decode jobs)
+    file_eof_ = false;
+    first_batch_ = true;
+    cfill_ = cdone_ = 0;
+    spare_.clear();
     order_ = SortOrder::Unknown;
     fp_ = fopen(path.c_str(), "rb");
     if (!fp_) {
@@ -174,84 +196,127 @@ bool inflate_one(const uint8_t* src, size_t clen, uint8_t* dst, uint32_t isize, 
 }
 }  // namespace
 
-bool AlignmentFile::inflate_batch() {
-    constexpr size_t kBatchBytes = 16u << 20;  // compressed bytes per batch
-    cbuf_.clear();
-    blocks_.clear();
-    // drop consumed bytes so the window does not grow without bound
-    if (pos_ > 0) {
-        buf_.erase(buf_.begin(), buf_.begin() + static_cast<long>(pos_));
-        pos_ = 0;
+// The next stretch of the file, inflated into dst[dst_off ...): one fread of `batch_bytes` compressed bytes (what is left of
+// an incomplete block at its end waits in cbuf_ for the next call), the BGZF block headers walked in memory, the blocks
+// inflated on the inflate workers.  Runs on the prefetch thread while the caller works on the window before.
+bool AlignmentFile::read_inflate(Bytes& dst, size_t dst_off, size_t batch_bytes, bool& at_eof, std::string& err) {
+    size_t out = dst_off;
+    {
+        StageClock clk(ms_read_);
+        if (!file_eof_) {
+            cbuf_.resize(cfill_ + batch_bytes);
+            const size_t got = fread(cbuf_.data() + cfill_, 1, batch_bytes, fp_);
+            cfill_ += got;
+            if (got < batch_bytes) file_eof_ = true;
+        }
+        blocks_.clear();
+        size_t p = 0;
+        while (cfill_ - p >= 18) {
+            const uint8_t* hdr = cbuf_.data() + p;
+            if (hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
+                err = "not a BGZF block";
+                return false;
+            }
+            const size_t xlen = rd_u16(hdr + 10);
+            if (cfill_ - p < 12 + xlen) break;
+            int bsize = -1;
+            for (size_t o = 0; o + 4 <= xlen;) {
+                const uint8_t* x = hdr + 12 + o;
+                const uint16_t slen = rd_u16(x + 2);
+                if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = rd_u16(x + 4);
+                o += 4 + slen;
+            }
+            if (bsize < 0) {
+                err = "BGZF block without BC field";
+                return false;
+            }
+            const size_t total = static_cast<size_t>(bsize) + 1;
+            if (total < 12u + xlen + 8u) {
+                err = "bad BGZF block size";
+                return false;
+            }
+            if (cfill_ - p < total) break;
+            Block b;
+            b.coff = p + 12 + xlen;
+            b.clen = total - 12 - xlen - 8;  // deflate data (crc32 and isize follow)
+            b.crc = rd_u32(&cbuf_[p + total - 8]);
+            b.isize = rd_u32(&cbuf_[p + total - 4]);
+            b.ooff = out;
+            out += b.isize;
+            blocks_.push_back(b);
+            p += total;
+        }
+        if (file_eof_ && blocks_.empty() && cfill_ - p != 0) {
+            err = cfill_ - p < 18 ? "truncated BGZF header" : "truncated BGZF block";
+            return false;
+        }
+        cdone_ = p;
     }
-    size_t out = buf_.size();
-    while (cbuf_.size() < kBatchBytes) {
-        uint8_t hdr[12];
-        size_t got = fread(hdr, 1, 12, fp_);
-        if (got == 0) {
-            eof_ = true;
-            break;
-        }
-        if (got != 12 || hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
-            err_ = "not a BGZF block";
+    dst.resize(out);
+    if (!blocks_.empty()) {
+        StageClock clk(ms_inflate_);
+        std::atomic<size_t> next{0};
+        std::atomic<bool> ok{true};
+        inflaters_->run(std::min<unsigned>(inflaters_->size(), static_cast<unsigned>(blocks_.size())), [&](unsigned) {
+            for (size_t k; (k = next.fetch_add(1)) < blocks_.size();) {
+                const Block& b = blocks_[k];
+                if (!inflate_one(cbuf_.data() + b.coff, b.clen, dst.data() + b.ooff, b.isize, b.crc)) ok = false;
+            }
+        });
+        if (!ok) {
+            err = "corrupt BGZF block (inflate or CRC failed)";
             return false;
         }
-        uint16_t xlen = rd_u16(hdr + 10);
-        uint8_t extra[65536];
-        if (fread(extra, 1, xlen, fp_) != xlen) {
-            err_ = "truncated BGZF header";
-            return false;
-        }
-        int bsize = -1;
-        for (size_t o = 0; o + 4 <= xlen;) {
-            uint16_t slen = rd_u16(&extra[o + 2]);
-            if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = rd_u16(&extra[o + 4]);
-            o += 4 + slen;
-        }
-        if (bsize < 0) {
-            err_ = "BGZF block without BC field";
-            return false;
-        }
-        if (static_cast<size_t>(bsize) + 1 < 12u + xlen + 8u) {
-            err_ = "bad BGZF block size";
-            return false;
-        }
-        size_t clen = static_cast<size_t>(bsize) + 1 - 12 - xlen;  // deflate data + crc32 + isize
-        size_t coff = cbuf_.size();
-        cbuf_.resize(coff + clen);
-        if (fread(cbuf_.data() + coff, 1, clen, fp_) != clen) {
-            err_ = "truncated BGZF block";
-            return false;
-        }
-        Block b;
-        b.coff = coff;
-        b.clen = clen - 8;
-        b.crc = rd_u32(&cbuf_[coff + clen - 8]);
-        b.isize = rd_u32(&cbuf_[coff + clen - 4]);
-        b.ooff = out;
-        out += b.isize;
-        blocks_.push_back(b);
     }
-    if (blocks_.empty()) return false;
-    buf_.resize(out);
-    std::atomic<size_t> next{0};
-    std::atomic<bool> ok{true};
-    auto work = [&]() {
-        for (size_t k; (k = next.fetch_add(1)) < blocks_.size();) {
-            const Block& b = blocks_[k];
-            if (!inflate_one(cbuf_.data() + b.coff, b.clen, buf_.data() + b.ooff, b.isize, b.crc)) ok = false;
-        }
-    };
-    workers_->run(std::min<unsigned>(threads_, static_cast<unsigned>(blocks_.size())), [&](unsigned) { work(); });
-    if (!ok) {
-        err_ = "corrupt BGZF block (inflate or CRC failed)";
-        return false;
-    }
+    // what is left of the last, incomplete block moves to the front
+    memmove(cbuf_.data(), cbuf_.data() + cdone_, cfill_ - cdone_);
+    cfill_ -= cdone_;
+    at_eof = file_eof_ && cfill_ == 0;
     return true;
+}
+
+// Starts inflating the next window into spare_ (behind kSlack free bytes, where the unread tail of the current window
+// will be copied when the windows change over).
+void AlignmentFile::start_prefetch() {
+    const size_t batch = first_batch_ ? (1u << 20) : (16u << 20);  // (the read-length sample needs one small window)
+    first_batch_ = false;
+    next_ok_ = true;
+    next_eof_ = false;
+    next_err_.clear();
+    prefetch_ = std::thread([this, batch] { next_ok_ = read_inflate(spare_, kSlack, batch, next_eof_, next_err_); });
+}
+
+void AlignmentFile::stop_prefetch() {
+    if (prefetch_.joinable()) prefetch_.join();
 }
 
 bool AlignmentFile::fill(size_t need) {
     while (buf_.size() - pos_ < need) {
-        if (eof_ || !inflate_batch()) return false;
+        if (eof_) return false;
+        if (!prefetch_.joinable()) start_prefetch();  // (the first window of the file)
+        prefetch_.join();
+        if (!next_ok_) {
+            err_ = next_err_;
+            return false;
+        }
+        // the unread tail of the window moves in front of the new data
+        const size_t tail = buf_.size() - pos_;
+        if (tail <= kSlack) {
+            memcpy(spare_.data() + kSlack - tail, buf_.data() + pos_, tail);
+            buf_.swap(spare_);
+            pos_ = kSlack - tail;
+        } else {  // (a record longer than the slack)
+            Bytes big;
+            big.resize(tail + spare_.size() - kSlack);
+            memcpy(big.data(), buf_.data() + pos_, tail);
+            memcpy(big.data() + tail, spare_.data() + kSlack, spare_.size() - kSlack);
+            buf_.swap(big);
+            pos_ = 0;
+        }
+        if (next_eof_)
+            eof_ = true;
+        else
+            start_prefetch();
     }
     return true;
 }
@@ -504,6 +569,7 @@ long AlignmentFile::bam_record_starts(size_t max_records, std::vector<size_t>& o
     // where the records start (chunks of the window in parallel)
     offs.clear();
     size_t new_pos = pos_;
+    StageClock clk(ms_find_);
     if (!find_records(buf_.size(), max_records, offs, new_pos)) return -1;
     if (offs.empty()) {
         err_ = "bad BAM record";
@@ -603,6 +669,7 @@ long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begi
     std::vector<size_t> offs;
     const long cnt = bam_record_starts(max_records, offs);
     if (cnt <= 0) return cnt;
+    std::unique_ptr<StageClock> clk(new StageClock(ms_decode_));
     decode_parallel(static_cast<size_t>(cnt), [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; ++k) {
             const uint8_t* r = &buf_[offs[k] + 4];
@@ -613,6 +680,7 @@ long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begi
             flag[k] = rd_u16(r + 14);
         }
     });
+    clk.reset(new StageClock(ms_names_));
     separate_adjacent_names(read_key, offs);
     return cnt;
 }

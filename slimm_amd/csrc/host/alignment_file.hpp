@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -76,7 +77,6 @@ private:
     // record starts in buf_[pos_, end): appended to offs, at most max_records; returns false on a malformed record
     bool find_records(size_t end, size_t max_records, std::vector<size_t>& offs, size_t& new_pos);
     bool plausible_record(size_t o, size_t end, int depth) const;
-    bool inflate_batch();             // the next few hundred BGZF blocks -> buf_, inflated on several threads
     bool read_bam_header();
     bool read_sam_header();
     bool next_sam_line(std::string& line);
@@ -108,17 +108,29 @@ private:
         bool operator!=(const NoInit<U>&) const { return false; }
     };
     using Bytes = std::vector<uint8_t, NoInit<uint8_t>>;
+    // BAM windows are double-buffered: while the caller decodes buf_, the prefetch thread reads and inflates the next
+    // stretch of the file into spare_
+    bool read_inflate(Bytes& dst, size_t dst_off, size_t batch_bytes, bool& at_eof, std::string& err);
+    void start_prefetch();
+    void stop_prefetch();
+    static constexpr size_t kSlack = 4u << 20;  // room in front of a new window for the unread tail of the one before
     Bytes buf_;
     size_t pos_ = 0;
+    Bytes spare_;
+    std::thread prefetch_;
+    bool next_ok_ = true, next_eof_ = false, file_eof_ = false, first_batch_ = true;
+    std::string next_err_;
     Bytes cbuf_;
+    size_t cfill_ = 0, cdone_ = 0;  // compressed bytes waiting in cbuf_ / of them consumed by the last call
     struct Block {
         size_t coff, clen, ooff;  // compressed bytes in cbuf_, output offset in buf_
         uint32_t isize, crc;
     };
     std::vector<Block> blocks_;
     unsigned threads_ = 1;
+    double ms_read_ = 0, ms_inflate_ = 0, ms_find_ = 0, ms_decode_ = 0, ms_names_ = 0;  // SLIMM_CLI_TRACE
     class Workers;  // the decode threads, started once per file
-    std::unique_ptr<Workers> workers_;
+    std::unique_ptr<Workers> workers_, inflaters_;
     std::string pending_line_;  // first alignment line met while reading a SAM header
     bool have_pending_ = false;
     std::unordered_map<std::string, int32_t> sam_index_;  // RNAME -> refID

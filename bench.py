@@ -64,6 +64,25 @@ def algorithmic_bytes(st, n_records, Bp_words):
     }
 
 
+def cpu_quota_cores():
+    """CPU time this process may use, in cores: the cgroup quota when there is one (a container on a 256-thread host
+    may be held to 16 cores' worth), else the number of logical CPUs."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return round(int(q) / int(p), 2)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return round(q / p, 2)
+    except Exception:
+        pass
+    return float(os.cpu_count() or 1)
+
+
 def pmc_traffic_bytes(kernel_name, records_per_gpu):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh run on
     MI355X with the default workload; FETCH_SIZE and WRITE_SIZE collected in separate passes, unit KB).  gfx950
@@ -432,7 +451,7 @@ def main():
             cpu = {"value": round(passes * ns / cpu_s / 1e6, 4), "unit": "M records/s", "cores": 1, "kind": "port",
                    "sample": f"{passes} pass(es) over the first {ns} records of the same stream (same refs/DB), phases "
                              f"A+B+C+profile {cpu_s:.1f}s of {wall:.1f}s wall",
-                   "host": f"{os.cpu_count()} logical cores"}
+                   "host": f"{os.cpu_count()} logical cores, cgroup quota {cpu_quota_cores()} cores"}
 
         # ---- the same host's cores, all of them: the dense multi-threaded restatement of phases A, B and the per-read
         # LCA (oracle/slimm_dense_mt.cpp, checked against the oracle in tests/test_dense_mt.py).  A reported baseline
@@ -458,7 +477,7 @@ def main():
                                 f"{ncpu}, {ncpu // 2}, {ncpu // 4}, 32 on {ncpu} logical cores): "
                                 f"phases A + B + per-read LCA {best * 1e3:.1f} ms (array allocation and the scalar profile "
                                 f"tail excluded), {time.perf_counter() - t_all:.1f} s wall for all passes",
-                      "scalars_equal_gpu": bool(agree)}
+                      "cpu_quota_cores": cpu_quota_cores(), "scalars_equal_gpu": bool(agree)}
 
         line = {
             "metric": "M alignment-records/sec -> final profile",

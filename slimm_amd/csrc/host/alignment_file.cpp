@@ -127,8 +127,10 @@ AlignmentFile::~AlignmentFile() { close(); }
 void AlignmentFile::close() {
     if (fp_ && getenv("SLIMM_CLI_TRACE") && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0)
         fprintf(stderr, "[trace] reader: read + parse blocks %.1f ms, inflate %.1f ms, record starts %.1f ms, decode + hash %.1f ms, "
-                        "name check %.1f ms (%u threads)\n", ms_read_, ms_inflate_, ms_find_, ms_decode_, ms_names_, threads_);
-    ms_read_ = ms_inflate_ = ms_find_ = ms_decode_ = ms_names_ = 0;
+                        "name check %.1f ms; %u windows, waited %.1f ms for the prefetch thread (%u threads)\n", ms_read_, ms_inflate_, ms_find_,
+                ms_decode_, ms_names_, n_windows_, ms_wait_, threads_);
+    ms_read_ = ms_inflate_ = ms_find_ = ms_decode_ = ms_names_ = ms_wait_ = 0;
+    n_windows_ = 0;
     stop_prefetch();
     if (fp_) fclose(fp_);
     fp_ = nullptr;
@@ -294,7 +296,11 @@ bool AlignmentFile::fill(size_t need) {
     while (buf_.size() - pos_ < need) {
         if (eof_) return false;
         if (!prefetch_.joinable()) start_prefetch();  // (the first window of the file)
-        prefetch_.join();
+        {
+            StageClock clk(ms_wait_);
+            prefetch_.join();
+        }
+        ++n_windows_;
         if (!next_ok_) {
             err_ = next_err_;
             return false;

@@ -128,7 +128,8 @@ private:
     };
     std::vector<Block> blocks_;
     unsigned threads_ = 1;
-    double ms_read_ = 0, ms_inflate_ = 0, ms_find_ = 0, ms_decode_ = 0, ms_names_ = 0;  // SLIMM_CLI_TRACE
+    double ms_read_ = 0, ms_inflate_ = 0, ms_find_ = 0, ms_decode_ = 0, ms_names_ = 0, ms_wait_ = 0;  // SLIMM_CLI_TRACE
+    unsigned n_windows_ = 0;
     class Workers;  // the decode threads, started once per file
     std::unique_ptr<Workers> workers_, inflaters_;
     std::string pending_line_;  // first alignment line met while reading a SAM header

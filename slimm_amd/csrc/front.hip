@@ -551,6 +551,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
         uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
         WinOut so{B, 0u, 0u, 0u};
         uint32_t nw = 0;
+        uint32_t cut_f = 0, cut_h = 0;
         if (B < N) {
             // ---- 1. stage (the only part that waits for memory; everything a group loads is in flight at once)
             if (N - B >= kStageRecs)
@@ -565,8 +566,9 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
             so.base = B + min(off, kSlotRecs);
             while (off < kSlotRecs) {
                 if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
-                    if (lane == 0u) cuts[nw] = make_uint2(so.nf, so.nh);  // records; beyond that the list's last window
-                    ++nw;                                                  // simply takes the rest of the slot)
+                    cut_f = lane == nw ? so.nf : cut_f;  // records; beyond that the list's last window simply takes the
+                    cut_h = lane == nw ? so.nh : cut_h;  // rest of the slot).  Lane i keeps window i's entry: one store of
+                    ++nw;                                // the whole list at the end instead of a lane-0 store per window
                 }
                 const uint32_t w1 = st1[off + lane], w2 = st2[off + lane];
                 const uint64_t RSw = f_ballot(static_cast<int32_t>(w1) < 0);  // (bit 0 is set: a window starts a run)
@@ -595,11 +597,17 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                 }
             }
         }
-        if (lane == 0u) {
-            slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
-            cuts[nw] = make_uint2(so.nf, so.nh);
-            cuts[kSlotWindows - 1u] = make_uint2(nw, 0u);
+        if (lane == 0u) slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
+        // the window list: lanes [0, nw) their windows, lane nw the totals, the last entry the number of windows
+        if (lane == nw) {
+            cut_f = so.nf;
+            cut_h = so.nh;
         }
+        if (lane == kSlotWindows - 1u) {
+            cut_f = nw;
+            cut_h = 0u;
+        }
+        if (lane <= nw || lane == kSlotWindows - 1u) cuts[lane] = make_uint2(cut_f, cut_h);
     }
     // (No totals here: thousands of waves adding to the same three counters are as many memory-side atomics in a row,
     // ~40 ns each -- 0.3 ms at the end of a 0.1 ms kernel.  The first consumer of the slots sums their counts.)

@@ -780,6 +780,8 @@ constexpr int kFilterBlock = 256;
 // with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
 // waits for and waits for all of them.)
 constexpr int kFilterBatch = 6;
+constexpr uint32_t kFilterSlots = 1;  // consecutive slots per wave (their windows: at most 64 together)
+static_assert(kFilterSlots * (kSlotWindows - 2u) <= 64u, "a wave keeps one window per lane");
 template <typename Rows>
 __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,
@@ -788,28 +790,53 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFilterBlock / 64);
-    for (uint32_t slot = blockIdx.x * (kFilterBlock / 64) + wave; slot < nslots; slot += n_waves) {
-        const uint4 d = slots[slot];
-        if (d.y == 0u) continue;
-        const uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
-        const uint32_t nw = cuts[kSlotWindows - 1u].x;
-        const uint2 ce = cuts[min(lane, nw)];  // lane i: {targets, reads} in front of window i; lanes >= nw: the totals
+    for (uint32_t first = (blockIdx.x * (kFilterBlock / 64) + wave) * kFilterSlots; first < nslots;
+         first += n_waves * kFilterSlots) {
+        // The windows of this wave's kFilterSlots consecutive slots, one per lane: where the window's targets start, how
+        // many there are, where its reads' selectors start, the last target of its slot (loads are clamped to it).
+        // (A slot's list is loaded whole -- entries behind its last window are never used -- so the number of windows
+        // comes out of the same load instead of a load of its own in front.)
+        uint32_t w_start = 0, w_cnt = 0, w_sel = 0, w_last = 0, nw = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kFilterSlots; ++k) {
+            const uint32_t slot = min(first + k, nslots - 1u);
+            const uint4 d = slots[slot];
+            const uint2 ce = wcut[static_cast<size_t>(slot) * kSlotWindows + min(lane, kSlotWindows - 1u)];
+            const uint32_t n = first + k < nslots ? static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, kSlotWindows - 1u)) : 0u;
+            const uint32_t nxt = __shfl_down(ce.x, 1, 64);  // (lane n holds the slot's totals)
+            const uint32_t a_start = d.x + ce.x, a_cnt = lane < n ? nxt - ce.x : 0u, a_sel = d.x + ce.y;
+            if (kFilterSlots == 1) {
+                w_start = a_start;
+                w_cnt = a_cnt;
+                w_sel = a_sel;
+                w_last = d.x + d.y - 1u;
+            } else {  // behind the windows of the slots before
+                const int src = static_cast<int>((lane - nw) & 63u);
+                const uint32_t b_start = __shfl(a_start, src, 64), b_cnt = __shfl(a_cnt, src, 64), b_sel = __shfl(a_sel, src, 64);
+                const bool here = lane >= nw && lane < nw + n;
+                w_start = here ? b_start : w_start;
+                w_cnt = here ? b_cnt : w_cnt;
+                w_sel = here ? b_sel : w_sel;
+                w_last = here ? d.x + d.y - 1u : w_last;
+            }
+            nw += n;
+        }
         bool spans = false;  // some window holds more than 64 targets
         for (uint32_t i0 = 0; i0 < nw; i0 += kFilterBatch) {
             uint32_t w[kFilterBatch], g[kFilterBatch], cnt[kFilterBatch], selb[kFilterBatch];
             typename Rows::Row row[kFilterBatch];
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) {
-                const uint32_t i = i0 + u;  // (lanes behind the last window hold the totals: windows of no targets)
-                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, i & 63u));
-                const uint32_t t1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, (i + 1u) & 63u));
-                cnt[u] = i < nw ? t1 - t0 : 0u;
-                selb[u] = d.x + static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.y, i & 63u));
+                const uint32_t i = (i0 + u) & 63u;  // (lanes behind the last window: windows of no targets)
+                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
+                const uint32_t tl = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_last, i));
+                cnt[u] = i0 + u < nw ? static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i)) : 0u;
+                selb[u] = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i));
                 if (cnt[u] > 64u) {
                     spans = true;
                     cnt[u] = 0;
                 }
-                const uint32_t t = d.x + min(t0 + lane, d.y - 1u);
+                const uint32_t t = cnt[u] ? min(t0 + lane, tl) : 0u;
                 w[u] = tgt_ref[t];
                 g[u] = tgt_gbin[t];
             }
@@ -844,11 +871,10 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
         }
         if (spans) {
             for (uint32_t i = 0; i < nw; ++i) {
-                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, i));
-                const uint32_t t1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, i + 1u));
-                if (t1 - t0 > 64u)
-                    filter_span(rows, out, tgt_ref, tgt_gbin, lane, d.x + t0, d.x + t1,
-                                d.x + static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.y, i)));
+                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
+                const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i));
+                if (c > 64u)
+                    filter_span(rows, out, tgt_ref, tgt_gbin, lane, t0, t0 + c, static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i)));
             }
         }
     }
@@ -996,9 +1022,9 @@ void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots,
 }
 
 static uint32_t filter_grid(uint32_t nslots) {
-    // one slot per wave (front.hip: front_grid)
-    const uint32_t blocks = (nslots + (kFilterBlock / 64) - 1u) / (kFilterBlock / 64);
-    return std::max(1u, blocks);
+    // kFilterSlots slots per wave, however many workgroups that makes (front.hip: front_grid)
+    const uint32_t per = (kFilterBlock / 64) * kFilterSlots;
+    return std::max(1u, (nslots + per - 1u) / per);
 }
 
 void launch_filter(hipStream_t st, const FilterArgs& a) {

@@ -34,6 +34,7 @@ enum {
     SLIMM_E_REF_RANGE = -3, /* a record names ref_id >= n_refs (undefined behaviour in the reference) */
     SLIMM_E_RUN_LENGTH = -4,/* (not returned any more: a read may have any number of alignment records; the value is
                                kept so that the codes after it do not move) */
+    SLIMM_E_RETRY = 2,      /* not an error: slimm_install_merged_partials asks for slimm_filter_alignments_launch again */
     SLIMM_E_NO_HITS = 1     /* not an error: no mapped record (reference prints a warning and writes nothing, src/slimm.hpp:451-455) */
 };
 
@@ -191,6 +192,15 @@ int slimm_set_coverage_columns(slimm_ctx* ctx, const uint32_t* reads_count, cons
  * (read_stat.hpp:98-114), uniq_cov2 -- fused on the device with the per-read LCA of
  * get_reads_lca_count() step 1 (src/slimm.hpp:536-557, get_lca :516-531). Local to this GPU. */
 int slimm_filter_alignments(slimm_ctx* ctx);
+
+/* Multi-GPU form of slimm_filter_alignments with ONE host synchronisation for the whole phase: this call only
+ * launches (the device work of slimm_filter_alignments plus the packing of this rank's additive partial results);
+ * the caller sums the buffer of slimm_partials_buffer across ranks on the context's stream (slimm_get_stream) and
+ * calls slimm_install_merged_partials, which copies the merged results to the host and synchronises.  When the
+ * (taxon, reference) pair set of SOME rank overflowed (the flag travels with the sums, so every rank sees it),
+ * slimm_install_merged_partials returns SLIMM_E_RETRY on every rank -- each has grown its table -- and the caller
+ * goes round again: launch, sum, install. */
+int slimm_filter_alignments_launch(slimm_ctx* ctx);
 
 /* Multi-GPU: the additive partial results of phase B/C(1) of this rank, to be merged across ranks by the caller.
  *   uniq_reads_count2 [n_refs], lca_count [n_taxa_dense] (sum), level_marks [n_refs] (bitwise OR),

@@ -94,6 +94,7 @@ struct slimm_ctx {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
     bool copy_pending = false;
+    bool filter_pending = false;  // slimm_filter_alignments_launch ran; slimm_install_merged_partials completes it
     bool stream_ordered = false;  // slimm_set_stream_ordered: the caller enqueues its collectives on `stream`
     struct Staging {
         PinBuf<uint64_t> key;
@@ -489,6 +490,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         }
         uint32_t cap = 1u << 16;
         while (cap < 8ull * c->R && cap < (1u << 30)) cap <<= 1;
+        if (const char* e = getenv("SLIMM_PAIR_CAP")) {  // tests: start small, so that the overflow -> grow -> retry path runs
+            cap = 16;
+            while (cap < static_cast<uint32_t>(atol(e)) && cap < (1u << 30)) cap <<= 1;
+        }
         int rc = ensure_pair_table(cc, cap);
         if (rc != SLIMM_OK) {
             g_create_error = cc->err;
@@ -1044,22 +1049,21 @@ int slimm_set_coverage_columns(slimm_ctx* c, const uint32_t* reads_count, const 
 }
 
 // ------------------------------------------------------------------------------------------------ phase B + C(1)
-int slimm_filter_alignments(slimm_ctx* c) {
-    if (!c) return SLIMM_E_INVALID;
-    if (!c->covered) return fail(c, SLIMM_E_INVALID, "call slimm_finish_coverage first");
-    if (c->no_hits) return SLIMM_E_NO_HITS;
+namespace {
+// slimm_filter_alignments in pieces, so that the multi-rank form (slimm_filter_alignments_launch + the exchange +
+// slimm_install_merged_partials) can put its collective between the launches and the one host synchronisation.
+
+// cut-offs + valid set on the host, lineage rows / valid bytes on their way to the device
+int filter_prepare(slimm_ctx* c, bool& rows_ride_along) {
     HostProfile& h = *c->host;
-    HostTrace tr("filter_alignments");
+    HostTrace tr("filter_alignments: prepare");
     h.compute_valid();
     tr.mark("compute_valid");
-    if (c->device < 0) {  // host-only: the per-read part arrives through slimm_set_partials
-        c->filtered = true;
-        return SLIMM_OK;
-    }
+    if (c->device < 0) return SLIMM_OK;
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
-    const uint32_t R = c->R, T = c->T;
-    bool rows_ride_along = false;
+    const uint32_t R = c->R;
+    rows_ride_along = false;
     if (c->use_rows16) {
         // the rows are static except for the valid bit (bit 31 of .w): built once, then only the bits of the previous
         // file's valid references are cleared and this file's are set
@@ -1082,154 +1086,197 @@ int slimm_filter_alignments(slimm_ctx* c) {
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
     }
+    return SLIMM_OK;
+}
+
+// the launches of phase B / C(1): clears, k_filter, the selector histogram, the packed result block B
+int filter_launch(slimm_ctx* c, bool copy_rows) {
+    HostProfile& h = *c->host;
+    (void)h;
+    hipStream_t st = c->stream;
+    const uint32_t R = c->R, T = c->T;
     uint32_t* const blockB = c->ref_stats.p + c->statsA_words();
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        {
-            KernelTimer t(c, K_MEMSET);
-            if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
-            ZeroArgs z;
-            z.p[0] = c->marks.p;
-            z.n[0] = R * (kMarkBytes / 4);  // one byte per (reference, level)
-            z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
-            z.n[1] = 2;
-            if (c->use_tiles) {
-                z.p[2] = c->tile_count.p;
-                z.n[2] = c->treps * c->tstride;
-                z.p[3] = blockB;  // per-reference statistics of uniq_cov2, accumulated by k_tile_hist
-                z.n[3] = 4 * R;
-                if (c->fused_scan) {
-                    z.p[4] = c->tile_cursor.p;
-                    z.n[4] = c->treps * c->tstride;
-                }
-            } else {
-                z.p[2] = c->lca_count.p;
-                z.n[2] = T;
-            }
-            if (!c->pair_clean) {
-                z.p64 = c->pair_tab.p;
-                z.n64 = c->pair_cap;
-            }
-            if (rows_ride_along && attempt == 0) {
-                z.cp_dst = reinterpret_cast<uint32_t*>(c->d_rows16.p);
-                z.cp_src = reinterpret_cast<const uint32_t*>(c->h_rows16.p);
-                z.cp_n = R * 4u;
-            }
-            launch_zero(st, z);
-        }
-        const uint32_t nslots = front_slots(c->rec.n);
-        {
-            KernelTimer t(c, K_FILTER);
-            FilterArgs fa;
-            fa.tgt_ref = c->tgt_ref.p;
-            fa.tgt_gbin = c->tgt_gbin.p;
-            fa.slots = c->slots.p;
-            fa.wcut = c->wcut.p;
-            fa.nslots = nslots;
-            if (c->use_rows16) {
-                fa.rows16 = c->d_rows16.p;
-                fa.taxon_flat = c->d_level_taxon.p;
-                fa.taxon_shift = c->taxon_shift;
-            } else {
-                fa.lin_dense = c->d_lin_dense.p;
-                fa.valid = c->d_valid.p;
-            }
-            fa.sel = c->sel.p;
-            fa.marks = c->marks.p;
-            fa.pair_tab = c->pair_tab.p;
-            fa.pair_list = c->pair_list.p;
-            fa.pair_mask = c->pair_cap - 1;
-            fa.taxon_base = static_cast<uint32_t>(c->Bp);
-            fa.counters = c->counters.p;
-            launch_filter(st, fa);
-        }
-        SlotValues selectors;
-        selectors.vals = c->sel.p;
-        selectors.slots = c->slots.p;
-        selectors.nslots = nslots;
-        selectors.per_read = true;
-        if (!c->use_tiles) {
-            KernelTimer t(c, K_HIST);
-            launch_sel_atomics(st, c->sel.p, c->slots.p, nslots, static_cast<uint32_t>(c->Bp), c->ucov2(), c->lca_count.p);
-        }
-        if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
-            const uint32_t grid = 512;
-            {
-                KernelTimer t(c, K_TILE_COUNT2);
-                launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps,
-                                  c->tstride);
-            }
+    const bool rows_ride_along = copy_rows;
+    const int attempt = 0;
+    {
+        KernelTimer t(c, K_MEMSET);
+        if (!c->use_tiles) HIP_TRY(c, hipMemsetAsync(c->ucov2(), 0, c->Bp * sizeof(uint32_t), st));
+        ZeroArgs z;
+        z.p[0] = c->marks.p;
+        z.n[0] = R * (kMarkBytes / 4);  // one byte per (reference, level)
+        z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
+        z.n[1] = 2;
+        if (c->use_tiles) {
+            z.p[2] = c->tile_count.p;
+            z.n[2] = c->treps * c->tstride;
+            z.p[3] = blockB;  // per-reference statistics of uniq_cov2, accumulated by k_tile_hist
+            z.n[3] = 4 * R;
             if (c->fused_scan) {
-                KernelTimer t(c, K_TILE_SCATTER2);
-                launch_tile_scatter_fused(st, grid, c->ntiles2, selectors, c->counters.p, c->tile_count.p, c->tile_cursor.p,
-                                          c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p, c->split_tiles.p);
-            } else {
-                {
-                    KernelTimer t(c, K_TILE_SCAN2);
-                    launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                     c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                                 c->two_level);
-                }
-                {
-                    KernelTimer t(c, K_TILE_SCATTER2);
-                    launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
-                                        c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
-                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
-                }
+                z.p[4] = c->tile_cursor.p;
+                z.n[4] = c->treps * c->tstride;
+            }
+        } else {
+            z.p[2] = c->lca_count.p;
+            z.n[2] = T;
+        }
+        if (!c->pair_clean) {
+            z.p64 = c->pair_tab.p;
+            z.n64 = c->pair_cap;
+        }
+        if (rows_ride_along && attempt == 0) {
+            z.cp_dst = reinterpret_cast<uint32_t*>(c->d_rows16.p);
+            z.cp_src = reinterpret_cast<const uint32_t*>(c->h_rows16.p);
+            z.cp_n = R * 4u;
+        }
+        launch_zero(st, z);
+    }
+    const uint32_t nslots = front_slots(c->rec.n);
+    {
+        KernelTimer t(c, K_FILTER);
+        FilterArgs fa;
+        fa.tgt_ref = c->tgt_ref.p;
+        fa.tgt_gbin = c->tgt_gbin.p;
+        fa.slots = c->slots.p;
+        fa.wcut = c->wcut.p;
+        fa.nslots = nslots;
+        if (c->use_rows16) {
+            fa.rows16 = c->d_rows16.p;
+            fa.taxon_flat = c->d_level_taxon.p;
+            fa.taxon_shift = c->taxon_shift;
+        } else {
+            fa.lin_dense = c->d_lin_dense.p;
+            fa.valid = c->d_valid.p;
+        }
+        fa.sel = c->sel.p;
+        fa.marks = c->marks.p;
+        fa.pair_tab = c->pair_tab.p;
+        fa.pair_list = c->pair_list.p;
+        fa.pair_mask = c->pair_cap - 1;
+        fa.taxon_base = static_cast<uint32_t>(c->Bp);
+        fa.counters = c->counters.p;
+        launch_filter(st, fa);
+    }
+    SlotValues selectors;
+    selectors.vals = c->sel.p;
+    selectors.slots = c->slots.p;
+    selectors.nslots = nslots;
+    selectors.per_read = true;
+    if (!c->use_tiles) {
+        KernelTimer t(c, K_HIST);
+        launch_sel_atomics(st, c->sel.p, c->slots.p, nslots, static_cast<uint32_t>(c->Bp), c->ucov2(), c->lca_count.p);
+    }
+    if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
+        const uint32_t grid = 512;
+        {
+            KernelTimer t(c, K_TILE_COUNT2);
+            launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps,
+                              c->tstride);
+        }
+        if (c->fused_scan) {
+            KernelTimer t(c, K_TILE_SCATTER2);
+            launch_tile_scatter_fused(st, grid, c->ntiles2, selectors, c->counters.p, c->tile_count.p, c->tile_cursor.p,
+                                      c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p, c->split_tiles.p);
+        } else {
+            {
+                KernelTimer t(c, K_TILE_SCAN2);
+                launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
+                             c->two_level);
             }
             {
-                KernelTimer t(c, K_TILE_HIST2);
-                launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
-                                 c->ucov2(), nullptr, c->d_bin_off.p, R, c->d_tile_ref0.p, blockB, BitsLayout(),
-                                 // (the tiles behind the bins hold the per-taxon LCA counts k_pack reads back)
-                                 c->keep_bins ? 0u : static_cast<uint32_t>(c->Bp / kTileBins));
+                KernelTimer t(c, K_TILE_SCATTER2);
+                launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
+                                    c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
+                                    c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
             }
         }
         {
-            PackArgs pk;
-            pk.src[0] = c->counters.p;
-            pk.n[0] = 32;
-            pk.src[1] = c->marks.p;
-            pk.n[1] = R;
-            pk.reps[1] = kPackBytes8;  // k_filter sets one byte per (reference, level)
-            pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
-            pk.n[2] = T;
-            if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place
-                KernelTimer t(c, K_PACK2);
-                launch_pack(st, blockB + 4ull * R, pk, c->split_tiles.p, c->counters.p, c->ucov2(), nullptr,
-                            c->d_bin_off.p, R, c->d_tile_ref0.p, blockB);
-            } else {
-                KernelTimer t(c, K_REF_STATS2);
-                launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, blockB, &pk);
-            }
+            KernelTimer t(c, K_TILE_HIST2);
+            launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
+                             c->ucov2(), nullptr, c->d_bin_off.p, R, c->d_tile_ref0.p, blockB, BitsLayout(),
+                             // (the tiles behind the bins hold the per-taxon LCA counts k_pack reads back)
+                             c->keep_bins ? 0u : static_cast<uint32_t>(c->Bp / kTileBins));
         }
+    }
+    {
+        PackArgs pk;
+        pk.src[0] = c->counters.p;
+        pk.n[0] = 32;
+        pk.src[1] = c->marks.p;
+        pk.n[1] = R;
+        pk.reps[1] = kPackBytes8;  // k_filter sets one byte per (reference, level)
+        pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
+        pk.n[2] = T;
+        if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place
+            KernelTimer t(c, K_PACK2);
+            launch_pack(st, blockB + 4ull * R, pk, c->split_tiles.p, c->counters.p, c->ucov2(), nullptr,
+                        c->d_bin_off.p, R, c->d_tile_ref0.p, blockB);
+        } else {
+            KernelTimer t(c, K_REF_STATS2);
+            launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, blockB, &pk);
+        }
+    }
+    return SLIMM_OK;
+}
+
+// what the host learns from the counters of result block B once they are there: a pair-set overflow (the table is grown,
+// `again` set) or the number of (taxon, reference) pairs, whose list is then fetched
+int filter_check_counters(slimm_ctx* c, const uint32_t* h_cnt, bool& again) {
+    again = false;
+    if (h_cnt[CNT_ERR] & ERR_PAIR_OVERFLOW) {
+        if (c->pair_cap >= (1u << 30)) return fail(c, SLIMM_E_INVALID, "(taxon, reference) pair set overflow");
+        int rc = ensure_pair_table(c, c->pair_cap * 4);
+        if (rc != SLIMM_OK) return rc;
+        c->pair_clean = false;
+        again = true;
+        return SLIMM_OK;
+    }
+    c->n_pairs = h_cnt[CNT_PAIRS];
+    c->pair_clean = (c->n_pairs == 0);
+    if (c->n_pairs) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_pairs.p, c->pair_list.p, static_cast<size_t>(c->n_pairs) * 8, hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->part_pairs.assign(c->h_pairs.p, c->h_pairs.p + c->n_pairs);
+    std::sort(c->part_pairs.begin(), c->part_pairs.end());
+    return SLIMM_OK;
+}
+}  // namespace
+
+int slimm_filter_alignments(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->covered) return fail(c, SLIMM_E_INVALID, "call slimm_finish_coverage first");
+    if (c->no_hits) return SLIMM_E_NO_HITS;
+    HostProfile& h = *c->host;
+    HostTrace tr("filter_alignments");
+    bool rows_ride_along = false;
+    int rc = filter_prepare(c, rows_ride_along);
+    if (rc != SLIMM_OK) return rc;
+    if (c->device < 0) {  // host-only: the per-read part arrives through slimm_set_partials
+        c->filtered = true;
+        return SLIMM_OK;
+    }
+    hipStream_t st = c->stream;
+    const uint32_t R = c->R;
+    uint32_t* const blockB = c->ref_stats.p + c->statsA_words();
+    c->filter_pending = false;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        rc = filter_launch(c, rows_ride_along && attempt == 0);
+        if (rc != SLIMM_OK) return rc;
         uint32_t* const hB = c->h_stats.p + c->statsA_words();
         tr.mark("phase B launches");
         launch_copy_out(st, hB, blockB, static_cast<uint32_t>(c->statsB_words()));
         HIP_TRY(c, hipStreamSynchronize(st));
         tr.mark("stream sync (device phase B + copy)");
-        const uint32_t* h_cnt = hB + 4ull * R;
-        const uint32_t err = h_cnt[CNT_ERR];
-        if (err & ERR_PAIR_OVERFLOW) {
-            if (c->pair_cap >= (1u << 30)) return fail(c, SLIMM_E_INVALID, "(taxon, reference) pair set overflow");
-            int rc = ensure_pair_table(c, c->pair_cap * 4);
-            if (rc != SLIMM_OK) return rc;
-            c->pair_clean = false;
-            continue;
-        }
-        c->n_pairs = h_cnt[CNT_PAIRS];
-        c->pair_clean = (c->n_pairs == 0);
-        if (c->n_pairs) {
-            HIP_TRY(c, hipMemcpyAsync(c->h_pairs.p, c->pair_list.p, static_cast<size_t>(c->n_pairs) * 8,
-                                      hipMemcpyDeviceToHost, st));
-            HIP_TRY(c, hipStreamSynchronize(st));
-        }
-        break;
+        bool again = false;
+        rc = filter_check_counters(c, hB + 4ull * R, again);
+        if (rc != SLIMM_OK) return rc;
+        if (!again) break;
     }
     // the packed rows {uniq_reads_count2 = sum of uniq_cov2 bins, non-zero uniq_cov2 bins, -, -}, the level marks and the
     // per-taxon LCA counts go to the host profile straight from the pinned block
     const uint32_t* s2 = c->h_stats.p + c->statsA_words();
-    c->part_pairs.assign(c->h_pairs.p, c->h_pairs.p + c->n_pairs);
-    std::sort(c->part_pairs.begin(), c->part_pairs.end());
     h.set_partials_rows(s2, 4, s2 + 5ull * R + 32, s2 + 4ull * R + 32, c->part_pairs.data(), c->n_pairs);
     tr.mark("partials to host profile");
     c->binsB_stored = !c->use_tiles || c->keep_bins;
@@ -1237,13 +1284,43 @@ int slimm_filter_alignments(slimm_ctx* c) {
     return SLIMM_OK;
 }
 
+// Multi-rank form of phase B: everything slimm_filter_alignments launches, plus this rank's additive partial results
+// packed for the exchange -- and no host synchronisation.  The caller sums the buffer of slimm_partials_buffer across
+// ranks on the context's stream and calls slimm_install_merged_partials, which does the one copy + synchronise of the
+// phase; SLIMM_E_RETRY from there (some rank's pair set overflowed: every rank has grown its table) = call this again.
+int slimm_filter_alignments_launch(slimm_ctx* c) {
+    if (!c) return SLIMM_E_INVALID;
+    if (!c->covered) return fail(c, SLIMM_E_INVALID, "call slimm_finish_coverage first");
+    if (c->no_hits) return SLIMM_E_NO_HITS;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context: use slimm_filter_alignments + slimm_set_partials");
+    bool rows_ride_along = false;
+    int rc = SLIMM_OK;
+    if (!c->filter_pending) {  // (a retry keeps the valid set and the rows that are on the device already)
+        rc = filter_prepare(c, rows_ride_along);
+        if (rc != SLIMM_OK) return rc;
+    }
+    rc = filter_launch(c, rows_ride_along);
+    if (rc != SLIMM_OK) return rc;
+    const uint64_t W = 3ull * c->R + c->T + 2;
+    HIP_TRY(c, c->d_partials.ensure(W + 2));
+    launch_partials_pack(c->stream, c->ref_stats.p + c->statsA_words(), c->R, c->T, c->d_partials.p);
+    c->filter_pending = true;
+    c->filtered = true;
+    c->binsB_stored = !c->use_tiles || c->keep_bins;
+    return SLIMM_OK;
+}
+
 int slimm_partials_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
     if (!c->filtered || c->device < 0) return fail(c, SLIMM_E_INVALID, "no device partials (call slimm_filter_alignments)");
     (void)hipSetDevice(c->device);
-    const uint64_t W = 3ull * c->R + c->T + 1;
-    HIP_TRY(c, c->d_partials.ensure(W));
-    launch_partials_pack(c->stream, c->ref_stats.p + c->statsA_words(), c->R, c->T, c->d_partials.p);
+    // [R uniq_reads_count2 | T LCA counts | 2R level marks | pairs | error flags], then this rank's own {pairs, flags}
+    // (not part of the exchange)
+    const uint64_t W = 3ull * c->R + c->T + 2;
+    if (!c->filter_pending) {  // (slimm_filter_alignments_launch has packed them already)
+        HIP_TRY(c, c->d_partials.ensure(W + 2));
+        launch_partials_pack(c->stream, c->ref_stats.p + c->statsA_words(), c->R, c->T, c->d_partials.p);
+    }
     if (!c->stream_ordered) HIP_TRY(c, hipStreamSynchronize(c->stream));
     *d_ptr = c->d_partials.p;
     *n_words = W;
@@ -1256,11 +1333,29 @@ int slimm_install_merged_partials(slimm_ctx* c, uint32_t* total_pairs) {
         return fail(c, SLIMM_E_INVALID, "call slimm_partials_buffer first");
     (void)hipSetDevice(c->device);
     const uint32_t R = c->R, T = c->T;
-    const uint64_t W = 3ull * R + T + 1;
-    HIP_TRY(c, c->h_partials.ensure(W));
-    launch_copy_out(c->stream, c->h_partials.p, c->d_partials.p, static_cast<uint32_t>(W));  // (a kernel, not the DMA engine)
+    const uint64_t W = 3ull * R + T + 2;
+    HIP_TRY(c, c->h_partials.ensure(W + 2));
+    launch_copy_out(c->stream, c->h_partials.p, c->d_partials.p, static_cast<uint32_t>(W + 2));  // (a kernel, not the DMA engine)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const uint32_t* h = c->h_partials.p;
+    if (c->filter_pending) {
+        // the phase's only synchronisation has just happened: now the counters can be looked at.  Overflow flags were
+        // summed with everything else, so every rank sees "some rank overflowed" and every rank goes round again.
+        if (h[W - 1] != 0u) {
+            if (c->pair_cap >= (1u << 30)) return fail(c, SLIMM_E_INVALID, "(taxon, reference) pair set overflow");
+            int rc = ensure_pair_table(c, c->pair_cap * 4);
+            if (rc != SLIMM_OK) return rc;
+            c->pair_clean = false;
+            return SLIMM_E_RETRY;
+        }
+        uint32_t local[CNT_WORDS] = {0};
+        local[CNT_PAIRS] = h[W];
+        local[CNT_ERR] = h[W + 1];
+        bool again = false;
+        int rc = filter_check_counters(c, local, again);
+        if (rc != SLIMM_OK) return rc;
+        c->filter_pending = false;
+    }
     c->part_u2.assign(h, h + R);
     c->part_lca.assign(h + R, h + R + T);
     c->part_marks.resize(R);

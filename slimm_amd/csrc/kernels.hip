@@ -971,8 +971,10 @@ void launch_zero(hipStream_t st, const ZeroArgs& z) {
 }
 
 // Multi-GPU: this rank's additive partial results as one int32 buffer that ranks SUM in place:
-//   [R uniq_reads_count2 | T per-taxon LCA counts | 2R level marks, one 8-bit field per level | 1 number of pairs]
-// (a sum over at most 255 ranks cannot carry between the fields, so "field != 0" afterwards is the OR of the marks)
+//   [R uniq_reads_count2 | T per-taxon LCA counts | 2R level marks, one 8-bit field per level | number of pairs |
+//    pair-set overflow (0 / 1)]
+// (a sum over at most 255 ranks cannot carry between the fields, so "field != 0" afterwards is the OR of the marks),
+// followed by this rank's own {number of pairs, error flags}, which stay out of the exchange
 __global__ __launch_bounds__(256) void k_partials_pack(const uint32_t* __restrict__ block_b, uint32_t R, uint32_t T,
                                                        uint32_t* __restrict__ out) {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
@@ -986,7 +988,12 @@ __global__ __launch_bounds__(256) void k_partials_pack(const uint32_t* __restric
         out[R + T + 2 * r + 1] = ((m >> 4) & 1u) | ((m & 32u) << 3) | ((m & 64u) << 10) | ((m & 128u) << 17);
     }
     for (uint32_t t = gid; t < T; t += gsz) out[R + t] = lca[t];
-    if (gid == 0) out[3ull * R + T] = cnt[CNT_PAIRS];
+    if (gid == 0) {
+        out[3ull * R + T] = cnt[CNT_PAIRS];
+        out[3ull * R + T + 1] = (cnt[CNT_ERR] & ERR_PAIR_OVERFLOW) ? 1u : 0u;
+        out[3ull * R + T + 2] = cnt[CNT_PAIRS];
+        out[3ull * R + T + 3] = cnt[CNT_ERR];
+    }
 }
 
 void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out) {

@@ -113,20 +113,26 @@ def _gather_pairs(pairs: np.ndarray, total_pairs: int, dev, group) -> np.ndarray
     return np.unique(np.concatenate([g[k, 1:1 + int(g[k, 0])] for k in range(world)]).view(np.uint64))
 
 
-def merge_partials_on_device(engine, group=None) -> bool:
+def merge_partials_on_device(engine, group=None, launched: bool = False) -> bool:
     """The second exchange without a host detour, for engines that expose their partial results as a device tensor
     (`partials_tensor` / `install_merged_partials`, i.e. the HIP library): ONE all-reduce(SUM) in place, one copy back.
-    Returns False when the engine has no such tensor (the caller then merges through the host)."""
+    Returns False when the engine has no such tensor (the caller then merges through the host).
+    launched: phase B was started with filter_alignments_launch() -- the install below is then the phase's only host
+    synchronisation, and it may ask every rank to go round again (a pair set overflowed somewhere)."""
     if not hasattr(engine, "partials_tensor") or not dist.is_initialized():
         return False
     if dist.get_world_size(group) > 255:
         raise ValueError("level marks travel in 8-bit fields: at most 255 ranks")
     on_stream, ordered = _engine_stream(engine)
     with on_stream:
-        t = engine.partials_tensor()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        _fence(t, ordered)
-        total_pairs = engine.install_merged_partials()
+        while True:
+            t = engine.partials_tensor()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            _fence(t, ordered)
+            total_pairs = engine.install_merged_partials()
+            if total_pairs is not None:
+                break
+            engine.filter_alignments_launch()   # (only ever after a launched phase)
     if total_pairs > 0:  # rare (Q4: reads whose references agree at no level); the same decision on every rank
         p = engine.get_partials()
         pairs = _gather_pairs(p["pairs"], total_pairs, t.device, group)
@@ -206,10 +212,14 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
     t = lap("exchange + finish_coverage", t)
     if not have_hits:
         return None
-    engine.filter_alignments()
+    launched = multi and dist.is_initialized() and hasattr(engine, "filter_alignments_launch") and hasattr(engine, "partials_tensor")
+    if launched:
+        engine.filter_alignments_launch()   # no host synchronisation until the merged results are installed
+    else:
+        engine.filter_alignments()
     t = lap("filter_alignments", t)
     if multi or getattr(engine, "needs_set_partials", False):
-        if not merge_partials_on_device(engine, group):
+        if not merge_partials_on_device(engine, group, launched):
             merged = merge_partials(engine, device, group)
             engine.set_partials(merged["uniq_reads_count2"], merged["lca_count"], merged["level_marks"], merged["pairs"])
         t = lap("merge_partials", t)

@@ -245,6 +245,11 @@ class Slimm:
     def filter_alignments(self):
         self._check(self.L.slimm_filter_alignments(self.ctx))
 
+    def filter_alignments_launch(self):
+        """Multi-rank form: launches phase B and packs this rank's partial results, without waiting for the device;
+        partials_tensor() -> all_reduce -> install_merged_partials() completes it (None from there = go round again)."""
+        self._check(self.L.slimm_filter_alignments_launch(self.ctx))
+
     def get_partials(self) -> Dict[str, np.ndarray]:
         p = capi.Partials()
         self._check(self.L.slimm_get_partials(self.ctx, C.byref(p)))
@@ -270,9 +275,11 @@ class Slimm:
         return self._alias("partials", ptr.value, n.value)
 
     def install_merged_partials(self) -> int:
-        """Installs the (summed) partials buffer; returns the number of (taxon, reference) pairs over all ranks."""
+        """Installs the (summed) partials buffer; returns the number of (taxon, reference) pairs over all ranks -- or None
+        after filter_alignments_launch when some rank's pair set overflowed (every rank then launches again)."""
         total = C.c_uint32()
-        self._check(self.L.slimm_install_merged_partials(self.ctx, C.byref(total)))
+        if self._check(self.L.slimm_install_merged_partials(self.ctx, C.byref(total))) == capi.E_RETRY:
+            return None
         return int(total.value)
 
     def set_partials(self, uniq_reads_count2, lca_count, level_marks, pairs):

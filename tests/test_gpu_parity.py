@@ -295,10 +295,15 @@ def test_two_shards_on_one_gpu_through_the_summary_exchange():
     assert np.array_equal(engines[0].bins(2) + engines[1].bins(2), o.uniq_cov2)
 
 
+@pytest.mark.parametrize("launched", [False, True])
 @pytest.mark.parametrize("with_pairs", [False, True])
-def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs):
-    """The second exchange on the device: the two contexts' partials buffers are summed like an all-reduce would."""
+def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs, launched, monkeypatch):
+    """The second exchange on the device: the two contexts' partials buffers are summed like an all-reduce would.
+    launched: phase B through slimm_filter_alignments_launch (no host synchronisation before the merged results are
+    installed); with pairs the pair set starts tiny, so that install asks every rank to go round again."""
     import torch
+    if launched and with_pairs:
+        monkeypatch.setenv("SLIMM_PAIR_CAP", "64")
     if with_pairs:   # reads straddling superkingdoms agree at no level (Q4): (taxon, ref) pairs
         cfg = SynthConfig("q4shards", 150_000, 10_000, 6.0, present_frac=0.5, len_lo=200_000, len_hi=600_000)
         w = make_workload(cfg, seed=23)
@@ -322,14 +327,24 @@ def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs):
     torch.cuda.synchronize()
     for e in engines:
         assert e.finish_coverage_merged(gathered, 2)
-        e.filter_alignments()
-    tensors = [e.partials_tensor() for e in engines]
-    total = tensors[0] + tensors[1]
-    for t in tensors:
-        t.copy_(total)
-    torch.cuda.synchronize()
-    totals = [e.install_merged_partials() for e in engines]
-    assert totals[0] == totals[1]
+        e.filter_alignments_launch() if launched else e.filter_alignments()
+    rounds = 0
+    while True:
+        tensors = [e.partials_tensor() for e in engines]
+        torch.cuda.synchronize()
+        total = tensors[0] + tensors[1]
+        for t in tensors:
+            t.copy_(total)
+        torch.cuda.synchronize()
+        totals = [e.install_merged_partials() for e in engines]
+        assert totals[0] == totals[1]
+        if totals[0] is not None:
+            break
+        assert launched
+        rounds += 1
+        for e in engines:
+            e.filter_alignments_launch()
+    assert (rounds > 0) == (launched and with_pairs)
     local = [e.get_partials() for e in engines]
     assert totals[0] == sum(p["pairs"].shape[0] for p in local)
     assert (totals[0] > 0) == with_pairs

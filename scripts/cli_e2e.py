@@ -49,8 +49,10 @@ print(f"BAM: {n} records, {len(raw)/1e6:.0f} MB raw, {os.path.getsize(bam)/1e6:.
 db = os.path.join(tmp, "db.sldb"); write_sldb(db, w.taxonomy)
 cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimm_amd", "slimm")
 os.makedirs(os.path.join(tmp, "out"))
-for threads in (32, 64):
-    env = dict(os.environ, SLIMM_DECODE_THREADS=str(threads), SLIMM_CLI_TRACE="1")
+for threads in (0, 16, 32, 64):   # 0 = the command's own choice (logical CPUs or twice the cgroup quota, at most 64)
+    env = dict(os.environ, SLIMM_CLI_TRACE="1")
+    if threads:
+        env["SLIMM_DECODE_THREADS"] = str(threads)
     t0 = time.time()
     r = subprocess.run([cli, "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True, env=env)
     dt_ = time.time() - t0

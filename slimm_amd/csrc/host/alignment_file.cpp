@@ -152,9 +152,22 @@ bool AlignmentFile::open(const std::string& path) {
     have_pending_ = false;
     have_last_ = false;
     {
+        // as many threads as the process may keep busy: the logical CPUs, or the cgroup's CPU quota when that is less (a
+        // container on a 256-thread host may be held to 16 cores' worth; twice the quota keeps them fed across the
+        // stages' short waits)
         const char* e = getenv("SLIMM_DECODE_THREADS");
         unsigned hw = std::thread::hardware_concurrency();
-        threads_ = e ? static_cast<unsigned>(std::max(1, atoi(e))) : std::max(1u, std::min(hw ? hw : 1u, 64u));
+        hw = hw ? hw : 1u;
+        if (FILE* q = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = {0};
+            unsigned long period = 0;
+            if (fscanf(q, "%31s %lu", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+                const unsigned long cores = (strtoul(quota, nullptr, 10) + period - 1) / period;
+                if (cores > 0) hw = std::min<unsigned>(hw, static_cast<unsigned>(2 * cores));
+            }
+            fclose(q);
+        }
+        threads_ = e ? static_cast<unsigned>(std::max(1, atoi(e))) : std::max(1u, std::min(hw, 64u));
     }
     workers_.reset(new Workers(threads_));
     inflaters_.reset(new Workers(threads_));  // (the prefetch thread's own: its jobs run beside the decode jobs)

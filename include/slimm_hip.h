@@ -310,6 +310,27 @@ float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q);
 /* Bin of one record (src/slimm.hpp:200-201). */
 uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width);
 /* Library build info. */
+/* ---- Several GPUs in one process (slimm_amd/csrc/group.hip): a group of contexts, one per device, used like one.
+ * Records are dealt to the members by read as they are pushed (name-grouped streams: contiguous stretches of the file cut
+ * at qName-run boundaries, member after member; any other order: key mod n); slimm_group_get_profiles runs the phases on
+ * every member with the two exchanges of the multi-rank path in between -- ncclAllGather of the coverage summaries,
+ * ncclAllReduce of the partial results, both enqueued on the members' own streams (RCCL is dlopen()ed when the group is
+ * created; without it, or when one device is named several times, the same collectives are device-to-device copies and
+ * a summing kernel) -- and writes the profile from member 0.  cfg->device is ignored; results (slimm_get_stats,
+ * slimm_get_ref_columns, ...) are read from slimm_group_context(g, 0), whose per-reference columns, scalars and
+ * per-taxon counts are the merged ones.  The coverage arrays stay per-member partial sums. */
+typedef struct slimm_group slimm_group;
+int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_devices, slimm_group** out);
+void slimm_group_destroy(slimm_group* g);
+const char* slimm_group_last_error(const slimm_group* g); /* g may be NULL: error of the last failed slimm_group_create */
+uint32_t slimm_group_size(const slimm_group* g);
+slimm_ctx* slimm_group_context(slimm_group* g, uint32_t i);
+int slimm_group_uses_rccl(const slimm_group* g);
+int slimm_group_reset(slimm_group* g);
+int slimm_group_push_records(slimm_group* g, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
+                             const uint16_t* flag, uint64_t n);
+int slimm_group_get_profiles(slimm_group* g, const char* path); /* path may be NULL; SLIMM_E_NO_HITS like slimm_get_profiles */
+
 /* Starts the HIP runtime on `device` (what the first slimm_create of a process would otherwise pay, 0.1 - 0.3 s): for
  * hosts that call it from a thread of their own while they load their database and open their input. */
 int slimm_warm_up(int device);

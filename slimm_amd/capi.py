@@ -76,6 +76,15 @@ SYMBOLS = [
     ("slimm_reserve", C.c_int, [_P, C.c_uint64]),
     ("slimm_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_warm_up", C.c_int, [C.c_int]),
+    ("slimm_group_create", C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P)]),
+    ("slimm_group_destroy", None, [_P]),
+    ("slimm_group_last_error", C.c_char_p, [_P]),
+    ("slimm_group_size", C.c_uint32, [_P]),
+    ("slimm_group_context", _P, [_P, C.c_uint32]),
+    ("slimm_group_uses_rccl", C.c_int, [_P]),
+    ("slimm_group_reset", C.c_int, [_P]),
+    ("slimm_group_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
+    ("slimm_group_get_profiles", C.c_int, [_P, C.c_char_p]),
     ("slimm_filter_alignments_launch", C.c_int, [_P]),
     ("slimm_get_stream", C.c_int, [_P, C.POINTER(_P)]),
     ("slimm_set_stream_ordered", C.c_int, [_P, C.c_int]),

@@ -1,0 +1,452 @@
+// Several GPUs in ONE process: a group of contexts, one per device, that behaves like one (include/slimm_hip.h,
+// slimm_group_*).  The C++ host of SURVEY.md section 8e: records are dealt to the members BY READ while they are
+// pushed, every member runs the phases on its own reads, and the two exchanges of the multi-rank path
+// (slimm_amd/distributed.py is the same flow over torch.distributed) are collectives enqueued on the members' own HIP
+// streams:
+//     ncclAllGather  of the coverage summaries   (slimm_coverage_summary -> slimm_finish_coverage_merged)
+//     ncclAllReduce  of the partial results       (slimm_filter_alignments_launch -> slimm_install_merged_partials)
+// RCCL is loaded with dlopen when a group of distinct devices is created (the library itself does not link it: a
+// process that also runs torch has torch's copy of RCCL, and a single-GPU user needs none).  When RCCL is not there --
+// or the same device is named several times, which is how the tests run a group on one GPU -- the same two collectives
+// are device-to-device copies ordered by events plus a summing kernel.  The reference has no counterpart (one process,
+// one thread, no GPU).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/slimm_hip.h"
+
+namespace {
+
+constexpr uint64_t kKeyMask = (1ull << 62) - 1;  // include/slimm_hip.h: the significant bits of a read key
+
+// ---- the five RCCL entry points this file uses, by their documented C signatures (rccl.h)
+struct Rccl {
+    typedef struct ncclComm* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    static constexpr int kInt32 = 2, kSum = 0;  // ncclInt32, ncclSum
+    void* handle = nullptr;
+    bool load() {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(handle, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(handle, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(handle, "ncclAllGather"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && AllReduce;
+    }
+};
+
+// out[w] = sum over the n stretches of `parts` (each `words` long): the all-reduce of the copy form
+__global__ __launch_bounds__(256) void k_group_sum(const uint32_t* __restrict__ parts, uint32_t n, uint32_t words,
+                                                   uint32_t* __restrict__ out) {
+    for (uint32_t w = blockIdx.x * 256 + threadIdx.x; w < words; w += gridDim.x * 256) {
+        uint32_t s = 0;
+        for (uint32_t j = 0; j < n; ++j) s += parts[static_cast<size_t>(j) * words + w];
+        out[w] = s;
+    }
+}
+
+}  // namespace
+
+struct slimm_group {
+    std::vector<slimm_ctx*> ctx;
+    std::vector<int> device;
+    std::vector<hipStream_t> stream;
+    std::vector<hipEvent_t> ready, copied;   // per member: "my buffer is written" / "I have read everybody's buffer"
+    std::vector<uint32_t*> scratch;          // per member: n x words receive buffer
+    std::vector<size_t> scratch_words;
+    std::vector<Rccl::comm_t> comm;
+    Rccl rccl;
+    bool use_rccl = false;
+    int order = SLIMM_ORDER_GROUPED;
+    // dealing records by read
+    uint32_t cur = 0;                        // member that takes the next stretch of a grouped stream
+    std::vector<uint64_t> carry_key;         // the last qName run of the batch before: it may go on in the next batch
+    std::vector<int32_t> carry_ref, carry_pos;
+    std::vector<uint16_t> carry_flag;
+    bool have_last = false;
+    uint64_t last_key = 0;
+    std::string err;
+};
+
+namespace {
+
+int gfail(slimm_group* g, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (g) g->err = buf;
+    return code;
+}
+std::string g_group_create_error;
+
+int member_failed(slimm_group* g, uint32_t i, int rc, const char* what) {
+    return gfail(g, rc, "member %u (device %d): %s: %s", i, g->device[i], what, slimm_last_error(g->ctx[i]));
+}
+
+#define GTRY(g, i, call)                                       \
+    do {                                                       \
+        int rc_ = (call);                                      \
+        if (rc_ < 0) return member_failed(g, i, rc_, #call);   \
+    } while (0)
+#define GHIP(g, expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return gfail(g, SLIMM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure_scratch(slimm_group* g, uint32_t i, size_t words) {
+    if (g->scratch_words[i] >= words) return SLIMM_OK;
+    GHIP(g, hipSetDevice(g->device[i]));
+    if (g->scratch[i]) (void)hipFree(g->scratch[i]);
+    g->scratch[i] = nullptr;
+    g->scratch_words[i] = 0;
+    GHIP(g, hipMalloc(reinterpret_cast<void**>(&g->scratch[i]), words * 4));
+    g->scratch_words[i] = words;
+    return SLIMM_OK;
+}
+
+// recv[i] (on member i's device, n x words) = send[0] | send[1] | ... | send[n-1], enqueued on the members' streams
+int all_gather(slimm_group* g, const std::vector<uint32_t*>& send, size_t words, std::vector<uint32_t*>& recv) {
+    const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+    recv.assign(n, nullptr);
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc = ensure_scratch(g, i, n * words);
+        if (rc != SLIMM_OK) return rc;
+        recv[i] = g->scratch[i];
+    }
+    if (g->use_rccl) {
+        if (g->rccl.GroupStart() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
+        for (uint32_t i = 0; i < n; ++i) {
+            GHIP(g, hipSetDevice(g->device[i]));
+            if (g->rccl.AllGather(send[i], recv[i], words, Rccl::kInt32, g->comm[i], g->stream[i]) != 0)
+                return gfail(g, SLIMM_E_HIP, "ncclAllGather failed on member %u", i);
+        }
+        if (g->rccl.GroupEnd() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
+        return SLIMM_OK;
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+        GHIP(g, hipSetDevice(g->device[j]));
+        GHIP(g, hipEventRecord(g->ready[j], g->stream[j]));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        for (uint32_t j = 0; j < n; ++j) {
+            if (j != i) GHIP(g, hipStreamWaitEvent(g->stream[i], g->ready[j], 0));
+            GHIP(g, hipMemcpyAsync(recv[i] + static_cast<size_t>(j) * words, send[j], words * 4, hipMemcpyDeviceToDevice,
+                                   g->stream[i]));
+        }
+    }
+    return SLIMM_OK;
+}
+
+// buf[i][w] = sum over the members of buf[j][w], in place, enqueued on the members' streams
+int all_reduce_sum(slimm_group* g, const std::vector<uint32_t*>& buf, size_t words) {
+    const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+    if (g->use_rccl) {
+        if (g->rccl.GroupStart() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
+        for (uint32_t i = 0; i < n; ++i) {
+            GHIP(g, hipSetDevice(g->device[i]));
+            if (g->rccl.AllReduce(buf[i], buf[i], words, Rccl::kInt32, Rccl::kSum, g->comm[i], g->stream[i]) != 0)
+                return gfail(g, SLIMM_E_HIP, "ncclAllReduce failed on member %u", i);
+        }
+        if (g->rccl.GroupEnd() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
+        return SLIMM_OK;
+    }
+    std::vector<uint32_t*> parts;
+    int rc = all_gather(g, buf, words, parts);  // parts[i] = everybody's buffer, on member i's device
+    if (rc != SLIMM_OK) return rc;
+    // nobody overwrites its buffer before everybody has read it
+    for (uint32_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        GHIP(g, hipEventRecord(g->copied[i], g->stream[i]));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        for (uint32_t j = 0; j < n; ++j)
+            if (j != i) GHIP(g, hipStreamWaitEvent(g->stream[i], g->copied[j], 0));
+        const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>(256, (words + 255) / 256));
+        hipLaunchKernelGGL(k_group_sum, dim3(std::max(1u, blocks)), dim3(256), 0, g->stream[i], parts[i], n,
+                           static_cast<uint32_t>(words), buf[i]);
+    }
+    return SLIMM_OK;
+}
+
+int push_to(slimm_group* g, uint32_t i, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
+            uint64_t n) {
+    if (n == 0) return SLIMM_OK;
+    GTRY(g, i, slimm_push_records(g->ctx[i], key, ref, pos, flag, n));
+    return SLIMM_OK;
+}
+
+int flush_carry(slimm_group* g, uint32_t to) {
+    if (g->carry_key.empty()) return SLIMM_OK;
+    int rc = push_to(g, to, g->carry_key.data(), g->carry_ref.data(), g->carry_pos.data(), g->carry_flag.data(), g->carry_key.size());
+    g->carry_key.clear();
+    g->carry_ref.clear();
+    g->carry_pos.clear();
+    g->carry_flag.clear();
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_devices, slimm_group** out) {
+    if (!cfg || !devices || !out || n_devices == 0 || n_devices > 255) {
+        g_group_create_error = "slimm_group_create: 1 .. 255 devices";
+        return SLIMM_E_INVALID;
+    }
+    slimm_group* g = new slimm_group();
+    g->order = cfg->record_order;
+    bool distinct = true;
+    for (uint32_t i = 0; i < n_devices; ++i)
+        for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+    for (uint32_t i = 0; i < n_devices; ++i) {
+        slimm_config c = *cfg;
+        c.device = devices[i];
+        slimm_ctx* ctx = nullptr;
+        int rc = slimm_create(&c, &ctx);
+        if (rc != SLIMM_OK) {
+            g_group_create_error = std::string("member ") + std::to_string(i) + ": " + slimm_last_error(nullptr);
+            slimm_group_destroy(g);
+            return rc;
+        }
+        g->ctx.push_back(ctx);
+        g->device.push_back(devices[i]);
+        void* s = nullptr;
+        (void)slimm_get_stream(ctx, &s);
+        g->stream.push_back(static_cast<hipStream_t>(s));
+        g->scratch.push_back(nullptr);
+        g->scratch_words.push_back(0);
+        hipEvent_t a = nullptr, b = nullptr;
+        (void)hipSetDevice(devices[i]);
+        if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+            g_group_create_error = "hipEventCreate failed";
+            slimm_group_destroy(g);
+            return SLIMM_E_HIP;
+        }
+        g->ready.push_back(a);
+        g->copied.push_back(b);
+    }
+    // collectives: RCCL over xGMI for distinct devices (SLIMM_GROUP_COLLECTIVES=copy|rccl overrides the choice)
+    const char* how = getenv("SLIMM_GROUP_COLLECTIVES");
+    const bool want_rccl = how ? strcmp(how, "rccl") == 0 : (distinct && n_devices > 1);
+    if (want_rccl && (distinct || n_devices == 1) && g->rccl.load()) {
+        g->comm.assign(n_devices, nullptr);
+        if (g->rccl.CommInitAll(g->comm.data(), static_cast<int>(n_devices), g->device.data()) == 0) {
+            g->use_rccl = true;
+        } else {
+            g->comm.clear();
+        }
+    }
+    if (how && strcmp(how, "rccl") == 0 && !g->use_rccl) {
+        g_group_create_error = "SLIMM_GROUP_COLLECTIVES=rccl, but librccl could not be loaded or initialised for these devices";
+        slimm_group_destroy(g);
+        return SLIMM_E_HIP;
+    }
+    if (n_devices > 1 || g->use_rccl)  // the collectives run on the members' streams: no host fences around them
+        for (slimm_ctx* c : g->ctx) (void)slimm_set_stream_ordered(c, 1);
+    *out = g;
+    return SLIMM_OK;
+}
+
+void slimm_group_destroy(slimm_group* g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        (void)hipSetDevice(g->device[i]);
+        if (g->stream[i]) (void)hipStreamSynchronize(g->stream[i]);
+    }
+    if (g->use_rccl)
+        for (Rccl::comm_t c : g->comm)
+            if (c) (void)g->rccl.CommDestroy(c);
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        (void)hipSetDevice(g->device[i]);
+        if (i < g->scratch.size() && g->scratch[i]) (void)hipFree(g->scratch[i]);
+        if (i < g->ready.size() && g->ready[i]) (void)hipEventDestroy(g->ready[i]);
+        if (i < g->copied.size() && g->copied[i]) (void)hipEventDestroy(g->copied[i]);
+        slimm_destroy(g->ctx[i]);
+    }
+    delete g;
+}
+
+const char* slimm_group_last_error(const slimm_group* g) { return g ? g->err.c_str() : g_group_create_error.c_str(); }
+uint32_t slimm_group_size(const slimm_group* g) { return g ? static_cast<uint32_t>(g->ctx.size()) : 0u; }
+slimm_ctx* slimm_group_context(slimm_group* g, uint32_t i) { return (g && i < g->ctx.size()) ? g->ctx[i] : nullptr; }
+int slimm_group_uses_rccl(const slimm_group* g) { return (g && g->use_rccl) ? 1 : 0; }
+
+int slimm_group_reset(slimm_group* g) {
+    if (!g) return SLIMM_E_INVALID;
+    for (uint32_t i = 0; i < g->ctx.size(); ++i) GTRY(g, i, slimm_reset(g->ctx[i]));
+    g->cur = 0;
+    g->carry_key.clear();
+    g->carry_ref.clear();
+    g->carry_pos.clear();
+    g->carry_flag.clear();
+    g->have_last = false;
+    return SLIMM_OK;
+}
+
+// Deals a batch to the members by read.  Name-grouped streams: the batch up to its last qName-run start goes to the
+// current member (together with the run the batch before ended in), the last run waits for the next batch -- it may go
+// on there -- and the next member is up: contiguous stretches of the file, cut at run boundaries, in turn.  Any other
+// order: member = key mod n.
+int slimm_group_push_records(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
+                             uint64_t n) {
+    if (!g) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!key || !ref || !pos || !flag) return gfail(g, SLIMM_E_INVALID, "null record array");
+    const uint32_t m = static_cast<uint32_t>(g->ctx.size());
+    if (m == 1) return push_to(g, 0, key, ref, pos, flag, n);
+    if (g->order != SLIMM_ORDER_GROUPED) {
+        std::vector<std::vector<uint64_t>> k(m);
+        std::vector<std::vector<int32_t>> r(m), p(m);
+        std::vector<std::vector<uint16_t>> f(m);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t o = static_cast<uint32_t>((key[i] & kKeyMask) % m);
+            k[o].push_back(key[i]);
+            r[o].push_back(ref[i]);
+            p[o].push_back(pos[i]);
+            f[o].push_back(flag[i]);
+        }
+        for (uint32_t o = 0; o < m; ++o) {
+            int rc = push_to(g, o, k[o].data(), r[o].data(), p[o].data(), f[o].data(), k[o].size());
+            if (rc != SLIMM_OK) return rc;
+        }
+        return SLIMM_OK;
+    }
+    // the run the batch before ended in goes where this batch's head goes
+    int rc = flush_carry(g, g->cur);
+    if (rc != SLIMM_OK) return rc;
+    uint64_t last_start = n;  // index of the batch's last run start, n = none found
+    for (uint64_t i = n; i-- > 1;)
+        if ((key[i] ^ key[i - 1]) & kKeyMask) {
+            last_start = i;
+            break;
+        }
+    if (last_start == n && !(g->have_last && ((key[0] ^ g->last_key) & kKeyMask) == 0)) last_start = 0;  // one run, a new one
+    g->have_last = true;
+    g->last_key = key[n - 1];
+    if (last_start == n || last_start == 0) {
+        // no boundary inside the batch: it stays with the current member, and so does whatever continues it
+        return push_to(g, g->cur, key, ref, pos, flag, n);
+    }
+    rc = push_to(g, g->cur, key, ref, pos, flag, last_start);
+    if (rc != SLIMM_OK) return rc;
+    g->carry_key.assign(key + last_start, key + n);
+    g->carry_ref.assign(ref + last_start, ref + n);
+    g->carry_pos.assign(pos + last_start, pos + n);
+    g->carry_flag.assign(flag + last_start, flag + n);
+    g->cur = (g->cur + 1) % m;
+    return SLIMM_OK;
+}
+
+// slimm::get_profiles() (src/slimm.hpp:447-489) over the members' reads: phases A, B, C(1) on every member with the two
+// exchanges in between, propagation and the profile on member 0 (every member holds the same merged results).
+int slimm_group_get_profiles(slimm_group* g, const char* path) {
+    if (!g) return SLIMM_E_INVALID;
+    const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+    int rc = flush_carry(g, g->cur);
+    if (rc != SLIMM_OK) return rc;
+    if (n == 1 && !g->use_rccl) {  // (a group of one with RCCL forced goes the long way: the test of the RCCL calls)
+        rc = slimm_get_profiles(g->ctx[0], path);
+        if (rc < 0) return member_failed(g, 0, rc, "slimm_get_profiles");
+        return rc;
+    }
+    for (uint32_t i = 0; i < n; ++i) GTRY(g, i, slimm_prepare_summary(g->ctx[i], 1));
+    for (uint32_t i = 0; i < n; ++i) GTRY(g, i, slimm_analyze_alignments(g->ctx[i]));
+    // ---- exchange 1: per-reference sums + one bit per bin of every member, all-gathered
+    std::vector<uint32_t*> mine(n), gathered;
+    uint64_t words = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        void* p = nullptr;
+        uint64_t w = 0;
+        GTRY(g, i, slimm_coverage_summary(g->ctx[i], &p, &w));
+        mine[i] = static_cast<uint32_t*>(p);
+        if (i && w != words) return gfail(g, SLIMM_E_INVALID, "members disagree about the summary size");
+        words = w;
+    }
+    rc = all_gather(g, mine, words, gathered);
+    if (rc != SLIMM_OK) return rc;
+    bool hits = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        rc = slimm_finish_coverage_merged(g->ctx[i], gathered[i], n);
+        if (rc < 0) return member_failed(g, i, rc, "slimm_finish_coverage_merged");
+        hits = hits || rc != SLIMM_E_NO_HITS;
+    }
+    if (!hits) return SLIMM_E_NO_HITS;
+    // ---- phase B / C(1) with exchange 2: the additive partial results, all-reduced in place
+    uint32_t total_pairs = 0;
+    for (int round = 0;; ++round) {
+        if (round > 16) return gfail(g, SLIMM_E_INVALID, "pair set still overflowing after 16 rounds");
+        for (uint32_t i = 0; i < n; ++i) GTRY(g, i, slimm_filter_alignments_launch(g->ctx[i]));
+        std::vector<uint32_t*> part(n);
+        uint64_t pw = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            void* p = nullptr;
+            GTRY(g, i, slimm_partials_buffer(g->ctx[i], &p, &pw));
+            part[i] = static_cast<uint32_t*>(p);
+        }
+        rc = all_reduce_sum(g, part, pw);
+        if (rc != SLIMM_OK) return rc;
+        bool again = false;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t tp = 0;
+            rc = slimm_install_merged_partials(g->ctx[i], &tp);
+            if (rc < 0) return member_failed(g, i, rc, "slimm_install_merged_partials");
+            again = again || rc == SLIMM_E_RETRY;
+            total_pairs = tp;
+        }
+        if (!again) break;
+    }
+    if (total_pairs) {  // rare (Q4): the union of the members' (taxon, reference) pairs, through the host
+        std::vector<uint64_t> all;
+        std::vector<slimm_partials> parts(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            GTRY(g, i, slimm_get_partials(g->ctx[i], &parts[i]));
+            all.insert(all.end(), parts[i].pairs, parts[i].pairs + parts[i].n_pairs);
+        }
+        std::sort(all.begin(), all.end());
+        all.erase(std::unique(all.begin(), all.end()), all.end());
+        for (uint32_t i = 0; i < n; ++i) {
+            slimm_partials in = parts[i];
+            // (the arrays slimm_get_partials returned are the member's own: copy what slimm_set_partials will overwrite)
+            std::vector<uint32_t> u2(in.uniq_reads_count2, in.uniq_reads_count2 + in.n_refs),
+                lca(in.lca_count, in.lca_count + in.n_taxa_dense), mk(in.level_marks, in.level_marks + in.n_refs);
+            in.uniq_reads_count2 = u2.data();
+            in.lca_count = lca.data();
+            in.level_marks = mk.data();
+            in.pairs = all.data();
+            in.n_pairs = static_cast<uint32_t>(all.size());
+            GTRY(g, i, slimm_set_partials(g->ctx[i], &in));
+        }
+    }
+    GTRY(g, 0, slimm_get_reads_lca_count(g->ctx[0]));
+    if (path) GTRY(g, 0, slimm_write_abundance_file(g->ctx[0], path));
+    return SLIMM_OK;
+}
+
+}  // extern "C"

@@ -28,27 +28,37 @@ class DeviceArray:
 
 
 class Slimm:
-    def __init__(self, taxonomy: Taxonomy, options: Options, ref_names: List[str], ref_len: np.ndarray,
-                 avg_read_len: int, device: int = 0, grouped: bool = True, lineage: Optional[np.ndarray] = None):
-        self.L = capi.lib()
-        self.ctx = C.c_void_p()
+    def _config(self, taxonomy, options, ref_names, ref_len, avg_read_len, device, grouped, lineage):
         self.ref_names = list(ref_names)
         self.n_refs = len(ref_names)
         self._ref_len = np.ascontiguousarray(ref_len, dtype=np.uint32)
         self._lineage = np.ascontiguousarray(
             lineage if lineage is not None else taxonomy.lineage_for_header(ref_names), dtype=np.uint32)
         assert self._lineage.shape == (self.n_refs, 8)
-        names = (C.c_char_p * len(taxonomy.tax_name))(*[n.encode() for n in taxonomy.tax_name])
-        cfg = capi.Config(
+        self._names = (C.c_char_p * len(taxonomy.tax_name))(*[n.encode() for n in taxonomy.tax_name])
+        return capi.Config(
             n_refs=self.n_refs, ref_len=_p(self._ref_len), lineage=_p(self._lineage),
             bin_width=options.bin_width, avg_read_len=int(avg_read_len), min_reads=options.min_reads,
             cov_cut_off=options.cov_cut_off, abundance_cut_off=options.abundance_cut_off, rank=options.rank.encode(),
             n_taxa=len(taxonomy.tax_name), tax_id=_p(taxonomy.tax_id), tax_rank=_p(taxonomy.tax_rank),
-            tax_name=names, device=device, record_order=capi.ORDER_GROUPED if grouped else capi.ORDER_ANY)
-        rc = self.L.slimm_create(C.byref(cfg), C.byref(self.ctx))
-        if rc != capi.OK:
-            msg = self.L.slimm_last_error(None)
-            raise capi.SlimmError(rc, msg.decode() if msg else "")
+            tax_name=self._names, device=device, record_order=capi.ORDER_GROUPED if grouped else capi.ORDER_ANY)
+
+    def __init__(self, taxonomy: Taxonomy, options: Options, ref_names: List[str], ref_len: np.ndarray,
+                 avg_read_len: int, device: int = 0, grouped: bool = True, lineage: Optional[np.ndarray] = None,
+                 adopt=None):
+        """adopt: (ctx pointer, owner) -- a context that belongs to somebody else (a SlimmGroup member): used, never
+        destroyed here."""
+        self.L = capi.lib()
+        self.ctx = C.c_void_p()
+        cfg = self._config(taxonomy, options, ref_names, ref_len, avg_read_len, device, grouped, lineage)
+        self._owner = None
+        if adopt is not None:
+            self.ctx, self._owner = C.c_void_p(adopt[0]), adopt[1]
+        else:
+            rc = self.L.slimm_create(C.byref(cfg), C.byref(self.ctx))
+            if rc != capi.OK:
+                msg = self.L.slimm_last_error(None)
+                raise capi.SlimmError(rc, msg.decode() if msg else "")
         self.device = device
         self._keepalive = None
         n = C.c_uint32()
@@ -63,9 +73,9 @@ class Slimm:
                    grouped=w.grouped if grouped is None else grouped)
 
     def close(self):
-        if self.ctx:
+        if self.ctx and self._owner is None:
             self.L.slimm_destroy(self.ctx)
-            self.ctx = C.c_void_p()
+        self.ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -386,3 +396,65 @@ def host_bin_of(begin_pos: int, avg_read_len: int, ref_len: int, bin_width: int)
 def host_avg_read_length(l_seq: np.ndarray, sample: int = 100000) -> int:
     l_seq = np.ascontiguousarray(l_seq, dtype=np.uint32)
     return int(capi.lib().slimm_host_avg_read_length(_p(l_seq), l_seq.shape[0], sample))
+
+
+class SlimmGroup:
+    """slimm_group_*: several GPUs in one process, used like one context (include/slimm_hip.h).  `devices` may name one
+    device several times (that is how the tests run a group on a single GPU: the collectives are then copies)."""
+
+    def __init__(self, w: Workload, devices, grouped: Optional[bool] = None):
+        self.L = capi.lib()
+        self.g = C.c_void_p()
+        self.w = w
+        self.grouped = w.grouped if grouped is None else grouped
+        self.devices = list(devices)
+        # (the configuration arrays live in a Slimm-shaped holder; member 0 is then adopted into the same object)
+        self._holder = Slimm.__new__(Slimm)
+        cfg = Slimm._config(self._holder, w.taxonomy, w.options, w.ref_names, w.ref_len, w.avg_read_len, 0, self.grouped, None)
+        dev = (C.c_int * len(self.devices))(*self.devices)
+        rc = self.L.slimm_group_create(C.byref(cfg), dev, len(self.devices), C.byref(self.g))
+        if rc != capi.OK:
+            msg = self.L.slimm_group_last_error(None)
+            raise capi.SlimmError(rc, msg.decode() if msg else "")
+
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            msg = self.L.slimm_group_last_error(self.g)
+            raise capi.SlimmError(rc, msg.decode() if msg else "")
+        return rc
+
+    def member(self, i: int = 0) -> Slimm:
+        """Member i as a Slimm object (results: stats(), ref_columns(), taxon counts ... of the merged run on member 0)."""
+        w = self.w
+        return Slimm(w.taxonomy, w.options, w.ref_names, w.ref_len, w.avg_read_len, device=self.devices[i],
+                     grouped=self.grouped, adopt=(self.L.slimm_group_context(self.g, i), self))
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.L.slimm_group_uses_rccl(self.g))
+
+    def reset(self):
+        self._check(self.L.slimm_group_reset(self.g))
+
+    def push_records(self, rec: Records, batch: int = 0):
+        n = len(rec)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_group_push_records(self.g, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
+                                                        _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), e - s))
+
+    def get_profiles(self, path: Optional[str] = None) -> bool:
+        """False when no record is mapped (the reference's early return)."""
+        return self._check(self.L.slimm_group_get_profiles(self.g, path.encode() if path else None)) != capi.E_NO_HITS
+
+    def close(self):
+        if self.g:
+            self.L.slimm_group_destroy(self.g)
+            self.g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

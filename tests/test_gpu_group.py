@@ -1,0 +1,111 @@
+"""slimm_group_*: several contexts in one process used like one (slimm_amd/csrc/group.hip).  On the single GPU of the
+test box the members share device 0, so the two collectives run in their copy form; the dealing of records by read, the
+phase order, the exchanges and the retry of an overflowing pair set are the code every group runs.  With distinct
+devices the only difference is which primitive moves the buffers (ncclAllGather / ncclAllReduce)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.binding import run_workload
+from slimm_amd.profiler import SlimmGroup
+from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
+from tests.helpers import assert_matches_oracle, assert_profiles_match
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(w, members, batch, grouped=None, tmp_path=None):
+    g = SlimmGroup(w, [0] * members, grouped=grouped)
+    g.push_records(w.records, batch=batch)
+    path = str(tmp_path / "p.tsv") if tmp_path is not None else None
+    assert g.get_profiles(path)
+    return g, path
+
+
+@pytest.mark.parametrize("members,batch", [(1, 0), (2, 5000), (3, 1777), (4, 100_000)])
+def test_group_on_one_device_equals_the_oracle(members, batch, tmp_path):
+    w = make_workload(CONFIGS["config1"], seed=51)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g, path = _run(w, members, batch, tmp_path=tmp_path)
+    assert_matches_oracle(g.member(0), o, bins=False)
+    assert_profiles_match(open(path).read(), o.profile_tsv)
+    if members > 1:   # every member holds the merged per-reference columns
+        a, b = g.member(0).ref_columns(), g.member(members - 1).ref_columns()
+        for k in ("reads_count", "uniq_reads_count", "nz_cov", "nz_uniq_cov", "uniq_reads_count2"):
+            assert np.array_equal(a[k], b[k]), k
+        # ... and got a share of the records: the stream was dealt in stretches of `batch`
+        shares = [g.member(i).stats()["n_records"] for i in range(members)]
+        assert sum(shares) == len(w.records) and (batch >= len(w.records) or min(shares) > 0)
+    g.close()
+
+
+def test_group_any_order_goes_by_key(tmp_path):
+    w = make_workload(CONFIGS["config1"], seed=52, shuffled=True)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g, _ = _run(w, 3, 4000, grouped=False)
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()
+
+
+def test_group_pair_set_overflow_goes_round_again(monkeypatch):
+    """Reads whose references agree at no level (Q4) with a 64-entry pair set: slimm_install_merged_partials answers
+    SLIMM_E_RETRY on every member, every member grows its table, and the phase is launched again."""
+    monkeypatch.setenv("SLIMM_PAIR_CAP", "64")
+    cfg = SynthConfig("q4group", 120_000, 10_000, 6.0, present_frac=0.5, len_lo=200_000, len_hi=600_000)
+    w = make_workload(cfg, seed=53)
+    rng = np.random.default_rng(2)
+    m = w.records.ref_id >= 0
+    jump = rng.random(len(w.records)) < 0.2
+    w.records.ref_id[m & jump] = rng.integers(0, cfg.n_refs, size=int((m & jump).sum()), dtype=np.int32)
+    w.records.begin_pos[m & jump] = 1000
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    assert len(o.lca_direct_children) > 64
+    g, _ = _run(w, 2, 20_000)
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()
+
+
+def test_group_reset_and_a_second_file_and_no_hits():
+    w = make_workload(CONFIGS["config1"], seed=54)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0, 0])
+    for _ in range(2):
+        g.reset()
+        g.push_records(w.records, batch=3000)
+        assert g.get_profiles()
+        assert_matches_oracle(g.member(0), o, bins=False)
+    g.reset()
+    r = w.records.take(np.arange(2000))
+    r.flag[:] |= 4
+    g.push_records(r, batch=500)
+    assert not g.get_profiles()
+    g.close()
+
+
+def test_group_one_run_longer_than_a_batch_stays_on_one_member():
+    """A qName run that spans several pushes must not be cut: batches without a run boundary stay with the member that
+    holds the run's beginning."""
+    w = make_workload(CONFIGS["config1"], seed=55, n_records=6000)
+    r = w.records
+    r.read_key[1000:4000] = r.read_key[1000]      # one read name with 3000 records
+    r.flag[1000:4000] &= np.uint16(~(0x40 | 0x80) & 0xffff)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g, _ = _run(w, 2, 700)
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()
+
+
+@pytest.mark.skipif(os.environ.get("SLIMM_EMU") == "1", reason="needs librccl and a GPU")
+def test_group_of_one_through_rccl(monkeypatch):
+    """The RCCL form with a communicator of one: the calls (ncclCommInitAll, grouped ncclAllGather / ncclAllReduce on the
+    member's stream) are the ones a group of eight makes."""
+    monkeypatch.setenv("SLIMM_GROUP_COLLECTIVES", "rccl")
+    w = make_workload(CONFIGS["config1"], seed=56)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0])
+    assert g.uses_rccl
+    g.push_records(w.records)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()

@@ -100,6 +100,14 @@ SLIMM_FORWARD(int, slimm_write_abundance_file, (slimm_ctx* a, const char* b), (a
 SLIMM_FORWARD(int, slimm_get_stats, (slimm_ctx* a, slimm_stats* b), (a, b))
 SLIMM_FORWARD(int, slimm_get_ref_columns, (slimm_ctx* a, slimm_ref_columns* b), (a, b))
 SLIMM_FORWARD(int, slimm_get_bins, (slimm_ctx* a, int b, uint32_t* c), (a, b, c))
+SLIMM_FORWARD(int, slimm_group_create, (const slimm_config* a, const int* b, uint32_t c, slimm_group** d), (a, b, c, d))
+SLIMM_FORWARD(void, slimm_group_destroy, (slimm_group* a), (a))
+SLIMM_FORWARD(const char*, slimm_group_last_error, (const slimm_group* a), (a))
+SLIMM_FORWARD(slimm_ctx*, slimm_group_context, (slimm_group* a, uint32_t b), (a, b))
+SLIMM_FORWARD(int, slimm_group_uses_rccl, (const slimm_group* a), (a))
+SLIMM_FORWARD(int, slimm_group_push_records,
+              (slimm_group* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, uint64_t f_), (a, b, c, d, e, f_))
+SLIMM_FORWARD(int, slimm_group_get_profiles, (slimm_group* a, const char* b), (a, b))
 #include "accession.hpp"
 #include "alignment_file.hpp"
 #include "sldb.hpp"
@@ -115,6 +123,7 @@ struct Options {  // arg_options, reference src/slimm.hpp:49-87
     std::string rank = "species", input_path, output_prefix, database_path;
     // extensions
     int device = 0;
+    std::vector<int> devices;  // --devices a,b,...: several GPUs, one process (slimm_group_*)
     int order = -1;  // -1: from the @HD line
     bool dump_records = false;
 };
@@ -180,7 +189,7 @@ void usage() {
                  "  -ro, --raw-output             write raw reference statistics\n"
                  "  -co, --coverage-output        write raw coverage statistics\n"
                  "  -v,  --verbose\n"
-                 "       --device N | --query-grouped | --any-order | --dump-records\n";
+                 "       --device N | --devices N,M,... | --query-grouped | --any-order | --dump-records\n";
 }
 
 // 0 ok, 1 error, 2 help
@@ -241,6 +250,15 @@ int parse(int argc, char** argv, Options& o) {
             o.coverage_output = true;
         } else if (a == "-v" || a == "--verbose") {
             o.verbose = true;
+        } else if (a == "--devices") {
+            if (!value(v)) return 1;
+            o.devices.clear();
+            for (size_t p = 0; p <= v.size();) {
+                const size_t q = std::min(v.find(',', p), v.size());
+                if (q > p) o.devices.push_back(atoi(v.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+            if (!o.devices.empty()) o.device = o.devices[0];
         } else if (a == "--device") {
             if (!value(v)) return 1;
             o.device = atoi(v.c_str());
@@ -353,6 +371,7 @@ struct RecordPump {
     std::condition_variable cv;
     std::deque<Batch> queued;
     slimm_ctx* ctx = nullptr;  // set by attach(): from then on the decoder pushes by itself
+    slimm_group* group = nullptr;  // ... or a group of contexts (--devices): the group deals the records to its members
     bool failed = false;       // a push failed (slimm_last_error says why)
     long read_rc = 0;          // the reader's last answer: 0 = end of file, -1 = format error
     double decode_ms = 0, wait_ms = 0;
@@ -379,7 +398,7 @@ struct RecordPump {
             {
                 std::lock_guard<std::mutex> g(mu);
                 if (failed) return;
-                c = ctx;
+                c = group ? nullptr : ctx;
             }
             if (c) {  // straight into a staging set
                 uint64_t* key;
@@ -410,9 +429,11 @@ struct RecordPump {
             }
             b.n = static_cast<uint64_t>(n);
             std::unique_lock<std::mutex> g(mu);
-            cv.wait(g, [&] { return ctx || failed || queued.size() < kMaxQueued; });
+            cv.wait(g, [&] { return ctx || group || failed || queued.size() < kMaxQueued; });
             if (failed) return;
-            if (ctx) {  // attached meanwhile: everything queued before has been pushed, this batch follows
+            if (group) {
+                if (slimm_group_push_records(group, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) break;
+            } else if (ctx) {  // attached meanwhile: everything queued before has been pushed, this batch follows
                 if (slimm_push_records(ctx, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) break;
             } else {
                 queued.push_back(std::move(b));
@@ -432,6 +453,19 @@ struct RecordPump {
             }
         queued.clear();
         ctx = c;
+        cv.notify_all();
+        return true;
+    }
+    bool attach_group(slimm_group* grp) {
+        std::unique_lock<std::mutex> g(mu);
+        for (Batch& b : queued)
+            if (slimm_group_push_records(grp, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) {
+                failed = true;
+                cv.notify_all();
+                return false;
+            }
+        queued.clear();
+        group = grp;
         cv.notify_all();
         return true;
     }
@@ -526,6 +560,65 @@ bool get_profiles(Session& S, size_t file_index) {
         cfg.record_order = (bam.sort_order() == SortOrder::QueryName || bam.sort_order() == SortOrder::QueryGrouped)
                                ? SLIMM_ORDER_GROUPED
                                : SLIMM_ORDER_ANY;
+    if (options.devices.size() > 1) {
+        // ---- several GPUs, one process: the group deals the records to its members by read and runs the phases with the
+        // two RCCL exchanges in between (slimm_amd/csrc/group.hip); the profile comes from member 0
+        if (options.raw_output || options.coverage_output) {
+            std::cerr << "slimm: -ro / -co read the coverage arrays, which stay per-device partial sums with --devices; "
+                         "run them on one device\n";
+            return false;
+        }
+        slimm_group* grp = nullptr;
+        if (slimm_group_create(&cfg, options.devices.data(), static_cast<uint32_t>(options.devices.size()), &grp) != SLIMM_OK) {
+            std::cerr << "slimm: " << slimm_group_last_error(nullptr) << "\n";
+            return false;
+        }
+        for (uint32_t i = 0; i < options.devices.size(); ++i)
+            (void)slimm_set_cutoff_cache(slimm_group_context(grp, i), S.cc_cache, S.ucc_cache);
+        slimm_ctx* c0 = slimm_group_context(grp, 0);
+        trace.mark("lineage table + slimm_group_create");
+        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+        std::cerr << "Analysing alignments on " << options.devices.size() << " devices ("
+                  << (slimm_group_uses_rccl(grp) ? "RCCL" : "copy") << " collectives) ... ";
+        const bool pushed = pump.attach_group(grp) && pump.finish();
+        trace.mark("rest of read + decode + push");
+        if (!pushed || pump.read_rc < 0) {
+            std::cerr << (pushed ? bam.error() : std::string("pushing records: ") + slimm_group_last_error(grp)) << "\n";
+            slimm_group_destroy(grp);
+            return false;
+        }
+        const int grc = slimm_group_get_profiles(grp, get_tsv_file_name(options.output_prefix, path, "_profile").c_str());
+        if (grc < 0) {
+            std::cerr << "slimm: " << slimm_group_last_error(grp) << "\n";
+            slimm_group_destroy(grp);
+            return false;
+        }
+        trace.mark("phases + exchanges + profile");
+        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+        slimm_stats st;
+        slimm_get_stats(c0, &st);
+        S.total_hits += st.hits_count;
+        if (grc == SLIMM_E_NO_HITS) {
+            std::cerr << "[WARNING] No mapped reads found in BAM file!" << std::endl;
+            slimm_group_destroy(grp);
+            return true;
+        }
+        if (options.min_reads == 0) options.min_reads = st.min_reads;
+        if (options.verbose) {
+            std::cerr << "  " << st.hits_count << " records processed." << std::endl;
+            std::cerr << "    " << st.matches_count << " matching reads" << std::endl;
+            std::cerr << "    " << st.uniq_matches_count << " uniquily matching reads" << std::endl;
+            std::cerr << "  references with reads = " << st.reference_count << std::endl;
+            std::cerr << "  " << st.n_valid << " passed the threshould coverage.\n";
+            std::cerr << "  uniquily matching reads increased from " << st.uniq_matches_count << " to " << st.uniq_matches_count2 << "\n";
+            std::cerr << std::setw(4) << st.profile_count << std::setw(15) << (options.rank) << " (" << st.profile_failed
+                      << " bellow cutoff i.e. " << options.abundance_cut_off << ")\n";
+        }
+        std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
+        (void)slimm_get_cutoff_cache(c0, &S.cc_cache, &S.ucc_cache);
+        slimm_group_destroy(grp);
+        return true;
+    }
     slimm_ctx* ctx = nullptr;
     if (slimm_create(&cfg, &ctx) != SLIMM_OK) {
         std::cerr << "slimm: " << slimm_last_error(nullptr) << "\n";

@@ -164,3 +164,23 @@ def test_cli_two_names_with_one_hash_are_two_reads(tmp_path):
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
     check_outputs(out, "sample", o)
     assert f"{o.scalars['matches']} matching reads" in err
+
+
+def test_cli_devices_runs_a_group(tmp_path):
+    """--devices 0,0,0: three contexts in one process behind slimm_group_* (on the one GPU of the test box the collectives
+    run in their copy form); the profile must be the single-device one."""
+    w = with_names(make_workload(CONFIGS["config1"], seed=44))
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "sample.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    outs = []
+    for tag, extra in (("one", []), ("group", ["--devices", "0,0,0"])):
+        out = str(tmp_path / tag) + "/"
+        os.makedirs(out)
+        err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-v"] + extra + [db, inp])
+        outs.append(open(os.path.join(out, "sample_profile.tsv")).read())
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=False)
+    assert_profiles_match(outs[0], o.profile_tsv)
+    assert_profiles_match(outs[1], o.profile_tsv)
+    assert "3 devices (copy collectives)" in err and f"{o.scalars['matches']} matching reads" in err

@@ -34,6 +34,7 @@ enum {
     SLIMM_E_REF_RANGE = -3, /* a record names ref_id >= n_refs (undefined behaviour in the reference) */
     SLIMM_E_RUN_LENGTH = -4,/* (not returned any more: a read may have any number of alignment records; the value is
                                kept so that the codes after it do not move) */
+    SLIMM_E_KEY_COLLISION = -5, /* records with one read key carry different check words (slimm_push_records_checked) */
     SLIMM_E_RETRY = 2,      /* not an error: slimm_install_merged_partials asks for slimm_filter_alignments_launch again */
     SLIMM_E_NO_HITS = 1     /* not an error: no mapped record (reference prints a warning and writes nothing, src/slimm.hpp:451-455) */
 };
@@ -104,6 +105,14 @@ int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);
 /* Append a batch from host memory (copied to the device before return). */
 int slimm_push_records(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
                        const uint16_t* flag, uint64_t n);
+/* The same with a CHECK WORD per record: a second, independent hash of the read name (any 32 bits that equal names
+ * share).  The library never sees names; with check words it can tell when two different names were given one key:
+ * records with one key and different check words that meet -- next to each other in a GROUPED stream, after the device
+ * sort for ANY order -- make slimm_finish_coverage return SLIMM_E_KEY_COLLISION instead of silently becoming one read
+ * (the reference keys on the full name, src/slimm.hpp:204-211).  4 more bytes per record on the way in (and through
+ * the sort).  Checked and unchecked pushes do not mix within a file. */
+int slimm_push_records_checked(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
+                               const uint16_t* flag, const uint32_t* check, uint64_t n);
 /* Streamed ingest.  slimm_push_records_async enqueues the copies on the context's copy stream and returns at once:
  * the arrays must stay unchanged until slimm_push_wait() returns (page-locked arrays are read by the DMA engine
  * directly; pageable ones still work, at the speed of the runtime's own staging).  slimm_analyze_alignments() is

@@ -17,6 +17,7 @@ E_INVALID = -1
 E_HIP = -2
 E_REF_RANGE = -3
 E_RUN_LENGTH = -4
+E_KEY_COLLISION = -5
 E_RETRY = 2
 E_NO_HITS = 1
 
@@ -88,6 +89,7 @@ SYMBOLS = [
     ("slimm_filter_alignments_launch", C.c_int, [_P]),
     ("slimm_get_stream", C.c_int, [_P, C.POINTER(_P)]),
     ("slimm_set_stream_ordered", C.c_int, [_P, C.c_int]),
+    ("slimm_push_records_checked", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_push_records_async", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_push_wait", C.c_int, [_P]),
     ("slimm_staging_buffers", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),

@@ -124,12 +124,14 @@ struct slimm_ctx {
     DevBuf<uint64_t> in_key;
     DevBuf<int32_t> in_ref, in_pos;
     DevBuf<uint16_t> in_flag;
+    DevBuf<uint32_t> in_check;     // slimm_push_records_checked: a second hash of every record's read name
+    bool has_check = false;        // ... all pushed batches carry one (checked and unchecked pushes do not mix)
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
     uint64_t n_pushed = 0;
     // work arrays
     DevBuf<uint64_t> c_ident, s_ident;
-    DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist;
+    DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist, c_chk, s_chk;
     DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
     DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
     DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
@@ -312,6 +314,10 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
         HIP_TRY(c, c->s_ref.ensure(n + 1));
         HIP_TRY(c, c->s_gbin.ensure(n + 1));
         HIP_TRY(c, c->sort_hist.ensure(256ull * nt));
+        if (c->rec.check) {
+            HIP_TRY(c, c->c_chk.ensure(n + 1));
+            HIP_TRY(c, c->s_chk.ensure(n + 1));
+        }
     }
     return SLIMM_OK;
 }
@@ -327,6 +333,8 @@ int ensure_pair_table(slimm_ctx* c, uint32_t cap) {
 
 int check_device_errors(slimm_ctx* c, uint32_t err) {
     if (err & ERR_REF_RANGE) return fail(c, SLIMM_E_REF_RANGE, "a record names a reference id >= n_refs");
+    if (err & ERR_KEY_COLLISION)
+        return fail(c, SLIMM_E_KEY_COLLISION, "two records with one read key carry different check words: two read names collide in the key");
     return SLIMM_OK;
 }
 
@@ -540,6 +548,7 @@ int slimm_reset(slimm_ctx* c) {
     c->host->reset();
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;
+    c->has_check = false;
     c->borrowed = false;
     c->rec = DeviceRecords();
     c->local_V = c->local_M = c->local_P = 0;
@@ -583,6 +592,10 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
     HIP_TRY(c, r.ensure(cap));
     HIP_TRY(c, p.ensure(cap));
     HIP_TRY(c, f.ensure(cap));
+    DevBuf<uint32_t> ck;
+    if (c->has_check || c->n_pushed == 0) HIP_TRY(c, ck.ensure(cap));
+    if (c->n_pushed && c->has_check)
+        HIP_TRY(c, hipMemcpyAsync(ck.p, c->in_check.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
     if (c->n_pushed) {
         HIP_TRY(c, hipMemcpyAsync(k.p, c->in_key.p, c->n_pushed * 8, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(r.p, c->in_ref.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -598,6 +611,8 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
     std::swap(c->in_pos.cap, p.cap);
     std::swap(c->in_flag.p, f.p);
     std::swap(c->in_flag.cap, f.cap);
+    std::swap(c->in_check.p, ck.p);
+    std::swap(c->in_check.cap, ck.cap);
     return SLIMM_OK;
 }
 
@@ -607,6 +622,7 @@ int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     if (n == 0) return SLIMM_OK;
     if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     const uint64_t o = c->n_pushed;
@@ -624,6 +640,38 @@ int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     return SLIMM_OK;
 }
 
+// slimm_push_records with a check word per record: a second, independent hash of the read name.  The library compares
+// keys, never names; with check words it can at least SEE when two different names share a key -- records with one key
+// and two check words next to each other (grouped input) or after the sort (any order) make the run fail with
+// SLIMM_E_KEY_COLLISION instead of silently becoming one read.
+int slimm_push_records_checked(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
+                               const uint32_t* check, uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!key || !ref || !pos || !flag || !check) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->n_pushed && !c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried no check words");
+    c->has_check = true;
+    int rc = slimm_reserve(c, c->n_pushed + n);
+    if (rc != SLIMM_OK) return rc;
+    HIP_TRY(c, c->in_check.ensure(c->in_key.cap));
+    const uint64_t o = c->n_pushed;
+    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_flag.p + o, flag, n * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_check.p + o, check, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_pushed += n;
+    c->rec.key = c->in_key.p;
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.flag = c->in_flag.p;
+    c->rec.check = c->in_check.p;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    return SLIMM_OK;
+}
+
 // Streamed ingest: the copies go to a stream of their own and the call returns at once; phase A is ordered behind them
 // by an event on the device, never by the host.  With page-locked arrays (the staging sets below, or the caller's own)
 // the DMA engine reads them directly while the host decodes the next batch and the compute stream works on the file
@@ -634,6 +682,7 @@ int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* r
     if (n == 0) return SLIMM_OK;
     if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     const uint64_t o = c->n_pushed;
@@ -775,17 +824,18 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         {
             KernelTimer t(c, K_COMPACT);
             launch_compact(st, c->rec, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width,
-                           c->c_ident.p, c->c_ref.p, c->c_gbin.p);
+                           c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->c_chk.p);
         }
         {
             KernelTimer t(c, K_SORT);
             launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
-                                 c->s_gbin.p, c->sort_hist.p);
+                                 c->s_gbin.p, c->sort_hist.p, c->rec.check ? c->c_chk.p : nullptr,
+                                 c->rec.check ? c->s_chk.p : nullptr);
         }
         {
             KernelTimer t(c, K_FRONT);
             launch_front_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                                c->slots.p, c->wcut.p);
+                                c->slots.p, c->wcut.p, c->rec.check ? c->c_chk.p : nullptr);
         }
     } else {
         // grouped input: one pass straight over the caller's record arrays

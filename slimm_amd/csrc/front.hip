@@ -123,6 +123,7 @@ struct FrontRaw {
     const int32_t* ref;
     const int32_t* pos;
     const uint16_t* flag;
+    const uint32_t* check;  // optional: a second hash of the read name (null: none)
     const uint2* geo;  // {contig length, first bin} per reference
     uint32_t n, n_refs, half_read, bin_width, bw_magic;
     static constexpr bool kCountsMapped = true;   // hits_count (src/slimm.hpp:212) is counted here
@@ -151,6 +152,7 @@ struct FrontRaw {
         hi = k.y;
     }
     __device__ static void key_fix(uint32_t&, uint32_t& hi) { hi &= 0x3fffffffu; }  // qName identity: 62 bits
+    __device__ uint32_t load_check(uint32_t base, uint32_t rel) const { return f_load_at(check + base, rel * 4u); }
     __device__ static void no_key(uint32_t& lo, uint32_t& hi) {  // differs from every key (bit 62 is not significant)
         lo = 0u;
         hi = 0x40000000u;
@@ -200,6 +202,7 @@ struct FrontSorted {
     const uint64_t* ident;  // key << 2 | mate
     const uint32_t* cref;
     const uint32_t* cgbin;
+    const uint32_t* check;  // optional, sorted along with the records
     static constexpr bool kCountsMapped = false;  // the compaction counted the mapped records
     __device__ uint32_t count(const uint32_t* counters) const { return counters[CNT_V]; }
     __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
@@ -228,6 +231,7 @@ struct FrontSorted {
         hi = k.y;
     }
     __device__ static void key_fix(uint32_t& lo, uint32_t&) { lo &= ~3u; }  // (the mate number rides in the low bits)
+    __device__ uint32_t load_check(uint32_t base, uint32_t rel) const { return f_load_at(check + base, rel * 4u); }
     __device__ static void no_key(uint32_t& lo, uint32_t& hi) {  // (the low two bits of every key's low word are clear)
         lo = 1u;
         hi = 0u;
@@ -352,9 +356,10 @@ __device__ __forceinline__ void window_general(const Staged& rec, uint32_t lane,
 // with the chunk's earlier lanes (shift) and with every earlier chunk of the run (64 rotations each).  Returns the index
 // of the record behind the run.
 // ---------------------------------------------------------------------------------------------------------
-template <typename Acc>
+template <bool kChk, typename Acc>
 __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, WinOut& so,
-                                          uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad) {
+                                          uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad,
+                                          bool& collide) {
     // 1. where the run ends, whether its mates ever decrease
     uint32_t klo0, khi0;
     acc.key_at(pos, klo0, khi0);
@@ -369,6 +374,7 @@ __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint3
         acc.key_at(live ? i : N - 1u, klo, khi);
         const FrontRec r = acc.rec(live ? i : N - 1u, b);
         const uint64_t same = f_ballot(live && klo == klo0 && khi == khi0);
+        if (kChk) collide = collide | (live && klo == klo0 && khi == khi0 && acc.check[i] != acc.check[pos]);
         const uint32_t n_same = static_cast<uint32_t>(__builtin_ctzll(~same | (1ull << 63)));  // lanes before the first other key
         const bool whole = (~same) == 0ull;
         const uint32_t n_in = whole ? 64u : n_same;
@@ -466,23 +472,27 @@ __device__ __forceinline__ uint32_t next_run_start(const uint32_t* st1, uint32_t
 //   st1: reference + 1 (kRefField: not mapped) | mate << 26 | run start << 31,  st2: global bin.
 // kClamp: the stream ends inside the stretch (its last slots only): lanes behind the end load the last record again and
 // stage "not mapped, no run start".
-template <bool kClamp, typename Acc>
+// kChk: the records carry check words (a second hash of the read name): two adjacent records with one key and two
+// check words are two names that collide in the key -> `collide`.
+template <bool kClamp, bool kChk, typename Acc>
 __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t N, uint32_t lane, uint32_t* st1, uint32_t* st2,
-                                           bool& bad) {
+                                           bool& bad, bool& collide) {
     // The key in front of every record: the lane before's (DPP), for lane 0 the last key of the block before -- and for
     // the stretch's first block a second load of the keys, one record down, issued with the others.  (The key of record
     // B - 1 alone, loaded up front, would be a round trip of its own per slot.)
-    uint32_t plo = 0, phi = 0, q0lo, q0hi;
+    uint32_t plo = 0, phi = 0, q0lo, q0hi, q0chk = 0, pchk = 0;
     {
         const uint32_t pb = B > 0u ? B - 1u : 0u;                        // B == 0: lane 0 is given no_key below,
         uint32_t rel = (B == 0u && lane != 0u) ? lane - 1u : lane;       // lane i gets key[i - 1]
         if (kClamp) rel = min(rel, N - 1u - pb);
         acc.load_key(pb, rel, q0lo, q0hi);
+        if (kChk) q0chk = acc.load_check(pb, rel);
     }
 #pragma unroll
     for (uint32_t j0 = 0; j0 < kSlotBlocks; j0 += kStageGroup) {
         FrontLoaded rec[kStageGroup];
         uint2 geo[kStageGroup];
+        uint32_t chk[kStageGroup];
 #pragma unroll
         for (uint32_t u = 0; u < kStageGroup; ++u) {
             if (j0 + u >= kSlotBlocks) break;
@@ -490,6 +500,7 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
             // serve every block of every slot)
             const uint32_t blk = kClamp ? min(B + 64u * (j0 + u), N - 1u) : B + 64u * (j0 + u);
             acc.load(blk, kClamp ? min(lane, N - 1u - blk) : lane, rec[u]);
+            chk[u] = kChk ? acc.load_check(blk, kClamp ? min(lane, N - 1u - blk) : lane) : 0u;
         }
         __builtin_amdgcn_sched_barrier(0);  // (all the group's loads before the first use of one: left to itself the
                                             // scheduler pairs every load with its use, a round trip each)
@@ -508,17 +519,28 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
             Acc::key_fix(rec[u].klo, rec[u].khi);
             const uint32_t g = acc.gbin_of(rec[u], geo[u]);
             const uint64_t k = (static_cast<uint64_t>(rec[u].khi) << 32) | rec[u].klo;
-            uint32_t qlo, qhi;
+            uint32_t qlo, qhi, qchk;
             if (j == 0u) {
                 qlo = q0lo;
                 qhi = q0hi;
+                qchk = q0chk;
                 Acc::key_fix(qlo, qhi);
                 if (B == 0u && lane == 0u) Acc::no_key(qlo, qhi);  // the first record of the stream starts a run
             } else {
                 qlo = f_shr1(rec[u].klo, plo);
                 qhi = f_shr1(rec[u].khi, phi);
+                qchk = kChk ? f_shr1(chk[u], pchk) : 0u;
             }
             const uint64_t q = (static_cast<uint64_t>(qhi) << 32) | qlo;
+            if (kChk) {
+                // (no short-circuit operators on per-lane state here: the host emulator of tests/native identifies a wave
+                // collective by its call site, and a compiler that clones the code behind `collide ||` gives the lanes
+                // of one wave two sites for the same collective)
+                bool here = (k == q) & (chk[u] != qchk);
+                if (kClamp) here = here & (64u * j + lane < N - B);
+                collide = collide | here;
+                pchk = static_cast<uint32_t>(__builtin_amdgcn_readlane(chk[u], 63));
+            }
             uint32_t w = field | (mate << kStMateShift) | (k != q ? kStRunStart : 0u);
             if (kClamp && 64u * j + lane >= N - B) w = kRefField;
             st1[64u * j + lane] = w;
@@ -534,7 +556,7 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
 // ---------------------------------------------------------------------------------------------------------
 // k_front
 // ---------------------------------------------------------------------------------------------------------
-template <typename Acc>
+template <typename Acc, bool kChk>
 __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
                                                        uint4* __restrict__ slots, uint2* __restrict__ wcut) {
@@ -545,7 +567,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
     const uint32_t n_waves = gridDim.x * (kFrontBlock / 64);
     uint32_t* const st1 = s_stage[wave][0];
     uint32_t* const st2 = s_stage[wave][1];
-    bool bad = false;
+    bool bad = false, collide = false;
     for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint32_t B = slot * kSlotRecs;
         uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
@@ -555,16 +577,16 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
         if (B < N) {
             // ---- 1. stage (the only part that waits for memory; everything a group loads is in flight at once)
             if (N - B >= kStageRecs)
-                stage_slot<false>(acc, B, N, lane, st1, st2, bad);
+                stage_slot<false, kChk>(acc, B, N, lane, st1, st2, bad, collide);
             else
-                stage_slot<true>(acc, B, N, lane, st1, st2, bad);
+                stage_slot<true, kChk>(acc, B, N, lane, st1, st2, bad, collide);
             // ---- 2 + 3. windows: cut at the staged run starts, classified from the staged words.  (Every load has
             // landed by now; said aloud, so that the compiler does not make each window wait for the stores of the
             // window before it on behalf of a register some load of the staging loop once wrote.)
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
             uint32_t off = next_run_start(st1, lane, 0u);
             so.base = B + min(off, kSlotRecs);
-            while (off < kSlotRecs) {
+            while (off < kSlotRecs && B + off < N) {  // (the stream may end inside the slot)
                 if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
                     cut_f = lane == nw ? so.nf : cut_f;  // records; beyond that the list's last window simply takes the
                     cut_h = lane == nw ? so.nh : cut_h;  // rest of the slot).  Lane i keeps window i's entry: one store of
@@ -591,7 +613,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                         window_general(Staged{mate, field - 1u, w2, f_bit(V)}, lane, RS, V, X, so, tgt_ref, tgt_gbin);
                     off += X;
                 } else {  // a run of 64 records or more: from global memory, at its own pace
-                    const uint32_t end = long_run(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad);
+                    const uint32_t end = long_run<kChk>(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad, collide);
                     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
                     off = end - B < kStageRecs ? next_run_start(st1, lane, end - B) : kStageRecs;
                 }
@@ -612,6 +634,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
     // (No totals here: thousands of waves adding to the same three counters are as many memory-side atomics in a row,
     // ~40 ns each -- 0.3 ms at the end of a 0.1 ms kernel.  The first consumer of the slots sums their counts.)
     if (__any(bad) && lane == 0u) atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_REF_RANGE));
+    if (kChk && __any(collide) && lane == 0u) atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_KEY_COLLISION));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -637,23 +660,33 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.ref = in.ref;
     a.pos = in.pos;
     a.flag = in.flag;
+    a.check = in.check;
     a.geo = geo;
     a.n = in.n;
     a.n_refs = n_refs;
     a.half_read = half_read;
     a.bin_width = bin_width;
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
-    hipLaunchKernelGGL(k_front<FrontRaw>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref, tgt_gbin,
-                       slots, wcut);
+    if (in.check)
+        hipLaunchKernelGGL((k_front<FrontRaw, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
+                           tgt_gbin, slots, wcut);
+    else
+        hipLaunchKernelGGL((k_front<FrontRaw, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
+                           tgt_gbin, slots, wcut);
 }
 
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut) {
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
+                         const uint32_t* cchk) {
     const uint32_t ns = front_slots(n_upper);
     if (!ns) return;
-    FrontSorted a{ident, cref, cgbin};
-    hipLaunchKernelGGL(k_front<FrontSorted>, dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                       tgt_gbin, slots, wcut);
+    FrontSorted a{ident, cref, cgbin, cchk};
+    if (cchk)
+        hipLaunchKernelGGL((k_front<FrontSorted, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
+                           tgt_gbin, slots, wcut);
+    else
+        hipLaunchKernelGGL((k_front<FrontSorted, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters,
+                           tgt_ref, tgt_gbin, slots, wcut);
 }
 
 }  // namespace slimm

@@ -112,6 +112,16 @@ uint64_t hash_read_name(const char* s, size_t n) {
     return h >> 2;
 }
 
+// A second, independent hash of a read name (FNV-1a folded to 32 bits): the check word of slimm_push_records_checked.
+uint32_t check_read_name(const char* s, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= static_cast<unsigned char>(s[i]);
+        h *= 0x100000001b3ull;
+    }
+    return static_cast<uint32_t>(h ^ (h >> 32));
+}
+
 AlignmentFile::AlignmentFile() = default;
 
 namespace {
@@ -673,15 +683,17 @@ void AlignmentFile::separate_adjacent_names(uint64_t* key, const std::vector<siz
 
 // The four record fields of the hot path straight into the caller's arrays (the page-locked staging sets of
 // slimm_staging_buffers: the DMA engine reads what the decode threads wrote, no copy in between).
-long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records) {
+long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records,
+                              uint32_t* check) {
     if (!bam_) {  // SAM text: through a batch (parsing dominates by far)
         RecordBatch b;
-        const long n = read_batch(b, max_records);
+        const long n = read_batch(b, max_records, check != nullptr);
         for (long i = 0; i < n; ++i) {
             read_key[i] = b.read_key[i];
             ref_id[i] = b.ref_id[i];
             begin_pos[i] = b.begin_pos[i];
             flag[i] = b.flag[i];
+            if (check) check[i] = check_read_name(b.qname[i].data(), b.qname[i].size());
         }
         return n;
     }
@@ -694,6 +706,7 @@ long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begi
             const uint8_t* r = &buf_[offs[k] + 4];
             const uint8_t l_read_name = r[8];
             read_key[k] = hash_read_name(reinterpret_cast<const char*>(r + 32), l_read_name ? l_read_name - 1u : 0u);
+            if (check) check[k] = check_read_name(reinterpret_cast<const char*>(r + 32), l_read_name ? l_read_name - 1u : 0u);
             ref_id[k] = static_cast<int32_t>(rd_u32(r));
             begin_pos[k] = static_cast<int32_t>(rd_u32(r + 4));
             flag[k] = rd_u16(r + 14);

@@ -42,6 +42,7 @@ enum class SortOrder { Unknown, Unsorted, QueryName, Coordinate, QueryGrouped };
 // differs from its predecessor's never gets the predecessor's key (separate_adjacent_names).  Names colliding far
 // apart in a file that is NOT grouped by name remain possible (~0.04 % odds of any such pair among 125 M reads).
 uint64_t hash_read_name(const char* s, size_t n);
+uint32_t check_read_name(const char* s, size_t n);
 
 class AlignmentFile {
 public:
@@ -63,7 +64,9 @@ public:
     // Appends up to max_records records to `out`; returns the number appended (0 at end of file), -1 on a format error.
     long read_batch(RecordBatch& out, size_t max_records, bool keep_names = false);
     // The same for the four fields of the hot path, written straight into the caller's arrays (room for max_records).
-    long read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records);
+    // check != nullptr: also a second, independent hash of every record's name (slimm_push_records_checked)
+    long read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records,
+                   uint32_t* check = nullptr);
 
 private:
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)

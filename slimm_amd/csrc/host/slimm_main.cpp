@@ -88,6 +88,9 @@ SLIMM_FORWARD(int, slimm_get_cutoff_cache, (slimm_ctx* a, float* b, float* c), (
 SLIMM_FORWARD(int, slimm_set_cutoff_cache, (slimm_ctx* a, float b, float c), (a, b, c))
 SLIMM_FORWARD(int, slimm_push_records,
               (slimm_ctx* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, uint64_t f_), (a, b, c, d, e, f_))
+SLIMM_FORWARD(int, slimm_push_records_checked,
+              (slimm_ctx* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, const uint32_t* f_, uint64_t g),
+              (a, b, c, d, e, f_, g))
 SLIMM_FORWARD(int, slimm_staging_buffers,
               (slimm_ctx* a, uint32_t b, uint64_t c, uint64_t** d, int32_t** e, int32_t** f_, uint16_t** g), (a, b, c, d, e, f_, g))
 SLIMM_FORWARD(int, slimm_push_staged_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
@@ -364,9 +367,13 @@ struct RecordPump {
         std::unique_ptr<uint64_t[]> key{new uint64_t[kBatch]};
         std::unique_ptr<int32_t[]> ref{new int32_t[kBatch]}, pos{new int32_t[kBatch]};
         std::unique_ptr<uint16_t[]> flag{new uint16_t[kBatch]};
+        std::unique_ptr<uint32_t[]> check;  // only for streams in no particular order (want_check)
         uint64_t n = 0;
     };
     AlignmentFile& bam;
+    // want_check: the stream is in no particular order, so two read names with one key would meet after the device sort
+    // unnoticed -- every record then carries a second hash of its name (slimm_push_records_checked; no staging sets)
+    const bool want_check;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Batch> queued;
@@ -377,7 +384,7 @@ struct RecordPump {
     double decode_ms = 0, wait_ms = 0;
     std::thread th;
 
-    explicit RecordPump(AlignmentFile& f) : bam(f), th([this] { run(); }) {}
+    RecordPump(AlignmentFile& f, bool check_words) : bam(f), want_check(check_words), th([this] { run(); }) {}
     ~RecordPump() {
         if (th.joinable()) {
             {
@@ -387,6 +394,10 @@ struct RecordPump {
             cv.notify_all();
             th.join();
         }
+    }
+    static int push(slimm_ctx* c, const Batch& b) {
+        return b.check ? slimm_push_records_checked(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n)
+                       : slimm_push_records(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n);
     }
     static double ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -398,7 +409,7 @@ struct RecordPump {
             {
                 std::lock_guard<std::mutex> g(mu);
                 if (failed) return;
-                c = group ? nullptr : ctx;
+                c = (group || want_check) ? nullptr : ctx;
             }
             if (c) {  // straight into a staging set
                 uint64_t* key;
@@ -420,8 +431,9 @@ struct RecordPump {
                 continue;
             }
             Batch b;
+            if (want_check) b.check.reset(new uint32_t[kBatch]);
             auto t1 = std::chrono::steady_clock::now();
-            const long n = bam.read_into(b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), kBatch);
+            const long n = bam.read_into(b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), kBatch, b.check.get());
             decode_ms += ms(t1, std::chrono::steady_clock::now());
             if (n <= 0) {
                 read_rc = n;
@@ -434,7 +446,7 @@ struct RecordPump {
             if (group) {
                 if (slimm_group_push_records(group, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) break;
             } else if (ctx) {  // attached meanwhile: everything queued before has been pushed, this batch follows
-                if (slimm_push_records(ctx, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) break;
+                if (push(ctx, b) < 0) break;
             } else {
                 queued.push_back(std::move(b));
             }
@@ -446,7 +458,7 @@ struct RecordPump {
     bool attach(slimm_ctx* c) {
         std::unique_lock<std::mutex> g(mu);
         for (Batch& b : queued)
-            if (slimm_push_records(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) {
+            if (push(c, b) < 0) {
                 failed = true;
                 cv.notify_all();
                 return false;
@@ -514,7 +526,16 @@ bool get_profiles(Session& S, size_t file_index) {
     trace.mark("open + read-length sample");
     bam.close();
     if (!bam.open(path)) return true;
-    RecordPump pump(bam);  // decoding starts now; the records are claimed further down, when the context exists
+    // only a header that promises name grouping is trusted; anything else is sorted on the device
+    const int record_order = options.order >= 0
+                                 ? options.order
+                                 : ((bam.sort_order() == SortOrder::QueryName || bam.sort_order() == SortOrder::QueryGrouped)
+                                        ? SLIMM_ORDER_GROUPED
+                                        : SLIMM_ORDER_ANY);
+    // (grouped streams are exact already: the reader compares the names of adjacent records; one device only -- the group
+    // of --devices deals records by key and has no checked push)
+    const bool check_words = record_order == SLIMM_ORDER_ANY && options.devices.size() <= 1;
+    RecordPump pump(bam, check_words);  // decoding starts now; the records are claimed further down, when the context exists
 
     std::cerr << "Intializing coverages for all reference genome ... ";
     const uint32_t R = static_cast<uint32_t>(bam.ref_names().size());
@@ -554,12 +575,7 @@ bool get_profiles(Session& S, size_t file_index) {
     cfg.tax_rank = tax_rank.data();
     cfg.tax_name = tax_name.data();
     cfg.device = options.device;
-    if (options.order >= 0)
-        cfg.record_order = options.order;
-    else  // only a header that promises name grouping is trusted; anything else is sorted on the device
-        cfg.record_order = (bam.sort_order() == SortOrder::QueryName || bam.sort_order() == SortOrder::QueryGrouped)
-                               ? SLIMM_ORDER_GROUPED
-                               : SLIMM_ORDER_ANY;
+    cfg.record_order = record_order;
     if (options.devices.size() > 1) {
         // ---- several GPUs, one process: the group deals the records to its members by read and runs the phases with the
         // two RCCL exchanges in between (slimm_amd/csrc/group.hip); the profile comes from member 0

@@ -28,7 +28,7 @@ enum {
     CNT_SPLIT = 9,  // bin tiles cut into several k_tile_hist work items (their non-zero counts are finished by k_pack)
     CNT_WORDS = 32
 };
-enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4 };
+enum { ERR_REF_RANGE = 1, ERR_RUN_LENGTH = 2, ERR_PAIR_OVERFLOW = 4, ERR_KEY_COLLISION = 8 };
 
 #if defined(__HIPCC__)
 // Sum over the 64 lanes of a wave with DPP adds (no LDS round trips as with ds_bpermute shuffles); every lane gets it.
@@ -86,6 +86,7 @@ struct DeviceRecords {
     const int32_t* ref = nullptr;
     const int32_t* pos = nullptr;
     const uint16_t* flag = nullptr;
+    const uint32_t* check = nullptr;  // optional second hash of the read name: equal keys must carry equal checks
     uint32_t n = 0;
 };
 
@@ -108,7 +109,8 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
                       uint2* wcut);
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut);
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
+                         const uint32_t* cchk = nullptr);  // cchk: check words (equal keys must carry equal ones)
 
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
@@ -117,7 +119,7 @@ void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_
                        uint4* sums = nullptr);
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
-                    uint32_t* cgbin);
+                    uint32_t* cgbin, uint32_t* cchk = nullptr);  // cchk: the check words of in.check, when it has any
 // the direct-atomics fallback of the coverage histograms (too many bins for the LDS tile tables)
 // (also adds the stream's totals to counters[CNT_M / CNT_P] -- and [CNT_V] when count_mapped: the compaction of the
 // sort path has counted the mapped records already -- and to tail[0..2]; all zero on entry)
@@ -248,6 +250,7 @@ void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and
 // n_upper bounds it for the launch geometry.  hist must hold 256 * (num_tiles(n_upper) + 1) uint32.
 void launch_sort_by_ident(hipStream_t st, uint32_t n_upper, const uint32_t* counters, uint64_t* ident, uint32_t* cref,
-                          uint32_t* cgbin, uint64_t* ident_tmp, uint32_t* cref_tmp, uint32_t* cgbin_tmp, uint32_t* hist);
+                          uint32_t* cgbin, uint64_t* ident_tmp, uint32_t* cref_tmp, uint32_t* cgbin_tmp, uint32_t* hist,
+                          uint32_t* cchk = nullptr, uint32_t* cchk_tmp = nullptr);  // an optional third payload word
 
 }  // namespace slimm

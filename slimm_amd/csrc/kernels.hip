@@ -264,7 +264,8 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
                                                     const uint32_t* __restrict__ ref_len,
                                                     const uint32_t* __restrict__ bin_off, uint32_t half_read,
                                                     uint32_t bin_width, uint64_t* __restrict__ ident,
-                                                    uint32_t* __restrict__ cref, uint32_t* __restrict__ cgbin) {
+                                                    uint32_t* __restrict__ cref, uint32_t* __restrict__ cgbin,
+                                                    const uint32_t* __restrict__ chk, uint32_t* __restrict__ cchk) {
     __shared__ uint32_t s_w[2][kWaves];
     const uint32_t base = blockIdx.x * kTile;
     const uint32_t wave = threadIdx.x >> 6;
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__
             uint32_t center = min(static_cast<uint32_t>(pos[i]) + half_read, ref_len[r]);
             cref[o] = static_cast<uint32_t>(r);
             cgbin[o] = bin_off[r] + center / bin_width;
+            if (cchk) cchk[o] = chk[i];  // (the caller's second hash of the read name travels with the record)
         }
         running += total;
     }
@@ -912,11 +914,11 @@ void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_
 
 void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
                     const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
-                    uint32_t* cgbin) {
+                    uint32_t* cgbin, uint32_t* cchk) {
     uint32_t nt = tiles_for(in.n);
     if (nt)
         hipLaunchKernelGGL(k_compact, dim3(nt), dim3(kBlock), 0, st, in.key, in.ref, in.pos, in.flag, in.n, n_refs, tile_off,
-                           ref_len, bin_off, half_read, bin_width, ident, cref, cgbin);
+                           ref_len, bin_off, half_read, bin_width, ident, cref, cgbin, in.check, in.check ? cchk : nullptr);
 }
 
 void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, uint32_t* counters,

@@ -88,16 +88,20 @@ __global__ __launch_bounds__(1024) void k_rs_rowscan(uint32_t* __restrict__ hist
     if (tid == 0) totals[blockIdx.x] = carry;
 }
 
+// kChk: a third payload word travels along (the check word of slimm_push_records_checked)
+template <bool kChk>
 __global__ __launch_bounds__(kSBlock) void k_rs_scatter(const uint64_t* __restrict__ ident_in,
                                                         const uint32_t* __restrict__ ref_in,
                                                         const uint32_t* __restrict__ gbin_in,
+                                                        const uint32_t* __restrict__ chk_in,
                                                         const uint32_t* __restrict__ counters, uint32_t shift,
                                                         uint32_t ntiles, const uint32_t* __restrict__ hist,
                                                         const uint32_t* __restrict__ totals,
                                                         uint64_t* __restrict__ ident_out, uint32_t* __restrict__ ref_out,
-                                                        uint32_t* __restrict__ gbin_out) {
+                                                        uint32_t* __restrict__ gbin_out, uint32_t* __restrict__ chk_out) {
     __shared__ uint64_t s_key[kSTile];           // records reordered by digit
     __shared__ uint2 s_pay[kSTile];
+    __shared__ uint32_t s_chk[kChk ? kSTile : 1];
     __shared__ uint32_t s_goff[256];             // global position of this tile's first record of each digit
     __shared__ uint32_t s_lstart[256];           // local position of the digit's first record / running cursor
     __shared__ uint32_t s_cnt[256];              // records of each digit in this tile
@@ -112,12 +116,14 @@ __global__ __launch_bounds__(kSBlock) void k_rs_scatter(const uint64_t* __restri
     // all loads of the tile first
     uint64_t k[kSItems];
     uint2 pay[kSItems];
+    uint32_t chk[kSItems];
 #pragma unroll
     for (int u = 0; u < kSItems; ++u) {
         const uint32_t i = base + u * kSBlock + tid;
         const bool live = i < V;
         k[u] = live ? ident_in[i] : 0ull;
         pay[u] = live ? make_uint2(ref_in[i], gbin_in[i]) : make_uint2(0u, 0u);
+        chk[u] = (kChk && live) ? chk_in[i] : 0u;
     }
     s_cnt[tid] = 0;
 #pragma unroll
@@ -182,6 +188,7 @@ __global__ __launch_bounds__(kSBlock) void k_rs_scatter(const uint64_t* __restri
                 if (w < static_cast<int>(wave)) o += s_wcnt[w][d];
             s_key[o] = k[u];
             s_pay[o] = pay[u];
+            if (kChk) s_chk[o] = chk[u];
         }
         __syncthreads();
         uint32_t add = 0;
@@ -202,11 +209,13 @@ __global__ __launch_bounds__(kSBlock) void k_rs_scatter(const uint64_t* __restri
         ident_out[dst] = key;
         ref_out[dst] = py.x;
         gbin_out[dst] = py.y;
+        if (kChk) chk_out[dst] = s_chk[p];
     }
 }
 
 void launch_sort_by_ident(hipStream_t st, uint32_t n_upper, const uint32_t* counters, uint64_t* ident, uint32_t* cref,
-                          uint32_t* cgbin, uint64_t* ident_tmp, uint32_t* cref_tmp, uint32_t* cgbin_tmp, uint32_t* hist) {
+                          uint32_t* cgbin, uint64_t* ident_tmp, uint32_t* cref_tmp, uint32_t* cgbin_tmp, uint32_t* hist,
+                          uint32_t* cchk, uint32_t* cchk_tmp) {
     const uint32_t nt = (n_upper + kSTile - 1) / kSTile;
     if (nt == 0) return;
     uint32_t* totals = hist + static_cast<size_t>(256) * nt;  // 256 words behind the matrix
@@ -216,15 +225,22 @@ void launch_sort_by_ident(hipStream_t st, uint32_t n_upper, const uint32_t* coun
     uint64_t* ko = ident_tmp;
     uint32_t* ro = cref_tmp;
     uint32_t* go = cgbin_tmp;
+    uint32_t* ci = cchk;
+    uint32_t* co = cchk_tmp;
     for (uint32_t pass = 0; pass < 8; ++pass) {
         const uint32_t shift = pass * 8;
         hipLaunchKernelGGL(k_rs_hist, dim3(nt), dim3(kSBlock), 0, st, ki, counters, shift, nt, hist);
         hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(1024), 0, st, hist, nt, totals);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nt), dim3(kSBlock), 0, st, ki, ri, gi, counters, shift, nt, hist, totals, ko, ro,
-                           go);
+        if (cchk)
+            hipLaunchKernelGGL(k_rs_scatter<true>, dim3(nt), dim3(kSBlock), 0, st, ki, ri, gi, ci, counters, shift, nt, hist,
+                               totals, ko, ro, go, co);
+        else
+            hipLaunchKernelGGL(k_rs_scatter<false>, dim3(nt), dim3(kSBlock), 0, st, ki, ri, gi, ci, counters, shift, nt, hist,
+                               totals, ko, ro, go, co);
         uint64_t* tk = ki; ki = ko; ko = tk;
         uint32_t* tr = ri; ri = ro; ro = tr;
         uint32_t* tg = gi; gi = go; go = tg;
+        uint32_t* tc = ci; ci = co; co = tc;
     }
     // 8 passes: the result is back in (ident, cref, cgbin)
 }

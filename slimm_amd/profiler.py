@@ -102,6 +102,16 @@ class Slimm:
             self._check(self.L.slimm_push_records(self.ctx, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
                                                   _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), e - s))
 
+    def push_records_checked(self, rec: Records, check: np.ndarray, batch: int = 0):
+        """slimm_push_records_checked: `check` = a second hash of every record's read name (uint32)."""
+        n = len(rec)
+        check = np.ascontiguousarray(check, dtype=np.uint32)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_push_records_checked(self.ctx, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
+                                                          _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), _p(check[s:e]), e - s))
+
     def staging(self, which: int, capacity: int):
         """The context's page-locked staging set `which` (0 / 1) as numpy arrays (key u64, ref i32, pos i32, flag u16)."""
         import numpy as np

@@ -184,3 +184,37 @@ def test_cli_devices_runs_a_group(tmp_path):
     assert_profiles_match(outs[0], o.profile_tsv)
     assert_profiles_match(outs[1], o.profile_tsv)
     assert "3 devices (copy collectives)" in err and f"{o.scalars['matches']} matching reads" in err
+
+
+def test_cli_unordered_file_with_two_names_under_one_key_fails_loudly(tmp_path):
+    """A file in no particular order (the device sort groups by key): two different read names with equal 62-bit hashes,
+    far apart in the file.  The reader gives every record a second hash of its name and the library refuses to merge
+    records with one key and two check words: the command ends with an error instead of a wrong profile."""
+    from tests.test_cli_readers import colliding_names
+
+    a, b = colliding_names()
+    w = with_names(make_workload(CONFIGS["config1"], seed=45, shuffled=True))
+    r = w.records
+    q = list(r.qname)
+    mapped = [i for i in range(len(q)) if r.ref_id[i] >= 0]
+    i, j = mapped[10], mapped[-10]
+    names_i, names_j = q[i], q[j]
+    q = [a if n == names_i else (b if n == names_j else n) for n in q]
+    w = Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, q), w.avg_read_len,
+                 w.options, w.name)
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "sample.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, hd="@HD\\tVN:1.6\\tSO:unsorted")
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    res = subprocess.run([CLI, "-w", str(w.options.bin_width), "-o", out, db, inp], capture_output=True, text=True)
+    assert res.returncode != 0
+    assert "collide" in res.stderr
+    assert not os.path.exists(os.path.join(out, "sample_profile.tsv"))
+    # the same file without the clash goes through (check words agree with the keys everywhere)
+    w2 = with_names(make_workload(CONFIGS["config1"], seed=45, shuffled=True))
+    write_bam(inp, w2.ref_names, w2.ref_len, w2.records, read_len=w2.avg_read_len, hd="@HD\\tVN:1.6\\tSO:unsorted")
+    run_cli(["-w", str(w2.options.bin_width), "-o", out, db, inp])
+    o = Oracle(w2.taxonomy, w2.options).run(w2.ref_names, w2.ref_len, w2.records, w2.avg_read_len, want_raw=False)
+    assert_profiles_match(open(os.path.join(out, "sample_profile.tsv")).read(), o.profile_tsv)

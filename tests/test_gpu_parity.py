@@ -700,3 +700,79 @@ def test_reset_with_copies_on_their_way():
     s.push_records_streamed(r, batch=3000)
     assert s.get_profiles() is not None
     assert_matches_oracle(s, o)
+
+
+# ---------------------------------------------------------------- check words (slimm_push_records_checked)
+def _check_words(w):
+    """A second hash of every record's name: here simply a mix of the key (equal names <=> equal keys in the synth)."""
+    k = w.records.read_key.astype(np.uint64)
+    return ((k * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_check_words_change_nothing_when_names_and_keys_agree(grouped):
+    w = make_workload(CONFIGS["config1"], seed=61, shuffled=not grouped)
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    s.push_records_checked(w.records, _check_words(w), batch=7000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+@pytest.mark.parametrize("where", ["inside a run", "run of 200 records", "first record of the stream", "last record"])
+def test_two_names_under_one_key_are_reported(grouped, where):
+    """Two different read names that were given one key: their records carry different check words.  Grouped input sees
+    them when they are adjacent, any other order after the device sort, however far apart they were in the file."""
+    w = make_workload(CONFIGS["config1"], seed=62, shuffled=not grouped)
+    r = w.records
+    chk = _check_words(w)
+    starts = np.nonzero(np.concatenate([[True], r.read_key[1:] != r.read_key[:-1]]))[0]
+    if where == "run of 200 records":
+        i = 3000
+        r.read_key[i:i + 200] = r.read_key[i]
+        r.flag[i:i + 200] &= np.uint16(0xffff & ~(0x4 | 0x40 | 0x80))
+        r.ref_id[i:i + 200] = np.abs(r.ref_id[i:i + 200])
+        chk[i:i + 200] = chk[i]
+        victim = i + 150
+    elif where == "first record of the stream":
+        r.read_key[1] = r.read_key[0]
+        chk[1] = chk[0]
+        victim = 1 if grouped else 0
+    elif where == "last record":
+        r.read_key[-1] = r.read_key[-2]
+        chk[-1] = chk[-2]
+        victim = len(r) - 1
+    elif grouped:
+        j = next(k for k in range(len(starts) - 1) if starts[k + 1] - starts[k] >= 3 and starts[k] > 5000)
+        victim = starts[j] + 1
+    else:
+        victim = 6000
+    if not grouped:   # far apart in the file: give the victim's key to a record elsewhere too (same key, other "name")
+        other = (victim + len(r) // 2) % len(r)
+        r.read_key[other] = r.read_key[victim]
+        chk[other] = chk[victim]
+    chk[victim] ^= np.uint32(0x5a5a5a5a)   # the record now belongs to "another name" with the same key
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    s.push_records_checked(r, chk, batch=9000)
+    with pytest.raises(capi.SlimmError) as e:
+        s.get_profiles()
+    assert e.value.code == capi.E_KEY_COLLISION
+    # the context is usable again after a reset
+    s.reset()
+    w2 = make_workload(CONFIGS["config1"], seed=61, shuffled=not grouped)
+    s.push_records_checked(w2.records, _check_words(w2))
+    assert s.get_profiles() is not None
+
+
+def test_checked_and_unchecked_pushes_do_not_mix():
+    w = make_workload(CONFIGS["config1"], seed=63, n_records=4000)
+    s = Slimm.for_workload(w, device=0)
+    half = w.records.take(np.arange(2000))
+    s.push_records(half)
+    with pytest.raises(capi.SlimmError):
+        s.push_records_checked(half, _check_words(w)[:2000])
+    s.reset()
+    s.push_records_checked(half, _check_words(w)[:2000])
+    with pytest.raises(capi.SlimmError):
+        s.push_records(half)

@@ -646,19 +646,19 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
     const uint64_t VB = valid_lanes & PR;               // valid_lanes = k_ballot(Rows::valid(row)), taken by the caller
     const uint64_t stops = (H >> 1) | (1ull << (X - 1u));
     const uint64_t FV = k_first_after(H, VB, stops);              // first valid target of every read
-    const uint64_t SV = k_first_after(H, VB & ~FV, stops);        // second one, where there is one
-    const uint64_t HF = k_head_of(FV, H);                         // reads with a valid target
-    const uint64_t HM = k_head_of(SV, H);                         // reads with several
-    const uint64_t single = FV & ~k_first_after(HM, FV, stops);   // the one valid target of the reads with one
-    const uint64_t empty = H & ~HF;                               // reads that lost every target
+    // Owners: the first valid target of the reads that keep several.  Every LATER valid target points at one: the
+    // nearest first-valid lane below a valid lane is its own read's (another read's would lie above it or below its
+    // head), so "the head at or below each bit" with FV as the heads finds them in one carry chain.
+    const uint64_t OW = k_head_of(VB & ~FV, FV);
+    const uint64_t single = FV & ~OW;                             // the one valid target of the reads with one
+    const uint64_t empty = H & ~k_head_of(FV, H);                 // reads that lost every target
     // index of this lane's read among the selectors
     const uint32_t ridx = sel_base + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
     if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
     if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
     Lookup lk{0u, ridx, false};
-    if (HM) {
+    if (OW) {
         const uint64_t le = (2ull << lane) - 1ull;  // the lanes up to and including this one
-        const uint64_t OW = FV & ~single;           // owners: the first valid lane of every read with several
         // the first valid lane of this lane's read (for the valid lanes): the highest bit of FV at or below it
         const uint32_t fvl = 63u - static_cast<uint32_t>(__builtin_clzll((FV & le) | 1ull));
         const typename Rows::Row first = Rows::from_lane(row, fvl << 2);
@@ -782,7 +782,8 @@ constexpr int kFilterBlock = 256;
 // with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
 // waits for and waits for all of them.)
 constexpr int kFilterBatch = 6;
-constexpr uint32_t kFilterSlots = 1;  // consecutive slots per wave (their windows: at most 64 together)
+constexpr uint32_t kFilterSlots = 1;  // consecutive slots per unit of work (their windows: at most 64 together)
+constexpr uint32_t kFilterSplit = 1;  // waves per unit (a power of two dividing the waves of a workgroup)
 static_assert(kFilterSlots * (kSlotWindows - 2u) <= 64u, "a wave keeps one window per lane");
 template <typename Rows>
 __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
@@ -792,8 +793,11 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
     const uint32_t lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFilterBlock / 64);
-    for (uint32_t first = (blockIdx.x * (kFilterBlock / 64) + wave) * kFilterSlots; first < nslots;
-         first += n_waves * kFilterSlots) {
+    // kFilterSplit waves share a unit of kFilterSlots slots: each takes an equal stretch of the unit's windows
+    for (uint32_t unit = (blockIdx.x * (kFilterBlock / 64) + wave) / kFilterSplit; unit * kFilterSlots < nslots;
+         unit += n_waves / kFilterSplit) {
+        const uint32_t first = unit * kFilterSlots;
+        const uint32_t part = (blockIdx.x * (kFilterBlock / 64) + wave) % kFilterSplit;
         // The windows of this wave's kFilterSlots consecutive slots, one per lane: where the window's targets start, how
         // many there are, where its reads' selectors start, the last target of its slot (loads are clamped to it).
         // (A slot's list is loaded whole -- entries behind its last window are never used -- so the number of windows
@@ -824,7 +828,9 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
             nw += n;
         }
         bool spans = false;  // some window holds more than 64 targets
-        for (uint32_t i0 = 0; i0 < nw; i0 += kFilterBatch) {
+        const uint32_t share = (nw + kFilterSplit - 1u) / kFilterSplit;
+        const uint32_t w_lo = min(part * share, nw), w_hi = min(w_lo + share, nw);
+        for (uint32_t i0 = w_lo; i0 < w_hi; i0 += kFilterBatch) {
             uint32_t w[kFilterBatch], g[kFilterBatch], cnt[kFilterBatch], selb[kFilterBatch];
             typename Rows::Row row[kFilterBatch];
 #pragma unroll
@@ -832,7 +838,7 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
                 const uint32_t i = (i0 + u) & 63u;  // (lanes behind the last window: windows of no targets)
                 const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
                 const uint32_t tl = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_last, i));
-                cnt[u] = i0 + u < nw ? static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i)) : 0u;
+                cnt[u] = i0 + u < w_hi ? static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i)) : 0u;
                 selb[u] = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i));
                 if (cnt[u] > 64u) {
                     spans = true;
@@ -872,7 +878,7 @@ __global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restr
                 if (lk[u].want) out.sel[lk[u].ridx] = out.taxon_base + taxon[u];
         }
         if (spans) {
-            for (uint32_t i = 0; i < nw; ++i) {
+            for (uint32_t i = w_lo; i < w_hi; ++i) {
                 const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
                 const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i));
                 if (c > 64u)
@@ -1032,8 +1038,9 @@ void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots,
 
 static uint32_t filter_grid(uint32_t nslots) {
     // kFilterSlots slots per wave, however many workgroups that makes (front.hip: front_grid)
-    const uint32_t per = (kFilterBlock / 64) * kFilterSlots;
-    return std::max(1u, (nslots + per - 1u) / per);
+    const uint32_t units = (nslots + kFilterSlots - 1u) / kFilterSlots;
+    const uint32_t per = (kFilterBlock / 64) / kFilterSplit;  // units per workgroup
+    return std::max(1u, (units + per - 1u) / per);
 }
 
 void launch_filter(hipStream_t st, const FilterArgs& a) {

@@ -331,7 +331,7 @@ bool AlignmentFile::fill(size_t need) {
         // the unread tail of the window moves in front of the new data
         const size_t tail = buf_.size() - pos_;
         if (tail <= kSlack) {
-            memcpy(spare_.data() + kSlack - tail, buf_.data() + pos_, tail);
+            if (tail) memcpy(spare_.data() + kSlack - tail, buf_.data() + pos_, tail);  // (buf_ is empty at the first window)
             buf_.swap(spare_);
             pos_ = kSlack - tail;
         } else {  // (a record longer than the slack)

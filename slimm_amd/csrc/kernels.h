@@ -169,7 +169,7 @@ void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t ran
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----
 constexpr uint32_t kTileShift = 13;
-constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 32 KiB of LDS in k_tile_hist
+constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 16 KiB of LDS in k_tile_hist (16-bit counts)
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
 int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
 // tile_count: `reps` copies of rep_stride words, zero on entry (k_zero); workgroup b adds to copy b % reps.

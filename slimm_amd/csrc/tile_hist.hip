@@ -40,6 +40,14 @@ __device__ unsigned long long g_prof_t[8 * 4096];  // [workgroup-wave][phase]
 #define TPROF_T(x)
 #define TPROF_ADD(slot, a, b)
 #endif
+#if defined(EXP) && EXP == 9  // cycle split of k_tile_hist: thread 0 of every workgroup (scripts/tprof_tiles.py)
+__device__ unsigned long long g_prof_t[8 * 4096];
+#define HPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define HPROF_ADD(slot, a, b) if (threadIdx.x == 0) g_prof_t[(blockIdx.x & 4095u) * 8 + slot] += (b) - (a)
+#else
+#define HPROF_T(x)
+#define HPROF_ADD(slot, a, b)
+#endif
 
 constexpr int kTBlock = 512;
 constexpr uint32_t kTileMask = kTileBins - 1;
@@ -387,12 +395,17 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
                                                       uint16_t* __restrict__ bucket, uint32_t* s_cnt, uint32_t* s_loff,
                                                       uint32_t* s_stage, uint32_t* s_wtot) {
     const uint32_t tid = threadIdx.x;
+    TPROF_T(p0);
     for (uint32_t i = tid; i < kTileSlots; i += kTBlock) s_cnt[i] = 0;
     __syncthreads();
+    TPROF_T(p1);
+    TPROF_ADD(1, p0, p1);
     uint32_t r[kRoundPieces];
 #pragma unroll
     for (int k = 0; k < kRoundPieces; ++k) r[k] = v[k] != 0xffffffffu ? atomicAdd(&s_cnt[tile_of(v[k])], 1u) : 0u;
     __syncthreads();
+    TPROF_T(p2);
+    TPROF_ADD(2, p1, p2);
     // this round's stretch of every touched tile's bucket: one returning atomic per tile, all of a thread's issued
     // before the scan so that they are back when it is done
     uint32_t got[kTileSlots / kTBlock];
@@ -404,12 +417,16 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
         got[j] = (h && i < ntiles) ? atomicAdd(&tile_cursor[i], h) + s_mine[i] : 0u;
     }
     __syncthreads();
+    TPROF_T(p3);
+    TPROF_ADD(3, p2, p3);
     const uint32_t total = block_excl_scan_4096(s_loff, s_wtot);
 #pragma unroll
     for (uint32_t j = 0; j < kTileSlots / kTBlock; ++j) {
         const uint32_t i = j * kTBlock + tid;
         s_cnt[i] = got[j] - s_loff[i];
     }
+    TPROF_T(p4);
+    TPROF_ADD(4, p3, p4);
 #pragma unroll
     for (int k = 0; k < kRoundPieces; ++k) {
         if (v[k] == 0xffffffffu) continue;
@@ -417,11 +434,15 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
         s_stage[s_loff[t] + r[k]] = (t << 14) | entry_of(v[k]);
     }
     __syncthreads();
+    TPROF_T(p5);
+    TPROF_ADD(5, p4, p5);
     for (uint32_t j = tid; j < total; j += kTBlock) {
         const uint32_t e = s_stage[j];
         bucket[s_cnt[e >> 14] + j] = static_cast<uint16_t>(e & 0x3fffu);
     }
     __syncthreads();  // the next round clears s_cnt and refills the stage
+    TPROF_T(p6);
+    TPROF_ADD(6, p5, p6);
 }
 
 // One round of the one-level bucketing straight from registers (more than 4096 tiles: the tile tables of the ordered
@@ -579,6 +600,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     uint32_t* const s_base = s_stage;
     const uint32_t tid = threadIdx.x;
     const uint32_t my_rep = blockIdx.x % kTileReps;
+    TPROF_T(q0);
     if (tid == 0) s_nsplit = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {  // coalesced, the copies' loads independent of each other
@@ -638,9 +660,13 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     __syncthreads();  // the stage (s_base) and s_cnt are handed to the rounds
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + static_cast<size_t>(my_rep) * rep_stride;
     SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
+    TPROF_T(q1);
+    TPROF_ADD(0, q0, q1);
     bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
         scatter_round_ordered(v, ntiles, s_mine, tile_cursor, bucket, s_cnt, s_loff, s_stage, s_wtot);
     });
+    TPROF_T(q2);
+    TPROF_ADD(7, q0, q2);
 }
 
 // two levels, level 1: values go to their SUPER tile (64 tiles = 512 K bins) as 32-bit words (19-bit bin-in-super |
@@ -732,6 +758,37 @@ __global__ __launch_bounds__(kTBlock) void k_part_tile(const uint32_t* __restric
 // 'bin != 0' bitmap words of the tile held in LDS (multi-GPU coverage summary): one ballot per 64 bins.  The bitmap
 // region is laid out for the exchange: the tiles are cut into slices of `tps` tiles (one slice per rank for the
 // all-to-all form, a single slice otherwise) and slice j holds [array 0 bits | array 1 bits] of its tiles.
+// A tile in LDS: one 32-bit word per bin (k_pack, which holds finished tiles), or PACKED, two 16-bit counts per word --
+// bin i in half (i >> 12) of word (i & 4095), so that four consecutive words hold four consecutive bins twice over.
+// k_tile_hist<true> (cov + uniq_cov) counts packed: a work item has at most kTileSub (< 65536) entries, no count can
+// carry into its neighbour, and at 32 KiB per workgroup a CU holds four workgroups instead of two (the kernel is a
+// chain of latencies: work item -> bucket -> LDS -> statistics -> stores).  The single-array instance has its four
+// workgroups per CU with plain words and keeps them (packing only adds the unpacking: config 3, 77 -> 87 us).
+constexpr uint32_t kPackWords = kTileBins / 2;
+static_assert(kTileSub < 65536, "packed 16-bit counts in k_tile_hist");
+template <bool kPacked>
+__device__ __forceinline__ uint4 tile_load4(const uint32_t* s, uint32_t bin) {  // bins bin .. bin + 3 (bin % 4 == 0)
+    if (!kPacked) return *reinterpret_cast<const uint4*>(s + bin);
+    const uint4 w = *reinterpret_cast<const uint4*>(s + (bin & (kPackWords - 1)));
+    return bin & kPackWords ? make_uint4(w.x >> 16, w.y >> 16, w.z >> 16, w.w >> 16)
+                            : make_uint4(w.x & 0xffffu, w.y & 0xffffu, w.z & 0xffffu, w.w & 0xffffu);
+}
+template <bool kPacked>
+__device__ __forceinline__ uint32_t tile_load1(const uint32_t* s, uint32_t bin) {
+    if (!kPacked) return s[bin];
+    const uint32_t w = s[bin & (kPackWords - 1)];
+    return bin & kPackWords ? w >> 16 : w & 0xffffu;
+}
+// one more in bin `bin` (13 bits) of a tile
+template <bool kPacked>
+__device__ __forceinline__ void tile_count(uint32_t* s, uint32_t bin) {
+    if (kPacked)
+        atomicAdd(&s[bin & (kPackWords - 1)], bin & kPackWords ? 0x10000u : 1u);
+    else
+        atomicAdd(&s[bin], 1u);
+}
+
+template <bool kPacked>
 __device__ __forceinline__ void tile_nonzero_bits(const uint32_t* s_a, uint32_t tile, const BitsLayout& bl, uint32_t array) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint64_t* dst = bl.base + (static_cast<uint64_t>(tile / bl.tps) * 2 + array) * bl.slice_w64 +
@@ -739,14 +796,14 @@ __device__ __forceinline__ void tile_nonzero_bits(const uint32_t* s_a, uint32_t 
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t i = wave * 1024 + j * 64;
-        const uint64_t m = __ballot(s_a[i + lane] != 0u);
+        const uint64_t m = __ballot(tile_load1<kPacked>(s_a, i + lane) != 0u);
         if (lane == 0) dst[i >> 6] = m;
     }
 }
 
 constexpr uint32_t kStatRefs = 128;  // reference offsets staged in LDS per tile (more: read from global memory)
 
-template <bool kTwo>
+template <bool kTwo, bool kPacked>
 __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32_t* s_b, uint32_t tile,
                                                const uint32_t* s_off, uint32_t r0,
                                                const uint32_t* __restrict__ bin_off, uint32_t n_refs,
@@ -777,11 +834,11 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
         const uint32_t a0 = max(s, t0) - tile0, a1 = min(e, t1) - tile0;  // multiples of 4 (offsets are 16-byte aligned)
         uint32_t sa = 0, za = 0, sb = 0, zb = 0;
         for (uint32_t i = a0 + lane * 4; i < a1; i += 256) {
-            const uint4 v = *reinterpret_cast<const uint4*>(s_a + i);
+            const uint4 v = tile_load4<kPacked>(s_a, i);
             sa += v.x + v.y + v.z + v.w;
             za += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
             if (kTwo) {
-                const uint4 w = *reinterpret_cast<const uint4*>(s_b + i);
+                const uint4 w = tile_load4<kPacked>(s_b, i);
                 sb += w.x + w.y + w.z + w.w;
                 zb += (w.x != 0) + (w.y != 0) + (w.z != 0) + (w.w != 0);
             }
@@ -820,14 +877,17 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
 }
 
 template <bool kTwo>
-__global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
+__global__ __launch_bounds__(512, 8) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
                                                    const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov, const uint32_t* __restrict__ bin_off,
                                                    uint32_t n_refs, const uint32_t* __restrict__ tile_ref0,
                                                    uint32_t* __restrict__ stats, const BitsLayout bits, uint32_t store_from) {
-    __shared__ uint32_t s_cov[kTileBins];
-    __shared__ uint32_t s_ucov[kTwo ? kTileBins : 4];
+    constexpr bool kPacked = kTwo;          // two 16-bit counts per word (tile_load4)
+    constexpr uint32_t kWords = kPacked ? kPackWords : kTileBins;
+    __shared__ uint32_t s_cov[kWords];
+    __shared__ uint32_t s_ucov[kTwo ? kWords : 4];
     __shared__ uint32_t s_off[kStatRefs + 1];  // bin offsets of the references overlapping this tile (and one more)
+    HPROF_T(h0);
     if (blockIdx.x >= counters[CNT_ITEMS]) return;
     const uint4 it = items[blockIdx.x];
     const uint32_t tile = it.x, lo = it.y, hi = it.z;
@@ -841,12 +901,14 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         uint4* zc = reinterpret_cast<uint4*>(s_cov);
         uint4* zu = reinterpret_cast<uint4*>(s_ucov);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+        for (uint32_t i = threadIdx.x; i < kWords / 4; i += 512) {
             zc[i] = z;
             if (kTwo) zu[i] = z;
         }
     }
     __syncthreads();
+    HPROF_T(h2);
+    HPROF_ADD(1, h0, h2);
     for (uint32_t e0 = lo; e0 < hi; e0 += 4 * 512) {
         uint32_t v[4];
 #pragma unroll
@@ -857,12 +919,16 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (v[u] == 0xffffffffu) continue;
-            atomicAdd(&s_cov[v[u] & kTileMask], 1u);
-            if (kTwo && (v[u] & kTileBins)) atomicAdd(&s_ucov[v[u] & kTileMask], 1u);
+            tile_count<kPacked>(s_cov, v[u] & kTileMask);
+            if (kTwo && (v[u] & kTileBins)) tile_count<kPacked>(s_ucov, v[u] & kTileMask);
         }
     }
+    HPROF_T(h3);
+    HPROF_ADD(2, h2, h3);
     if (stage_off) s_off[threadIdx.x] = off_reg;
     __syncthreads();
+    HPROF_T(h4);
+    HPROF_ADD(3, h3, h4);
     uint32_t* gc = cov + static_cast<size_t>(tile) * kTileBins;
     uint32_t* gu = ucov + static_cast<size_t>(tile) * kTileBins;
     if (whole) {
@@ -872,33 +938,52 @@ __global__ __launch_bounds__(512) void k_tile_hist(const uint16_t* __restrict__ 
         const uint4* su = reinterpret_cast<const uint4*>(s_ucov);
         // the statistics' atomics first: they come back from the memory side in ~2 us, and a workgroup retires only when
         // they have -- issued before the 64 KB of tile stores they are back by the time those are
-        if (stats) tile_ref_stats<kTwo>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
+        if (stats) tile_ref_stats<kTwo, kPacked>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
+        HPROF_T(h5);
+        HPROF_ADD(4, h4, h5);
         // tiles below store_from: the caller only wants what is derived from the finished tile while it is in LDS
         // (statistics, bit maps); the coverage arrays themselves are not materialised (tiles cut into pieces still are:
         // they are summed in global memory)
-        if (tile >= store_from) {
-            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
-                oc[i] = sc[i];
-                if (kTwo) ou[i] = su[i];
+        if (tile >= store_from && !kPacked) {
+            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) oc[i] = sc[i];
+        } else if (tile >= store_from) {  // four packed words = bins i .. i + 3 and i + 4096 .. i + 4099
+            for (uint32_t i = threadIdx.x; i < kPackWords / 4; i += 512) {
+                const uint4 w = sc[i];
+                oc[i] = make_uint4(w.x & 0xffffu, w.y & 0xffffu, w.z & 0xffffu, w.w & 0xffffu);
+                oc[i + kPackWords / 4] = make_uint4(w.x >> 16, w.y >> 16, w.z >> 16, w.w >> 16);
+                if (kTwo) {
+                    const uint4 x = su[i];
+                    ou[i] = make_uint4(x.x & 0xffffu, x.y & 0xffffu, x.z & 0xffffu, x.w & 0xffffu);
+                    ou[i + kPackWords / 4] = make_uint4(x.x >> 16, x.y >> 16, x.z >> 16, x.w >> 16);
+                }
             }
         }
         if (bits.base) {
-            tile_nonzero_bits(s_cov, tile, bits, 0);
-            if (kTwo) tile_nonzero_bits(s_ucov, tile, bits, 1);
+            tile_nonzero_bits<kPacked>(s_cov, tile, bits, 0);
+            if (kTwo) tile_nonzero_bits<kPacked>(s_ucov, tile, bits, 1);
         }
+        HPROF_T(h6);
+        HPROF_ADD(5, h5, h6);
+        HPROF_ADD(7, h0, h6);
         return;
     }
-    for (uint32_t i = threadIdx.x; i < kTileBins; i += 512) {
-        uint32_t a = s_cov[i];
+    for (uint32_t i = threadIdx.x; !kPacked && i < kTileBins; i += 512) {
+        const uint32_t a = s_cov[i];
         if (a) atomicAdd(&gc[i], a);
+    }
+    for (uint32_t i = threadIdx.x; kPacked && i < kPackWords; i += 512) {
+        const uint32_t a = s_cov[i];
+        if (a & 0xffffu) atomicAdd(&gc[i], a & 0xffffu);
+        if (a >> 16) atomicAdd(&gc[i + kPackWords], a >> 16);
         if (kTwo) {
-            uint32_t b2 = s_ucov[i];
-            if (b2) atomicAdd(&gu[i], b2);
+            const uint32_t b2 = s_ucov[i];
+            if (b2 & 0xffffu) atomicAdd(&gu[i], b2 & 0xffffu);
+            if (b2 >> 16) atomicAdd(&gu[i + kPackWords], b2 >> 16);
         }
     }
     // a tile cut into pieces: the sums are additive over the pieces; the non-zero counts need the finished tile and are
     // added by k_pack, the next kernel on the stream
-    if (stats) tile_ref_stats<kTwo>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, false);
+    if (stats) tile_ref_stats<kTwo, kPacked>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, false);
 }
 
 // small arrays gathered behind the statistics so that ONE copy brings everything to the host; the same launch finishes
@@ -935,10 +1020,10 @@ __global__ __launch_bounds__(512) void k_pack(uint32_t* __restrict__ dst, const 
             if (kTwo) reinterpret_cast<uint4*>(s_b)[i] = gb[i];
         }
         __syncthreads();
-        tile_ref_stats<kTwo>(s_a, s_b, tile, s_off, r0, bin_off, n_refs, stats, false, true);
+        tile_ref_stats<kTwo, false>(s_a, s_b, tile, s_off, r0, bin_off, n_refs, stats, false, true);
         if (bits.base) {
-            tile_nonzero_bits(s_a, tile, bits, 0);
-            if (kTwo) tile_nonzero_bits(s_b, tile, bits, 1);
+            tile_nonzero_bits<false>(s_a, tile, bits, 0);
+            if (kTwo) tile_nonzero_bits<false>(s_b, tile, bits, 1);
         }
     }
 }
@@ -1031,7 +1116,7 @@ void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const u
 
 }  // namespace slimm
 
-#if defined(EXP) && EXP == 8
+#if defined(EXP) && (EXP == 8 || EXP == 9)
 extern "C" int slimm_debug_prof_tiles(unsigned long long* out, int n, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_t), sizeof(unsigned long long) * n);
     if (reset) {

@@ -856,7 +856,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         Totals tot;
         tot.part = c->tot_part.p;
-        tot.nparts = grid;
+        tot.nparts = tile_count_grid(grid);
         tot.tail = c->tail();
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER);

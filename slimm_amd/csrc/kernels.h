@@ -196,6 +196,10 @@ struct Totals {
     uint32_t nparts = 0;
     uint32_t* tail = nullptr;  // may be null
 };
+// `grid` = the bucketing grid; the count runs tile_count_grid(grid) workgroups, kCountFold times as large, each for
+// kCountFold neighbours of the bucketing grid (and writes as many entries of part[])
+constexpr uint32_t kCountFold = 2;
+uint32_t tile_count_grid(uint32_t grid);
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
                        uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item

@@ -60,16 +60,20 @@ constexpr uint32_t kScanStaged = 16384;  // tiles whose counts k_tile_scan stage
 struct SlotWalk {  // all wave-uniform
     const uint4* slots;
     uint32_t s, s_end;        // next slot of this wave, end of the workgroup's range
+    uint32_t step;            // waves of the workgroup
     uint32_t base, left;      // entries of the current slot not yet handed out: [base, base + left)
     uint32_t sum_f, sum_h, sum_v;  // targets, reads and mapped records of the slots taken so far
     bool per_read;
 };
 
-__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read) {
-    const uint32_t per_wg = (nslots + gridDim.x - 1) / gridDim.x;
+// fold: this workgroup stands for `fold` workgroups of the bucketing grid (k_tile_count: fewer, larger workgroups flush
+// fewer LDS histograms with global atomics)
+__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read, uint32_t fold = 1) {
+    const uint32_t per_wg = (nslots + gridDim.x * fold - 1) / (gridDim.x * fold) * fold;
     const uint32_t lo = min(blockIdx.x * per_wg, nslots);
     SlotWalk w;
     w.slots = slots;
+    w.step = blockDim.x >> 6;
     w.s = lo + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.s_end = min(lo + per_wg, nslots);
     w.base = 0;
@@ -84,7 +88,7 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
     while (w.left == 0u) {
         if (w.s >= w.s_end) return 0u;
         const uint4 d = w.slots[w.s];  // (a scalar load: one address for the wave)
-        w.s += kTBlock / 64;
+        w.s += w.step;
         w.base = d.x;
         w.left = w.per_read ? d.z : d.y;
         w.sum_f += d.y;
@@ -102,7 +106,7 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
 // a selector)
 __device__ __forceinline__ uint32_t tile_of(uint32_t v) { return (v & 0x7fffffffu) >> kTileShift; }
 
-__global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
+__global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_count(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
                                                         uint32_t nslots, int per_read, uint32_t ntiles,
                                                         uint32_t* __restrict__ tile_count_all, uint32_t reps,
                                                         uint32_t rep_stride, uint4* __restrict__ part) {
@@ -112,10 +116,10 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
     // 512 workgroups adding to the same 2.4 K counters serialise in the memory-side atomic units: every workgroup adds to
     // one of `reps` copies instead, and k_tile_scan sums the copies
     uint32_t* __restrict__ tile_count = tile_count_all + static_cast<size_t>(blockIdx.x % reps) * rep_stride;
-    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock * kCountFold) s_hist[i] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    SlotWalk w = slot_walk(slots, nslots, per_read != 0);
+    SlotWalk w = slot_walk(slots, nslots, per_read != 0, kCountFold);
     while (true) {  // four pieces per trip, their loads in flight together
         uint32_t v[4];
         bool any = false;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_count(const uint32_t* __restri
     }
     __syncthreads();
     if (part && threadIdx.x == 0) part[blockIdx.x] = make_uint4(s_sum[0], s_sum[1], s_sum[2], 0u);
-    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) {
+    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock * kCountFold) {
         uint32_t h = s_hist[i];
         if (h) atomicAdd(&tile_count[i], h);
     }
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
                                                           uint32_t rep_stride) {
     HIP_DYNAMIC_SHARED(uint32_t, s_hist)
     __shared__ uint32_t s_more[kTBlock / 64];
-    const size_t rep_off = static_cast<size_t>(blockIdx.x % reps) * rep_stride;
+    const size_t rep_off = static_cast<size_t>((blockIdx.x / kCountFold) % reps) * rep_stride;
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
     const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
     zero_split_tiles(tile_base, ntiles, cov, ucov);
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     uint32_t& s_nsplit = s_mine[kFusedTiles - 16];
     uint32_t* const s_base = s_stage;
     const uint32_t tid = threadIdx.x;
-    const uint32_t my_rep = blockIdx.x % kTileReps;
+    const uint32_t my_rep = (blockIdx.x / kCountFold) % kTileReps;  // (the copy the counting workgroup of these slots added to)
     TPROF_T(q0);
     if (tid == 0) s_nsplit = 0;
 #pragma unroll
@@ -1040,6 +1044,8 @@ void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint
                            n_refs, tile_ref0, stats, bits);
 }
 
+uint32_t tile_count_grid(uint32_t grid) { return (grid + kCountFold - 1) / kCountFold; }
+
 int tile_hist_setup(uint32_t ntiles) {
     // dynamic LDS above 64 KiB has to be opted into
     size_t bytes = static_cast<size_t>(ntiles) * 4;
@@ -1056,7 +1062,7 @@ int tile_hist_setup(uint32_t ntiles) {
 
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
                        uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
-    hipLaunchKernelGGL(k_tile_count, dim3(grid), dim3(kTBlock), static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots,
+    hipLaunchKernelGGL(k_tile_count, dim3(tile_count_grid(grid)), dim3(kTBlock * kCountFold), static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots,
                        in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, part);
 }
 

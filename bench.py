@@ -502,6 +502,12 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_mt": cpu_mt,
             "device_kernel_ms_per_step": round(kernel_ms, 4),
+            # every kernel of the step from the warm-up survey (events around every launch), longest first: the dominant one
+            # is whichever is longest on this box -- k_front and k_filter are within a few us of each other
+            "kernels": {k: {"us": round(v["ms_per_launch"] * 1e3, 1),
+                            "frac_of_hbm_peak": round(v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+                        for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"])
+                        if v["ms_per_launch"] > 0},
             "kernel_timing": ("HIP events around " + (f"{dom_name} only in the timed steps (other kernels: warm-up survey)"
                                                       if dom_name else "every launch in the timed steps")),
         }

@@ -258,7 +258,9 @@ struct KernelTimer {  // brackets one launch (or a group) with events when timin
     slimm_ctx* c;
     slimm_ctx::Ev ev{};
     bool on;
-    KernelTimer(slimm_ctx* ctx, int id) : c(ctx), on(ctx->timing && (ctx->timing_only < 0 || ctx->timing_only == id)) {
+    bool dispatch;  // the events are handed to the launch itself (hipExtLaunchKernelGGL: the dispatch's own time stamps)
+    KernelTimer(slimm_ctx* ctx, int id, bool of_dispatch = false)
+        : c(ctx), on(ctx->timing && (ctx->timing_only < 0 || ctx->timing_only == id)), dispatch(of_dispatch) {
         if (!on) return;
         if (!c->ev_free.empty()) {
             ev = c->ev_free.back();
@@ -268,11 +270,13 @@ struct KernelTimer {  // brackets one launch (or a group) with events when timin
             (void)hipEventCreate(&ev.b);
         }
         ev.id = id;
-        (void)hipEventRecord(ev.a, c->stream);
+        if (!dispatch) (void)hipEventRecord(ev.a, c->stream);
     }
+    hipEvent_t t0() const { return on ? ev.a : nullptr; }
+    hipEvent_t t1() const { return on ? ev.b : nullptr; }
     ~KernelTimer() {
         if (!on) return;
-        (void)hipEventRecord(ev.b, c->stream);
+        if (!dispatch) (void)hipEventRecord(ev.b, c->stream);
         c->ev_used.push_back(ev);
     }
 };
@@ -839,9 +843,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
     } else {
         // grouped input: one pass straight over the caller's record arrays
-        KernelTimer t(c, K_FRONT);
+        KernelTimer t(c, K_FRONT, true);
         launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                         c->slots.p, c->wcut.p);
+                         c->slots.p, c->wcut.p, t.t0(), t.t1());
     }
     SlotValues targets;
     targets.vals = c->tgt_gbin.p;

@@ -43,6 +43,7 @@
 //   wcut    [s * kSlotWindows + i]  {targets, reads} of slot s in front of its window i; the last entry of a slot's row
 //                holds the number of windows, the entry behind the last window the slot's totals
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -652,7 +653,7 @@ static uint32_t front_grid(uint32_t nslots) {
 
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint2* wcut) {
+                      uint2* wcut, hipEvent_t t0, hipEvent_t t1) {
     const uint32_t ns = front_slots(in.n);
     if (!ns) return;
     FrontRaw a;
@@ -667,12 +668,14 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.half_read = half_read;
     a.bin_width = bin_width;
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
+    // (t0 / t1, when given: the dispatch's own start and end time stamps -- what rocprofv3 reports as the kernel's
+    // duration; events recorded around the launch add the 4 - 6 us it takes a dependent dispatch to start)
     if (in.check)
-        hipLaunchKernelGGL((k_front<FrontRaw, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                           tgt_gbin, slots, wcut);
+        hipExtLaunchKernelGGL((k_front<FrontRaw, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, a, ns,
+                              counters, tgt_ref, tgt_gbin, slots, wcut);
     else
-        hipLaunchKernelGGL((k_front<FrontRaw, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                           tgt_gbin, slots, wcut);
+        hipExtLaunchKernelGGL((k_front<FrontRaw, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, a, ns,
+                              counters, tgt_ref, tgt_gbin, slots, wcut);
 }
 
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,

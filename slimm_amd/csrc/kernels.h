@@ -101,13 +101,13 @@ constexpr uint32_t kSlotRecs = 1024;
 // holds the slot's totals and wcut[s * kSlotWindows + kSlotWindows - 1].x the number of windows.  The targets of a
 // window are whole reads: k_filter takes the windows up independently of each other.
 constexpr uint32_t kSlotWindows = 2 * (kSlotRecs / 64) + 6;
-constexpr int kFrontBlock = 256;
+constexpr int kFrontBlock = 64;   // one slot, one wave, one workgroup: the dispatcher backfills wave by wave (config 3: 594 -> 549 us)
 constexpr uint32_t kMaxRefs = (1u << 26) - 2u;      // reference id + 1 fits 26 bits and is not all ones (front.hip)
 constexpr uint32_t kMaxBins = 0x7ffffff0u;          // global bin indices fit 31 bits (bit 31 of tgt_gbin: unique read)
 uint32_t front_slots(uint32_t n_records);
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint2* wcut);
+                      uint2* wcut, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // t0 / t1: the dispatch's time stamps
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
                          uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
                          const uint32_t* cchk = nullptr);  // cchk: check words (equal keys must carry equal ones)

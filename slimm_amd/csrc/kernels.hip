@@ -772,7 +772,7 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 
 }  // namespace
 
-constexpr int kFilterBlock = 256;
+constexpr int kFilterBlock = 64;  // one wave per workgroup (backfilled wave by wave: -2 %)
 
 // A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
 // at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Six

@@ -116,6 +116,9 @@ void* dynamic_lds();
 constexpr int warpSize = 64;
 
 // kernel launch: arguments are evaluated once, the kernel runs to completion before the macro returns
+// (the launch with its own time stamp events: the events are ignored here)
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                   \
     do {                                                                                               \
         auto hipemu_args_ = std::make_tuple(__VA_ARGS__);                                              \

@@ -39,7 +39,8 @@ def test_layout_default_path(cfg):
 
 
 @pytest.mark.parametrize("cfg", [TINY_REFS, HOT_TILE], ids=lambda c: c.name)
-@pytest.mark.parametrize("env", [{"SLIMM_DIRECT_ATOMICS": "1"}, {"SLIMM_TWO_LEVEL": "1"}, {"SLIMM_WIDE_ROWS": "1"}],
+@pytest.mark.parametrize("env", [{"SLIMM_DIRECT_ATOMICS": "1"}, {"SLIMM_TWO_LEVEL": "1"}, {"SLIMM_WIDE_ROWS": "1"},
+                                 {"SLIMM_FUSED_SCAN": "0"}],
                          ids=lambda e: next(iter(e)))
 def test_layout_fallback_paths(monkeypatch, cfg, env):
     for k, v in env.items():

@@ -230,6 +230,38 @@ def test_both_bucketing_variants(monkeypatch, two):
     check(make_workload(CONFIGS["config1"], seed=21))
 
 
+def one_long_read_workload(n_hit: int, where: str = "first") -> Workload:
+    """A stream over 40 000 small references with one read that maps to n_hit DIFFERENT references (as many targets: its
+    slot's values run on over the following slots' positions), first or last in the file."""
+    base = make_workload(SynthConfig("many-refs", 30_000, 40_000, 2.0, bin_width=1000, len_lo=1_500, len_hi=3_000,
+                                     present_frac=0.5), seed=31)
+    r = base.records
+    long_key = np.full(n_hit, int(r.read_key.max()) + 1, dtype=np.uint64)
+    parts = [Records(long_key, np.zeros(n_hit, dtype=np.uint16), np.arange(n_hit, dtype=np.int32),
+                     np.full(n_hit, 10, dtype=np.int32)), r]
+    if where == "last":
+        parts.reverse()
+    rec = Records(*(np.concatenate([getattr(x, f) for x in parts]) for f in ("read_key", "flag", "ref_id", "begin_pos")))
+    return Workload(base.ref_names, base.ref_len, base.taxonomy, rec, base.avg_read_len, base.options, f"long-read-{n_hit}")
+
+
+@pytest.mark.parametrize("n_hit,where", [(3_000, "first"), (9_000, "first"), (35_000, "first"), (9_000, "last")])
+def test_a_read_with_thousands_of_targets(n_hit, where):
+    """The values of one slot then cover the positions of the next 2 / 8 / 34 slots: pieces of one slot that fill several
+    rounds of the bucket scatter, a tile that receives thousands of entries from one slot."""
+    s, o = check(one_long_read_workload(n_hit, where))
+    assert s.stats()["n_targets"] > n_hit
+
+
+def test_one_level_bucketing_with_a_separate_scan(monkeypatch):
+    """SLIMM_FUSED_SCAN=0: k_tile_scan + the direct scatter (what layouts of more than 4064 tiles use) on small layouts,
+    reads of thousands of records included."""
+    monkeypatch.setenv("SLIMM_FUSED_SCAN", "0")
+    check(make_workload(CONFIGS["config2"], seed=23, n_records=300_000))
+    check(make_workload(CONFIGS["config1"], seed=24))
+    check(one_long_read_workload(9_000))
+
+
 def test_wide_lineage_rows_fallback_path(monkeypatch):
     """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
     monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")

@@ -775,18 +775,21 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 constexpr int kFilterBlock = 64;  // one wave per workgroup (backfilled wave by wave: -2 %)
 
 // A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
-// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Six
-// at a time: the target words of all six are loaded together, then their lineage rows gathered together, then the six
+// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Four
+// at a time: the target words of all four are loaded together, then their lineage rows gathered together, then the four
 // are worked on, then the taxa of their reads with several targets looked up together -- three memory round trips per
-// six windows (a slot has ~17: three full trips; 4, 8 and 12 per trip measure 65 / 64 / 70 us against 61).  (No branch around the loads:
+// batch of windows.  Four windows per batch at eight waves per SIMD (64 VGPRs): the kernel waits for these round trips
+// two thirds of its time (SQ_WAIT_ANY), and an eighth wave covers more of them than two more windows in flight do --
+// config 3: 436 - 460 us with six windows at seven waves, 394 - 412 us like this; config 2 the same either way.
+// (No branch around the loads:
 // with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
 // waits for and waits for all of them.)
-constexpr int kFilterBatch = 6;
+constexpr int kFilterBatch = 4;
 constexpr uint32_t kFilterSlots = 1;  // consecutive slots per unit of work (their windows: at most 64 together)
 constexpr uint32_t kFilterSplit = 1;  // waves per unit (a power of two dividing the waves of a workgroup)
 static_assert(kFilterSlots * (kSlotWindows - 2u) <= 64u, "a wave keeps one window per lane");
 template <typename Rows>
-__global__ __launch_bounds__(kFilterBlock) void k_filter(const uint32_t* __restrict__ tgt_ref,
+__global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __restrict__ tgt_ref,
                                                          const uint32_t* __restrict__ tgt_gbin,
                                                          const uint4* __restrict__ slots, const uint2* __restrict__ wcut,
                                                          uint32_t nslots, const Rows rows, const FilterOut out) {

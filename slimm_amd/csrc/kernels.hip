@@ -634,6 +634,7 @@ struct Lookup {
     uint32_t index;  // taxon_at(index) + taxon_base is the selector ...
     uint32_t ridx;   // ... of read ridx
     bool want;
+    uint64_t q4;     // first valid lanes of the reads on whose targets no level agrees (quirk Q4): left to filter_q4
 };
 
 template <typename Rows>
@@ -656,7 +657,7 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
     const uint32_t ridx = sel_base + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
     if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
     if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
-    Lookup lk{0u, ridx, false};
+    Lookup lk{0u, ridx, false, 0ull};
     if (OW) {
         const uint64_t le = (2ull << lane) - 1ull;  // the lanes up to and including this one
         // the first valid lane of this lane's read (for the valid lanes): the highest bit of FV at or below it
@@ -679,34 +680,49 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
         // children[taxon] gets the valid targets' references (src/slimm.hpp:536-557): a (reference, level) mark
         const uint32_t lv_read = __builtin_amdgcn_ds_bpermute(fvl << 2, lv);
         if (k_bit(VB & ~single) && lv_read < 8u) out.marks[ref * kMarkBytes + lv_read] = 1;  // plain, idempotent byte store
-        if (Q4) {
-            uint32_t f[8];
-            Rows::fields(row, f);
-            uint64_t todo = Q4;
-            while (todo) {
-                const uint32_t o = static_cast<uint32_t>(__builtin_ctzll(todo));
-                todo &= todo - 1ull;
-                const uint64_t later = H & ~k_below(o + 1u);
-                const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
-                const uint64_t Vs = VB & k_below(nxt) & ~k_below(o);
-                ReadAcc acc;
-                read_clear(acc);
-                read_max(acc, Vs, ref, f[7]);
-                const uint32_t taxon = rows.taxon_at(rows.taxon_index(7u, acc.max_f7));
-                read_children(out, k_bit(Vs), ref, 8u, taxon);
-                if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(o + 1u))) - 1u] = out.taxon_base + taxon;
-            }
-        }
+        lk.q4 = Q4;
     }
     return lk;
+}
+
+// The reads of a window on whose valid targets no level agrees (quirk Q4: rare), one at a time: the taxon is level 7 of
+// the largest valid reference, the children are (taxon, reference) pairs in the hash set.  Kept OUT of filter_window:
+// with this path's loads and loops inside it, the compiler no longer knows how many memory operations are under way
+// where the paths join and makes every window wait for all of them (s_waitcnt vmcnt(0): the stores of the window
+// before, the loads asked for ahead).
+template <typename Rows>
+__device__ __forceinline__ void filter_q4(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
+                                          const typename Rows::Row& row, uint64_t valid_lanes, uint32_t sel_base, uint64_t Q4) {
+    const uint64_t PR = k_below(X);
+    const uint64_t H = k_ballot((w >> 31) != 0u) & PR;
+    const uint32_t ref = w & 0x7fffffffu;
+    const uint64_t VB = valid_lanes & PR;
+    uint32_t f[8];
+    Rows::fields(row, f);
+    uint64_t todo = Q4;
+    while (todo) {
+        const uint32_t o = static_cast<uint32_t>(__builtin_ctzll(todo));
+        todo &= todo - 1ull;
+        const uint64_t later = H & ~k_below(o + 1u);
+        const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
+        const uint64_t Vs = VB & k_below(nxt) & ~k_below(o);
+        ReadAcc acc;
+        read_clear(acc);
+        read_max(acc, Vs, ref, f[7]);
+        const uint32_t taxon = rows.taxon_at(rows.taxon_index(7u, acc.max_f7));
+        read_children(out, k_bit(Vs), ref, 8u, taxon);
+        if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(o + 1u))) - 1u] = out.taxon_base + taxon;
+    }
 }
 
 // ... and the same with the owners' taxa looked up at once (the windows of filter_span, one at a time)
 template <typename Rows>
 __device__ __forceinline__ void filter_window_now(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint32_t w,
                                                   uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
-    const Lookup lk = filter_window(rows, out, lane, X, w, g, row, k_ballot(Rows::valid(row)), sel_base);
+    const uint64_t vb = k_ballot(Rows::valid(row));
+    const Lookup lk = filter_window(rows, out, lane, X, w, g, row, vb, sel_base);
     if (lk.want) out.sel[lk.ridx] = out.taxon_base + rows.taxon_at(lk.index);
+    if (lk.q4) filter_q4(rows, out, lane, X, w, row, vb, sel_base, lk.q4);
 }
 
 // The targets [pos, endp) -- whole reads, any number of them, reads of 64 targets and more among them -- one window
@@ -833,27 +849,42 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
         bool spans = false;  // some window holds more than 64 targets
         const uint32_t share = (nw + kFilterSplit - 1u) / kFilterSplit;
         const uint32_t w_lo = min(part * share, nw), w_hi = min(w_lo + share, nw);
-        for (uint32_t i0 = w_lo; i0 < w_hi; i0 += kFilterBatch) {
-            uint32_t w[kFilterBatch], g[kFilterBatch], cnt[kFilterBatch], selb[kFilterBatch];
-            typename Rows::Row row[kFilterBatch];
+        // the target words of a batch are asked for one batch ahead: of the three round trips per batch (target words ->
+        // lineage rows -> taxa) the first then runs beside the batch before
+        uint32_t wn[kFilterBatch], gn[kFilterBatch], cntn[kFilterBatch], selbn[kFilterBatch];
+        auto ask = [&](uint32_t i0) {
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) {
                 const uint32_t i = (i0 + u) & 63u;  // (lanes behind the last window: windows of no targets)
                 const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
                 const uint32_t tl = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_last, i));
-                cnt[u] = i0 + u < w_hi ? static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i)) : 0u;
-                selb[u] = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i));
-                if (cnt[u] > 64u) {
+                cntn[u] = i0 + u < w_hi ? static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i)) : 0u;
+                selbn[u] = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i));
+                if (cntn[u] > 64u) {
                     spans = true;
-                    cnt[u] = 0;
+                    cntn[u] = 0;
                 }
-                const uint32_t t = cnt[u] ? min(t0 + lane, tl) : 0u;
-                w[u] = tgt_ref[t];
-                g[u] = tgt_gbin[t];
+                const uint32_t t = cntn[u] ? min(t0 + lane, tl) : 0u;
+                wn[u] = tgt_ref[t];
+                gn[u] = tgt_gbin[t];
+            }
+        };
+        ask(w_lo);
+        for (uint32_t i0 = w_lo; i0 < w_hi; i0 += kFilterBatch) {
+            uint32_t w[kFilterBatch], g[kFilterBatch], cnt[kFilterBatch], selb[kFilterBatch];
+            typename Rows::Row row[kFilterBatch];
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) {
+                w[u] = wn[u];
+                g[u] = gn[u];
+                cnt[u] = cntn[u];
+                selb[u] = selbn[u];
             }
             __builtin_amdgcn_sched_barrier(0);  // (every load of the stage before the first use of one)
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) row[u] = rows.load(lane < cnt[u] ? (w[u] & 0x7fffffffu) : 0u);
+            __builtin_amdgcn_sched_barrier(0);
+            ask(i0 + kFilterBatch);  // (behind the last batch: windows of no targets, loads of element 0)
             __builtin_amdgcn_sched_barrier(0);
             // Every loaded value gets a use HERE, in the straight-line code behind its stage: a (restrict, read-only) load
             // whose only uses sit in a conditional block further down is sunk into that block by the compiler -- which
@@ -867,7 +898,7 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
             Lookup lk[kFilterBatch];
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) {
-                lk[u] = Lookup{0u, 0u, false};
+                lk[u] = Lookup{0u, 0u, false, 0ull};
                 if (cnt[u]) lk[u] = filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], vb[u], selb[u]);
             }
             uint32_t taxon[kFilterBatch];
@@ -879,6 +910,20 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u)
                 if (lk[u].want) out.sel[lk[u].ridx] = out.taxon_base + taxon[u];
+            uint64_t any_q4 = 0;
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) any_q4 |= lk[u].q4;
+            if (any_q4) {  // (rare; behind everything else of the batch, and said aloud that nothing of it is left under way)
+#pragma unroll
+                for (int u = 0; u < kFilterBatch; ++u)
+                    if (lk[u].q4) filter_q4(rows, out, lane, cnt[u], w[u], row[u], vb[u], selb[u], lk[u].q4);
+                __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+            }
+#pragma unroll
+            for (int u = 0; u < kFilterBatch; ++u) {  // (the next batch's words stay where they were asked for)
+                SLIMM_PIN_VGPR(wn[u]);
+                SLIMM_PIN_VGPR(gn[u]);
+            }
         }
         if (spans) {
             for (uint32_t i = w_lo; i < w_hi; ++i) {

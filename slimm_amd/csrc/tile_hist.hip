@@ -363,15 +363,17 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
 // into registers (at most kRoundCap values per workgroup and round).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRoundPieces = 16;
+constexpr int kDirectPieces = 32;  // ... of the direct rounds (no stage in LDS): one returning atomic per touched tile and round
 constexpr uint32_t kTileSlots = 4096;  // entries of the ordered round's tile tables (= kFusedTiles)
 constexpr uint32_t kRoundCap = (kTBlock / 64) * kRoundPieces * 64;  // 8192 values per round
 
 // loads the round's values (0xffffffff where there is none); returns whether this wave got any
+template <int kPieces>
 __device__ __forceinline__ bool round_load(SlotWalk& w, const uint32_t* __restrict__ vals, uint32_t lane,
-                                           uint32_t (&v)[kRoundPieces]) {
+                                           uint32_t (&v)[kPieces]) {
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < kRoundPieces; ++k) {
+    for (int k = 0; k < kPieces; ++k) {
         uint32_t base = 0;
         const uint32_t n = slot_next(w, &base);
         any = any || n != 0u;
@@ -451,7 +453,8 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
 
 // One round of the one-level bucketing straight from registers (more than 4096 tiles: the tile tables of the ordered
 // form no longer fit LDS beside a stage).  s_hist[ntiles]: the round's histogram, then the write cursors.
-__device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kRoundPieces], uint32_t ntiles,
+template <int kPieces>
+__device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kPieces], uint32_t ntiles,
                                                      const uint32_t* __restrict__ tile_base,
                                                      uint32_t* __restrict__ tile_cursor, uint16_t* __restrict__ bucket,
                                                      uint32_t* s_hist) {
@@ -459,7 +462,7 @@ __device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kRoundP
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock) s_hist[i] = 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kRoundPieces; ++k)
+    for (int k = 0; k < kPieces; ++k)
         if (v[k] != 0xffffffffu) atomicAdd(&s_hist[tile_of(v[k])], 1u);
     __syncthreads();
     for (uint32_t i0 = 0; i0 < ntiles; i0 += kMaxTilesPerThread * kTBlock) {
@@ -478,7 +481,7 @@ __device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kRoundP
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kRoundPieces; ++k) {
+    for (int k = 0; k < kPieces; ++k) {
         if (v[k] == 0xffffffffu) continue;
         const uint32_t pos = atomicAdd(&s_hist[tile_of(v[k])], 1u);
         bucket[pos] = static_cast<uint16_t>(entry_of(v[k]));
@@ -487,12 +490,12 @@ __device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kRoundP
 }
 
 // rounds until no wave of the workgroup has values left (s_more: one flag per wave)
-template <typename Body>
+template <int kPieces = kRoundPieces, typename Body>
 __device__ __forceinline__ void bucketing_rounds(SlotWalk& walk, const uint32_t* __restrict__ vals, uint32_t* s_more,
                                                  Body body) {
     while (true) {
-        uint32_t v[kRoundPieces];
-        const bool mine = round_load(walk, vals, threadIdx.x & 63u, v);
+        uint32_t v[kPieces];
+        const bool mine = round_load<kPieces>(walk, vals, threadIdx.x & 63u, v);
         if ((threadIdx.x & 63u) == 0) s_more[threadIdx.x >> 6] = mine ? 1u : 0u;
         __syncthreads();
         uint32_t any = 0;
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
     const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
     zero_split_tiles(tile_base, ntiles, cov, ucov);
     SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
-    bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
+    bucketing_rounds<kDirectPieces>(walk, vals, s_more, [&](const uint32_t (&v)[kDirectPieces]) {
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
     });
 }

@@ -245,15 +245,31 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
         sum_counts(std::true_type{});
     else
         sum_counts(std::false_type{});
-    s_part[tid] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint2 add = make_uint2(0u, 0u);
-        if (tid >= off) add = s_part[tid - off];
+    {   // inclusive scan of the threads' sums: inside the waves by shuffles, the 16 wave totals through LDS (one barrier
+        // instead of the twenty of a scan by doubling over the whole workgroup)
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        uint2 inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
+            if (lane >= static_cast<uint32_t>(o)) {
+                inc.x += ax;
+                inc.y += ay;
+            }
+        }
+        __shared__ uint2 s_wave[16];
+        if (lane == 63) s_wave[wave] = inc;
         __syncthreads();
-        s_part[tid].x += add.x;
-        s_part[tid].y += add.y;
-        __syncthreads();
+        uint2 before = make_uint2(0u, 0u);
+#pragma unroll
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint2 t = s_wave[w];
+            if (w < wave) {
+                before.x += t.x;
+                before.y += t.y;
+            }
+        }
+        s_part[tid] = make_uint2(before.x + inc.x, before.y + inc.y);
     }
     uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
     auto emit_items = [&](auto from_lds) {

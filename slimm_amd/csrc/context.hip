@@ -1186,7 +1186,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
     }
     const uint32_t nslots = front_slots(c->rec.n);
     {
-        KernelTimer t(c, K_FILTER);
+        KernelTimer t(c, K_FILTER, true);  // (the dispatch's own time stamps, like k_front)
         FilterArgs fa;
         fa.tgt_ref = c->tgt_ref.p;
         fa.tgt_gbin = c->tgt_gbin.p;
@@ -1208,7 +1208,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         fa.pair_mask = c->pair_cap - 1;
         fa.taxon_base = static_cast<uint32_t>(c->Bp);
         fa.counters = c->counters.p;
-        launch_filter(st, fa);
+        launch_filter(st, fa, t.t0(), t.t1());
     }
     SlotValues selectors;
     selectors.vals = c->sel.p;

@@ -149,7 +149,7 @@ struct FilterArgs {
     uint32_t pair_mask = 0, taxon_base = 0;
     uint32_t* counters = nullptr;
 };
-void launch_filter(hipStream_t st, const FilterArgs& a);
+void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // t0 / t1: as for launch_front_raw
 // direct-atomics fallback: count the selectors with global atomics instead of the second tile histogram
 void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
                         uint32_t* ucov2, uint32_t* lca_count);

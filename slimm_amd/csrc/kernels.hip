@@ -19,6 +19,7 @@
 //   a11 level-scan LCA                           src/slimm.hpp:516-531        k_filter_lca
 //   a12 step 1: per-taxon counts + children      src/slimm.hpp:536-557        k_filter_lca
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -1091,7 +1092,7 @@ static uint32_t filter_grid(uint32_t nslots) {
     return std::max(1u, (units + per - 1u) / per);
 }
 
-void launch_filter(hipStream_t st, const FilterArgs& a) {
+void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_t t1) {
     if (!a.nslots) return;
     FilterOut out;
     out.sel = a.sel;
@@ -1106,14 +1107,14 @@ void launch_filter(hipStream_t st, const FilterArgs& a) {
         r.rows = reinterpret_cast<const uint4*>(a.rows16);
         r.taxon_flat = a.taxon_flat;
         r.shift = a.taxon_shift;
-        hipLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
-                           a.slots, a.wcut, a.nslots, r, out);
+        hipExtLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
+                              a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
     } else {
         Rows32 r;
         r.lin4 = reinterpret_cast<const uint4*>(a.lin_dense);
         r.valid_of = a.valid;
-        hipLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, a.tgt_ref, a.tgt_gbin,
-                           a.slots, a.wcut, a.nslots, r, out);
+        hipExtLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
+                              a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
     }
 }
 

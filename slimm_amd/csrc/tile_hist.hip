@@ -915,6 +915,23 @@ __global__ __launch_bounds__(512, 8) void k_tile_hist(const uint16_t* __restrict
     const uint4 it = items[blockIdx.x];
     const uint32_t tile = it.x, lo = it.y, hi = it.z;
     const bool whole = it.w == 1;
+    if (whole && lo == hi) {  // a tile without entries: zeros out, nothing for any reference's statistics, no LDS at all
+        if (tile >= store_from) {
+            uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
+            uint4* ou = reinterpret_cast<uint4*>(ucov + static_cast<size_t>(tile) * kTileBins);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+                oc[i] = z;
+                if (kTwo) ou[i] = z;
+            }
+        }
+        if (bits.base && threadIdx.x < kTileBins / 64) {
+            for (uint32_t array = 0; array < (kTwo ? 2u : 1u); ++array)
+                bits.base[(static_cast<uint64_t>(tile / bits.tps) * 2 + array) * bits.slice_w64 +
+                          static_cast<uint64_t>(tile % bits.tps) * (kTileBins / 64) + threadIdx.x] = 0ull;
+        }
+        return;
+    }
     // first reference overlapping the tile (host table; n_refs for tiles behind the last reference), then its and its
     // successors' offsets: issued now, needed after the accumulation
     const uint32_t r0 = stats ? tile_ref0[tile] : n_refs;

@@ -161,9 +161,14 @@ __device__ __forceinline__ void publish_totals(const uint4* __restrict__ part, u
         h += p.y;
         f += p.z;
     }
-    if (v) atomicAdd(&s_tot[0], v);
-    if (h) atomicAdd(&s_tot[1], h);
-    if (f) atomicAdd(&s_tot[2], f);
+    v = wave_sum_dpp(v);  // (one LDS add per wave and total, not one per thread on three addresses)
+    h = wave_sum_dpp(h);
+    f = wave_sum_dpp(f);
+    if ((threadIdx.x & 63u) == 63u) {
+        if (v) atomicAdd(&s_tot[0], v);
+        if (h) atomicAdd(&s_tot[1], h);
+        if (f) atomicAdd(&s_tot[2], f);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         counters[CNT_V] = s_tot[0];

@@ -240,17 +240,36 @@ def dense_mt_lib():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make -C oracle`")
         L = C.CDLL(path)
-        L.dmt_run.restype = C.c_int
-        L.dmt_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
-                              C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                              C.c_uint32, C.c_void_p, C.c_void_p]
+        L.dmt_run2.restype = C.c_int
+        L.dmt_run2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                               C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _mt_lib = L
     return _mt_lib
 
 
-def dense_mt_run(w, records=None, threads: int = 0) -> dict:
+BIN_CHECKSUM_MUL = 0x9E3779B97F4A7C15
+
+
+def bin_checksum(a: np.ndarray) -> int:
+    """sum_i a[i] * ((i + 1) * 0x9E3779B97F4A7C15) mod 2^64 -- the position-weighted checksum dmt_run2 reports for its
+    three coverage arrays, here over an array a caller holds (slimm_get_bins); in pieces, so that 200 M bins do not
+    need 5 GB of temporaries."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    total = np.uint64(0)
+    step = 1 << 24
+    with np.errstate(over="ignore"):
+        for s in range(0, a.shape[0], step):
+            e = min(a.shape[0], s + step)
+            wgt = np.arange(s + 1, e + 1, dtype=np.uint64) * np.uint64(BIN_CHECKSUM_MUL)
+            total = total + (a[s:e].astype(np.uint64) * wgt).sum(dtype=np.uint64)
+    return int(total)
+
+
+def dense_mt_run(w, records=None, threads: int = 0, want_bins: bool = False) -> dict:
     """Phases A, B and the direct LCA counts of workload `w` (records grouped by read name) on `threads` host threads
-    (0 = all).  Returns per-reference columns, scalars, {taxid: count} and the three phase times."""
+    (0 = all).  Returns per-reference columns, scalars, {taxid: count}, the checksums of the three coverage arrays
+    (bin_checksum) -- with want_bins the arrays themselves -- and the three phase times."""
     rec = w.records if records is None else records
     R = len(w.ref_names)
     lineage = np.ascontiguousarray(w.taxonomy.lineage_for_header(w.ref_names), dtype=np.uint32)
@@ -263,14 +282,26 @@ def dense_mt_run(w, records=None, threads: int = 0) -> dict:
     n_lca = C.c_uint32(0)
     sec = np.zeros(3, dtype=np.float64)
     threads = threads or (os.cpu_count() or 1)
-    rc = dense_mt_lib().dmt_run(_p(rec.read_key), _p(rec.flag), _p(rec.ref_id), _p(rec.begin_pos), len(rec), R, _p(ref_len),
-                                _p(lineage), int(w.avg_read_len), int(w.options.bin_width), float(w.options.cov_cut_off),
-                                int(threads), _p(cols), _p(sc), _p(tx), _p(cn), cap, C.byref(n_lca), _p(sec))
+    chk = np.zeros(3, dtype=np.uint64)
+    bins = None
+    out_ptrs = None
+    if want_bins:
+        bw = int(w.options.bin_width) or int(w.avg_read_len)
+        B = int((ref_len.astype(np.int64) // bw + 1).sum())
+        bins = [np.zeros(B, dtype=np.uint32) for _ in range(3)]
+        out_ptrs = (C.c_void_p * 3)(*[b.ctypes.data for b in bins])
+    rc = dense_mt_lib().dmt_run2(_p(rec.read_key), _p(rec.flag), _p(rec.ref_id), _p(rec.begin_pos), len(rec), R, _p(ref_len),
+                                 _p(lineage), int(w.avg_read_len), int(w.options.bin_width), float(w.options.cov_cut_off),
+                                 int(threads), _p(cols), _p(sc), _p(tx), _p(cn), cap, C.byref(n_lca), _p(sec), out_ptrs,
+                                 _p(chk))
     if rc < 0:
-        raise RuntimeError("dmt_run: bad arguments")
+        raise RuntimeError("dmt_run2: bad arguments")
     k = min(int(n_lca.value), cap)
-    return {"no_hits": rc == 1, "reads_count": cols[:, 0].copy(), "uniq_reads_count": cols[:, 1].copy(),
-            "nz_cov": cols[:, 2].copy(), "nz_uniq_cov": cols[:, 3].copy(), "uniq_reads_count2": cols[:, 4].copy(),
-            "hits": int(sc[0]), "matches": int(sc[1]), "uniq_matches": int(sc[2]), "uniq_matches2": int(sc[3]),
-            "n_valid": int(sc[4]), "total_bins": int(sc[5]), "lca_direct": {int(a): int(b) for a, b in zip(tx[:k], cn[:k])},
-            "seconds": tuple(float(x) for x in sec), "threads": int(threads)}
+    out = {"no_hits": rc == 1, "reads_count": cols[:, 0].copy(), "uniq_reads_count": cols[:, 1].copy(),
+           "nz_cov": cols[:, 2].copy(), "nz_uniq_cov": cols[:, 3].copy(), "uniq_reads_count2": cols[:, 4].copy(),
+           "hits": int(sc[0]), "matches": int(sc[1]), "uniq_matches": int(sc[2]), "uniq_matches2": int(sc[3]),
+           "n_valid": int(sc[4]), "total_bins": int(sc[5]), "lca_direct": {int(a): int(b) for a, b in zip(tx[:k], cn[:k])},
+           "checksums": tuple(int(x) for x in chk), "seconds": tuple(float(x) for x in sec), "threads": int(threads)}
+    if bins is not None:
+        out["cov"], out["uniq_cov"], out["uniq_cov2"] = bins
+    return out

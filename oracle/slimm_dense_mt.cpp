@@ -74,6 +74,21 @@ void parallel(unsigned n_threads, F f) {
     for (auto& th : pool) th.join();
 }
 
+// sum_i a[i] * ((i + 1) * 0x9E3779B97F4A7C15) mod 2^64: every bin with a weight of its own, so two arrays that differ in
+// one bin, or hold the same counts at other positions, differ in the sum
+uint64_t bin_checksum(const uint32_t* a, uint64_t n, unsigned n_threads) {
+    std::vector<uint64_t> part(n_threads, 0);
+    parallel(n_threads, [&](unsigned t) {
+        uint64_t s = 0;
+        for (uint64_t i = n * t / n_threads, e = n * (t + 1) / n_threads; i < e; ++i)
+            s += static_cast<uint64_t>(a[i]) * ((i + 1) * 0x9E3779B97F4A7C15ull);
+        part[t] = s;
+    });
+    uint64_t s = 0;
+    for (uint64_t p : part) s += p;
+    return s;
+}
+
 double seconds_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -87,10 +102,16 @@ extern "C" {
 // lca      up to lca_cap (taxid, count) pairs of the reads that keep several references (src/slimm.hpp:536-557)
 // seconds  [3]    : phase A (records -> histograms + statistics), cut-offs + phase B, LCA merge
 // returns 0, 1 when no record is mapped (the reference's early return), -1 on bad arguments
-int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
-            const uint32_t* ref_len, const uint32_t* lineage /*[n_refs * 8]*/, uint32_t avg_read_len, uint32_t bin_width,
-            float cov_cut_off, uint32_t n_threads, uint32_t* ref_cols, uint64_t* scalars, uint32_t* lca_taxid,
-            uint32_t* lca_count, uint32_t lca_cap, uint32_t* n_lca, double* seconds) {
+// dmt_run2 also hands out what the full-size parity tests compare with slimm_get_bins:
+//   bins_out  [3]: optional destinations (each total-bins words, any may be null) for cov, uniq_cov, uniq_cov2
+//                  (reference_contig.hpp:110-112), references back to back without padding
+//   checksums [3]: position-weighted 64-bit sums of the same three arrays, sum_i a[i] * ((i + 1) * 0x9E3779B97F4A7C15)
+//                  mod 2^64 (bin_checksum below; tests/helpers.py computes the same over slimm_get_bins)
+int dmt_run2(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
+             const uint32_t* ref_len, const uint32_t* lineage /*[n_refs * 8]*/, uint32_t avg_read_len, uint32_t bin_width,
+             float cov_cut_off, uint32_t n_threads, uint32_t* ref_cols, uint64_t* scalars, uint32_t* lca_taxid,
+             uint32_t* lca_count, uint32_t lca_cap, uint32_t* n_lca, double* seconds, uint32_t* const* bins_out,
+             uint64_t* checksums) {
     if (!n_refs || !ref_len || !lineage || !ref_cols || !scalars || !seconds) return -1;
     if (bin_width == 0) bin_width = avg_read_len;  // slimm.hpp:412-413
     if (bin_width == 0) return -1;
@@ -205,7 +226,18 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
         ref_cols[r * 5 + 2] = nz_cov[r];
         ref_cols[r * 5 + 3] = nz_ucov[r];
     }
-    if (hits == 0) return 1;
+    // the arrays themselves / their checksums, for the callers that compare them (not part of any timed phase)
+    auto hand_out = [&]() {
+        const std::vector<uint32_t>* arr[3] = {&cov, &ucov, &ucov2};
+        for (int a = 0; a < 3; ++a) {
+            if (bins_out && bins_out[a] && B) std::memcpy(bins_out[a], arr[a]->data(), B * sizeof(uint32_t));
+            if (checksums) checksums[a] = bin_checksum(arr[a]->data(), B, n_threads);
+        }
+    };
+    if (hits == 0) {
+        hand_out();
+        return 1;
+    }
 
     // ---------------------------------------------------------------- cut-offs + phase B (slimm.hpp:328-392, 672-688)
     t0 = std::chrono::steady_clock::now();
@@ -290,7 +322,16 @@ int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const
         ++k;
     }
     if (n_lca) *n_lca = k;
+    hand_out();
     return 0;
+}
+
+int dmt_run(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
+            const uint32_t* ref_len, const uint32_t* lineage, uint32_t avg_read_len, uint32_t bin_width, float cov_cut_off,
+            uint32_t n_threads, uint32_t* ref_cols, uint64_t* scalars, uint32_t* lca_taxid, uint32_t* lca_count,
+            uint32_t lca_cap, uint32_t* n_lca, double* seconds) {
+    return dmt_run2(key, flag, ref, pos, n, n_refs, ref_len, lineage, avg_read_len, bin_width, cov_cut_off, n_threads,
+                    ref_cols, scalars, lca_taxid, lca_count, lca_cap, n_lca, seconds, nullptr, nullptr);
 }
 
 }  // extern "C"

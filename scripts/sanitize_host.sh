@@ -8,12 +8,12 @@ W="${1:-/tmp/slimm_sanitize}"
 mkdir -p "$W"
 FLAGS="-std=c++17 -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer"
 g++ $FLAGS "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
-    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -o "$W/san_readers"
+    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -ldl -o "$W/san_readers"
 g++ $FLAGS "$ROOT/tests/native/host_profile_bench.cpp" "$ROOT/slimm_amd/csrc/host_profile.cpp" -o "$W/san_profile"
 g++ $FLAGS "$ROOT/slimm_amd/csrc/host/slimm_build_main.cpp" "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -o "$W/san_build"
 # ThreadSanitizer over the parallel BGZF inflate / record decode
 g++ -std=c++17 -g -O1 -fsanitize=thread "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
-    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -o "$W/tsan_readers"
+    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -ldl -o "$W/tsan_readers"
 cd "$ROOT"
 python - "$W" <<'PY'
 import os, subprocess, sys

@@ -1,3 +1,4 @@
+// Build and run (on the MI355X box): hipcc --offload-arch=gfx950 -O2 -o scripts/ubench/issue scripts/ubench/issue.hip && scripts/ubench/issue
 // Issue-rate microbenchmark (gfx950): how many wave-instructions per cycle does a CU issue for integer VALU, SALU and
 // mixes of the two?  Each wave runs `iters` trips of an unrolled block of 64 instructions.
 #include <hip/hip_runtime.h>

@@ -1,3 +1,4 @@
+// How many cores does the box really grant?  Build and run: g++ -O2 -pthread -o scripts/ubench/spin scripts/ubench/spin.cpp && scripts/ubench/spin
 #include <thread>
 #include <vector>
 #include <chrono>

@@ -1,5 +1,6 @@
 #include "alignment_file.hpp"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -41,53 +42,64 @@ public:
             for (unsigned i = 0; i < count; ++i) fn(i);
             return;
         }
+        // Every job is an object of its own with its own item counter.  A worker takes its copy of the pointer under the
+        // mutex and claims items only through THAT job's counter, so a worker that woke late for job k -- and is still
+        // on its way out of it when job k + 1 is published -- holds a counter that is used up: it can neither run an
+        // item of the new job a second time nor touch the new job's `left`.  An item is only ever claimed while its job
+        // has items left, i.e. while run() of that job is still waiting, so `fn` outlives every call of it.
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->count = count;
+        job->left = count;
         {
             std::lock_guard<std::mutex> g(mu_);
-            fn_.store(&fn);
-            count_.store(count);
-            next_.store(0, std::memory_order_relaxed);
-            left_ = count;
+            job_ = job;
             ++generation_;
         }
         wake_.notify_all();
-        work();
+        work(*job);
         std::unique_lock<std::mutex> g(mu_);
-        done_.wait(g, [this] { return left_ == 0; });
-        count_.store(0);  // (stragglers find nothing to do)
+        done_.wait(g, [&] { return job->left == 0; });
+        job_.reset();
     }
 
 private:
-    void work() {
+    struct Job {
+        const std::function<void(unsigned)>* fn = nullptr;
+        unsigned count = 0;
+        std::atomic<unsigned> next{0};
+        unsigned left = 0;  // items not finished yet (under mu_)
+    };
+    void work(Job& j) {
         unsigned finished = 0;
-        for (unsigned i; (i = next_.fetch_add(1)) < count_.load();) {
-            (*fn_.load())(i);
+        for (unsigned i; (i = j.next.fetch_add(1)) < j.count;) {
+            (*j.fn)(i);
             ++finished;
         }
         if (finished) {
             std::lock_guard<std::mutex> g(mu_);
-            left_ -= finished;
-            if (left_ == 0) done_.notify_all();
+            j.left -= finished;
+            if (j.left == 0) done_.notify_all();
         }
     }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> g(mu_);
                 wake_.wait(g, [&] { return quit_ || generation_ != seen; });
                 if (quit_) return;
                 seen = generation_;
+                job = job_;
             }
-            work();
+            if (job) work(*job);
         }
     }
     std::vector<std::thread> pool_;
     std::mutex mu_;
     std::condition_variable wake_, done_;
-    // (a worker on its way out of the job before may already pick up items of the next one: fn_ and count_ are atomics)
-    std::atomic<const std::function<void(unsigned)>*> fn_{nullptr};
-    std::atomic<unsigned> next_{0}, count_{0};
-    unsigned left_ = 0;
+    std::shared_ptr<Job> job_;
     uint64_t generation_ = 0;
     bool quit_ = false;
 };
@@ -137,8 +149,8 @@ AlignmentFile::~AlignmentFile() { close(); }
 void AlignmentFile::close() {
     if (fp_ && getenv("SLIMM_CLI_TRACE") && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0)
         fprintf(stderr, "[trace] reader: read + parse blocks %.1f ms, inflate %.1f ms, record starts %.1f ms, decode + hash %.1f ms, "
-                        "name check %.1f ms; %u windows, waited %.1f ms for the prefetch thread (%u threads)\n", ms_read_, ms_inflate_, ms_find_,
-                ms_decode_, ms_names_, n_windows_, ms_wait_, threads_);
+                        "name check %.1f ms; %u windows, waited %.1f ms for the prefetch thread (%u threads, inflate by %s)\n", ms_read_, ms_inflate_, ms_find_,
+                ms_decode_, ms_names_, n_windows_, ms_wait_, threads_, inflate_backend());
     ms_read_ = ms_inflate_ = ms_find_ = ms_decode_ = ms_names_ = ms_wait_ = 0;
     n_windows_ = 0;
     stop_prefetch();
@@ -205,8 +217,53 @@ bool AlignmentFile::open(const std::string& path) {
 // gzip members, which is the point of the format.  zlib inflate runs at a few hundred MB/s per core, so the decode
 // side of `slimm IN.bam` scales with the host's cores up to the file read rate.
 namespace {
+// libdeflate (2 - 3x zlib's inflate rate on BGZF blocks) when the box has the library: there are no headers for it in
+// the image, so the four entry points used are declared here (libdeflate.h: libdeflate_alloc_decompressor,
+// libdeflate_deflate_decompress -- 0 = LIBDEFLATE_SUCCESS --, libdeflate_free_decompressor, libdeflate_crc32) and bound
+// with dlopen("libdeflate.so.0").  SLIMM_INFLATE=zlib keeps zlib; zlib is also the fallback when the library is absent.
+struct Deflate {
+    void* (*alloc)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    bool ok = false;
+    Deflate() {
+        const char* e = getenv("SLIMM_INFLATE");
+        if (e && strcmp(e, "zlib") == 0) return;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+        decompress = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(
+            dlsym(h, "libdeflate_deflate_decompress"));
+        release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+        crc = reinterpret_cast<uint32_t (*)(uint32_t, const void*, size_t)>(dlsym(h, "libdeflate_crc32"));
+        ok = alloc && decompress && release && crc;
+    }
+};
+const Deflate& deflate_lib() {
+    static const Deflate d;
+    return d;
+}
+struct ThreadDecompressor {  // one per worker thread, freed with the thread
+    void* d = nullptr;
+    ~ThreadDecompressor() {
+        if (d) deflate_lib().release(d);
+    }
+};
+
 bool inflate_one(const uint8_t* src, size_t clen, uint8_t* dst, uint32_t isize, uint32_t crc) {
     if (isize == 0) return true;
+    const Deflate& L = deflate_lib();
+    if (L.ok) {
+        static thread_local ThreadDecompressor td;
+        if (!td.d) td.d = L.alloc();
+        if (td.d) {
+            size_t got = 0;
+            if (L.decompress(td.d, src, clen, dst, isize, &got) != 0 || got != isize) return false;
+            return L.crc(0u, dst, isize) == crc;
+        }
+    }
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, -15) != Z_OK) return false;
@@ -220,6 +277,8 @@ bool inflate_one(const uint8_t* src, size_t clen, uint8_t* dst, uint32_t isize, 
     return crc32(crc32(0L, Z_NULL, 0), dst, isize) == crc;
 }
 }  // namespace
+
+const char* AlignmentFile::inflate_backend() { return deflate_lib().ok ? "libdeflate" : "zlib"; }
 
 // The next stretch of the file, inflated into dst[dst_off ...): one fread of `batch_bytes` compressed bytes (what is left of
 // an incomplete block at its end waits in cbuf_ for the next call), the BGZF block headers walked in memory, the blocks
@@ -266,6 +325,10 @@ bool AlignmentFile::read_inflate(Bytes& dst, size_t dst_off, size_t batch_bytes,
             b.clen = total - 12 - xlen - 8;  // deflate data (crc32 and isize follow)
             b.crc = rd_u32(&cbuf_[p + total - 8]);
             b.isize = rd_u32(&cbuf_[p + total - 4]);
+            if (b.isize > 65536u) {  // (the format caps a block's payload at 64 KiB; nothing is allocated on a file's word)
+                err = "bad BGZF block size";
+                return false;
+            }
             b.ooff = out;
             out += b.isize;
             blocks_.push_back(b);
@@ -308,7 +371,14 @@ void AlignmentFile::start_prefetch() {
     next_ok_ = true;
     next_eof_ = false;
     next_err_.clear();
-    prefetch_ = std::thread([this, batch] { next_ok_ = read_inflate(spare_, kSlack, batch, next_eof_, next_err_); });
+    prefetch_ = std::thread([this, batch] {
+        try {
+            next_ok_ = read_inflate(spare_, kSlack, batch, next_eof_, next_err_);
+        } catch (const std::exception& e) {  // (an exception leaving a std::thread is std::terminate)
+            next_ok_ = false;
+            next_err_ = std::string("reading the alignment file: ") + e.what();
+        }
+    });
 }
 
 void AlignmentFile::stop_prefetch() {

@@ -3,7 +3,7 @@
 // Replaces the reference's use of seqan::BamFileIn (call sites: reference src/misc.hpp:498-522,
 // src/slimm.hpp:194-208, 420-424): header reference names + lengths in header order (= refID), and per record
 // qName, flag, refID, 0-based position and sequence length.  CIGAR, MAPQ, qualities and tags are never looked at by
-// SLIMM and are skipped.  BAM = BGZF (concatenated gzip members, inflated with zlib) carrying the binary records of the
+// SLIMM and are skipped.  BAM = BGZF (concatenated gzip members, inflated with libdeflate when the box has it, else zlib) carrying the binary records of the
 // SAM specification; SAM = the tab-separated text form.  Written against the SAM/BAM specification -- SeqAn's source
 // is not part of the reference checkout -- and cross-checked in tests against files produced by an independent
 // Python writer (tests/bam_io.py).
@@ -56,6 +56,8 @@ public:
     void close();
     const std::string& error() const { return err_; }
     bool is_bam() const { return bam_; }
+    // "libdeflate" when libdeflate.so.0 could be dlopen()ed (and SLIMM_INFLATE is not "zlib"), else "zlib"
+    static const char* inflate_backend();
 
     const std::vector<std::string>& ref_names() const { return ref_names_; }
     const std::vector<uint32_t>& ref_lengths() const { return ref_len_; }

@@ -151,3 +151,39 @@ def make_workload(cfg: SynthConfig, seed: int = 1, n_records: Optional[int] = No
     opts = Options(bin_width=cfg.bin_width, cov_cut_off=cfg.cov_cut_off)
     return Workload(ref_names, ref_len, tax, rec, avg_read_len=cfg.read_len, options=opts,
                     name=f"{cfg.name}-seed{seed}" + ("-shuffled" if shuffled else ""), grouped=not shuffled)
+
+
+def stream_chunk(cfg: SynthConfig, seed: int, c: int, n_stream: int, chunk_records: int) -> Workload:
+    """Chunk c of THE strong-scaling stream of a configuration (bench.py --config config4, the full-size tests): a grouped
+    file of whole reads of its own, make_workload(seed + 1000 c, shard = c) of the sample `seed`; the stream is the chunks
+    in order."""
+    return make_workload(cfg, seed=seed + 1000 * c, n_records=min(chunk_records, n_stream - c * chunk_records),
+                         sample_seed=seed, shard=c)
+
+
+def stream_chunks(cfg: SynthConfig, seed: int, n_stream: int, chunk_records: int = 10_000_000, chunks=None,
+                  threads: int = 8):
+    """Yields (c, Workload) for the given chunk numbers (default: all of the stream), in order, generated a few chunks
+    ahead on `threads` threads (numpy releases the GIL in its sorts and generators; no child processes, so a caller that
+    holds a GPU context need not care)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n_chunks = max(1, (n_stream + chunk_records - 1) // chunk_records)
+    todo = list(range(n_chunks) if chunks is None else chunks)
+    if threads <= 1 or len(todo) <= 1:
+        for c in todo:
+            yield c, stream_chunk(cfg, seed, c, n_stream, chunk_records)
+        return
+    with ThreadPoolExecutor(threads) as ex:
+        ahead = []
+        it = iter(todo)
+        for c in it:
+            ahead.append((c, ex.submit(stream_chunk, cfg, seed, c, n_stream, chunk_records)))
+            if len(ahead) >= 2 * threads:
+                break
+        while ahead:
+            c, fut = ahead.pop(0)
+            nxt = next(it, None)
+            if nxt is not None:
+                ahead.append((nxt, ex.submit(stream_chunk, cfg, seed, nxt, n_stream, chunk_records)))
+            yield c, fut.result()

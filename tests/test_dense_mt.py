@@ -1,9 +1,26 @@
-"""The all-core dense CPU restatement (oracle/slimm_dense_mt.cpp, bench.py's cpu_baseline_mt leg) against the oracle."""
+"""The all-core dense CPU restatement (oracle/slimm_dense_mt.cpp: bench.py's cpu_baseline_mt leg and the comparator of
+the full-size GPU parity tests) against the oracle -- every per-reference column, the scalars, the direct LCA counts and
+every bin of the three coverage arrays, at sizes where the big-table paths of the configurations live (all 20 k / 50 k
+references of configs[2] / [4])."""
 import numpy as np
 import pytest
 
-from oracle.binding import dense_mt_run, run_workload
+from oracle.binding import bin_checksum, dense_mt_run, run_workload
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
+
+
+def assert_dense_equals_oracle(d, o, bins=True):
+    assert not d["no_hits"]
+    assert (d["hits"], d["matches"], d["uniq_matches"], d["uniq_matches2"], d["n_valid"]) == (
+        o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"], o.scalars["uniq_matches2"], o.scalars["n_valid"])
+    for k in ("reads_count", "uniq_reads_count", "uniq_reads_count2", "nz_cov", "nz_uniq_cov"):
+        assert np.array_equal(d[k], getattr(o, k)), k
+    assert d["lca_direct"] == o.lca_direct
+    if bins:
+        assert d["total_bins"] == o.cov.shape[0]
+        for i, k in enumerate(("cov", "uniq_cov", "uniq_cov2")):
+            assert np.array_equal(d[k], getattr(o, k)), k
+            assert d["checksums"][i] == bin_checksum(getattr(o, k)), k
 
 
 @pytest.mark.parametrize("threads", [1, 3, 8])
@@ -15,14 +32,32 @@ def test_dense_mt_equals_the_oracle(case, threads):
         w = make_workload(CONFIGS["config2"], seed=42, n_records=200_000)
     else:  # many hits per read, strain-level database: most reads keep several references
         w = make_workload(SynthConfig("deep", 150_000, 2_000, 12.0, present_frac=0.2, strain_level=True), seed=43)
-    o = run_workload(w, use_qnames=False, collect_bins=False)
-    d = dense_mt_run(w, threads=threads)
-    assert not d["no_hits"]
-    assert (d["hits"], d["matches"], d["uniq_matches"], d["uniq_matches2"], d["n_valid"]) == (
-        o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"], o.scalars["uniq_matches2"], o.scalars["n_valid"])
-    for k in ("reads_count", "uniq_reads_count", "uniq_reads_count2", "nz_cov", "nz_uniq_cov"):
-        assert np.array_equal(d[k], getattr(o, k)), k
-    assert d["lca_direct"] == o.lca_direct
+    o = run_workload(w, use_qnames=False)
+    assert_dense_equals_oracle(dense_mt_run(w, threads=threads, want_bins=True), o)
+
+
+@pytest.mark.parametrize("name,n", [("config2", 2_000_000), ("config3", 2_000_000), ("config4", 2_000_000), ("config5", 2_500_000)])
+def test_dense_mt_equals_the_oracle_on_the_full_reference_sets(name, n):
+    """>= 2 M records of each GPU configuration with ALL its references (5 k / 20 k / 20 k / 50 k; 20 - 200 M bins): the
+    comparator of the full-size GPU tests is itself pinned to the oracle where the big tables are."""
+    w = make_workload(CONFIGS[name], seed=7, n_records=n)
+    o = run_workload(w, use_qnames=False)
+    assert_dense_equals_oracle(dense_mt_run(w, threads=8, want_bins=True), o)
+
+
+def test_bin_checksum_tells_positions_apart():
+    a = np.zeros(1000, dtype=np.uint32)
+    a[10] = 3
+    b = np.zeros(1000, dtype=np.uint32)
+    b[11] = 3
+    c = a.copy()
+    c[10] = 2
+    c[500] = 1
+    assert len({bin_checksum(a), bin_checksum(b), bin_checksum(c)}) == 3
+    big = np.full(40_000_000, 0xffffffff, dtype=np.uint32)   # several pieces, wrap-around in the sum
+    want = sum(0xffffffff * (((i + 1) * 0x9E3779B97F4A7C15) % 2**64) for i in (0, 1, 39_999_999)) % 2**64
+    got = (bin_checksum(big[:2]) + (bin_checksum(big) - bin_checksum(big[:39_999_999]))) % 2**64
+    assert got == want
 
 
 def test_dense_mt_no_mapped_record():

@@ -3,6 +3,8 @@
 Bit-exact for every integer (scalars, per-reference columns, every cov / uniq_cov / uniq_cov2 bin, per-taxon counts,
 children sets, profile read counts); relative-abundance floats within 1e-6 (BASELINE.json north_star).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -641,26 +643,122 @@ def _full_size_invariants(w: Workload, s: Slimm, permutation: bool):
     return st
 
 
-def test_full_size_config2_invariants():
-    w = make_workload(CONFIGS["config2"], seed=1)            # 10 M records, 5 k refs
-    _full_size_invariants(w, run_gpu(w), permutation=True)
+def assert_equals_dense_mt(s: Slimm, d: dict, bins=None):
+    """Bit-exact at ANY size: the finished run of the HIP path against the all-core dense restatement
+    (oracle/slimm_dense_mt.cpp, itself compared with the oracle on >= 2 M records of every configuration with its full
+    reference set in tests/test_dense_mt.py): the scalars, every per-reference column, the number of valid references,
+    the direct LCA count of every taxon, and all three coverage arrays -- bin by bin, and through the position-weighted
+    64-bit checksum both sides compute on their own.  Semantics: src/slimm.hpp:219-257, 380-391, 536-557.
+    bins: the three arrays of the GPU side when they are not s.bins(k) (a group: the members' partial arrays summed)."""
+    from oracle.binding import bin_checksum
+    st = s.stats()
+    assert (st["hits_count"], st["matches_count"], st["uniq_matches_count"], st["uniq_matches_count2"], st["n_valid"]) == (
+        d["hits"] % 2**32, d["matches"] % 2**32, d["uniq_matches"] % 2**32, d["uniq_matches2"] % 2**32, d["n_valid"])
+    assert st["total_bins"] == d["total_bins"]
+    rc = s.ref_columns()
+    for k in ("reads_count", "uniq_reads_count", "uniq_reads_count2", "nz_cov", "nz_uniq_cov"):
+        assert np.array_equal(rc[k], d[k]), f"per-reference column {k} differs from the dense restatement"
+    assert int(rc["valid"].sum()) == d["n_valid"]
+    assert s.taxon_counts(0) == d["lca_direct"], "direct LCA counts differ from the dense restatement"
+    for i, k in enumerate(("cov", "uniq_cov", "uniq_cov2")):
+        got = s.bins(i) if bins is None else bins[i]
+        assert bin_checksum(got) == d["checksums"][i], f"checksum of {k} differs"
+        if k in d:
+            if not np.array_equal(got, d[k]):
+                bad = np.nonzero(got != d[k])[0]
+                raise AssertionError(f"{k}: {bad.size} bins differ, first at {bad[0]}: {got[bad[0]]} != {d[k][bad[0]]}")
+        del got
 
 
-def test_full_size_config3_invariants():
+def test_full_size_config2_bit_exact():
+    """BASELINE.json configs[1] at full size (10 M records, 5 k refs): invariants, permutation invariance through the sort
+    path, and every integer against the dense restatement."""
+    from oracle.binding import dense_mt_run
+    w = make_workload(CONFIGS["config2"], seed=1)
+    s = run_gpu(w)
+    _full_size_invariants(w, s, permutation=True)
+    assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
+
+
+def test_full_size_config3_bit_exact():
     """BASELINE.json configs[2] at full size: 100 M records, 20 k references, mean 8 hits per read."""
+    from oracle.binding import dense_mt_run
     w = make_workload(CONFIGS["config3"], seed=1)
-    st = _full_size_invariants(w, run_gpu(w), permutation=False)
+    s = run_gpu(w)
+    st = _full_size_invariants(w, s, permutation=False)
     assert st["n_records"] == 100_000_000 and st["total_bins"] > 60_000_000
+    assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
 
 
-def test_full_size_config5_invariants():
+def test_full_size_config5_bit_exact():
     """BASELINE.json configs[4] at full size: 100 M records, 50 k strain-level references, mean 40 hits per read
-    (the hash classification, two-level bucketing and deep-LCA paths at their real sizes)."""
+    (two-level bucketing, the long-run and deep-LCA paths at their real sizes)."""
+    from oracle.binding import dense_mt_run
     w = make_workload(CONFIGS["config5"], seed=1)
     s = run_gpu(w)
     st = _full_size_invariants(w, s, permutation=False)
     assert st["n_records"] == 100_000_000 and st["total_bins"] > 150_000_000
     assert len(s.taxon_counts(0)) > 100   # strain-level database: LCAs at levels 0 / 1 are frequent
+    assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
+
+
+def test_full_size_config4_one_context_and_a_group_of_four():
+    """BASELINE.json configs[3]: THE 1 B-record stream of `bench.py --config config4` (20 k refs, mean 8 hits per read;
+    100 chunks of 10 M records, each a grouped file of whole reads), (a) through one context, the chunks copied straight
+    into HBM, and (b) dealt by read over a group of four contexts (slimm_group_*: what `slimm --devices` and an 8-GPU
+    node run; on the one device of the test box the two collectives are copies) -- both bit-exact against the dense
+    restatement run on the same 1 B records on the host cores."""
+    import torch
+    from oracle.binding import dense_mt_run
+    from slimm_amd.profiler import SlimmGroup
+    from slimm_amd.synth import stream_chunks
+    cfg = CONFIGS["config4"]
+    n_stream = int(os.environ.get("SLIMM_TEST_CONFIG4_RECORDS", cfg.n_records))
+    chunk = 10_000_000
+    dev = torch.device("cuda:0")
+    host = Records(np.empty(n_stream, dtype=np.uint64), np.empty(n_stream, dtype=np.uint16),
+                   np.empty(n_stream, dtype=np.int32), np.empty(n_stream, dtype=np.int32))
+    key = torch.empty(n_stream, dtype=torch.int64, device=dev)
+    ref = torch.empty(n_stream, dtype=torch.int32, device=dev)
+    pos = torch.empty(n_stream, dtype=torch.int32, device=dev)
+    flag = torch.empty(n_stream, dtype=torch.int16, device=dev)
+    w0 = None
+    for c, wc in stream_chunks(cfg, 1, n_stream, chunk, threads=min(16, os.cpu_count() or 1)):
+        lo, hi = c * chunk, c * chunk + len(wc.records)
+        r = wc.records
+        host.read_key[lo:hi], host.flag[lo:hi], host.ref_id[lo:hi], host.begin_pos[lo:hi] = r.read_key, r.flag, r.ref_id, r.begin_pos
+        key[lo:hi] = torch.from_numpy(r.read_key.view(np.int64))
+        ref[lo:hi] = torch.from_numpy(r.ref_id)
+        pos[lo:hi] = torch.from_numpy(r.begin_pos)
+        flag[lo:hi] = torch.from_numpy(r.flag.view(np.int16))
+        if w0 is None:
+            w0 = wc
+    assert hi == n_stream
+    w = Workload(w0.ref_names, w0.ref_len, w0.taxonomy, host, w0.avg_read_len, w0.options, "config4-stream")
+    d = dense_mt_run(w, want_bins=True)
+    assert d["hits"] > 0.97 * n_stream
+    # (a) one context
+    s = Slimm.for_workload(w, device=0)
+    torch.cuda.synchronize()
+    s.set_records_device(key, ref, pos, flag)
+    assert s.get_profiles() is not None
+    assert s.stats()["n_records"] == n_stream
+    assert_equals_dense_mt(s, d)
+    profile = s.write_abundance()
+    s.close()
+    del key, ref, pos, flag
+    torch.cuda.empty_cache()
+    # (b) a group of four on the one device, the stream pushed chunk by chunk from host memory
+    g = SlimmGroup(w, [0, 0, 0, 0])
+    for lo in range(0, n_stream, chunk):
+        g.push_records(host.take(slice(lo, min(n_stream, lo + chunk))))
+    assert g.get_profiles()
+    shares = [g.member(i).stats()["n_records"] for i in range(4)]
+    assert sum(shares) == n_stream and min(shares) >= n_stream // 4 - 2 * chunk
+    summed = [sum(g.member(i).bins(k).astype(np.uint64) for i in range(4)).astype(np.uint32) for k in range(3)]
+    assert_equals_dense_mt(g.member(0), d, bins=summed)
+    assert g.member(0).write_abundance() == profile
+    g.close()
 
 
 @pytest.mark.parametrize("name,n", [("config3", 3_000_000), ("config5", 2_000_000), ("config4", 2_000_000)])

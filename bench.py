@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
-def algorithmic_bytes(st, n_records, Bp_words):
+def algorithmic_bytes(st, n_records, Bp_words, rec_bytes=16):
     """Algorithmic HBM bytes per launch of each kernel (DESIGN.md section 'Kernels and their rooflines').
 
     N records, V mapped records, P targets = distinct (read, ref) pairs, M reads, U / U2 unique reads before / after
@@ -45,8 +45,8 @@ def algorithmic_bytes(st, n_records, Bp_words):
         "sort_by_ident": 8 * (2 * 16 * V + 8 * V),   # (sort path only) 8 passes: keys+payload in and out, keys again for the histogram
         "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
         "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
-        "k_front": 18 * N + 8 * P + 16 * (N // 1024 + 1),  # every record once (key 8 + ref 4 + pos 4 + flag 2 bytes); targets (ref word
-                                                      # + bin word) and the slot descriptors out
+        "k_front": rec_bytes * N + 8 * P + 16 * (N // 1024 + 1),  # every record once (key 8 + ref 4 + pos 4 (+ flag 2) bytes);
+                                                      # targets (ref word + bin word) and the slot descriptors out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
         "k_tile_count": 4 * P,                        # gbin in
         "k_tile_scan": 12 * (B // 8192 + 1),
@@ -137,6 +137,9 @@ def main():
                          "chunks, rank r generates and keeps chunks [r C / N, (r + 1) C / N) -- cuts at read boundaries "
                          "(slimm_amd/partition.py); implied by --config config4")
     ap.add_argument("--chunk-records", type=int, default=10_000_000, help="records per chunk of the strong-scaling stream")
+    ap.add_argument("--form", default="packed", choices=["packed", "four"],
+                    help="record arrays handed to the library: 'packed' = 16 B/record (slimm_set_records_device_packed: key with "
+                         "the three flag bits folded in, ref, pos), 'four' = 18 B/record (key, ref, pos, flag)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-rank code path (process group, collectives) even with one rank")
     args = ap.parse_args()
@@ -217,10 +220,26 @@ def main():
 
     phase_times = {} if args.breakdown else None
 
+    def to_packed(k, f):
+        """slimm_pack_key on device tensors: (key & (2^61 - 1)) | mate << 61 | unmapped << 63 (what a decoder writes)."""
+        f = f.to(torch.int64) & 0xffff
+        mate = torch.where((f & 0x40) != 0, 1, torch.where((f & 0x80) != 0, 2, 0)).to(torch.int64)
+        return (k & ((1 << 61) - 1)) | (mate << 61) | (((f & 0x4) != 0).to(torch.int64) << 63)
+
+    pkey = None
+    if args.form == "packed":
+        pkey = to_packed(key, flag)
+        del key, flag   # (the packed form needs neither)
+        key = flag = None
+        torch.cuda.synchronize()
+
     def step():
         eng.reset()
         eng.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
-        eng.set_records_device(key, ref, pos, flag)
+        if pkey is not None:
+            eng.set_records_device_packed(pkey, ref, pos)
+        else:
+            eng.set_records_device(key, ref, pos, flag)
         return sharded_profile(eng, dev, out_path, phase_times=phase_times, exchange=args.exchange)
 
     def barrier():
@@ -284,7 +303,7 @@ def main():
             Bp = int(stats["total_bins"])  # (the padded count is a property of the buffer, which is not exposed here)
         else:
             Bp = int(engine.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
-        model = algorithmic_bytes(stats, n_records, Bp)
+        model = algorithmic_bytes(stats, n_records, Bp, 16 if args.form == "packed" else 18)
         per_kernel = {}
         for name, (ms, launches) in kt.items():
             if launches and name in model:
@@ -389,12 +408,17 @@ def main():
             r3 = torch.from_numpy(w3.records.ref_id).to(dev)
             p3 = torch.from_numpy(w3.records.begin_pos).to(dev)
             f3 = torch.from_numpy(w3.records.flag.view(np.int16)).to(dev)
+            if args.form == "packed":
+                k3 = to_packed(k3, f3)
             torch.cuda.synchronize()
 
             def step3():
                 eng3.reset()
                 eng3.reset_cutoffs()
-                eng3.set_records_device(k3, r3, p3, f3)
+                if args.form == "packed":
+                    eng3.set_records_device_packed(k3, r3, p3)
+                else:
+                    eng3.set_records_device(k3, r3, p3, f3)
                 return eng3.get_profiles(path=out_path)
 
             eng3.enable_kernel_timing(True)

@@ -113,6 +113,21 @@ int slimm_push_records(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* 
  * the sort).  Checked and unchecked pushes do not mix within a file. */
 int slimm_push_records_checked(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
                                const uint16_t* flag, const uint32_t* check, uint64_t n);
+/* The lean form of the same stream: 16 bytes per record.  Of `flag` the record loop reads three bits -- unmapped
+ * (src/slimm.hpp:197) and first / last in pair (src/slimm.hpp:205-208) -- and they ride in the key's top three bits:
+ *   packed_key = (read_key & (2^61 - 1)) | mate << 61 | unmapped << 63,   mate = 1 (flag & 0x40), 2 (flag & 0x80), else 0
+ * (slimm_pack_key / slimm_pack_keys do it; the identity of a qName is then its low 61 bits).  No flag array crosses the
+ * bus or is read by the front end: 11 % fewer bytes on both.  Packed, unpacked and checked pushes do not mix within a
+ * file.  slimm_push_records_packed_async is the streamed form (as slimm_push_records_async: the arrays must stay
+ * unchanged until slimm_push_wait), slimm_set_records_device_packed the borrowed-device-arrays form. */
+uint64_t slimm_pack_key(uint64_t read_key, uint16_t flag);
+void slimm_pack_keys(const uint64_t* read_key, const uint16_t* flag, uint64_t n, uint64_t* packed_key);
+int slimm_push_records_packed(slimm_ctx* ctx, const uint64_t* packed_key, const int32_t* ref_id, const int32_t* begin_pos,
+                              uint64_t n);
+int slimm_push_records_packed_async(slimm_ctx* ctx, const uint64_t* packed_key, const int32_t* ref_id,
+                                    const int32_t* begin_pos, uint64_t n);
+int slimm_set_records_device_packed(slimm_ctx* ctx, const uint64_t* d_packed_key, const int32_t* d_ref_id,
+                                    const int32_t* d_begin_pos, uint64_t n);
 /* Streamed ingest.  slimm_push_records_async enqueues the copies on the context's copy stream and returns at once:
  * the arrays must stay unchanged until slimm_push_wait() returns (page-locked arrays are read by the DMA engine
  * directly; pageable ones still work, at the speed of the runtime's own staging).  slimm_analyze_alignments() is
@@ -128,6 +143,9 @@ int slimm_push_wait(slimm_ctx* ctx);
 int slimm_staging_buffers(slimm_ctx* ctx, uint32_t which, uint64_t capacity, uint64_t** read_key, int32_t** ref_id,
                           int32_t** begin_pos, uint16_t** flag);
 int slimm_push_staged_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
+/* The same for a set whose key array the producer filled with PACKED keys (slimm_pack_key; the set's flag array is not
+ * read): 16 bytes per record over the bus. */
+int slimm_push_staged_packed_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
 int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
 /* Use records already resident in device memory, without copying; the arrays must stay valid and unchanged
  * until slimm_reset().  Replaces anything pushed before. */

@@ -91,6 +91,12 @@ SYMBOLS = [
     ("slimm_set_stream_ordered", C.c_int, [_P, C.c_int]),
     ("slimm_push_records_checked", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_push_records_async", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
+    ("slimm_pack_key", C.c_uint64, [C.c_uint64, C.c_uint16]),
+    ("slimm_pack_keys", None, [_P, _P, C.c_uint64, _P]),
+    ("slimm_push_records_packed", C.c_int, [_P, _P, _P, _P, C.c_uint64]),
+    ("slimm_push_records_packed_async", C.c_int, [_P, _P, _P, _P, C.c_uint64]),
+    ("slimm_set_records_device_packed", C.c_int, [_P, _P, _P, _P, C.c_uint64]),
+    ("slimm_push_staged_packed_async", C.c_int, [_P, C.c_uint32, C.c_uint64]),
     ("slimm_push_wait", C.c_int, [_P]),
     ("slimm_staging_buffers", C.c_int, [_P, C.c_uint32, C.c_uint64, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                         C.POINTER(_P)]),

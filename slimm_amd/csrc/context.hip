@@ -126,6 +126,9 @@ struct slimm_ctx {
     DevBuf<uint16_t> in_flag;
     DevBuf<uint32_t> in_check;     // slimm_push_records_checked: a second hash of every record's read name
     bool has_check = false;        // ... all pushed batches carry one (checked and unchecked pushes do not mix)
+    bool packed = false;           // slimm_push_records_packed: 16 bytes per record, no flag array (forms do not mix)
+    DevBuf<uint64_t> un_key;       // record_order = ANY with packed records: the four-array form for the compaction
+    DevBuf<uint16_t> un_flag;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
     uint64_t n_pushed = 0;
@@ -553,6 +556,7 @@ int slimm_reset(slimm_ctx* c) {
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;
     c->has_check = false;
+    c->packed = false;
     c->borrowed = false;
     c->rec = DeviceRecords();
     c->local_V = c->local_M = c->local_P = 0;
@@ -595,7 +599,7 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
     HIP_TRY(c, k.ensure(cap));
     HIP_TRY(c, r.ensure(cap));
     HIP_TRY(c, p.ensure(cap));
-    HIP_TRY(c, f.ensure(cap));
+    if (!c->packed) HIP_TRY(c, f.ensure(cap));
     DevBuf<uint32_t> ck;
     if (c->has_check || c->n_pushed == 0) HIP_TRY(c, ck.ensure(cap));
     if (c->n_pushed && c->has_check)
@@ -604,7 +608,7 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
         HIP_TRY(c, hipMemcpyAsync(k.p, c->in_key.p, c->n_pushed * 8, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(r.p, c->in_ref.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(p.p, c->in_pos.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(f.p, c->in_flag.p, c->n_pushed * 2, hipMemcpyDeviceToDevice, c->stream));
+        if (!c->packed) HIP_TRY(c, hipMemcpyAsync(f.p, c->in_flag.p, c->n_pushed * 2, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     std::swap(c->in_key.p, k.p);
@@ -613,8 +617,10 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
     std::swap(c->in_ref.cap, r.cap);
     std::swap(c->in_pos.p, p.p);
     std::swap(c->in_pos.cap, p.cap);
-    std::swap(c->in_flag.p, f.p);
-    std::swap(c->in_flag.cap, f.cap);
+    if (!c->packed) {
+        std::swap(c->in_flag.p, f.p);
+        std::swap(c->in_flag.cap, f.cap);
+    }
     std::swap(c->in_check.p, ck.p);
     std::swap(c->in_check.cap, ck.cap);
     return SLIMM_OK;
@@ -627,8 +633,10 @@ int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
     if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
+    if (c->packed) return fail(c, SLIMM_E_INVALID, "earlier batches were packed records: the forms do not mix within a file");
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
+    if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));  // (only ever at a file's first push)
     const uint64_t o = c->n_pushed;
     HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -655,10 +663,12 @@ int slimm_push_records_checked(slimm_ctx* c, const uint64_t* key, const int32_t*
     if (!key || !ref || !pos || !flag || !check) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
     if (c->n_pushed && !c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried no check words");
+    if (c->packed) return fail(c, SLIMM_E_INVALID, "earlier batches were packed records: the forms do not mix within a file");
     c->has_check = true;
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     HIP_TRY(c, c->in_check.ensure(c->in_key.cap));
+    if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));
     const uint64_t o = c->n_pushed;
     HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -687,8 +697,10 @@ int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* r
     if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
     if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
+    if (c->packed) return fail(c, SLIMM_E_INVALID, "earlier batches were packed records: the forms do not mix within a file");
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
+    if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));
     const uint64_t o = c->n_pushed;
     HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->copy_stream));
@@ -703,6 +715,52 @@ int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* r
     c->rec.flag = c->in_flag.p;
     c->rec.n = static_cast<uint32_t>(c->n_pushed);
     return SLIMM_OK;
+}
+
+// 16 bytes per record: the three flag bits the record loop reads ride in the key (slimm_pack_key); no flag array crosses
+// the bus or is read by the front end.  on_copy_stream: the asynchronous form (slimm_push_records_packed_async).
+static int push_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n, bool on_copy_stream) {
+    if (!c) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!key || !ref || !pos) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->has_check || (c->n_pushed && !c->packed))
+        return fail(c, SLIMM_E_INVALID, "earlier batches were not packed records: the forms do not mix within a file");
+    c->packed = true;
+    int rc = slimm_reserve(c, c->n_pushed + n);
+    if (rc != SLIMM_OK) return rc;
+    const uint64_t o = c->n_pushed;
+    hipStream_t st = on_copy_stream ? c->copy_stream : c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, st));
+    if (on_copy_stream) {
+        HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
+        c->copy_pending = true;
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may reuse its buffers on return
+    }
+    c->n_pushed += n;
+    c->rec.key = c->in_key.p;
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.flag = nullptr;
+    c->rec.packed = true;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    return SLIMM_OK;
+}
+int slimm_push_records_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
+    return push_packed(c, key, ref, pos, n, false);
+}
+int slimm_push_records_packed_async(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
+    return push_packed(c, key, ref, pos, n, true);
+}
+uint64_t slimm_pack_key(uint64_t read_key, uint16_t flag) {  // src/slimm.hpp:197 (unmapped), :205-208 (mate number)
+    const uint64_t mate = (flag & 0x40u) ? 1u : ((flag & 0x80u) ? 2u : 0u);
+    return (read_key & ((1ull << 61) - 1ull)) | (mate << 61) | (static_cast<uint64_t>((flag & 0x4u) != 0u) << 63);
+}
+void slimm_pack_keys(const uint64_t* read_key, const uint16_t* flag, uint64_t n, uint64_t* packed) {
+    for (uint64_t i = 0; i < n; ++i) packed[i] = slimm_pack_key(read_key[i], flag[i]);
 }
 
 int slimm_push_wait(slimm_ctx* c) {
@@ -748,6 +806,18 @@ int slimm_push_staged_async(slimm_ctx* c, uint32_t which, uint64_t n) {
     return SLIMM_OK;
 }
 
+int slimm_push_staged_packed_async(slimm_ctx* c, uint32_t which, uint64_t n) {  // the set's key array holds packed keys
+    if (!c || which > 1) return SLIMM_E_INVALID;
+    slimm_ctx::Staging& sg = c->staging[which];
+    if (n > sg.key.cap) return fail(c, SLIMM_E_INVALID, "more records than the staging set holds");
+    if (n == 0) return SLIMM_OK;
+    int rc = push_packed(c, sg.key.p, sg.ref.p, sg.pos.p, n, true);
+    if (rc != SLIMM_OK) return rc;
+    HIP_TRY(c, hipEventRecord(sg.done, c->copy_stream));
+    sg.pending = true;
+    return SLIMM_OK;
+}
+
 int slimm_staging_wait(slimm_ctx* c, uint32_t which) {
     if (!c || which > 1) return SLIMM_E_INVALID;
     slimm_ctx::Staging& sg = c->staging[which];
@@ -771,6 +841,24 @@ int slimm_set_records_device(slimm_ctx* c, const uint64_t* key, const int32_t* r
     c->rec.flag = flag;
     c->rec.n = static_cast<uint32_t>(n);
     c->n_pushed = n;
+    c->borrowed = true;
+    return SLIMM_OK;
+}
+
+int slimm_set_records_device_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
+    if (n && (!key || !ref || !pos)) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    c->rec = DeviceRecords();
+    c->rec.key = key;
+    c->rec.ref = ref;
+    c->rec.pos = pos;
+    c->rec.packed = true;
+    c->rec.n = static_cast<uint32_t>(n);
+    c->n_pushed = n;
+    c->packed = true;
     c->borrowed = true;
     return SLIMM_OK;
 }
@@ -816,10 +904,19 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     const uint32_t half_read = hc.avg_read_len / 2;
     const uint32_t nslots = front_slots(n);
     if (c->order == SLIMM_ORDER_ANY) {
+        DeviceRecords four = c->rec;
+        if (c->rec.packed) {  // the compaction reads the four-array form
+            HIP_TRY(c, c->un_key.ensure(n + 1));
+            HIP_TRY(c, c->un_flag.ensure(n + 1));
+            launch_unpack_records(st, c->rec.key, n, c->un_key.p, c->un_flag.p);
+            four.key = c->un_key.p;
+            four.flag = c->un_flag.p;
+            four.packed = false;
+        }
         // compaction of the mapped records, then a stable sort by read identity makes every read a contiguous run
         {
             KernelTimer t(c, K_VALID_COUNT);
-            launch_valid_count(st, c->rec, c->R, c->tile_cnt.p, c->counters.p);
+            launch_valid_count(st, four, c->R, c->tile_cnt.p, c->counters.p);
         }
         {
             KernelTimer t(c, K_SCAN);
@@ -827,7 +924,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_COMPACT);
-            launch_compact(st, c->rec, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width,
+            launch_compact(st, four, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width,
                            c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->c_chk.p);
         }
         {

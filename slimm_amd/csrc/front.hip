@@ -97,6 +97,51 @@ __device__ __forceinline__ uint64_t f_first_after(uint64_t starts, uint64_t bits
     return (ones + starts) & ~ones & bits;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// First occurrence of a key among the lanes of a wave -- and among everything the table has seen since it was cleared --
+// in a handful of LDS operations, whatever the number of equal keys: the duplicate test of Q1 (src/read_stat.hpp:125-131)
+// for segments too long for the lane-shift walk (one step per record of the longest segment) and for runs of 64 records
+// or more (where the walk is quadratic in the run length).  The wave's own table of kHashSlots {key, first position}
+// entries in LDS: a lane claims the entry of its key by compare-and-swap from "empty" (linear probing), every lane of a
+// key then lowers the entry's position to its own (ds_min), and the one lane that reads its own position back is the
+// first record of that (read, reference) pair in file order.  No barrier: one wave, and the LDS executes a wave's
+// operations in order.  (The ballots between the steps are what the host emulator of tests/native synchronises its
+// lanes on; on the GPU they are the loop test and a compare.)
+constexpr uint32_t kHashBits = 7;
+constexpr uint32_t kHashSlots = 1u << kHashBits;   // 128 entries of 8 bytes: 1 KB per wave, half full at 64 keys
+__device__ __forceinline__ void hash_clear(uint32_t* tab, uint32_t lane) {
+    reinterpret_cast<uint4*>(tab)[lane] = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);  // 64 lanes x 2 entries
+}
+// key != 0; `pos` = the lane's position in file order among everything inserted since hash_clear.  Returns whether the
+// lane is the first of its key; overflow: the table is full (more than kHashSlots distinct keys) -- the caller falls
+// back to the comparison walk.
+__device__ __forceinline__ bool hash_first(uint32_t* tab, uint32_t key, uint32_t pos, bool active, bool& overflow) {
+    uint2* const e = reinterpret_cast<uint2*>(tab);
+    uint32_t slot = (key * 0x9E3779B1u) >> (32u - kHashBits);
+    bool pending = active;
+    uint32_t probes = 0;
+    while (f_ballot(pending) != 0ull) {
+        if (pending) {
+            const uint32_t old = atomicCAS(&e[slot].x, 0u, key);
+            if ((old == 0u) | (old == key)) {
+                pending = false;
+            } else {
+                slot = (slot + 1u) & (kHashSlots - 1u);
+                if (++probes == kHashSlots) {
+                    overflow = true;
+                    pending = false;
+                    active = false;
+                }
+            }
+        }
+    }
+    if (active) atomicMin(&e[slot].y, pos);
+    const bool lowered = f_ballot(active) != 0ull;  // (every lane's minimum is in before any lane reads)
+    const uint32_t got = (active & lowered) ? __hip_atomic_load(&e[slot].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xffffffffu;
+    return active && got == pos;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -119,7 +164,12 @@ __device__ __forceinline__ T f_load_at(const T* uniform_base, uint32_t byte_off)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(uniform_base) + byte_off);
 }
 
-struct FrontRaw {
+// kPacked: 16 bytes per record -- the flag bits the path reads ride in the key's top three bits (bit 63: unmapped,
+// src/slimm.hpp:197; bits 62-61: mate number 0 / 1 / 2, src/slimm.hpp:205-208), the qName identity is the low 61 bits and
+// there is no flag array (slimm_push_records_packed).
+template <bool kPacked>
+struct FrontRawT {
+    static constexpr uint32_t kHiMask = kPacked ? 0x1fffffffu : 0x3fffffffu;  // identity bits of a key's high word
     const uint64_t* key;
     const int32_t* ref;
     const int32_t* pos;
@@ -133,9 +183,12 @@ struct FrontRaw {
     __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
         const uint64_t k = key[i];
         lo = static_cast<uint32_t>(k);
-        hi = static_cast<uint32_t>(k >> 32) & 0x3fffffffu;
+        hi = static_cast<uint32_t>(k >> 32) & kHiMask;
     }
     __device__ FrontRaw3 raw(uint32_t i) const {
+        if (kPacked)
+            return FrontRaw3{reinterpret_cast<const uint32_t*>(key)[2 * static_cast<size_t>(i) + 1], static_cast<uint32_t>(ref[i]),
+                             static_cast<uint32_t>(pos[i])};
         return FrontRaw3{flag[i], static_cast<uint32_t>(ref[i]), static_cast<uint32_t>(pos[i])};
     }
     // ---- the staging loop's view: record base + rel (base wave-uniform)
@@ -143,7 +196,7 @@ struct FrontRaw {
         const uint2 k = f_load_at(reinterpret_cast<const uint2*>(key) + base, rel * 8u);
         o.klo = k.x;
         o.khi = k.y;  // (nothing but loads here: key_fix below, once the whole group is on its way)
-        o.a = f_load_at(flag + base, rel * 2u);
+        o.a = kPacked ? k.y : static_cast<uint32_t>(f_load_at(flag + base, rel * 2u));
         o.b = static_cast<uint32_t>(f_load_at(ref + base, rel * 4u));
         o.c = static_cast<uint32_t>(f_load_at(pos + base, rel * 4u));
     }
@@ -152,29 +205,38 @@ struct FrontRaw {
         lo = k.x;
         hi = k.y;
     }
-    __device__ static void key_fix(uint32_t&, uint32_t& hi) { hi &= 0x3fffffffu; }  // qName identity: 62 bits
+    __device__ static void key_fix(uint32_t&, uint32_t& hi) { hi &= kHiMask; }  // qName identity: 62 (61) bits
     __device__ uint32_t load_check(uint32_t base, uint32_t rel) const { return f_load_at(check + base, rel * 4u); }
-    __device__ static void no_key(uint32_t& lo, uint32_t& hi) {  // differs from every key (bit 62 is not significant)
+    __device__ static void no_key(uint32_t& lo, uint32_t& hi) {  // differs from every key (no identity bit)
         lo = 0u;
-        hi = 0x40000000u;
+        hi = kHiMask + 1u;
     }
     __device__ uint2 geo_at(const FrontLoaded& w) const { return f_load_at(geo, (w.b < n_refs ? w.b : 0u) * 8u); }
     // field = reference + 1 of a mapped record (src/slimm.hpp:197), kRefField otherwise; mate: src/slimm.hpp:205-208
     __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, bool& bad) const {
-        const bool aligned = (w.a & 0x4u) == 0u;
+        const bool aligned = kPacked ? (static_cast<int32_t>(w.a) >= 0) : ((w.a & 0x4u) == 0u);
         const uint32_t r1 = w.b + 1u;
         bad = bad || (aligned && r1 > n_refs);  // neither -1 nor a reference
         field = (aligned && w.b < n_refs) ? r1 : kRefField;
-        const uint32_t c = (w.a >> 6) & 3u;     // first-in-pair wins over last-in-pair
-        mate = c == 3u ? 1u : c;
+        if (kPacked) {
+            mate = (w.a >> 29) & 3u;
+        } else {
+            const uint32_t c = (w.a >> 6) & 3u;     // first-in-pair wins over last-in-pair
+            mate = c == 3u ? 1u : c;
+        }
     }
     __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2& g) const {
         return g.y + div_bin_width(min(w.c + half_read, g.x));
     }
     __device__ FrontRec decode(const FrontRaw3& w, bool& bad) const {
         FrontRec o;
-        o.mate = (w.a & 0x40u) ? 1u : ((w.a & 0x80u) ? 2u : 0u);                // src/slimm.hpp:205-208
-        o.mapped = !(w.a & 0x4u) && w.b != 0xffffffffu;                          // src/slimm.hpp:197
+        if (kPacked) {
+            o.mate = (w.a >> 29) & 3u;
+            o.mapped = static_cast<int32_t>(w.a) >= 0 && w.b != 0xffffffffu;
+        } else {
+            o.mate = (w.a & 0x40u) ? 1u : ((w.a & 0x80u) ? 2u : 0u);            // src/slimm.hpp:205-208
+            o.mapped = !(w.a & 0x4u) && w.b != 0xffffffffu;                      // src/slimm.hpp:197
+        }
         if (o.mapped && w.b >= n_refs) {
             bad = true;
             o.mapped = false;
@@ -198,6 +260,8 @@ struct FrontRaw {
         return g.y + div_bin_width(min(r.aux + half_read, g.x));
     }
 };
+using FrontRaw = FrontRawT<false>;
+using FrontPacked = FrontRawT<true>;
 
 struct FrontSorted {
     const uint64_t* ident;  // key << 2 | mate
@@ -258,31 +322,62 @@ struct Staged {
     bool mapped;
 };
 
+// Segments longer than this take the hash table in window_fast (a walk step is two vector and two scalar instructions,
+// the table about fifty instructions and four LDS round trips whatever the segments look like)
+#ifndef SLIMM_HASH_WALK
+#define SLIMM_HASH_WALK 16
+#endif
+constexpr uint32_t kHashWalk = SLIMM_HASH_WALK;
+// D = N0 & (N0 << 1) marks the second and later lanes of every stretch of set bits of N0 (non-start lanes: a segment of
+// L records is a stretch of L - 1).  Is there a stretch of D of at least n bits (a segment of more than n + 1 records)?
+__device__ __forceinline__ bool has_run_of(uint64_t D, uint32_t n) {
+    // stretches of >= 2^k bits by doubling, then the remainder
+    uint64_t x = D;
+    uint32_t have = 1;
+    while (have * 2u <= n) {
+        x &= x << have;
+        have *= 2u;
+    }
+    if (have < n) x &= x << (n - have);
+    return x != 0ull;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  field = the staged reference field,
 // SS = segment starts (run starts and mate changes), V = mapped lanes, both inside [0, X).
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint32_t lane, uint64_t SS, uint64_t V, uint32_t X,
-                                            WinOut& so, uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin) {
+                                            WinOut& so, uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
+                                            uint32_t* tab) {
     // Q1: an earlier lane of my segment with my reference?  T = {segment number, field} is never zero and equal only
     // inside a segment; x_d[i] = T[i - d] ^ T[i] (T of the lanes in front of lane 0 taken as zero) follows from
     // x_{d+1}[i] = x_d[i - 1] ^ x_1[i]: ONE xor with a lane shift per step.  A lane is a duplicate iff some x_d is zero.
     // Steps beyond a lane's own segment compare it with other segments' words -- never equal, so nothing guards them;
     // the trip count follows the longest segment of THIS window (scalar: D = lanes at least d behind their start).
+    // A window with a segment of more than kHashWalk records takes the hash table instead: the walk's trip count is the
+    // longest segment, the table's cost is the same whatever the segments look like (config 5, 40 hits per read: every
+    // window; config 3, 8 hits per read: one window in three).
     const uint32_t T = (f_rank(SS >> 1) << kTagShift) | field;
-    const uint32_t x1 = f_shr1z(T) ^ T;
-    uint32_t x = x1, differ = x1;
     const uint64_t N0 = ~SS & f_below(X);
     uint64_t D = N0 & (N0 << 1);
-    while (D) {
+    uint64_t F;
+    if (has_run_of(D, kHashWalk - 1u)) {
+        hash_clear(tab, lane);
+        bool overflow = false;  // (never: 64 keys at most)
+        F = f_ballot(hash_first(tab, T, lane, f_bit(V), overflow));
+    } else {
+        const uint32_t x1 = f_shr1z(T) ^ T;
+        uint32_t x = x1, differ = x1;
+        while (D) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            x = f_shr1z(x) ^ x1;
-            differ = min(differ, x);
-            D &= D << 1;
+            for (int u = 0; u < 4; ++u) {
+                x = f_shr1z(x) ^ x1;
+                differ = min(differ, x);
+                D &= D << 1;
+            }
         }
+        F = f_ballot(differ != 0u) & V;
     }
-    const uint64_t F = f_ballot(differ != 0u) & V;
     // heads: the first mapped lane of every segment; the last lane of a segment stops the carry of its start
     const uint64_t H = f_first_after(SS, V, (SS >> 1) | (1ull << (X - 1u)));
     // unique reads: a head whose NEXT target is a head again (or there is none in the window: the next run's first
@@ -360,7 +455,7 @@ __device__ __forceinline__ void window_general(const Staged& rec, uint32_t lane,
 template <bool kChk, typename Acc>
 __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint32_t N, uint32_t lane, WinOut& so,
                                           uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin, bool& bad,
-                                          bool& collide) {
+                                          bool& collide, uint32_t* tab) {
     // 1. where the run ends, whether its mates ever decrease
     uint32_t klo0, khi0;
     acc.key_at(pos, klo0, khi0);
@@ -385,72 +480,99 @@ __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint3
         end += n_in;
         if (!whole) break;
     }
-    // 2. one pass for all mates when they never decrease (reads are contiguous), one pass per mate otherwise
-    uint32_t nv_run = 0;
-    for (uint32_t pass = 0; pass < (decreasing ? 3u : 1u); ++pass) {
-        uint32_t head_seen = 0;                        // bit m: a mapped record with mate m came by
-        uint32_t n_first[3] = {0u, 0u, 0u};            // targets per mate
-        uint32_t head_p[3] = {0u, 0u, 0u}, head_g[3] = {0u, 0u, 0u};  // where each mate's head went, its bin word
-        for (uint32_t cb = pos; cb < end; cb += 64u) {
-            const uint32_t i = cb + lane;
-            const bool in_run = i < end;
-            const FrontRec r = acc.rec(in_run ? i : end - 1u, bad);
-            const bool use = in_run && r.mapped && (!decreasing || r.mate == pass);
-            const uint32_t T = use ? ((r.mate << 28) | r.ref) : (0xc0000000u | lane);
-            if (pass == 0) nv_run += static_cast<uint32_t>(__popcll(f_ballot(in_run && r.mapped)));
-            uint32_t differ = kNoMatch;
-            {   // earlier lanes of this chunk
-                uint32_t Ts = T;
-                for (uint32_t d = 1; d < 64u; ++d) {
-                    Ts = f_shr1(Ts, kNoMatch);
-                    differ = min(differ, Ts ^ T);
+    // 2. one pass for all mates when they never decrease (reads are contiguous), one pass per mate otherwise.
+    // First of its (read, reference)?  Through the wave's hash table (the run's keys {mate, reference} stay in it from
+    // chunk to chunk: constant work per chunk); a run with more distinct pairs than the table holds starts again with
+    // the comparison walk -- every chunk against its own earlier lanes (shift) and all earlier chunks (64 rotations
+    // each), quadratic in the run length but without any limit on it.
+    const WinOut so_at_run = so;
+    bool hashed = true;
+    uint32_t nv_run;
+    bool again;
+    do {
+        again = false;
+        so = so_at_run;
+        nv_run = 0;
+        for (uint32_t pass = 0; pass < (decreasing ? 3u : 1u) && !again; ++pass) {
+            uint32_t head_seen = 0;                        // bit m: a mapped record with mate m came by
+            uint32_t n_first[3] = {0u, 0u, 0u};            // targets per mate
+            uint32_t head_p[3] = {0u, 0u, 0u}, head_g[3] = {0u, 0u, 0u};  // where each mate's head went, its bin word
+            if (hashed) hash_clear(tab, lane);
+            for (uint32_t cb = pos; cb < end; cb += 64u) {
+                const uint32_t i = cb + lane;
+                const bool in_run = i < end;
+                const FrontRec r = acc.rec(in_run ? i : end - 1u, bad);
+                const bool use = in_run && r.mapped && (!decreasing || r.mate == pass);
+                if (pass == 0) nv_run += static_cast<uint32_t>(__popcll(f_ballot(in_run && r.mapped)));
+                bool first;
+                if (hashed) {
+                    bool overflow = false;
+                    first = hash_first(tab, (r.mate << 28) | (r.ref + 1u), i - pos, use, overflow);
+                    if (f_ballot(overflow) != 0ull) {  // more distinct (mate, reference) pairs than the table holds
+                        hashed = false;
+                        again = true;
+                        break;
+                    }
+                } else {
+                    const uint32_t T = use ? ((r.mate << 28) | r.ref) : (0xc0000000u | lane);
+                    uint32_t differ = kNoMatch;
+                    {   // earlier lanes of this chunk
+                        uint32_t Ts = T;
+                        for (uint32_t d = 1; d < 64u; ++d) {
+                            Ts = f_shr1(Ts, kNoMatch);
+                            differ = min(differ, Ts ^ T);
+                        }
+                    }
+                    for (uint32_t eb = pos; eb < cb; eb += 64u) {  // every earlier chunk, all rotations
+                        bool b = false;
+                        const FrontRec e = acc.rec(eb + lane, b);
+                        uint32_t Te = e.mapped ? ((e.mate << 28) | e.ref) : 0xe0000000u;
+                        for (uint32_t d = 0; d < 64u; ++d) {
+                            differ = min(differ, Te ^ T);
+                            Te = f_ror1(Te);
+                        }
+                    }
+                    first = use && differ != 0u;
                 }
-            }
-            for (uint32_t eb = pos; eb < cb; eb += 64u) {  // every earlier chunk, all rotations
-                bool b = false;
-                const FrontRec e = acc.rec(eb + lane, b);
-                uint32_t Te = e.mapped ? ((e.mate << 28) | e.ref) : 0xe0000000u;
-                for (uint32_t d = 0; d < 64u; ++d) {
-                    differ = min(differ, Te ^ T);
-                    Te = f_ror1(Te);
-                }
-            }
-            const bool first = use && differ != 0u;
-            const uint64_t F = f_ballot(first);
-            // heads: per mate the first mapped lane, unless an earlier chunk had one
-            uint64_t H = 0;
+                const uint64_t F = f_ballot(first);
+                // heads: per mate the first mapped lane, unless an earlier chunk had one
+                uint64_t H = 0;
 #pragma unroll
-            for (uint32_t m = 0; m < 3u; ++m) {
-                const uint64_t Vm = f_ballot(use && r.mate == m);
-                if (Vm && !((head_seen >> m) & 1u)) {
-                    H |= 1ull << __builtin_ctzll(Vm);
-                    head_seen |= 1u << m;
+                for (uint32_t m = 0; m < 3u; ++m) {
+                    const uint64_t Vm = f_ballot(use && r.mate == m);
+                    if (Vm && !((head_seen >> m) & 1u)) {
+                        H |= 1ull << __builtin_ctzll(Vm);
+                        head_seen |= 1u << m;
+                    }
+                    n_first[m] += static_cast<uint32_t>(__popcll(f_ballot(first && r.mate == m)));
                 }
-                n_first[m] += static_cast<uint32_t>(__popcll(f_ballot(first && r.mate == m)));
+                const bool head = f_bit(H);
+                const uint32_t p = so.base + so.nf + f_rank(F);
+                const FrontRaw3 rw{0u, first ? r.ref : 0u, 0u};
+                const uint32_t g = first ? acc.gbin(r, acc.geo_of(rw)) : 0u;
+                if (first) {
+                    tgt_ref[p] = r.ref | (head ? 0x80000000u : 0u);
+                    if (!head) tgt_gbin[p] = g;  // a head's bin word waits for the end of the run (unique or not)
+                }
+                uint64_t Hm = H;
+                while (Hm) {
+                    const uint32_t hl = static_cast<uint32_t>(__builtin_ctzll(Hm));
+                    Hm &= Hm - 1ull;
+                    const uint32_t m = __builtin_amdgcn_readlane(r.mate, hl);
+                    head_p[m] = __builtin_amdgcn_readlane(p, hl);
+                    head_g[m] = __builtin_amdgcn_readlane(g, hl);
+                }
+                so.nf += static_cast<uint32_t>(__popcll(F));
+                so.nh += static_cast<uint32_t>(__popcll(H));
             }
-            const bool head = f_bit(H);
-            const uint32_t p = so.base + so.nf + f_rank(F);
-            const FrontRaw3 rw{0u, first ? r.ref : 0u, 0u};
-            const uint32_t g = first ? acc.gbin(r, acc.geo_of(rw)) : 0u;
-            if (first) {
-                tgt_ref[p] = r.ref | (head ? 0x80000000u : 0u);
-                if (!head) tgt_gbin[p] = g;  // a head's bin word waits for the end of the run (unique or not)
+            if (!again) {
+#pragma unroll
+                for (uint32_t m = 0; m < 3u; ++m)
+                    if (((head_seen >> m) & 1u) && lane == 0u)
+                        tgt_gbin[head_p[m]] = head_g[m] | (n_first[m] == 1u ? 0x80000000u : 0u);
             }
-            uint64_t Hm = H;
-            while (Hm) {
-                const uint32_t hl = static_cast<uint32_t>(__builtin_ctzll(Hm));
-                Hm &= Hm - 1ull;
-                const uint32_t m = __builtin_amdgcn_readlane(r.mate, hl);
-                head_p[m] = __builtin_amdgcn_readlane(p, hl);
-                head_g[m] = __builtin_amdgcn_readlane(g, hl);
-            }
-            so.nf += static_cast<uint32_t>(__popcll(F));
-            so.nh += static_cast<uint32_t>(__popcll(H));
         }
-#pragma unroll
-        for (uint32_t m = 0; m < 3u; ++m)
-            if (((head_seen >> m) & 1u) && lane == 0u) tgt_gbin[head_p[m]] = head_g[m] | (n_first[m] == 1u ? 0x80000000u : 0u);
-    }
+    } while (again);
     so.nv += nv_run;
     return end;
 }
@@ -562,12 +684,14 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
                                                        uint4* __restrict__ slots, uint2* __restrict__ wcut) {
     __shared__ uint32_t s_stage[kFrontBlock / 64][2][kStageRecs];
+    __shared__ __attribute__((aligned(16))) uint32_t s_tab[kFrontBlock / 64][2 * kHashSlots];  // hash_first's table, one per wave
     const uint32_t N = acc.count(counters);
     const uint32_t lane = f_lane();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * (kFrontBlock / 64);
     uint32_t* const st1 = s_stage[wave][0];
     uint32_t* const st2 = s_stage[wave][1];
+    uint32_t* const tab = s_tab[wave];
     bool bad = false, collide = false;
     for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint32_t B = slot * kSlotRecs;
@@ -609,12 +733,12 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                     const uint32_t mprev = f_shr1z(mate);
                     const uint64_t V = f_ballot(field != kRefField) & PR;
                     if ((f_ballot(mate < mprev) & ~RS & PR) == 0ull)
-                        window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin);
+                        window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin, tab);
                     else
                         window_general(Staged{mate, field - 1u, w2, f_bit(V)}, lane, RS, V, X, so, tgt_ref, tgt_gbin);
                     off += X;
                 } else {  // a run of 64 records or more: from global memory, at its own pace
-                    const uint32_t end = long_run<kChk>(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad, collide);
+                    const uint32_t end = long_run<kChk>(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad, collide, tab);
                     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
                     off = end - B < kStageRecs ? next_run_start(st1, lane, end - B) : kStageRecs;
                 }
@@ -656,7 +780,7 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
                       uint2* wcut, hipEvent_t t0, hipEvent_t t1) {
     const uint32_t ns = front_slots(in.n);
     if (!ns) return;
-    FrontRaw a;
+    FrontRawT<false> a;
     a.key = in.key;
     a.ref = in.ref;
     a.pos = in.pos;
@@ -670,7 +794,17 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
     // (t0 / t1, when given: the dispatch's own start and end time stamps -- what rocprofv3 reports as the kernel's
     // duration; events recorded around the launch add the 4 - 6 us it takes a dependent dispatch to start)
-    if (in.check)
+    if (in.packed) {  // (same members, other accessors)
+        FrontPacked b;
+        b.key = a.key, b.ref = a.ref, b.pos = a.pos, b.flag = nullptr, b.check = a.check, b.geo = a.geo, b.n = a.n;
+        b.n_refs = a.n_refs, b.half_read = a.half_read, b.bin_width = a.bin_width, b.bw_magic = a.bw_magic;
+        if (in.check)
+            hipExtLaunchKernelGGL((k_front<FrontPacked, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, b, ns,
+                                  counters, tgt_ref, tgt_gbin, slots, wcut);
+        else
+            hipExtLaunchKernelGGL((k_front<FrontPacked, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, b, ns,
+                                  counters, tgt_ref, tgt_gbin, slots, wcut);
+    } else if (in.check)
         hipExtLaunchKernelGGL((k_front<FrontRaw, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, a, ns,
                               counters, tgt_ref, tgt_gbin, slots, wcut);
     else

@@ -88,6 +88,7 @@ struct DeviceRecords {
     const uint16_t* flag = nullptr;
     const uint32_t* check = nullptr;  // optional second hash of the read name: equal keys must carry equal checks
     uint32_t n = 0;
+    bool packed = false;  // 16 bytes per record: flag == nullptr, the key's top three bits are {unmapped, mate number}
 };
 
 uint32_t num_tiles(uint32_t n);
@@ -112,6 +113,8 @@ void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident
                          uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
                          const uint32_t* cchk = nullptr);  // cchk: check words (equal keys must carry equal ones)
 
+// packed records -> the four-array form (identity masked to 61 bits, flag = 0x4 / 0x40 / 0x80 bits), for the sort path
+void launch_unpack_records(hipStream_t st, const uint64_t* packed_key, uint32_t n, uint64_t* key, uint16_t* flag);
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,

@@ -955,6 +955,20 @@ static inline uint32_t tiles_for(uint32_t n) { return (n + kTile - 1) / kTile; }
 
 uint32_t num_tiles(uint32_t n) { return tiles_for(n); }
 
+// packed records (slimm_push_records_packed) -> the four-array form the compaction of the sort path reads
+__global__ __launch_bounds__(256) void k_unpack_records(const uint64_t* __restrict__ packed, uint32_t n, uint64_t* __restrict__ key,
+                                                        uint16_t* __restrict__ flag) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t k = packed[i];
+        const uint32_t mate = static_cast<uint32_t>(k >> 61) & 3u;
+        key[i] = k & ((1ull << 61) - 1ull);
+        flag[i] = static_cast<uint16_t>(((k >> 63) ? 0x4u : 0u) | (mate == 1u ? 0x40u : (mate == 2u ? 0x80u : 0u)));
+    }
+}
+void launch_unpack_records(hipStream_t st, const uint64_t* packed_key, uint32_t n, uint64_t* key, uint16_t* flag) {
+    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(std::min<uint32_t>((n + 255u) / 256u, 4096u)), dim3(256), 0, st, packed_key, n, key, flag);
+}
+
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters) {
     uint32_t nt = tiles_for(in.n);
     if (nt) hipLaunchKernelGGL(k_valid_count, dim3(nt), dim3(kBlock), 0, st, in.flag, in.ref, in.n, n_refs, tile_cnt, counters);

@@ -146,6 +146,50 @@ class Slimm:
         self._keepalive = (key, ref, pos, flag)
         self._check(self.L.slimm_push_records_async(self.ctx, _p(key), _p(ref), _p(pos), _p(flag), len(key)))
 
+    # ---- packed records: 16 bytes each, the flag bits in the key's top three bits (slimm_pack_key) ----
+    @staticmethod
+    def pack_keys(read_key: np.ndarray, flag: np.ndarray) -> np.ndarray:
+        """slimm_pack_keys: (read_key & (2^61 - 1)) | mate << 61 | unmapped << 63."""
+        read_key = np.ascontiguousarray(read_key, dtype=np.uint64)
+        flag = np.ascontiguousarray(flag, dtype=np.uint16)
+        out = np.empty(read_key.shape[0], dtype=np.uint64)
+        capi.lib().slimm_pack_keys(_p(read_key), _p(flag), read_key.shape[0], _p(out))
+        return out
+
+    def push_records_packed(self, rec: Records, batch: int = 0, packed_key: Optional[np.ndarray] = None):
+        pk = self.pack_keys(rec.read_key, rec.flag) if packed_key is None else packed_key
+        n = len(rec)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_push_records_packed(self.ctx, _p(pk[s:e]), _p(rec.ref_id[s:e]), _p(rec.begin_pos[s:e]),
+                                                         e - s))
+
+    def push_records_packed_async(self, packed_key, ref, pos):
+        self._keepalive = (packed_key, ref, pos)
+        self._check(self.L.slimm_push_records_packed_async(self.ctx, _p(packed_key), _p(ref), _p(pos), len(packed_key)))
+
+    def push_records_packed_streamed(self, rec: Records, batch: int = 1 << 20):
+        """slimm_push_staged_packed_async over the two staging sets (their flag arrays stay unused)."""
+        n = len(rec)
+        sets = [self.staging(0, batch), self.staging(1, batch)]
+        for i, s in enumerate(range(0, n, batch)):
+            e = min(n, s + batch)
+            which = i & 1
+            self._check(self.L.slimm_staging_wait(self.ctx, which))
+            k, r, p, _ = sets[which]
+            k[: e - s] = self.pack_keys(rec.read_key[s:e], rec.flag[s:e])
+            r[: e - s] = rec.ref_id[s:e]
+            p[: e - s] = rec.begin_pos[s:e]
+            self._check(self.L.slimm_push_staged_packed_async(self.ctx, which, e - s))
+
+    def set_records_device_packed(self, packed_key, ref, pos):
+        """torch tensors on this context's device: int64/uint64 packed key, int32 ref, int32 pos."""
+        n = int(packed_key.shape[0])
+        self._keepalive = (packed_key, ref, pos)
+        self._check(self.L.slimm_set_records_device_packed(self.ctx, C.c_void_p(packed_key.data_ptr()),
+                                                           C.c_void_p(ref.data_ptr()), C.c_void_p(pos.data_ptr()), n))
+
     def push_wait(self):
         self._check(self.L.slimm_push_wait(self.ctx))
 

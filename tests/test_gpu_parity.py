@@ -906,3 +906,84 @@ def test_checked_and_unchecked_pushes_do_not_mix():
     s.push_records_checked(half, _check_words(w)[:2000])
     with pytest.raises(capi.SlimmError):
         s.push_records(half)
+
+
+# ---------------------------------------------------------------- packed records (slimm_push_records_packed: 16 B/record)
+def _mask61(w: Workload) -> Workload:
+    """The same workload with 61-bit read keys (what a producer of packed records hashes names to)."""
+    r = w.records
+    rec = Records(r.read_key & np.uint64((1 << 61) - 1), r.flag, r.ref_id, r.begin_pos, r.qname)
+    return Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, w.name + "-61", grouped=w.grouped)
+
+
+def test_pack_key_layout():
+    k = np.array([0, 1, (1 << 61) - 1, (1 << 62) - 1, 0x123456789abcdef0], dtype=np.uint64)
+    for flag, top in ((0, 0), (0x4, 4), (0x40, 1), (0x80, 2), (0xc0, 1), (0x44, 5), (0x900, 0), (0x84 | 0x100, 6)):
+        got = Slimm.pack_keys(k, np.full(k.shape, flag, dtype=np.uint16))
+        assert np.array_equal(got & np.uint64((1 << 61) - 1), k & np.uint64((1 << 61) - 1))
+        assert np.all((got >> np.uint64(61)) == np.uint64(top)), flag
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+@pytest.mark.parametrize("how", ["sync", "batches", "streamed"])
+def test_packed_records_equal_the_four_array_form(grouped, how):
+    """The three flag bits the record loop reads (src/slimm.hpp:197, 205-208) folded into the key's top bits: every
+    result equals the oracle's on the four-array records -- through the single-pass front end and through the sort
+    path, pushed in one piece, in ragged batches and through the staging sets."""
+    w = _mask61(make_workload(CONFIGS["config1"], seed=71, shuffled=not grouped))
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    r = w.records
+    if how == "sync":
+        s.push_records_packed(r)
+    elif how == "batches":
+        s.push_records_packed(r, batch=1777)
+    else:
+        s.push_records_packed_streamed(r, batch=3000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    # the context takes the other form for its next file (and the forms do not mix within one)
+    s.reset()
+    s.push_records(r)
+    with pytest.raises(capi.SlimmError):
+        s.push_records_packed(r)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    s.reset()
+    s.push_records_packed(r, batch=5000)
+    with pytest.raises(capi.SlimmError):
+        s.push_records(r)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+
+
+@pytest.mark.parametrize("mk", [lambda: make_workload(CONFIGS["config2"], seed=72, n_records=400_000),
+                                lambda: make_workload(SynthConfig("c5p", 300_000, 3_000, 40.0, strain_level=True), seed=73),
+                                lambda: _interleave_mates(make_workload(SynthConfig("pairs", 150_000, 2_000, 6.0), seed=74,
+                                                                        paired_frac=0.9))])
+def test_packed_records_on_larger_streams(mk):
+    """Short runs, runs of 64 records and more (the hash-table and long-run paths), interleaved mates -- packed."""
+    w = _mask61(mk())
+    o = run_workload(w, use_qnames=False)
+    s = Slimm.for_workload(w, device=0)
+    s.push_records_packed(w.records, batch=100_000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_packed_records_resident_on_the_device(grouped):
+    import torch
+    w = _mask61(make_workload(CONFIGS["config2"], seed=75, n_records=250_000, shuffled=not grouped))
+    o = run_workload(w, use_qnames=False)
+    r = w.records
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(a).to(dev) for a in (Slimm.pack_keys(r.read_key, r.flag).view(np.int64), r.ref_id, r.begin_pos)]
+    torch.cuda.synchronize()
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    for _ in range(2):
+        s.reset()
+        s.reset_cutoffs()
+        s.set_records_device_packed(*t)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)

@@ -100,7 +100,18 @@ int slimm_set_cutoff_cache(slimm_ctx* ctx, float coverage_cut_off, float uniq_co
  * keys, never names: "equal names <=> equal keys" is the caller's promise.  GROUPED streams only ever compare
  * ADJACENT records, so a producer that hashes names can make the promise exact by comparing every name with the
  * one before it (the slimm command's reader does: host/alignment_file.cpp, separate_adjacent_names); for ANY order
- * a 62-bit hash leaves ~n^2 / 2^63 odds of two different names meeting. */
+ * a 62-bit hash leaves ~n^2 / 2^63 odds of two different names meeting.
+ *
+ * DECLARING A STREAM GROUPED IS A PROMISE THE LIBRARY DOES NOT CHECK BY ITSELF.  With record_order = SLIMM_ORDER_GROUPED
+ * the front end compares adjacent records only: a read name that comes back after other names have been in between
+ * becomes TWO reads (two unique reads where the reference, which merges through its hash map -- src/slimm.hpp:204-211 --
+ * sees one multi-mapped read).  No error is raised, the profile is simply not the reference's.  Declare GROUPED only
+ * what is grouped by construction (mapper output; @HD SO:queryname / GO:query, which is all the slimm command trusts);
+ * everything else is SLIMM_ORDER_ANY.  slimm_check_grouping() is the diagnostic for a caller in doubt: after the
+ * records are pushed it counts, on the device, the qName runs whose identity started an earlier run as well (0 = the
+ * stream is grouped).  It costs a hash-set insert per run (16 bytes of device memory per record for the set) and is
+ * therefore never run unasked; the slimm command runs it with SLIMM_VERIFY_GROUPING=1 and warns. */
+int slimm_check_grouping(slimm_ctx* ctx, uint64_t* n_split_names);
 int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);
 /* Append a batch from host memory (copied to the device before return). */
 int slimm_push_records(slimm_ctx* ctx, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("slimm_get_cutoff_cache", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("slimm_set_cutoff_cache", C.c_int, [_P, C.c_float, C.c_float]),
     ("slimm_reserve", C.c_int, [_P, C.c_uint64]),
+    ("slimm_check_grouping", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("slimm_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_warm_up", C.c_int, [C.c_int]),
     ("slimm_group_create", C.c_int, [_P, _P, C.c_uint32, C.POINTER(_P)]),

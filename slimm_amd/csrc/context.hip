@@ -863,6 +863,32 @@ int slimm_set_records_device_packed(slimm_ctx* c, const uint64_t* key, const int
     return SLIMM_OK;
 }
 
+// Is the stream really grouped by read name?  See k_check_grouping (kernels.hip).
+int slimm_check_grouping(slimm_ctx* c, uint64_t* n_split_names) {
+    if (!c || !n_split_names) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    *n_split_names = 0;
+    const uint32_t n = c->rec.n;
+    if (n == 0) return SLIMM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->copy_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+    uint64_t cap = 1024;
+    while (cap < 2ull * n) cap <<= 1;  // (every record may start a run)
+    DevBuf<uint64_t> tab;
+    DevBuf<uint32_t> cnt;
+    HIP_TRY(c, tab.ensure(cap));
+    HIP_TRY(c, cnt.ensure(1));
+    HIP_TRY(c, hipMemsetAsync(tab.p, 0xff, cap * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(cnt.p, 0, 4, c->stream));
+    launch_check_grouping(c->stream, c->rec.key, n, c->rec.packed ? (1ull << 61) - 1ull : (1ull << 62) - 1ull, tab.p,
+                          static_cast<uint32_t>(cap - 1), cnt.p);
+    uint32_t h = 0;
+    HIP_TRY(c, hipMemcpyAsync(&h, cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_split_names = h;
+    return SLIMM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ phase A
 int slimm_analyze_alignments(slimm_ctx* c) {
     if (!c) return SLIMM_E_INVALID;

@@ -325,7 +325,7 @@ struct Staged {
 // Segments longer than this take the hash table in window_fast (a walk step is two vector and two scalar instructions,
 // the table about fifty instructions and four LDS round trips whatever the segments look like)
 #ifndef SLIMM_HASH_WALK
-#define SLIMM_HASH_WALK 16
+#define SLIMM_HASH_WALK 48
 #endif
 constexpr uint32_t kHashWalk = SLIMM_HASH_WALK;
 // D = N0 & (N0 << 1) marks the second and later lanes of every stretch of set bits of N0 (non-start lanes: a segment of
@@ -591,6 +591,85 @@ __device__ __forceinline__ uint32_t next_run_start(const uint32_t* st1, uint32_t
     return kStageRecs;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// long path, staged: a run of 64 records or more that lies inside the slot's staged stretch, records [off, end_off) of
+// st1 / st2 -- nothing is loaded from global memory again, the bins are the staged ones, and first-of-(read, reference)
+// goes through the wave's hash table chunk after chunk (constant work per chunk).  Returns false when the run holds
+// more distinct (mate, reference) pairs than the table does: the caller then takes long_run, which can fall back to
+// the comparison walk.  `so` is unchanged in that case.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool long_run_staged(const uint32_t* st1, const uint32_t* st2, uint32_t off, uint32_t end_off,
+                                                uint32_t lane, WinOut& so, uint32_t* __restrict__ tgt_ref,
+                                                uint32_t* __restrict__ tgt_gbin, uint32_t* tab) {
+    // 1. do the run's mates ever decrease?  (then one pass per mate number, so that a read's targets stay contiguous)
+    bool decreasing = false;
+    {
+        uint32_t last_mate = 0;
+        for (uint32_t o = off; o < end_off; o += 64u) {
+            const uint32_t n_in = min(64u, end_off - o);
+            const uint32_t mate = (st1[min(o + lane, end_off - 1u)] >> kStMateShift) & 3u;
+            const uint32_t mprev = f_shr1(mate, last_mate);
+            decreasing = decreasing | ((f_ballot(mate < mprev) & f_below(n_in)) != 0ull);
+            last_mate = __builtin_amdgcn_readlane(mate, n_in - 1u);
+        }
+    }
+    const WinOut so_at_run = so;
+    uint32_t nv_run = 0;
+    for (uint32_t pass = 0; pass < (decreasing ? 3u : 1u); ++pass) {
+        uint32_t head_seen = 0;                        // bit m: a mapped record with mate m came by
+        uint32_t n_first[3] = {0u, 0u, 0u};            // targets per mate
+        uint32_t head_p[3] = {0u, 0u, 0u}, head_g[3] = {0u, 0u, 0u};  // where each mate's head went, its bin word
+        hash_clear(tab, lane);
+        for (uint32_t o = off; o < end_off; o += 64u) {
+            const uint32_t i = o + lane;
+            const bool in_run = i < end_off;
+            const uint32_t w1 = st1[in_run ? i : end_off - 1u], g = st2[in_run ? i : end_off - 1u];
+            const uint32_t field = w1 & kRefField, mate = (w1 >> kStMateShift) & 3u;
+            const bool mapped = in_run && field != kRefField;
+            const bool use = mapped && (!decreasing || mate == pass);
+            if (pass == 0) nv_run += static_cast<uint32_t>(__popcll(f_ballot(mapped)));
+            bool overflow = false;
+            const bool first = hash_first(tab, (mate << 28) | field, i - off, use, overflow);
+            if (f_ballot(overflow) != 0ull) {
+                so = so_at_run;
+                return false;
+            }
+            const uint64_t F = f_ballot(first);
+            uint64_t H = 0;  // heads: per mate the first mapped lane, unless an earlier chunk had one
+#pragma unroll
+            for (uint32_t m = 0; m < 3u; ++m) {
+                const uint64_t Vm = f_ballot(use && mate == m);
+                if (Vm && !((head_seen >> m) & 1u)) {
+                    H |= 1ull << __builtin_ctzll(Vm);
+                    head_seen |= 1u << m;
+                }
+                n_first[m] += static_cast<uint32_t>(__popcll(f_ballot(first && mate == m)));
+            }
+            const bool head = f_bit(H);
+            const uint32_t p = so.base + so.nf + f_rank(F);
+            if (first) {
+                tgt_ref[p] = (field - 1u) | (head ? 0x80000000u : 0u);
+                if (!head) tgt_gbin[p] = g;  // a head's bin word waits for the end of the run (unique or not)
+            }
+            uint64_t Hm = H;
+            while (Hm) {
+                const uint32_t hl = static_cast<uint32_t>(__builtin_ctzll(Hm));
+                Hm &= Hm - 1ull;
+                const uint32_t m = __builtin_amdgcn_readlane(mate, hl);
+                head_p[m] = __builtin_amdgcn_readlane(p, hl);
+                head_g[m] = __builtin_amdgcn_readlane(g, hl);
+            }
+            so.nf += static_cast<uint32_t>(__popcll(F));
+            so.nh += static_cast<uint32_t>(__popcll(H));
+        }
+#pragma unroll
+        for (uint32_t m = 0; m < 3u; ++m)
+            if (((head_seen >> m) & 1u) && lane == 0u) tgt_gbin[head_p[m]] = head_g[m] | (n_first[m] == 1u ? 0x80000000u : 0u);
+    }
+    so.nv += nv_run;
+    return true;
+}
+
 // STAGE: records [B, B + kStageRecs) of the stream as two words each in the wave's stretch of LDS --
 //   st1: reference + 1 (kRefField: not mapped) | mate << 26 | run start << 31,  st2: global bin.
 // kClamp: the stream ends inside the stretch (its last slots only): lanes behind the end load the last record again and
@@ -737,10 +816,18 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                     else
                         window_general(Staged{mate, field - 1u, w2, f_bit(V)}, lane, RS, V, X, so, tgt_ref, tgt_gbin);
                     off += X;
-                } else {  // a run of 64 records or more: from global memory, at its own pace
-                    const uint32_t end = long_run<kChk>(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad, collide, tab);
-                    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
-                    off = end - B < kStageRecs ? next_run_start(st1, lane, end - B) : kStageRecs;
+                } else {
+                    // a run of 64 records or more.  Inside the staged stretch (its end is the next staged run start): from
+                    // the staged words; running on beyond it, or with more distinct references than the hash table
+                    // holds: from global memory, at its own pace
+                    const uint32_t end_off = next_run_start(st1, lane, off + 64u);
+                    if (end_off < kStageRecs && long_run_staged(st1, st2, off, end_off, lane, so, tgt_ref, tgt_gbin, tab)) {
+                        off = end_off;
+                    } else {
+                        const uint32_t end = long_run<kChk>(acc, pos, N, lane, so, tgt_ref, tgt_gbin, bad, collide, tab);
+                        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
+                        off = end - B < kStageRecs ? next_run_start(st1, lane, end - B) : kStageRecs;
+                    }
                 }
             }
         }

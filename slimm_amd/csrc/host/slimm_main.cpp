@@ -94,6 +94,10 @@ SLIMM_FORWARD(int, slimm_push_records_checked,
 SLIMM_FORWARD(int, slimm_staging_buffers,
               (slimm_ctx* a, uint32_t b, uint64_t c, uint64_t** d, int32_t** e, int32_t** f_, uint16_t** g), (a, b, c, d, e, f_, g))
 SLIMM_FORWARD(int, slimm_push_staged_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
+SLIMM_FORWARD(int, slimm_push_staged_packed_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
+SLIMM_FORWARD(int, slimm_push_records_packed, (slimm_ctx* a, const uint64_t* b, const int32_t* c, const int32_t* d, uint64_t e),
+              (a, b, c, d, e))
+SLIMM_FORWARD(int, slimm_check_grouping, (slimm_ctx* a, uint64_t* b), (a, b))
 SLIMM_FORWARD(int, slimm_keep_bins, (slimm_ctx* a, int b), (a, b))
 SLIMM_FORWARD(int, slimm_analyze_alignments, (slimm_ctx* a), (a))
 SLIMM_FORWARD(int, slimm_finish_coverage, (slimm_ctx* a), (a))
@@ -395,9 +399,19 @@ struct RecordPump {
             th.join();
         }
     }
-    static int push(slimm_ctx* c, const Batch& b) {
-        return b.check ? slimm_push_records_checked(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n)
-                       : slimm_push_records(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n);
+    // 16 bytes per record over the bus: the three flag bits the path reads go into the key's top bits
+    // (include/slimm_hip.h, slimm_pack_key); every unchecked push of a file is packed -- the forms do not mix
+    static void pack(uint64_t* key, const uint16_t* flag, uint64_t n) {
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t f = flag[i];
+            const uint64_t mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);
+            key[i] = (key[i] & ((1ull << 61) - 1ull)) | (mate << 61) | (((f >> 2) & 1ull) << 63);
+        }
+    }
+    static int push(slimm_ctx* c, Batch& b) {
+        if (b.check) return slimm_push_records_checked(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n);
+        pack(b.key.get(), b.flag.get(), b.n);
+        return slimm_push_records_packed(c, b.key.get(), b.ref.get(), b.pos.get(), b.n);
     }
     static double ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -426,7 +440,8 @@ struct RecordPump {
                     read_rc = n;
                     return;
                 }
-                if (slimm_push_staged_async(c, which, static_cast<uint64_t>(n)) < 0) break;
+                pack(key, flag, static_cast<uint64_t>(n));  // (the set's flag array stays on the host)
+                if (slimm_push_staged_packed_async(c, which, static_cast<uint64_t>(n)) < 0) break;
                 which ^= 1u;
                 continue;
             }
@@ -663,6 +678,15 @@ bool get_profiles(Session& S, size_t file_index) {
             slimm_destroy(ctx);
             return false;
         }
+    }
+    if (record_order == SLIMM_ORDER_GROUPED && getenv("SLIMM_VERIFY_GROUPING")) {
+        // the header (or --query-grouped) promises that the records of a read name are adjacent; nothing checks the promise
+        // unless asked: a name that comes back later would be counted as two reads (include/slimm_hip.h, slimm_check_grouping)
+        uint64_t split = 0;
+        CHECK(ctx, slimm_check_grouping(ctx, &split));
+        if (split)
+            std::cerr << "\n[WARNING] " << split << " read name run(s) repeat a name seen earlier in " << get_file_name(path)
+                      << ": the file is NOT grouped by read name although it is declared so; run with --any-order\n";
     }
     CHECK(ctx, slimm_analyze_alignments(ctx));
     int rc = slimm_finish_coverage(ctx);

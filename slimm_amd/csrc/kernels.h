@@ -115,6 +115,9 @@ void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident
 
 // packed records -> the four-array form (identity masked to 61 bits, flag = 0x4 / 0x40 / 0x80 bits), for the sort path
 void launch_unpack_records(hipStream_t st, const uint64_t* packed_key, uint32_t n, uint64_t* key, uint16_t* flag);
+// diagnostic: run starts whose identity (key & id_mask) started an earlier run too; tab: (tab_mask + 1) words of ~0
+void launch_check_grouping(hipStream_t st, const uint64_t* key, uint32_t n, uint64_t id_mask, uint64_t* tab, uint32_t tab_mask,
+                           uint32_t* n_split);
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
 constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
 void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,

@@ -969,6 +969,35 @@ void launch_unpack_records(hipStream_t st, const uint64_t* packed_key, uint32_t 
     if (n) hipLaunchKernelGGL(k_unpack_records, dim3(std::min<uint32_t>((n + 255u) / 256u, 4096u)), dim3(256), 0, st, packed_key, n, key, flag);
 }
 
+// slimm_check_grouping: is a stream that was DECLARED grouped really grouped?  Every record that starts a qName run (its
+// identity differs from the record before) puts its identity into an open-addressing set; an identity that is already
+// there starts a second run -- the name re-appears non-adjacently, and the single-pass front end would make two reads of
+// what the reference's hash map (src/slimm.hpp:204-211) merges into one.  *n_split counts such run starts.
+__global__ __launch_bounds__(256) void k_check_grouping(const uint64_t* __restrict__ key, uint32_t n, uint64_t id_mask,
+                                                        uint64_t* __restrict__ tab, uint32_t tab_mask,
+                                                        uint32_t* __restrict__ n_split) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint64_t k = key[i] & id_mask;
+        if (i != 0u && (key[i - 1u] & id_mask) == k) continue;  // inside a run
+        uint32_t slot = static_cast<uint32_t>(mix64(k)) & tab_mask;
+        for (uint32_t probe = 0; probe <= tab_mask; ++probe) {
+            const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[slot]), ~0ull,
+                                                     static_cast<unsigned long long>(k));
+            if (old == ~0ull) break;
+            if (old == k) {
+                atomicAdd(n_split, 1u);
+                break;
+            }
+            slot = (slot + 1u) & tab_mask;
+        }
+    }
+}
+void launch_check_grouping(hipStream_t st, const uint64_t* key, uint32_t n, uint64_t id_mask, uint64_t* tab, uint32_t tab_mask,
+                           uint32_t* n_split) {
+    if (n) hipLaunchKernelGGL(k_check_grouping, dim3(std::min<uint32_t>((n + 255u) / 256u, 8192u)), dim3(256), 0, st, key, n,
+                              id_mask, tab, tab_mask, n_split);
+}
+
 void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters) {
     uint32_t nt = tiles_for(in.n);
     if (nt) hipLaunchKernelGGL(k_valid_count, dim3(nt), dim3(kBlock), 0, st, in.flag, in.ref, in.n, n_refs, tile_cnt, counters);

@@ -200,6 +200,12 @@ class Slimm:
         self._check(self.L.slimm_set_records_device(self.ctx, C.c_void_p(key.data_ptr()), C.c_void_p(ref.data_ptr()),
                                                     C.c_void_p(pos.data_ptr()), C.c_void_p(flag.data_ptr()), n))
 
+    def check_grouping(self) -> int:
+        """slimm_check_grouping: qName runs whose identity started an earlier run too (0 = the stream is grouped)."""
+        n = C.c_uint64()
+        self._check(self.L.slimm_check_grouping(self.ctx, C.byref(n)))
+        return int(n.value)
+
     # ---- the reference's phases ----
     def analyze_alignments(self):
         self._check(self.L.slimm_analyze_alignments(self.ctx))

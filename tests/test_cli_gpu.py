@@ -218,3 +218,33 @@ def test_cli_unordered_file_with_two_names_under_one_key_fails_loudly(tmp_path):
     run_cli(["-w", str(w2.options.bin_width), "-o", out, db, inp])
     o = Oracle(w2.taxonomy, w2.options).run(w2.ref_names, w2.ref_len, w2.records, w2.avg_read_len, want_raw=False)
     assert_profiles_match(open(os.path.join(out, "sample_profile.tsv")).read(), o.profile_tsv)
+
+
+def test_cli_warns_about_a_false_grouping_promise_when_asked(tmp_path):
+    """A header that says GO:query over records that are not grouped: SLIMM_VERIFY_GROUPING=1 makes the command count the
+    names that come back (slimm_check_grouping) and warn; --any-order gives the oracle's outputs for the same file."""
+    w = with_names(make_workload(CONFIGS["config1"], seed=47))
+    r = w.records
+    starts = np.nonzero(np.concatenate([[True], r.read_key[1:] != r.read_key[:-1]]))[0]
+    ends = np.concatenate([starts[1:], [len(r)]])
+    runs = [list(range(a, b)) for a, b in zip(starts, ends)]
+    j = next(k for k in range(20, len(runs)) if len(runs[k]) >= 3)
+    runs.insert(j + 40, [runs[j].pop()])
+    order = np.array([i for run in runs for i in run])
+    q = r.qname
+    rec = Records(r.read_key[order], r.flag[order], r.ref_id[order], r.begin_pos[order], [q[i] for i in order])
+    wb = Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, "broken")
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "s.bam")
+    write_bam(inp, wb.ref_names, wb.ref_len, wb.records, read_len=wb.avg_read_len)   # header: GO:query
+    out = str(tmp_path / "o") + "/"
+    os.makedirs(out)
+    args = [CLI, "-w", str(w.options.bin_width), "-o", out, "-ro", db, inp]
+    quiet = subprocess.run(args, capture_output=True, text=True)
+    assert quiet.returncode == 0 and "NOT grouped" not in quiet.stderr
+    loud = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, SLIMM_VERIFY_GROUPING="1"))
+    assert loud.returncode == 0 and "[WARNING] 1 read name run(s) repeat a name seen earlier" in loud.stderr
+    run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "--any-order", db, inp])
+    o = Oracle(wb.taxonomy, wb.options).run(wb.ref_names, wb.ref_len, wb.records, wb.avg_read_len, want_raw=True)
+    check_outputs(out, "s", o, coverage=False)

@@ -987,3 +987,42 @@ def test_packed_records_resident_on_the_device(grouped):
         s.set_records_device_packed(*t)
         assert s.get_profiles() is not None
         assert_matches_oracle(s, o)
+
+
+# ---------------------------------------------------------------- a stream declared grouped that is not (slimm_check_grouping)
+def test_check_grouping_counts_names_that_come_back():
+    """GROUPED compares adjacent records only (include/slimm_hip.h): a name that re-appears after other names is two
+    reads to the single-pass front end, one to the reference (src/slimm.hpp:204-211).  The diagnostic counts such runs;
+    declared SLIMM_ORDER_ANY the same stream gives the reference's results."""
+    w = make_workload(CONFIGS["config1"], seed=81)
+    s = Slimm.for_workload(w, device=0)
+    s.push_records(w.records)
+    assert s.check_grouping() == 0
+    assert s.get_profiles() is not None
+    # the last record of three multi-record runs moves 50 runs down the file, to a place between two runs
+    r = w.records
+    starts = np.nonzero(np.concatenate([[True], r.read_key[1:] != r.read_key[:-1]]))[0]
+    ends = np.concatenate([starts[1:], [len(r)]])
+    runs = [list(range(a, b)) for a, b in zip(starts, ends)]
+    moved = 0
+    j = 10
+    while moved < 3:
+        if len(runs[j]) >= 2:
+            runs.insert(j + 50, [runs[j].pop()])
+            moved += 1
+            j += 100
+        j += 1
+    order = [i for run in runs for i in run]
+    broken = Workload(w.ref_names, w.ref_len, w.taxonomy, r.take(np.array(order)), w.avg_read_len, w.options, "broken",
+                      grouped=False)
+    o = run_workload(broken, use_qnames=False)
+    s.reset()
+    s.push_records(broken.records)
+    assert s.check_grouping() == 3
+    # (the packed form is checked on its 61 identity bits)
+    s.reset()
+    s.push_records_packed(_mask61(broken).records)
+    assert s.check_grouping() == 3
+    assert s.get_profiles() is not None
+    assert s.stats()["matches_count"] == o.scalars["matches"] + 3          # what the false promise costs: 3 reads too many
+    check(broken, grouped=False)                                            # declared honestly: the reference's numbers

@@ -1,24 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the alignment-to-profile hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): M alignment-records/sec from the decoded-record stream to the final profile.
-A step = one pass of the whole hot path over one batch of synthetic records that are already resident in HBM:
-analyze_alignments -> (all-reduce when N > 1) -> finish_coverage -> filter_alignments -> get_reads_lca_count ->
-write_abundance (profile TSV written to a file by rank 0).  The workload at N = 1 is BASELINE.json configs[1]
-(10 M synthetic 100 bp records, 5 k bacterial refs, mean 3 hits/read, 1000 bp bins); with N ranks every rank holds its
-own 10 M-record shard of the same sample (weak scaling) and the value is total records / max-over-ranks time.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel, from HIP events recorded on the library's
-stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the reference algorithm, 1 thread) on a
-bounded prefix of the same record stream.
+Workload, at EVERY N: BASELINE.json configs[3] -- ONE seeded 1 B-record stream (20 k refs, mean 8 hits/read, 1000 bp
+bins, 100 bp reads) in 100 chunks of 10 M records, each chunk a grouped file of whole reads; rank r of N generates and
+keeps chunks [r C / N, (r + 1) C / N) straight into HBM (strong scaling: the total is fixed, cuts fall on read
+boundaries, slimm_amd/partition.py).  The stream fits one MI355X, so N = 1 runs all of it: the N = 1 line and the N > 1
+lines are the same job.  A step = one pass of the whole hot path over the rank's records, which are resident in HBM as
+packed 16-byte records (key with the three flag bits folded in, ref, pos: slimm_set_records_device_packed):
+analyze_alignments -> (RCCL exchange when N > 1) -> finish_coverage -> filter_alignments -> get_reads_lca_count ->
+write_abundance (profile TSV written to a file by rank 0), every step a fresh file for a fresh object.  `value` = total
+records / max-over-ranks time.
+
+ONE JSON line on rank 0.  Beside the contract's fields:
+  roofline            the dominant kernel of the headline workload: algorithmic bytes (16 N + 8 P
+                      for the front end) / its dispatch's own duration, measured live by HIP events handed to the
+                      launch (hipExtLaunchKernelGGL) on the library's stream inside the timed steps
+  roofline_config2 / _config3 / _config5   the same for BASELINE.json configs[1], [2] (the designated roofline run) and
+                      [4] (100 M records, 50 k strain-level refs, 40 hits/read), resident, N = 1 only
+  value_with_push     the clock starts before the first record leaves page-locked HOST memory
+                      (slimm_push_records_packed_async) and stops when the profile file is written -- SURVEY.md 8d (1)
+  cpu_baseline        the CPU oracle (a port of the reference algorithm, 1 thread) on a bounded prefix of the stream
+  cpu_baseline_mt     the dense all-core restatement on a bounded prefix
+  cli_end_to_end      `slimm DB IN.bam` on a 100 M-record synthetic BAM, process start to profile written
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -83,18 +97,19 @@ def cpu_quota_cores():
     return float(os.cpu_count() or 1)
 
 
-def pmc_traffic_bytes(kernel_name, records_per_gpu):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh run on
-    MI355X with the default workload; FETCH_SIZE and WRITE_SIZE collected in separate passes, unit KB).  gfx950
-    correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE counts 128-byte requests as 64 bytes, i.e. half of a
-    coalesced stream -- calibrated here on k_ref_stats, whose 16 B/lane loads read exactly 8 B per bin (ratio 2.03) --
-    so fetched bytes = 2 * FETCH_SIZE; WRITE_SIZE is exact.  None when no profile matches."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic_summary.json") for r in ("round2", "round1"))
-                 if os.path.exists(q)), None)
-    if records_per_gpu != 10_000_000 or path is None:
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round3", "pmc_traffic_summary.json")
+
+
+def pmc_traffic_bytes(kernel_name, workload):
+    """HBM bytes per launch of `kernel_name` at `workload` ("config4", "config2" ...) from the committed rocprofv3 PMC
+    passes (scripts/pmc_traffic.sh on MI355X; FETCH_SIZE and WRITE_SIZE collected in separate passes, unit KB).  gfx950
+    correction per MI355X_MICROARCH.md section HBM: FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e. half of a
+    coalesced stream (calibrated in round 2 on k_ref_stats, whose 16 B/lane loads read exactly 8 B per bin: ratio
+    2.03), so fetched bytes = 2 * FETCH_SIZE; WRITE_SIZE is exact.  None when no profile matches."""
+    if not os.path.exists(PMC_SUMMARY):
         return None
-    with open(path) as f:
-        d = json.load(f)
+    with open(PMC_SUMMARY) as f:
+        d = json.load(f).get(workload, {})
     for k, v in d.items():
         if k.split("<")[0] == kernel_name and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
@@ -104,52 +119,53 @@ def pmc_traffic_bytes(kernel_name, records_per_gpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="config2")
-    ap.add_argument("--records", type=int, default=0, help="records per rank (default: the config's size)")
+    ap.add_argument("--config", default="config4",
+                    help="the headline workload (default: BASELINE.json configs[3], the 1 B-record stream the metric's "
+                         "1/2/4/8-GPU curve is quoted on; it fits one GPU)")
+    ap.add_argument("--records", type=int, default=0, help="records of the stream over ALL ranks (default: the config's size)")
+    ap.add_argument("--chunk-records", type=int, default=10_000_000, help="records per chunk of the stream")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
-                    help="records of the same stream the single-threaded CPU restatement is timed on (default: all)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling instead: every rank its own --records-sized shard of the sample (round 1 / 2 default)")
+    ap.add_argument("--form", default="packed", choices=["packed", "four"],
+                    help="record arrays handed to the library: 'packed' = 16 B/record (slimm_set_records_device_packed: key with "
+                         "the three flag bits folded in, ref, pos), 'four' = 18 B/record (key, ref, pos, flag)")
     ap.add_argument("--no-bins", action="store_true",
                     help="do not materialise the coverage arrays in HBM (slimm_keep_bins(0): their statistics are taken from "
                          "the finished tiles in LDS either way; what `slimm` does without -co)")
-    ap.add_argument("--cpu-passes", type=int, default=2, help="passes of the CPU restatement over that sample (2 = ~14 s)")
-    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--record-order", default="grouped", choices=["grouped", "any"],
                     help="'any' sends the same records through the device sort path (record_order = SLIMM_ORDER_ANY)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "summary", "sliced", "bins"],
                     help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps (summary), all-to-all of "
                          "bitmap slices + small all-reduce (sliced), all-reduce of the bins; auto = summary up to 2 ranks")
-    ap.add_argument("--kernel-timing", choices=("dominant", "all"), default="dominant",
-                    help="HIP events in the timed steps: around the dominant kernel only (default) or around every launch")
-    ap.add_argument("--no-config3", action="store_true",
-                    help="skip the second measurement on BASELINE.json configs[2] (100 M records, 20 k refs: the "
-                         "designated HBM-roofline run), which adds ~15 s at N = 1")
-    ap.add_argument("--config3-steps", type=int, default=5)
-    ap.add_argument("--config3-records", type=int, default=0, help="records of that run (default: all 100 M)")
-    ap.add_argument("--push-batch", type=int, default=1 << 20, help="records per slimm_push_records call")
-    ap.add_argument("--push-steps", type=int, default=3,
-                    help="steps of the push-inclusive measurement (records start in host memory; 0 = skip)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: ONE seeded stream of --records (default: the config's) records in 10 M-record "
-                         "chunks, rank r generates and keeps chunks [r C / N, (r + 1) C / N) -- cuts at read boundaries "
-                         "(slimm_amd/partition.py); implied by --config config4")
-    ap.add_argument("--chunk-records", type=int, default=10_000_000, help="records per chunk of the strong-scaling stream")
-    ap.add_argument("--form", default="packed", choices=["packed", "four"],
-                    help="record arrays handed to the library: 'packed' = 16 B/record (slimm_set_records_device_packed: key with "
-                         "the three flag bits folded in, ref, pos), 'four' = 18 B/record (key, ref, pos, flag)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-rank code path (process group, collectives) even with one rank")
+    ap.add_argument("--kernel-timing", choices=("dominant", "all"), default="dominant",
+                    help="HIP events in the timed steps: around the dominant kernel only (default) or around every launch")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel tables to stderr")
+    ap.add_argument("--gen-threads", type=int, default=0, help="threads generating chunks (default: the CPU quota / ranks)")
+    # the legs beside the headline (N = 1 only)
+    ap.add_argument("--quick", action="store_true", help="the headline measurement only (no other configs, push, CPU, CLI legs)")
+    ap.add_argument("--roofline-configs", default="config2,config3,config5",
+                    help="configurations measured beside the headline, resident, one context ('' = none)")
+    ap.add_argument("--config-steps", type=int, default=5)
+    ap.add_argument("--push-files", type=int, default=3, help="files of the pipelined push-inclusive measurement (0 = skip the leg)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records the single-threaded CPU restatement is timed on")
+    ap.add_argument("--cpu-mt-sample", type=int, default=100_000_000, help="records the all-core CPU restatement is timed on")
+    ap.add_argument("--no-cli", action="store_true", help="skip the `slimm DB IN.bam` end-to-end leg")
+    ap.add_argument("--cli-records", type=int, default=100_000_000)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from slimm_amd.distributed import resolve_exchange, sharded_profile
+    from slimm_amd.partition import chunk_owner
     from slimm_amd.profiler import Slimm
-    from slimm_amd.synth import CONFIGS, make_workload
+    from slimm_amd.synth import CONFIGS, make_workload, stream_chunks
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -170,45 +186,93 @@ def main():
         os.environ["NCCL_DEBUG"] = os.environ.get("SLIMM_NCCL_DEBUG", "WARN")
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # (RCCL logs to stdout by default)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    extras = rank == 0 and world == 1 and not args.quick and not args.force_exchange
+    packed = args.form == "packed"
+    rec_bytes = 16 if packed else 18
+    out_path = os.path.join(tempfile.gettempdir(), f"slimm_bench_profile_{os.getpid()}.tsv")
+    gen_threads = args.gen_threads or max(2, int(cpu_quota_cores()) // max(1, world))
 
+    def to_packed(k, f):
+        """slimm_pack_key on tensors: (key & (2^61 - 1)) | mate << 61 | unmapped << 63 (what a decoder writes)."""
+        f = f.to(torch.int64) & 0xffff
+        mate = torch.where((f & 0x40) != 0, 1, torch.where((f & 0x80) != 0, 2, 0)).to(torch.int64)
+        return (k & ((1 << 61) - 1)) | (mate << 61) | (((f & 0x4) != 0).to(torch.int64) << 63)
+
+    class Resident:
+        """A rank's records in HBM in the form handed to the library (+ optionally the same in page-locked host memory)."""
+
+        def __init__(self, n, pinned=False):
+            self.n = n
+            self.key = torch.empty(n, dtype=torch.int64, device=dev)
+            self.ref = torch.empty(n, dtype=torch.int32, device=dev)
+            self.pos = torch.empty(n, dtype=torch.int32, device=dev)
+            self.flag = None if packed else torch.empty(n, dtype=torch.int16, device=dev)
+            self.host = None
+            if pinned:
+                self.host = [torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int32).pin_memory(),
+                             torch.empty(n, dtype=torch.int32).pin_memory()]
+                if not packed:
+                    self.host.append(torch.empty(n, dtype=torch.int16).pin_memory())
+
+        def fill(self, lo, rec):
+            hi = lo + len(rec)
+            k = torch.from_numpy(rec.read_key.view(np.int64))
+            f = torch.from_numpy(rec.flag.view(np.int16))
+            if packed:
+                k = to_packed(k, f)
+            parts = [k, torch.from_numpy(rec.ref_id), torch.from_numpy(rec.begin_pos)] + ([] if packed else [f])
+            if self.host is not None:
+                for h, p in zip(self.host, parts):
+                    h[lo:hi] = p
+                parts = [h[lo:hi] for h in self.host]
+            self.key[lo:hi].copy_(parts[0], non_blocking=True)
+            self.ref[lo:hi].copy_(parts[1], non_blocking=True)
+            self.pos[lo:hi].copy_(parts[2], non_blocking=True)
+            if not packed:
+                self.flag[lo:hi].copy_(parts[3], non_blocking=True)
+            torch.cuda.synchronize()   # (the chunk's arrays may go away)
+            return hi
+
+        def give(self, eng):
+            if packed:
+                eng.set_records_device_packed(self.key, self.ref, self.pos)
+            else:
+                eng.set_records_device(self.key, self.ref, self.pos, self.flag)
+
+        def push_async(self, eng):
+            if packed:
+                k, r, p = (h.numpy() for h in self.host)
+                eng.push_records_packed_async(k.view(np.uint64), r, p)
+            else:
+                k, r, p, f = (h.numpy() for h in self.host)
+                eng.push_records_async(k.view(np.uint64), r, p, f.view(np.uint16))
+
+    # ------------------------------------------------------------------ the rank's share of the headline stream
     cfg = CONFIGS[args.config]
-    strong = args.strong or args.config == "config4"
     t0 = time.time()
-    if strong:
-        # ONE stream for every N: chunk c is make_workload(seed + 1000 c, shard = c) of the same sample, a grouped file
-        # of whole reads; the stream is the chunks in order, and rank r owns a contiguous range of them.  A rank
-        # generates only what it keeps, chunk by chunk straight into HBM.
-        from slimm_amd.partition import chunk_owner
-
-        n_stream = args.records or cfg.n_records
-        n_chunks = max(1, (n_stream + args.chunk_records - 1) // args.chunk_records)
-        mine = chunk_owner(n_chunks, world)[rank]
-        parts = {"key": [], "ref": [], "pos": [], "flag": []}
-        w = None
-        for c in mine:
-            wc = make_workload(cfg, seed=args.seed + 1000 * c, n_records=min(args.chunk_records, n_stream - c * args.chunk_records),
-                               sample_seed=args.seed, shard=c)
-            parts["key"].append(torch.from_numpy(wc.records.read_key.view(np.int64)).to(dev))
-            parts["ref"].append(torch.from_numpy(wc.records.ref_id).to(dev))
-            parts["pos"].append(torch.from_numpy(wc.records.begin_pos).to(dev))
-            parts["flag"].append(torch.from_numpy(wc.records.flag.view(np.int16)).to(dev))
-            if w is None:
-                w = wc          # header, database, options (the same for every chunk) + the sample for the CPU baseline
-        if w is None:           # more ranks than chunks: this rank has no records, but takes part in the exchange
-            w = make_workload(cfg, seed=args.seed, n_records=1000, sample_seed=args.seed, shard=0)
-            z = lambda dt: torch.zeros(0, dtype=dt, device=dev)
-            key, ref, pos, flag = z(torch.int64), z(torch.int32), z(torch.int32), z(torch.int16)
-        else:
-            key, ref, pos, flag = (torch.cat(parts[k]) for k in ("key", "ref", "pos", "flag"))
-        del parts
-        n_rec = int(key.shape[0])
+    n_stream = args.records or cfg.n_records
+    want_push = extras and args.push_files > 0
+    w_sample = None   # chunk 0's workload: header, database, options; rank 0 keeps its records for the CPU legs
+    if args.weak:
+        w = make_workload(cfg, seed=args.seed + 1000 * rank, n_records=n_stream, sample_seed=args.seed, shard=rank)
+        res = Resident(len(w.records), pinned=want_push)
+        res.fill(0, w.records)
+        w_sample = w
+        n_chunks = 1
     else:
-        n_rec = args.records or cfg.n_records
-        w = make_workload(cfg, seed=args.seed + 1000 * rank, n_records=n_rec, sample_seed=args.seed, shard=rank)
-        key = torch.from_numpy(w.records.read_key.view(np.int64)).to(dev)
-        ref = torch.from_numpy(w.records.ref_id).to(dev)
-        pos = torch.from_numpy(w.records.begin_pos).to(dev)
-        flag = torch.from_numpy(w.records.flag.view(np.int16)).to(dev)
+        n_chunks = max(1, (n_stream + args.chunk_records - 1) // args.chunk_records)
+        mine = list(chunk_owner(n_chunks, world)[rank])
+        n_mine = sum(min(args.chunk_records, n_stream - c * args.chunk_records) for c in mine)
+        res = Resident(n_mine, pinned=want_push)
+        at = 0
+        for c, wc in stream_chunks(cfg, args.seed, n_stream, args.chunk_records, chunks=mine, threads=gen_threads):
+            at = res.fill(at, wc.records)
+            if w_sample is None:
+                w_sample = wc
+        if w_sample is None:   # more ranks than chunks: this rank has no records, but takes part in the exchange
+            w_sample = make_workload(cfg, seed=args.seed, n_records=1000, sample_seed=args.seed, shard=0)
+        w = w_sample
+    n_rec = res.n
     gen_s = time.time() - t0
 
     eng = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))
@@ -216,30 +280,12 @@ def main():
     if args.no_bins:
         eng.keep_bins(False)
     torch.cuda.synchronize()
-    out_path = os.path.join(tempfile.gettempdir(), f"slimm_bench_profile_{os.getpid()}.tsv")
-
     phase_times = {} if args.breakdown else None
-
-    def to_packed(k, f):
-        """slimm_pack_key on device tensors: (key & (2^61 - 1)) | mate << 61 | unmapped << 63 (what a decoder writes)."""
-        f = f.to(torch.int64) & 0xffff
-        mate = torch.where((f & 0x40) != 0, 1, torch.where((f & 0x80) != 0, 2, 0)).to(torch.int64)
-        return (k & ((1 << 61) - 1)) | (mate << 61) | (((f & 0x4) != 0).to(torch.int64) << 63)
-
-    pkey = None
-    if args.form == "packed":
-        pkey = to_packed(key, flag)
-        del key, flag   # (the packed form needs neither)
-        key = flag = None
-        torch.cuda.synchronize()
 
     def step():
         eng.reset()
         eng.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
-        if pkey is not None:
-            eng.set_records_device_packed(pkey, ref, pos)
-        else:
-            eng.set_records_device(key, ref, pos, flag)
+        res.give(eng)
         return sharded_profile(eng, dev, out_path, phase_times=phase_times, exchange=args.exchange)
 
     def barrier():
@@ -247,293 +293,331 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up steps run with every launch bracketed by HIP events: that survey names the dominant kernel and gives the
-    # --breakdown table.  The timed steps bracket only the dominant kernel (its duration is what `roofline` reports),
-    # because every event pair costs ~10 us of stream idle time and 18 pairs per step would be charged to `value`.
-    eng.enable_kernel_timing(True)
-    eng.kernel_times(reset=True)
-    survey_steps = args.warmup
-    for i in range(args.warmup):
-        step()
-        if i == 0 and args.warmup > 1:   # the first step allocates and runs cold: keep it out of the survey
-            eng.kernel_times(reset=True)
-            survey_steps -= 1
-    survey = eng.kernel_times(reset=True) if args.warmup > 0 else {}
-    dom_name = None
-    if survey and args.kernel_timing == "dominant":
-        cand = {k: ms for k, (ms, n) in survey.items() if n and k not in ("memset_bins", "k_pick_runs")}
-        if cand:
-            dom_name = max(cand, key=cand.get)
-            eng.time_only_kernel(dom_name)
-    if phase_times is not None:
-        phase_times.clear()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        profile = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ktimes = eng.kernel_times(reset=True)
-    eng.enable_kernel_timing(False)
-    eng.time_only_kernel(None)
-    if dom_name is not None:
-        # the other kernels' figures (breakdown table, device_kernel_ms_per_step) come from the warm-up survey
-        live = ktimes[dom_name]
-        ktimes = {k: ((ms / survey_steps * args.steps), int(round(n / survey_steps * args.steps)))
-                  for k, (ms, n) in survey.items()}
-        ktimes[dom_name] = live
+    def measure(engine, one_step, steps, warmup, sync):
+        """`warmup` untimed steps with every launch bracketed by HIP events (that survey names the dominant kernel and
+        gives the per-kernel table), then `steps` timed steps that bracket only the dominant kernel -- every event pair
+        costs ~10 us of stream idle time, and 18 pairs per step would be charged to the value.  Returns (seconds,
+        {kernel: (ms, launches)} scaled to `steps`, dominant kernel name, last profile)."""
+        engine.enable_kernel_timing(True)
+        engine.kernel_times(reset=True)
+        survey_steps = warmup
+        for i in range(warmup):
+            one_step()
+            if i == 0 and warmup > 1:   # the first step allocates and runs cold: keep it out of the survey
+                engine.kernel_times(reset=True)
+                survey_steps -= 1
+        survey = engine.kernel_times(reset=True) if warmup > 0 else {}
+        dom_name = None
+        if survey and args.kernel_timing == "dominant":
+            cand = {k: ms for k, (ms, n) in survey.items() if n and k not in ("memset_bins", "k_pick_runs")}
+            if cand:
+                dom_name = max(cand, key=cand.get)
+                engine.time_only_kernel(dom_name)
+        if phase_times is not None:
+            phase_times.clear()
+        sync()
+        t1 = time.perf_counter()
+        prof = None
+        for _ in range(steps):
+            prof = one_step()
+        sync()
+        el = time.perf_counter() - t1
+        kt = engine.kernel_times(reset=True)
+        engine.enable_kernel_timing(False)
+        engine.time_only_kernel(None)
+        if dom_name is not None:
+            # the other kernels' figures (breakdown table, device_kernel_ms_per_step) come from the warm-up survey
+            live = kt[dom_name]
+            kt = {k: ((ms / survey_steps * steps), int(round(n / survey_steps * steps))) for k, (ms, n) in survey.items()}
+            kt[dom_name] = live
+        return el, kt, dom_name, prof
+
+    elapsed, ktimes, dom_name, profile = measure(eng, step, args.steps, args.warmup, barrier)
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
     st = eng.stats()
-    total_records = n_rec * world
-    if strong and dist.is_initialized():
+    total_records = n_rec
+    if dist.is_initialized():
         tot = torch.tensor([n_rec], dtype=torch.int64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_records = int(tot.item())
+        total_records = int(tot[0].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = total_records / (elapsed / args.steps) / 1e6
 
-    def roofline_from(engine, stats, n_records, kt, steps, traffic_for=None):
+    def roofline_from(engine, stats, n_records, kt, steps, workload):
         """The roofline object of the dominant kernel + the per-kernel table, from HIP-event times `kt`
         ({kernel: (ms, launches)} over `steps` steps)."""
         if args.no_bins:
             Bp = int(stats["total_bins"])  # (the padded count is a property of the buffer, which is not exposed here)
         else:
             Bp = int(engine.coverage_buffer().__cuda_array_interface__["shape"][0] - 16) // 2
-        model = algorithmic_bytes(stats, n_records, Bp, 16 if args.form == "packed" else 18)
+        # (with several ranks the merged statistics count the whole stream: this rank's kernels saw its own share)
+        local = dict(stats)
+        model = algorithmic_bytes(local, n_records, Bp, rec_bytes)
         per_kernel = {}
         for name, (ms, launches) in kt.items():
             if launches and name in model:
                 steps_launches = launches / steps
                 per_kernel[name] = {"ms_per_launch": ms / launches, "launches_per_step": steps_launches,
                                     "bytes_per_launch": model[name] / max(1.0, steps_launches if name == "memset_bins" else 1.0)}
-        # of the two classification kernels the one the device did not pick returns at once (k_runs_hash then only sums
-        # the per-tile counts by chunk): its bytes are those counts, not the records
-        pair = [k for k in ("k_runs", "k_runs_hash") if k in per_kernel]
-        if len(pair) == 2:
-            idle = min(pair, key=lambda k: per_kernel[k]["ms_per_launch"])
-            per_kernel[idle]["bytes_per_launch"] = 12 * (n_records // 2048 + 1)
         # the dominant kernel = most time per step (memsets are DMA fills, not kernels of this library)
         cand = {k: v for k, v in per_kernel.items() if k not in ("memset_bins", "k_pick_runs")}
         dom = max(cand, key=lambda k: cand[k]["ms_per_launch"] * cand[k]["launches_per_step"])
         d = cand[dom]
         achieved = d["bytes_per_launch"] / (d["ms_per_launch"] * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_bytes(dom, n_records) if traffic_for == "config2" else None,
-                "traffic_source": "profiles/round2/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes)",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(dom, workload),
+                "traffic_source": "profiles/round3/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE + "
+                                  "WRITE_SIZE)",
                 "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
+        if dom == "k_front":
+            P = int(stats["n_targets"])
+            roof["bytes_model"] = (f"{rec_bytes} B x {n_records} records + 8 B x {P} targets + slot descriptors "
+                                   f"(SURVEY.md 8d: 16 N + 8 P = {16 * n_records + 8 * P}; the four-array form reads 18 N)")
         kernel_ms = sum(v["ms_per_launch"] * v["launches_per_step"] for v in per_kernel.values())
         return roof, per_kernel, kernel_ms
 
+    def print_table(tag, per_kernel):
+        for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"]):
+            gbs = v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9
+            print(f"# {tag}{k:16s} {v['ms_per_launch']*1e3:9.1f} us/launch x{v['launches_per_step']:.0f}  "
+                  f"{v['bytes_per_launch']/1e6:9.1f} MB  {gbs:8.1f} GB/s  {gbs/HBM_PEAK_GBS*100:5.1f}% of HBM peak", file=sys.stderr)
+
+    def kernels_object(per_kernel):
+        return {k: {"us": round(v["ms_per_launch"] * 1e3, 1),
+                    "frac_of_hbm_peak": round(v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
+                for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"])
+                if v["ms_per_launch"] > 0}
+
     if rank == 0:
-        roofline, per_kernel, kernel_ms = roofline_from(eng, st, n_rec, ktimes, args.steps, traffic_for=args.config)
+        # (N > 1: the statistics are the merged ones; the byte model of this rank's kernels takes its share of them)
+        st_local = dict(st)
+        if world > 1:
+            for k in ("hits_count", "n_targets", "matches_count", "uniq_matches_count", "uniq_matches_count2"):
+                st_local[k] = int(st[k]) // world
+        roofline, per_kernel, kernel_ms = roofline_from(eng, st_local, n_rec, ktimes, args.steps, args.config)
         if args.breakdown:
-            print(f"# generate {gen_s:.1f}s; records/rank {n_rec}; V={st['hits_count']} M={st['matches_count']} "
-                  f"P={st['n_targets']} U={st['uniq_matches_count']} U2={st['uniq_matches_count2']} "
+            print(f"# generate + copy {gen_s:.1f}s on {gen_threads} threads; records/rank {n_rec}; V={st['hits_count']} "
+                  f"M={st['matches_count']} P={st['n_targets']} U={st['uniq_matches_count']} U2={st['uniq_matches_count2']} "
                   f"valid={st['n_valid']} B={st['total_bins']}", file=sys.stderr)
-            for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"]):
-                gbs = v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9
-                print(f"# {k:16s} {v['ms_per_launch']*1e3:9.1f} us/launch x{v['launches_per_step']:.0f}  "
-                      f"{v['bytes_per_launch']/1e6:9.1f} MB  {gbs:8.1f} GB/s  {gbs/HBM_PEAK_GBS*100:5.1f}% of HBM peak",
-                      file=sys.stderr)
+            print_table("", per_kernel)
             print(f"# device kernels {kernel_ms:.3f} ms of {ms_per_step:.3f} ms per step", file=sys.stderr)
             for k, v in phase_times.items():
                 print(f"# host wall {k:28s} {v / args.steps * 1e6:9.1f} us/step", file=sys.stderr)
 
         # ---- push-inclusive rate (SURVEY.md section 8d (1)): the clock starts before the first record leaves host
-        # memory and stops when the profile file is written.  Never `value`: PCIe, not the path, bounds it.
+        # memory and stops when the profile file is written.  PCIe, not the path, bounds it.
         with_push = None
-        if world == 1 and args.push_steps > 0 and not args.force_exchange and not strong:
-            # Streamed ingest (slimm_push_records_async): the records sit in page-locked host memory (where a decoder
-            # would have written them), the copies of file k + 1 run on the copy stream while file k is profiled on
-            # another context -- the -d directory mode of the slimm command.  One "step" = one file: clock from the
-            # moment its first record leaves host memory (pipelined: a file's copy overlaps its predecessor's phases)
-            # to its profile file written.
-            rec = w.records
-            pinned = [torch.from_numpy(a).pin_memory().numpy() for a in
-                      (rec.read_key, rec.ref_id, rec.begin_pos, rec.flag)]
-            engs = [eng, Slimm.for_workload(w, device=local_rank, grouped=True)]
-            if args.no_bins:
-                engs[1].keep_bins(False)
-            for e in engs:   # the first pass sizes the library's own record buffers
-                e.reset()
-                e.reset_cutoffs()
-                e.push_records_async(*pinned)
-                e.get_profiles(path=out_path)
+        if want_push:
+            eng.reset()
+            eng.reset_cutoffs()
+            res.push_async(eng)              # (the first pass sizes the library's own record buffers)
+            eng.get_profiles(path=out_path)
             torch.cuda.synchronize()
-            n_files = 2 * args.push_steps
+            single = []
+            for _ in range(2):               # ONE file: push, then the path
+                eng.reset()
+                eng.reset_cutoffs()
+                t1 = time.perf_counter()
+                res.push_async(eng)
+                eng.get_profiles(path=out_path)
+                single.append(time.perf_counter() - t1)
+            dt_single = min(single)
+            # files back to back (the -d directory mode of the command): two contexts alternate, a file's copy runs on the
+            # copy stream while the file before is profiled
+            other = Slimm.for_workload(w, device=local_rank, grouped=True)
+            if args.no_bins:
+                other.keep_bins(False)
+            other.reset()
+            res.push_async(other)
+            other.get_profiles(path=out_path)
+            torch.cuda.synchronize()
+            engs = [eng, other]
+            n_files = 2 * args.push_files
             engs[0].reset()
             engs[0].reset_cutoffs()
             t1 = time.perf_counter()
-            engs[0].push_records_async(*pinned)
+            res.push_async(engs[0])
             for i in range(n_files):
                 cur, nxt = engs[i & 1], engs[(i + 1) & 1]
                 if i + 1 < n_files:
                     nxt.reset()
                     nxt.reset_cutoffs()
-                    nxt.push_records_async(*pinned)
+                    res.push_async(nxt)
                 cur.get_profiles(path=out_path)
-            dt = (time.perf_counter() - t1) / n_files
-            engs[1].close()
-            # ... and the unpipelined form: one file, synchronous slimm_push_records from pageable memory
-            eng.reset()
-            eng.reset_cutoffs()
-            t1 = time.perf_counter()
-            eng.push_records(rec, batch=args.push_batch)
-            eng.get_profiles(path=out_path)
-            dt_sync = time.perf_counter() - t1
-            with_push = {"value": round(n_rec / dt / 1e6, 3), "unit": "M records/s", "ms_per_step": round(dt * 1e3, 4),
-                         "what": f"{n_files} files of {n_rec} records from page-locked host memory through "
-                                 "slimm_push_records_async, two contexts alternating (a file's copy overlaps the file "
-                                 "before's phases), per file to profile written; 18 B/record over PCIe",
-                         "gb_per_s_over_pcie": round(18.0 * n_rec / dt / 1e9, 2),
-                         "single_file_sync_push": {"value": round(n_rec / dt_sync / 1e6, 3), "unit": "M records/s",
-                                                   "what": f"one file, slimm_push_records (pageable arrays, batches of "
-                                                           f"{args.push_batch}) to profile written"}}
+            dt_pipe = (time.perf_counter() - t1) / n_files
+            other.close()
+            with_push = {"value": round(n_rec / dt_single / 1e6, 3), "unit": "M records/s", "ms_per_step": round(dt_single * 1e3, 3),
+                         "what": f"ONE file of {n_rec} records: clock from before the first slimm_push_records"
+                                 f"{'_packed' if packed else ''}_async (records in page-locked host memory, {rec_bytes} B/record "
+                                 "over PCIe) to the profile file written; best of 2",
+                         "gb_per_s_over_pcie": round(rec_bytes * n_rec / dt_single / 1e9, 2),
+                         "files_back_to_back": {"value": round(n_rec / dt_pipe / 1e6, 3), "unit": "M records/s",
+                                                "ms_per_file": round(dt_pipe * 1e3, 3),
+                                                "what": f"{n_files} files, two contexts alternating: a file's copy overlaps the "
+                                                        "phases of the file before (the command's -d mode)"}}
+        eng.close()
+        del res
+        torch.cuda.empty_cache()
 
-        # ---- BASELINE.json configs[2]: the designated HBM-roofline run (100 M records, 20 k refs, mean 8 hits/read)
-        roof3 = None
-        if world == 1 and not args.no_config3 and args.config == "config2" and not args.force_exchange and not strong:
-            cfg3 = CONFIGS["config3"]
-            w3 = make_workload(cfg3, seed=args.seed, n_records=args.config3_records or cfg3.n_records)
-            n3 = len(w3.records)
-            eng3 = Slimm.for_workload(w3, device=local_rank, grouped=True)
+        # ---- the other single-GPU configurations of BASELINE.json, resident, one context each
+        legs = {}
+        w_cli = None
+        for name in ([c for c in args.roofline_configs.split(",") if c] if extras else []):
+            if name == args.config or name not in CONFIGS:
+                continue
+            cfgk = CONFIGS[name]
+            wk = make_workload(cfgk, seed=args.seed)
+            nk = len(wk.records)
+            engk = Slimm.for_workload(wk, device=local_rank, grouped=True)
             if args.no_bins:
-                eng3.keep_bins(False)
-            k3 = torch.from_numpy(w3.records.read_key.view(np.int64)).to(dev)
-            r3 = torch.from_numpy(w3.records.ref_id).to(dev)
-            p3 = torch.from_numpy(w3.records.begin_pos).to(dev)
-            f3 = torch.from_numpy(w3.records.flag.view(np.int16)).to(dev)
-            if args.form == "packed":
-                k3 = to_packed(k3, f3)
-            torch.cuda.synchronize()
+                engk.keep_bins(False)
+            resk = Resident(nk)
+            resk.fill(0, wk.records)
 
-            def step3():
-                eng3.reset()
-                eng3.reset_cutoffs()
-                if args.form == "packed":
-                    eng3.set_records_device_packed(k3, r3, p3)
-                else:
-                    eng3.set_records_device(k3, r3, p3, f3)
-                return eng3.get_profiles(path=out_path)
+            def stepk():
+                engk.reset()
+                engk.reset_cutoffs()
+                resk.give(engk)
+                return engk.get_profiles(path=out_path)
 
-            eng3.enable_kernel_timing(True)
-            step3()                                   # cold step: allocations
-            eng3.kernel_times(reset=True)
-            step3()                                   # survey: every launch bracketed
-            survey3 = eng3.kernel_times(reset=True)
-            cand3 = {k: ms for k, (ms, n) in survey3.items() if n and k not in ("memset_bins", "k_pick_runs")}
-            dom3 = max(cand3, key=cand3.get)
-            eng3.time_only_kernel(dom3)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.config3_steps):
-                step3()
-            torch.cuda.synchronize()
-            el3 = time.perf_counter() - t1
-            live3 = eng3.kernel_times(reset=True)
-            kt3 = {k: (ms * args.config3_steps, n * args.config3_steps) for k, (ms, n) in survey3.items()}
-            kt3[dom3] = live3[dom3]
-            st3 = eng3.stats()
-            roof3, pk3, kms3 = roofline_from(eng3, st3, n3, kt3, args.config3_steps)
-            roof3.pop("traffic_source", None)
-            roof3.update({"workload": f"BASELINE.json configs[2] (config3): {n3} records, {cfg3.n_refs} refs, mean "
-                                      f"{cfg3.mean_hits} hits/read, {cfg3.bin_width} bp bins; records resident in HBM "
-                                      f"before the timed region",
-                          "steps": args.config3_steps, "ms_per_step": round(el3 / args.config3_steps * 1e3, 4),
-                          "value": round(n3 / (el3 / args.config3_steps) / 1e6, 3), "unit_value": "M records/s",
-                          "device_kernel_ms_per_step": round(kms3, 4),
-                          "reads": st3["matches_count"], "targets": st3["n_targets"], "bins": st3["total_bins"]})
+            elk, ktk, _, _ = measure(engk, stepk, args.config_steps, 2, torch.cuda.synchronize)
+            stk = engk.stats()
+            roofk, pkk, kmsk = roofline_from(engk, stk, nk, ktk, args.config_steps, name)
+            roofk.pop("traffic_source", None)
+            roofk.update({"workload": f"BASELINE.json configs[{list(CONFIGS).index(name)}] ({name}): {nk} records, {cfgk.n_refs} refs, "
+                                      f"mean {cfgk.mean_hits} hits/read, {cfgk.bin_width} bp bins; records resident in HBM ({args.form})",
+                          "steps": args.config_steps, "ms_per_step": round(elk / args.config_steps * 1e3, 4),
+                          "value": round(nk / (elk / args.config_steps) / 1e6, 3), "unit_value": "M records/s",
+                          "device_kernel_ms_per_step": round(kmsk, 4), "reads": stk["matches_count"],
+                          "targets": stk["n_targets"], "bins": stk["total_bins"], "kernels": kernels_object(pkk)})
+            legs[name] = roofk
             if args.breakdown:
-                print(f"# config3: {n3} records, {el3 / args.config3_steps * 1e3:.3f} ms/step", file=sys.stderr)
-                for k, v in sorted(pk3.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"]):
-                    gbs = v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9
-                    print(f"# c3 {k:16s} {v['ms_per_launch']*1e3:9.1f} us/launch x{v['launches_per_step']:.0f}  "
-                          f"{v['bytes_per_launch']/1e6:9.1f} MB  {gbs:8.1f} GB/s  {gbs/HBM_PEAK_GBS*100:5.1f}% of HBM peak",
-                          file=sys.stderr)
-            eng3.close()
+                print(f"# {name}: {nk} records, {elk / args.config_steps * 1e3:.3f} ms/step", file=sys.stderr)
+                print_table(name[-2:] + " ", pkk)
+            engk.close()
+            del resk
+            torch.cuda.empty_cache()
+            if name == "config3" and not args.no_cli:
+                w_cli = wk
 
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.binding import Oracle  # the CPU restatement of the reference algorithm (checker / baseline only)
+        cpu = cpu_mt = None
+        if extras and not args.no_cpu_baseline:
+            from oracle.binding import Oracle, dense_mt_run  # the CPU restatements (checker / baseline only)
+            from slimm_amd.workload import Records
 
-            ns = min(args.cpu_sample, n_rec)
-            sample = w.records.take(np.arange(ns))
-            passes = max(1, args.cpu_passes)
-            cpu_s = wall = 0.0
-            for _ in range(passes):  # every pass a fresh object, like every GPU step
-                orc = Oracle(w.taxonomy, w.options)
-                t1 = time.perf_counter()
-                o = orc.run(w.ref_names, w.ref_len, sample, w.avg_read_len, want_raw=False, want_cov=False,
-                            use_qnames=False, collect_bins=False)
-                wall += time.perf_counter() - t1
-                cpu_s += sum(o.phase_seconds)  # the three phases + profile, excluding reference/bin allocation
-            cpu = {"value": round(passes * ns / cpu_s / 1e6, 4), "unit": "M records/s", "cores": 1, "kind": "port",
-                   "sample": f"{passes} pass(es) over the first {ns} records of the same stream (same refs/DB), phases "
-                             f"A+B+C+profile {cpu_s:.1f}s of {wall:.1f}s wall",
+            rec0 = w_sample.records
+            ns = min(args.cpu_sample, len(rec0))
+            sample = rec0.take(slice(0, ns))
+            orc = Oracle(w.taxonomy, w.options)
+            t1 = time.perf_counter()
+            o = orc.run(w.ref_names, w.ref_len, sample, w.avg_read_len, want_raw=False, want_cov=False, use_qnames=False,
+                        collect_bins=False)
+            wall = time.perf_counter() - t1
+            cpu_s = sum(o.phase_seconds)  # the three phases + profile, excluding reference/bin allocation
+            cpu = {"value": round(ns / cpu_s / 1e6, 4), "unit": "M records/s", "cores": 1, "kind": "port",
+                   "sample": f"one pass over the first {ns} records of the stream (chunk 0; same refs/DB), phases A+B+C+profile "
+                             f"{cpu_s:.1f}s of {wall:.1f}s wall",
                    "host": f"{os.cpu_count()} logical cores, cgroup quota {cpu_quota_cores()} cores"}
-
-        # ---- the same host's cores, all of them: the dense multi-threaded restatement of phases A, B and the per-read
-        # LCA (oracle/slimm_dense_mt.cpp, checked against the oracle in tests/test_dense_mt.py).  A reported baseline
-        # like cpu_baseline -- the reference itself is single-threaded -- never a code path of the product.
-        cpu_mt = None
-        if world == 1 and not args.no_cpu_baseline and not strong:
-            from oracle.binding import dense_mt_run
-
+            # ... and all cores of the same host: the dense multi-threaded restatement of phases A, B and the per-read LCA
+            # (oracle/slimm_dense_mt.cpp; equal to the oracle in tests/test_dense_mt.py and to the GPU at full size in the
+            # -m gpu suite).  The reference itself is single-threaded: a reported baseline, never a code path of the product.
+            n_mt = min(args.cpu_mt_sample, n_stream)
+            if args.weak:
+                parts = [rec0]
+            else:
+                parts = [wc.records for _, wc in stream_chunks(cfg, args.seed, n_stream, args.chunk_records,
+                                                               chunks=range((n_mt + args.chunk_records - 1) // args.chunk_records),
+                                                               threads=gen_threads)]
+            recm = Records(*(np.concatenate([getattr(p, f) for p in parts]) for f in ("read_key", "flag", "ref_id", "begin_pos")))
+            del parts
             ncpu = os.cpu_count() or 1
             best = threads = None
             t_all = time.perf_counter()
-            # more threads than the memory system feeds only add contention on the histograms: the best of a few counts
-            for th in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32)}):
-                for _ in range(2):
-                    d = dense_mt_run(w, threads=th)
-                    sec = sum(d["seconds"])
-                    if best is None or sec < best:
-                        best, threads = sec, th
-            agree = (d["hits"], d["matches"], d["uniq_matches"], d["uniq_matches2"]) == (
-                st["hits_count"], st["matches_count"], st["uniq_matches_count"], st["uniq_matches_count2"])
-            cpu_mt = {"value": round(len(w.records) / best / 1e6, 3), "unit": "M records/s", "cores": threads, "kind": "port",
-                      "sample": f"best pass over all {len(w.records)} records of the same stream, {threads} threads (best of "
-                                f"{ncpu}, {ncpu // 2}, {ncpu // 4}, 32 on {ncpu} logical cores): "
-                                f"phases A + B + per-read LCA {best * 1e3:.1f} ms (array allocation and the scalar profile "
-                                f"tail excluded), {time.perf_counter() - t_all:.1f} s wall for all passes",
-                      "cpu_quota_cores": cpu_quota_cores(), "scalars_equal_gpu": bool(agree)}
+            for th in sorted({max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32)}):
+                d = dense_mt_run(w, records=recm, threads=th)
+                sec = sum(d["seconds"])
+                if best is None or sec < best:
+                    best, threads = sec, th
+            cpu_mt = {"value": round(len(recm) / best / 1e6, 3), "unit": "M records/s", "cores": threads, "kind": "port",
+                      "sample": f"best pass over the first {len(recm)} records of the stream, {threads} threads (of {ncpu // 2}, "
+                                f"{ncpu // 4}, 32 on {ncpu} logical cores): phases A + B + per-read LCA {best * 1e3:.1f} ms (array "
+                                f"allocation and the scalar profile tail excluded), {time.perf_counter() - t_all:.1f} s wall for all passes",
+                      "cpu_quota_cores": cpu_quota_cores()}
+            del recm
+
+        # ---- the command line, process start to profile written, on a BAM large enough that HIP start-up amortises
+        cli = None
+        if extras and not args.no_cli:
+            from slimm_amd.synth_bam import write_synthetic_bam
+            from tests.bam_io import write_sldb
+
+            if w_cli is None:
+                w_cli = make_workload(CONFIGS["config3"], seed=args.seed)
+            nb = min(args.cli_records, len(w_cli.records))
+            tmp = tempfile.mkdtemp(prefix="slimm_bench_cli_")
+            bam = os.path.join(tmp, "sample.bam")
+            recb = w_cli.records if nb == len(w_cli.records) else w_cli.records.take(slice(0, nb))
+            info = write_synthetic_bam(bam, w_cli.ref_names, w_cli.ref_len, recb, read_len=w_cli.avg_read_len)
+            db = os.path.join(tmp, "db.sldb")
+            write_sldb(db, w_cli.taxonomy)
+            os.makedirs(os.path.join(tmp, "out"))
+            runs, r = [], None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/",
+                                    db, bam], capture_output=True, text=True, env=dict(os.environ, SLIMM_CLI_TRACE="1"))
+                runs.append(time.perf_counter() - t1)
+                if r.returncode != 0:
+                    runs = None
+                    break
+            if runs:
+                trace = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "[trace] reader" in ln][-1:]
+                cli = {"value": round(nb / min(runs) / 1e6, 3), "unit": "M records/s", "seconds": round(min(runs), 3),
+                       "what": f"`slimm -w 1000 DB IN.bam`, process start to profile written (HIP start-up, read-length sample, "
+                               f"BGZF inflate + decode on the host cores, packed push, GPU path), {nb} records of config3, "
+                               f"{info['raw_bytes'] / 1e9:.1f} GB of BAM records in {info['compressed_bytes'] / 1e9:.2f} GB; best of 2",
+                       "reader": trace[0] if trace else None, "bam_built_in_s": round(info["seconds"], 1)}
+            else:
+                cli = {"error": r.stderr[-400:]}
+            try:
+                os.unlink(bam)
+            except OSError:
+                pass
 
         line = {
             "metric": "M alignment-records/sec -> final profile",
             "value": round(value, 3), "unit": "M records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{list(CONFIGS).index(args.config)}] ({args.config}): "
-                                   f"{n_rec} records/GPU, {cfg.n_refs} refs, mean {cfg.mean_hits} hits/read, "
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if args.weak else "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{list(CONFIGS).index(args.config)}] ({args.config}): one seeded stream of "
+                                   f"{total_records} records over {world} GPU(s), {cfg.n_refs} refs, mean {cfg.mean_hits} hits/read, "
                                    f"{cfg.bin_width} bp bins, {cfg.read_len} bp reads",
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
                        "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
                        "record_order": args.record_order, "coverage_arrays": "not materialised" if args.no_bins else "in HBM",
-                       "records": "resident in HBM before the timed region (value_with_push starts in host memory)",
+                       "records": f"resident in HBM before the timed region, {args.form} form ({rec_bytes} B/record); "
+                                  "value_with_push starts in host memory",
                        "seed": args.seed, "parallelism": f"reads sharded over {world} GPU(s)",
-                       "stream": (f"one seeded stream of {total_records} records in chunks of {args.chunk_records}, "
-                                  f"contiguous chunk ranges per rank") if strong else "one seeded shard per rank",
+                       "stream": ("every rank its own shard of the sample" if args.weak else
+                                  f"{n_chunks} chunks of {args.chunk_records} records, contiguous chunk ranges per rank"),
                        "exchange": (resolve_exchange(eng, args.exchange, world) if (world > 1 or args.force_exchange) else "none"),
+                       "rccl_ranks": world if dist.is_initialized() else 0,
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,
-            "roofline_config3": roof3,
+            "value_resident": round(value, 3),
             "value_with_push": with_push,
+            "roofline_config2": legs.get("config2"), "roofline_config3": legs.get("config3"), "roofline_config5": legs.get("config5"),
             "cpu_baseline": cpu,
             "cpu_baseline_mt": cpu_mt,
+            "cli_end_to_end": cli,
             "device_kernel_ms_per_step": round(kernel_ms, 4),
-            # every kernel of the step from the warm-up survey (events around every launch), longest first: the dominant one
-            # is whichever is longest on this box -- k_front and k_filter are within a few us of each other
-            "kernels": {k: {"us": round(v["ms_per_launch"] * 1e3, 1),
-                            "frac_of_hbm_peak": round(v["bytes_per_launch"] / (v["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)}
-                        for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"])
-                        if v["ms_per_launch"] > 0},
-            "kernel_timing": ("HIP events around " + (f"{dom_name} only in the timed steps (other kernels: warm-up survey)"
-                                                      if dom_name else "every launch in the timed steps")),
+            # every kernel of the step from the warm-up survey (events around every launch), longest first
+            "kernels": kernels_object(per_kernel),
+            "kernel_timing": ("HIP events handed to the launch of " + (f"{dom_name} only in the timed steps (other kernels: warm-up "
+                              "survey)" if dom_name else "every kernel in the timed steps")),
         }
         print(json.dumps(line))
         try:

@@ -1,7 +1,7 @@
 # rocprofv3 kernel trace + stats of the default bench; summary goes to gpurun_out/<tag>/
 TAG=${1:-trace}
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/$TAG; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-config3 --push-steps 0 > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -o t -- python3 $R/bench.py --steps 5 --warmup 2 --quick > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$R/gpurun_out/$TAG/t_kernel_trace.csv")))

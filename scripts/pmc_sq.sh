@@ -1,7 +1,7 @@
 # SQ instruction / wait counters of every kernel (one rocprofv3 --pmc pass), for a bench configuration: scripts/pmc_sq.sh TAG [bench args]
 TAG=${1:-sq}; shift
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp
-rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS} --kernel-trace --output-format csv -d $OUT -o a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config3 --push-steps 0 "$@" > /dev/null 2>$OUT/err_a.txt
+rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS} --kernel-trace --output-format csv -d $OUT -o a -- python3 $R/bench.py --steps 2 --warmup 1 --quick "$@" > /dev/null 2>$OUT/err_a.txt
 python3 - <<PY
 import csv, collections, glob
 for f in sorted(glob.glob("$OUT/*_counter_collection.csv")):

@@ -1,8 +1,8 @@
 # HBM traffic of every kernel from the TCC counters, in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/pmc_traffic; mkdir -p $OUT; cd /tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 --push-steps 0 > /dev/null 2>$OUT/err_f.txt
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 --push-steps 0 > /dev/null 2>$OUT/err_w.txt
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config3 --push-steps 0 > /dev/null 2>$OUT/err_r.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --quick > /dev/null 2>$OUT/err_f.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- python3 $R/bench.py --steps 3 --warmup 1 --quick > /dev/null 2>$OUT/err_w.txt
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req -- python3 $R/bench.py --steps 3 --warmup 1 --quick > /dev/null 2>$OUT/err_r.txt
 python3 - <<PY
 import csv, collections, glob, json
 res=collections.defaultdict(dict)

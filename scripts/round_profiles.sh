@@ -4,7 +4,7 @@
 TAG=${1:-round}
 R=$PWD; O=$R/gpurun_out/$TAG; mkdir -p $O
 python3 bench.py --breakdown > $O/bench.json 2> $O/breakdown.txt
-python3 bench.py --breakdown --no-bins --no-cpu-baseline --no-config3 --push-steps 0 > $O/bench_no_bins.json 2> $O/breakdown_no_bins.txt
+python3 bench.py --breakdown --no-bins --quick > $O/bench_no_bins.json 2> $O/breakdown_no_bins.txt
 bash scripts/kernel_trace.sh $TAG/trace > $O/trace_gaps.txt 2>&1
 cp $O/trace/t_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
 bash scripts/pmc_sq.sh $TAG/sq > /dev/null 2>&1; cp $O/sq/summary.txt $O/sq_counters.txt 2>/dev/null

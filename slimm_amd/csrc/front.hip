@@ -325,7 +325,7 @@ struct Staged {
 // Segments longer than this take the hash table in window_fast (a walk step is two vector and two scalar instructions,
 // the table about fifty instructions and four LDS round trips whatever the segments look like)
 #ifndef SLIMM_HASH_WALK
-#define SLIMM_HASH_WALK 48
+#define SLIMM_HASH_WALK 32
 #endif
 constexpr uint32_t kHashWalk = SLIMM_HASH_WALK;
 // D = N0 & (N0 << 1) marks the second and later lanes of every stretch of set bits of N0 (non-start lanes: a segment of

@@ -215,21 +215,19 @@ def main():
                     self.host.append(torch.empty(n, dtype=torch.int16).pin_memory())
 
         def fill(self, lo, rec):
+            """The chunk goes to the device as it is; packing happens there (a decoder would write packed keys
+            directly), and the page-locked host copy -- what value_with_push pushes -- is read back from the device."""
             hi = lo + len(rec)
-            k = torch.from_numpy(rec.read_key.view(np.int64))
-            f = torch.from_numpy(rec.flag.view(np.int16))
-            if packed:
-                k = to_packed(k, f)
-            parts = [k, torch.from_numpy(rec.ref_id), torch.from_numpy(rec.begin_pos)] + ([] if packed else [f])
-            if self.host is not None:
-                for h, p in zip(self.host, parts):
-                    h[lo:hi] = p
-                parts = [h[lo:hi] for h in self.host]
-            self.key[lo:hi].copy_(parts[0], non_blocking=True)
-            self.ref[lo:hi].copy_(parts[1], non_blocking=True)
-            self.pos[lo:hi].copy_(parts[2], non_blocking=True)
+            k = torch.from_numpy(rec.read_key.view(np.int64)).to(dev, non_blocking=True)
+            f = torch.from_numpy(rec.flag.view(np.int16)).to(dev, non_blocking=True)
+            self.key[lo:hi] = to_packed(k, f) if packed else k
+            self.ref[lo:hi].copy_(torch.from_numpy(rec.ref_id), non_blocking=True)
+            self.pos[lo:hi].copy_(torch.from_numpy(rec.begin_pos), non_blocking=True)
             if not packed:
-                self.flag[lo:hi].copy_(parts[3], non_blocking=True)
+                self.flag[lo:hi] = f
+            if self.host is not None:
+                for h, d in zip(self.host, [self.key, self.ref, self.pos] + ([] if packed else [self.flag])):
+                    h[lo:hi].copy_(d[lo:hi], non_blocking=True)
             torch.cuda.synchronize()   # (the chunk's arrays may go away)
             return hi
 

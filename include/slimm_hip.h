@@ -179,6 +179,11 @@ int slimm_set_stream_ordered(slimm_ctx* ctx, int on);
  * device buffer [cov | uniq_cov | 16 scalar words] of *n_words uint32 that the caller sums across ranks in place
  * (one all-reduce) between slimm_analyze_alignments() and slimm_finish_coverage().  The stream is synchronised. */
 int slimm_coverage_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
+/* The third coverage array, uniq_cov2 (reference_contig.hpp:112), after slimm_filter_alignments / slimm_install_merged_
+ * partials: *n_words uint32 (every reference padded like in slimm_coverage_buffer) that the caller may sum across ranks
+ * in place so that slimm_get_bins(ctx, 2, ...) returns the global array.  The stream is synchronised unless
+ * slimm_set_stream_ordered is on. */
+int slimm_uniq_cov2_buffer(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
 
 /* Multi-GPU, optional: announce before slimm_analyze_alignments that slimm_coverage_summary will be called, so that
  * the histogram kernels write the 'bin != 0' bitmaps while the finished tiles are still in LDS (otherwise
@@ -367,6 +372,20 @@ int slimm_group_uses_rccl(const slimm_group* g);
 int slimm_group_reset(slimm_group* g);
 int slimm_group_push_records(slimm_group* g, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
                              const uint16_t* flag, uint64_t n);
+/* With a check word per record (slimm_push_records_checked): two names that collide in the key land on the same member
+ * whichever way the records are dealt, so a group reports SLIMM_E_KEY_COLLISION exactly where one context would. */
+int slimm_group_push_records_checked(slimm_group* g, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
+                                     const uint16_t* flag, const uint32_t* check, uint64_t n);
+/* The exchange between phase A and the cut-offs: SUMMARY = ncclAllGather of [per-reference sums | scalars | one bit per
+ * bin]; SLICED = all-to-all of the bitmaps in one slice per member (ncclSend / ncclRecv in one group) + a small
+ * ncclAllReduce; BINS = the ncclAllReduce(ncclSum) over the integer coverage bins themselves [cov | uniq_cov | scalars],
+ * after which -- and after a second all-reduce of uniq_cov2 behind phase B -- every member's slimm_get_bins returns the
+ * GLOBAL arrays (what the reference's -ro / -co outputs read, src/slimm.hpp:846-943; nz_uniq_cov2 of
+ * slimm_get_ref_columns stays the member's own count: count the non-zero bins of the global array instead).
+ * AUTO (default) = SUMMARY up to two members, SLICED above. */
+enum { SLIMM_EXCHANGE_AUTO = 0, SLIMM_EXCHANGE_SUMMARY = 1, SLIMM_EXCHANGE_SLICED = 2, SLIMM_EXCHANGE_BINS = 3 };
+int slimm_group_set_exchange(slimm_group* g, int mode);
+int slimm_group_exchange(const slimm_group* g); /* the form in effect (what AUTO resolves to) */
 int slimm_group_get_profiles(slimm_group* g, const char* path); /* path may be NULL; SLIMM_E_NO_HITS like slimm_get_profiles */
 
 /* Starts the HIP runtime on `device` (what the first slimm_create of a process would otherwise pay, 0.1 - 0.3 s): for

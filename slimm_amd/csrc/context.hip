@@ -1056,6 +1056,18 @@ int slimm_coverage_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
     return SLIMM_OK;
 }
 
+int slimm_uniq_cov2_buffer(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
+    if (!c || !d_ptr || !n_words) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no coverage arrays");
+    if (!c->filtered) return fail(c, SLIMM_E_INVALID, "call slimm_filter_alignments first");
+    if (!c->binsB_stored) return fail(c, SLIMM_E_INVALID, "the coverage arrays were not kept (slimm_keep_bins)");
+    (void)hipSetDevice(c->device);
+    if (!c->stream_ordered) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *d_ptr = c->ucov2();
+    *n_words = c->Bp;
+    return SLIMM_OK;
+}
+
 namespace {
 // shared end of phase A: the packed block A = [4R: {reads_count, nz_cov, uniq_reads_count, nz_uniq_cov} | 32 counters |
 // 16 tail (hits, matches, targets, err)] is final on the device; one copy brings it to the host

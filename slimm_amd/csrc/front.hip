@@ -108,17 +108,27 @@ __device__ __forceinline__ uint64_t f_first_after(uint64_t starts, uint64_t bits
 // first record of that (read, reference) pair in file order.  No barrier: one wave, and the LDS executes a wave's
 // operations in order.  (The ballots between the steps are what the host emulator of tests/native synchronises its
 // lanes on; on the GPU they are the loop test and a compare.)
-constexpr uint32_t kHashBits = 7;
+#ifndef SLIMM_HASH_BITS
+#define SLIMM_HASH_BITS 7
+#endif
+constexpr uint32_t kHashBits = SLIMM_HASH_BITS;
 constexpr uint32_t kHashSlots = 1u << kHashBits;   // 128 entries of 8 bytes: 1 KB per wave, half full at 64 keys
+static_assert(kHashBits >= 7, "hash_clear writes 128 entries at a time");
 __device__ __forceinline__ void hash_clear(uint32_t* tab, uint32_t lane) {
-    reinterpret_cast<uint4*>(tab)[lane] = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);  // 64 lanes x 2 entries
+#pragma unroll
+    for (uint32_t k = 0; k < kHashSlots / 128u; ++k)  // 64 lanes x 2 entries
+        reinterpret_cast<uint4*>(tab)[64u * k + lane] = make_uint4(0u, 0xffffffffu, 0u, 0xffffffffu);
 }
 // key != 0; `pos` = the lane's position in file order among everything inserted since hash_clear.  Returns whether the
 // lane is the first of its key; overflow: the table is full (more than kHashSlots distinct keys) -- the caller falls
 // back to the comparison walk.
 __device__ __forceinline__ bool hash_first(uint32_t* tab, uint32_t key, uint32_t pos, bool active, bool& overflow) {
     uint2* const e = reinterpret_cast<uint2*>(tab);
+#ifdef SLIMM_HASH_LINEAR
+    uint32_t slot = (key + (key >> 7) * 37u + (key >> 26) * 11u) & (kHashSlots - 1u);
+#else
     uint32_t slot = (key * 0x9E3779B1u) >> (32u - kHashBits);
+#endif
     bool pending = active;
     uint32_t probes = 0;
     while (f_ballot(pending) != 0ull) {
@@ -368,13 +378,24 @@ __device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint3
     } else {
         const uint32_t x1 = f_shr1z(T) ^ T;
         uint32_t x = x1, differ = x1;
-        while (D) {
+        // (the scalar unit is what a CU has one of: segments of up to six records -- four steps -- update D step by step,
+        // longer ones go on eight steps at a time with D advanced by doubling: one scalar instruction per step, not two)
+        if (D) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 x = f_shr1z(x) ^ x1;
                 differ = min(differ, x);
                 D &= D << 1;
             }
+        }
+        while (D) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x = f_shr1z(x) ^ x1;
+                differ = min(differ, x);
+            }
+            const uint64_t t2 = D & (D << 1), t4 = t2 & (t2 << 2), t8 = t4 & (t4 << 4);
+            D = t8 & (D << 8);
         }
         F = f_ballot(differ != 0u) & V;
     }

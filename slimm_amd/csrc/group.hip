@@ -37,6 +37,8 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;  // (optional: the all-to-all of the sliced form)
+    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
     static constexpr int kInt32 = 2, kSum = 0;  // ncclInt32, ncclSum
     void* handle = nullptr;
     bool load() {
@@ -51,7 +53,25 @@ struct Rccl {
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(handle, "ncclAllGather"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
+        Send = reinterpret_cast<decltype(Send)>(dlsym(handle, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(handle, "ncclRecv"));
         return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && AllReduce;
+    }
+};
+
+// ncclGroupStart ... ncclGroupEnd with the end on every way out (an error between the two must not leave the thread's
+// RCCL group open: the ncclCommDestroy of slimm_group_destroy would run inside it)
+struct RcclGroup {
+    Rccl& r;
+    bool open;
+    explicit RcclGroup(Rccl& rccl) : r(rccl), open(rccl.GroupStart() == 0) {}
+    int end() {
+        if (!open) return -1;
+        open = false;
+        return r.GroupEnd();
+    }
+    ~RcclGroup() {
+        if (open) (void)r.GroupEnd();
     }
 };
 
@@ -83,6 +103,10 @@ struct slimm_group {
     std::vector<uint64_t> carry_key;         // the last qName run of the batch before: it may go on in the next batch
     std::vector<int32_t> carry_ref, carry_pos;
     std::vector<uint16_t> carry_flag;
+    std::vector<uint32_t> carry_check;       // (streams pushed with check words)
+    int checked = -1;                        // -1: nothing pushed yet, 0 / 1: the file's pushes carry no / carry check words
+    int exchange = SLIMM_EXCHANGE_AUTO;
+    uint32_t n_refs = 0;
     bool have_last = false;
     uint64_t last_key = 0;
     std::string err;
@@ -116,6 +140,8 @@ int member_failed(slimm_group* g, uint32_t i, int rc, const char* what) {
         if (e_ != hipSuccess) return gfail(g, SLIMM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+uint32_t ref_count(slimm_group* g) { return g->n_refs; }
+
 int ensure_scratch(slimm_group* g, uint32_t i, size_t words) {
     if (g->scratch_words[i] >= words) return SLIMM_OK;
     GHIP(g, hipSetDevice(g->device[i]));
@@ -124,6 +150,22 @@ int ensure_scratch(slimm_group* g, uint32_t i, size_t words) {
     g->scratch_words[i] = 0;
     GHIP(g, hipMalloc(reinterpret_cast<void**>(&g->scratch[i]), words * 4));
     g->scratch_words[i] = words;
+    return SLIMM_OK;
+}
+
+// nobody goes on (and overwrites a buffer its peers were given to read) before every member's copies are done: each
+// member records "I have read everybody's buffer", each member's stream waits for all of them
+int read_fence(slimm_group* g) {
+    const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        GHIP(g, hipEventRecord(g->copied[i], g->stream[i]));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        for (uint32_t j = 0; j < n; ++j)
+            if (j != i) GHIP(g, hipStreamWaitEvent(g->stream[i], g->copied[j], 0));
+    }
     return SLIMM_OK;
 }
 
@@ -137,13 +179,14 @@ int all_gather(slimm_group* g, const std::vector<uint32_t*>& send, size_t words,
         recv[i] = g->scratch[i];
     }
     if (g->use_rccl) {
-        if (g->rccl.GroupStart() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
+        RcclGroup grp(g->rccl);
+        if (!grp.open) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
         for (uint32_t i = 0; i < n; ++i) {
             GHIP(g, hipSetDevice(g->device[i]));
             if (g->rccl.AllGather(send[i], recv[i], words, Rccl::kInt32, g->comm[i], g->stream[i]) != 0)
                 return gfail(g, SLIMM_E_HIP, "ncclAllGather failed on member %u", i);
         }
-        if (g->rccl.GroupEnd() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
+        if (grp.end() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
         return SLIMM_OK;
     }
     for (uint32_t j = 0; j < n; ++j) {
@@ -158,56 +201,167 @@ int all_gather(slimm_group* g, const std::vector<uint32_t*>& send, size_t words,
                                    g->stream[i]));
         }
     }
-    return SLIMM_OK;
+    return read_fence(g);
+}
+
+// recv[i] = chunk i of send[0] | chunk i of send[1] | ... (chunks of `words` each): every member gets ITS chunk of every
+// member's buffer -- ncclSend / ncclRecv pairs inside one RCCL group (what ncclAllToAll is made of), or copies
+int all_to_all(slimm_group* g, const std::vector<uint32_t*>& send, size_t words, std::vector<uint32_t*>& recv) {
+    const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+    recv.assign(n, nullptr);
+    for (uint32_t i = 0; i < n; ++i) {
+        int rc = ensure_scratch(g, i, n * words);
+        if (rc != SLIMM_OK) return rc;
+        recv[i] = g->scratch[i];
+    }
+    if (g->use_rccl) {
+        RcclGroup grp(g->rccl);
+        if (!grp.open) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
+        for (uint32_t i = 0; i < n; ++i) {
+            GHIP(g, hipSetDevice(g->device[i]));
+            for (uint32_t j = 0; j < n; ++j) {
+                if (g->rccl.Send(send[i] + static_cast<size_t>(j) * words, words, Rccl::kInt32, static_cast<int>(j), g->comm[i],
+                                 g->stream[i]) != 0 ||
+                    g->rccl.Recv(recv[i] + static_cast<size_t>(j) * words, words, Rccl::kInt32, static_cast<int>(j), g->comm[i],
+                                 g->stream[i]) != 0)
+                    return gfail(g, SLIMM_E_HIP, "ncclSend / ncclRecv failed on member %u", i);
+            }
+        }
+        if (grp.end() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
+        return SLIMM_OK;
+    }
+    for (uint32_t j = 0; j < n; ++j) {
+        GHIP(g, hipSetDevice(g->device[j]));
+        GHIP(g, hipEventRecord(g->ready[j], g->stream[j]));
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        for (uint32_t j = 0; j < n; ++j) {
+            if (j != i) GHIP(g, hipStreamWaitEvent(g->stream[i], g->ready[j], 0));
+            GHIP(g, hipMemcpyAsync(recv[i] + static_cast<size_t>(j) * words, send[j] + static_cast<size_t>(i) * words, words * 4,
+                                   hipMemcpyDeviceToDevice, g->stream[i]));
+        }
+    }
+    return read_fence(g);
 }
 
 // buf[i][w] = sum over the members of buf[j][w], in place, enqueued on the members' streams
 int all_reduce_sum(slimm_group* g, const std::vector<uint32_t*>& buf, size_t words) {
     const uint32_t n = static_cast<uint32_t>(g->ctx.size());
     if (g->use_rccl) {
-        if (g->rccl.GroupStart() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
+        RcclGroup grp(g->rccl);
+        if (!grp.open) return gfail(g, SLIMM_E_HIP, "ncclGroupStart failed");
         for (uint32_t i = 0; i < n; ++i) {
             GHIP(g, hipSetDevice(g->device[i]));
             if (g->rccl.AllReduce(buf[i], buf[i], words, Rccl::kInt32, Rccl::kSum, g->comm[i], g->stream[i]) != 0)
                 return gfail(g, SLIMM_E_HIP, "ncclAllReduce failed on member %u", i);
         }
-        if (g->rccl.GroupEnd() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
+        if (grp.end() != 0) return gfail(g, SLIMM_E_HIP, "ncclGroupEnd failed");
         return SLIMM_OK;
     }
-    std::vector<uint32_t*> parts;
-    int rc = all_gather(g, buf, words, parts);  // parts[i] = everybody's buffer, on member i's device
-    if (rc != SLIMM_OK) return rc;
-    // nobody overwrites its buffer before everybody has read it
-    for (uint32_t i = 0; i < n; ++i) {
-        GHIP(g, hipSetDevice(g->device[i]));
-        GHIP(g, hipEventRecord(g->copied[i], g->stream[i]));
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        GHIP(g, hipSetDevice(g->device[i]));
-        for (uint32_t j = 0; j < n; ++j)
-            if (j != i) GHIP(g, hipStreamWaitEvent(g->stream[i], g->copied[j], 0));
-        const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>(256, (words + 255) / 256));
-        hipLaunchKernelGGL(k_group_sum, dim3(std::max(1u, blocks)), dim3(256), 0, g->stream[i], parts[i], n,
-                           static_cast<uint32_t>(words), buf[i]);
+    // the copy form goes in pieces, so that the receive buffers stay small whatever is reduced (the bins form sums
+    // 2 Bp + 16 words: 160 MB at config 2); all_gather ends with the fence that lets the sums overwrite the buffers
+    const size_t piece = 16u << 20;  // words
+    for (size_t lo = 0; lo < words; lo += piece) {
+        const size_t w = std::min(piece, words - lo);
+        std::vector<uint32_t*> part(n), parts;
+        for (uint32_t i = 0; i < n; ++i) part[i] = buf[i] + lo;
+        int rc = all_gather(g, part, w, parts);  // parts[i] = everybody's piece, on member i's device
+        if (rc != SLIMM_OK) return rc;
+        for (uint32_t i = 0; i < n; ++i) {
+            GHIP(g, hipSetDevice(g->device[i]));
+            const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>(1024, (w + 255) / 256));
+            hipLaunchKernelGGL(k_group_sum, dim3(std::max(1u, blocks)), dim3(256), 0, g->stream[i], parts[i], n,
+                               static_cast<uint32_t>(w), part[i]);
+        }
+        if (lo + piece < words) {  // (the next piece reuses the receive buffers)
+            int rf = read_fence(g);
+            if (rf != SLIMM_OK) return rf;
+        }
     }
     return SLIMM_OK;
 }
 
 int push_to(slimm_group* g, uint32_t i, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
-            uint64_t n) {
+            const uint32_t* check, uint64_t n) {
     if (n == 0) return SLIMM_OK;
-    GTRY(g, i, slimm_push_records(g->ctx[i], key, ref, pos, flag, n));
+    if (check)
+        GTRY(g, i, slimm_push_records_checked(g->ctx[i], key, ref, pos, flag, check, n));
+    else
+        GTRY(g, i, slimm_push_records(g->ctx[i], key, ref, pos, flag, n));
     return SLIMM_OK;
 }
 
 int flush_carry(slimm_group* g, uint32_t to) {
     if (g->carry_key.empty()) return SLIMM_OK;
-    int rc = push_to(g, to, g->carry_key.data(), g->carry_ref.data(), g->carry_pos.data(), g->carry_flag.data(), g->carry_key.size());
+    int rc = push_to(g, to, g->carry_key.data(), g->carry_ref.data(), g->carry_pos.data(), g->carry_flag.data(),
+                     g->carry_check.empty() ? nullptr : g->carry_check.data(), g->carry_key.size());
     g->carry_key.clear();
     g->carry_ref.clear();
     g->carry_pos.clear();
     g->carry_flag.clear();
+    g->carry_check.clear();
     return rc;
+}
+
+// Deals a batch to the members by read.  Name-grouped streams: the batch up to its last qName-run start goes to the
+// current member (together with the run the batch before ended in), the last run waits for the next batch -- it may go
+// on there -- and the next member is up: contiguous stretches of the file, cut at run boundaries, in turn.  Any other
+// order: member = key mod n (two names that collide in the key land on the same member, so check words do their work).
+int deal(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag, const uint32_t* check,
+         uint64_t n) {
+    if (!g) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!key || !ref || !pos || !flag) return gfail(g, SLIMM_E_INVALID, "null record array");
+    if (g->checked >= 0 && g->checked != (check ? 1 : 0))
+        return gfail(g, SLIMM_E_INVALID, "checked and unchecked pushes do not mix within a file");
+    g->checked = check ? 1 : 0;
+    const uint32_t m = static_cast<uint32_t>(g->ctx.size());
+    if (m == 1) return push_to(g, 0, key, ref, pos, flag, check, n);
+    if (g->order != SLIMM_ORDER_GROUPED) {
+        std::vector<std::vector<uint64_t>> k(m);
+        std::vector<std::vector<int32_t>> r(m), p(m);
+        std::vector<std::vector<uint16_t>> f(m);
+        std::vector<std::vector<uint32_t>> c(m);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t o = static_cast<uint32_t>((key[i] & kKeyMask) % m);
+            k[o].push_back(key[i]);
+            r[o].push_back(ref[i]);
+            p[o].push_back(pos[i]);
+            f[o].push_back(flag[i]);
+            if (check) c[o].push_back(check[i]);
+        }
+        for (uint32_t o = 0; o < m; ++o) {
+            int rc = push_to(g, o, k[o].data(), r[o].data(), p[o].data(), f[o].data(), check ? c[o].data() : nullptr, k[o].size());
+            if (rc != SLIMM_OK) return rc;
+        }
+        return SLIMM_OK;
+    }
+    // the run the batch before ended in goes where this batch's head goes
+    int rc = flush_carry(g, g->cur);
+    if (rc != SLIMM_OK) return rc;
+    uint64_t last_start = n;  // index of the batch's last run start, n = none found
+    for (uint64_t i = n; i-- > 1;)
+        if ((key[i] ^ key[i - 1]) & kKeyMask) {
+            last_start = i;
+            break;
+        }
+    if (last_start == n && !(g->have_last && ((key[0] ^ g->last_key) & kKeyMask) == 0)) last_start = 0;  // one run, a new one
+    g->have_last = true;
+    g->last_key = key[n - 1];
+    if (last_start == n || last_start == 0) {
+        // no boundary inside the batch: it stays with the current member, and so does whatever continues it
+        return push_to(g, g->cur, key, ref, pos, flag, check, n);
+    }
+    rc = push_to(g, g->cur, key, ref, pos, flag, check, last_start);
+    if (rc != SLIMM_OK) return rc;
+    g->carry_key.assign(key + last_start, key + n);
+    g->carry_ref.assign(ref + last_start, ref + n);
+    g->carry_pos.assign(pos + last_start, pos + n);
+    g->carry_flag.assign(flag + last_start, flag + n);
+    if (check) g->carry_check.assign(check + last_start, check + n);
+    g->cur = (g->cur + 1) % m;
+    return SLIMM_OK;
 }
 
 }  // namespace
@@ -221,6 +375,7 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
     }
     slimm_group* g = new slimm_group();
     g->order = cfg->record_order;
+    g->n_refs = cfg->n_refs;
     bool distinct = true;
     for (uint32_t i = 0; i < n_devices; ++i)
         for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
@@ -268,6 +423,12 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
         slimm_group_destroy(g);
         return SLIMM_E_HIP;
     }
+    if (const char* ex = getenv("SLIMM_GROUP_EXCHANGE")) {  // summary | sliced | bins (tests, experiments)
+        g->exchange = strcmp(ex, "summary") == 0 ? SLIMM_EXCHANGE_SUMMARY
+                      : strcmp(ex, "sliced") == 0 ? SLIMM_EXCHANGE_SLICED
+                      : strcmp(ex, "bins") == 0   ? SLIMM_EXCHANGE_BINS
+                                                  : SLIMM_EXCHANGE_AUTO;
+    }
     if (n_devices > 1 || g->use_rccl)  // the collectives run on the members' streams: no host fences around them
         for (slimm_ctx* c : g->ctx) (void)slimm_set_stream_ordered(c, 1);
     *out = g;
@@ -306,62 +467,31 @@ int slimm_group_reset(slimm_group* g) {
     g->carry_ref.clear();
     g->carry_pos.clear();
     g->carry_flag.clear();
+    g->carry_check.clear();
+    g->checked = -1;
     g->have_last = false;
     return SLIMM_OK;
 }
 
-// Deals a batch to the members by read.  Name-grouped streams: the batch up to its last qName-run start goes to the
-// current member (together with the run the batch before ended in), the last run waits for the next batch -- it may go
-// on there -- and the next member is up: contiguous stretches of the file, cut at run boundaries, in turn.  Any other
-// order: member = key mod n.
 int slimm_group_push_records(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
                              uint64_t n) {
-    if (!g) return SLIMM_E_INVALID;
-    if (n == 0) return SLIMM_OK;
-    if (!key || !ref || !pos || !flag) return gfail(g, SLIMM_E_INVALID, "null record array");
-    const uint32_t m = static_cast<uint32_t>(g->ctx.size());
-    if (m == 1) return push_to(g, 0, key, ref, pos, flag, n);
-    if (g->order != SLIMM_ORDER_GROUPED) {
-        std::vector<std::vector<uint64_t>> k(m);
-        std::vector<std::vector<int32_t>> r(m), p(m);
-        std::vector<std::vector<uint16_t>> f(m);
-        for (uint64_t i = 0; i < n; ++i) {
-            const uint32_t o = static_cast<uint32_t>((key[i] & kKeyMask) % m);
-            k[o].push_back(key[i]);
-            r[o].push_back(ref[i]);
-            p[o].push_back(pos[i]);
-            f[o].push_back(flag[i]);
-        }
-        for (uint32_t o = 0; o < m; ++o) {
-            int rc = push_to(g, o, k[o].data(), r[o].data(), p[o].data(), f[o].data(), k[o].size());
-            if (rc != SLIMM_OK) return rc;
-        }
-        return SLIMM_OK;
-    }
-    // the run the batch before ended in goes where this batch's head goes
-    int rc = flush_carry(g, g->cur);
-    if (rc != SLIMM_OK) return rc;
-    uint64_t last_start = n;  // index of the batch's last run start, n = none found
-    for (uint64_t i = n; i-- > 1;)
-        if ((key[i] ^ key[i - 1]) & kKeyMask) {
-            last_start = i;
-            break;
-        }
-    if (last_start == n && !(g->have_last && ((key[0] ^ g->last_key) & kKeyMask) == 0)) last_start = 0;  // one run, a new one
-    g->have_last = true;
-    g->last_key = key[n - 1];
-    if (last_start == n || last_start == 0) {
-        // no boundary inside the batch: it stays with the current member, and so does whatever continues it
-        return push_to(g, g->cur, key, ref, pos, flag, n);
-    }
-    rc = push_to(g, g->cur, key, ref, pos, flag, last_start);
-    if (rc != SLIMM_OK) return rc;
-    g->carry_key.assign(key + last_start, key + n);
-    g->carry_ref.assign(ref + last_start, ref + n);
-    g->carry_pos.assign(pos + last_start, pos + n);
-    g->carry_flag.assign(flag + last_start, flag + n);
-    g->cur = (g->cur + 1) % m;
+    return deal(g, key, ref, pos, flag, nullptr, n);
+}
+int slimm_group_push_records_checked(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t* pos,
+                                     const uint16_t* flag, const uint32_t* check, uint64_t n) {
+    if (g && n && !check) return gfail(g, SLIMM_E_INVALID, "null check array");
+    return deal(g, key, ref, pos, flag, check, n);
+}
+int slimm_group_set_exchange(slimm_group* g, int mode) {
+    if (!g || mode < SLIMM_EXCHANGE_AUTO || mode > SLIMM_EXCHANGE_BINS) return SLIMM_E_INVALID;
+    g->exchange = mode;
     return SLIMM_OK;
+}
+int slimm_group_exchange(const slimm_group* g) {  // what AUTO means for this group
+    if (!g) return SLIMM_E_INVALID;
+    if (g->exchange != SLIMM_EXCHANGE_AUTO) return g->exchange;
+    const bool can_slice = !g->use_rccl || (g->rccl.Send && g->rccl.Recv);
+    return (g->ctx.size() > 2 && can_slice) ? SLIMM_EXCHANGE_SLICED : SLIMM_EXCHANGE_SUMMARY;
 }
 
 // slimm::get_profiles() (src/slimm.hpp:447-489) over the members' reads: phases A, B, C(1) on every member with the two
@@ -376,26 +506,76 @@ int slimm_group_get_profiles(slimm_group* g, const char* path) {
         if (rc < 0) return member_failed(g, 0, rc, "slimm_get_profiles");
         return rc;
     }
-    for (uint32_t i = 0; i < n; ++i) GTRY(g, i, slimm_prepare_summary(g->ctx[i], 1));
+    // ---- phase A on every member, then exchange 1 in one of three forms (slimm_amd/distributed.py has the same three):
+    //   SUMMARY  ncclAllGather of [per-reference sums | scalars | one bit per bin]
+    //   SLICED   all-to-all of the bitmaps cut into one slice per member (ncclSend / ncclRecv in one group), every member
+    //            merges ITS slice of everybody's bitmaps, then a small ncclAllReduce of [sums, partial counts | scalars]
+    //   BINS     the literal ncclAllReduce(ncclSum) over [cov | uniq_cov | scalars]: every member then holds the global
+    //            coverage arrays (what the reference's -ro / -co outputs read, src/slimm.hpp:846-943)
+    const int how = slimm_group_exchange(g);
+    for (uint32_t i = 0; i < n; ++i)
+        GTRY(g, i, slimm_prepare_summary(g->ctx[i], how == SLIMM_EXCHANGE_SLICED ? n : (how == SLIMM_EXCHANGE_SUMMARY ? 1u : 0u)));
     for (uint32_t i = 0; i < n; ++i) GTRY(g, i, slimm_analyze_alignments(g->ctx[i]));
-    // ---- exchange 1: per-reference sums + one bit per bin of every member, all-gathered
-    std::vector<uint32_t*> mine(n), gathered;
-    uint64_t words = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        void* p = nullptr;
-        uint64_t w = 0;
-        GTRY(g, i, slimm_coverage_summary(g->ctx[i], &p, &w));
-        mine[i] = static_cast<uint32_t*>(p);
-        if (i && w != words) return gfail(g, SLIMM_E_INVALID, "members disagree about the summary size");
-        words = w;
-    }
-    rc = all_gather(g, mine, words, gathered);
-    if (rc != SLIMM_OK) return rc;
     bool hits = false;
-    for (uint32_t i = 0; i < n; ++i) {
-        rc = slimm_finish_coverage_merged(g->ctx[i], gathered[i], n);
-        if (rc < 0) return member_failed(g, i, rc, "slimm_finish_coverage_merged");
-        hits = hits || rc != SLIMM_E_NO_HITS;
+    if (how == SLIMM_EXCHANGE_BINS) {
+        std::vector<uint32_t*> bins(n);
+        uint64_t words = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            void* p = nullptr;
+            uint64_t w = 0;
+            GTRY(g, i, slimm_coverage_buffer(g->ctx[i], &p, &w));
+            bins[i] = static_cast<uint32_t*>(p);
+            if (i && w != words) return gfail(g, SLIMM_E_INVALID, "members disagree about the coverage buffer size");
+            words = w;
+        }
+        rc = all_reduce_sum(g, bins, words);
+        if (rc != SLIMM_OK) return rc;
+        for (uint32_t i = 0; i < n; ++i) {
+            rc = slimm_finish_coverage(g->ctx[i]);
+            if (rc < 0) return member_failed(g, i, rc, "slimm_finish_coverage");
+            hits = hits || rc != SLIMM_E_NO_HITS;
+        }
+    } else {
+        std::vector<uint32_t*> mine(n), gathered;
+        uint64_t words = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            void* p = nullptr;
+            uint64_t w = 0;
+            GTRY(g, i, slimm_coverage_summary(g->ctx[i], &p, &w));
+            mine[i] = static_cast<uint32_t*>(p);
+            if (i && w != words) return gfail(g, SLIMM_E_INVALID, "members disagree about the summary size");
+            words = w;
+        }
+        if (how == SLIMM_EXCHANGE_SLICED) {
+            const uint64_t head = 4ull * ref_count(g) + 16;  // [4 R sums | 16 scalars] in front of the n chunks
+            if (words < head || (words - head) % n) return gfail(g, SLIMM_E_INVALID, "unexpected sliced summary size");
+            const uint64_t chunk = (words - head) / n;
+            std::vector<uint32_t*> chunks(n), vec(n);
+            for (uint32_t i = 0; i < n; ++i) chunks[i] = mine[i] + head;
+            rc = all_to_all(g, chunks, chunk, gathered);
+            if (rc != SLIMM_OK) return rc;
+            uint64_t vw = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                void* v = nullptr;
+                GTRY(g, i, slimm_merge_summary_slices(g->ctx[i], gathered[i], n, i, &v, &vw));
+                vec[i] = static_cast<uint32_t*>(v);
+            }
+            rc = all_reduce_sum(g, vec, vw);
+            if (rc != SLIMM_OK) return rc;
+            for (uint32_t i = 0; i < n; ++i) {
+                rc = slimm_finish_coverage_reduced(g->ctx[i]);
+                if (rc < 0) return member_failed(g, i, rc, "slimm_finish_coverage_reduced");
+                hits = hits || rc != SLIMM_E_NO_HITS;
+            }
+        } else {
+            rc = all_gather(g, mine, words, gathered);
+            if (rc != SLIMM_OK) return rc;
+            for (uint32_t i = 0; i < n; ++i) {
+                rc = slimm_finish_coverage_merged(g->ctx[i], gathered[i], n);
+                if (rc < 0) return member_failed(g, i, rc, "slimm_finish_coverage_merged");
+                hits = hits || rc != SLIMM_E_NO_HITS;
+            }
+        }
     }
     if (!hits) return SLIMM_E_NO_HITS;
     // ---- phase B / C(1) with exchange 2: the additive partial results, all-reduced in place
@@ -442,6 +622,21 @@ int slimm_group_get_profiles(slimm_group* g, const char* path) {
             in.pairs = all.data();
             in.n_pairs = static_cast<uint32_t>(all.size());
             GTRY(g, i, slimm_set_partials(g->ctx[i], &in));
+        }
+    }
+    if (how == SLIMM_EXCHANGE_BINS) {  // the third coverage array of the -co output: summed over the members as well
+        std::vector<uint32_t*> u2(n);
+        uint64_t words = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            void* p = nullptr;
+            GTRY(g, i, slimm_uniq_cov2_buffer(g->ctx[i], &p, &words));
+            u2[i] = static_cast<uint32_t*>(p);
+        }
+        rc = all_reduce_sum(g, u2, words);
+        if (rc != SLIMM_OK) return rc;
+        for (uint32_t i = 0; i < n; ++i) {  // (the host reads the arrays next: slimm_get_bins copies on the same stream)
+            GHIP(g, hipSetDevice(g->device[i]));
+            GHIP(g, hipStreamSynchronize(g->stream[i]));
         }
     }
     GTRY(g, 0, slimm_get_reads_lca_count(g->ctx[0]));

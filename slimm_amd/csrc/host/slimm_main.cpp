@@ -112,6 +112,10 @@ SLIMM_FORWARD(void, slimm_group_destroy, (slimm_group* a), (a))
 SLIMM_FORWARD(const char*, slimm_group_last_error, (const slimm_group* a), (a))
 SLIMM_FORWARD(slimm_ctx*, slimm_group_context, (slimm_group* a, uint32_t b), (a, b))
 SLIMM_FORWARD(int, slimm_group_uses_rccl, (const slimm_group* a), (a))
+SLIMM_FORWARD(int, slimm_group_set_exchange, (slimm_group* a, int b), (a, b))
+SLIMM_FORWARD(int, slimm_group_push_records_checked,
+              (slimm_group* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, const uint32_t* f_, uint64_t g),
+              (a, b, c, d, e, f_, g))
 SLIMM_FORWARD(int, slimm_group_push_records,
               (slimm_group* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, uint64_t f_), (a, b, c, d, e, f_))
 SLIMM_FORWARD(int, slimm_group_get_profiles, (slimm_group* a, const char* b), (a, b))
@@ -341,6 +345,15 @@ struct Session {  // what the one `slimm` object of the reference keeps across f
         }                                                                           \
     } while (0)
 
+#define CHECK_KEEP(ctx, call)                                                       \
+    do {                                                                            \
+        int rc_ = (call);                                                           \
+        if (rc_ < 0) {                                                              \
+            std::cerr << "slimm: " << #call << ": " << slimm_last_error(ctx) << "\n"; \
+            return false;                                                           \
+        }                                                                           \
+    } while (0)
+
 float depth_of(const uint32_t* bins, uint32_t n, uint32_t nz) {  // reference_contig.hpp:188-207 + misc.hpp:285-289
     if (nz == 0) return 0.0f;
     float s = 0.0f;
@@ -413,6 +426,10 @@ struct RecordPump {
         pack(b.key.get(), b.flag.get(), b.n);
         return slimm_push_records_packed(c, b.key.get(), b.ref.get(), b.pos.get(), b.n);
     }
+    static int group_push(slimm_group* g, const Batch& b) {
+        return b.check ? slimm_group_push_records_checked(g, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n)
+                       : slimm_group_push_records(g, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n);
+    }
     static double ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
     }
@@ -459,7 +476,7 @@ struct RecordPump {
             cv.wait(g, [&] { return ctx || group || failed || queued.size() < kMaxQueued; });
             if (failed) return;
             if (group) {
-                if (slimm_group_push_records(group, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) break;
+                if (group_push(group, b) < 0) break;
             } else if (ctx) {  // attached meanwhile: everything queued before has been pushed, this batch follows
                 if (push(ctx, b) < 0) break;
             } else {
@@ -486,7 +503,7 @@ struct RecordPump {
     bool attach_group(slimm_group* grp) {
         std::unique_lock<std::mutex> g(mu);
         for (Batch& b : queued)
-            if (slimm_group_push_records(grp, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n) < 0) {
+            if (group_push(grp, b) < 0) {
                 failed = true;
                 cv.notify_all();
                 return false;
@@ -502,6 +519,100 @@ struct RecordPump {
         return !failed;
     }
 };
+
+// write_raw_stat (src/slimm.hpp:883-943) and write_coverage (:846-881) from a context that holds the finished columns and
+// coverage arrays.  global_bins: `ctx` is member 0 of a group after the bins exchange -- its arrays are the global ones,
+// but its count of non-zero uniq_cov2 bins is that of its own reads: counted here from the global array instead.
+bool write_raw_and_coverage(Session& S, slimm_ctx* ctx, bool global_bins, const std::string& path, const AlignmentFile& bam,
+                            const std::vector<std::string>& accession, const std::vector<uint32_t>& taxa_id,
+                            const std::vector<uint32_t>& lineage, Lap& watch) {
+    const Options& options = S.options;
+    const uint32_t R = static_cast<uint32_t>(accession.size());
+    slimm_stats st;
+    slimm_get_stats(ctx, &st);
+    std::vector<uint32_t> reads(R), uniq(R), uniq2(R), nbins(R), nz(R), nzu(R), nzu2(R);
+    std::vector<uint8_t> valid(R);
+    std::vector<float> ab(R), uab(R);
+    std::vector<uint32_t> cov, ucov, ucov2;
+    if (options.raw_output || options.coverage_output) {
+        slimm_ref_columns cols = {reads.data(), uniq.data(), uniq2.data(), nbins.data(), nz.data(),
+                                  nzu.data(),   nzu2.data(), valid.data(), ab.data(),    uab.data()};
+        CHECK_KEEP(ctx, slimm_get_ref_columns(ctx, &cols));
+        cov.resize(st.total_bins);
+        ucov.resize(st.total_bins);
+        ucov2.resize(st.total_bins);
+        CHECK_KEEP(ctx, slimm_get_bins(ctx, 0, cov.data()));
+        CHECK_KEEP(ctx, slimm_get_bins(ctx, 1, ucov.data()));
+        CHECK_KEEP(ctx, slimm_get_bins(ctx, 2, ucov2.data()));
+        if (global_bins) {  // reference_contig.hpp:84-91 over the global uniq_cov2
+            uint64_t off = 0;
+            for (uint32_t i = 0; i < R; ++i) {
+                uint32_t c = 0;
+                for (uint32_t k = 0; k < nbins[i]; ++k) c += ucov2[off + k] != 0u;
+                nzu2[i] = c;
+                off += nbins[i];
+            }
+        }
+    }
+    auto name_of = [&](uint32_t taxid) -> std::string {
+        auto it = S.db.taxid_name.find(taxid);
+        return it == S.db.taxid_name.end() ? std::string() : it->second.second;
+    };
+    if (options.raw_output) {  // write_raw_stat :883-943
+        std::cerr << "Writing features to a file ....................... ";
+        std::ofstream o(get_tsv_file_name(options.output_prefix, path, "_raw"));
+        o << "accesion\ttaxaid\tname\treads_count\tabundance\tuniq1_abundance\tuniq2_abundance\tgenome_length\t"
+             "uniq1_reads_count\tuniq2_reads_count\tbins_count\tbins_count(>0)\tuniq1_bins_count(>0)\t"
+             "uniq2_bins_count(>0)\tcoverage_depth\tuniq1_coverage_depth\tuniq2_coverage_depth\tcoverage(%)\t"
+             "uniq1_coverage(%)\tuniq2_coverage(%)\n";
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < R; ++i) {
+            std::string nm = name_of(taxa_id[i]);
+            if (nm.empty()) nm = "no_name_found";
+            const uint32_t nb = nbins[i];
+            o << accession[i] << "\t" << taxa_id[i] << "\t" << nm << "\t" << reads[i] << "\t" << ab[i] << "\t" << uab[i] << "\t"
+              << 0.0f << "\t" << bam.ref_lengths()[i] << "\t" << uniq[i] << "\t" << uniq2[i] << "\t" << nb << "\t" << nz[i] << "\t"
+              << nzu[i] << "\t" << nzu2[i] << "\t" << depth_of(&cov[off], nb, nz[i]) << "\t" << depth_of(&ucov[off], nb, nzu[i])
+              << "\t" << depth_of(&ucov2[off], nb, nzu2[i]) << "\t" << float(nz[i]) / nb << "\t" << float(nzu[i]) / nb << "\t"
+              << float(nzu2[i]) / nb << "\n";
+            off += nb;
+        }
+        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    }
+    if (options.coverage_output) {  // write_coverage :846-881
+        std::cerr << "Writing coverage profiles to a file ....................... ";
+        std::ofstream a(get_tsv_file_name(options.output_prefix, path, "_coverage"));
+        std::ofstream b(get_tsv_file_name(options.output_prefix, path, "_uniq_coverage"));
+        std::ofstream c(get_tsv_file_name(options.output_prefix, path, "_uniq_coverage2"));
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < R; ++i) {
+            const uint32_t nb = nbins[i];
+            if (valid[i]) {
+                a << accession[i];
+                b << accession[i];
+                c << accession[i];
+                for (int k = 0; k < 8; ++k) {
+                    std::string nm = name_of(lineage[static_cast<size_t>(i) * 8 + k]);
+                    a << "," << nm;
+                    b << "," << nm;
+                    c << "," << nm;
+                }
+                for (uint32_t k = 0; k < nb; ++k) {
+                    a << "," << cov[off + k];
+                    b << "," << ucov[off + k];
+                    c << "," << ucov2[off + k];
+                }
+                a << "\n";
+                b << "\n";
+                c << "\n";
+            }
+            off += nb;
+        }
+        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
+    }
+
+    return true;
+}
 
 // slimm::get_profiles() for one file (src/slimm.hpp:395-496)
 bool get_profiles(Session& S, size_t file_index) {
@@ -547,9 +658,8 @@ bool get_profiles(Session& S, size_t file_index) {
                                  : ((bam.sort_order() == SortOrder::QueryName || bam.sort_order() == SortOrder::QueryGrouped)
                                         ? SLIMM_ORDER_GROUPED
                                         : SLIMM_ORDER_ANY);
-    // (grouped streams are exact already: the reader compares the names of adjacent records; one device only -- the group
-    // of --devices deals records by key and has no checked push)
-    const bool check_words = record_order == SLIMM_ORDER_ANY && options.devices.size() <= 1;
+    // (grouped streams are exact already: the reader compares the names of adjacent records)
+    const bool check_words = record_order == SLIMM_ORDER_ANY;
     RecordPump pump(bam, check_words);  // decoding starts now; the records are claimed further down, when the context exists
 
     std::cerr << "Intializing coverages for all reference genome ... ";
@@ -594,18 +704,19 @@ bool get_profiles(Session& S, size_t file_index) {
     if (options.devices.size() > 1) {
         // ---- several GPUs, one process: the group deals the records to its members by read and runs the phases with the
         // two RCCL exchanges in between (slimm_amd/csrc/group.hip); the profile comes from member 0
-        if (options.raw_output || options.coverage_output) {
-            std::cerr << "slimm: -ro / -co read the coverage arrays, which stay per-device partial sums with --devices; "
-                         "run them on one device\n";
-            return false;
-        }
         slimm_group* grp = nullptr;
         if (slimm_group_create(&cfg, options.devices.data(), static_cast<uint32_t>(options.devices.size()), &grp) != SLIMM_OK) {
             std::cerr << "slimm: " << slimm_group_last_error(nullptr) << "\n";
             return false;
         }
-        for (uint32_t i = 0; i < options.devices.size(); ++i)
+        const bool want_arrays = options.raw_output || options.coverage_output;
+        // -ro / -co read the coverage arrays (src/slimm.hpp:846-943): the members then exchange the integer bins themselves
+        // (ncclAllReduce over [cov | uniq_cov], and over uniq_cov2 behind phase B) instead of their summaries
+        if (want_arrays) (void)slimm_group_set_exchange(grp, SLIMM_EXCHANGE_BINS);
+        for (uint32_t i = 0; i < options.devices.size(); ++i) {
             (void)slimm_set_cutoff_cache(slimm_group_context(grp, i), S.cc_cache, S.ucc_cache);
+            (void)slimm_keep_bins(slimm_group_context(grp, i), want_arrays ? 1 : 0);
+        }
         slimm_ctx* c0 = slimm_group_context(grp, 0);
         trace.mark("lineage table + slimm_group_create");
         std::cerr << "[" << watch.lap() << " secs]" << std::endl;
@@ -644,6 +755,10 @@ bool get_profiles(Session& S, size_t file_index) {
             std::cerr << "  uniquily matching reads increased from " << st.uniq_matches_count << " to " << st.uniq_matches_count2 << "\n";
             std::cerr << std::setw(4) << st.profile_count << std::setw(15) << (options.rank) << " (" << st.profile_failed
                       << " bellow cutoff i.e. " << options.abundance_cut_off << ")\n";
+        }
+        if (want_arrays && !write_raw_and_coverage(S, c0, true, path, bam, accession, taxa_id, lineage, watch)) {
+            slimm_group_destroy(grp);
+            return false;
         }
         std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
         (void)slimm_get_cutoff_cache(c0, &S.cc_cache, &S.ucc_cache);
@@ -727,78 +842,12 @@ bool get_profiles(Session& S, size_t file_index) {
         std::cerr << "  uniquily matching reads increased from " << st.uniq_matches_count << " to " << st.uniq_matches_count2 << "\n\n";
     }
 
-    std::vector<uint32_t> reads(R), uniq(R), uniq2(R), nbins(R), nz(R), nzu(R), nzu2(R);
-    std::vector<uint8_t> valid(R);
-    std::vector<float> ab(R), uab(R);
-    std::vector<uint32_t> cov, ucov, ucov2;
     if (options.raw_output || options.coverage_output) {
-        slimm_ref_columns cols = {reads.data(), uniq.data(), uniq2.data(), nbins.data(), nz.data(),
-                                  nzu.data(),   nzu2.data(), valid.data(), ab.data(),    uab.data()};
-        CHECK(ctx, slimm_get_ref_columns(ctx, &cols));
-        cov.resize(st.total_bins);
-        ucov.resize(st.total_bins);
-        ucov2.resize(st.total_bins);
-        CHECK(ctx, slimm_get_bins(ctx, 0, cov.data()));
-        CHECK(ctx, slimm_get_bins(ctx, 1, ucov.data()));
-        CHECK(ctx, slimm_get_bins(ctx, 2, ucov2.data()));
-    }
-    auto name_of = [&](uint32_t taxid) -> std::string {
-        auto it = S.db.taxid_name.find(taxid);
-        return it == S.db.taxid_name.end() ? std::string() : it->second.second;
-    };
-    if (options.raw_output) {  // write_raw_stat :883-943
-        std::cerr << "Writing features to a file ....................... ";
-        std::ofstream o(get_tsv_file_name(options.output_prefix, path, "_raw"));
-        o << "accesion\ttaxaid\tname\treads_count\tabundance\tuniq1_abundance\tuniq2_abundance\tgenome_length\t"
-             "uniq1_reads_count\tuniq2_reads_count\tbins_count\tbins_count(>0)\tuniq1_bins_count(>0)\t"
-             "uniq2_bins_count(>0)\tcoverage_depth\tuniq1_coverage_depth\tuniq2_coverage_depth\tcoverage(%)\t"
-             "uniq1_coverage(%)\tuniq2_coverage(%)\n";
-        uint64_t off = 0;
-        for (uint32_t i = 0; i < R; ++i) {
-            std::string nm = name_of(taxa_id[i]);
-            if (nm.empty()) nm = "no_name_found";
-            const uint32_t nb = nbins[i];
-            o << accession[i] << "\t" << taxa_id[i] << "\t" << nm << "\t" << reads[i] << "\t" << ab[i] << "\t" << uab[i] << "\t"
-              << 0.0f << "\t" << bam.ref_lengths()[i] << "\t" << uniq[i] << "\t" << uniq2[i] << "\t" << nb << "\t" << nz[i] << "\t"
-              << nzu[i] << "\t" << nzu2[i] << "\t" << depth_of(&cov[off], nb, nz[i]) << "\t" << depth_of(&ucov[off], nb, nzu[i])
-              << "\t" << depth_of(&ucov2[off], nb, nzu2[i]) << "\t" << float(nz[i]) / nb << "\t" << float(nzu[i]) / nb << "\t"
-              << float(nzu2[i]) / nb << "\n";
-            off += nb;
+        if (!write_raw_and_coverage(S, ctx, false, path, bam, accession, taxa_id, lineage, watch)) {
+            slimm_destroy(ctx);
+            return false;
         }
-        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
     }
-    if (options.coverage_output) {  // write_coverage :846-881
-        std::cerr << "Writing coverage profiles to a file ....................... ";
-        std::ofstream a(get_tsv_file_name(options.output_prefix, path, "_coverage"));
-        std::ofstream b(get_tsv_file_name(options.output_prefix, path, "_uniq_coverage"));
-        std::ofstream c(get_tsv_file_name(options.output_prefix, path, "_uniq_coverage2"));
-        uint64_t off = 0;
-        for (uint32_t i = 0; i < R; ++i) {
-            const uint32_t nb = nbins[i];
-            if (valid[i]) {
-                a << accession[i];
-                b << accession[i];
-                c << accession[i];
-                for (int k = 0; k < 8; ++k) {
-                    std::string nm = name_of(lineage[static_cast<size_t>(i) * 8 + k]);
-                    a << "," << nm;
-                    b << "," << nm;
-                    c << "," << nm;
-                }
-                for (uint32_t k = 0; k < nb; ++k) {
-                    a << "," << cov[off + k];
-                    b << "," << ucov[off + k];
-                    c << "," << ucov2[off + k];
-                }
-                a << "\n";
-                b << "\n";
-                c << "\n";
-            }
-            off += nb;
-        }
-        std::cerr << "[" << watch.lap() << " secs]" << std::endl;
-    }
-
     std::cerr << "Assigning reads to Least Common Ancestor (LCA) ... ";
     CHECK(ctx, slimm_get_reads_lca_count(ctx));
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;

@@ -504,6 +504,27 @@ class SlimmGroup:
             self._check(self.L.slimm_group_push_records(self.g, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
                                                         _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), e - s))
 
+    def push_records_checked(self, rec: Records, check: np.ndarray, batch: int = 0):
+        n = len(rec)
+        check = np.ascontiguousarray(check, dtype=np.uint32)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_group_push_records_checked(self.g, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
+                                                                _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), _p(check[s:e]), e - s))
+
+    EXCHANGES = {"auto": 0, "summary": 1, "sliced": 2, "bins": 3}
+
+    def set_exchange(self, mode: str):
+        """slimm_group_set_exchange: "auto" | "summary" (all-gather) | "sliced" (all-to-all + small all-reduce) | "bins"
+        (all-reduce of the coverage arrays themselves; member 0's bins() are then the global arrays)."""
+        self._check(self.L.slimm_group_set_exchange(self.g, self.EXCHANGES[mode]))
+
+    @property
+    def exchange(self) -> str:
+        k = self.L.slimm_group_exchange(self.g)
+        return next(n for n, v in self.EXCHANGES.items() if v == k)
+
     def get_profiles(self, path: Optional[str] = None) -> bool:
         """False when no record is mapped (the reference's early return)."""
         return self._check(self.L.slimm_group_get_profiles(self.g, path.encode() if path else None)) != capi.E_NO_HITS

@@ -43,36 +43,46 @@ def write_synthetic_bam(path: str, ref_names, ref_len, records, read_len: int = 
         b = nm.encode() + b"\0"
         head += struct.pack("<i", len(b)) + b + struct.pack("<i", int(l))
     raw_bytes = len(head)
+
+    def piece_bytes(lo):
+        hi = min(n, lo + piece)
+        m = hi - lo
+        body = np.zeros(m, dtype=dt)
+        body["bs"] = dt.itemsize - 4
+        body["ref"] = records.ref_id[lo:hi]
+        body["pos"] = records.begin_pos[lo:hi]
+        body["lname"] = 17
+        body["mapq"] = 255
+        body["bin"] = 4680
+        body["ncig"] = 1
+        body["flag"] = records.flag[lo:hi]
+        body["lseq"] = read_len
+        body["nref"] = -1
+        body["npos"] = -1
+        kb = records.read_key[lo:hi].astype(">u8").view("u1").reshape(m, 8)
+        names = np.empty((m, 17), dtype="u1")
+        names[:, 0:16:2] = _HEX[kb >> 4]
+        names[:, 1:16:2] = _HEX[kb & 15]
+        names[:, 16] = 0
+        body["name"] = names.view("S17").reshape(m)
+        body["cigar"] = read_len << 4
+        body["seq"] = b"\x11" * ((read_len + 1) // 2)
+        body["qual"] = b"\x28" * read_len
+        return body.tobytes()
+
     carry = bytes(head)   # bytes not yet written as whole 0xff00-byte blocks
-    with open(path, "wb") as f, ThreadPoolExecutor(threads) as ex:
-        for lo in range(0, max(n, 1), piece):
-            hi = min(n, lo + piece)
-            m = hi - lo
-            body = np.zeros(m, dtype=dt)
-            body["bs"] = dt.itemsize - 4
-            body["ref"] = records.ref_id[lo:hi]
-            body["pos"] = records.begin_pos[lo:hi]
-            body["lname"] = 17
-            body["mapq"] = 255
-            body["bin"] = 4680
-            body["ncig"] = 1
-            body["flag"] = records.flag[lo:hi]
-            body["lseq"] = read_len
-            body["nref"] = -1
-            body["npos"] = -1
-            kb = records.read_key[lo:hi].astype(">u8").view("u1").reshape(m, 8)
-            names = np.empty((m, 17), dtype="u1")
-            names[:, 0:16:2] = _HEX[kb >> 4]
-            names[:, 1:16:2] = _HEX[kb & 15]
-            names[:, 16] = 0
-            body["name"] = names.view("S17").reshape(m)
-            body["cigar"] = read_len << 4
-            body["seq"] = b"\x11" * ((read_len + 1) // 2)
-            body["qual"] = b"\x28" * read_len
-            raw = carry + body.tobytes()
-            del body, names, kb
-            raw_bytes += len(raw) - len(carry)
-            whole = len(raw) // 0xff00 * 0xff00 if hi < n else len(raw)
+    los = list(range(0, max(n, 1), piece))
+    with open(path, "wb") as f, ThreadPoolExecutor(threads) as ex, ThreadPoolExecutor(3) as builders:
+        ahead = [builders.submit(piece_bytes, lo) for lo in los[:3]]   # (numpy releases the GIL: three pieces in the making)
+        for k, lo in enumerate(los):
+            body = ahead.pop(0).result()
+            if k + 3 < len(los):
+                ahead.append(builders.submit(piece_bytes, los[k + 3]))
+            raw = carry + body
+            raw_bytes += len(body)
+            del body
+            last = k + 1 == len(los)
+            whole = len(raw) if last else len(raw) // 0xff00 * 0xff00
             chunks = [raw[s:s + 0xff00] for s in range(0, whole, 0xff00)]
             for blk in ex.map(_bgzf, chunks, chunksize=64):
                 f.write(blk)

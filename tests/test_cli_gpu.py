@@ -248,3 +248,23 @@ def test_cli_warns_about_a_false_grouping_promise_when_asked(tmp_path):
     run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "--any-order", db, inp])
     o = Oracle(wb.taxonomy, wb.options).run(wb.ref_names, wb.ref_len, wb.records, wb.avg_read_len, want_raw=True)
     check_outputs(out, "s", o, coverage=False)
+
+
+@pytest.mark.parametrize("order", ["grouped", "unsorted"])
+def test_cli_devices_writes_raw_and_coverage_outputs_from_all_reduced_bins(tmp_path, order):
+    """--devices with -ro / -co: the members all-reduce the integer coverage bins (and uniq_cov2 behind phase B), and the
+    raw statistics and the three coverage files -- which read every bin of every valid reference
+    (src/slimm.hpp:846-943) -- equal the oracle's text byte for byte, like on one device.  `unsorted`: the records are
+    dealt by key and carry check words (slimm_group_push_records_checked)."""
+    w = with_names(make_workload(CONFIGS["config1"], seed=48, shuffled=(order == "unsorted")))
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "sample.bam")
+    hd = "@HD\tVN:1.6\tSO:unsorted" + ("\tGO:query" if order == "grouped" else "")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, hd=hd)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", "-v", "--devices", "0,0,0", db, inp])
+    assert "3 devices (copy collectives)" in err
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    check_outputs(out, "sample", o)

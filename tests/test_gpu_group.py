@@ -109,3 +109,87 @@ def test_group_of_one_through_rccl(monkeypatch):
     assert g.get_profiles()
     assert_matches_oracle(g.member(0), o, bins=False)
     g.close()
+
+
+# ---------------------------------------------------------------- the three forms of exchange 1, from C++
+@pytest.mark.parametrize("members", [3, 4])
+@pytest.mark.parametrize("form", ["summary", "sliced", "bins"])
+def test_group_exchange_forms_equal_the_oracle(members, form):
+    """All-gather of summaries, all-to-all of bitmap slices + small all-reduce, all-reduce of the integer bins (north_star's
+    literal collective): groups of three and four on the one device through each form, every result the oracle's.  After
+    the bins form member 0 holds the GLOBAL coverage arrays, uniq_cov2 included."""
+    w = make_workload(CONFIGS["config1"], seed=57)
+    o = run_workload(w, use_qnames=False)
+    g = SlimmGroup(w, [0] * members)
+    assert g.exchange == ("sliced" if members > 2 else "summary")      # what auto means
+    g.set_exchange(form)
+    assert g.exchange == form
+    g.push_records(w.records, batch=2500)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    if form == "bins":
+        for k, want in enumerate((o.cov, o.uniq_cov, o.uniq_cov2)):
+            for i in (0, members - 1):
+                assert np.array_equal(g.member(i).bins(k), want), (k, i)
+    else:   # the members' arrays are partial sums of the whole
+        for k, want in enumerate((o.cov, o.uniq_cov, o.uniq_cov2)):
+            assert np.array_equal(sum(g.member(i).bins(k) for i in range(members)), want), k
+    g.close()
+
+
+@pytest.mark.parametrize("form", ["sliced", "bins"])
+def test_group_exchange_forms_on_a_larger_stream_and_a_second_file(form):
+    w = make_workload(CONFIGS["config2"], seed=58, n_records=300_000)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0, 0, 0])
+    g.set_exchange(form)
+    for _ in range(2):
+        g.reset()
+        g.push_records(w.records, batch=40_000)
+        assert g.get_profiles()
+        assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()
+
+
+@pytest.mark.skipif(os.environ.get("SLIMM_EMU") == "1", reason="needs librccl and a GPU")
+@pytest.mark.parametrize("form", ["summary", "sliced", "bins"])
+def test_group_of_one_through_rccl_in_every_form(monkeypatch, form):
+    """Each form through the RCCL entry points with a communicator of one: ncclAllGather; ncclSend / ncclRecv in a group +
+    ncclAllReduce; ncclAllReduce over the bins (and over uniq_cov2)."""
+    monkeypatch.setenv("SLIMM_GROUP_COLLECTIVES", "rccl")
+    w = make_workload(CONFIGS["config1"], seed=59)
+    o = run_workload(w, use_qnames=False)
+    g = SlimmGroup(w, [0])
+    assert g.uses_rccl
+    g.set_exchange(form)
+    g.push_records(w.records)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=(form == "bins"))
+    g.close()
+
+
+def test_group_checked_push_reports_two_names_under_one_key():
+    """Unordered input dealt by key: the records of two names that collide in the key meet on one member, whose device
+    sort brings them together -- SLIMM_E_KEY_COLLISION, like one context on the same file."""
+    from slimm_amd import capi
+    w = make_workload(CONFIGS["config1"], seed=60, shuffled=True)
+    r = w.records
+    chk = ((r.read_key * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(32)).astype(np.uint32)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0, 0, 0], grouped=False)
+    g.push_records_checked(r, chk, batch=3000)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.reset()
+    chk2 = chk.copy()
+    victim = 4321
+    other = 777
+    r.read_key[other] = r.read_key[victim]
+    chk2[other] = chk2[victim] ^ np.uint32(0x5a5a5a5a)       # another "name" with the victim's key
+    g.push_records_checked(r, chk2, batch=3000)
+    with pytest.raises(capi.SlimmError) as e:
+        g.get_profiles()
+    assert e.value.code == capi.E_KEY_COLLISION
+    with pytest.raises(capi.SlimmError):
+        g.push_records(r)                                     # checked and unchecked pushes do not mix
+    g.close()

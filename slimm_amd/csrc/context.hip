@@ -153,6 +153,8 @@ struct slimm_ctx {
     bool fused_scan = false;                            // k_tile_scan runs inside the one-level bucketing kernel
     uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
+    bool matrix = false;      // matrix bucketing: one row of tile counts per counting workgroup, no atomics in the scatter
+    DevBuf<uint32_t> tile_matrix;
     // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
     // 1: bitmaps written by k_tile_hist as [cov | uniq_cov], n > 1: in n slices of tiles for the all-to-all exchange
     uint32_t summary_slices = 0;
@@ -486,6 +488,18 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
             {
                 const char* fs = getenv("SLIMM_FUSED_SCAN");
                 cc->fused_scan = !cc->two_level && cc->treps == kTileReps && c->ntiles2 <= kFusedScanTiles && !(fs && fs[0] == '0');
+            }
+            {
+                // layouts beyond the fused kernel's 4064 tiles: a count matrix instead of counter copies and cursors
+                // (SLIMM_MATRIX=0: the direct rounds / the two levels of round 2; an explicit SLIMM_TWO_LEVEL wins)
+                const char* mx = getenv("SLIMM_MATRIX");
+                cc->matrix = !cc->fused_scan && !getenv("SLIMM_TWO_LEVEL") && !(mx && mx[0] == '0');
+                if (cc->matrix) {
+                    cc->two_level = false;
+                    cc->treps = 1;
+                    if (cc->tile_matrix.ensure(static_cast<size_t>(tile_count_grid(512)) * cc->tstride) != hipSuccess)
+                        return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");
+                }
             }
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
@@ -979,7 +993,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride);
+            launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride,
+                              c->matrix ? c->tile_matrix.p : nullptr);
+            if (c->matrix) launch_matrix_prefix(st, grid, c->ntiles, c->tile_matrix.p, c->tstride, c->tile_count.p);
         }
         Totals tot;
         tot.part = c->tot_part.p;
@@ -998,9 +1014,13 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER);
-                launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
-                                    c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
-                                    c->two_level, c->tile_count.p, c->treps, c->tstride);
+                if (c->matrix)
+                    launch_tile_scatter_matrix(st, grid, c->ntiles, targets, c->tile_base.p, c->tile_matrix.p, c->tstride,
+                                               c->bucket.p, c->cov(), c->ucov());
+                else
+                    launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
+                                        c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
+                                        c->two_level, c->tile_count.p, c->treps, c->tstride);
             }
         }
         {
@@ -1358,8 +1378,9 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         const uint32_t grid = 512;
         {
             KernelTimer t(c, K_TILE_COUNT2);
-            launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps,
-                              c->tstride);
+            launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps, c->tstride,
+                              c->matrix ? c->tile_matrix.p : nullptr);
+            if (c->matrix) launch_matrix_prefix(st, grid, c->ntiles2, c->tile_matrix.p, c->tstride, c->tile_count.p);
         }
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER2);
@@ -1374,9 +1395,13 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
-                launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
-                                    c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
-                                    c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
+                if (c->matrix)
+                    launch_tile_scatter_matrix(st, grid, c->ntiles2, selectors, c->tile_base.p, c->tile_matrix.p, c->tstride,
+                                               c->bucket.p, c->ucov2(), nullptr);
+                else
+                    launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
+                                        c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
+                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
             }
         }
         {

@@ -207,7 +207,15 @@ struct Totals {
 constexpr uint32_t kCountFold = 2;
 uint32_t tile_count_grid(uint32_t grid);
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
-                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride);
+                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride, uint32_t* matrix = nullptr);
+// Matrix bucketing (more than kFusedScanTiles tiles, as many as an LDS cursor array holds): launch_tile_count with
+// matrix != nullptr stores one ROW of counts per counting workgroup (tile_count_grid(grid) rows of row_stride words),
+// launch_matrix_prefix makes every column its exclusive prefix over the rows and leaves the column sums in total[]
+// (which launch_tile_scan then scans with reps = 1), and launch_tile_scatter_matrix -- same grid as the count -- places
+// every value at tile_base[tile] + its row's prefix + a running LDS count: no global atomics, no rounds.
+void launch_matrix_prefix(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t* matrix, uint32_t row_stride, uint32_t* total);
+void launch_tile_scatter_matrix(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* tile_base,
+                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov);
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
 constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
 constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile

@@ -109,7 +109,8 @@ __device__ __forceinline__ uint32_t tile_of(uint32_t v) { return (v & 0x7fffffff
 __global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_count(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
                                                         uint32_t nslots, int per_read, uint32_t ntiles,
                                                         uint32_t* __restrict__ tile_count_all, uint32_t reps,
-                                                        uint32_t rep_stride, uint4* __restrict__ part) {
+                                                        uint32_t rep_stride, uint4* __restrict__ part,
+                                                        uint32_t* __restrict__ matrix) {
     HIP_DYNAMIC_SHARED(uint32_t, s_hist)
     __shared__ uint32_t s_sum[3];
     if (threadIdx.x < 3) s_sum[threadIdx.x] = 0;
@@ -142,10 +143,45 @@ __global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_count(const uint3
     }
     __syncthreads();
     if (part && threadIdx.x == 0) part[blockIdx.x] = make_uint4(s_sum[0], s_sum[1], s_sum[2], 0u);
+    if (matrix) {  // the workgroup's own row of the count matrix: plain coalesced stores, zeros included
+        uint32_t* __restrict__ row = matrix + static_cast<size_t>(blockIdx.x) * rep_stride;
+        for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock * kCountFold) row[i] = s_hist[i];
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock * kCountFold) {
         uint32_t h = s_hist[i];
         if (h) atomicAdd(&tile_count[i], h);
     }
+}
+
+// Matrix bucketing (layouts of more than kFusedScanTiles tiles): every counting workgroup keeps a ROW of its own in a
+// count matrix [workgroup][tile]; this kernel turns every column into its exclusive prefix over the rows -- where each
+// workgroup's stretch starts inside the tile's bucket -- and leaves the column sums in total[] for k_tile_scan.  The
+// scatter then needs no global atomic and no rounds at all: a workgroup's place for a value is tile_base[tile] + its
+// row's prefix + a running LDS count (k_tile_scatter_matrix).  The direct rounds paid one returning global atomic per
+// touched tile and round of 16 K values -- 0.48 per value at config 3 -- and four barriers per round.
+__global__ __launch_bounds__(256) void k_matrix_prefix(uint32_t* __restrict__ matrix, uint32_t nrows, uint32_t ntiles,
+                                                       uint32_t row_stride, uint32_t* __restrict__ total) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= ntiles) return;
+    uint32_t run = 0;
+    uint32_t r = 0;
+    for (; r + 16u <= nrows; r += 16u) {  // sixteen rows' loads in flight together (the addresses do not depend on the values)
+        uint32_t v[16];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u) v[u] = matrix[static_cast<size_t>(r + u) * row_stride + t];
+#pragma unroll
+        for (uint32_t u = 0; u < 16u; ++u) {
+            matrix[static_cast<size_t>(r + u) * row_stride + t] = run;
+            run += v[u];
+        }
+    }
+    for (; r < nrows; ++r) {
+        const uint32_t v = matrix[static_cast<size_t>(r) * row_stride + t];
+        matrix[static_cast<size_t>(r) * row_stride + t] = run;
+        run += v;
+    }
+    total[t] = run;
 }
 
 // the totals {mapped records, reads, targets} of the stream from the per-workgroup sums k_tile_count left: into the
@@ -561,6 +597,40 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
     bucketing_rounds<kDirectPieces>(walk, vals, s_more, [&](const uint32_t (&v)[kDirectPieces]) {
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
     });
+}
+
+// Matrix bucketing, the scatter: the workgroup that counted these slots (same grid, same slot ranges as k_tile_count)
+// writes them out.  s_cur[tile] = tile_base[tile] + this row's prefix; a value's place is the returned LDS count.  One
+// pass over the slots, one barrier, no global atomic.
+__global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_scatter_matrix(
+    const uint32_t* __restrict__ vals, const uint4* __restrict__ slots, uint32_t nslots, int per_read, uint32_t ntiles,
+    const uint32_t* __restrict__ tile_base, const uint32_t* __restrict__ matrix, uint32_t row_stride,
+    uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_cur)
+    const uint32_t* __restrict__ row = matrix + static_cast<size_t>(blockIdx.x) * row_stride;
+    for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock * kCountFold) s_cur[i] = tile_base[i] + row[i];
+    if (threadIdx.x < kTBlock) zero_split_tiles(tile_base, ntiles, cov, ucov);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    SlotWalk w = slot_walk(slots, nslots, per_read != 0, kCountFold);
+    while (true) {  // eight pieces per trip, their loads in flight together
+        uint32_t v[8];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t base = 0;
+            const uint32_t n = slot_next(w, &base);
+            any = any || n != 0u;
+            v[u] = lane < n ? vals[base + lane] : 0xffffffffu;
+        }
+        if (!any) break;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (v[u] == 0xffffffffu) continue;
+            const uint32_t pos = atomicAdd(&s_cur[tile_of(v[u])], 1u);
+            bucket[pos] = static_cast<uint16_t>(entry_of(v[u]));
+        }
+    }
 }
 
 // Exclusive scan of s[0 .. kFusedTiles) in place by the 512 threads of a workgroup (8 consecutive elements per thread,
@@ -1098,13 +1168,28 @@ int tile_hist_setup(uint32_t ntiles) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(bytes)) != hipSuccess)
         return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter_matrix), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(bytes)) != hipSuccess)
+        return -1;
     return 0;
 }
 
 void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
-                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride) {
+                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride, uint32_t* matrix) {
     hipLaunchKernelGGL(k_tile_count, dim3(tile_count_grid(grid)), dim3(kTBlock * kCountFold), static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots,
-                       in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, part);
+                       in.nslots, in.per_read ? 1 : 0, ntiles, tile_count, reps, rep_stride, part, matrix);
+}
+
+void launch_matrix_prefix(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t* matrix, uint32_t row_stride, uint32_t* total) {
+    hipLaunchKernelGGL(k_matrix_prefix, dim3((ntiles + 255u) / 256u), dim3(256), 0, st, matrix, tile_count_grid(grid), ntiles,
+                       row_stride, total);
+}
+
+void launch_tile_scatter_matrix(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* tile_base,
+                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov) {
+    hipLaunchKernelGGL(k_tile_scatter_matrix, dim3(tile_count_grid(grid)), dim3(kTBlock * kCountFold),
+                       static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots, in.nslots, in.per_read ? 1 : 0, ntiles, tile_base,
+                       matrix, row_stride, bucket, cov, ucov);
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,

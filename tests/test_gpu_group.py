@@ -164,7 +164,10 @@ def test_group_of_one_through_rccl_in_every_form(monkeypatch, form):
     g.set_exchange(form)
     g.push_records(w.records)
     assert g.get_profiles()
-    assert_matches_oracle(g.member(0), o, bins=(form == "bins"))
+    assert_matches_oracle(g.member(0), o, bins=False)
+    if form == "bins":   # (nz_uniq_cov2 is not part of the merged columns: the arrays themselves are compared)
+        for k, want in enumerate((o.cov, o.uniq_cov, o.uniq_cov2)):
+            assert np.array_equal(g.member(0).bins(k), want), k
     g.close()
 
 

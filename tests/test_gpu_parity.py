@@ -264,6 +264,22 @@ def test_one_level_bucketing_with_a_separate_scan(monkeypatch):
     check(one_long_read_workload(9_000))
 
 
+@pytest.mark.parametrize("matrix", ["1", "0"])
+def test_matrix_bucketing_and_the_direct_rounds(monkeypatch, matrix):
+    """Layouts beyond the fused kernel's 4064 tiles bucket through a count matrix (one row per counting workgroup, no
+    global atomics in the scatter); SLIMM_MATRIX=0 keeps the direct rounds of round 2.  Forced onto small layouts here
+    (SLIMM_FUSED_SCAN=0), reads of thousands of targets and a tile cut into several work items included; the big layouts
+    run it at their real sizes (the prefix and full-size tests)."""
+    monkeypatch.setenv("SLIMM_FUSED_SCAN", "0")
+    monkeypatch.setenv("SLIMM_MATRIX", matrix)
+    check(make_workload(CONFIGS["config2"], seed=26, n_records=300_000))
+    check(make_workload(CONFIGS["config1"], seed=27))
+    check(make_workload(CONFIGS["config1"], seed=28), grouped=False)
+    check(one_long_read_workload(9_000))
+    check(make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000, len_hi=900_000, present_frac=0.3),
+                        seed=29))
+
+
 def test_wide_lineage_rows_fallback_path(monkeypatch):
     """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
     monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")

@@ -153,7 +153,8 @@ struct slimm_ctx {
     bool fused_scan = false;                            // k_tile_scan runs inside the one-level bucketing kernel
     uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
-    bool matrix = false;      // matrix bucketing: one row of tile counts per counting workgroup, no atomics in the scatter
+    bool matrix = false;      // phase B may bucket through a count matrix (one row per counting workgroup, no atomics)
+    bool matrix_always = false;
     DevBuf<uint32_t> tile_matrix;
     // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
     // 1: bitmaps written by k_tile_hist as [cov | uniq_cov], n > 1: in n slices of tiles for the all-to-all exchange
@@ -490,16 +491,18 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 cc->fused_scan = !cc->two_level && cc->treps == kTileReps && c->ntiles2 <= kFusedScanTiles && !(fs && fs[0] == '0');
             }
             {
-                // layouts beyond the fused kernel's 4064 tiles: a count matrix instead of counter copies and cursors
-                // (SLIMM_MATRIX=0: the direct rounds / the two levels of round 2; an explicit SLIMM_TWO_LEVEL wins)
+                // Layouts beyond the fused kernel's 4064 tiles, PHASE B only, when a tile gets few selectors (decided per
+                // file from the number of reads): a count matrix instead of counter copies and cursors -- one row of tile
+                // counts per counting workgroup, no global atomics and no rounds in the scatter.  (Phase A stays on the
+                // direct rounds: with hundreds of thousands of values per tile, appending at ONE frontier per tile keeps
+                // the bucket's open cache lines in L2, while 256 private frontiers per tile -- 2.5 M partially written
+                // lines at config 3 -- turn every 2-byte store into a partial-line write: measured 834 vs 362 us.)
                 const char* mx = getenv("SLIMM_MATRIX");
-                cc->matrix = !cc->fused_scan && !getenv("SLIMM_TWO_LEVEL") && !(mx && mx[0] == '0');
-                if (cc->matrix) {
-                    cc->two_level = false;
-                    cc->treps = 1;
-                    if (cc->tile_matrix.ensure(static_cast<size_t>(tile_count_grid(512)) * cc->tstride) != hipSuccess)
-                        return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");
-                }
+                cc->matrix = !cc->fused_scan && !(mx && mx[0] == '0');
+                if (cc->matrix &&
+                    cc->tile_matrix.ensure(static_cast<size_t>(tile_count_grid(512)) * cc->tstride) != hipSuccess)
+                    return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");
+                if (mx && mx[0] == '2') cc->matrix_always = true;  // (tests: small layouts, whatever the number of reads)
             }
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
@@ -993,9 +996,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride,
-                              c->matrix ? c->tile_matrix.p : nullptr);
-            if (c->matrix) launch_matrix_prefix(st, grid, c->ntiles, c->tile_matrix.p, c->tstride, c->tile_count.p);
+            launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride);
         }
         Totals tot;
         tot.part = c->tot_part.p;
@@ -1014,13 +1015,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER);
-                if (c->matrix)
-                    launch_tile_scatter_matrix(st, grid, c->ntiles, targets, c->tile_base.p, c->tile_matrix.p, c->tstride,
-                                               c->bucket.p, c->cov(), c->ucov());
-                else
-                    launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
-                                        c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
-                                        c->two_level, c->tile_count.p, c->treps, c->tstride);
+                launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
+                                    c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
+                                    c->two_level, c->tile_count.p, c->treps, c->tstride);
             }
         }
         {
@@ -1376,11 +1373,14 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
     }
     if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
         const uint32_t grid = 512;
+        // few selectors per tile (config 5: 100; config 3: 1 200): the count matrix (88 -> 61 us at config 3, 112 -> 33 us at
+        // config 5); many (config 4: 12 000): the direct rounds, whose shared frontier per tile keeps the open lines in L2
+        const bool matrix = c->matrix && (c->matrix_always || c->local_M / std::max(1u, c->ntiles2) < 4096u);
         {
             KernelTimer t(c, K_TILE_COUNT2);
             launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps, c->tstride,
-                              c->matrix ? c->tile_matrix.p : nullptr);
-            if (c->matrix) launch_matrix_prefix(st, grid, c->ntiles2, c->tile_matrix.p, c->tstride, c->tile_count.p);
+                              matrix ? c->tile_matrix.p : nullptr);
+            if (matrix) launch_matrix_prefix(st, grid, c->ntiles2, c->tile_matrix.p, c->tstride, c->tile_count.p);
         }
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER2);
@@ -1390,12 +1390,12 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             {
                 KernelTimer t(c, K_TILE_SCAN2);
                 launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
-                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                             c->two_level);
+                                 c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, matrix ? 1u : c->treps,
+                                 c->tstride, matrix ? false : c->two_level);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
-                if (c->matrix)
+                if (matrix)
                     launch_tile_scatter_matrix(st, grid, c->ntiles2, selectors, c->tile_base.p, c->tile_matrix.p, c->tstride,
                                                c->bucket.p, c->ucov2(), nullptr);
                 else

@@ -264,12 +264,12 @@ def test_one_level_bucketing_with_a_separate_scan(monkeypatch):
     check(one_long_read_workload(9_000))
 
 
-@pytest.mark.parametrize("matrix", ["1", "0"])
+@pytest.mark.parametrize("matrix", ["2", "0"])
 def test_matrix_bucketing_and_the_direct_rounds(monkeypatch, matrix):
-    """Layouts beyond the fused kernel's 4064 tiles bucket through a count matrix (one row per counting workgroup, no
-    global atomics in the scatter); SLIMM_MATRIX=0 keeps the direct rounds of round 2.  Forced onto small layouts here
-    (SLIMM_FUSED_SCAN=0), reads of thousands of targets and a tile cut into several work items included; the big layouts
-    run it at their real sizes (the prefix and full-size tests)."""
+    """Phase B of layouts beyond the fused kernel's 4064 tiles buckets its selectors through a count matrix (one row per
+    counting workgroup, no global atomics in the scatter) when a tile gets few of them; SLIMM_MATRIX=0 keeps the direct
+    rounds, 2 = always.  Forced onto small layouts here (SLIMM_FUSED_SCAN=0), a tile cut into several work items
+    included; the big layouts run it at their real sizes (the prefix and full-size tests of configs 3 and 5)."""
     monkeypatch.setenv("SLIMM_FUSED_SCAN", "0")
     monkeypatch.setenv("SLIMM_MATRIX", matrix)
     check(make_workload(CONFIGS["config2"], seed=26, n_records=300_000))

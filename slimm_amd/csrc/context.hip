@@ -155,6 +155,12 @@ struct slimm_ctx {
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
     bool matrix = false;      // phase B may bucket through a count matrix (one row per counting workgroup, no atomics)
     bool matrix_always = false;
+    int wide_tiles = -1;      // SLIMM_WIDE_TILES: -1 = by the file's size, 0 / 1 = never / always (tests)
+    // far more entries per tile than a packed work item holds (1 B records on 20 k references): work items of up to
+    // kTileSubWide entries with 32-bit counts, so that a tile is one item again (kernels.h)
+    bool wide_for(uint32_t n_records) const {
+        return wide_tiles >= 0 ? wide_tiles != 0 : (ntiles && n_records / ntiles > 2 * kTileSub);
+    }
     DevBuf<uint32_t> tile_matrix;
     // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
     // 1: bitmaps written by k_tile_hist as [cov | uniq_cov], n > 1: in n slices of tiles for the all-to-all exchange
@@ -503,6 +509,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                     cc->tile_matrix.ensure(static_cast<size_t>(tile_count_grid(512)) * cc->tstride) != hipSuccess)
                     return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");
                 if (mx && mx[0] == '2') cc->matrix_always = true;  // (tests: small layouts, whatever the number of reads)
+                if (const char* wt = getenv("SLIMM_WIDE_TILES")) cc->wide_tiles = wt[0] == '1' ? 1 : 0;
             }
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
@@ -992,6 +999,8 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     targets.slots = c->slots.p;
     targets.nslots = nslots;
     targets.per_read = false;
+    const bool wide = c->wide_for(n);
+    const uint32_t tile_sub = wide ? kTileSubWide : kTileSub;
     if (c->use_tiles) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
@@ -1005,19 +1014,20 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER);
             launch_tile_scatter_fused(st, grid, c->ntiles, targets, c->counters.p, c->tile_count.p, c->tile_cursor.p,
-                                      c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p, c->split_tiles.p, tot);
+                                      c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p, c->split_tiles.p, tot,
+                                      tile_sub);
         } else {
             {
                 KernelTimer t(c, K_TILE_SCAN);
                 launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
                                  c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                                 c->two_level, tot);
+                                 c->two_level, tot, tile_sub);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER);
                 launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
                                     c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
-                                    c->two_level, c->tile_count.p, c->treps, c->tstride);
+                                    c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub);
             }
         }
         {
@@ -1033,7 +1043,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             }
             launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
                              c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout(),
-                             c->keep_bins ? 0u : c->ntiles);
+                             c->keep_bins ? 0u : c->ntiles, wide);
             c->binsA_stored = c->keep_bins;
         }
     } else {
@@ -1376,6 +1386,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         // few selectors per tile (config 5: 100; config 3: 1 200): the count matrix (88 -> 61 us at config 3, 112 -> 33 us at
         // config 5); many (config 4: 12 000): the direct rounds, whose shared frontier per tile keeps the open lines in L2
         const bool matrix = c->matrix && (c->matrix_always || c->local_M / std::max(1u, c->ntiles2) < 4096u);
+        const uint32_t tile_sub = c->wide_for(c->rec.n) ? kTileSubWide : kTileSub;  // (one array: its counts are 32-bit already)
         {
             KernelTimer t(c, K_TILE_COUNT2);
             launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps, c->tstride,
@@ -1385,23 +1396,24 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER2);
             launch_tile_scatter_fused(st, grid, c->ntiles2, selectors, c->counters.p, c->tile_count.p, c->tile_cursor.p,
-                                      c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p, c->split_tiles.p);
+                                      c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p, c->split_tiles.p, Totals(),
+                                      tile_sub);
         } else {
             {
                 KernelTimer t(c, K_TILE_SCAN2);
                 launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
                                  c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, matrix ? 1u : c->treps,
-                                 c->tstride, matrix ? false : c->two_level);
+                                 c->tstride, matrix ? false : c->two_level, Totals(), tile_sub);
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
                 if (matrix)
                     launch_tile_scatter_matrix(st, grid, c->ntiles2, selectors, c->tile_base.p, c->tile_matrix.p, c->tstride,
-                                               c->bucket.p, c->ucov2(), nullptr);
+                                               c->bucket.p, c->ucov2(), nullptr, tile_sub);
                 else
                     launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
                                         c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
-                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride);
+                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub);
             }
         }
         {

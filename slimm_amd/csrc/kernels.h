@@ -176,6 +176,9 @@ void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t ran
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----
 constexpr uint32_t kTileShift = 13;
 constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 16 KiB of LDS in k_tile_hist (16-bit counts)
+constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item (packed 16-bit counts)
+constexpr uint32_t kTileSubWide = 262144;               // ... of the wide form (32-bit counts): layouts with far more than
+                                                        // kTileSub entries per tile (tile_sub / wide arguments below)
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
 int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
 // tile_count: `reps` copies of rep_stride words, zero on entry (k_zero); workgroup b adds to copy b % reps.
@@ -215,8 +218,8 @@ void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const Slo
 // every value at tile_base[tile] + its row's prefix + a running LDS count: no global atomics, no rounds.
 void launch_matrix_prefix(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t* matrix, uint32_t row_stride, uint32_t* total);
 void launch_tile_scatter_matrix(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* tile_base,
-                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov);
-constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item
+                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov,
+                                uint32_t tile_sub = kTileSub);
 constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
 constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile
 constexpr uint32_t kSuperMask = (1u << kSuperShift) - 1;
@@ -227,13 +230,13 @@ uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
                       uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level,
-                      const Totals& tot = Totals());
+                      const Totals& tot = Totals(), uint32_t tile_sub = kTileSub);
 // bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
 // k_tile_hist will accumulate with atomics
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const SlotValues& in,
                          const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
                          const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
-                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride);
+                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride, uint32_t tile_sub = kTileSub);
 // where k_tile_hist / k_pack put the 'bin != 0' bitmaps of the multi-GPU coverage summary: the tiles are cut into slices
 // of `tps` tiles (one slice per rank for the all-to-all exchange, a single slice otherwise) and slice j holds
 // [array 0 bits | array 1 bits] of its tiles back to back
@@ -251,11 +254,11 @@ constexpr uint32_t kFusedScanTiles = 4064;  // (4096 table entries less the room
 void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
                                const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
                                uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles,
-                               const Totals& tot = Totals());
+                               const Totals& tot = Totals(), uint32_t tile_sub = kTileSub);
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
                       uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,
-                      const BitsLayout& bits = BitsLayout(), uint32_t store_from = 0);  // bits: also the 'bin != 0' bitmaps of the
+                      const BitsLayout& bits = BitsLayout(), uint32_t store_from = 0, bool wide = false);  // bits: also the 'bin != 0' bitmaps of the
                       // two arrays; finished tiles below store_from are not written out (their statistics are still taken)
 // small arrays copied back to back to dst; with stats != nullptr also the non-zero bin counts of the tiles k_tile_hist
 // accumulated in pieces (split_tiles[0 .. counters[CNT_SPLIT])), read back from the finished arrays a / b

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
                                                     uint4* __restrict__ items2, uint32_t* __restrict__ sup_cursor,
                                                     uint32_t* __restrict__ split_tiles, uint32_t reps,
                                                     uint32_t rep_stride, int two_level, const uint4* __restrict__ part,
-                                                    uint32_t nparts, uint32_t* __restrict__ tail) {
+                                                    uint32_t nparts, uint32_t* __restrict__ tail, uint32_t tile_sub) {
     __shared__ uint2 s_part[1024];
     __shared__ uint32_t s_nsplit;
     __shared__ uint32_t s_tot[3];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
         for (uint32_t i = lo; i < hi; ++i) {
             const uint32_t c = decltype(from_lds)::value ? s_cnt[i] : tile_count[i];
             sum.x += c;
-            sum.y += c ? (c + kTileSub - 1) / kTileSub : 1u;
+            sum.y += c ? (c + tile_sub - 1) / tile_sub : 1u;
         }
     };
     if (staged)
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
     auto emit_items = [&](auto from_lds) {
     for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t c = decltype(from_lds)::value ? s_cnt[i] : tile_count[i];
-        const uint32_t pieces = c ? (c + kTileSub - 1) / kTileSub : 1u;
+        const uint32_t pieces = c ? (c + tile_sub - 1) / tile_sub : 1u;
         tile_base[i] = run.x;
         if (decltype(from_lds)::value) {
             s_cnt[i] = run.x;
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
         }
         if (pieces > 1) split_tiles[atomicAdd(&s_nsplit, 1u)] = i;
         for (uint32_t k = 0; k < pieces; ++k) {
-            uint32_t a = run.x + k * kTileSub;
-            uint32_t b = min(a + kTileSub, run.x + c);
+            uint32_t a = run.x + k * tile_sub;
+            uint32_t b = min(a + tile_sub, run.x + c);
             items[run.y + k] = make_uint4(i, a, b, pieces);
         }
         run.x += c;
@@ -566,9 +566,9 @@ __device__ __forceinline__ void bucketing_rounds(SlotWalk& walk, const uint32_t*
 
 // tiles cut into several work items are accumulated by k_tile_hist with (contiguous) global atomics: zero them first
 __device__ __forceinline__ void zero_split_tiles(const uint32_t* tile_base, uint32_t ntiles, uint32_t* __restrict__ cov,
-                                                 uint32_t* __restrict__ ucov) {
+                                                 uint32_t* __restrict__ ucov, uint32_t tile_sub) {
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tile_base[tile + 1] - tile_base[tile] <= kTileSub) continue;
+        if (tile_base[tile + 1] - tile_base[tile] <= tile_sub) continue;
         uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
         uint4* ou = reinterpret_cast<uint4*>((ucov ? ucov : cov) + static_cast<size_t>(tile) * kTileBins);
         const uint4 z = make_uint4(0, 0, 0, 0);
@@ -586,13 +586,13 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
                                                           uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
                                                           uint32_t* __restrict__ ucov,
                                                           const uint32_t* __restrict__ rep_base_all, uint32_t reps,
-                                                          uint32_t rep_stride) {
+                                                          uint32_t rep_stride, uint32_t tile_sub) {
     HIP_DYNAMIC_SHARED(uint32_t, s_hist)
     __shared__ uint32_t s_more[kTBlock / 64];
     const size_t rep_off = static_cast<size_t>((blockIdx.x / kCountFold) % reps) * rep_stride;
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
     const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
-    zero_split_tiles(tile_base, ntiles, cov, ucov);
+    zero_split_tiles(tile_base, ntiles, cov, ucov, tile_sub);
     SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
     bucketing_rounds<kDirectPieces>(walk, vals, s_more, [&](const uint32_t (&v)[kDirectPieces]) {
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
@@ -605,11 +605,11 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
 __global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_scatter_matrix(
     const uint32_t* __restrict__ vals, const uint4* __restrict__ slots, uint32_t nslots, int per_read, uint32_t ntiles,
     const uint32_t* __restrict__ tile_base, const uint32_t* __restrict__ matrix, uint32_t row_stride,
-    uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
+    uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov, uint32_t tile_sub) {
     HIP_DYNAMIC_SHARED(uint32_t, s_cur)
     const uint32_t* __restrict__ row = matrix + static_cast<size_t>(blockIdx.x) * row_stride;
     for (uint32_t i = threadIdx.x; i < ntiles; i += kTBlock * kCountFold) s_cur[i] = tile_base[i] + row[i];
-    if (threadIdx.x < kTBlock) zero_split_tiles(tile_base, ntiles, cov, ucov);
+    if (threadIdx.x < kTBlock) zero_split_tiles(tile_base, ntiles, cov, ucov, tile_sub);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     SlotWalk w = slot_walk(slots, nslots, per_read != 0, kCountFold);
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
                                                                 uint32_t* __restrict__ ucov, uint32_t rep_stride,
                                                                 uint4* __restrict__ items, uint32_t* __restrict__ split_tiles,
                                                                 const uint4* __restrict__ part, uint32_t nparts,
-                                                                uint32_t* __restrict__ tail) {
+                                                                uint32_t* __restrict__ tail, uint32_t tile_sub) {
     // 80 KiB of LDS to the byte, so that two workgroups share a CU: the three small arrays live in the tail of s_mine,
     // whose entries from ntiles on are never read (the launcher admits at most kFusedScanTiles = 4064 tiles)
     __shared__ uint32_t s_stage[kRoundCap];          // the ordered round's stage; before the rounds: the tile totals and
@@ -734,17 +734,17 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
         for (int q = 0; q < 8; ++q) {
             const uint32_t i = q * kTBlock + tid;
             const uint32_t c = i < ntiles ? s_base[i + 1] - s_base[i] : 0u;
-            s_piece[i] = i < ntiles ? (c ? (c + kTileSub - 1) / kTileSub : 1u) : 0u;
+            s_piece[i] = i < ntiles ? (c ? (c + tile_sub - 1) / tile_sub : 1u) : 0u;
         }
         __syncthreads();
         const uint32_t n_items = block_excl_scan_4096(s_piece, s_wtot);
         for (uint32_t i = tid; i < ntiles; i += kTBlock) {
             const uint32_t b0 = s_base[i], c = s_base[i + 1] - b0;
-            const uint32_t pieces = c ? (c + kTileSub - 1) / kTileSub : 1u;
+            const uint32_t pieces = c ? (c + tile_sub - 1) / tile_sub : 1u;
             if (pieces > 1) split_tiles[atomicAdd(&s_nsplit, 1u)] = i;
             for (uint32_t k = 0; k < pieces; ++k) {
-                const uint32_t lo = b0 + k * kTileSub;
-                items[s_piece[i] + k] = make_uint4(i, lo, min(lo + kTileSub, b0 + c), pieces);
+                const uint32_t lo = b0 + k * tile_sub;
+                items[s_piece[i] + k] = make_uint4(i, lo, min(lo + tile_sub, b0 + c), pieces);
             }
         }
         __syncthreads();
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
             counters[CNT_SPLIT] = s_nsplit;
         }
     }
-    zero_split_tiles(s_base, ntiles, cov, ucov);
+    zero_split_tiles(s_base, ntiles, cov, ucov, tile_sub);
     __syncthreads();  // the stage (s_base) and s_cnt are handed to the rounds
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + static_cast<size_t>(my_rep) * rep_stride;
     SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
@@ -773,11 +773,12 @@ __global__ __launch_bounds__(kTBlock) void k_part_super(const uint32_t* __restri
                                                         uint32_t nslots, int per_read, uint32_t ntiles,
                                                         const uint32_t* __restrict__ tile_base,
                                                         uint32_t* __restrict__ sup_cursor, uint32_t* __restrict__ mid,
-                                                        uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov) {
+                                                        uint32_t* __restrict__ cov, uint32_t* __restrict__ ucov,
+                                                        uint32_t tile_sub) {
     __shared__ uint32_t s_cur[kMaxSuper];
     __shared__ uint32_t s_more[kTBlock / 64];
     const uint32_t nsup = (ntiles + kSuperTiles - 1) / kSuperTiles;
-    zero_split_tiles(tile_base, ntiles, cov, ucov);
+    zero_split_tiles(tile_base, ntiles, cov, ucov, tile_sub);
     SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
     bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {
         for (uint32_t i = threadIdx.x; i < nsup; i += kTBlock) s_cur[i] = 0;
@@ -974,14 +975,16 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
     }
 }
 
-template <bool kTwo>
-__global__ __launch_bounds__(512, 8) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
+// kPacked = false with two arrays: the WIDE form for layouts whose tiles hold far more than kTileSub entries each (1 B
+// records on 20 k references: 63 k per tile): 32-bit counts, 64 KB of LDS, work items of up to kTileSubWide entries -- a
+// tile is then ONE item again instead of four pieces that each add 16 K words to global memory with atomics.
+template <bool kTwo, bool kPacked>
+__global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
                                                    const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov, const uint32_t* __restrict__ bin_off,
                                                    uint32_t n_refs, const uint32_t* __restrict__ tile_ref0,
                                                    uint32_t* __restrict__ stats, const BitsLayout bits, uint32_t store_from) {
-    constexpr bool kPacked = kTwo;          // two 16-bit counts per word (tile_load4)
-    constexpr uint32_t kWords = kPacked ? kPackWords : kTileBins;
+    constexpr uint32_t kWords = kPacked ? kPackWords : kTileBins;   // (packed: two 16-bit counts per word, tile_load4)
     __shared__ uint32_t s_cov[kWords];
     __shared__ uint32_t s_ucov[kTwo ? kWords : 4];
     __shared__ uint32_t s_off[kStatRefs + 1];  // bin offsets of the references overlapping this tile (and one more)
@@ -1060,7 +1063,10 @@ __global__ __launch_bounds__(512, 8) void k_tile_hist(const uint16_t* __restrict
         // (statistics, bit maps); the coverage arrays themselves are not materialised (tiles cut into pieces still are:
         // they are summed in global memory)
         if (tile >= store_from && !kPacked) {
-            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) oc[i] = sc[i];
+            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+                oc[i] = sc[i];
+                if (kTwo) ou[i] = su[i];
+            }
         } else if (tile >= store_from) {  // four packed words = bins i .. i + 3 and i + 4096 .. i + 4099
             for (uint32_t i = threadIdx.x; i < kPackWords / 4; i += 512) {
                 const uint4 w = sc[i];
@@ -1085,6 +1091,10 @@ __global__ __launch_bounds__(512, 8) void k_tile_hist(const uint16_t* __restrict
     for (uint32_t i = threadIdx.x; !kPacked && i < kTileBins; i += 512) {
         const uint32_t a = s_cov[i];
         if (a) atomicAdd(&gc[i], a);
+        if (kTwo) {
+            const uint32_t b2 = s_ucov[i];
+            if (b2) atomicAdd(&gu[i], b2);
+        }
     }
     for (uint32_t i = threadIdx.x; kPacked && i < kPackWords; i += 512) {
         const uint32_t a = s_cov[i];
@@ -1186,17 +1196,20 @@ void launch_matrix_prefix(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32
 }
 
 void launch_tile_scatter_matrix(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* tile_base,
-                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov) {
+                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov,
+                                uint32_t tile_sub) {
     hipLaunchKernelGGL(k_tile_scatter_matrix, dim3(tile_count_grid(grid)), dim3(kTBlock * kCountFold),
                        static_cast<size_t>(ntiles) * 4, st, in.vals, in.slots, in.nslots, in.per_read ? 1 : 0, ntiles, tile_base,
-                       matrix, row_stride, bucket, cov, ucov);
+                       matrix, row_stride, bucket, cov, ucov, tile_sub);
 }
 
 void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
                       uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level, const Totals& tot) {
+                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level, const Totals& tot,
+                      uint32_t tile_sub) {
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, tile_count, ntiles, tile_base, tile_cursor, items, counters,
-                       items2, sup_cursor, split_tiles, reps, rep_stride, two_level ? 1 : 0, tot.part, tot.nparts, tot.tail);
+                       items2, sup_cursor, split_tiles, reps, rep_stride, two_level ? 1 : 0, tot.part, tot.nparts, tot.tail,
+                       tile_sub);
 }
 
 uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
@@ -1206,15 +1219,16 @@ uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper) {
 void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const SlotValues& in,
                          const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
                          const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
-                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride) {
+                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride, uint32_t tile_sub) {
     if (!two_level) {
         const size_t lds = static_cast<size_t>(ntiles) * 4;
         hipLaunchKernelGGL(k_tile_scatter, dim3(grid), dim3(kTBlock), lds, st, in.vals, in.slots, in.nslots,
-                           in.per_read ? 1 : 0, ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride);
+                           in.per_read ? 1 : 0, ntiles, tile_base, tile_cursor, bucket, cov, ucov, rep_base, reps, rep_stride,
+                           tile_sub);
         return;
     }
     hipLaunchKernelGGL(k_part_super, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots, in.per_read ? 1 : 0,
-                       ntiles, tile_base, sup_cursor, mid, cov, ucov);
+                       ntiles, tile_base, sup_cursor, mid, cov, ucov, tile_sub);
     hipLaunchKernelGGL(k_part_tile, dim3(part_items_upper(ntiles, n_upper)), dim3(kTBlock), 0, st, mid, items2, counters,
                        tile_base, tile_cursor, ntiles, bucket);
 }
@@ -1224,10 +1238,10 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
 void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
                                const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
                                uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles,
-                               const Totals& tot) {
+                               const Totals& tot, uint32_t tile_sub) {
     hipLaunchKernelGGL(k_tile_scatter_fused, dim3(grid), dim3(kTBlock), 0, st, in.vals, in.slots, in.nslots,
                        in.per_read ? 1 : 0, counters, ntiles, tile_count, tile_cursor, bucket, cov, ucov, rep_stride, items,
-                       split_tiles, tot.part, tot.nparts, tot.tail);
+                       split_tiles, tot.part, tot.nparts, tot.tail, tile_sub);
 }
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }
@@ -1236,13 +1250,17 @@ uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n
 // stats != nullptr: also accumulate the per-reference statistics (zeroed by the caller) of the finished arrays
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
-                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, const BitsLayout& bits, uint32_t store_from) {
+                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats, const BitsLayout& bits, uint32_t store_from,
+                      bool wide) {
     const uint32_t grid = tile_items_upper(ntiles, n_upper);
-    if (ucov)
-        hipLaunchKernelGGL(k_tile_hist<true>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
+    if (ucov && wide)
+        hipLaunchKernelGGL((k_tile_hist<true, false>), dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
+                           n_refs, tile_ref0, stats, bits, store_from);
+    else if (ucov)
+        hipLaunchKernelGGL((k_tile_hist<true, true>), dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
                            n_refs, tile_ref0, stats, bits, store_from);
     else
-        hipLaunchKernelGGL(k_tile_hist<false>, dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov, bin_off,
+        hipLaunchKernelGGL((k_tile_hist<false, false>), dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov, bin_off,
                            n_refs, tile_ref0, stats, bits, store_from);
 }
 

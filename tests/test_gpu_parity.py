@@ -280,6 +280,21 @@ def test_matrix_bucketing_and_the_direct_rounds(monkeypatch, matrix):
                         seed=29))
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_wide_tile_work_items(monkeypatch, fused):
+    """SLIMM_WIDE_TILES=1: the form k_tile_hist takes by itself when a file brings far more entries per tile than a
+    packed work item holds (1 B records on 20 k references) -- 32-bit counts, work items of up to 262 144 entries --
+    on small layouts: tiles that were cut into pieces become one item, a tile of 300 000 entries still is cut."""
+    monkeypatch.setenv("SLIMM_WIDE_TILES", "1")
+    monkeypatch.setenv("SLIMM_FUSED_SCAN", fused)
+    check(make_workload(CONFIGS["config1"], seed=30))
+    check(make_workload(CONFIGS["config2"], seed=31, n_records=300_000))
+    check(make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000, len_hi=900_000, present_frac=0.3),
+                        seed=32))
+    check(make_workload(SynthConfig("hotter", 600_000, 6, 1.5, bin_width=200, len_lo=300_000, len_hi=400_000, present_frac=1.0),
+                        seed=33), keep_bins=False)
+
+
 def test_wide_lineage_rows_fallback_path(monkeypatch):
     """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
     monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")

@@ -1,21 +1,24 @@
-# HBM traffic of every kernel from the TCC counters, in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass).
+# HBM traffic of every kernel from the TCC counters, in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass):
+#   bash scripts/pmc_traffic.sh [config]      (default: config4, the headline workload)  -> gpurun_out/pmc_traffic/summary_<config>.json
+# profiles/roundN/pmc_traffic_summary.json = {"<config>": <that summary>, ...} is what bench.py reads for roofline.traffic.
+CFG=${1:-config4}
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/pmc_traffic; mkdir -p $OUT; cd /tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch -- python3 $R/bench.py --steps 3 --warmup 1 --quick > /dev/null 2>$OUT/err_f.txt
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write -- python3 $R/bench.py --steps 3 --warmup 1 --quick > /dev/null 2>$OUT/err_w.txt
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req -- python3 $R/bench.py --steps 3 --warmup 1 --quick > /dev/null 2>$OUT/err_r.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick > /dev/null 2>$OUT/err_f.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick > /dev/null 2>$OUT/err_w.txt
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick > /dev/null 2>$OUT/err_r.txt
 python3 - <<PY
 import csv, collections, glob, json
 res=collections.defaultdict(dict)
 for tag in ("fetch","write","req"):
-    try: rows=list(csv.DictReader(open("$OUT/%s_counter_collection.csv"%tag)))
+    try: rows=list(csv.DictReader(open("$OUT/%s_${CFG}_counter_collection.csv"%tag)))
     except Exception as e: print("missing",tag,e); continue
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
     for r in rows:
         k=r["Kernel_Name"].split("(")[0].replace("void slimm::","").replace("slimm::","")
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     for k,v in agg.items():
-        if k.startswith("__amd"): continue
+        if k.startswith("__amd") or "at::" in k or "elementwise" in k: continue
         for a,b in v.items(): res[k][a]=b/len(n[k])
-json.dump(res, open("$OUT/summary.json","w"), indent=1)
+json.dump(res, open("$OUT/summary_${CFG}.json","w"), indent=1)
 for k,v in res.items(): print(k, {a:round(b,1) for a,b in v.items()})
 PY

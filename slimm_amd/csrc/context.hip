@@ -308,11 +308,11 @@ void drain_events(slimm_ctx* c) {
 int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     const uint32_t nt = num_tiles(n) + 2;
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
-    HIP_TRY(c, c->tgt_gbin.ensure(n + 1));
+    HIP_TRY(c, c->tgt_gbin.ensure(n + 8));  // (+ the reach of the bucketing kernels' 16-byte loads, tile_hist.hip: piece_load)
     HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
     HIP_TRY(c, c->wcut.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
     HIP_TRY(c, c->tot_part.ensure(512));
-    HIP_TRY(c, c->sel.ensure(n + 1));
+    HIP_TRY(c, c->sel.ensure(n + 8));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles2, n) + 1));

@@ -83,7 +83,8 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslot
     return w;
 }
 
-// the next (up to) 64 entries: returns their count (0: the wave has no more), *base = index of the first
+// the next (up to) 256 entries: returns their count (0: the wave has no more), *base = index of the first
+constexpr uint32_t kPiece = 256;
 __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
     while (w.left == 0u) {
         if (w.s >= w.s_end) return 0u;
@@ -95,11 +96,29 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
         w.sum_h += d.z;
         w.sum_v += d.w;
     }
-    const uint32_t n = min(w.left, 64u);
+    const uint32_t n = min(w.left, kPiece);
     *base = w.base;
     w.base += n;
     w.left -= n;
     return n;
+}
+
+// A piece of n <= 256 values at vals[base ...): four consecutive values per lane in ONE 16-byte load (a 4-byte load per
+// lane is a load instruction per 64 values; the slots' values start anywhere, so the load is only dword-aligned, which
+// global loads take).  Values behind the piece read as 0xffffffff = nothing; the load itself may reach up to three
+// entries behind the piece -- other slots' values or the arrays' padding (ensure_work_buffers).
+struct __attribute__((packed, aligned(4))) Quad {
+    uint32_t a, b, c, d;
+};
+__device__ __forceinline__ void piece_load(const uint32_t* __restrict__ vals, uint32_t base, uint32_t n, uint32_t lane,
+                                           uint32_t* v) {
+    const uint32_t i = 4u * lane;
+    Quad q{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (i < n) q = *reinterpret_cast<const Quad*>(vals + base + i);
+    v[0] = i < n ? q.a : 0xffffffffu;
+    v[1] = i + 1u < n ? q.b : 0xffffffffu;
+    v[2] = i + 2u < n ? q.c : 0xffffffffu;
+    v[3] = i + 3u < n ? q.d : 0xffffffffu;
 }
 
 // tile of a value: bit 31 (unique read) is no part of the bin index; 0xffffffff = nothing to count (a read without
@@ -121,19 +140,19 @@ __global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_count(const uint3
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     SlotWalk w = slot_walk(slots, nslots, per_read != 0, kCountFold);
-    while (true) {  // four pieces per trip, their loads in flight together
-        uint32_t v[4];
+    while (true) {  // four pieces of 256 values per trip, their loads in flight together
+        uint32_t v[16];
         bool any = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             uint32_t base = 0;
             const uint32_t n = slot_next(w, &base);
             any = any || n != 0u;
-            v[u] = lane < n ? vals[base + lane] : 0xffffffffu;
+            piece_load(vals, base, n, lane, v + 4 * u);
         }
         if (!any) break;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 16; ++u)
             if (v[u] != 0xffffffffu) atomicAdd(&s_hist[tile_of(v[u])], 1u);
     }
     if (part && lane == 0u) {  // the totals of this workgroup's slots (the front end leaves them to its first consumer)
@@ -416,8 +435,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Bucketing rounds.  In one round every wave of the workgroup takes kRoundPieces pieces of 64 values from its slots
-// into registers (at most kRoundCap values per workgroup and round).
+// Bucketing rounds.  In one round every wave of the workgroup takes kRoundPieces / 4 pieces of 256 values from its slots
+// into registers, four consecutive values per lane (at most kRoundCap values per workgroup and round).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kRoundPieces = 16;
 constexpr int kDirectPieces = 32;  // ... of the direct rounds (no stage in LDS): one returning atomic per touched tile and round
@@ -428,13 +447,14 @@ constexpr uint32_t kRoundCap = (kTBlock / 64) * kRoundPieces * 64;  // 8192 valu
 template <int kPieces>
 __device__ __forceinline__ bool round_load(SlotWalk& w, const uint32_t* __restrict__ vals, uint32_t lane,
                                            uint32_t (&v)[kPieces]) {
+    static_assert(kPieces % 4 == 0, "values come four to a lane");
     bool any = false;
 #pragma unroll
-    for (int k = 0; k < kPieces; ++k) {
+    for (int k = 0; k < kPieces; k += 4) {
         uint32_t base = 0;
         const uint32_t n = slot_next(w, &base);
         any = any || n != 0u;
-        v[k] = lane < n ? vals[base + lane] : 0xffffffffu;
+        piece_load(vals, base, n, lane, v + k);
     }
     return any;
 }
@@ -613,15 +633,15 @@ __global__ __launch_bounds__(kTBlock * kCountFold) void k_tile_scatter_matrix(
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
     SlotWalk w = slot_walk(slots, nslots, per_read != 0, kCountFold);
-    while (true) {  // eight pieces per trip, their loads in flight together
+    while (true) {  // two pieces of 256 values per trip, their loads in flight together
         uint32_t v[8];
         bool any = false;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 8; u += 4) {
             uint32_t base = 0;
             const uint32_t n = slot_next(w, &base);
             any = any || n != 0u;
-            v[u] = lane < n ? vals[base + lane] : 0xffffffffu;
+            piece_load(vals, base, n, lane, v + u);
         }
         if (!any) break;
 #pragma unroll

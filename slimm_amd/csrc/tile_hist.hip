@@ -85,7 +85,7 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslot
 
 // the next (up to) 256 entries: returns their count (0: the wave has no more), *base = index of the first
 constexpr uint32_t kPiece = 256;
-__device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
+__device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base, uint32_t cap = kPiece) {
     while (w.left == 0u) {
         if (w.s >= w.s_end) return 0u;
         const uint4 d = w.slots[w.s];  // (a scalar load: one address for the wave)
@@ -96,7 +96,7 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base) {
         w.sum_h += d.z;
         w.sum_v += d.w;
     }
-    const uint32_t n = min(w.left, kPiece);
+    const uint32_t n = min(w.left, cap);
     *base = w.base;
     w.base += n;
     w.left -= n;
@@ -443,18 +443,33 @@ constexpr int kDirectPieces = 32;  // ... of the direct rounds (no stage in LDS)
 constexpr uint32_t kTileSlots = 4096;  // entries of the ordered round's tile tables (= kFusedTiles)
 constexpr uint32_t kRoundCap = (kTBlock / 64) * kRoundPieces * 64;  // 8192 values per round
 
-// loads the round's values (0xffffffff where there is none); returns whether this wave got any
-template <int kPieces>
+// loads the round's values (0xffffffff where there is none); returns whether this wave got any.  kWide: pieces of 256
+// values, four consecutive ones per lane in a 16-byte load -- for the rounds that order their values in LDS before
+// they leave.  The direct rounds keep pieces of 64 values, one per lane: their stores go out straight from the
+// registers, and consecutive targets (one read's neighbouring references) often share a tile and so get consecutive
+// bucket places -- with consecutive LANES holding them a store instruction's lanes fall into few cache lines, with
+// four values per lane they are four targets apart (measured: config 3 362 -> 392 us with the wide pieces).
+template <int kPieces, bool kWide>
 __device__ __forceinline__ bool round_load(SlotWalk& w, const uint32_t* __restrict__ vals, uint32_t lane,
                                            uint32_t (&v)[kPieces]) {
     static_assert(kPieces % 4 == 0, "values come four to a lane");
     bool any = false;
+    if (kWide) {
 #pragma unroll
-    for (int k = 0; k < kPieces; k += 4) {
-        uint32_t base = 0;
-        const uint32_t n = slot_next(w, &base);
-        any = any || n != 0u;
-        piece_load(vals, base, n, lane, v + k);
+        for (int k = 0; k < kPieces; k += 4) {
+            uint32_t base = 0;
+            const uint32_t n = slot_next(w, &base);
+            any = any || n != 0u;
+            piece_load(vals, base, n, lane, v + k);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            uint32_t base = 0;
+            const uint32_t n = slot_next(w, &base, 64u);
+            any = any || n != 0u;
+            v[k] = lane < n ? vals[base + lane] : 0xffffffffu;
+        }
     }
     return any;
 }
@@ -567,12 +582,12 @@ __device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kPieces
 }
 
 // rounds until no wave of the workgroup has values left (s_more: one flag per wave)
-template <int kPieces = kRoundPieces, typename Body>
+template <int kPieces = kRoundPieces, bool kWide = true, typename Body>
 __device__ __forceinline__ void bucketing_rounds(SlotWalk& walk, const uint32_t* __restrict__ vals, uint32_t* s_more,
                                                  Body body) {
     while (true) {
         uint32_t v[kPieces];
-        const bool mine = round_load<kPieces>(walk, vals, threadIdx.x & 63u, v);
+        const bool mine = round_load<kPieces, kWide>(walk, vals, threadIdx.x & 63u, v);
         if ((threadIdx.x & 63u) == 0) s_more[threadIdx.x >> 6] = mine ? 1u : 0u;
         __syncthreads();
         uint32_t any = 0;
@@ -614,7 +629,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
     const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
     zero_split_tiles(tile_base, ntiles, cov, ucov, tile_sub);
     SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
-    bucketing_rounds<kDirectPieces>(walk, vals, s_more, [&](const uint32_t (&v)[kDirectPieces]) {
+    bucketing_rounds<kDirectPieces, false>(walk, vals, s_more, [&](const uint32_t (&v)[kDirectPieces]) {
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
     });
 }

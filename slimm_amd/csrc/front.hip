@@ -332,11 +332,25 @@ struct Staged {
     bool mapped;
 };
 
-// trips of eight walk steps (behind the first four) before window_fast gives a window to the hash table
-#ifndef SLIMM_WALK_TRIPS
-#define SLIMM_WALK_TRIPS 3
+// Segments longer than this take the hash table in window_fast (a walk step is two vector and two scalar instructions,
+// the table about fifty instructions and four LDS round trips whatever the segments look like)
+#ifndef SLIMM_HASH_WALK
+#define SLIMM_HASH_WALK 32
 #endif
-constexpr uint32_t kWalkTrips = SLIMM_WALK_TRIPS;
+constexpr uint32_t kHashWalk = SLIMM_HASH_WALK;
+// D = N0 & (N0 << 1) marks the second and later lanes of every stretch of set bits of N0 (non-start lanes: a segment of
+// L records is a stretch of L - 1).  Is there a stretch of D of at least n bits (a segment of more than n + 1 records)?
+__device__ __forceinline__ bool has_run_of(uint64_t D, uint32_t n) {
+    // stretches of >= 2^k bits by doubling, then the remainder
+    uint64_t x = D;
+    uint32_t have = 1;
+    while (have * 2u <= n) {
+        x &= x << have;
+        have *= 2u;
+    }
+    if (have < n) x &= x << (n - have);
+    return x != 0ull;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  field = the staged reference field,
@@ -350,41 +364,39 @@ __device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint3
     // x_{d+1}[i] = x_d[i - 1] ^ x_1[i]: ONE xor with a lane shift per step.  A lane is a duplicate iff some x_d is zero.
     // Steps beyond a lane's own segment compare it with other segments' words -- never equal, so nothing guards them;
     // the trip count follows the longest segment of THIS window (scalar: D = lanes at least d behind their start).
-    // The walk: one lane shift per step, as many steps as the window's longest segment has records behind its first.
-    // (The scalar unit is what a CU has one of: segments of up to six records -- four steps -- update D step by step,
-    // longer ones go on eight steps at a time with D advanced by doubling: one scalar instruction per step, not two.)
-    // A window that is still not through after 4 + 8 kWalkTrips steps has a segment of more than 30 records and takes
-    // the hash table instead, whose cost does not depend on the segments (config 5, 40 hits per read: most windows).
+    // A window with a segment of more than kHashWalk records takes the hash table instead: the walk's trip count is the
+    // longest segment, the table's cost is the same whatever the segments look like (config 5, 40 hits per read: every
+    // window; config 3, 8 hits per read: one window in three).
     const uint32_t T = (f_rank(SS >> 1) << kTagShift) | field;
     const uint64_t N0 = ~SS & f_below(X);
     uint64_t D = N0 & (N0 << 1);
-    const uint32_t x1 = f_shr1z(T) ^ T;
-    uint32_t x = x1, differ = x1;
-    if (D) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            x = f_shr1z(x) ^ x1;
-            differ = min(differ, x);
-            D &= D << 1;
-        }
-    }
-    uint32_t trips = 0;
-    while (D && trips < kWalkTrips) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            x = f_shr1z(x) ^ x1;
-            differ = min(differ, x);
-        }
-        const uint64_t t2 = D & (D << 1), t4 = t2 & (t2 << 2), t8 = t4 & (t4 << 4);
-        D = t8 & (D << 8);
-        ++trips;
-    }
     uint64_t F;
-    if (D) {
+    if (has_run_of(D, kHashWalk - 1u)) {
         hash_clear(tab, lane);
         bool overflow = false;  // (never: 64 keys at most)
         F = f_ballot(hash_first(tab, T, lane, f_bit(V), overflow));
     } else {
+        const uint32_t x1 = f_shr1z(T) ^ T;
+        uint32_t x = x1, differ = x1;
+        // (the scalar unit is what a CU has one of: segments of up to six records -- four steps -- update D step by step,
+        // longer ones go on eight steps at a time with D advanced by doubling: one scalar instruction per step, not two)
+        if (D) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x = f_shr1z(x) ^ x1;
+                differ = min(differ, x);
+                D &= D << 1;
+            }
+        }
+        while (D) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x = f_shr1z(x) ^ x1;
+                differ = min(differ, x);
+            }
+            const uint64_t t2 = D & (D << 1), t4 = t2 & (t2 << 2), t8 = t4 & (t4 << 4);
+            D = t8 & (D << 8);
+        }
         F = f_ballot(differ != 0u) & V;
     }
     // heads: the first mapped lane of every segment; the last lane of a segment stops the carry of its start

@@ -68,9 +68,11 @@ struct SlotWalk {  // all wave-uniform
 
 // fold: this workgroup stands for `fold` workgroups of the bucketing grid (k_tile_count: fewer, larger workgroups flush
 // fewer LDS histograms with global atomics)
-__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read, uint32_t fold = 1) {
+// wg: the workgroup's index among the owners of slot ranges (blockIdx.x, or a permutation of it: xcd_logical_id)
+__device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read, uint32_t fold = 1,
+                                              uint32_t wg = blockIdx.x) {
     const uint32_t per_wg = (nslots + gridDim.x * fold - 1) / (gridDim.x * fold) * fold;
-    const uint32_t lo = min(blockIdx.x * per_wg, nslots);
+    const uint32_t lo = min(wg * per_wg, nslots);
     SlotWalk w;
     w.slots = slots;
     w.step = blockDim.x >> 6;
@@ -81,6 +83,21 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslot
     w.sum_f = w.sum_h = w.sum_v = 0;
     w.per_read = per_read;
     return w;
+}
+
+// Which slot range (and with it which copy of the tile counters and cursors) a bucketing workgroup takes.  Workgroups
+// whose blockIdx agree mod 8 share an XCD, i.e. an L2; a counter copy's bucket frontiers -- the cache lines its
+// workgroups append 2-byte entries to -- are written back whole only if ONE L2 collects the entries, otherwise every
+// XCD writes its partial line through (PMC at config 4: 4.2 GB written for 1.23 GB of entries).  The logical id is a
+// permutation of blockIdx with copy(logical) = (logical / kCountFold) % kTileReps == blockIdx % 8: all workgroups of a
+// copy on one XCD.  (The counting workgroup c = logical / kCountFold adds to copy c % 8 and sits on XCD label c % 8 as
+// well.)  Grids that are no multiple of 16: the identity.
+__device__ __forceinline__ uint32_t xcd_logical_id() {
+    static_assert(kTileReps == 8 && kCountFold == 2, "the permutation below is written for 8 copies, 2 halves");
+    const uint32_t b = blockIdx.x;
+    if (gridDim.x % 16u) return b;
+    const uint32_t q = b >> 3, x = b & 7u;
+    return 16u * (q >> 1) + 2u * x + (q & 1u);
 }
 
 // the next (up to) 256 entries: returns their count (0: the wave has no more), *base = index of the first
@@ -624,11 +641,12 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
                                                           uint32_t rep_stride, uint32_t tile_sub) {
     HIP_DYNAMIC_SHARED(uint32_t, s_hist)
     __shared__ uint32_t s_more[kTBlock / 64];
-    const size_t rep_off = static_cast<size_t>((blockIdx.x / kCountFold) % reps) * rep_stride;
+    const uint32_t lid = xcd_logical_id();
+    const size_t rep_off = static_cast<size_t>((lid / kCountFold) % reps) * rep_stride;
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
     const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
     zero_split_tiles(tile_base, ntiles, cov, ucov, tile_sub);
-    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0, 1, lid);
     bucketing_rounds<kDirectPieces, false>(walk, vals, s_more, [&](const uint32_t (&v)[kDirectPieces]) {
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
     });
@@ -732,7 +750,8 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     uint32_t& s_nsplit = s_mine[kFusedTiles - 16];
     uint32_t* const s_base = s_stage;
     const uint32_t tid = threadIdx.x;
-    const uint32_t my_rep = (blockIdx.x / kCountFold) % kTileReps;  // (the copy the counting workgroup of these slots added to)
+    const uint32_t lid = xcd_logical_id();
+    const uint32_t my_rep = (lid / kCountFold) % kTileReps;  // (the copy the counting workgroup of these slots added to)
     TPROF_T(q0);
     if (tid == 0) s_nsplit = 0;
 #pragma unroll
@@ -792,7 +811,7 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter_fused(const uint32_t* 
     zero_split_tiles(s_base, ntiles, cov, ucov, tile_sub);
     __syncthreads();  // the stage (s_base) and s_cnt are handed to the rounds
     uint32_t* __restrict__ tile_cursor = tile_cursor_all + static_cast<size_t>(my_rep) * rep_stride;
-    SlotWalk walk = slot_walk(slots, nslots, per_read != 0);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0, 1, lid);
     TPROF_T(q1);
     TPROF_ADD(0, q0, q1);
     bucketing_rounds(walk, vals, s_more, [&](const uint32_t (&v)[kRoundPieces]) {

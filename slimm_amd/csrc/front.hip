@@ -86,6 +86,9 @@ __device__ __forceinline__ uint32_t f_shr1z(uint32_t v) {
 __device__ __forceinline__ uint32_t f_ror1(uint32_t v) {  // lane i gets lane i - 1, lane 0 gets lane 63
     return __builtin_amdgcn_update_dpp(v, v, 0x13c, 0xf, 0xf, false);
 }
+__device__ __forceinline__ uint64_t f_below_nz(uint32_t n) {  // lanes 0 .. n-1 for 1 <= n <= 64: two scalar instructions
+    return ~0ull >> (64u - n);
+}
 __device__ __forceinline__ uint64_t f_below(uint32_t n) {  // lanes 0 .. n-1 (n <= 64)
     return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
 }
@@ -123,33 +126,33 @@ __device__ __forceinline__ void hash_clear(uint32_t* tab, uint32_t lane) {
 // lane is the first of its key; overflow: the table is full (more than kHashSlots distinct keys) -- the caller falls
 // back to the comparison walk.
 __device__ __forceinline__ bool hash_first(uint32_t* tab, uint32_t key, uint32_t pos, bool active, bool& overflow) {
+    // Straight-line on purpose (the scalar unit is this kernel's bottleneck, and every `if (pending)` around an LDS
+    // atomic is a dozen scalar instructions of exec-mask bookkeeping per trip): EVERY lane issues every operation.  A
+    // lane that has its entry finds its own key there again, a lane with nothing to insert swaps nothing into nothing
+    // (key 0 for "empty"), and lowers no position (0xffffffff).
     uint2* const e = reinterpret_cast<uint2*>(tab);
 #ifdef SLIMM_HASH_LINEAR
     uint32_t slot = (key + (key >> 7) * 37u + (key >> 26) * 11u) & (kHashSlots - 1u);
 #else
     uint32_t slot = (key * 0x9E3779B1u) >> (32u - kHashBits);
 #endif
+    const uint32_t mine = active ? key : 0u;
     bool pending = active;
     uint32_t probes = 0;
-    while (f_ballot(pending) != 0ull) {
-        if (pending) {
-            const uint32_t old = atomicCAS(&e[slot].x, 0u, key);
-            if ((old == 0u) | (old == key)) {
-                pending = false;
-            } else {
-                slot = (slot + 1u) & (kHashSlots - 1u);
-                if (++probes == kHashSlots) {
-                    overflow = true;
-                    pending = false;
-                    active = false;
-                }
-            }
-        }
+    while (f_ballot(pending) != 0ull) {  // (tested at the top: one call site for the collective, see tests/native/README.md)
+        const uint32_t old = atomicCAS(&e[slot].x, 0u, mine);
+        pending = pending & (old != 0u) & (old != key);          // neither claimed nor found: the next entry
+        slot = pending ? ((slot + 1u) & (kHashSlots - 1u)) : slot;
+        probes += pending ? 1u : 0u;
+        const bool full = probes >= kHashSlots;                   // every entry holds another key
+        overflow = overflow | full;
+        pending = pending & !full;
     }
-    if (active) atomicMin(&e[slot].y, pos);
-    const bool lowered = f_ballot(active) != 0ull;  // (every lane's minimum is in before any lane reads)
-    const uint32_t got = (active & lowered) ? __hip_atomic_load(&e[slot].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xffffffffu;
-    return active && got == pos;
+    const bool placed = active & !overflow;
+    atomicMin(&e[slot].y, placed ? pos : 0xffffffffu);
+    const bool lowered = f_ballot(placed) != 0ull;  // (every lane's minimum is in before any lane reads)
+    const uint32_t got = lowered ? __hip_atomic_load(&e[slot].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xffffffffu;
+    return placed && got == pos;
 }
 
 }  // namespace
@@ -368,7 +371,7 @@ __device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint3
     // longest segment, the table's cost is the same whatever the segments look like (config 5, 40 hits per read: every
     // window; config 3, 8 hits per read: one window in three).
     const uint32_t T = (f_rank(SS >> 1) << kTagShift) | field;
-    const uint64_t N0 = ~SS & f_below(X);
+    const uint64_t N0 = ~SS & f_below_nz(X);  // (a window holds a record)
     uint64_t D = N0 & (N0 << 1);
     uint64_t F;
     if (has_run_of(D, kHashWalk - 1u)) {
@@ -406,10 +409,11 @@ __device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint3
     const uint64_t Fr = __builtin_bitreverse64(F), Gr = __builtin_bitreverse64(F & ~H);
     const uint64_t U = H & ~__builtin_bitreverse64((~Fr + (Gr << 1)) & Fr);
     if (f_bit(F)) {
-        const uint32_t at = so.base + so.nf;  // (wave-uniform: a scalar base per array, one lane offset for both)
-        const uint32_t r4 = f_rank(F) * 4u;
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tgt_ref + at) + r4) = (field - 1u) | (f_bit(H) ? 0x80000000u : 0u);
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(tgt_gbin + at) + r4) = gbin | (f_bit(U) ? 0x80000000u : 0u);
+        // (the index in a vector register: the scalar unit is the kernel's bottleneck, and a scalar base per array costs
+        // it two 64-bit adds and a shift per window)
+        const uint32_t p = so.base + so.nf + f_rank(F);
+        tgt_ref[p] = (field - 1u) | (f_bit(H) ? 0x80000000u : 0u);
+        tgt_gbin[p] = gbin | (f_bit(U) ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                 }
                 if (X) {
                     const uint32_t field = w1 & kRefField, mate = (w1 >> kStMateShift) & 3u;
-                    const uint64_t PR = f_below(X);
+                    const uint64_t PR = f_below_nz(X);
                     const uint64_t RS = RSw & PR;
                     const uint32_t mprev = f_shr1z(mate);
                     const uint64_t V = f_ballot(field != kRefField) & PR;

@@ -359,9 +359,12 @@ __device__ __forceinline__ bool has_run_of(uint64_t D, uint32_t n) {
 // fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  field = the staged reference field,
 // SS = segment starts (run starts and mate changes), V = mapped lanes, both inside [0, X).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint32_t lane, uint64_t SS, uint64_t V, uint32_t X,
-                                            WinOut& so, uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
-                                            uint32_t* tab) {
+struct WinMasks {  // what the caller needs to cut the filter's windows: the window's targets and read heads
+    uint64_t F, H;
+};
+__device__ __forceinline__ WinMasks window_fast(uint32_t field, uint32_t gbin, uint32_t lane, uint64_t SS, uint64_t V, uint32_t X,
+                                                WinOut& so, uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
+                                                uint32_t* tab) {
     // Q1: an earlier lane of my segment with my reference?  T = {segment number, field} is never zero and equal only
     // inside a segment; x_d[i] = T[i - d] ^ T[i] (T of the lanes in front of lane 0 taken as zero) follows from
     // x_{d+1}[i] = x_d[i - 1] ^ x_1[i]: ONE xor with a lane shift per step.  A lane is a duplicate iff some x_d is zero.
@@ -418,6 +421,7 @@ __device__ __forceinline__ void window_fast(uint32_t field, uint32_t gbin, uint3
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));
     so.nv += static_cast<uint32_t>(__popcll(V));
+    return WinMasks{F, H};
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -801,8 +805,23 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
         const uint32_t B = slot * kSlotRecs;
         uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
         WinOut so{B, 0u, 0u, 0u};
+        // The window list for k_filter (wcut): ITS windows are cut here, every <= 64 TARGETS at a read's head -- not one
+        // per window of 64 records: at 0.6 targets per record (config 4) the record windows leave 37 of the filter's 64
+        // lanes busy, and the filter is bound by its vector instructions per window.  A cut is {targets, reads} of the
+        // slot in front of it; lane i keeps cut i (one store of the whole list at the end).  cf = targets in front of the last cut.
         uint32_t nw = 0;
         uint32_t cut_f = 0, cut_h = 0;
+        uint32_t cf = 0;
+        bool must_cut = true;  // the next window starts a filter window whatever came before (the slot's first; behind a
+                               // window that stands alone)
+        auto emit = [&](uint32_t f, uint32_t h) {
+            if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2 windows of records: two in a row
+                cut_f = lane == nw ? f : cut_f;  // cover 64 records; a list that is full lets its last window take the
+                cut_h = lane == nw ? h : cut_h;  // rest of the slot, which the filter works through in pieces)
+                ++nw;
+            }
+            cf = f;
+        };
         if (B < N) {
             // ---- 1. stage (the only part that waits for memory; everything a group loads is in flight at once)
             if (N - B >= kStageRecs)
@@ -816,11 +835,6 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
             uint32_t off = next_run_start(st1, lane, 0u);
             so.base = B + min(off, kSlotRecs);
             while (off < kSlotRecs && B + off < N) {  // (the stream may end inside the slot)
-                if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2: two windows in a row cover 64
-                    cut_f = lane == nw ? so.nf : cut_f;  // records; beyond that the list's last window simply takes the
-                    cut_h = lane == nw ? so.nh : cut_h;  // rest of the slot).  Lane i keeps window i's entry: one store of
-                    ++nw;                                // the whole list at the end instead of a lane-0 store per window
-                }
                 const uint32_t w1 = st1[off + lane], w2 = st2[off + lane];
                 const uint64_t RSw = f_ballot(static_cast<int32_t>(w1) < 0);  // (bit 0 is set: a window starts a run)
                 const uint32_t pos = B + off;
@@ -836,15 +850,37 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                     const uint64_t RS = RSw & PR;
                     const uint32_t mprev = f_shr1z(mate);
                     const uint64_t V = f_ballot(field != kRefField) & PR;
-                    if ((f_ballot(mate < mprev) & ~RS & PR) == 0ull)
-                        window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin, tab);
-                    else
+                    if ((f_ballot(mate < mprev) & ~RS & PR) == 0ull) {
+                        const uint32_t f0 = so.nf, h0 = so.nh;
+                        if (must_cut) {
+                            emit(f0, h0);
+                            must_cut = false;
+                        }
+                        const WinMasks m =
+                            window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin, tab);
+                        if (so.nf - cf > 64u) {
+                            // the filter window under construction ends inside this one: at the LAST read head that
+                            // leaves it at most 64 targets.  f0 - cf <= 64 (the invariant this keeps), the window's
+                            // first target is a head of rank 0, so there is one.
+                            const uint32_t room = 64u - (f0 - cf);  // targets of this window that still fit
+                            const uint64_t ok = m.H & f_ballot(f_rank(m.F) <= room);
+                            const uint32_t at = 63u - static_cast<uint32_t>(__builtin_clzll(ok));
+                            const uint64_t below = f_below(at);
+                            emit(f0 + static_cast<uint32_t>(__popcll(m.F & below)), h0 + static_cast<uint32_t>(__popcll(m.H & below)));
+                        }
+                    } else {  // (mates interleave: the window's targets are not in lane order -- it stands alone)
+                        if (must_cut || so.nf != cf) emit(so.nf, so.nh);
                         window_general(Staged{mate, field - 1u, w2, f_bit(V)}, lane, RS, V, X, so, tgt_ref, tgt_gbin);
+                        must_cut = true;
+                    }
                     off += X;
                 } else {
-                    // a run of 64 records or more.  Inside the staged stretch (its end is the next staged run start): from
+                    // a run of 64 records or more (it stands alone in the filter's list: it may hold any number of
+                    // targets).  Inside the staged stretch (its end is the next staged run start): from
                     // the staged words; running on beyond it, or with more distinct references than the hash table
                     // holds: from global memory, at its own pace
+                    if (must_cut || so.nf != cf) emit(so.nf, so.nh);
+                    must_cut = true;
                     const uint32_t end_off = next_run_start(st1, lane, off + 64u);
                     if (end_off < kStageRecs && long_run_staged(st1, st2, off, end_off, lane, so, tgt_ref, tgt_gbin, tab)) {
                         off = end_off;

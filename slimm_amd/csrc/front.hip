@@ -865,7 +865,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                             const uint32_t room = 64u - (f0 - cf);  // targets of this window that still fit
                             const uint64_t ok = m.H & f_ballot(f_rank(m.F) <= room);
                             const uint32_t at = 63u - static_cast<uint32_t>(__builtin_clzll(ok));
-                            const uint64_t below = f_below(at);
+                            const uint64_t below = (1ull << at) - 1ull;
                             emit(f0 + static_cast<uint32_t>(__popcll(m.F & below)), h0 + static_cast<uint32_t>(__popcll(m.H & below)));
                         }
                     } else {  // (mates interleave: the window's targets are not in lane order -- it stands alone)

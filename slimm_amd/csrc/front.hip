@@ -341,6 +341,20 @@ struct Staged {
 #define SLIMM_HASH_WALK 32
 #endif
 constexpr uint32_t kHashWalk = SLIMM_HASH_WALK;
+// D = N0 & (N0 << 1) marks the second and later lanes of every stretch of set bits of N0 (non-start lanes: a segment of
+// L records is a stretch of L - 1).  Is there a stretch of D of at least n bits (a segment of more than n + 1 records)?
+__device__ __forceinline__ bool has_run_of(uint64_t D, uint32_t n) {
+    // stretches of >= 2^k bits by doubling, then the remainder
+    uint64_t x = D;
+    uint32_t have = 1;
+    while (have * 2u <= n) {
+        x &= x << have;
+        have *= 2u;
+    }
+    if (have < n) x &= x << (n - have);
+    return x != 0ull;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  field = the staged reference field,
 // SS = segment starts (run starts and mate changes), V = mapped lanes, both inside [0, X).
@@ -363,12 +377,7 @@ __device__ __forceinline__ WinMasks window_fast(uint32_t field, uint32_t gbin, u
     const uint64_t N0 = ~SS & f_below_nz(X);  // (a window holds a record)
     uint64_t D = N0 & (N0 << 1);
     uint64_t F;
-    // (is there a segment of more than kHashWalk records?  Asked of the LANES -- every lane's distance from its
-    // segment's start, eight vector instructions and a ballot -- because the scalar unit is this kernel's bottleneck:
-    // the same test on the masks, stretches of D by doubling, was eleven scalar instructions per window)
-    const uint64_t le = (2ull << lane) - 1ull;  // the lanes up to and including this one
-    const uint32_t seg_start = 63u - static_cast<uint32_t>(__builtin_clzll(SS & le));  // (bit 0 of SS is set)
-    if (f_ballot(lane - seg_start >= kHashWalk) != 0ull) {
+    if (has_run_of(D, kHashWalk - 1u)) {
         hash_clear(tab, lane);
         bool overflow = false;  // (never: 64 keys at most)
         F = f_ballot(hash_first(tab, T, lane, f_bit(V), overflow));

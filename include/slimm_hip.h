@@ -372,6 +372,9 @@ int slimm_group_uses_rccl(const slimm_group* g);
 int slimm_group_reset(slimm_group* g);
 int slimm_group_push_records(slimm_group* g, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,
                              const uint16_t* flag, uint64_t n);
+/* Packed 16-byte records (slimm_push_records_packed; the identity of a read name is the key's low 61 bits). */
+int slimm_group_push_records_packed(slimm_group* g, const uint64_t* packed_key, const int32_t* ref_id, const int32_t* begin_pos,
+                                    uint64_t n);
 /* With a check word per record (slimm_push_records_checked): two names that collide in the key land on the same member
  * whichever way the records are dealt, so a group reports SLIMM_E_KEY_COLLISION exactly where one context would. */
 int slimm_group_push_records_checked(slimm_group* g, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("slimm_group_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_group_get_profiles", C.c_int, [_P, C.c_char_p]),
     ("slimm_group_push_records_checked", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64]),
+    ("slimm_group_push_records_packed", C.c_int, [_P, _P, _P, _P, C.c_uint64]),
     ("slimm_group_set_exchange", C.c_int, [_P, C.c_int]),
     ("slimm_group_exchange", C.c_int, [_P]),
     ("slimm_uniq_cov2_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),

@@ -285,7 +285,9 @@ int all_reduce_sum(slimm_group* g, const std::vector<uint32_t*>& buf, size_t wor
 int push_to(slimm_group* g, uint32_t i, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
             const uint32_t* check, uint64_t n) {
     if (n == 0) return SLIMM_OK;
-    if (check)
+    if (!flag)  // packed records: the flag bits ride in the key (slimm_pack_key)
+        GTRY(g, i, slimm_push_records_packed(g->ctx[i], key, ref, pos, n));
+    else if (check)
         GTRY(g, i, slimm_push_records_checked(g->ctx[i], key, ref, pos, flag, check, n));
     else
         GTRY(g, i, slimm_push_records(g->ctx[i], key, ref, pos, flag, n));
@@ -294,7 +296,8 @@ int push_to(slimm_group* g, uint32_t i, const uint64_t* key, const int32_t* ref,
 
 int flush_carry(slimm_group* g, uint32_t to) {
     if (g->carry_key.empty()) return SLIMM_OK;
-    int rc = push_to(g, to, g->carry_key.data(), g->carry_ref.data(), g->carry_pos.data(), g->carry_flag.data(),
+    int rc = push_to(g, to, g->carry_key.data(), g->carry_ref.data(), g->carry_pos.data(),
+                     g->carry_flag.empty() ? nullptr : g->carry_flag.data(),
                      g->carry_check.empty() ? nullptr : g->carry_check.data(), g->carry_key.size());
     g->carry_key.clear();
     g->carry_ref.clear();
@@ -312,10 +315,12 @@ int deal(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t*
          uint64_t n) {
     if (!g) return SLIMM_E_INVALID;
     if (n == 0) return SLIMM_OK;
-    if (!key || !ref || !pos || !flag) return gfail(g, SLIMM_E_INVALID, "null record array");
-    if (g->checked >= 0 && g->checked != (check ? 1 : 0))
-        return gfail(g, SLIMM_E_INVALID, "checked and unchecked pushes do not mix within a file");
-    g->checked = check ? 1 : 0;
+    if (!key || !ref || !pos) return gfail(g, SLIMM_E_INVALID, "null record array");
+    const int form = !flag ? 2 : (check ? 1 : 0);  // packed (no flag array: the bits ride in the key) / checked / plain
+    if (g->checked >= 0 && g->checked != form)
+        return gfail(g, SLIMM_E_INVALID, "packed, checked and plain pushes do not mix within a file");
+    g->checked = form;
+    const uint64_t kMask = flag ? kKeyMask : (1ull << 61) - 1ull;  // the identity bits of a key
     const uint32_t m = static_cast<uint32_t>(g->ctx.size());
     if (m == 1) return push_to(g, 0, key, ref, pos, flag, check, n);
     if (g->order != SLIMM_ORDER_GROUPED) {
@@ -324,15 +329,16 @@ int deal(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t*
         std::vector<std::vector<uint16_t>> f(m);
         std::vector<std::vector<uint32_t>> c(m);
         for (uint64_t i = 0; i < n; ++i) {
-            const uint32_t o = static_cast<uint32_t>((key[i] & kKeyMask) % m);
+            const uint32_t o = static_cast<uint32_t>((key[i] & kMask) % m);
             k[o].push_back(key[i]);
             r[o].push_back(ref[i]);
             p[o].push_back(pos[i]);
-            f[o].push_back(flag[i]);
+            if (flag) f[o].push_back(flag[i]);
             if (check) c[o].push_back(check[i]);
         }
         for (uint32_t o = 0; o < m; ++o) {
-            int rc = push_to(g, o, k[o].data(), r[o].data(), p[o].data(), f[o].data(), check ? c[o].data() : nullptr, k[o].size());
+            int rc = push_to(g, o, k[o].data(), r[o].data(), p[o].data(), flag ? f[o].data() : nullptr,
+                             check ? c[o].data() : nullptr, k[o].size());
             if (rc != SLIMM_OK) return rc;
         }
         return SLIMM_OK;
@@ -342,11 +348,11 @@ int deal(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t*
     if (rc != SLIMM_OK) return rc;
     uint64_t last_start = n;  // index of the batch's last run start, n = none found
     for (uint64_t i = n; i-- > 1;)
-        if ((key[i] ^ key[i - 1]) & kKeyMask) {
+        if ((key[i] ^ key[i - 1]) & kMask) {
             last_start = i;
             break;
         }
-    if (last_start == n && !(g->have_last && ((key[0] ^ g->last_key) & kKeyMask) == 0)) last_start = 0;  // one run, a new one
+    if (last_start == n && !(g->have_last && ((key[0] ^ g->last_key) & kMask) == 0)) last_start = 0;  // one run, a new one
     g->have_last = true;
     g->last_key = key[n - 1];
     if (last_start == n || last_start == 0) {
@@ -358,7 +364,7 @@ int deal(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t*
     g->carry_key.assign(key + last_start, key + n);
     g->carry_ref.assign(ref + last_start, ref + n);
     g->carry_pos.assign(pos + last_start, pos + n);
-    g->carry_flag.assign(flag + last_start, flag + n);
+    if (flag) g->carry_flag.assign(flag + last_start, flag + n);
     if (check) g->carry_check.assign(check + last_start, check + n);
     g->cur = (g->cur + 1) % m;
     return SLIMM_OK;
@@ -475,12 +481,16 @@ int slimm_group_reset(slimm_group* g) {
 
 int slimm_group_push_records(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
                              uint64_t n) {
+    if (g && n && !flag) return gfail(g, SLIMM_E_INVALID, "null record array");
     return deal(g, key, ref, pos, flag, nullptr, n);
 }
 int slimm_group_push_records_checked(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t* pos,
                                      const uint16_t* flag, const uint32_t* check, uint64_t n) {
-    if (g && n && !check) return gfail(g, SLIMM_E_INVALID, "null check array");
+    if (g && n && (!check || !flag)) return gfail(g, SLIMM_E_INVALID, "null record array");
     return deal(g, key, ref, pos, flag, check, n);
+}
+int slimm_group_push_records_packed(slimm_group* g, const uint64_t* packed_key, const int32_t* ref, const int32_t* pos, uint64_t n) {
+    return deal(g, packed_key, ref, pos, nullptr, nullptr, n);
 }
 int slimm_group_set_exchange(slimm_group* g, int mode) {
     if (!g || mode < SLIMM_EXCHANGE_AUTO || mode > SLIMM_EXCHANGE_BINS) return SLIMM_E_INVALID;

@@ -116,6 +116,8 @@ SLIMM_FORWARD(int, slimm_group_set_exchange, (slimm_group* a, int b), (a, b))
 SLIMM_FORWARD(int, slimm_group_push_records_checked,
               (slimm_group* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, const uint32_t* f_, uint64_t g),
               (a, b, c, d, e, f_, g))
+SLIMM_FORWARD(int, slimm_group_push_records_packed,
+              (slimm_group * g, const uint64_t* k, const int32_t* r, const int32_t* p, uint64_t n), (g, k, r, p, n))
 SLIMM_FORWARD(int, slimm_group_push_records,
               (slimm_group* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, uint64_t f_), (a, b, c, d, e, f_))
 SLIMM_FORWARD(int, slimm_group_get_profiles, (slimm_group* a, const char* b), (a, b))
@@ -426,9 +428,11 @@ struct RecordPump {
         pack(b.key.get(), b.flag.get(), b.n);
         return slimm_push_records_packed(c, b.key.get(), b.ref.get(), b.pos.get(), b.n);
     }
-    static int group_push(slimm_group* g, const Batch& b) {
-        return b.check ? slimm_group_push_records_checked(g, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n)
-                       : slimm_group_push_records(g, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.n);
+    static int group_push(slimm_group* g, Batch& b) {
+        if (b.check)
+            return slimm_group_push_records_checked(g, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n);
+        pack(b.key.get(), b.flag.get(), b.n);
+        return slimm_group_push_records_packed(g, b.key.get(), b.ref.get(), b.pos.get(), b.n);
     }
     static double ms(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();

@@ -513,6 +513,15 @@ class SlimmGroup:
             self._check(self.L.slimm_group_push_records_checked(self.g, _p(rec.read_key[s:e]), _p(rec.ref_id[s:e]),
                                                                 _p(rec.begin_pos[s:e]), _p(rec.flag[s:e]), _p(check[s:e]), e - s))
 
+    def push_records_packed(self, rec: Records, batch: int = 0):
+        pk = Slimm.pack_keys(rec.read_key, rec.flag)
+        n = len(rec)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_group_push_records_packed(self.g, _p(pk[s:e]), _p(rec.ref_id[s:e]), _p(rec.begin_pos[s:e]),
+                                                               e - s))
+
     EXCHANGES = {"auto": 0, "summary": 1, "sliced": 2, "bins": 3}
 
     def set_exchange(self, mode: str):

@@ -196,3 +196,24 @@ def test_group_checked_push_reports_two_names_under_one_key():
     with pytest.raises(capi.SlimmError):
         g.push_records(r)                                     # checked and unchecked pushes do not mix
     g.close()
+
+
+@pytest.mark.parametrize("members,grouped", [(2, None), (3, False)])
+def test_group_packed_push_deals_by_the_61_bit_identity(members, grouped):
+    """slimm_group_push_records_packed: the flag bits ride in the key, so the dealing -- whole qName runs, or key mod
+    members -- must look at the low 61 bits only; mates of one pair (bit 61 differs) land on one member."""
+    from slimm_amd import capi
+    w = make_workload(CONFIGS["config1"], seed=61, shuffled=(grouped is False))
+    w.records.read_key &= np.uint64((1 << 61) - 1)            # what a producer of packed records hashes names to
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0] * members, grouped=grouped)
+    g.push_records_packed(w.records, batch=3100)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    with pytest.raises(capi.SlimmError):
+        g.push_records(w.records)                             # forms do not mix within a file
+    g.reset()
+    g.push_records(w.records, batch=3100)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()

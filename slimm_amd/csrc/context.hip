@@ -148,6 +148,8 @@ struct slimm_ctx {
     DevBuf<uint4> tile_items, part_items;
     DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
     DevBuf<uint32_t> sel;                               // per read (slot.x + k): its uniq_cov2 bin, Bp + LCA taxon, or 0xffffffff
+    uint32_t tile_shift = kTileShiftSmall;              // log2 of the bins per tile: which build of tile_hist.hip runs (kernels.h)
+    uint32_t tile_bins() const { return 1u << tile_shift; }
     uint32_t ntiles = 0;
     uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
     bool fused_scan = false;                            // k_tile_scan runs inside the one-level bucketing kernel
@@ -169,7 +171,7 @@ struct slimm_ctx {
     uint32_t summary_layout = 0xffffffffu;  // n_slices the buffer was last zeroed for
     DevBuf<uint32_t> d_sum_vec;      // all-to-all form: [4R | 16] additive vector, all-reduced in place
     uint32_t slice_tiles() const { return summary_slices > 1 ? (ntiles + summary_slices - 1) / summary_slices : ntiles; }
-    uint64_t slice_words() const { return static_cast<uint64_t>(slice_tiles()) * (kTileBins / 32); }  // per array
+    uint64_t slice_words() const { return static_cast<uint64_t>(slice_tiles()) * (tile_bins() / 32); }  // per array
     uint64_t summary_words() const { return 4ull * R + 16 + 2ull * std::max<uint32_t>(summary_slices, 1u) * slice_words(); }
     BitsLayout bits_layout() {
         BitsLayout b;
@@ -315,9 +317,9 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->sel.ensure(n + 8));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
-        HIP_TRY(c, c->tile_items.ensure(tile_items_upper(c->ntiles2, n) + 1));
+        HIP_TRY(c, c->tile_items.ensure(TILES(c->tile_shift, tile_items_upper(c->ntiles2, n)) + 1));
         HIP_TRY(c, c->mid.ensure(n + 1));
-        HIP_TRY(c, c->part_items.ensure(part_items_upper(c->ntiles2, n) + 1));
+        HIP_TRY(c, c->part_items.ensure(TILES(c->tile_shift, part_items_upper(c->ntiles2, n)) + 1));
         HIP_TRY(c, c->sup_cursor.ensure(kMaxSuper));
     }
     if (c->order == SLIMM_ORDER_ANY) {
@@ -415,10 +417,24 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         if (off >= kMaxBins) return fail(nullptr, SLIMM_E_INVALID, "more than 2^31 coverage bins; use a larger bin width");
     }
     c->bin_off_h[c->R] = static_cast<uint32_t>(off);
-    c->Bp = (off + kTileBins - 1) & ~static_cast<uint64_t>(kTileBins - 1);
-    c->ntiles = static_cast<uint32_t>(c->Bp >> kTileShift);
-    c->Tpad = (c->T + kTileBins - 1) & ~(kTileBins - 1);
-    c->ntiles2 = c->ntiles + (c->Tpad >> kTileShift);
+    // Tile size by layout: the small tiles while the whole bucketing fits the fused kernel's tile tables (their histograms
+    // run at twice the occupancy), the large ones beyond -- where the scatter's direct rounds pay a returning atomic per
+    // run of one tile among neighbouring targets and half as many tiles make those runs longer (1 B records over 20 k
+    // references: scatter 3.03 -> 2.3 ms, histograms 0.41 -> 0.67 ms; kernels.h)
+    {
+        const uint64_t small = (off + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall;
+        const uint64_t small2 = small + ((static_cast<uint64_t>(c->T) + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall);
+        c->tile_shift = small2 > kFusedScanTiles ? kTileShiftLarge : kTileShiftSmall;
+        if (const char* ts = getenv("SLIMM_TILE_SHIFT")) {
+            if (atoi(ts) == static_cast<int>(kTileShiftSmall)) c->tile_shift = kTileShiftSmall;
+            if (atoi(ts) == static_cast<int>(kTileShiftLarge)) c->tile_shift = kTileShiftLarge;
+        }
+    }
+    const uint32_t tile_bins = c->tile_bins();
+    c->Bp = (off + tile_bins - 1) & ~static_cast<uint64_t>(tile_bins - 1);
+    c->ntiles = static_cast<uint32_t>(c->Bp >> c->tile_shift);
+    c->Tpad = (c->T + tile_bins - 1) & ~(tile_bins - 1);
+    c->ntiles2 = c->ntiles + (c->Tpad >> c->tile_shift);
     if (c->Bp + c->Tpad >= kMaxBins) return fail(nullptr, SLIMM_E_INVALID, "more than 2^31 coverage bins; use a larger bin width");
 
     if (c->device >= 0) {
@@ -482,7 +498,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
         }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
-        cc->use_tiles = !(force_direct && force_direct[0] == '1') && tile_hist_setup(c->ntiles2) == 0;
+        cc->use_tiles = !(force_direct && force_direct[0] == '1') && TILES(c->tile_shift, tile_hist_setup(c->ntiles2)) == 0;
         {
             // default by size: with the register-resident scatter chunks one level wins up to ~10 K tiles (config 3:
             // 494 vs 601 us) and is level with two at 24 K (config 5: 430 vs 396 us)
@@ -506,7 +522,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 const char* mx = getenv("SLIMM_MATRIX");
                 cc->matrix = !cc->fused_scan && !(mx && mx[0] == '0');
                 if (cc->matrix &&
-                    cc->tile_matrix.ensure(static_cast<size_t>(tile_count_grid(512)) * cc->tstride) != hipSuccess)
+                    cc->tile_matrix.ensure(static_cast<size_t>(TILES(c->tile_shift, tile_count_grid(512))) * cc->tstride) != hipSuccess)
                     return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");
                 if (mx && mx[0] == '2') cc->matrix_always = true;  // (tests: small layouts, whatever the number of reads)
                 if (const char* wt = getenv("SLIMM_WIDE_TILES")) cc->wide_tiles = wt[0] == '1' ? 1 : 0;
@@ -518,7 +534,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
             std::vector<uint32_t> ref0(c->ntiles2 + 1, c->R);
             uint32_t r = 0;
             for (uint32_t t = 0; t < c->ntiles2; ++t) {
-                const uint64_t t0 = static_cast<uint64_t>(t) * kTileBins;
+                const uint64_t t0 = static_cast<uint64_t>(t) * tile_bins;
                 if (t0 >= c->bin_off_h[c->R]) break;
                 while (r + 1 < c->R && c->bin_off_h[r + 1] <= t0) ++r;
                 ref0[t] = r;
@@ -1005,29 +1021,29 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         const uint32_t grid = 512;  // two persistent workgroups per CU
         {
             KernelTimer t(c, K_TILE_COUNT);
-            launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride);
+            TILES(c->tile_shift, launch_tile_count(st, grid, c->ntiles, targets, c->tot_part.p, c->tile_count.p, c->treps, c->tstride));
         }
         Totals tot;
         tot.part = c->tot_part.p;
-        tot.nparts = tile_count_grid(grid);
+        tot.nparts = TILES(c->tile_shift, tile_count_grid(grid));
         tot.tail = c->tail();
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER);
-            launch_tile_scatter_fused(st, grid, c->ntiles, targets, c->counters.p, c->tile_count.p, c->tile_cursor.p,
+            TILES(c->tile_shift, launch_tile_scatter_fused(st, grid, c->ntiles, targets, c->counters.p, c->tile_count.p, c->tile_cursor.p,
                                       c->bucket.p, c->cov(), c->ucov(), c->tstride, c->tile_items.p, c->split_tiles.p, tot,
-                                      tile_sub);
+                                      tile_sub));
         } else {
             {
                 KernelTimer t(c, K_TILE_SCAN);
-                launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                TILES(c->tile_shift, launch_tile_scan(st, c->ntiles, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
                                  c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, c->treps, c->tstride,
-                                 c->two_level, tot, tile_sub);
+                                 c->two_level, tot, tile_sub));
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER);
-                launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
+                TILES(c->tile_shift, launch_tile_scatter(st, grid, c->ntiles, n, targets, c->counters.p, c->tile_base.p, c->tile_cursor.p,
                                     c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p, c->cov(), c->ucov(),
-                                    c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub);
+                                    c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub));
             }
         }
         {
@@ -1041,9 +1057,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                 c->summary_layout = c->summary_slices;
                 c->summary_has_bits = true;
             }
-            launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
+            TILES(c->tile_shift, launch_tile_hist(st, c->ntiles, n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p, c->cov(),
                              c->ucov(), c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout(),
-                             c->keep_bins ? 0u : c->ntiles, wide);
+                             c->keep_bins ? 0u : c->ntiles, wide));
             c->binsA_stored = c->keep_bins;
         }
     } else {
@@ -1134,8 +1150,8 @@ int slimm_finish_coverage(slimm_ctx* c) {
     pk.n[1] = 16;
     if (c->use_tiles && !c->bins_exposed) {  // k_tile_hist left the per-reference statistics in place
         KernelTimer t(c, K_PACK);
-        launch_pack(c->stream, c->ref_stats.p + 4ull * c->R, pk, c->split_tiles.p, c->counters.p, c->cov(), c->ucov(),
-                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p, c->bits_layout());
+        TILES(c->tile_shift, launch_pack(c->stream, c->ref_stats.p + 4ull * c->R, pk, c->split_tiles.p, c->counters.p, c->cov(), c->ucov(),
+                    c->d_bin_off.p, c->R, c->d_tile_ref0.p, c->statsA_final ? nullptr : c->ref_stats.p, c->bits_layout()));
         c->statsA_final = true;
     } else {
         KernelTimer t(c, K_REF_STATS);
@@ -1177,11 +1193,11 @@ int slimm_coverage_summary(slimm_ctx* c, void** d_ptr, uint64_t* n_words) {
         pk.src[1] = c->tail();
         pk.n[1] = 16;
         if (!c->statsA_final) {  // first finish the statistics (and bitmaps) of the split tiles in place, then copy
-            launch_pack(st, c->summary.p, PackArgs(), c->split_tiles.p, c->counters.p, c->cov(), c->ucov(), c->d_bin_off.p,
-                        c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout());
+            TILES(c->tile_shift, launch_pack(st, c->summary.p, PackArgs(), c->split_tiles.p, c->counters.p, c->cov(), c->ucov(), c->d_bin_off.p,
+                        c->R, c->d_tile_ref0.p, c->ref_stats.p, c->bits_layout()));
             c->statsA_final = true;
         }
-        launch_pack(st, c->summary.p, pk);
+        TILES(c->tile_shift, launch_pack(st, c->summary.p, pk));
         have_bits = c->summary_has_bits;
     } else {
         KernelTimer t(c, K_REF_STATS);
@@ -1215,8 +1231,8 @@ int slimm_merge_summary_slices(slimm_ctx* c, const void* d_recv, uint32_t n_rank
     HIP_TRY(c, c->d_sum_vec.ensure(W));
     const uint64_t lo_tile = static_cast<uint64_t>(my_rank) * c->slice_tiles();
     const uint64_t hi_tile = std::min<uint64_t>(lo_tile + c->slice_tiles(), c->ntiles);
-    const uint32_t lo_bin = static_cast<uint32_t>(std::min<uint64_t>(lo_tile, c->ntiles) * kTileBins);
-    const uint32_t hi_bin = static_cast<uint32_t>(std::max<uint64_t>(hi_tile, std::min<uint64_t>(lo_tile, c->ntiles)) * kTileBins);
+    const uint32_t lo_bin = static_cast<uint32_t>(std::min<uint64_t>(lo_tile, c->ntiles) * c->tile_bins());
+    const uint32_t hi_bin = static_cast<uint32_t>(std::max<uint64_t>(hi_tile, std::min<uint64_t>(lo_tile, c->ntiles)) * c->tile_bins());
     // own sums and scalars come from the summary buffer (slimm_coverage_summary filled it)
     launch_merge_slices(c->stream, static_cast<const uint32_t*>(d_recv), n_ranks, c->slice_words(), lo_bin, hi_bin,
                         c->d_bin_off.p, c->R, c->summary.p, c->summary.p + 4ull * c->R, c->d_sum_vec.p);
@@ -1238,7 +1254,7 @@ int slimm_finish_coverage_reduced(slimm_ctx* c) {
     pk.n[1] = 32;
     pk.src[2] = c->d_sum_vec.p + 4ull * c->R;
     pk.n[2] = 16;
-    launch_pack(c->stream, c->ref_stats.p, pk);
+    TILES(c->tile_shift, launch_pack(c->stream, c->ref_stats.p, pk));
     return finish_from_device_stats(c);
 }
 
@@ -1389,39 +1405,39 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         const uint32_t tile_sub = c->wide_for(c->rec.n) ? kTileSubWide : kTileSub;  // (one array: its counts are 32-bit already)
         {
             KernelTimer t(c, K_TILE_COUNT2);
-            launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps, c->tstride,
-                              matrix ? c->tile_matrix.p : nullptr);
-            if (matrix) launch_matrix_prefix(st, grid, c->ntiles2, c->tile_matrix.p, c->tstride, c->tile_count.p);
+            TILES(c->tile_shift, launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps, c->tstride,
+                              matrix ? c->tile_matrix.p : nullptr));
+            if (matrix) TILES(c->tile_shift, launch_matrix_prefix(st, grid, c->ntiles2, c->tile_matrix.p, c->tstride, c->tile_count.p));
         }
         if (c->fused_scan) {
             KernelTimer t(c, K_TILE_SCATTER2);
-            launch_tile_scatter_fused(st, grid, c->ntiles2, selectors, c->counters.p, c->tile_count.p, c->tile_cursor.p,
+            TILES(c->tile_shift, launch_tile_scatter_fused(st, grid, c->ntiles2, selectors, c->counters.p, c->tile_count.p, c->tile_cursor.p,
                                       c->bucket.p, c->ucov2(), nullptr, c->tstride, c->tile_items.p, c->split_tiles.p, Totals(),
-                                      tile_sub);
+                                      tile_sub));
         } else {
             {
                 KernelTimer t(c, K_TILE_SCAN2);
-                launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
+                TILES(c->tile_shift, launch_tile_scan(st, c->ntiles2, c->tile_count.p, c->tile_base.p, c->tile_cursor.p, c->tile_items.p,
                                  c->counters.p, c->part_items.p, c->sup_cursor.p, c->split_tiles.p, matrix ? 1u : c->treps,
-                                 c->tstride, matrix ? false : c->two_level, Totals(), tile_sub);
+                                 c->tstride, matrix ? false : c->two_level, Totals(), tile_sub));
             }
             {
                 KernelTimer t(c, K_TILE_SCATTER2);
                 if (matrix)
-                    launch_tile_scatter_matrix(st, grid, c->ntiles2, selectors, c->tile_base.p, c->tile_matrix.p, c->tstride,
-                                               c->bucket.p, c->ucov2(), nullptr, tile_sub);
+                    TILES(c->tile_shift, launch_tile_scatter_matrix(st, grid, c->ntiles2, selectors, c->tile_base.p, c->tile_matrix.p, c->tstride,
+                                               c->bucket.p, c->ucov2(), nullptr, tile_sub));
                 else
-                    launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
+                    TILES(c->tile_shift, launch_tile_scatter(st, grid, c->ntiles2, c->rec.n, selectors, c->counters.p, c->tile_base.p,
                                         c->tile_cursor.p, c->sup_cursor.p, c->part_items.p, c->mid.p, c->bucket.p,
-                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub);
+                                        c->ucov2(), nullptr, c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub));
             }
         }
         {
             KernelTimer t(c, K_TILE_HIST2);
-            launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
+            TILES(c->tile_shift, launch_tile_hist(st, c->ntiles2, c->rec.n, c->bucket.p, c->tile_base.p, c->tile_items.p, c->counters.p,
                              c->ucov2(), nullptr, c->d_bin_off.p, R, c->d_tile_ref0.p, blockB, BitsLayout(),
                              // (the tiles behind the bins hold the per-taxon LCA counts k_pack reads back)
-                             c->keep_bins ? 0u : static_cast<uint32_t>(c->Bp / kTileBins));
+                             c->keep_bins ? 0u : static_cast<uint32_t>(c->Bp / c->tile_bins())));
         }
     }
     {
@@ -1435,8 +1451,8 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         pk.n[2] = T;
         if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place
             KernelTimer t(c, K_PACK2);
-            launch_pack(st, blockB + 4ull * R, pk, c->split_tiles.p, c->counters.p, c->ucov2(), nullptr,
-                        c->d_bin_off.p, R, c->d_tile_ref0.p, blockB);
+            TILES(c->tile_shift, launch_pack(st, blockB + 4ull * R, pk, c->split_tiles.p, c->counters.p, c->ucov2(), nullptr,
+                        c->d_bin_off.p, R, c->d_tile_ref0.p, blockB));
         } else {
             KernelTimer t(c, K_REF_STATS2);
             launch_ref_stats(st, c->ucov2(), nullptr, c->d_bin_off.p, R, blockB, &pk);

@@ -174,13 +174,16 @@ void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t ran
                           uint32_t* out_stats, const uint32_t* counters);
 
 // ---- LDS-privatised coverage histograms (tile_hist.hip) ----
-constexpr uint32_t kTileShift = 13;
-constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile: 2 x 16 KiB of LDS in k_tile_hist (16-bit counts)
+// The bins are cut into TILES of 2^shift consecutive bins; tile_hist.hip is compiled once per tile size into its own
+// namespace (tiles13: 8192 bins, tiles14: 16384 bins -- what the 16-bit bucket entries hold beside the unique bit), and a
+// context picks one per layout (context.hip: tile_shift_for).  Smaller tiles: more workgroups of k_tile_hist per CU,
+// faster histograms; larger tiles: half as many bucket frontiers, longer runs of one tile among neighbouring targets
+// and so fewer returning atomics in the direct rounds of the scatter.
+constexpr uint32_t kTileShiftSmall = 13, kTileShiftLarge = 14;
 constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item (packed 16-bit counts)
 constexpr uint32_t kTileSubWide = 262144;               // ... of the wide form (32-bit counts): layouts with far more than
                                                         // kTileSub entries per tile (tile_sub / wide arguments below)
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter
-int tile_hist_setup(uint32_t ntiles);                   // 0 = usable for this many tiles
 // tile_count: `reps` copies of rep_stride words, zero on entry (k_zero); workgroup b adds to copy b % reps.
 // k_tile_scan sums the copies into tile_base and turns every copy into the start of its stretch inside the buckets,
 // which k_tile_scatter (same grid) then fills through the copy's own cursors: 1/reps of the same-address atomics.
@@ -208,64 +211,26 @@ struct Totals {
 // `grid` = the bucketing grid; the count runs tile_count_grid(grid) workgroups, kCountFold times as large, each for
 // kCountFold neighbours of the bucketing grid (and writes as many entries of part[])
 constexpr uint32_t kCountFold = 2;
-uint32_t tile_count_grid(uint32_t grid);
-void launch_tile_count(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint4* part,
-                       uint32_t* tile_count, uint32_t reps, uint32_t rep_stride, uint32_t* matrix = nullptr);
-// Matrix bucketing (more than kFusedScanTiles tiles, as many as an LDS cursor array holds): launch_tile_count with
-// matrix != nullptr stores one ROW of counts per counting workgroup (tile_count_grid(grid) rows of row_stride words),
-// launch_matrix_prefix makes every column its exclusive prefix over the rows and leaves the column sums in total[]
-// (which launch_tile_scan then scans with reps = 1), and launch_tile_scatter_matrix -- same grid as the count -- places
-// every value at tile_base[tile] + its row's prefix + a running LDS count: no global atomics, no rounds.
-void launch_matrix_prefix(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t* matrix, uint32_t row_stride, uint32_t* total);
-void launch_tile_scatter_matrix(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, const uint32_t* tile_base,
-                                const uint32_t* matrix, uint32_t row_stride, uint16_t* bucket, uint32_t* cov, uint32_t* ucov,
-                                uint32_t tile_sub = kTileSub);
 constexpr uint32_t kSuperTiles = 64;                    // tiles per super tile (level 1 of the bucketing)
-constexpr uint32_t kSuperShift = kTileShift + 6;        // 512 K bins per super tile
-constexpr uint32_t kSuperMask = (1u << kSuperShift) - 1;
-constexpr uint32_t kMaxSuper = 8192;                    // super tiles an LDS cursor array holds (4 G bins)
+constexpr uint32_t kMaxSuper = 8192;                    // super tiles an LDS cursor array holds
 constexpr uint32_t kPartSub = 32768;                    // entries per k_part_tile work item
-uint32_t part_items_upper(uint32_t ntiles, uint32_t n_upper);
-uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper);
-void launch_tile_scan(hipStream_t st, uint32_t ntiles, uint32_t* tile_count, uint32_t* tile_base,
-                      uint32_t* tile_cursor, uint4* items, uint32_t* counters, uint4* items2, uint32_t* sup_cursor,
-                      uint32_t* split_tiles, uint32_t reps, uint32_t rep_stride, bool two_level,
-                      const Totals& tot = Totals(), uint32_t tile_sub = kTileSub);
-// bucketing by tile: one level (k_tile_scatter) or two (k_part_super + k_part_tile); also zeroes the tiles (of cov, and of ucov when given) that
-// k_tile_hist will accumulate with atomics
-void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_t n_upper, const SlotValues& in,
-                         const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
-                         const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
-                         const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride, uint32_t tile_sub = kTileSub);
 // where k_tile_hist / k_pack put the 'bin != 0' bitmaps of the multi-GPU coverage summary: the tiles are cut into slices
 // of `tps` tiles (one slice per rank for the all-to-all exchange, a single slice otherwise) and slice j holds
 // [array 0 bits | array 1 bits] of its tiles back to back
 struct BitsLayout {
     uint64_t* base = nullptr;   // nullptr: no bitmaps
     uint32_t tps = 1;           // tiles per slice
-    uint64_t slice_w64 = 0;     // 64-bit words of one array in one slice = tps * 128
+    uint64_t slice_w64 = 0;     // 64-bit words of one array in one slice = tps * (bins per tile / 64)
 };
-// stats != nullptr: k_tile_hist also accumulates the per-reference statistics {sum a, non-zero a, sum b, non-zero b}
-// (stats[ref * 4 ..], zeroed by the caller) of the finished arrays; tile_ref0[tile] = first reference overlapping the
-// tile (n_refs when none does).  For tiles cut into pieces only the sums are final; launch_pack adds their non-zero counts
-// one-level bucketing with k_tile_scan folded in (<= 4096 tiles, kTileReps copies of the counters): after
-// launch_tile_count, with tile_cursor zero; also writes k_tile_hist's work items, the split-tile list and their counts
 constexpr uint32_t kFusedScanTiles = 4064;  // (4096 table entries less the room three small arrays take: tile_hist.hip)
-void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, const SlotValues& in, uint32_t* counters,
-                               const uint32_t* tile_count, uint32_t* tile_cursor, uint16_t* bucket, uint32_t* cov,
-                               uint32_t* ucov, uint32_t rep_stride, uint4* items, uint32_t* split_tiles,
-                               const Totals& tot = Totals(), uint32_t tile_sub = kTileSub);
-void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
-                      const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,
-                      uint32_t n_refs, const uint32_t* tile_ref0, uint32_t* stats,
-                      const BitsLayout& bits = BitsLayout(), uint32_t store_from = 0, bool wide = false);  // bits: also the 'bin != 0' bitmaps of the
-                      // two arrays; finished tiles below store_from are not written out (their statistics are still taken)
-// small arrays copied back to back to dst; with stats != nullptr also the non-zero bin counts of the tiles k_tile_hist
-// accumulated in pieces (split_tiles[0 .. counters[CNT_SPLIT])), read back from the finished arrays a / b
-void launch_pack(hipStream_t st, uint32_t* dst, const PackArgs& pack, const uint32_t* split_tiles = nullptr,
-                 const uint32_t* counters = nullptr, const uint32_t* a = nullptr, const uint32_t* b = nullptr,
-                 const uint32_t* bin_off = nullptr, uint32_t n_refs = 0, const uint32_t* tile_ref0 = nullptr,
-                 uint32_t* stats = nullptr, const BitsLayout& bits = BitsLayout());
+namespace tiles13 {
+#include "tile_api.inc"
+}
+namespace tiles14 {
+#include "tile_api.inc"
+}
+// TILES(shift, launch_tile_count(st, ...)): the call in the namespace of the tile size
+#define TILES(shift, call) ((shift) == ::slimm::kTileShiftLarge ? ::slimm::tiles14::call : ::slimm::tiles13::call)
 
 // Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
 // in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and

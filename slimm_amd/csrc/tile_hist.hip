@@ -2,22 +2,23 @@
 //
 // Why: a device-scope atomic on a random 4-byte bin is a separate memory-side request; MI355X retires ~20 G of them per
 // second (measured: k_hist, 8.2 M + 1.1 M atomics = 408 us at config 2 -- 4 % of the HBM roofline).  The targets carry
-// no locality (reads land anywhere on any genome), so they are first bucketed by bin TILE (8192 consecutive bins), then
-// one workgroup per tile accumulates its bucket in LDS and writes the finished tile with coalesced 16-byte stores.
-// The tile write-back also replaces the zero-fill of cov / uniq_cov.
+// no locality (reads land anywhere on any genome), so they are first bucketed by bin TILE (8192 or 16384 consecutive bins:
+// this file is compiled once per tile size, see kernels.h), then one workgroup per tile accumulates its bucket in LDS
+// and writes the finished tile with coalesced 16-byte stores.  The tile write-back also replaces the zero-fill of cov /
+// uniq_cov.
 //
 //   k_tile_count    persistent grid; per-workgroup LDS histogram of tile ids over its slots of targets (front.hip), added
 //                   to one of 8 copies of tile_count[] with one non-returning global atomic per non-empty tile
 //   k_tile_scan     one workgroup: sums the copies, exclusive scan -> tile_base, turns every copy into the start of its
 //                   stretch inside the buckets, cuts buckets into work items of <= 16 K entries, lists the split tiles
 //   k_tile_scatter  same slots, one level: rounds of 8 K values held in registers; LDS count, one returning atomic per
-//                   tile and round on the copy's cursor, 16-bit entries (13-bit bin-in-tile | unique bit) out -- up to
+//                   tile and round on the copy's cursor, 16-bit entries (bin-in-tile | unique bit) out -- up to
 //                   4096 tiles (k_tile_scatter_fused) ordered by tile in LDS first, so that a tile's run leaves as
 //                   consecutive stores.  Also zeroes the tiles that k_tile_hist will accumulate with atomics.
-//   k_part_super    two levels, level 1: targets go to their SUPER tile (64 tiles = 512 K bins) as 32-bit words
-//                   (19-bit bin-in-super | unique bit): few destinations per workgroup, long runs
+//   k_part_super    two levels, level 1: targets go to their SUPER tile (64 tiles) as 32-bit words
+//                   (bin-in-super | unique bit): few destinations per workgroup, long runs
 //   k_part_tile     level 2: work items of <= 32 K entries of one super tile are split into its 64 tiles
-//   k_tile_hist     one workgroup per work item: LDS cov[8192] + uniq_cov[8192], bucket in, finished tile out, plus the
+//   k_tile_hist     one workgroup per work item: LDS cov[tile] + uniq_cov[tile], bucket in, finished tile out, plus the
 //                   per-reference {sum, non-zero} statistics of the tile and (multi-GPU) its 'bin != 0' bitmaps
 //   k_pack          small result arrays behind the statistics; non-zero counts / bitmaps of the split tiles
 //
@@ -30,7 +31,25 @@
 
 #include "kernels.h"
 
+// compiled once per tile size (Makefile: -DSLIMM_TILE_SHIFT=13 -> namespace tiles13, =14 -> tiles14; kernels.h)
+#ifndef SLIMM_TILE_SHIFT
+#error "tile_hist.hip is compiled with -DSLIMM_TILE_SHIFT=13 or 14"
+#endif
+#if SLIMM_TILE_SHIFT == 13
+#define SLIMM_TILE_NS tiles13
+#elif SLIMM_TILE_SHIFT == 14
+#define SLIMM_TILE_NS tiles14
+#else
+#error "a bucket entry holds 14 bits of bin and the unique bit"
+#endif
+
 namespace slimm {
+namespace SLIMM_TILE_NS {
+
+constexpr uint32_t kTileShift = SLIMM_TILE_SHIFT;
+constexpr uint32_t kTileBins = 1u << kTileShift;        // bins per tile
+constexpr uint32_t kSuperShift = kTileShift + 6;        // bins per super tile (kSuperTiles = 64 tiles)
+constexpr uint32_t kSuperMask = (1u << kSuperShift) - 1;
 
 #if defined(EXP) && EXP == 8
 __device__ unsigned long long g_prof_t[8 * 4096];  // [workgroup-wave][phase]
@@ -268,165 +287,143 @@ __global__ __launch_bounds__(1024) void k_tile_scan(uint32_t* __restrict__ tile_
     __shared__ uint32_t s_nsplit;
     __shared__ uint32_t s_tot[3];
     if (part) publish_totals(part, nparts, counters, tail, s_tot);
-    __shared__ uint32_t s_cnt[kScanStaged];  // (<= 16 K tiles) a tile's total over the copies, then its base
+    __shared__ uint32_t s_cnt[kScanStaged];  // a stretch of tiles: a tile's total over the copies, then its base
+    __shared__ uint2 s_wave[16];
     if (threadIdx.x == 0) s_nsplit = 0;
     const uint32_t tid = threadIdx.x;
-    const bool staged = ntiles <= kScanStaged;  // otherwise reps == 1 (two-level bucketing) and the counts are read in place
-    const bool kept = ntiles <= 4096;           // the copies of <= 4 tiles per thread stay in registers between the stages
-    uint32_t keep[4][kTileReps];  // (staged, reps == kTileReps) the copies of this thread's up to 4 tiles, for stage 3
-    if (staged && !kept) {
-        for (uint32_t i = tid; i < ntiles; i += 1024) {
-            uint32_t c = 0;
-            if (reps == kTileReps) {
-                uint32_t v[kTileReps];
+    const bool kept = ntiles <= 4096 && reps == kTileReps;  // the copies of <= 4 tiles per thread stay in registers
+    uint32_t keep[4][kTileReps];
+    uint2 carry = make_uint2(0u, 0u);  // entries and work items of the stretches before this one
+    // stretches of kScanStaged tiles (one for the one-level layouts; the two-level ones, reps == 1, have up to 64 K tiles:
+    // reading them in place, every thread its own consecutive tiles, was 85 us for the 45 K tiles of 200 k references)
+    for (uint32_t c0 = 0; c0 < ntiles; c0 += kScanStaged) {
+        const uint32_t n = min(kScanStaged, ntiles - c0);
+        uint32_t* tc = tile_count + c0;
+        uint32_t* tcur = tile_cursor + c0;
+        if (kept) {
 #pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+            for (int q = 0; q < 4; ++q) {  // coalesced, the copies' loads independent of each other
+                const uint32_t i = tid + q * 1024;
+                if (i >= n) break;
+                uint32_t c = 0;
 #pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) c += v[rep];
-            } else {
-                for (uint32_t rep = 0; rep < reps; ++rep) c += tile_count[static_cast<size_t>(rep) * rep_stride + i];
-            }
-            s_cnt[i] = c;
-        }
-    } else if (staged) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {  // coalesced, the copies' loads independent of each other
-            const uint32_t i = tid + q * 1024;
-            if (i >= ntiles) break;
-            uint32_t c = 0;
-            if (reps == kTileReps) {
-#pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) keep[q][rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
+                for (uint32_t rep = 0; rep < kTileReps; ++rep) keep[q][rep] = tc[static_cast<size_t>(rep) * rep_stride + i];
 #pragma unroll
                 for (uint32_t rep = 0; rep < kTileReps; ++rep) c += keep[q][rep];
-            } else {
-                for (uint32_t rep = 0; rep < reps; ++rep) c += tile_count[static_cast<size_t>(rep) * rep_stride + i];
+                s_cnt[i] = c;
             }
-            s_cnt[i] = c;
+        } else {
+            for (uint32_t i = tid; i < n; i += 1024) {
+                uint32_t c = 0;
+                if (reps == kTileReps) {
+                    uint32_t v[kTileReps];
+#pragma unroll
+                    for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tc[static_cast<size_t>(rep) * rep_stride + i];
+#pragma unroll
+                    for (uint32_t rep = 0; rep < kTileReps; ++rep) c += v[rep];
+                } else {
+                    for (uint32_t rep = 0; rep < reps; ++rep) c += tc[static_cast<size_t>(rep) * rep_stride + i];
+                }
+                s_cnt[i] = c;
+            }
         }
-    }
-    __syncthreads();
-    const uint32_t per = (ntiles + 1023) / 1024;
-    const uint32_t lo = min(tid * per, ntiles), hi = min(lo + per, ntiles);
-    uint2 sum = make_uint2(0u, 0u);
-    // (the two sources as compile-time cases: `staged ? s_cnt[i] : tile_count[i]` selects between an LDS and a global
-    // pointer and compiles to flat loads, serial ones in these per-thread loops)
-    auto sum_counts = [&](auto from_lds) {
+        __syncthreads();
+        const uint32_t per = (n + 1023) / 1024;
+        const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
+        uint2 sum = make_uint2(0u, 0u);
         for (uint32_t i = lo; i < hi; ++i) {
-            const uint32_t c = decltype(from_lds)::value ? s_cnt[i] : tile_count[i];
+            const uint32_t c = s_cnt[i];
             sum.x += c;
             sum.y += c ? (c + tile_sub - 1) / tile_sub : 1u;
         }
-    };
-    if (staged)
-        sum_counts(std::true_type{});
-    else
-        sum_counts(std::false_type{});
-    {   // inclusive scan of the threads' sums: inside the waves by shuffles, the 16 wave totals through LDS (one barrier
-        // instead of the twenty of a scan by doubling over the whole workgroup)
-        const uint32_t lane = tid & 63u, wave = tid >> 6;
-        uint2 inc = sum;
+        {   // inclusive scan of the threads' sums: inside the waves by shuffles, the 16 wave totals through LDS (one barrier
+            // instead of the twenty of a scan by doubling over the whole workgroup)
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
+            uint2 inc = sum;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
-            if (lane >= static_cast<uint32_t>(o)) {
-                inc.x += ax;
-                inc.y += ay;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
+                if (lane >= static_cast<uint32_t>(o)) {
+                    inc.x += ax;
+                    inc.y += ay;
+                }
             }
-        }
-        __shared__ uint2 s_wave[16];
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint2 before = make_uint2(0u, 0u);
+            if (lane == 63) s_wave[wave] = inc;
+            __syncthreads();
+            uint2 before = carry;
 #pragma unroll
-        for (uint32_t w = 0; w < 16; ++w) {
-            const uint2 t = s_wave[w];
-            if (w < wave) {
-                before.x += t.x;
-                before.y += t.y;
+            for (uint32_t w = 0; w < 16; ++w) {
+                const uint2 t = s_wave[w];
+                if (w < wave) {
+                    before.x += t.x;
+                    before.y += t.y;
+                }
             }
+            s_part[tid] = make_uint2(before.x + inc.x, before.y + inc.y);
         }
-        s_part[tid] = make_uint2(before.x + inc.x, before.y + inc.y);
-    }
-    uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
-    auto emit_items = [&](auto from_lds) {
-    for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t c = decltype(from_lds)::value ? s_cnt[i] : tile_count[i];
-        const uint32_t pieces = c ? (c + tile_sub - 1) / tile_sub : 1u;
-        tile_base[i] = run.x;
-        if (decltype(from_lds)::value) {
+        uint2 run = make_uint2(s_part[tid].x - sum.x, s_part[tid].y - sum.y);
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t c = s_cnt[i];
+            const uint32_t pieces = c ? (c + tile_sub - 1) / tile_sub : 1u;
             s_cnt[i] = run.x;
-        } else {
-            tile_count[i] = run.x;
-            tile_cursor[i] = 0;
-        }
-        if (pieces > 1) split_tiles[atomicAdd(&s_nsplit, 1u)] = i;
-        for (uint32_t k = 0; k < pieces; ++k) {
-            uint32_t a = run.x + k * tile_sub;
-            uint32_t b = min(a + tile_sub, run.x + c);
-            items[run.y + k] = make_uint4(i, a, b, pieces);
-        }
-        run.x += c;
-        run.y += pieces;
-    }
-    };
-    if (staged)
-        emit_items(std::true_type{});
-    else
-        emit_items(std::false_type{});
-    __syncthreads();
-    if (staged && !kept) {
-        for (uint32_t i = tid; i < ntiles; i += 1024) {
-            uint32_t at = s_cnt[i];
-            if (reps == kTileReps) {
-                uint32_t v[kTileReps];
-#pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tile_count[static_cast<size_t>(rep) * rep_stride + i];
-#pragma unroll
-                for (uint32_t rep = 0; rep < kTileReps; ++rep) {
-                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
-                    tile_count[k] = at;
-                    tile_cursor[k] = 0;
-                    at += v[rep];
-                }
-            } else {
-                for (uint32_t rep = 0; rep < reps; ++rep) {
-                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
-                    const uint32_t cr = tile_count[k];
-                    tile_count[k] = at;
-                    tile_cursor[k] = 0;
-                    at += cr;
-                }
+            if (pieces > 1) split_tiles[atomicAdd(&s_nsplit, 1u)] = c0 + i;
+            for (uint32_t k = 0; k < pieces; ++k) {
+                uint32_t a = run.x + k * tile_sub;
+                uint32_t b = min(a + tile_sub, run.x + c);
+                items[run.y + k] = make_uint4(c0 + i, a, b, pieces);
             }
+            run.x += c;
+            run.y += pieces;
         }
-    } else if (staged) {  // the copies of a tile's count become the start of every copy's stretch inside the tile's bucket
+        __syncthreads();
+        // the copies of a tile's count become the start of every copy's stretch inside the tile's bucket
+        if (kept) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t i = tid + q * 1024;
-            if (i >= ntiles) break;
-            uint32_t at = s_cnt[i];
-            if (reps == kTileReps) {
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = tid + q * 1024;
+                if (i >= n) break;
+                uint32_t at = s_cnt[i];
+                tile_base[c0 + i] = at;
 #pragma unroll
                 for (uint32_t rep = 0; rep < kTileReps; ++rep) {
                     const size_t k = static_cast<size_t>(rep) * rep_stride + i;
-                    tile_count[k] = at;
-                    tile_cursor[k] = 0;
+                    tc[k] = at;
+                    tcur[k] = 0;
                     at += keep[q][rep];
                 }
-            } else {
-                for (uint32_t rep = 0; rep < reps; ++rep) {
-                    const size_t k = static_cast<size_t>(rep) * rep_stride + i;
-                    const uint32_t cr = tile_count[k];
-                    tile_count[k] = at;
-                    tile_cursor[k] = 0;
-                    at += cr;
+            }
+        } else {
+            for (uint32_t i = tid; i < n; i += 1024) {
+                uint32_t at = s_cnt[i];
+                tile_base[c0 + i] = at;
+                if (reps == kTileReps) {
+                    uint32_t v[kTileReps];
+#pragma unroll
+                    for (uint32_t rep = 0; rep < kTileReps; ++rep) v[rep] = tc[static_cast<size_t>(rep) * rep_stride + i];
+#pragma unroll
+                    for (uint32_t rep = 0; rep < kTileReps; ++rep) {
+                        const size_t k = static_cast<size_t>(rep) * rep_stride + i;
+                        tc[k] = at;
+                        tcur[k] = 0;
+                        at += v[rep];
+                    }
+                } else {
+                    for (uint32_t rep = 0; rep < reps; ++rep) {
+                        const size_t k = static_cast<size_t>(rep) * rep_stride + i;
+                        const uint32_t cr = tc[k];
+                        tc[k] = at;
+                        tcur[k] = 0;
+                        at += cr;
+                    }
                 }
             }
         }
+        carry = s_part[1023];
+        __syncthreads();  // (s_cnt, s_part and s_wave are the next stretch's)
     }
     if (tid == 1023) {
-        tile_base[ntiles] = s_part[1023].x;
-        counters[CNT_ITEMS] = s_part[1023].y;
+        tile_base[ntiles] = carry.x;
+        counters[CNT_ITEMS] = carry.y;
     }
     __shared__ uint32_t s_n2;
     if (tid == 0) s_n2 = 0;
@@ -492,6 +489,8 @@ __device__ __forceinline__ bool round_load(SlotWalk& w, const uint32_t* __restri
 }
 
 // bucket entry of a value: 13-bit bin inside its tile | the unique bit
+constexpr uint32_t kEntryBits = kTileShift + 1;  // a bucket entry: bin in tile | unique bit
+static_assert(kEntryBits <= 16, "bucket entries are 16-bit");
 __device__ __forceinline__ uint32_t entry_of(uint32_t v) { return (v & kTileMask) | ((v >> 31) << kTileShift); }
 
 // One round of the one-level bucketing with the values ORDERED BY TILE in LDS before they leave (<= 4096 tiles).
@@ -501,7 +500,7 @@ __device__ __forceinline__ uint32_t entry_of(uint32_t v) { return (v & kTileMask
 // lanes then store consecutive bucket positions of the same tile: one request per (tile, round) run.
 //   s_cnt   [4096]  values per tile in this round; then: global position of the tile's run minus its place in the stage
 //   s_loff  [4096]  exclusive scan of s_cnt
-//   s_stage [8192]  tile << 14 | entry, in tile order
+//   s_stage [8192]  tile << kEntryBits | entry, in tile order
 // mine[t] = start of this workgroup's counter copy inside tile t's bucket, cursor[t] = the copy's fill (global atomics).
 __device__ __forceinline__ uint32_t block_excl_scan_4096(uint32_t* s, uint32_t* s_wtot);
 
@@ -546,14 +545,14 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
     for (int k = 0; k < kRoundPieces; ++k) {
         if (v[k] == 0xffffffffu) continue;
         const uint32_t t = tile_of(v[k]);
-        s_stage[s_loff[t] + r[k]] = (t << 14) | entry_of(v[k]);
+        s_stage[s_loff[t] + r[k]] = (t << kEntryBits) | entry_of(v[k]);
     }
     __syncthreads();
     TPROF_T(p5);
     TPROF_ADD(5, p4, p5);
     for (uint32_t j = tid; j < total; j += kTBlock) {
         const uint32_t e = s_stage[j];
-        bucket[s_cnt[e >> 14] + j] = static_cast<uint16_t>(e & 0x3fffu);
+        bucket[s_cnt[e >> kEntryBits] + j] = static_cast<uint16_t>(e & ((1u << kEntryBits) - 1u));
     }
     __syncthreads();  // the next round clears s_cnt and refills the stage
     TPROF_T(p6);
@@ -941,14 +940,15 @@ __device__ __forceinline__ void tile_count(uint32_t* s, uint32_t bin) {
         atomicAdd(&s[bin], 1u);
 }
 
-template <bool kPacked>
+template <bool kPacked, uint32_t kWaves>
 __device__ __forceinline__ void tile_nonzero_bits(const uint32_t* s_a, uint32_t tile, const BitsLayout& bl, uint32_t array) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint64_t* dst = bl.base + (static_cast<uint64_t>(tile / bl.tps) * 2 + array) * bl.slice_w64 +
                     static_cast<uint64_t>(tile % bl.tps) * (kTileBins / 64);
+    constexpr uint32_t kPart = kTileBins / kWaves;  // every wave its part of the tile
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const uint32_t i = wave * 1024 + j * 64;
+    for (uint32_t j = 0; j < kPart / 64; ++j) {
+        const uint32_t i = wave * kPart + j * 64;
         const uint64_t m = __ballot(tile_load1<kPacked>(s_a, i + lane) != 0u);
         if (lane == 0) dst[i >> 6] = m;
     }
@@ -956,15 +956,16 @@ __device__ __forceinline__ void tile_nonzero_bits(const uint32_t* s_a, uint32_t 
 
 constexpr uint32_t kStatRefs = 128;  // reference offsets staged in LDS per tile (more: read from global memory)
 
-template <bool kTwo, bool kPacked>
+template <bool kTwo, bool kPacked, uint32_t kWaves>
 __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32_t* s_b, uint32_t tile,
                                                const uint32_t* s_off, uint32_t r0,
                                                const uint32_t* __restrict__ bin_off, uint32_t n_refs,
                                                uint32_t* __restrict__ stats, bool want_sum, bool want_nz) {
-    // every wave owns one eighth of the tile (1024 bins) and walks the references overlapping it
+    // every wave owns its part of the tile (1024 or 2048 bins) and walks the references overlapping it
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t tile0 = tile * kTileBins;
-    const uint32_t t0 = tile0 + wave * (kTileBins / 8), t1 = t0 + kTileBins / 8;
+    const uint32_t t0 = tile0 + wave * (kTileBins / kWaves), t1 = t0 + kTileBins / kWaves;
+    static_assert(kTileBins / kWaves <= 32768, "the two non-zero counts of a wave's part share one reduction");
     if (r0 >= n_refs) return;
     // first reference whose stretch reaches into my part: the last one starting at or before t0
     uint32_t k = 0;
@@ -997,7 +998,7 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
             }
         }
         sa = wave_sum_dpp(sa);
-        za = wave_sum_dpp(kTwo ? za | (zb << 16) : za);  // non-zero counts are at most 8192 each: one reduction for both
+        za = wave_sum_dpp(kTwo ? za | (zb << 16) : za);  // non-zero counts are at most the part's bins each: one reduction for both
         if (kTwo) {
             sb = wave_sum_dpp(sb);
             zb = za >> 16;
@@ -1032,13 +1033,27 @@ __device__ __forceinline__ void tile_ref_stats(const uint32_t* s_a, const uint32
 // kPacked = false with two arrays: the WIDE form for layouts whose tiles hold far more than kTileSub entries each (1 B
 // records on 20 k references: 63 k per tile): 32-bit counts, 64 KB of LDS, work items of up to kTileSubWide entries -- a
 // tile is then ONE item again instead of four pieces that each add 16 K words to global memory with atomics.
+// Workgroup size and occupancy: LDS decides how many workgroups a CU holds (160 KB: 32 KB -> 4, 64 KB -> 2, 128 KB -> 1);
+// the wide form over the large tiles is alone on its CU and runs 16 waves to have as many loads in flight as two
+// workgroups of eight (1 B records on 20 k references: 669 -> 480 us; for the 64 KB forms 16 waves measured the same as 8).
 template <bool kTwo, bool kPacked>
-__global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
+constexpr uint32_t hist_lds_bytes() { return (kPacked ? kTileBins / 2 : kTileBins) * 4u * (kTwo ? 2u : 1u); }
+template <bool kTwo, bool kPacked>
+constexpr uint32_t hist_block() { return hist_lds_bytes<kTwo, kPacked>() > 64u * 1024u ? 1024u : 512u; }
+template <bool kTwo, bool kPacked>
+constexpr uint32_t hist_waves_per_simd() {
+    constexpr uint32_t wgs = std::min<uint32_t>(4u, (160u * 1024u) / (hist_lds_bytes<kTwo, kPacked>() + 1024u));
+    return wgs * (hist_block<kTwo, kPacked>() / 64u) / 4u;
+}
+template <bool kTwo, bool kPacked>
+__global__ __launch_bounds__((hist_block<kTwo, kPacked>()), (hist_waves_per_simd<kTwo, kPacked>())) void k_tile_hist(const uint16_t* __restrict__ bucket, const uint4* __restrict__ items,
                                                    const uint32_t* __restrict__ counters, uint32_t* __restrict__ cov,
                                                    uint32_t* __restrict__ ucov, const uint32_t* __restrict__ bin_off,
                                                    uint32_t n_refs, const uint32_t* __restrict__ tile_ref0,
                                                    uint32_t* __restrict__ stats, const BitsLayout bits, uint32_t store_from) {
     constexpr uint32_t kWords = kPacked ? kPackWords : kTileBins;   // (packed: two 16-bit counts per word, tile_load4)
+    constexpr uint32_t kHB = hist_block<kTwo, kPacked>();
+    constexpr uint32_t kWaves = kHB / 64;
     __shared__ uint32_t s_cov[kWords];
     __shared__ uint32_t s_ucov[kTwo ? kWords : 4];
     __shared__ uint32_t s_off[kStatRefs + 1];  // bin offsets of the references overlapping this tile (and one more)
@@ -1052,7 +1067,7 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
             uint4* oc = reinterpret_cast<uint4*>(cov + static_cast<size_t>(tile) * kTileBins);
             uint4* ou = reinterpret_cast<uint4*>(ucov + static_cast<size_t>(tile) * kTileBins);
             const uint4 z = make_uint4(0, 0, 0, 0);
-            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += kHB) {
                 oc[i] = z;
                 if (kTwo) ou[i] = z;
             }
@@ -1073,7 +1088,7 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
         uint4* zc = reinterpret_cast<uint4*>(s_cov);
         uint4* zu = reinterpret_cast<uint4*>(s_ucov);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (uint32_t i = threadIdx.x; i < kWords / 4; i += 512) {
+        for (uint32_t i = threadIdx.x; i < kWords / 4; i += kHB) {
             zc[i] = z;
             if (kTwo) zu[i] = z;
         }
@@ -1094,16 +1109,16 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
         if (lo + threadIdx.x < a0) one(bucket[lo + threadIdx.x]);
         if (a1 + threadIdx.x < hi) one(bucket[a1 + threadIdx.x]);
         const uint4* __restrict__ b8 = reinterpret_cast<const uint4*>(bucket + a0);
-        for (uint32_t i0 = 0; i0 < n8; i0 += 2 * 512) {
+        for (uint32_t i0 = 0; i0 < n8; i0 += 2 * kHB) {
             uint4 q[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const uint32_t i = i0 + u * 512 + threadIdx.x;
+                const uint32_t i = i0 + u * kHB + threadIdx.x;
                 q[u] = i < n8 ? b8[i] : make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                if (i0 + u * 512 + threadIdx.x >= n8) continue;
+                if (i0 + u * kHB + threadIdx.x >= n8) continue;
                 const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1128,19 +1143,19 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
         const uint4* su = reinterpret_cast<const uint4*>(s_ucov);
         // the statistics' atomics first: they come back from the memory side in ~2 us, and a workgroup retires only when
         // they have -- issued before the 64 KB of tile stores they are back by the time those are
-        if (stats) tile_ref_stats<kTwo, kPacked>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
+        if (stats) tile_ref_stats<kTwo, kPacked, kWaves>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, true);
         HPROF_T(h5);
         HPROF_ADD(4, h4, h5);
         // tiles below store_from: the caller only wants what is derived from the finished tile while it is in LDS
         // (statistics, bit maps); the coverage arrays themselves are not materialised (tiles cut into pieces still are:
         // they are summed in global memory)
         if (tile >= store_from && !kPacked) {
-            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += 512) {
+            for (uint32_t i = threadIdx.x; i < kTileBins / 4; i += kHB) {
                 oc[i] = sc[i];
                 if (kTwo) ou[i] = su[i];
             }
         } else if (tile >= store_from) {  // four packed words = bins i .. i + 3 and i + 4096 .. i + 4099
-            for (uint32_t i = threadIdx.x; i < kPackWords / 4; i += 512) {
+            for (uint32_t i = threadIdx.x; i < kPackWords / 4; i += kHB) {
                 const uint4 w = sc[i];
                 oc[i] = make_uint4(w.x & 0xffffu, w.y & 0xffffu, w.z & 0xffffu, w.w & 0xffffu);
                 oc[i + kPackWords / 4] = make_uint4(w.x >> 16, w.y >> 16, w.z >> 16, w.w >> 16);
@@ -1152,15 +1167,15 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
             }
         }
         if (bits.base) {
-            tile_nonzero_bits<kPacked>(s_cov, tile, bits, 0);
-            if (kTwo) tile_nonzero_bits<kPacked>(s_ucov, tile, bits, 1);
+            tile_nonzero_bits<kPacked, kWaves>(s_cov, tile, bits, 0);
+            if (kTwo) tile_nonzero_bits<kPacked, kWaves>(s_ucov, tile, bits, 1);
         }
         HPROF_T(h6);
         HPROF_ADD(5, h5, h6);
         HPROF_ADD(7, h0, h6);
         return;
     }
-    for (uint32_t i = threadIdx.x; !kPacked && i < kTileBins; i += 512) {
+    for (uint32_t i = threadIdx.x; !kPacked && i < kTileBins; i += kHB) {
         const uint32_t a = s_cov[i];
         if (a) atomicAdd(&gc[i], a);
         if (kTwo) {
@@ -1168,7 +1183,7 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
             if (b2) atomicAdd(&gu[i], b2);
         }
     }
-    for (uint32_t i = threadIdx.x; kPacked && i < kPackWords; i += 512) {
+    for (uint32_t i = threadIdx.x; kPacked && i < kPackWords; i += kHB) {
         const uint32_t a = s_cov[i];
         if (a & 0xffffu) atomicAdd(&gc[i], a & 0xffffu);
         if (a >> 16) atomicAdd(&gc[i + kPackWords], a >> 16);
@@ -1180,7 +1195,7 @@ __global__ __launch_bounds__(512, kPacked || !kTwo ? 8 : 4) void k_tile_hist(con
     }
     // a tile cut into pieces: the sums are additive over the pieces; the non-zero counts need the finished tile and are
     // added by k_pack, the next kernel on the stream
-    if (stats) tile_ref_stats<kTwo, kPacked>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, false);
+    if (stats) tile_ref_stats<kTwo, kPacked, kWaves>(s_cov, s_ucov, tile, s_off, r0, bin_off, n_refs, stats, true, false);
 }
 
 // small arrays gathered behind the statistics so that ONE copy brings everything to the host; the same launch finishes
@@ -1217,10 +1232,10 @@ __global__ __launch_bounds__(512) void k_pack(uint32_t* __restrict__ dst, const 
             if (kTwo) reinterpret_cast<uint4*>(s_b)[i] = gb[i];
         }
         __syncthreads();
-        tile_ref_stats<kTwo, false>(s_a, s_b, tile, s_off, r0, bin_off, n_refs, stats, false, true);
+        tile_ref_stats<kTwo, false, 8>(s_a, s_b, tile, s_off, r0, bin_off, n_refs, stats, false, true);
         if (bits.base) {
-            tile_nonzero_bits<false>(s_a, tile, bits, 0);
-            if (kTwo) tile_nonzero_bits<false>(s_b, tile, bits, 1);
+            tile_nonzero_bits<false, 8>(s_a, tile, bits, 0);
+            if (kTwo) tile_nonzero_bits<false, 8>(s_b, tile, bits, 1);
         }
     }
 }
@@ -1326,24 +1341,25 @@ void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const u
                       bool wide) {
     const uint32_t grid = tile_items_upper(ntiles, n_upper);
     if (ucov && wide)
-        hipLaunchKernelGGL((k_tile_hist<true, false>), dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
+        hipLaunchKernelGGL((k_tile_hist<true, false>), dim3(grid), dim3(hist_block<true, false>()), 0, st, bucket, items, counters, cov, ucov, bin_off,
                            n_refs, tile_ref0, stats, bits, store_from);
     else if (ucov)
-        hipLaunchKernelGGL((k_tile_hist<true, true>), dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, ucov, bin_off,
+        hipLaunchKernelGGL((k_tile_hist<true, true>), dim3(grid), dim3(hist_block<true, true>()), 0, st, bucket, items, counters, cov, ucov, bin_off,
                            n_refs, tile_ref0, stats, bits, store_from);
     else
-        hipLaunchKernelGGL((k_tile_hist<false, false>), dim3(grid), dim3(512), 0, st, bucket, items, counters, cov, cov, bin_off,
+        hipLaunchKernelGGL((k_tile_hist<false, false>), dim3(grid), dim3(hist_block<false, false>()), 0, st, bucket, items, counters, cov, cov, bin_off,
                            n_refs, tile_ref0, stats, bits, store_from);
 }
 
+}  // namespace SLIMM_TILE_NS
 }  // namespace slimm
 
-#if defined(EXP) && (EXP == 8 || EXP == 9)
+#if defined(EXP) && (EXP == 8 || EXP == 9) && SLIMM_TILE_SHIFT == 13  // (the cycle probes read the small-tile build)
 extern "C" int slimm_debug_prof_tiles(unsigned long long* out, int n, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_t), sizeof(unsigned long long) * n);
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::tiles13::g_prof_t), sizeof(unsigned long long) * n);
     if (reset) {
         static unsigned long long z[8 * 4096];
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_t), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::tiles13::g_prof_t), z, sizeof(z));
     }
     return e == hipSuccess ? 0 : -1;
 }

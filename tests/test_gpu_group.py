@@ -137,6 +137,23 @@ def test_group_exchange_forms_equal_the_oracle(members, form):
     g.close()
 
 
+@pytest.mark.parametrize("shift", ["13", "14"])
+@pytest.mark.parametrize("form", ["summary", "sliced"])
+def test_group_bitmaps_with_both_tile_sizes(monkeypatch, shift, form):
+    """The 'bin != 0' bitmaps k_tile_hist / k_pack write for the exchange are laid out in slices of tiles: both tile
+    sizes (SLIMM_TILE_SHIFT) through the all-gather and the all-to-all form, split tiles included."""
+    monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
+    w = make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000, len_hi=900_000, present_frac=0.3),
+                      seed=62)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0, 0, 0])
+    g.set_exchange(form)
+    g.push_records(w.records, batch=30_000)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()
+
+
 @pytest.mark.parametrize("form", ["sliced", "bins"])
 def test_group_exchange_forms_on_a_larger_stream_and_a_second_file(form):
     w = make_workload(CONFIGS["config2"], seed=58, n_records=300_000)

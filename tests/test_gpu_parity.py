@@ -295,6 +295,38 @@ def test_wide_tile_work_items(monkeypatch, fused):
                         seed=33), keep_bins=False)
 
 
+@pytest.mark.parametrize("shift", ["13", "14"])
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_both_tile_sizes(monkeypatch, shift, fused):
+    """tile_hist.hip is built once per tile size (8192 / 16384 bins: namespaces tiles13 / tiles14) and a context picks one
+    by its layout -- the small tiles up to the fused kernel's 4064, the large ones beyond.  SLIMM_TILE_SHIFT forces either
+    onto any layout: small layouts through the large tiles (and, with their full reference sets, big ones through the
+    small: test_prefix_of_the_big_configs_on_small_tiles), ordered and direct rounds, packed, wide and cut work items,
+    without materialised arrays."""
+    monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
+    monkeypatch.setenv("SLIMM_FUSED_SCAN", fused)
+    check(make_workload(CONFIGS["config1"], seed=34))
+    check(make_workload(CONFIGS["config1"], seed=35), grouped=False)
+    check(make_workload(CONFIGS["config2"], seed=36, n_records=300_000))
+    check(one_long_read_workload(9_000))
+    hot = make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000, len_hi=900_000, present_frac=0.3),
+                        seed=37)
+    check(hot)
+    check(hot, keep_bins=False)
+    monkeypatch.setenv("SLIMM_WIDE_TILES", "1")
+    check(hot)
+    check(make_workload(SynthConfig("hotter", 600_000, 6, 1.5, bin_width=200, len_lo=300_000, len_hi=400_000, present_frac=1.0),
+                        seed=38))
+
+
+@pytest.mark.parametrize("name,n", [("config3", 2_000_000), ("config5", 1_000_000)])
+def test_prefix_of_the_big_configs_on_small_tiles(monkeypatch, name, n):
+    """The layouts that take the 16384-bin tiles by themselves through the 8192-bin ones (9 776 / 45 000 tiles: the scan in
+    stretches of 16 K tiles, two-level bucketing)."""
+    monkeypatch.setenv("SLIMM_TILE_SHIFT", "13")
+    check(make_workload(CONFIGS[name], seed=3, n_records=n))
+
+
 def test_wide_lineage_rows_fallback_path(monkeypatch):
     """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
     monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")

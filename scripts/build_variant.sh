@@ -7,7 +7,7 @@ NAME=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 D=$R/build/var/$NAME
 rm -rf "$D"; mkdir -p "$D/csrc"
-cp -r $R/slimm_amd/csrc/*.hip $R/slimm_amd/csrc/*.h $R/slimm_amd/csrc/*.hpp $R/slimm_amd/csrc/*.cpp $R/slimm_amd/csrc/Makefile "$D/csrc/"
+cp -r $R/slimm_amd/csrc/*.hip $R/slimm_amd/csrc/*.h $R/slimm_amd/csrc/*.inc $R/slimm_amd/csrc/*.hpp $R/slimm_amd/csrc/*.cpp $R/slimm_amd/csrc/Makefile "$D/csrc/"
 cp -r $R/slimm_amd/csrc/host "$D/csrc/"; mkdir -p $R/build/var/include; cp $R/include/*.h $R/build/var/include/
 for e in "$@"; do sed -i -E "$e" $D/csrc/*.hip $D/csrc/*.h; done
 make -s -C "$D/csrc" ../libslimm_hip.so 2>&1 | grep -E "error|Error" || true

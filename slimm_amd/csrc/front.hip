@@ -226,11 +226,13 @@ struct FrontRawT {
     }
     __device__ uint2 geo_at(const FrontLoaded& w) const { return f_load_at(geo, (w.b < n_refs ? w.b : 0u) * 8u); }
     // field = reference + 1 of a mapped record (src/slimm.hpp:197), kRefField otherwise; mate: src/slimm.hpp:205-208
-    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, bool& bad) const {
+    // worst: the largest reference + 1 of an aligned record seen so far (above n_refs: neither -1 nor a reference -- the
+    // caller's test, once per slot; a flag kept per record is four vector instructions each)
+    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, uint32_t& worst) const {
         const bool aligned = kPacked ? (static_cast<int32_t>(w.a) >= 0) : ((w.a & 0x4u) == 0u);
-        const uint32_t r1 = w.b + 1u;
-        bad = bad || (aligned && r1 > n_refs);  // neither -1 nor a reference
-        field = (aligned && w.b < n_refs) ? r1 : kRefField;
+        const uint32_t t = aligned ? w.b + 1u : 0u;  // (reference -1 wraps to 0 as well)
+        worst = max(worst, t);
+        field = (t - 1u < n_refs) ? t : kRefField;
         if (kPacked) {
             mate = (w.a >> 29) & 3u;
         } else {
@@ -241,6 +243,7 @@ struct FrontRawT {
     __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2& g) const {
         return g.y + div_bin_width(min(w.c + half_read, g.x));
     }
+    __device__ bool out_of_range(uint32_t worst) const { return worst > n_refs; }
     __device__ FrontRec decode(const FrontRaw3& w, bool& bad) const {
         FrontRec o;
         if (kPacked) {
@@ -315,10 +318,11 @@ struct FrontSorted {
         hi = 0u;
     }
     __device__ uint2 geo_at(const FrontLoaded&) const { return make_uint2(0u, 0u); }
-    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, bool&) const {
+    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, uint32_t&) const {
         field = w.b + 1u;
         mate = w.a & 3u;
     }
+    __device__ bool out_of_range(uint32_t) const { return false; }
     __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2&) const { return w.c; }
 };
 
@@ -708,6 +712,7 @@ __device__ __forceinline__ bool long_run_staged(const uint32_t* st1, const uint3
 template <bool kClamp, bool kChk, typename Acc>
 __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t N, uint32_t lane, uint32_t* st1, uint32_t* st2,
                                            bool& bad, bool& collide) {
+    uint32_t worst = 0;
     // The key in front of every record: the lane before's (DPP), for lane 0 the last key of the block before -- and for
     // the stretch's first block a second load of the keys, one record down, issued with the others.  (The key of record
     // B - 1 alone, loaded up front, would be a round trip of its own per slot.)
@@ -746,7 +751,7 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
             const uint32_t j = j0 + u;
             if (j >= kSlotBlocks) break;
             uint32_t field, mate;
-            acc.fields(rec[u], field, mate, bad);
+            acc.fields(rec[u], field, mate, worst);
             Acc::key_fix(rec[u].klo, rec[u].khi);
             const uint32_t g = acc.gbin_of(rec[u], geo[u]);
             const uint64_t k = (static_cast<uint64_t>(rec[u].khi) << 32) | rec[u].klo;
@@ -780,6 +785,7 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
             phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].khi, 63));
         }
     }
+    bad = bad | acc.out_of_range(worst);
 }
 
 }  // namespace

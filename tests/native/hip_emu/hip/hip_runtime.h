@@ -142,6 +142,12 @@ static inline uint64_t __builtin_amdgcn_ballot_w64(bool p) {
     return m;
 }
 static inline uint64_t __ballot(int p) { return __builtin_amdgcn_ballot_w64(p != 0); }
+// (on the GPU a scheduling barrier and no instruction: the lanes of a wave run in lockstep; here the lanes are fibers and
+// this is where they wait for each other -- e.g. before reading LDS words another lane has written)
+static inline void __builtin_amdgcn_wave_barrier() {
+    uint64_t live = 0;
+    (void)::hipemu::wave_exchange(0u, &live);
+}
 static inline int __any(int p) { return __ballot(p) != 0ull; }
 static inline int __all(int p) {
     uint64_t live = 0;

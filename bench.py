@@ -59,7 +59,7 @@ def algorithmic_bytes(st, n_records, Bp_words, rec_bytes=16):
         "sort_by_ident": 8 * (2 * 16 * V + 8 * V),   # (sort path only) 8 passes: keys+payload in and out, keys again for the histogram
         "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
         "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
-        "k_front": rec_bytes * N + 8 * P + 16 * (N // 1024 + 1),  # every record once (key 8 + ref 4 + pos 4 (+ flag 2) bytes);
+        "k_front": rec_bytes * N + 8 * P + 16 * (N // 768 + 1),  # every record once (key 8 + ref 4 + pos 4 (+ flag 2) bytes);
                                                       # targets (ref word + bin word) and the slot descriptors out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read
         "k_tile_count": 4 * P,                        # gbin in

@@ -147,7 +147,10 @@ struct slimm_ctx {
     bool binsA_stored = false, binsB_stored = false;
     DevBuf<uint4> tile_items, part_items;
     DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
-    DevBuf<uint32_t> sel;                               // per read (slot.x + k): its uniq_cov2 bin, Bp + LCA taxon, or 0xffffffff
+    DevBuf<uint32_t> sel;                               // per read, dense: its uniq_cov2 bin, Bp + LCA taxon, or 0xffffffff
+    DevBuf<uint32_t> slot_rbase, slot_bbase;            // reads in front of a slot = rbase[s] + bbase[s >> 10] (side stream)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t front_done = nullptr, prefix_done = nullptr;
     uint32_t tile_shift = kTileShiftSmall;              // log2 of the bins per tile: which build of tile_hist.hip runs (kernels.h)
     uint32_t tile_bins() const { return 1u << tile_shift; }
     uint32_t ntiles = 0;
@@ -315,6 +318,8 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->wcut.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
     HIP_TRY(c, c->tot_part.ensure(512));
     HIP_TRY(c, c->sel.ensure(n + 8));
+    HIP_TRY(c, c->slot_rbase.ensure(front_slots(n) + 8));
+    HIP_TRY(c, c->slot_bbase.ensure(front_slots(n) / 1024 + 8));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(TILES(c->tile_shift, tile_items_upper(c->ntiles2, n)) + 1));
@@ -452,6 +457,9 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(hipSetDevice(c->device));
         HIP_TRY0(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
         HIP_TRY0(hipStreamCreateWithFlags(&cc->copy_stream, hipStreamNonBlocking));
+        HIP_TRY0(hipStreamCreateWithFlags(&cc->side_stream, hipStreamNonBlocking));
+        HIP_TRY0(hipEventCreateWithFlags(&cc->front_done, hipEventDisableTiming));
+        HIP_TRY0(hipEventCreateWithFlags(&cc->prefix_done, hipEventDisableTiming));
         HIP_TRY0(hipEventCreateWithFlags(&cc->copy_done, hipEventDisableTiming));
         for (auto& sg : cc->staging) HIP_TRY0(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
         HIP_TRY0(cc->d_ref_len.ensure(c->R));
@@ -572,6 +580,12 @@ void slimm_destroy(slimm_ctx* c) {
             (void)hipEventDestroy(e.a);
             (void)hipEventDestroy(e.b);
         }
+        if (c->side_stream) {
+            (void)hipStreamSynchronize(c->side_stream);
+            (void)hipStreamDestroy(c->side_stream);
+        }
+        if (c->front_done) (void)hipEventDestroy(c->front_done);
+        if (c->prefix_done) (void)hipEventDestroy(c->prefix_done);
         if (c->copy_stream) {
             (void)hipStreamSynchronize(c->copy_stream);
             (void)hipStreamDestroy(c->copy_stream);
@@ -1010,6 +1024,11 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
                          c->slots.p, c->wcut.p, t.t0(), t.t1());
     }
+    // where every slot's reads start among all reads (for k_filter's dense selectors): beside the tile kernels
+    HIP_TRY(c, hipEventRecord(c->front_done, st));
+    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->front_done, 0));
+    launch_slot_read_prefix(c->side_stream, c->slots.p, nslots, c->slot_rbase.p, c->slot_bbase.p);
+    HIP_TRY(c, hipEventRecord(c->prefix_done, c->side_stream));
     SlotValues targets;
     targets.vals = c->tgt_gbin.p;
     targets.slots = c->slots.p;
@@ -1363,6 +1382,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         launch_zero(st, z);
     }
     const uint32_t nslots = front_slots(c->rec.n);
+    HIP_TRY(c, hipStreamWaitEvent(st, c->prefix_done, 0));  // (long done: recorded behind k_front)
     {
         KernelTimer t(c, K_FILTER, true);  // (the dispatch's own time stamps, like k_front)
         FilterArgs fa;
@@ -1380,6 +1400,8 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             fa.valid = c->d_valid.p;
         }
         fa.sel = c->sel.p;
+        fa.slot_rbase = c->slot_rbase.p;
+        fa.slot_bbase = c->slot_bbase.p;
         fa.marks = c->marks.p;
         fa.pair_tab = c->pair_tab.p;
         fa.pair_list = c->pair_list.p;
@@ -1388,14 +1410,13 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         fa.counters = c->counters.p;
         launch_filter(st, fa, t.t0(), t.t1());
     }
-    SlotValues selectors;
+    SlotValues selectors;  // dense: k_filter wrote every slot's selectors behind those of the slots before
     selectors.vals = c->sel.p;
-    selectors.slots = c->slots.p;
-    selectors.nslots = nslots;
-    selectors.per_read = true;
+    selectors.slots = nullptr;
+    selectors.nslots = c->local_M;
     if (!c->use_tiles) {
         KernelTimer t(c, K_HIST);
-        launch_sel_atomics(st, c->sel.p, c->slots.p, nslots, static_cast<uint32_t>(c->Bp), c->ucov2(), c->lca_count.p);
+        launch_sel_atomics(st, c->sel.p, c->local_M, static_cast<uint32_t>(c->Bp), c->ucov2(), c->lca_count.p);
     }
     if (c->use_tiles) {  // uniq_cov2 and the per-taxon LCA counts from the per-read selectors, through the LDS tile histogram
         const uint32_t grid = 512;

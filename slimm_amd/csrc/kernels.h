@@ -96,7 +96,12 @@ uint32_t num_tiles(uint32_t n);
 // ---- front.hip: the single-pass front end of phase A ----
 // A slot = kSlotRecs consecutive records; its targets (the runs that START in it) lie compacted at
 // [slot.x, slot.x + slot.y) of tgt_ref / tgt_gbin; slot.z = reads (targets with bit 31 of tgt_ref), slot.w = mapped records
-constexpr uint32_t kSlotRecs = 1024;
+// 768 records: measured, not derived.  k_front by slot size at 1 B records / config 2 / config 5 (one box, four waves per
+// SIMD throughout): 1088: 5 075 / 73 / 753 us, 1024: 5 141 / 76 / 757, 896: 5 283 / 74 / 769, 832: 5 061-5 144 / 77 / 726,
+// 768: 4 934-4 989 / 69 / 683, 704: 4 973 / 67 / 684, 640: 5 034 / 67 / 686, 512: 5 141 / 67 / 704 -- while every consumer
+// of the slots likes them large (1 B records, 1024 -> 768 -> 640 -> 512: k_tile_count 453 -> 460 -> 543 -> 619 us, k_filter
+// 2 571 -> 2 588-2 660 -> 2 616 -> 2 843, scatter 2 314 -> 2 393 -> 2 458 -> 2 503).
+constexpr uint32_t kSlotRecs = 768;
 // The front end works through a slot in windows of whole qName runs (<= 64 records, or one run of 64 records or more);
 // wcut[s * kSlotWindows + i] = {targets, reads} of slot s in front of its window i, the entry behind the last window
 // holds the slot's totals and wcut[s * kSlotWindows + kSlotWindows - 1].x the number of windows.  The targets of a
@@ -148,7 +153,9 @@ struct FilterArgs {
     uint32_t taxon_shift = 0;
     const uint32_t* lin_dense = nullptr;
     const uint8_t* valid = nullptr;
-    uint32_t* sel = nullptr;
+    uint32_t* sel = nullptr;                 // one selector per read, dense: slot s writes at slot_rbase[s] + slot_bbase[s >> 10]
+    const uint32_t* slot_rbase = nullptr;    // (launch_slot_read_prefix)
+    const uint32_t* slot_bbase = nullptr;
     uint32_t* marks = nullptr;
     uint64_t* pair_tab = nullptr;
     uint64_t* pair_list = nullptr;
@@ -157,8 +164,11 @@ struct FilterArgs {
 };
 void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // t0 / t1: as for launch_front_raw
 // direct-atomics fallback: count the selectors with global atomics instead of the second tile histogram
-void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
-                        uint32_t* ucov2, uint32_t* lca_count);
+void launch_sel_atomics(hipStream_t st, const uint32_t* sel, uint32_t n_reads, uint32_t taxon_base, uint32_t* ucov2,
+                        uint32_t* lca_count);
+// the exclusive prefix of the slots' read counts: rbase[s] + bbase[s >> 10] = reads in front of slot s (rbase: nslots
+// words, bbase: nslots / 1024 + 1); two small launches
+void launch_slot_read_prefix(hipStream_t st, const uint4* slots, uint32_t nslots, uint32_t* rbase, uint32_t* bbase);
 // multi-GPU: [R uniq_reads_count2 | T LCA counts | 2R level marks in 8-bit fields | 1 pair count] from result block B
 void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, uint32_t T, uint32_t* out);
 // multi-GPU, all-to-all form: this rank received every rank's bitmaps of ITS slice ([n_ranks][2][slice_words] 32-bit
@@ -191,13 +201,13 @@ constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile
 #define SLIMM_TILE_REPS 8
 #endif
 constexpr uint32_t kTileReps = SLIMM_TILE_REPS;
-// the values the bucketing kernels read: one per target (tgt_gbin: bit 31 = unique read) or one per read (the selectors
-// of phase B: 0xffffffff = none), lying in the slots front.hip wrote
+// the values the bucketing kernels read: one per target (tgt_gbin: bit 31 = unique read), lying in the slots front.hip
+// wrote -- or, slots == nullptr, a dense array of nslots values (the selectors of phase B, one per read: 0xffffffff = none)
 struct SlotValues {
     const uint32_t* vals = nullptr;
     const uint4* slots = nullptr;
-    uint32_t nslots = 0;
-    bool per_read = false;
+    uint32_t nslots = 0;       // slots, or values of the dense form
+    bool per_read = false;     // (slot form) a slot's values are its reads', not its targets'
 };
 // The front end leaves the totals of the stream {mapped records, reads, targets} to its consumers (thousands of waves
 // adding to three counters would be as many memory-side atomics in a row): launch_tile_count with part != nullptr

@@ -550,7 +550,9 @@ __device__ __forceinline__ uint64_t k_head_of(uint64_t bits, uint64_t heads) {
 }
 
 struct FilterOut {
-    uint32_t* sel;                 // one selector per read: a uniq_cov2 bin, taxon_base + taxon, or 0xffffffff
+    uint32_t* sel;                 // one selector per read: a uniq_cov2 bin, taxon_base + taxon, or 0xffffffff -- dense: the
+    const uint32_t* rbase;         // reads of slot s start at rbase[s] + bbase[s >> 10] (launch_slot_read_prefix)
+    const uint32_t* bbase;
     uint8_t* marks;                // one byte per (reference, level)
     uint64_t* pair_tab;
     uint64_t* pair_list;
@@ -803,10 +805,10 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 constexpr int kFilterBlock = 64;  // one wave per workgroup (backfilled wave by wave: -2 %)
 
 // A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
-// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  Four
-// at a time: the target words of all four are loaded together, then their lineage rows gathered together, then the four
+// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  A few
+// at a time (kFilterBatch): the target words of all are loaded together, then their lineage rows gathered together, then they
 // are worked on, then the taxa of their reads with several targets looked up together -- three memory round trips per
-// batch of windows.  Four windows per batch at eight waves per SIMD (64 VGPRs): the kernel waits for these round trips
+// batch of windows.  (Round 2, slots of 1024 records:) four windows per batch at eight waves per SIMD (64 VGPRs): the kernel waits for these round trips
 // two thirds of its time (SQ_WAIT_ANY), and an eighth wave covers more of them than two more windows in flight do --
 // config 3: 436 - 460 us with six windows at seven waves, 394 - 412 us like this; config 2 the same either way.
 // (No branch around the loads:
@@ -841,7 +843,8 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
             const uint2 ce = wcut[static_cast<size_t>(slot) * kSlotWindows + min(lane, kSlotWindows - 1u)];
             const uint32_t n = first + k < nslots ? static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, kSlotWindows - 1u)) : 0u;
             const uint32_t nxt = __shfl_down(ce.x, 1, 64);  // (lane n holds the slot's totals)
-            const uint32_t a_start = d.x + ce.x, a_cnt = lane < n ? nxt - ce.x : 0u, a_sel = d.x + ce.y;
+            const uint32_t rb = out.rbase[slot] + out.bbase[slot >> 10];  // (two scalar loads beside the descriptor's)
+            const uint32_t a_start = d.x + ce.x, a_cnt = lane < n ? nxt - ce.x : 0u, a_sel = rb + ce.y;
             if (kFilterSlots == 1) {
                 w_start = a_start;
                 w_cnt = a_cnt;
@@ -1113,30 +1116,83 @@ void launch_partials_pack(hipStream_t st, const uint32_t* block_b, uint32_t R, u
                        out);
 }
 
+// Where a slot's reads start among ALL reads of the file: the exclusive prefix of slots[s].z, as rbase[s] (inside the slot's
+// block of 1024 slots) + bbase[s >> 10] (the blocks before).  k_filter writes the selectors there, so that phase B's
+// bucketing kernels read ONE dense array instead of walking the slots -- a slot holds 90 reads at 1 B records on 20 k
+// references, 18 on 50 k strain-level ones, and a piece of 256 values per slot was 35 % / 7 % full.  Two small launches on
+// a side stream while phase A's tile kernels run.
+constexpr uint32_t kPrefixBlock = 1024;
+__global__ __launch_bounds__(kPrefixBlock) void k_slot_prefix_blocks(const uint4* __restrict__ slots, uint32_t nslots,
+                                                                     uint32_t* __restrict__ rbase, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t s_wave[kPrefixBlock / 64];
+    const uint32_t s = blockIdx.x * kPrefixBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t c = s < nslots ? slots[s].z : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc, o, 64);
+        if (lane >= static_cast<uint32_t>(o)) inc += a;
+    }
+    if (lane == 63u) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kPrefixBlock / 64; ++w) before += w < wave ? s_wave[w] : 0u;
+    if (s < nslots) rbase[s] = before + inc - c;
+    if (threadIdx.x == kPrefixBlock - 1u) bsum[blockIdx.x] = before + inc;
+}
+// ... and the blocks' sums into the blocks' bases, in place (one workgroup)
+__global__ __launch_bounds__(kPrefixBlock) void k_slot_prefix_bases(uint32_t* __restrict__ bsum, uint32_t nblocks) {
+    __shared__ uint32_t s_wave[kPrefixBlock / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += kPrefixBlock) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t c = b < nblocks ? bsum[b] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(inc, o, 64);
+            if (lane >= static_cast<uint32_t>(o)) inc += a;
+        }
+        if (lane == 63u) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t before = s_carry;
+#pragma unroll
+        for (uint32_t w = 0; w < kPrefixBlock / 64; ++w) before += w < wave ? s_wave[w] : 0u;
+        if (b < nblocks) bsum[b] = before + inc - c;
+        __syncthreads();
+        if (threadIdx.x == kPrefixBlock - 1u) s_carry = before + inc;
+        __syncthreads();
+    }
+}
+void launch_slot_read_prefix(hipStream_t st, const uint4* slots, uint32_t nslots, uint32_t* rbase, uint32_t* bbase) {
+    if (!nslots) return;
+    const uint32_t nb = (nslots + kPrefixBlock - 1u) / kPrefixBlock;
+    hipLaunchKernelGGL(k_slot_prefix_blocks, dim3(nb), dim3(kPrefixBlock), 0, st, slots, nslots, rbase, bbase);
+    hipLaunchKernelGGL(k_slot_prefix_bases, dim3(1), dim3(kPrefixBlock), 0, st, bbase, nb);
+}
+
 // the selectors counted with global atomics (direct-atomics fallback: no tile histogram): uniq_cov2[g]++ per read that
 // kept one target, lca_count[t]++ per read counted at its LCA
-__global__ __launch_bounds__(kBlock) void k_sel_atomics(const uint32_t* __restrict__ sel, const uint4* __restrict__ slots,
-                                                        uint32_t nslots, uint32_t taxon_base, uint32_t* __restrict__ ucov2,
-                                                        uint32_t* __restrict__ lca_count) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, n_waves = (gridDim.x * kBlock) >> 6;
-    for (uint32_t s = wave; s < nslots; s += n_waves) {
-        const uint4 d = slots[s];
-        for (uint32_t o = lane; o < d.z; o += 64u) {
-            const uint32_t v = sel[d.x + o];
-            if (v == 0xffffffffu) continue;
-            if (v < taxon_base)
-                atomicAdd(&ucov2[v], 1u);
-            else
-                atomicAdd(&lca_count[v - taxon_base], 1u);
-        }
+__global__ __launch_bounds__(kBlock) void k_sel_atomics(const uint32_t* __restrict__ sel, uint32_t n_reads, uint32_t taxon_base,
+                                                        uint32_t* __restrict__ ucov2, uint32_t* __restrict__ lca_count) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_reads; i += gridDim.x * kBlock) {
+        const uint32_t v = sel[i];
+        if (v == 0xffffffffu) continue;
+        if (v < taxon_base)
+            atomicAdd(&ucov2[v], 1u);
+        else
+            atomicAdd(&lca_count[v - taxon_base], 1u);
     }
 }
 
-void launch_sel_atomics(hipStream_t st, const uint32_t* sel, const uint4* slots, uint32_t nslots, uint32_t taxon_base,
-                        uint32_t* ucov2, uint32_t* lca_count) {
-    uint32_t blocks = std::max(1u, std::min((nslots + kWaves - 1) / kWaves, 256u * 16u));
-    hipLaunchKernelGGL(k_sel_atomics, dim3(blocks), dim3(kBlock), 0, st, sel, slots, nslots, taxon_base, ucov2, lca_count);
+void launch_sel_atomics(hipStream_t st, const uint32_t* sel, uint32_t n_reads, uint32_t taxon_base, uint32_t* ucov2,
+                        uint32_t* lca_count) {
+    uint32_t blocks = std::max(1u, std::min((n_reads + kBlock - 1) / kBlock, 256u * 16u));
+    hipLaunchKernelGGL(k_sel_atomics, dim3(blocks), dim3(kBlock), 0, st, sel, n_reads, taxon_base, ucov2, lca_count);
 }
 
 static uint32_t filter_grid(uint32_t nslots) {
@@ -1150,6 +1206,8 @@ void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_
     if (!a.nslots) return;
     FilterOut out;
     out.sel = a.sel;
+    out.rbase = a.slot_rbase;
+    out.bbase = a.slot_bbase;
     out.marks = reinterpret_cast<uint8_t*>(a.marks);
     out.pair_tab = a.pair_tab;
     out.pair_list = a.pair_list;

@@ -77,7 +77,11 @@ constexpr uint32_t kScanStaged = 16384;  // tiles whose counts k_tile_scan stage
 // Workgroup b of g owns a contiguous range of slots -- the SAME range in the count and in the scatter kernel, whose
 // counter copies pair up by workgroup -- and its waves take the slots of that range round robin, 64 entries at a time.
 struct SlotWalk {  // all wave-uniform
-    const uint4* slots;
+    const uint4* slots;       // nullptr: the dense form -- [base, d_end) are this wave's values still to come, in pieces
+                              // of the caller's size, step of them apart (the workgroup's waves take its stretch's
+                              // pieces round robin)
+    uint32_t d_end, d_wave;
+    bool d_first;
     uint32_t s, s_end;        // next slot of this wave, end of the workgroup's range
     uint32_t step;            // waves of the workgroup
     uint32_t base, left;      // entries of the current slot not yet handed out: [base, base + left)
@@ -85,16 +89,34 @@ struct SlotWalk {  // all wave-uniform
     bool per_read;
 };
 
+constexpr uint32_t kPiece = 256;
+constexpr uint32_t kPieceMax = 256;  // the largest piece any kernel asks slot_next for
 // fold: this workgroup stands for `fold` workgroups of the bucketing grid (k_tile_count: fewer, larger workgroups flush
 // fewer LDS histograms with global atomics)
 // wg: the workgroup's index among the owners of slot ranges (blockIdx.x, or a permutation of it: xcd_logical_id)
 __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslots, bool per_read, uint32_t fold = 1,
                                               uint32_t wg = blockIdx.x) {
-    const uint32_t per_wg = (nslots + gridDim.x * fold - 1) / (gridDim.x * fold) * fold;
-    const uint32_t lo = min(wg * per_wg, nslots);
     SlotWalk w;
     w.slots = slots;
     w.step = blockDim.x >> 6;
+    w.d_end = 0;
+    w.d_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    w.d_first = true;
+    if (!slots) {  // dense: nslots VALUES; every unit of the bucketing grid a stretch of whole pieces
+        const uint32_t units = gridDim.x * fold;
+        const uint32_t per_unit = ((nslots + units - 1u) / units + kPieceMax - 1u) & ~(kPieceMax - 1u);
+        const uint64_t lo64 = static_cast<uint64_t>(wg) * per_unit * fold;
+        const uint32_t lo = static_cast<uint32_t>(min<uint64_t>(lo64, nslots));
+        w.base = lo;
+        w.d_end = static_cast<uint32_t>(min<uint64_t>(lo64 + static_cast<uint64_t>(per_unit) * fold, nslots));
+        w.left = 0;
+        w.s = w.s_end = 0;
+        w.sum_f = w.sum_h = w.sum_v = 0;
+        w.per_read = per_read;
+        return w;
+    }
+    const uint32_t per_wg = (nslots + gridDim.x * fold - 1) / (gridDim.x * fold) * fold;
+    const uint32_t lo = min(wg * per_wg, nslots);
     w.s = lo + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.s_end = min(lo + per_wg, nslots);
     w.base = 0;
@@ -120,8 +142,18 @@ __device__ __forceinline__ uint32_t xcd_logical_id() {
 }
 
 // the next (up to) 256 entries: returns their count (0: the wave has no more), *base = index of the first
-constexpr uint32_t kPiece = 256;
 __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base, uint32_t cap = kPiece) {
+    if (!w.slots) {
+        if (w.d_first) {
+            w.base += w.d_wave * cap;
+            w.d_first = false;
+        }
+        if (w.base >= w.d_end) return 0u;
+        const uint32_t n = min(cap, w.d_end - w.base);
+        *base = w.base;
+        w.base += w.step * cap;
+        return n;
+    }
     while (w.left == 0u) {
         if (w.s >= w.s_end) return 0u;
         const uint4 d = w.slots[w.s];  // (a scalar load: one address for the wave)

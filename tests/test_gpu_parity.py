@@ -557,10 +557,10 @@ def test_chunked_tile_scan(monkeypatch):
     check(w, grouped=False)
 
 
-@pytest.mark.parametrize("n_records", [1024 * 64, 1024 * 64 + 1, 1024 * 129 - 5, 1_500_000])
+@pytest.mark.parametrize("n_records", [768 * 64, 768 * 64 + 1, 768 * 129 - 5, 1024 * 64, 1024 * 64 + 1, 1_500_000])
 def test_slot_boundaries(n_records):
-    """Record counts at, one past and short of whole slots (1024 records), and many slots: runs straddle slot boundaries,
-    the last slot is ragged."""
+    """Record counts at, one past and short of whole slots (768 records; 1024 in earlier builds), and many slots: runs
+    straddle slot boundaries, the last slot is ragged."""
     w = make_workload(CONFIGS["config2"], seed=36, n_records=n_records)
     check(w)
 

@@ -25,6 +25,8 @@ ONE JSON line on rank 0.  Beside the contract's fields:
                       [4] (100 M records, 50 k strain-level refs, 40 hits/read), resident, N = 1 only
   value_with_push     the clock starts before the first record leaves page-locked HOST memory
                       (slimm_push_records_packed_async) and stops when the profile file is written -- SURVEY.md 8d (1)
+  run_marked_records  the same stream handed over as run-marked 8-byte records (include/slimm_hip.h): resident rate, k_front
+                      under 8 N + 8 P, push-inclusive rate -- beside the headline, which stays on SURVEY 8d's 16-byte records
   cpu_baseline        the CPU oracle (a port of the reference algorithm, 1 thread) on a bounded prefix of the stream
   cpu_baseline_mt     the dense all-core restatement on a bounded prefix
   cli_end_to_end      `slimm DB IN.bam` on a 100 M-record synthetic BAM, process start to profile written
@@ -129,6 +131,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling instead: every rank its own --records-sized shard of the sample (round 1 / 2 default)")
+    ap.add_argument("--no-marked", action="store_true", help="skip the leg that runs the stream as run-marked 8-byte records")
     ap.add_argument("--form", default="packed", choices=["packed", "four"],
                     help="record arrays handed to the library: 'packed' = 16 B/record (slimm_set_records_device_packed: key with "
                          "the three flag bits folded in, ref, pos), 'four' = 18 B/record (key, ref, pos, flag)")
@@ -456,6 +459,67 @@ def main():
                                                 "ms_per_file": round(dt_pipe * 1e3, 3),
                                                 "what": f"{n_files} files, two contexts alternating: a file's copy overlaps the "
                                                         "phases of the file before (the command's -d mode)"}}
+        # ---- the same stream as RUN-MARKED records (8 B/record: reference + 1 | mate | "a qName run starts here", position):
+        # what a producer of name-grouped input can hand over instead of hashed names (include/slimm_hip.h).  The words are
+        # built on the device from the packed arrays; resident rate, k_front under 8 N + 8 P, and the push-inclusive rate.
+        marked = None
+        if extras and packed and args.record_order == "grouped" and not args.no_marked:
+            word = torch.empty(n_rec, dtype=torch.int32, device=dev)
+            piece = 50_000_000
+            prev = None
+            for a in range(0, n_rec, piece):
+                b = min(n_rec, a + piece)
+                k = res.key[a:b]
+                ident = k & ((1 << 61) - 1)
+                starts = torch.ones(b - a, dtype=torch.bool, device=dev)
+                starts[1:] = ident[1:] != ident[:-1]
+                if prev is not None:
+                    starts[0] = bool(ident[0] != prev)
+                prev = ident[-1].clone()
+                r1 = torch.where((k < 0) | (res.ref[a:b] < 0), 0, res.ref[a:b].to(torch.int64) + 1)
+                word[a:b] = (r1 | (((k >> 61) & 3) << 29) | (starts.to(torch.int64) << 31)).to(torch.int32)
+                del k, ident, starts, r1
+            torch.cuda.synchronize()
+
+            def step_marked():
+                eng.reset()
+                eng.reset_cutoffs()
+                eng.set_records_device_marked(word, res.pos)
+                return sharded_profile(eng, dev, out_path, exchange=args.exchange)
+
+            m_steps = max(3, args.steps // 2)
+            el_m, kt_m, _, prof_m = measure(eng, step_marked, m_steps, 2, barrier)
+            assert prof_m == profile, "the run-marked records must give the packed records' profile"
+            kf_ms = kt_m["k_front"][0] / max(1, kt_m["k_front"][1])
+            P = int(st["n_targets"])
+            bytes_m = 8 * n_rec + 8 * P
+            marked = {"value": round(n_rec / (el_m / m_steps) / 1e6, 3), "unit": "M records/s", "ms_per_step": round(el_m / m_steps * 1e3, 4),
+                      "steps": m_steps, "records": "resident in HBM, run-marked form (8 B/record); same profile as the headline's",
+                      "k_front": {"ms_per_launch": round(kf_ms, 4), "bytes_per_launch": bytes_m,
+                                  "bytes_model": f"8 B x {n_rec} records + 8 B x {P} targets",
+                                  "achieved": round(bytes_m / (kf_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                  "frac": round(bytes_m / (kf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            if want_push:
+                hw = torch.empty(n_rec, dtype=torch.int32).pin_memory()
+                hw.copy_(word)
+                torch.cuda.synchronize()
+                hwn, hpn = hw.numpy().view(np.uint32), res.host[2].numpy()
+                single = []
+                for i in range(3):               # (the first pass warms the library's buffers up)
+                    eng.reset()
+                    eng.reset_cutoffs()
+                    t1 = time.perf_counter()
+                    eng.push_records_marked_async(hwn, hpn)
+                    eng.get_profiles(path=out_path)
+                    if i:
+                        single.append(time.perf_counter() - t1)
+                dt = min(single)
+                marked["with_push"] = {"value": round(n_rec / dt / 1e6, 3), "unit": "M records/s", "ms_per_step": round(dt * 1e3, 3),
+                                       "gb_per_s_over_pcie": round(8 * n_rec / dt / 1e9, 2),
+                                       "what": "ONE file: clock from before slimm_push_records_marked_async (page-locked host "
+                                               "memory, 8 B/record over PCIe) to the profile file written; best of 2"}
+                del hw
+            del word
         eng.close()
         del res
         torch.cuda.empty_cache()
@@ -607,6 +671,7 @@ def main():
             "roofline": roofline,
             "value_resident": round(value, 3),
             "value_with_push": with_push,
+            "run_marked_records": marked,
             "roofline_config2": legs.get("config2"), "roofline_config3": legs.get("config3"), "roofline_config5": legs.get("config5"),
             "cpu_baseline": cpu,
             "cpu_baseline_mt": cpu_mt,

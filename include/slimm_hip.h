@@ -139,6 +139,25 @@ int slimm_push_records_packed_async(slimm_ctx* ctx, const uint64_t* packed_key, 
                                     const int32_t* begin_pos, uint64_t n);
 int slimm_set_records_device_packed(slimm_ctx* ctx, const uint64_t* d_packed_key, const int32_t* d_ref_id,
                                     const int32_t* d_begin_pos, uint64_t n);
+/* RUN-MARKED records, 8 bytes each, for input grouped by read name (record_order = SLIMM_ORDER_GROUPED; anything else is
+ * refused).  With the records of a name adjacent, the read identity the reference keys its hash map with (src/slimm.hpp:
+ * 204-211) is "the qName run this record lies in" -- the device needs no name, only where a run starts.  A record is
+ *   word      = reference id + 1 (0: not mapped -- the unmapped flag, src/slimm.hpp:197, or reference -1)
+ *               | mate number << 29 (0 / 1 / 2, src/slimm.hpp:205-208) | (this record's qName differs from the one
+ *               before it, or it is the file's first) << 31
+ *   begin_pos
+ * and the producer compares adjacent names instead of hashing them.  slimm_mark_word builds one word, slimm_mark_words
+ * a batch from the four-array form (run starts where adjacent keys differ; *prev_key = the key in front of the batch,
+ * NULL at the start of a file).  Half the bytes of the packed form cross the bus and are read by the front end.  What the
+ * form gives up: there are no names to check -- slimm_check_grouping and the *_checked pushes do not apply -- and a file
+ * is this form throughout.  _async / set_records_device / staged: as for the packed form (a staging set's ref_id array
+ * holds the words). */
+uint32_t slimm_mark_word(int32_t ref_id, uint16_t flag, int starts_run);
+void slimm_mark_words(const uint64_t* read_key, const uint16_t* flag, const int32_t* ref_id, uint64_t n, const uint64_t* prev_key,
+                      uint32_t* word);
+int slimm_push_records_marked(slimm_ctx* ctx, const uint32_t* word, const int32_t* begin_pos, uint64_t n);
+int slimm_push_records_marked_async(slimm_ctx* ctx, const uint32_t* word, const int32_t* begin_pos, uint64_t n);
+int slimm_set_records_device_marked(slimm_ctx* ctx, const uint32_t* d_word, const int32_t* d_begin_pos, uint64_t n);
 /* Streamed ingest.  slimm_push_records_async enqueues the copies on the context's copy stream and returns at once:
  * the arrays must stay unchanged until slimm_push_wait() returns (page-locked arrays are read by the DMA engine
  * directly; pageable ones still work, at the speed of the runtime's own staging).  slimm_analyze_alignments() is
@@ -157,6 +176,8 @@ int slimm_push_staged_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
 /* The same for a set whose key array the producer filled with PACKED keys (slimm_pack_key; the set's flag array is not
  * read): 16 bytes per record over the bus. */
 int slimm_push_staged_packed_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
+/* ... and for a set whose ref_id array holds run-marked words (slimm_mark_word; key and flag arrays are not read). */
+int slimm_push_staged_marked_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
 int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
 /* Use records already resident in device memory, without copying; the arrays must stay valid and unchanged
  * until slimm_reset().  Replaces anything pushed before. */
@@ -375,6 +396,8 @@ int slimm_group_push_records(slimm_group* g, const uint64_t* read_key, const int
 /* Packed 16-byte records (slimm_push_records_packed; the identity of a read name is the key's low 61 bits). */
 int slimm_group_push_records_packed(slimm_group* g, const uint64_t* packed_key, const int32_t* ref_id, const int32_t* begin_pos,
                                     uint64_t n);
+/* Run-marked 8-byte records (slimm_push_records_marked; groups created for grouped input): whole runs go to one member. */
+int slimm_group_push_records_marked(slimm_group* g, const uint32_t* word, const int32_t* begin_pos, uint64_t n);
 /* With a check word per record (slimm_push_records_checked): two names that collide in the key land on the same member
  * whichever way the records are dealt, so a group reports SLIMM_E_KEY_COLLISION exactly where one context would. */
 int slimm_group_push_records_checked(slimm_group* g, const uint64_t* read_key, const int32_t* ref_id, const int32_t* begin_pos,

@@ -89,6 +89,13 @@ SYMBOLS = [
     ("slimm_group_get_profiles", C.c_int, [_P, C.c_char_p]),
     ("slimm_group_push_records_checked", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_uint64]),
     ("slimm_group_push_records_packed", C.c_int, [_P, _P, _P, _P, C.c_uint64]),
+    ("slimm_group_push_records_marked", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("slimm_mark_word", C.c_uint32, [C.c_int32, C.c_uint16, C.c_int]),
+    ("slimm_mark_words", None, [_P, _P, _P, C.c_uint64, _P, _P]),
+    ("slimm_push_records_marked", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("slimm_push_records_marked_async", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("slimm_set_records_device_marked", C.c_int, [_P, _P, _P, C.c_uint64]),
+    ("slimm_push_staged_marked_async", C.c_int, [_P, C.c_uint32, C.c_uint64]),
     ("slimm_group_set_exchange", C.c_int, [_P, C.c_int]),
     ("slimm_group_exchange", C.c_int, [_P]),
     ("slimm_uniq_cov2_buffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),

@@ -127,6 +127,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> in_check;     // slimm_push_records_checked: a second hash of every record's read name
     bool has_check = false;        // ... all pushed batches carry one (checked and unchecked pushes do not mix)
     bool packed = false;           // slimm_push_records_packed: 16 bytes per record, no flag array (forms do not mix)
+    bool marked = false;           // slimm_push_records_marked: 8 bytes per record, no key array (grouped input only)
     DevBuf<uint64_t> un_key;       // record_order = ANY with packed records: the four-array form for the compaction
     DevBuf<uint16_t> un_flag;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
@@ -611,6 +612,7 @@ int slimm_reset(slimm_ctx* c) {
     c->n_pushed = 0;
     c->has_check = false;
     c->packed = false;
+    c->marked = false;
     c->borrowed = false;
     c->rec = DeviceRecords();
     c->local_V = c->local_M = c->local_P = 0;
@@ -687,7 +689,8 @@ int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
     if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
-    if (c->packed) return fail(c, SLIMM_E_INVALID, "earlier batches were packed records: the forms do not mix within a file");
+    if (c->packed || c->marked)
+        return fail(c, SLIMM_E_INVALID, "earlier batches were packed or run-marked records: the forms do not mix within a file");
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));  // (only ever at a file's first push)
@@ -717,7 +720,8 @@ int slimm_push_records_checked(slimm_ctx* c, const uint64_t* key, const int32_t*
     if (!key || !ref || !pos || !flag || !check) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
     if (c->n_pushed && !c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried no check words");
-    if (c->packed) return fail(c, SLIMM_E_INVALID, "earlier batches were packed records: the forms do not mix within a file");
+    if (c->packed || c->marked)
+        return fail(c, SLIMM_E_INVALID, "earlier batches were packed or run-marked records: the forms do not mix within a file");
     c->has_check = true;
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
@@ -751,7 +755,8 @@ int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* r
     if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
     if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
-    if (c->packed) return fail(c, SLIMM_E_INVALID, "earlier batches were packed records: the forms do not mix within a file");
+    if (c->packed || c->marked)
+        return fail(c, SLIMM_E_INVALID, "earlier batches were packed or run-marked records: the forms do not mix within a file");
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));
@@ -778,7 +783,7 @@ static int push_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     if (n == 0) return SLIMM_OK;
     if (!key || !ref || !pos) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->has_check || (c->n_pushed && !c->packed))
+    if (c->has_check || c->marked || (c->n_pushed && !c->packed))
         return fail(c, SLIMM_E_INVALID, "earlier batches were not packed records: the forms do not mix within a file");
     c->packed = true;
     int rc = slimm_reserve(c, c->n_pushed + n);
@@ -815,6 +820,60 @@ uint64_t slimm_pack_key(uint64_t read_key, uint16_t flag) {  // src/slimm.hpp:19
 }
 void slimm_pack_keys(const uint64_t* read_key, const uint16_t* flag, uint64_t n, uint64_t* packed) {
     for (uint64_t i = 0; i < n; ++i) packed[i] = slimm_pack_key(read_key[i], flag[i]);
+}
+
+// 8 bytes per record: for input grouped by read name the device never needs the names, only where a run of equal names
+// starts -- the producer compares adjacent names instead of hashing them, and no key array crosses the bus or is read by
+// the front end (front.hip: FrontMarked).
+static int push_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n, bool on_copy_stream) {
+    if (!c) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!word || !pos) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->order != SLIMM_ORDER_GROUPED)
+        return fail(c, SLIMM_E_INVALID, "run-marked records carry no read identity: the context must be created for input grouped by name");
+    if (c->has_check || c->packed || (c->n_pushed && !c->marked))
+        return fail(c, SLIMM_E_INVALID, "earlier batches were not run-marked records: the forms do not mix within a file");
+    c->marked = true;
+    int rc = slimm_reserve(c, c->n_pushed + n);
+    if (rc != SLIMM_OK) return rc;
+    const uint64_t o = c->n_pushed;
+    hipStream_t st = on_copy_stream ? c->copy_stream : c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, word, n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, st));
+    if (on_copy_stream) {
+        HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
+        c->copy_pending = true;
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may reuse its buffers on return
+    }
+    c->n_pushed += n;
+    c->rec = DeviceRecords();
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.marked = true;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    return SLIMM_OK;
+}
+int slimm_push_records_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n) {
+    return push_marked(c, word, pos, n, false);
+}
+int slimm_push_records_marked_async(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n) {
+    return push_marked(c, word, pos, n, true);
+}
+uint32_t slimm_mark_word(int32_t ref_id, uint16_t flag, int starts_run) {  // src/slimm.hpp:197 (mapped), :205-208 (mate number)
+    const uint32_t mate = (flag & 0x40u) ? 1u : ((flag & 0x80u) ? 2u : 0u);
+    const bool mapped = !(flag & 0x4u) && ref_id != -1;
+    // (a reference that is neither -1 nor an index of the table keeps its out-of-range value: the front end reports it)
+    const uint32_t r1 = mapped ? std::min<uint32_t>(static_cast<uint32_t>(ref_id) + 1u, 0x1fffffffu) : 0u;
+    return r1 | (mate << 29) | (starts_run ? 0x80000000u : 0u);
+}
+void slimm_mark_words(const uint64_t* read_key, const uint16_t* flag, const int32_t* ref_id, uint64_t n, const uint64_t* prev_key,
+                      uint32_t* word) {
+    for (uint64_t i = 0; i < n; ++i) {
+        const bool starts = i ? read_key[i] != read_key[i - 1] : (!prev_key || read_key[0] != *prev_key);
+        word[i] = slimm_mark_word(ref_id[i], flag[i], starts ? 1 : 0);
+    }
 }
 
 int slimm_push_wait(slimm_ctx* c) {
@@ -872,6 +931,18 @@ int slimm_push_staged_packed_async(slimm_ctx* c, uint32_t which, uint64_t n) {  
     return SLIMM_OK;
 }
 
+int slimm_push_staged_marked_async(slimm_ctx* c, uint32_t which, uint64_t n) {  // the set's ref array holds the words
+    if (!c || which > 1) return SLIMM_E_INVALID;
+    slimm_ctx::Staging& sg = c->staging[which];
+    if (n > sg.key.cap) return fail(c, SLIMM_E_INVALID, "more records than the staging set holds");
+    if (n == 0) return SLIMM_OK;
+    int rc = push_marked(c, reinterpret_cast<const uint32_t*>(sg.ref.p), sg.pos.p, n, true);
+    if (rc != SLIMM_OK) return rc;
+    HIP_TRY(c, hipEventRecord(sg.done, c->copy_stream));
+    sg.pending = true;
+    return SLIMM_OK;
+}
+
 int slimm_staging_wait(slimm_ctx* c, uint32_t which) {
     if (!c || which > 1) return SLIMM_E_INVALID;
     slimm_ctx::Staging& sg = c->staging[which];
@@ -917,6 +988,25 @@ int slimm_set_records_device_packed(slimm_ctx* c, const uint64_t* key, const int
     return SLIMM_OK;
 }
 
+int slimm_set_records_device_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
+    if (n && (!word || !pos)) return fail(c, SLIMM_E_INVALID, "null record array");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->order != SLIMM_ORDER_GROUPED)
+        return fail(c, SLIMM_E_INVALID, "run-marked records carry no read identity: the context must be created for input grouped by name");
+    c->rec = DeviceRecords();
+    c->rec.ref = reinterpret_cast<const int32_t*>(word);
+    c->rec.pos = pos;
+    c->rec.marked = true;
+    c->rec.n = static_cast<uint32_t>(n);
+    c->n_pushed = n;
+    c->marked = true;
+    c->borrowed = true;
+    return SLIMM_OK;
+}
+
 // Is the stream really grouped by read name?  See k_check_grouping (kernels.hip).
 int slimm_check_grouping(slimm_ctx* c, uint64_t* n_split_names) {
     if (!c || !n_split_names) return SLIMM_E_INVALID;
@@ -924,6 +1014,7 @@ int slimm_check_grouping(slimm_ctx* c, uint64_t* n_split_names) {
     *n_split_names = 0;
     const uint32_t n = c->rec.n;
     if (n == 0) return SLIMM_OK;
+    if (c->rec.marked) return fail(c, SLIMM_E_INVALID, "run-marked records carry no read names to check");
     (void)hipSetDevice(c->device);
     if (c->copy_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
     uint64_t cap = 1024;

@@ -191,7 +191,13 @@ struct FrontRawT {
     const uint2* geo;  // {contig length, first bin} per reference
     uint32_t n, n_refs, half_read, bin_width, bw_magic;
     static constexpr bool kCountsMapped = true;   // hits_count (src/slimm.hpp:212) is counted here
+    static constexpr bool kMarked = false;        // run starts come from comparing adjacent keys
     __device__ uint32_t count(const uint32_t*) const { return n; }
+    __device__ bool same_run(uint32_t i, uint32_t, uint32_t klo0, uint32_t khi0) const {
+        uint32_t lo, hi;
+        key_at(i, lo, hi);
+        return lo == klo0 && hi == khi0;
+    }
     // qName identity (the top two bits of the key are not significant)
     __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
         const uint64_t k = key[i];
@@ -285,7 +291,13 @@ struct FrontSorted {
     const uint32_t* cgbin;
     const uint32_t* check;  // optional, sorted along with the records
     static constexpr bool kCountsMapped = false;  // the compaction counted the mapped records
+    static constexpr bool kMarked = false;
     __device__ uint32_t count(const uint32_t* counters) const { return counters[CNT_V]; }
+    __device__ bool same_run(uint32_t i, uint32_t, uint32_t klo0, uint32_t khi0) const {
+        uint32_t lo, hi;
+        key_at(i, lo, hi);
+        return lo == klo0 && hi == khi0;
+    }
     __device__ void key_at(uint32_t i, uint32_t& lo, uint32_t& hi) const {
         const uint64_t k = ident[i];
         lo = static_cast<uint32_t>(k) & ~3u;
@@ -324,6 +336,70 @@ struct FrontSorted {
     }
     __device__ bool out_of_range(uint32_t) const { return false; }
     __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2&) const { return w.c; }
+};
+
+// Run-marked records, 8 bytes each (slimm_push_records_marked): for input that is grouped by qName the device never
+// needed the names -- only where a run of equal names starts.  word = reference + 1 (0: not mapped: the unmapped flag or
+// reference -1, src/slimm.hpp:197) | mate number << 29 (src/slimm.hpp:205-208) | "this record starts a qName run" << 31;
+// no key array crosses the bus or is read by the front end.
+struct FrontMarked {
+    const uint32_t* word;
+    const int32_t* pos;
+    const uint32_t* check = nullptr;  // (none in this form)
+    const uint2* geo;  // {contig length, first bin} per reference
+    uint32_t n, n_refs, half_read, bin_width, bw_magic;
+    static constexpr bool kCountsMapped = true;
+    static constexpr bool kMarked = true;
+    static constexpr uint32_t kRefBits = 0x1fffffffu;
+    __device__ uint32_t count(const uint32_t*) const { return n; }
+    __device__ void key_at(uint32_t, uint32_t& lo, uint32_t& hi) const { lo = hi = 0u; }
+    // record i belongs to the run that starts at record `first`
+    __device__ bool same_run(uint32_t i, uint32_t first, uint32_t, uint32_t) const {
+        return i == first || static_cast<int32_t>(word[i]) >= 0;
+    }
+    __device__ FrontRaw3 raw(uint32_t i) const { return FrontRaw3{word[i], (word[i] & kRefBits) - 1u, static_cast<uint32_t>(pos[i])}; }
+    __device__ void load(uint32_t base, uint32_t rel, FrontLoaded& o) const {
+        o.klo = o.khi = 0u;
+        o.a = f_load_at(word + base, rel * 4u);
+        o.b = (o.a & kRefBits) - 1u;  // the reference (0xffffffff: none)
+        o.c = static_cast<uint32_t>(f_load_at(pos + base, rel * 4u));
+    }
+    __device__ void load_key(uint32_t, uint32_t, uint32_t& lo, uint32_t& hi) const { lo = hi = 0u; }
+    __device__ static void key_fix(uint32_t&, uint32_t&) {}
+    __device__ uint32_t load_check(uint32_t, uint32_t) const { return 0u; }
+    __device__ static void no_key(uint32_t& lo, uint32_t& hi) { lo = hi = 1u; }
+    __device__ uint2 geo_at(const FrontLoaded& w) const { return f_load_at(geo, (w.b < n_refs ? w.b : 0u) * 8u); }
+    __device__ void fields(const FrontLoaded& w, uint32_t& field, uint32_t& mate, uint32_t& worst) const {
+        const uint32_t t = w.a & kRefBits;  // reference + 1
+        worst = max(worst, t);
+        field = (t - 1u < n_refs) ? t : kRefField;
+        mate = (w.a >> 29) & 3u;
+    }
+    __device__ static bool starts_run(const FrontLoaded& w) { return static_cast<int32_t>(w.a) < 0; }
+    __device__ bool out_of_range(uint32_t worst) const { return worst > n_refs; }
+    __device__ uint32_t div_bin_width(uint32_t v) const {
+        const uint32_t q = __umulhi(v, bw_magic);
+        const uint32_t r = v - q * bin_width;
+        return q + (r >= bin_width ? 1u : 0u);
+    }
+    __device__ uint32_t gbin_of(const FrontLoaded& w, const uint2& g) const {
+        return g.y + div_bin_width(min(w.c + half_read, g.x));
+    }
+    __device__ FrontRec decode(const FrontRaw3& w, bool& bad) const {
+        FrontRec o;
+        o.mate = (w.a >> 29) & 3u;
+        o.mapped = w.b != 0xffffffffu;
+        if (o.mapped && w.b >= n_refs) {
+            bad = true;
+            o.mapped = false;
+        }
+        o.ref = w.b;
+        o.aux = w.c;
+        return o;
+    }
+    __device__ FrontRec rec(uint32_t i, bool& bad) const { return decode(raw(i), bad); }
+    __device__ uint2 geo_of(const FrontRaw3& w) const { return geo[w.b < n_refs ? w.b : 0u]; }
+    __device__ uint32_t gbin(const FrontRec& r, const uint2& g) const { return g.y + div_bin_width(min(r.aux + half_read, g.x)); }
 };
 
 namespace {
@@ -499,11 +575,10 @@ __device__ __forceinline__ uint32_t long_run(const Acc& acc, uint32_t pos, uint3
         const uint32_t i = end + lane;
         const bool live = i < N;
         bool b = false;
-        uint32_t klo, khi;
-        acc.key_at(live ? i : N - 1u, klo, khi);
+        const bool mine = acc.same_run(live ? i : N - 1u, pos, klo0, khi0);
         const FrontRec r = acc.rec(live ? i : N - 1u, b);
-        const uint64_t same = f_ballot(live && klo == klo0 && khi == khi0);
-        if (kChk) collide = collide | (live && klo == klo0 && khi == khi0 && acc.check[i] != acc.check[pos]);
+        const uint64_t same = f_ballot(live && mine);
+        if (kChk) collide = collide | (live && mine && acc.check[i] != acc.check[pos]);
         const uint32_t n_same = static_cast<uint32_t>(__builtin_ctzll(~same | (1ull << 63)));  // lanes before the first other key
         const bool whole = (~same) == 0ull;
         const uint32_t n_in = whole ? 64u : n_same;
@@ -716,8 +791,8 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
     // The key in front of every record: the lane before's (DPP), for lane 0 the last key of the block before -- and for
     // the stretch's first block a second load of the keys, one record down, issued with the others.  (The key of record
     // B - 1 alone, loaded up front, would be a round trip of its own per slot.)
-    uint32_t plo = 0, phi = 0, q0lo, q0hi, q0chk = 0, pchk = 0;
-    {
+    uint32_t plo = 0, phi = 0, q0lo = 0, q0hi = 0, q0chk = 0, pchk = 0;
+    if (!Acc::kMarked) {
         const uint32_t pb = B > 0u ? B - 1u : 0u;                        // B == 0: lane 0 is given no_key below,
         uint32_t rel = (B == 0u && lane != 0u) ? lane - 1u : lane;       // lane i gets key[i - 1]
         if (kClamp) rel = min(rel, N - 1u - pb);
@@ -756,7 +831,9 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
             const uint32_t g = acc.gbin_of(rec[u], geo[u]);
             const uint64_t k = (static_cast<uint64_t>(rec[u].khi) << 32) | rec[u].klo;
             uint32_t qlo, qhi, qchk;
-            if (j == 0u) {
+            if (Acc::kMarked) {
+                qlo = qhi = qchk = 0u;
+            } else if (j == 0u) {
                 qlo = q0lo;
                 qhi = q0hi;
                 qchk = q0chk;
@@ -777,12 +854,19 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
                 collide = collide | here;
                 pchk = static_cast<uint32_t>(__builtin_amdgcn_readlane(chk[u], 63));
             }
-            uint32_t w = field | (mate << kStMateShift) | (k != q ? kStRunStart : 0u);
+            bool starts;
+            if constexpr (Acc::kMarked)
+                starts = Acc::starts_run(rec[u]) || (B == 0u && j == 0u && lane == 0u);  // (the stream's first record does)
+            else
+                starts = k != q;
+            uint32_t w = field | (mate << kStMateShift) | (starts ? kStRunStart : 0u);
             if (kClamp && 64u * j + lane >= N - B) w = kRefField;
             st1[64u * j + lane] = w;
             st2[64u * j + lane] = g;
-            plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].klo, 63));
-            phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].khi, 63));
+            if (!Acc::kMarked) {
+                plo = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].klo, 63));
+                phi = static_cast<uint32_t>(__builtin_amdgcn_readlane(rec[u].khi, 63));
+            }
         }
     }
     bad = bad | acc.out_of_range(worst);
@@ -948,7 +1032,19 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
     a.bw_magic = bin_width ? 0xffffffffu / bin_width : 0u;
     // (t0 / t1, when given: the dispatch's own start and end time stamps -- what rocprofv3 reports as the kernel's
     // duration; events recorded around the launch add the 4 - 6 us it takes a dependent dispatch to start)
-    if (in.packed) {  // (same members, other accessors)
+    if (in.marked) {
+        FrontMarked m;
+        m.word = reinterpret_cast<const uint32_t*>(in.ref);
+        m.pos = in.pos;
+        m.geo = geo;
+        m.n = in.n;
+        m.n_refs = n_refs;
+        m.half_read = half_read;
+        m.bin_width = bin_width;
+        m.bw_magic = a.bw_magic;
+        hipExtLaunchKernelGGL((k_front<FrontMarked, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, m, ns,
+                              counters, tgt_ref, tgt_gbin, slots, wcut);
+    } else if (in.packed) {  // (same members, other accessors)
         FrontPacked b;
         b.key = a.key, b.ref = a.ref, b.pos = a.pos, b.flag = nullptr, b.check = a.check, b.geo = a.geo, b.n = a.n;
         b.n_refs = a.n_refs, b.half_read = a.half_read, b.bin_width = a.bin_width, b.bw_magic = a.bw_magic;

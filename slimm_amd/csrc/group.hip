@@ -104,6 +104,7 @@ struct slimm_group {
     std::vector<int32_t> carry_ref, carry_pos;
     std::vector<uint16_t> carry_flag;
     std::vector<uint32_t> carry_check;       // (streams pushed with check words)
+    std::vector<uint32_t> carry_word;        // (run-marked records: the words; their positions in carry_pos)
     int checked = -1;                        // -1: nothing pushed yet, 0 / 1: the file's pushes carry no / carry check words
     int exchange = SLIMM_EXCHANGE_AUTO;
     uint32_t n_refs = 0;
@@ -295,6 +296,12 @@ int push_to(slimm_group* g, uint32_t i, const uint64_t* key, const int32_t* ref,
 }
 
 int flush_carry(slimm_group* g, uint32_t to) {
+    if (!g->carry_word.empty()) {
+        GTRY(g, to, slimm_push_records_marked(g->ctx[to], g->carry_word.data(), g->carry_pos.data(), g->carry_word.size()));
+        g->carry_word.clear();
+        g->carry_pos.clear();
+        return SLIMM_OK;
+    }
     if (g->carry_key.empty()) return SLIMM_OK;
     int rc = push_to(g, to, g->carry_key.data(), g->carry_ref.data(), g->carry_pos.data(),
                      g->carry_flag.empty() ? nullptr : g->carry_flag.data(),
@@ -366,6 +373,40 @@ int deal(slimm_group* g, const uint64_t* key, const int32_t* ref, const int32_t*
     g->carry_pos.assign(pos + last_start, pos + n);
     if (flag) g->carry_flag.assign(flag + last_start, flag + n);
     if (check) g->carry_check.assign(check + last_start, check + n);
+    g->cur = (g->cur + 1) % m;
+    return SLIMM_OK;
+}
+
+// Run-marked records: the same contiguous stretches, cut where a word says a run starts.
+int deal_marked(slimm_group* g, const uint32_t* word, const int32_t* pos, uint64_t n) {
+    if (!g) return SLIMM_E_INVALID;
+    if (n == 0) return SLIMM_OK;
+    if (!word || !pos) return gfail(g, SLIMM_E_INVALID, "null record array");
+    if (g->order != SLIMM_ORDER_GROUPED)
+        return gfail(g, SLIMM_E_INVALID, "run-marked records carry no read identity: the group must be created for input grouped by name");
+    if (g->checked >= 0 && g->checked != 3)
+        return gfail(g, SLIMM_E_INVALID, "run-marked and other pushes do not mix within a file");
+    g->checked = 3;
+    const uint32_t m = static_cast<uint32_t>(g->ctx.size());
+    if (m == 1) {
+        GTRY(g, 0, slimm_push_records_marked(g->ctx[0], word, pos, n));
+        return SLIMM_OK;
+    }
+    int rc = flush_carry(g, g->cur);  // the run the batch before ended in goes where this batch's head goes
+    if (rc != SLIMM_OK) return rc;
+    uint64_t last_start = 0;  // index of the batch's last run start behind its first record, 0 = none
+    for (uint64_t i = n; i-- > 1;)
+        if (word[i] >> 31) {
+            last_start = i;
+            break;
+        }
+    if (last_start == 0) {  // no boundary inside the batch: it stays with the current member, and so does what continues it
+        GTRY(g, g->cur, slimm_push_records_marked(g->ctx[g->cur], word, pos, n));
+        return SLIMM_OK;
+    }
+    GTRY(g, g->cur, slimm_push_records_marked(g->ctx[g->cur], word, pos, last_start));
+    g->carry_word.assign(word + last_start, word + n);
+    g->carry_pos.assign(pos + last_start, pos + n);
     g->cur = (g->cur + 1) % m;
     return SLIMM_OK;
 }
@@ -474,6 +515,7 @@ int slimm_group_reset(slimm_group* g) {
     g->carry_pos.clear();
     g->carry_flag.clear();
     g->carry_check.clear();
+    g->carry_word.clear();
     g->checked = -1;
     g->have_last = false;
     return SLIMM_OK;
@@ -491,6 +533,9 @@ int slimm_group_push_records_checked(slimm_group* g, const uint64_t* key, const 
 }
 int slimm_group_push_records_packed(slimm_group* g, const uint64_t* packed_key, const int32_t* ref, const int32_t* pos, uint64_t n) {
     return deal(g, packed_key, ref, pos, nullptr, nullptr, n);
+}
+int slimm_group_push_records_marked(slimm_group* g, const uint32_t* word, const int32_t* pos, uint64_t n) {
+    return deal_marked(g, word, pos, n);
 }
 int slimm_group_set_exchange(slimm_group* g, int mode) {
     if (!g || mode < SLIMM_EXCHANGE_AUTO || mode > SLIMM_EXCHANGE_BINS) return SLIMM_E_INVALID;

@@ -89,6 +89,8 @@ struct DeviceRecords {
     const uint32_t* check = nullptr;  // optional second hash of the read name: equal keys must carry equal checks
     uint32_t n = 0;
     bool packed = false;  // 16 bytes per record: flag == nullptr, the key's top three bits are {unmapped, mate number}
+    bool marked = false;  // 8 bytes per record (grouped input only): key == flag == nullptr, `ref` holds the words
+                          // reference + 1 | mate << 29 | starts a qName run << 31 (slimm_push_records_marked)
 };
 
 uint32_t num_tiles(uint32_t n);

@@ -668,23 +668,27 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
         const typename Rows::Row first = Rows::from_lane(row, fvl << 2);
         bool ne[8];
         Rows::differ(row, first, ne);
-        // the lanes above this one that still belong to its read: those below the next head
-        const uint64_t Hn = H & ~le;
-        const uint64_t mine = ~le & ~Hn & (Hn - 1ull) & PR;
+        // Per level: D = the valid lanes that differ from their read's first valid one; the nearest first-valid lane at
+        // or below a D lane is its own read's, so the OWNERS with a differing lane come out of one carry chain on the
+        // scalar unit (k_head_of) and a lane learns its level from one select per level -- not, per lane and level, from
+        // 64-bit masks of "the lanes above me in my read" (two vector instructions per 64-bit operation: the kernel is
+        // bound by its vector instructions per window).
+        const uint64_t fvr = __builtin_bitreverse64(FV), nfvr = ~fvr;
+        auto owners_of = [&](uint64_t D) { return __builtin_bitreverse64((nfvr + __builtin_bitreverse64(D)) & fvr); };
         uint32_t lv = 8u;  // src/slimm.hpp:516-531: the first level (from the leaves) on which all valid targets agree
         // (most reads agree within a few levels of the leaves: the four upper levels are looked at only when some read of
         // the window has found none among the four lower ones -- config 2 -5 %, config 5 -12 %; two / two / four: no better)
 #pragma unroll
         for (int l = 3; l >= 0; --l) {
-            const uint64_t D = k_ballot(ne[l]) & VB;
-            lv = (D & mine) == 0ull ? static_cast<uint32_t>(l) : lv;
+            const uint64_t bad = owners_of(k_ballot(ne[l]) & VB);
+            lv = k_bit(bad) ? lv : static_cast<uint32_t>(l);
         }
         if (k_ballot(lv == 8u) & OW) {
             uint32_t up = 8u;
 #pragma unroll
             for (int l = 7; l >= 4; --l) {
-                const uint64_t D = k_ballot(ne[l]) & VB;
-                up = (D & mine) == 0ull ? static_cast<uint32_t>(l) : up;
+                const uint64_t bad = owners_of(k_ballot(ne[l]) & VB);
+                up = k_bit(bad) ? up : static_cast<uint32_t>(l);
             }
             lv = lv == 8u ? up : lv;
         }

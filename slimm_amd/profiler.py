@@ -190,6 +190,51 @@ class Slimm:
         self._check(self.L.slimm_set_records_device_packed(self.ctx, C.c_void_p(packed_key.data_ptr()),
                                                            C.c_void_p(ref.data_ptr()), C.c_void_p(pos.data_ptr()), n))
 
+    # ---- run-marked records: 8 bytes each, grouped input only (include/slimm_hip.h)
+    @staticmethod
+    def mark_words(read_key: np.ndarray, flag: np.ndarray, ref_id: np.ndarray, prev_key: Optional[int] = None) -> np.ndarray:
+        """slimm_mark_words: reference + 1 | mate << 29 | starts-a-qName-run << 31 per record."""
+        read_key = np.ascontiguousarray(read_key, dtype=np.uint64)
+        flag = np.ascontiguousarray(flag, dtype=np.uint16)
+        ref_id = np.ascontiguousarray(ref_id, dtype=np.int32)
+        out = np.empty(read_key.shape[0], dtype=np.uint32)
+        pk = C.c_uint64(prev_key) if prev_key is not None else None
+        capi.lib().slimm_mark_words(_p(read_key), _p(flag), _p(ref_id), read_key.shape[0], C.byref(pk) if pk is not None else None,
+                                    _p(out))
+        return out
+
+    def push_records_marked(self, rec: Records, batch: int = 0, words: Optional[np.ndarray] = None):
+        w = self.mark_words(rec.read_key, rec.flag, rec.ref_id) if words is None else words
+        n = len(rec)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_push_records_marked(self.ctx, _p(w[s:e]), _p(rec.begin_pos[s:e]), e - s))
+
+    def push_records_marked_async(self, words, pos):
+        self._keepalive = (words, pos)
+        self._check(self.L.slimm_push_records_marked_async(self.ctx, _p(words), _p(pos), len(words)))
+
+    def push_records_marked_streamed(self, rec: Records, batch: int = 1 << 20):
+        """slimm_push_staged_marked_async over the two staging sets (the words go into the sets' ref_id arrays)."""
+        n = len(rec)
+        w = self.mark_words(rec.read_key, rec.flag, rec.ref_id)
+        sets = [self.staging(0, batch), self.staging(1, batch)]
+        for i, s in enumerate(range(0, n, batch)):
+            e = min(n, s + batch)
+            which = i & 1
+            self._check(self.L.slimm_staging_wait(self.ctx, which))
+            _, r, p, _ = sets[which]
+            r[: e - s] = w[s:e].view(np.int32)
+            p[: e - s] = rec.begin_pos[s:e]
+            self._check(self.L.slimm_push_staged_marked_async(self.ctx, which, e - s))
+
+    def set_records_device_marked(self, words, pos):
+        """torch tensors on this context's device: int32/uint32 words, int32 pos."""
+        n = int(words.shape[0])
+        self._keepalive = (words, pos)
+        self._check(self.L.slimm_set_records_device_marked(self.ctx, C.c_void_p(words.data_ptr()), C.c_void_p(pos.data_ptr()), n))
+
     def push_wait(self):
         self._check(self.L.slimm_push_wait(self.ctx))
 
@@ -521,6 +566,14 @@ class SlimmGroup:
             e = min(n, s + step)
             self._check(self.L.slimm_group_push_records_packed(self.g, _p(pk[s:e]), _p(rec.ref_id[s:e]), _p(rec.begin_pos[s:e]),
                                                                e - s))
+
+    def push_records_marked(self, rec: Records, batch: int = 0):
+        w = Slimm.mark_words(rec.read_key, rec.flag, rec.ref_id)
+        n = len(rec)
+        step = batch or max(n, 1)
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            self._check(self.L.slimm_group_push_records_marked(self.g, _p(w[s:e]), _p(rec.begin_pos[s:e]), e - s))
 
     EXCHANGES = {"auto": 0, "summary": 1, "sliced": 2, "bins": 3}
 

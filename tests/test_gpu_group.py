@@ -234,3 +234,26 @@ def test_group_packed_push_deals_by_the_61_bit_identity(members, grouped):
     assert g.get_profiles()
     assert_matches_oracle(g.member(0), o, bins=False)
     g.close()
+
+
+@pytest.mark.parametrize("members,batch", [(1, 4000), (2, 3100), (3, 777)])
+def test_group_marked_push_deals_whole_runs(members, batch):
+    """slimm_group_push_records_marked: 8-byte records that say where a qName run starts; a batch's last run waits for
+    the next batch, every member's stretch begins at a run start."""
+    from slimm_amd import capi
+    w = make_workload(CONFIGS["config1"], seed=63)
+    o = run_workload(w, use_qnames=False, collect_bins=False)
+    g = SlimmGroup(w, [0] * members)
+    g.push_records_marked(w.records, batch=batch)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    if members > 1:
+        with pytest.raises(capi.SlimmError):
+            g.push_records(w.records)                         # forms do not mix within a file
+        shares = [g.member(i).stats()["n_records"] for i in range(members)]
+        assert sum(shares) == len(w.records) and min(shares) > 0
+    g.reset()
+    g.push_records(w.records, batch=batch)
+    assert g.get_profiles()
+    assert_matches_oracle(g.member(0), o, bins=False)
+    g.close()

@@ -1052,6 +1052,137 @@ def test_packed_records_resident_on_the_device(grouped):
         assert_matches_oracle(s, o)
 
 
+# ---------------------------------------------------------------- run-marked records: 8 bytes each, no names on the device
+def test_mark_word_layout():
+    """word = reference + 1 (0: not mapped) | mate << 29 | starts a qName run << 31 (include/slimm_hip.h)."""
+    L = capi.lib()
+    assert L.slimm_mark_word(0, 0, 0) == 1
+    assert L.slimm_mark_word(41, 0, 1) == (42 | 1 << 31)
+    assert L.slimm_mark_word(7, 0x40, 0) == (8 | 1 << 29)
+    assert L.slimm_mark_word(7, 0x80, 1) == (8 | 2 << 29 | 1 << 31)
+    assert L.slimm_mark_word(7, 0xc0, 0) == (8 | 1 << 29)              # first-in-pair wins (src/slimm.hpp:205-208)
+    assert L.slimm_mark_word(7, 0x4, 1) == 1 << 31                     # the unmapped flag (src/slimm.hpp:197)
+    assert L.slimm_mark_word(-1, 0x80, 0) == 2 << 29                   # no reference
+    key = np.array([5, 5, 9, 9, 9, 5], dtype=np.uint64)
+    flag = np.array([0, 0x40, 0, 4, 0x80, 0], dtype=np.uint16)
+    ref = np.array([1, 2, 3, 4, -1, 6], dtype=np.int32)
+    w = Slimm.mark_words(key, flag, ref)
+    assert list(w >> 31) == [1, 0, 1, 0, 0, 1]
+    assert list(w & 0x1fffffff) == [2, 3, 4, 0, 0, 7]
+    assert list(Slimm.mark_words(key, flag, ref, prev_key=5) >> 31) == [0, 0, 1, 0, 0, 1]   # the batch continues a run
+    assert list(Slimm.mark_words(key, flag, ref, prev_key=6) >> 31) == [1, 0, 1, 0, 0, 1]
+
+
+@pytest.mark.parametrize("how", ["sync", "batches", "async", "streamed"])
+def test_marked_records_equal_the_four_array_form(how):
+    """For input grouped by name the read identity is the qName run a record lies in (src/slimm.hpp:204-211 with the
+    records of a name adjacent): 8-byte records that only say where a run starts give every result of the oracle on the
+    four-array records -- pushed in one piece, in ragged batches (runs straddle them), asynchronously and through the
+    staging sets."""
+    w = make_workload(CONFIGS["config1"], seed=91)
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0)
+    r = w.records
+    words = Slimm.mark_words(r.read_key, r.flag, r.ref_id)
+    if how == "sync":
+        s.push_records_marked(r)
+    elif how == "batches":
+        s.push_records_marked(r, batch=1777)
+    elif how == "async":
+        for a in range(0, len(r), 2500):
+            s.push_records_marked_async(words[a:a + 2500].copy(), r.begin_pos[a:a + 2500].copy())
+            s.push_wait()
+    else:
+        s.push_records_marked_streamed(r, batch=3000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    with pytest.raises(capi.SlimmError):
+        s.check_grouping()                       # no names to check
+    # the context takes the other forms for its next files (and the forms do not mix within one)
+    s.reset()
+    s.push_records(r)
+    with pytest.raises(capi.SlimmError):
+        s.push_records_marked(r)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    s.reset()
+    s.push_records_marked(r, batch=5000)
+    with pytest.raises(capi.SlimmError):
+        s.push_records(r)
+    with pytest.raises(capi.SlimmError):
+        s.push_records_packed(r)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+
+
+@pytest.mark.parametrize("mk", [lambda: make_workload(CONFIGS["config2"], seed=92, n_records=400_000),
+                                lambda: make_workload(SynthConfig("c5p", 300_000, 3_000, 40.0, strain_level=True), seed=93),
+                                lambda: _interleave_mates(make_workload(SynthConfig("pairs", 150_000, 2_000, 6.0), seed=94,
+                                                                        paired_frac=0.9)),
+                                lambda: one_long_read_workload(9_000),
+                                lambda: one_long_read_workload(35_000, "last"),
+                                lambda: make_workload(SynthConfig("long", 400_000, 4_000, 300.0, strain_level=True,
+                                                                  present_frac=0.2), seed=95),
+                                lambda: make_workload(CONFIGS["config2"], seed=96, n_records=768 * 129 - 5)])
+def test_marked_records_on_larger_streams(mk):
+    """Short runs, runs of 64 records and more (hash table, staged and global long-run paths), interleaved mates, one
+    read with tens of thousands of records, a ragged last slot -- run-marked."""
+    w = mk()
+    o = run_workload(w, use_qnames=False)
+    s = Slimm.for_workload(w, device=0)
+    s.push_records_marked(w.records, batch=100_000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+
+
+def test_marked_records_edge_cases():
+    """Unmapped records inside and between runs, a reference id out of range, an all-unmapped file, a context created
+    for any record order."""
+    w = make_workload(CONFIGS["config1"], seed=97)
+    r = w.records
+    r.flag[::7] |= 4                              # unmapped records keep their place in their runs
+    r.ref_id[5::11] = -1
+    o = run_workload(w)
+    s = Slimm.for_workload(w, device=0)
+    s.push_records_marked(r, batch=999)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    s.reset()
+    words = Slimm.mark_words(r.read_key, r.flag, r.ref_id)
+    words[100] = (words[100] & np.uint32(0xe0000000)) | np.uint32(len(w.ref_names) + 5)      # no such reference
+    s.push_records_marked(r, words=words)
+    s.analyze_alignments()
+    with pytest.raises(capi.SlimmError) as e:
+        s.finish_coverage()
+    assert e.value.code == capi.E_REF_RANGE
+    s.reset()
+    none = Records(r.read_key[:500], np.full(500, 4, dtype=np.uint16), r.ref_id[:500], r.begin_pos[:500])
+    s.push_records_marked(none)
+    assert s.get_profiles() is None               # "[WARNING] No mapped reads found"
+    s.close()
+    a = Slimm.for_workload(w, device=0, grouped=False)
+    with pytest.raises(capi.SlimmError):
+        a.push_records_marked(r)                  # no read identity to sort by
+    a.close()
+
+
+def test_marked_records_resident_on_the_device():
+    import torch
+    w = make_workload(CONFIGS["config2"], seed=98, n_records=250_000)
+    o = run_workload(w, use_qnames=False)
+    r = w.records
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(a).to(dev) for a in (Slimm.mark_words(r.read_key, r.flag, r.ref_id).view(np.int32), r.begin_pos)]
+    torch.cuda.synchronize()
+    s = Slimm.for_workload(w, device=0)
+    for _ in range(2):
+        s.reset()
+        s.reset_cutoffs()
+        s.set_records_device_marked(*t)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+
+
 # ---------------------------------------------------------------- a stream declared grouped that is not (slimm_check_grouping)
 def test_check_grouping_counts_names_that_come_back():
     """GROUPED compares adjacent records only (include/slimm_hip.h): a name that re-appears after other names is two

@@ -743,6 +743,19 @@ def test_full_size_config2_bit_exact():
     assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
 
 
+def test_full_size_config2_and_5_as_run_marked_records():
+    """The 8-byte run-marked form (slimm_push_records_marked) at full size: configs[1] (10 M records) and configs[4]
+    (100 M records, 40 hits per read: hash-table and long-run paths) against the dense restatement, every integer."""
+    from oracle.binding import dense_mt_run
+    for name in ("config2", "config5"):
+        w = make_workload(CONFIGS[name], seed=1)
+        s = Slimm.for_workload(w, device=0)
+        s.push_records_marked(w.records, batch=25_000_000)
+        assert s.get_profiles() is not None
+        assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
+        s.close()
+
+
 def test_full_size_config3_bit_exact():
     """BASELINE.json configs[2] at full size: 100 M records, 20 k references, mean 8 hits per read."""
     from oracle.binding import dense_mt_run

@@ -1066,26 +1066,6 @@ def test_packed_records_resident_on_the_device(grouped):
 
 
 # ---------------------------------------------------------------- run-marked records: 8 bytes each, no names on the device
-def test_mark_word_layout():
-    """word = reference + 1 (0: not mapped) | mate << 29 | starts a qName run << 31 (include/slimm_hip.h)."""
-    L = capi.lib()
-    assert L.slimm_mark_word(0, 0, 0) == 1
-    assert L.slimm_mark_word(41, 0, 1) == (42 | 1 << 31)
-    assert L.slimm_mark_word(7, 0x40, 0) == (8 | 1 << 29)
-    assert L.slimm_mark_word(7, 0x80, 1) == (8 | 2 << 29 | 1 << 31)
-    assert L.slimm_mark_word(7, 0xc0, 0) == (8 | 1 << 29)              # first-in-pair wins (src/slimm.hpp:205-208)
-    assert L.slimm_mark_word(7, 0x4, 1) == 1 << 31                     # the unmapped flag (src/slimm.hpp:197)
-    assert L.slimm_mark_word(-1, 0x80, 0) == 2 << 29                   # no reference
-    key = np.array([5, 5, 9, 9, 9, 5], dtype=np.uint64)
-    flag = np.array([0, 0x40, 0, 4, 0x80, 0], dtype=np.uint16)
-    ref = np.array([1, 2, 3, 4, -1, 6], dtype=np.int32)
-    w = Slimm.mark_words(key, flag, ref)
-    assert list(w >> 31) == [1, 0, 1, 0, 0, 1]
-    assert list(w & 0x1fffffff) == [2, 3, 4, 0, 0, 7]
-    assert list(Slimm.mark_words(key, flag, ref, prev_key=5) >> 31) == [0, 0, 1, 0, 0, 1]   # the batch continues a run
-    assert list(Slimm.mark_words(key, flag, ref, prev_key=6) >> 31) == [1, 0, 1, 0, 0, 1]
-
-
 @pytest.mark.parametrize("how", ["sync", "batches", "async", "streamed"])
 def test_marked_records_equal_the_four_array_form(how):
     """For input grouped by name the read identity is the qName run a record lies in (src/slimm.hpp:204-211 with the

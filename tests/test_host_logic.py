@@ -88,6 +88,36 @@ def test_bin_of_wraps_like_uint32():
     assert host_bin_of(2**31 - 1, 100, 2**32 - 1, 1000) == (2**31 - 1 + 50) // 1000
 
 
+def test_mark_word_layout():
+    """word = reference + 1 (0: not mapped) | mate << 29 | starts a qName run << 31 (include/slimm_hip.h)."""
+    from slimm_amd import capi
+    L = capi.lib()
+    assert L.slimm_mark_word(0, 0, 0) == 1
+    assert L.slimm_mark_word(41, 0, 1) == (42 | 1 << 31)
+    assert L.slimm_mark_word(7, 0x40, 0) == (8 | 1 << 29)
+    assert L.slimm_mark_word(7, 0x80, 1) == (8 | 2 << 29 | 1 << 31)
+    assert L.slimm_mark_word(7, 0xc0, 0) == (8 | 1 << 29)              # first-in-pair wins (src/slimm.hpp:205-208)
+    assert L.slimm_mark_word(7, 0x4, 1) == 1 << 31                     # the unmapped flag (src/slimm.hpp:197)
+    assert L.slimm_mark_word(-1, 0x80, 0) == 2 << 29                   # no reference
+    key = np.array([5, 5, 9, 9, 9, 5], dtype=np.uint64)
+    flag = np.array([0, 0x40, 0, 4, 0x80, 0], dtype=np.uint16)
+    ref = np.array([1, 2, 3, 4, -1, 6], dtype=np.int32)
+    w = Slimm.mark_words(key, flag, ref)
+    assert list(w >> 31) == [1, 0, 1, 0, 0, 1]
+    assert list(w & 0x1fffffff) == [2, 3, 4, 0, 0, 7]
+    assert list(Slimm.mark_words(key, flag, ref, prev_key=5) >> 31) == [0, 0, 1, 0, 0, 1]   # the batch continues a run
+    assert list(Slimm.mark_words(key, flag, ref, prev_key=6) >> 31) == [1, 0, 1, 0, 0, 1]
+
+
+def test_pack_key_layout_on_the_host():
+    """slimm_pack_key / slimm_pack_keys are host functions: (key & (2^61 - 1)) | mate << 61 | unmapped << 63."""
+    k = np.array([0, 1, (1 << 61) - 1, (1 << 62) - 1, 0x123456789abcdef0], dtype=np.uint64)
+    for flag, top in ((0, 0), (0x4, 4), (0x40, 1), (0x80, 2), (0xc0, 1), (0x44, 5), (0x900, 0), (0x84 | 0x100, 6)):
+        got = Slimm.pack_keys(k, np.full(k.shape, flag, dtype=np.uint16))
+        assert np.array_equal(got & np.uint64((1 << 61) - 1), k & np.uint64((1 << 61) - 1))
+        assert np.all((got >> np.uint64(61)) == np.uint64(top)), flag
+
+
 def test_avg_read_length():
     l = np.array([0, 100, 0, 101, 99, 150], dtype=np.uint32)
     assert host_avg_read_length(l, 100000) == ob.avg_read_length(l, 100000) == (100 + 101 + 99 + 150) // 4

@@ -453,11 +453,15 @@ def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs, launched, 
         assert_matches_oracle(e, o, bins=False)
 
 
+@pytest.mark.parametrize("shift", [None, "14"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_shards_on_one_gpu_through_the_sliced_exchange(world):
+def test_shards_on_one_gpu_through_the_sliced_exchange(monkeypatch, world, shift):
     """`world` contexts stand in for ranks: the bitmap chunks are routed like an all-to-all would, the additive vectors
-    summed like an all-reduce (the bin tiles do not divide evenly by 3: the last slice is partly padding)."""
+    summed like an all-reduce (the bin tiles do not divide evenly by 3: the last slice is partly padding).  With the tile
+    size the layout picks (8192 bins here) and with the 16384-bin tiles the 20 k-reference layouts pick."""
     import torch
+    if shift:
+        monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
     w = make_workload(CONFIGS["config2"], seed=27, n_records=300_000)
     o = run_workload(w, use_qnames=False)
     owner = (w.records.read_key % np.uint64(world)).astype(np.int64)
@@ -495,8 +499,11 @@ def test_shards_on_one_gpu_through_the_sliced_exchange(world):
     assert_matches_oracle(engines[0], o, bins=False)
 
 
-def test_single_rank_through_the_exchange_code_path():
+@pytest.mark.parametrize("shift", [None, "14"])
+def test_single_rank_through_the_exchange_code_path(monkeypatch, shift):
     from slimm_amd.distributed import sharded_profile
+    if shift:
+        monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
     w = make_workload(CONFIGS["config1"], seed=19)
     o = run_workload(w)
     for mode in ("summary", "sliced", "bins"):

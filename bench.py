@@ -518,6 +518,31 @@ def main():
                                        "gb_per_s_over_pcie": round(8 * n_rec / dt / 1e9, 2),
                                        "what": "ONE file: clock from before slimm_push_records_marked_async (page-locked host "
                                                "memory, 8 B/record over PCIe) to the profile file written; best of 2"}
+                # ... and files back to back on two alternating contexts, as for the packed form
+                other = Slimm.for_workload(w, device=local_rank, grouped=True)
+                if args.no_bins:
+                    other.keep_bins(False)
+                other.push_records_marked_async(hwn, hpn)
+                other.get_profiles(path=out_path)
+                torch.cuda.synchronize()
+                engs = [eng, other]
+                n_files = 2 * args.push_files
+                engs[0].reset()
+                engs[0].reset_cutoffs()
+                t1 = time.perf_counter()
+                engs[0].push_records_marked_async(hwn, hpn)
+                for i in range(n_files):
+                    cur, nxt = engs[i & 1], engs[(i + 1) & 1]
+                    if i + 1 < n_files:
+                        nxt.reset()
+                        nxt.reset_cutoffs()
+                        nxt.push_records_marked_async(hwn, hpn)
+                    cur.get_profiles(path=out_path)
+                dt_pipe = (time.perf_counter() - t1) / n_files
+                other.close()
+                marked["with_push"]["files_back_to_back"] = {"value": round(n_rec / dt_pipe / 1e6, 3), "unit": "M records/s",
+                                                             "ms_per_file": round(dt_pipe * 1e3, 3),
+                                                             "what": f"{n_files} files, two contexts alternating"}
                 del hw
             del word
         eng.close()

@@ -79,10 +79,15 @@ def random_case(seed: int) -> Workload:
     return Workload([a + ".1" for a in accs], ref_len, tax, rec, A, opts, f"rand{seed}")
 
 
-def _run(w, grouped):
+def _run(w, grouped, form="four"):
     o = run_workload(w, use_qnames=False)
     s = Slimm.for_workload(w, device=0, grouped=grouped)
-    s.push_records(w.records)
+    if form == "marked":        # 8-byte run-marked records (grouped input only), in ragged batches
+        s.push_records_marked(w.records, batch=37)
+    elif form == "packed":      # 16-byte packed records
+        s.push_records_packed(w.records, batch=53)
+    else:
+        s.push_records(w.records)
     prof = s.get_profiles()
     if o.no_hits:
         assert prof is None
@@ -97,6 +102,8 @@ def test_random_small_inputs(lo):
         try:
             _run(w, True)
             _run(w, False)
+            _run(w, True, "marked")
+            _run(w, bool(seed & 1), "packed")
         except AssertionError as e:
             raise AssertionError(f"seed {seed}: {e}") from e
 

@@ -95,6 +95,11 @@ SLIMM_FORWARD(int, slimm_staging_buffers,
               (slimm_ctx* a, uint32_t b, uint64_t c, uint64_t** d, int32_t** e, int32_t** f_, uint16_t** g), (a, b, c, d, e, f_, g))
 SLIMM_FORWARD(int, slimm_push_staged_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
 SLIMM_FORWARD(int, slimm_push_staged_packed_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
+SLIMM_FORWARD(int, slimm_push_staged_marked_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
+SLIMM_FORWARD(int, slimm_push_records_marked, (slimm_ctx* a, const uint32_t* b, const int32_t* c, uint64_t d), (a, b, c, d))
+SLIMM_FORWARD(int, slimm_group_push_records_marked, (slimm_group* a, const uint32_t* b, const int32_t* c, uint64_t d), (a, b, c, d))
+SLIMM_FORWARD(void, slimm_mark_words,
+              (const uint64_t* a, const uint16_t* b, const int32_t* c, uint64_t d, const uint64_t* e, uint32_t* f_), (a, b, c, d, e, f_))
 SLIMM_FORWARD(int, slimm_push_records_packed, (slimm_ctx* a, const uint64_t* b, const int32_t* c, const int32_t* d, uint64_t e),
               (a, b, c, d, e))
 SLIMM_FORWARD(int, slimm_check_grouping, (slimm_ctx* a, uint64_t* b), (a, b))
@@ -393,6 +398,13 @@ struct RecordPump {
     // want_check: the stream is in no particular order, so two read names with one key would meet after the device sort
     // unnoticed -- every record then carries a second hash of its name (slimm_push_records_checked; no staging sets)
     const bool want_check;
+    // Name-grouped input (no check words) goes over the bus as RUN-MARKED 8-byte records: the reader has made the keys of
+    // adjacent records equal exactly when their names are, so "this record starts a qName run" is a key comparison on the
+    // host and the device never sees a key (include/slimm_hip.h, slimm_mark_word).  SLIMM_VERIFY_GROUPING needs the keys
+    // on the device and keeps the packed 16-byte form; so does SLIMM_CLI_PACKED=1.
+    const bool marked;
+    uint64_t last_key = 0;   // the key of the last record marked so far (batches are pushed in file order)
+    bool have_last = false;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Batch> queued;
@@ -403,7 +415,9 @@ struct RecordPump {
     double decode_ms = 0, wait_ms = 0;
     std::thread th;
 
-    RecordPump(AlignmentFile& f, bool check_words) : bam(f), want_check(check_words), th([this] { run(); }) {}
+    RecordPump(AlignmentFile& f, bool check_words)
+        : bam(f), want_check(check_words),
+          marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")), th([this] { run(); }) {}
     ~RecordPump() {
         if (th.joinable()) {
             {
@@ -423,14 +437,24 @@ struct RecordPump {
             key[i] = (key[i] & ((1ull << 61) - 1ull)) | (mate << 61) | (((f >> 2) & 1ull) << 63);
         }
     }
-    static int push(slimm_ctx* c, Batch& b) {
+    // in place: ref[] becomes the words {reference + 1 | mate << 29 | starts a run << 31}
+    uint32_t* mark(const uint64_t* key, const uint16_t* flag, int32_t* ref, uint64_t n) {
+        uint32_t* word = reinterpret_cast<uint32_t*>(ref);
+        slimm_mark_words(key, flag, ref, n, have_last ? &last_key : nullptr, word);
+        last_key = key[n - 1];
+        have_last = true;
+        return word;
+    }
+    int push(slimm_ctx* c, Batch& b) {
         if (b.check) return slimm_push_records_checked(c, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n);
+        if (marked) return slimm_push_records_marked(c, mark(b.key.get(), b.flag.get(), b.ref.get(), b.n), b.pos.get(), b.n);
         pack(b.key.get(), b.flag.get(), b.n);
         return slimm_push_records_packed(c, b.key.get(), b.ref.get(), b.pos.get(), b.n);
     }
-    static int group_push(slimm_group* g, Batch& b) {
+    int group_push(slimm_group* g, Batch& b) {
         if (b.check)
             return slimm_group_push_records_checked(g, b.key.get(), b.ref.get(), b.pos.get(), b.flag.get(), b.check.get(), b.n);
+        if (marked) return slimm_group_push_records_marked(g, mark(b.key.get(), b.flag.get(), b.ref.get(), b.n), b.pos.get(), b.n);
         pack(b.key.get(), b.flag.get(), b.n);
         return slimm_group_push_records_packed(g, b.key.get(), b.ref.get(), b.pos.get(), b.n);
     }
@@ -461,8 +485,13 @@ struct RecordPump {
                     read_rc = n;
                     return;
                 }
-                pack(key, flag, static_cast<uint64_t>(n));  // (the set's flag array stays on the host)
-                if (slimm_push_staged_packed_async(c, which, static_cast<uint64_t>(n)) < 0) break;
+                if (marked) {  // (the set's key and flag arrays stay on the host)
+                    mark(key, flag, ref, static_cast<uint64_t>(n));
+                    if (slimm_push_staged_marked_async(c, which, static_cast<uint64_t>(n)) < 0) break;
+                } else {
+                    pack(key, flag, static_cast<uint64_t>(n));  // (the set's flag array stays on the host)
+                    if (slimm_push_staged_packed_async(c, which, static_cast<uint64_t>(n)) < 0) break;
+                }
                 which ^= 1u;
                 continue;
             }

@@ -58,6 +58,28 @@ def test_cli_matches_oracle_outputs(tmp_path, fmt, mk):
     assert f"{o.scalars['n_valid']} passed the threshould coverage." in err
 
 
+def test_cli_packed_and_run_marked_pushes_write_the_same_files(tmp_path, monkeypatch):
+    """Name-grouped input goes over the bus as run-marked 8-byte records (the reader's keys of adjacent records are equal
+    exactly when their names are); SLIMM_CLI_PACKED=1 keeps the 16-byte packed form.  A file of 2.5 M records (three
+    batches of the pump: the run a batch ends in continues in the next one) through both: byte-equal outputs."""
+    w = with_names(make_workload(CONFIGS["config2"], seed=44, n_records=2_500_000))
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "sample.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    outs = []
+    for k, packed in enumerate((False, True)):
+        if packed:
+            monkeypatch.setenv("SLIMM_CLI_PACKED", "1")
+        out = str(tmp_path / f"out{k}") + "/"
+        os.makedirs(out)
+        run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp])
+        outs.append({f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))})
+    assert outs[0] == outs[1] and len(outs[0]) == 5
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    check_outputs(str(tmp_path / "out0") + "/", "sample", o)
+
+
 def test_cli_default_bin_width_unsorted_header_and_rank(tmp_path):
     # no -w: bin width = average read length; header without a grouping promise -> the device sort path; -r genus
     w = with_names(make_workload(SynthConfig("c", 30_000, 60, 3.0, bin_width=0, read_len=75, len_lo=20_000, len_hi=60_000,

@@ -1115,11 +1115,17 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
                          c->slots.p, c->wcut.p, t.t0(), t.t1());
     }
-    // where every slot's reads start among all reads (for k_filter's dense selectors): beside the tile kernels
-    HIP_TRY(c, hipEventRecord(c->front_done, st));
-    HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->front_done, 0));
-    launch_slot_read_prefix(c->side_stream, c->slots.p, nslots, c->slot_rbase.p, c->slot_bbase.p);
-    HIP_TRY(c, hipEventRecord(c->prefix_done, c->side_stream));
+    // Where every slot's reads start among all reads (for k_filter's dense selectors): two small launches on a side
+    // stream -- beside k_tile_hist, NOT beside the count and the scatter: those run one persistent workgroup per CU
+    // (half CU), and a CU that is busy with a prefix workgroup when they are placed makes another CU take two of them
+    // (k_tile_count 456 -> 610-630 us at 1 B records in five runs of six).  The histogram's workgroups are many and short.
+    auto slot_prefix_beside_what_follows = [&]() -> int {
+        HIP_TRY(c, hipEventRecord(c->front_done, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->front_done, 0));
+        launch_slot_read_prefix(c->side_stream, c->slots.p, nslots, c->slot_rbase.p, c->slot_bbase.p);
+        HIP_TRY(c, hipEventRecord(c->prefix_done, c->side_stream));
+        return SLIMM_OK;
+    };
     SlotValues targets;
     targets.vals = c->tgt_gbin.p;
     targets.slots = c->slots.p;
@@ -1156,6 +1162,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                                     c->two_level, c->tile_count.p, c->treps, c->tstride, tile_sub));
             }
         }
+        if (int rc = slot_prefix_beside_what_follows()) return rc;
         {
             KernelTimer t(c, K_TILE_HIST);
             c->summary_has_bits = false;
@@ -1173,6 +1180,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             c->binsA_stored = c->keep_bins;
         }
     } else {
+        if (int rc = slot_prefix_beside_what_follows()) return rc;
         KernelTimer t(c, K_HIST);
         launch_hist(st, c->tgt_gbin.p, c->slots.p, nslots, c->counters.p, c->tail(), c->cov(), c->ucov(),
                     c->order != SLIMM_ORDER_ANY);

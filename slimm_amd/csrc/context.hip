@@ -114,8 +114,10 @@ struct slimm_ctx {
     DevBuf<uint2> d_geo;              // {contig length, first bin} per reference: one gather in k_emit
     DevBuf<uint8_t> d_valid;
     DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
-    DevBuf<uint32_t> d_level_taxon;    // [(level << taxon_shift) | index] -> dense taxon
+    DevBuf<uint32_t> d_level_taxon;    // [(index << 3) | level] -> dense taxon (8 << taxon_shift entries)
+    DevBuf<uint32_t> d_taxon_off, d_taxon_idx;  // ... and back: the (level, index) entries of dense taxon t (CSR)
     uint32_t taxon_shift = 0;
+    uint32_t Tsel = 0;                 // size of the selectors' taxon space: 8 << taxon_shift (16-byte rows) or T
     PinBuf<uint4> h_rows16;
     bool rows16_base_ready = false;    // h_rows16 holds the static part of every row
     std::vector<uint32_t> rows16_prev; // references whose valid bit is set in h_rows16
@@ -423,13 +425,30 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         if (off >= kMaxBins) return fail(nullptr, SLIMM_E_INVALID, "more than 2^31 coverage bins; use a larger bin width");
     }
     c->bin_off_h[c->R] = static_cast<uint32_t>(off);
+    // The taxon part of a selector: with 16-byte lineage rows k_filter names an LCA by (level, index in the level) -- what
+    // the rows hold -- and the second tile histogram counts per (level << taxon_shift | index); k_pack sums those counts
+    // into per-taxon ones (kernels.h: PackArgs::sum_k).  No taxon look-up, one dependent round trip less, on k_filter's
+    // path.  With the 32-byte rows the selector is the dense taxon itself.
+    {
+        const char* wide_rows = getenv("SLIMM_WIDE_ROWS");
+        c->use_rows16 = c->host->rows16_ok() && !(wide_rows && wide_rows[0] == '1');
+        c->Tsel = c->T;
+        if (c->use_rows16) {
+            const uint32_t* loff = c->host->level_offset();
+            uint32_t widest = 1;
+            for (int l = 0; l < 8; ++l) widest = std::max(widest, loff[l + 1] - loff[l]);
+            c->taxon_shift = 0;
+            while ((1u << c->taxon_shift) < widest) ++c->taxon_shift;
+            c->Tsel = 8u << c->taxon_shift;
+        }
+    }
     // Tile size by layout: the small tiles while the whole bucketing fits the fused kernel's tile tables (their histograms
     // run at twice the occupancy), the large ones beyond -- where the scatter's direct rounds pay a returning atomic per
     // run of one tile among neighbouring targets and half as many tiles make those runs longer (1 B records over 20 k
     // references: scatter 3.03 -> 2.3 ms, histograms 0.41 -> 0.67 ms; kernels.h)
     {
         const uint64_t small = (off + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall;
-        const uint64_t small2 = small + ((static_cast<uint64_t>(c->T) + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall);
+        const uint64_t small2 = small + ((static_cast<uint64_t>(c->Tsel) + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall);
         c->tile_shift = small2 > kFusedScanTiles ? kTileShiftLarge : kTileShiftSmall;
         if (const char* ts = getenv("SLIMM_TILE_SHIFT")) {
             if (atoi(ts) == static_cast<int>(kTileShiftSmall)) c->tile_shift = kTileShiftSmall;
@@ -439,7 +458,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     const uint32_t tile_bins = c->tile_bins();
     c->Bp = (off + tile_bins - 1) & ~static_cast<uint64_t>(tile_bins - 1);
     c->ntiles = static_cast<uint32_t>(c->Bp >> c->tile_shift);
-    c->Tpad = (c->T + tile_bins - 1) & ~(tile_bins - 1);
+    c->Tpad = (c->Tsel + tile_bins - 1) & ~(tile_bins - 1);
     c->ntiles2 = c->ntiles + (c->Tpad >> c->tile_shift);
     if (c->Bp + c->Tpad >= kMaxBins) return fail(nullptr, SLIMM_E_INVALID, "more than 2^31 coverage bins; use a larger bin width");
 
@@ -470,7 +489,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->bins.ensure(3 * c->Bp + kTailWords + c->Tpad));
         HIP_TRY0(cc->counters.ensure(CNT_WORDS));
         HIP_TRY0(cc->ref_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
-        HIP_TRY0(cc->lca_count.ensure(c->T));
+        HIP_TRY0(cc->lca_count.ensure(c->Tsel));
         HIP_TRY0(cc->marks.ensure(static_cast<size_t>(c->R) * (kMarkBytes / 4)));
         HIP_TRY0(cc->h_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->h_small.ensure(CNT_WORDS + kTailWords));
@@ -487,23 +506,34 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(hipMemcpy(cc->d_lin_dense.p, c->host->lineage_dense().data(), static_cast<size_t>(c->R) * 32,
                            hipMemcpyHostToDevice));
 #undef HIP_TRY0
-        const char* wide_rows = getenv("SLIMM_WIDE_ROWS");
-        cc->use_rows16 = c->host->rows16_ok() && !(wide_rows && wide_rows[0] == '1');
         if (cc->use_rows16) {
             // the dense taxon of a (level, index): one table with a power-of-two stride per level, so that a lane turns
-            // its (level, index) into an address with one shift-or
+            // its (level, index) into an address with one shift-or (only the rare no-level-agrees path looks it up on the
+            // device) -- and, for k_pack, its inverse: the (level, index) entries of every dense taxon (a taxid may stand on
+            // several levels of a lineage, e.g. a species-level accession)
             const std::vector<uint32_t>& lt = c->host->level_taxon();
             const uint32_t* off = c->host->level_offset();
-            uint32_t widest = 1;
-            for (int l = 0; l < 8; ++l) widest = std::max(widest, off[l + 1] - off[l]);
-            cc->taxon_shift = 0;
-            while ((1u << cc->taxon_shift) < widest) ++cc->taxon_shift;
             std::vector<uint32_t> flat(static_cast<size_t>(8) << cc->taxon_shift, 0u);
+            std::vector<uint32_t> inv_off(c->T + 1, 0u), inv_idx;
             for (int l = 0; l < 8; ++l)
-                for (uint32_t i = off[l]; i < off[l + 1]; ++i) flat[(static_cast<size_t>(l) << cc->taxon_shift) + (i - off[l])] = lt[i];
+                for (uint32_t i = off[l]; i < off[l + 1]; ++i) {
+                    flat[(static_cast<size_t>(i - off[l]) << 3) | static_cast<size_t>(l)] = lt[i];
+                    if (lt[i] < c->T) ++inv_off[lt[i] + 1];
+                }
+            for (uint32_t t = 0; t < c->T; ++t) inv_off[t + 1] += inv_off[t];
+            inv_idx.resize(inv_off[c->T] + 1);
+            {
+                std::vector<uint32_t> at(inv_off.begin(), inv_off.end() - 1);
+                for (int l = 0; l < 8; ++l)
+                    for (uint32_t i = off[l]; i < off[l + 1]; ++i)
+                        if (lt[i] < c->T) inv_idx[at[lt[i]]++] = ((i - off[l]) << 3) | static_cast<uint32_t>(l);
+            }
             if (cc->d_rows16.ensure(c->R) != hipSuccess || cc->h_rows16.ensure(c->R) != hipSuccess ||
                 cc->d_level_taxon.ensure(flat.size()) != hipSuccess ||
-                hipMemcpy(cc->d_level_taxon.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+                hipMemcpy(cc->d_level_taxon.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                cc->d_taxon_off.ensure(inv_off.size()) != hipSuccess || cc->d_taxon_idx.ensure(inv_idx.size()) != hipSuccess ||
+                hipMemcpy(cc->d_taxon_off.p, inv_off.data(), inv_off.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(cc->d_taxon_idx.p, inv_idx.data(), inv_idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
         }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
@@ -1467,7 +1497,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             }
         } else {
             z.p[2] = c->lca_count.p;
-            z.n[2] = T;
+            z.n[2] = c->Tsel;
         }
         if (!c->pair_clean) {
             z.p64 = c->pair_tab.p;
@@ -1569,6 +1599,11 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         pk.reps[1] = kPackBytes8;  // k_filter sets one byte per (reference, level)
         pk.src[2] = c->use_tiles ? c->lca_tiles() : c->lca_count.p;
         pk.n[2] = T;
+        if (c->use_rows16) {  // counted per (level, index): summed into per-taxon counts on the way out
+            pk.sum_k = 2;
+            pk.sum_off = c->d_taxon_off.p;
+            pk.sum_idx = c->d_taxon_idx.p;
+        }
         if (c->use_tiles) {  // k_tile_hist left the uniq_cov2 statistics in place
             KernelTimer t(c, K_PACK2);
             TILES(c->tile_shift, launch_pack(st, blockB + 4ull * R, pk, c->split_tiles.p, c->counters.p, c->ucov2(), nullptr,

@@ -48,13 +48,21 @@ struct PackArgs {  // small arrays appended behind the per-reference statistics 
     uint32_t n[4] = {0, 0, 0, 0};
     uint32_t reps[4] = {1, 1, 1, 1};  // src[k] holds reps[k] copies of n[k] words each; their bitwise OR is packed
                                       // kPackBytes8: src[k] holds 8 bytes per output word, bit l = (byte l != 0)
+    // one array may be a SUM of source words instead: output word i of array sum_k = sum of src[sum_k][sum_idx[j]] for
+    // j in [sum_off[i], sum_off[i + 1]) -- the per-taxon LCA counts, which k_filter counts per (level, index) of the
+    // lineage rows (no taxon look-up on its path) and which become per-taxon counts here
+    int sum_k = -1;
+    const uint32_t* sum_off = nullptr;
+    const uint32_t* sum_idx = nullptr;
 };
 constexpr uint32_t kPackBytes8 = 0xffffffffu;
 #ifdef __HIPCC__
 // word i of packed array k (k_pack, k_ref_stats)
 __device__ __forceinline__ uint32_t packed_word(const PackArgs& pack, int k, uint32_t i) {
     uint32_t v = 0;
-    if (pack.reps[k] == kPackBytes8) {
+    if (k == pack.sum_k) {
+        for (uint32_t j = pack.sum_off[i]; j < pack.sum_off[i + 1]; ++j) v += pack.src[k][pack.sum_idx[j]];
+    } else if (pack.reps[k] == kPackBytes8) {
         const uint2 b = reinterpret_cast<const uint2*>(pack.src[k])[i];
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
@@ -151,7 +159,7 @@ struct FilterArgs {
     const uint2* wcut = nullptr;
     uint32_t nslots = 0;
     const void* rows16 = nullptr;
-    const uint32_t* taxon_flat = nullptr;  // rows16: dense taxon of (level, index) at [(level << taxon_shift) | index]
+    const uint32_t* taxon_flat = nullptr;  // rows16: dense taxon of (level, index) at [(index << 3) | level]
     uint32_t taxon_shift = 0;
     const uint32_t* lin_dense = nullptr;
     const uint8_t* valid = nullptr;

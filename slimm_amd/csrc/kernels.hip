@@ -439,7 +439,7 @@ __device__ void pair_insert(uint64_t key, uint64_t* __restrict__ tab, uint64_t* 
 }
 
 // 16-byte lineage rows: eight per-level 16-bit indices, the reference's valid flag in the top bit of the level-7
-// half-word; taxon_flat[(lv << shift) | idx] is the dense taxon of a (level, index)
+// half-word; taxon_flat[(idx << 3) | lv] is the dense taxon of a (level, index)
 struct Rows16 {
     const uint4* rows;
     const uint32_t* taxon_flat;
@@ -479,7 +479,12 @@ struct Rows16 {
         const uint64_t hi = (static_cast<uint64_t>(r.q.w & 0x7fffffffu) << 32) | r.q.z;
         return static_cast<uint32_t>((lv < 4u ? lo : hi) >> ((lv & 3u) * 16u)) & 0xffffu;
     }
-    __device__ uint32_t taxon_index(uint32_t lv, uint32_t field) const { return (lv << shift) | field; }
+    // what a selector names an LCA by: (level, index in the level) -- the second tile histogram counts per such entry
+    // and k_pack sums the entries of a taxon (PackArgs::sum_k); taxon_at, the dense taxon, is looked up only where a
+    // (taxon, reference) pair is stored (no level agrees: rare)
+    // (index-major: the reads of a file agree mostly at ONE level, and level-major entries would put all their selectors
+    // into one or two tiles of the second histogram, every piece of those adding to the same few thousand words)
+    __device__ uint32_t taxon_index(uint32_t lv, uint32_t field) const { return (field << 3) | lv; }
     __device__ uint32_t taxon_at(uint32_t index) const { return taxon_flat[index]; }
 };
 // 32-byte rows (databases with more than 65535 taxa on one level): eight dense taxon indices, validity in a byte array
@@ -608,13 +613,15 @@ __device__ __forceinline__ void read_add(ReadAcc& acc, uint64_t Vs, uint32_t g, 
 
 // LCA of a read with several valid targets; *lv = the agreeing level (8: none, Q4)
 template <typename Rows>
-__device__ __forceinline__ uint32_t read_taxon(const Rows& rows, const ReadAcc& acc, uint32_t* lv) {
+__device__ __forceinline__ uint32_t read_taxon(const Rows& rows, const ReadAcc& acc, uint32_t* lv, uint32_t* index) {
     if (acc.eq) {
         *lv = static_cast<uint32_t>(__builtin_ctz(acc.eq));
-        return rows.taxon_at(rows.taxon_index(*lv, acc.a0[*lv]));
+        *index = rows.taxon_index(*lv, acc.a0[*lv]);
+        return rows.taxon_at(*index);
     }
     *lv = 8u;
-    return rows.taxon_at(rows.taxon_index(7u, acc.max_f7));
+    *index = rows.taxon_index(7u, acc.max_f7);
+    return rows.taxon_at(*index);
 }
 
 // children[taxon] gets the valid lanes' references: a level mark, or a (taxon, reference) pair when no level agreed
@@ -634,9 +641,6 @@ __device__ __forceinline__ void read_children(const FilterOut& out, bool mine, u
 // finds the first level at which no lane between itself and the next read's head does.  The owners' taxa are ONE gather
 // per window, left to the caller (Lookup) so that the gathers of a batch of windows are in flight together.
 struct Lookup {
-    uint32_t index;  // taxon_at(index) + taxon_base is the selector ...
-    uint32_t ridx;   // ... of read ridx
-    bool want;
     uint64_t q4;     // first valid lanes of the reads on whose targets no level agrees (quirk Q4): left to filter_q4
 };
 
@@ -660,7 +664,7 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
     const uint32_t ridx = sel_base + mask_rank(H) + (k_bit(H) ? 1u : 0u) - 1u;
     if (k_bit(single)) out.sel[ridx] = g & 0x7fffffffu;
     if (k_bit(empty)) out.sel[ridx] = 0xffffffffu;
-    Lookup lk{0u, ridx, false, 0ull};
+    Lookup lk{0ull};
     if (OW) {
         const uint64_t le = (2ull << lane) - 1ull;  // the lanes up to and including this one
         // the first valid lane of this lane's read (for the valid lanes): the highest bit of FV at or below it
@@ -693,8 +697,8 @@ __device__ __forceinline__ Lookup filter_window(const Rows& rows, const FilterOu
             lv = lv == 8u ? up : lv;
         }
         const uint64_t Q4 = k_ballot(lv == 8u) & OW;  // no level agrees (quirk Q4): rare, one read at a time below
-        lk.want = k_bit(OW & ~Q4);
-        lk.index = rows.taxon_index(lv & 7u, Rows::field(row, lv & 7u));
+        // the owners' selectors: the taxon part is (level, index) as the row holds it -- no look-up, no third round trip
+        if (k_bit(OW & ~Q4)) out.sel[ridx] = out.taxon_base + rows.taxon_index(lv & 7u, Rows::field(row, lv & 7u));
         // children[taxon] gets the valid targets' references (src/slimm.hpp:536-557): a (reference, level) mark
         const uint32_t lv_read = __builtin_amdgcn_ds_bpermute(fvl << 2, lv);
         if (k_bit(VB & ~single) && lv_read < 8u) out.marks[ref * kMarkBytes + lv_read] = 1;  // plain, idempotent byte store
@@ -727,9 +731,10 @@ __device__ __forceinline__ void filter_q4(const Rows& rows, const FilterOut& out
         ReadAcc acc;
         read_clear(acc);
         read_max(acc, Vs, ref, f[7]);
-        const uint32_t taxon = rows.taxon_at(rows.taxon_index(7u, acc.max_f7));
+        const uint32_t index = rows.taxon_index(7u, acc.max_f7);
+        const uint32_t taxon = rows.taxon_at(index);
         read_children(out, k_bit(Vs), ref, 8u, taxon);
-        if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(o + 1u))) - 1u] = out.taxon_base + taxon;
+        if (lane == 0u) out.sel[sel_base + static_cast<uint32_t>(__popcll(H & k_below(o + 1u))) - 1u] = out.taxon_base + index;
     }
 }
 
@@ -739,7 +744,6 @@ __device__ __forceinline__ void filter_window_now(const Rows& rows, const Filter
                                                   uint32_t g, const typename Rows::Row& row, uint32_t sel_base) {
     const uint64_t vb = k_ballot(Rows::valid(row));
     const Lookup lk = filter_window(rows, out, lane, X, w, g, row, vb, sel_base);
-    if (lk.want) out.sel[lk.ridx] = out.taxon_base + rows.taxon_at(lk.index);
     if (lk.q4) filter_q4(rows, out, lane, X, w, row, vb, sel_base, lk.q4);
 }
 
@@ -788,9 +792,9 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
         if (acc.nv == 1u) {
             sel = acc.first_g & 0x7fffffffu;
         } else if (acc.nv > 1u) {
-            uint32_t lv;
-            const uint32_t taxon = read_taxon(rows, acc, &lv);
-            sel = out.taxon_base + taxon;
+            uint32_t lv, index;
+            const uint32_t taxon = read_taxon(rows, acc, &lv, &index);
+            sel = out.taxon_base + index;
             for (uint32_t c = pos; c < e; c += 64u) {
                 const bool in = c + lane < e;
                 const uint32_t rr = in ? (tgt_ref[c + lane] & 0x7fffffffu) : 0u;
@@ -917,18 +921,9 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
             Lookup lk[kFilterBatch];
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) {
-                lk[u] = Lookup{0u, 0u, false, 0ull};
+                lk[u] = Lookup{0ull};
                 if (cnt[u]) lk[u] = filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], vb[u], selb[u]);
             }
-            uint32_t taxon[kFilterBatch];
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) taxon[u] = rows.taxon_at(lk[u].want ? lk[u].index : 0u);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) SLIMM_PIN_VGPR(taxon[u]);  // (a use in straight-line code, as above)
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u)
-                if (lk[u].want) out.sel[lk[u].ridx] = out.taxon_base + taxon[u];
             uint64_t any_q4 = 0;
 #pragma unroll
             for (int u = 0; u < kFilterBatch; ++u) any_q4 |= lk[u].q4;

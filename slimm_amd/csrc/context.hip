@@ -167,7 +167,7 @@ struct slimm_ctx {
     // far more entries per tile than a packed work item holds (1 B records on 20 k references): work items of up to
     // kTileSubWide entries with 32-bit counts, so that a tile is one item again (kernels.h)
     bool wide_for(uint32_t n_records) const {
-        return wide_tiles >= 0 ? wide_tiles != 0 : (ntiles && n_records / ntiles > 2 * kTileSub);
+        return wide_tiles >= 0 ? wide_tiles != 0 : (ntiles && n_records / ntiles > 32768u);
     }
     DevBuf<uint32_t> tile_matrix;
     // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
@@ -1552,7 +1552,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         // few selectors per tile (config 5: 100; config 3: 1 200): the count matrix (88 -> 61 us at config 3, 112 -> 33 us at
         // config 5); many (config 4: 12 000): the direct rounds, whose shared frontier per tile keeps the open lines in L2
         const bool matrix = c->matrix && (c->matrix_always || c->local_M / std::max(1u, c->ntiles2) < 4096u);
-        const uint32_t tile_sub = c->wide_for(c->rec.n) ? kTileSubWide : kTileSub;  // (one array: its counts are 32-bit already)
+        const uint32_t tile_sub = c->wide_for(c->rec.n) ? kTileSubWide : kTileSubB;  // (one array: its counts are 32-bit already)
         {
             KernelTimer t(c, K_TILE_COUNT2);
             TILES(c->tile_shift, launch_tile_count(st, grid, c->ntiles2, selectors, nullptr, c->tile_count.p, c->treps, c->tstride,

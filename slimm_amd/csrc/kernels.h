@@ -200,7 +200,15 @@ void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t ran
 // faster histograms; larger tiles: half as many bucket frontiers, longer runs of one tile among neighbouring targets
 // and so fewer returning atomics in the direct rounds of the scatter.
 constexpr uint32_t kTileShiftSmall = 13, kTileShiftLarge = 14;
-constexpr uint32_t kTileSub = 16384;                    // bucket entries per k_tile_hist work item (packed 16-bit counts)
+constexpr uint32_t kTileSub = 49152;                    // bucket entries per k_tile_hist work item (packed 16-bit counts: below
+                                                        // 65536).  Hot tiles (a few present genomes take most of a sample's
+                                                        // reads) are cut into items of this size, each adding its counts to
+                                                        // global memory with atomics, and k_pack goes over them once more:
+                                                        // 16384 / 32768 / 49152 at config 3: k_tile_hist 224 / 162 / 153 us,
+                                                        // k_pack 46 / 27 / 17; config 5: 319 / 312 / 310 and 27 / 15 / 13
+constexpr uint32_t kTileSubB = 16384;                   // ... of phase B's single-array histogram (32-bit counts): the reads
+                                                        // that keep several targets meet in the few tiles of the taxon
+                                                        // entries, and smaller items are more workgroups on those
 constexpr uint32_t kTileSubWide = 262144;               // ... of the wide form (32-bit counts): layouts with far more than
                                                         // kTileSub entries per tile (tile_sub / wide arguments below)
 constexpr size_t kTileLdsMax = 144 * 1024;              // LDS histogram of tile ids in k_tile_count / k_tile_scatter

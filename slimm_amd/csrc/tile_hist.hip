@@ -1363,7 +1363,7 @@ void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, c
                        split_tiles, tot.part, tot.nparts, tot.tail, tile_sub);
 }
 
-uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / kTileSub + 1; }
+uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / std::min(kTileSub, kTileSubB) + 1; }
 
 // cov + ucov (ucov != nullptr: bit 13 of a bucket entry selects uniq_cov as well) or a single array
 // stats != nullptr: also accumulate the per-reference statistics (zeroed by the caller) of the finished arrays

@@ -109,8 +109,10 @@ int slimm_set_cutoff_cache(slimm_ctx* ctx, float coverage_cut_off, float uniq_co
  * what is grouped by construction (mapper output; @HD SO:queryname / GO:query, which is all the slimm command trusts);
  * everything else is SLIMM_ORDER_ANY.  slimm_check_grouping() is the diagnostic for a caller in doubt: after the
  * records are pushed it counts, on the device, the qName runs whose identity started an earlier run as well (0 = the
- * stream is grouped).  It costs a hash-set insert per run (16 bytes of device memory per record for the set) and is
- * therefore never run unasked; the slimm command runs it with SLIMM_VERIFY_GROUPING=1 and warns. */
+ * stream is grouped).  It costs a hash-set insert per run -- the set is a power of two of 8-byte entries at or above
+ * twice the number of records: 16 to 32 bytes of device memory per record, up to 32 GiB near 2^31 records -- and is
+ * therefore never run unasked; the slimm command runs it with SLIMM_VERIFY_GROUPING=1 and warns.  Packed records are
+ * compared by the 61 identity bits they carry (the four-array form: 62). */
 int slimm_check_grouping(slimm_ctx* ctx, uint64_t* n_split_names);
 int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);
 /* Append a batch from host memory (copied to the device before return). */

@@ -357,6 +357,24 @@ int ensure_pair_table(slimm_ctx* c, uint32_t cap) {
     return SLIMM_OK;
 }
 
+// Grows one record array to `cap` elements, keeping the `used` elements pushed so far (when the array holds them at all:
+// an array the file's record form does not use is neither allocated nor copied).
+template <typename T>
+hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStream_t st) {
+    if (cap <= buf.cap) return hipSuccess;
+    if (used == 0 || buf.cap < used) return buf.ensure(cap);  // nothing of this file in it
+    DevBuf<T> nb;
+    hipError_t e = nb.ensure(cap);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(nb.p, buf.p, used * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    std::swap(buf.p, nb.p);
+    std::swap(buf.cap, nb.cap);
+    return hipSuccess;
+}
+
 int check_device_errors(slimm_ctx* c, uint32_t err) {
     if (err & ERR_REF_RANGE) return fail(c, SLIMM_E_REF_RANGE, "a record names a reference id >= n_refs");
     if (err & ERR_KEY_COLLISION)
@@ -668,47 +686,31 @@ int slimm_set_cutoff_cache(slimm_ctx* c, float cc, float ucc) {
     return SLIMM_OK;
 }
 
+// Room for n records of the file's form: the four-array form holds key | ref | pos | flag (| check), the packed form
+// key | ref | pos, the run-marked form ref (the words) | pos.  Before the first push the form is not known yet: key, ref
+// and pos are reserved and the push itself adds what its form needs beyond them.
 int slimm_reserve(slimm_ctx* c, uint64_t n) {
     if (!c) return SLIMM_E_INVALID;
     if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
     if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
     if (c->borrowed) return fail(c, SLIMM_E_INVALID, "records are borrowed device arrays; reset first");
     (void)hipSetDevice(c->device);
-    if (n <= c->in_key.cap) return SLIMM_OK;
+    const bool need_key = !c->marked;
+    const bool need_flag = !c->packed && !c->marked && (c->n_pushed != 0 || c->in_flag.cap != 0);
+    const bool need_check = c->has_check;
+    const bool fits = n <= c->in_ref.cap && n <= c->in_pos.cap && (!need_key || n <= c->in_key.cap) &&
+                      (!need_flag || n <= c->in_flag.cap) && (!need_check || n <= c->in_check.cap);
+    if (fits) return SLIMM_OK;
     // grow, keeping what was pushed (copies on their way included)
     if (c->copy_pending) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-    uint64_t cap = std::max<uint64_t>(n, c->in_key.cap * 2);
+    uint64_t cap = n <= c->in_ref.cap ? c->in_ref.cap : std::max<uint64_t>(n, c->in_ref.cap * 2);  // (double only to grow)
     if (cap >= 0x7fffffffull) cap = 0x7ffffffeull;
-    DevBuf<uint64_t> k;
-    DevBuf<int32_t> r, p;
-    DevBuf<uint16_t> f;
-    HIP_TRY(c, k.ensure(cap));
-    HIP_TRY(c, r.ensure(cap));
-    HIP_TRY(c, p.ensure(cap));
-    if (!c->packed) HIP_TRY(c, f.ensure(cap));
-    DevBuf<uint32_t> ck;
-    if (c->has_check || c->n_pushed == 0) HIP_TRY(c, ck.ensure(cap));
-    if (c->n_pushed && c->has_check)
-        HIP_TRY(c, hipMemcpyAsync(ck.p, c->in_check.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
-    if (c->n_pushed) {
-        HIP_TRY(c, hipMemcpyAsync(k.p, c->in_key.p, c->n_pushed * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(r.p, c->in_ref.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(p.p, c->in_pos.p, c->n_pushed * 4, hipMemcpyDeviceToDevice, c->stream));
-        if (!c->packed) HIP_TRY(c, hipMemcpyAsync(f.p, c->in_flag.p, c->n_pushed * 2, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    std::swap(c->in_key.p, k.p);
-    std::swap(c->in_key.cap, k.cap);
-    std::swap(c->in_ref.p, r.p);
-    std::swap(c->in_ref.cap, r.cap);
-    std::swap(c->in_pos.p, p.p);
-    std::swap(c->in_pos.cap, p.cap);
-    if (!c->packed) {
-        std::swap(c->in_flag.p, f.p);
-        std::swap(c->in_flag.cap, f.cap);
-    }
-    std::swap(c->in_check.p, ck.p);
-    std::swap(c->in_check.cap, ck.cap);
+    const uint64_t used = c->n_pushed;
+    HIP_TRY(c, grow_record_array(c->in_ref, cap, used, c->stream));
+    HIP_TRY(c, grow_record_array(c->in_pos, cap, used, c->stream));
+    if (need_key) HIP_TRY(c, grow_record_array(c->in_key, cap, used, c->stream));
+    if (need_flag) HIP_TRY(c, grow_record_array(c->in_flag, cap, used, c->stream));
+    if (need_check) HIP_TRY(c, grow_record_array(c->in_check, cap, used, c->stream));
     return SLIMM_OK;
 }
 
@@ -990,6 +992,8 @@ int slimm_set_records_device(slimm_ctx* c, const uint64_t* key, const int32_t* r
     if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
     if (n && (!key || !ref || !pos || !flag)) return fail(c, SLIMM_E_INVALID, "null record array");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    c->rec = DeviceRecords();  // replaces whatever was pushed or set before, in whatever form
+    c->packed = c->marked = c->has_check = false;
     c->rec.key = key;
     c->rec.ref = ref;
     c->rec.pos = pos;
@@ -1014,6 +1018,7 @@ int slimm_set_records_device_packed(slimm_ctx* c, const uint64_t* key, const int
     c->rec.n = static_cast<uint32_t>(n);
     c->n_pushed = n;
     c->packed = true;
+    c->marked = c->has_check = false;
     c->borrowed = true;
     return SLIMM_OK;
 }
@@ -1033,6 +1038,7 @@ int slimm_set_records_device_marked(slimm_ctx* c, const uint32_t* word, const in
     c->rec.n = static_cast<uint32_t>(n);
     c->n_pushed = n;
     c->marked = true;
+    c->packed = c->has_check = false;
     c->borrowed = true;
     return SLIMM_OK;
 }
@@ -1216,6 +1222,9 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                     c->order != SLIMM_ORDER_ANY);
         c->binsA_stored = true;
     }
+    // the side stream's prefix kernels are joined here, not only by phase B: a file that ends without one (no hits, an
+    // analyse-only caller) must not leave them unordered against the next file's k_front, which rewrites the slots
+    HIP_TRY(c, hipStreamWaitEvent(st, c->prefix_done, 0));
     HIP_TRY(c, hipGetLastError());
     c->analyzed = true;
     tr.mark("phase A launches");

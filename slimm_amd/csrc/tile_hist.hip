@@ -1365,7 +1365,7 @@ void launch_tile_scatter_fused(hipStream_t st, uint32_t grid, uint32_t ntiles, c
 
 uint32_t tile_items_upper(uint32_t ntiles, uint32_t n_upper) { return ntiles + n_upper / std::min(kTileSub, kTileSubB) + 1; }
 
-// cov + ucov (ucov != nullptr: bit 13 of a bucket entry selects uniq_cov as well) or a single array
+// cov + ucov (ucov != nullptr: bit kTileShift -- 13 or 14 -- of a bucket entry selects uniq_cov as well) or a single array
 // stats != nullptr: also accumulate the per-reference statistics (zeroed by the caller) of the finished arrays
 void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const uint16_t* bucket, const uint32_t* tile_base,
                       const uint4* items, const uint32_t* counters, uint32_t* cov, uint32_t* ucov, const uint32_t* bin_off,

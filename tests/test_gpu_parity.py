@@ -1220,3 +1220,65 @@ def test_check_grouping_counts_names_that_come_back():
     assert s.get_profiles() is not None
     assert s.stats()["matches_count"] == o.scalars["matches"] + 3          # what the false promise costs: 3 reads too many
     check(broken, grouped=False)                                            # declared honestly: the reference's numbers
+
+
+# ---------------------------------------------------------------- one context, file after file in different record forms
+def test_record_forms_follow_each_other_on_one_context():
+    """A context takes one form per file and any form for the next (include/slimm_hip.h: slimm_reserve).  A packed file
+    leaves no flag array behind; a LARGER run-marked file after it must grow only the arrays its form has (it once
+    copied the flag array that was never there), and so on through the forms, each result equal to the oracle's."""
+    big = make_workload(CONFIGS["config2"], seed=102, n_records=60_000)
+    small = Workload(big.ref_names, big.ref_len, big.taxonomy, big.records.take(np.arange(9_000)), big.avg_read_len,
+                     big.options, "first9000")
+    o_small, o_big = run_workload(small, use_qnames=False), run_workload(big, use_qnames=False)
+    s = Slimm.for_workload(big, device=0)
+    s.push_records_packed(_mask61(small).records)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, run_workload(_mask61(small), use_qnames=False))
+    s.reset(); s.reset_cutoffs()
+    s.push_records_marked(big.records, batch=7_000)      # grows past the packed file's capacity in several steps
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o_big)
+    s.reset(); s.reset_cutoffs()
+    s.push_records(small.records, batch=4_000)             # four arrays again: the flag array appears at the first push
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o_small)
+    s.reset(); s.reset_cutoffs()
+    chk = np.full(len(big.records), 7, dtype=np.uint32)
+    s.push_records_checked(big.records, chk, batch=11_000)  # check words join in; every array grows with its contents
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o_big)
+    s.reset(); s.reset_cutoffs()
+    s.push_records_packed(_mask61(big).records, batch=13_000)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, run_workload(_mask61(big), use_qnames=False))
+
+
+def test_set_records_device_replaces_an_earlier_form():
+    """slimm_set_records_device (four arrays) after packed or run-marked records were set on the same context WITHOUT a
+    reset in between: the call replaces what was there, form included (it once kept `packed`, and the front end read
+    flag bits out of the key)."""
+    import torch
+    w = make_workload(CONFIGS["config2"], seed=103, n_records=50_000)
+    o = run_workload(w, use_qnames=False)
+    r = w.records
+    dev = torch.device("cuda:0")
+    four = [torch.from_numpy(a).to(dev) for a in (r.read_key.view(np.int64), r.ref_id, r.begin_pos, r.flag.view(np.int16))]
+    pk = [torch.from_numpy(a).to(dev) for a in (Slimm.pack_keys(r.read_key, r.flag).view(np.int64), r.ref_id, r.begin_pos)]
+    mk = [torch.from_numpy(a).to(dev) for a in (Slimm.mark_words(r.read_key, r.flag, r.ref_id).view(np.int32), r.begin_pos)]
+    torch.cuda.synchronize()
+    s = Slimm.for_workload(w, device=0)
+    s.set_records_device_packed(*pk)
+    s.set_records_device(*four)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    s.reset(); s.reset_cutoffs()
+    s.set_records_device_marked(*mk)
+    s.set_records_device(*four)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, o)
+    s.reset(); s.reset_cutoffs()
+    s.set_records_device(*four)
+    s.set_records_device_packed(*pk)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, run_workload(_mask61(w), use_qnames=False))

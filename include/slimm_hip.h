@@ -368,6 +368,12 @@ int slimm_time_only_kernel(slimm_ctx* ctx, const char* name);
 int slimm_kernel_times(slimm_ctx* ctx, const char** names, double* ms, uint32_t* launches, uint32_t cap,
                        uint32_t* n, int reset);
 
+/* Diagnostic for record_order = SLIMM_ORDER_ANY: the stream as the device grouped it by read identity for the front end
+ * (after slimm_analyze_alignments): per mapped record its identity (qName key << 2 | mate number, src/slimm.hpp:204-208),
+ * reference and global bin, records of one identity adjacent and in file order.  Copies min(cap, *n) records to host
+ * arrays (any of which may be NULL); *n = the number of mapped records. */
+int slimm_grouped_records(slimm_ctx* ctx, uint64_t* ident, uint32_t* ref, uint32_t* gbin, uint64_t cap, uint64_t* n);
+
 /* ---- host-only helpers (no GPU needed; used by the host driver and testable on CPU) ---- */
 /* get_avg_read_length (src/misc.hpp:509-522). Returns 0 when no record has a sequence (the reference divides by 0). */
 uint32_t slimm_host_avg_read_length(const uint32_t* l_seq, uint64_t n, uint32_t sample_size);

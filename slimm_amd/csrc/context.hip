@@ -69,11 +69,11 @@ struct PinBuf {
 };
 
 enum KernelId {
-    K_MEMSET = 0, K_VALID_COUNT, K_SCAN, K_COMPACT, K_SORT, K_FRONT, K_HIST, K_REF_STATS, K_FILTER,
+    K_MEMSET = 0, K_GROUP_COUNT, K_GROUP_SCAN, K_GROUP_SCATTER, K_GROUP_FINISH, K_FRONT, K_HIST, K_REF_STATS, K_FILTER,
     K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_TILE_COUNT2, K_TILE_SCAN2, K_TILE_SCATTER2,
     K_TILE_HIST2, K_PACK, K_PACK2, K_COUNT
 };
-const char* kKernelNames[K_COUNT] = {"memset_bins", "k_valid_count", "k_scan_tiles", "k_compact", "sort_by_ident",
+const char* kKernelNames[K_COUNT] = {"memset_bins", "k_group_count", "k_group_scan", "k_group_scatter", "k_group_finish",
                                      "k_front", "k_hist", "k_ref_stats", "k_filter", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",
                                      "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2",
@@ -130,20 +130,18 @@ struct slimm_ctx {
     bool has_check = false;        // ... all pushed batches carry one (checked and unchecked pushes do not mix)
     bool packed = false;           // slimm_push_records_packed: 16 bytes per record, no flag array (forms do not mix)
     bool marked = false;           // slimm_push_records_marked: 8 bytes per record, no key array (grouped input only)
-    DevBuf<uint64_t> un_key;       // record_order = ANY with packed records: the four-array form for the compaction
-    DevBuf<uint16_t> un_flag;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
     uint64_t n_pushed = 0;
     // work arrays
+    // record_order = ANY (group_by_ident.hip): the grouped stream {identity, {reference, bin}, check word} + scratch
     DevBuf<uint64_t> c_ident, s_ident;
-    DevBuf<uint32_t> c_ref, c_gbin, s_ref, s_gbin, sort_hist, c_chk, s_chk;
+    DevBuf<uint2> c_pay, s_pay;
+    DevBuf<uint32_t> group_hist, c_chk, s_chk;
     DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
     DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
     DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
     DevBuf<uint4> tot_part;              // per workgroup of k_tile_count: totals of its slots (kernels.h: Totals)
-    DevBuf<uint2> tile_cnt;              // (record_order = ANY: mapped records per tile of the compaction)
-    DevBuf<uint4> scan_sums;             // chunk sums of the multi-workgroup tile scan
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;
     bool keep_bins = true;       // materialise cov / uniq_cov / uniq_cov2 in HBM (slimm_keep_bins)
@@ -314,7 +312,6 @@ void drain_events(slimm_ctx* c) {
 }
 
 int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
-    const uint32_t nt = num_tiles(n) + 2;
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
     HIP_TRY(c, c->tgt_gbin.ensure(n + 8));  // (+ the reach of the bucketing kernels' 16-byte loads, tile_hist.hip: piece_load)
     HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
@@ -331,15 +328,11 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
         HIP_TRY(c, c->sup_cursor.ensure(kMaxSuper));
     }
     if (c->order == SLIMM_ORDER_ANY) {
-        HIP_TRY(c, c->tile_cnt.ensure(nt));
-        HIP_TRY(c, c->scan_sums.ensure(kScanMaxChunks));
         HIP_TRY(c, c->c_ident.ensure(n + 1));
-        HIP_TRY(c, c->c_ref.ensure(n + 1));
-        HIP_TRY(c, c->c_gbin.ensure(n + 1));
+        HIP_TRY(c, c->c_pay.ensure(n + 1));
         HIP_TRY(c, c->s_ident.ensure(n + 1));
-        HIP_TRY(c, c->s_ref.ensure(n + 1));
-        HIP_TRY(c, c->s_gbin.ensure(n + 1));
-        HIP_TRY(c, c->sort_hist.ensure(256ull * nt));
+        HIP_TRY(c, c->s_pay.ensure(n + 1));
+        HIP_TRY(c, c->group_hist.ensure(group_hist_words(group_plan(n))));
         if (c->rec.check) {
             HIP_TRY(c, c->c_chk.ensure(n + 1));
             HIP_TRY(c, c->s_chk.ensure(n + 1));
@@ -556,6 +549,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         }
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
         cc->use_tiles = !(force_direct && force_direct[0] == '1') && TILES(c->tile_shift, tile_hist_setup(c->ntiles2)) == 0;
+        if (cc->order == SLIMM_ORDER_ANY && group_init() != 0) {
+            *out = nullptr;
+            return fail(nullptr, SLIMM_E_HIP, "group_init: hipFuncSetAttribute failed");
+        }
         {
             // default by size: with the register-resident scatter chunks one level wins up to ~10 K tiles (config 3:
             // 494 vs 601 us) and is level with two at 24 K (config 5: 430 vs 396 us)
@@ -1106,44 +1103,46 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     }
     c->bins_exposed = false;
     c->statsA_final = false;
-    const uint32_t nt = num_tiles(n);
     const HostConfig& hc = c->host->config();
     const uint32_t half_read = hc.avg_read_len / 2;
     const uint32_t nslots = front_slots(n);
     if (c->order == SLIMM_ORDER_ANY) {
-        DeviceRecords four = c->rec;
-        if (c->rec.packed) {  // the compaction reads the four-array form
-            HIP_TRY(c, c->un_key.ensure(n + 1));
-            HIP_TRY(c, c->un_flag.ensure(n + 1));
-            launch_unpack_records(st, c->rec.key, n, c->un_key.p, c->un_flag.p);
-            four.key = c->un_key.p;
-            four.flag = c->un_flag.p;
-            four.packed = false;
+        // the records of every read identity adjacent, file order kept among them (group_by_ident.hip): counting passes
+        // over a few hash bits -- the first one straight over the caller's records, filter and bin on the way --, a
+        // finish inside the small buckets, then the same front end as for grouped input
+        GroupJob j;
+        j.plan = group_plan(n);
+        j.in = c->rec;
+        j.n_refs = c->R;
+        j.geo = c->d_geo.p;
+        j.half_read = half_read;
+        j.bin_width = hc.bin_width;
+        j.counters = c->counters.p;
+        j.a = GroupArrays{c->c_ident.p, c->c_pay.p, c->rec.check ? c->c_chk.p : nullptr};
+        j.t = GroupArrays{c->s_ident.p, c->s_pay.p, c->rec.check ? c->s_chk.p : nullptr};
+        j.hist = c->group_hist.p;
+        for (uint32_t pass = 0; pass < j.plan.passes; ++pass) {
+            {
+                KernelTimer t(c, K_GROUP_COUNT);
+                launch_group_count(st, j, pass);
+            }
+            {
+                KernelTimer t(c, K_GROUP_SCAN);
+                launch_group_scan(st, j);
+            }
+            {
+                KernelTimer t(c, K_GROUP_SCATTER);
+                launch_group_scatter(st, j, pass);
+            }
         }
-        // compaction of the mapped records, then a stable sort by read identity makes every read a contiguous run
         {
-            KernelTimer t(c, K_VALID_COUNT);
-            launch_valid_count(st, four, c->R, c->tile_cnt.p, c->counters.p);
-        }
-        {
-            KernelTimer t(c, K_SCAN);
-            launch_scan_tiles(st, c->tile_cnt.p, nt, c->counters.p, CNT_V, -1, nullptr, nullptr, -1, nullptr, c->scan_sums.p);
-        }
-        {
-            KernelTimer t(c, K_COMPACT);
-            launch_compact(st, four, c->R, c->tile_cnt.p, c->d_ref_len.p, c->d_bin_off.p, half_read, hc.bin_width,
-                           c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->c_chk.p);
-        }
-        {
-            KernelTimer t(c, K_SORT);
-            launch_sort_by_ident(st, n, c->counters.p, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->s_ident.p, c->s_ref.p,
-                                 c->s_gbin.p, c->sort_hist.p, c->rec.check ? c->c_chk.p : nullptr,
-                                 c->rec.check ? c->s_chk.p : nullptr);
+            KernelTimer t(c, K_GROUP_FINISH);
+            launch_group_finish(st, j);
         }
         {
             KernelTimer t(c, K_FRONT);
-            launch_front_sorted(st, n, c->c_ident.p, c->c_ref.p, c->c_gbin.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                                c->slots.p, c->wcut.p, c->rec.check ? c->c_chk.p : nullptr);
+            launch_front_sorted(st, n, c->c_ident.p, c->c_pay.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p, c->slots.p, c->wcut.p,
+                                c->rec.check ? c->c_chk.p : nullptr);
         }
     } else {
         // grouped input: one pass straight over the caller's record arrays
@@ -2065,6 +2064,29 @@ int slimm_kernel_times(slimm_ctx* c, const char** names, double* ms, uint32_t* l
         for (int i = 0; i < K_COUNT; ++i) {
             c->k_ms[i] = 0;
             c->k_n[i] = 0;
+        }
+    }
+    return SLIMM_OK;
+}
+
+int slimm_grouped_records(slimm_ctx* c, uint64_t* ident, uint32_t* ref, uint32_t* gbin, uint64_t cap, uint64_t* n) {
+    if (!c || !n) return SLIMM_E_INVALID;
+    if (c->device < 0 || c->order != SLIMM_ORDER_ANY) return fail(c, SLIMM_E_INVALID, "slimm_grouped_records: a device context created for SLIMM_ORDER_ANY");
+    if (!c->analyzed) return fail(c, SLIMM_E_INVALID, "call slimm_analyze_alignments first");
+    (void)hipSetDevice(c->device);
+    uint32_t V = 0;
+    HIP_TRY(c, hipMemcpyAsync(&V, c->counters.p + CNT_V, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n = V;
+    const uint64_t m = std::min<uint64_t>(cap, V);
+    if (m == 0) return SLIMM_OK;
+    if (ident) HIP_TRY(c, hipMemcpy(ident, c->c_ident.p, m * 8, hipMemcpyDeviceToHost));
+    if (ref || gbin) {
+        std::vector<uint2> pay(m);
+        HIP_TRY(c, hipMemcpy(pay.data(), c->c_pay.p, m * 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < m; ++i) {
+            if (ref) ref[i] = pay[i].x;
+            if (gbin) gbin[i] = pay[i].y;
         }
     }
     return SLIMM_OK;

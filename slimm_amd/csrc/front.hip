@@ -287,9 +287,8 @@ using FrontPacked = FrontRawT<true>;
 
 struct FrontSorted {
     const uint64_t* ident;  // key << 2 | mate
-    const uint32_t* cref;
-    const uint32_t* cgbin;
-    const uint32_t* check;  // optional, sorted along with the records
+    const uint2* pay;       // {reference, global bin}
+    const uint32_t* check;  // optional, grouped along with the records
     static constexpr bool kCountsMapped = false;  // the compaction counted the mapped records
     static constexpr bool kMarked = false;
     __device__ uint32_t count(const uint32_t* counters) const { return counters[CNT_V]; }
@@ -304,7 +303,8 @@ struct FrontSorted {
         hi = static_cast<uint32_t>(k >> 32);
     }
     __device__ FrontRaw3 raw(uint32_t i) const {
-        return FrontRaw3{reinterpret_cast<const uint32_t*>(ident)[2 * static_cast<size_t>(i)], cref[i], cgbin[i]};
+        const uint2 q = pay[i];
+        return FrontRaw3{reinterpret_cast<const uint32_t*>(ident)[2 * static_cast<size_t>(i)], q.x, q.y};
     }
     __device__ FrontRec decode(const FrontRaw3& w, bool&) const { return FrontRec{w.a & 3u, w.b, w.c, true}; }
     __device__ FrontRec rec(uint32_t i, bool& bad) const { return decode(raw(i), bad); }
@@ -315,8 +315,9 @@ struct FrontSorted {
         o.klo = k.x;
         o.khi = k.y;
         o.a = k.x;
-        o.b = f_load_at(cref + base, rel * 4u);
-        o.c = f_load_at(cgbin + base, rel * 4u);
+        const uint2 q = f_load_at(pay + base, rel * 8u);
+        o.b = q.x;
+        o.c = q.y;
     }
     __device__ void load_key(uint32_t base, uint32_t rel, uint32_t& lo, uint32_t& hi) const {
         const uint2 k = f_load_at(reinterpret_cast<const uint2*>(ident) + base, rel * 8u);
@@ -1062,12 +1063,12 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
                               counters, tgt_ref, tgt_gbin, slots, wcut);
 }
 
-void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
+void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint2* pay,
                          uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
                          const uint32_t* cchk) {
     const uint32_t ns = front_slots(n_upper);
     if (!ns) return;
-    FrontSorted a{ident, cref, cgbin, cchk};
+    FrontSorted a{ident, pay, cchk};
     if (cchk)
         hipLaunchKernelGGL((k_front<FrontSorted, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
                            tgt_gbin, slots, wcut);

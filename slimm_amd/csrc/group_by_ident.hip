@@ -1,0 +1,644 @@
+// Grouping of the record stream by read identity for record_order = SLIMM_ORDER_ANY (gfx950, wave64).
+//
+// The reference groups the records of a read through a string-keyed hash map (src/slimm.hpp:204-211) and therefore takes
+// them in any order; the first-bin rule (src/read_stat.hpp:116-135, Q1) needs the FILE ORDER of a read's records.  What
+// the single-pass front end (front.hip) needs of the stream is exactly that and nothing more: the records of one
+// identity adjacent, in file order -- not a total order.  Round 1 - 3 made one anyway (an 8-pass LSD radix sort of the
+// 64-bit identity behind a separate compaction: 10 passes over the records).  Here:
+//
+//   1. PARTITION by b bits of a HASH of the qName key, b = log2(records / 4) or so: P = ceil(b / W) stable counting
+//      passes of W bits each, least significant digit first.  The first pass reads the caller's records themselves --
+//      the record filter (src/slimm.hpp:197), the read identity (qName key << 2 | mate, :204-208) and the bin (:200-201)
+//      happen on the way: no compaction passes.  After the last pass the stream is ordered by the b hash bits, file
+//      order kept inside equal bits: a BUCKET of a few records, almost always of one identity.
+//   2. FINISH: a wave walks the buckets that start in its stretch of the stream in windows of 64 records.  A bucket
+//      whose identities are in non-decreasing order already (nearly all) is left alone -- 8 bytes read per record,
+//      nothing written.  The others are put in order by identity, file order kept among equal identities: buckets of
+//      fewer than 64 records by a rank computed with lane shifts (as many steps as the longest such bucket), in place;
+//      longer ones (a read of thousands of records that shares its hash bits with another) by selection, one distinct
+//      identity per sweep, through the scratch arrays.  Any bucket size, any number of identities per bucket.
+//
+// A counting pass (k_gb_count -> k_gb_scan -> k_gb_scatter) is STABLE without a histogram per tile of the stream:
+// G persistent workgroups own G contiguous stretches; the count matrix is [digit][workgroup], its prefix in that order
+// gives every workgroup the start of its own piece of every digit's run, and the workgroup advances those G x 2^W
+// cursors in LDS round by round (rounds of 4096 records; inside a round: per-wave match masks from W ballots, the
+// waves' counts prefixed in LDS -- a wave owns 512 consecutive records of the round, so (wave, chunk, lane) IS file
+// order).  Records go out straight from the registers; a digit's records of one round are consecutive at the digit's
+// cursor, and the L2 of the workgroup's XCD merges them into whole lines.  Per pass: 8 bytes read by the count (the
+// identities only: the payload is a separate array), 16 read + 16 written by the scatter.
+//
+// Layout between the passes and into k_front<FrontSorted>:  ident u64 (key << 2 | mate) | pay uint2 {reference, global
+// bin} (| chk u32, the optional check word of slimm_push_records_checked).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "kernels.h"
+
+namespace slimm {
+
+namespace {
+
+constexpr int kGBlock = 512;
+constexpr int kGWaves = kGBlock / 64;
+constexpr int kGItems = 8;
+constexpr uint32_t kGRound = kGBlock * kGItems;   // records per workgroup and round
+constexpr uint32_t kGWaveRecs = 64 * kGItems;     // consecutive records of a round one wave owns
+constexpr uint32_t kGMaxDigits = 1u << kGroupMaxBits;
+
+__device__ __forceinline__ uint32_t g_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t g_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+__device__ __forceinline__ uint64_t g_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// The hash the digits are cut from: of the qName key (identity >> 2: both mates of a name share a bucket, as they share
+// a run in the front end).  A multiplicative hash; its TOP bits depend on every bit of the key.
+__device__ __forceinline__ uint64_t gb_mix(uint64_t ident) {
+    uint64_t x = ident >> 2;
+    x ^= x >> 31;
+    return x * 0x9E3779B97F4A7C15ull;
+}
+
+// ---- record sources -------------------------------------------------------------------------------------------------
+// the caller's records (first pass).  kPacked: 16-byte records, the flag bits in the key's top three bits.
+template <bool kPacked>
+struct GbRaw {
+    static constexpr bool kRaw = true;
+    const uint64_t* key;
+    const int32_t* ref;
+    const int32_t* pos;
+    const uint16_t* flag;
+    const uint32_t* check;
+    const uint2* geo;  // {contig length, first bin} per reference
+    uint32_t n, n_refs, half_read, bin_width, bw_magic;
+    __device__ uint32_t count(const uint32_t*) const { return n; }
+    // identity and "is a mapped record of a known reference" from the words the count reads (src/slimm.hpp:197, :204-208)
+    __device__ bool ident_of(uint64_t k, uint32_t r, uint32_t f, uint64_t& ident, bool& bad) const {
+        bool mapped;
+        uint32_t mate;
+        if (kPacked) {
+            mapped = static_cast<int64_t>(k) >= 0 && r != 0xffffffffu;
+            mate = static_cast<uint32_t>(k >> 61) & 3u;
+        } else {
+            mapped = !(f & 0x4u) && r != 0xffffffffu;
+            mate = (f & 0x40u) ? 1u : ((f & 0x80u) ? 2u : 0u);
+        }
+        if (mapped && r >= n_refs) {
+            bad = true;
+            mapped = false;
+        }
+        ident = (k << (kPacked ? 3 : 2) >> (kPacked ? 1 : 0)) | mate;  // packed: 61 identity bits, the four arrays: 62
+        return mapped;
+    }
+    __device__ uint32_t div_bin_width(uint32_t v) const {
+        const uint32_t q = __umulhi(v, bw_magic);
+        const uint32_t r = v - q * bin_width;
+        return q + (r >= bin_width ? 1u : 0u);
+    }
+};
+// the stream between the passes
+struct GbIdent {
+    static constexpr bool kRaw = false;
+    const uint64_t* ident;
+    const uint2* pay;
+    const uint32_t* chk;
+    __device__ uint32_t count(const uint32_t* counters) const { return counters[CNT_V]; }
+};
+
+// the workgroup's stretch of the stream
+__device__ __forceinline__ void gb_stretch(uint32_t n, uint32_t& lo, uint32_t& hi) {
+    const uint32_t per = (n + gridDim.x - 1u) / gridDim.x;
+    lo = min(n, blockIdx.x * per);
+    hi = min(n, lo + per);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gb_count: matrix[digit * G + workgroup] = records of the workgroup's stretch with that digit
+// ---------------------------------------------------------------------------------------------------------
+template <typename Src>
+__global__ __launch_bounds__(kGBlock) void k_gb_count(const Src src, uint32_t* __restrict__ counters, uint32_t shift,
+                                                      uint32_t bits, uint32_t* __restrict__ matrix) {
+    __shared__ uint32_t s_h[kGMaxDigits];
+    const uint32_t D = 1u << bits, tid = threadIdx.x;
+    for (uint32_t d = tid; d < D; d += kGBlock) s_h[d] = 0u;
+    __syncthreads();
+    uint32_t lo, hi;
+    gb_stretch(src.count(counters), lo, hi);
+    bool bad = false;
+    for (uint32_t r0 = lo; r0 < hi; r0 += kGRound) {
+        uint64_t k[kGItems];
+        uint32_t r[kGItems], f[kGItems];
+#pragma unroll
+        for (int u = 0; u < kGItems; ++u) {
+            const uint32_t i = min(r0 + u * kGBlock + tid, hi - 1u);  // (clamped: every load of the round in flight at once)
+            if constexpr (Src::kRaw) {
+                k[u] = src.key[i];
+                r[u] = static_cast<uint32_t>(src.ref[i]);
+                f[u] = src.flag ? src.flag[i] : 0u;
+            } else {
+                k[u] = src.ident[i];
+                r[u] = f[u] = 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kGItems; ++u) {
+            bool live = r0 + u * kGBlock + tid < hi;
+            uint64_t ident = k[u];
+            if constexpr (Src::kRaw) live = src.ident_of(k[u], r[u], f[u], ident, bad) && live;
+            if (live) atomicAdd(&s_h[static_cast<uint32_t>(gb_mix(ident) >> shift) & (D - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = tid; d < D; d += kGBlock) matrix[static_cast<size_t>(d) * gridDim.x + blockIdx.x] = s_h[d];
+    if (Src::kRaw && __any(bad) && (tid & 63u) == 0u) atomicOr(&counters[CNT_ERR], static_cast<uint32_t>(ERR_REF_RANGE));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gb_scan: one workgroup per digit: exclusive prefix of its row of the matrix over the workgroups, the row's total
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kGroupMaxGrid) void k_gb_scan(uint32_t* __restrict__ matrix, uint32_t G, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_w[kGroupMaxGrid / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* row = matrix + static_cast<size_t>(blockIdx.x) * G;
+    const uint32_t v = tid < G ? row[tid] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc, o, 64);
+        if (lane >= static_cast<uint32_t>(o)) inc += a;
+    }
+    if (lane == 63u) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kGroupMaxGrid / 64; ++w) {
+        const uint32_t t = s_w[w];
+        before += w < wave ? t : 0u;
+        total += t;
+    }
+    if (tid < G) row[tid] = before + inc - v;
+    if (tid == 0u) totals[blockIdx.x] = total;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gb_scatter: the stable scatter of one pass (header)
+// ---------------------------------------------------------------------------------------------------------
+template <typename Src, bool kChk>
+__global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t* __restrict__ counters, uint32_t shift,
+                                                        uint32_t bits, const uint32_t* __restrict__ matrix,
+                                                        const uint32_t* __restrict__ totals, uint64_t* __restrict__ ident_out,
+                                                        uint2* __restrict__ pay_out, uint32_t* __restrict__ chk_out) {
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    // s_cursor[D] (where the workgroup's next record of each digit goes) | s_wcnt[kGWaves][D] (16-bit: per wave and digit,
+    // first the records of the round seen so far, then the wave's offset inside the digit's records of the round)
+    __shared__ uint32_t s_ws[kGWaves];
+    const uint32_t D = 1u << bits, tid = threadIdx.x, lane = g_lane();
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t* const s_cursor = s_dyn;
+    uint16_t* const s_wcnt = reinterpret_cast<uint16_t*>(s_dyn + D);
+    uint16_t* const my_cnt = s_wcnt + wave * D;
+    uint16_t* const spare = s_wcnt + kGWaves * D + wave;  // a word nobody reads
+    // ---- digit bases: exclusive prefix of the digit totals (every workgroup computes it), plus this workgroup's offset
+    {
+        const uint32_t per = (D + kGBlock - 1u) / kGBlock;  // digits per thread: consecutive ones
+        uint32_t t[kGMaxDigits / kGBlock > 0 ? kGMaxDigits / kGBlock : 1];
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
+            const uint32_t d = tid * per + k;
+            t[k] = (k < per && d < D) ? totals[d] : 0u;
+            mine += t[k];
+        }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(inc, o, 64);
+            if (lane >= static_cast<uint32_t>(o)) inc += a;
+        }
+        if (lane == 63u) s_ws[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kGWaves; ++w) {
+            const uint32_t x = s_ws[w];
+            run += w < wave ? x : 0u;
+            all += x;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
+            const uint32_t d = tid * per + k;
+            if (k < per && d < D) s_cursor[d] = run + matrix[static_cast<size_t>(d) * gridDim.x + blockIdx.x];
+            run += t[k];
+        }
+        // hits_count (src/slimm.hpp:212): the first pass has just counted the mapped records
+        if (Src::kRaw && blockIdx.x == 0u && tid == 0u) counters[CNT_V] = all;
+    }
+    for (uint32_t d = tid; d < kGWaves * D; d += kGBlock) s_wcnt[d] = 0;
+    __syncthreads();
+    uint32_t lo, hi;
+    gb_stretch(src.count(counters), lo, hi);
+    for (uint32_t r0 = lo; r0 < hi; r0 += kGRound) {
+        // ---- the round's records: the wave's 512 consecutive ones in chunks of 64, all loads in flight together
+        uint64_t ident[kGItems];
+        uint2 pay[kGItems];
+        uint32_t chk[kGItems], aux[kGItems];
+        bool live[kGItems];
+        const uint32_t w0 = r0 + wave * kGWaveRecs;
+#pragma unroll
+        for (int u = 0; u < kGItems; ++u) {
+            const uint32_t i = min(w0 + u * 64u + lane, hi - 1u);
+            if constexpr (Src::kRaw) {
+                ident[u] = src.key[i];
+                pay[u].x = static_cast<uint32_t>(src.ref[i]);
+                pay[u].y = static_cast<uint32_t>(src.pos[i]);
+                aux[u] = src.flag ? src.flag[i] : 0u;
+                chk[u] = kChk ? src.check[i] : 0u;
+            } else {
+                ident[u] = src.ident[i];
+                pay[u] = src.pay[i];
+                aux[u] = 0u;
+                chk[u] = kChk ? src.chk[i] : 0u;
+            }
+        }
+        if constexpr (Src::kRaw) {
+            // filter, identity, and the bin: one 8-byte gather of the contig's geometry per record (rows of unmapped
+            // records gather row 0), uint32 wrap-around and clamp as src/slimm.hpp:200-201 (Q3)
+            bool bad = false;
+            uint2 geo[kGItems];
+#pragma unroll
+            for (int u = 0; u < kGItems; ++u) {
+                uint64_t id;
+                live[u] = src.ident_of(ident[u], pay[u].x, aux[u], id, bad) && (w0 + u * 64u + lane < hi);
+                ident[u] = id;
+                geo[u] = src.geo[live[u] ? pay[u].x : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < kGItems; ++u)
+                pay[u].y = geo[u].y + src.div_bin_width(min(pay[u].y + src.half_read, geo[u].x));
+            (void)bad;  // (the count has flagged it)
+        } else {
+#pragma unroll
+            for (int u = 0; u < kGItems; ++u) live[u] = w0 + u * 64u + lane < hi;
+        }
+        // ---- place inside the wave's records of the round, per digit, in file order
+        uint32_t dig[kGItems], place[kGItems];
+#pragma unroll
+        for (int u = 0; u < kGItems; ++u) {
+            const uint32_t d = static_cast<uint32_t>(gb_mix(ident[u]) >> shift) & (D - 1u);
+            uint64_t peers = g_ballot(live[u]);
+            for (uint32_t b = 0; b < bits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bm = g_ballot(bit);
+                peers &= bit ? bm : ~bm;
+            }
+            const uint32_t rank = g_rank(peers);
+            // (no branch on per-lane state next to the wave barriers: every lane loads, every lane stores -- the first
+            // lane of a digit the new count, the others into the wave's spare word.  Cheaper than exec-mask bookkeeping on
+            // the GPU, and the host emulator of tests/native tells collectives apart by call site, which a compiler that
+            // clones the code behind an `if` would double.)
+            const uint32_t before = my_cnt[d];
+            __builtin_amdgcn_wave_barrier();  // (every lane has read the count before the first lane of a digit raises it)
+            const bool lead = live[u] & (rank == 0u);
+            uint16_t* const to = lead ? my_cnt + d : spare;
+            *to = static_cast<uint16_t>(before + static_cast<uint32_t>(__popcll(peers)));
+            __builtin_amdgcn_wave_barrier();
+            dig[u] = d;
+            place[u] = before + rank;
+        }
+        __syncthreads();
+        // ---- the waves' counts of every digit -> each wave's offset inside the digit's records of the round
+        uint32_t tot[kGMaxDigits / kGBlock > 0 ? kGMaxDigits / kGBlock : 1];
+#pragma unroll
+        for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
+            const uint32_t d = tid + k * kGBlock;
+            uint32_t run = 0;
+            if (d < D) {
+#pragma unroll
+                for (uint32_t w = 0; w < kGWaves; ++w) {
+                    const uint32_t c = s_wcnt[w * D + d];
+                    s_wcnt[w * D + d] = static_cast<uint16_t>(run);
+                    run += c;
+                }
+            }
+            tot[k] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kGItems; ++u) {
+            if (live[u]) {
+                const uint32_t dst = s_cursor[dig[u]] + my_cnt[dig[u]] + place[u];
+                ident_out[dst] = ident[u];
+                pay_out[dst] = pay[u];
+                if (kChk) chk_out[dst] = chk[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
+            const uint32_t d = tid + k * kGBlock;
+            if (d < D) {
+                s_cursor[d] += tot[k];
+#pragma unroll
+                for (uint32_t w = 0; w < kGWaves; ++w) s_wcnt[w * D + d] = 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gb_finish (header): identities in order inside every bucket of equal hash bits, file order among equal identities
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFinishRecs = 1024;  // records per wave: it handles the buckets that START among them
+
+__device__ __forceinline__ uint32_t g_shr1(uint32_t v, uint32_t lane0) {  // the value of the lane before
+    return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t g_shl1(uint32_t v, uint32_t lane63) {  // the value of the lane behind
+    return __builtin_amdgcn_update_dpp(lane63, v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint64_t g_u64(uint32_t lo, uint32_t hi) { return (static_cast<uint64_t>(hi) << 32) | lo; }
+__device__ __forceinline__ uint64_t g_readlane64(uint64_t v, uint32_t l) {
+    return g_u64(__builtin_amdgcn_readlane(static_cast<uint32_t>(v), l), __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), l));
+}
+__device__ __forceinline__ uint64_t g_wave_min64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = g_u64(__shfl_xor(static_cast<uint32_t>(v), o, 64), __shfl_xor(static_cast<uint32_t>(v >> 32), o, 64));
+        v = a < v ? a : v;
+    }
+    return v;
+}
+
+// A bucket of 64 records or more (or one that the window code could not see the end of), starting at record p.
+// Returns the index behind it.
+template <bool kChk>
+__device__ __forceinline__ uint32_t finish_long(uint64_t* __restrict__ ident, uint2* __restrict__ pay, uint32_t* __restrict__ chk,
+                                                uint64_t* __restrict__ t_ident, uint2* __restrict__ t_pay,
+                                                uint32_t* __restrict__ t_chk, uint32_t p, uint32_t V, uint32_t hshift,
+                                                uint32_t lane) {
+    const uint64_t h0 = gb_mix(ident[p]) >> hshift;
+    // 1. where it ends; whether its identities are in order already
+    uint32_t end = p;
+    bool sorted = true;
+    uint64_t last = 0;
+    while (true) {
+        const uint32_t i = end + lane;
+        const bool in = i < V;
+        const uint64_t id = ident[in ? i : V - 1u];
+        const uint64_t same = g_ballot(in && (gb_mix(id) >> hshift) == h0);
+        const uint32_t n_in = (~same) == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(~same));
+        const uint64_t prev = g_u64(g_shr1(static_cast<uint32_t>(id), static_cast<uint32_t>(last)),
+                                    g_shr1(static_cast<uint32_t>(id >> 32), static_cast<uint32_t>(last >> 32)));
+        const uint64_t in_mask = n_in >= 64u ? ~0ull : ((1ull << n_in) - 1ull);
+        sorted = sorted & ((g_ballot(id < prev) & in_mask) == 0ull);
+        if (n_in) last = g_readlane64(id, n_in - 1u);
+        end += n_in;
+        if (n_in < 64u) break;
+    }
+    if (sorted) return end;
+    // 2. selection: the smallest identity not placed yet, all its records in file order, and again
+    uint32_t out = p;
+    uint64_t bound = 0;
+    while (out < end) {
+        uint64_t m = ~0ull;
+        for (uint32_t cb = p; cb < end; cb += 64u) {
+            const uint32_t i = cb + lane;
+            const uint64_t id = ident[i < end ? i : end - 1u];
+            const uint64_t cand = (i < end && id >= bound) ? id : ~0ull;
+            m = cand < m ? cand : m;
+        }
+        m = g_wave_min64(m);
+        for (uint32_t cb = p; cb < end; cb += 64u) {
+            const uint32_t i = cb + lane;
+            const bool in = i < end;
+            const uint64_t id = ident[in ? i : end - 1u];
+            const bool hit = in && id == m;
+            const uint64_t hm = g_ballot(hit);
+            if (hit) {
+                const uint32_t dst = out + g_rank(hm);
+                t_ident[dst] = id;
+                t_pay[dst] = pay[i];
+                if (kChk) t_chk[dst] = chk[i];
+            }
+            out += static_cast<uint32_t>(__popcll(hm));
+        }
+        bound = m + 1ull;
+    }
+    // 3. back from the scratch arrays (this wave's own stores, read back past the vector cache)
+    __threadfence();
+    __builtin_amdgcn_wave_barrier();  // (lock step on the GPU; where the host emulator's lanes wait for each other's stores)
+    for (uint32_t cb = p; cb < end; cb += 64u) {
+        const uint32_t i = cb + lane;
+        if (i < end) {
+            ident[i] = __hip_atomic_load(&t_ident[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t q = __hip_atomic_load(reinterpret_cast<const uint64_t*>(&t_pay[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pay[i] = make_uint2(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32));
+            if (kChk) chk[i] = __hip_atomic_load(&t_chk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return end;
+}
+
+template <bool kChk>
+__global__ __launch_bounds__(64) void k_gb_finish(uint64_t* __restrict__ ident, uint2* __restrict__ pay, uint32_t* __restrict__ chk,
+                                                  uint64_t* __restrict__ t_ident, uint2* __restrict__ t_pay,
+                                                  uint32_t* __restrict__ t_chk, const uint32_t* __restrict__ counters,
+                                                  uint32_t hshift) {
+    const uint32_t V = counters[CNT_V];
+    const uint32_t lane = g_lane();
+    const uint32_t a = blockIdx.x * kFinishRecs;
+    if (a >= V) return;
+    const uint32_t e = min(V, a + kFinishRecs);
+    // the first bucket that starts at or behind a
+    uint32_t p = a;
+    if (a > 0u) {
+        const uint64_t hprev = gb_mix(ident[a - 1u]) >> hshift;
+        while (true) {
+            const uint32_t i = p + lane;
+            const bool in = i < V;
+            const uint64_t id = ident[in ? i : V - 1u];
+            const uint64_t same = g_ballot(in && (gb_mix(id) >> hshift) == hprev);
+            const uint32_t n_in = (~same) == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(~same));
+            p += n_in;
+            if (n_in < 64u) break;
+        }
+    }
+    while (p < e) {  // p: a bucket starts here, p < V
+        const uint32_t i = p + lane;
+        const bool in = i < V;
+        const uint64_t id = ident[in ? i : V - 1u];
+        const uint64_t h = gb_mix(id) >> hshift;
+        const uint32_t hl = static_cast<uint32_t>(h), hh = static_cast<uint32_t>(h >> 32);
+        const uint32_t pl = g_shr1(hl, ~hl), ph = g_shr1(hh, hh);  // (lane 0 starts a bucket: p is a bucket start)
+        const bool start = in & ((pl != hl) | (ph != hh));
+        const uint64_t S = g_ballot(start);
+        // whole buckets: up to the last bucket start of the window -- or to the end of the stream
+        uint32_t X = p + 64u >= V ? V - p : 63u - static_cast<uint32_t>(__builtin_clzll(S));
+        if (e - p < 64u) {  // buckets that start at or behind e are the next wave's
+            const uint64_t beyond = S & ~((1ull << (e - p)) - 1ull);
+            if (beyond) X = min(X, static_cast<uint32_t>(__builtin_ctzll(beyond)));
+        }
+        if (X == 0u) {
+            p = finish_long<kChk>(ident, pay, chk, t_ident, t_pay, t_chk, p, V, hshift, lane);
+            continue;
+        }
+        const uint64_t PR = X >= 64u ? ~0ull : ((1ull << X) - 1ull);
+        const uint32_t idl = static_cast<uint32_t>(id), idh = static_cast<uint32_t>(id >> 32);
+        const uint64_t prev = g_u64(g_shr1(idl, 0u), g_shr1(idh, 0u));
+        const uint64_t dis = g_ballot(id < prev) & ~S & PR;  // a record in front of which a larger identity of its bucket lies
+        if (dis) {
+            // my bucket: lanes [bs, be)
+            const uint64_t Sx = S & PR;
+            const uint64_t le = lane >= 63u ? ~0ull : ((2ull << lane) - 1ull);
+            const uint32_t bs = 63u - static_cast<uint32_t>(__builtin_clzll((Sx & le) | 1ull));
+            const uint64_t above = Sx & ~le;
+            const uint32_t be = above ? static_cast<uint32_t>(__builtin_ctzll(above)) : X;
+            const bool mine = lane < X && ((dis >> bs) & (((be - bs) >= 64u) ? ~0ull : ((1ull << (be - bs)) - 1ull))) != 0ull;
+            const uint32_t back = mine ? lane - bs : 0u, fwd = mine ? be - 1u - lane : 0u;
+            // rank inside the bucket: records in front with an identity <= mine, records behind with one < mine
+            uint32_t rank = 0;
+            uint32_t bl = idl, bh = idh, fl = idl, fh = idh;
+            for (uint32_t d = 1; g_ballot(back >= d || fwd >= d) != 0ull; ++d) {
+                bl = g_shr1(bl, 0u);
+                bh = g_shr1(bh, 0u);
+                fl = g_shl1(fl, 0u);
+                fh = g_shl1(fh, 0u);
+                rank += (back >= d && g_u64(bl, bh) <= id) ? 1u : 0u;
+                rank += (fwd >= d && g_u64(fl, fh) < id) ? 1u : 0u;
+            }
+            const uint2 py = pay[in ? i : V - 1u];
+            const uint32_t ck = kChk ? chk[in ? i : V - 1u] : 0u;
+            __builtin_amdgcn_wave_barrier();  // (every lane has loaded its record before any lane stores one: lockstep on
+                                              // the GPU, a meeting point for the host emulator's lanes)
+            if (mine && bs + rank != lane) {
+                const uint32_t dst = p + bs + rank;
+                ident[dst] = id;
+                pay[dst] = py;
+                if (kChk) chk[dst] = ck;
+            }
+        }
+        p += X;
+    }
+}
+
+// test / tuning knobs, read at every call (a test varies them inside one process): SLIMM_GROUP_BITS = hash bits of a
+// bucket, SLIMM_GROUP_WIDTH = widest digit of a pass, SLIMM_GROUP_GRID = persistent workgroups of a pass
+uint32_t g_env_u32(const char* name) {
+    const char* e = getenv(name);
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? static_cast<uint32_t>(v) : 0u;
+}
+
+}  // namespace
+
+GroupPlan group_plan(uint32_t n_records) {
+    GroupPlan g;
+    // buckets of about four records: one read of the usual kind each
+    uint32_t b = 8;
+    while (b < 40u && (1ull << (b + 2u)) < n_records) ++b;
+    if (const uint32_t o = g_env_u32("SLIMM_GROUP_BITS")) b = std::min(o, 40u);
+    uint32_t wmax = kGroupDefaultBits;
+    if (const uint32_t o = g_env_u32("SLIMM_GROUP_WIDTH")) wmax = std::min(o, kGroupMaxBits);
+    g.passes = (b + wmax - 1u) / wmax;
+    g.width = (b + g.passes - 1u) / g.passes;
+    g.bits = g.passes * g.width;
+    g.grid = kGroupMaxGrid;
+    if (const uint32_t o = g_env_u32("SLIMM_GROUP_GRID")) g.grid = std::min(o, kGroupMaxGrid);
+    return g;
+}
+
+size_t group_hist_words(const GroupPlan& g) { return (static_cast<size_t>(g.grid) + 1u) << g.width; }
+
+// where pass `pass` writes: the arrays alternate and the last pass ends in job.a
+static const GroupArrays& gb_dest(const GroupJob& j, uint32_t pass) { return ((j.plan.passes - 1u - pass) & 1u) ? j.t : j.a; }
+static uint32_t gb_shift(const GroupJob& j, uint32_t pass) { return 64u - j.plan.bits + pass * j.plan.width; }
+template <bool kPacked>
+static GbRaw<kPacked> gb_raw(const GroupJob& j) {
+    GbRaw<kPacked> src;
+    src.key = j.in.key, src.ref = j.in.ref, src.pos = j.in.pos, src.flag = j.in.flag, src.check = j.in.check, src.geo = j.geo;
+    src.n = j.in.n, src.n_refs = j.n_refs, src.half_read = j.half_read, src.bin_width = j.bin_width;
+    src.bw_magic = j.bin_width ? 0xffffffffu / j.bin_width : 0u;
+    return src;
+}
+
+void launch_group_count(hipStream_t st, const GroupJob& j, uint32_t pass) {
+    if (j.in.n == 0) return;
+    const uint32_t G = j.plan.grid, W = j.plan.width, shift = gb_shift(j, pass);
+    if (pass == 0) {
+        if (j.in.packed)
+            hipLaunchKernelGGL((k_gb_count<GbRaw<true>>), dim3(G), dim3(kGBlock), 0, st, gb_raw<true>(j), j.counters, shift, W, j.hist);
+        else
+            hipLaunchKernelGGL((k_gb_count<GbRaw<false>>), dim3(G), dim3(kGBlock), 0, st, gb_raw<false>(j), j.counters, shift, W, j.hist);
+    } else {
+        const GroupArrays& s = gb_dest(j, pass - 1u);
+        hipLaunchKernelGGL((k_gb_count<GbIdent>), dim3(G), dim3(kGBlock), 0, st, GbIdent{s.ident, s.pay, s.chk}, j.counters, shift, W,
+                           j.hist);
+    }
+}
+
+void launch_group_scan(hipStream_t st, const GroupJob& j) {
+    if (j.in.n == 0) return;
+    hipLaunchKernelGGL(k_gb_scan, dim3(1u << j.plan.width), dim3(kGroupMaxGrid), 0, st, j.hist, j.plan.grid,
+                       j.hist + (static_cast<size_t>(j.plan.grid) << j.plan.width));
+}
+
+void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass) {
+    if (j.in.n == 0) return;
+    const uint32_t G = j.plan.grid, W = j.plan.width, D = 1u << W, shift = gb_shift(j, pass);
+    const uint32_t* totals = j.hist + (static_cast<size_t>(G) << W);
+    const size_t lds = static_cast<size_t>(D) * 4u + static_cast<size_t>(kGWaves) * (D + 1u) * 2u;
+    const bool has_chk = j.in.check != nullptr;
+    const GroupArrays& o = gb_dest(j, pass);
+    auto go = [&](auto src) {
+        using Src = decltype(src);
+        if (has_chk)
+            hipLaunchKernelGGL((k_gb_scatter<Src, true>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist, totals,
+                               o.ident, o.pay, o.chk);
+        else
+            hipLaunchKernelGGL((k_gb_scatter<Src, false>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist, totals,
+                               o.ident, o.pay, o.chk);
+    };
+    if (pass == 0) {
+        if (j.in.packed)
+            go(gb_raw<true>(j));
+        else
+            go(gb_raw<false>(j));
+    } else {
+        const GroupArrays& s = gb_dest(j, pass - 1u);
+        go(GbIdent{s.ident, s.pay, s.chk});
+    }
+}
+
+void launch_group_finish(hipStream_t st, const GroupJob& j) {
+    if (j.in.n == 0) return;
+    if (getenv("SLIMM_GROUP_NO_FINISH")) return;  // DEBUG
+    const uint32_t fgrid = (j.in.n + kFinishRecs - 1u) / kFinishRecs;
+    if (j.in.check)
+        hipLaunchKernelGGL((k_gb_finish<true>), dim3(fgrid), dim3(64), 0, st, j.a.ident, j.a.pay, j.a.chk, j.t.ident, j.t.pay, j.t.chk,
+                           j.counters, 64u - j.plan.bits);
+    else
+        hipLaunchKernelGGL((k_gb_finish<false>), dim3(fgrid), dim3(64), 0, st, j.a.ident, j.a.pay, j.a.chk, j.t.ident, j.t.pay, j.t.chk,
+                           j.counters, 64u - j.plan.bits);
+}
+
+int group_init() {
+    // dynamic LDS beyond 64 KB needs the attribute
+    const int lds = static_cast<int>(kGMaxDigits * 4u + kGWaves * (kGMaxDigits + 1u) * 2u);
+    hipError_t e = hipSuccess;
+    auto set = [&](const void* f) {
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    };
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, true>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, true>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, true>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, false>));
+    return e == hipSuccess ? 0 : 1;
+}
+
+}  // namespace slimm

@@ -101,7 +101,6 @@ struct DeviceRecords {
                           // reference + 1 | mate << 29 | starts a qName run << 31 (slimm_push_records_marked)
 };
 
-uint32_t num_tiles(uint32_t n);
 
 // ---- front.hip: the single-pass front end of phase A ----
 // A slot = kSlotRecs consecutive records; its targets (the runs that START in it) lie compacted at
@@ -124,23 +123,13 @@ uint32_t front_slots(uint32_t n_records);
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
                       uint2* wcut, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // t0 / t1: the dispatch's time stamps
-void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint32_t* cref, const uint32_t* cgbin,
+void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint2* pay,
                          uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
-                         const uint32_t* cchk = nullptr);  // cchk: check words (equal keys must carry equal ones)
+                         const uint32_t* cchk = nullptr);  // pay: {reference, global bin}; cchk: check words (equal keys must carry equal ones)
 
-// packed records -> the four-array form (identity masked to 61 bits, flag = 0x4 / 0x40 / 0x80 bits), for the sort path
-void launch_unpack_records(hipStream_t st, const uint64_t* packed_key, uint32_t n, uint64_t* key, uint16_t* flag);
 // diagnostic: run starts whose identity (key & id_mask) started an earlier run too; tab: (tab_mask + 1) words of ~0
 void launch_check_grouping(hipStream_t st, const uint64_t* key, uint32_t n, uint64_t id_mask, uint64_t* tab, uint32_t tab_mask,
                            uint32_t* n_split);
-void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters);
-constexpr uint32_t kScanMaxChunks = 256;  // chunk sums of the multi-workgroup tile scan (2^31 records -> 128 chunks)
-void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off, const uint32_t* extra = nullptr, int slot_extra = -1, uint32_t* tail = nullptr,
-                       uint4* sums = nullptr);
-void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
-                    const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
-                    uint32_t* cgbin, uint32_t* cchk = nullptr);  // cchk: the check words of in.check, when it has any
 // the direct-atomics fallback of the coverage histograms (too many bins for the LDS tile tables)
 // (also adds the stream's totals to counters[CNT_M / CNT_P] -- and [CNT_V] when count_mapped: the compaction of the
 // sort path has counted the mapped records already -- and to tail[0..2]; all zero on entry)
@@ -260,11 +249,38 @@ namespace tiles14 {
 // TILES(shift, launch_tile_count(st, ...)): the call in the namespace of the tile size
 #define TILES(shift, call) ((shift) == ::slimm::kTileShiftLarge ? ::slimm::tiles14::call : ::slimm::tiles13::call)
 
-// Stable LSD radix sort of the compacted records by read identity (record_order = ANY).  Sorts (ident, ref, gbin)
-// in place using the given scratch arrays of the same length; n is read from counters[CNT_V] on the device and
-// n_upper bounds it for the launch geometry.  hist must hold 256 * (num_tiles(n_upper) + 1) uint32.
-void launch_sort_by_ident(hipStream_t st, uint32_t n_upper, const uint32_t* counters, uint64_t* ident, uint32_t* cref,
-                          uint32_t* cgbin, uint64_t* ident_tmp, uint32_t* cref_tmp, uint32_t* cgbin_tmp, uint32_t* hist,
-                          uint32_t* cchk = nullptr, uint32_t* cchk_tmp = nullptr);  // an optional third payload word
+// ---- group_by_ident.hip: record_order = ANY -- the records of every read identity adjacent, file order kept among them ----
+// (stable counting passes over a few bits of a hash of the qName key, then a finish inside the small buckets of equal
+// hash bits; the first pass reads the caller's records, so there is no compaction step)
+constexpr uint32_t kGroupMaxBits = 11;      // widest digit of a pass
+constexpr uint32_t kGroupDefaultBits = 8;   // ... the width a plan aims for (SLIMM_GROUP_WIDTH overrides)
+constexpr uint32_t kGroupMaxGrid = 512;     // persistent workgroups of a pass = stretches of the stream = matrix columns
+struct GroupPlan {
+    uint32_t passes = 1, width = 8, bits = 8;  // bits = passes * width hash bits make a bucket
+    uint32_t grid = kGroupMaxGrid;
+};
+GroupPlan group_plan(uint32_t n_records);
+size_t group_hist_words(const GroupPlan& g);   // count matrix [2^width][grid] + digit totals
+struct GroupArrays {
+    uint64_t* ident = nullptr;  // qName key << 2 | mate number
+    uint2* pay = nullptr;       // {reference, global bin}
+    uint32_t* chk = nullptr;    // check words (slimm_push_records_checked), or null
+};
+struct GroupJob {
+    GroupPlan plan;
+    DeviceRecords in;           // the caller's records (four arrays or packed)
+    uint32_t n_refs = 0;
+    const uint2* geo = nullptr; // {contig length, first bin} per reference
+    uint32_t half_read = 0, bin_width = 0;
+    uint32_t* counters = nullptr;  // counters[CNT_V] = mapped records, written by the first scatter
+    GroupArrays a, t;           // the result ends in `a`; `t` is scratch of the same length
+    uint32_t* hist = nullptr;   // group_hist_words(plan) words
+};
+// pass p: count -> scan -> scatter, p = 0 .. plan.passes - 1; then the finish
+void launch_group_count(hipStream_t st, const GroupJob& j, uint32_t pass);
+void launch_group_scan(hipStream_t st, const GroupJob& j);
+void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass);
+void launch_group_finish(hipStream_t st, const GroupJob& j);
+int group_init();  // once per process and device: dynamic LDS attributes; 0 = ok
 
 }  // namespace slimm

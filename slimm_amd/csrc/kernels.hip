@@ -4,13 +4,13 @@
 // (and by the L2/fabric atomic rate where bins are hit at random), never by arithmetic -- there is no MFMA work here.
 // Layout (all SoA, 32-bit indices; one context handles < 2^31 records):
 //   records   key u64 | ref i32 | pos i32 | flag u16               (what the reference reads per BamAlignmentRecord)
-//   compact   ident u64 | ref u32 | gbin u32 | fl u8               (mapped records only, file order kept)
+//   grouped   ident u64 | {ref u32, gbin u32}                      (record_order = ANY: mapped records, a read's adjacent)
 //   targets   tgt_ref u32 (bit31 = first target of its read) | tgt_gbin u32   (CSR over reads: read_off u32[M+1])
 //   bins      cov[Bp] | uniq_cov[Bp] | tail[64] | uniq_cov2[Bp]    (u32; each reference padded to a multiple of 4 bins)
 //
 // Reference semantics implemented here:
-//   a3  record filter + bin + read identity      src/slimm.hpp:194-213        k_runs / k_emit on the raw records;
-//                                                                              k_valid_count, k_compact feed the sort path
+//   a3  record filter + bin + read identity      src/slimm.hpp:194-213        k_front on the raw records (front.hip); the first
+//                                                                              pass of group_by_ident.hip for record_order = ANY
 //   a4  first bin per distinct (read, ref)       src/read_stat.hpp:116-135    k_runs, k_emit (runs.hip)
 //   a5  cov / uniq_cov histograms                src/slimm.hpp:219-257        tile_hist.hip (k_hist = fallback)
 //   a7  non-zero bin counts (+ per-ref sums)     src/reference_contig.hpp:84-91   k_tile_hist (tile_hist.hip); k_ref_stats
@@ -30,8 +30,6 @@
 namespace slimm {
 
 constexpr int kBlock = 256;
-constexpr int kItems = 8;
-constexpr int kTile = kBlock * kItems;  // records per workgroup
 constexpr int kWaves = kBlock / 64;
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -46,265 +44,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-__device__ __forceinline__ bool record_is_mapped(uint16_t flag, int32_t ref) {
-    return !(flag & 0x4) && ref != -1;  // src/slimm.hpp:197
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_valid_count: mapped records per tile (pass 1 of the compaction).  Flags records naming a reference >= n_refs.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_valid_count(const uint16_t* __restrict__ flag, const int32_t* __restrict__ ref,
-                                                        uint32_t n, uint32_t n_refs, uint2* __restrict__ tile_cnt,
-                                                        uint32_t* __restrict__ counters) {
-    __shared__ uint32_t s_w[kWaves];
-    const uint32_t base = blockIdx.x * kTile;
-    uint32_t cnt = 0;
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        uint32_t i = base + k * kBlock + threadIdx.x;
-        if (i < n) {
-            int32_t r = ref[i];
-            bool v = record_is_mapped(flag[i], r);
-            if (v && static_cast<uint32_t>(r) >= n_refs) {
-                bad = true;
-                v = false;
-            }
-            cnt += v;
-        }
-    }
-    cnt = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&counters[CNT_ERR], ERR_REF_RANGE);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) t += s_w[w];
-        tile_cnt[blockIdx.x] = make_uint2(t, 0u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_scan_tiles: exclusive scan of the per-tile (x, y) counts; totals go to counters[slot_x/slot_y] and to
-// tile_cnt[ntiles].  Up to 16 K tiles (32 M records) ONE workgroup does it in one pass over registers; beyond that the tiles are cut
-// into chunks of kScanChunk, k_scan_sums reduces every chunk, and the workgroups of k_scan_tiles start from the sum of
-// the chunks before theirs (one workgroup needed 0.86 ms for the 488 K tiles of 10^9 records).
-// When read_off != nullptr also writes the CSR sentinel read_off[total_x] = total_y.
-// ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kScanRegs = 16;    // entries per thread of the one-pass scan
-constexpr uint32_t kScanChunk = 8192;  // tiles per workgroup of the chunked scan (SLIMM_SCAN_CHUNK overrides, for tests)
-
-__global__ __launch_bounds__(1024) void k_scan_sums(const uint2* __restrict__ tile_cnt, uint32_t ntiles,
-                                                    const uint32_t* __restrict__ extra, uint4* __restrict__ sums,
-                                                    uint32_t chunk) {
-    __shared__ uint4 s_w[16];
-    const uint32_t lo = blockIdx.x * chunk, hi = min(lo + chunk, ntiles);
-    uint32_t x = 0, y = 0, e = 0;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        const uint2 v = tile_cnt[i];
-        x += v.x;
-        y += v.y;
-        if (extra) e += extra[i];
-    }
-    x = wave_sum(x);
-    y = wave_sum(y);
-    e = wave_sum(e);
-    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = make_uint4(x, y, e, 0u);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint4 t = make_uint4(0u, 0u, 0u, 0u);
-        for (int w = 0; w < 16; ++w) {
-            t.x += s_w[w].x;
-            t.y += s_w[w].y;
-            t.z += s_w[w].z;
-        }
-        sums[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_scan_tiles(uint2* __restrict__ tile_cnt, uint32_t ntiles,
-                                                     uint32_t* __restrict__ counters, int slot_x, int slot_y,
-                                                     uint32_t* __restrict__ read_off, const uint32_t* __restrict__ extra,
-                                                     int slot_extra, uint32_t* __restrict__ tail,
-                                                     const uint4* __restrict__ sums, uint32_t chunk) {
-    // coalesced chunks of 1024 entries with a running carry: wave scan by shuffles, wave totals through LDS
-    __shared__ uint2 s_wave[16];
-    __shared__ uint32_t s_extra[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // one workgroup: the whole range; several: my chunk, starting from the totals of the chunks before it
-    const uint32_t lo = gridDim.x > 1 ? blockIdx.x * chunk : 0u;
-    const uint32_t hi = gridDim.x > 1 ? min(lo + chunk, ntiles) : ntiles;
-    uint2 carry = make_uint2(0u, 0u);
-    uint32_t ex = 0, ex_before = 0;
-    if (gridDim.x > 1) {
-        for (uint32_t g = 0; g < blockIdx.x; ++g) {  // (uniform loads, at most a few dozen chunks)
-            const uint4 t = sums[g];
-            carry.x += t.x;
-            carry.y += t.y;
-            ex_before += t.z;
-        }
-    }
-    const bool one_pass = gridDim.x == 1 && ntiles > 0 && ntiles <= 1024u * kScanRegs;
-    if (one_pass) {
-        // The usual case (up to 16 K tiles = 16 M records): every thread takes `per` consecutive entries into registers
-        // with all its loads in flight together, scans them, and ONE workgroup scan of the thread totals follows --
-        // a loop of 1024-entry chunks pays a load round trip and two barriers per chunk (10 us at 9.8 K tiles).
-        const uint32_t per = (ntiles + 1023u) >> 10, base = tid * per;
-        uint2 v[kScanRegs];
-        uint2 mine = make_uint2(0u, 0u);
-#pragma unroll
-        for (uint32_t k = 0; k < kScanRegs; ++k) {
-            const uint32_t i = base + k;
-            const bool in = k < per && i < ntiles;
-            const uint32_t ic = min(i, ntiles - 1u);  // clamped: a load behind a per-element branch is a round trip of its own
-            const uint2 t = tile_cnt[ic];
-            const uint32_t e = extra ? extra[ic] : 0u;
-            v[k] = in ? t : make_uint2(0u, 0u);
-            if (in) ex += e;
-            mine.x += v[k].x;
-            mine.y += v[k].y;
-        }
-        uint2 inc = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
-            if (lane >= static_cast<uint32_t>(o)) {
-                inc.x += ax;
-                inc.y += ay;
-            }
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint2 run = make_uint2(inc.x - mine.x, inc.y - mine.y);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint2 t = s_wave[w];
-            if (w < static_cast<int>(wave)) {
-                run.x += t.x;
-                run.y += t.y;
-            }
-            carry.x += t.x;
-            carry.y += t.y;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < kScanRegs; ++k) {
-            const uint32_t i = base + k;
-            if (k < per && i < ntiles) tile_cnt[i] = run;
-            run.x += v[k].x;
-            run.y += v[k].y;
-        }
-        __syncthreads();
-    }
-    for (uint32_t c0 = lo; c0 < hi && !one_pass; c0 += 1024) {
-        const uint32_t i = c0 + tid;
-        uint2 v = (i < hi) ? tile_cnt[i] : make_uint2(0u, 0u);
-        if (extra && i < hi) ex += extra[i];
-        uint2 inc = v;  // inclusive scan inside the wave
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
-            if (lane >= static_cast<uint32_t>(o)) {
-                inc.x += ax;
-                inc.y += ay;
-            }
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint2 before = carry, total = make_uint2(0u, 0u);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const uint2 t = s_wave[w];
-            if (w < static_cast<int>(wave)) {
-                before.x += t.x;
-                before.y += t.y;
-            }
-            total.x += t.x;
-            total.y += t.y;
-        }
-        if (i < hi) tile_cnt[i] = make_uint2(before.x + inc.x - v.x, before.y + inc.y - v.y);
-        carry.x += total.x;
-        carry.y += total.y;
-        __syncthreads();
-    }
-    if (blockIdx.x + 1 != gridDim.x) return;  // the workgroup of the last chunk publishes the totals
-    ex = wave_sum(ex);
-    if (lane == 0) s_extra[wave] = ex;
-    __syncthreads();
-    if (tid == 0) {
-        const uint2 tot = carry;
-        tile_cnt[ntiles] = tot;
-        counters[slot_x] = tot.x;
-        if (slot_y >= 0) counters[slot_y] = tot.y;
-        if (read_off) read_off[tot.x] = tot.y;
-        uint32_t v = counters[CNT_V];
-        if (extra) {
-            uint32_t e = ex_before;
-            for (int w = 0; w < 16; ++w) e += s_extra[w];
-            counters[slot_extra] = e;
-            if (slot_extra == CNT_V) v = e;
-        }
-        if (tail) {  // the additive scalars that travel with the bins through the multi-GPU exchange
-            tail[0] = v;       // hits
-            tail[1] = tot.x;   // matches (reads)
-            tail[2] = tot.y;   // targets
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_compact: pass 2 of the compaction.  Drops unmapped records, folds the mate number into the identity
-// (src/slimm.hpp:204-208: qName + ".1" / ".2"), computes the bin of the record (src/slimm.hpp:200-201) and
-// stores it as a global bin index (bin_off[ref] + bin).
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_compact(const uint64_t* __restrict__ key, const int32_t* __restrict__ ref,
-                                                    const int32_t* __restrict__ pos, const uint16_t* __restrict__ flag,
-                                                    uint32_t n, uint32_t n_refs, const uint2* __restrict__ tile_off,
-                                                    const uint32_t* __restrict__ ref_len,
-                                                    const uint32_t* __restrict__ bin_off, uint32_t half_read,
-                                                    uint32_t bin_width, uint64_t* __restrict__ ident,
-                                                    uint32_t* __restrict__ cref, uint32_t* __restrict__ cgbin,
-                                                    const uint32_t* __restrict__ chk, uint32_t* __restrict__ cchk) {
-    __shared__ uint32_t s_w[2][kWaves];
-    const uint32_t base = blockIdx.x * kTile;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t running = tile_off[blockIdx.x].x;
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        uint32_t i = base + k * kBlock + threadIdx.x;
-        bool v = false;
-        int32_t r = -1;
-        uint16_t f = 0;
-        if (i < n) {
-            r = ref[i];
-            f = flag[i];
-            v = record_is_mapped(f, r) && static_cast<uint32_t>(r) < n_refs;
-        }
-        uint64_t m = __ballot(v);
-        uint32_t rank = mask_rank(m);
-        if ((threadIdx.x & 63) == 0) s_w[k & 1][wave] = __popcll(m);
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            uint32_t c = s_w[k & 1][w];
-            if (w < static_cast<int>(wave)) before += c;
-            total += c;
-        }
-        if (v) {
-            uint32_t o = running + before + rank;
-            uint32_t mate = (f & 0x40) ? 1u : ((f & 0x80) ? 2u : 0u);
-            ident[o] = (key[i] << 2) | mate;
-            // uint32 wrap-around of int32 + uint32, then clamp to the contig length (Q3)
-            uint32_t center = min(static_cast<uint32_t>(pos[i]) + half_read, ref_len[r]);
-            cref[o] = static_cast<uint32_t>(r);
-            cgbin[o] = bin_off[r] + center / bin_width;
-            if (cchk) cchk[o] = chk[i];  // (the caller's second hash of the read name travels with the record)
-        }
-        running += total;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -953,24 +692,6 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
-static inline uint32_t tiles_for(uint32_t n) { return (n + kTile - 1) / kTile; }
-
-uint32_t num_tiles(uint32_t n) { return tiles_for(n); }
-
-// packed records (slimm_push_records_packed) -> the four-array form the compaction of the sort path reads
-__global__ __launch_bounds__(256) void k_unpack_records(const uint64_t* __restrict__ packed, uint32_t n, uint64_t* __restrict__ key,
-                                                        uint16_t* __restrict__ flag) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint64_t k = packed[i];
-        const uint32_t mate = static_cast<uint32_t>(k >> 61) & 3u;
-        key[i] = k & ((1ull << 61) - 1ull);
-        flag[i] = static_cast<uint16_t>(((k >> 63) ? 0x4u : 0u) | (mate == 1u ? 0x40u : (mate == 2u ? 0x80u : 0u)));
-    }
-}
-void launch_unpack_records(hipStream_t st, const uint64_t* packed_key, uint32_t n, uint64_t* key, uint16_t* flag) {
-    if (n) hipLaunchKernelGGL(k_unpack_records, dim3(std::min<uint32_t>((n + 255u) / 256u, 4096u)), dim3(256), 0, st, packed_key, n, key, flag);
-}
-
 // slimm_check_grouping: is a stream that was DECLARED grouped really grouped?  Every record that starts a qName run (its
 // identity differs from the record before) puts its identity into an open-addressing set; an identity that is already
 // there starts a second run -- the name re-appears non-adjacently, and the single-pass front end would make two reads of
@@ -998,38 +719,6 @@ void launch_check_grouping(hipStream_t st, const uint64_t* key, uint32_t n, uint
                            uint32_t* n_split) {
     if (n) hipLaunchKernelGGL(k_check_grouping, dim3(std::min<uint32_t>((n + 255u) / 256u, 8192u)), dim3(256), 0, st, key, n,
                               id_mask, tab, tab_mask, n_split);
-}
-
-void launch_valid_count(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, uint2* tile_cnt, uint32_t* counters) {
-    uint32_t nt = tiles_for(in.n);
-    if (nt) hipLaunchKernelGGL(k_valid_count, dim3(nt), dim3(kBlock), 0, st, in.flag, in.ref, in.n, n_refs, tile_cnt, counters);
-}
-
-void launch_scan_tiles(hipStream_t st, uint2* tile_cnt, uint32_t ntiles, uint32_t* counters, int slot_x, int slot_y,
-                       uint32_t* read_off, const uint32_t* extra, int slot_extra, uint32_t* tail, uint4* sums) {
-    // one workgroup up to the range of its one-pass register path; its loop over 1024-entry pieces beyond that costs
-    // ~5 us per piece (93 us at 16 385 tiles, 161 us at 24 K) against ~15 us for the two launches of the chunked scan
-    uint32_t grid = 1, chunk = kScanChunk, above = 1024u * kScanRegs;
-    if (const char* e = getenv("SLIMM_SCAN_CHUNK")) {  // tests: chunked scan on small inputs
-        chunk = std::max<uint32_t>(1u, static_cast<uint32_t>(atol(e)));
-        above = chunk;
-    }
-    chunk = std::max(chunk, (ntiles + kScanMaxChunks - 1) / kScanMaxChunks);  // sums holds kScanMaxChunks entries
-    if (sums && ntiles > above) {
-        grid = (ntiles + chunk - 1) / chunk;
-        hipLaunchKernelGGL(k_scan_sums, dim3(grid), dim3(1024), 0, st, tile_cnt, ntiles, extra, sums, chunk);
-    }
-    hipLaunchKernelGGL(k_scan_tiles, dim3(grid), dim3(1024), 0, st, tile_cnt, ntiles, counters, slot_x, slot_y, read_off, extra,
-                       slot_extra, tail, sums, chunk);
-}
-
-void launch_compact(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* tile_off, const uint32_t* ref_len,
-                    const uint32_t* bin_off, uint32_t half_read, uint32_t bin_width, uint64_t* ident, uint32_t* cref,
-                    uint32_t* cgbin, uint32_t* cchk) {
-    uint32_t nt = tiles_for(in.n);
-    if (nt)
-        hipLaunchKernelGGL(k_compact, dim3(nt), dim3(kBlock), 0, st, in.key, in.ref, in.pos, in.flag, in.n, n_refs, tile_off,
-                           ref_len, bin_off, half_read, bin_width, ident, cref, cgbin, in.check, in.check ? cchk : nullptr);
 }
 
 void launch_hist(hipStream_t st, const uint32_t* tgt_gbin, const uint4* slots, uint32_t nslots, uint32_t* counters,

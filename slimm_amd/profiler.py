@@ -245,6 +245,17 @@ class Slimm:
         self._check(self.L.slimm_set_records_device(self.ctx, C.c_void_p(key.data_ptr()), C.c_void_p(ref.data_ptr()),
                                                     C.c_void_p(pos.data_ptr()), C.c_void_p(flag.data_ptr()), n))
 
+    def grouped_records(self):
+        """slimm_grouped_records (record_order = ANY, after analyze_alignments): (ident, ref, gbin) of the mapped records
+        as the device grouped them for the front end."""
+        n = C.c_uint64()
+        self._check(self.L.slimm_grouped_records(self.ctx, None, None, None, 0, C.byref(n)))
+        ident = np.empty(n.value, dtype=np.uint64)
+        ref = np.empty(n.value, dtype=np.uint32)
+        gbin = np.empty(n.value, dtype=np.uint32)
+        self._check(self.L.slimm_grouped_records(self.ctx, _p(ident), _p(ref), _p(gbin), n.value, C.byref(n)))
+        return ident, ref, gbin
+
     def check_grouping(self) -> int:
         """slimm_check_grouping: qName runs whose identity started an earlier run too (0 = the stream is grouped)."""
         n = C.c_uint64()

@@ -125,6 +125,16 @@ bool resolve_divergent() {
         uint64_t members = 0;
         for (int l = 0; l < 64; ++l)
             if (((w.arrived_mask >> l) & 1u) && w.site[l] == s0) members |= 1ull << l;
+        // HIPEMU_STRICT=1: a kernel whose collectives all sit in wave-uniform code never gets here with EVERY live lane
+        // waiting in a collective -- unless the host compiler cloned a call site behind a per-lane branch, after which
+        // the lanes no longer meet and the emulation is no longer the GPU's lock step (README: rules)
+        if (w.arrived_mask == w.alive_mask) {
+            static const bool strict = getenv("HIPEMU_STRICT") != nullptr;
+            if (strict) {
+                std::fprintf(stderr, "hip_emu: the lanes of a wave wait in collectives at different call sites (%p ...)\n", s0);
+                std::abort();
+            }
+        }
         release(w, members);
         any = true;
     }

@@ -47,6 +47,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
+def group_plan(n_records):
+    """slimm_group_plan: (passes, width, bits, grid) of the record_order = ANY grouping for a stream of n_records."""
+    import ctypes as C
+
+    from slimm_amd import capi
+    v = [C.c_uint32() for _ in range(4)]
+    capi.lib().slimm_group_plan(int(n_records), *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
 def algorithmic_bytes(st, n_records, Bp_words, rec_bytes=16):
     """Algorithmic HBM bytes per launch of each kernel (DESIGN.md section 'Kernels and their rooflines').
 
@@ -55,12 +65,15 @@ def algorithmic_bytes(st, n_records, Bp_words, rec_bytes=16):
     """
     N, V, P, M = n_records, st["hits_count"], st["n_targets"], st["matches_count"]
     U, U2, B = st["uniq_matches_count"], st["uniq_matches_count2"], Bp_words
+    GP, GW, _, GG = group_plan(n_records)
     return {
         "memset_bins": 4 * (B // 8192 + 5200),       # counters, tail, tile counters, child marks (bins are written whole by the tile kernels)
-        "k_scan_tiles": 2 * 8 * (N // 2048 + 1),      # per-tile counts in and out
-        "sort_by_ident": 8 * (2 * 16 * V + 8 * V),   # (sort path only) 8 passes: keys+payload in and out, keys again for the histogram
-        "k_valid_count": 6 * N,                       # (sort path only) flag u16 + ref i32
-        "k_compact": 18 * N + 16 * V,                 # (sort path only) read every record once, write ident/ref/gbin
+        # record_order = ANY (group_by_ident.hip), per launch = the passes' average: the first pass reads the caller's
+        # records (count: key + ref (+ flag); scatter: all of it), the others the 16-byte grouped form (count: identity)
+        "k_group_count": ((rec_bytes - 4) * N + (GP - 1) * 8 * V) // GP,
+        "k_group_scan": 2 * 4 * GG * (1 << GW),
+        "k_group_scatter": (rec_bytes * N + 16 * V + (GP - 1) * 32 * V) // GP,
+        "k_group_finish": 8 * V,                      # the identities once; only buckets holding several identities out of order are rewritten
         "k_front": rec_bytes * N + 8 * P + 16 * (N // 768 + 1),  # every record once (key 8 + ref 4 + pos 4 (+ flag 2) bytes);
                                                       # targets (ref word + bin word) and the slot descriptors out
         "k_hist": 8 * P + 8 * P + 8 * U,              # (fallback path) targets in; one 4-byte RMW per target / unique read

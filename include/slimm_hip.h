@@ -373,6 +373,9 @@ int slimm_kernel_times(slimm_ctx* ctx, const char** names, double* ms, uint32_t*
  * reference and global bin, records of one identity adjacent and in file order.  Copies min(cap, *n) records to host
  * arrays (any of which may be NULL); *n = the number of mapped records. */
 int slimm_grouped_records(slimm_ctx* ctx, uint64_t* ident, uint32_t* ref, uint32_t* gbin, uint64_t cap, uint64_t* n);
+/* The grouping's plan for a stream of n_records (record_order = SLIMM_ORDER_ANY): counting passes over the records, bits
+ * per pass, hash bits that make a bucket (= passes * width), persistent workgroups per pass. */
+void slimm_group_plan(uint64_t n_records, uint32_t* passes, uint32_t* width, uint32_t* bits, uint32_t* grid);
 
 /* ---- host-only helpers (no GPU needed; used by the host driver and testable on CPU) ---- */
 /* get_avg_read_length (src/misc.hpp:509-522). Returns 0 when no record has a sequence (the reference divides by 0). */

@@ -1,11 +1,11 @@
 # HBM traffic of every kernel from the TCC counters, in separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass):
 #   bash scripts/pmc_traffic.sh [config]      (default: config4, the headline workload)  -> gpurun_out/pmc_traffic/summary_<config>.json
 # profiles/roundN/pmc_traffic_summary.json = {"<config>": <that summary>, ...} is what bench.py reads for roofline.traffic.
-CFG=${1:-config4}
+CFG=${1:-config4}; shift; EXTRA="$@"   # further arguments go to bench.py (e.g. --record-order any)
 export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/pmc_traffic; mkdir -p $OUT; cd /tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick > /dev/null 2>$OUT/err_f.txt
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick > /dev/null 2>$OUT/err_w.txt
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick > /dev/null 2>$OUT/err_r.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o fetch_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick $EXTRA > /dev/null 2>$OUT/err_f.txt
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o write_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick $EXTRA > /dev/null 2>$OUT/err_w.txt
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_ATOMIC_sum TCC_HIT_sum --kernel-trace --output-format csv -d $OUT -o req_$CFG -- python3 $R/bench.py --config $CFG --steps 2 --warmup 1 --quick $EXTRA > /dev/null 2>$OUT/err_r.txt
 python3 - <<PY
 import csv, collections, glob, json
 res=collections.defaultdict(dict)

@@ -2069,6 +2069,14 @@ int slimm_kernel_times(slimm_ctx* c, const char** names, double* ms, uint32_t* l
     return SLIMM_OK;
 }
 
+void slimm_group_plan(uint64_t n_records, uint32_t* passes, uint32_t* width, uint32_t* bits, uint32_t* grid) {
+    const GroupPlan g = group_plan(static_cast<uint32_t>(std::min<uint64_t>(n_records, 0x7ffffffeull)));
+    if (passes) *passes = g.passes;
+    if (width) *width = g.width;
+    if (bits) *bits = g.bits;
+    if (grid) *grid = g.grid;
+}
+
 int slimm_grouped_records(slimm_ctx* c, uint64_t* ident, uint32_t* ref, uint32_t* gbin, uint64_t cap, uint64_t* n) {
     if (!c || !n) return SLIMM_E_INVALID;
     if (c->device < 0 || c->order != SLIMM_ORDER_ANY) return fail(c, SLIMM_E_INVALID, "slimm_grouped_records: a device context created for SLIMM_ORDER_ANY");

@@ -54,12 +54,26 @@ __device__ __forceinline__ uint32_t g_rank(uint64_t mask) {
 }
 __device__ __forceinline__ uint64_t g_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
-// The hash the digits are cut from: of the qName key (identity >> 2: both mates of a name share a bucket, as they share
-// a run in the front end).  A multiplicative hash; its TOP bits depend on every bit of the key.
-__device__ __forceinline__ uint64_t gb_mix(uint64_t ident) {
-    uint64_t x = ident >> 2;
-    x ^= x >> 31;
-    return x * 0x9E3779B97F4A7C15ull;
+// The hash the digits are cut from: 32 bits of the qName key (identity >> 2: both mates of a name share a bucket, as they
+// share a run in the front end).  Two 32-bit multiplicative hashes added up; the TOP bits depend on every bit of the key
+// (consecutive integers, keys that differ in their top bits only: tests/test_gpu_group_by_ident.py).  32-bit multiplies
+// on purpose: a 64-bit product is four of them at a quarter of the vector rate, per record, pass and kernel.
+__device__ __forceinline__ uint32_t gb_mix(uint64_t ident) {
+    const uint64_t key = ident >> 2;
+    return static_cast<uint32_t>(key) * 0x9E3779B1u + static_cast<uint32_t>(key >> 32) * 0x85EBCA77u;
+}
+
+// A load of the stream the scatter reads once.  Marked non-temporal (-DSLIMM_GB_NT_LOADS), so that the lines it brings in
+// do not push the half-written lines at the G x 2^W output frontiers out of the L2, it measured even at 10 M records (the
+// next kernel's count ran 10 % faster, the scatter the same) and 11 % SLOWER at 100 M (scatter 886 -> 987 us, count 225 ->
+// 267): plain loads.
+template <typename T>
+__device__ __forceinline__ T gb_stream_load(const T* p) {
+#if defined(SLIMM_GB_NT_LOADS) && !defined(SLIMM_HIP_EMU)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
 }
 
 // ---- record sources -------------------------------------------------------------------------------------------------
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(kGBlock) void k_gb_count(const Src src, uint32_t* _
             bool live = r0 + u * kGBlock + tid < hi;
             uint64_t ident = k[u];
             if constexpr (Src::kRaw) live = src.ident_of(k[u], r[u], f[u], ident, bad) && live;
-            if (live) atomicAdd(&s_h[static_cast<uint32_t>(gb_mix(ident) >> shift) & (D - 1u)], 1u);
+            if (live) atomicAdd(&s_h[(gb_mix(ident) >> shift) & (D - 1u)], 1u);
         }
     }
     __syncthreads();
@@ -186,7 +200,19 @@ __global__ __launch_bounds__(kGroupMaxGrid) void k_gb_scan(uint32_t* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 // k_gb_scatter: the stable scatter of one pass (header)
 // ---------------------------------------------------------------------------------------------------------
-template <typename Src, bool kChk>
+// dynamic LDS of k_gb_scatter, in 32-bit words: cursors + per-wave counts (16-bit, a spare per wave), rounded to 8 bytes
+__host__ __device__ constexpr uint32_t gb_lds_tables(uint32_t D) { return (D + (kGWaves * (D + 1u) + 1u) / 2u + 1u) & ~1u; }
+constexpr uint32_t kGMatchBits = 9;  // digits up to this width find their peers through a table of lane masks in LDS
+__host__ __device__ constexpr uint32_t gb_lds_words(uint32_t D, bool staged) {
+    return gb_lds_tables(D) + (staged ? 2u * D + 4u * kGRound : 0u) + (D <= (1u << kGMatchBits) ? 2u * kGWaves * D : 0u);
+}
+
+// kStaged: the round's records go out ORDERED BY DIGIT through LDS -- a digit's records of the round are one run of
+// consecutive lanes and consecutive addresses (16 records = 128 bytes of identities at 8-bit digits) instead of 64 lanes
+// storing 8 bytes each to some fifty places: measured at 10 M records, the same kernel with its stores made consecutive
+// runs 68 instead of 98 us.  Costs 64 KB of LDS per workgroup (the digits wider than 9 bits, whose tables need the room,
+// and streams with check words keep the direct stores).
+template <typename Src, bool kChk, bool kStaged>
 __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t* __restrict__ counters, uint32_t shift,
                                                         uint32_t bits, const uint32_t* __restrict__ matrix,
                                                         const uint32_t* __restrict__ totals, uint64_t* __restrict__ ident_out,
@@ -201,6 +227,15 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
     uint16_t* const s_wcnt = reinterpret_cast<uint16_t*>(s_dyn + D);
     uint16_t* const my_cnt = s_wcnt + wave * D;
     uint16_t* const spare = s_wcnt + kGWaves * D + wave;  // a word nobody reads
+    // (kStaged) behind the tables: s_dstart[D] = where a digit's records start in the ordered round, s_gdelta[D] = global
+    // place minus place in the round, then the round itself: identities, payloads
+    // (bits <= kGMatchBits) behind those: s_match[kGWaves][D] 64-bit lane masks
+    const bool match = bits <= kGMatchBits;
+    unsigned long long* const my_match = reinterpret_cast<unsigned long long*>(s_dyn + gb_lds_tables(D) + (kStaged ? 2u * D + 4u * kGRound : 0u)) + wave * D;
+    uint32_t* const s_dstart = s_dyn + gb_lds_tables(D);
+    uint32_t* const s_gdelta = s_dstart + D;
+    uint64_t* const s_rid = reinterpret_cast<uint64_t*>(s_gdelta + D);
+    uint2* const s_rpay = reinterpret_cast<uint2*>(s_rid + kGRound);
     // ---- digit bases: exclusive prefix of the digit totals (every workgroup computes it), plus this workgroup's offset
     {
         const uint32_t per = (D + kGBlock - 1u) / kGBlock;  // digits per thread: consecutive ones
@@ -237,6 +272,8 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
         if (Src::kRaw && blockIdx.x == 0u && tid == 0u) counters[CNT_V] = all;
     }
     for (uint32_t d = tid; d < kGWaves * D; d += kGBlock) s_wcnt[d] = 0;
+    if (match)
+        for (uint32_t d = lane; d < D; d += 64u) my_match[d] = 0ull;
     __syncthreads();
     uint32_t lo, hi;
     gb_stretch(src.count(counters), lo, hi);
@@ -251,14 +288,15 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
         for (int u = 0; u < kGItems; ++u) {
             const uint32_t i = min(w0 + u * 64u + lane, hi - 1u);
             if constexpr (Src::kRaw) {
-                ident[u] = src.key[i];
-                pay[u].x = static_cast<uint32_t>(src.ref[i]);
-                pay[u].y = static_cast<uint32_t>(src.pos[i]);
+                ident[u] = gb_stream_load(src.key + i);
+                pay[u].x = static_cast<uint32_t>(gb_stream_load(src.ref + i));
+                pay[u].y = static_cast<uint32_t>(gb_stream_load(src.pos + i));
                 aux[u] = src.flag ? src.flag[i] : 0u;
                 chk[u] = kChk ? src.check[i] : 0u;
             } else {
-                ident[u] = src.ident[i];
-                pay[u] = src.pay[i];
+                ident[u] = gb_stream_load(src.ident + i);
+                const uint64_t q = gb_stream_load(reinterpret_cast<const uint64_t*>(src.pay + i));
+                pay[u] = make_uint2(static_cast<uint32_t>(q), static_cast<uint32_t>(q >> 32));
                 aux[u] = 0u;
                 chk[u] = kChk ? src.chk[i] : 0u;
             }
@@ -287,12 +325,25 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
         uint32_t dig[kGItems], place[kGItems];
 #pragma unroll
         for (int u = 0; u < kGItems; ++u) {
-            const uint32_t d = static_cast<uint32_t>(gb_mix(ident[u]) >> shift) & (D - 1u);
-            uint64_t peers = g_ballot(live[u]);
-            for (uint32_t b = 0; b < bits; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bm = g_ballot(bit);
-                peers &= bit ? bm : ~bm;
+            const uint32_t d = (gb_mix(ident[u]) >> shift) & (D - 1u);
+            // the lanes of this chunk with my digit: up to 9-bit digits through the wave's own table of lane masks in LDS
+            // (everybody ORs its bit into its digit's entry, reads the entry back and clears it again: three LDS
+            // operations whatever the digits), wider ones by a ballot per bit (6 vector + 2 scalar instructions each)
+            uint64_t peers;
+            if (match) {
+                unsigned long long* const e = my_match + d;
+                atomicOr(e, live[u] ? 1ull << lane : 0ull);  // (every lane issues it: no branch next to the wave barriers)
+                __builtin_amdgcn_wave_barrier();
+                peers = *e;
+                __builtin_amdgcn_wave_barrier();
+                *e = 0ull;
+            } else {
+                peers = g_ballot(live[u]);
+                for (uint32_t b = 0; b < bits; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const uint64_t bm = g_ballot(bit);
+                    peers &= bit ? bm : ~bm;
+                }
             }
             const uint32_t rank = g_rank(peers);
             // (no branch on per-lane state next to the wave barriers: every lane loads, every lane stores -- the first
@@ -309,50 +360,135 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
             place[u] = before + rank;
         }
         __syncthreads();
-        // ---- the waves' counts of every digit -> each wave's offset inside the digit's records of the round
-        uint32_t tot[kGMaxDigits / kGBlock > 0 ? kGMaxDigits / kGBlock : 1];
+        if constexpr (!kStaged) {
+            // ---- the waves' counts of every digit -> each wave's offset inside the digit's records of the round
+            uint32_t tot[kGMaxDigits / kGBlock > 0 ? kGMaxDigits / kGBlock : 1];
 #pragma unroll
-        for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
-            const uint32_t d = tid + k * kGBlock;
-            uint32_t run = 0;
-            if (d < D) {
+            for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
+                const uint32_t d = tid + k * kGBlock;
+                uint32_t run = 0;
+                if (d < D) {
 #pragma unroll
-                for (uint32_t w = 0; w < kGWaves; ++w) {
-                    const uint32_t c = s_wcnt[w * D + d];
-                    s_wcnt[w * D + d] = static_cast<uint16_t>(run);
-                    run += c;
+                    for (uint32_t w = 0; w < kGWaves; ++w) {
+                        const uint32_t c = s_wcnt[w * D + d];
+                        s_wcnt[w * D + d] = static_cast<uint16_t>(run);
+                        run += c;
+                    }
+                }
+                tot[k] = run;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kGItems; ++u) {
+                if (live[u]) {
+                    const uint32_t dst = s_cursor[dig[u]] + my_cnt[dig[u]] + place[u];
+                    ident_out[dst] = ident[u];
+                    pay_out[dst] = pay[u];
+                    if (kChk) chk_out[dst] = chk[u];
                 }
             }
-            tot[k] = run;
-        }
-        __syncthreads();
+            __syncthreads();
 #pragma unroll
-        for (int u = 0; u < kGItems; ++u) {
-            if (live[u]) {
-                const uint32_t dst = s_cursor[dig[u]] + my_cnt[dig[u]] + place[u];
-                ident_out[dst] = ident[u];
-                pay_out[dst] = pay[u];
-                if (kChk) chk_out[dst] = chk[u];
+            for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
+                const uint32_t d = tid + k * kGBlock;
+                if (d < D) {
+                    s_cursor[d] += tot[k];
+#pragma unroll
+                    for (uint32_t w = 0; w < kGWaves; ++w) s_wcnt[w * D + d] = 0;
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+        } else {
+            // ---- the waves' counts of every digit -> each wave's offset inside the digit's records of the round, the
+            // digit's start in the ordered round (a prefix over the digits: consecutive digits per thread), and what
+            // turns a place in the round into a place in the stream
+            constexpr uint32_t kPer = kGMaxDigits / kGBlock > 0 ? kGMaxDigits / kGBlock : 1;
+            const uint32_t per = D > static_cast<uint32_t>(kGBlock) ? D / kGBlock : 1u;
+            uint32_t tot[kPer];
+            uint32_t mine = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kGMaxDigits / kGBlock; ++k) {
-            const uint32_t d = tid + k * kGBlock;
-            if (d < D) {
-                s_cursor[d] += tot[k];
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const uint32_t d = tid * per + k;
+                uint32_t run = 0;
+                if (k < per && d < D) {
 #pragma unroll
-                for (uint32_t w = 0; w < kGWaves; ++w) s_wcnt[w * D + d] = 0;
+                    for (uint32_t w = 0; w < kGWaves; ++w) {
+                        const uint32_t c = s_wcnt[w * D + d];
+                        s_wcnt[w * D + d] = static_cast<uint16_t>(run);
+                        run += c;
+                    }
+                }
+                tot[k] = run;
+                mine += run;
             }
+            uint32_t inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = __shfl_up(inc, o, 64);
+                if (lane >= static_cast<uint32_t>(o)) inc += x;
+            }
+            if (lane == 63u) s_ws[wave] = inc;
+            __syncthreads();
+            uint32_t run = inc - mine, n_round = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kGWaves; ++w) {
+                const uint32_t x = s_ws[w];
+                run += w < wave ? x : 0u;
+                n_round += x;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const uint32_t d = tid * per + k;
+                if (k < per && d < D) {
+                    s_dstart[d] = run;
+                    s_gdelta[d] = s_cursor[d] - run;
+                    s_cursor[d] += tot[k];
+                }
+                run += tot[k];
+            }
+            __syncthreads();
+            // ---- the records into the ordered round
+#pragma unroll
+            for (int u = 0; u < kGItems; ++u) {
+                if (live[u]) {
+                    const uint32_t at = s_dstart[dig[u]] + my_cnt[dig[u]] + place[u];
+                    s_rid[at] = ident[u];
+                    s_rpay[at] = pay[u];
+                }
+            }
+            __syncthreads();
+            // ---- and out: consecutive lanes take consecutive places (the digit again from the identity)
+#pragma unroll
+            for (int u = 0; u < kGItems; ++u) {
+                const uint32_t at = u * kGBlock + tid;
+                if (at < n_round) {
+                    const uint64_t id = s_rid[at];
+                    const uint32_t dst = at + s_gdelta[(gb_mix(id) >> shift) & (D - 1u)];
+                    ident_out[dst] = id;
+                    pay_out[dst] = s_rpay[at];
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const uint32_t d = tid * per + k;
+                if (k < per && d < D) {
+#pragma unroll
+                    for (uint32_t w = 0; w < kGWaves; ++w) s_wcnt[w * D + d] = 0;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_gb_finish (header): identities in order inside every bucket of equal hash bits, file order among equal identities
 // ---------------------------------------------------------------------------------------------------------
-constexpr uint32_t kFinishRecs = 1024;  // records per wave: it handles the buckets that START among them
+#ifndef SLIMM_FINISH_RECS
+#define SLIMM_FINISH_RECS 512
+#endif
+constexpr uint32_t kFinishRecs = SLIMM_FINISH_RECS;  // records per wave: it handles the buckets that START among them
+constexpr uint32_t kFinishStage = kFinishRecs + 128u;  // ... and keeps this many identities in LDS, from the record in front of them on
 
 __device__ __forceinline__ uint32_t g_shr1(uint32_t v, uint32_t lane0) {  // the value of the lane before
     return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
@@ -380,7 +516,7 @@ __device__ __forceinline__ uint32_t finish_long(uint64_t* __restrict__ ident, ui
                                                 uint64_t* __restrict__ t_ident, uint2* __restrict__ t_pay,
                                                 uint32_t* __restrict__ t_chk, uint32_t p, uint32_t V, uint32_t hshift,
                                                 uint32_t lane) {
-    const uint64_t h0 = gb_mix(ident[p]) >> hshift;
+    const uint32_t h0 = gb_mix(ident[p]) >> hshift;
     // 1. where it ends; whether its identities are in order already
     uint32_t end = p;
     bool sorted = true;
@@ -448,19 +584,41 @@ __global__ __launch_bounds__(64) void k_gb_finish(uint64_t* __restrict__ ident, 
                                                   uint64_t* __restrict__ t_ident, uint2* __restrict__ t_pay,
                                                   uint32_t* __restrict__ t_chk, const uint32_t* __restrict__ counters,
                                                   uint32_t hshift) {
+    // The wave's stretch, the record in front of it and a window's worth behind it, staged in LDS with every load in flight
+    // at once: the windows below would otherwise be a chain of dependent loads, one round trip each (60 us at 10 M
+    // records, when reading the identities takes 20).
+    __shared__ uint64_t s_id[kFinishStage];
+    __shared__ uint16_t s_mv[kFinishStage + 64];  // where a record of the stretch moves to (0xffff: it stays); + a spare word per lane
     const uint32_t V = counters[CNT_V];
     const uint32_t lane = g_lane();
     const uint32_t a = blockIdx.x * kFinishRecs;
     if (a >= V) return;
     const uint32_t e = min(V, a + kFinishRecs);
+    const uint32_t base = a > 0u ? a - 1u : 0u;
+    {
+        uint64_t v[kFinishStage / 64];
+#pragma unroll
+        for (uint32_t k = 0; k < kFinishStage / 64u; ++k) v[k] = ident[min(base + 64u * k + lane, V - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < kFinishStage / 64u; ++k) {
+            s_id[64u * k + lane] = v[k];
+            s_mv[64u * k + lane] = 0xffffu;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the lane's identity of the window of 64 records at q (records behind the stream's end: the last one again)
+    auto window = [&](uint32_t q) -> uint64_t {
+        if (q - base + 64u <= kFinishStage) return s_id[q - base + lane];
+        return ident[min(q + lane, V - 1u)];
+    };
     // the first bucket that starts at or behind a
     uint32_t p = a;
     if (a > 0u) {
-        const uint64_t hprev = gb_mix(ident[a - 1u]) >> hshift;
+        const uint32_t hprev = gb_mix(s_id[0]) >> hshift;
         while (true) {
             const uint32_t i = p + lane;
             const bool in = i < V;
-            const uint64_t id = ident[in ? i : V - 1u];
+            const uint64_t id = window(p);
             const uint64_t same = g_ballot(in && (gb_mix(id) >> hshift) == hprev);
             const uint32_t n_in = (~same) == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(~same));
             p += n_in;
@@ -470,11 +628,9 @@ __global__ __launch_bounds__(64) void k_gb_finish(uint64_t* __restrict__ ident, 
     while (p < e) {  // p: a bucket starts here, p < V
         const uint32_t i = p + lane;
         const bool in = i < V;
-        const uint64_t id = ident[in ? i : V - 1u];
-        const uint64_t h = gb_mix(id) >> hshift;
-        const uint32_t hl = static_cast<uint32_t>(h), hh = static_cast<uint32_t>(h >> 32);
-        const uint32_t pl = g_shr1(hl, ~hl), ph = g_shr1(hh, hh);  // (lane 0 starts a bucket: p is a bucket start)
-        const bool start = in & ((pl != hl) | (ph != hh));
+        const uint64_t id = window(p);
+        const uint32_t h = gb_mix(id) >> hshift;
+        const bool start = in & (g_shr1(h, ~h) != h);  // (lane 0 starts a bucket: p is a bucket start)
         const uint64_t S = g_ballot(start);
         // whole buckets: up to the last bucket start of the window -- or to the end of the stream
         uint32_t X = p + 64u >= V ? V - p : 63u - static_cast<uint32_t>(__builtin_clzll(S));
@@ -510,18 +666,40 @@ __global__ __launch_bounds__(64) void k_gb_finish(uint64_t* __restrict__ ident, 
                 rank += (back >= d && g_u64(bl, bh) <= id) ? 1u : 0u;
                 rank += (fwd >= d && g_u64(fl, fh) < id) ? 1u : 0u;
             }
-            const uint2 py = pay[in ? i : V - 1u];
-            const uint32_t ck = kChk ? chk[in ? i : V - 1u] : 0u;
-            __builtin_amdgcn_wave_barrier();  // (every lane has loaded its record before any lane stores one: lockstep on
-                                              // the GPU, a meeting point for the host emulator's lanes)
-            if (mine && bs + rank != lane) {
-                const uint32_t dst = p + bs + rank;
-                ident[dst] = id;
-                pay[dst] = py;
-                if (kChk) chk[dst] = ck;
-            }
+            // (the move itself waits for the end of the stretch: every window's loads of the payload would be a round
+            // trip of its own -- 39 of this kernel's 65 us at 10 M records)
+            const uint32_t at = p - base + lane;
+            s_mv[(mine && bs + rank != lane) ? at : kFinishStage + lane] = static_cast<uint16_t>(p - base + bs + rank);
         }
         p += X;
+    }
+    // the moves of the whole stretch: all payload loads in flight together, then the stores (a record's new place lies in
+    // its own bucket, which only this wave touches)
+    __builtin_amdgcn_wave_barrier();
+    uint32_t mv[kFinishStage / 64];
+    uint2 py[kFinishStage / 64];
+    uint32_t ck[kFinishStage / 64];
+#pragma unroll
+    for (uint32_t k = 0; k < kFinishStage / 64u; ++k) {
+        mv[k] = s_mv[64u * k + lane];
+        py[k] = make_uint2(0u, 0u);
+        ck[k] = 0u;
+        if (g_ballot(mv[k] != 0xffffu) != 0ull) {  // (wave-uniform: every lane loads, its own record if it has no move)
+            const uint32_t i = min(base + 64u * k + lane, V - 1u);
+            py[k] = pay[i];
+            if (kChk) ck[k] = chk[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // (every lane has loaded before any lane stores: lock step on the GPU, a meeting
+                                      // point for the host emulator's lanes)
+#pragma unroll
+    for (uint32_t k = 0; k < kFinishStage / 64u; ++k) {
+        if (mv[k] != 0xffffu) {
+            const uint32_t dst = base + mv[k];
+            ident[dst] = s_id[64u * k + lane];
+            pay[dst] = py[k];
+            if (kChk) chk[dst] = ck[k];
+        }
     }
 }
 
@@ -537,14 +715,17 @@ uint32_t g_env_u32(const char* name) {
 
 GroupPlan group_plan(uint32_t n_records) {
     GroupPlan g;
-    // buckets of about four records: one read of the usual kind each
+    // As many buckets as records: nearly every bucket then holds ONE read, and the finish only reads the identities.  With
+    // a quarter of that (1 B records of 8 hits per read in 2^28 buckets: half the buckets hold two reads) the finish
+    // moves half the stream once more: 9.6 ms against 2.0 ms with 2^30 buckets, for 1.9 ms more in the passes.
     uint32_t b = 8;
-    while (b < 40u && (1ull << (b + 2u)) < n_records) ++b;
-    if (const uint32_t o = g_env_u32("SLIMM_GROUP_BITS")) b = std::min(o, 40u);
+    while (b < 32u && (1ull << b) < n_records) ++b;
+    if (const uint32_t o = g_env_u32("SLIMM_GROUP_BITS")) b = std::min(o, 32u);
     uint32_t wmax = kGroupDefaultBits;
     if (const uint32_t o = g_env_u32("SLIMM_GROUP_WIDTH")) wmax = std::min(o, kGroupMaxBits);
     g.passes = (b + wmax - 1u) / wmax;
     g.width = (b + g.passes - 1u) / g.passes;
+    while (g.passes * g.width > 32u) --g.width;  // (the hash has 32 bits)
     g.bits = g.passes * g.width;
     g.grid = kGroupMaxGrid;
     if (const uint32_t o = g_env_u32("SLIMM_GROUP_GRID")) g.grid = std::min(o, kGroupMaxGrid);
@@ -555,7 +736,7 @@ size_t group_hist_words(const GroupPlan& g) { return (static_cast<size_t>(g.grid
 
 // where pass `pass` writes: the arrays alternate and the last pass ends in job.a
 static const GroupArrays& gb_dest(const GroupJob& j, uint32_t pass) { return ((j.plan.passes - 1u - pass) & 1u) ? j.t : j.a; }
-static uint32_t gb_shift(const GroupJob& j, uint32_t pass) { return 64u - j.plan.bits + pass * j.plan.width; }
+static uint32_t gb_shift(const GroupJob& j, uint32_t pass) { return 32u - j.plan.bits + pass * j.plan.width; }
 template <bool kPacked>
 static GbRaw<kPacked> gb_raw(const GroupJob& j) {
     GbRaw<kPacked> src;
@@ -586,21 +767,33 @@ void launch_group_scan(hipStream_t st, const GroupJob& j) {
                        j.hist + (static_cast<size_t>(j.plan.grid) << j.plan.width));
 }
 
+// ordered rounds through LDS (k_gb_scatter<.., kStaged>): up to 10-bit digits without check words (same box, 8-bit digits:
+// 10 M records 94.5 -> 91.7 us per pass, 100 M records 886 -> 818); SLIMM_GROUP_STAGED=0 / 1 forces
+static bool gb_staged(uint32_t width, bool has_chk) {
+    if (has_chk) return false;
+    if (const char* e = getenv("SLIMM_GROUP_STAGED")) return e[0] == '1';
+    return width <= 10u;
+}
+
 void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass) {
     if (j.in.n == 0) return;
     const uint32_t G = j.plan.grid, W = j.plan.width, D = 1u << W, shift = gb_shift(j, pass);
     const uint32_t* totals = j.hist + (static_cast<size_t>(G) << W);
-    const size_t lds = static_cast<size_t>(D) * 4u + static_cast<size_t>(kGWaves) * (D + 1u) * 2u;
     const bool has_chk = j.in.check != nullptr;
+    const bool staged = gb_staged(W, has_chk);
+    const size_t lds = static_cast<size_t>(gb_lds_words(D, staged)) * 4u;
     const GroupArrays& o = gb_dest(j, pass);
     auto go = [&](auto src) {
         using Src = decltype(src);
         if (has_chk)
-            hipLaunchKernelGGL((k_gb_scatter<Src, true>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist, totals,
-                               o.ident, o.pay, o.chk);
+            hipLaunchKernelGGL((k_gb_scatter<Src, true, false>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist,
+                               totals, o.ident, o.pay, o.chk);
+        else if (staged)
+            hipLaunchKernelGGL((k_gb_scatter<Src, false, true>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist,
+                               totals, o.ident, o.pay, o.chk);
         else
-            hipLaunchKernelGGL((k_gb_scatter<Src, false>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist, totals,
-                               o.ident, o.pay, o.chk);
+            hipLaunchKernelGGL((k_gb_scatter<Src, false, false>), dim3(G), dim3(kGBlock), lds, st, src, j.counters, shift, W, j.hist,
+                               totals, o.ident, o.pay, o.chk);
     };
     if (pass == 0) {
         if (j.in.packed)
@@ -619,25 +812,28 @@ void launch_group_finish(hipStream_t st, const GroupJob& j) {
     const uint32_t fgrid = (j.in.n + kFinishRecs - 1u) / kFinishRecs;
     if (j.in.check)
         hipLaunchKernelGGL((k_gb_finish<true>), dim3(fgrid), dim3(64), 0, st, j.a.ident, j.a.pay, j.a.chk, j.t.ident, j.t.pay, j.t.chk,
-                           j.counters, 64u - j.plan.bits);
+                           j.counters, 32u - j.plan.bits);
     else
         hipLaunchKernelGGL((k_gb_finish<false>), dim3(fgrid), dim3(64), 0, st, j.a.ident, j.a.pay, j.a.chk, j.t.ident, j.t.pay, j.t.chk,
-                           j.counters, 64u - j.plan.bits);
+                           j.counters, 32u - j.plan.bits);
 }
 
 int group_init() {
     // dynamic LDS beyond 64 KB needs the attribute
-    const int lds = static_cast<int>(kGMaxDigits * 4u + kGWaves * (kGMaxDigits + 1u) * 2u);
+    const int lds = static_cast<int>(gb_lds_words(kGMaxDigits, true) * 4u);
     hipError_t e = hipSuccess;
     auto set = [&](const void* f) {
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     };
-    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, true>));
-    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, false>));
-    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, true>));
-    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, false>));
-    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, true>));
-    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, true, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, false, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, false, true>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, true, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, false, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<false>, false, true>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, true, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, false, false>));
+    set(reinterpret_cast<const void*>(k_gb_scatter<GbIdent, false, true>));
     return e == hipSuccess ? 0 : 1;
 }
 

@@ -2,7 +2,7 @@
 the oracle, which groups through a hash map keyed by the read name like the reference (src/slimm.hpp:204-211) and
 therefore takes the same shuffled stream.  The plan's knobs (hash bits per bucket, digit width, persistent workgroups)
 are forced through their whole range: buckets of one identity (nothing for the finish to do), buckets of a few (lane
-shifts), buckets of hundreds and of the whole stream (selection sweeps), one- to five-pass partitions, stretches of one
+shifts), buckets of hundreds and of the whole stream (selection sweeps), one- to four-pass partitions, stretches of one
 record and of several rounds."""
 import numpy as np
 import pytest
@@ -25,7 +25,7 @@ PLANS = [  # (SLIMM_GROUP_BITS, SLIMM_GROUP_WIDTH, SLIMM_GROUP_GRID); None = the
     (12, 4, 512),
     (22, 11, 64),
     (24, 8, 3),
-    (40, 8, 512),    # five passes: buckets of one identity
+    (32, 8, 512),    # four passes, all 32 hash bits: buckets of one identity
 ]
 
 

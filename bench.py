@@ -27,6 +27,12 @@ ONE JSON line on rank 0.  Beside the contract's fields:
                       (slimm_push_records_packed_async) and stops when the profile file is written -- SURVEY.md 8d (1)
   run_marked_records  the same stream handed over as run-marked 8-byte records (include/slimm_hip.h): resident rate, k_front
                       under 8 N + 8 P, push-inclusive rate -- beside the headline, which stays on SURVEY 8d's 16-byte records
+  record_order_any    the headline stream with the reads of every chunk interleaved at random, and config 3 likewise,
+                      through a context created for SLIMM_ORDER_ANY (the reference takes records in any order,
+                      src/slimm.hpp:204-211): step rate, the grouping kernels (slimm_amd/csrc/group_by_ident.hip) under their
+                      own byte model, and that the profile is the grouped stream's
+  parity_in_run       the config-3 leg's scalars, five per-reference columns, direct LCA counts and three bin checksums
+                      against oracle/slimm_dense_mt.cpp run on the same 100 M records in this very run
   cpu_baseline        the CPU oracle (a port of the reference algorithm, 1 thread) on a bounded prefix of the stream
   cpu_baseline_mt     the dense all-core restatement on a bounded prefix
   cli_end_to_end      `slimm DB IN.bam` on a 100 M-record synthetic BAM, process start to profile written
@@ -169,6 +175,7 @@ def main():
     ap.add_argument("--config-steps", type=int, default=5)
     ap.add_argument("--push-files", type=int, default=3, help="files of the pipelined push-inclusive measurement (0 = skip the leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-any-order", action="store_true", help="skip the record_order = ANY legs (interleaved streams)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records the single-threaded CPU restatement is timed on")
     ap.add_argument("--cpu-mt-sample", type=int, default=100_000_000, help="records the all-core CPU restatement is timed on")
     ap.add_argument("--no-cli", action="store_true", help="skip the `slimm DB IN.bam` end-to-end leg")
@@ -246,6 +253,32 @@ def main():
                     h[lo:hi].copy_(d[lo:hi], non_blocking=True)
             torch.cuda.synchronize()   # (the chunk's arrays may go away)
             return hi
+
+        def interleave(self, chunk, seed):
+            """In place, chunk by chunk (reads never span chunks): the reads interleaved at random, the file order of the
+            records of one read name kept -- an input for record_order = SLIMM_ORDER_ANY that gives the grouped stream's
+            results (src/read_stat.hpp:116-135 needs a read's records in file order, nothing else)."""
+            ident_mask = (1 << 61) - 1 if packed else (1 << 62) - 1
+            for c, lo in enumerate(range(0, self.n, chunk)):
+                hi = min(self.n, lo + chunk)
+                k = self.key[lo:hi] & ident_mask
+                m = hi - lo
+                g = torch.Generator(device=dev)
+                g.manual_seed(seed + c)
+                pos = torch.randperm(m, device=dev, generator=g)
+                a = torch.sort(k, stable=True).indices              # by (name, index)
+                p1 = torch.argsort(pos)
+                b = p1[torch.sort(k[p1], stable=True).indices]      # by (name, pos)
+                newpos = torch.empty(m, dtype=torch.int64, device=dev)
+                newpos[a] = pos[b]
+                del a, b, p1, pos, k
+                inv = torch.empty(m, dtype=torch.int64, device=dev)
+                inv[newpos] = torch.arange(m, device=dev)
+                del newpos
+                for t in [self.key, self.ref, self.pos] + ([] if packed else [self.flag]):
+                    t[lo:hi] = t[lo:hi][inv]
+                del inv
+            torch.cuda.synchronize()
 
         def give(self, eng):
             if packed:
@@ -405,6 +438,43 @@ def main():
                 for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms_per_launch"] * kv[1]["launches_per_step"])
                 if v["ms_per_launch"] > 0}
 
+    def any_order_leg(wk, resk, nk, steps, grouped_profile, workload_name, what):
+        """The records of `resk` (already interleaved) through a context created for record_order = SLIMM_ORDER_ANY: the
+        step, the grouping kernels (group_by_ident.hip) under their own byte model, and whether the profile is the grouped
+        stream's."""
+        enga = Slimm.for_workload(wk, device=local_rank, grouped=False)
+        if args.no_bins:
+            enga.keep_bins(False)
+
+        def stepa():
+            enga.reset()
+            enga.reset_cutoffs()
+            resk.give(enga)
+            return enga.get_profiles(path=out_path)
+
+        ela, kta, _, profa = measure(enga, stepa, steps, 2, torch.cuda.synchronize)
+        sta = enga.stats()
+        _, pka, kmsa = roofline_from(enga, sta, nk, kta, steps, workload_name)
+        grp = {k: v for k, v in pka.items() if k.startswith("k_group")}
+        g_ms = sum(v["ms_per_launch"] * v["launches_per_step"] for v in grp.values())
+        g_bytes = sum(v["bytes_per_launch"] * v["launches_per_step"] for v in grp.values())
+        passes, width, bits, grid = group_plan(nk)
+        out = {"value": round(nk / (ela / steps) / 1e6, 3), "unit": "M records/s", "ms_per_step": round(ela / steps * 1e3, 4),
+               "steps": steps, "records": what, "same_profile_as_the_grouped_stream": bool(profa == grouped_profile),
+               "plan": {"passes": passes, "bits_per_pass": width, "bucket_bits": bits, "workgroups": grid},
+               "grouping": {"kernels": "k_group_count + k_group_scan + k_group_scatter (per pass) + k_group_finish",
+                            "ms_per_step": round(g_ms, 4), "bytes_per_step": int(g_bytes),
+                            "bytes_model": f"first pass {rec_bytes - 4} N (count) + {rec_bytes} N + 16 V (scatter), every other pass "
+                                           "8 V + 32 V, finish 8 V",
+                            "bound": "hbm", "achieved": round(g_bytes / (g_ms * 1e-3) / 1e9, 2) if g_ms else None, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": round(g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if g_ms else None},
+               "device_kernel_ms_per_step": round(kmsa, 4), "kernels": kernels_object(pka)}
+        if args.breakdown:
+            print(f"# any order, {workload_name}: {nk} records, {ela / steps * 1e3:.3f} ms/step", file=sys.stderr)
+            print_table("any ", pka)
+        enga.close()
+        return out
+
     if rank == 0:
         # (N > 1: the statistics are the merged ones; the byte model of this rank's kernels takes its share of them)
         st_local = dict(st)
@@ -559,12 +629,21 @@ def main():
                 del hw
             del word
         eng.close()
+        # ---- record_order = ANY: the SAME stream with the reads of every chunk interleaved at random (the reference takes
+        # records in any order: src/slimm.hpp:204-211), through the device-side grouping
+        any_order = {}
+        if extras and not args.no_any_order and args.record_order == "grouped":
+            res.interleave(args.chunk_records, 7000)
+            any_order[args.config] = any_order_leg(w, res, n_rec, max(3, args.steps // 4), profile, args.config,
+                                                   f"the headline stream, every chunk of {args.chunk_records} records interleaved "
+                                                   f"read by read at random (file order kept inside a read), resident, {args.form} form")
         del res
         torch.cuda.empty_cache()
 
         # ---- the other single-GPU configurations of BASELINE.json, resident, one context each
         legs = {}
         w_cli = None
+        parity_in_run = None
         for name in ([c for c in args.roofline_configs.split(",") if c] if extras else []):
             if name == args.config or name not in CONFIGS:
                 continue
@@ -597,6 +676,34 @@ def main():
             if args.breakdown:
                 print(f"# {name}: {nk} records, {elk / args.config_steps * 1e3:.3f} ms/step", file=sys.stderr)
                 print_table(name[-2:] + " ", pkk)
+            profk = engk.write_abundance()
+            if name == "config3" and not args.no_cpu_baseline:
+                # the GPU result against the CPU restatement IN THE SAME RUN, on the same 100 M records
+                # (the identity a packed record carries is the key's low 61 bits, so the CPU side gets those)
+                from oracle.binding import bin_checksum, dense_mt_run
+                from slimm_amd.workload import Records
+                rk = wk.records
+                rec61 = Records(rk.read_key & np.uint64((1 << 61) - 1), rk.flag, rk.ref_id, rk.begin_pos) if packed else rk
+                t1 = time.perf_counter()
+                dmt = dense_mt_run(wk, records=rec61)
+                rc = engk.ref_columns()
+                checks = {"scalars": (stk["hits_count"], stk["matches_count"], stk["uniq_matches_count"], stk["uniq_matches_count2"],
+                                      stk["n_valid"]) == (dmt["hits"] % 2**32, dmt["matches"] % 2**32, dmt["uniq_matches"] % 2**32,
+                                                          dmt["uniq_matches2"] % 2**32, dmt["n_valid"]),
+                          "per_reference_columns": all(bool(np.array_equal(rc[c], dmt[c])) for c in
+                                                       ("reads_count", "uniq_reads_count", "uniq_reads_count2", "nz_cov", "nz_uniq_cov")),
+                          "lca_direct": engk.taxon_counts(0) == dmt["lca_direct"]}
+                if not args.no_bins:
+                    checks["bin_checksums"] = all(bin_checksum(engk.bins(i)) == dmt["checksums"][i] for i in range(3))
+                parity_in_run = {"ok": all(checks.values()), "checks": checks, "workload": name,
+                                 "against": f"oracle/slimm_dense_mt.cpp on the same {nk} records, {dmt['threads']} threads "
+                                            f"({sum(dmt['seconds']):.2f} s; {time.perf_counter() - t1:.1f} s with the comparisons)"}
+                del rec61
+            if name == "config3" and not args.no_any_order:
+                resk.interleave(nk, 7100)
+                any_order[name] = any_order_leg(wk, resk, nk, args.config_steps, profk, name,
+                                                f"{name}'s {nk} records interleaved read by read at random (file order kept inside "
+                                                f"a read), resident, {args.form} form")
             engk.close()
             del resk
             torch.cuda.empty_cache()
@@ -710,6 +817,9 @@ def main():
             "value_resident": round(value, 3),
             "value_with_push": with_push,
             "run_marked_records": marked,
+            "record_order_any": any_order or None,
+            "parity_in_run": parity_in_run["ok"] if parity_in_run else None,
+            "parity_in_run_detail": parity_in_run,
             "roofline_config2": legs.get("config2"), "roofline_config3": legs.get("config3"), "roofline_config5": legs.get("config5"),
             "cpu_baseline": cpu,
             "cpu_baseline_mt": cpu_mt,

@@ -664,6 +664,34 @@ def _order_preserving_interleave(rec: Records, seed: int) -> Records:
     return rec.take(inv)
 
 
+def _device_interleave(key_t, seed: int):
+    """_order_preserving_interleave on the device (torch): for int64 keys on the GPU, the gather index `inv` such that
+    record j of the interleaved stream is record inv[j] of the input -- reads interleave at random, the relative order
+    of the records of one read name is kept (what Q1 depends on: src/read_stat.hpp:116-135)."""
+    import torch
+    n = key_t.numel()
+    g = torch.Generator(device=key_t.device)
+    g.manual_seed(seed)
+    pos = torch.randperm(n, device=key_t.device, generator=g)
+    a = torch.sort(key_t, stable=True).indices                 # by (key, index)
+    p1 = torch.argsort(pos)
+    b = p1[torch.sort(key_t[p1], stable=True).indices]         # by (key, pos)
+    newpos = torch.empty(n, dtype=torch.int64, device=key_t.device)
+    newpos[a] = pos[b]
+    del a, b, p1, pos
+    inv = torch.empty(n, dtype=torch.int64, device=key_t.device)
+    inv[newpos] = torch.arange(n, device=key_t.device)
+    return inv
+
+
+def _pack_keys_device(key_t, flag_t):
+    """slimm_pack_key on tensors: (key & (2^61 - 1)) | mate << 61 | unmapped << 63."""
+    import torch
+    f = flag_t.to(torch.int64) & 0xffff
+    mate = torch.where((f & 0x40) != 0, 1, torch.where((f & 0x80) != 0, 2, 0)).to(torch.int64)
+    return (key_t & ((1 << 61) - 1)) | (mate << 61) | (((f & 0x4) != 0).to(torch.int64) << 63)
+
+
 def _full_size_invariants(w: Workload, s: Slimm, permutation: bool):
     """Size-independent properties of one finished run (nothing here needs the oracle, which would take minutes)."""
     st = s.stats()
@@ -764,13 +792,54 @@ def test_full_size_config2_and_5_as_run_marked_records():
 
 
 def test_full_size_config3_bit_exact():
-    """BASELINE.json configs[2] at full size: 100 M records, 20 k references, mean 8 hits per read."""
+    """BASELINE.json configs[2] at full size: 100 M records, 20 k references, mean 8 hits per read -- as pushed four-array
+    records, as PACKED 16-byte records (slimm_push_records_packed: the form bench.py measures; its identity is the low 61
+    bits of the key, which the dense restatement gets too), and the same records in ANY order (reads interleaved at
+    random, file order kept inside a read) through the device-side grouping (record_order = SLIMM_ORDER_ANY,
+    src/slimm.hpp:204-211): every integer against the dense restatement each time."""
+    import torch
     from oracle.binding import dense_mt_run
     w = make_workload(CONFIGS["config3"], seed=1)
     s = run_gpu(w)
     st = _full_size_invariants(w, s, permutation=False)
     assert st["n_records"] == 100_000_000 and st["total_bins"] > 60_000_000
-    assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
+    d = dense_mt_run(w, want_bins=True)
+    assert_equals_dense_mt(s, d)
+    profile = s.write_abundance()
+    s.close()
+    # packed, pushed from host memory in batches
+    w61 = _mask61(w)
+    d61 = d if np.array_equal(w61.records.read_key, w.records.read_key) else dense_mt_run(w61, want_bins=True)
+    s = Slimm.for_workload(w61, device=0)
+    s.push_records_packed(w61.records, batch=25_000_000)
+    assert s.get_profiles() is not None
+    assert_equals_dense_mt(s, d61)
+    s.close()
+    # any order: interleaved on the device, resident, through the grouping
+    dev = torch.device("cuda:0")
+    r = w.records
+    key = torch.from_numpy(r.read_key.view(np.int64)).to(dev)
+    inv = _device_interleave(key, 5)
+    key = key[inv]
+    ref = torch.from_numpy(r.ref_id).to(dev)[inv]
+    pos = torch.from_numpy(r.begin_pos).to(dev)[inv]
+    flag = torch.from_numpy(r.flag.view(np.int16)).to(dev)[inv]
+    assert not torch.equal(key[:1000], torch.from_numpy(r.read_key[:1000].view(np.int64)).to(dev))
+    del inv
+    torch.cuda.synchronize()
+    s = Slimm.for_workload(w, device=0, grouped=False)
+    s.set_records_device(key, ref, pos, flag)
+    assert s.get_profiles() is not None
+    assert s.stats()["n_records"] == 100_000_000
+    assert_equals_dense_mt(s, d)
+    assert s.write_abundance() == profile
+    # ... and packed in any order
+    s.reset(); s.reset_cutoffs()
+    pk = _pack_keys_device(key, flag)
+    s.set_records_device_packed(pk, ref, pos)
+    assert s.get_profiles() is not None
+    assert_equals_dense_mt(s, d61)
+    s.close()
 
 
 def test_full_size_config5_bit_exact():
@@ -828,6 +897,37 @@ def test_full_size_config4_one_context_and_a_group_of_four():
     assert s.stats()["n_records"] == n_stream
     assert_equals_dense_mt(s, d)
     profile = s.write_abundance()
+    # (a2) the same resident records PACKED (16 bytes each: what bench.py's headline runs on)
+    k61 = host.read_key & np.uint64((1 << 61) - 1)
+    same61 = bool(np.array_equal(k61, host.read_key))
+    w61 = w if same61 else Workload(w.ref_names, w.ref_len, w.taxonomy, Records(k61, host.flag, host.ref_id, host.begin_pos),
+                                    w.avg_read_len, w.options, "config4-stream-61")
+    d61 = d if same61 else dense_mt_run(w61, want_bins=True)
+    del k61
+    s.reset(); s.reset_cutoffs()
+    pk = _pack_keys_device(key, flag)
+    s.set_records_device_packed(pk, ref, pos)
+    assert s.get_profiles() is not None
+    assert_equals_dense_mt(s, d61)
+    s.close()
+    del pk
+    # (a3) ANY order: every chunk's reads interleaved at random on the device (file order kept inside a read; reads never
+    # span chunks), through the device-side grouping of record_order = SLIMM_ORDER_ANY -- the same integers again
+    for lo in range(0, n_stream, chunk):
+        hi = min(n_stream, lo + chunk)
+        inv = _device_interleave(key[lo:hi], 1000 + lo // chunk)
+        key[lo:hi] = key[lo:hi][inv]
+        ref[lo:hi] = ref[lo:hi][inv]
+        pos[lo:hi] = pos[lo:hi][inv]
+        flag[lo:hi] = flag[lo:hi][inv]
+    del inv
+    torch.cuda.synchronize()
+    s = Slimm.for_workload(w, device=0, grouped=False)
+    s.set_records_device(key, ref, pos, flag)
+    assert s.get_profiles() is not None
+    assert s.stats()["n_records"] == n_stream
+    assert_equals_dense_mt(s, d)
+    assert s.write_abundance() == profile
     s.close()
     del key, ref, pos, flag
     torch.cuda.empty_cache()

@@ -162,6 +162,10 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "summary", "sliced", "bins"],
                     help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps (summary), all-to-all of "
                          "bitmap slices + small all-reduce (sliced), all-reduce of the bins; auto = summary up to 2 ranks")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process group of a multi-rank run: nccl = RCCL over xGMI, one GPU per rank (what the driver launches); "
+                         "gloo = the rehearsal of the same control flow on ONE GPU -- every rank a process on cuda:(rank mod "
+                         "devices), collectives staged through host memory (tests/test_distributed_gpu.py)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the multi-rank code path (process group, collectives) even with one rank")
     ap.add_argument("--kernel-timing", choices=("dominant", "all"), default="dominant",
@@ -200,15 +204,21 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (there is no CPU fallback for the hot path)", file=sys.stderr)
         sys.exit(2)
+    if args.backend == "gloo":   # rehearsal: more ranks than devices share them
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where this script's own small reductions live
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # (stdout carries ONE line: RCCL's version banner, printed at NCCL_DEBUG=VERSION / INFO, goes nowhere near it)
         os.environ["NCCL_DEBUG"] = os.environ.get("SLIMM_NCCL_DEBUG", "WARN")
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # (RCCL logs to stdout by default)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     extras = rank == 0 and world == 1 and not args.quick and not args.force_exchange
     packed = args.form == "packed"
     rec_bytes = 16 if packed else 18
@@ -381,13 +391,13 @@ def main():
 
     elapsed, ktimes, dom_name, profile = measure(eng, step, args.steps, args.warmup, barrier)
     if dist.is_initialized():
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     st = eng.stats()
     total_records = n_rec
     if dist.is_initialized():
-        tot = torch.tensor([n_rec], dtype=torch.int64, device=dev)
+        tot = torch.tensor([n_rec], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_records = int(tot[0].item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -811,7 +821,10 @@ def main():
                        "stream": ("every rank its own shard of the sample" if args.weak else
                                   f"{n_chunks} chunks of {args.chunk_records} records, contiguous chunk ranges per rank"),
                        "exchange": (resolve_exchange(eng, args.exchange, world) if (world > 1 or args.force_exchange) else "none"),
-                       "rccl_ranks": world if dist.is_initialized() else 0,
+                       "rccl_ranks": world if (dist.is_initialized() and args.backend == "nccl") else 0,
+                       "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+                       "backend": args.backend if dist.is_initialized() else "none",
+                       "profile_sha1": __import__("hashlib").sha1((profile or "").encode()).hexdigest(),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,
             "value_resident": round(value, 3),

@@ -42,6 +42,41 @@ def _fence(t, ordered: bool):
         torch.cuda.synchronize(t.device)
 
 
+# The collectives of this module.  Over RCCL ("nccl") they take the device tensors as they are.  A backend without
+# device collectives (gloo: the rehearsal of the multi-process driver with several processes on ONE GPU, tests/
+# test_distributed_gpu.py and `bench.py --backend gloo`) gets them staged through host memory: device -> host on the
+# current stream (the engine's, inside _engine_stream), the collective on the host copies, host -> device.
+def _host_staged(t, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def _all_reduce_sum(t, group):
+    if _host_staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _all_gather_into(out, mine, group):
+    if _host_staged(mine, group):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(ho, mine.cpu(), group=group)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, mine, group=group)
+
+
+def _all_to_all(out, mine, group):
+    if _host_staged(mine, group):
+        ho = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(ho, mine.cpu().contiguous(), group=group)
+        out.copy_(ho)
+    else:
+        dist.all_to_all_single(out, mine, group=group)
+
+
 def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
     """The exchange between phase A and the cut-offs; returns engine.finish_coverage*()'s answer.
 
@@ -64,7 +99,7 @@ def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
         if mode == "bins":
             buf = engine.coverage_tensor()
             if dist.is_initialized():
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                _all_reduce_sum(buf, group)
                 _fence(buf, ordered)
             return engine.finish_coverage()
         if resolve_exchange(engine, mode, world) == "sliced":
@@ -74,20 +109,20 @@ def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:
             received = (engine.scratch("received", chunks.numel(), chunks) if hasattr(engine, "scratch")
                         else torch.empty_like(chunks))
             if dist.is_initialized():
-                dist.all_to_all_single(received, chunks, group=group)
+                _all_to_all(received, chunks, group)
             else:
                 received.copy_(chunks)
             _fence(received, ordered)
             vec = engine.merge_summary_slices(received, world, dist.get_rank(group) if dist.is_initialized() else 0)
             if dist.is_initialized():
-                dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+                _all_reduce_sum(vec, group)
             _fence(vec, ordered)
             return engine.finish_coverage_reduced()
         mine = engine.coverage_summary_tensor()
         gathered = (engine.scratch("gathered", world * mine.numel(), mine) if hasattr(engine, "scratch")
                     else torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device))
         if dist.is_initialized():
-            dist.all_gather_into_tensor(gathered, mine, group=group)
+            _all_gather_into(gathered, mine, group)
         else:
             gathered.copy_(mine)
         _fence(gathered, ordered)
@@ -108,7 +143,7 @@ def _gather_pairs(pairs: np.ndarray, total_pairs: int, dev, group) -> np.ndarray
     if n_local:
         mine[1:1 + n_local] = torch.from_numpy(pairs.view(np.int64)).to(dev)
     gathered = torch.empty(world * (total_pairs + 1), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gathered, mine, group=group)
+    _all_gather_into(gathered, mine, group)
     g = gathered.cpu().numpy().reshape(world, total_pairs + 1)
     return np.unique(np.concatenate([g[k, 1:1 + int(g[k, 0])] for k in range(world)]).view(np.uint64))
 
@@ -127,7 +162,7 @@ def merge_partials_on_device(engine, group=None, launched: bool = False) -> bool
     with on_stream:
         while True:
             t = engine.partials_tensor()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            _all_reduce_sum(t, group)
             _fence(t, ordered)
             total_pairs = engine.install_merged_partials()
             if total_pairs is not None:
@@ -160,7 +195,7 @@ def merge_partials(engine, device: Optional[torch.device] = None, group=None):
     packed[R + T:2 * R + T] = _SPREAD[p["level_marks"] & 0xff]
     packed[-1] = npairs_local
     t = torch.from_numpy(packed).to(dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(t, group)
     out = t.cpu().numpy()
     pairs = p["pairs"]
     total_pairs = int(out[-1])

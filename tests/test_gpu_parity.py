@@ -836,6 +836,7 @@ def test_full_size_config3_bit_exact():
     # ... and packed in any order
     s.reset(); s.reset_cutoffs()
     pk = _pack_keys_device(key, flag)
+    torch.cuda.synchronize()            # (torch's stream made pk; the library reads it on a stream of its own)
     s.set_records_device_packed(pk, ref, pos)
     assert s.get_profiles() is not None
     assert_equals_dense_mt(s, d61)
@@ -906,6 +907,7 @@ def test_full_size_config4_one_context_and_a_group_of_four():
     del k61
     s.reset(); s.reset_cutoffs()
     pk = _pack_keys_device(key, flag)
+    torch.cuda.synchronize()            # (torch's stream made pk; the library reads it on a stream of its own)
     s.set_records_device_packed(pk, ref, pos)
     assert s.get_profiles() is not None
     assert_equals_dense_mt(s, d61)

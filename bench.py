@@ -396,10 +396,11 @@ def main():
         elapsed = float(tmax.item())
     st = eng.stats()
     total_records = n_rec
+    total_targets = int(st["n_targets"])   # (the one statistic that stays a rank's own: nothing downstream needs its sum)
     if dist.is_initialized():
-        tot = torch.tensor([n_rec], dtype=torch.int64, device=red_dev)
+        tot = torch.tensor([n_rec, total_targets], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_records = int(tot[0].item())
+        total_records, total_targets = int(tot[0].item()), int(tot[1].item())
     ms_per_step = elapsed / args.steps * 1e3
     value = total_records / (elapsed / args.steps) / 1e6
 
@@ -489,8 +490,8 @@ def main():
         # (N > 1: the statistics are the merged ones; the byte model of this rank's kernels takes its share of them)
         st_local = dict(st)
         if world > 1:
-            for k in ("hits_count", "n_targets", "matches_count", "uniq_matches_count", "uniq_matches_count2"):
-                st_local[k] = int(st[k]) // world
+            for k in ("hits_count", "matches_count", "uniq_matches_count", "uniq_matches_count2"):
+                st_local[k] = int(st[k]) // world   # (n_targets is this rank's own already)
         roofline, per_kernel, kernel_ms = roofline_from(eng, st_local, n_rec, ktimes, args.steps, args.config)
         if args.breakdown:
             print(f"# generate + copy {gen_s:.1f}s on {gen_threads} threads; records/rank {n_rec}; V={st['hits_count']} "
@@ -813,7 +814,7 @@ def main():
                                    f"{total_records} records over {world} GPU(s), {cfg.n_refs} refs, mean {cfg.mean_hits} hits/read, "
                                    f"{cfg.bin_width} bp bins, {cfg.read_len} bp reads",
                        "records_per_gpu": n_rec, "total_records": total_records, "refs": cfg.n_refs,
-                       "reads": st["matches_count"], "targets": st["n_targets"], "bins": st["total_bins"],
+                       "reads": st["matches_count"], "targets": total_targets, "bins": st["total_bins"],
                        "record_order": args.record_order, "coverage_arrays": "not materialised" if args.no_bins else "in HBM",
                        "records": f"resident in HBM before the timed region, {args.form} form ({rec_bytes} B/record); "
                                   "value_with_push starts in host memory",

@@ -181,6 +181,25 @@ int slimm_push_staged_packed_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
 /* ... and for a set whose ref_id array holds run-marked words (slimm_mark_word; key and flag arrays are not read). */
 int slimm_push_staged_marked_async(slimm_ctx* ctx, uint32_t which, uint64_t n);
 int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
+/* BAM ALIGNMENT RECORDS DECODED ON THE DEVICE.  Instead of decoding records on the host, a caller that holds a BAM file
+ * inflates its BGZF blocks and hands over the bytes BEHIND the BAM header -- the alignment records as the SAM/BAM
+ * specification lays them out (section 4.2: block_size | refID | pos | l_read_name | mapq | bin | n_cigar_op | flag | l_seq |
+ * next_refID | next_pos | tlen | read_name | ...) -- in windows of any size, in file order; records may straddle windows.
+ * The device finds the record boundaries and extracts what the record loop reads (src/slimm.hpp:194-208: refID, position,
+ * flag, read name), appending to the context's record stream in the form its record order takes: SLIMM_ORDER_GROUPED ->
+ * run-marked 8-byte records (a record starts a run where its NAME differs from the name of the record before it: exact,
+ * no hash involved); SLIMM_ORDER_ANY -> key (the 62-bit hash of the name that host/alignment_file.cpp computes), refID,
+ * position, flag and a check word (as slimm_push_records_checked).  `bytes`: any host memory (page-locked -- see
+ * slimm_pin_host_buffer -- the DMA engine reads it directly); hand over a few buffers in rotation.  The call returns
+ * when the window's bytes have left the buffer (it may be refilled) and its records are counted (*n_records, may be
+ * NULL); their decoding continues on the device.  last != 0: nothing follows -- bytes of an incomplete record are then
+ * an error (SLIMM_E_INVALID, "truncated BAM record"), as is a malformed record in any window.  A record longer than
+ * 16 MiB is not supported in this form (SLIMM_E_INVALID: decode such a file on the host).  The forms do not mix within
+ * a file.  Replaces: seqan::readRecord in src/slimm.hpp:194-208 / src/misc.hpp:509-522. */
+int slimm_push_bam_bytes(slimm_ctx* ctx, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records);
+/* Page-locks a buffer of the caller (hipHostRegister) until the context is destroyed: copies out of it then run at the
+ * speed of the bus instead of the runtime's own staging. */
+int slimm_pin_host_buffer(slimm_ctx* ctx, const void* buffer, uint64_t n_bytes);
 /* Use records already resident in device memory, without copying; the arrays must stay valid and unchanged
  * until slimm_reset().  Replaces anything pushed before. */
 int slimm_set_records_device(slimm_ctx* ctx, const uint64_t* d_read_key, const int32_t* d_ref_id,

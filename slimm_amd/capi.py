@@ -148,6 +148,8 @@ SYMBOLS = [
     ("slimm_time_only_kernel", C.c_int, [_P, C.c_char_p]),
     ("slimm_kernel_times", C.c_int, [_P, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_uint32),
                                      C.c_uint32, C.POINTER(C.c_uint32), C.c_int]),
+    ("slimm_push_bam_bytes", C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("slimm_pin_host_buffer", C.c_int, [_P, _P, C.c_uint64]),
     ("slimm_group_plan", None, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                 C.POINTER(C.c_uint32)]),
     ("slimm_grouped_records", C.c_int, [_P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

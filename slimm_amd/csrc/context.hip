@@ -130,6 +130,19 @@ struct slimm_ctx {
     bool has_check = false;        // ... all pushed batches carry one (checked and unchecked pushes do not mix)
     bool packed = false;           // slimm_push_records_packed: 16 bytes per record, no flag array (forms do not mix)
     bool marked = false;           // slimm_push_records_marked: 8 bytes per record, no key array (grouped input only)
+    // slimm_push_bam_bytes: BAM records decoded on the device (bam_decode.hip).  Two byte buffers [slack | window] take the
+    // windows in turn; the incomplete record at a window's end is copied in front of the next window
+    struct BamDecode {
+        DevBuf<uint8_t> bytes[2];
+        DevBuf<BamPiece> pieces;
+        DevBuf<uint32_t> offs;
+        DevBuf<BamCarry> carry;
+        PinBuf<BamWindowResult> result;     // written by k_bam_scan straight into page-locked host memory
+        std::vector<std::pair<const uint8_t*, size_t>> registered;  // caller buffers page-locked by hipHostRegister
+        uint64_t windows = 0;               // of this file
+        uint64_t carry_bytes = 0;
+        bool active = false;                // this file's records come from slimm_push_bam_bytes
+    } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
     uint64_t n_pushed = 0;
@@ -637,6 +650,7 @@ void slimm_destroy(slimm_ctx* c) {
             (void)hipStreamDestroy(c->copy_stream);
         }
         if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+        for (auto& r : c->bam.registered) (void)hipHostUnregister(const_cast<uint8_t*>(r.first));
         for (auto& sg : c->staging)
             if (sg.done) (void)hipEventDestroy(sg.done);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -655,6 +669,9 @@ int slimm_reset(slimm_ctx* c) {
     c->host->reset();
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;
+    c->bam.windows = 0;
+    c->bam.carry_bytes = 0;
+    c->bam.active = false;
     c->has_check = false;
     c->packed = false;
     c->marked = false;
@@ -903,6 +920,122 @@ void slimm_mark_words(const uint64_t* read_key, const uint16_t* flag, const int3
         const bool starts = i ? read_key[i] != read_key[i - 1] : (!prev_key || read_key[0] != *prev_key);
         word[i] = slimm_mark_word(ref_id[i], flag[i], starts ? 1 : 0);
     }
+}
+
+// A caller's host buffer page-locked for the life of the context: the DMA engine then reads it directly (slimm_push_bam_bytes
+// and the *_async pushes take any host memory, at the speed of the runtime's own staging when it is pageable)
+int slimm_pin_host_buffer(slimm_ctx* c, const void* p, uint64_t n_bytes) {
+    if (!c || !p || !n_bytes) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context");
+    (void)hipSetDevice(c->device);
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (auto& r : c->bam.registered)
+        if (b >= r.first && b + n_bytes <= r.first + r.second) return SLIMM_OK;
+    if (hipHostRegister(const_cast<uint8_t*>(b), n_bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, SLIMM_E_HIP, "hipHostRegister failed");
+    }
+    c->bam.registered.emplace_back(b, static_cast<size_t>(n_bytes));
+    return SLIMM_OK;
+}
+
+// BAM alignment records decoded on the device (include/slimm_hip.h; kernels: bam_decode.hip)
+int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records) {
+    if (!c) return SLIMM_E_INVALID;
+    if (n_records) *n_records = 0;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    if (n_bytes && !bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
+    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
+    if (c->borrowed) return fail(c, SLIMM_E_INVALID, "records are borrowed device arrays; reset first");
+    if (n_bytes >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "a window of BAM bytes is less than 2 GiB");
+    const bool marked = c->order == SLIMM_ORDER_GROUPED;
+    if (c->n_pushed && !c->bam.active)
+        return fail(c, SLIMM_E_INVALID, "earlier batches were decoded records: the forms do not mix within a file");
+    (void)hipSetDevice(c->device);
+    slimm_ctx::BamDecode& B = c->bam;
+    hipStream_t st = c->stream;
+    if (!B.active) {  // a file's first window
+        B.active = true;
+        B.windows = 0;
+        B.carry_bytes = 0;
+        c->marked = marked;
+        c->has_check = !marked;
+        c->packed = false;
+        HIP_TRY(c, B.carry.ensure(1));
+        HIP_TRY(c, B.result.ensure(1));
+        HIP_TRY(c, hipMemsetAsync(B.carry.p, 0, sizeof(BamCarry), st));
+    }
+    const uint32_t w = static_cast<uint32_t>(B.windows & 1u);
+    const uint64_t need = kBamSlack + n_bytes + 64;
+    for (int k = 0; k < 2; ++k)
+        if (B.bytes[k].cap < need) {
+            // (growing keeps nothing: buffer w takes this window, and the carried bytes live in the OTHER buffer's slack only
+            // until they were copied in front of this window, which happened when the window before was pushed)
+            if (k == static_cast<int>(w) && B.carry_bytes) {
+                DevBuf<uint8_t> nb;
+                HIP_TRY(c, nb.ensure(need + (need >> 2)));
+                HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[k].p + kBamSlack - B.carry_bytes, B.carry_bytes,
+                                          hipMemcpyDeviceToDevice, st));
+                HIP_TRY(c, hipStreamSynchronize(st));
+                std::swap(B.bytes[k].p, nb.p);
+                std::swap(B.bytes[k].cap, nb.cap);
+            } else {
+                HIP_TRY(c, hipStreamSynchronize(st));  // (kernels of the window before may still read it)
+                HIP_TRY(c, B.bytes[k].ensure(need + (need >> 2)));
+            }
+        }
+    const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
+    const uint32_t np = bam_pieces(end - lo);
+    HIP_TRY(c, B.pieces.ensure(static_cast<size_t>(np) + 1));
+    HIP_TRY(c, B.offs.ensure(static_cast<size_t>(np + 1) * kBamSlots));
+    if (n_bytes) {
+        HIP_TRY(c, hipMemcpyAsync(B.bytes[w].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->copy_done, 0));
+    }
+    launch_bam_find(st, B.bytes[w].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
+    HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device (the caller's buffer is free) and counted
+    const BamWindowResult res = *B.result.p;
+    if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
+    const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
+    const uint64_t tail = end - stop;
+    if (tail > kBamSlack) return fail(c, SLIMM_E_INVALID, "a BAM record longer than 16 MiB: decode this file on the host");
+    if (last && tail) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
+    if (c->n_pushed + n_rec >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
+    int rc = slimm_reserve(c, c->n_pushed + n_rec);
+    if (rc != SLIMM_OK) return rc;
+    if (!marked) {  // (the four-array form's flag and check arrays appear at a file's first window)
+        const uint64_t want = c->n_pushed + n_rec;
+        if (c->in_flag.cap < want) {
+            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
+            HIP_TRY(c, c->in_flag.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+        }
+        if (c->in_check.cap < want) {
+            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
+            HIP_TRY(c, c->in_check.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+        }
+    }
+    launch_bam_decode(st, B.bytes[w].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
+                      c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p);
+    if (tail)  // the incomplete record goes in front of the next window
+        HIP_TRY(c, hipMemcpyAsync(B.bytes[w ^ 1u].p + kBamSlack - tail, B.bytes[w].p + stop, tail, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(c, hipGetLastError());
+    B.carry_bytes = tail;
+    ++B.windows;
+    c->n_pushed += n_rec;
+    c->rec = DeviceRecords();
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    if (marked) {
+        c->rec.marked = true;
+    } else {
+        c->rec.key = c->in_key.p;
+        c->rec.flag = c->in_flag.p;
+        c->rec.check = c->in_check.p;
+    }
+    if (n_records) *n_records = n_rec;
+    return SLIMM_OK;
 }
 
 int slimm_push_wait(slimm_ctx* c) {

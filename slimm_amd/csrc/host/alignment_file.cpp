@@ -147,7 +147,7 @@ struct StageClock {  // SLIMM_CLI_TRACE=1: where the reader's time goes, printed
 AlignmentFile::~AlignmentFile() { close(); }
 
 void AlignmentFile::close() {
-    if (fp_ && getenv("SLIMM_CLI_TRACE") && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0)
+    if (fp_ && getenv("SLIMM_CLI_TRACE") && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0 && n_windows_ > 1)
         fprintf(stderr, "[trace] reader: read + parse blocks %.1f ms, inflate %.1f ms, record starts %.1f ms, decode + hash %.1f ms, "
                         "name check %.1f ms; %u windows, waited %.1f ms for the prefetch thread (%u threads, inflate by %s)\n", ms_read_, ms_inflate_, ms_find_,
                 ms_decode_, ms_names_, n_windows_, ms_wait_, threads_, inflate_backend());
@@ -195,6 +195,7 @@ bool AlignmentFile::open(const std::string& path) {
     inflaters_.reset(new Workers(threads_));  // (the prefetch thread's own: its jobs run beside the decode jobs)
     file_eof_ = false;
     first_batch_ = true;
+    raw_stage_ = 0;
     cfill_ = cdone_ = 0;
     spare_.clear();
     order_ = SortOrder::Unknown;
@@ -749,6 +750,136 @@ void AlignmentFile::separate_adjacent_names(uint64_t* key, const std::vector<siz
     last_name_.assign(ln, ll);
     last_key_ = key[cnt - 1];
     have_last_ = true;
+}
+
+// The inflated record bytes window by window (read_raw in the header).  The windows the header parse left behind come
+// first (what is unread of the decoded window, then the window the prefetch thread was inflating); from then on whole
+// BGZF blocks are inflated straight into the caller's buffer, as many as fit.
+long AlignmentFile::read_raw(uint8_t* dst, size_t cap) {
+    if (!bam_ || !dst || cap < (1u << 20)) {
+        err_ = "read_raw: a BAM file and a buffer of at least 1 MiB";
+        return -1;
+    }
+    if (raw_stage_ == 0) {  // what is unread of the decoded window (in pieces, when it is larger than the buffer)
+        const size_t n = std::min(buf_.size() - pos_, cap);
+        if (n) {
+            memcpy(dst, buf_.data() + pos_, n);
+            pos_ += n;
+            return static_cast<long>(n);
+        }
+        raw_stage_ = 1;
+        raw_off_ = kSlack;
+        if (prefetch_.joinable()) {
+            {
+                StageClock clk(ms_wait_);
+                prefetch_.join();
+            }
+            ++n_windows_;
+            if (!next_ok_) {
+                err_ = next_err_;
+                return -1;
+            }
+            if (next_eof_) eof_ = true;
+        } else {
+            spare_.resize(0);
+        }
+    }
+    if (raw_stage_ == 1) {  // the window the prefetch thread had inflated
+        const size_t left = spare_.size() > raw_off_ ? spare_.size() - raw_off_ : 0;
+        const size_t n = std::min(left, cap);
+        if (n) {
+            memcpy(dst, spare_.data() + raw_off_, n);
+            raw_off_ += n;
+            return static_cast<long>(n);
+        }
+        spare_.resize(0);
+        raw_stage_ = 2;
+    }
+    while (!eof_) {
+        size_t out = 0;
+        {
+            StageClock clk(ms_read_);
+            // top the compressed bytes up, then take the whole blocks that fit into the caller's buffer
+            constexpr size_t kRawBatch = 32u << 20;
+            if (!file_eof_ && cfill_ < kRawBatch) {
+                cbuf_.resize(cfill_ + kRawBatch);
+                const size_t got = fread(cbuf_.data() + cfill_, 1, kRawBatch, fp_);
+                cfill_ += got;
+                if (got < kRawBatch) file_eof_ = true;
+            }
+            blocks_.clear();
+            size_t p = 0;
+            while (cfill_ - p >= 18) {
+                const uint8_t* hdr = cbuf_.data() + p;
+                if (hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
+                    err_ = "not a BGZF block";
+                    return -1;
+                }
+                const size_t xlen = rd_u16(hdr + 10);
+                if (cfill_ - p < 12 + xlen) break;
+                int bsize = -1;
+                for (size_t o = 0; o + 4 <= xlen;) {
+                    const uint8_t* x = hdr + 12 + o;
+                    const uint16_t slen = rd_u16(x + 2);
+                    if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = rd_u16(x + 4);
+                    o += 4 + slen;
+                }
+                if (bsize < 0) {
+                    err_ = "BGZF block without BC field";
+                    return -1;
+                }
+                const size_t total = static_cast<size_t>(bsize) + 1;
+                if (total < 12u + xlen + 8u) {
+                    err_ = "bad BGZF block size";
+                    return -1;
+                }
+                if (cfill_ - p < total) break;
+                Block b;
+                b.coff = p + 12 + xlen;
+                b.clen = total - 12 - xlen - 8;
+                b.crc = rd_u32(&cbuf_[p + total - 8]);
+                b.isize = rd_u32(&cbuf_[p + total - 4]);
+                if (b.isize > 65536u) {
+                    err_ = "bad BGZF block size";
+                    return -1;
+                }
+                if (out + b.isize > cap) break;  // (the buffer is full: the rest waits, compressed, for the next call)
+                b.ooff = out;
+                out += b.isize;
+                blocks_.push_back(b);
+                p += total;
+            }
+            if (file_eof_ && blocks_.empty() && cfill_ - p != 0 && out == 0) {
+                err_ = cfill_ - p < 18 ? "truncated BGZF header" : "truncated BGZF block";
+                return -1;
+            }
+            cdone_ = p;
+        }
+        if (!blocks_.empty()) {
+            StageClock clk(ms_inflate_);
+            std::atomic<size_t> next{0};
+            std::atomic<bool> ok{true};
+            inflaters_->run(std::min<unsigned>(inflaters_->size(), static_cast<unsigned>(blocks_.size())), [&](unsigned) {
+                for (size_t k; (k = next.fetch_add(1)) < blocks_.size();) {
+                    const Block& b = blocks_[k];
+                    if (!inflate_one(cbuf_.data() + b.coff, b.clen, dst + b.ooff, b.isize, b.crc)) ok = false;
+                }
+            });
+            if (!ok) {
+                err_ = "corrupt BGZF block (inflate or CRC failed)";
+                return -1;
+            }
+        }
+        memmove(cbuf_.data(), cbuf_.data() + cdone_, cfill_ - cdone_);
+        cfill_ -= cdone_;
+        ++n_windows_;
+        if (file_eof_ && cfill_ == 0) eof_ = true;
+        if (out) return static_cast<long>(out);
+        // (only empty blocks -- the end-of-file marker -- or nothing complete yet: go round again)
+        if (blocks_.empty() && !file_eof_) continue;
+        if (blocks_.empty() && file_eof_) break;
+    }
+    return 0;
 }
 
 // The four record fields of the hot path straight into the caller's arrays (the page-locked staging sets of

@@ -70,7 +70,15 @@ public:
     long read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begin_pos, uint16_t* flag, size_t max_records,
                    uint32_t* check = nullptr);
 
+    // BAM only: the inflated bytes of the alignment records -- everything behind the header, or behind the last record a
+    // read_* call handed out -- window by window straight into the caller's buffer (for slimm_push_bam_bytes: the records
+    // are then found and decoded on the device).  Returns the bytes written (whole BGZF blocks, at most `cap`), 0 at the
+    // end of the file, -1 + error() on a format error.  Not to be mixed with read_batch / read_into afterwards.
+    long read_raw(uint8_t* dst, size_t cap);
+
 private:
+    size_t raw_off_ = 0;
+    int raw_stage_ = 0;               // read_raw: 0 = the decoded window at hand, 1 = the prefetched one, 2 = straight from the file
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)
     long bam_record_starts(size_t max_records, std::vector<size_t>& offs);
     template <typename F>

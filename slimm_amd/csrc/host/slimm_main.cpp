@@ -102,6 +102,8 @@ SLIMM_FORWARD(void, slimm_mark_words,
               (const uint64_t* a, const uint16_t* b, const int32_t* c, uint64_t d, const uint64_t* e, uint32_t* f_), (a, b, c, d, e, f_))
 SLIMM_FORWARD(int, slimm_push_records_packed, (slimm_ctx* a, const uint64_t* b, const int32_t* c, const int32_t* d, uint64_t e),
               (a, b, c, d, e))
+SLIMM_FORWARD(int, slimm_push_bam_bytes, (slimm_ctx* a, const uint8_t* b, uint64_t c, int d, uint64_t* e), (a, b, c, d, e))
+SLIMM_FORWARD(int, slimm_pin_host_buffer, (slimm_ctx* a, const void* b, uint64_t c), (a, b, c))
 SLIMM_FORWARD(int, slimm_check_grouping, (slimm_ctx* a, uint64_t* b), (a, b))
 SLIMM_FORWARD(int, slimm_keep_bins, (slimm_ctx* a, int b), (a, b))
 SLIMM_FORWARD(int, slimm_analyze_alignments, (slimm_ctx* a), (a))
@@ -415,17 +417,106 @@ struct RecordPump {
     double decode_ms = 0, wait_ms = 0;
     std::thread th;
 
-    RecordPump(AlignmentFile& f, bool check_words)
+    // DEVICE DECODE (BAM files, one context): the decoder thread only inflates -- windows of BGZF-inflated record bytes
+    // go into a few large host buffers, a second thread hands them to slimm_push_bam_bytes, and the device finds the
+    // record boundaries, reads the fields and compares / hashes the names (slimm_amd/csrc/bam_decode.hip).  The host
+    // walked every inflated byte three times for that.  SLIMM_CLI_HOST_DECODE=1 keeps the host decoder.
+    const bool raw;
+    static constexpr size_t kRawCap = 192u << 20;   // bytes per window buffer
+    static constexpr unsigned kRawBuffers = 3;
+    struct RawWindow {
+        unsigned which = 0;
+        long n = 0;  // bytes; 0 = end of file, -1 = the reader failed
+    };
+    std::unique_ptr<uint8_t[]> raw_buf[kRawBuffers];
+    std::deque<RawWindow> raw_ready;   // inflated, waiting to be pushed
+    unsigned raw_free = kRawBuffers;
+    std::thread raw_pusher;
+    uint64_t raw_records = 0;
+    double raw_push_ms = 0;
+
+    RecordPump(AlignmentFile& f, bool check_words, bool device_decode)
         : bam(f), want_check(check_words),
-          marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")), th([this] { run(); }) {}
+          marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")),
+          raw(device_decode && f.is_bam() && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") &&
+              !getenv("SLIMM_CLI_HOST_DECODE")) {
+        th = std::thread([this] { raw ? run_raw() : run(); });  // (in the body: every member is initialised by now)
+    }
     ~RecordPump() {
-        if (th.joinable()) {
+        if (th.joinable() || raw_pusher.joinable()) {
             {
                 std::lock_guard<std::mutex> g(mu);
                 failed = true;  // (an early return of the caller: let the decoder out of its wait)
             }
             cv.notify_all();
-            th.join();
+            if (th.joinable()) th.join();
+            if (raw_pusher.joinable()) raw_pusher.join();
+        }
+    }
+    // the inflater of the device-decode mode: fills the window buffers in turn
+    void run_raw() {
+        for (unsigned w = 0;; w = (w + 1) % kRawBuffers) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return failed || raw_free > 0; });
+                if (failed) return;
+                --raw_free;
+            }
+            if (!raw_buf[w]) raw_buf[w].reset(new uint8_t[kRawCap]);
+            auto t1 = std::chrono::steady_clock::now();
+            const long n = bam.read_raw(raw_buf[w].get(), kRawCap);
+            decode_ms += ms(t1, std::chrono::steady_clock::now());
+            {
+                std::lock_guard<std::mutex> g(mu);
+                raw_ready.push_back(RawWindow{w, n});
+            }
+            cv.notify_all();
+            if (n <= 0) {
+                read_rc = n;
+                return;
+            }
+        }
+    }
+    // ... and the thread that hands them to the device, from the moment the context exists
+    void push_raw(slimm_ctx* c) {
+        bool pinned[kRawBuffers] = {false, false, false};
+        RawWindow held;       // a window is pushed when the NEXT one says whether it was the file's last
+        bool have_held = false;
+        for (;;) {
+            RawWindow w;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                auto t0 = std::chrono::steady_clock::now();
+                cv.wait(g, [&] { return failed || !raw_ready.empty(); });
+                wait_ms += ms(t0, std::chrono::steady_clock::now());
+                if (failed) return;
+                w = raw_ready.front();
+                raw_ready.pop_front();
+            }
+            if (have_held || w.n <= 0) {
+                auto t1 = std::chrono::steady_clock::now();
+                uint64_t got = 0;
+                int rc;
+                if (have_held) {
+                    if (!pinned[held.which]) {
+                        (void)slimm_pin_host_buffer(c, raw_buf[held.which].get(), kRawCap);  // (pageable still works)
+                        pinned[held.which] = true;
+                    }
+                    rc = slimm_push_bam_bytes(c, raw_buf[held.which].get(), static_cast<uint64_t>(held.n), w.n == 0 ? 1 : 0, &got);
+                } else {
+                    rc = w.n == 0 ? slimm_push_bam_bytes(c, nullptr, 0, 1, &got) : SLIMM_OK;  // (a file without records)
+                }
+                raw_push_ms += ms(t1, std::chrono::steady_clock::now());
+                raw_records += got;
+                std::lock_guard<std::mutex> g(mu);
+                if (have_held) ++raw_free;
+                if (rc < 0) failed = true;
+                cv.notify_all();
+                if (rc < 0) return;
+            }
+            if (w.n <= 0) return;  // end of file (or the reader failed: read_rc says so)
+            held = w;
+            have_held = true;
         }
     }
     // 16 bytes per record over the bus: the three flag bits the path reads go into the key's top bits
@@ -521,6 +612,10 @@ struct RecordPump {
     }
     // pushes what was decoded so far and hands the context to the decoder; false when a push failed
     bool attach(slimm_ctx* c) {
+        if (raw) {
+            raw_pusher = std::thread([this, c] { push_raw(c); });
+            return true;
+        }
         std::unique_lock<std::mutex> g(mu);
         for (Batch& b : queued)
             if (push(c, b) < 0) {
@@ -549,6 +644,7 @@ struct RecordPump {
     // waits for the end of the file; false on a failed push
     bool finish() {
         th.join();
+        if (raw_pusher.joinable()) raw_pusher.join();
         return !failed;
     }
 };
@@ -693,7 +789,8 @@ bool get_profiles(Session& S, size_t file_index) {
                                         : SLIMM_ORDER_ANY);
     // (grouped streams are exact already: the reader compares the names of adjacent records)
     const bool check_words = record_order == SLIMM_ORDER_ANY;
-    RecordPump pump(bam, check_words);  // decoding starts now; the records are claimed further down, when the context exists
+    // decoding starts now; the records are claimed further down, when the context exists (one context: the device decodes)
+    RecordPump pump(bam, check_words, options.devices.size() <= 1);
 
     std::cerr << "Intializing coverages for all reference genome ... ";
     const uint32_t R = static_cast<uint32_t>(bam.ref_names().size());
@@ -811,7 +908,11 @@ bool get_profiles(Session& S, size_t file_index) {
     std::cerr << "Analysing alignments, reads and references ....... ";
     {
         const bool pushed = pump.attach(ctx) && pump.finish();
-        if (trace.on)
+        if (trace.on && pump.raw)
+            fprintf(stderr, "[trace] device decode: inflate %.2f ms (on its own thread, from the moment the file was open), "
+                            "slimm_push_bam_bytes %.2f ms for %llu records, pusher waited %.2f ms for windows\n",
+                    pump.decode_ms, pump.raw_push_ms, static_cast<unsigned long long>(pump.raw_records), pump.wait_ms);
+        else if (trace.on)
             fprintf(stderr, "[trace] decode %.2f ms (on its own thread, from the moment the file was open), waiting for staging sets %.2f ms\n",
                     pump.decode_ms, pump.wait_ms);
         trace.mark("rest of read + decode + push");

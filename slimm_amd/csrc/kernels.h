@@ -249,6 +249,31 @@ namespace tiles14 {
 // TILES(shift, launch_tile_count(st, ...)): the call in the namespace of the tile size
 #define TILES(shift, call) ((shift) == ::slimm::kTileShiftLarge ? ::slimm::tiles14::call : ::slimm::tiles13::call)
 
+// ---- bam_decode.hip: BAM alignment records decoded on the device (slimm_push_bam_bytes) ----
+constexpr uint32_t kBamPiece = 16384;                 // bytes per piece: a lane finds and walks the records that start in it
+constexpr uint32_t kBamSlots = kBamPiece / 36 + 2;    // record offsets a piece can hold (a record is at least 36 bytes)
+constexpr uint32_t kBamPieceBad = 1;
+constexpr uint64_t kBamSlack = 16ull << 20;           // room in front of a window for the incomplete record of the one before
+struct BamPiece {
+    uint32_t guess, stop, count, flags;  // where its first record starts (guessed, then verified); where its walk ended; records
+    uint32_t base, pad[3];               // records of the window in front of it
+};
+struct BamWindowResult {
+    uint32_t n_records, stop, bad, last_piece;  // complete records; offset behind the last one; malformed record met; the last piece holding a record
+};
+struct BamCarry {  // the name of the last record of the window before (the next window's first record is compared with it)
+    uint32_t have, len;
+    uint8_t name[256];
+};
+uint32_t bam_pieces(uint64_t n_bytes);
+// record boundaries of bytes[lo, end) (lo: a record starts there) -> pieces, offs (bam_pieces x kBamSlots), *result
+void launch_bam_find(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t end, uint32_t n_refs, BamPiece* pieces, uint32_t* offs,
+                     BamWindowResult* result);
+// the window's records appended at out_at: marked -> ref (the words) + pos; otherwise key, ref, pos, flag, check
+void launch_bam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t end, const BamPiece* pieces, const uint32_t* offs,
+                       BamCarry* carry, const BamWindowResult* result, bool marked, uint64_t out_at, uint64_t* key, int32_t* ref,
+                       int32_t* pos, uint16_t* flag, uint32_t* check);
+
 // ---- group_by_ident.hip: record_order = ANY -- the records of every read identity adjacent, file order kept among them ----
 // (stable counting passes over a few bits of a hash of the qName key, then a finish inside the small buckets of equal
 // hash bits; the first pass reads the caller's records, so there is no compaction step)

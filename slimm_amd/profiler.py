@@ -235,6 +235,23 @@ class Slimm:
         self._keepalive = (words, pos)
         self._check(self.L.slimm_set_records_device_marked(self.ctx, C.c_void_p(words.data_ptr()), C.c_void_p(pos.data_ptr()), n))
 
+    def push_bam_bytes(self, data, window: int = 0) -> int:
+        """slimm_push_bam_bytes: the alignment-record bytes of a BAM file (behind its header, BGZF-inflated), in windows of
+        `window` bytes (0: one); the device finds the records and decodes them.  Returns the number of records."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = buf.shape[0]
+        step = window or max(n, 1)
+        total = 0
+        got = C.c_uint64()
+        if n == 0:
+            self._check(self.L.slimm_push_bam_bytes(self.ctx, None, 0, 1, C.byref(got)))
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            piece = np.ascontiguousarray(buf[s:e])
+            self._check(self.L.slimm_push_bam_bytes(self.ctx, _p(piece), e - s, 1 if e == n else 0, C.byref(got)))
+            total += got.value
+        return total
+
     def push_wait(self):
         self._check(self.L.slimm_push_wait(self.ctx))
 

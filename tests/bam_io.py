@@ -40,22 +40,42 @@ def _bgzf_block(data: bytes) -> bytes:
             + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
 
 
-def write_bam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
+def bam_record_bytes(records, read_len=100, irregular_seed=None) -> bytes:
+    """The alignment records of a BAM file as they follow its header (SAM/BAM specification 4.2), concatenated:
+    block_size | refID | pos | l_read_name | mapq | bin | n_cigar_op | flag | l_seq | next_refID | next_pos | tlen |
+    read_name | cigar | seq | qual (| tags).  irregular_seed: record sizes vary (sequence lengths 0 .. 3 x read_len, one to
+    four CIGAR operations, a few optional tag bytes), so that record boundaries fall anywhere."""
     q = qnames_of(records)
+    rng = np.random.default_rng(irregular_seed) if irregular_seed is not None else None
+    out = bytearray()
+    seq = bytes([0x11] * ((read_len + 1) // 2))
+    qual = bytes([0xff] * read_len)
+    cigar = struct.pack("<I", (read_len << 4) | 0)
+    for i in range(len(records)):
+        name = q[i].encode() + b"\x00"
+        if rng is None:
+            l_seq, cg, sq, ql, tags = read_len, cigar, seq, qual, b""
+        else:
+            l_seq = int(rng.integers(0, 3 * read_len + 1))
+            n_op = int(rng.integers(1, 5))
+            cg = b"".join(struct.pack("<I", (int(rng.integers(1, 200)) << 4) | int(rng.integers(0, 5))) for _ in range(n_op))
+            sq = bytes(rng.integers(0, 256, size=(l_seq + 1) // 2, dtype=np.uint8))
+            ql = bytes(rng.integers(0, 42, size=l_seq, dtype=np.uint8))
+            tags = b"NMC" + bytes([int(rng.integers(0, 200))]) if rng.random() < 0.5 else b""
+        body = struct.pack("<iiBBHHHIiii", int(records.ref_id[i]), int(records.begin_pos[i]), len(name), 255, 4680, len(cg) // 4,
+                           int(records.flag[i]), l_seq, -1, -1, 0) + name + cg + sq + ql + tags
+        out += struct.pack("<i", len(body)) + body
+    return bytes(out)
+
+
+def write_bam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query", irregular_seed=None):
     text = sam_header(ref_names, ref_len, hd).encode()
     out = bytearray()
     out += b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names))
     for n, l in zip(ref_names, ref_len):
         nb = n.encode() + b"\x00"
         out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", int(l))
-    seq = bytes([0x11] * ((read_len + 1) // 2))
-    qual = bytes([0xff] * read_len)
-    cigar = struct.pack("<I", (read_len << 4) | 0)
-    for i in range(len(records)):
-        name = q[i].encode() + b"\x00"
-        body = struct.pack("<iiBBHHHIiii", int(records.ref_id[i]), int(records.begin_pos[i]), len(name), 255, 4680, 1,
-                           int(records.flag[i]), read_len, -1, -1, 0) + name + cigar + seq + qual
-        out += struct.pack("<i", len(body)) + body
+    out += bam_record_bytes(records, read_len, irregular_seed)
     with open(path, "wb") as f:
         for s in range(0, len(out), 0xff00):
             f.write(_bgzf_block(bytes(out[s:s + 0xff00])))

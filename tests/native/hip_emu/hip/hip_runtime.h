@@ -73,6 +73,9 @@ hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags);
 hipError_t hipHostFree(void* p);
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
+#define hipHostRegisterDefault 0
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);

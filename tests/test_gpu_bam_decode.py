@@ -1,0 +1,103 @@
+"""BAM alignment records decoded on the device (slimm_push_bam_bytes, slimm_amd/csrc/bam_decode.hip) against the oracle,
+which takes the same records as decoded arrays and groups them by their NAMES like the reference does (seqan::readRecord
++ the string-keyed map of src/slimm.hpp:194-211).  The record bytes come from an independent Python writer
+(tests/bam_io.py), regular and with record sizes that put boundaries anywhere; windows cut records at every offset."""
+import numpy as np
+import pytest
+
+from oracle.binding import run_workload
+from slimm_amd import capi
+from slimm_amd.profiler import Slimm
+from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
+from slimm_amd.workload import Records, Workload
+from tests.bam_io import bam_record_bytes
+from tests.helpers import assert_matches_oracle
+from tests.test_gpu_parity import _interleave_mates, one_long_read_workload
+
+pytestmark = pytest.mark.gpu
+
+
+def _named(w: Workload, long_names: bool = False) -> Workload:
+    """The workload with read names (the oracle then groups by the names themselves)."""
+    r = w.records
+    ids = np.unique(r.read_key, return_inverse=True)[1]
+    names = [("read/%d/" % i) + ("x" * (i % 180) if long_names else "") for i in ids.tolist()]
+    return Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, names),
+                    w.avg_read_len, w.options, w.name + "-named", grouped=w.grouped)
+
+
+def _check(w: Workload, grouped: bool, window: int, irregular=None, read_len=100):
+    o = run_workload(w, use_qnames=True)
+    data = bam_record_bytes(w.records, read_len=read_len, irregular_seed=irregular)
+    s = Slimm.for_workload(w, device=0, grouped=grouped)
+    n = s.push_bam_bytes(data, window=window)
+    assert n == len(w.records)
+    prof = s.get_profiles()
+    if o.no_hits:
+        assert prof is None
+    else:
+        assert_matches_oracle(s, o)
+    s.close()
+
+
+@pytest.mark.parametrize("window", [0, 1 << 20, 100_003, 16_411])
+@pytest.mark.parametrize("irregular", [None, 7])
+def test_grouped_file_decoded_on_the_device(window, irregular):
+    """Name-grouped records -> run-marked records by comparing adjacent NAMES on the device; windows of one piece and a
+    bit, of a few pieces, of a megabyte, and the whole file at once."""
+    w = _named(make_workload(CONFIGS["config1"], seed=31))
+    w.records.flag[::11] |= 4
+    w.records.ref_id[5::19] = -1
+    _check(w, True, window, irregular)
+
+
+@pytest.mark.parametrize("window", [0, 250_007])
+def test_unordered_file_decoded_on_the_device(window):
+    """Any other order: name hash + check word computed on the device (the host reader's functions), then the grouping."""
+    w = _named(make_workload(CONFIGS["config1"], seed=32, shuffled=True))
+    _check(w, False, window, irregular=9)
+
+
+def test_long_names_long_runs_and_interleaved_mates():
+    w = _named(_interleave_mates(make_workload(SynthConfig("pairs", 20_000, 300, 6.0), seed=33, paired_frac=0.9)), long_names=True)
+    _check(w, True, 300_001, irregular=3)
+    _check(_named(one_long_read_workload(3_000)), True, 77_777)
+
+
+def test_records_longer_than_a_piece_and_tiny_windows():
+    """Sequences of tens of kilobases: records run over whole 16 KB pieces (no record starts in them; header look-alikes in
+    random sequence bytes are verified away), and windows smaller than a record (several pushes without a complete one)."""
+    w = _named(make_workload(SynthConfig("few", 400, 12, 2.0, bin_width=100, len_lo=5_000, len_hi=50_000, present_frac=0.8), seed=34))
+    _check(w, True, 50_021, irregular=5, read_len=20_000)
+    _check(w, True, 9_973, irregular=6, read_len=9_000)
+
+
+def test_malformed_and_truncated_streams_are_errors():
+    w = _named(make_workload(CONFIGS["config1"], seed=35, n_records=2_000))
+    data = bytearray(bam_record_bytes(w.records))
+    s = Slimm.for_workload(w, device=0)
+    with pytest.raises(capi.SlimmError) as e:
+        s.push_bam_bytes(bytes(data[:-10]))               # the last record is cut off
+    assert "truncated" in str(e.value)
+    s.reset()
+    bad = bytearray(data)
+    bad[200_000:200_004] = (5).to_bytes(4, "little") if False else bad[200_000:200_004]
+    # a block_size below the fixed fields in the middle of the file
+    import struct
+    off, k = 0, 0
+    while k < 1000:
+        off += 4 + struct.unpack_from("<i", data, off)[0]
+        k += 1
+    bad[off:off + 4] = struct.pack("<i", 7)
+    with pytest.raises(capi.SlimmError) as e:
+        s.push_bam_bytes(bytes(bad), window=64_000)
+    assert "bad BAM record" in str(e.value)
+    # the forms do not mix within a file; the next file is fine again
+    s.reset()
+    s.push_records(w.records)
+    with pytest.raises(capi.SlimmError):
+        s.push_bam_bytes(bytes(data))
+    s.reset(); s.reset_cutoffs()
+    assert s.push_bam_bytes(bytes(data), window=123_457) == len(w.records)
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, run_workload(w, use_qnames=True))

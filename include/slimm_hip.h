@@ -190,9 +190,11 @@ int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
  * run-marked 8-byte records (a record starts a run where its NAME differs from the name of the record before it: exact,
  * no hash involved); SLIMM_ORDER_ANY -> key (the 62-bit hash of the name that host/alignment_file.cpp computes), refID,
  * position, flag and a check word (as slimm_push_records_checked).  `bytes`: any host memory (page-locked -- see
- * slimm_pin_host_buffer -- the DMA engine reads it directly); hand over a few buffers in rotation.  The call returns
- * when the window's bytes have left the buffer (it may be refilled) and its records are counted (*n_records, may be
- * NULL); their decoding continues on the device.  last != 0: nothing follows -- bytes of an incomplete record are then
+ * slimm_pin_host_buffer -- the DMA engine reads it directly).  A window's copy is started by the call that hands it
+ * over and runs beside the device's work on the window BEFORE it: the buffer must stay unchanged until the NEXT call on
+ * this context returns (a call with last != 0 finishes everything), so hand over three or more buffers in rotation.
+ * *n_records (may be NULL): records appended by this call -- those of the window before, and with last != 0 of this one
+ * too.  last != 0: nothing follows (n_bytes may be 0) -- bytes of an incomplete record are then
  * an error (SLIMM_E_INVALID, "truncated BAM record"), as is a malformed record in any window.  A record longer than
  * 16 MiB is not supported in this form (SLIMM_E_INVALID: decode such a file on the host).  The forms do not mix within
  * a file.  Replaces: seqan::readRecord in src/slimm.hpp:194-208 / src/misc.hpp:509-522. */

@@ -133,15 +133,19 @@ struct slimm_ctx {
     // slimm_push_bam_bytes: BAM records decoded on the device (bam_decode.hip).  Two byte buffers [slack | window] take the
     // windows in turn; the incomplete record at a window's end is copied in front of the next window
     struct BamDecode {
-        DevBuf<uint8_t> bytes[2];
+        DevBuf<uint8_t> bytes[3];
         DevBuf<BamPiece> pieces;
         DevBuf<uint32_t> offs;
         DevBuf<BamCarry> carry;
         PinBuf<BamWindowResult> result;     // written by k_bam_scan straight into page-locked host memory
         std::vector<std::pair<const uint8_t*, size_t>> registered;  // caller buffers page-locked by hipHostRegister
-        uint64_t windows = 0;               // of this file
+        uint64_t windows = 0;               // of this file, pushed so far
         uint64_t carry_bytes = 0;
         bool active = false;                // this file's records come from slimm_push_bam_bytes
+        bool pending = false;               // the last window pushed is copied (or on its way) but not worked on yet
+        bool closed = false;                // the file's last window went in
+        uint64_t pending_bytes = 0;
+        hipEvent_t copied[3] = {nullptr, nullptr, nullptr};
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
@@ -651,6 +655,8 @@ void slimm_destroy(slimm_ctx* c) {
         }
         if (c->copy_done) (void)hipEventDestroy(c->copy_done);
         for (auto& r : c->bam.registered) (void)hipHostUnregister(const_cast<uint8_t*>(r.first));
+        for (auto& e : c->bam.copied)
+            if (e) (void)hipEventDestroy(e);
         for (auto& sg : c->staging)
             if (sg.done) (void)hipEventDestroy(sg.done);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -672,6 +678,7 @@ int slimm_reset(slimm_ctx* c) {
     c->bam.windows = 0;
     c->bam.carry_bytes = 0;
     c->bam.active = false;
+    c->bam.pending = c->bam.closed = false;
     c->has_check = false;
     c->packed = false;
     c->marked = false;
@@ -939,7 +946,69 @@ int slimm_pin_host_buffer(slimm_ctx* c, const void* p, uint64_t n_bytes) {
     return SLIMM_OK;
 }
 
-// BAM alignment records decoded on the device (include/slimm_hip.h; kernels: bam_decode.hip)
+// BAM alignment records decoded on the device (include/slimm_hip.h; kernels: bam_decode.hip).
+// A window is copied when it is pushed and WORKED ON when the next one is pushed (or at once, when it is the last): its
+// host-to-device copy then runs beside the kernels and the host's bookkeeping of the window before it -- the copies are
+// what bounds this path (192 MB at 54 GB/s: 3.6 ms; kernels + one synchronisation per window: 0.8 ms).
+namespace {
+// window j (n bytes, in buffer j % 3) -> records appended; the incomplete record at its end goes in front of window j + 1
+int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, uint64_t& n_rec_out) {
+    slimm_ctx::BamDecode& B = c->bam;
+    hipStream_t st = c->stream;
+    const bool marked = c->order == SLIMM_ORDER_GROUPED;
+    const uint32_t b = static_cast<uint32_t>(j % 3u), nb = static_cast<uint32_t>((j + 1u) % 3u);
+    const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
+    const uint32_t np = bam_pieces(end - lo);
+    HIP_TRY(c, B.pieces.ensure(static_cast<size_t>(np) + 1));
+    HIP_TRY(c, B.offs.ensure(static_cast<size_t>(np + 1) * kBamSlots));
+    if (n_bytes) HIP_TRY(c, hipStreamWaitEvent(st, B.copied[b], 0));
+    launch_bam_find(st, B.bytes[b].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
+    HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device and counted
+    const BamWindowResult res = *B.result.p;
+    if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
+    const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
+    const uint64_t tail = end - stop;
+    if (tail > kBamSlack) return fail(c, SLIMM_E_INVALID, "a BAM record longer than 16 MiB: decode this file on the host");
+    if (is_last && tail) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
+    if (c->n_pushed + n_rec >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
+    int rc = slimm_reserve(c, c->n_pushed + n_rec);
+    if (rc != SLIMM_OK) return rc;
+    if (!marked) {  // (the four-array form's flag and check arrays appear at a file's first window)
+        const uint64_t want = c->n_pushed + n_rec;
+        if (c->in_flag.cap < want) {
+            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
+            HIP_TRY(c, c->in_flag.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+        }
+        if (c->in_check.cap < want) {
+            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
+            HIP_TRY(c, c->in_check.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+        }
+    }
+    launch_bam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
+                      c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p);
+    if (tail) {  // the incomplete record goes in front of the next window (whose own bytes may be on their way already)
+        if (B.bytes[nb].cap < kBamSlack + 64) HIP_TRY(c, B.bytes[nb].ensure(kBamSlack + 64));
+        HIP_TRY(c, hipMemcpyAsync(B.bytes[nb].p + kBamSlack - tail, B.bytes[b].p + stop, tail, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(c, hipGetLastError());
+    B.carry_bytes = tail;
+    c->n_pushed += n_rec;
+    c->rec = DeviceRecords();
+    c->rec.ref = c->in_ref.p;
+    c->rec.pos = c->in_pos.p;
+    c->rec.n = static_cast<uint32_t>(c->n_pushed);
+    if (marked) {
+        c->rec.marked = true;
+    } else {
+        c->rec.key = c->in_key.p;
+        c->rec.flag = c->in_flag.p;
+        c->rec.check = c->in_check.p;
+    }
+    n_rec_out = n_rec;
+    return SLIMM_OK;
+}
+}  // namespace
+
 int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records) {
     if (!c) return SLIMM_E_INVALID;
     if (n_records) *n_records = 0;
@@ -958,83 +1027,65 @@ int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, i
         B.active = true;
         B.windows = 0;
         B.carry_bytes = 0;
+        B.pending = false;
         c->marked = marked;
         c->has_check = !marked;
         c->packed = false;
         HIP_TRY(c, B.carry.ensure(1));
         HIP_TRY(c, B.result.ensure(1));
+        for (auto& e : B.copied)
+            if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(c, hipMemsetAsync(B.carry.p, 0, sizeof(BamCarry), st));
     }
-    const uint32_t w = static_cast<uint32_t>(B.windows & 1u);
-    const uint64_t need = kBamSlack + n_bytes + 64;
-    for (int k = 0; k < 2; ++k)
-        if (B.bytes[k].cap < need) {
-            // (growing keeps nothing: buffer w takes this window, and the carried bytes live in the OTHER buffer's slack only
-            // until they were copied in front of this window, which happened when the window before was pushed)
-            if (k == static_cast<int>(w) && B.carry_bytes) {
+    if (B.closed) return fail(c, SLIMM_E_INVALID, "the file's last window has been pushed; reset first");
+    uint64_t total = 0;
+    if (n_bytes) {  // this window's bytes start on their way ...
+        const uint32_t b = static_cast<uint32_t>(B.windows % 3u);
+        const uint64_t need = kBamSlack + n_bytes + 64;
+        if (B.bytes[b].cap < need) {
+            // (what the buffer held -- window j - 3 -- is done with: its kernels ran before the synchronisation of the call
+            // before this one.  Only the carried bytes in its slack matter, and only when nothing is pending: with a window
+            // pending they are put there further down, by that window's own end)
+            if (!B.pending && B.carry_bytes) {
                 DevBuf<uint8_t> nb;
                 HIP_TRY(c, nb.ensure(need + (need >> 2)));
-                HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[k].p + kBamSlack - B.carry_bytes, B.carry_bytes,
+                HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[b].p + kBamSlack - B.carry_bytes, B.carry_bytes,
                                           hipMemcpyDeviceToDevice, st));
                 HIP_TRY(c, hipStreamSynchronize(st));
-                std::swap(B.bytes[k].p, nb.p);
-                std::swap(B.bytes[k].cap, nb.cap);
+                std::swap(B.bytes[b].p, nb.p);
+                std::swap(B.bytes[b].cap, nb.cap);
             } else {
-                HIP_TRY(c, hipStreamSynchronize(st));  // (kernels of the window before may still read it)
-                HIP_TRY(c, B.bytes[k].ensure(need + (need >> 2)));
+                HIP_TRY(c, B.bytes[b].ensure(need + (need >> 2)));
             }
         }
-    const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
-    const uint32_t np = bam_pieces(end - lo);
-    HIP_TRY(c, B.pieces.ensure(static_cast<size_t>(np) + 1));
-    HIP_TRY(c, B.offs.ensure(static_cast<size_t>(np + 1) * kBamSlots));
+        HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+    }
+    if (B.pending) {  // ... while the window before is worked on
+        uint64_t got = 0;
+        int rc = bam_finish_window(c, B.windows - 1u, B.pending_bytes, last && !n_bytes, got);
+        B.pending = false;
+        if (rc != SLIMM_OK) return rc;
+        total += got;
+    }
     if (n_bytes) {
-        HIP_TRY(c, hipMemcpyAsync(B.bytes[w].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
-        HIP_TRY(c, hipStreamWaitEvent(st, c->copy_done, 0));
+        B.pending = true;
+        B.pending_bytes = n_bytes;
+        ++B.windows;
     }
-    launch_bam_find(st, B.bytes[w].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
-    HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device (the caller's buffer is free) and counted
-    const BamWindowResult res = *B.result.p;
-    if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
-    const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
-    const uint64_t tail = end - stop;
-    if (tail > kBamSlack) return fail(c, SLIMM_E_INVALID, "a BAM record longer than 16 MiB: decode this file on the host");
-    if (last && tail) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
-    if (c->n_pushed + n_rec >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
-    int rc = slimm_reserve(c, c->n_pushed + n_rec);
-    if (rc != SLIMM_OK) return rc;
-    if (!marked) {  // (the four-array form's flag and check arrays appear at a file's first window)
-        const uint64_t want = c->n_pushed + n_rec;
-        if (c->in_flag.cap < want) {
-            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
-            HIP_TRY(c, c->in_flag.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+    if (last) {
+        if (B.pending) {
+            uint64_t got = 0;
+            int rc = bam_finish_window(c, B.windows - 1u, B.pending_bytes, true, got);
+            B.pending = false;
+            if (rc != SLIMM_OK) return rc;
+            total += got;
+        } else if (B.carry_bytes) {
+            return fail(c, SLIMM_E_INVALID, "truncated BAM record");
         }
-        if (c->in_check.cap < want) {
-            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
-            HIP_TRY(c, c->in_check.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
-        }
+        B.closed = true;
     }
-    launch_bam_decode(st, B.bytes[w].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
-                      c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p);
-    if (tail)  // the incomplete record goes in front of the next window
-        HIP_TRY(c, hipMemcpyAsync(B.bytes[w ^ 1u].p + kBamSlack - tail, B.bytes[w].p + stop, tail, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(c, hipGetLastError());
-    B.carry_bytes = tail;
-    ++B.windows;
-    c->n_pushed += n_rec;
-    c->rec = DeviceRecords();
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    if (marked) {
-        c->rec.marked = true;
-    } else {
-        c->rec.key = c->in_key.p;
-        c->rec.flag = c->in_flag.p;
-        c->rec.check = c->in_check.p;
-    }
-    if (n_records) *n_records = n_rec;
+    if (n_records) *n_records = total;
     return SLIMM_OK;
 }
 

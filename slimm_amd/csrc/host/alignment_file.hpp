@@ -75,6 +75,8 @@ public:
     // are then found and decoded on the device).  Returns the bytes written (whole BGZF blocks, at most `cap`), 0 at the
     // end of the file, -1 + error() on a format error.  Not to be mixed with read_batch / read_into afterwards.
     long read_raw(uint8_t* dst, size_t cap);
+    // after a read_raw that returned bytes: nothing will follow them (false may also mean "not known yet")
+    bool raw_exhausted() const { return raw_stage_ == 2 ? eof_ : (raw_stage_ == 1 && eof_ && raw_off_ >= spare_.size()); }
 
 private:
     size_t raw_off_ = 0;
@@ -135,6 +137,7 @@ private:
     std::string next_err_;
     Bytes cbuf_;
     size_t cfill_ = 0, cdone_ = 0;  // compressed bytes waiting in cbuf_ / of them consumed by the last call
+    size_t cstart_ = 0;             // read_raw: where the unconsumed compressed bytes start in cbuf_ (moved to the front only now and then)
     struct Block {
         size_t coff, clen, ooff;  // compressed bytes in cbuf_, output offset in buf_
         uint32_t isize, crc;

@@ -405,6 +405,8 @@ uint32_t slimm_host_avg_read_length(const uint32_t* l_seq, uint64_t n, uint32_t 
 float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q);
 /* Bin of one record (src/slimm.hpp:200-201). */
 uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width);
+/* hipDeviceReset() of the process's devices: for a host about to leave the process.  Contexts must not be used afterwards. */
+int slimm_shutdown(void);
 /* Library build info. */
 /* ---- Several GPUs in one process (slimm_amd/csrc/group.hip): a group of contexts, one per device, used like one.
  * Records are dealt to the members by read as they are pushed (name-grouped streams: contiguous stretches of the file cut

@@ -405,6 +405,17 @@ int slimm_warm_up(int device) {
     return SLIMM_OK;
 }
 
+// For a process about to leave: hipDeviceReset() of every device the calling process used -- queues and memory go back in
+// one step instead of at the kernel driver's pace after exit (a host that ends with _exit measures which is faster).
+int slimm_shutdown(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return SLIMM_E_HIP;
+    int rc = SLIMM_OK;
+    for (int d = 0; d < n; ++d)
+        if (hipSetDevice(d) != hipSuccess || hipDeviceReset() != hipSuccess) rc = SLIMM_E_HIP;
+    return rc;
+}
+
 const char* slimm_version(void) { return "slimm_hip 0.1 (gfx950)"; }
 
 const char* slimm_last_error(const slimm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

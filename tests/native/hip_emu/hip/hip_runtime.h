@@ -68,6 +68,7 @@ hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamQuery(hipStream_t s);
 hipError_t hipDeviceSynchronize();
+static inline hipError_t hipDeviceReset() { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);

@@ -143,4 +143,5 @@ def test_bench_multi_process_control_flow_on_one_gpu(nproc):
     for k in ("reads", "targets", "bins", "profile_rows", "profile_sha1"):
         assert many["config"][k] == one["config"][k], k
     assert many["config"]["exchange"] == ("summary" if nproc == 2 else "sliced")
-    assert many["value"] > 0 and many["roofline"]["kernel"] == "k_front"
+    # (which kernel the shared GPU makes the longest is no property of the code: two processes time-slice one device)
+    assert many["value"] > 0 and many["roofline"]["kernel"].startswith("k_") and many["roofline"]["frac"] > 0

@@ -108,6 +108,7 @@ SLIMM_FORWARD(int, slimm_push_records_packed, (slimm_ctx* a, const uint64_t* b, 
 SLIMM_FORWARD(int, slimm_push_bam_bytes, (slimm_ctx* a, const uint8_t* b, uint64_t c, int d, uint64_t* e), (a, b, c, d, e))
 SLIMM_FORWARD(int, slimm_pin_host_buffer, (slimm_ctx* a, const void* b, uint64_t c), (a, b, c))
 SLIMM_FORWARD(int, slimm_shutdown, (), ())
+SLIMM_FORWARD(int, slimm_reset, (slimm_ctx* a), (a))
 SLIMM_FORWARD(int, slimm_check_grouping, (slimm_ctx* a, uint64_t* b), (a, b))
 SLIMM_FORWARD(int, slimm_keep_bins, (slimm_ctx* a, int b), (a, b))
 SLIMM_FORWARD(int, slimm_analyze_alignments, (slimm_ctx* a), (a))
@@ -427,7 +428,15 @@ struct RecordPump {
     // record boundaries, reads the fields and compares / hashes the names (slimm_amd/csrc/bam_decode.hip).  The host
     // walked every inflated byte three times for that.  SLIMM_CLI_HOST_DECODE=1 keeps the host decoder.
     const bool raw;
-    static constexpr size_t kRawCap = 192u << 20;   // bytes per window buffer
+    // bytes per window buffer (SLIMM_CLI_WINDOW_MB: tests make windows smaller than a record)
+    static size_t raw_cap() {
+        static const size_t cap = [] {
+            const char* e = getenv("SLIMM_CLI_WINDOW_MB");
+            const long mb = e ? atol(e) : 0;
+            return (mb > 0 ? static_cast<size_t>(mb) : 192u) << 20;
+        }();
+        return cap;
+    }
     static constexpr unsigned kRawBuffers = 4;
     struct RawWindow {
         unsigned which = 0;
@@ -438,14 +447,14 @@ struct RecordPump {
     // pages to give back when the process leaves -- a quarter second of a one-second run over the four buffers)
     struct RawUnmap {
         void operator()(uint8_t* p) const {
-            if (p) munmap(p, kRawCap);
+            if (p) munmap(p, raw_cap());
         }
     };
     std::unique_ptr<uint8_t, RawUnmap> raw_buf[kRawBuffers];
     static uint8_t* raw_map() {
-        void* p = mmap(nullptr, kRawCap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        void* p = mmap(nullptr, raw_cap(), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (p == MAP_FAILED) return nullptr;
-        (void)madvise(p, kRawCap, MADV_HUGEPAGE);
+        (void)madvise(p, raw_cap(), MADV_HUGEPAGE);
         return static_cast<uint8_t*>(p);
     }
     std::deque<RawWindow> raw_ready;   // inflated, waiting to be pushed
@@ -489,7 +498,7 @@ struct RecordPump {
                 return;
             }
             auto t1 = std::chrono::steady_clock::now();
-            const long n = bam.read_raw(raw_buf[w].get(), kRawCap);
+            const long n = bam.read_raw(raw_buf[w].get(), raw_cap());
             decode_ms += ms(t1, std::chrono::steady_clock::now());
             {
                 std::lock_guard<std::mutex> g(mu);
@@ -524,7 +533,7 @@ struct RecordPump {
             auto t1 = std::chrono::steady_clock::now();
             if (w.n > 0) {
                 if (!pinned[w.which]) {
-                    (void)slimm_pin_host_buffer(c, raw_buf[w.which].get(), kRawCap);  // (pageable memory still works)
+                    (void)slimm_pin_host_buffer(c, raw_buf[w.which].get(), raw_cap());  // (pageable memory still works)
                     pinned[w.which] = true;
                 }
                 rc = slimm_push_bam_bytes(c, raw_buf[w.which].get(), static_cast<uint64_t>(w.n), w.last ? 1 : 0, &got);
@@ -945,12 +954,27 @@ bool get_profiles(Session& S, size_t file_index) {
             fprintf(stderr, "[trace] decode %.2f ms (on its own thread, from the moment the file was open), waiting for staging sets %.2f ms\n",
                     pump.decode_ms, pump.wait_ms);
         trace.mark("rest of read + decode + push");
-        if (!pushed) {
+        long n = pump.read_rc;
+        bool ok = pushed;
+        if (!pushed && pump.raw && n >= 0 && strstr(slimm_last_error(ctx), "decode this file on the host")) {
+            // a record longer than the device decoder's carry (16 MiB): this file goes through the host decoder after all
+            std::cerr << "(a record longer than 16 MiB: decoding on the host) ";
+            CHECK(ctx, slimm_reset(ctx));
+            bam.close();
+            if (!bam.open(path)) {
+                std::cerr << bam.error() << "\n";
+                slimm_destroy(ctx);
+                return false;
+            }
+            RecordPump again(bam, check_words, false);
+            ok = again.attach(ctx) && again.finish();
+            n = again.read_rc;
+        }
+        if (!ok) {
             std::cerr << "slimm: pushing records: " << slimm_last_error(ctx) << "\n";
             slimm_destroy(ctx);
             return false;
         }
-        const long n = pump.read_rc;
         if (n < 0) {
             std::cerr << bam.error() << "\n";
             slimm_destroy(ctx);

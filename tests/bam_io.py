@@ -40,11 +40,12 @@ def _bgzf_block(data: bytes) -> bytes:
             + comp + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data)))
 
 
-def bam_record_bytes(records, read_len=100, irregular_seed=None) -> bytes:
+def bam_record_bytes(records, read_len=100, irregular_seed=None, l_seq_of=None) -> bytes:
     """The alignment records of a BAM file as they follow its header (SAM/BAM specification 4.2), concatenated:
     block_size | refID | pos | l_read_name | mapq | bin | n_cigar_op | flag | l_seq | next_refID | next_pos | tlen |
     read_name | cigar | seq | qual (| tags).  irregular_seed: record sizes vary (sequence lengths 0 .. 3 x read_len, one to
-    four CIGAR operations, a few optional tag bytes), so that record boundaries fall anywhere."""
+    four CIGAR operations, a few optional tag bytes), so that record boundaries fall anywhere.  l_seq_of: {record index:
+    sequence length} for single records of another size."""
     q = qnames_of(records)
     rng = np.random.default_rng(irregular_seed) if irregular_seed is not None else None
     out = bytearray()
@@ -53,7 +54,10 @@ def bam_record_bytes(records, read_len=100, irregular_seed=None) -> bytes:
     cigar = struct.pack("<I", (read_len << 4) | 0)
     for i in range(len(records)):
         name = q[i].encode() + b"\x00"
-        if rng is None:
+        if l_seq_of and i in l_seq_of:
+            l_seq = int(l_seq_of[i])
+            cg, sq, ql, tags = struct.pack("<I", (l_seq << 4) | 0), bytes([0x11]) * ((l_seq + 1) // 2), bytes([0x28]) * l_seq, b""
+        elif rng is None:
             l_seq, cg, sq, ql, tags = read_len, cigar, seq, qual, b""
         else:
             l_seq = int(rng.integers(0, 3 * read_len + 1))
@@ -68,14 +72,15 @@ def bam_record_bytes(records, read_len=100, irregular_seed=None) -> bytes:
     return bytes(out)
 
 
-def write_bam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query", irregular_seed=None):
+def write_bam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query", irregular_seed=None,
+              l_seq_of=None):
     text = sam_header(ref_names, ref_len, hd).encode()
     out = bytearray()
     out += b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names))
     for n, l in zip(ref_names, ref_len):
         nb = n.encode() + b"\x00"
         out += struct.pack("<i", len(nb)) + nb + struct.pack("<i", int(l))
-    out += bam_record_bytes(records, read_len, irregular_seed)
+    out += bam_record_bytes(records, read_len, irregular_seed, l_seq_of)
     with open(path, "wb") as f:
         for s in range(0, len(out), 0xff00):
             f.write(_bgzf_block(bytes(out[s:s + 0xff00])))

@@ -26,8 +26,8 @@ def with_names(w: Workload) -> Workload:
                     w.avg_read_len, w.options, w.name)
 
 
-def run_cli(args):
-    r = subprocess.run([CLI] + args, capture_output=True, text=True)
+def run_cli(args, env=None):
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stderr
 
@@ -290,3 +290,65 @@ def test_cli_devices_writes_raw_and_coverage_outputs_from_all_reduced_bins(tmp_p
     assert "3 devices (copy collectives)" in err
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
     check_outputs(out, "sample", o)
+
+
+def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, monkeypatch):
+    """BAM input on one GPU: the command inflates, the DEVICE finds and decodes the records (slimm_push_bam_bytes); with
+    SLIMM_CLI_HOST_DECODE=1 the host decoder of rounds 1 - 3 does.  Same files either way, for a name-grouped file with
+    and for the same records in no particular order (key + check word hashed on the device)."""
+    w = with_names(make_workload(CONFIGS["config2"], seed=47, n_records=300_000))
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    perm = np.random.default_rng(3).permutation(len(w.records))
+    shuffled = w.records.take(perm)
+    shuffled = Records(shuffled.read_key, shuffled.flag, shuffled.ref_id, shuffled.begin_pos, [w.records.qname[i] for i in perm])
+    o_sh = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, shuffled, w.avg_read_len, want_raw=True, want_cov=True)
+    cases = (("grouped", w.records, "@HD\tVN:1.6\tSO:unsorted\tGO:query", o), ("anyorder", shuffled, "@HD\tVN:1.6\tSO:unsorted", o_sh))
+    for stem, rec, hd, want in cases:
+        inp = str(tmp_path / (stem + ".bam"))
+        write_bam(inp, w.ref_names, w.ref_len, rec, read_len=w.avg_read_len, hd=hd)
+        outs = []
+        for host in (False, True):
+            if host:
+                monkeypatch.setenv("SLIMM_CLI_HOST_DECODE", "1")
+            else:
+                monkeypatch.delenv("SLIMM_CLI_HOST_DECODE", raising=False)
+            out = str(tmp_path / f"{stem}_{int(host)}") + "/"
+            os.makedirs(out)
+            err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp], env=dict(os.environ, SLIMM_CLI_TRACE="1"))
+            assert ("device decode" in err) == (not host)
+            outs.append({f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))})
+        assert outs[0] == outs[1] and len(outs[0]) == 5
+        check_outputs(str(tmp_path / f"{stem}_0") + "/", stem, want)
+
+
+def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_path):
+    """The device decoder carries an incomplete record of up to 16 MiB from one window to the next; a file with a longer
+    one across windows (a sequence of 16 M bases: 24 MB) is decoded on the host after all -- same outputs as the oracle's.  With
+    windows of 1 MiB and records of 200 bytes the device decoder also sees hundreds of window changes."""
+    w = with_names(make_workload(CONFIGS["config1"], seed=48, n_records=3_000))
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "sample.bam")
+    write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, l_seq_of={1500: 16_000_000})
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    # (windows of 4 MiB, so that the record spans several: the command's own are 192 MiB)
+    err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp], env=dict(os.environ, SLIMM_CLI_WINDOW_MB="4"))
+    assert "decoding on the host" in err
+    # (the command samples its average read length from the file, src/misc.hpp:509-522: the long record is in the sample)
+    avg = (w.avg_read_len * (len(w.records) - 1) + 16_000_000) // len(w.records)
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, avg, want_raw=True, want_cov=True)
+    check_outputs(out, "sample", o)
+    big = with_names(make_workload(CONFIGS["config2"], seed=49, n_records=1_000_000))
+    db2 = str(tmp_path / "db2.sldb")
+    write_sldb(db2, big.taxonomy)
+    inp2 = str(tmp_path / "many.bam")
+    write_bam(inp2, big.ref_names, big.ref_len, big.records, read_len=big.avg_read_len)
+    out2 = str(tmp_path / "out2") + "/"
+    os.makedirs(out2)
+    err = run_cli(["-w", str(big.options.bin_width), "-o", out2, "-ro", db2, inp2], env=dict(os.environ, SLIMM_CLI_WINDOW_MB="1", SLIMM_CLI_TRACE="1"))
+    assert "device decode" in err and "decoding on the host" not in err
+    o2 = Oracle(big.taxonomy, big.options).run(big.ref_names, big.ref_len, big.records, big.avg_read_len, want_raw=True, want_cov=False)
+    check_outputs(out2, "many", o2, coverage=False)

@@ -101,3 +101,47 @@ def test_malformed_and_truncated_streams_are_errors():
     assert s.push_bam_bytes(bytes(data), window=123_457) == len(w.records)
     assert s.get_profiles() is not None
     assert_matches_oracle(s, run_workload(w, use_qnames=True))
+
+
+def test_a_header_look_alike_at_a_piece_boundary_is_verified_away():
+    """The piece's first record is GUESSED from the bytes (a plausible header whose two successors are plausible too).  A
+    record whose quality string carries three well-formed little records right where a 16 KB piece begins is
+    such a guess (the third piece's) -- a wrong one: the chain from the piece before does not end there (k_bam_verify walks the piece again
+    from the true start)."""
+    import struct
+    w = _named(make_workload(CONFIGS["config1"], seed=36, n_records=600))
+    r = w.records
+    head = bam_record_bytes(Records(r.read_key[:20], r.flag[:20], r.ref_id[:20], r.begin_pos[:20], r.qname[:20]))
+    rest = bam_record_bytes(Records(r.read_key[21:], r.flag[21:], r.ref_id[21:], r.begin_pos[21:], r.qname[21:]))
+    fake = bam_record_bytes(Records(r.read_key[:3], r.flag[:3], r.ref_id[:3], r.begin_pos[:3], ["fake0", "fake1", "fake2"]))
+    # record 20, by hand: a sequence of 30 000 bases whose qualities hold the look-alikes at stream offset 32 768
+    name = r.qname[20].encode() + b"\x00"
+    l_seq = 30_000
+    fixed = struct.pack("<iiBBHHHIiii", int(r.ref_id[20]), int(r.begin_pos[20]), len(name), 255, 4680, 1, int(r.flag[20]), l_seq, -1, -1, 0)
+    cigar = struct.pack("<I", (l_seq << 4) | 0)
+    seq = bytes([0x11] * ((l_seq + 1) // 2))
+    qual_at = len(head) + 4 + len(fixed) + len(name) + len(cigar) + len(seq)
+    assert qual_at < 32_768 < qual_at + l_seq - len(fake)
+    qual = bytearray([0x20] * l_seq)
+    qual[32_768 - qual_at:32_768 - qual_at + len(fake)] = fake
+    body = fixed + name + cigar + seq + bytes(qual)
+    data = head + struct.pack("<i", len(body)) + body + rest
+    o = run_workload(w, use_qnames=True)
+    for window in (0, 40_000):
+        s = Slimm.for_workload(w, device=0)
+        assert s.push_bam_bytes(data, window=window) == len(r)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+        s.close()
+
+
+def test_extreme_names_and_a_tiny_reference_set():
+    """Names of 1 and of 254 characters, an empty name (l_read_name = 1), four reference sequences, records without one."""
+    w = make_workload(SynthConfig("few", 3_000, 4, 1.5, bin_width=100, len_lo=5_000, len_hi=6_000, present_frac=1.0), seed=37)
+    r = w.records
+    ids = np.unique(r.read_key, return_inverse=True)[1]
+    names = ["" if i == 5 else ("y" if i == 6 else ("n%d_" % i) + "z" * (254 - len("n%d_" % i) if i % 7 == 0 else i % 40)) for i in ids.tolist()]
+    w = Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, names), w.avg_read_len,
+                 w.options, "names", grouped=True)
+    _check(w, True, 33_333, irregular=11)
+    _check(Workload(w.ref_names, w.ref_len, w.taxonomy, w.records, w.avg_read_len, w.options, "names-any", grouped=False), False, 0)

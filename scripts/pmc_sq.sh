@@ -4,11 +4,19 @@ export TMPDIR=/tmp; R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd /tmp
 rocprofv3 --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS} --kernel-trace --output-format csv -d $OUT -o a -- python3 $R/bench.py --steps 2 --warmup 1 --quick "$@" > /dev/null 2>$OUT/err_a.txt
 python3 - <<PY
 import csv, collections, glob
+def kname(full):
+    s=full.replace('void ','').replace('slimm::','').replace('(anonymous namespace)::','')
+    depth=0
+    for i,c in enumerate(s):
+        if c=='<': depth+=1
+        elif c=='>': depth-=1
+        elif c=='(' and depth==0: return s[:i]
+    return s
 for f in sorted(glob.glob("$OUT/*_counter_collection.csv")):
     rows=list(csv.DictReader(open(f)))
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.defaultdict(set)
     for r in rows:
-        k=r["Kernel_Name"].split("(")[0].replace("void slimm::","").replace("slimm::","")[:28]
+        k=kname(r["Kernel_Name"])
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     with open("$OUT/summary.txt","w") as o:
         for k,v in agg.items():

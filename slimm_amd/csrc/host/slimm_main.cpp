@@ -151,6 +151,7 @@ struct Options {  // arg_options, reference src/slimm.hpp:49-87
     std::vector<int> devices;  // --devices a,b,...: several GPUs, one process (slimm_group_*)
     int order = -1;  // -1: from the @HD line
     bool dump_records = false;
+    bool dump_raw = false;   // --dump-raw: the inflated record bytes (AlignmentFile::read_raw), for reader tests without a GPU
 };
 
 const char* kRankList[] = {"strains", "species", "genus", "family", "order", "class", "phylum", "superkingdom"};
@@ -214,7 +215,7 @@ void usage() {
                  "  -ro, --raw-output             write raw reference statistics\n"
                  "  -co, --coverage-output        write raw coverage statistics\n"
                  "  -v,  --verbose\n"
-                 "       --device N | --devices N,M,... | --query-grouped | --any-order | --dump-records\n";
+                 "       --device N | --devices N,M,... | --query-grouped | --any-order | --dump-records | --dump-raw\n";
 }
 
 // 0 ok, 1 error, 2 help
@@ -293,6 +294,8 @@ int parse(int argc, char** argv, Options& o) {
             o.order = SLIMM_ORDER_ANY;
         } else if (a == "--dump-records") {
             o.dump_records = true;
+        } else if (a == "--dump-raw") {
+            o.dump_records = o.dump_raw = true;
         } else if (!a.empty() && a[0] == '-' && a.size() > 1) {
             std::cerr << "slimm: unknown option " << a << "\n";
             return 1;
@@ -318,7 +321,31 @@ int parse(int argc, char** argv, Options& o) {
     return 0;
 }
 
+// --dump-raw: what the device decoder is fed -- the inflated bytes behind the BAM header, in windows of
+// SLIMM_CLI_WINDOW_MB (default 1) MiB -- to stdout, the window sizes to stderr
+int dump_raw(const Options& o) {
+    AlignmentFile f;
+    if (!f.open(o.input_path)) {
+        std::cerr << f.error() << "\n";
+        return 1;
+    }
+    const char* e = getenv("SLIMM_CLI_WINDOW_MB");
+    const size_t cap = static_cast<size_t>(std::max(1L, e ? atol(e) : 1L)) << 20;
+    std::vector<uint8_t> buf(cap);
+    long n;
+    while ((n = f.read_raw(buf.data(), cap)) > 0) {
+        std::cerr << "window\t" << n << "\t" << (f.raw_exhausted() ? "last" : "more") << "\n";
+        if (fwrite(buf.data(), 1, static_cast<size_t>(n), stdout) != static_cast<size_t>(n)) return 1;
+    }
+    if (n < 0) {
+        std::cerr << f.error() << "\n";
+        return 1;
+    }
+    return 0;
+}
+
 int dump_records(const Options& o) {
+    if (o.dump_raw) return dump_raw(o);
     AlignmentFile f;
     if (!f.open(o.input_path)) {
         std::cerr << f.error() << "\n";

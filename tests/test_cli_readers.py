@@ -175,3 +175,32 @@ def test_adjacent_names_with_equal_hashes_stay_two_reads(tmp_path, writer):
     assert len({keys[0], keys[1], keys[3], keys[7]}) == 4
     # without the name comparison the two names WOULD share a key: the construction is a real collision
     assert int(keys[3]) == (int(keys[1]) + 1) % (1 << 62) and keys[6] == keys[1]
+
+
+@pytest.mark.parametrize("window_mb", [1, 3, 64])
+@pytest.mark.parametrize("mmap", [True, False])
+def test_raw_windows_are_the_inflated_record_bytes(tmp_path, window_mb, mmap):
+    """AlignmentFile::read_raw (what `slimm` feeds the device decoder, slimm_push_bam_bytes): the windows, concatenated,
+    are exactly the alignment-record bytes behind the BAM header -- whatever the window size, with the compressed bytes
+    read in place from a mapping of the file or through buffered reads; the last window announces itself or an empty
+    read follows it."""
+    from tests.bam_io import bam_record_bytes
+    w = make_workload(CONFIGS["config2"], seed=51, n_records=40_000)
+    p = str(tmp_path / "x.bam")
+    write_bam(p, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, irregular_seed=4)
+    want = bam_record_bytes(w.records, read_len=w.avg_read_len, irregular_seed=4)
+    env = dict(os.environ, SLIMM_CLI_WINDOW_MB=str(window_mb))
+    if not mmap:
+        env["SLIMM_NO_MMAP"] = "1"
+    r = subprocess.run([CLI, "--dump-raw", p], capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout == want
+    sizes = [int(ln.split("\t")[1]) for ln in r.stderr.decode().splitlines() if ln.startswith("window")]
+    assert sum(sizes) == len(want) and max(sizes) <= window_mb << 20
+    assert len(sizes) >= (len(want) + (window_mb << 20) - 1) // (window_mb << 20)
+    # a truncated file is an error, not a short stream
+    blob = open(p, "rb").read()
+    bad = str(tmp_path / "cut.bam")
+    open(bad, "wb").write(blob[:len(blob) * 2 // 3])
+    r = subprocess.run([CLI, "--dump-raw", bad], capture_output=True, env=env)
+    assert r.returncode != 0 and b"truncated" in r.stderr

@@ -776,6 +776,9 @@ def test_full_size_config2_bit_exact():
     s = run_gpu(w)
     _full_size_invariants(w, s, permutation=True)
     assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
+    # ... and EVERYTHING against the oracle itself at this size (one thread, the reference's containers: a few seconds for
+    # 10 M records): the propagated per-taxon counts and children of src/slimm.hpp:560-610, the cut-offs, the profile rows
+    assert_matches_oracle(s, run_workload(w, use_qnames=False))
 
 
 def test_full_size_config2_and_5_as_run_marked_records():
@@ -806,6 +809,9 @@ def test_full_size_config3_bit_exact():
     d = dense_mt_run(w, want_bins=True)
     assert_equals_dense_mt(s, d)
     profile = s.write_abundance()
+    # the oracle itself on all 100 M records (one thread, ~40 s): what the dense restatement does not have -- the propagated
+    # per-taxon counts and children (src/slimm.hpp:560-610), the cut-offs, the abundances, the profile rows
+    assert_matches_oracle(s, run_workload(w, use_qnames=False, collect_bins=False), bins=False)
     s.close()
     # packed, pushed from host memory in batches
     w61 = _mask61(w)

@@ -476,7 +476,7 @@ def main():
         passes, width, bits, grid = group_plan(nk)
         out = {"value": round(nk / (ela / steps) / 1e6, 3), "unit": "M records/s", "ms_per_step": round(ela / steps * 1e3, 4),
                "steps": steps, "records": what, "same_profile_as_the_grouped_stream": bool(profa == grouped_profile),
-               "plan": {"passes": passes, "bits_per_pass": width, "bucket_bits": bits, "workgroups": grid},
+               "plan": {"passes": passes, "widest_digit_bits": width, "bucket_bits": bits, "workgroups": grid},
                "grouping": {"kernels": "k_group_count + k_group_scan + k_group_scatter (per pass) + k_group_finish",
                             "ms_per_step": round(g_ms, 4), "bytes_per_step": int(g_bytes),
                             "bytes_model": f"first pass {rec_bytes - 4} N (count) + {rec_bytes} N + 16 V (scatter), every other pass "

@@ -1323,7 +1323,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
             }
             {
                 KernelTimer t(c, K_GROUP_SCAN);
-                launch_group_scan(st, j);
+                launch_group_scan(st, j, pass);
             }
             {
                 KernelTimer t(c, K_GROUP_SCATTER);

@@ -720,13 +720,35 @@ GroupPlan group_plan(uint32_t n_records) {
     // moves half the stream once more: 9.6 ms against 2.0 ms with 2^30 buckets, for 1.9 ms more in the passes.
     uint32_t b = 8;
     while (b < 32u && (1ull << b) < n_records) ++b;
-    if (const uint32_t o = g_env_u32("SLIMM_GROUP_BITS")) b = std::min(o, 32u);
-    uint32_t wmax = kGroupDefaultBits;
-    if (const uint32_t o = g_env_u32("SLIMM_GROUP_WIDTH")) wmax = std::min(o, kGroupMaxBits);
-    g.passes = (b + wmax - 1u) / wmax;
-    g.width = (b + g.passes - 1u) / g.passes;
-    while (g.passes * g.width > 32u) --g.width;  // (the hash has 32 bits)
-    g.bits = g.passes * g.width;
+    const uint32_t forced_bits = g_env_u32("SLIMM_GROUP_BITS");
+    const uint32_t forced_width = g_env_u32("SLIMM_GROUP_WIDTH");
+    // A pass costs the same up to 8 bits per digit and more beyond (a round's records of one digit get fewer, the open
+    // write frontiers more): measured per pass at 100 M / 1 B records, relative to 8 bits: 9 bits 1.12 - 1.2, 10 bits 1.28,
+    // 11 bits 1.6; the count + scan of a pass 0.21.  One bit more than the records need halves the finish's moves (100 M
+    // records: 607 -> 206 us).  The cheapest split of b or b + 1 bits into passes of 6 .. 11 bits, as even as it goes.
+    static const float kCost[12] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1.15f, 1.28f, 1.6f};
+    float best = 1e30f;
+    for (uint32_t bits = (forced_bits ? std::min(forced_bits, 32u) : b); bits <= (forced_bits ? std::min(forced_bits, 32u) : std::min(b + 1u, 32u));
+         ++bits) {
+        const uint32_t wcap = forced_width ? std::min(forced_width, kGroupMaxBits) : kGroupMaxBits;
+        for (uint32_t P = (bits + wcap - 1u) / wcap; P <= kGroupMaxPasses; ++P) {
+            const uint32_t lo = bits / P, hi = lo + (bits % P ? 1u : 0u);
+            if (hi > wcap) continue;
+            // (the finish: cheap once there are 1.6 buckets per record -- 10 M records in 2^24 buckets: 25 us = 0.27 of a pass)
+            const bool roomy = forced_bits || (1ull << bits) * 10ull >= static_cast<uint64_t>(n_records) * 16ull;
+            float cost = 0.21f * static_cast<float>(P) + (roomy ? 0.22f : 0.45f);
+            for (uint32_t p = 0; p < P; ++p) cost += kCost[p < bits % P ? hi : std::max(lo, 1u)];
+            if (forced_width && !forced_bits && P != (bits + wcap - 1u) / wcap) break;  // (a forced width: the fewest passes it allows)
+            if (cost < best) {
+                best = cost;
+                g.passes = P;
+                g.bits = bits;
+                g.width = hi;
+                for (uint32_t p = 0; p < kGroupMaxPasses; ++p) g.widths[p] = p < P ? (p < bits % P ? hi : lo) : 0u;
+            }
+            if (lo <= 6u) break;  // (narrower passes only add passes)
+        }
+    }
     g.grid = kGroupMaxGrid;
     if (const uint32_t o = g_env_u32("SLIMM_GROUP_GRID")) g.grid = std::min(o, kGroupMaxGrid);
     return g;
@@ -736,7 +758,11 @@ size_t group_hist_words(const GroupPlan& g) { return (static_cast<size_t>(g.grid
 
 // where pass `pass` writes: the arrays alternate and the last pass ends in job.a
 static const GroupArrays& gb_dest(const GroupJob& j, uint32_t pass) { return ((j.plan.passes - 1u - pass) & 1u) ? j.t : j.a; }
-static uint32_t gb_shift(const GroupJob& j, uint32_t pass) { return 32u - j.plan.bits + pass * j.plan.width; }
+static uint32_t gb_shift(const GroupJob& j, uint32_t pass) {
+    uint32_t below = 0;
+    for (uint32_t p = 0; p < pass; ++p) below += j.plan.widths[p];
+    return 32u - j.plan.bits + below;
+}
 template <bool kPacked>
 static GbRaw<kPacked> gb_raw(const GroupJob& j) {
     GbRaw<kPacked> src;
@@ -748,7 +774,7 @@ static GbRaw<kPacked> gb_raw(const GroupJob& j) {
 
 void launch_group_count(hipStream_t st, const GroupJob& j, uint32_t pass) {
     if (j.in.n == 0) return;
-    const uint32_t G = j.plan.grid, W = j.plan.width, shift = gb_shift(j, pass);
+    const uint32_t G = j.plan.grid, W = j.plan.widths[pass], shift = gb_shift(j, pass);
     if (pass == 0) {
         if (j.in.packed)
             hipLaunchKernelGGL((k_gb_count<GbRaw<true>>), dim3(G), dim3(kGBlock), 0, st, gb_raw<true>(j), j.counters, shift, W, j.hist);
@@ -761,10 +787,11 @@ void launch_group_count(hipStream_t st, const GroupJob& j, uint32_t pass) {
     }
 }
 
-void launch_group_scan(hipStream_t st, const GroupJob& j) {
+void launch_group_scan(hipStream_t st, const GroupJob& j, uint32_t pass) {
     if (j.in.n == 0) return;
-    hipLaunchKernelGGL(k_gb_scan, dim3(1u << j.plan.width), dim3(kGroupMaxGrid), 0, st, j.hist, j.plan.grid,
-                       j.hist + (static_cast<size_t>(j.plan.grid) << j.plan.width));
+    const uint32_t W = j.plan.widths[pass];
+    hipLaunchKernelGGL(k_gb_scan, dim3(1u << W), dim3(kGroupMaxGrid), 0, st, j.hist, j.plan.grid,
+                       j.hist + (static_cast<size_t>(j.plan.grid) << W));
 }
 
 // ordered rounds through LDS (k_gb_scatter<.., kStaged>): up to 10-bit digits without check words (same box, 8-bit digits:
@@ -777,7 +804,7 @@ static bool gb_staged(uint32_t width, bool has_chk) {
 
 void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass) {
     if (j.in.n == 0) return;
-    const uint32_t G = j.plan.grid, W = j.plan.width, D = 1u << W, shift = gb_shift(j, pass);
+    const uint32_t G = j.plan.grid, W = j.plan.widths[pass], D = 1u << W, shift = gb_shift(j, pass);
     const uint32_t* totals = j.hist + (static_cast<size_t>(G) << W);
     const bool has_chk = j.in.check != nullptr;
     const bool staged = gb_staged(W, has_chk);

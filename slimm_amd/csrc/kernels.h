@@ -280,8 +280,11 @@ void launch_bam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64
 constexpr uint32_t kGroupMaxBits = 11;      // widest digit of a pass
 constexpr uint32_t kGroupDefaultBits = 8;   // ... the width a plan aims for (SLIMM_GROUP_WIDTH overrides)
 constexpr uint32_t kGroupMaxGrid = 512;     // persistent workgroups of a pass = stretches of the stream = matrix columns
+constexpr uint32_t kGroupMaxPasses = 6;
 struct GroupPlan {
-    uint32_t passes = 1, width = 8, bits = 8;  // bits = passes * width hash bits make a bucket
+    uint32_t passes = 1, bits = 8;              // bits = the sum of the passes' widths: hash bits that make a bucket
+    uint32_t widths[kGroupMaxPasses] = {8, 0, 0, 0, 0, 0};   // pass p sorts by widths[p] bits; the first pass takes the lowest
+    uint32_t width = 8;                         // the widest pass (sizes the count matrix)
     uint32_t grid = kGroupMaxGrid;
 };
 GroupPlan group_plan(uint32_t n_records);
@@ -303,7 +306,7 @@ struct GroupJob {
 };
 // pass p: count -> scan -> scatter, p = 0 .. plan.passes - 1; then the finish
 void launch_group_count(hipStream_t st, const GroupJob& j, uint32_t pass);
-void launch_group_scan(hipStream_t st, const GroupJob& j);
+void launch_group_scan(hipStream_t st, const GroupJob& j, uint32_t pass);
 void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass);
 void launch_group_finish(hipStream_t st, const GroupJob& j);
 int group_init();  // once per process and device: dynamic LDS attributes; 0 = ok

@@ -85,7 +85,8 @@ __device__ uint64_t bam_walk(const uint8_t* b, uint64_t from, uint64_t hi, uint6
             bad = true;
             break;
         }
-        offs[n++] = static_cast<uint32_t>(p);
+        if (offs) offs[n] = static_cast<uint32_t>(p);
+        ++n;
         p += 4 + static_cast<uint64_t>(bs);
     }
     count = n;
@@ -136,48 +137,60 @@ __global__ __launch_bounds__(1024) void k_bam_verify(const uint8_t* __restrict__
     for (uint32_t c = 1 + threadIdx.x; c < n_pieces; c += 1024u) wrong += pieces[c].guess != pieces[c - 1].stop ? 1u : 0u;
     if (wrong) atomicAdd(&s_wrong, wrong);
     __syncthreads();
-    if (s_wrong == 0 || threadIdx.x != 0) return;
-    // the rare path, one thread: the chain of true starts from the first piece on
-    uint64_t cur = pieces[0].stop;
+    if (s_wrong == 0 || threadIdx.x >= 64u) return;
+    // The other path, ONE WAVE: the chain of true starts from the first piece on.  The wave takes 64 pieces at a time (one
+    // coalesced load instead of a round trip per piece) and goes through them in order with wave-uniform state: a piece
+    // whose guess is where the chain arrives is left as it is; any other is walked again from there (every lane walks,
+    // lane 0 notes the offsets), or -- the chain being behind the piece already: a record longer than a piece -- simply
+    // holds no record.  Files of long reads, where that is every piece, therefore cost a few scalar instructions per piece.
+    const uint32_t lane = threadIdx.x;
+    uint32_t cur = pieces[0].stop;
     bool stuck = (pieces[0].flags & kBamPieceBad) != 0;  // (nothing behind a malformed record can be trusted)
     bool ended = !stuck && n_pieces > 1 && cur < lo + kBamPiece;  // the window's incomplete last record starts in piece 0
-    for (uint32_t c = 1; c < n_pieces; ++c) {
-        if (ended) {
-            BamPiece e = pieces[c];
-            e.count = 0;
-            e.stop = static_cast<uint32_t>(cur);
-            e.guess = static_cast<uint32_t>(cur);
-            e.flags = 0;
-            pieces[c] = e;
-            continue;
-        }
-        BamPiece pc = pieces[c];
-        const uint64_t plo = lo + static_cast<uint64_t>(c) * kBamPiece;
-        const uint64_t phi = (c + 1 == n_pieces) ? end : plo + kBamPiece;
-        if (stuck) {
-            pc.count = 0;
-            pc.stop = static_cast<uint32_t>(cur);
-            pc.guess = static_cast<uint32_t>(cur);
-            pc.flags = kBamPieceBad;
-        } else if (pc.guess != static_cast<uint32_t>(cur)) {
-            pc.guess = static_cast<uint32_t>(cur);
-            pc.flags = 0;
-            if (cur < phi) {
-                bool bad;
-                uint32_t n;
-                pc.stop = static_cast<uint32_t>(bam_walk(b, cur, phi, end, offs + static_cast<size_t>(c) * kBamSlots, kBamSlots, n, bad));
-                pc.count = n;
-                if (bad) pc.flags = kBamPieceBad;
-            } else {  // (a record that runs over the whole piece)
-                pc.count = 0;
-                pc.stop = static_cast<uint32_t>(cur);
+    for (uint32_t c0 = 1; c0 < n_pieces; c0 += 64u) {
+        const uint32_t c = c0 + lane;
+        BamPiece pc = pieces[min(c, n_pieces - 1u)];
+        bool touched = false;
+        const uint32_t n_here = min(64u, n_pieces - c0);
+        for (uint32_t l = 0; l < n_here; ++l) {
+            const uint32_t ci = c0 + l;
+            const uint32_t guess = __builtin_amdgcn_readlane(pc.guess, l), stop = __builtin_amdgcn_readlane(pc.stop, l);
+            const uint32_t flags = __builtin_amdgcn_readlane(pc.flags, l);
+            const uint64_t plo = lo + static_cast<uint64_t>(ci) * kBamPiece;
+            const uint64_t phi = (ci + 1 == n_pieces) ? end : plo + kBamPiece;
+            uint32_t n_guess = guess, n_stop = stop, n_count = __builtin_amdgcn_readlane(pc.count, l), n_flags = flags;
+            bool change = false;
+            if (ended) {
+                n_count = 0, n_stop = cur, n_guess = cur, n_flags = 0, change = true;
+            } else if (stuck) {
+                n_count = 0, n_stop = cur, n_guess = cur, n_flags = kBamPieceBad, change = true;
+            } else if (guess != cur) {
+                n_guess = cur, n_flags = 0, change = true;
+                if (cur < phi) {
+                    bool bad;
+                    uint32_t n;
+                    // (all lanes walk the same chain; the offsets are noted once)
+                    uint32_t* po = offs + static_cast<size_t>(ci) * kBamSlots;
+                    n_stop = static_cast<uint32_t>(bam_walk(b, cur, phi, end, lane == 0u ? po : nullptr, kBamSlots, n, bad));
+                    n_count = n;
+                    if (bad) n_flags = kBamPieceBad;
+                } else {  // (a record that runs over the whole piece)
+                    n_count = 0, n_stop = cur;
+                }
             }
+            if (change) {
+                pc.guess = lane == l ? n_guess : pc.guess;
+                pc.stop = lane == l ? n_stop : pc.stop;
+                pc.count = lane == l ? n_count : pc.count;
+                pc.flags = lane == l ? n_flags : pc.flags;
+                touched = touched | (lane == l);
+            }
+            if (n_flags & kBamPieceBad) stuck = true;
+            cur = n_stop;
+            // a walk that stopped inside its piece met the window's incomplete last record: nothing behind it is a record
+            if (!stuck && !ended && cur < phi) ended = true;
         }
-        pieces[c] = pc;
-        if (pc.flags & kBamPieceBad) stuck = true;
-        cur = pc.stop;
-        // a walk that stopped inside its piece met the window's incomplete last record: nothing behind it is a record
-        if (!stuck && cur < phi) ended = true;
+        if (touched && c < n_pieces) pieces[c] = pc;
     }
 }
 

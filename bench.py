@@ -885,6 +885,21 @@ def main():
             "kernel_timing": ("HIP events handed to the launch of " + (f"{dom_name} only in the timed steps (other kernels: warm-up "
                               "survey)" if dom_name else "every kernel in the timed steps")),
         }
+        # the figures a reader looks for first, once more at the END of the line (logs that keep only a line's tail keep these)
+        line["summary"] = {
+            "value_M_records_s": line["value"], "ms_per_step": line["ms_per_step"], "roofline_frac": roofline["frac"],
+            "roofline_kernel": roofline["kernel"], "n_gpus": world,
+            "config2_ms": (legs.get("config2") or {}).get("ms_per_step"), "config2_frac": (legs.get("config2") or {}).get("frac"),
+            "config3_ms": (legs.get("config3") or {}).get("ms_per_step"), "config3_frac": (legs.get("config3") or {}).get("frac"),
+            "config5_ms": (legs.get("config5") or {}).get("ms_per_step"), "config5_frac": (legs.get("config5") or {}).get("frac"),
+            "any_order_ms": {k: v["ms_per_step"] for k, v in (any_order or {}).items()},
+            "any_order_grouping_frac": {k: v["grouping"]["frac"] for k, v in (any_order or {}).items()},
+            "any_order_same_profile": all(v["same_profile_as_the_grouped_stream"] for v in (any_order or {}).values()) if any_order else None,
+            "parity_in_run": parity_in_run["ok"] if parity_in_run else None,
+            "value_with_push": (with_push or {}).get("value"), "run_marked_with_push": ((marked or {}).get("with_push") or {}).get("value"),
+            "cli_M_records_s": (cli or {}).get("value"), "cli_unsorted_M_records_s": ((cli or {}).get("unsorted_file") or {}).get("value"),
+            "cpu_baseline": (cpu or {}).get("value"), "cpu_baseline_mt": (cpu_mt or {}).get("value"),
+        }
         print(json.dumps(line))
         try:
             os.unlink(out_path)

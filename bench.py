@@ -158,7 +158,11 @@ def main():
                     help="do not materialise the coverage arrays in HBM (slimm_keep_bins(0): their statistics are taken from "
                          "the finished tiles in LDS either way; what `slimm` does without -co)")
     ap.add_argument("--record-order", default="grouped", choices=["grouped", "any"],
-                    help="'any' sends the same records through the device sort path (record_order = SLIMM_ORDER_ANY)")
+                    help="'any': the headline runs on the stream with the reads of every chunk INTERLEAVED at random (file order "
+                         "kept inside a read) through a context created for record_order = SLIMM_ORDER_ANY (the device-side "
+                         "grouping); --keep-file-order sends the grouped stream through that path instead (its scatter then "
+                         "writes runs of a read's records to one place: 15 - 25 %% faster, and no input of interest)")
+    ap.add_argument("--keep-file-order", action="store_true")
     ap.add_argument("--exchange", default="auto", choices=["auto", "summary", "sliced", "bins"],
                     help="multi-GPU exchange before the cut-offs: all-gather of sums + bin bitmaps (summary), all-to-all of "
                          "bitmap slices + small all-reduce (sliced), all-reduce of the bins; auto = summary up to 2 ranks")
@@ -334,6 +338,8 @@ def main():
             w_sample = make_workload(cfg, seed=args.seed, n_records=1000, sample_seed=args.seed, shard=0)
         w = w_sample
     n_rec = res.n
+    if args.record_order == "any" and not args.keep_file_order:
+        res.interleave(args.chunk_records, 7000 + 100 * rank)
     gen_s = time.time() - t0
 
     eng = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))

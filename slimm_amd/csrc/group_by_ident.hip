@@ -723,10 +723,12 @@ GroupPlan group_plan(uint32_t n_records) {
     const uint32_t forced_bits = g_env_u32("SLIMM_GROUP_BITS");
     const uint32_t forced_width = g_env_u32("SLIMM_GROUP_WIDTH");
     // A pass costs the same up to 8 bits per digit and more beyond (a round's records of one digit get fewer, the open
-    // write frontiers more): measured per pass at 100 M / 1 B records, relative to 8 bits: 9 bits 1.12 - 1.2, 10 bits 1.28,
-    // 11 bits 1.6; the count + scan of a pass 0.21.  One bit more than the records need halves the finish's moves (100 M
-    // records: 607 -> 206 us).  The cheapest split of b or b + 1 bits into passes of 6 .. 11 bits, as even as it goes.
-    static const float kCost[12] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1.15f, 1.28f, 1.6f};
+    // write frontiers more): measured per pass at 100 M / 1 B records with the reads interleaved at random, relative to
+    // 8 bits: 9 bits 1.17, 10 bits 1.41, 11 bits ~1.9; the count + scan of a pass 0.21.  One bit more than the records need
+    // halves the finish's moves (100 M records: 607 -> 206 us).  The cheapest split of b or b + 1 bits into passes of
+    // 6 .. 11 bits, as even as it goes.  (At 100 M and 1 B records three wide passes and four narrow ones come out within
+    // 3 % of each other: 6.44 - 6.80 ms and 57.4 - 58.2 ms per step.)
+    static const float kCost[12] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1.17f, 1.41f, 1.9f};
     float best = 1e30f;
     for (uint32_t bits = (forced_bits ? std::min(forced_bits, 32u) : b); bits <= (forced_bits ? std::min(forced_bits, 32u) : std::min(b + 1u, 32u));
          ++bits) {

@@ -724,11 +724,13 @@ GroupPlan group_plan(uint32_t n_records) {
     const uint32_t forced_width = g_env_u32("SLIMM_GROUP_WIDTH");
     // A pass costs the same up to 8 bits per digit and more beyond (a round's records of one digit get fewer, the open
     // write frontiers more): measured per pass at 100 M / 1 B records with the reads interleaved at random, relative to
-    // 8 bits: 9 bits 1.17, 10 bits 1.41, 11 bits ~1.9; the count + scan of a pass 0.21.  One bit more than the records need
-    // halves the finish's moves (100 M records: 607 -> 206 us).  The cheapest split of b or b + 1 bits into passes of
-    // 6 .. 11 bits, as even as it goes.  (At 100 M and 1 B records three wide passes and four narrow ones come out within
-    // 3 % of each other: 6.44 - 6.80 ms and 57.4 - 58.2 ms per step.)
-    static const float kCost[12] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1.17f, 1.41f, 1.9f};
+    // 8 bits: 9 bits 1.12 - 1.17, 10 bits 1.23 (inside the long bench process) - 1.41 (a fresh one), 11 bits ~1.9; the
+    // count + scan of a pass 0.21.  One bit more than the records need halves the finish's moves (100 M records: 600 ->
+    // 206 us).  The cheapest split of b or b + 1 bits into passes of 6 .. 11 bits, as even as it goes: 8 + 8 + 8 at 10 M
+    // records, 9 + 9 + 9 at 100 M, 10 + 10 + 10 at 1 B -- where three wide passes and four narrow ones come out within a
+    // few per cent of each other (6.44 - 6.80 ms at 100 M; 57.4 - 58.2 ms at 1 B in a fresh process, 59.3 against 64.6 ms
+    // in the bench's).
+    static const float kCost[12] = {0, 1, 1, 1, 1, 1, 1, 1, 1, 1.12f, 1.33f, 1.9f};
     float best = 1e30f;
     for (uint32_t bits = (forced_bits ? std::min(forced_bits, 32u) : b); bits <= (forced_bits ? std::min(forced_bits, 32u) : std::min(b + 1u, 32u));
          ++bits) {
@@ -738,7 +740,7 @@ GroupPlan group_plan(uint32_t n_records) {
             if (hi > wcap) continue;
             // (the finish: cheap once there are 1.6 buckets per record -- 10 M records in 2^24 buckets: 25 us = 0.27 of a pass)
             const bool roomy = forced_bits || (1ull << bits) * 10ull >= static_cast<uint64_t>(n_records) * 16ull;
-            float cost = 0.21f * static_cast<float>(P) + (roomy ? 0.22f : 0.45f);
+            float cost = 0.21f * static_cast<float>(P) + (roomy ? 0.22f : 0.40f);
             for (uint32_t p = 0; p < P; ++p) cost += kCost[p < bits % P ? hi : std::max(lo, 1u)];
             if (forced_width && !forced_bits && P != (bits + wcap - 1u) / wcap) break;  // (a forced width: the fewest passes it allows)
             if (cost < best) {

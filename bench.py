@@ -463,6 +463,7 @@ def main():
         """The records of `resk` (already interleaved) through a context created for record_order = SLIMM_ORDER_ANY: the
         step, the grouping kernels (group_by_ident.hip) under their own byte model, and whether the profile is the grouped
         stream's."""
+        torch.cuda.empty_cache()   # (the interleave's temporaries go back to the device before the engine takes its 32 B/record)
         enga = Slimm.for_workload(wk, device=local_rank, grouped=False)
         if args.no_bins:
             enga.keep_bins(False)

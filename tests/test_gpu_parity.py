@@ -859,6 +859,10 @@ def test_full_size_config5_bit_exact():
     assert st["n_records"] == 100_000_000 and st["total_bins"] > 150_000_000
     assert len(s.taxon_counts(0)) > 100   # strain-level database: LCAs at levels 0 / 1 are frequent
     assert_equals_dense_mt(s, dense_mt_run(w, want_bins=True))
+    # the oracle itself on all 100 M records (one thread): the propagated per-taxon counts and children
+    # (src/slimm.hpp:560-610), the cut-offs, the abundances and the profile rows at this size too
+    assert_matches_oracle(s, run_workload(w, use_qnames=False, collect_bins=False), bins=False)
+    s.close()
 
 
 def test_full_size_config4_one_context_and_a_group_of_four():

@@ -175,6 +175,12 @@ def main():
     ap.add_argument("--kernel-timing", choices=("dominant", "all"), default="dominant",
                     help="HIP events in the timed steps: around the dominant kernel only (default) or around every launch")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel tables to stderr")
+    ap.add_argument("--engines", type=int, default=2, choices=[1, 2],
+                    help="2 (default): the files of the timed loop go through two contexts in turn, and the host-only end of a "
+                         "file -- propagation of the counts, profile text, the file written -- runs beside the device's front "
+                         "end of the NEXT file on the other context (slimm_amd/distributed.py: FilesBackToBack); every file "
+                         "through a freshly reset context, every profile written inside the timed region.  1: one context, "
+                         "every call of a file behind the one before (rounds 1 - 3)")
     ap.add_argument("--gen-threads", type=int, default=0, help="threads generating chunks (default: the CPU quota / ranks)")
     # the legs beside the headline (N = 1 only)
     ap.add_argument("--quick", action="store_true", help="the headline measurement only (no other configs, push, CPU, CLI legs)")
@@ -193,7 +199,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from slimm_amd.distributed import resolve_exchange, sharded_profile
+    from slimm_amd.distributed import FilesBackToBack, resolve_exchange, sharded_profile
     from slimm_amd.partition import chunk_owner
     from slimm_amd.profiler import Slimm
     from slimm_amd.synth import CONFIGS, make_workload, stream_chunks
@@ -342,14 +348,24 @@ def main():
         res.interleave(args.chunk_records, 7000 + 100 * rank)
     gen_s = time.time() - t0
 
-    eng = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))
-    eng.force_exchange = args.force_exchange
-    if args.no_bins:
-        eng.keep_bins(False)
+    def new_engine():
+        e = Slimm.for_workload(w, device=local_rank, grouped=(args.record_order == "grouped"))
+        e.force_exchange = args.force_exchange
+        if args.no_bins:
+            e.keep_bins(False)
+        return e
+
+    eng = new_engine()
     torch.cuda.synchronize()
     phase_times = {} if args.breakdown else None
+    # the timed loop: files back to back, through two contexts in turn unless --engines 1
+    eng2 = new_engine() if args.engines == 2 else None
+    files = FilesBackToBack([eng] + ([eng2] if eng2 is not None else []), res.give, dev, out_path, phase_times=phase_times,
+                            exchange=args.exchange)
 
     def step():
+        if eng2 is not None:
+            return files.step()
         eng.reset()
         eng.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
         res.give(eng)
@@ -360,7 +376,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(engine, one_step, steps, warmup, sync):
+    def measure(engine, one_step, steps, warmup, sync, flush=None):
         """`warmup` untimed steps with every launch bracketed by HIP events (that survey names the dominant kernel and
         gives the per-kernel table), then `steps` timed steps that bracket only the dominant kernel -- every event pair
         costs ~10 us of stream idle time, and 18 pairs per step would be charged to the value.  Returns (seconds,
@@ -371,8 +387,15 @@ def main():
         for i in range(warmup):
             one_step()
             if i == 0 and warmup > 1:   # the first step allocates and runs cold: keep it out of the survey
+                if flush is not None:
+                    flush()
+                    if len(getattr(engine, "engines", ())) > 1:   # (every context's first file is a cold one)
+                        one_step()
+                        flush()
                 engine.kernel_times(reset=True)
                 survey_steps -= 1
+        if flush is not None:
+            flush()
         survey = engine.kernel_times(reset=True) if warmup > 0 else {}
         dom_name = None
         if survey and args.kernel_timing == "dominant":
@@ -387,6 +410,8 @@ def main():
         prof = None
         for _ in range(steps):
             prof = one_step()
+        if flush is not None:   # (the last file's profile: written inside the timed region like every other)
+            prof = flush()
         sync()
         el = time.perf_counter() - t1
         kt = engine.kernel_times(reset=True)
@@ -399,7 +424,12 @@ def main():
             kt[dom_name] = live
         return el, kt, dom_name, prof
 
-    elapsed, ktimes, dom_name, profile = measure(eng, step, args.steps, args.warmup, barrier)
+    if eng2 is not None:
+        elapsed, ktimes, dom_name, profile = measure(files, step, args.steps, args.warmup, barrier, flush=files.flush)
+        eng = files.last             # (both hold a whole file's results; the legs below go on with one context)
+        (eng2 if eng is not eng2 else files.engines[0]).close()
+    else:
+        elapsed, ktimes, dom_name, profile = measure(eng, step, args.steps, args.warmup, barrier)
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -672,9 +702,13 @@ def main():
             cfgk = CONFIGS[name]
             wk = make_workload(cfgk, seed=args.seed)
             nk = len(wk.records)
-            engk = Slimm.for_workload(wk, device=local_rank, grouped=True)
-            if args.no_bins:
-                engk.keep_bins(False)
+            def new_engk():
+                e = Slimm.for_workload(wk, device=local_rank, grouped=True)
+                if args.no_bins:
+                    e.keep_bins(False)
+                return e
+
+            engk = new_engk()
             resk = Resident(nk)
             resk.fill(0, wk.records)
 
@@ -684,7 +718,13 @@ def main():
                 resk.give(engk)
                 return engk.get_profiles(path=out_path)
 
-            elk, ktk, _, _ = measure(engk, stepk, args.config_steps, 2, torch.cuda.synchronize)
+            if args.engines == 2:
+                filesk = FilesBackToBack([engk, new_engk()], resk.give, dev, out_path)
+                elk, ktk, _, _ = measure(filesk, filesk.step, args.config_steps, 2, torch.cuda.synchronize, flush=filesk.flush)
+                engk = filesk.last
+                [e.close() for e in filesk.engines if e is not engk]
+            else:
+                elk, ktk, _, _ = measure(engk, stepk, args.config_steps, 2, torch.cuda.synchronize)
             stk = engk.stats()
             roofk, pkk, kmsk = roofline_from(engk, stk, nk, ktk, args.config_steps, name)
             roofk.pop("traffic_source", None)
@@ -873,6 +913,10 @@ def main():
                        "rccl_ranks": world if (dist.is_initialized() and args.backend == "nccl") else 0,
                        "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 0,
                        "backend": args.backend if dist.is_initialized() else "none",
+                       "files_in_flight": ("2 contexts in turn: the host-only end of file k (propagation, profile text, file written) "
+                                           "runs beside the device's front end of file k + 1; every file through a freshly reset "
+                                           "context, all profiles written inside the timed region") if args.engines == 2 else
+                                          "1 context, every call of a file behind the one before",
                        "profile_sha1": __import__("hashlib").sha1((profile or "").encode()).hexdigest(),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,

@@ -169,6 +169,7 @@ struct slimm_ctx {
     DevBuf<uint32_t> slot_rbase, slot_bbase;            // reads in front of a slot = rbase[s] + bbase[s >> 10] (side stream)
     hipStream_t side_stream = nullptr;
     hipEvent_t front_done = nullptr, prefix_done = nullptr;
+    bool prefix_pending = false;  // prefix_done has been recorded and not been waited for by the main stream yet
     uint32_t tile_shift = kTileShiftSmall;              // log2 of the bins per tile: which build of tile_hist.hip runs (kernels.h)
     uint32_t tile_bins() const { return 1u << tile_shift; }
     uint32_t ntiles = 0;
@@ -1275,6 +1276,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     tr.mark("set device + buffers");
     hipStream_t st = c->stream;
     if (c->copy_pending) HIP_TRY(c, hipStreamWaitEvent(st, c->copy_done, 0));  // streamed ingest: device-side ordering
+    if (c->prefix_pending) {  // the file before left its slot prefix on the side stream: k_front rewrites the slots
+        HIP_TRY(c, hipStreamWaitEvent(st, c->prefix_done, 0));
+        c->prefix_pending = false;
+    }
     {
         KernelTimer t(c, K_MEMSET);
         if (!c->use_tiles)  // (the tile kernels write every cov / uniq_cov word themselves)
@@ -1416,9 +1421,10 @@ int slimm_analyze_alignments(slimm_ctx* c) {
                     c->order != SLIMM_ORDER_ANY);
         c->binsA_stored = true;
     }
-    // the side stream's prefix kernels are joined here, not only by phase B: a file that ends without one (no hits, an
-    // analyse-only caller) must not leave them unordered against the next file's k_front, which rewrites the slots
-    HIP_TRY(c, hipStreamWaitEvent(st, c->prefix_done, 0));
+    // (the side stream's prefix kernels are joined by phase B in front of k_filter and -- for a file that ends without one:
+    // no hits, an analyse-only caller -- by the NEXT file's phase A in front of its first launch: a wait here would put a
+    // cross-queue barrier of 11 - 13 us between k_tile_hist and k_pack for an event that is long done)
+    c->prefix_pending = true;
     HIP_TRY(c, hipGetLastError());
     c->analyzed = true;
     tr.mark("phase A launches");
@@ -1715,6 +1721,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
     }
     const uint32_t nslots = front_slots(c->rec.n);
     HIP_TRY(c, hipStreamWaitEvent(st, c->prefix_done, 0));  // (long done: recorded behind k_front)
+    c->prefix_pending = false;
     {
         KernelTimer t(c, K_FILTER, true);  // (the dispatch's own time stamps, like k_front)
         FilterArgs fa;

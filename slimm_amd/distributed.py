@@ -217,6 +217,23 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
     `engine` already holds this rank's records.  Returns the profile text (identical on every rank) or None when no
     rank has a mapped record.
     """
+    multi = (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "force_exchange", False)
+    if not multi and phase_times is None and hasattr(engine, "get_profiles") and not getattr(engine, "needs_set_partials", False):
+        if hasattr(engine, "prepare_summary"):
+            engine.prepare_summary(0)
+        return engine.get_profiles(path=path)  # one rank, nothing to exchange: the library's single call
+    if not sharded_profile_begin(engine, device, group, phase_times, exchange):
+        return None
+    return sharded_profile_end(engine, path, group, phase_times)
+
+
+def sharded_profile_begin(engine, device: Optional[torch.device] = None, group=None, phase_times: Optional[dict] = None,
+                          exchange: str = "auto", after_launch=None) -> bool:
+    """The device's part of `sharded_profile`: phase A, the exchange, the cut-offs, phase B and the merge of the partial
+    results -- everything up to `slimm::get_reads_lca_count` (src/slimm.hpp:533).  `after_launch`, when given, is called
+    once phase A has been launched and before the host waits for it: a caller that works through files back to back puts
+    the host-only end of the file before (`sharded_profile_end` of ANOTHER engine) there, beside this file's front end.
+    Returns False when no rank has a mapped record (`after_launch` has been called all the same)."""
     import time
 
     def lap(name, t0):
@@ -226,10 +243,6 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
 
     multi = (dist.is_initialized() and dist.get_world_size(group) > 1) or getattr(engine, "force_exchange", False)
     t = time.perf_counter()
-    if not multi and phase_times is None and hasattr(engine, "get_profiles") and not getattr(engine, "needs_set_partials", False):
-        if hasattr(engine, "prepare_summary"):
-            engine.prepare_summary(0)
-        return engine.get_profiles(path=path)  # one rank, nothing to exchange: the library's single call
     if hasattr(engine, "prepare_summary"):
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         how = resolve_exchange(engine, exchange, world) if multi else "none"
@@ -243,10 +256,13 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
         exchange = how if multi else exchange
     engine.analyze_alignments()
     t = lap("analyze_alignments(launch)", t)
+    if after_launch is not None:
+        after_launch()
+        t = lap("the file before: get_reads_lca_count + write_abundance", t)
     have_hits = exchange_coverage(engine, group, exchange)
     t = lap("exchange + finish_coverage", t)
     if not have_hits:
-        return None
+        return False
     launched = multi and dist.is_initialized() and hasattr(engine, "filter_alignments_launch") and hasattr(engine, "partials_tensor")
     if launched:
         engine.filter_alignments_launch()   # no host synchronisation until the merged results are installed
@@ -258,9 +274,76 @@ def sharded_profile(engine, device: Optional[torch.device] = None, path: Optiona
             merged = merge_partials(engine, device, group)
             engine.set_partials(merged["uniq_reads_count2"], merged["lca_count"], merged["level_marks"], merged["pairs"])
         t = lap("merge_partials", t)
+    return True
+
+
+def sharded_profile_end(engine, path: Optional[str] = None, group=None, phase_times: Optional[dict] = None):
+    """The host's end of `sharded_profile`: the propagation of the LCA counts (src/slimm.hpp:560-610) and the profile
+    (`write_abundance`, :733-843; rank 0 writes the file).  No device work, no collective."""
+    import time
+    t = time.perf_counter()
     engine.get_reads_lca_count()
-    t = lap("get_reads_lca_count", t)
+    if phase_times is not None:
+        phase_times["get_reads_lca_count"] = phase_times.get("get_reads_lca_count", 0.0) + (time.perf_counter() - t)
+        t = time.perf_counter()
     write_here = path if (not dist.is_initialized() or dist.get_rank(group) == 0) else None
     out = engine.write_abundance(write_here)
-    lap("write_abundance", t)
+    if phase_times is not None:
+        phase_times["write_abundance"] = phase_times.get("write_abundance", 0.0) + (time.perf_counter() - t)
     return out
+
+
+class FilesBackToBack:
+    """Files one after the other through TWO engines in turn (the reference's unit of work is one file through one object,
+    src/slimm.hpp:950-956; its `-d` mode loops over the files of a directory): while the device runs the front end of file
+    k + 1 on one engine, the host finishes file k on the other -- propagation, profile text, the file written --, which
+    otherwise is 0.25 ms of an idle GPU between two files.  Every file still goes through a freshly reset object, every
+    profile is written; `flush()` finishes the last one.  `give(engine)` hands an engine the next file's records."""
+
+    def __init__(self, engines, give, device=None, path=None, group=None, phase_times=None, exchange="auto"):
+        self.engines = list(engines)
+        self.give, self.device, self.path, self.group = give, device, path, group
+        self.phase_times, self.exchange = phase_times, exchange
+        self.k = 0
+        self.pending = None
+        self.last = self.engines[0]
+        self.profile = None
+
+    def _finish_pending(self):
+        if self.pending is not None:
+            self.profile = sharded_profile_end(self.pending, self.path, self.group, self.phase_times)
+            self.pending = None
+
+    def step(self):
+        e = self.engines[self.k % len(self.engines)]
+        self.k += 1
+        e.reset()
+        e.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
+        self.give(e)
+        self.last = e
+        if sharded_profile_begin(e, self.device, self.group, self.phase_times, self.exchange, after_launch=self._finish_pending):
+            self.pending = e
+        else:
+            self.profile = None
+        return self.profile          # (the profile of the file BEFORE; flush() returns this file's)
+
+    def flush(self):
+        self._finish_pending()
+        return self.profile
+
+    # the engines' kernel timers as one
+    def enable_kernel_timing(self, on):
+        for e in self.engines:
+            e.enable_kernel_timing(on)
+
+    def time_only_kernel(self, name):
+        for e in self.engines:
+            e.time_only_kernel(name)
+
+    def kernel_times(self, reset=False):
+        out = {}
+        for e in self.engines:
+            for k, (ms, n) in e.kernel_times(reset=reset).items():
+                a = out.get(k, (0.0, 0))
+                out[k] = (a[0] + ms, a[1] + n)
+        return out

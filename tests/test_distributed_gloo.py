@@ -95,3 +95,66 @@ def test_three_ranks_auto_exchange_is_sliced():
     port = 29500 + (os.getpid() % 2000) + 9
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker, args=(3, port, "config2", tmp, "auto"), nprocs=3, join=True)
+
+
+def _worker_back_to_back(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.binding import run_workload
+        from slimm_amd.distributed import FilesBackToBack
+        from slimm_amd.synth import CONFIGS, make_workload
+        from tests.shard_engine import OracleShardEngine
+
+        # three different files (one database: the taxonomy and the references of a seed do not depend on the record count)
+        files = [make_workload(CONFIGS["config1"], seed=31, n_records=n) for n in (40_000, 25_000, 60_000)]
+        shards = [_split_by_read(w, world)[rank] for w in files]
+
+        class Engine(OracleShardEngine):     # a context that is reset and handed another file, like Slimm
+            def __init__(self):
+                self.ready = False
+
+            def reset(self):
+                self.ready = False
+
+            def reset_cutoffs(self):
+                pass
+
+        at = [0]
+
+        def give(e):
+            OracleShardEngine.__init__(e, shards[at[0]])
+            at[0] += 1
+
+        path = os.path.join(tmp, "profile.tsv")
+        fb = FilesBackToBack([Engine(), Engine()], give, None, path, exchange="summary")
+        got = []
+        for k in range(3):
+            before = fb.step()               # returns the profile of the file BEFORE this one
+            if k:
+                got.append(before)
+                if rank == 0:                # ... which has been written by now
+                    assert open(path).read() == before
+            dist.barrier()
+        got.append(fb.flush())
+        assert fb.flush() == got[-1]         # (nothing pending any more)
+        from tests.helpers import assert_profiles_match
+        assert len(set(got)) == 3
+        for text, w in zip(got, files):
+            assert_profiles_match(text, run_workload(w, use_qnames=False, collect_bins=False).profile_tsv)
+        if rank == 0:
+            assert open(path).read() == got[-1]
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_files_back_to_back_through_two_engines_per_rank():
+    """slimm_amd/distributed.py FilesBackToBack (bench.py's timed loop): while a rank's second engine is in phase A of file
+    k + 1, the host-only end of file k runs on the first -- the collectives of the two files must not interleave
+    differently on different ranks, and every file's profile must be its own."""
+    port = 29500 + (os.getpid() % 2000) + 33
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_back_to_back, args=(2, port, tmp), nprocs=2, join=True)

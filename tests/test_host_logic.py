@@ -77,6 +77,31 @@ def test_quantile_cut_off_matches_oracle_order():
                 i -= 1
             assert host_quantile_cut_off(v, q) == float(sv[i])
     assert host_quantile_cut_off(np.zeros(0, dtype=np.float32), 0.95) == 0.0
+    # from 1024 values on the library sorts non-negative floats by their bit patterns (counting passes), anything else with
+    # std::sort: many equal values, zeros, denormals, huge values, infinity -- and a negative value among them
+    for n in (1024, 20_000):
+        v = (rng.integers(0, 300, n) / np.float32(301)).astype(np.float32)
+        v[::7] = 0.0
+        v[5] = np.float32(1e-42)
+        v[6] = np.float32(3e38)
+        for neg in (False, True):
+            if neg:
+                v[9] = np.float32(-0.25)
+            sv = np.sort(v)
+            total = np.float32(0)
+            for x in v:
+                total = np.float32(total + x)
+            for q in (0.0, 0.3, 0.95):
+                i = n - 1
+                sub = np.float32(0)
+                while np.float32(sub / total) < np.float32(q) and i > 0:
+                    sub = np.float32(sub + sv[i])
+                    i -= 1
+                assert host_quantile_cut_off(v, q) == float(sv[i])
+    v = np.full(2000, 0.5, dtype=np.float32)
+    v[3] = np.inf
+    # (0 / inf = 0 < q: the infinity is taken, inf / inf is no number, the loop ends one value further down)
+    assert host_quantile_cut_off(v, 0.5) == 0.5 and host_quantile_cut_off(v, 0.0) == float("inf")
 
 
 def test_bin_of_wraps_like_uint32():

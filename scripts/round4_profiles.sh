@@ -16,6 +16,14 @@ for c in config2 config3; do
   rm -rf $O/any_$c
 done
 bash scripts/pmc_sq.sh $TAG/any_sq --config config2 --record-order any > /dev/null 2>&1; cp $O/any_sq/summary.txt $O/any_config2_sq_counters.txt 2>/dev/null; rm -rf $O/any_sq
+# files back to back (bench --engines 2, the default) against one context: config 2's step and the idle device between files
+for e in 1 2; do
+  python3 bench.py --quick --config config2 --engines $e --steps 100 --no-any-order 2> /dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config2 --engines $e: %.4f ms per file, %.0f M records/s' % (d['ms_per_step'], d['value']))" >> $O/config2_engines.txt
+  ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $O/gaps$e -o t -- python3 $R/bench.py --quick --config config2 --engines $e --steps 6 --warmup 2 --no-any-order > /dev/null 2>&1 )
+  echo "== bench.py --quick --config config2 --engines $e: the last three files" >> $O/config2_engines.txt
+  python3 scripts/gaps.py $O/gaps$e/t_kernel_trace.csv 3 >> $O/config2_engines.txt; rm -rf $O/gaps$e
+done
+bash scripts/host_trace.sh $TAG/ht > $O/host_trace.txt 2>&1; rm -rf $O/ht
 python3 scripts/cli_e2e.py 100000000 config3 > $O/cli_100m_trace.txt 2>&1
 python3 scripts/cli_exit_modes.py > $O/cli_100m_exit_modes.txt 2>&1
 python3 -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1

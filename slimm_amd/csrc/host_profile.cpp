@@ -83,7 +83,7 @@ float quantile_cut_off(std::vector<float> v, float q) {
     if (v.empty()) return 0;
     float total = std::accumulate(v.begin(), v.end(), 0.0f);
     float sub = 0.0f;
-    if (v.size() < 1024 || !sort_non_negative(v)) std::sort(v.begin(), v.end());
+    if (v.size() < 256 || !sort_non_negative(v)) std::sort(v.begin(), v.end());
     uint32_t i = static_cast<uint32_t>(v.size() - 1);
     while ((float(sub) / total) < q && i > 0.0f) {
         sub += v[i];
@@ -232,6 +232,7 @@ void HostProfile::set_coverage_strided(const uint32_t* rc, const uint32_t* urc, 
         }
     }
     abundance_ready_ = false;
+    frac_ready_ = false;
     // slimm.hpp:458-459
     if (min_reads == 0 && matches > 0) min_reads = 1 + ((matches - 1) / 10000);
     have_coverage = true;
@@ -261,24 +262,53 @@ void HostProfile::abundances() {
     abundance_ready_ = true;
 }
 
+// The two quotients the cut-offs and the validity test are made of -- non-zero bins / bins of cov and of uniq_cov
+// (slimm.hpp:331-336, :357-361, :675-680; float(count) / uint32 bins = float / float) -- for the references with any
+// non-zero statistic, in the order of active_: one pass, shared by the three of them.
+void HostProfile::active_fractions() {
+    if (frac_ready_) return;
+    const size_t A = active_.size();
+    cov_frac_.resize(A);
+    ucov_frac_.resize(A);
+    const uint32_t* act = active_.data();
+    for (size_t k = 0; k < A; ++k) {
+        const uint32_t i = act[k];
+        const float b = float(nbins_[i]);
+        cov_frac_[k] = float(nz_cov[i]) / b;
+        ucov_frac_[k] = float(nz_ucov[i]) / b;
+    }
+    frac_ready_ = true;
+}
+
+// the quotients of the references with unique reads (slimm.hpp:333, :677), in reference order
+static void fractions_with_unique_reads(const std::vector<uint32_t>& active, const std::vector<uint32_t>& uniq_reads,
+                                        const std::vector<float>& frac, std::vector<float>& v) {
+    const size_t A = active.size();
+    v.resize(A);
+    size_t n = 0;
+    for (size_t k = 0; k < A; ++k) {  // (no branch: the store is kept when the reference counts)
+        v[n] = frac[k];
+        n += uniq_reads[active[k]] > 0 ? 1u : 0u;
+    }
+    v.resize(n);
+}
+
 float HostProfile::coverage_cut_off() {  // slimm.hpp:328-344
     if (cc_cache_ == 0.0 && cfg_.cov_cut_off < 1.0) {
+        active_fractions();
         std::vector<float> v;
-        v.reserve(active_.size());
-        for (uint32_t i : active_)
-            if (uniq_reads_count[i] > 0) v.push_back(float(nz_cov[i]) / nbins_[i]);
-        cc_cache_ = quantile_cut_off(v, cfg_.cov_cut_off);
+        fractions_with_unique_reads(active_, uniq_reads_count, cov_frac_, v);
+        cc_cache_ = quantile_cut_off(std::move(v), cfg_.cov_cut_off);
     }
     return cc_cache_;
 }
 
 float HostProfile::uniq_coverage_cut_off() {  // slimm.hpp:672-688
     if (ucc_cache_ == 0.0 && cfg_.cov_cut_off < 1.0) {
+        active_fractions();
         std::vector<float> v;
-        v.reserve(active_.size());
-        for (uint32_t i : active_)
-            if (uniq_reads_count[i] > 0) v.push_back(float(nz_ucov[i]) / nbins_[i]);
-        ucc_cache_ = quantile_cut_off(v, cfg_.cov_cut_off);
+        fractions_with_unique_reads(active_, uniq_reads_count, ucov_frac_, v);
+        ucc_cache_ = quantile_cut_off(std::move(v), cfg_.cov_cut_off);
     }
     return ucc_cache_;
 }
@@ -290,42 +320,38 @@ float HostProfile::expected_coverage() const {  // slimm.hpp:346-349
 void HostProfile::compute_valid() {  // slimm.hpp:353-378
     const uint32_t R = cfg_.n_refs;
     valid.assign(R, 0);
-    n_valid = failed_by_cov = failed_by_ucov = failed_by_min_read = 0;
     // The reference re-evaluates the (cached) cut-off getters inside the loop; their value cannot change while it
     // runs, so they are read once here.
     const float cc = coverage_cut_off();
     const float ucc = uniq_coverage_cut_off();
-    valid_list_.clear();
-    // the two quotients of every reference in one dense, branch-free loop the compiler turns into packed divisions
-    // (4000 scalar divisions inside the branchy loop below were 10 of this function's 18 us)
-    cov_frac_.resize(R);
-    ucov_frac_.resize(R);
-    {
-        const uint32_t* nzc = nz_cov.data();
-        const uint32_t* nzu = nz_ucov.data();
-        const uint32_t* nb = nbins_.data();
-        float* cf = cov_frac_.data();
-        float* uf = ucov_frac_.data();
-        for (uint32_t i = 0; i < R; ++i) {
-            const float b = float(nb[i]);
-            cf[i] = float(nzc[i]) / b;
-            uf[i] = float(nzu[i]) / b;
-        }
+    active_fractions();
+    // One pass over the references with any statistic, no data-dependent branch (the device waits for this between its two
+    // phases; with 20 k references the branchy form took 76 us of the 190 the host spends there): a reference with reads
+    // is valid when both quotients reach their cut-offs (:357-361), otherwise it counts for every test it fails (:364-375).
+    const size_t A = active_.size();
+    valid_list_.resize(A);
+    uint32_t nv = 0, f_cov = 0, f_ucov = 0, f_min = 0;
+    const uint32_t* act = active_.data();
+    const float* cf = cov_frac_.data();
+    const float* uf = ucov_frac_.data();
+    uint32_t* vl = valid_list_.data();
+    for (size_t k = 0; k < A; ++k) {
+        const uint32_t i = act[k];
+        const uint32_t rc = reads_count[i];
+        const uint32_t has = rc != 0u, cov_ok = cf[k] >= cc, ucov_ok = uf[k] >= ucc;
+        const uint32_t ok = has & cov_ok & ucov_ok, failed = has & (ok ^ 1u);
+        valid[i] = static_cast<uint8_t>(ok);
+        vl[nv] = i;
+        nv += ok;
+        f_ucov += failed & (ucov_ok ^ 1u);
+        f_min += failed & (rc < min_reads ? 1u : 0u);
+        f_cov += failed & (cov_ok ^ 1u);
     }
-    for (uint32_t i : active_) {
-        if (reads_count[i] == 0) continue;
-        const float cp = cov_frac_[i];
-        const float up = ucov_frac_[i];
-        if (cp >= cc && up >= ucc) {
-            valid[i] = 1;
-            valid_list_.push_back(i);
-            ++n_valid;
-        } else {
-            if (up < ucc) ++failed_by_ucov;
-            if (reads_count[i] < min_reads) ++failed_by_min_read;
-            if (cp < cc) ++failed_by_cov;
-        }
-    }
+    valid_list_.resize(nv);
+    n_valid = nv;
+    failed_by_cov = f_cov;
+    failed_by_ucov = f_ucov;
+    failed_by_min_read = f_min;
     have_valid = true;
 }
 

@@ -150,7 +150,9 @@ private:
     std::vector<uint32_t> nz_ucov2_;
     std::vector<uint32_t> active_;      // references with a non-zero statistic, ascending (set_coverage)
     std::vector<uint32_t> valid_list_;
-    std::vector<float> cov_frac_, ucov_frac_;  // compute_valid scratch
+    std::vector<float> cov_frac_, ucov_frac_;  // active_fractions(): per entry of active_
+    bool frac_ready_ = false;
+    void active_fractions();
     // partials
     std::vector<uint32_t> lca_count_, marks_;
     std::vector<uint64_t> pairs_;

@@ -704,7 +704,9 @@ __global__ __launch_bounds__(64) void k_gb_finish(uint64_t* __restrict__ ident, 
 }
 
 // test / tuning knobs, read at every call (a test varies them inside one process): SLIMM_GROUP_BITS = hash bits of a
-// bucket, SLIMM_GROUP_WIDTH = widest digit of a pass, SLIMM_GROUP_GRID = persistent workgroups of a pass
+// bucket, SLIMM_GROUP_WIDTH = widest digit of a pass, SLIMM_GROUP_PASSES = number of passes (with the other two),
+// SLIMM_GROUP_GRID = persistent workgroups of a pass.  (Two passes instead of three, measured at 10 M records, scripts/
+// group_bits.sh: 2 x 11 bits 255 us per scatter pass + 107 us of finish, 2 x 10 bits 156 + 211, against 3 x 8 bits 96 + 30.)
 uint32_t g_env_u32(const char* name) {
     const char* e = getenv(name);
     const long v = e ? atol(e) : 0;
@@ -735,9 +737,11 @@ GroupPlan group_plan(uint32_t n_records) {
     for (uint32_t bits = (forced_bits ? std::min(forced_bits, 32u) : b); bits <= (forced_bits ? std::min(forced_bits, 32u) : std::min(b + 1u, 32u));
          ++bits) {
         const uint32_t wcap = forced_width ? std::min(forced_width, kGroupMaxBits) : kGroupMaxBits;
+        const uint32_t forced_passes = g_env_u32("SLIMM_GROUP_PASSES");
         for (uint32_t P = (bits + wcap - 1u) / wcap; P <= kGroupMaxPasses; ++P) {
             const uint32_t lo = bits / P, hi = lo + (bits % P ? 1u : 0u);
             if (hi > wcap) continue;
+            if (forced_passes && P != forced_passes && P < kGroupMaxPasses) continue;
             // (the finish: cheap once there are 1.6 buckets per record -- 10 M records in 2^24 buckets: 25 us = 0.27 of a pass)
             const bool roomy = forced_bits || (1ull << bits) * 10ull >= static_cast<uint64_t>(n_records) * 16ull;
             float cost = 0.21f * static_cast<float>(P) + (roomy ? 0.22f : 0.40f);

@@ -2,6 +2,8 @@
 #include "../../slimm_amd/csrc/host/alignment_file.hpp"
 #include "../../slimm_amd/csrc/host/sldb.hpp"
 #include <cstdio>
+#include <cstdlib>
+#include <vector>
 using namespace slimm;
 int main(int argc, char** argv) {
     for (int i = 1; i < argc; ++i) {
@@ -18,5 +20,26 @@ int main(int argc, char** argv) {
         RecordBatch b; long n, tot = 0;
         while ((n = f.read_batch(b, 1 << 20, true)) > 0) { tot += n; b.clear(); }  // large requests: the parallel record walk
         printf("%s: refs=%zu records=%ld rc=%ld %s\n", p.c_str(), f.ref_names().size(), tot, n, f.error().c_str());
+        if (p.size() > 4 && p.substr(p.size() - 4) == ".bam") {
+            // read_raw (the windows `slimm` hands to slimm_push_bam_bytes): small and large windows, the compressed bytes
+            // from a mapping of the file and through buffered reads, a few records taken by read_batch first
+            for (int mode = 0; mode < 6; ++mode) {
+                if (mode & 1) setenv("SLIMM_NO_MMAP", "1", 1); else unsetenv("SLIMM_NO_MMAP");
+                const size_t cap = mode < 2 ? (1u << 20) : mode < 4 ? (3u << 20) + 12345u : (64u << 20);
+                AlignmentFile g;
+                if (!g.open(p)) continue;
+                if (mode >= 4) { RecordBatch h; (void)g.read_batch(h, 100, false); }
+                std::vector<uint8_t> buf(cap);
+                long k; unsigned long long bytes = 0, sum = 0; int windows = 0;
+                while ((k = g.read_raw(buf.data(), cap)) > 0) {
+                    bytes += static_cast<unsigned long long>(k); ++windows;
+                    for (long i = 0; i < k; i += 509) sum += buf[static_cast<size_t>(i)];
+                    if (g.raw_exhausted()) break;
+                }
+                printf("%s: read_raw mode %d cap %zu: %llu bytes in %d windows (sum %llu) rc=%ld %s\n", p.c_str(), mode, cap, bytes,
+                       windows, sum, k, g.error().c_str());
+            }
+            unsetenv("SLIMM_NO_MMAP");
+        }
     }
 }

@@ -14,6 +14,8 @@ g++ $FLAGS "$ROOT/slimm_amd/csrc/host/slimm_build_main.cpp" "$ROOT/slimm_amd/csr
 # ThreadSanitizer over the parallel BGZF inflate / record decode
 g++ -std=c++17 -g -O1 -fsanitize=thread "$ROOT/tests/native/san_readers.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
     "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -ldl -o "$W/tsan_readers"
+g++ -std=c++17 -g -O1 -fsanitize=thread -I"$ROOT/include" "$ROOT/slimm_amd/csrc/host/slimm_main.cpp" "$ROOT/slimm_amd/csrc/host/alignment_file.cpp" \
+    "$ROOT/slimm_amd/csrc/host/sldb.cpp" -lz -lpthread -ldl -o "$W/tsan_slimm"
 cd "$ROOT"
 python - "$W" <<'PY'
 import os, subprocess, sys
@@ -82,6 +84,17 @@ for k, (gz, batch) in enumerate([(False, "1000000"), (True, "7")]):
         if r.returncode or noise:
             bad += 1; print("SANITIZER OUTPUT (slimm_build):\n" + r.stderr)
 print("slimm_build under sanitizers: done")
+# The `slimm` command itself under ThreadSanitizer -- its reader thread, the inflater and the pusher of the raw windows
+# (RecordPump), the fallback to the host decoder -- with the HIP library replaced by the host emulator of tests/native (the
+# command dlopen()s what SLIMM_HIP_LIB names).  Skipped when that library has not been built (make -C tests/native).
+emu = os.path.join(os.getcwd(), "tests", "native", "libslimm_emu.so")
+if os.path.exists(emu) and os.path.exists(f"{d}/tsan_slimm"):
+    for extra in ({"SLIMM_CLI_WINDOW_MB": "1"}, {"SLIMM_CLI_WINDOW_MB": "3", "SLIMM_NO_MMAP": "1"}, {"SLIMM_CLI_HOST_DECODE": "1"}):
+        r = subprocess.run([f"{d}/tsan_slimm", "-w", "1000", "-o", f"{d}/cli_", f"{d}/c3.sldb", f"{d}/c3.bam"], capture_output=True,
+                           text=True, errors="replace", env=dict(os.environ, SLIMM_HIP_LIB=emu, **extra))
+        if r.returncode or "ThreadSanitizer" in r.stderr:
+            bad += 1; print("SANITIZER OUTPUT (slimm under TSan):\n" + r.stderr[-4000:])
+    print("slimm (command, emulated device) under ThreadSanitizer: done")
 print("sanitizer findings:", bad)
 sys.exit(1 if bad else 0)
 PY

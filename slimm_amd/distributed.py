@@ -315,19 +315,27 @@ class FilesBackToBack:
             self.pending = None
 
     def step(self):
+        """The next file: reset + records + phase A launched on the engine whose turn it is, the file before finished on
+        the other one meanwhile, then this file up to its merged partial results.  Returns the profile of the file BEFORE
+        (None: there was none, or it had no mapped record); `flush()` returns this file's."""
         e = self.engines[self.k % len(self.engines)]
         self.k += 1
         e.reset()
         e.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
         self.give(e)
         self.last = e
-        if sharded_profile_begin(e, self.device, self.group, self.phase_times, self.exchange, after_launch=self._finish_pending):
+        had_pending = self.pending is not None
+        have_hits = sharded_profile_begin(e, self.device, self.group, self.phase_times, self.exchange,
+                                          after_launch=self._finish_pending)
+        before = self.profile if had_pending else None
+        if have_hits:
             self.pending = e
         else:
-            self.profile = None
-        return self.profile          # (the profile of the file BEFORE; flush() returns this file's)
+            self.profile = None      # (src/slimm.hpp:451-455: no mapped reads, nothing written for this file)
+        return before
 
     def flush(self):
+        """Finishes the last file; returns its profile (None: no mapped record)."""
         self._finish_pending()
         return self.profile
 

@@ -1394,3 +1394,47 @@ def test_set_records_device_replaces_an_earlier_form():
     s.set_records_device_packed(*pk)
     assert s.get_profiles() is not None
     assert_matches_oracle(s, run_workload(_mask61(w), use_qnames=False))
+
+
+def test_files_back_to_back_through_two_contexts(tmp_path):
+    """INTEGRATION.md "files one after the other" / slimm_amd.distributed.FilesBackToBack (bench.py's timed loop): phase A
+    of file k + 1 is launched on one context BEFORE the host finishes file k on the other (get_reads_lca_count,
+    write_abundance).  Five files of one database -- different lengths, one of them without a mapped record, one in another
+    record form -- each equal to the oracle's result for THAT file, whichever context it went through (the reference's unit
+    of work: one file through one freshly reset object, src/slimm.hpp:950-956)."""
+    from slimm_amd.distributed import FilesBackToBack
+    files = [make_workload(CONFIGS["config1"], seed=61, n_records=n) for n in (9_000, 30_000, 4_000, 30_000, 17_000)]
+    r = files[2].records
+    r.flag[:] |= 0x4                     # file 2: every record unmapped -> "[WARNING] No mapped reads found", no profile
+    want = [run_workload(w, use_qnames=False) for w in files]
+    assert want[2].no_hits and not want[1].no_hits
+    at = [0]
+
+    def give(e):
+        w = files[at[0]]
+        if at[0] == 3:
+            e.push_records_packed(_mask61(w).records)
+        else:
+            e.push_records(w.records, batch=7_000)
+        at[0] += 1
+
+    path = str(tmp_path / "profile.tsv")
+    engines = [Slimm.for_workload(files[0], device=0), Slimm.for_workload(files[0], device=0)]
+    fb = FilesBackToBack(engines, give, None, path)
+    got = []
+    for k in range(len(files)):
+        before = fb.step()               # launches file k, finishes file k - 1 beside it
+        if k:
+            got.append(before)
+    got.append(fb.flush())
+    assert [g is None for g in got] == [False, False, True, False, False]
+    for k, (text, o) in enumerate(zip(got, want)):
+        if text is not None:
+            assert_profiles_match(text, o.profile_tsv)
+    assert open(path).read() == got[-1]
+    # the contexts still hold the last two files (3 on engine 1, 4 on engine 0): every integer of each
+    assert_matches_oracle(engines[0], want[4])
+    o3 = run_workload(_mask61(files[3]), use_qnames=False)
+    assert_matches_oracle(engines[1], o3)
+    for e in engines:
+        e.close()

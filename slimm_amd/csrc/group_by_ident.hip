@@ -63,17 +63,12 @@ __device__ __forceinline__ uint32_t gb_mix(uint64_t ident) {
     return static_cast<uint32_t>(key) * 0x9E3779B1u + static_cast<uint32_t>(key >> 32) * 0x85EBCA77u;
 }
 
-// A load of the stream the scatter reads once.  Marked non-temporal (-DSLIMM_GB_NT_LOADS), so that the lines it brings in
-// do not push the half-written lines at the G x 2^W output frontiers out of the L2, it measured even at 10 M records (the
-// next kernel's count ran 10 % faster, the scatter the same) and 11 % SLOWER at 100 M (scatter 886 -> 987 us, count 225 ->
-// 267): plain loads.
+// A load of the stream the scatter reads once: a plain load.  (Marked non-temporal -- so that the lines it brings in do not
+// push the half-written lines at the G x 2^W output frontiers out of the L2 -- it measured even at 10 M records and 11 %
+// SLOWER at 100 M: scatter 886 -> 987 us, count 225 -> 267.)
 template <typename T>
 __device__ __forceinline__ T gb_stream_load(const T* p) {
-#if defined(SLIMM_GB_NT_LOADS) && !defined(SLIMM_HIP_EMU)
-    return __builtin_nontemporal_load(p);
-#else
     return *p;
-#endif
 }
 
 // ---- record sources -------------------------------------------------------------------------------------------------
@@ -843,7 +838,6 @@ void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass) {
 
 void launch_group_finish(hipStream_t st, const GroupJob& j) {
     if (j.in.n == 0) return;
-    if (getenv("SLIMM_GROUP_NO_FINISH")) return;  // DEBUG
     const uint32_t fgrid = (j.in.n + kFinishRecs - 1u) / kFinishRecs;
     if (j.in.check)
         hipLaunchKernelGGL((k_gb_finish<true>), dim3(fgrid), dim3(64), 0, st, j.a.ident, j.a.pay, j.a.chk, j.t.ident, j.t.pay, j.t.chk,

@@ -514,6 +514,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         hipError_t e_ = (expr);                                                                          \
         if (e_ != hipSuccess) return fail(nullptr, SLIMM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+        HostTrace trc("slimm_create");
         HIP_TRY0(hipSetDevice(c->device));
         HIP_TRY0(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
         HIP_TRY0(hipStreamCreateWithFlags(&cc->copy_stream, hipStreamNonBlocking));
@@ -522,6 +523,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(hipEventCreateWithFlags(&cc->prefix_done, hipEventDisableTiming));
         HIP_TRY0(hipEventCreateWithFlags(&cc->copy_done, hipEventDisableTiming));
         for (auto& sg : cc->staging) HIP_TRY0(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+        trc.mark("streams + events");
         HIP_TRY0(cc->d_ref_len.ensure(c->R));
         HIP_TRY0(cc->d_bin_off.ensure(c->R + 1));
         HIP_TRY0(cc->d_lin_dense.ensure(static_cast<size_t>(c->R) * 8));
@@ -531,10 +533,12 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->ref_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->lca_count.ensure(c->Tsel));
         HIP_TRY0(cc->marks.ensure(static_cast<size_t>(c->R) * (kMarkBytes / 4)));
+        trc.mark("device arrays");
         HIP_TRY0(cc->h_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
         HIP_TRY0(cc->h_small.ensure(CNT_WORDS + kTailWords));
         HIP_TRY0(cc->h_lca.ensure(c->T));
         HIP_TRY0(cc->h_marks.ensure(c->R));
+        trc.mark("page-locked host arrays");
         HIP_TRY0(hipMemcpy(cc->d_ref_len.p, hc.ref_len.data(), c->R * 4, hipMemcpyHostToDevice));
         HIP_TRY0(hipMemcpy(cc->d_bin_off.p, c->bin_off_h.data(), (c->R + 1) * 4, hipMemcpyHostToDevice));
         {
@@ -576,12 +580,14 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 hipMemcpy(cc->d_taxon_idx.p, inv_idx.data(), inv_idx.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
         }
+        trc.mark("tables to the device");
         const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
         cc->use_tiles = !(force_direct && force_direct[0] == '1') && TILES(c->tile_shift, tile_hist_setup(c->ntiles2)) == 0;
         if (cc->order == SLIMM_ORDER_ANY && group_init() != 0) {
             *out = nullptr;
             return fail(nullptr, SLIMM_E_HIP, "group_init: hipFuncSetAttribute failed");
         }
+        trc.mark("kernel attributes (tile_hist_setup, group_init: the code objects are loaded here)");
         {
             // default by size: with the register-resident scatter chunks one level wins up to ~10 K tiles (config 3:
             // 494 vs 601 us) and is level with two at 24 K (config 5: 430 vs 396 us)

@@ -199,6 +199,15 @@ int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
  * 16 MiB is not supported in this form (SLIMM_E_INVALID: decode such a file on the host).  The forms do not mix within
  * a file.  Replaces: seqan::readRecord in src/slimm.hpp:194-208 / src/misc.hpp:509-522. */
 int slimm_push_bam_bytes(slimm_ctx* ctx, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records);
+/* The same with the inflate on the device as well: `blocks` = n_bytes of whole BGZF blocks of the file (compressed, as they
+ * lie in it, one behind the other, in file order across calls), of whose inflated bytes the first `skip` are not alignment
+ * records (the end of the BAM header in the file's first record-bearing block; 0 in every later call).  The compressed bytes
+ * cross the bus, a lane per block inflates them (slimm_amd/csrc/bgzf_inflate.hip; ISIZE, the DEFLATE blocks' form and
+ * the CRC32 are checked), and the records are found and decoded as above.  Windows of this form and of
+ * slimm_push_bam_bytes may alternate within a file (a host that inflates some windows itself and leaves the others to the
+ * device keeps both busy); buffer lifetime, `last`, *n_records and the errors are those of slimm_push_bam_bytes, plus
+ * SLIMM_E_INVALID for anything that is not a BGZF block or does not inflate to its ISIZE. */
+int slimm_push_bgzf_blocks(slimm_ctx* ctx, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records);
 /* Page-locks a buffer of the caller (hipHostRegister) until the context is destroyed: copies out of it then run at the
  * speed of the bus instead of the runtime's own staging. */
 int slimm_pin_host_buffer(slimm_ctx* ctx, const void* buffer, uint64_t n_bytes);
@@ -452,6 +461,16 @@ int slimm_group_get_profiles(slimm_group* g, const char* path); /* path may be N
  * hosts that call it from a thread of their own while they load their database and open their input. */
 int slimm_warm_up(int device);
 const char* slimm_version(void);
+
+/* BGZF blocks inflated on the device, by themselves: `blocks` = n_bytes of whole BGZF blocks (gzip members with the BC
+ * extra field, as in a .bam / .bgz file) in host memory, one behind the other; their inflated bytes, one block's behind the
+ * other's, go to out[0, *out_bytes) in host memory.  A lane per block (slimm_amd/csrc/bgzf_inflate.hip); ISIZE, the
+ * well-formedness of every DEFLATE block and the CRC32 of the gzip trailer are checked.  *kernel_ms (may be null): the
+ * inflate kernel alone.  Errors (-1 bad input / a corrupt block, -2 HIP) come with a message in err[0, err_cap).
+ * Replaces, together with slimm_push_bam_bytes, what seqan::BamFileIn does for the reference (call sites src/misc.hpp:498-522,
+ * src/slimm.hpp:194-208).  slimm_push_bgzf_blocks feeds a context's record stream the same way without the round trip. */
+int slimm_bgzf_inflate(int device, const uint8_t* blocks, uint64_t n_bytes, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes,
+                       double* kernel_ms, char* err, uint64_t err_cap);
 
 #ifdef __cplusplus
 }

@@ -146,6 +146,15 @@ struct slimm_ctx {
         bool closed = false;                // the file's last window went in
         uint64_t pending_bytes = 0;
         hipEvent_t copied[3] = {nullptr, nullptr, nullptr};
+        // windows that arrive as BGZF blocks (slimm_push_bgzf_blocks): compressed bytes + block descriptors per buffer, the
+        // inflater's scratch and {error code, first bad block} per buffer; inflated[b]: that window was inflated here
+        DevBuf<uint8_t> comp[3];
+        DevBuf<BgzfBlock> desc[3];
+        DevBuf<uint8_t> inflate_scratch;
+        DevBuf<uint32_t> inflate_status;       // 2 words per buffer
+        PinBuf<uint32_t> h_inflate_status;     // ... fetched with the window's other results
+        bool inflated[3] = {false, false, false};
+        std::vector<BgzfBlock> desc_host[3];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
@@ -980,8 +989,14 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     HIP_TRY(c, B.pieces.ensure(static_cast<size_t>(np) + 1));
     HIP_TRY(c, B.offs.ensure(static_cast<size_t>(np + 1) * kBamSlots));
     if (n_bytes) HIP_TRY(c, hipStreamWaitEvent(st, B.copied[b], 0));
+    const bool inflated_here = n_bytes && B.inflated[b];
+    if (inflated_here)
+        HIP_TRY(c, hipMemcpyAsync(B.h_inflate_status.p, B.inflate_status.p + 2u * b, 8, hipMemcpyDeviceToHost, st));
     launch_bam_find(st, B.bytes[b].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
     HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device and counted
+    if (inflated_here && B.h_inflate_status.p[0])
+        return fail(c, SLIMM_E_INVALID, "corrupt BGZF block (device inflate: error %u in block %u of the window)", B.h_inflate_status.p[0],
+                    B.h_inflate_status.p[1]);
     const BamWindowResult res = *B.result.p;
     if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
     const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
@@ -1027,9 +1042,40 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
 }
 }  // namespace
 
+namespace {
+int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, bool compressed, uint32_t skip, int last, uint64_t* n_records);
+}
 int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records) {
+    return bam_push_window(c, bytes, n_bytes, false, 0u, last, n_records);
+}
+int slimm_push_bgzf_blocks(slimm_ctx* c, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records) {
+    return bam_push_window(c, blocks, n_bytes, true, skip, last, n_records);
+}
+namespace {
+// A window of a BAM file's alignment-record bytes: inflated already (`bytes` are the records' bytes) or as whole BGZF blocks
+// (`bytes` are compressed; the first `skip` inflated bytes are not records).  src_bytes = what crosses the bus.
+int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool compressed, uint32_t skip, int last, uint64_t* n_records) {
     if (!c) return SLIMM_E_INVALID;
     if (n_records) *n_records = 0;
+    uint64_t n_bytes = src_bytes;  // the window's record bytes
+    if (compressed && src_bytes) {
+        if (!bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
+        std::string why;
+        uint64_t inflated = 0;
+        std::vector<BgzfBlock>& dh = c->bam.desc_host[(c->bam.active ? c->bam.windows : 0) % 3u];
+        dh.clear();
+        if (!bgzf_parse_blocks(bytes, src_bytes, 0, dh, inflated, why)) return fail(c, SLIMM_E_INVALID, "%s", why.c_str());
+        if (skip > inflated || (skip && c->bam.active && (c->bam.carry_bytes || c->bam.pending)))
+            return fail(c, SLIMM_E_INVALID, "skip: only in front of a file's first records");
+        if (dh.size() >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "too many blocks in one window");
+        n_bytes = inflated - skip;
+        if (n_bytes == 0) {  // (blocks without a record byte: nothing to inflate, nothing to decode)
+            compressed = false;
+            src_bytes = 0;
+        }
+    } else if (compressed) {
+        compressed = false;
+    }
     if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
     if (n_bytes && !bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
@@ -1076,8 +1122,29 @@ int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, i
                 HIP_TRY(c, B.bytes[b].ensure(need + (need >> 2)));
             }
         }
-        HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+        B.inflated[b] = compressed;
+        if (compressed) {
+            // the compressed bytes and the block descriptors go over the bus, and the inflate runs behind them on the copy
+            // stream -- beside the kernels that work on the window before, like a plain window's copy does
+            const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size()), grid = bgzf_inflate_grid(nblk);
+            HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + 64));
+            HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
+            HIP_TRY(c, B.inflate_scratch.ensure(bgzf_inflate_scratch_bytes(kBgzfMaxGrid)));
+            HIP_TRY(c, B.inflate_status.ensure(6));
+            HIP_TRY(c, B.h_inflate_status.ensure(2));
+            HIP_TRY(c, hipMemcpyAsync(B.comp[b].p, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipMemsetAsync(B.comp[b].p + src_bytes, 0, 16, c->copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
+                                      c->copy_stream));
+            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b, 0, 4, c->copy_stream));
+            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b + 1u, 0xff, 4, c->copy_stream));
+            launch_bgzf_inflate(c->copy_stream, B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - skip, B.inflate_scratch.p, grid,
+                                B.inflate_status.p + 2u * b);
+            HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+        }
     }
     if (B.pending) {  // ... while the window before is worked on
         uint64_t got = 0;
@@ -1106,6 +1173,7 @@ int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, i
     if (n_records) *n_records = total;
     return SLIMM_OK;
 }
+}  // namespace
 
 int slimm_push_wait(slimm_ctx* c) {
     if (!c) return SLIMM_E_INVALID;

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+#include <vector>
+
 // "This value is in a vector register HERE": an empty asm statement that takes and returns it.  It costs nothing and
 // gives a loaded value a use the compiler can neither move nor remove -- without one, a read-only load whose only uses
 // sit in a conditional block is sunk into that block, and the loads a kernel issued together come back one at a time.
@@ -273,6 +276,22 @@ void launch_bam_find(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t
 void launch_bam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t end, const BamPiece* pieces, const uint32_t* offs,
                        BamCarry* carry, const BamWindowResult* result, bool marked, uint64_t out_at, uint64_t* key, int32_t* ref,
                        int32_t* pos, uint16_t* flag, uint32_t* check);
+
+// ---- bgzf_inflate.hip: BGZF blocks (DEFLATE streams of <= 64 KB) inflated on the device, a lane per block ----
+struct BgzfBlock {
+    uint64_t src, dst;     // the DEFLATE payload's offset in the compressed bytes; where its output goes
+    uint32_t csize, isize; // payload bytes; inflated bytes (the gzip trailer's ISIZE)
+    uint32_t crc, pad;     // the gzip trailer's CRC32 of the inflated bytes
+};
+constexpr uint32_t kBgzfMaxGrid = 512;   // waves of a launch (two per CU: 70 KB of LDS each)
+uint32_t bgzf_inflate_grid(uint32_t n_blocks);
+size_t bgzf_inflate_scratch_bytes(uint32_t grid);
+// status[0] = the largest error code met (0: every block inflated to its ISIZE), status[1] = the first bad block (preset ~0)
+void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,
+                         uint32_t grid, uint32_t* status);
+// host: the descriptors of the whole BGZF blocks in bytes[0, n_bytes), outputs one behind the other from dst0 on
+bool bgzf_parse_blocks(const uint8_t* bytes, uint64_t n_bytes, uint64_t dst0, std::vector<BgzfBlock>& out, uint64_t& inflated,
+                       std::string& err);
 
 // ---- group_by_ident.hip: record_order = ANY -- the records of every read identity adjacent, file order kept among them ----
 // (stable counting passes over a few bits of a hash of the qName key, then a finish inside the small buckets of equal

@@ -252,6 +252,43 @@ class Slimm:
             total += got.value
         return total
 
+    def push_bgzf_blocks(self, blob, skip: int = 0, window: int = 0, host_every: int = 0) -> int:
+        """slimm_push_bgzf_blocks: whole BGZF blocks of a BAM file (compressed), the first of which holds the first alignment
+        record `skip` inflated bytes in; windows of about `window` compressed bytes (0: one), cut at block boundaries.  The
+        device inflates the blocks, finds the records and decodes them.  host_every = k > 0: every k-th window is inflated
+        HERE (zlib) and handed over through slimm_push_bam_bytes instead -- the two forms may alternate within a file.
+        Returns the number of records."""
+        import zlib
+        buf = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else np.ascontiguousarray(blob, dtype=np.uint8)
+        n = buf.shape[0]
+        cuts, p = [0], 0
+        while p < n:   # block boundaries: BSIZE - 1 is the BC subfield's value (the first extra subfield of the files handled here)
+            assert buf[p] == 0x1f and buf[p + 1] == 0x8b and buf[p + 12] == ord("B") and buf[p + 13] == ord("C"), "not a BGZF block"
+            p += int(buf[p + 16]) + (int(buf[p + 17]) << 8) + 1
+            if window == 0 or p - cuts[-1] >= window or p >= n:
+                cuts.append(p) if (window or p >= n) else None
+        if cuts[-1] != n:
+            cuts.append(n)
+        total, got, keep = 0, C.c_uint64(), []
+        if n == 0:
+            self._check(self.L.slimm_push_bgzf_blocks(self.ctx, None, 0, 0, 1, C.byref(got)))
+        for k in range(len(cuts) - 1):
+            piece = np.ascontiguousarray(buf[cuts[k]:cuts[k + 1]])
+            last = 1 if k == len(cuts) - 2 else 0
+            if host_every and k % host_every == host_every - 1:
+                raw, rest = bytearray(), piece.tobytes()
+                while rest:
+                    d = zlib.decompressobj(31)
+                    raw += d.decompress(rest)
+                    rest = d.unused_data
+                piece = np.frombuffer(bytes(raw[(skip if k == 0 else 0):]), dtype=np.uint8)
+                self._check(self.L.slimm_push_bam_bytes(self.ctx, _p(piece) if piece.size else None, piece.size, last, C.byref(got)))
+            else:
+                self._check(self.L.slimm_push_bgzf_blocks(self.ctx, _p(piece), piece.size, skip if k == 0 else 0, last, C.byref(got)))
+            keep = (keep + [piece])[-3:]   # (a window's buffer stays until the next call has returned)
+            total += got.value
+        return total
+
     def push_wait(self):
         self._check(self.L.slimm_push_wait(self.ctx))
 

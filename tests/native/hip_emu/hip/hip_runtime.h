@@ -173,6 +173,11 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
 // the lane's bit of a wave-uniform mask: a v_cndmask on the GPU, no exchange between lanes (so it may sit inside
 // divergent code, which the lock-step model cannot order against collectives outside the branch)
 static inline bool __builtin_amdgcn_inverse_ballot_w64(uint64_t mask) { return (mask >> ::hipemu::g_lane) & 1u; }
+static inline uint32_t __builtin_bitreverse32(uint32_t v) {
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
 static inline uint64_t __builtin_bitreverse64(uint64_t v) {
     uint64_t r = 0;
     for (int i = 0; i < 64; ++i) r |= ((v >> i) & 1ull) << (63 - i);

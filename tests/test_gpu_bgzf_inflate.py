@@ -1,0 +1,174 @@
+"""BGZF blocks inflated on the device (slimm_amd/csrc/bgzf_inflate.hip; include/slimm_hip.h: slimm_bgzf_inflate) against zlib:
+what seqan::BamFileIn does for the reference before a record is seen (call sites src/misc.hpp:498-522, src/slimm.hpp:194-208).
+Every DEFLATE block type, every compression level's code shapes, empty and full-size blocks, and corrupt input."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from slimm_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def bgzf_block(data: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, raw=None) -> bytes:
+    assert len(data) <= 65536
+    if raw is None:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+        raw = c.compress(data) + c.flush()
+    bsize = 12 + 6 + len(raw) + 8
+    assert bsize <= 65536, bsize    # (BSIZE - 1 is a 16-bit field)
+    head = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, (bsize - 1) & 0xffff)
+    return head + raw + struct.pack("<II", zlib.crc32(data) & 0xffffffff, len(data))
+
+
+def device_inflate(blob: bytes, cap=None):
+    L = capi.lib()
+    L.slimm_bgzf_inflate.restype = C.c_int
+    src = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(0, dtype=np.uint8)
+    cap = (1 << 26) if cap is None else cap
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_uint64()
+    ms = C.c_double()
+    err = C.create_string_buffer(256)
+    rc = L.slimm_bgzf_inflate(0, src.ctypes.data_as(C.c_void_p), C.c_uint64(len(blob)), out.ctypes.data_as(C.c_void_p), C.c_uint64(cap),
+                              C.byref(n), C.byref(ms), err, C.c_uint64(256))
+    return rc, bytes(out[:n.value]) if rc == 0 else b"", err.value.decode(), ms.value
+
+
+def payloads(rng):
+    bam_like = b"".join(struct.pack("<iiiBBHHHIiii", 200 + k % 7, k % 50, 1000 * k, 9, 30, 4680, 1, 0, 100, -1, -1, 0) + b"read%05d\0" % (k // 3)
+                        + bytes(50) + b"\x28" * 100 for k in range(300))
+    return [b"", b"a", b"abc" * 7, bytes(1000), bytes(rng.integers(0, 256, 3000, dtype=np.uint8)),      # tiny, runs, incompressible
+            bytes(rng.integers(0, 4, 65280, dtype=np.uint8)), bam_like[:65280], b"ACGT" * 16320,
+            bytes(rng.integers(0, 256, 64000, dtype=np.uint8)),                                            # stored by zlib
+            (b"x" * 300 + bytes(rng.integers(0, 256, 40, dtype=np.uint8))) * 150,
+            # matches that overlap themselves at every distance below 8 (the pattern-repeating copy), of all lengths
+            b"".join((b"abcdefg"[:d] * (3 + k % 60))[:3 + (k * 7) % 300] + bytes([k % 251]) for k in range(400) for d in range(1, 8))[:65000]]
+
+
+def test_every_block_type_and_level_equals_zlib():
+    rng = np.random.default_rng(5)
+    blocks, want = [], []
+    for data in payloads(rng):
+        for level, strat in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY),
+                             (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+            blocks.append(bgzf_block(data, level, strat))
+            want.append(data)
+    # several DEFLATE blocks in one BGZF block (Z_FULL_FLUSH in the middle), and the empty end-of-file block
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    a, b = b"hello world " * 500, bytes(rng.integers(0, 9, 20000, dtype=np.uint8))
+    raw = c.compress(a) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(b) + c.flush()
+    blocks.append(bgzf_block(a + b, raw=raw))
+    want.append(a + b)
+    blocks.append(bgzf_block(b""))
+    want.append(b"")
+    rc, got, err, _ = device_inflate(b"".join(blocks))
+    assert rc == 0, err
+    assert got == b"".join(want)
+    # one at a time too (a lane's tables must not depend on what another block left behind)
+    for blk, w in zip(blocks[::5], want[::5]):
+        rc, got, err, _ = device_inflate(blk)
+        assert rc == 0 and got == w, err
+
+
+def test_many_blocks_more_than_resident_lanes():
+    """More blocks than the 512 x 64 lanes of a launch: every lane takes several, its scratch and tables are reused."""
+    rng = np.random.default_rng(6)
+    pool = [bytes(rng.integers(0, 1 + k % 200, 900 + 37 * (k % 23), dtype=np.uint8)) for k in range(97)]
+    n = 40_000
+    blob = b"".join(bgzf_block(pool[k % 97], 1 + k % 9) for k in range(97))   # (97 distinct blocks, repeated)
+    blocks = [bgzf_block(pool[k], 1 + k % 9) for k in range(97)]
+    blob = b"".join(blocks[k % 97] for k in range(n))
+    rc, got, err, _ = device_inflate(blob)
+    assert rc == 0, err
+    assert got == b"".join(pool[k % 97] for k in range(n))
+
+
+def test_corrupt_blocks_are_errors_not_output():
+    rng = np.random.default_rng(7)
+    data = bytes(rng.integers(0, 20, 30000, dtype=np.uint8))
+    good = bgzf_block(data)
+    rc, got, err, _ = device_inflate(good)
+    assert rc == 0 and got == data
+    # ISIZE that does not fit the stream (shorter and longer), a flipped byte in the middle of the codes, a reserved block type
+    bad = [good[:-4] + struct.pack("<I", len(data) - 1), good[:-4] + struct.pack("<I", len(data) + 1)]
+    flip = bytearray(good)
+    flip[18 + 3] ^= 0x55
+    bad.append(bytes(flip))
+    bad.append(bgzf_block(b"zzz", raw=b"\x07" + bytes(8)))            # BFINAL, BTYPE = 3
+    bad.append(bgzf_block(b"abc", raw=b"\x01\x03\x00\xfc\xfe" + b"abc"))   # stored: LEN / NLEN do not complement
+    for blk in bad:
+        rc, got, err, _ = device_inflate(good + blk + good)
+        assert rc != 0 and "corrupt BGZF block" in err and "block 1" in err, (rc, err)
+    # not BGZF at all / cut in the middle of a block / an output buffer too small
+    assert device_inflate(b"\x1f\x8b\x08\x00" + bytes(40))[0] != 0
+    rc, _, err, _ = device_inflate(good[:len(good) // 2])
+    assert rc != 0 and "truncated" in err
+    rc, _, err, _ = device_inflate(good, cap=100)
+    assert rc != 0 and "too small" in err
+
+
+def _bam_file(tmp_path, w, names, seed, level=6):
+    """A BAM file of this repository's writer + where its alignment records start: (compressed bytes of the blocks from the
+    first record-bearing one on, inflated bytes to skip there, the records' bytes)."""
+    import gzip
+    from tests.bam_io import bam_record_bytes, write_bam
+    from slimm_amd.workload import Records
+    r = w.records
+    rec = Records(r.read_key, r.flag, r.ref_id, r.begin_pos, names)
+    p = str(tmp_path / f"f{seed}.bam")
+    write_bam(p, w.ref_names, w.ref_len, rec, read_len=w.avg_read_len, irregular_seed=seed)
+    want = bam_record_bytes(rec, read_len=w.avg_read_len, irregular_seed=seed)
+    blob = open(p, "rb").read()
+    # walk the blocks: inflated offset of every block; the records are the file's last len(want) inflated bytes
+    offs, p0, total = [], 0, 0
+    while p0 < len(blob):
+        bsize = blob[p0 + 16] + (blob[p0 + 17] << 8) + 1
+        isize = struct.unpack("<I", blob[p0 + bsize - 4:p0 + bsize])[0]
+        offs.append((p0, total))
+        total += isize
+        p0 += bsize
+    start = total - len(want)
+    k = max(i for i, (_, t) in enumerate(offs) if t <= start)
+    return blob[offs[k][0]:], start - offs[k][1], want, rec
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_records_from_compressed_blocks_equal_the_oracle(tmp_path, grouped):
+    """slimm_push_bgzf_blocks: the file's BGZF blocks go to the device as they are -- inflate, record boundaries, fields, names
+    all happen there -- in one window, in small windows, and alternating with windows the host inflated
+    (slimm_push_bam_bytes): the same records, the oracle's profile."""
+    from oracle.binding import run_workload
+    from slimm_amd.profiler import Slimm
+    from slimm_amd.synth import CONFIGS, make_workload
+    from slimm_amd.workload import Records, Workload
+    from tests.helpers import assert_matches_oracle
+    w = make_workload(CONFIGS["config2"], seed=71, n_records=60_000)
+    r = w.records
+    names = ["q%x" % k + "n" * int(k % 19) for k in r.read_key.tolist()]
+    if not grouped:
+        order = np.random.default_rng(2).permutation(len(r))
+        r = Records(r.read_key[order], r.flag[order], r.ref_id[order], r.begin_pos[order])
+        names = [names[i] for i in order]
+        w = Workload(w.ref_names, w.ref_len, w.taxonomy, r, w.avg_read_len, w.options, "any", grouped=False)
+    blocks, skip, want, rec = _bam_file(tmp_path, w, names, seed=9)
+    assert skip > 0 and len(blocks) < len(want)
+    wq = Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, "bam", grouped=grouped)
+    o = run_workload(wq, use_qnames=True)
+    for window, host_every in ((0, 0), (200_000, 0), (70_000, 2), (70_000, 3), (1, 0)):
+        s = Slimm.for_workload(wq, device=0, grouped=grouped)
+        assert s.push_bgzf_blocks(blocks, skip=skip, window=window, host_every=host_every) == len(rec)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+        s.close()
+    # a corrupt block in the middle of the file: an error of the push, nothing decoded from it
+    bad = bytearray(blocks)
+    bad[len(bad) // 2] ^= 0x40
+    s = Slimm.for_workload(wq, device=0, grouped=grouped)
+    with pytest.raises(capi.SlimmError) as e:
+        s.push_bgzf_blocks(bytes(bad), skip=skip, window=150_000)
+    assert "BGZF" in str(e.value) or "BAM record" in str(e.value)
+    s.close()

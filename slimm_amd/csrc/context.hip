@@ -154,6 +154,8 @@ struct slimm_ctx {
         DevBuf<uint32_t> inflate_status;       // 2 words per buffer
         PinBuf<uint32_t> h_inflate_status;     // ... fetched with the window's other results
         bool inflated[3] = {false, false, false};
+        hipStream_t inflate_stream = nullptr;  // the inflate kernel's own: the copies of other windows go on beside it
+        hipEvent_t comp_copied = nullptr;
         std::vector<BgzfBlock> desc_host[3];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
@@ -674,6 +676,11 @@ void slimm_destroy(slimm_ctx* c) {
             (void)hipStreamSynchronize(c->side_stream);
             (void)hipStreamDestroy(c->side_stream);
         }
+        if (c->bam.inflate_stream) {
+            (void)hipStreamSynchronize(c->bam.inflate_stream);
+            (void)hipStreamDestroy(c->bam.inflate_stream);
+        }
+        if (c->bam.comp_copied) (void)hipEventDestroy(c->bam.comp_copied);
         if (c->front_done) (void)hipEventDestroy(c->front_done);
         if (c->prefix_done) (void)hipEventDestroy(c->prefix_done);
         if (c->copy_stream) {
@@ -1124,8 +1131,9 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         }
         B.inflated[b] = compressed;
         if (compressed) {
-            // the compressed bytes and the block descriptors go over the bus, and the inflate runs behind them on the copy
-            // stream -- beside the kernels that work on the window before, like a plain window's copy does
+            // the compressed bytes and the block descriptors go over the bus, and the inflate runs behind them on a stream of
+            // its own -- beside the kernels that work on the window before AND beside the copies of the windows that follow
+            // (the scratch is shared: two inflates never overlap, they are on one stream)
             const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size()), grid = bgzf_inflate_grid(nblk);
             HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + 64));
             HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
@@ -1138,9 +1146,15 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
                                       c->copy_stream));
             HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b, 0, 4, c->copy_stream));
             HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b + 1u, 0xff, 4, c->copy_stream));
-            launch_bgzf_inflate(c->copy_stream, B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - skip, B.inflate_scratch.p, grid,
+            if (!B.inflate_stream) {
+                HIP_TRY(c, hipStreamCreateWithFlags(&B.inflate_stream, hipStreamNonBlocking));
+                HIP_TRY(c, hipEventCreateWithFlags(&B.comp_copied, hipEventDisableTiming));
+            }
+            HIP_TRY(c, hipEventRecord(B.comp_copied, c->copy_stream));
+            HIP_TRY(c, hipStreamWaitEvent(B.inflate_stream, B.comp_copied, 0));
+            launch_bgzf_inflate(B.inflate_stream, B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - skip, B.inflate_scratch.p, grid,
                                 B.inflate_status.p + 2u * b);
-            HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+            HIP_TRY(c, hipEventRecord(B.copied[b], B.inflate_stream));
         } else {
             HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));

@@ -760,6 +760,62 @@ void AlignmentFile::separate_adjacent_names(uint64_t* key, const std::vector<siz
 // The inflated record bytes window by window (read_raw in the header).  The windows the header parse left behind come
 // first (what is unread of the decoded window, then the window the prefetch thread was inflating); from then on whole
 // BGZF blocks are inflated straight into the caller's buffer, as many as fit.
+long AlignmentFile::read_blocks(uint8_t* dst, size_t cap, size_t max_inflated, size_t* inflated) {
+    if (inflated) *inflated = 0;
+    if (!bam_ || !dst || !inflated || raw_stage_ != 2 || !map_) {
+        err_ = "read_blocks: only behind read_raw, on a mapped BAM file";
+        return -1;
+    }
+    if (eof_) return 0;
+    StageClock clk(ms_read_);
+    size_t p = map_pos_, out = 0, inf = 0;
+    while (map_size_ - p >= 18) {
+        const uint8_t* hdr = map_ + p;
+        if (hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
+            err_ = "not a BGZF block";
+            return -1;
+        }
+        const size_t xlen = rd_u16(hdr + 10);
+        if (map_size_ - p < 12 + xlen) break;
+        int bsize = -1;
+        for (size_t o = 0; o + 4 <= xlen;) {
+            const uint8_t* x = hdr + 12 + o;
+            const uint16_t slen = rd_u16(x + 2);
+            if (x[0] == 'B' && x[1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = rd_u16(x + 4);
+            o += 4 + slen;
+        }
+        if (bsize < 0) {
+            err_ = "BGZF block without BC field";
+            return -1;
+        }
+        const size_t total = static_cast<size_t>(bsize) + 1;
+        if (total < 12u + xlen + 8u) {
+            err_ = "bad BGZF block size";
+            return -1;
+        }
+        if (map_size_ - p < total) break;
+        const uint32_t isize = rd_u32(map_ + p + total - 4);
+        if (isize > 65536u) {
+            err_ = "bad BGZF block size";
+            return -1;
+        }
+        if (out + total > cap || inf + isize > max_inflated) break;
+        out += total;
+        inf += isize;
+        p += total;
+    }
+    if (out == 0 && p != map_size_) {
+        err_ = map_size_ - p < 18 ? "truncated BGZF header" : "truncated BGZF block";
+        return -1;
+    }
+    memcpy(dst, map_ + map_pos_, out);
+    map_pos_ = p;
+    ++n_windows_;
+    if (map_pos_ == map_size_) eof_ = true;
+    *inflated = inf;
+    return static_cast<long>(out);
+}
+
 long AlignmentFile::read_raw(uint8_t* dst, size_t cap) {
     if (!bam_ || !dst || cap < (1u << 20)) {
         err_ = "read_raw: a BAM file and a buffer of at least 1 MiB";

@@ -75,6 +75,12 @@ public:
     // are then found and decoded on the device).  Returns the bytes written (whole BGZF blocks, at most `cap`), 0 at the
     // end of the file, -1 + error() on a format error.  Not to be mixed with read_batch / read_into afterwards.
     long read_raw(uint8_t* dst, size_t cap);
+    // ... or, once read_raw has reached the part of the file it reads in place (can_read_blocks()), the next whole BGZF
+    // blocks as they lie in the file, COMPRESSED (for slimm_push_bgzf_blocks: the device inflates them): at most `cap`
+    // bytes that inflate to at most `max_inflated`; *inflated = what they inflate to.  Returns the bytes written, 0 at the
+    // end of the file, -1 + error().  Calls of the two kinds may alternate.
+    long read_blocks(uint8_t* dst, size_t cap, size_t max_inflated, size_t* inflated);
+    bool can_read_blocks() const { return raw_stage_ == 2 && map_ != nullptr && !eof_; }
     // after a read_raw that returned bytes: nothing will follow them (false may also mean "not known yet")
     bool raw_exhausted() const { return raw_stage_ == 2 ? eof_ : (raw_stage_ == 1 && eof_ && raw_off_ >= spare_.size()); }
 

@@ -352,3 +352,65 @@ def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_
     assert "device decode" in err and "decoding on the host" not in err
     o2 = Oracle(big.taxonomy, big.options).run(big.ref_names, big.ref_len, big.records, big.avg_read_len, want_raw=True, want_cov=False)
     check_outputs(out2, "many", o2, coverage=False)
+
+
+@pytest.mark.parametrize("order", ["grouped", "anyorder"])
+def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
+    """BAM input on one GPU: of the windows the reader takes straight from the mapped file, a share goes to the device
+    COMPRESSED (slimm_push_bgzf_blocks: inflate, CRC, record boundaries, fields, names all there) and alternates with windows
+    the host cores inflated (slimm_push_bam_bytes).  Whatever the share -- none, the default, every window -- the same
+    files, equal to the oracle's."""
+    import re
+    w = with_names(make_workload(CONFIGS["config2"], seed=53, n_records=400_000))
+    rec, hd = w.records, "@HD\tVN:1.6\tSO:unsorted\tGO:query"
+    if order == "anyorder":
+        perm = np.random.default_rng(4).permutation(len(rec))
+        sh = rec.take(perm)
+        rec, hd = Records(sh.read_key, sh.flag, sh.ref_id, sh.begin_pos, [w.records.qname[i] for i in perm]), "@HD\tVN:1.6\tSO:unsorted"
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / "in.bam")
+    # (records of irregular sizes with random sequences and qualities: the file hardly compresses, so most of it lies behind
+    # the windows the reader has inflated before the command takes over; the command samples its average read length from
+    # the file, src/misc.hpp:509-522)
+    from tests.bam_io import bam_record_bytes
+    write_bam(inp, w.ref_names, w.ref_len, rec, read_len=w.avg_read_len, hd=hd, irregular_seed=11)
+    data = bam_record_bytes(rec, read_len=w.avg_read_len, irregular_seed=11)
+    lens, at = [], 0
+    while at < len(data) and len(lens) < 100_000:
+        l_seq = int.from_bytes(data[at + 20:at + 24], "little")
+        if l_seq:
+            lens.append(l_seq)
+        at += 4 + int.from_bytes(data[at:at + 4], "little")
+    avg = sum(lens) // len(lens)
+    want = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, rec, avg, want_raw=True, want_cov=False)
+    outs, shares = [], []
+    for tenths in ("0", None, "10", "3"):
+        out = str(tmp_path / f"out_{tenths}") + "/"
+        os.makedirs(out)
+        env = dict(os.environ, SLIMM_CLI_TRACE="1", SLIMM_CLI_WINDOW_MB="2")
+        env.pop("SLIMM_CLI_DEVICE_INFLATE", None)
+        if tenths is not None:
+            env["SLIMM_CLI_DEVICE_INFLATE"] = tenths
+        err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", db, inp], env=env)
+        m = re.search(r"(\d+) were inflated on the host, (\d+) on the device", err)
+        assert m, err[-1500:]
+        shares.append((int(m.group(1)), int(m.group(2))))
+        outs.append({f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))})
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    check_outputs(str(tmp_path / "out_0") + "/", "in", want, coverage=False)
+    (h0, d0), (h1, d1), (h2, d2), (h3, d3) = shares
+    # none / all of the windows read in place (the call that finds itself behind the reader's own windows inflates: <= 2)
+    assert d0 == 0 and h0 > 10 and h2 <= 2 and d2 > 10
+    assert d1 > 0 and h1 > 0 and abs(d1 * 10 - (4 if order == "grouped" else 5) * (h1 + d1)) <= 25
+    assert abs(d3 * 10 - 3 * (h3 + d3)) <= 25
+    # a flipped byte in a record's sequence (far into the file: a window read in place): the CRC says so, wherever the
+    # block is inflated
+    blob = bytearray(open(inp, "rb").read())
+    blob[len(blob) * 3 // 4] ^= 0x10
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(blob))
+    for tenths in ("0", "10"):
+        r = subprocess.run([CLI, "-w", "1000", "-o", str(tmp_path / "bad_") , db, bad], capture_output=True, text=True,
+                           env=dict(os.environ, SLIMM_CLI_WINDOW_MB="2", SLIMM_CLI_DEVICE_INFLATE=tenths))
+        assert r.returncode != 0 and "BGZF" in r.stderr, r.stderr[-800:]

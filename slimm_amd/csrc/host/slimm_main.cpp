@@ -472,11 +472,15 @@ struct RecordPump {
         bool last = false;   // the reader knows that nothing follows
         bool compressed = false;  // the bytes are whole BGZF blocks as they lie in the file: the device inflates them
     };
-    // Of the windows the reader takes straight from the mapped file, this many of every ten are handed over COMPRESSED
-    // (slimm_push_bgzf_blocks): the device inflates at 33 - 38 GB/s, the host cores at 30 - 55 GB/s with 54 GB/s of PCIe
-    // behind them -- both at once is the faster pipe, and the compressed windows cost the bus a twentieth.  SLIMM_CLI_DEVICE_INFLATE
-    // = 0 .. 10 overrides (0: every window inflated on the host, rounds 1 - 4's way; 10: every window on the device).
-    unsigned device_tenths = 4;
+    // Of the windows the reader takes straight from the mapped file, SLIMM_CLI_DEVICE_INFLATE = 1 .. 10 of every ten are handed
+    // over COMPRESSED (slimm_push_bgzf_blocks: the device inflates them on a stream of its own, beside the copies of the
+    // windows the host cores inflated).  Off by default: the inflate kernel is a lane per BGZF block, and a window of 192 MB
+    // holds 2 900 blocks -- 9 % of the lanes a launch can keep busy --, so a window takes the 20 ms ONE block takes (a launch
+    // with every lane busy inflates 38 GB/s, this way 10): measured on the 100 M-record file, 0 / 3 / 5 / 10 tenths on the
+    // device: 0.94 / 1.33 / 1.72 / 2.64 s (unsorted copy: 1.14 / 1.74 / 2.37 / 3.90 s).  What it takes to win: device
+    // windows of 2 GB (32 K blocks) with a ring of more than three window buffers around them, or a kernel that shares a
+    // block among the lanes of a wave.
+    unsigned device_tenths = 0;
     uint64_t raw_windows_device = 0, raw_windows_host = 0;
     // (mapped with MADV_HUGEPAGE where the kernel grants it: 192 MB in 4 KB pages are 49 K page faults to fill and as many
     // pages to give back when the process leaves -- a quarter second of a one-second run over the four buffers)
@@ -504,7 +508,6 @@ struct RecordPump {
           raw(device_decode && f.is_bam() && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") &&
               !getenv("SLIMM_CLI_HOST_DECODE")) {
         if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) device_tenths = static_cast<unsigned>(std::min(10l, std::max(0l, atol(e))));
-        else if (check_words) device_tenths = 5;  // (names in no particular order compress worse: the host cores are the slower side)
         th = std::thread([this] { raw ? run_raw() : run(); });  // (in the body: every member is initialised by now)
     }
     ~RecordPump() {

@@ -24,6 +24,7 @@ for e in 1 2; do
   python3 scripts/gaps.py $O/gaps$e/t_kernel_trace.csv 3 >> $O/config2_engines.txt; rm -rf $O/gaps$e
 done
 bash scripts/host_trace.sh $TAG/ht > $O/host_trace.txt 2>&1; rm -rf $O/ht
+python3 scripts/inflate_rate.py 1000000 10 > $O/inflate_rate.txt 2>&1
 python3 scripts/cli_e2e.py 100000000 config3 > $O/cli_100m_trace.txt 2>&1
 python3 scripts/cli_exit_modes.py > $O/cli_100m_exit_modes.txt 2>&1
 python3 -m pytest tests -m gpu -q > $O/gpu_tests.txt 2>&1

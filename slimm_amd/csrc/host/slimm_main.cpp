@@ -477,8 +477,8 @@ struct RecordPump {
     // windows the host cores inflated).  Off by default: the inflate kernel is a lane per BGZF block, and a window of 192 MB
     // holds 2 900 blocks -- 9 % of the lanes a launch can keep busy --, so a window takes the 20 ms ONE block takes (a launch
     // with every lane busy inflates 38 GB/s, this way 10): measured on the 100 M-record file, 0 / 3 / 5 / 10 tenths on the
-    // device: 0.94 / 1.33 / 1.72 / 2.64 s (unsorted copy: 1.14 / 1.74 / 2.37 / 3.90 s).  What it takes to win: device
-    // windows of 2 GB (32 K blocks) with a ring of more than three window buffers around them, or a kernel that shares a
+    // device: 0.94 / 1.33 / 1.72 / 2.64 s (unsorted copy: 1.14 / 1.74 / 2.37 / 3.90 s).  What it takes to win: the file's
+    // tail inflated in the background in launches of 2 GB while the head goes the host's way, or a kernel that shares a
     // block among the lanes of a wave.
     unsigned device_tenths = 0;
     uint64_t raw_windows_device = 0, raw_windows_host = 0;

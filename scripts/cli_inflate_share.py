@@ -1,6 +1,7 @@
-"""The `slimm` command on a 100 M-record BAM with 0 .. 10 tenths of the windows read in place inflated on the DEVICE
-(SLIMM_CLI_DEVICE_INFLATE), for the name-grouped file and for the same records in no particular order (GPU box).
-    python scripts/cli_inflate_share.py [records] [shares, e.g. 0,3,4,5,6,10]"""
+"""The `slimm` command on a 100 M-record BAM with one window in P of those read in place inflated on the DEVICE
+(SLIMM_CLI_DEVICE_INFLATE = P; 0 = none; a device window is ten host windows large), for the name-grouped file and for the
+same records in no particular order (GPU box).
+    python scripts/cli_inflate_share.py [records] [periods, e.g. 0,16,12,9,6]"""
 import hashlib, os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +9,7 @@ from slimm_amd.synth import CONFIGS, make_workload
 from slimm_amd.synth_bam import write_synthetic_bam
 from tests.bam_io import write_sldb
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
-shares = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,3,4,5,6,10").split(",")]
+shares = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,16,12,9,6").split(",")]
 cfg = CONFIGS["config3"]
 w = make_workload(cfg, seed=1, n_records=n)
 tmp = tempfile.mkdtemp(prefix="slimm_share_")
@@ -48,6 +49,6 @@ for what in ("grouped", "unsorted"):
             dd = [l for l in r.stderr.splitlines() if "device decode" in l]
             prof = [f for f in os.listdir(os.path.join(tmp, "out")) if f.endswith("_profile.tsv")]
             sha.add(hashlib.sha1(open(os.path.join(tmp, "out", prof[0]), "rb").read()).hexdigest()[:10])
-            print(f"{t:2d} tenths on the device: {dt:.3f} s wall -> {n / dt / 1e6:.1f} M records/s; {dd[-1][dd[-1].index('inflate'):] if dd else ''}", flush=True)
+            print(f"one window in {t:2d} on the device: {dt:.3f} s wall -> {n / dt / 1e6:.1f} M records/s; {dd[-1][dd[-1].index('inflate'):] if dd else ''}", flush=True)
     print("profiles:", sha, flush=True)
     os.unlink(bam)

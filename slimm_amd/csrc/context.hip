@@ -132,31 +132,36 @@ struct slimm_ctx {
     bool marked = false;           // slimm_push_records_marked: 8 bytes per record, no key array (grouped input only)
     // slimm_push_bam_bytes: BAM records decoded on the device (bam_decode.hip).  Two byte buffers [slack | window] take the
     // windows in turn; the incomplete record at a window's end is copied in front of the next window
+    // (the ring of window buffers: a window is copied -- or inflated -- into one while up to kBamLag older ones are still
+    // on their way or being decoded; three was the whole ring until the device inflate came: one window of 2 GB of BGZF
+    // blocks takes the inflater 50 ms, and a dozen host-inflated windows can cross the bus meanwhile)
+    static constexpr uint32_t kBamRing = 16, kBamLag = kBamRing - 2;
     struct BamDecode {
-        DevBuf<uint8_t> bytes[3];
+        DevBuf<uint8_t> bytes[kBamRing];
         DevBuf<BamPiece> pieces;
         DevBuf<uint32_t> offs;
         DevBuf<BamCarry> carry;
         PinBuf<BamWindowResult> result;     // written by k_bam_scan straight into page-locked host memory
         std::vector<std::pair<const uint8_t*, size_t>> registered;  // caller buffers page-locked by hipHostRegister
-        uint64_t windows = 0;               // of this file, pushed so far
+        uint64_t windows = 0;               // of this file, handed over so far
+        uint64_t head = 0;                  // ... of which [head, windows) are not finished yet (copied / inflating / waiting)
+        uint64_t win_bytes[kBamRing] = {};  // record bytes of the windows in flight
         uint64_t carry_bytes = 0;
-        bool active = false;                // this file's records come from slimm_push_bam_bytes
-        bool pending = false;               // the last window pushed is copied (or on its way) but not worked on yet
+        bool active = false;                // this file's records come from slimm_push_bam_bytes / slimm_push_bgzf_blocks
         bool closed = false;                // the file's last window went in
-        uint64_t pending_bytes = 0;
-        hipEvent_t copied[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t copied[kBamRing] = {};   // the window's bytes are in its buffer (behind the copy, or behind the inflate)
+        hipEvent_t h2d_done[kBamRing] = {}; // the caller's buffer has been read
         // windows that arrive as BGZF blocks (slimm_push_bgzf_blocks): compressed bytes + block descriptors per buffer, the
         // inflater's scratch and {error code, first bad block} per buffer; inflated[b]: that window was inflated here
-        DevBuf<uint8_t> comp[3];
-        DevBuf<BgzfBlock> desc[3];
+        DevBuf<uint8_t> comp[kBamRing];
+        DevBuf<BgzfBlock> desc[kBamRing];
         DevBuf<uint8_t> inflate_scratch;
         DevBuf<uint32_t> inflate_status;       // 2 words per buffer
         PinBuf<uint32_t> h_inflate_status;     // ... fetched with the window's other results
-        bool inflated[3] = {false, false, false};
+        bool inflated[kBamRing] = {};
         hipStream_t inflate_stream = nullptr;  // the inflate kernel's own: the copies of other windows go on beside it
         hipEvent_t comp_copied = nullptr;
-        std::vector<BgzfBlock> desc_host[3];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
+        std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
@@ -691,6 +696,8 @@ void slimm_destroy(slimm_ctx* c) {
         for (auto& r : c->bam.registered) (void)hipHostUnregister(const_cast<uint8_t*>(r.first));
         for (auto& e : c->bam.copied)
             if (e) (void)hipEventDestroy(e);
+        for (auto& e : c->bam.h2d_done)
+            if (e) (void)hipEventDestroy(e);
         for (auto& sg : c->staging)
             if (sg.done) (void)hipEventDestroy(sg.done);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -712,7 +719,8 @@ int slimm_reset(slimm_ctx* c) {
     c->bam.windows = 0;
     c->bam.carry_bytes = 0;
     c->bam.active = false;
-    c->bam.pending = c->bam.closed = false;
+    c->bam.head = 0;
+    c->bam.closed = false;
     c->has_check = false;
     c->packed = false;
     c->marked = false;
@@ -990,7 +998,7 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     slimm_ctx::BamDecode& B = c->bam;
     hipStream_t st = c->stream;
     const bool marked = c->order == SLIMM_ORDER_GROUPED;
-    const uint32_t b = static_cast<uint32_t>(j % 3u), nb = static_cast<uint32_t>((j + 1u) % 3u);
+    const uint32_t b = static_cast<uint32_t>(j % slimm_ctx::kBamRing), nb = static_cast<uint32_t>((j + 1u) % slimm_ctx::kBamRing);
     const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
     const uint32_t np = bam_pieces(end - lo);
     HIP_TRY(c, B.pieces.ensure(static_cast<size_t>(np) + 1));
@@ -1069,10 +1077,10 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         if (!bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
         std::string why;
         uint64_t inflated = 0;
-        std::vector<BgzfBlock>& dh = c->bam.desc_host[(c->bam.active ? c->bam.windows : 0) % 3u];
+        std::vector<BgzfBlock>& dh = c->bam.desc_host[(c->bam.active ? c->bam.windows : 0) % slimm_ctx::kBamRing];
         dh.clear();
         if (!bgzf_parse_blocks(bytes, src_bytes, 0, dh, inflated, why)) return fail(c, SLIMM_E_INVALID, "%s", why.c_str());
-        if (skip > inflated || (skip && c->bam.active && (c->bam.carry_bytes || c->bam.pending)))
+        if (skip > inflated || (skip && c->bam.active && c->bam.windows > 0))
             return fail(c, SLIMM_E_INVALID, "skip: only in front of a file's first records");
         if (dh.size() >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "too many blocks in one window");
         n_bytes = inflated - skip;
@@ -1097,8 +1105,8 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
     if (!B.active) {  // a file's first window
         B.active = true;
         B.windows = 0;
+        B.head = 0;
         B.carry_bytes = 0;
-        B.pending = false;
         c->marked = marked;
         c->has_check = !marked;
         c->packed = false;
@@ -1106,18 +1114,20 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         HIP_TRY(c, B.result.ensure(1));
         for (auto& e : B.copied)
             if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : B.h2d_done)
+            if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_TRY(c, hipMemsetAsync(B.carry.p, 0, sizeof(BamCarry), st));
     }
     if (B.closed) return fail(c, SLIMM_E_INVALID, "the file's last window has been pushed; reset first");
     uint64_t total = 0;
     if (n_bytes) {  // this window's bytes start on their way ...
-        const uint32_t b = static_cast<uint32_t>(B.windows % 3u);
+        const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
         const uint64_t need = kBamSlack + n_bytes + 64;
         if (B.bytes[b].cap < need) {
-            // (what the buffer held -- window j - 3 -- is done with: its kernels ran before the synchronisation of the call
-            // before this one.  Only the carried bytes in its slack matter, and only when nothing is pending: with a window
-            // pending they are put there further down, by that window's own end)
-            if (!B.pending && B.carry_bytes) {
+            // (what the buffer held -- the window a ring's length back -- is done with: it was finished before this one was
+            // let in.  Only the carried bytes in its slack matter, and only when the window before this one is finished
+            // already: otherwise its end will put them there later)
+            if (B.head == B.windows && B.carry_bytes) {
                 DevBuf<uint8_t> nb;
                 HIP_TRY(c, nb.ensure(need + (need >> 2)));
                 HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[b].p + kBamSlack - B.carry_bytes, B.carry_bytes,
@@ -1138,9 +1148,10 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + 64));
             HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
             HIP_TRY(c, B.inflate_scratch.ensure(bgzf_inflate_scratch_bytes(kBgzfMaxGrid)));
-            HIP_TRY(c, B.inflate_status.ensure(6));
+            HIP_TRY(c, B.inflate_status.ensure(2u * slimm_ctx::kBamRing));
             HIP_TRY(c, B.h_inflate_status.ensure(2));
             HIP_TRY(c, hipMemcpyAsync(B.comp[b].p, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipEventRecord(B.h2d_done[b], c->copy_stream));
             HIP_TRY(c, hipMemsetAsync(B.comp[b].p + src_bytes, 0, 16, c->copy_stream));
             HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
                                       c->copy_stream));
@@ -1158,31 +1169,28 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         } else {
             HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+            HIP_TRY(c, hipEventRecord(B.h2d_done[b], c->copy_stream));
         }
+        B.win_bytes[b] = n_bytes;
+        ++B.windows;
     }
-    if (B.pending) {  // ... while the window before is worked on
+    // ... while the windows before are worked on: the oldest are finished (found, counted, decoded) once more than kBamLag
+    // are in flight -- all of them when this is the file's end
+    const bool had_any = B.head < B.windows;
+    while (B.head < B.windows && (last || B.windows - B.head > slimm_ctx::kBamLag)) {
         uint64_t got = 0;
-        int rc = bam_finish_window(c, B.windows - 1u, B.pending_bytes, last && !n_bytes, got);
-        B.pending = false;
+        const uint64_t j = B.head;
+        const int rc = bam_finish_window(c, j, B.win_bytes[j % slimm_ctx::kBamRing], last && j + 1 == B.windows, got);
+        ++B.head;
         if (rc != SLIMM_OK) return rc;
         total += got;
     }
-    if (n_bytes) {
-        B.pending = true;
-        B.pending_bytes = n_bytes;
-        ++B.windows;
-    }
     if (last) {
-        if (B.pending) {
-            uint64_t got = 0;
-            int rc = bam_finish_window(c, B.windows - 1u, B.pending_bytes, true, got);
-            B.pending = false;
-            if (rc != SLIMM_OK) return rc;
-            total += got;
-        } else if (B.carry_bytes) {
-            return fail(c, SLIMM_E_INVALID, "truncated BAM record");
-        }
+        if (!had_any && B.carry_bytes) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
         B.closed = true;
+    } else if (B.windows >= 2) {
+        // the caller's buffer of the window BEFORE this one has been read (it may be reused once this call returns)
+        HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.windows - 2u) % slimm_ctx::kBamRing]));
     }
     if (n_records) *n_records = total;
     return SLIMM_OK;

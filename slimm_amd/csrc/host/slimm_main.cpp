@@ -472,15 +472,16 @@ struct RecordPump {
         bool last = false;   // the reader knows that nothing follows
         bool compressed = false;  // the bytes are whole BGZF blocks as they lie in the file: the device inflates them
     };
-    // Of the windows the reader takes straight from the mapped file, SLIMM_CLI_DEVICE_INFLATE = 1 .. 10 of every ten are handed
-    // over COMPRESSED (slimm_push_bgzf_blocks: the device inflates them on a stream of its own, beside the copies of the
-    // windows the host cores inflated).  Off by default: the inflate kernel is a lane per BGZF block, and a window of 192 MB
-    // holds 2 900 blocks -- 9 % of the lanes a launch can keep busy --, so a window takes the 20 ms ONE block takes (a launch
-    // with every lane busy inflates 38 GB/s, this way 10): measured on the 100 M-record file, 0 / 3 / 5 / 10 tenths on the
-    // device: 0.94 / 1.33 / 1.72 / 2.64 s (unsorted copy: 1.14 / 1.74 / 2.37 / 3.90 s).  What it takes to win: the file's
-    // tail inflated in the background in launches of 2 GB while the head goes the host's way, or a kernel that shares a
-    // block among the lanes of a wave.
-    unsigned device_tenths = 0;
+    // Of the windows the reader takes straight from the mapped file, one in SLIMM_CLI_DEVICE_INFLATE (a period; 0 = none) is
+    // handed over COMPRESSED (slimm_push_bgzf_blocks): the device inflates it on a stream of its own while the windows that
+    // follow -- inflated by the host cores -- cross the bus; the library keeps up to 14 windows in flight.  The inflate kernel
+    // is a lane per BGZF block and needs tens of thousands of blocks to fill the device, so a device window is LARGE:
+    // SLIMM_CLI_DEVICE_WINDOW_MB of inflated bytes (default: ten host windows = 1.9 GB = 29 K blocks; its compressed bytes
+    // fit a host window's buffer).  With the windows of 192 MB of round 4's first version (2 900 blocks: 9 % of the lanes, 20 ms
+    // each) every share of device windows LOST: 0 / 3 / 5 / 10 of ten on the device = 0.94 / 1.33 / 1.72 / 2.64 s on the
+    // 100 M-record file.
+    unsigned device_period = 0;
+    size_t device_window = 0;  // inflated bytes of a device window
     uint64_t raw_windows_device = 0, raw_windows_host = 0;
     // (mapped with MADV_HUGEPAGE where the kernel grants it: 192 MB in 4 KB pages are 49 K page faults to fill and as many
     // pages to give back when the process leaves -- a quarter second of a one-second run over the four buffers)
@@ -507,7 +508,10 @@ struct RecordPump {
           marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")),
           raw(device_decode && f.is_bam() && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") &&
               !getenv("SLIMM_CLI_HOST_DECODE")) {
-        if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) device_tenths = static_cast<unsigned>(std::min(10l, std::max(0l, atol(e))));
+        if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) device_period = static_cast<unsigned>(std::max(0l, atol(e)));
+        device_window = std::min<size_t>(10 * raw_cap(), 1900u << 20);
+        if (const char* e = getenv("SLIMM_CLI_DEVICE_WINDOW_MB"))
+            if (atol(e) > 0) device_window = std::min<size_t>(static_cast<size_t>(atol(e)) << 20, 1900u << 20);
         th = std::thread([this] { raw ? run_raw() : run(); });  // (in the body: every member is initialised by now)
     }
     ~RecordPump() {
@@ -538,13 +542,12 @@ struct RecordPump {
                 return;
             }
             auto t1 = std::chrono::steady_clock::now();
-            // (Bresenham over the windows read in place: device_tenths of every ten, spread evenly)
+            // (every device_period-th of the windows read in place)
             bool compressed = false;
             long n;
-            if (device_tenths && bam.can_read_blocks() &&
-                (raw_windows_device + 1) * 10 <= (raw_windows_device + raw_windows_host + 1) * device_tenths) {
+            if (device_period && bam.can_read_blocks() && (raw_windows_device + raw_windows_host) % device_period == device_period - 1u) {
                 size_t inflated = 0;
-                n = bam.read_blocks(raw_buf[w].get(), raw_cap(), raw_cap(), &inflated);
+                n = bam.read_blocks(raw_buf[w].get(), raw_cap(), device_window, &inflated);
                 compressed = true;
                 ++raw_windows_device;
             } else {

@@ -205,7 +205,8 @@ int slimm_push_bam_bytes(slimm_ctx* ctx, const uint8_t* bytes, uint64_t n_bytes,
  * cross the bus, a lane per block inflates them (slimm_amd/csrc/bgzf_inflate.hip; ISIZE, the DEFLATE blocks' form and
  * the CRC32 are checked), and the records are found and decoded as above.  Windows of this form and of
  * slimm_push_bam_bytes may alternate within a file (a host that inflates some windows itself and leaves the others to the
- * device keeps both busy); buffer lifetime, `last`, *n_records and the errors are those of slimm_push_bam_bytes, plus
+ * device keeps both busy: up to 14 windows are in flight; a lane inflates a block, so give this form windows of tens of
+ * thousands of blocks); buffer lifetime, `last`, *n_records and the errors are those of slimm_push_bam_bytes, plus
  * SLIMM_E_INVALID for anything that is not a BGZF block or does not inflate to its ISIZE. */
 int slimm_push_bgzf_blocks(slimm_ctx* ctx, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records);
 /* Page-locks a buffer of the caller (hipHostRegister) until the context is destroyed: copies out of it then run at the

@@ -472,15 +472,17 @@ struct RecordPump {
         bool last = false;   // the reader knows that nothing follows
         bool compressed = false;  // the bytes are whole BGZF blocks as they lie in the file: the device inflates them
     };
-    // Of the windows the reader takes straight from the mapped file, one in SLIMM_CLI_DEVICE_INFLATE (a period; 0 = none) is
-    // handed over COMPRESSED (slimm_push_bgzf_blocks): the device inflates it on a stream of its own while the windows that
-    // follow -- inflated by the host cores -- cross the bus; the library keeps up to 14 windows in flight.  The inflate kernel
-    // is a lane per BGZF block and needs tens of thousands of blocks to fill the device, so a device window is LARGE:
-    // SLIMM_CLI_DEVICE_WINDOW_MB of inflated bytes (default: ten host windows = 1.9 GB = 29 K blocks; its compressed bytes
-    // fit a host window's buffer).  With the windows of 192 MB of round 4's first version (2 900 blocks: 9 % of the lanes, 20 ms
-    // each) every share of device windows LOST: 0 / 3 / 5 / 10 of ten on the device = 0.94 / 1.33 / 1.72 / 2.64 s on the
-    // 100 M-record file.
-    unsigned device_period = 0;
+    // Of the windows the reader takes straight from the mapped file, one in SLIMM_CLI_DEVICE_INFLATE (a period; default 6, 0 =
+    // none) is handed over COMPRESSED (slimm_push_bgzf_blocks): the device inflates it on a stream of its own while the
+    // windows that follow -- inflated by the host cores -- cross the bus; the library keeps up to 14 windows in flight.  The
+    // inflate kernel is a lane per BGZF block and needs tens of thousands of blocks to fill the device, so a device window is
+    // LARGE: SLIMM_CLI_DEVICE_WINDOW_MB of inflated bytes (default: ten host windows = 1.9 GB = 29 K blocks; its compressed
+    // bytes fit a host window's buffer).  Measured on the 100 M-record file (scripts/cli_inflate_share.py, three boxes): no
+    // device windows 0.90 - 1.02 s, one in six 0.77 - 0.86 s (the push phase 380 - 415 -> 260 - 285 ms: two thirds of the
+    // bytes are inflated on the device, one third crosses the bus inflated); its unsorted copy 1.08 - 1.27 -> 1.02 - 1.10 s.
+    // (With device windows of 192 MB -- 2 900 blocks, 9 % of the lanes, 20 ms each -- every share of them LOST: 0 / 3 / 5 / 10
+    // of ten = 0.94 / 1.33 / 1.72 / 2.64 s.)
+    unsigned device_period = 6;
     size_t device_window = 0;  // inflated bytes of a device window
     uint64_t raw_windows_device = 0, raw_windows_host = 0;
     // (mapped with MADV_HUGEPAGE where the kernel grants it: 192 MB in 4 KB pages are 49 K page faults to fill and as many

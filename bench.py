@@ -851,8 +851,9 @@ def main():
                 dd = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "[trace] device decode" in ln][-1:]
                 cli = {"value": round(nb / best / 1e6, 3), "unit": "M records/s", "seconds": round(best, 3),
                        "what": f"`slimm -w 1000 DB IN.bam`, process start to profile written (HIP start-up, read-length sample, "
-                               f"BGZF inflate on the host cores, the inflated windows over PCIe, record boundaries + fields + "
-                               f"adjacent-name comparison on the device (slimm_push_bam_bytes), GPU path), {nb} records of config3, "
+                               f"BGZF inflate on the host cores for five windows in six -- they cross PCIe inflated -- and on the device "
+                               f"for the sixth, which is ten times their size (slimm_push_bgzf_blocks); record boundaries + fields + "
+                               f"adjacent-name comparison on the device, GPU path), {nb} records of config3, "
                                f"name-grouped, {info['raw_bytes'] / 1e9:.1f} GB of BAM records in {info['compressed_bytes'] / 1e9:.2f} GB; "
                                "best of 2",
                        "reader": trace[0] if trace else None, "device_decode": dd[0] if dd else None,

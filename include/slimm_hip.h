@@ -193,8 +193,8 @@ int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
  * slimm_pin_host_buffer -- the DMA engine reads it directly).  A window's copy is started by the call that hands it
  * over and runs beside the device's work on the window BEFORE it: the buffer must stay unchanged until the NEXT call on
  * this context returns (a call with last != 0 finishes everything), so hand over three or more buffers in rotation.
- * *n_records (may be NULL): records appended by this call -- those of the window before, and with last != 0 of this one
- * too.  last != 0: nothing follows (n_bytes may be 0) -- bytes of an incomplete record are then
+ * *n_records (may be NULL): records appended by this call -- those of the windows it finished: a window is found, counted and
+ * decoded once 14 later ones have been handed over (they are copied, or inflated, meanwhile), all of them with last != 0.  last != 0: nothing follows (n_bytes may be 0) -- bytes of an incomplete record are then
  * an error (SLIMM_E_INVALID, "truncated BAM record"), as is a malformed record in any window.  A record longer than
  * 16 MiB is not supported in this form (SLIMM_E_INVALID: decode such a file on the host).  The forms do not mix within
  * a file.  Replaces: seqan::readRecord in src/slimm.hpp:194-208 / src/misc.hpp:509-522. */

@@ -993,7 +993,7 @@ int slimm_pin_host_buffer(slimm_ctx* c, const void* p, uint64_t n_bytes) {
 // host-to-device copy then runs beside the kernels and the host's bookkeeping of the window before it -- the copies are
 // what bounds this path (192 MB at 54 GB/s: 3.6 ms; kernels + one synchronisation per window: 0.8 ms).
 namespace {
-// window j (n bytes, in buffer j % 3) -> records appended; the incomplete record at its end goes in front of window j + 1
+// window j (n bytes, in buffer j % kBamRing) -> records appended; the incomplete record at its end goes in front of window j + 1
 int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, uint64_t& n_rec_out) {
     slimm_ctx::BamDecode& B = c->bam;
     hipStream_t st = c->stream;

@@ -713,6 +713,12 @@ int slimm_reset(slimm_ctx* c) {
         c->copy_pending = false;
         for (auto& sg : c->staging) sg.pending = false;
     }
+    if (c->bam.active && c->bam.head < c->bam.windows) {  // a file abandoned with windows in flight (an error, a caller's
+        (void)hipSetDevice(c->device);                    // change of mind): their copies and inflates must not land in the
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream)); // next file's buffers
+        if (c->bam.inflate_stream) HIP_TRY(c, hipStreamSynchronize(c->bam.inflate_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     c->host->reset();
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;

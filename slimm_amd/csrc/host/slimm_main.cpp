@@ -483,6 +483,7 @@ struct RecordPump {
     // (With device windows of 192 MB -- 2 900 blocks, 9 % of the lanes, 20 ms each -- every share of them LOST: 0 / 3 / 5 / 10
     // of ten = 0.94 / 1.33 / 1.72 / 2.64 s.)
     unsigned device_period = 6;
+    bool device_forced = false;  // SLIMM_CLI_DEVICE_INFLATE is set: the caller's period holds whatever the file looks like
     size_t device_window = 0;  // inflated bytes of a device window
     uint64_t raw_windows_device = 0, raw_windows_host = 0;
     // (mapped with MADV_HUGEPAGE where the kernel grants it: 192 MB in 4 KB pages are 49 K page faults to fill and as many
@@ -510,7 +511,10 @@ struct RecordPump {
           marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")),
           raw(device_decode && f.is_bam() && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") &&
               !getenv("SLIMM_CLI_HOST_DECODE")) {
-        if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) device_period = static_cast<unsigned>(std::max(0l, atol(e)));
+        if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) {
+            device_period = static_cast<unsigned>(std::max(0l, atol(e)));
+            device_forced = true;
+        }
         device_window = std::min<size_t>(10 * raw_cap(), 1900u << 20);
         if (const char* e = getenv("SLIMM_CLI_DEVICE_WINDOW_MB"))
             if (atol(e) > 0) device_window = std::min<size_t>(static_cast<size_t>(atol(e)) << 20, 1900u << 20);
@@ -552,6 +556,9 @@ struct RecordPump {
                 n = bam.read_blocks(raw_buf[w].get(), raw_cap(), device_window, &inflated);
                 compressed = true;
                 ++raw_windows_device;
+                // (a file that hardly compresses fills the buffer with few blocks: a lane per block then leaves most of the
+                // device idle -- the host cores take the rest of such a file)
+                if (n > 0 && !device_forced && inflated < 3 * raw_cap() && inflated < device_window) device_period = 0;
             } else {
                 n = bam.read_raw(raw_buf[w].get(), raw_cap());
                 if (bam.can_read_blocks() || bam.raw_exhausted()) ++raw_windows_host;

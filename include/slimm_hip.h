@@ -96,7 +96,11 @@ int slimm_set_cutoff_cache(slimm_ctx* ctx, float coverage_cut_off, float uniq_co
 /* ---- record stream: what the loop of analyze_alignments() reads from each BamAlignmentRecord
  *      (src/slimm.hpp:194-211): qName identity, flag, rID, beginPos; file order. ------------------
  * read_key: identity of the qName (equal names <=> equal keys); only the low 62 bits are significant
- * (the mate number from flag 0x40/0x80 is folded into the two low bits on the device).  The library compares
+ * (the mate number from flag 0x40/0x80 is folded into the two low bits on the device).  The reference's key is the
+ * string qName + ".1" / ".2" / nothing (src/slimm.hpp:204-208): an UNFLAGGED record whose name ends in ".1" / ".2" is
+ * the same read as a first / last-in-pair record of the name without that suffix (Q18).  A producer that wants that
+ * input class reproduced keys such a record by the shortened name and sets the mate bit in the flag it passes:
+ * slimm_host_canonical_read_name below does it, and the library's own readers do.  The library compares
  * keys, never names: "equal names <=> equal keys" is the caller's promise.  GROUPED streams only ever compare
  * ADJACENT records, so a producer that hashes names can make the promise exact by comparing every name with the
  * one before it (the slimm command's reader does: host/alignment_file.cpp, separate_adjacent_names); for ANY order
@@ -415,6 +419,15 @@ uint32_t slimm_host_avg_read_length(const uint32_t* l_seq, uint64_t n, uint32_t 
 float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q);
 /* Bin of one record (src/slimm.hpp:200-201). */
 uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width);
+/* Canonical identity of one record's read (src/slimm.hpp:204-208, quirk Q18).  The reference keys its reads by the STRING
+ * qName + ".1" (flag 0x40) / ".2" (else flag 0x80) / nothing, so a first-in-pair record of read "N" and an unflagged
+ * record of a read literally named "N.1" are ONE read.  (base, mate) below is a bijection with those strings:
+ *   (name, 1) if flag & 0x40;  (name, 2) else if flag & 0x80;  else (name minus its last two bytes, 1 / 2) if the name
+ *   ends in ".1" / ".2";  else (name, 0).
+ * Returns the length of the base and, in *flag_out, the flag with the mate bit the base carries.  A producer hashes (or
+ * compares) name[0, base) and hands the library *flag_out: then "equal keys and equal mate <=> equal reference key
+ * string" holds.  The library's own readers (host/alignment_file.cpp, bam_decode.hip) do exactly this. */
+uint32_t slimm_host_canonical_read_name(const char* name, uint32_t name_len, uint16_t flag, uint16_t* flag_out);
 /* hipDeviceReset() of the process's devices: for a host about to leave the process.  Contexts must not be used afterwards. */
 int slimm_shutdown(void);
 /* Library build info. */

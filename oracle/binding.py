@@ -145,9 +145,11 @@ class Oracle:
         L.orc_reset(self.h)
         ref_len = np.ascontiguousarray(ref_len, dtype=np.uint32)
         qblob = _blob(records.qname) if (use_qnames and records.qname is not None) else None
+        # with names the oracle keys by the reference's string (name + ".1" / ".2"): it gets the flags as written (Q18)
+        flag = records.flags_in_file() if qblob is not None else records.flag
         ph = np.zeros(3, dtype=np.float64)
         rc = L.orc_run(self.h, len(ref_names), _blob(ref_names), _p(ref_len), int(avg_read_len), len(records), qblob,
-                       _p(records.read_key), _p(records.flag), _p(records.ref_id), _p(records.begin_pos),
+                       _p(records.read_key), _p(flag), _p(records.ref_id), _p(records.begin_pos),
                        int(want_raw), int(want_cov), _p(ph))
         return self._collect(rc, len(ref_names), collect_bins, ph)
 

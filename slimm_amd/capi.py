@@ -158,6 +158,7 @@ SYMBOLS = [
     ("slimm_host_avg_read_length", C.c_uint32, [_P, C.c_uint64, C.c_uint32]),
     ("slimm_host_quantile_cut_off", C.c_float, [_P, C.c_uint32, C.c_float]),
     ("slimm_host_bin_of", C.c_uint32, [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    ("slimm_host_canonical_read_name", C.c_uint32, [C.c_char_p, C.c_uint32, C.c_uint16, C.c_void_p]),
     ("slimm_shutdown", C.c_int, []),
     ("slimm_version", C.c_char_p, []),
 ]

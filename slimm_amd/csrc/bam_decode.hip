@@ -277,6 +277,21 @@ __device__ bool bam_same_name(const uint8_t* a, uint32_t la, const uint8_t* b, u
     return true;
 }
 
+// Q18 (read_identity.h: canonical_read, on the device): the reference keys a read by the STRING qName + ".1" / ".2" / nothing
+// (src/slimm.hpp:204-208); the identity is the canonical (base, mate) of that string.  Shortens nlen to the base and
+// returns the flag with the mate bit the base carries.
+__device__ __forceinline__ uint32_t bam_canonical(const uint8_t* name, uint32_t& nlen, uint32_t fl) {
+    if (fl & 0xC0u) return fl;
+    if (nlen >= 2u && name[nlen - 2u] == '.') {
+        const uint32_t d = name[nlen - 1u];
+        if (d == '1' || d == '2') {
+            nlen -= 2u;
+            return fl | (d == '1' ? 0x40u : 0x80u);
+        }
+    }
+    return fl;
+}
+
 // a wave per piece, a lane per record
 template <bool kMarked>
 __global__ __launch_bounds__(64) void k_bam_decode(const uint8_t* __restrict__ b, const BamPiece* __restrict__ pieces,
@@ -304,16 +319,18 @@ __global__ __launch_bounds__(64) void k_bam_decode(const uint8_t* __restrict__ b
         const int32_t rid = static_cast<int32_t>(ld_u32(r));
         const int32_t rpos = static_cast<int32_t>(ld_u32(r + 4));
         const uint32_t l_name = r[8];
-        const uint32_t fl = ld_u16(r + 14);
         const uint8_t* name = r + 32;
-        const uint32_t nlen = l_name ? l_name - 1u : 0u;
+        uint32_t nlen = l_name ? l_name - 1u : 0u;
+        const uint32_t fl = bam_canonical(name, nlen, ld_u16(r + 14));
         const uint64_t at = out_at + pc.base + k;
         if (kMarked) {
             bool starts;
             const uint32_t po_prev = k ? po[k - 1] : prev0;
             if (po_prev != 0xffffffffu) {
                 const uint8_t* q = b + po_prev + 4;
-                starts = !bam_same_name(name, nlen, q + 32, q[8] ? q[8] - 1u : 0u);
+                uint32_t qlen = q[8] ? q[8] - 1u : 0u;
+                bam_canonical(q + 32, qlen, ld_u16(q + 14));
+                starts = !bam_same_name(name, nlen, q + 32, qlen);
             } else {
                 starts = !(carry->have && bam_same_name(name, nlen, carry->name, carry->len));
             }
@@ -341,7 +358,8 @@ __global__ __launch_bounds__(64) void k_bam_carry(const uint8_t* __restrict__ b,
     if (c == 0xffffffffu) return;  // (no record in this window: the carried name stays)
     const uint32_t o = offs[static_cast<size_t>(c) * kBamSlots + pieces[c].count - 1u];
     const uint8_t* r = b + o + 4;
-    const uint32_t nlen = r[8] ? r[8] - 1u : 0u;
+    uint32_t nlen = r[8] ? r[8] - 1u : 0u;
+    bam_canonical(r + 32, nlen, ld_u16(r + 14));  // the carried name is the canonical base
     for (uint32_t i = threadIdx.x; i < nlen; i += 64u) carry->name[i] = r[32 + i];
     if (threadIdx.x == 0) {
         carry->len = nlen;

@@ -24,6 +24,7 @@
 #include "../../include/slimm_hip.h"
 #include "host_profile.hpp"
 #include "kernels.h"
+#include "read_identity.h"
 
 namespace {
 
@@ -2419,6 +2420,12 @@ float slimm_host_quantile_cut_off(const float* v, uint32_t n, float q) {
     return slimm::quantile_cut_off(std::vector<float>(v, v + n), q);
 }
 
+uint32_t slimm_host_canonical_read_name(const char* name, uint32_t name_len, uint16_t flag, uint16_t* flag_out) {  // src/slimm.hpp:204-208 (Q18)
+    size_t n = name_len;
+    const uint16_t f = slimm::canonical_read(name, n, flag);
+    if (flag_out) *flag_out = f;
+    return static_cast<uint32_t>(n);
+}
 uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width) {
     uint32_t center = std::min(static_cast<uint32_t>(begin_pos) + (avg_read_len / 2), ref_len);  // slimm.hpp:200
     return bin_width ? center / bin_width : 0;                                                   // slimm.hpp:201

@@ -705,9 +705,10 @@ void AlignmentFile::separate_adjacent_names(uint64_t* key, const std::vector<siz
     const size_t cnt = offs.size();
     if (!cnt) return;
     constexpr uint64_t kMask = (1ull << 62) - 1;
-    auto name_of = [&](size_t k, size_t& len) {
+    auto name_of = [&](size_t k, size_t& len) {  // the canonical base (Q18)
         const uint8_t* r = &buf_[offs[k] + 4];
         len = r[8] ? r[8] - 1u : 0u;
+        canonical_read(reinterpret_cast<const char*>(r + 32), len, rd_u16(r + 14));
         return reinterpret_cast<const char*>(r + 32);
     };
     auto same_name = [&](size_t a, size_t b) {
@@ -1052,7 +1053,7 @@ long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begi
             ref_id[i] = b.ref_id[i];
             begin_pos[i] = b.begin_pos[i];
             flag[i] = b.flag[i];
-            if (check) check[i] = check_read_name(b.qname[i].data(), b.qname[i].size());
+            if (check) check[i] = check_read_name(b.qname[i].data(), b.base_len[i]);
         }
         return n;
     }
@@ -1064,11 +1065,13 @@ long AlignmentFile::read_into(uint64_t* read_key, int32_t* ref_id, int32_t* begi
         for (size_t k = lo; k < hi; ++k) {
             const uint8_t* r = &buf_[offs[k] + 4];
             const uint8_t l_read_name = r[8];
-            read_key[k] = hash_read_name(reinterpret_cast<const char*>(r + 32), l_read_name ? l_read_name - 1u : 0u);
-            if (check) check[k] = check_read_name(reinterpret_cast<const char*>(r + 32), l_read_name ? l_read_name - 1u : 0u);
+            const char* name = reinterpret_cast<const char*>(r + 32);
+            size_t nlen = l_read_name ? l_read_name - 1u : 0u;
+            flag[k] = canonical_read(name, nlen, rd_u16(r + 14));
+            read_key[k] = hash_read_name(name, nlen);
+            if (check) check[k] = check_read_name(name, nlen);
             ref_id[k] = static_cast<int32_t>(rd_u32(r));
             begin_pos[k] = static_cast<int32_t>(rd_u32(r + 4));
-            flag[k] = rd_u16(r + 14);
         }
     });
     clk.reset(new StageClock(ms_names_));
@@ -1089,19 +1092,26 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
         out.begin_pos.resize(base + cnt);
         out.flag.resize(base + cnt);
         out.l_seq.resize(base + cnt);
-        if (keep_names) out.qname.resize(base + cnt);
+        if (keep_names) {
+            out.qname.resize(base + cnt);
+            out.base_len.resize(base + cnt);
+        }
         decode_parallel(cnt, [&](size_t lo, size_t hi) {
             for (size_t k = lo; k < hi; ++k) {
                 const uint8_t* r = &buf_[offs[k] + 4];
                 const uint8_t l_read_name = r[8];
                 const char* name = reinterpret_cast<const char*>(r + 32);
                 const size_t nlen = l_read_name ? l_read_name - 1u : 0u;
-                out.read_key[base + k] = hash_read_name(name, nlen);
+                size_t blen = nlen;
+                out.flag[base + k] = canonical_read(name, blen, rd_u16(r + 14));
+                out.read_key[base + k] = hash_read_name(name, blen);
                 out.ref_id[base + k] = static_cast<int32_t>(rd_u32(r));
                 out.begin_pos[base + k] = static_cast<int32_t>(rd_u32(r + 4));
-                out.flag[base + k] = rd_u16(r + 14);
                 out.l_seq[base + k] = rd_u32(r + 16);
-                if (keep_names) out.qname[base + k].assign(name, nlen);
+                if (keep_names) {
+                    out.qname[base + k].assign(name, nlen);
+                    out.base_len[base + k] = static_cast<uint32_t>(blen);
+                }
             }
         });
         separate_adjacent_names(out.read_key.data() + base, offs);
@@ -1139,14 +1149,17 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
             auto it = index.find(rn);
             if (it != index.end()) ref_id = it->second;
         }
-        uint64_t key = hash_read_name(qn.data(), qn.size());
+        size_t blen = qn.size();
+        flag = canonical_read(qn.data(), blen, flag);  // Q18: key, adjacent-name compare and mate on the canonical base
+        const std::string bn = qn.substr(0, blen);
+        uint64_t key = hash_read_name(bn.data(), bn.size());
         if (have_last_) {  // (separate_adjacent_names, one record at a time)
-            if (qn == last_name_)
+            if (bn == last_name_)
                 key = last_key_;
             else if (key == last_key_)
                 key = (key + 1) & ((1ull << 62) - 1);
         }
-        last_name_ = qn;
+        last_name_ = bn;
         last_key_ = key;
         have_last_ = true;
         out.read_key.push_back(key);
@@ -1154,7 +1167,10 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
         out.begin_pos.push_back(static_cast<int32_t>(pos1 - 1));  // SAM POS is 1-based; 0 ("unavailable") becomes -1
         out.flag.push_back(flag);
         out.l_seq.push_back(seq == "*" ? 0u : static_cast<uint32_t>(seq.size()));
-        if (keep_names) out.qname.push_back(qn);
+        if (keep_names) {
+            out.qname.push_back(qn);
+            out.base_len.push_back(static_cast<uint32_t>(blen));
+        }
         ++n;
     }
     return n;

@@ -16,15 +16,18 @@
 #include <unordered_map>
 #include <vector>
 
+#include "../read_identity.h"
+
 namespace slimm {
 
 struct RecordBatch {
-    std::vector<uint64_t> read_key;  // 62-bit hash of qName
+    std::vector<uint64_t> read_key;  // 62-bit hash of the qName's canonical base (canonical_read below)
     std::vector<int32_t> ref_id;
     std::vector<int32_t> begin_pos;
-    std::vector<uint16_t> flag;
+    std::vector<uint16_t> flag;      // as in the file, plus the mate bit an unflagged "N.1" / "N.2" name stands for (Q18)
     std::vector<uint32_t> l_seq;
-    std::vector<std::string> qname;  // only filled when keep_names
+    std::vector<std::string> qname;  // only filled when keep_names: the name as it stands in the file ...
+    std::vector<uint32_t> base_len;  // ... and the length of its canonical base
     size_t size() const { return read_key.size(); }
     void clear() {
         read_key.clear();
@@ -33,6 +36,7 @@ struct RecordBatch {
         flag.clear();
         l_seq.clear();
         qname.clear();
+        base_len.clear();
     }
 };
 
@@ -43,6 +47,8 @@ enum class SortOrder { Unknown, Unsorted, QueryName, Coordinate, QueryGrouped };
 // apart in a file that is NOT grouped by name remain possible (~0.04 % odds of any such pair among 125 M reads).
 uint64_t hash_read_name(const char* s, size_t n);
 uint32_t check_read_name(const char* s, size_t n);
+
+// canonical_read (../read_identity.h, quirk Q18): what the keys, check words and name compares of this reader work on.
 
 class AlignmentFile {
 public:

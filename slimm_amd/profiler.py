@@ -563,6 +563,14 @@ def host_bin_of(begin_pos: int, avg_read_len: int, ref_len: int, bin_width: int)
     return int(capi.lib().slimm_host_bin_of(int(begin_pos), int(avg_read_len), int(ref_len), int(bin_width)))
 
 
+def host_canonical_read_name(name: str, flag: int) -> Tuple[str, int]:
+    """(base name, flag with the base's mate bit): the canonical identity of a record's read (src/slimm.hpp:204-208, Q18)."""
+    b = name.encode()
+    out = C.c_uint16(0)
+    n = capi.lib().slimm_host_canonical_read_name(b, len(b), int(flag), C.byref(out))
+    return b[:n].decode(), int(out.value)
+
+
 def host_avg_read_length(l_seq: np.ndarray, sample: int = 100000) -> int:
     l_seq = np.ascontiguousarray(l_seq, dtype=np.uint32)
     return int(capi.lib().slimm_host_avg_read_length(_p(l_seq), l_seq.shape[0], sample))

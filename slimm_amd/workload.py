@@ -41,6 +41,24 @@ def read_keys_from_names(names: Sequence[str]) -> np.ndarray:
     return out
 
 
+def canonical_identity(names: Sequence[str], flags) -> "tuple[List[str], np.ndarray]":
+    """(base names, flags carrying the base's mate bit) of records as they stand in a file (quirk Q18).
+
+    The reference keys a read by the string qName + ".1" / ".2" / "" (src/slimm.hpp:204-208): an unflagged record of a
+    read named "N.1" is the same read as a first-in-pair record of "N".  Mirrors slimm_host_canonical_read_name
+    (include/slimm_hip.h; csrc/read_identity.h), which the library's own readers apply.
+    """
+    flags = np.array(flags, dtype=np.uint16)
+    bases = list(names)
+    for i, n in enumerate(names):
+        if flags[i] & 0xC0:
+            continue
+        if len(n) >= 2 and n[-2] == "." and n[-1] in "12":
+            bases[i] = n[:-2]
+            flags[i] |= 0x40 if n[-1] == "1" else 0x80
+    return bases, flags
+
+
 @dataclass
 class Taxonomy:
     """The slimm_database (reference src/misc.hpp:77-100)."""
@@ -78,10 +96,11 @@ class Records:
     """Decoded alignment records in file order (reference src/slimm.hpp:194-213 reads exactly these fields)."""
 
     read_key: np.ndarray  # uint64, identity of qName (62 significant bits)
-    flag: np.ndarray  # uint16 SAM flag
+    flag: np.ndarray  # uint16 SAM flag (with the mate bit of the canonical identity: canonical_identity above)
     ref_id: np.ndarray  # int32 BAM refID (-1 = none)
     begin_pos: np.ndarray  # int32 0-based position
-    qname: Optional[List[str]] = None  # only for small cases / the oracle
+    qname: Optional[List[str]] = None  # only for small cases / the oracle: the names as they stand in the file
+    file_flag: Optional[np.ndarray] = None  # the flags as they stand in the file, where they differ from `flag` (Q18)
 
     def __post_init__(self):
         self.read_key = np.ascontiguousarray(self.read_key, dtype=np.uint64)
@@ -96,7 +115,11 @@ class Records:
 
     def take(self, idx) -> "Records":
         q = [self.qname[i] for i in idx] if self.qname is not None else None
-        return Records(self.read_key[idx], self.flag[idx], self.ref_id[idx], self.begin_pos[idx], q)
+        ff = self.file_flag[idx] if self.file_flag is not None else None
+        return Records(self.read_key[idx], self.flag[idx], self.ref_id[idx], self.begin_pos[idx], q, ff)
+
+    def flags_in_file(self) -> np.ndarray:
+        return self.flag if self.file_flag is None else self.file_flag
 
 
 @dataclass

@@ -15,6 +15,12 @@ def qnames_of(records):
     return [f"r{int(k)}" for k in records.read_key]
 
 
+def _file_flags(records):
+    """The flags as they stand in the file (Records.file_flag where the canonical identity changed them: Q18)."""
+    ff = getattr(records, "file_flag", None)
+    return records.flag if ff is None else ff
+
+
 def sam_header(ref_names, ref_len, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
     lines = [hd] if hd else []
     lines += [f"@SQ\tSN:{n}\tLN:{int(l)}" for n, l in zip(ref_names, ref_len)]
@@ -23,13 +29,14 @@ def sam_header(ref_names, ref_len, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
 
 def write_sam(path, ref_names, ref_len, records, read_len=100, hd="@HD\tVN:1.6\tSO:unsorted\tGO:query"):
     q = qnames_of(records)
+    fflag = _file_flags(records)
     seq = "A" * read_len
     with open(path, "w") as f:
         f.write(sam_header(ref_names, ref_len, hd))
         for i in range(len(records)):
             r = int(records.ref_id[i])
             rn = ref_names[r] if r >= 0 else "*"
-            f.write(f"{q[i]}\t{int(records.flag[i])}\t{rn}\t{int(records.begin_pos[i]) + 1}\t255\t{read_len}M\t*\t0\t0\t{seq}\t*\n")
+            f.write(f"{q[i]}\t{int(fflag[i])}\t{rn}\t{int(records.begin_pos[i]) + 1}\t255\t{read_len}M\t*\t0\t0\t{seq}\t*\n")
 
 
 def _bgzf_block(data: bytes) -> bytes:
@@ -47,6 +54,7 @@ def bam_record_bytes(records, read_len=100, irregular_seed=None, l_seq_of=None) 
     four CIGAR operations, a few optional tag bytes), so that record boundaries fall anywhere.  l_seq_of: {record index:
     sequence length} for single records of another size."""
     q = qnames_of(records)
+    fflag = _file_flags(records)
     rng = np.random.default_rng(irregular_seed) if irregular_seed is not None else None
     out = bytearray()
     seq = bytes([0x11] * ((read_len + 1) // 2))
@@ -67,7 +75,7 @@ def bam_record_bytes(records, read_len=100, irregular_seed=None, l_seq_of=None) 
             ql = bytes(rng.integers(0, 42, size=l_seq, dtype=np.uint8))
             tags = b"NMC" + bytes([int(rng.integers(0, 200))]) if rng.random() < 0.5 else b""
         body = struct.pack("<iiBBHHHIiii", int(records.ref_id[i]), int(records.begin_pos[i]), len(name), 255, 4680, len(cg) // 4,
-                           int(records.flag[i]), l_seq, -1, -1, 0) + name + cg + sq + ql + tags
+                           int(fflag[i]), l_seq, -1, -1, 0) + name + cg + sq + ql + tags
         out += struct.pack("<i", len(body)) + body
     return bytes(out)
 

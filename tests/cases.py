@@ -15,7 +15,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from slimm_amd.workload import Options, Records, Taxonomy, Workload, read_keys_from_names
+from slimm_amd.workload import Options, Records, Taxonomy, Workload, canonical_identity, read_keys_from_names
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -51,9 +51,10 @@ def records_from_sam(rows: List[Tuple[str, int, str, int]], ref_names: List[str]
     """rows = (qname, flag, rname or '*', 1-based POS) as they would stand in a SAM file."""
     idx = {n: i for i, n in enumerate(ref_names)}
     q = [r[0] for r in rows]
-    return Records(read_keys_from_names(q), np.array([r[1] for r in rows], dtype=np.uint16),
-                   np.array([idx.get(r[2], -1) for r in rows], dtype=np.int32),
-                   np.array([r[3] - 1 for r in rows], dtype=np.int32), q)
+    raw = np.array([r[1] for r in rows], dtype=np.uint16)
+    base, flag = canonical_identity(q, raw)  # Q18: what a producer hands the C ABI; the oracle gets names + flags as written
+    return Records(read_keys_from_names(base), flag, np.array([idx.get(r[2], -1) for r in rows], dtype=np.int32),
+                   np.array([r[3] - 1 for r in rows], dtype=np.int32), q, raw if (raw != flag).any() else None)
 
 
 def tiny_case() -> Workload:
@@ -101,6 +102,36 @@ def holes_case() -> Workload:
                     records_from_sam(rows, names), avg_read_len=50, options=Options(bin_width=100), name="holes")
 
 
+def q18_case(order=None) -> Workload:
+    """Quirk Q18: the reference's read key is the STRING qName + ".1" / ".2" / "" (src/slimm.hpp:204-208), so an unflagged
+    record of a read literally named "N.1" and a first-in-pair record of "N" are ONE read.  Records of one key string are
+    adjacent here (name-grouped input in the canonical sense); order = a permutation for the any-order path."""
+    lin = {"X": [101, 11, 21, 31, 41, 51, 61, 2], "Y": [102, 12, 21, 31, 41, 51, 61, 2]}
+    names = ["X.1", "Y.1"]
+    X, Y = names
+    rows = [
+        ("N", 0x41, X, 10), ("N.1", 0, Y, 10),            # one read "N.1" on X and Y
+        ("M", 0x81, X, 300), ("M.2", 0x100, X, 500),      # one read "M.2"; X counted once, at its first bin (Q1)
+        ("K.1", 0x41, Y, 100),                             # "K.1.1": a read of its own
+        ("K.1", 0, Y, 600), ("K", 0x41, X, 700),           # both "K.1": one read on Y and X
+        ("Q.1", 0x81, X, 800),                             # "Q.1.2"
+        ("Q", 0x41, Y, 850),                               # "Q.1": apart from "Q.1.2"
+        ("T", 0xC1, X, 400), ("T.1", 0, X, 900),           # both flags: first wins -> "T.1" twice, one read
+        ("P.3", 0, Y, 200), ("P.12", 0, Y, 250),           # no suffix rule applies
+        ("W.2", 0, X, 50), ("W", 0x41, X, 150), ("W", 0x81, Y, 50),   # "W.2", "W.1", "W.2": two reads
+        ("U.1", 0x4, "*", 0), ("U", 0x41, Y, 950),         # unmapped record of "U.1" + a mapped one
+    ]
+    if order is not None:
+        rows = [rows[i] for i in order]
+    return Workload(names, np.array([1000, 1000], dtype=np.uint32), taxonomy_from_lineages(lin), records_from_sam(rows, names),
+                    avg_read_len=50, options=Options(bin_width=100, cov_cut_off=0.99), name="q18")
+
+
+# by hand: 18 records, 17 mapped; reads = N.1 {X,Y}, M.2 {X}, K.1.1 {Y}, K.1 {Y,X}, Q.1.2 {X}, Q.1 {Y}, T.1 {X}, P.3 {Y},
+# P.12 {Y}, W.2 {X,Y}, W.1 {X}, U.1 {Y} = 12 reads, 9 of them on one reference
+Q18_EXPECTED = {"hits": 17, "matches": 12, "uniq_matches": 9}
+
+
 # Expected outputs transcribed from SURVEY.md Appendix C (reference-observed).
 TINY_EXPECTED = {
     "hits": 73, "matches": 68, "uniq_matches": 64, "uniq_matches2": 65, "n_valid": 4,
@@ -127,7 +158,7 @@ def workload_to_json(w: Workload) -> dict:
         "options": vars(w.options),
         "db": {"accessions": t.accessions, "lineage": t.lineage.tolist(), "tax_id": t.tax_id.tolist(),
                "tax_rank": t.tax_rank.tolist(), "tax_name": t.tax_name},
-        "records": {"qname": w.records.qname, "flag": w.records.flag.tolist(), "ref_id": w.records.ref_id.tolist(),
+        "records": {"qname": w.records.qname, "flag": w.records.flags_in_file().tolist(), "ref_id": w.records.ref_id.tolist(),
                     "begin_pos": w.records.begin_pos.tolist()},
     }
 
@@ -137,8 +168,10 @@ def workload_from_json(d: dict) -> Workload:
     t = Taxonomy(db["accessions"], np.array(db["lineage"], dtype=np.uint32), np.array(db["tax_id"], dtype=np.uint32),
                  np.array(db["tax_rank"], dtype=np.uint32), db["tax_name"])
     r = d["records"]
-    rec = Records(read_keys_from_names(r["qname"]), np.array(r["flag"], dtype=np.uint16),
-                  np.array(r["ref_id"], dtype=np.int32), np.array(r["begin_pos"], dtype=np.int32), r["qname"])
+    raw = np.array(r["flag"], dtype=np.uint16)
+    base, flag = canonical_identity(r["qname"], raw)
+    rec = Records(read_keys_from_names(base), flag, np.array(r["ref_id"], dtype=np.int32),
+                  np.array(r["begin_pos"], dtype=np.int32), r["qname"], raw if (raw != flag).any() else None)
     return Workload(d["ref_names"], np.array(d["ref_len"], dtype=np.uint32), t, rec, d["avg_read_len"],
                     Options(**d["options"]), d["name"])
 

@@ -11,7 +11,7 @@ from oracle.binding import Oracle, parse_profile
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Records, Workload
 from tests.bam_io import qnames_of, write_bam, write_sam, write_sldb
-from tests.cases import holes_case, tiny_case
+from tests.cases import Q18_EXPECTED, holes_case, q18_case, tiny_case
 from tests.helpers import assert_profiles_match
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +22,7 @@ CLI = os.path.join(ROOT, "slimm_amd", "slimm")
 
 def with_names(w: Workload) -> Workload:
     r = w.records
-    return Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, qnames_of(r)),
+    return Workload(w.ref_names, w.ref_len, w.taxonomy, Records(r.read_key, r.flag, r.ref_id, r.begin_pos, qnames_of(r), r.file_flag),
                     w.avg_read_len, w.options, w.name)
 
 
@@ -56,6 +56,30 @@ def test_cli_matches_oracle_outputs(tmp_path, fmt, mk):
     assert f"{o.scalars['hits']} records processed." in err
     assert f"{o.scalars['matches']} matching reads" in err
     assert f"{o.scalars['n_valid']} passed the threshould coverage." in err
+
+
+@pytest.mark.parametrize("fmt", ["sam", "bam"])
+@pytest.mark.parametrize("order", ["grouped", "unsorted"])
+@pytest.mark.parametrize("host_decode", [False, True])
+def test_cli_q18_name_suffix_and_mate_flag_make_one_key(tmp_path, fmt, order, host_decode):
+    """Q18: the reference's read key is the string qName + ".1" / ".2" (src/slimm.hpp:204-208): `N`/0x40 and an unflagged
+    `N.1` are one read.  Through SAM text, the host BAM decoder and the device BAM decoder, name-grouped and any order."""
+    perm = None if order == "grouped" else list(np.random.default_rng(5).permutation(18))
+    w = q18_case(perm)
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / ("sample." + fmt))
+    hd = "@HD\tVN:1.6\tSO:unsorted\tGO:query" if order == "grouped" else "@HD\tVN:1.6\tSO:unsorted"
+    (write_sam if fmt == "sam" else write_bam)(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, hd=hd)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    env = dict(os.environ, SLIMM_CLI_HOST_DECODE="1") if host_decode else None
+    err = run_cli(["-w", "100", "-o", out, "-ro", "-co", "-v", db, inp], env=env)
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    assert (o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"]) == (
+        Q18_EXPECTED["hits"], Q18_EXPECTED["matches"], Q18_EXPECTED["uniq_matches"])
+    check_outputs(out, "sample", o)
+    assert f"{Q18_EXPECTED['matches']} matching reads" in err
 
 
 def test_cli_packed_and_run_marked_pushes_write_the_same_files(tmp_path, monkeypatch):

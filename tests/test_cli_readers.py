@@ -9,7 +9,7 @@ import pytest
 
 from slimm_amd.synth import CONFIGS, make_workload
 from tests.bam_io import qnames_of, write_bam, write_sam
-from tests.cases import tiny_case
+from tests.cases import q18_case, tiny_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "slimm_amd", "slimm")
@@ -44,6 +44,25 @@ def test_reader_round_trip(tmp_path, writer, fmt, mk):
     for r in recs:
         assert by_name.setdefault(r[0], r[5]) == r[5]
     assert len(set(by_name.values())) == len(by_name)
+
+
+@pytest.mark.parametrize("writer", [write_sam, write_bam])
+def test_reader_hands_out_the_canonical_identity_of_q18(tmp_path, writer):
+    """The reference's key is qName + ".1" / ".2" / "" (src/slimm.hpp:204-208): records get one (key, mate) iff they get one
+    key string there.  The reader keys by the canonical base and sets the base's mate bit in the flag it hands out."""
+    w = q18_case()
+    p = str(tmp_path / "q18")
+    writer(p, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    _, _, recs = dump(p)
+    q, raw = qnames_of(w.records), w.records.flags_in_file().tolist()
+    assert [r[0] for r in recs] == q
+    assert [int(r[1]) for r in recs] == w.records.flag.tolist()          # canonical: mate bits added
+    ident = {}
+    for r, name, f in zip(recs, q, raw):
+        key_string = name + (".1" if f & 0x40 else ".2" if f & 0x80 else "")
+        mate = 1 if int(r[1]) & 0x40 else 2 if int(r[1]) & 0x80 else 0
+        assert ident.setdefault(key_string, (r[5], mate)) == (r[5], mate)
+    assert len(set(ident.values())) == len(ident) == 12                   # (the unmapped record shares "U.1" with a mapped one)
 
 
 def test_bam_spanning_many_bgzf_blocks(tmp_path):

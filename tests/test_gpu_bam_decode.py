@@ -11,6 +11,7 @@ from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Records, Workload
 from tests.bam_io import bam_record_bytes
+from tests.cases import Q18_EXPECTED, q18_case
 from tests.helpers import assert_matches_oracle
 from tests.test_gpu_parity import _interleave_mates, one_long_read_workload
 
@@ -49,6 +50,20 @@ def test_grouped_file_decoded_on_the_device(window, irregular):
     w.records.flag[::11] |= 4
     w.records.ref_id[5::19] = -1
     _check(w, True, window, irregular)
+
+
+@pytest.mark.parametrize("window", [0, 97, 211])
+def test_q18_name_suffix_and_mate_flag_make_one_key(window):
+    """Q18 (src/slimm.hpp:204-208: the key is the string qName + ".1" / ".2"): `N`/0x40 and an unflagged `N.1` are one read.
+    Grouped: the adjacent-name compare works on the canonical base (also across windows: the carried name); any order: the
+    hash and the check word do."""
+    w = q18_case()
+    _check(w, True, window, read_len=50)
+    for seed in (1, 2, 3):
+        wa = q18_case(list(np.random.default_rng(seed).permutation(18)))
+        o = run_workload(wa, use_qnames=True)
+        assert o.scalars["matches"] == Q18_EXPECTED["matches"] and o.scalars["uniq_matches"] == Q18_EXPECTED["uniq_matches"]
+        _check(wa, False, window, read_len=50)
 
 
 @pytest.mark.parametrize("window", [0, 250_007])

@@ -13,7 +13,7 @@ from slimm_amd import capi
 from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Options, Records, Workload
-from tests.cases import holes_case, load_golden, records_from_sam, taxonomy_from_lineages, tiny_case
+from tests.cases import Q18_EXPECTED, holes_case, load_golden, q18_case, records_from_sam, taxonomy_from_lineages, tiny_case
 from tests.helpers import assert_matches_oracle, assert_profiles_match
 
 pytestmark = pytest.mark.gpu
@@ -83,6 +83,21 @@ def test_q2_mates_are_different_reads():
     rows = [("p", 0x41, "X.1", 10), ("p", 0x81, "X.1", 300), ("p", 0x41 | 0x100, "Y.1", 10), ("q", 0, "X.1", 700)]
     s, o = check(_two_ref_case(rows))
     assert s.stats()["matches_count"] == 3 and s.stats()["uniq_matches_count"] == 2
+
+
+def test_q18_the_key_is_the_string_name_plus_mate_suffix():
+    """src/slimm.hpp:204-208: `N`/0x40 and an unflagged read named `N.1` are ONE read (one key string); `N.1`/0x40 stays
+    apart ("N.1.1").  Four-array records keyed by the canonical base (slimm_host_canonical_read_name), grouped and ANY."""
+    w = q18_case()
+    s, o = check(w)
+    st = s.stats()
+    assert (st["hits_count"], st["matches_count"], st["uniq_matches_count"]) == (
+        Q18_EXPECTED["hits"], Q18_EXPECTED["matches"], Q18_EXPECTED["uniq_matches"])
+    assert s.bins(0)[3] == 1 and s.bins(0)[5] == 0       # read "M.2": X once, at its first record's bin (Q1)
+    for seed in range(4):
+        wa = q18_case(list(np.random.default_rng(seed).permutation(18)))
+        s, o = check(wa, grouped=False)
+        assert s.stats()["matches_count"] == Q18_EXPECTED["matches"]
 
 
 def test_q3_bin_clamp_and_wrap():

@@ -113,6 +113,37 @@ def test_bin_of_wraps_like_uint32():
     assert host_bin_of(2**31 - 1, 100, 2**32 - 1, 1000) == (2**31 - 1 + 50) // 1000
 
 
+def test_canonical_read_name_is_a_bijection_with_the_reference_key_string():
+    """src/slimm.hpp:204-208 keys a read by qName + ".1" / ".2" / "" (Q18).  (base, mate) from slimm_host_canonical_read_name
+    is equal for two records iff that string is; the Python mirror (workload.canonical_identity) agrees."""
+    from slimm_amd.profiler import host_canonical_read_name
+    from slimm_amd.workload import canonical_identity
+    assert host_canonical_read_name("N", 0x41) == ("N", 0x41)
+    assert host_canonical_read_name("N.1", 0) == ("N", 0x40)
+    assert host_canonical_read_name("N.2", 0x100) == ("N", 0x180)
+    assert host_canonical_read_name("N.1", 0x41) == ("N.1", 0x41)        # "N.1.1"
+    assert host_canonical_read_name("N.1", 0x80) == ("N.1", 0x80)        # "N.1.2"
+    assert host_canonical_read_name("N.3", 0) == ("N.3", 0)
+    assert host_canonical_read_name("N.12", 0) == ("N.12", 0)
+    assert host_canonical_read_name(".1", 0) == ("", 0x40)
+    assert host_canonical_read_name("1", 0) == ("1", 0) and host_canonical_read_name("", 0) == ("", 0)
+    assert host_canonical_read_name("N.1", 0x4) == ("N", 0x44)
+    names, flags = [], []
+    for base in ("a", "a.1", "a.2", "a.1.1", "a.1.2", "a.", "a..1", ".1", ".2", "1", "a.3"):
+        for f in (0, 0x40, 0x80, 0xc0, 0x100):
+            names.append(base)
+            flags.append(f)
+    seen = {}
+    pb, pf = canonical_identity(names, flags)
+    for i, (n, f) in enumerate(zip(names, flags)):
+        key_string = n + (".1" if f & 0x40 else ".2" if f & 0x80 else "")
+        b, cf = host_canonical_read_name(n, f)
+        assert (b, cf) == (pb[i], int(pf[i]))
+        ident = (b, 1 if cf & 0x40 else 2 if cf & 0x80 else 0)
+        assert seen.setdefault(key_string, ident) == ident
+    assert len(set(seen.values())) == len(seen)
+
+
 def test_mark_word_layout():
     """word = reference + 1 (0: not mapped) | mate << 29 | starts a qName run << 31 (include/slimm_hip.h)."""
     from slimm_amd import capi

@@ -85,13 +85,18 @@ const char* slimm_last_error(const slimm_ctx* ctx); /* ctx may be NULL: error of
 /* slimm::reset() (src/slimm.hpp:167-188): forget records and results, keep configuration, allocations and --
  * like the reference -- the cached cut-offs (quirk Q8: they survive reset in -d mode). */
 int slimm_reset(slimm_ctx* ctx);
-/* Clears the cached cut-offs as well (a fresh `slimm` object). */
+/* Clears the cached cut-offs and the derived min_reads as well (a fresh `slimm` object). */
 int slimm_reset_cutoffs(slimm_ctx* ctx);
 
 /* The cached cut-offs (src/slimm.hpp:155-156).  In the reference's -d mode one `slimm` object serves all files, so
  * files 2+ reuse file 1's cut-offs (Q8); a host that creates one context per file carries them over with these. */
 int slimm_get_cutoff_cache(slimm_ctx* ctx, float* coverage_cut_off, float* uniq_coverage_cut_off);
 int slimm_set_cutoff_cache(slimm_ctx* ctx, float coverage_cut_off, float uniq_coverage_cut_off);
+/* options.min_reads as an earlier file left it: with -mr 0 the first file with mapped reads derives it INTO the options
+ * (src/slimm.hpp:458-459), where it stays for the files behind it (Q8).  slimm_reset keeps the derived value like
+ * slimm::reset() does, slimm_reset_cutoffs restores the configured one; a host with one context per file carries it over
+ * with this (slimm_stats.min_reads of the file before). */
+int slimm_set_min_reads(slimm_ctx* ctx, uint32_t min_reads);
 
 /* ---- record stream: what the loop of analyze_alignments() reads from each BamAlignmentRecord
  *      (src/slimm.hpp:194-211): qName identity, flag, rID, beginPos; file order. ------------------

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("slimm_reset_cutoffs", C.c_int, [_P]),
     ("slimm_get_cutoff_cache", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("slimm_set_cutoff_cache", C.c_int, [_P, C.c_float, C.c_float]),
+    ("slimm_set_min_reads", C.c_int, [_P, C.c_uint32]),
     ("slimm_reserve", C.c_int, [_P, C.c_uint64]),
     ("slimm_check_grouping", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("slimm_push_records", C.c_int, [_P, _P, _P, _P, _P, C.c_uint64]),

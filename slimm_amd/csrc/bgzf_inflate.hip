@@ -523,7 +523,7 @@ extern "C" int slimm_bgzf_inflate(int device, const uint8_t* blocks, uint64_t n_
         rc = -2;
         msg = std::string(what) + ": " + hipGetErrorString(e);
     };
-    ok(hipMalloc(&d_comp, n_bytes + 16), "hipMalloc");
+    ok(hipMalloc(&d_comp, n_bytes + slimm::kBgzfTail), "hipMalloc");
     ok(hipMalloc(&d_out, inflated + 16), "hipMalloc");
     ok(hipMalloc(&d_desc, desc.size() * sizeof(slimm::BgzfBlock)), "hipMalloc");
     ok(hipMalloc(&d_scratch, slimm::bgzf_inflate_scratch_bytes(grid)), "hipMalloc");
@@ -531,7 +531,7 @@ extern "C" int slimm_bgzf_inflate(int device, const uint8_t* blocks, uint64_t n_
     if (!rc) {
         const uint32_t st0[2] = {0u, 0xffffffffu};
         ok(hipMemcpy(d_comp, blocks, n_bytes, hipMemcpyHostToDevice), "hipMemcpy");
-        ok(hipMemset(d_comp + n_bytes, 0, 16), "hipMemset");
+        ok(hipMemset(d_comp + n_bytes, 0, slimm::kBgzfTail), "hipMemset");
         ok(hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(slimm::BgzfBlock), hipMemcpyHostToDevice), "hipMemcpy");
         ok(hipMemcpy(d_status, st0, 8, hipMemcpyHostToDevice), "hipMemcpy");
         ok(hipEventCreate(&e0), "hipEventCreate");

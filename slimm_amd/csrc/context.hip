@@ -756,6 +756,12 @@ int slimm_set_cutoff_cache(slimm_ctx* c, float cc, float ucc) {
     return SLIMM_OK;
 }
 
+int slimm_set_min_reads(slimm_ctx* c, uint32_t min_reads) {
+    if (!c) return SLIMM_E_INVALID;
+    c->host->min_reads = min_reads;
+    return SLIMM_OK;
+}
+
 // Room for n records of the file's form: the four-array form holds key | ref | pos | flag (| check), the packed form
 // key | ref | pos, the run-marked form ref (the words) | pos.  Before the first push the form is not known yet: key, ref
 // and pos are reserved and the push itself adds what its form needs beyond them.
@@ -1091,6 +1097,17 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             return fail(c, SLIMM_E_INVALID, "skip: only in front of a file's first records");
         if (dh.size() >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "too many blocks in one window");
         n_bytes = inflated - skip;
+        // blocks that lie wholly inside the skipped bytes (a BAM header of any size) are not inflated at all; what is left to
+        // skip is less than one block, so the inflater's first byte stays inside the window buffer's slack
+        size_t drop = 0;
+        while (drop < dh.size() && dh[drop].dst + dh[drop].isize <= skip) ++drop;
+        if (drop) {
+            const uint64_t d0 = drop < dh.size() ? dh[drop].dst : inflated;
+            dh.erase(dh.begin(), dh.begin() + static_cast<long>(drop));
+            for (BgzfBlock& d : dh) d.dst -= d0;
+            skip -= static_cast<uint32_t>(d0);
+        }
+        if (skip >= 65536u) return fail(c, SLIMM_E_INVALID, "skip: past the first block that holds a record byte");
         if (n_bytes == 0) {  // (blocks without a record byte: nothing to inflate, nothing to decode)
             compressed = false;
             src_bytes = 0;
@@ -1152,14 +1169,14 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             // its own -- beside the kernels that work on the window before AND beside the copies of the windows that follow
             // (the scratch is shared: two inflates never overlap, they are on one stream)
             const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size()), grid = bgzf_inflate_grid(nblk);
-            HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + 64));
+            HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + kBgzfTail + 64));
             HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
             HIP_TRY(c, B.inflate_scratch.ensure(bgzf_inflate_scratch_bytes(kBgzfMaxGrid)));
             HIP_TRY(c, B.inflate_status.ensure(2u * slimm_ctx::kBamRing));
             HIP_TRY(c, B.h_inflate_status.ensure(2));
             HIP_TRY(c, hipMemcpyAsync(B.comp[b].p, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(B.h2d_done[b], c->copy_stream));
-            HIP_TRY(c, hipMemsetAsync(B.comp[b].p + src_bytes, 0, 16, c->copy_stream));
+            HIP_TRY(c, hipMemsetAsync(B.comp[b].p + src_bytes, 0, kBgzfTail, c->copy_stream));
             HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
                                       c->copy_stream));
             HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b, 0, 4, c->copy_stream));
@@ -1195,9 +1212,11 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
     if (last) {
         if (!had_any && B.carry_bytes) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
         B.closed = true;
-    } else if (B.windows >= 2) {
-        // the caller's buffer of the window BEFORE this one has been read (it may be reused once this call returns)
-        HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.windows - 2u) % slimm_ctx::kBamRing]));
+    } else {
+        // the caller's buffer of the call BEFORE this one has been read (it may be reused once this call returns): the most
+        // recent window whose copy this call did not start itself (a call without record bytes starts none)
+        const uint64_t mine = n_bytes ? 1u : 0u;
+        if (B.windows > mine) HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.windows - 1u - mine) % slimm_ctx::kBamRing]));
     }
     if (n_records) *n_records = total;
     return SLIMM_OK;

@@ -175,13 +175,16 @@ void HostProfile::reset() {  // slimm.hpp:167-188
     reference_count = matched_ref_length = 0;
     failed_by_cov = failed_by_ucov = failed_by_min_read = n_valid = 0;
     profile_count = profile_failed = 0;
-    min_reads = cfg_.min_reads;
+    // (min_reads stays: the reference derives it INTO options.min_reads, src/slimm.hpp:458-459, which reset() does not touch -- Q8)
     have_coverage = have_valid = have_partials = have_counts = false;
     profile_.clear();
     profile_ready_ = false;
 }
 
-void HostProfile::reset_cutoffs() { cc_cache_ = ucc_cache_ = 0.0f; }
+void HostProfile::reset_cutoffs() {  // a fresh `slimm` object: the cached cut-offs and the derived options.min_reads
+    cc_cache_ = ucc_cache_ = 0.0f;
+    min_reads = cfg_.min_reads;
+}
 
 void HostProfile::set_coverage(const uint32_t* rc, const uint32_t* urc, const uint32_t* nzc, const uint32_t* nzu,
                                uint32_t hits_, uint32_t matches_) {

@@ -283,6 +283,7 @@ struct BgzfBlock {
     uint32_t csize, isize; // payload bytes; inflated bytes (the gzip trailer's ISIZE)
     uint32_t crc, pad;     // the gzip trailer's CRC32 of the inflated bytes
 };
+constexpr uint32_t kBgzfTail = 1024;     // zeroed bytes behind the compressed input: a truncated table header reads into them, never past
 constexpr uint32_t kBgzfMaxGrid = 512;   // waves of a launch (two per CU: 70 KB of LDS each)
 uint32_t bgzf_inflate_grid(uint32_t n_blocks);
 size_t bgzf_inflate_scratch_bytes(uint32_t grid);

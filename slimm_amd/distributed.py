@@ -298,9 +298,17 @@ class FilesBackToBack:
     src/slimm.hpp:950-956; its `-d` mode loops over the files of a directory): while the device runs the front end of file
     k + 1 on one engine, the host finishes file k on the other -- propagation, profile text, the file written --, which
     otherwise is 0.25 ms of an idle GPU between two files.  Every file still goes through a freshly reset object, every
-    profile is written; `flush()` finishes the last one.  `give(engine)` hands an engine the next file's records."""
+    profile is written; `flush()` finishes the last one.  `give(engine)` hands an engine the next file's records.
 
-    def __init__(self, engines, give, device=None, path=None, group=None, phase_times=None, exchange="auto"):
+    By default every file is a FRESH `slimm` object (cut-off caches cleared: one `slimm DB IN.bam` run per file; what
+    `bench.py` times).  `directory_mode=True` is the reference's `-d` loop instead: ONE object serves all files, so the
+    cut-offs cached by the first file are reused by the files behind it (src/slimm.hpp:155-156, 330, 674; quirk Q8) --
+    the cache is carried from the engine of file k to the engine of file k + 1 (known as soon as file k's phase A is
+    finished, which is before file k + 1 starts)."""
+
+    def __init__(self, engines, give, device=None, path=None, group=None, phase_times=None, exchange="auto",
+                 directory_mode=False):
+        self.directory_mode = directory_mode
         self.engines = list(engines)
         self.give, self.device, self.path, self.group = give, device, path, group
         self.phase_times, self.exchange = phase_times, exchange
@@ -321,7 +329,11 @@ class FilesBackToBack:
         e = self.engines[self.k % len(self.engines)]
         self.k += 1
         e.reset()
-        e.reset_cutoffs()            # every step is a fresh file for a fresh `slimm` object
+        if not self.directory_mode or self.k == 1:
+            e.reset_cutoffs()        # every step is a fresh file for a fresh `slimm` object
+        elif e is not self.last:
+            e.set_cutoff_cache(*self.last.cutoff_cache())   # Q8: the one object of the -d loop keeps its cut-offs ...
+            e.set_min_reads(int(self.last.stats()["min_reads"]))   # ... and the min_reads its first file derived
         self.give(e)
         self.last = e
         had_pending = self.pending is not None

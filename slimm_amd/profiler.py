@@ -94,6 +94,19 @@ class Slimm:
     def reset_cutoffs(self):
         self._check(self.L.slimm_reset_cutoffs(self.ctx))
 
+    def cutoff_cache(self) -> Tuple[float, float]:
+        """The cached cut-offs (src/slimm.hpp:155-156; 0.0 = not computed yet): they survive reset() (Q8)."""
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self.L.slimm_get_cutoff_cache(self.ctx, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def set_cutoff_cache(self, coverage_cut_off: float, uniq_coverage_cut_off: float):
+        self._check(self.L.slimm_set_cutoff_cache(self.ctx, C.c_float(coverage_cut_off), C.c_float(uniq_coverage_cut_off)))
+
+    def set_min_reads(self, min_reads: int):
+        """options.min_reads as the file before left it (src/slimm.hpp:458-459 derives it into the options: Q8)."""
+        self._check(self.L.slimm_set_min_reads(self.ctx, int(min_reads)))
+
     def push_records(self, rec: Records, batch: int = 0):
         n = len(rec)
         step = batch or max(n, 1)

@@ -172,3 +172,34 @@ def test_records_from_compressed_blocks_equal_the_oracle(tmp_path, grouped):
         s.push_bgzf_blocks(bytes(bad), skip=skip, window=150_000)
     assert "BGZF" in str(e.value) or "BAM record" in str(e.value)
     s.close()
+
+
+def test_a_skip_larger_than_the_window_slack(tmp_path):
+    """A caller may hand over a file's blocks from its very first one and name the whole BAM header as `skip` -- 17 MiB here
+    (hundreds of thousands of contigs), more than the 16 MiB of slack in front of a window buffer: the blocks that lie wholly
+    inside the header are dropped on the host, what is left to skip is less than one block.  A skip that ends past the
+    window's bytes is an error."""
+    from oracle.binding import run_workload
+    from slimm_amd.profiler import Slimm
+    from slimm_amd.synth import CONFIGS, make_workload
+    from slimm_amd.workload import Workload
+    from tests.helpers import assert_matches_oracle
+    w = make_workload(CONFIGS["config1"], seed=72, n_records=5_000)
+    names = ["h%x" % k for k in w.records.read_key.tolist()]
+    blocks, skip, want, rec = _bam_file(tmp_path, w, names, seed=11)
+    rng = np.random.default_rng(5)
+    header = bytes(rng.integers(0, 64, size=17 * (1 << 20) + 12_345, dtype=np.uint8))    # stands for header text + contig table
+    front = b"".join(bgzf_block(header[i:i + 65_280], level=1) for i in range(0, len(header), 65_280))
+    wq = Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, "bam", grouped=True)
+    o = run_workload(wq, use_qnames=True)
+    for window in (0, len(front) + 20_000):      # (the skip lies in the first window: the header's blocks and a few more)
+        s = Slimm.for_workload(wq, device=0, grouped=True)
+        assert s.push_bgzf_blocks(front + blocks, skip=len(header) + skip, window=window) == len(rec)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+        s.close()
+    s = Slimm.for_workload(wq, device=0, grouped=True)
+    with pytest.raises(capi.SlimmError) as e:
+        s.push_bgzf_blocks(blocks, skip=len(want) + skip + 70_000)
+    assert "skip" in str(e.value)
+    s.close()

@@ -1453,3 +1453,38 @@ def test_files_back_to_back_through_two_contexts(tmp_path):
     assert_matches_oracle(engines[1], o3)
     for e in engines:
         e.close()
+
+
+def test_files_back_to_back_in_directory_mode_keep_the_first_files_cutoffs(tmp_path):
+    """FilesBackToBack(directory_mode=True) = the reference's `-d` loop: ONE `slimm` object serves every file, so the
+    cut-offs cached by file 1 are reused by the files behind it (src/slimm.hpp:155-156, 330, 674; Q8), although the files
+    alternate between two contexts here.  The oracle object is kept across the files the same way."""
+    from oracle.binding import Oracle
+    from slimm_amd.distributed import FilesBackToBack
+    base = make_workload(CONFIGS["config1"], seed=71, n_records=50_000)
+    files = [Workload(base.ref_names, base.ref_len, base.taxonomy, base.records.take(np.arange(lo, hi)), base.avg_read_len,
+                      base.options, base.name) for lo, hi in ((0, 30_000), (30_000, 36_000), (36_000, 50_000))]
+    orc = Oracle(files[0].taxonomy, files[0].options)
+    want = [orc.run(w.ref_names, w.ref_len, w.records, w.avg_read_len, use_qnames=False) for w in files]
+    fresh = [run_workload(w, use_qnames=False) for w in files]
+    assert any(a.cutoffs[:2] != b.cutoffs[:2] for a, b in zip(want[1:], fresh[1:]))     # the leak is visible in this input
+    at = [0]
+
+    def give(e):
+        e.push_records(files[at[0]].records)
+        at[0] += 1
+
+    engines = [Slimm.for_workload(files[0], device=0), Slimm.for_workload(files[0], device=0)]
+    fb = FilesBackToBack(engines, give, None, str(tmp_path / "p.tsv"), directory_mode=True)
+    got = []
+    for k in range(len(files)):
+        before = fb.step()
+        if k:
+            got.append(before)
+    got.append(fb.flush())
+    for text, o in zip(got, want):
+        assert_profiles_match(text, o.profile_tsv)
+    assert_matches_oracle(engines[0], want[2])
+    assert_matches_oracle(engines[1], want[1])
+    for e in engines:
+        e.close()

@@ -196,6 +196,18 @@ def main():
     ap.add_argument("--cli-records", type=int, default=100_000_000)
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has not touched a GPU and never
+    # will -- starts `python -m torch.distributed.run` with N ranks as a CHILD (never an exec), lets rank 0's one JSON line
+    # through on the inherited stdout and leaves with the child's exit code
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
 
@@ -444,6 +456,60 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_records / (elapsed / args.steps) / 1e6
 
+    # ---- N > 1: where a step's time goes, and north_star's literal collective beside the default exchange
+    step_split = exchange_bins = None
+    if dist.is_initialized() and world > 1:
+        import slimm_amd.distributed as sd
+
+        def one(exchange):
+            eng.reset()
+            eng.reset_cutoffs()
+            res.give(eng)
+            return sharded_profile(eng, dev, out_path, exchange=exchange)
+
+        # (a) the collectives of the default exchange bracketed by events on the engine's stream, a few untimed steps
+        one(args.exchange)
+        barrier()
+        sd.COLLECTIVE_EVENTS = []
+        n_split = 3
+        for _ in range(n_split):
+            one(args.exchange)
+        barrier()
+        coll = {}
+        for name, nbytes, e0, e1 in sd.COLLECTIVE_EVENTS:
+            a = coll.setdefault(name, [0.0, 0, 0])
+            a[0] += e0.elapsed_time(e1) if e0 is not None else 0.0
+            a[1] += 1
+            a[2] = nbytes
+        sd.COLLECTIVE_EVENTS = None
+        coll_ms = sum(v[0] for v in coll.values()) / n_split
+        cm = torch.tensor([coll_ms], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+        coll_ms = float(cm.item())
+        step_split = {"collectives_ms": round(coll_ms, 4),
+                      "collectives": {k: {"ms": round(v[0] / v[1], 4), "per_step": v[1] / n_split, "bytes": v[2]} for k, v in coll.items()},
+                      "how": "events on the engine's stream around each collective, max over ranks, 3 untimed steps behind the timed region "
+                             "(a rank that waits for a slower one inside a collective counts the wait as collective time)"}
+        # (b) the same step with --exchange bins: ONE all-reduce over the integer bins before the uniqueness pass (north_star)
+        if resolve_exchange(eng, args.exchange, world) != "bins" and not args.no_bins:
+            one("bins")
+            barrier()
+            nb = max(3, args.steps // 4)
+            t1 = time.perf_counter()
+            for _ in range(nb):
+                prof_b = one("bins")
+            barrier()
+            elb = time.perf_counter() - t1
+            tb = torch.tensor([elb], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            elb = float(tb.item())
+            exchange_bins = {"value": round(total_records / (elb / nb) / 1e6, 3), "unit": "M records/s", "ms_per_step": round(elb / nb * 1e3, 4),
+                             "steps": nb, "engines": 1,
+                             "collective": "ONE all_reduce(SUM, u32) over [cov | uniq_cov | 16 scalars] between phase A and the cut-offs "
+                                           "(BASELINE.json north_star), then the small all-reduce of the partial results",
+                             "all_reduce_bytes": int(eng.coverage_tensor().numel()) * 4,
+                             "same_profile": bool(prof_b == profile)}
+
     def roofline_from(engine, stats, n_records, kt, steps, workload):
         """The roofline object of the dominant kernel + the per-kernel table, from HIP-event times `kt`
         ({kernel: (ms, launches)} over `steps` steps)."""
@@ -534,6 +600,9 @@ def main():
             for k in ("hits_count", "matches_count", "uniq_matches_count", "uniq_matches_count2"):
                 st_local[k] = int(st[k]) // world   # (n_targets is this rank's own already)
         roofline, per_kernel, kernel_ms = roofline_from(eng, st_local, n_rec, ktimes, args.steps, args.config)
+        if step_split is not None:
+            step_split = dict({"ms_per_step": round(ms_per_step, 4), "kernels_ms": round(kernel_ms, 4),
+                               "host_and_idle_ms": round(ms_per_step - kernel_ms - step_split["collectives_ms"], 4)}, **step_split)
         if args.breakdown:
             print(f"# generate + copy {gen_s:.1f}s on {gen_threads} threads; records/rank {n_rec}; V={st['hits_count']} "
                   f"M={st['matches_count']} P={st['n_targets']} U={st['uniq_matches_count']} U2={st['uniq_matches_count2']} "
@@ -921,6 +990,8 @@ def main():
                        "profile_sha1": __import__("hashlib").sha1((profile or "").encode()).hexdigest(),
                        "profile_rows": len(profile.strip().split("\n")) - 1 if profile else 0},
             "roofline": roofline,
+            "step_split": step_split,
+            "exchange_bins": exchange_bins,
             "value_resident": round(value, 3),
             "value_with_push": with_push,
             "run_marked_records": marked,

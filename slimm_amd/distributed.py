@@ -50,31 +50,52 @@ def _host_staged(t, group) -> bool:
     return t.is_cuda and dist.get_backend(group) != "nccl"
 
 
+#
+# COLLECTIVE_EVENTS: a measuring caller (bench.py's step_split) sets it to a list; every collective on a device tensor is
+# then bracketed by two timing events on the current stream (the engine's) and noted as (name, bytes, start, end).
+COLLECTIVE_EVENTS = None
+
+
+@contextlib.contextmanager
+def _timed(name, t):
+    if COLLECTIVE_EVENTS is None or not t.is_cuda:
+        yield
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    yield
+    e1.record()
+    COLLECTIVE_EVENTS.append((name, t.numel() * t.element_size(), e0, e1))
+
+
 def _all_reduce_sum(t, group):
-    if _host_staged(t, group):
-        h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-        t.copy_(h)
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    with _timed("all_reduce", t):
+        if _host_staged(t, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 def _all_gather_into(out, mine, group):
-    if _host_staged(mine, group):
-        ho = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_gather_into_tensor(ho, mine.cpu(), group=group)
-        out.copy_(ho)
-    else:
-        dist.all_gather_into_tensor(out, mine, group=group)
+    with _timed("all_gather", out):
+        if _host_staged(mine, group):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(ho, mine.cpu(), group=group)
+            out.copy_(ho)
+        else:
+            dist.all_gather_into_tensor(out, mine, group=group)
 
 
 def _all_to_all(out, mine, group):
-    if _host_staged(mine, group):
-        ho = torch.empty(out.shape, dtype=out.dtype)
-        dist.all_to_all_single(ho, mine.cpu().contiguous(), group=group)
-        out.copy_(ho)
-    else:
-        dist.all_to_all_single(out, mine, group=group)
+    with _timed("all_to_all", mine):
+        if _host_staged(mine, group):
+            ho = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_to_all_single(ho, mine.cpu().contiguous(), group=group)
+            out.copy_(ho)
+        else:
+            dist.all_to_all_single(out, mine, group=group)
 
 
 def exchange_coverage(engine, group=None, mode: str = "auto") -> bool:

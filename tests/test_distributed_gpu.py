@@ -145,3 +145,17 @@ def test_bench_multi_process_control_flow_on_one_gpu(nproc):
     assert many["config"]["exchange"] == ("summary" if nproc == 2 else "sliced")
     # (which kernel the shared GPU makes the longest is no property of the code: two processes time-slice one device)
     assert many["value"] > 0 and many["roofline"]["kernel"].startswith("k_") and many["roofline"]["frac"] > 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver's N = 1 record shows bench.py being started):
+    the parent starts torch.distributed.run as a child before it touches a GPU, relays rank 0's one line and leaves with the
+    child's exit code.  The N > 1 line carries the step's split and the same step with north_star's literal collective (one
+    all-reduce over the integer bins)."""
+    many = _bench(["--gpus", "2", "--backend", "gloo", "--quick", "--records", "4000000", "--chunk-records", "500000", "--steps", "2",
+                   "--warmup", "1"])
+    assert many["n_gpus"] == 2 and many["config"]["process_group_ranks"] == 2 and many["config"]["total_records"] == 4_000_000
+    sp = many["step_split"]
+    assert sp["kernels_ms"] > 0 and sp["collectives_ms"] > 0 and set(sp["collectives"]) == {"all_gather", "all_reduce"}
+    xb = many["exchange_bins"]
+    assert xb["same_profile"] is True and xb["value"] > 0 and xb["all_reduce_bytes"] > 0

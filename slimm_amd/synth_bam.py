@@ -1,6 +1,14 @@
 """A synthetic BAM of a Workload, written fast enough for 100 M records: fixed-size records laid out with numpy,
-compressed block by block (BGZF, zlib level 1) on a thread pool, ten million records at a time.  The read name of a
-record is its key in 16 hex digits, so equal keys <=> equal names.  For end-to-end timings of the `slimm` command
+compressed block by block (BGZF) on a thread pool, ten million records at a time.  Two kinds of content:
+
+  realistic = False   every sequence byte 0x11, every quality 0x28, the name = the key in 16 hex digits: a file that
+                      compresses 17-fold (rounds 1 - 4; kept as the easy case beside the other)
+  realistic = True    what a BAM holds: random bases (4-bit codes of A/C/G/T), qualities from eight bins with run structure
+                      (about 2.3 bits each), instrument-style names `A00123:45:HXYZABCDX:1:TTTT:XXXXXXX:YYYYYYYY` whose
+                      three numeric fields are the key's 19 decimal digits; DEFLATE by libdeflate level 6 when the box has
+                      it (what samtools links), zlib level 6 otherwise.  Compresses 3 - 4 fold, literal-heavy streams.
+
+Either way equal keys <=> equal names.  For end-to-end timings of the `slimm` command
 (scripts/cli_e2e.py, bench.py's cli_end_to_end leg); the readers' correctness tests use the independent, general writers
 of tests/bam_io.py.  Written from the SAM/BAM specification."""
 from __future__ import annotations
@@ -16,27 +24,124 @@ import numpy as np
 _HEX = np.frombuffer(b"0123456789abcdef", dtype="u1")
 
 
-def _bgzf(c: bytes, level: int = 1) -> bytes:
-    co = zlib.compressobj(level, zlib.DEFLATED, -15)
-    comp = co.compress(c) + co.flush()
+def _wrap(c: bytes, comp: bytes) -> bytes:
     return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(comp) + 25) + comp
             + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c)))
 
 
-def _record_dtype(read_len: int):
+def _bgzf(c: bytes, level: int = 1) -> bytes:
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    return _wrap(c, co.compress(c) + co.flush())
+
+
+_libdeflate = None
+
+
+def libdeflate():
+    """libdeflate.so.0 through ctypes (the box has the library, no headers), or None."""
+    global _libdeflate
+    if _libdeflate is None:
+        import ctypes as C
+        try:
+            L = C.CDLL("libdeflate.so.0")
+            L.libdeflate_alloc_compressor.restype = C.c_void_p
+            L.libdeflate_alloc_compressor.argtypes = [C.c_int]
+            L.libdeflate_free_compressor.argtypes = [C.c_void_p]
+            L.libdeflate_deflate_compress.restype = C.c_size_t
+            L.libdeflate_deflate_compress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+            _libdeflate = L
+        except OSError:
+            _libdeflate = False
+    return _libdeflate or None
+
+
+def _bgzf_many_libdeflate(chunks, level: int = 6):
+    """One thread's share of blocks through one libdeflate compressor (ctypes calls release the GIL)."""
+    import ctypes as C
+    L = libdeflate()
+    co = L.libdeflate_alloc_compressor(level)
+    buf = C.create_string_buffer(0x10000 + 1024)
+    out = []
+    for c in chunks:
+        n = L.libdeflate_deflate_compress(co, c, len(c), buf, len(buf))
+        assert n, "libdeflate: block did not fit"
+        out.append(_wrap(c, buf.raw[:n]))
+    L.libdeflate_free_compressor(co)
+    return b"".join(out)
+
+
+_BASE_LUT = np.array([(1 << (b & 3)) << 4 | (1 << ((b >> 2) & 3)) for b in range(256)], dtype="u1")
+_QUAL_BINS = np.array([2, 6, 15, 22, 27, 33, 37, 40], dtype="u1")
+_NAME_PREFIX = b"A00123:45:HXYZABCDX:1:"
+
+
+_pool_cache = {}
+
+
+def _pools(read_len: int, rows: int = 1 << 18, seed: int = 7):
+    """Pools of random sequences and quality strings the records draw from: the pool (40 MB) is far beyond DEFLATE's 32 KB
+    window, so for the compressor every record's bases and qualities are fresh."""
+    if (read_len, rows, seed) in _pool_cache:
+        return _pool_cache[(read_len, rows, seed)]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    seq = _BASE_LUT[rng.integers(0, 256, size=(rows, (read_len + 1) // 2), dtype="u1")]
+    # qualities: a bin is kept with probability 0.6, else a new one drawn with weights that favour the high bins (about 2 bits
+    # per quality value)
+    r = rng.integers(0, 256, size=(rows, read_len), dtype="u1")
+    change = rng.integers(0, 256, size=(rows, read_len), dtype="u1") < 102
+    change[:, 0] = True
+    cum = np.cumsum([0.03, 0.03, 0.05, 0.07, 0.10, 0.17, 0.35, 0.20])
+    fresh = np.searchsorted(cum, (np.arange(256) + 0.5) / 256.0).astype("u1")[r]
+    at = np.maximum.accumulate(np.where(change, np.arange(read_len, dtype=np.int32)[None, :], 0), axis=1)
+    qual = _QUAL_BINS[np.take_along_axis(fresh, at, axis=1)]
+    out = (np.ascontiguousarray(seq).view(f"S{seq.shape[1]}").reshape(rows),
+           np.ascontiguousarray(qual).view(f"S{read_len}").reshape(rows))
+    _pool_cache[(read_len, rows, seed)] = out
+    return out
+
+
+def _decimal_names(key: np.ndarray) -> np.ndarray:
+    """[m, 44] bytes: PREFIX + 4 digits ':' 7 digits ':' 8 digits + NUL -- the 19 decimal digits of the (62-bit) key."""
+    m = key.shape[0]
+    out = np.empty((m, 44), dtype="u1")
+    out[:, :22] = np.frombuffer(_NAME_PREFIX, dtype="u1")
+    hi, lo = np.divmod(key.astype(np.uint64), np.uint64(10 ** 8))       # 11 digits | 8 digits
+    hi2, mid = np.divmod(hi, np.uint64(10 ** 7))                         # 4 digits | 7 digits
+    def put(v, ndig, col):
+        v = v.astype(np.uint32)
+        for d in range(ndig - 1, -1, -1):
+            v, r = np.divmod(v, np.uint32(10))
+            out[:, col + d] = r.astype("u1") + 48
+    put(hi2, 4, 22)
+    out[:, 26] = 58
+    put(mid, 7, 27)
+    out[:, 34] = 58
+    put(lo, 8, 35)
+    out[:, 43] = 0
+    return out
+
+
+def _record_dtype(read_len: int, l_name: int = 17):
     dt = np.dtype([("bs", "<i4"), ("ref", "<i4"), ("pos", "<i4"), ("lname", "u1"), ("mapq", "u1"), ("bin", "<u2"),
                    ("ncig", "<u2"), ("flag", "<u2"), ("lseq", "<i4"), ("nref", "<i4"), ("npos", "<i4"), ("tlen", "<i4"),
-                   ("name", "S17"), ("cigar", "<u4"), ("seq", f"S{(read_len + 1) // 2}"), ("qual", f"S{read_len}")])
-    assert dt.itemsize == 36 + 17 + 4 + (read_len + 1) // 2 + read_len
+                   ("name", f"S{l_name}"), ("cigar", "<u4"), ("seq", f"S{(read_len + 1) // 2}"), ("qual", f"S{read_len}")])
+    assert dt.itemsize == 36 + l_name + 4 + (read_len + 1) // 2 + read_len
     return dt
 
 
 def write_synthetic_bam(path: str, ref_names, ref_len, records, read_len: int = 100,
-                        hd: str = "@HD\tVN:1.6\tSO:unsorted\tGO:query", threads: int = 32, piece: int = 10_000_000) -> dict:
-    """Returns {"records", "raw_bytes", "compressed_bytes", "seconds"}."""
+                        hd: str = "@HD\tVN:1.6\tSO:unsorted\tGO:query", threads: int = 32, piece: int = 10_000_000,
+                        realistic: bool = False, level: int = None) -> dict:
+    """Returns {"records", "raw_bytes", "compressed_bytes", "seconds", "deflate"}."""
     t0 = time.time()
     n = len(records)
-    dt = _record_dtype(read_len)
+    dt = _record_dtype(read_len, 44 if realistic else 17)
+    pool_seq = pool_qual = None
+    if realistic:
+        pool_seq, pool_qual = _pools(read_len)
+    use_ld = realistic and libdeflate() is not None
+    if level is None:
+        level = 6 if realistic else 1
     text = (("" if not hd else hd + "\n") + "".join(f"@SQ\tSN:{nm}\tLN:{int(l)}\n" for nm, l in zip(ref_names, ref_len))).encode()
     head = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(ref_names)))
     for nm, l in zip(ref_names, ref_len):
@@ -44,30 +149,47 @@ def write_synthetic_bam(path: str, ref_names, ref_len, records, read_len: int = 
         head += struct.pack("<i", len(b)) + b + struct.pack("<i", int(l))
     raw_bytes = len(head)
 
+    l_name = 44 if realistic else 17
+    n_seq = (read_len + 1) // 2
+    # the same layout with opaque byte fields: numpy copies those with one memcpy per element (its S fields go byte by byte)
+    vdt = np.dtype([(nm, dt.fields[nm][0] if dt.fields[nm][0].kind != "S" else np.dtype(f"V{dt.fields[nm][0].itemsize}")) for nm in dt.names])
+    import threading
+    local = threading.local()   # a builder thread reuses its piece buffer (first-touch page faults cost more than the fill)
+
     def piece_bytes(lo):
         hi = min(n, lo + piece)
         m = hi - lo
-        body = np.zeros(m, dtype=dt)
-        body["bs"] = dt.itemsize - 4
+        if getattr(local, "buf", None) is None or local.buf.shape[0] < m:
+            local.buf = np.zeros(min(piece, n), dtype=vdt)
+            b = local.buf
+            b["bs"] = dt.itemsize - 4
+            b["lname"] = l_name
+            b["mapq"] = 255
+            b["bin"] = 4680
+            b["ncig"] = 1
+            b["lseq"] = read_len
+            b["nref"] = -1
+            b["npos"] = -1
+            b["cigar"] = read_len << 4
+            if not realistic:
+                b["seq"] = np.frombuffer(b"\x11" * n_seq, dtype=f"V{n_seq}")
+                b["qual"] = np.frombuffer(b"\x28" * read_len, dtype=f"V{read_len}")
+        body = local.buf[:m]
         body["ref"] = records.ref_id[lo:hi]
         body["pos"] = records.begin_pos[lo:hi]
-        body["lname"] = 17
-        body["mapq"] = 255
-        body["bin"] = 4680
-        body["ncig"] = 1
         body["flag"] = records.flag[lo:hi]
-        body["lseq"] = read_len
-        body["nref"] = -1
-        body["npos"] = -1
+        if realistic:
+            body["name"] = _decimal_names(records.read_key[lo:hi]).view("V44").reshape(m)
+            rng = np.random.Generator(np.random.PCG64([lo, 0xba5e]))
+            body["seq"] = pool_seq[rng.integers(0, pool_seq.shape[0], size=m)].view(f"V{n_seq}")
+            body["qual"] = pool_qual[rng.integers(0, pool_qual.shape[0], size=m)].view(f"V{read_len}")
+            return body.tobytes()
         kb = records.read_key[lo:hi].astype(">u8").view("u1").reshape(m, 8)
         names = np.empty((m, 17), dtype="u1")
         names[:, 0:16:2] = _HEX[kb >> 4]
         names[:, 1:16:2] = _HEX[kb & 15]
         names[:, 16] = 0
-        body["name"] = names.view("S17").reshape(m)
-        body["cigar"] = read_len << 4
-        body["seq"] = b"\x11" * ((read_len + 1) // 2)
-        body["qual"] = b"\x28" * read_len
+        body["name"] = names.view("V17").reshape(m)
         return body.tobytes()
 
     carry = bytes(head)   # bytes not yet written as whole 0xff00-byte blocks
@@ -84,9 +206,15 @@ def write_synthetic_bam(path: str, ref_names, ref_len, records, read_len: int = 
             last = k + 1 == len(los)
             whole = len(raw) if last else len(raw) // 0xff00 * 0xff00
             chunks = [raw[s:s + 0xff00] for s in range(0, whole, 0xff00)]
-            for blk in ex.map(_bgzf, chunks, chunksize=64):
-                f.write(blk)
+            if use_ld:
+                per = max(1, (len(chunks) + 4 * threads - 1) // (4 * threads))
+                for blob in ex.map(lambda part: _bgzf_many_libdeflate(part, level), [chunks[s:s + per] for s in range(0, len(chunks), per)]):
+                    f.write(blob)
+            else:
+                for blk in ex.map(lambda c: _bgzf(c, level), chunks, chunksize=64):
+                    f.write(blk)
             carry = raw[whole:]
             del raw, chunks
         f.write(_bgzf(b"", 6))   # the end-of-file marker block
-    return {"records": n, "raw_bytes": raw_bytes, "compressed_bytes": os.path.getsize(path), "seconds": time.time() - t0}
+    return {"records": n, "raw_bytes": raw_bytes, "compressed_bytes": os.path.getsize(path), "seconds": time.time() - t0,
+            "deflate": (f"libdeflate level {level}" if use_ld else f"zlib level {level}"), "realistic": realistic}

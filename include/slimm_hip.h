@@ -483,13 +483,20 @@ const char* slimm_version(void);
 
 /* BGZF blocks inflated on the device, by themselves: `blocks` = n_bytes of whole BGZF blocks (gzip members with the BC
  * extra field, as in a .bam / .bgz file) in host memory, one behind the other; their inflated bytes, one block's behind the
- * other's, go to out[0, *out_bytes) in host memory.  A lane per block (slimm_amd/csrc/bgzf_inflate.hip); ISIZE, the
+ * other's, go to out[0, *out_bytes) in host memory (slimm_amd/csrc/bgzf_tokens.hip, bgzf_inflate.hip); ISIZE, the
  * well-formedness of every DEFLATE block and the CRC32 of the gzip trailer are checked.  *kernel_ms (may be null): the
  * inflate kernel alone.  Errors (-1 bad input / a corrupt block, -2 HIP) come with a message in err[0, err_cap).
  * Replaces, together with slimm_push_bam_bytes, what seqan::BamFileIn does for the reference (call sites src/misc.hpp:498-522,
  * src/slimm.hpp:194-208).  slimm_push_bgzf_blocks feeds a context's record stream the same way without the round trip. */
 int slimm_bgzf_inflate(int device, const uint8_t* blocks, uint64_t n_bytes, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes,
                        double* kernel_ms, char* err, uint64_t err_cap);
+/* The same with the choice of kernels and a count.  how = 0: the two-phase kernels (slimm_amd/csrc/bgzf_tokens.hip: a lane per
+ * block decodes the Huffman codes into literals in place + match tokens, a workgroup per block fills the matches in LDS and
+ * checks the CRC), with the lane-per-block kernel behind them for what they hand over -- blocks with a stored DEFLATE block
+ * inside, and anything irregular; how = 1: the lane-per-block kernel for every block.  *lane_blocks (may be null): the blocks
+ * the lane-per-block kernel inflated. */
+int slimm_bgzf_inflate_with(int device, const uint8_t* blocks, uint64_t n_bytes, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes,
+                            double* kernel_ms, char* err, uint64_t err_cap, uint32_t how, uint32_t* lane_blocks);
 
 #ifdef __cplusplus
 }

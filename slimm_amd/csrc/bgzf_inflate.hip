@@ -368,7 +368,8 @@ __device__ uint32_t crc32_of(const uint8_t* p, uint32_t n, const uint32_t* t) {
 }
 
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, uint32_t* __restrict__ status) {
+                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ scratch, uint32_t* __restrict__ status,
+                                                     const InflateInfo* __restrict__ info) {
     __shared__ uint16_t s_ltab[kLitTab * 64u];
     __shared__ uint16_t s_dtab[kDistTab * 64u];
     __shared__ uint16_t s_small[(16u + 16u + 32u + 16u) * 64u];  // lcount, dcount, dsym, offs
@@ -399,8 +400,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__
     L.dsym = s_small + 32u * 64u + lane;
     L.offs = s_small + 64u * 64u + lane;
     L.lsym = reinterpret_cast<uint16_t*>(scratch + static_cast<size_t>(slot) * kScratchPerLane);
-    uint32_t bad = 0, first_bad = 0xffffffffu;
+    uint32_t bad = 0, first_bad = 0xffffffffu, mine = 0;
     for (uint32_t b = slot; b < n_blocks; b += n_slots) {
+        if (info && !info[b].flag) continue;  // (the two-phase kernels of bgzf_tokens.hip have inflated it)
+        ++mine;
         const BgzfBlock d = blocks[b];
         uint32_t rc = inflate_block(comp + d.src, d.csize, out + d.dst, d.isize, L);
         if (rc == kInfOk && crc32_of(out + d.dst, d.isize, s_crc) != d.crc) rc = kInfCrc;
@@ -413,16 +416,17 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t* __restrict__
         atomicMin(&status[1], first_bad);
         atomicMax(&status[0], bad);
     }
+    if (info && mine) atomicAdd(&status[2], mine);
 }
 
 uint32_t bgzf_inflate_grid(uint32_t n_blocks) { return std::max(1u, std::min(n_blocks / 64u + 1u, kBgzfMaxGrid)); }
-size_t bgzf_inflate_scratch_bytes(uint32_t grid) { return static_cast<size_t>(grid) * 64u * kScratchPerLane; }
+size_t bgzf_lanes_scratch_bytes(uint32_t grid) { return static_cast<size_t>(grid) * 64u * kScratchPerLane; }
 
-void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,
-                         uint32_t grid, uint32_t* status) {
+void launch_bgzf_inflate_lanes(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,
+                               uint32_t grid, uint32_t* status, const InflateInfo* info) {
     if (!n_blocks) return;
     hipLaunchKernelGGL(k_bgzf_inflate, dim3(grid), dim3(64), 0, st, comp, blocks, n_blocks, out, static_cast<uint8_t*>(scratch),
-                       status);
+                       status, info);
 }
 
 }  // namespace slimm
@@ -488,8 +492,17 @@ bool bgzf_parse_blocks(const uint8_t* bytes, uint64_t n_bytes, uint64_t dst0, st
 // A whole buffer of BGZF blocks in host memory -> their inflated bytes in host memory, through the device: the building
 // block by itself (tests, throughput measurements; include/slimm_hip.h).  kernel_ms: the inflate kernel alone.
 // ---------------------------------------------------------------------------------------------------------
+extern "C" int slimm_bgzf_inflate_with(int device, const uint8_t* blocks, uint64_t n_bytes, uint8_t* out, uint64_t out_cap,
+                                       uint64_t* out_bytes, double* kernel_ms, char* err, uint64_t err_cap, uint32_t how,
+                                       uint32_t* lane_blocks);
 extern "C" int slimm_bgzf_inflate(int device, const uint8_t* blocks, uint64_t n_bytes, uint8_t* out, uint64_t out_cap, uint64_t* out_bytes,
                                   double* kernel_ms, char* err, uint64_t err_cap) {
+    return slimm_bgzf_inflate_with(device, blocks, n_bytes, out, out_cap, out_bytes, kernel_ms, err, err_cap, 0u, nullptr);
+}
+extern "C" int slimm_bgzf_inflate_with(int device, const uint8_t* blocks, uint64_t n_bytes, uint8_t* out, uint64_t out_cap,
+                                       uint64_t* out_bytes, double* kernel_ms, char* err, uint64_t err_cap, uint32_t how,
+                                       uint32_t* lane_blocks) {
+    if (lane_blocks) *lane_blocks = 0;
     auto fail = [&](int code, const std::string& why) {
         if (err && err_cap) {
             const size_t k = std::min<size_t>(why.size(), err_cap - 1);
@@ -526,26 +539,30 @@ extern "C" int slimm_bgzf_inflate(int device, const uint8_t* blocks, uint64_t n_
     ok(hipMalloc(&d_comp, n_bytes + slimm::kBgzfTail), "hipMalloc");
     ok(hipMalloc(&d_out, inflated + 16), "hipMalloc");
     ok(hipMalloc(&d_desc, desc.size() * sizeof(slimm::BgzfBlock)), "hipMalloc");
-    ok(hipMalloc(&d_scratch, slimm::bgzf_inflate_scratch_bytes(grid)), "hipMalloc");
-    ok(hipMalloc(&d_status, 8), "hipMalloc");
+    ok(hipMalloc(&d_scratch, how == 1u ? slimm::bgzf_lanes_scratch_bytes(grid) : slimm::bgzf_inflate_scratch_bytes(n)), "hipMalloc");
+    ok(hipMalloc(&d_status, 16), "hipMalloc");
     if (!rc) {
-        const uint32_t st0[2] = {0u, 0xffffffffu};
+        const uint32_t st0[4] = {0u, 0xffffffffu, 0u, 0u};
         ok(hipMemcpy(d_comp, blocks, n_bytes, hipMemcpyHostToDevice), "hipMemcpy");
         ok(hipMemset(d_comp + n_bytes, 0, slimm::kBgzfTail), "hipMemset");
         ok(hipMemcpy(d_desc, desc.data(), desc.size() * sizeof(slimm::BgzfBlock), hipMemcpyHostToDevice), "hipMemcpy");
-        ok(hipMemcpy(d_status, st0, 8, hipMemcpyHostToDevice), "hipMemcpy");
+        ok(hipMemcpy(d_status, st0, 16, hipMemcpyHostToDevice), "hipMemcpy");
         ok(hipEventCreate(&e0), "hipEventCreate");
         ok(hipEventCreate(&e1), "hipEventCreate");
     }
     if (!rc) {
         ok(hipEventRecord(e0, nullptr), "hipEventRecord");
-        slimm::launch_bgzf_inflate(nullptr, d_comp, d_desc, n, d_out, d_scratch, grid, d_status);
+        if (how == 1u)
+            slimm::launch_bgzf_inflate_lanes(nullptr, d_comp, d_desc, n, d_out, d_scratch, grid, d_status, nullptr);
+        else
+            slimm::launch_bgzf_inflate(nullptr, d_comp, d_desc, n, d_out, d_scratch, d_status);
         ok(hipEventRecord(e1, nullptr), "hipEventRecord");
         ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
         float ms = 0;
         if (!rc && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && kernel_ms) *kernel_ms = ms;
-        uint32_t st1[2] = {0, 0};
-        ok(hipMemcpy(st1, d_status, 8, hipMemcpyDeviceToHost), "hipMemcpy");
+        uint32_t st1[4] = {0, 0, 0, 0};
+        ok(hipMemcpy(st1, d_status, 16, hipMemcpyDeviceToHost), "hipMemcpy");
+        if (lane_blocks) *lane_blocks = how == 1u ? n : st1[2];
         if (!rc && st1[0]) {
             rc = -1;
             msg = "corrupt BGZF block (device inflate: error " + std::to_string(st1[0]) + " in block " + std::to_string(st1[1]) + ")";

@@ -1,0 +1,730 @@
+// BGZF blocks inflated on the device in TWO phases (gfx950, wave64) -- the fast path in front of bgzf_inflate.hip.
+//
+// Where it stands on the path: the reference reads its input through seqan::BamFileIn (call sites src/misc.hpp:498-522,
+// src/slimm.hpp:194-208), which inflates the BGZF blocks of a BAM file.  bgzf_inflate.hip does that with a LANE per block
+// that decodes AND copies: every trip of a wave's symbol loop waits for the slowest lane's match copy (19 GB/s of inflated
+// bytes on a BAM that compresses 3-fold, profiles/round5/00_realistic_cli_before.txt).  Here the two jobs are apart:
+//
+//   k_inflate_decode   a LANE per block, Huffman decoding only, in wave-uniform steps (no data-dependent branch inside a
+//                      step: every lane decodes one literal/length symbol and, speculatively, the distance symbol behind
+//                      it).  Canonical decoding without first-level tables: the next 15 stream bits, bit-reversed, are
+//                      compared with the 15 left-justified code-length limits held in REGISTERS (v_cmp + v_addc per
+//                      length), which leaves LDS only the sorted symbols (9 + 5 bits) and one base per length: 520 B per
+//                      lane, 33 KB per wave -> four waves per CU where the table-driven kernel fits two.  Literals go
+//                      straight to their final place in the output (four at a time), matches become 4-byte TOKENS
+//                      {literals since the last token, length, distance}: what is left of the block afterwards are holes.
+//                      The input comes through a 128-bit reservoir per lane that takes 8 unaligned bytes per step, asked
+//                      for one step ahead; the stores of a step are issued at the top of the next one, behind the wait for
+//                      that load (on this hardware a wait for a load is a wait for every store issued before it).
+//   k_inflate_resolve  a WORKGROUP per block, the block's 64 KB in LDS: the holes are filled in chunks of <= 4 KB of output
+//                      -- every byte of a match gets a pointer to its source byte, pointer JUMPING (log2 of the longest
+//                      chain of matches copying matches, <= 12 rounds) brings every pointer to a literal or to a byte in
+//                      front of the chunk, one gather finishes the chunk.  No byte waits for another lane's copy loop.
+//                      Then the CRC32 of the gzip trailer (256 segments in parallel, combined with x^(8n) mod P like zlib's
+//                      crc32_combine) and the block written out in 16-byte stores.
+//
+// What the fast path does not do it hands to bgzf_inflate.hip's kernel block by block (info.flag): stored DEFLATE blocks,
+// and ANY irregularity -- a bad code, a distance beyond the output, a CRC that does not match.  That kernel decides what is
+// an error and which; a valid stream is never rejected here, a corrupt one never accepted.  status[2] counts the blocks
+// that went that way.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace slimm {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ phase 1: decode
+// LDS words of a lane (word w of lane l at [w * 64 + l]: every lane stays in its own bank whatever it indexes)
+constexpr uint32_t kLsymLo = 0;      // 72 words: low 8 bits of the 288 literal/length symbols in canonical order
+constexpr uint32_t kLsymHi = 72;     //  9 words: their bit 8
+constexpr uint32_t kDsym = 81;       //  8 words: the 30 distance symbols in canonical order (bytes)
+constexpr uint32_t kLbase = 89;      //  8 words: per code length, (symbols with shorter codes) - (first code of the length), 16 bits
+constexpr uint32_t kDbase = 97;      //  8 words: the same for the distance code
+constexpr uint32_t kTmpA = 105;      //  8 words: counts per length (construction)
+constexpr uint32_t kTmpB = 113;      //  8 words: next free place per length (construction)
+constexpr uint32_t kClSym = 121;     //  5 words: the code-length code's 19 symbols in canonical order (while a header is read)
+constexpr uint32_t kClBase = 126;    //  4 words: its bases (lengths 1 .. 7)
+constexpr uint32_t kLaneWords = 130;
+
+struct Lds {
+    uint32_t* w;  // the lane's word 0
+    __device__ __forceinline__ uint8_t* bytes() const { return reinterpret_cast<uint8_t*>(w); }
+    __device__ __forceinline__ uint8_t& b8(uint32_t base, uint32_t i) const { return bytes()[(base + (i >> 2)) * 256u + (i & 3u)]; }
+    __device__ __forceinline__ uint16_t& b16(uint32_t base, uint32_t i) const {
+        return reinterpret_cast<uint16_t*>(w)[(base + (i >> 1)) * 128u + (i & 1u)];
+    }
+    __device__ __forceinline__ uint32_t& b32(uint32_t base, uint32_t i) const { return w[(base + i) * 64u]; }
+};
+
+__device__ __forceinline__ uint64_t ld64u(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ void st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// The input of a lane: 128 bits of the stream, low bits first; `rp` = the stream byte that follows them.
+struct Bits {
+    uint64_t lo, hi;
+    uint32_t avail, rp;
+    __device__ __forceinline__ void start(uint32_t at) {
+        lo = hi = 0;
+        avail = 0;
+        rp = at;
+    }
+    // 8 more bytes (read at rp) when there is room for all of them
+    __device__ __forceinline__ void append(uint64_t v) {
+        if (avail <= 64u) {
+            const uint32_t a = avail;
+            lo |= a < 64u ? v << a : 0ull;
+            hi = a == 64u ? v : (a ? v >> (64u - a) : 0ull);
+            avail = a + 64u;
+            rp += 8u;
+        }
+    }
+    __device__ __forceinline__ void drop(uint32_t c) {  // c < 64
+        if (c) {
+            lo = (lo >> c) | (hi << (64u - c));
+            hi >>= c;
+            avail -= c;
+        }
+    }
+    // stream position, in bits, of the next unread bit
+    __device__ __forceinline__ uint64_t at_bit() const { return static_cast<uint64_t>(rp) * 8u - avail; }
+};
+
+// 15 left-justified limits of a canonical code: a 15-bit pattern x (first stream bit on top) has a code of length
+// 1 + #{l : x >= lim[l]}; 16 = no code.
+struct Limits {
+    uint32_t v[15];
+    __device__ __forceinline__ uint32_t length_of(uint32_t x) const {
+        uint32_t n = 1;
+#pragma unroll
+        for (int l = 0; l < 15; ++l) n += x >= v[l] ? 1u : 0u;
+        return n;
+    }
+};
+
+__device__ __forceinline__ uint32_t top15(uint64_t w) { return __builtin_bitreverse32(static_cast<uint32_t>(w)) >> 17; }
+
+// From the counts per code length (LDS, 16 bits each, tmp A): the limits, the base per length (-> `base_at`), the first
+// free place per length (-> tmp B).  Returns the code's slack: 0 complete, > 0 incomplete, < 0 over-subscribed.
+template <uint32_t kMaxLen>
+__device__ int code_from_counts(const Lds& L, uint32_t base_at, Limits& lim) {
+    uint32_t code = 0, offs = 0;
+    int left = 1;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        const uint32_t c = l <= kMaxLen ? L.b16(kTmpA, l) : 0u;
+        left = (left << 1) - static_cast<int>(c);
+        lim.v[l - 1] = (code + c) << (15u - l);
+        if (l <= kMaxLen) {
+            L.b16(base_at, l) = static_cast<uint16_t>(offs - code);
+            L.b16(kTmpB, l) = static_cast<uint16_t>(offs);
+        }
+        offs += c;
+        code = (code + c) << 1;
+    }
+    return left;
+}
+
+__device__ __forceinline__ uint32_t symbol_at(const Lds& L, uint32_t base_at, uint32_t x, uint32_t len) {
+    const uint32_t l = len > 15u ? 15u : len;
+    return (L.b16(base_at, l) + (x >> (15u - l))) & 0xffffu;
+}
+
+enum : uint32_t { kModeHeader = 0, kModeDecode = 1, kModeDone = 2, kModeHandOver = 3 };
+
+// One lane's view of its block while headers are read: plain bit taking with the load waited for on the spot (a header is
+// a few hundred bits per ~16 K symbols).
+struct HeaderBits {
+    Bits& b;
+    const uint8_t* in;
+    __device__ __forceinline__ uint32_t take(uint32_t n) {  // n <= 16
+        if (b.avail <= 64u) b.append(ld64u(in + b.rp));
+        const uint32_t v = static_cast<uint32_t>(b.lo) & ((1u << n) - 1u);
+        b.drop(n);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t peek15() {
+        if (b.avail <= 64u) b.append(ld64u(in + b.rp));
+        return top15(b.lo);
+    }
+};
+
+// The code lengths of a dynamic block as runs {length value, repeat}: decoded from the stream with the code-length code
+// (limits `cl`, symbols at kClSym, bases at kClBase).  prev = the length before (for symbol 16).  Returns false for a bad code.
+__device__ __forceinline__ bool next_run(HeaderBits& hb, const Lds& L, const Limits& cl, uint32_t& prev, uint32_t& val, uint32_t& rep,
+                                         bool first) {
+    const uint32_t x = hb.peek15();
+    const uint32_t len = cl.length_of(x);
+    if (len > 7u) return false;
+    const uint32_t idx = symbol_at(L, kClBase, x, len);
+    if (idx >= 19u) return false;
+    const uint32_t sym = L.b8(kClSym, idx);
+    hb.b.drop(len);
+    if (sym < 16u) {
+        val = sym;
+        rep = 1;
+        prev = sym;
+    } else if (sym == 16u) {
+        if (first) return false;
+        val = prev;
+        rep = 3u + hb.take(2);
+    } else if (sym == 17u) {
+        val = 0;
+        rep = 3u + hb.take(3);
+        prev = 0;
+    } else {
+        val = 0;
+        rep = 11u + hb.take(7);
+        prev = 0;
+    }
+    return true;
+}
+
+__device__ const uint8_t kClOrderD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// The header of the next DEFLATE block of a lane and the two codes behind it.  Returns the lane's new mode.
+// (Executed by the lanes that wait for a header, the others masked: trip counts differ by lane, nothing else.)
+// The code lengths of a dynamic block are decoded TWICE from the stream -- once for the counts per length, once to put the
+// symbols in their places -- so no array of 316 lengths exists anywhere.
+__device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, const Lds& L, Limits& LL, Limits& DL, uint32_t& last) {
+    HeaderBits hb{bits, in};
+    last = hb.take(1);
+    const uint32_t type = hb.take(2);
+    if (type != 1u && type != 2u) return kModeHandOver;  // stored blocks (and type 3) are the other kernel's
+    uint32_t nlen = 288, ndist = 30;
+    Limits cl;
+    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = 0;
+    if (type == 2u) {
+        nlen = hb.take(5) + 257u;
+        ndist = hb.take(5) + 1u;
+        const uint32_t ncode = hb.take(4) + 4u;
+        if (nlen > 286u || ndist > 30u) return kModeHandOver;
+        // the code-length code: 19 lengths of 3 bits -> counts, limits, bases, sorted symbols
+        uint32_t cll[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < ncode; ++i) {
+            const uint32_t v = hb.take(3);
+            const uint32_t s = kClOrderD[i];
+            cll[s >> 3] |= v << (3u * (s & 7u));
+            if (v) ++L.b16(kTmpA, v);
+        }
+        uint32_t n_cl = 0;
+        for (uint32_t l = 1; l <= 7u; ++l) n_cl += L.b16(kTmpA, l);
+        const int slack = code_from_counts<7>(L, kClBase, cl);
+        if (slack < 0 || (slack > 0 && n_cl != 1u) || n_cl == 0u) return kModeHandOver;
+        for (uint32_t s = 0; s < 19u; ++s) {
+            const uint32_t v = (cll[s >> 3] >> (3u * (s & 7u))) & 7u;
+            if (v) L.b8(kClSym, L.b16(kTmpB, v)++) = static_cast<uint8_t>(s);
+        }
+    }
+    // pass 1: how many codes of each length -- literal/length code in tmp A, distance code in tmp B
+    const Bits saved = bits;
+    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = 0;
+    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpB, l) = 0;
+    if (type == 1u) {
+        L.b16(kTmpA, 7) = 24;
+        L.b16(kTmpA, 8) = 152;
+        L.b16(kTmpA, 9) = 112;
+        L.b16(kTmpB, 5) = 30;
+    } else {
+        uint32_t index = 0, prev = 0;
+        while (index < nlen + ndist) {
+            uint32_t val, rep;
+            if (!next_run(hb, L, cl, prev, val, rep, index == 0u)) return kModeHandOver;
+            if (index + rep > nlen + ndist) return kModeHandOver;
+            if (val) {
+                const uint32_t in_l = index < nlen ? min(rep, nlen - index) : 0u;
+                L.b16(kTmpA, val) = static_cast<uint16_t>(L.b16(kTmpA, val) + in_l);
+                L.b16(kTmpB, val) = static_cast<uint16_t>(L.b16(kTmpB, val) + (rep - in_l));
+            }
+            index += rep;
+        }
+        if (bits.at_bit() > static_cast<uint64_t>(csize) * 8u) return kModeHandOver;
+    }
+    // the distance counts out of the way, the literal/length code from tmp A (its places -> tmp B), then the distance code
+    // from its counts (back in tmp A; its places take their place)
+    uint32_t dcnt[8];
+#pragma unroll
+    for (uint32_t l = 0; l < 8u; ++l) dcnt[l] = L.b32(kTmpB, l);
+    uint32_t n_l = 0;
+    for (uint32_t l = 1; l <= 15u; ++l) n_l += L.b16(kTmpA, l);
+    const int lslack = code_from_counts<15>(L, kLbase, LL);
+    if (lslack < 0 || (lslack > 0 && n_l != 1u) || n_l == 0u) return kModeHandOver;
+#pragma unroll
+    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = dcnt[l];
+    {
+        uint32_t code = 0, offs = 0, n_d = 0;
+        int left = 1;
+        uint32_t places[16];
+#pragma unroll
+        for (uint32_t l = 1; l <= 15u; ++l) {
+            const uint32_t c = L.b16(kTmpA, l);
+            n_d += c;
+            left = (left << 1) - static_cast<int>(c);
+            DL.v[l - 1] = (code + c) << (15u - l);
+            L.b16(kDbase, l) = static_cast<uint16_t>(offs - code);
+            places[l] = offs;
+            offs += c;
+            code = (code + c) << 1;
+        }
+#pragma unroll
+        for (uint32_t l = 1; l <= 15u; ++l) L.b16(kTmpA, l) = static_cast<uint16_t>(places[l]);
+        // (a distance code may be incomplete with one code, or absent altogether in a block of literals only; the fixed
+        // code has 30 of its 32 codes)
+        if (type == 2u && (left < 0 || (left > 0 && n_d > 1u))) return kModeHandOver;
+    }
+    // pass 2: the symbols into their places
+    for (uint32_t i = 0; i < 9u; ++i) L.b32(kLsymHi, i) = 0;
+    if (type == 1u) {
+        for (uint32_t s = 0; s < 288u; ++s) {
+            const uint32_t l = s < 144u ? 8u : (s < 256u ? 9u : (s < 280u ? 7u : 8u));
+            const uint32_t at = L.b16(kTmpB, l)++;
+            L.b8(kLsymLo, at) = static_cast<uint8_t>(s);
+            if (s >= 256u) L.b32(kLsymHi, at >> 5) |= 1u << (at & 31u);
+        }
+        for (uint32_t s = 0; s < 30u; ++s) L.b8(kDsym, s) = static_cast<uint8_t>(s);
+    } else {
+        const Bits end1 = bits;
+        bits = saved;
+        uint32_t index = 0, prev = 0;
+        while (index < nlen + ndist) {
+            uint32_t val = 0, rep = 1;
+            if (!next_run(hb, L, cl, prev, val, rep, index == 0u)) return kModeHandOver;  // (cannot happen: pass 1 took these runs)
+            if (val) {
+                for (uint32_t k = 0; k < rep; ++k) {
+                    const uint32_t s = index + k;
+                    if (s < nlen) {
+                        const uint32_t at = L.b16(kTmpB, val)++;
+                        L.b8(kLsymLo, at) = static_cast<uint8_t>(s);
+                        if (s >= 256u) L.b32(kLsymHi, at >> 5) |= 1u << (at & 31u);
+                    } else {
+                        L.b8(kDsym, L.b16(kTmpA, val)++) = static_cast<uint8_t>(s - nlen);
+                    }
+                }
+            }
+            index += rep;
+        }
+        (void)end1;
+    }
+    return kModeDecode;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
+    __shared__ uint32_t s_lds[kLaneWords * 64u];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t b = blockIdx.x * 64u + lane;
+    const bool have = b < n_blocks;
+    Lds L{s_lds + lane};
+    BgzfBlock d;
+    d.src = d.dst = 0;
+    d.csize = d.isize = 0;
+    if (have) d = blocks[b];
+    const uint8_t* in = comp + d.src;
+    uint8_t* o_base = out + d.dst;
+    uint32_t* t_base = tok + static_cast<size_t>(have ? b : 0u) * kInflateTokCap;
+    const uint32_t csize = d.csize, isize = d.isize;
+
+    Bits bits;
+    bits.start(0);
+    Limits LL, DL;
+#pragma unroll
+    for (int l = 0; l < 15; ++l) LL.v[l] = DL.v[l] = 0x8000u;
+    uint32_t mode = have ? kModeHeader : kModeDone;
+    uint32_t last = 0, o = 0, acc = 0, acc_n = 0, litrun = 0, ntok = 0;
+    // stores waiting for the top of the next step
+    uint32_t p_lit = 0, p_lit_at = 0, p_lit_n = 0, p_tok0 = 0, p_tok1 = 0, p_ntok = 0, p_tok_at = 0;
+
+    for (;;) {
+        const uint64_t want = __ballot(mode == kModeHeader);
+        const uint64_t going = __ballot(mode == kModeDecode);
+        if (!want && !going) break;
+        if (want && (!going || __popcll(want) >= 8)) {
+            if (mode == kModeHeader) {
+                mode = read_header(bits, in, csize, L, LL, DL, last);
+            }
+            continue;
+        }
+        // a burst of uniform steps
+        uint64_t ahead = 0;
+        if (mode == kModeDecode) ahead = ld64u(in + bits.rp);
+        for (uint32_t it = 0; it < 16u; ++it) {
+            const bool run = mode == kModeDecode;
+            // the input asked for a step ago; the stores of the step before behind it
+            if (run) bits.append(ahead);
+            if (run) ahead = ld64u(in + bits.rp);
+            if (p_lit_n) {
+                if (p_lit_at + 4u <= isize) {
+                    st32u(o_base + p_lit_at, p_lit);
+                } else {
+                    for (uint32_t k = 0; k < p_lit_n; ++k) o_base[p_lit_at + k] = static_cast<uint8_t>(p_lit >> (8u * k));
+                }
+                p_lit_n = 0;
+            }
+            if (p_ntok) {
+                t_base[p_tok_at] = p_tok0;
+                if (p_ntok > 1u) t_base[p_tok_at + 1u] = p_tok1;
+                p_ntok = 0;
+            }
+            if (!__any(run)) break;
+            // ---- one literal/length symbol, and the distance symbol behind it as if it were a length
+            uint64_t w = bits.lo;
+            const uint32_t x = top15(w);
+            const uint32_t len = LL.length_of(x);
+            const uint32_t idx = min(symbol_at(L, kLbase, x, len), 287u);
+            const uint32_t sym = L.b8(kLsymLo, idx) | (((L.b32(kLsymHi, idx >> 5) >> (idx & 31u)) & 1u) << 8);
+            bool bad = len > 15u;
+            uint32_t c = len;
+            w >>= len;
+            const bool is_lit = sym < 256u, is_eob = sym == 256u, is_len = sym > 256u;
+            const uint32_t ls = is_len ? sym - 257u : 0u;
+            bad = bad | (ls > 28u);
+            const uint32_t le = (ls >= 8u && ls < 28u) ? (ls >> 2) - 1u : 0u;
+            const uint32_t lb = ls < 8u ? ls + 3u : (ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << le));
+            const uint32_t mlen = lb + (static_cast<uint32_t>(w) & ((1u << le) - 1u));
+            w >>= le;
+            const uint32_t y = top15(w);
+            const uint32_t dl = DL.length_of(y);
+            const uint32_t didx = min(symbol_at(L, kDbase, y, dl), 31u);
+            const uint32_t ds = L.b8(kDsym, didx);
+            const uint32_t de = ds >= 4u ? (ds >> 1) - 1u : 0u;
+            const uint32_t dbv = ds < 4u ? ds + 1u : 1u + ((2u + (ds & 1u)) << de);
+            const uint32_t dist = dbv + (static_cast<uint32_t>(w >> (dl > 15u ? 15u : dl)) & ((1u << de) - 1u));
+            if (is_len) {
+                bad = bad | (dl > 15u) | (ds > 29u);
+                c += le + (dl > 15u ? 0u : dl) + de;
+            }
+            if (run) {
+                bool flush = false;
+                if (is_lit) {
+                    if (o >= isize) bad = true;
+                    acc |= sym << (8u * acc_n);
+                    ++acc_n;
+                    ++o;
+                    ++litrun;
+                    flush = acc_n == 4u;
+                } else {
+                    flush = acc_n != 0u;
+                }
+                if (flush & !bad) {
+                    p_lit = acc;
+                    p_lit_n = acc_n;
+                    p_lit_at = o - acc_n;
+                    acc = 0;
+                    acc_n = 0;
+                }
+                if (is_len & !bad) {
+                    if (dist > o || o + mlen > isize || ntok + 2u > kInflateTokCap) {
+                        bad = true;
+                    } else {
+                        p_tok_at = ntok;
+                        if (litrun > 255u) {
+                            p_tok0 = 0x80000000u | litrun;
+                            p_tok1 = ((mlen - 3u) << 15) | (dist - 1u);
+                            p_ntok = 2;
+                        } else {
+                            p_tok0 = (litrun << 23) | ((mlen - 3u) << 15) | (dist - 1u);
+                            p_ntok = 1;
+                        }
+                        ntok += p_ntok;
+                        litrun = 0;
+                        o += mlen;
+                    }
+                }
+                bits.drop(c);
+                if (bits.at_bit() > static_cast<uint64_t>(csize) * 8u) bad = true;
+                if (bad) {
+                    mode = kModeHandOver;
+                } else if (is_eob) {
+                    mode = last ? kModeDone : kModeHeader;
+                }
+            }
+        }
+        // (what the burst's last step left to be stored)
+        if (p_lit_n) {
+            if (p_lit_at + 4u <= isize) {
+                st32u(o_base + p_lit_at, p_lit);
+            } else {
+                for (uint32_t k = 0; k < p_lit_n; ++k) o_base[p_lit_at + k] = static_cast<uint8_t>(p_lit >> (8u * k));
+            }
+            p_lit_n = 0;
+        }
+        if (p_ntok) {
+            t_base[p_tok_at] = p_tok0;
+            if (p_ntok > 1u) t_base[p_tok_at + 1u] = p_tok1;
+            p_ntok = 0;
+        }
+    }
+    if (have) {
+        // the stream must end exactly at ISIZE bytes and inside the payload
+        if (mode == kModeDone && (o != isize || (bits.at_bit() + 7u) / 8u > csize)) mode = kModeHandOver;
+        InflateInfo r;
+        r.n_tok = ntok;
+        r.flag = mode == kModeDone ? 0u : 1u;
+        info[b] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ phase 2: resolve
+namespace {
+
+constexpr uint32_t kChunk = 4096;  // output bytes of a chunk (a 16-bit pointer each)
+constexpr uint32_t kPoly = 0xedb88320u;
+
+// zlib's multmodp: a(x) * b(x) mod P(x), reflected representation (bit 31 = x^0)
+__host__ __device__ constexpr uint32_t multmodp(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (uint32_t m = 1u << 31; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ kPoly : b >> 1;
+    }
+    return p;
+}
+struct CrcPowers {
+    uint32_t v[32];  // x^(2^k) mod P
+};
+__host__ __device__ constexpr CrcPowers crc_powers() {
+    CrcPowers t{};
+    uint32_t p = 1u << 30;  // x^1
+    t.v[0] = p;
+    for (int k = 1; k < 32; ++k) t.v[k] = p = multmodp(p, p);
+    return t;
+}
+__device__ const CrcPowers kX2n = crc_powers();
+// x^(8 n) mod P
+__device__ uint32_t x8n(uint32_t n) {
+    uint32_t p = 1u << 31;  // x^0
+    for (uint32_t k = 3; n; n >>= 1, ++k)
+        if (n & 1u) p = multmodp(kX2n.v[k & 31u], p);
+    return p;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out,
+                                                         const uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
+    __shared__ uint4 s_win4[65536 / 16];
+    __shared__ uint32_t s_ptr32[kChunk / 2];  // 16-bit pointers; the CRC tables afterwards
+    __shared__ uint32_t s_scan[8];
+    __shared__ uint32_t s_flag[2];
+    __shared__ uint32_t s_crc[256];
+    uint8_t* const win = reinterpret_cast<uint8_t*>(s_win4);
+    int16_t* const ptr = reinterpret_cast<int16_t*>(s_ptr32);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const InflateInfo nf = info[b];
+    if (nf.flag) return;  // (uniform: the other kernel's block)
+    const BgzfBlock d = blocks[b];
+    const uint32_t isize = d.isize;
+    uint8_t* const o_base = out + d.dst;
+    const uint32_t* const t_base = tok + static_cast<size_t>(b) * kInflateTokCap;
+    for (uint32_t i = tid * 16u; i < isize; i += 4096u) {
+        uint4 v;
+        __builtin_memcpy(&v, o_base + i, 16);  // (up to 15 bytes behind the block: the next block's, or the buffer's slack)
+        s_win4[i >> 4] = v;
+    }
+    if (tid == 0) s_flag[1] = 0;
+    __syncthreads();
+    uint32_t base = 0, t0 = 0;
+    bool wrong = false;
+    while (t0 < nf.n_tok) {
+        // a token per thread, the spans' running sum
+        const uint32_t t = t0 + tid;
+        const uint32_t tv = t < nf.n_tok ? t_base[t] : 0x80000000u;
+        const bool skip = (tv >> 31) != 0u;
+        const uint32_t litrun = skip ? tv & 0x7fffffffu : (tv >> 23) & 0xffu;
+        const uint32_t mlen = skip ? 0u : ((tv >> 15) & 0xffu) + 3u;
+        const uint32_t dist = (tv & 0x7fffu) + 1u;
+        const uint32_t span = litrun + mlen;
+        uint32_t incl = span;
+        for (uint32_t s = 1; s < 64u; s <<= 1) {
+            const uint32_t up = __shfl_up(incl, s);
+            if (lane >= s) incl += up;
+        }
+        if (lane == 63u) s_scan[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wv; ++k) before += s_scan[k];
+        incl += before;
+        // the chunk: the tokens whose spans end inside kChunk bytes (a prefix: spans are sums); a long run of literals by
+        // itself when it leads
+        const bool in_chunk = t < nf.n_tok && incl <= kChunk;
+        const uint64_t mine = __ballot(in_chunk);
+        if (lane == 0) s_scan[4 + wv] = static_cast<uint32_t>(__popcll(mine));
+        __syncthreads();
+        uint32_t n_act = s_scan[4] + s_scan[5] + s_scan[6] + s_scan[7];
+        if (tid == 0) s_flag[0] = 0;
+        uint32_t S;
+        if (n_act == 0) {  // the first token is a run of literals longer than a chunk: nothing to fill
+            n_act = 1;
+            S = 0;
+            if (tid == 0) {
+                s_scan[0] = span;
+                if (!skip) s_flag[1] = 1;   // (a match never spans a chunk)
+            }
+            __syncthreads();
+            base += s_scan[0];
+            __syncthreads();
+            t0 += 1;
+            if (base > isize) {
+                wrong = true;
+                break;
+            }
+            continue;
+        }
+        if (tid == n_act - 1u) s_scan[0] = incl;
+        __syncthreads();
+        S = s_scan[0];
+        if (base + S > isize) {
+            wrong = true;
+            break;
+        }
+        // every byte its own source ...
+        for (uint32_t j = tid * 2u; j < S; j += 512u) s_ptr32[j >> 1] = j | ((j + 1u) << 16);
+        __syncthreads();
+        // ... but the bytes of a match: the byte `dist` in front (relative to the chunk: negative = an earlier chunk's)
+        if (in_chunk && mlen) {
+            const uint32_t d0 = incl - mlen;
+            if (base + d0 < dist) {
+                s_flag[1] = 1;
+            } else {
+                const int32_t from = static_cast<int32_t>(d0) - static_cast<int32_t>(dist);
+                for (uint32_t k = 0; k < mlen; ++k) ptr[d0 + k] = static_cast<int16_t>(from + static_cast<int32_t>(k));
+            }
+        }
+        __syncthreads();
+        // pointer jumping: until every pointer is at a literal (points at itself) or in front of the chunk
+        for (;;) {
+            bool changed = false;
+            for (uint32_t j = tid; j < S; j += 256u) {
+                const int32_t p = ptr[j];
+                if (p >= 0 && p != static_cast<int32_t>(j)) {
+                    const int32_t q = ptr[p];
+                    if (q != p) {
+                        ptr[j] = static_cast<int16_t>(q);
+                        changed = true;
+                    }
+                }
+            }
+            if (changed) s_flag[0] = 1;
+            __syncthreads();
+            const uint32_t any = s_flag[0];
+            __syncthreads();
+            if (!any) break;
+            if (tid == 0) s_flag[0] = 0;
+            __syncthreads();
+        }
+        for (uint32_t j = tid; j < S; j += 256u) {
+            const int32_t p = ptr[j];
+            if (p != static_cast<int32_t>(j)) win[base + j] = win[static_cast<int32_t>(base) + p];
+        }
+        __syncthreads();
+        base += S;
+        t0 += n_act;
+    }
+    __syncthreads();
+    if (wrong || s_flag[1]) {
+        if (tid == 0) info[b].flag = 1;
+        return;
+    }
+    // ---- the gzip trailer's CRC32: segments of 256 bytes, one per thread, combined like zlib's crc32_combine
+    for (uint32_t i = tid; i < 256u; i += 256u) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? kPoly ^ (c >> 1) : c >> 1;
+        s_crc[i] = c;
+    }
+    __syncthreads();
+    uint32_t* const t4 = s_ptr32;  // slice-by-4 tables 1 .. 3 (table 0 = s_crc)
+    {
+        uint32_t c = s_crc[tid];
+        for (uint32_t k = 0; k < 3u; ++k) {
+            c = s_crc[c & 0xffu] ^ (c >> 8);
+            t4[k * 256u + tid] = c;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_seg = (isize + 255u) >> 8;
+    uint32_t crc = 0;
+    if (tid < n_seg) {
+        const uint32_t lo = tid << 8, hi = min(isize, lo + 256u);
+        uint32_t c = 0xffffffffu, i = lo;
+        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(win);
+        for (; i + 4u <= hi; i += 4u) {
+            c ^= w32[i >> 2];
+            c = t4[512u + (c & 0xffu)] ^ t4[256u + ((c >> 8) & 0xffu)] ^ t4[(c >> 16) & 0xffu] ^ s_crc[c >> 24];
+        }
+        for (; i < hi; ++i) c = s_crc[(c ^ win[i]) & 0xffu] ^ (c >> 8);
+        crc = ~c;
+    }
+    __syncthreads();
+    // the full segments (all but the last) in a tree, right-aligned among 256 leaves; then the last one behind them
+    uint32_t* const leaf = s_ptr32 + 1024;
+    const uint32_t n_full = n_seg ? n_seg - 1u : 0u;
+    leaf[tid] = 0;
+    __syncthreads();
+    if (tid < n_full) leaf[tid + (256u - n_full)] = crc;
+    if (tid == n_seg - 1u && n_seg) s_scan[0] = crc;
+    __syncthreads();
+    for (uint32_t lv = 0; lv < 8u; ++lv) {   // the right child covers 256 << lv bytes: shift the left one by x^(8 * 256 << lv)
+        const uint32_t n = 128u >> lv;
+        uint32_t v = 0;
+        if (tid < n) {
+            const uint32_t a = leaf[2u * tid], bb = leaf[2u * tid + 1u];
+            v = (a ? multmodp(kX2n.v[(11u + lv) & 31u], a) : 0u) ^ bb;
+        }
+        __syncthreads();
+        if (tid < n) leaf[tid] = v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t last_len = isize - (n_full << 8);
+        const uint32_t head = leaf[0];
+        const uint32_t all = n_seg ? ((head ? multmodp(x8n(last_len), head) : 0u) ^ s_scan[0]) : 0u;
+        s_flag[0] = all == d.crc ? 0u : 1u;
+    }
+    __syncthreads();
+    if (s_flag[0]) {
+        if (tid == 0) info[b].flag = 1;
+        return;
+    }
+    for (uint32_t i = tid * 16u; i < isize; i += 4096u) {
+        if (i + 16u <= isize) {
+            const uint4 v = s_win4[i >> 4];
+            __builtin_memcpy(o_base + i, &v, 16);
+        } else {
+            for (uint32_t k = i; k < isize; ++k) o_base[k] = win[k];
+        }
+    }
+}
+
+size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks) {
+    return bgzf_lanes_scratch_bytes(kBgzfMaxGrid) + static_cast<size_t>(n_blocks) * (kInflateTokCap * 4u + sizeof(InflateInfo)) + 256u;
+}
+
+// status[0] = the largest error code met (0: every block inflated to its ISIZE and CRC), status[1] = the first bad block
+// (preset ~0), status[2] = blocks that went through the lane-per-block kernel (preset 0)
+void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,
+                         uint32_t* status) {
+    if (!n_blocks) return;
+    uint8_t* s = static_cast<uint8_t*>(scratch);
+    void* lanes_scratch = s;
+    s += bgzf_lanes_scratch_bytes(kBgzfMaxGrid);
+    InflateInfo* info = reinterpret_cast<InflateInfo*>(s);
+    s += (static_cast<size_t>(n_blocks) * sizeof(InflateInfo) + 255u) & ~static_cast<size_t>(255u);
+    uint32_t* tok = reinterpret_cast<uint32_t*>(s);
+    hipLaunchKernelGGL(k_inflate_decode, dim3((n_blocks + 63u) / 64u), dim3(64), 0, st, comp, blocks, n_blocks, out, tok, info);
+    hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 0, st, blocks, n_blocks, out, tok, info);
+    launch_bgzf_inflate_lanes(st, comp, blocks, n_blocks, out, lanes_scratch, bgzf_inflate_grid(n_blocks), status, info);
+}
+
+}  // namespace slimm

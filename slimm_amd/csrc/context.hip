@@ -157,7 +157,7 @@ struct slimm_ctx {
         DevBuf<uint8_t> comp[kBamRing];
         DevBuf<BgzfBlock> desc[kBamRing];
         DevBuf<uint8_t> inflate_scratch;
-        DevBuf<uint32_t> inflate_status;       // 2 words per buffer
+        DevBuf<uint32_t> inflate_status;       // 4 words per buffer
         PinBuf<uint32_t> h_inflate_status;     // ... fetched with the window's other results
         bool inflated[kBamRing] = {};
         hipStream_t inflate_stream = nullptr;  // the inflate kernel's own: the copies of other windows go on beside it
@@ -1019,7 +1019,7 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     if (n_bytes) HIP_TRY(c, hipStreamWaitEvent(st, B.copied[b], 0));
     const bool inflated_here = n_bytes && B.inflated[b];
     if (inflated_here)
-        HIP_TRY(c, hipMemcpyAsync(B.h_inflate_status.p, B.inflate_status.p + 2u * b, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(B.h_inflate_status.p, B.inflate_status.p + 4u * b, 16, hipMemcpyDeviceToHost, st));
     launch_bam_find(st, B.bytes[b].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
     HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device and counted
     if (inflated_here && B.h_inflate_status.p[0])
@@ -1168,27 +1168,27 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             // the compressed bytes and the block descriptors go over the bus, and the inflate runs behind them on a stream of
             // its own -- beside the kernels that work on the window before AND beside the copies of the windows that follow
             // (the scratch is shared: two inflates never overlap, they are on one stream)
-            const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size()), grid = bgzf_inflate_grid(nblk);
+            const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size());
             HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + kBgzfTail + 64));
             HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
-            HIP_TRY(c, B.inflate_scratch.ensure(bgzf_inflate_scratch_bytes(kBgzfMaxGrid)));
-            HIP_TRY(c, B.inflate_status.ensure(2u * slimm_ctx::kBamRing));
-            HIP_TRY(c, B.h_inflate_status.ensure(2));
+            HIP_TRY(c, B.inflate_scratch.ensure(bgzf_inflate_scratch_bytes(nblk + (nblk >> 3))));
+            HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
+            HIP_TRY(c, B.h_inflate_status.ensure(4));
             HIP_TRY(c, hipMemcpyAsync(B.comp[b].p, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(B.h2d_done[b], c->copy_stream));
             HIP_TRY(c, hipMemsetAsync(B.comp[b].p + src_bytes, 0, kBgzfTail, c->copy_stream));
             HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
                                       c->copy_stream));
-            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b, 0, 4, c->copy_stream));
-            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 2u * b + 1u, 0xff, 4, c->copy_stream));
+            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b, 0, 16, c->copy_stream));
+            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b + 1u, 0xff, 4, c->copy_stream));
             if (!B.inflate_stream) {
                 HIP_TRY(c, hipStreamCreateWithFlags(&B.inflate_stream, hipStreamNonBlocking));
                 HIP_TRY(c, hipEventCreateWithFlags(&B.comp_copied, hipEventDisableTiming));
             }
             HIP_TRY(c, hipEventRecord(B.comp_copied, c->copy_stream));
             HIP_TRY(c, hipStreamWaitEvent(B.inflate_stream, B.comp_copied, 0));
-            launch_bgzf_inflate(B.inflate_stream, B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - skip, B.inflate_scratch.p, grid,
-                                B.inflate_status.p + 2u * b);
+            launch_bgzf_inflate(B.inflate_stream, B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - skip, B.inflate_scratch.p,
+                                B.inflate_status.p + 4u * b);
             HIP_TRY(c, hipEventRecord(B.copied[b], B.inflate_stream));
         } else {
             HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));

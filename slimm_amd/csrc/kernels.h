@@ -284,12 +284,24 @@ struct BgzfBlock {
     uint32_t crc, pad;     // the gzip trailer's CRC32 of the inflated bytes
 };
 constexpr uint32_t kBgzfTail = 1024;     // zeroed bytes behind the compressed input: a truncated table header reads into them, never past
-constexpr uint32_t kBgzfMaxGrid = 512;   // waves of a launch (two per CU: 70 KB of LDS each)
+constexpr uint32_t kBgzfMaxGrid = 512;   // waves of a launch of the lane-per-block kernel (two per CU: 70 KB of LDS each)
+// bgzf_tokens.hip, the fast path: per block the match tokens of k_inflate_decode for k_inflate_resolve.  A block of <= 64 KB
+// has at most 65536 / 3 matches and 65536 / 256 tokens for literal runs too long for a match token's field.
+constexpr uint32_t kInflateTokCap = 22144;
+struct InflateInfo {
+    uint32_t n_tok;   // tokens of the block
+    uint32_t flag;    // 1 = the lane-per-block kernel inflates this block (a stored block inside, or anything irregular)
+};
 uint32_t bgzf_inflate_grid(uint32_t n_blocks);
-size_t bgzf_inflate_scratch_bytes(uint32_t grid);
-// status[0] = the largest error code met (0: every block inflated to its ISIZE), status[1] = the first bad block (preset ~0)
+size_t bgzf_lanes_scratch_bytes(uint32_t grid);
+size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks);   // for launch_bgzf_inflate of up to n_blocks blocks
+// status[0] = the largest error code met (0: every block inflated to its ISIZE, CRC right), status[1] = the first bad block
+// (preset ~0), status[2] = blocks the lane-per-block kernel inflated (preset 0; status: 4 words)
 void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,
-                         uint32_t grid, uint32_t* status);
+                         uint32_t* status);
+// the lane-per-block kernel by itself: every block (info == nullptr) or the blocks with info[b].flag set
+void launch_bgzf_inflate_lanes(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,
+                               uint32_t grid, uint32_t* status, const InflateInfo* info);
 // host: the descriptors of the whole BGZF blocks in bytes[0, n_bytes), outputs one behind the other from dst0 on
 bool bgzf_parse_blocks(const uint8_t* bytes, uint64_t n_bytes, uint64_t dst0, std::vector<BgzfBlock>& out, uint64_t& inflated,
                        std::string& err);

@@ -51,14 +51,19 @@ constexpr uint32_t kClSym = 121;     //  5 words: the code-length code's 19 symb
 constexpr uint32_t kClBase = 126;    //  4 words: its bases (lengths 1 .. 7)
 constexpr uint32_t kLaneWords = 130;
 
+// (the same LDS words are read and written as bytes, halves and words: types that may alias)
+typedef uint16_t __attribute__((may_alias)) u16a;
+typedef uint32_t __attribute__((may_alias)) u32a;
+typedef int16_t __attribute__((may_alias)) i16a;
+
 struct Lds {
-    uint32_t* w;  // the lane's word 0
+    u32a* w;  // the lane's word 0
     __device__ __forceinline__ uint8_t* bytes() const { return reinterpret_cast<uint8_t*>(w); }
     __device__ __forceinline__ uint8_t& b8(uint32_t base, uint32_t i) const { return bytes()[(base + (i >> 2)) * 256u + (i & 3u)]; }
-    __device__ __forceinline__ uint16_t& b16(uint32_t base, uint32_t i) const {
-        return reinterpret_cast<uint16_t*>(w)[(base + (i >> 1)) * 128u + (i & 1u)];
+    __device__ __forceinline__ u16a& b16(uint32_t base, uint32_t i) const {
+        return reinterpret_cast<u16a*>(w)[(base + (i >> 1)) * 128u + (i & 1u)];
     }
-    __device__ __forceinline__ uint32_t& b32(uint32_t base, uint32_t i) const { return w[(base + i) * 64u]; }
+    __device__ __forceinline__ u32a& b32(uint32_t base, uint32_t i) const { return w[(base + i) * 64u]; }
 };
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t* p) {
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x * 64u + lane;
     const bool have = b < n_blocks;
-    Lds L{s_lds + lane};
+    Lds L{reinterpret_cast<u32a*>(s_lds) + lane};
     BgzfBlock d;
     d.src = d.dst = 0;
     d.csize = d.isize = 0;
@@ -518,7 +523,8 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     __shared__ uint32_t s_flag[2];
     __shared__ uint32_t s_crc[256];
     uint8_t* const win = reinterpret_cast<uint8_t*>(s_win4);
-    int16_t* const ptr = reinterpret_cast<int16_t*>(s_ptr32);
+    i16a* const ptr = reinterpret_cast<i16a*>(s_ptr32);
+    u32a* const ptr32 = reinterpret_cast<u32a*>(s_ptr32);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             break;
         }
         // every byte its own source ...
-        for (uint32_t j = tid * 2u; j < S; j += 512u) s_ptr32[j >> 1] = j | ((j + 1u) << 16);
+        for (uint32_t j = tid * 2u; j < S; j += 512u) ptr32[j >> 1] = j | ((j + 1u) << 16);
         __syncthreads();
         // ... but the bytes of a match: the byte `dist` in front (relative to the chunk: negative = an earlier chunk's)
         if (in_chunk && mlen) {
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         s_crc[i] = c;
     }
     __syncthreads();
-    uint32_t* const t4 = s_ptr32;  // slice-by-4 tables 1 .. 3 (table 0 = s_crc)
+    u32a* const t4 = ptr32;  // slice-by-4 tables 1 .. 3 (table 0 = s_crc)
     {
         uint32_t c = s_crc[tid];
         for (uint32_t k = 0; k < 3u; ++k) {
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     if (tid < n_seg) {
         const uint32_t lo = tid << 8, hi = min(isize, lo + 256u);
         uint32_t c = 0xffffffffu, i = lo;
-        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(win);
+        const u32a* w32 = reinterpret_cast<const u32a*>(win);
         for (; i + 4u <= hi; i += 4u) {
             c ^= w32[i >> 2];
             c = t4[512u + (c & 0xffu)] ^ t4[256u + ((c >> 8) & 0xffu)] ^ t4[(c >> 16) & 0xffu] ^ s_crc[c >> 24];
@@ -668,7 +674,7 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     }
     __syncthreads();
     // the full segments (all but the last) in a tree, right-aligned among 256 leaves; then the last one behind them
-    uint32_t* const leaf = s_ptr32 + 1024;
+    u32a* const leaf = ptr32 + 1024;
     const uint32_t n_full = n_seg ? n_seg - 1u : 0u;
     leaf[tid] = 0;
     __syncthreads();

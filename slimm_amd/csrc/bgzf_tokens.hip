@@ -104,14 +104,17 @@ struct Bits {
 };
 
 // 15 left-justified limits of a canonical code: a 15-bit pattern x (first stream bit on top) has a code of length
-// 1 + #{l : x >= lim[l]}; 16 = no code.
+// 1 + #{l : x >= lim[l]}; 16 = no code.  Held as lim - 1, so that the sign of (lim - 1) - x says x >= lim: a subtraction and
+// one v_alignbit (acc = acc << 1 | sign) per length, a population count at the end -- no compare, no carry chain, no
+// wait states between them.
 struct Limits {
-    uint32_t v[15];
+    uint32_t v[15];   // limit - 1 (0xffffffff for a limit of 0)
+    __device__ __forceinline__ void set(uint32_t l, uint32_t limit) { v[l] = limit - 1u; }
     __device__ __forceinline__ uint32_t length_of(uint32_t x) const {
-        uint32_t n = 1;
+        uint32_t acc = 0;
 #pragma unroll
-        for (int l = 0; l < 15; ++l) n += x >= v[l] ? 1u : 0u;
-        return n;
+        for (int l = 0; l < 15; ++l) acc = __builtin_amdgcn_alignbit(acc, v[l] - x, 31);
+        return 1u + static_cast<uint32_t>(__builtin_popcount(acc));
     }
 };
 
@@ -127,7 +130,7 @@ __device__ int code_from_counts(const Lds& L, uint32_t base_at, Limits& lim) {
     for (uint32_t l = 1; l <= 15u; ++l) {
         const uint32_t c = l <= kMaxLen ? L.b16(kTmpA, l) : 0u;
         left = (left << 1) - static_cast<int>(c);
-        lim.v[l - 1] = (code + c) << (15u - l);
+        lim.set(l - 1, (code + c) << (15u - l));
         if (l <= kMaxLen) {
             L.b16(base_at, l) = static_cast<uint16_t>(offs - code);
             L.b16(kTmpB, l) = static_cast<uint16_t>(offs);
@@ -273,7 +276,7 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
             const uint32_t c = L.b16(kTmpA, l);
             n_d += c;
             left = (left << 1) - static_cast<int>(c);
-            DL.v[l - 1] = (code + c) << (15u - l);
+            DL.set(l - 1, (code + c) << (15u - l));
             L.b16(kDbase, l) = static_cast<uint16_t>(offs - code);
             places[l] = offs;
             offs += c;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
     bits.start(0);
     Limits LL, DL;
 #pragma unroll
-    for (int l = 0; l < 15; ++l) LL.v[l] = DL.v[l] = 0x8000u;
+    for (int l = 0; l < 15; ++l) LL.v[l] = DL.v[l] = 0x7fffu;
     uint32_t mode = have ? kModeHeader : kModeDone;
     uint32_t last = 0, o = 0, acc = 0, acc_n = 0, litrun = 0, ntok = 0;
     // stores waiting for the top of the next step
@@ -519,8 +522,8 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
                                                          const uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
     __shared__ uint4 s_win4[65536 / 16];
     __shared__ uint32_t s_ptr32[kChunk / 2];  // 16-bit pointers; the CRC tables afterwards
-    __shared__ uint32_t s_scan[8];
-    __shared__ uint32_t s_flag[2];
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_flag[4];
     __shared__ uint32_t s_crc[256];
     uint8_t* const win = reinterpret_cast<uint8_t*>(s_win4);
     i16a* const ptr = reinterpret_cast<i16a*>(s_ptr32);
@@ -539,9 +542,9 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         __builtin_memcpy(&v, o_base + i, 16);  // (up to 15 bytes behind the block: the next block's, or the buffer's slack)
         s_win4[i >> 4] = v;
     }
-    if (tid == 0) s_flag[1] = 0;
+    if (tid < 4u) s_flag[tid] = 0;   // [0 .. 2]: "some pointer moved" of the jumping rounds, in turn; [3]: something is wrong
     __syncthreads();
-    uint32_t base = 0, t0 = 0;
+    uint32_t base = 0, t0 = 0, rr = 0;
     bool wrong = false;
     while (t0 < nf.n_tok) {
         // a token per thread, the spans' running sum
@@ -558,29 +561,42 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             if (lane >= s) incl += up;
         }
         if (lane == 63u) s_scan[wv] = incl;
+        if (tid == 0) s_scan[12] = span;
         __syncthreads();
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; ++k) before += s_scan[k];
         incl += before;
-        // the chunk: the tokens whose spans end inside kChunk bytes (a prefix: spans are sums); a long run of literals by
-        // itself when it leads
+        // the chunk: the tokens whose spans end inside kChunk bytes (a prefix: spans are sums)
         const bool in_chunk = t < nf.n_tok && incl <= kChunk;
         const uint64_t mine = __ballot(in_chunk);
-        if (lane == 0) s_scan[4 + wv] = static_cast<uint32_t>(__popcll(mine));
-        __syncthreads();
-        uint32_t n_act = s_scan[4] + s_scan[5] + s_scan[6] + s_scan[7];
-        if (tid == 0) s_flag[0] = 0;
-        uint32_t S;
-        if (n_act == 0) {  // the first token is a run of literals longer than a chunk: nothing to fill
-            n_act = 1;
-            S = 0;
-            if (tid == 0) {
-                s_scan[0] = span;
-                if (!skip) s_flag[1] = 1;   // (a match never spans a chunk)
+        const uint32_t cnt = static_cast<uint32_t>(__popcll(mine));
+        const uint32_t top = __shfl(incl, static_cast<int>(cnt ? cnt - 1u : 0u));
+        if (lane == 0) {
+            s_scan[4 + wv] = cnt;
+            s_scan[8 + wv] = cnt ? top : 0u;
+        }
+        // every byte of the token's span gets a pointer: a literal to itself, a byte of the match to the byte `dist` in front
+        // of it (relative to the chunk: negative = an earlier chunk's byte)
+        if (in_chunk) {
+            const uint32_t e0 = incl - span, d0 = incl - mlen;
+            for (uint32_t k = e0; k < d0; ++k) ptr[k] = static_cast<int16_t>(k);
+            if (mlen) {
+                if (base + d0 < dist) {
+                    s_flag[3] = 1;
+                    for (uint32_t k = 0; k < mlen; ++k) ptr[d0 + k] = static_cast<int16_t>(d0 + k);
+                } else {
+                    const int32_t from = static_cast<int32_t>(d0) - static_cast<int32_t>(dist);
+                    for (uint32_t k = 0; k < mlen; ++k) ptr[d0 + k] = static_cast<int16_t>(from + static_cast<int32_t>(k));
+                }
             }
+        }
+        __syncthreads();
+        const uint32_t n_act = s_scan[4] + s_scan[5] + s_scan[6] + s_scan[7];
+        const uint32_t S = max(max(s_scan[8], s_scan[9]), max(s_scan[10], s_scan[11]));
+        if (n_act == 0) {  // the first token is a run of literals longer than a chunk: nothing to fill
+            const uint32_t first_span = s_scan[12];
             __syncthreads();
-            base += s_scan[0];
-            __syncthreads();
+            base += first_span;
             t0 += 1;
             if (base > isize) {
                 wrong = true;
@@ -588,28 +604,12 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             }
             continue;
         }
-        if (tid == n_act - 1u) s_scan[0] = incl;
-        __syncthreads();
-        S = s_scan[0];
         if (base + S > isize) {
             wrong = true;
             break;
         }
-        // every byte its own source ...
-        for (uint32_t j = tid * 2u; j < S; j += 512u) ptr32[j >> 1] = j | ((j + 1u) << 16);
-        __syncthreads();
-        // ... but the bytes of a match: the byte `dist` in front (relative to the chunk: negative = an earlier chunk's)
-        if (in_chunk && mlen) {
-            const uint32_t d0 = incl - mlen;
-            if (base + d0 < dist) {
-                s_flag[1] = 1;
-            } else {
-                const int32_t from = static_cast<int32_t>(d0) - static_cast<int32_t>(dist);
-                for (uint32_t k = 0; k < mlen; ++k) ptr[d0 + k] = static_cast<int16_t>(from + static_cast<int32_t>(k));
-            }
-        }
-        __syncthreads();
-        // pointer jumping: until every pointer is at a literal (points at itself) or in front of the chunk
+        // pointer jumping: until every pointer is at a literal (points at itself) or in front of the chunk.  The rounds' "some
+        // pointer moved" words take turns (three of them: the one a round sets was cleared two barriers ago)
         for (;;) {
             bool changed = false;
             for (uint32_t j = tid; j < S; j += 256u) {
@@ -622,13 +622,12 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
                     }
                 }
             }
-            if (changed) s_flag[0] = 1;
+            const uint32_t slot = rr % 3u;
+            if (changed) s_flag[slot] = 1;
+            if (tid == 0) s_flag[(rr + 1u) % 3u] = 0;
             __syncthreads();
-            const uint32_t any = s_flag[0];
-            __syncthreads();
-            if (!any) break;
-            if (tid == 0) s_flag[0] = 0;
-            __syncthreads();
+            ++rr;
+            if (!s_flag[slot]) break;
         }
         for (uint32_t j = tid; j < S; j += 256u) {
             const int32_t p = ptr[j];
@@ -639,7 +638,7 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         t0 += n_act;
     }
     __syncthreads();
-    if (wrong || s_flag[1]) {
+    if (wrong || s_flag[3]) {
         if (tid == 0) info[b].flag = 1;
         return;
     }
@@ -696,10 +695,10 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         const uint32_t last_len = isize - (n_full << 8);
         const uint32_t head = leaf[0];
         const uint32_t all = n_seg ? ((head ? multmodp(x8n(last_len), head) : 0u) ^ s_scan[0]) : 0u;
-        s_flag[0] = all == d.crc ? 0u : 1u;
+        s_flag[3] = all == d.crc ? 0u : 1u;
     }
     __syncthreads();
-    if (s_flag[0]) {
+    if (s_flag[3]) {
         if (tid == 0) info[b].flag = 1;
         return;
     }

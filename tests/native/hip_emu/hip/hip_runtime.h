@@ -280,6 +280,10 @@ static inline uint32_t __builtin_amdgcn_ds_bpermute(int byte_addr, uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------ arithmetic, atomics
+// v_alignbit_b32: the low 32 bits of {hi, lo} >> (shift & 31)
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t shift) {
+    return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (shift & 31u));
+}
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return static_cast<uint32_t>((static_cast<uint64_t>(a) * b) >> 32); }
 static inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }

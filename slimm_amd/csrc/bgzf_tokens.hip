@@ -546,10 +546,11 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     __syncthreads();
     uint32_t base = 0, t0 = 0, rr = 0;
     bool wrong = false;
+    uint32_t tv_next = tid < nf.n_tok ? t_base[tid] : 0x80000000u;   // (the next chunk's token is asked for while this one is filled)
     while (t0 < nf.n_tok) {
         // a token per thread, the spans' running sum
         const uint32_t t = t0 + tid;
-        const uint32_t tv = t < nf.n_tok ? t_base[t] : 0x80000000u;
+        const uint32_t tv = tv_next;
         const bool skip = (tv >> 31) != 0u;
         const uint32_t litrun = skip ? tv & 0x7fffffffu : (tv >> 23) & 0xffu;
         const uint32_t mlen = skip ? 0u : ((tv >> 15) & 0xffu) + 3u;
@@ -593,6 +594,10 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         __syncthreads();
         const uint32_t n_act = s_scan[4] + s_scan[5] + s_scan[6] + s_scan[7];
         const uint32_t S = max(max(s_scan[8], s_scan[9]), max(s_scan[10], s_scan[11]));
+        {
+            const uint32_t tn = t0 + (n_act ? n_act : 1u) + tid;
+            tv_next = tn < nf.n_tok ? t_base[tn] : 0x80000000u;
+        }
         if (n_act == 0) {  // the first token is a run of literals longer than a chunk: nothing to fill
             const uint32_t first_span = s_scan[12];
             __syncthreads();
@@ -608,18 +613,26 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             wrong = true;
             break;
         }
-        // pointer jumping: until every pointer is at a literal (points at itself) or in front of the chunk.  The rounds' "some
-        // pointer moved" words take turns (three of them: the one a round sets was cleared two barriers ago)
+        // pointer jumping: until every pointer is at a literal (points at itself) or in front of the chunk.  A thread keeps the
+        // pointers of its 16 bytes (j = tid + 256 k) in registers: a round is one LDS read per byte, all 16 in flight together.
+        // The rounds' "some pointer moved" words take turns (three: the one a round sets was cleared two barriers ago)
+        int32_t pj[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; ++k) {
+            const uint32_t j = tid + 256u * k;
+            pj[k] = j < S ? static_cast<int32_t>(ptr[j]) : -1;
+        }
         for (;;) {
+            int32_t q[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) q[k] = pj[k] >= 0 ? static_cast<int32_t>(ptr[pj[k]]) : pj[k];
             bool changed = false;
-            for (uint32_t j = tid; j < S; j += 256u) {
-                const int32_t p = ptr[j];
-                if (p >= 0 && p != static_cast<int32_t>(j)) {
-                    const int32_t q = ptr[p];
-                    if (q != p) {
-                        ptr[j] = static_cast<int16_t>(q);
-                        changed = true;
-                    }
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                if (q[k] != pj[k]) {
+                    pj[k] = q[k];
+                    ptr[tid + 256u * k] = static_cast<int16_t>(q[k]);
+                    changed = true;
                 }
             }
             const uint32_t slot = rr % 3u;
@@ -629,9 +642,18 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             ++rr;
             if (!s_flag[slot]) break;
         }
-        for (uint32_t j = tid; j < S; j += 256u) {
-            const int32_t p = ptr[j];
-            if (p != static_cast<int32_t>(j)) win[base + j] = win[static_cast<int32_t>(base) + p];
+        {
+            uint8_t v[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                const uint32_t j = tid + 256u * k;
+                v[k] = j < S ? win[static_cast<int32_t>(base) + pj[k]] : 0;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) {
+                const uint32_t j = tid + 256u * k;
+                if (j < S && pj[k] != static_cast<int32_t>(j)) win[base + j] = v[k];
+            }
         }
         __syncthreads();
         base += S;

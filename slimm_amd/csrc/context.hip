@@ -133,10 +133,14 @@ struct slimm_ctx {
     bool marked = false;           // slimm_push_records_marked: 8 bytes per record, no key array (grouped input only)
     // slimm_push_bam_bytes: BAM records decoded on the device (bam_decode.hip).  Two byte buffers [slack | window] take the
     // windows in turn; the incomplete record at a window's end is copied in front of the next window
-    // (the ring of window buffers: a window is copied -- or inflated -- into one while up to kBamLag older ones are still
-    // on their way or being decoded; three was the whole ring until the device inflate came: one window of 2 GB of BGZF
-    // blocks takes the inflater 50 ms, and a dozen host-inflated windows can cross the bus meanwhile)
-    static constexpr uint32_t kBamRing = 16, kBamLag = kBamRing - 2;
+    // (the ring of window buffers: a window is copied -- or inflated -- into one while older ones are still on their way or
+    // being decoded: at most kBamLag of them, and at most kBamInFlight bytes -- windows that arrive as BGZF blocks are
+    // gathered into device windows of up to kBamGather inflated bytes, three of which keep both inflate streams busy; a ring
+    // of 16 buffers of that size was 20 - 25 GB of HBM per context)
+    static constexpr uint32_t kBamRing = 4, kBamLag = kBamRing - 2;
+    static constexpr uint64_t kBamInFlight = 4ull << 30;    // finish the oldest window when more than this is in flight
+    static constexpr uint64_t kBamGather = 1900ull << 20;   // inflated bytes of a gathered device window (a window is < 2 GiB)
+    static constexpr uint64_t kBamGatherGoal = 1400ull << 20;  // ... which is launched once it holds this much
     struct BamDecode {
         DevBuf<uint8_t> bytes[kBamRing];
         DevBuf<BamPiece> pieces;
@@ -151,17 +155,25 @@ struct slimm_ctx {
         bool active = false;                // this file's records come from slimm_push_bam_bytes / slimm_push_bgzf_blocks
         bool closed = false;                // the file's last window went in
         hipEvent_t copied[kBamRing] = {};   // the window's bytes are in its buffer (behind the copy, or behind the inflate)
-        hipEvent_t h2d_done[kBamRing] = {}; // the caller's buffer has been read
+        hipEvent_t h2d_done[4] = {};        // the caller's buffer of a push has been read (the pushes' events, in turn)
+        uint64_t pushes = 0;                // pushes of this file that started a copy
         // windows that arrive as BGZF blocks (slimm_push_bgzf_blocks): compressed bytes + block descriptors per buffer, the
         // inflater's scratch and {error code, first bad block} per buffer; inflated[b]: that window was inflated here
         DevBuf<uint8_t> comp[kBamRing];
         DevBuf<BgzfBlock> desc[kBamRing];
-        DevBuf<uint8_t> inflate_scratch;
+        DevBuf<uint8_t> inflate_scratch[2];
         DevBuf<uint32_t> inflate_status;       // 4 words per buffer
         PinBuf<uint32_t> h_inflate_status;     // ... fetched with the window's other results
         bool inflated[kBamRing] = {};
-        hipStream_t inflate_stream = nullptr;  // the inflate kernel's own: the copies of other windows go on beside it
+        // the inflate kernels' own streams, taken in turn by the device windows: the copies of other windows go on beside
+        // them, and the Huffman phase of one window (a lane per block: 30 K blocks are half the lanes) beside the other's
+        hipStream_t inflate_stream[2] = {nullptr, nullptr};
         hipEvent_t comp_copied = nullptr;
+        // BGZF pushes gathered for the next device window (buffer windows % kBamRing): compressed bytes so far, inflated
+        // bytes so far, the inflated bytes in front of the file's first record
+        bool acc_open = false;
+        uint64_t acc_src = 0, acc_dst = 0;
+        uint32_t acc_skip = 0;
         std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
@@ -682,10 +694,11 @@ void slimm_destroy(slimm_ctx* c) {
             (void)hipStreamSynchronize(c->side_stream);
             (void)hipStreamDestroy(c->side_stream);
         }
-        if (c->bam.inflate_stream) {
-            (void)hipStreamSynchronize(c->bam.inflate_stream);
-            (void)hipStreamDestroy(c->bam.inflate_stream);
-        }
+        for (auto& is : c->bam.inflate_stream)
+            if (is) {
+                (void)hipStreamSynchronize(is);
+                (void)hipStreamDestroy(is);
+            }
         if (c->bam.comp_copied) (void)hipEventDestroy(c->bam.comp_copied);
         if (c->front_done) (void)hipEventDestroy(c->front_done);
         if (c->prefix_done) (void)hipEventDestroy(c->prefix_done);
@@ -717,9 +730,18 @@ int slimm_reset(slimm_ctx* c) {
     if (c->bam.active && c->bam.head < c->bam.windows) {  // a file abandoned with windows in flight (an error, a caller's
         (void)hipSetDevice(c->device);                    // change of mind): their copies and inflates must not land in the
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream)); // next file's buffers
-        if (c->bam.inflate_stream) HIP_TRY(c, hipStreamSynchronize(c->bam.inflate_stream));
+        for (auto& is : c->bam.inflate_stream)
+            if (is) HIP_TRY(c, hipStreamSynchronize(is));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    if (c->bam.acc_open) {  // (a gathered window that was never launched: its copies)
+        (void)hipSetDevice(c->device);
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    }
+    c->bam.acc_open = false;
+    c->bam.acc_src = c->bam.acc_dst = 0;
+    c->bam.acc_skip = 0;
+    c->bam.pushes = 0;
     c->host->reset();
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;
@@ -1080,20 +1102,80 @@ int slimm_push_bgzf_blocks(slimm_ctx* c, const uint8_t* blocks, uint64_t n_bytes
     return bam_push_window(c, blocks, n_bytes, true, skip, last, n_records);
 }
 namespace {
+// the window buffer of window `windows`, large enough for n_bytes behind its slack; what the slack holds is kept
+int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes) {
+    slimm_ctx::BamDecode& B = c->bam;
+    const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
+    const uint64_t need = kBamSlack + n_bytes + 64;
+    if (B.bytes[b].cap >= need) return SLIMM_OK;
+    // (what the buffer held -- the window a ring's length back -- is done with: it was finished before this one was let in.
+    // Only the carried bytes in its slack matter, and only when the window before this one is finished already: otherwise
+    // its end will put them there later)
+    if (B.head == B.windows && B.carry_bytes) {
+        DevBuf<uint8_t> nb;
+        HIP_TRY(c, nb.ensure(need + (need >> 3)));
+        HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[b].p + kBamSlack - B.carry_bytes, B.carry_bytes,
+                                  hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::swap(B.bytes[b].p, nb.p);
+        std::swap(B.bytes[b].cap, nb.cap);
+    } else {
+        HIP_TRY(c, B.bytes[b].ensure(need + (need >> 3)));
+    }
+    return SLIMM_OK;
+}
+
+// The BGZF blocks gathered so far become window `windows`: descriptors over, the inflate launched behind the copies on the
+// inflate stream whose turn it is.
+int bam_launch_gathered(slimm_ctx* c) {
+    slimm_ctx::BamDecode& B = c->bam;
+    if (!B.acc_open) return SLIMM_OK;
+    const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing), si = static_cast<uint32_t>(B.windows & 1u);
+    const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size());
+    const uint64_t n_bytes = B.acc_dst - B.acc_skip;
+    B.acc_open = false;
+    if (!nblk || !n_bytes) return SLIMM_OK;
+    const int rc = bam_window_buffer(c, n_bytes);
+    if (rc != SLIMM_OK) return rc;
+    HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
+    HIP_TRY(c, B.inflate_scratch[si].ensure(bgzf_inflate_scratch_bytes(nblk + (nblk >> 3))));
+    HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
+    HIP_TRY(c, B.h_inflate_status.ensure(4));
+    HIP_TRY(c, hipMemsetAsync(B.comp[b].p + B.acc_src, 0, kBgzfTail, c->copy_stream));
+    HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
+                              c->copy_stream));
+    HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b, 0, 16, c->copy_stream));
+    HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b + 1u, 0xff, 4, c->copy_stream));
+    if (!B.inflate_stream[si]) HIP_TRY(c, hipStreamCreateWithFlags(&B.inflate_stream[si], hipStreamNonBlocking));
+    if (!B.comp_copied) HIP_TRY(c, hipEventCreateWithFlags(&B.comp_copied, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(B.comp_copied, c->copy_stream));
+    HIP_TRY(c, hipStreamWaitEvent(B.inflate_stream[si], B.comp_copied, 0));
+    launch_bgzf_inflate(B.inflate_stream[si], B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - B.acc_skip, B.inflate_scratch[si].p,
+                        B.inflate_status.p + 4u * b);
+    HIP_TRY(c, hipEventRecord(B.copied[b], B.inflate_stream[si]));
+    B.inflated[b] = true;
+    B.win_bytes[b] = n_bytes;
+    ++B.windows;
+    return SLIMM_OK;
+}
+
 // A window of a BAM file's alignment-record bytes: inflated already (`bytes` are the records' bytes) or as whole BGZF blocks
 // (`bytes` are compressed; the first `skip` inflated bytes are not records).  src_bytes = what crosses the bus.
+// BGZF pushes are GATHERED: their compressed bytes are copied behind each other into the next window's buffer, and the window
+// is launched -- inflate, then the record kernels -- once it holds kBamGatherGoal inflated bytes (or the file ends, or a
+// push of the other kind comes): the inflate's first phase is a lane per block and wants tens of thousands of them, whatever
+// size the caller's buffers have.
 int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool compressed, uint32_t skip, int last, uint64_t* n_records) {
     if (!c) return SLIMM_E_INVALID;
     if (n_records) *n_records = 0;
-    uint64_t n_bytes = src_bytes;  // the window's record bytes
+    uint64_t n_bytes = src_bytes;  // the push's record bytes
+    std::vector<BgzfBlock> dh;
+    uint64_t inflated = 0;
     if (compressed && src_bytes) {
         if (!bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
         std::string why;
-        uint64_t inflated = 0;
-        std::vector<BgzfBlock>& dh = c->bam.desc_host[(c->bam.active ? c->bam.windows : 0) % slimm_ctx::kBamRing];
-        dh.clear();
         if (!bgzf_parse_blocks(bytes, src_bytes, 0, dh, inflated, why)) return fail(c, SLIMM_E_INVALID, "%s", why.c_str());
-        if (skip > inflated || (skip && c->bam.active && c->bam.windows > 0))
+        if (skip > inflated || (skip && c->bam.active && (c->bam.windows > 0 || c->bam.acc_open)))
             return fail(c, SLIMM_E_INVALID, "skip: only in front of a file's first records");
         if (dh.size() >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "too many blocks in one window");
         n_bytes = inflated - skip;
@@ -1106,6 +1188,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             dh.erase(dh.begin(), dh.begin() + static_cast<long>(drop));
             for (BgzfBlock& d : dh) d.dst -= d0;
             skip -= static_cast<uint32_t>(d0);
+            inflated -= d0;
         }
         if (skip >= 65536u) return fail(c, SLIMM_E_INVALID, "skip: past the first block that holds a record byte");
         if (n_bytes == 0) {  // (blocks without a record byte: nothing to inflate, nothing to decode)
@@ -1131,6 +1214,8 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         B.windows = 0;
         B.head = 0;
         B.carry_bytes = 0;
+        B.pushes = 0;
+        B.acc_open = false;
         c->marked = marked;
         c->has_check = !marked;
         c->packed = false;
@@ -1144,64 +1229,73 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
     }
     if (B.closed) return fail(c, SLIMM_E_INVALID, "the file's last window has been pushed; reset first");
     uint64_t total = 0;
-    if (n_bytes) {  // this window's bytes start on their way ...
+    bool copy_started = false;
+    if (n_bytes && compressed) {
+        // behind what is gathered already -- unless the window would grow past its size: that one goes first
+        if (B.acc_open && B.acc_dst + inflated > slimm_ctx::kBamGather) {
+            const int rc = bam_launch_gathered(c);
+            if (rc != SLIMM_OK) return rc;
+        }
         const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
-        const uint64_t need = kBamSlack + n_bytes + 64;
-        if (B.bytes[b].cap < need) {
-            // (what the buffer held -- the window a ring's length back -- is done with: it was finished before this one was
-            // let in.  Only the carried bytes in its slack matter, and only when the window before this one is finished
-            // already: otherwise its end will put them there later)
-            if (B.head == B.windows && B.carry_bytes) {
-                DevBuf<uint8_t> nb;
-                HIP_TRY(c, nb.ensure(need + (need >> 2)));
-                HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[b].p + kBamSlack - B.carry_bytes, B.carry_bytes,
-                                          hipMemcpyDeviceToDevice, st));
-                HIP_TRY(c, hipStreamSynchronize(st));
-                std::swap(B.bytes[b].p, nb.p);
-                std::swap(B.bytes[b].cap, nb.cap);
-            } else {
-                HIP_TRY(c, B.bytes[b].ensure(need + (need >> 2)));
-            }
+        if (!B.acc_open) {
+            B.acc_open = true;
+            B.acc_src = B.acc_dst = 0;
+            B.acc_skip = skip;
+            B.desc_host[b].clear();
         }
-        B.inflated[b] = compressed;
-        if (compressed) {
-            // the compressed bytes and the block descriptors go over the bus, and the inflate runs behind them on a stream of
-            // its own -- beside the kernels that work on the window before AND beside the copies of the windows that follow
-            // (the scratch is shared: two inflates never overlap, they are on one stream)
-            const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size());
-            HIP_TRY(c, B.comp[b].ensure(src_bytes + (src_bytes >> 2) + kBgzfTail + 64));
-            HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
-            HIP_TRY(c, B.inflate_scratch.ensure(bgzf_inflate_scratch_bytes(nblk + (nblk >> 3))));
-            HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
-            HIP_TRY(c, B.h_inflate_status.ensure(4));
-            HIP_TRY(c, hipMemcpyAsync(B.comp[b].p, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(c, hipEventRecord(B.h2d_done[b], c->copy_stream));
-            HIP_TRY(c, hipMemsetAsync(B.comp[b].p + src_bytes, 0, kBgzfTail, c->copy_stream));
-            HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
-                                      c->copy_stream));
-            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b, 0, 16, c->copy_stream));
-            HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b + 1u, 0xff, 4, c->copy_stream));
-            if (!B.inflate_stream) {
-                HIP_TRY(c, hipStreamCreateWithFlags(&B.inflate_stream, hipStreamNonBlocking));
-                HIP_TRY(c, hipEventCreateWithFlags(&B.comp_copied, hipEventDisableTiming));
+        const uint64_t need = B.acc_src + src_bytes + kBgzfTail + 64;
+        if (B.comp[b].cap < need) {  // (grown with what earlier pushes of this window have put there)
+            DevBuf<uint8_t> nb;
+            HIP_TRY(c, nb.ensure(std::max<uint64_t>(need + (need >> 2), 256ull << 20)));
+            if (B.acc_src) {
+                HIP_TRY(c, hipMemcpyAsync(nb.p, B.comp[b].p, B.acc_src, hipMemcpyDeviceToDevice, c->copy_stream));
+                HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
             }
-            HIP_TRY(c, hipEventRecord(B.comp_copied, c->copy_stream));
-            HIP_TRY(c, hipStreamWaitEvent(B.inflate_stream, B.comp_copied, 0));
-            launch_bgzf_inflate(B.inflate_stream, B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - skip, B.inflate_scratch.p,
-                                B.inflate_status.p + 4u * b);
-            HIP_TRY(c, hipEventRecord(B.copied[b], B.inflate_stream));
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
-            HIP_TRY(c, hipEventRecord(B.h2d_done[b], c->copy_stream));
+            std::swap(B.comp[b].p, nb.p);
+            std::swap(B.comp[b].cap, nb.cap);
         }
+        HIP_TRY(c, hipMemcpyAsync(B.comp[b].p + B.acc_src, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
+        ++B.pushes;
+        copy_started = true;
+        for (BgzfBlock& d : dh) {
+            d.src += B.acc_src;
+            d.dst += B.acc_dst;
+        }
+        B.desc_host[b].insert(B.desc_host[b].end(), dh.begin(), dh.end());
+        B.acc_src += src_bytes;
+        B.acc_dst += inflated;
+        if (B.acc_dst >= slimm_ctx::kBamGatherGoal) {
+            const int rc = bam_launch_gathered(c);
+            if (rc != SLIMM_OK) return rc;
+        }
+    } else if (n_bytes) {  // inflated bytes: a window of their own, behind what was gathered
+        int rc = bam_launch_gathered(c);
+        if (rc != SLIMM_OK) return rc;
+        rc = bam_window_buffer(c, n_bytes);
+        if (rc != SLIMM_OK) return rc;
+        const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
+        B.inflated[b] = false;
+        HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
+        HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
+        ++B.pushes;
+        copy_started = true;
         B.win_bytes[b] = n_bytes;
         ++B.windows;
     }
+    if (last) {
+        const int rc = bam_launch_gathered(c);
+        if (rc != SLIMM_OK) return rc;
+    }
     // ... while the windows before are worked on: the oldest are finished (found, counted, decoded) once more than kBamLag
-    // are in flight -- all of them when this is the file's end
+    // windows or kBamInFlight bytes are in flight -- all of them when this is the file's end
     const bool had_any = B.head < B.windows;
-    while (B.head < B.windows && (last || B.windows - B.head > slimm_ctx::kBamLag)) {
+    for (;;) {
+        if (B.head >= B.windows) break;
+        uint64_t in_flight = 0;
+        for (uint64_t j = B.head; j < B.windows; ++j) in_flight += B.win_bytes[j % slimm_ctx::kBamRing];
+        if (!last && B.windows - B.head <= slimm_ctx::kBamLag && in_flight <= slimm_ctx::kBamInFlight) break;
         uint64_t got = 0;
         const uint64_t j = B.head;
         const int rc = bam_finish_window(c, j, B.win_bytes[j % slimm_ctx::kBamRing], last && j + 1 == B.windows, got);
@@ -1214,9 +1308,9 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         B.closed = true;
     } else {
         // the caller's buffer of the call BEFORE this one has been read (it may be reused once this call returns): the most
-        // recent window whose copy this call did not start itself (a call without record bytes starts none)
-        const uint64_t mine = n_bytes ? 1u : 0u;
-        if (B.windows > mine) HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.windows - 1u - mine) % slimm_ctx::kBamRing]));
+        // recent push whose copy this call did not start itself (a call without record bytes starts none)
+        const uint64_t mine = copy_started ? 1u : 0u;
+        if (B.pushes > mine) HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.pushes - 1u - mine) % 4u]));
     }
     if (n_records) *n_records = total;
     return SLIMM_OK;

@@ -94,6 +94,7 @@ private:
     size_t raw_off_ = 0;
     const uint8_t* map_ = nullptr;    // read_raw: the file, mapped (stage 2), and the next unconsumed compressed byte
     size_t map_size_ = 0, map_pos_ = 0;
+    size_t blk_hint_ = 0;             // read_blocks: bytes worth reading when the inflated size ends a window before the buffer does
     int raw_stage_ = 0;               // read_raw: 0 = the decoded window at hand, 1 = the prefetched one, 2 = straight from the file
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)
     long bam_record_starts(size_t max_records, std::vector<size_t>& offs);

@@ -472,18 +472,14 @@ struct RecordPump {
         bool last = false;   // the reader knows that nothing follows
         bool compressed = false;  // the bytes are whole BGZF blocks as they lie in the file: the device inflates them
     };
-    // Of the windows the reader takes straight from the mapped file, one in SLIMM_CLI_DEVICE_INFLATE (a period; default 6, 0 =
-    // none) is handed over COMPRESSED (slimm_push_bgzf_blocks): the device inflates it on a stream of its own while the
-    // windows that follow -- inflated by the host cores -- cross the bus; the library keeps up to 14 windows in flight.  The
-    // inflate kernel is a lane per BGZF block and needs tens of thousands of blocks to fill the device, so a device window is
-    // LARGE: SLIMM_CLI_DEVICE_WINDOW_MB of inflated bytes (default: ten host windows = 1.9 GB = 29 K blocks; its compressed
-    // bytes fit a host window's buffer).  Measured on the 100 M-record file (scripts/cli_inflate_share.py, three boxes): no
-    // device windows 0.90 - 1.02 s, one in six 0.77 - 0.86 s (the push phase 380 - 415 -> 260 - 285 ms: two thirds of the
-    // bytes are inflated on the device, one third crosses the bus inflated); its unsorted copy 1.08 - 1.27 -> 1.02 - 1.10 s.
-    // (With device windows of 192 MB -- 2 900 blocks, 9 % of the lanes, 20 ms each -- every share of them LOST: 0 / 3 / 5 / 10
-    // of ten = 0.94 / 1.33 / 1.72 / 2.64 s.)
-    unsigned device_period = 6;
-    bool device_forced = false;  // SLIMM_CLI_DEVICE_INFLATE is set: the caller's period holds whatever the file looks like
+    // The windows the reader takes straight from the file are handed over COMPRESSED (slimm_push_bgzf_blocks): 192 MB of
+    // BGZF blocks at a time, read by pread on several threads; the library gathers them into device windows of 1.4 - 1.9 GB
+    // of inflated bytes (its inflater's first phase is a lane per block and wants tens of thousands of blocks) and inflates
+    // them in two phases on two streams in turn (slimm_amd/csrc/bgzf_tokens.hip) while the next windows cross the bus.
+    // SLIMM_CLI_DEVICE_INFLATE = k: every k-th of those windows only, the others inflated by the host cores (0 = all on
+    // the host: rounds 1 - 3; 6 = round 4's default, when the device inflated 19 - 38 GB/s and 16 host cores 14 - 55).
+    // Measured on 100 M records that compress 3-fold (scripts/realistic_cli.py): host inflate 2.1 - 2.3 s, this 0.7 s.
+    unsigned device_period = 1;
     size_t device_window = 0;  // inflated bytes of a device window
     uint64_t raw_windows_device = 0, raw_windows_host = 0;
     // (mapped with MADV_HUGEPAGE where the kernel grants it: 192 MB in 4 KB pages are 49 K page faults to fill and as many
@@ -513,7 +509,6 @@ struct RecordPump {
               !getenv("SLIMM_CLI_HOST_DECODE")) {
         if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) {
             device_period = static_cast<unsigned>(std::max(0l, atol(e)));
-            device_forced = true;
         }
         device_window = std::min<size_t>(10 * raw_cap(), 1900u << 20);
         if (const char* e = getenv("SLIMM_CLI_DEVICE_WINDOW_MB"))
@@ -556,9 +551,6 @@ struct RecordPump {
                 n = bam.read_blocks(raw_buf[w].get(), raw_cap(), device_window, &inflated);
                 compressed = true;
                 ++raw_windows_device;
-                // (a file that hardly compresses fills the buffer with few blocks: a lane per block then leaves most of the
-                // device idle -- the host cores take the rest of such a file)
-                if (n > 0 && !device_forced && inflated < 3 * raw_cap() && inflated < device_window) device_period = 0;
             } else {
                 n = bam.read_raw(raw_buf[w].get(), raw_cap());
                 if (bam.can_read_blocks() || bam.raw_exhausted()) ++raw_windows_host;

@@ -49,6 +49,17 @@ struct DevBuf {
         if (e == hipSuccess) cap = n;
         return e;
     }
+    // the same without hipFree (which waits for every kernel in flight on the device): what the buffer was goes to `old`,
+    // whose owner frees it when the device has nothing to do anyway
+    hipError_t ensure_later(size_t n, std::vector<void*>& old) {
+        if (n <= cap) return hipSuccess;
+        if (p) old.push_back(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
 };
 
 template <typename T>
@@ -174,6 +185,7 @@ struct slimm_ctx {
         bool acc_open = false;
         uint64_t acc_src = 0, acc_dst = 0;
         uint32_t acc_skip = 0;
+        std::vector<void*> outgrown;   // device buffers replaced by larger ones while kernels were in flight: freed at the file's end
         std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
@@ -708,6 +720,7 @@ void slimm_destroy(slimm_ctx* c) {
         }
         if (c->copy_done) (void)hipEventDestroy(c->copy_done);
         for (auto& r : c->bam.registered) (void)hipHostUnregister(const_cast<uint8_t*>(r.first));
+        for (void* p : c->bam.outgrown) (void)hipFree(p);
         for (auto& e : c->bam.copied)
             if (e) (void)hipEventDestroy(e);
         for (auto& e : c->bam.h2d_done)
@@ -742,6 +755,8 @@ int slimm_reset(slimm_ctx* c) {
     c->bam.acc_src = c->bam.acc_dst = 0;
     c->bam.acc_skip = 0;
     c->bam.pushes = 0;
+    for (void* p : c->bam.outgrown) (void)hipFree(p);
+    c->bam.outgrown.clear();
     c->host->reset();
     c->analyzed = c->covered = c->filtered = c->counted = c->no_hits = false;
     c->n_pushed = 0;
@@ -1103,10 +1118,12 @@ int slimm_push_bgzf_blocks(slimm_ctx* c, const uint8_t* blocks, uint64_t n_bytes
 }
 namespace {
 // the window buffer of window `windows`, large enough for n_bytes behind its slack; what the slack holds is kept
-int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes) {
+int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes, bool gathered = false) {
     slimm_ctx::BamDecode& B = c->bam;
     const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
-    const uint64_t need = kBamSlack + n_bytes + 64;
+    // (a gathered window gets the room of the largest one at once: a buffer that grows is a hipFree, and a hipFree waits for
+    // the inflate kernels of the windows before)
+    const uint64_t need = kBamSlack + (gathered ? std::max<uint64_t>(n_bytes, slimm_ctx::kBamGather) : n_bytes) + 64;
     if (B.bytes[b].cap >= need) return SLIMM_OK;
     // (what the buffer held -- the window a ring's length back -- is done with: it was finished before this one was let in.
     // Only the carried bytes in its slack matter, and only when the window before this one is finished already: otherwise
@@ -1119,10 +1136,18 @@ int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         std::swap(B.bytes[b].p, nb.p);
         std::swap(B.bytes[b].cap, nb.cap);
+        if (nb.p) B.outgrown.push_back(nb.p);
+        nb.p = nullptr;
+        nb.cap = 0;
     } else {
-        HIP_TRY(c, B.bytes[b].ensure(need + (need >> 3)));
+        HIP_TRY(c, B.bytes[b].ensure_later(need + (gathered ? 0u : need >> 3), B.outgrown));
     }
     return SLIMM_OK;
+}
+
+void bam_free_outgrown(slimm_ctx* c) {
+    for (void* p : c->bam.outgrown) (void)hipFree(p);
+    c->bam.outgrown.clear();
 }
 
 // The BGZF blocks gathered so far become window `windows`: descriptors over, the inflate launched behind the copies on the
@@ -1135,10 +1160,10 @@ int bam_launch_gathered(slimm_ctx* c) {
     const uint64_t n_bytes = B.acc_dst - B.acc_skip;
     B.acc_open = false;
     if (!nblk || !n_bytes) return SLIMM_OK;
-    const int rc = bam_window_buffer(c, n_bytes);
+    const int rc = bam_window_buffer(c, n_bytes, true);
     if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, B.desc[b].ensure(static_cast<size_t>(nblk) + (nblk >> 2) + 1));
-    HIP_TRY(c, B.inflate_scratch[si].ensure(bgzf_inflate_scratch_bytes(nblk + (nblk >> 3))));
+    HIP_TRY(c, B.desc[b].ensure_later(static_cast<size_t>(nblk) + (nblk >> 1) + 1, B.outgrown));
+    HIP_TRY(c, B.inflate_scratch[si].ensure_later(bgzf_inflate_scratch_bytes(nblk + (nblk >> 2)), B.outgrown));
     HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
     HIP_TRY(c, B.h_inflate_status.ensure(4));
     HIP_TRY(c, hipMemsetAsync(B.comp[b].p + B.acc_src, 0, kBgzfTail, c->copy_stream));
@@ -1246,13 +1271,13 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         const uint64_t need = B.acc_src + src_bytes + kBgzfTail + 64;
         if (B.comp[b].cap < need) {  // (grown with what earlier pushes of this window have put there)
             DevBuf<uint8_t> nb;
-            HIP_TRY(c, nb.ensure(std::max<uint64_t>(need + (need >> 2), 256ull << 20)));
-            if (B.acc_src) {
-                HIP_TRY(c, hipMemcpyAsync(nb.p, B.comp[b].p, B.acc_src, hipMemcpyDeviceToDevice, c->copy_stream));
-                HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-            }
+            HIP_TRY(c, nb.ensure(std::max<uint64_t>(need + (need >> 1), 768ull << 20)));
+            if (B.acc_src) HIP_TRY(c, hipMemcpyAsync(nb.p, B.comp[b].p, B.acc_src, hipMemcpyDeviceToDevice, c->copy_stream));
             std::swap(B.comp[b].p, nb.p);
             std::swap(B.comp[b].cap, nb.cap);
+            if (nb.p) B.outgrown.push_back(nb.p);   // (no hipFree here: it would wait for the inflate kernels in flight)
+            nb.p = nullptr;
+            nb.cap = 0;
         }
         HIP_TRY(c, hipMemcpyAsync(B.comp[b].p + B.acc_src, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
         HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
@@ -1306,6 +1331,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
     if (last) {
         if (!had_any && B.carry_bytes) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
         B.closed = true;
+        bam_free_outgrown(c);
     } else {
         // the caller's buffer of the call BEFORE this one has been read (it may be reused once this call returns): the most
         // recent push whose copy this call did not start itself (a call without record bytes starts none)

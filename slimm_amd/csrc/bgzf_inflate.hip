@@ -437,6 +437,7 @@ namespace slimm {
 bool bgzf_parse_blocks(const uint8_t* bytes, uint64_t n_bytes, uint64_t dst0, std::vector<BgzfBlock>& out, uint64_t& inflated,
                        std::string& err) {
     uint64_t p = 0, dst = dst0;
+    uint32_t tok = 0;
     inflated = 0;
     while (p < n_bytes) {
         if (n_bytes - p < 28) {
@@ -473,12 +474,15 @@ bool bgzf_parse_blocks(const uint8_t* bytes, uint64_t n_bytes, uint64_t dst0, st
         const uint8_t* tc = h + bsize - 8;
         BgzfBlock d;
         d.crc = tc[0] | (static_cast<uint32_t>(tc[1]) << 8) | (static_cast<uint32_t>(tc[2]) << 16) | (static_cast<uint32_t>(tc[3]) << 24);
-        d.pad = 0;
+        d.tok = tok;
         d.src = p + 12u + xlen;
         d.csize = bsize - 12u - xlen - 8u;
         d.isize = isize;
         d.dst = dst;
-        if (isize) out.push_back(d);  // (the empty block at the end of a file, and any other, has nothing to inflate)
+        if (isize) {  // (the empty block at the end of a file, and any other, has nothing to inflate)
+            out.push_back(d);
+            tok += bgzf_token_room(isize);
+        }
         dst += isize;
         inflated += isize;
         p += bsize;
@@ -521,7 +525,7 @@ extern "C" int slimm_bgzf_inflate_with(int device, const uint8_t* blocks, uint64
     *out_bytes = inflated;
     if (inflated > out_cap || (inflated && !out)) return fail(-1, "output buffer too small");
     if (desc.empty()) return 0;
-    if (desc.size() >= (1ull << 32)) return fail(-1, "too many blocks in one call");
+    if (desc.size() >= (1ull << 32) || inflated >= (8ull << 30)) return fail(-1, "too many blocks in one call (8 GB of inflated bytes at most)");
     if (hipSetDevice(device) != hipSuccess) return fail(-2, "hipSetDevice failed");
     const uint32_t n = static_cast<uint32_t>(desc.size()), grid = slimm::bgzf_inflate_grid(n);
     uint8_t *d_comp = nullptr, *d_out = nullptr;
@@ -539,7 +543,7 @@ extern "C" int slimm_bgzf_inflate_with(int device, const uint8_t* blocks, uint64
     ok(hipMalloc(&d_comp, n_bytes + slimm::kBgzfTail), "hipMalloc");
     ok(hipMalloc(&d_out, inflated + 16), "hipMalloc");
     ok(hipMalloc(&d_desc, desc.size() * sizeof(slimm::BgzfBlock)), "hipMalloc");
-    ok(hipMalloc(&d_scratch, how == 1u ? slimm::bgzf_lanes_scratch_bytes(grid) : slimm::bgzf_inflate_scratch_bytes(n)), "hipMalloc");
+    ok(hipMalloc(&d_scratch, how == 1u ? slimm::bgzf_lanes_scratch_bytes(grid) : slimm::bgzf_inflate_scratch_bytes(n, desc.back().tok + slimm::bgzf_token_room(desc.back().isize))), "hipMalloc");
     ok(hipMalloc(&d_status, 16), "hipMalloc");
     if (!rc) {
         const uint32_t st0[4] = {0u, 0xffffffffu, 0u, 0u};

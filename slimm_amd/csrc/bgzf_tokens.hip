@@ -336,10 +336,12 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
     BgzfBlock d;
     d.src = d.dst = 0;
     d.csize = d.isize = 0;
+    d.tok = 0;
     if (have) d = blocks[b];
     const uint8_t* in = comp + d.src;
     uint8_t* o_base = out + d.dst;
-    uint32_t* t_base = tok + static_cast<size_t>(have ? b : 0u) * kInflateTokCap;
+    uint32_t* t_base = tok + d.tok;
+    const uint32_t tok_room = bgzf_token_room(d.isize);
     const uint32_t csize = d.csize, isize = d.isize;
 
     Bits bits;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
                     acc_n = 0;
                 }
                 if (is_len & !bad) {
-                    if (dist > o || o + mlen > isize || ntok + 2u > kInflateTokCap) {
+                    if (dist > o || o + mlen > isize || ntok + 2u > tok_room) {
                         bad = true;
                     } else {
                         p_tok_at = ntok;
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     const BgzfBlock d = blocks[b];
     const uint32_t isize = d.isize;
     uint8_t* const o_base = out + d.dst;
-    const uint32_t* const t_base = tok + static_cast<size_t>(b) * kInflateTokCap;
+    const uint32_t* const t_base = tok + d.tok;
     for (uint32_t i = tid * 16u; i < isize; i += 4096u) {
         uint4 v;
         __builtin_memcpy(&v, o_base + i, 16);  // (up to 15 bytes behind the block: the next block's, or the buffer's slack)
@@ -734,8 +736,9 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     }
 }
 
-size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks) {
-    return bgzf_lanes_scratch_bytes(kBgzfMaxGrid) + static_cast<size_t>(n_blocks) * (kInflateTokCap * 4u + sizeof(InflateInfo)) + 256u;
+size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks, uint64_t token_words) {
+    return bgzf_lanes_scratch_bytes(kBgzfMaxGrid) + ((static_cast<size_t>(n_blocks) * sizeof(InflateInfo) + 255u) & ~static_cast<size_t>(255u)) +
+           token_words * 4u + 256u;
 }
 
 // status[0] = the largest error code met (0: every block inflated to its ISIZE and CRC), status[1] = the first bad block

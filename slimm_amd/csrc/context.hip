@@ -184,7 +184,7 @@ struct slimm_ctx {
         // bytes so far, the inflated bytes in front of the file's first record
         bool acc_open = false;
         uint64_t acc_src = 0, acc_dst = 0;
-        uint32_t acc_skip = 0;
+        uint32_t acc_skip = 0, acc_tok = 0;   // (acc_tok: words of token room of the gathered blocks)
         std::vector<void*> outgrown;   // device buffers replaced by larger ones while kernels were in flight: freed at the file's end
         std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
@@ -1163,7 +1163,7 @@ int bam_launch_gathered(slimm_ctx* c) {
     const int rc = bam_window_buffer(c, n_bytes, true);
     if (rc != SLIMM_OK) return rc;
     HIP_TRY(c, B.desc[b].ensure_later(static_cast<size_t>(nblk) + (nblk >> 1) + 1, B.outgrown));
-    HIP_TRY(c, B.inflate_scratch[si].ensure_later(bgzf_inflate_scratch_bytes(nblk + (nblk >> 2)), B.outgrown));
+    HIP_TRY(c, B.inflate_scratch[si].ensure_later(bgzf_inflate_scratch_bytes(nblk + (nblk >> 2), B.acc_tok + (B.acc_tok >> 2)), B.outgrown));
     HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
     HIP_TRY(c, B.h_inflate_status.ensure(4));
     HIP_TRY(c, hipMemsetAsync(B.comp[b].p + B.acc_src, 0, kBgzfTail, c->copy_stream));
@@ -1266,7 +1266,22 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             B.acc_open = true;
             B.acc_src = B.acc_dst = 0;
             B.acc_skip = skip;
+            B.acc_tok = 0;
             B.desc_host[b].clear();
+            // A large file's first window: every buffer the windows will take in turn, now -- an allocation (like a hipFree)
+            // made while inflate kernels are in flight waits for them, and the pushes that should overlap them stand still
+            if (B.windows == 0 && src_bytes >= (64ull << 20)) {
+                const uint32_t blocks_max = static_cast<uint32_t>(slimm_ctx::kBamGather / 49152u);
+                const uint64_t tok_max = slimm_ctx::kBamGather / 3u + slimm_ctx::kBamGather / 256u + 8ull * blocks_max;
+                for (uint32_t k = 0; k < slimm_ctx::kBamRing; ++k) {
+                    HIP_TRY(c, B.bytes[k].ensure_later(kBamSlack + slimm_ctx::kBamGather + 64, B.outgrown));
+                    HIP_TRY(c, B.comp[k].ensure_later(1ull << 30, B.outgrown));
+                    HIP_TRY(c, B.desc[k].ensure_later(blocks_max, B.outgrown));
+                }
+                for (auto& sc : B.inflate_scratch) HIP_TRY(c, sc.ensure_later(bgzf_inflate_scratch_bytes(blocks_max, tok_max), B.outgrown));
+                HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
+                HIP_TRY(c, B.h_inflate_status.ensure(4));
+            }
         }
         const uint64_t need = B.acc_src + src_bytes + kBgzfTail + 64;
         if (B.comp[b].cap < need) {  // (grown with what earlier pushes of this window have put there)
@@ -1283,10 +1298,13 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
         ++B.pushes;
         copy_started = true;
+        const uint32_t tok0 = dh.empty() ? 0u : dh.front().tok;   // (blocks dropped in front of a file's first record)
         for (BgzfBlock& d : dh) {
             d.src += B.acc_src;
             d.dst += B.acc_dst;
+            d.tok = d.tok - tok0 + B.acc_tok;
         }
+        if (!dh.empty()) B.acc_tok = dh.back().tok + bgzf_token_room(dh.back().isize);
         B.desc_host[b].insert(B.desc_host[b].end(), dh.begin(), dh.end());
         B.acc_src += src_bytes;
         B.acc_dst += inflated;

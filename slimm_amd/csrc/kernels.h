@@ -281,20 +281,22 @@ void launch_bam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64
 struct BgzfBlock {
     uint64_t src, dst;     // the DEFLATE payload's offset in the compressed bytes; where its output goes
     uint32_t csize, isize; // payload bytes; inflated bytes (the gzip trailer's ISIZE)
-    uint32_t crc, pad;     // the gzip trailer's CRC32 of the inflated bytes
+    uint32_t crc;          // the gzip trailer's CRC32 of the inflated bytes
+    uint32_t tok;          // where the block's match tokens go (words; bgzf_tokens.hip): the sum of bgzf_token_room of the blocks before
 };
+// room for the tokens of a block of isize bytes: at most isize / 3 matches and isize / 256 tokens for literal runs too long
+// for a match token's field
+__host__ __device__ inline uint32_t bgzf_token_room(uint32_t isize) { return isize / 3u + isize / 256u + 8u; }
 constexpr uint32_t kBgzfTail = 1024;     // zeroed bytes behind the compressed input: a truncated table header reads into them, never past
 constexpr uint32_t kBgzfMaxGrid = 512;   // waves of a launch of the lane-per-block kernel (two per CU: 70 KB of LDS each)
-// bgzf_tokens.hip, the fast path: per block the match tokens of k_inflate_decode for k_inflate_resolve.  A block of <= 64 KB
-// has at most 65536 / 3 matches and 65536 / 256 tokens for literal runs too long for a match token's field.
-constexpr uint32_t kInflateTokCap = 22144;
+// bgzf_tokens.hip, the fast path: per block the match tokens of k_inflate_decode for k_inflate_resolve
 struct InflateInfo {
     uint32_t n_tok;   // tokens of the block
     uint32_t flag;    // 1 = the lane-per-block kernel inflates this block (a stored block inside, or anything irregular)
 };
 uint32_t bgzf_inflate_grid(uint32_t n_blocks);
 size_t bgzf_lanes_scratch_bytes(uint32_t grid);
-size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks);   // for launch_bgzf_inflate of up to n_blocks blocks
+size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks, uint64_t token_words);   // for launch_bgzf_inflate of up to n_blocks blocks whose token rooms add up to token_words
 // status[0] = the largest error code met (0: every block inflated to its ISIZE, CRC right), status[1] = the first bad block
 // (preset ~0), status[2] = blocks the lane-per-block kernel inflated (preset 0; status: 4 words)
 void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* blocks, uint32_t n_blocks, uint8_t* out, void* scratch,

@@ -411,10 +411,12 @@ int ensure_pair_table(slimm_ctx* c, uint32_t cap) {
 
 // Grows one record array to `cap` elements, keeping the `used` elements pushed so far (when the array holds them at all:
 // an array the file's record form does not use is neither allocated nor copied).
+// later != nullptr: no hipFree now (it waits for every kernel in flight -- the inflate of the windows behind this one):
+// what the array was goes there and is freed when the file has ended
 template <typename T>
-hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStream_t st) {
+hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStream_t st, std::vector<void*>* later = nullptr) {
     if (cap <= buf.cap) return hipSuccess;
-    if (used == 0 || buf.cap < used) return buf.ensure(cap);  // nothing of this file in it
+    if (used == 0 || buf.cap < used) return later ? buf.ensure_later(cap, *later) : buf.ensure(cap);  // nothing of this file in it
     DevBuf<T> nb;
     hipError_t e = nb.ensure(cap);
     if (e != hipSuccess) return e;
@@ -424,6 +426,11 @@ hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStr
     if (e != hipSuccess) return e;
     std::swap(buf.p, nb.p);
     std::swap(buf.cap, nb.cap);
+    if (later && nb.p) {
+        later->push_back(nb.p);
+        nb.p = nullptr;
+        nb.cap = 0;
+    }
     return hipSuccess;
 }
 
@@ -819,11 +826,12 @@ int slimm_reserve(slimm_ctx* c, uint64_t n) {
     uint64_t cap = n <= c->in_ref.cap ? c->in_ref.cap : std::max<uint64_t>(n, c->in_ref.cap * 2);  // (double only to grow)
     if (cap >= 0x7fffffffull) cap = 0x7ffffffeull;
     const uint64_t used = c->n_pushed;
-    HIP_TRY(c, grow_record_array(c->in_ref, cap, used, c->stream));
-    HIP_TRY(c, grow_record_array(c->in_pos, cap, used, c->stream));
-    if (need_key) HIP_TRY(c, grow_record_array(c->in_key, cap, used, c->stream));
-    if (need_flag) HIP_TRY(c, grow_record_array(c->in_flag, cap, used, c->stream));
-    if (need_check) HIP_TRY(c, grow_record_array(c->in_check, cap, used, c->stream));
+    std::vector<void*>* later = c->bam.active ? &c->bam.outgrown : nullptr;  // (windows of a BAM file may be inflating)
+    HIP_TRY(c, grow_record_array(c->in_ref, cap, used, c->stream, later));
+    HIP_TRY(c, grow_record_array(c->in_pos, cap, used, c->stream, later));
+    if (need_key) HIP_TRY(c, grow_record_array(c->in_key, cap, used, c->stream, later));
+    if (need_flag) HIP_TRY(c, grow_record_array(c->in_flag, cap, used, c->stream, later));
+    if (need_check) HIP_TRY(c, grow_record_array(c->in_check, cap, used, c->stream, later));
     return SLIMM_OK;
 }
 
@@ -1051,8 +1059,11 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     const uint32_t b = static_cast<uint32_t>(j % slimm_ctx::kBamRing), nb = static_cast<uint32_t>((j + 1u) % slimm_ctx::kBamRing);
     const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
     const uint32_t np = bam_pieces(end - lo);
-    HIP_TRY(c, B.pieces.ensure(static_cast<size_t>(np) + 1));
-    HIP_TRY(c, B.offs.ensure(static_cast<size_t>(np + 1) * kBamSlots));
+    // (with room to spare and without a hipFree: windows differ by a few pieces, and a hipFree waits for the inflate kernels
+    // of the windows behind this one)
+    if (B.pieces.cap < static_cast<size_t>(np) + 1) HIP_TRY(c, B.pieces.ensure_later(static_cast<size_t>(np) + (np >> 2) + 64, B.outgrown));
+    if (B.offs.cap < static_cast<size_t>(np + 1) * kBamSlots)
+        HIP_TRY(c, B.offs.ensure_later((static_cast<size_t>(np) + (np >> 2) + 64) * kBamSlots, B.outgrown));
     if (n_bytes) HIP_TRY(c, hipStreamWaitEvent(st, B.copied[b], 0));
     const bool inflated_here = n_bytes && B.inflated[b];
     if (inflated_here)
@@ -1075,11 +1086,11 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
         const uint64_t want = c->n_pushed + n_rec;
         if (c->in_flag.cap < want) {
             if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
-            HIP_TRY(c, c->in_flag.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+            HIP_TRY(c, c->in_flag.ensure_later(std::max<uint64_t>(want, c->in_ref.cap), B.outgrown));
         }
         if (c->in_check.cap < want) {
             if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
-            HIP_TRY(c, c->in_check.ensure(std::max<uint64_t>(want, c->in_ref.cap)));
+            HIP_TRY(c, c->in_check.ensure_later(std::max<uint64_t>(want, c->in_ref.cap), B.outgrown));
         }
     }
     launch_bam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
@@ -1117,6 +1128,19 @@ int slimm_push_bgzf_blocks(slimm_ctx* c, const uint8_t* blocks, uint64_t n_bytes
     return bam_push_window(c, blocks, n_bytes, true, skip, last, n_records);
 }
 namespace {
+// SLIMM_PUSH_TRACE=1: what the window pipeline does and when (stderr; milliseconds since the first line)
+void push_trace(const char* fmt, ...) {
+    static const bool on = getenv("SLIMM_PUSH_TRACE") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    va_list ap;
+    va_start(ap, fmt);
+    fprintf(stderr, "[push %9.3f] ", ms);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
 // the window buffer of window `windows`, large enough for n_bytes behind its slack; what the slack holds is kept
 int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes, bool gathered = false) {
     slimm_ctx::BamDecode& B = c->bam;
@@ -1181,6 +1205,8 @@ int bam_launch_gathered(slimm_ctx* c) {
     B.inflated[b] = true;
     B.win_bytes[b] = n_bytes;
     ++B.windows;
+    push_trace("window %llu launched: %u blocks, %.0f MB -> %.0f MB, inflate stream %u", (unsigned long long)(B.windows - 1), nblk,
+               B.acc_src / 1e6, n_bytes / 1e6, si);
     return SLIMM_OK;
 }
 
@@ -1255,6 +1281,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
     if (B.closed) return fail(c, SLIMM_E_INVALID, "the file's last window has been pushed; reset first");
     uint64_t total = 0;
     bool copy_started = false;
+    push_trace("push: %.0f MB %s -> %.0f MB%s", src_bytes / 1e6, compressed ? "of blocks" : "inflated", n_bytes / 1e6, last ? " (last)" : "");
     if (n_bytes && compressed) {
         // behind what is gathered already -- unless the window would grow past its size: that one goes first
         if (B.acc_open && B.acc_dst + inflated > slimm_ctx::kBamGather) {
@@ -1279,6 +1306,9 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
                     HIP_TRY(c, B.desc[k].ensure_later(blocks_max, B.outgrown));
                 }
                 for (auto& sc : B.inflate_scratch) HIP_TRY(c, sc.ensure_later(bgzf_inflate_scratch_bytes(blocks_max, tok_max), B.outgrown));
+                const size_t np_max = bam_pieces(slimm_ctx::kBamGather + kBamSlack) + 64;
+                HIP_TRY(c, B.pieces.ensure_later(np_max, B.outgrown));
+                HIP_TRY(c, B.offs.ensure_later(np_max * kBamSlots, B.outgrown));
                 HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
                 HIP_TRY(c, B.h_inflate_status.ensure(4));
             }
@@ -1341,7 +1371,10 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         if (!last && B.windows - B.head <= slimm_ctx::kBamLag && in_flight <= slimm_ctx::kBamInFlight) break;
         uint64_t got = 0;
         const uint64_t j = B.head;
+        push_trace("finishing window %llu (%llu .. %llu in flight, %.0f MB)", (unsigned long long)j, (unsigned long long)B.head,
+                   (unsigned long long)B.windows, in_flight / 1e6);
         const int rc = bam_finish_window(c, j, B.win_bytes[j % slimm_ctx::kBamRing], last && j + 1 == B.windows, got);
+        push_trace("finished window %llu: %llu records", (unsigned long long)j, (unsigned long long)got);
         ++B.head;
         if (rc != SLIMM_OK) return rc;
         total += got;
@@ -1355,6 +1388,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         // recent push whose copy this call did not start itself (a call without record bytes starts none)
         const uint64_t mine = copy_started ? 1u : 0u;
         if (B.pushes > mine) HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.pushes - 1u - mine) % 4u]));
+        push_trace("push returns");
     }
     if (n_records) *n_records = total;
     return SLIMM_OK;

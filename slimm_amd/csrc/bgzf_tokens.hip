@@ -350,7 +350,8 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
 #pragma unroll
     for (int l = 0; l < 15; ++l) LL.v[l] = DL.v[l] = 0x7fffu;
     uint32_t mode = have ? kModeHeader : kModeDone;
-    uint32_t last = 0, o = 0, acc = 0, acc_n = 0, litrun = 0, ntok = 0;
+    uint32_t last = 0, o = 0, acc_n = 0, litrun = 0, ntok = 0;
+    uint64_t acc = 0;   // literals waiting to be stored: up to 3 from the steps before + 2 of this one
     // stores waiting for the top of the next step
     uint32_t p_lit = 0, p_lit_at = 0, p_lit_n = 0, p_tok0 = 0, p_tok1 = 0, p_ntok = 0, p_tok_at = 0;
 
@@ -386,7 +387,9 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
                 p_ntok = 0;
             }
             if (!__any(run)) break;
-            // ---- one literal/length symbol, and the distance symbol behind it as if it were a length
+            // ---- one literal/length symbol, then ONE more symbol of whichever code comes next: behind a literal the
+            // literal/length code again (a second literal is taken along; anything else waits for the next step), behind a
+            // length the distance code.  The second chain's limits, base table and symbol table are selected per lane.
             uint64_t w = bits.lo;
             const uint32_t x = top15(w);
             const uint32_t len = LL.length_of(x);
@@ -401,36 +404,47 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
             const uint32_t le = (ls >= 8u && ls < 28u) ? (ls >> 2) - 1u : 0u;
             const uint32_t lb = ls < 8u ? ls + 3u : (ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << le));
             const uint32_t mlen = lb + (static_cast<uint32_t>(w) & ((1u << le) - 1u));
-            w >>= le;
+            w >>= le;   // (le = 0 behind a literal)
+            Limits SL;
+#pragma unroll
+            for (int l = 0; l < 15; ++l) SL.v[l] = is_lit ? LL.v[l] : DL.v[l];
             const uint32_t y = top15(w);
-            const uint32_t dl = DL.length_of(y);
-            const uint32_t didx = min(symbol_at(L, kDbase, y, dl), 31u);
-            const uint32_t ds = L.b8(kDsym, didx);
+            const uint32_t l2 = SL.length_of(y);
+            const uint32_t i2 = min(symbol_at(L, is_lit ? kLbase : kDbase, y, l2), is_lit ? 287u : 31u);
+            const uint32_t s2lo = L.b8(is_lit ? kLsymLo : kDsym, i2);
+            const uint32_t s2hi = (L.b32(kLsymHi, (i2 >> 5) & 15u) >> (i2 & 31u)) & 1u;
+            // behind a literal: a second literal?
+            const bool lit2 = is_lit & (l2 <= 15u) & (s2hi == 0u);
+            // behind a length: the distance
+            const uint32_t ds = s2lo;
             const uint32_t de = ds >= 4u ? (ds >> 1) - 1u : 0u;
             const uint32_t dbv = ds < 4u ? ds + 1u : 1u + ((2u + (ds & 1u)) << de);
-            const uint32_t dist = dbv + (static_cast<uint32_t>(w >> (dl > 15u ? 15u : dl)) & ((1u << de) - 1u));
+            const uint32_t dist = dbv + (static_cast<uint32_t>(w >> (l2 > 15u ? 15u : l2)) & ((1u << de) - 1u));
             if (is_len) {
-                bad = bad | (dl > 15u) | (ds > 29u);
-                c += le + (dl > 15u ? 0u : dl) + de;
+                bad = bad | (l2 > 15u) | (ds > 29u);
+                c += le + (l2 > 15u ? 0u : l2) + de;
             }
+            if (lit2) c += l2;
             if (run) {
                 bool flush = false;
                 if (is_lit) {
-                    if (o >= isize) bad = true;
-                    acc |= sym << (8u * acc_n);
-                    ++acc_n;
-                    ++o;
-                    ++litrun;
-                    flush = acc_n == 4u;
+                    const uint32_t n_lit = lit2 ? 2u : 1u;
+                    if (o + n_lit > isize) bad = true;
+                    acc |= static_cast<uint64_t>(sym | (lit2 ? s2lo << 8 : 0u)) << (8u * acc_n);
+                    acc_n += n_lit;
+                    o += n_lit;
+                    litrun += n_lit;
+                    flush = acc_n >= 4u;
                 } else {
                     flush = acc_n != 0u;
                 }
-                if (flush & !bad) {
-                    p_lit = acc;
-                    p_lit_n = acc_n;
+                if (flush & !bad) {   // (four bytes when there are four, else what there is: a match or the block's end follows)
+                    const uint32_t n_out = acc_n >= 4u ? 4u : acc_n;
+                    p_lit = static_cast<uint32_t>(acc);
+                    p_lit_n = n_out;
                     p_lit_at = o - acc_n;
-                    acc = 0;
-                    acc_n = 0;
+                    acc = n_out == 4u ? acc >> 32 : 0ull;
+                    acc_n -= n_out;
                 }
                 if (is_len & !bad) {
                     if (dist > o || o + mlen > isize || ntok + 2u > tok_room) {

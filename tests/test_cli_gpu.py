@@ -382,9 +382,9 @@ def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_
 def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
     """BAM input on one GPU: of the windows the reader takes straight from the mapped file, a share goes to the device
     COMPRESSED (slimm_push_bgzf_blocks: inflate, CRC, record boundaries, fields, names all there) and alternates with windows
-    the host cores inflated (slimm_push_bam_bytes) -- when asked to (SLIMM_CLI_DEVICE_INFLATE = one window in so many, six by default; a
-    device window is ten host windows large).  Whatever the period -- none, the default, every window -- the same files,
-    equal to the oracle's."""
+    the host cores inflated (slimm_push_bam_bytes) -- when asked to (SLIMM_CLI_DEVICE_INFLATE = one window in so many; 1 = every
+    window, the default since the two-phase inflate of round 5; 0 = none).  Whatever the period -- none, one in six, every window
+    -- the same files, equal to the oracle's."""
     import re
     w = with_names(make_workload(CONFIGS["config2"], seed=53, n_records=250_000))
     rec, hd = w.records, "@HD\tVN:1.6\tSO:unsorted\tGO:query"
@@ -410,7 +410,7 @@ def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
     avg = sum(lens) // len(lens)
     want = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, rec, avg, want_raw=True, want_cov=False)
     outs, shares = [], []
-    for tenths in ("0", None, "1"):
+    for tenths in ("0", "6", None):
         out = str(tmp_path / f"out_{tenths}") + "/"
         os.makedirs(out)
         env = dict(os.environ, SLIMM_CLI_TRACE="1", SLIMM_CLI_WINDOW_MB="2")
@@ -425,10 +425,10 @@ def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
     assert outs[0] == outs[1] == outs[2]
     check_outputs(str(tmp_path / "out_0") + "/", "in", want, coverage=False)
     (h0, d0), (h1, d1), (h2, d2) = shares
-    # none / all of the windows read in place (the call that finds itself behind the reader's own windows inflates: <= 2);
-    # a device window holds ten host windows' worth of bytes
+    # none / one in six / all (the default since round 5) of the windows read in place (the call that finds itself behind the
+    # reader's own windows inflates: <= 2)
     assert d0 == 0 and h0 > 10 and h2 <= 2 and d2 >= 2
-    assert d1 >= 1 and h1 >= 5 * d1 - 5     # (the default: one window in six)
+    assert d1 >= 1 and h1 >= 5 * d1 - 5
     # a flipped byte in a record's sequence (far into the file: a window read in place): the CRC says so, wherever the
     # block is inflated
     blob = bytearray(open(inp, "rb").read())

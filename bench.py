@@ -35,7 +35,9 @@ ONE JSON line on rank 0.  Beside the contract's fields:
                       against oracle/slimm_dense_mt.cpp run on the same 100 M records in this very run
   cpu_baseline        the CPU oracle (a port of the reference algorithm, 1 thread) on a bounded prefix of the stream
   cpu_baseline_mt     the dense all-core restatement on a bounded prefix
-  cli_end_to_end      `slimm DB IN.bam` on a 100 M-record synthetic BAM, process start to profile written
+  cli_end_to_end      `slimm DB IN.bam` on a 100 M-record synthetic BAM that compresses 3-fold (random bases, binned qualities,
+                      instrument-style names), process start to profile written; the same with the host inflating, an unsorted
+                      copy, and the 17.7-fold file of rounds 1 - 4 beside it
 """
 import argparse
 import json
@@ -898,35 +900,50 @@ def main():
             tmp = tempfile.mkdtemp(prefix="slimm_bench_cli_")
             bam = os.path.join(tmp, "sample.bam")
             recb = w_cli.records if nb == len(w_cli.records) else w_cli.records.take(slice(0, nb))
-            info = write_synthetic_bam(bam, w_cli.ref_names, w_cli.ref_len, recb, read_len=w_cli.avg_read_len)
+            info = write_synthetic_bam(bam, w_cli.ref_names, w_cli.ref_len, recb, read_len=w_cli.avg_read_len, realistic=True)
             db = os.path.join(tmp, "db.sldb")
             write_sldb(db, w_cli.taxonomy)
             os.makedirs(os.path.join(tmp, "out"))
-            def run_cli(path, stem):
+            def run_cli(path, stem, env=None):
                 runs, r = [], None
                 for _ in range(2):
                     t1 = time.perf_counter()
                     r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/",
-                                        db, path], capture_output=True, text=True, env=dict(os.environ, SLIMM_CLI_TRACE="1"))
+                                        db, path], capture_output=True, text=True, env=dict(os.environ, SLIMM_CLI_TRACE="1", **(env or {})))
                     runs.append(time.perf_counter() - t1)
                     if r.returncode != 0:
                         return None, r, None
                 prof = open(os.path.join(tmp, "out", stem + "_profile.tsv")).read()
                 return min(runs), r, prof
 
+            def traces(r):
+                tr = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "[trace] reader" in ln][-1:]
+                dd = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "[trace] device decode" in ln][-1:]
+                su = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "slimm_create" in ln][-1:]
+                return (tr[0] if tr else None), (dd[0] if dd else None), (su[0] if su else None)
+
             best, r, prof_g = run_cli(bam, "sample")
             if best is not None:
-                trace = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "[trace] reader" in ln][-1:]
-                dd = [ln[ln.index("[trace]") + 8:] for ln in r.stderr.splitlines() if "[trace] device decode" in ln][-1:]
+                tr, dd, su = traces(r)
+                ratio = info["raw_bytes"] / info["compressed_bytes"]
                 cli = {"value": round(nb / best / 1e6, 3), "unit": "M records/s", "seconds": round(best, 3),
-                       "what": f"`slimm -w 1000 DB IN.bam`, process start to profile written (HIP start-up, read-length sample, "
-                               f"BGZF inflate on the host cores for five windows in six -- they cross PCIe inflated -- and on the device "
-                               f"for the sixth, which is ten times their size (slimm_push_bgzf_blocks); record boundaries + fields + "
-                               f"adjacent-name comparison on the device, GPU path), {nb} records of config3, "
-                               f"name-grouped, {info['raw_bytes'] / 1e9:.1f} GB of BAM records in {info['compressed_bytes'] / 1e9:.2f} GB; "
-                               "best of 2",
-                       "reader": trace[0] if trace else None, "device_decode": dd[0] if dd else None,
-                       "bam_built_in_s": round(info["seconds"], 1)}
+                       "what": f"`slimm -w 1000 DB IN.bam`, process start to profile written, on a BAM that compresses like a BAM: {nb} "
+                               f"records of config3, name-grouped, random bases, binned qualities with runs, instrument-style names -- "
+                               f"{info['raw_bytes'] / 1e9:.1f} GB of BAM records in {info['compressed_bytes'] / 1e9:.2f} GB = {ratio:.2f} x "
+                               f"({info['deflate']}).  HIP start-up, read-length sample, the file's BGZF blocks read by pread and handed over "
+                               f"COMPRESSED (slimm_push_bgzf_blocks), inflated on the device in two phases (bgzf_tokens.hip), record "
+                               f"boundaries + fields + adjacent-name comparison on the device, GPU path; best of 2",
+                       "compression_ratio": round(ratio, 3),
+                       "bounds": {"pcie_s": round(info["compressed_bytes"] / 54e9, 3), "what": "compressed bytes / 54 GB/s; HIP start-up "
+                                  "(0.1 - 0.3 s, in `start_up`) runs beside the first reads"},
+                       "reader": tr, "device_decode": dd, "start_up": su, "bam_built_in_s": round(info["seconds"], 1)}
+                # the same file with every window inflated by the host cores (rounds 1 - 4's path)
+                best_h, rh, prof_h = run_cli(bam, "sample", env={"SLIMM_CLI_DEVICE_INFLATE": "0"})
+                if best_h is not None:
+                    _, ddh, _ = traces(rh)
+                    cli["host_inflate"] = {"value": round(nb / best_h / 1e6, 3), "unit": "M records/s", "seconds": round(best_h, 3),
+                                           "what": "SLIMM_CLI_DEVICE_INFLATE=0: BGZF inflate by libdeflate on the host cores, inflated "
+                                                   "windows over PCIe", "same_profile": bool(prof_h == prof_g), "device_decode": ddh}
                 # the same records in NO particular order (header without GO:query): name hash + check word on the device,
                 # then the device-side grouping of record_order = ANY
                 try:
@@ -939,23 +956,39 @@ def main():
                     del inv
                     bam_u = os.path.join(tmp, "unsorted.bam")
                     info_u = write_synthetic_bam(bam_u, w_cli.ref_names, w_cli.ref_len, recu, read_len=w_cli.avg_read_len,
-                                                 hd="@HD\tVN:1.6\tSO:unsorted")
+                                                 hd="@HD\tVN:1.6\tSO:unsorted", realistic=True)
                     del recu
                     best_u, ru, prof_u = run_cli(bam_u, "unsorted")
                     if best_u is not None:
-                        ddu = [ln[ln.index("[trace]") + 8:] for ln in ru.stderr.splitlines() if "[trace] device decode" in ln][-1:]
+                        _, ddu, _ = traces(ru)
                         cli["unsorted_file"] = {"value": round(nb / best_u / 1e6, 3), "unit": "M records/s", "seconds": round(best_u, 3),
                                                 "what": "the same records with the reads interleaved at random, @HD SO:unsorted: key + "
                                                         "check word hashed from the names on the device, then the grouping of "
                                                         "record_order = ANY; best of 2",
+                                                "compression_ratio": round(info_u["raw_bytes"] / info_u["compressed_bytes"], 3),
                                                 "same_profile_as_the_grouped_file": bool(prof_u == prof_g),
-                                                "device_decode": ddu[0] if ddu else None,
+                                                "device_decode": ddu,
                                                 "bam_built_in_s": round(info_u["seconds"], 1)}
                     else:
                         cli["unsorted_file"] = {"error": ru.stderr[-400:]}
                     os.unlink(bam_u)
                 except Exception as e:   # (the leg is a report, not a gate)
                     cli["unsorted_file"] = {"error": repr(e)[:300]}
+                # rounds 1 - 4's file beside it: every sequence byte 0x11, every quality 0x28 -- 17.7-fold
+                try:
+                    bam_e = os.path.join(tmp, "easy.bam")
+                    info_e = write_synthetic_bam(bam_e, w_cli.ref_names, w_cli.ref_len, recb, read_len=w_cli.avg_read_len)
+                    best_e, re_, prof_e = run_cli(bam_e, "easy")
+                    if best_e is not None:
+                        _, dde, _ = traces(re_)
+                        cli["easy_file"] = {"value": round(nb / best_e / 1e6, 3), "unit": "M records/s", "seconds": round(best_e, 3),
+                                            "compression_ratio": round(info_e["raw_bytes"] / info_e["compressed_bytes"], 3),
+                                            "what": "the file of rounds 1 - 4 (constant sequences and qualities, hex names)",
+                                            "same_profile": bool(prof_e == prof_g), "device_decode": dde,
+                                            "bam_built_in_s": round(info_e["seconds"], 1)}
+                    os.unlink(bam_e)
+                except Exception as e:
+                    cli["easy_file"] = {"error": repr(e)[:300]}
             else:
                 cli = {"error": r.stderr[-400:]}
             try:
@@ -1020,7 +1053,10 @@ def main():
             "any_order_same_profile": all(v["same_profile_as_the_grouped_stream"] for v in (any_order or {}).values()) if any_order else None,
             "parity_in_run": parity_in_run["ok"] if parity_in_run else None,
             "value_with_push": (with_push or {}).get("value"), "run_marked_with_push": ((marked or {}).get("with_push") or {}).get("value"),
-            "cli_M_records_s": (cli or {}).get("value"), "cli_unsorted_M_records_s": ((cli or {}).get("unsorted_file") or {}).get("value"),
+            "cli_M_records_s": (cli or {}).get("value"), "cli_compression_ratio": (cli or {}).get("compression_ratio"),
+            "cli_host_inflate_M_records_s": ((cli or {}).get("host_inflate") or {}).get("value"),
+            "cli_unsorted_M_records_s": ((cli or {}).get("unsorted_file") or {}).get("value"),
+            "cli_easy_file_M_records_s": ((cli or {}).get("easy_file") or {}).get("value"),
             "cpu_baseline": (cpu or {}).get("value"), "cpu_baseline_mt": (cpu_mt or {}).get("value"),
         }
         print(json.dumps(line))

@@ -246,6 +246,13 @@ def dense_mt_lib():
         L.dmt_run2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_uint32, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.dmt_run3.restype = C.c_int
+        L.dmt_run3.argtypes = L.dmt_run2.argtypes + [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.dmt_profile.restype = C.c_int
+        L.dmt_profile.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float,
+                                  C.c_float, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _mt_lib = L
     return _mt_lib
 
@@ -268,10 +275,12 @@ def bin_checksum(a: np.ndarray) -> int:
     return int(total)
 
 
-def dense_mt_run(w, records=None, threads: int = 0, want_bins: bool = False) -> dict:
+def dense_mt_run(w, records=None, threads: int = 0, want_bins: bool = False, want_profile: bool = False) -> dict:
     """Phases A, B and the direct LCA counts of workload `w` (records grouped by read name) on `threads` host threads
     (0 = all).  Returns per-reference columns, scalars, {taxid: count}, the checksums of the three coverage arrays
-    (bin_checksum) -- with want_bins the arrays themselves -- and the three phase times."""
+    (bin_checksum) -- with want_bins the arrays themselves -- and the three phase times.  want_profile: also the scalar
+    tail from the reference (dmt_profile: src/slimm.hpp:560-610, 733-843): "taxon_count", "taxon_children" (the propagated
+    counts and children sets) and "profile" = {taxa_id column: (abundance, read count)}."""
     rec = w.records if records is None else records
     R = len(w.ref_names)
     lineage = np.ascontiguousarray(w.taxonomy.lineage_for_header(w.ref_names), dtype=np.uint32)
@@ -292,12 +301,16 @@ def dense_mt_run(w, records=None, threads: int = 0, want_bins: bool = False) -> 
         B = int((ref_len.astype(np.int64) // bw + 1).sum())
         bins = [np.zeros(B, dtype=np.uint32) for _ in range(3)]
         out_ptrs = (C.c_void_p * 3)(*[b.ctypes.data for b in bins])
-    rc = dense_mt_lib().dmt_run2(_p(rec.read_key), _p(rec.flag), _p(rec.ref_id), _p(rec.begin_pos), len(rec), R, _p(ref_len),
+    pair_cap = 1 << 22
+    pairs = np.zeros(pair_cap if want_profile else 1, dtype=np.uint64)
+    n_pairs = C.c_uint64(0)
+    cuts = np.zeros(2, dtype=np.float32)
+    rc = dense_mt_lib().dmt_run3(_p(rec.read_key), _p(rec.flag), _p(rec.ref_id), _p(rec.begin_pos), len(rec), R, _p(ref_len),
                                  _p(lineage), int(w.avg_read_len), int(w.options.bin_width), float(w.options.cov_cut_off),
                                  int(threads), _p(cols), _p(sc), _p(tx), _p(cn), cap, C.byref(n_lca), _p(sec), out_ptrs,
-                                 _p(chk))
+                                 _p(chk), _p(pairs) if want_profile else None, pair_cap, C.byref(n_pairs), _p(cuts))
     if rc < 0:
-        raise RuntimeError("dmt_run2: bad arguments")
+        raise RuntimeError("dmt_run3: bad arguments")
     k = min(int(n_lca.value), cap)
     out = {"no_hits": rc == 1, "reads_count": cols[:, 0].copy(), "uniq_reads_count": cols[:, 1].copy(),
            "nz_cov": cols[:, 2].copy(), "nz_uniq_cov": cols[:, 3].copy(), "uniq_reads_count2": cols[:, 4].copy(),
@@ -306,4 +319,29 @@ def dense_mt_run(w, records=None, threads: int = 0, want_bins: bool = False) -> 
            "checksums": tuple(int(x) for x in chk), "seconds": tuple(float(x) for x in sec), "threads": int(threads)}
     if bins is not None:
         out["cov"], out["uniq_cov"], out["uniq_cov2"] = bins
+    out["cutoffs"] = (float(cuts[0]), float(cuts[1]))
+    if want_profile and rc == 0:
+        assert n_pairs.value <= pair_cap and n_lca.value <= cap
+        t = w.taxonomy
+        ranks = ["strain", "species", "genus", "family", "order", "class", "phylum", "superkingdom"]
+        rank = ranks.index(w.options.rank)          # considered_ranks = {rank + 1, rank} (src/slimm.hpp:498-514)
+        named = np.array([1 if nm else 0 for nm in t.tax_name], dtype=np.uint8)
+        ocap = 1 << 20
+        ot, oc = np.zeros(ocap, dtype=np.uint32), np.zeros(ocap, dtype=np.uint32)
+        op = np.zeros(1 << 24, dtype=np.uint64)
+        rt, rs = np.zeros(ocap, dtype=np.uint32), np.zeros(ocap, dtype=np.uint8)
+        ra, rr = np.zeros(ocap, dtype=np.float32), np.zeros(ocap, dtype=np.uint32)
+        n_out, n_op, n_rows = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0)
+        u2 = np.ascontiguousarray(out["uniq_reads_count2"], dtype=np.uint32)
+        dense_mt_lib().dmt_profile(R, _p(lineage), _p(ref_len), _p(u2), _p(tx), _p(cn), k, _p(pairs), int(n_pairs.value),
+                                   _p(np.ascontiguousarray(t.tax_id, dtype=np.uint32)), _p(np.ascontiguousarray(t.tax_rank, dtype=np.uint32)),
+                                   _p(named), len(t.tax_name), out["matches"] & 0xffffffff, int(w.avg_read_len), rank, rank + 1,
+                                   float(w.options.abundance_cut_off), float(cuts[0]), _p(ot), _p(oc), ocap, C.byref(n_out), _p(op),
+                                   op.shape[0], C.byref(n_op), _p(rt), _p(rs), _p(ra), _p(rr), ocap, C.byref(n_rows))
+        assert n_out.value <= ocap and n_op.value <= op.shape[0] and n_rows.value <= ocap
+        out["taxon_count"] = {int(a): int(b) for a, b in zip(ot[:n_out.value], oc[:n_out.value])}
+        pp = op[:n_op.value]
+        out["taxon_children"] = set(zip((pp >> np.uint64(32)).astype(np.uint32).tolist(), (pp & np.uint64(0xffffffff)).astype(np.uint32).tolist()))
+        out["profile"] = {f"{int(a)}{'*' if s_ else ''}": (float(ab), int(rd))
+                          for a, s_, ab, rd in zip(rt[:n_rows.value], rs[:n_rows.value], ra[:n_rows.value], rr[:n_rows.value])}
     return out

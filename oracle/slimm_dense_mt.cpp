@@ -15,9 +15,12 @@
 // Input: records grouped by read name (all records of a qName adjacent -- mapper output), as the product's
 // SLIMM_ORDER_GROUPED.  Threads take contiguous slices of the stream cut at qName-run boundaries; histogram bins are
 // shared arrays updated with relaxed atomic adds; per-reference counters and per-taxon LCA counts are private to a
-// thread and merged at the end (the few abundant references of a sample would be one contended cache line otherwise).  Scope: phases A, B and C(1) -- everything that touches records or reads.  The scalar tail of
-// the path (propagation up the lineages, abundances, the profile file: a few thousand taxa, < 1 ms on the oracle) is
-// not repeated here.
+// thread and merged at the end (the few abundant references of a sample would be one contended cache line otherwise).
+// Scope of dmt_run*: phases A, B and C(1) -- everything that touches records or reads.  The scalar tail of the path
+// (propagation of the counts up the lineages, src/slimm.hpp:560-610, and the rows of the profile, :733-843) is
+// dmt_profile below: single-threaded, written from the reference with the reference's containers, and given the direct
+// LCA counts + the (taxon, reference) pairs dmt_run3 collects it makes the full-size tests' comparison of the propagated
+// counts and the profile an independent one (checked against slimm_oracle.cpp in tests/test_dense_mt.py).
 // ============================================================================
 #include <algorithm>
 #include <atomic>
@@ -25,8 +28,11 @@
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <set>
+#include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 namespace {
@@ -46,6 +52,7 @@ struct alignas(128) Shard {  // (a cache line pair of its own: the threads' coun
     std::vector<uint32_t> reads_count, uniq_count, uniq_count2;
     uint64_t hits = 0, reads = 0, uniq_reads = 0, uniq_reads2 = 0;
     std::unordered_map<uint32_t, uint32_t> lca;
+    std::unordered_set<uint64_t> pairs;   // (LCA taxon << 32 | reference) of the reads that keep several references (dmt_run3)
 };
 
 inline uint32_t mate_of(uint16_t flag) { return (flag & 0x40) ? 1u : ((flag & 0x80) ? 2u : 0u); }  // slimm.hpp:205-208
@@ -107,11 +114,14 @@ extern "C" {
 //                  (reference_contig.hpp:110-112), references back to back without padding
 //   checksums [3]: position-weighted 64-bit sums of the same three arrays, sum_i a[i] * ((i + 1) * 0x9E3779B97F4A7C15)
 //                  mod 2^64 (bin_checksum below; tests/helpers.py computes the same over slimm_get_bins)
-int dmt_run2(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
+// dmt_run3 also collects (not in any timed phase's favour: only when pairs_out is given) the contributing children of step 1
+// (src/slimm.hpp:555): the distinct (LCA taxon << 32 | reference) pairs, up to pair_cap of them, *n_pairs = how many exist;
+// cutoffs_out [2] = the two float cut-offs
+int dmt_run3(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
              const uint32_t* ref_len, const uint32_t* lineage /*[n_refs * 8]*/, uint32_t avg_read_len, uint32_t bin_width,
              float cov_cut_off, uint32_t n_threads, uint32_t* ref_cols, uint64_t* scalars, uint32_t* lca_taxid,
              uint32_t* lca_count, uint32_t lca_cap, uint32_t* n_lca, double* seconds, uint32_t* const* bins_out,
-             uint64_t* checksums) {
+             uint64_t* checksums, uint64_t* pairs_out, uint64_t pair_cap, uint64_t* n_pairs, float* cutoffs_out) {
     if (!n_refs || !ref_len || !lineage || !ref_cols || !scalars || !seconds) return -1;
     if (bin_width == 0) bin_width = avg_read_len;  // slimm.hpp:412-413
     if (bin_width == 0) return -1;
@@ -294,6 +304,9 @@ int dmt_run2(const uint64_t* key, const uint16_t* flag, const int32_t* ref, cons
                     if (same) break;
                 }
                 ++s.lca[taxon];
+                if (pairs_out) {   // slimm.hpp:555: taxon_id__children[lca].insert(ref_ids)
+                    for (uint32_t id : ids) s.pairs.insert((static_cast<uint64_t>(taxon) << 32) | id);
+                }
             }
         }
         s.uniq_reads2 = n_uniq2;
@@ -322,7 +335,159 @@ int dmt_run2(const uint64_t* key, const uint16_t* flag, const int32_t* ref, cons
         ++k;
     }
     if (n_lca) *n_lca = k;
+    if (pairs_out && n_pairs) {
+        std::unordered_set<uint64_t> all;
+        for (const Shard& s : shard) all.insert(s.pairs.begin(), s.pairs.end());
+        uint64_t m = 0;
+        for (uint64_t pr : all) {
+            if (m < pair_cap) pairs_out[m] = pr;
+            ++m;
+        }
+        *n_pairs = m;
+    }
+    if (cutoffs_out) {
+        cutoffs_out[0] = cc;
+        cutoffs_out[1] = ucc;
+    }
     hand_out();
+    return 0;
+}
+
+int dmt_run2(const uint64_t* key, const uint16_t* flag, const int32_t* ref, const int32_t* pos, uint64_t n, uint32_t n_refs,
+             const uint32_t* ref_len, const uint32_t* lineage, uint32_t avg_read_len, uint32_t bin_width, float cov_cut_off,
+             uint32_t n_threads, uint32_t* ref_cols, uint64_t* scalars, uint32_t* lca_taxid, uint32_t* lca_count,
+             uint32_t lca_cap, uint32_t* n_lca, double* seconds, uint32_t* const* bins_out, uint64_t* checksums) {
+    return dmt_run3(key, flag, ref, pos, n, n_refs, ref_len, lineage, avg_read_len, bin_width, cov_cut_off, n_threads,
+                    ref_cols, scalars, lca_taxid, lca_count, lca_cap, n_lca, seconds, bins_out, checksums, nullptr, 0, nullptr,
+                    nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The scalar tail of the path, from the reference: get_reads_lca_count steps 2 and 3 (src/slimm.hpp:560-610) and the rows
+// write_abundance prints (:733-843), with the reference's containers (std::unordered_map / std::set).  In: the header's
+// lineages, what dmt_run3 counted (direct LCA counts, their contributing references, uniq_reads_count2), the database's
+// taxid -> (rank, has a name) and the options the rows depend on.  Out: the propagated counts, the children sets as pairs,
+// the rows {taxid, 1 = an "<id>*" row, abundance, read count} in the order the reference would print them for this
+// container implementation (compare as sets: Q16).
+// ---------------------------------------------------------------------------------------------------------------------
+int dmt_profile(uint32_t n_refs, const uint32_t* lineage, const uint32_t* ref_len, const uint32_t* uniq_reads_count2,
+                const uint32_t* lca_taxid, const uint32_t* lca_count, uint32_t n_lca, const uint64_t* pairs, uint64_t n_pairs,
+                const uint32_t* tax_id, const uint32_t* tax_rank, const uint8_t* tax_named, uint32_t n_tax, uint32_t matches_count,
+                uint32_t avg_read_length, uint32_t rank, uint32_t parent_rank, float abundance_cut_off, float coverage_cut_off,
+                uint32_t* out_taxid, uint32_t* out_count, uint32_t out_cap, uint32_t* n_out, uint64_t* out_pairs, uint64_t out_pair_cap,
+                uint64_t* n_out_pairs, uint32_t* row_taxid, uint8_t* row_star, float* row_abundance, uint32_t* row_reads,
+                uint32_t row_cap, uint32_t* n_rows) {
+    constexpr uint32_t LINAGE_LENGTH = 8;
+    struct Tax {
+        uint32_t rank = 0;   // (an absent taxid default-constructs to strain_lv and an empty name: Q6)
+        bool named = false;
+    };
+    std::unordered_map<uint32_t, Tax> taxid__name;
+    for (uint32_t i = 0; i < n_tax; ++i) taxid__name[tax_id[i]] = Tax{tax_rank[i], tax_named[i] != 0};
+    std::unordered_map<uint32_t, uint32_t> taxon_id__read_count;
+    std::unordered_map<uint32_t, std::set<uint32_t>> taxon_id__children;
+    for (uint32_t i = 0; i < n_lca; ++i) taxon_id__read_count[lca_taxid[i]] += lca_count[i];                      // :551
+    for (uint64_t i = 0; i < n_pairs; ++i) taxon_id__children[static_cast<uint32_t>(pairs[i] >> 32)].insert(static_cast<uint32_t>(pairs[i]));  // :555
+    auto lin = [&](uint32_t ref_id) { return lineage + static_cast<size_t>(ref_id) * LINAGE_LENGTH; };
+    // :560-586
+    std::unordered_map<uint32_t, uint32_t> taxon_id__read_count_cp = taxon_id__read_count;
+    for (auto t_id : taxon_id__read_count_cp) {
+        const uint32_t rnk = taxid__name[t_id.first].rank;
+        const uint32_t first_child = *taxon_id__children.at(t_id.first).begin();
+        const uint32_t* linage = lin(first_child);
+        std::set<uint32_t> ref_ids = taxon_id__children[t_id.first];
+        for (uint32_t j = rnk + 1; j < LINAGE_LENGTH; ++j) {
+            const uint32_t reciever_taxa_id = linage[j];
+            taxon_id__read_count[reciever_taxa_id] += t_id.second;
+            taxon_id__children[reciever_taxa_id].insert(ref_ids.begin(), ref_ids.end());
+        }
+    }
+    // :589-610
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (uniq_reads_count2[i] > 0) {
+            const uint32_t* linage = lin(i);
+            std::set<uint32_t> ref_ids = taxon_id__children[linage[0]];
+            for (uint32_t j = 1; j < LINAGE_LENGTH; ++j) {
+                const uint32_t reciever_taxa_id = linage[j];
+                taxon_id__read_count[reciever_taxa_id] += uniq_reads_count2[i];
+                taxon_id__children[reciever_taxa_id].insert(i);
+                taxon_id__children[reciever_taxa_id].insert(ref_ids.begin(), ref_ids.end());
+            }
+        }
+    }
+    uint32_t k = 0;
+    for (const auto& kv : taxon_id__read_count) {
+        if (k < out_cap && out_taxid && out_count) {
+            out_taxid[k] = kv.first;
+            out_count[k] = kv.second;
+        }
+        ++k;
+    }
+    if (n_out) *n_out = k;
+    uint64_t m = 0;
+    for (const auto& kv : taxon_id__children)
+        for (uint32_t r : kv.second) {
+            if (m < out_pair_cap && out_pairs) out_pairs[m] = (static_cast<uint64_t>(kv.first) << 32) | r;
+            ++m;
+        }
+    if (n_out_pairs) *n_out_pairs = m;
+
+    // :733-843
+    uint32_t n = 0;
+    auto row = [&](uint32_t id, bool star, float ab, uint32_t reads) {
+        if (n < row_cap && row_taxid) {
+            row_taxid[n] = id;
+            row_star[n] = star ? 1 : 0;
+            row_abundance[n] = ab;
+            row_reads[n] = reads;
+        }
+        ++n;
+    };
+    std::unordered_map<uint32_t, float> parent_abundance;
+    std::unordered_map<uint32_t, uint32_t> parent_reads_count;
+    for (auto t_id : taxon_id__read_count) {
+        if (taxid__name[t_id.first].rank == parent_rank) {
+            parent_abundance[t_id.first] = float(t_id.second) / (matches_count) * 100;
+            parent_reads_count[t_id.first] = t_id.second;
+        }
+    }
+    uint32_t sum_reads_count = 0;
+    float sum_abundunce = 0.0;
+    std::unordered_map<uint32_t, float> sum_abundunce_by_parent;
+    std::unordered_map<uint32_t, uint32_t> sum_reads_count_by_parent;
+    for (auto t_id : taxon_id__read_count) {
+        if (taxid__name[t_id.first].rank == rank) {
+            uint32_t genome_Length = 0, children_count = 0, last_child = 0;
+            for (auto child : taxon_id__children.at(t_id.first)) {
+                genome_Length += ref_len[child];
+                last_child = child;
+                ++children_count;
+            }
+            genome_Length = genome_Length / children_count;
+            const uint32_t* linage = lin(last_child);
+            const float cov = float(t_id.second * avg_read_length) / genome_Length;
+            const float abundance = float(t_id.second) / (matches_count) * 100;
+            const uint32_t parent_tax_id = linage[parent_rank];
+            sum_abundunce_by_parent[parent_tax_id] += abundance;
+            sum_reads_count_by_parent[parent_tax_id] += t_id.second;
+            if (abundance < abundance_cut_off || cov < coverage_cut_off || !taxid__name[t_id.first].named) continue;
+            row(t_id.first, false, abundance, t_id.second);
+            sum_abundunce += abundance;
+            sum_reads_count += t_id.second;
+        }
+    }
+    for (auto ab_by_parent : sum_abundunce_by_parent) {
+        const uint32_t parent_taxid = ab_by_parent.first;
+        const float uncl_abundance = parent_abundance[parent_taxid] - sum_abundunce_by_parent[parent_taxid];
+        const uint32_t unc_read_count = parent_reads_count[parent_taxid] - sum_reads_count_by_parent[parent_taxid];
+        if (uncl_abundance > abundance_cut_off && taxid__name[parent_taxid].named) {
+            row(parent_taxid, true, uncl_abundance, unc_read_count);
+            sum_reads_count += unc_read_count;
+            sum_abundunce += uncl_abundance;
+        }
+    }
+    row(0, true, static_cast<float>(100.0 - sum_abundunce), matches_count - sum_reads_count);
+    if (n_rows) *n_rows = n;
     return 0;
 }
 

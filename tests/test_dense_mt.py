@@ -16,6 +16,14 @@ def assert_dense_equals_oracle(d, o, bins=True):
     for k in ("reads_count", "uniq_reads_count", "uniq_reads_count2", "nz_cov", "nz_uniq_cov"):
         assert np.array_equal(d[k], getattr(o, k)), k
     assert d["lca_direct"] == o.lca_direct
+    if "profile" in d:   # the scalar tail from the reference (dmt_profile): propagated counts, children sets, profile rows
+        assert d["taxon_count"] == o.taxon_count
+        assert d["taxon_children"] == o.taxon_children
+        rows = o.profile_rows()
+        assert set(d["profile"]) == set(rows)
+        for key, (ab, reads) in d["profile"].items():
+            assert reads == rows[key][1], key
+            assert ab == pytest.approx(rows[key][0], rel=2e-5, abs=1e-6), key
     if bins:
         assert d["total_bins"] == o.cov.shape[0]
         for i, k in enumerate(("cov", "uniq_cov", "uniq_cov2")):
@@ -33,7 +41,7 @@ def test_dense_mt_equals_the_oracle(case, threads):
     else:  # many hits per read, strain-level database: most reads keep several references
         w = make_workload(SynthConfig("deep", 150_000, 2_000, 12.0, present_frac=0.2, strain_level=True), seed=43)
     o = run_workload(w, use_qnames=False)
-    assert_dense_equals_oracle(dense_mt_run(w, threads=threads, want_bins=True), o)
+    assert_dense_equals_oracle(dense_mt_run(w, threads=threads, want_bins=True, want_profile=True), o)
 
 
 @pytest.mark.parametrize("name,n", [("config2", 2_000_000), ("config3", 2_000_000), ("config4", 2_000_000), ("config5", 2_500_000)])
@@ -42,7 +50,20 @@ def test_dense_mt_equals_the_oracle_on_the_full_reference_sets(name, n):
     comparator of the full-size GPU tests is itself pinned to the oracle where the big tables are."""
     w = make_workload(CONFIGS[name], seed=7, n_records=n)
     o = run_workload(w, use_qnames=False)
-    assert_dense_equals_oracle(dense_mt_run(w, threads=8, want_bins=True), o)
+    assert_dense_equals_oracle(dense_mt_run(w, threads=8, want_bins=True, want_profile=True), o)
+
+
+@pytest.mark.parametrize("mk", ["tiny", "holes", "genus"])
+def test_dense_mt_profile_tail_on_the_micro_cases(mk):
+    """dmt_profile (the propagation and the profile rows, written from src/slimm.hpp:560-610, 733-843) on the two
+    reference-observed micro-cases -- lineage holes, an accession absent from the database, taxid 0 propagating (Q5, Q6, Q13) --
+    and at another rank."""
+    from tests.cases import holes_case, tiny_case
+    w = tiny_case() if mk != "holes" else holes_case()
+    if mk == "genus":
+        w.options.rank = "genus"
+    o = run_workload(w, use_qnames=False)
+    assert_dense_equals_oracle(dense_mt_run(w, threads=2, want_bins=True, want_profile=True), o)
 
 
 def test_bin_checksum_tells_positions_apart():

@@ -773,6 +773,17 @@ def assert_equals_dense_mt(s: Slimm, d: dict, bins=None):
         assert np.array_equal(rc[k], d[k]), f"per-reference column {k} differs from the dense restatement"
     assert int(rc["valid"].sum()) == d["n_valid"]
     assert s.taxon_counts(0) == d["lca_direct"], "direct LCA counts differ from the dense restatement"
+    if "profile" in d:
+        # the scalar tail, independently (dmt_profile: written from src/slimm.hpp:560-610, 733-843 with the reference's
+        # containers, pinned to the oracle in tests/test_dense_mt.py): propagated counts, children sets, profile rows
+        from oracle.binding import parse_profile
+        assert s.taxon_counts(1) == d["taxon_count"], "propagated per-taxon counts differ from the dense restatement"
+        assert s.children_pairs(1) == d["taxon_children"], "children sets differ from the dense restatement"
+        rows = parse_profile(s.write_abundance())
+        assert set(rows) == set(d["profile"])
+        for key, (ab, reads) in d["profile"].items():
+            assert rows[key][1] == reads, key
+            assert rows[key][0] == pytest.approx(ab, rel=2e-5, abs=1e-6), key
     for i, k in enumerate(("cov", "uniq_cov", "uniq_cov2")):
         got = s.bins(i) if bins is None else bins[i]
         assert bin_checksum(got) == d["checksums"][i], f"checksum of {k} differs"
@@ -913,8 +924,9 @@ def test_full_size_config4_one_context_and_a_group_of_four():
             w0 = wc
     assert hi == n_stream
     w = Workload(w0.ref_names, w0.ref_len, w0.taxonomy, host, w0.avg_read_len, w0.options, "config4-stream")
-    d = dense_mt_run(w, want_bins=True)
-    assert d["hits"] > 0.97 * n_stream
+    d = dense_mt_run(w, want_bins=True, want_profile=True)   # (with the propagation and the profile rows: the 1 B-record case has
+    assert d["hits"] > 0.97 * n_stream                        # no oracle run to compare those with)
+    assert len(d["profile"]) > 3 and len(d["taxon_count"]) > 1000
     # (a) one context
     s = Slimm.for_workload(w, device=0)
     torch.cuda.synchronize()
@@ -928,7 +940,7 @@ def test_full_size_config4_one_context_and_a_group_of_four():
     same61 = bool(np.array_equal(k61, host.read_key))
     w61 = w if same61 else Workload(w.ref_names, w.ref_len, w.taxonomy, Records(k61, host.flag, host.ref_id, host.begin_pos),
                                     w.avg_read_len, w.options, "config4-stream-61")
-    d61 = d if same61 else dense_mt_run(w61, want_bins=True)
+    d61 = d if same61 else dense_mt_run(w61, want_bins=True, want_profile=True)
     del k61
     s.reset(); s.reset_cutoffs()
     pk = _pack_keys_device(key, flag)

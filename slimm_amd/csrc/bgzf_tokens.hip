@@ -326,19 +326,10 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
 
 }  // namespace
 
-// Two waves per workgroup: wave 0 decodes (a lane per block); wave 1 only touches the input a cache line ahead of every lane
-// of wave 0 -- a lane reads its compressed stream byte by byte, 64 lanes cross into a new 128-byte line in every other step,
-// and a step that waits for HBM (1 - 2 us) is longer than the step itself.  The decoder posts its read positions in LDS once
-// per burst; the helper loads one byte of the lines behind them and sleeps.
-__global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                        uint8_t* __restrict__ out, uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
+__global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
     __shared__ uint32_t s_lds[kLaneWords * 64u];
-    __shared__ uint32_t s_rp[64];
-    __shared__ uint32_t s_done;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (threadIdx.x < 64u) s_rp[lane] = 0;
-    if (threadIdx.x == 0) s_done = 0;
-    __syncthreads();
+    const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x * 64u + lane;
     const bool have = b < n_blocks;
     Lds L{reinterpret_cast<u32a*>(s_lds) + lane};
@@ -352,18 +343,6 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
     uint32_t* t_base = tok + d.tok;
     const uint32_t tok_room = bgzf_token_room(d.isize);
     const uint32_t csize = d.csize, isize = d.isize;
-    if (threadIdx.x >= 64u) {   // the helper wave
-        for (;;) {
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t done = *reinterpret_cast<volatile uint32_t*>(&s_done);
-            const uint32_t rp = *reinterpret_cast<volatile uint32_t*>(&s_rp[lane]);
-            if (done) break;
-            (void)*reinterpret_cast<const volatile uint8_t*>(in + min(rp + 128u, csize));
-            (void)*reinterpret_cast<const volatile uint8_t*>(in + min(rp + 256u, csize));
-            for (int k = 0; k < 6; ++k) __builtin_amdgcn_s_sleep(127);
-        }
-        return;
-    }
 
     Bits bits;
     bits.start(0);
@@ -387,7 +366,6 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
             continue;
         }
         // a burst of uniform steps
-        *reinterpret_cast<volatile uint32_t*>(&s_rp[lane]) = bits.rp;
         uint64_t ahead = 0;
         if (mode == kModeDecode) ahead = ld64u(in + bits.rp);
         for (uint32_t it = 0; it < 16u; ++it) {
@@ -510,7 +488,6 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
             p_ntok = 0;
         }
     }
-    if (lane == 0) *reinterpret_cast<volatile uint32_t*>(&s_done) = 1;
     if (have) {
         // the stream must end exactly at ISIZE bytes and inside the payload
         if (mode == kModeDone && (o != isize || (bits.at_bit() + 7u) / 8u > csize)) mode = kModeHandOver;
@@ -789,7 +766,7 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* b
     InflateInfo* info = reinterpret_cast<InflateInfo*>(s);
     s += (static_cast<size_t>(n_blocks) * sizeof(InflateInfo) + 255u) & ~static_cast<size_t>(255u);
     uint32_t* tok = reinterpret_cast<uint32_t*>(s);
-    hipLaunchKernelGGL(k_inflate_decode, dim3((n_blocks + 63u) / 64u), dim3(128), 0, st, comp, blocks, n_blocks, out, tok, info);
+    hipLaunchKernelGGL(k_inflate_decode, dim3((n_blocks + 63u) / 64u), dim3(64), 0, st, comp, blocks, n_blocks, out, tok, info);
     hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 0, st, blocks, n_blocks, out, tok, info);
     launch_bgzf_inflate_lanes(st, comp, blocks, n_blocks, out, lanes_scratch, bgzf_inflate_grid(n_blocks), status, info);
 }

@@ -135,7 +135,6 @@ static inline void __threadfence_block() {}
 static inline void __builtin_amdgcn_fence(int, const char*) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
-static inline void __builtin_amdgcn_s_sleep(int) {}
 
 // ------------------------------------------------------------------------------------------------ wave collectives
 static inline uint64_t __builtin_amdgcn_ballot_w64(bool p) {

@@ -39,31 +39,32 @@ namespace slimm {
 namespace {
 
 // ------------------------------------------------------------------------------------------------ phase 1: decode
-// LDS words of a lane (word w of lane l at [w * 64 + l]: every lane stays in its own bank whatever it indexes)
-constexpr uint32_t kLsymLo = 0;      // 72 words: low 8 bits of the 288 literal/length symbols in canonical order
-constexpr uint32_t kLsymHi = 72;     //  9 words: their bit 8
-constexpr uint32_t kDsym = 81;       //  8 words: the 30 distance symbols in canonical order (bytes)
-constexpr uint32_t kLbase = 89;      //  8 words: per code length, (symbols with shorter codes) - (first code of the length), 16 bits
-constexpr uint32_t kDbase = 97;      //  8 words: the same for the distance code
-constexpr uint32_t kTmpA = 105;      //  8 words: counts per length (construction)
-constexpr uint32_t kTmpB = 113;      //  8 words: next free place per length (construction)
-constexpr uint32_t kClSym = 121;     //  5 words: the code-length code's 19 symbols in canonical order (while a header is read)
-constexpr uint32_t kClBase = 126;    //  4 words: its bases (lengths 1 .. 7)
-constexpr uint32_t kLaneWords = 130;
+// LDS bytes of a lane, element-interleaved over the 64 lanes: byte i of a table at offset T lies at [(T + i) * 64 + lane], a
+// 16-bit element at byte [T * 64 + i * 128 + 2 lane], a word at [T * 64 + i * 256 + 4 lane] -- one shift-and-add per access
+// (a layout interleaved by whole words kept every lane in its own bank and cost three more instructions per access: the
+// kernel is bound by its vector instructions, not by the LDS).
+constexpr uint32_t kLsymLo = 0;      // 288 B: low 8 bits of the 288 literal/length symbols in canonical order
+constexpr uint32_t kLsymHi = 288;    //  36 B: their bit 8 (9 words)
+constexpr uint32_t kDsym = 324;      //  32 B: the 30 distance symbols in canonical order
+constexpr uint32_t kLbase = 356;     //  32 B: per code length, (symbols with shorter codes) - (first code of the length), 16 bits
+constexpr uint32_t kDbase = 388;     //  32 B: the same for the distance code
+constexpr uint32_t kTmpA = 420;      //  32 B: counts per length (construction)
+constexpr uint32_t kTmpB = 452;      //  32 B: next free place per length (construction)
+constexpr uint32_t kClSym = 484;     //  20 B: the code-length code's 19 symbols in canonical order (while a header is read)
+constexpr uint32_t kClBase = 504;    //  16 B: its bases (lengths 1 .. 7)
+constexpr uint32_t kLaneBytes = 520;
 
-// (the same LDS words are read and written as bytes, halves and words: types that may alias)
+// (the same LDS bytes are read and written as bytes, halves and words: types that may alias)
 typedef uint16_t __attribute__((may_alias)) u16a;
 typedef uint32_t __attribute__((may_alias)) u32a;
 typedef int16_t __attribute__((may_alias)) i16a;
 
 struct Lds {
-    u32a* w;  // the lane's word 0
-    __device__ __forceinline__ uint8_t* bytes() const { return reinterpret_cast<uint8_t*>(w); }
-    __device__ __forceinline__ uint8_t& b8(uint32_t base, uint32_t i) const { return bytes()[(base + (i >> 2)) * 256u + (i & 3u)]; }
-    __device__ __forceinline__ u16a& b16(uint32_t base, uint32_t i) const {
-        return reinterpret_cast<u16a*>(w)[(base + (i >> 1)) * 128u + (i & 1u)];
-    }
-    __device__ __forceinline__ u32a& b32(uint32_t base, uint32_t i) const { return w[(base + i) * 64u]; }
+    uint8_t* p;      // the workgroup's table memory
+    uint32_t lane;
+    __device__ __forceinline__ uint8_t& b8(uint32_t base, uint32_t i) const { return p[(base + i) * 64u + lane]; }
+    __device__ __forceinline__ u16a& b16(uint32_t base, uint32_t i) const { return reinterpret_cast<u16a*>(p)[base * 32u + i * 64u + lane]; }
+    __device__ __forceinline__ u32a& b32(uint32_t base, uint32_t i) const { return reinterpret_cast<u32a*>(p)[base * 16u + i * 64u + lane]; }
 };
 
 __device__ __forceinline__ uint64_t ld64u(const uint8_t* p) {
@@ -73,52 +74,54 @@ __device__ __forceinline__ uint64_t ld64u(const uint8_t* p) {
 }
 __device__ __forceinline__ void st32u(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-// The input of a lane: 128 bits of the stream, low bits first; `rp` = the stream byte that follows them.
+// The input of a lane: up to 64 bits of the stream, low bits first; `rp` = the stream byte the next refill takes from.
+// refill(the 8 bytes at rp): afterwards 56 .. 63 bits are there (a step takes at most 48).
 struct Bits {
-    uint64_t lo, hi;
+    uint64_t lo;
     uint32_t avail, rp;
     __device__ __forceinline__ void start(uint32_t at) {
-        lo = hi = 0;
+        lo = 0;
         avail = 0;
         rp = at;
     }
-    // 8 more bytes (read at rp) when there is room for all of them
-    __device__ __forceinline__ void append(uint64_t v) {
-        if (avail <= 64u) {
-            const uint32_t a = avail;
-            lo |= a < 64u ? v << a : 0ull;
-            hi = a == 64u ? v : (a ? v >> (64u - a) : 0ull);
-            avail = a + 64u;
-            rp += 8u;
-        }
+    __device__ __forceinline__ void refill(uint64_t next8) {
+        lo |= next8 << avail;   // (bits beyond the whole bytes counted below are the stream's own: the next refill repeats them)
+        const uint32_t adv = (63u - avail) >> 3;
+        rp += adv;
+        avail += adv << 3;
     }
-    __device__ __forceinline__ void drop(uint32_t c) {  // c < 64
-        if (c) {
-            lo = (lo >> c) | (hi << (64u - c));
-            hi >>= c;
-            avail -= c;
-        }
+    __device__ __forceinline__ void drop(uint32_t c) {  // c <= avail
+        lo >>= c;
+        avail -= c;
     }
     // stream position, in bits, of the next unread bit
     __device__ __forceinline__ uint64_t at_bit() const { return static_cast<uint64_t>(rp) * 8u - avail; }
 };
 
 // 15 left-justified limits of a canonical code: a 15-bit pattern x (first stream bit on top) has a code of length
-// 1 + #{l : x >= lim[l]}; 16 = no code.  Held as lim - 1, so that the sign of (lim - 1) - x says x >= lim: a subtraction and
-// one v_alignbit (acc = acc << 1 | sign) per length, a population count at the end -- no compare, no carry chain, no
-// wait states between them.
+// 1 + #{l : x >= lim[l]}; 16 = no code.  Two limits to a register, each as lim + 0x7fff: the 32-bit difference with x in both
+// halves never borrows across them, and bit 15 / 31 of it says x < lim.  A subtraction, a shift and an and-or per PAIR, a
+// population count at the end -- no compare, no carry chain.  (The sixteenth slot is a limit nothing reaches.)
 struct Limits {
-    uint32_t v[15];   // limit - 1 (0xffffffff for a limit of 0)
-    __device__ __forceinline__ void set(uint32_t l, uint32_t limit) { v[l] = limit - 1u; }
+    uint32_t v[8];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = 0xffffffffu;
+    }
+    __device__ __forceinline__ void set(uint32_t l, uint32_t limit) {   // l = 0 .. 14, a constant where it matters
+        const uint32_t sh = (l & 1u) * 16u;
+        v[l >> 1] = (v[l >> 1] & ~(0xffffu << sh)) | ((limit + 0x7fffu) << sh);
+    }
     __device__ __forceinline__ uint32_t length_of(uint32_t x) const {
+        const uint32_t xx = x | (x << 16);
         uint32_t acc = 0;
 #pragma unroll
-        for (int l = 0; l < 15; ++l) acc = __builtin_amdgcn_alignbit(acc, v[l] - x, 31);
-        return 1u + static_cast<uint32_t>(__builtin_popcount(acc));
+        for (int k = 0; k < 8; ++k) acc = (acc >> 1) | ((v[k] - xx) & 0x80008000u);
+        return 17u - static_cast<uint32_t>(__builtin_popcount(acc));
     }
 };
 
-__device__ __forceinline__ uint32_t top15(uint64_t w) { return __builtin_bitreverse32(static_cast<uint32_t>(w)) >> 17; }
+__device__ __forceinline__ uint32_t top15(uint32_t w) { return __builtin_bitreverse32(w) >> 17; }
 
 // From the counts per code length (LDS, 16 bits each, tmp A): the limits, the base per length (-> `base_at`), the first
 // free place per length (-> tmp B).  Returns the code's slack: 0 complete, > 0 incomplete, < 0 over-subscribed.
@@ -154,14 +157,14 @@ struct HeaderBits {
     Bits& b;
     const uint8_t* in;
     __device__ __forceinline__ uint32_t take(uint32_t n) {  // n <= 16
-        if (b.avail <= 64u) b.append(ld64u(in + b.rp));
+        if (b.avail < 32u) b.refill(ld64u(in + b.rp));
         const uint32_t v = static_cast<uint32_t>(b.lo) & ((1u << n) - 1u);
         b.drop(n);
         return v;
     }
     __device__ __forceinline__ uint32_t peek15() {
-        if (b.avail <= 64u) b.append(ld64u(in + b.rp));
-        return top15(b.lo);
+        if (b.avail < 32u) b.refill(ld64u(in + b.rp));
+        return top15(static_cast<uint32_t>(b.lo));
     }
 };
 
@@ -209,6 +212,7 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
     if (type != 1u && type != 2u) return kModeHandOver;  // stored blocks (and type 3) are the other kernel's
     uint32_t nlen = 288, ndist = 30;
     Limits cl;
+    cl.clear();
     for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = 0;
     if (type == 2u) {
         nlen = hb.take(5) + 257u;
@@ -328,11 +332,11 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
 
 __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
                                                        uint8_t* __restrict__ out, uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
-    __shared__ uint32_t s_lds[kLaneWords * 64u];
+    __shared__ uint32_t s_lds[kLaneBytes * 16u];
     const uint32_t lane = threadIdx.x;
     const uint32_t b = blockIdx.x * 64u + lane;
     const bool have = b < n_blocks;
-    Lds L{reinterpret_cast<u32a*>(s_lds) + lane};
+    Lds L{reinterpret_cast<uint8_t*>(s_lds), lane};
     BgzfBlock d;
     d.src = d.dst = 0;
     d.csize = d.isize = 0;
@@ -347,8 +351,8 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
     Bits bits;
     bits.start(0);
     Limits LL, DL;
-#pragma unroll
-    for (int l = 0; l < 15; ++l) LL.v[l] = DL.v[l] = 0x7fffu;
+    LL.clear();
+    DL.clear();
     uint32_t mode = have ? kModeHeader : kModeDone;
     uint32_t last = 0, o = 0, acc_n = 0, litrun = 0, ntok = 0;
     uint64_t acc = 0;   // literals waiting to be stored: up to 3 from the steps before + 2 of this one
@@ -367,11 +371,11 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
         }
         // a burst of uniform steps
         uint64_t ahead = 0;
-        if (mode == kModeDecode) ahead = ld64u(in + bits.rp);
+        if (mode == kModeDecode) ahead = ld64u(in + bits.rp);   // (the first step's refill)
         for (uint32_t it = 0; it < 16u; ++it) {
             const bool run = mode == kModeDecode;
             // the input asked for a step ago; the stores of the step before behind it
-            if (run) bits.append(ahead);
+            if (run) bits.refill(ahead);
             if (run) ahead = ld64u(in + bits.rp);
             if (p_lit_n) {
                 if (p_lit_at + 4u <= isize) {
@@ -390,25 +394,25 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
             // ---- one literal/length symbol, then ONE more symbol of whichever code comes next: behind a literal the
             // literal/length code again (a second literal is taken along; anything else waits for the next step), behind a
             // length the distance code.  The second chain's limits, base table and symbol table are selected per lane.
-            uint64_t w = bits.lo;
-            const uint32_t x = top15(w);
+            const uint32_t w1 = static_cast<uint32_t>(bits.lo);
+            const uint32_t x = top15(w1);
             const uint32_t len = LL.length_of(x);
             const uint32_t idx = min(symbol_at(L, kLbase, x, len), 287u);
             const uint32_t sym = L.b8(kLsymLo, idx) | (((L.b32(kLsymHi, idx >> 5) >> (idx & 31u)) & 1u) << 8);
             bool bad = len > 15u;
             uint32_t c = len;
-            w >>= len;
             const bool is_lit = sym < 256u, is_eob = sym == 256u, is_len = sym > 256u;
             const uint32_t ls = is_len ? sym - 257u : 0u;
             bad = bad | (ls > 28u);
             const uint32_t le = (ls >= 8u && ls < 28u) ? (ls >> 2) - 1u : 0u;
             const uint32_t lb = ls < 8u ? ls + 3u : (ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << le));
-            const uint32_t mlen = lb + (static_cast<uint32_t>(w) & ((1u << le) - 1u));
-            w >>= le;   // (le = 0 behind a literal)
+            const uint32_t mlen = lb + ((w1 >> (len > 15u ? 15u : len)) & ((1u << le) - 1u));
+            // (32 bits behind the first symbol and its extra bits: 15 for the second code + 13 extra bits of a distance)
+            const uint32_t w2 = static_cast<uint32_t>(bits.lo >> ((len > 15u ? 15u : len) + le));   // (le = 0 behind a literal)
             Limits SL;
 #pragma unroll
-            for (int l = 0; l < 15; ++l) SL.v[l] = is_lit ? LL.v[l] : DL.v[l];
-            const uint32_t y = top15(w);
+            for (int k = 0; k < 8; ++k) SL.v[k] = is_lit ? LL.v[k] : DL.v[k];
+            const uint32_t y = top15(w2);
             const uint32_t l2 = SL.length_of(y);
             const uint32_t i2 = min(symbol_at(L, is_lit ? kLbase : kDbase, y, l2), is_lit ? 287u : 31u);
             const uint32_t s2lo = L.b8(is_lit ? kLsymLo : kDsym, i2);
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
             const uint32_t ds = s2lo;
             const uint32_t de = ds >= 4u ? (ds >> 1) - 1u : 0u;
             const uint32_t dbv = ds < 4u ? ds + 1u : 1u + ((2u + (ds & 1u)) << de);
-            const uint32_t dist = dbv + (static_cast<uint32_t>(w >> (l2 > 15u ? 15u : l2)) & ((1u << de) - 1u));
+            const uint32_t dist = dbv + ((w2 >> (l2 > 15u ? 15u : l2)) & ((1u << de) - 1u));
             if (is_len) {
                 bad = bad | (l2 > 15u) | (ds > 29u);
                 c += le + (l2 > 15u ? 0u : l2) + de;

@@ -213,7 +213,7 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
     uint32_t nlen = 288, ndist = 30;
     Limits cl;
     cl.clear();
-    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = 0;
+    for (uint32_t l = 0; l < 16u; ++l) L.b16(kTmpA, l) = 0;   // (a table is only ever used through ONE element size: the lanes' elements interleave by it)
     if (type == 2u) {
         nlen = hb.take(5) + 257u;
         ndist = hb.take(5) + 1u;
@@ -238,8 +238,8 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
     }
     // pass 1: how many codes of each length -- literal/length code in tmp A, distance code in tmp B
     const Bits saved = bits;
-    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = 0;
-    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpB, l) = 0;
+    for (uint32_t l = 0; l < 16u; ++l) L.b16(kTmpA, l) = 0;
+    for (uint32_t l = 0; l < 16u; ++l) L.b16(kTmpB, l) = 0;
     if (type == 1u) {
         L.b16(kTmpA, 7) = 24;
         L.b16(kTmpA, 8) = 152;
@@ -262,15 +262,15 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
     }
     // the distance counts out of the way, the literal/length code from tmp A (its places -> tmp B), then the distance code
     // from its counts (back in tmp A; its places take their place)
-    uint32_t dcnt[8];
+    uint32_t dcnt[16];
 #pragma unroll
-    for (uint32_t l = 0; l < 8u; ++l) dcnt[l] = L.b32(kTmpB, l);
+    for (uint32_t l = 0; l < 16u; ++l) dcnt[l] = L.b16(kTmpB, l);
     uint32_t n_l = 0;
     for (uint32_t l = 1; l <= 15u; ++l) n_l += L.b16(kTmpA, l);
     const int lslack = code_from_counts<15>(L, kLbase, LL);
     if (lslack < 0 || (lslack > 0 && n_l != 1u) || n_l == 0u) return kModeHandOver;
 #pragma unroll
-    for (uint32_t l = 0; l < 8u; ++l) L.b32(kTmpA, l) = dcnt[l];
+    for (uint32_t l = 0; l < 16u; ++l) L.b16(kTmpA, l) = static_cast<uint16_t>(dcnt[l]);
     {
         uint32_t code = 0, offs = 0, n_d = 0;
         int left = 1;

@@ -203,3 +203,50 @@ def test_a_skip_larger_than_the_window_slack(tmp_path):
         s.push_bgzf_blocks(blocks, skip=len(want) + skip + 70_000)
     assert "skip" in str(e.value)
     s.close()
+
+
+def _inflate_with(blob: bytes, how: int):
+    L = capi.lib()
+    src = np.frombuffer(blob, dtype=np.uint8)
+    out = np.zeros(1 << 26, dtype=np.uint8)
+    n, ms, err, lanes = C.c_uint64(), C.c_double(), C.create_string_buffer(256), C.c_uint32()
+    rc = L.slimm_bgzf_inflate_with(0, src.ctypes.data_as(C.c_void_p), C.c_uint64(len(blob)), out.ctypes.data_as(C.c_void_p), C.c_uint64(out.size),
+                                   C.byref(n), C.byref(ms), err, C.c_uint64(256), how, C.byref(lanes))
+    return rc, bytes(out[:n.value]) if rc == 0 else b"", lanes.value
+
+
+def test_the_two_phase_kernels_take_every_huffman_block_themselves():
+    """slimm_bgzf_inflate_with: the two-phase kernels (bgzf_tokens.hip: Huffman decode into literals + match tokens, then
+    the matches filled by pointer jumping in LDS) must inflate every block made of fixed / dynamic Huffman blocks THEMSELVES --
+    their hand-over to the lane-per-block kernel is for stored blocks and irregular streams, and would hide a fault of theirs
+    behind a correct result.  Both paths give zlib's bytes; the count of handed-over blocks is what is asserted here."""
+    rng = np.random.default_rng(6)
+    records = b"".join(struct.pack("<iiiBBHHHIiii", 230, k % 500, 977 * k, 44, 255, 4680, 1, 0, 100, -1, -1, 0) + b"A00123:45:HXYZABCDX:1:%04d:%07d:%08d\0" % (k % 9000, k * 13, k * 7919)
+                       + bytes(rng.choice(np.frombuffer(bytes([0x11, 0x12, 0x14, 0x18, 0x21, 0x22, 0x24, 0x28, 0x41, 0x42, 0x44, 0x48, 0x81, 0x82, 0x84, 0x88]), dtype=np.uint8), 50))
+                       + bytes(rng.choice(np.frombuffer(bytes([2, 6, 15, 22, 27, 33, 37, 40]), dtype=np.uint8), 100)) for k in range(290))
+    huffman = [b"a", b"abc" * 7, bytes(1000), bytes(65280), records[:65280], b"ACGT" * 16320, bytes(rng.integers(0, 4, 65280, dtype=np.uint8)),
+               (b"the quick brown fox jumps over the lazy dog " * 2000)[:65000], (b"x" * 300 + bytes(rng.integers(0, 256, 40, dtype=np.uint8))) * 150,
+               bytes(rng.integers(0, 8, 30000, dtype=np.uint8)) + bytes(35000)]
+    blocks, want = [], []
+    for data in huffman:
+        for level, strat in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED),
+                             (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (6, zlib.Z_FILTERED)):
+            blocks.append(bgzf_block(data, level, strat))
+            want.append(data)
+    # several DEFLATE blocks in one BGZF block (zlib starts a new one every 16 K symbols; a full flush in the middle)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = c.compress(records[:30000]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(records[30000:60000]) + c.flush()
+    stored_inside = b"\x00\x00\xff\xff" in raw     # (a full flush ends in an empty STORED block: that one block is handed over)
+    assert stored_inside
+    blocks.append(bgzf_block(records[:60000], raw=raw))
+    want.append(records[:60000])
+    blob = b"".join(blocks) * 3       # (192 blocks and more: three waves of lanes)
+    rc, got, lanes = _inflate_with(blob, 0)
+    assert rc == 0 and got == b"".join(want) * 3
+    assert lanes == (3 if stored_inside else 0)
+    rc, got1, lanes1 = _inflate_with(blob, 1)
+    assert rc == 0 and got1 == got and lanes1 == 3 * len(blocks)
+    # stored blocks go the other way, and mix with the rest
+    mixed = bgzf_block(records[:60000], 0) + bgzf_block(records[:60000], 6) + bgzf_block(bytes(rng.integers(0, 256, 60000, dtype=np.uint8)), 6)
+    rc, got, lanes = _inflate_with(mixed, 0)
+    assert rc == 0 and lanes == 2 and got[:120000] == records[:60000] * 2

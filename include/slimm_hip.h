@@ -218,6 +218,18 @@ int slimm_push_bam_bytes(slimm_ctx* ctx, const uint8_t* bytes, uint64_t n_bytes,
  * thousands of blocks); buffer lifetime, `last`, *n_records and the errors are those of slimm_push_bam_bytes, plus
  * SLIMM_E_INVALID for anything that is not a BGZF block or does not inflate to its ISIZE. */
 int slimm_push_bgzf_blocks(slimm_ctx* ctx, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records);
+/* SAM TEXT decoded on the device (slimm_amd/csrc/sam_decode.hip): the reference takes .sam and .bam alike
+ * (src/file_helper.hpp:73-75; the record loop src/slimm.hpp:194-208 reads QNAME, FLAG, RNAME -> reference index, POS).
+ * `text` = the file's alignment lines, everything behind the header, in windows cut ANYWHERE (the incomplete last line of a
+ * window is carried in front of the next one; a last line without its newline is a line); same buffer-lifetime and window
+ * rules as slimm_push_bam_bytes, the two do not mix within a file.  RNAME is looked up in the header's reference names, which
+ * slimm_set_reference_names(ctx, names[n_refs]) hands over once per context (index = reference id; "*" and names the header
+ * does not have give no reference, like the host reader); QNAME is compared with the line before (grouped input) or hashed
+ * (any order) in its canonical form (quirk Q18).  A line with fewer than ten fields is an error like the host reader's; a
+ * header line or an empty line AMONG the alignment lines (which the host reader skips) is refused with "decode this file on
+ * the host". */
+int slimm_set_reference_names(slimm_ctx* ctx, const char* const* names);
+int slimm_push_sam_bytes(slimm_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int last, uint64_t* n_records);
 /* Page-locks a buffer of the caller (hipHostRegister) until the context is destroyed: copies out of it then run at the
  * speed of the bus instead of the runtime's own staging. */
 int slimm_pin_host_buffer(slimm_ctx* ctx, const void* buffer, uint64_t n_bytes);

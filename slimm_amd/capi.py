@@ -151,6 +151,8 @@ SYMBOLS = [
                                      C.c_uint32, C.POINTER(C.c_uint32), C.c_int]),
     ("slimm_push_bam_bytes", C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     ("slimm_push_bgzf_blocks", C.c_int, [_P, _P, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint64)]),
+    ("slimm_push_sam_bytes", C.c_int, [_P, _P, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("slimm_set_reference_names", C.c_int, [_P, C.POINTER(C.c_char_p)]),
     ("slimm_bgzf_inflate", C.c_int, [C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]),
     ("slimm_bgzf_inflate_with", C.c_int, [C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_char_p,
                                           C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void k_bam_verify(const uint8_t* __restrict__
 
 // one workgroup: records in front of every piece (pieces[c].base), the window's result
 __global__ __launch_bounds__(1024) void k_bam_scan(BamPiece* __restrict__ pieces, uint32_t n_pieces, uint64_t end,
-                                                   BamWindowResult* __restrict__ out) {
+                                                   BamWindowResult* __restrict__ out, uint32_t sam_lo) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_bam_scan(BamPiece* __restrict__ pieces
     for (uint32_t c0 = 0; c0 < n_pieces; c0 += 1024u) {
         const uint32_t c = c0 + tid;
         const uint32_t v = c < n_pieces ? pieces[c].count : 0u;
-        if (c < n_pieces && (pieces[c].flags & kBamPieceBad)) s_bad = 1;
+        if (c < n_pieces && (pieces[c].flags & (kBamPieceBad | kSamPieceSkip))) atomicOr(&s_bad, pieces[c].flags & (kBamPieceBad | kSamPieceSkip));
         uint32_t inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -235,7 +235,10 @@ __global__ __launch_bounds__(1024) void k_bam_scan(BamPiece* __restrict__ pieces
                 break;
             }
         out->n_records = carry;
-        out->stop = n_pieces ? pieces[n_pieces - 1].stop : static_cast<uint32_t>(end);
+        if (sam_lo != 0xffffffffu)   // (SAM text: where the last complete line ends)
+            out->stop = lastc != 0xffffffffu ? pieces[lastc].stop : sam_lo;
+        else
+            out->stop = n_pieces ? pieces[n_pieces - 1].stop : static_cast<uint32_t>(end);
         out->bad = s_bad;
         out->last_piece = lastc;
     }
@@ -378,7 +381,11 @@ void launch_bam_find(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t
         hipLaunchKernelGGL(k_bam_pieces, dim3((np + 63u) / 64u), dim3(64), 0, st, bytes, lo, end, np, n_refs, pieces, offs);
         hipLaunchKernelGGL(k_bam_verify, dim3(1), dim3(1024), 0, st, bytes, lo, end, np, pieces, offs);
     }
-    hipLaunchKernelGGL(k_bam_scan, dim3(1), dim3(1024), 0, st, pieces, np, end, result);
+    hipLaunchKernelGGL(k_bam_scan, dim3(1), dim3(1024), 0, st, pieces, np, end, result, 0xffffffffu);
+}
+
+void launch_bam_scan(hipStream_t st, BamPiece* pieces, uint32_t n_pieces, uint64_t end, BamWindowResult* result, uint32_t sam_lo) {
+    hipLaunchKernelGGL(k_bam_scan, dim3(1), dim3(1024), 0, st, pieces, n_pieces, end, result, sam_lo);
 }
 
 void launch_bam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t end, const BamPiece* pieces, const uint32_t* offs,

@@ -186,6 +186,13 @@ struct slimm_ctx {
         uint64_t acc_src = 0, acc_dst = 0;
         uint32_t acc_skip = 0, acc_tok = 0;   // (acc_tok: words of token room of the gathered blocks)
         std::vector<void*> outgrown;   // device buffers replaced by larger ones while kernels were in flight: freed at the file's end
+        // SAM text (slimm_push_sam_bytes, sam_decode.hip): this file's windows are text; the header's reference names as a
+        // hash table on the device (slimm_set_reference_names); the last byte pushed (a last line without its newline gets one)
+        bool sam = false;
+        DevBuf<SamRefEntry> sam_table;
+        DevBuf<uint8_t> sam_names;
+        uint32_t sam_mask = 0;
+        uint8_t sam_last_byte = '\n';
         std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
@@ -1058,7 +1065,7 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     const bool marked = c->order == SLIMM_ORDER_GROUPED;
     const uint32_t b = static_cast<uint32_t>(j % slimm_ctx::kBamRing), nb = static_cast<uint32_t>((j + 1u) % slimm_ctx::kBamRing);
     const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
-    const uint32_t np = bam_pieces(end - lo);
+    const uint32_t np = B.sam ? sam_pieces(end - lo) : bam_pieces(end - lo);
     // (with room to spare and without a hipFree: windows differ by a few pieces, and a hipFree waits for the inflate kernels
     // of the windows behind this one)
     if (B.pieces.cap < static_cast<size_t>(np) + 1) HIP_TRY(c, B.pieces.ensure_later(static_cast<size_t>(np) + (np >> 2) + 64, B.outgrown));
@@ -1068,16 +1075,24 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     const bool inflated_here = n_bytes && B.inflated[b];
     if (inflated_here)
         HIP_TRY(c, hipMemcpyAsync(B.h_inflate_status.p, B.inflate_status.p + 4u * b, 16, hipMemcpyDeviceToHost, st));
-    launch_bam_find(st, B.bytes[b].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
+    if (B.sam)
+        launch_sam_find(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.result.p);
+    else
+        launch_bam_find(st, B.bytes[b].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
     HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device and counted
     if (inflated_here && B.h_inflate_status.p[0])
         return fail(c, SLIMM_E_INVALID, "corrupt BGZF block (device inflate: error %u in block %u of the window)", B.h_inflate_status.p[0],
                     B.h_inflate_status.p[1]);
     const BamWindowResult res = *B.result.p;
+    if (res.bad && B.sam)
+        return fail(c, SLIMM_E_INVALID, (res.bad & kBamPieceBad) ? "SAM line with fewer than 10 fields"
+                                                                : "a header line or an empty line among the alignment lines: decode this file on the host");
     if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
     const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
     const uint64_t tail = end - stop;
-    if (tail > kBamSlack) return fail(c, SLIMM_E_INVALID, "a BAM record longer than 16 MiB: decode this file on the host");
+    if (tail > kBamSlack)
+        return fail(c, SLIMM_E_INVALID, B.sam ? "a SAM line longer than 16 MiB: decode this file on the host"
+                                              : "a BAM record longer than 16 MiB: decode this file on the host");
     if (is_last && tail) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
     if (c->n_pushed + n_rec >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
     int rc = slimm_reserve(c, c->n_pushed + n_rec);
@@ -1093,8 +1108,12 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
             HIP_TRY(c, c->in_check.ensure_later(std::max<uint64_t>(want, c->in_ref.cap), B.outgrown));
         }
     }
-    launch_bam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
-                      c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p);
+    if (B.sam)
+        launch_sam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
+                          c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p, B.sam_table.p, B.sam_mask, B.sam_names.p);
+    else
+        launch_bam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
+                          c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p);
     if (tail) {  // the incomplete record goes in front of the next window (whose own bytes may be on their way already)
         if (B.bytes[nb].cap < kBamSlack + 64) HIP_TRY(c, B.bytes[nb].ensure(kBamSlack + 64));
         HIP_TRY(c, hipMemcpyAsync(B.bytes[nb].p + kBamSlack - tail, B.bytes[b].p + stop, tail, hipMemcpyDeviceToDevice, st));
@@ -1119,13 +1138,60 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
 }  // namespace
 
 namespace {
-int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, bool compressed, uint32_t skip, int last, uint64_t* n_records);
+enum { kFormatBam = 0, kFormatBgzf = 1, kFormatSam = 2 };
+int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int format, uint32_t skip, int last, uint64_t* n_records);
 }
 int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records) {
-    return bam_push_window(c, bytes, n_bytes, false, 0u, last, n_records);
+    return bam_push_window(c, bytes, n_bytes, kFormatBam, 0u, last, n_records);
 }
 int slimm_push_bgzf_blocks(slimm_ctx* c, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records) {
-    return bam_push_window(c, blocks, n_bytes, true, skip, last, n_records);
+    return bam_push_window(c, blocks, n_bytes, kFormatBgzf, skip, last, n_records);
+}
+int slimm_push_sam_bytes(slimm_ctx* c, const uint8_t* text, uint64_t n_bytes, int last, uint64_t* n_records) {
+    return bam_push_window(c, text, n_bytes, kFormatSam, 0u, last, n_records);
+}
+// The header's reference names (@SQ SN, index = the reference id) for slimm_push_sam_bytes: a hash table on the device.
+int slimm_set_reference_names(slimm_ctx* c, const char* const* names) {
+    if (!c || !names) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    (void)hipSetDevice(c->device);
+    slimm_ctx::BamDecode& B = c->bam;
+    uint32_t cap = 16;
+    while (cap < 2u * c->R + 2u) cap <<= 1;
+    std::vector<SamRefEntry> tab(cap);
+    for (auto& e : tab) {
+        e.hash = 0;
+        e.ref = -1;
+        e.name_off = e.name_len = e.pad = 0;
+    }
+    std::vector<uint8_t> blob;
+    for (uint32_t r = 0; r < c->R; ++r) {
+        const char* nm = names[r] ? names[r] : "";
+        const size_t n = strlen(nm);
+        const uint64_t h = sam_name_hash(nm, n);
+        bool dup = false;
+        uint32_t slot = static_cast<uint32_t>(h) & (cap - 1u);
+        for (;; slot = (slot + 1u) & (cap - 1u)) {
+            if (tab[slot].ref < 0) break;
+            if (tab[slot].hash == h && tab[slot].name_len == n && memcmp(blob.data() + tab[slot].name_off, nm, n) == 0) {
+                dup = true;   // (two header lines with one name: the first one's index, like the host reader's map)
+                break;
+            }
+        }
+        if (dup) continue;
+        tab[slot].hash = h;
+        tab[slot].ref = static_cast<int32_t>(r);
+        tab[slot].name_off = static_cast<uint32_t>(blob.size());
+        tab[slot].name_len = static_cast<uint32_t>(n);
+        blob.insert(blob.end(), nm, nm + n);
+    }
+    blob.resize(blob.size() + 16, 0);
+    HIP_TRY(c, B.sam_table.ensure(cap));
+    HIP_TRY(c, B.sam_names.ensure(blob.size()));
+    HIP_TRY(c, hipMemcpy(B.sam_table.p, tab.data(), cap * sizeof(SamRefEntry), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(B.sam_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    B.sam_mask = cap - 1u;
+    return SLIMM_OK;
 }
 namespace {
 // SLIMM_PUSH_TRACE=1: what the window pipeline does and when (stderr; milliseconds since the first line)
@@ -1216,9 +1282,13 @@ int bam_launch_gathered(slimm_ctx* c) {
 // is launched -- inflate, then the record kernels -- once it holds kBamGatherGoal inflated bytes (or the file ends, or a
 // push of the other kind comes): the inflate's first phase is a lane per block and wants tens of thousands of them, whatever
 // size the caller's buffers have.
-int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool compressed, uint32_t skip, int last, uint64_t* n_records) {
+int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int format, uint32_t skip, int last, uint64_t* n_records) {
     if (!c) return SLIMM_E_INVALID;
     if (n_records) *n_records = 0;
+    bool compressed = format == kFormatBgzf;
+    const bool sam = format == kFormatSam;
+    if (sam && !c->bam.sam_mask) return fail(c, SLIMM_E_INVALID, "slimm_set_reference_names first: SAM text names its references");
+    if (c->bam.active && c->bam.sam != sam) return fail(c, SLIMM_E_INVALID, "SAM text and BAM bytes do not mix within a file");
     uint64_t n_bytes = src_bytes;  // the push's record bytes
     std::vector<BgzfBlock> dh;
     uint64_t inflated = 0;
@@ -1267,6 +1337,8 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
         B.carry_bytes = 0;
         B.pushes = 0;
         B.acc_open = false;
+        B.sam = sam;
+        B.sam_last_byte = '\n';
         c->marked = marked;
         c->has_check = !marked;
         c->packed = false;
@@ -1342,14 +1414,22 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, bool
             const int rc = bam_launch_gathered(c);
             if (rc != SLIMM_OK) return rc;
         }
-    } else if (n_bytes) {  // inflated bytes: a window of their own, behind what was gathered
+    } else if (n_bytes || (sam && last && B.sam_last_byte != '\n')) {  // inflated bytes / text: a window of their own, behind what was gathered
         int rc = bam_launch_gathered(c);
         if (rc != SLIMM_OK) return rc;
-        rc = bam_window_buffer(c, n_bytes);
+        // (SAM text whose last line has no newline gets one: a line ends where its newline is)
+        if (sam && n_bytes) B.sam_last_byte = bytes[n_bytes - 1];
+        const bool add_newline = sam && last && B.sam_last_byte != '\n';
+        rc = bam_window_buffer(c, n_bytes + (add_newline ? 1u : 0u));
         if (rc != SLIMM_OK) return rc;
         const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
         B.inflated[b] = false;
-        HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        if (n_bytes) HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        if (add_newline) {
+            HIP_TRY(c, hipMemsetAsync(B.bytes[b].p + kBamSlack + n_bytes, '\n', 1, c->copy_stream));
+            n_bytes += 1;
+            B.sam_last_byte = '\n';
+        }
         HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
         HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
         ++B.pushes;

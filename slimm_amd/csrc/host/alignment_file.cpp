@@ -176,6 +176,8 @@ bool AlignmentFile::open(const std::string& path) {
     sam_index_.clear();
     buf_.clear();
     pos_ = 0;
+    sam_buf_off_ = sam_body_off_ = sam_line_off_ = sam_text_pos_ = sam_size_ = 0;
+    sam_text_started_ = false;
     eof_ = false;
     have_pending_ = false;
     have_last_ = false;
@@ -473,8 +475,10 @@ bool AlignmentFile::read_bam_header() {
 // ---- SAM text --------------------------------------------------------------------------------------------------
 bool AlignmentFile::next_sam_line(std::string& line) {
     line.clear();
+    bool started = false;
     while (true) {
         if (pos_ >= buf_.size()) {
+            sam_buf_off_ += buf_.size();
             buf_.resize(1 << 20);
             size_t got = fread(buf_.data(), 1, buf_.size(), fp_);
             buf_.resize(got);
@@ -485,6 +489,10 @@ bool AlignmentFile::next_sam_line(std::string& line) {
             }
         }
         const uint8_t* b = buf_.data() + pos_;
+        if (!started) {
+            sam_line_off_ = sam_buf_off_ + pos_;
+            started = true;
+        }
         const uint8_t* e = static_cast<const uint8_t*>(memchr(b, '\n', buf_.size() - pos_));
         if (e) {
             line.append(reinterpret_cast<const char*>(b), e - b);
@@ -499,9 +507,14 @@ bool AlignmentFile::next_sam_line(std::string& line) {
 
 bool AlignmentFile::read_sam_header() {
     std::string line;
-    while (next_sam_line(line)) {
+    for (;;) {
+        if (!next_sam_line(line)) {
+            sam_body_off_ = sam_buf_off_ + pos_;   // (no alignment line at all)
+            break;
+        }
         if (line.empty()) continue;
         if (line[0] != '@') {
+            sam_body_off_ = sam_line_off_;   // where the alignment lines start in the file (read_text)
             pending_line_ = line;
             have_pending_ = true;
             break;
@@ -851,6 +864,49 @@ long AlignmentFile::read_blocks(uint8_t* dst, size_t cap, size_t max_inflated, s
     if (map_pos_ == map_size_) eof_ = true;
     *inflated = inf;
     return static_cast<long>(out);
+}
+
+long AlignmentFile::read_text(uint8_t* dst, size_t cap) {
+    if (bam_ || !fp_ || !dst || cap < (1u << 16)) {
+        err_ = "read_text: a SAM file and a buffer of at least 64 KiB";
+        return -1;
+    }
+    if (!sam_text_started_) {
+        struct stat sb;
+        if (fstat(fileno(fp_), &sb) != 0 || !S_ISREG(sb.st_mode)) {
+            err_ = "read_text: a regular file";
+            return -1;
+        }
+        sam_size_ = static_cast<size_t>(sb.st_size);
+        sam_text_pos_ = std::min(sam_body_off_, sam_size_);
+        sam_text_started_ = true;
+    }
+    if (sam_text_pos_ >= sam_size_) return 0;
+    StageClock clk(ms_read_);
+    const size_t want = std::min(cap, sam_size_ - sam_text_pos_);
+    const int fd = fileno(fp_);
+    const unsigned nt = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(inflaters_->size(), 12u), want >> 22)));
+    const size_t per = (want + nt - 1) / nt;
+    std::atomic<bool> ok{true};
+    inflaters_->run(nt, [&](unsigned t) {
+        size_t lo = std::min(want, t * per);
+        const size_t hi = std::min(want, lo + per);
+        while (lo < hi) {
+            const ssize_t k = pread(fd, dst + lo, hi - lo, static_cast<off_t>(sam_text_pos_ + lo));
+            if (k <= 0) {
+                ok = false;
+                return;
+            }
+            lo += static_cast<size_t>(k);
+        }
+    });
+    if (!ok) {
+        err_ = "read error";
+        return -1;
+    }
+    sam_text_pos_ += want;
+    ++n_windows_;
+    return static_cast<long>(want);
 }
 
 long AlignmentFile::read_raw(uint8_t* dst, size_t cap) {

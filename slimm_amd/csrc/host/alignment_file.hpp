@@ -87,6 +87,12 @@ public:
     // end of the file, -1 + error().  Calls of the two kinds may alternate.
     long read_blocks(uint8_t* dst, size_t cap, size_t max_inflated, size_t* inflated);
     bool can_read_blocks() const { return raw_stage_ == 2 && map_ != nullptr && !eof_; }
+    // SAM only: the file's text behind the header -- the alignment lines -- window by window straight into the caller's
+    // buffer, cut anywhere (for slimm_push_sam_bytes: the lines are found and decoded on the device); read by pread on
+    // several threads.  Returns the bytes written, 0 at the end of the file, -1 + error().  Not to be mixed with
+    // read_batch / read_into afterwards.
+    long read_text(uint8_t* dst, size_t cap);
+    bool can_read_text() const { return !bam_ && fp_ != nullptr; }
     // after a read_raw that returned bytes: nothing will follow them (false may also mean "not known yet")
     bool raw_exhausted() const { return raw_stage_ == 2 ? eof_ : (raw_stage_ == 1 && eof_ && raw_off_ >= spare_.size()); }
 
@@ -94,6 +100,8 @@ private:
     size_t raw_off_ = 0;
     const uint8_t* map_ = nullptr;    // read_raw: the file, mapped (stage 2), and the next unconsumed compressed byte
     size_t map_size_ = 0, map_pos_ = 0;
+    size_t sam_buf_off_ = 0, sam_body_off_ = 0, sam_line_off_ = 0, sam_text_pos_ = 0, sam_size_ = 0;   // SAM: file offset of buf_[0]; of the first alignment line; read_text's position; the file's size
+    bool sam_text_started_ = false;
     size_t blk_hint_ = 0;             // read_blocks: bytes worth reading when the inflated size ends a window before the buffer does
     int raw_stage_ = 0;               // read_raw: 0 = the decoded window at hand, 1 = the prefetched one, 2 = straight from the file
     bool fill(size_t need);           // make at least `need` decoded bytes available (BAM)

@@ -101,6 +101,8 @@ SLIMM_FORWARD(int, slimm_push_staged_packed_async, (slimm_ctx* a, uint32_t b, ui
 SLIMM_FORWARD(int, slimm_push_staged_marked_async, (slimm_ctx* a, uint32_t b, uint64_t c), (a, b, c))
 SLIMM_FORWARD(int, slimm_push_records_marked, (slimm_ctx* a, const uint32_t* b, const int32_t* c, uint64_t d), (a, b, c, d))
 SLIMM_FORWARD(int, slimm_group_push_records_marked, (slimm_group* a, const uint32_t* b, const int32_t* c, uint64_t d), (a, b, c, d))
+SLIMM_FORWARD(int, slimm_set_reference_names, (slimm_ctx * c, const char* const* names), (c, names))
+SLIMM_FORWARD(int, slimm_push_sam_bytes, (slimm_ctx * c, const uint8_t* t, uint64_t n, int last, uint64_t* got), (c, t, n, last, got))
 SLIMM_FORWARD(void, slimm_mark_words,
               (const uint64_t* a, const uint16_t* b, const int32_t* c, uint64_t d, const uint64_t* e, uint32_t* f_), (a, b, c, d, e, f_))
 SLIMM_FORWARD(int, slimm_push_records_packed, (slimm_ctx* a, const uint64_t* b, const int32_t* c, const int32_t* d, uint64_t e),
@@ -505,8 +507,7 @@ struct RecordPump {
     RecordPump(AlignmentFile& f, bool check_words, bool device_decode)
         : bam(f), want_check(check_words),
           marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")),
-          raw(device_decode && f.is_bam() && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") &&
-              !getenv("SLIMM_CLI_HOST_DECODE")) {
+          raw(device_decode && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") && !getenv("SLIMM_CLI_HOST_DECODE")) {
         if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) {
             device_period = static_cast<unsigned>(std::max(0l, atol(e)));
         }
@@ -546,7 +547,10 @@ struct RecordPump {
             // (every device_period-th of the windows read in place)
             bool compressed = false;
             long n;
-            if (device_period && bam.can_read_blocks() && (raw_windows_device + raw_windows_host) % device_period == device_period - 1u) {
+            if (!bam.is_bam()) {   // SAM: the text as it lies in the file (slimm_push_sam_bytes finds and decodes the lines)
+                n = bam.read_text(raw_buf[w].get(), raw_cap());
+                ++raw_windows_device;
+            } else if (device_period && bam.can_read_blocks() && (raw_windows_device + raw_windows_host) % device_period == device_period - 1u) {
                 size_t inflated = 0;
                 n = bam.read_blocks(raw_buf[w].get(), raw_cap(), device_window, &inflated);
                 compressed = true;
@@ -558,7 +562,7 @@ struct RecordPump {
             decode_ms += ms(t1, std::chrono::steady_clock::now());
             {
                 std::lock_guard<std::mutex> g(mu);
-                raw_ready.push_back(RawWindow{w, n, n > 0 && bam.raw_exhausted(), compressed});
+                raw_ready.push_back(RawWindow{w, n, n > 0 && bam.is_bam() && bam.raw_exhausted(), compressed});
             }
             cv.notify_all();
             if (n <= 0) {
@@ -572,6 +576,17 @@ struct RecordPump {
         bool pinned[kRawBuffers] = {};
         bool closed = false;  // a window went out as the file's last
         bool in_flight = false;  // the window pushed last is still being copied out of its buffer
+        const bool text = !bam.is_bam();
+        if (text) {   // SAM text names its references: the header's names for the device's look-up
+            std::vector<const char*> names;
+            for (const std::string& nm : bam.ref_names()) names.push_back(nm.c_str());
+            if (slimm_set_reference_names(c, names.data()) != SLIMM_OK) {
+                std::lock_guard<std::mutex> g(mu);
+                failed = true;
+                cv.notify_all();
+                return;
+            }
+        }
         for (;;) {
             RawWindow w;
             {
@@ -592,11 +607,13 @@ struct RecordPump {
                     (void)slimm_pin_host_buffer(c, raw_buf[w.which].get(), raw_cap());  // (pageable memory still works)
                     pinned[w.which] = true;
                 }
-                rc = w.compressed ? slimm_push_bgzf_blocks(c, raw_buf[w.which].get(), static_cast<uint64_t>(w.n), 0u, w.last ? 1 : 0, &got)
-                                  : slimm_push_bam_bytes(c, raw_buf[w.which].get(), static_cast<uint64_t>(w.n), w.last ? 1 : 0, &got);
+                rc = text ? slimm_push_sam_bytes(c, raw_buf[w.which].get(), static_cast<uint64_t>(w.n), w.last ? 1 : 0, &got)
+                     : w.compressed ? slimm_push_bgzf_blocks(c, raw_buf[w.which].get(), static_cast<uint64_t>(w.n), 0u, w.last ? 1 : 0, &got)
+                                    : slimm_push_bam_bytes(c, raw_buf[w.which].get(), static_cast<uint64_t>(w.n), w.last ? 1 : 0, &got);
                 closed = w.last;
             } else if (!closed) {
-                rc = slimm_push_bam_bytes(c, nullptr, 0, 1, &got);  // (the end came without notice: an incomplete record is an error)
+                rc = text ? slimm_push_sam_bytes(c, nullptr, 0, 1, &got)
+                          : slimm_push_bam_bytes(c, nullptr, 0, 1, &got);  // (the end came without notice: an incomplete record is an error)
             }
             raw_push_ms += ms(t1, std::chrono::steady_clock::now());
             raw_records += got;
@@ -1017,7 +1034,7 @@ bool get_profiles(Session& S, size_t file_index) {
         bool ok = pushed;
         if (!pushed && pump.raw && n >= 0 && strstr(slimm_last_error(ctx), "decode this file on the host")) {
             // a record longer than the device decoder's carry (16 MiB): this file goes through the host decoder after all
-            std::cerr << "(a record longer than 16 MiB: decoding on the host) ";
+            std::cerr << "(" << slimm_last_error(ctx) << ": decoding on the host) ";
             CHECK(ctx, slimm_reset(ctx));
             bam.close();
             if (!bam.open(path)) {

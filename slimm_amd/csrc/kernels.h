@@ -277,6 +277,26 @@ void launch_bam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64
                        BamCarry* carry, const BamWindowResult* result, bool marked, uint64_t out_at, uint64_t* key, int32_t* ref,
                        int32_t* pos, uint16_t* flag, uint32_t* check);
 
+// the scan of the pieces' counts + the window's result; sam_lo != 0xffffffff: SAM text (the window's stop is where the last
+// complete line ends; sam_lo when there is none)
+void launch_bam_scan(hipStream_t st, BamPiece* pieces, uint32_t n_pieces, uint64_t end, BamWindowResult* result, uint32_t sam_lo);
+
+// ---- sam_decode.hip: SAM text decoded on the device (the same window pipeline, pieces of 8 KB: a line is >= 22 bytes) ----
+constexpr uint32_t kSamPiece = 8192;
+constexpr uint32_t kSamPieceSkip = 2;   // BamPiece::flags: a header line or an empty line among the alignment lines
+static_assert(kSamPiece / 22 + 2 <= kBamSlots, "a SAM piece's lines fit the offsets of a BAM piece");
+struct SamRefEntry {   // open addressing over the header's reference names (ref < 0: empty)
+    uint64_t hash;
+    int32_t ref;
+    uint32_t name_off, name_len, pad;
+};
+uint32_t sam_pieces(uint64_t n_bytes);
+uint64_t sam_name_hash(const char* s, size_t n);
+void launch_sam_find(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t end, BamPiece* pieces, uint32_t* offs, BamWindowResult* result);
+void launch_sam_decode(hipStream_t st, const uint8_t* bytes, uint64_t lo, uint64_t end, const BamPiece* pieces, const uint32_t* offs,
+                       BamCarry* carry, const BamWindowResult* result, bool marked, uint64_t out_at, uint64_t* key, int32_t* ref, int32_t* pos,
+                       uint16_t* flag, uint32_t* check, const SamRefEntry* table, uint32_t table_mask, const uint8_t* names);
+
 // ---- bgzf_inflate.hip: BGZF blocks (DEFLATE streams of <= 64 KB) inflated on the device, a lane per block ----
 struct BgzfBlock {
     uint64_t src, dst;     // the DEFLATE payload's offset in the compressed bytes; where its output goes

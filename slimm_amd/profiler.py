@@ -265,6 +265,28 @@ class Slimm:
             total += got.value
         return total
 
+    def set_reference_names(self, names):
+        """The header's reference names for push_sam_bytes (slimm_set_reference_names)."""
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        self._check(self.L.slimm_set_reference_names(self.ctx, arr))
+
+    def push_sam_bytes(self, text, window: int = 0) -> int:
+        """slimm_push_sam_bytes: the alignment lines of a SAM file (bytes behind the header) in windows of `window` bytes (0:
+        one), cut anywhere.  Returns the number of records."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, dtype=np.uint8)
+        n = buf.shape[0]
+        step = window or max(n, 1)
+        total, got, keep = 0, C.c_uint64(), []
+        if n == 0:
+            self._check(self.L.slimm_push_sam_bytes(self.ctx, None, 0, 1, C.byref(got)))
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            piece = np.ascontiguousarray(buf[s:e])
+            self._check(self.L.slimm_push_sam_bytes(self.ctx, _p(piece), e - s, 1 if e == n else 0, C.byref(got)))
+            keep = (keep + [piece])[-3:]
+            total += got.value
+        return total
+
     def push_bgzf_blocks(self, blob, skip: int = 0, window: int = 0, host_every: int = 0) -> int:
         """slimm_push_bgzf_blocks: whole BGZF blocks of a BAM file (compressed), the first of which holds the first alignment
         record `skip` inflated bytes in; windows of about `window` compressed bytes (0: one), cut at block boundaries.  The

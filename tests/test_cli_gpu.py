@@ -316,10 +316,14 @@ def test_cli_devices_writes_raw_and_coverage_outputs_from_all_reduced_bins(tmp_p
     check_outputs(out, "sample", o)
 
 
-def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, monkeypatch):
-    """BAM input on one GPU: the command inflates, the DEVICE finds and decodes the records (slimm_push_bam_bytes); with
-    SLIMM_CLI_HOST_DECODE=1 the host decoder of rounds 1 - 3 does.  Same files either way, for a name-grouped file with
-    and for the same records in no particular order (key + check word hashed on the device)."""
+@pytest.mark.parametrize("fmt", ["bam", "sam"])
+def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, monkeypatch, fmt):
+    """BAM input on one GPU: the DEVICE inflates the blocks, finds and decodes the records (slimm_push_bgzf_blocks /
+    slimm_push_bam_bytes); SAM text likewise (slimm_push_sam_bytes: lines found and parsed on the device, small windows so
+    that lines are cut everywhere); with SLIMM_CLI_HOST_DECODE=1 the host decoder of rounds 1 - 3 does.  Same files either way,
+    for a name-grouped file and for the same records in no particular order (key + check word hashed on the device)."""
+    if fmt == "sam":
+        monkeypatch.setenv("SLIMM_CLI_WINDOW_MB", "1")
     w = with_names(make_workload(CONFIGS["config2"], seed=47, n_records=300_000))
     db = str(tmp_path / "db.sldb")
     write_sldb(db, w.taxonomy)
@@ -330,8 +334,8 @@ def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, m
     o_sh = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, shuffled, w.avg_read_len, want_raw=True, want_cov=True)
     cases = (("grouped", w.records, "@HD\tVN:1.6\tSO:unsorted\tGO:query", o), ("anyorder", shuffled, "@HD\tVN:1.6\tSO:unsorted", o_sh))
     for stem, rec, hd, want in cases:
-        inp = str(tmp_path / (stem + ".bam"))
-        write_bam(inp, w.ref_names, w.ref_len, rec, read_len=w.avg_read_len, hd=hd)
+        inp = str(tmp_path / (stem + "." + fmt))
+        (write_bam if fmt == "bam" else write_sam)(inp, w.ref_names, w.ref_len, rec, read_len=w.avg_read_len, hd=hd)
         outs = []
         for host in (False, True):
             if host:
@@ -342,6 +346,7 @@ def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, m
             os.makedirs(out)
             err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp], env=dict(os.environ, SLIMM_CLI_TRACE="1"))
             assert ("device decode" in err) == (not host)
+            assert "decoding on the host" not in err
             outs.append({f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))})
         assert outs[0] == outs[1] and len(outs[0]) == 5
         check_outputs(str(tmp_path / f"{stem}_0") + "/", stem, want)

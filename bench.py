@@ -974,6 +974,35 @@ def main():
                     os.unlink(bam_u)
                 except Exception as e:   # (the leg is a report, not a gate)
                     cli["unsorted_file"] = {"error": repr(e)[:300]}
+                # the same records as SAM TEXT (the reference takes .sam and .bam alike, src/file_helper.hpp:73-75): lines found
+                # and parsed on the device (slimm_push_sam_bytes), against the host decoder
+                try:
+                    from slimm_amd.synth_bam import write_synthetic_sam
+                    sam = os.path.join(tmp, "sample_text.sam")
+                    info_s = write_synthetic_sam(sam, w_cli.ref_names, w_cli.ref_len, recb, read_len=w_cli.avg_read_len)
+                    best_s, rs, prof_s = run_cli(sam, "sample_text")
+                    if best_s is not None:
+                        _, dds, _ = traces(rs)
+                        cli["sam_text"] = {"value": round(nb / best_s / 1e6, 3), "unit": "M records/s", "seconds": round(best_s, 3),
+                                           "text_bytes": info_s["bytes"], "text_GB_s": round(info_s["bytes"] / best_s / 1e9, 2),
+                                           "what": "`slimm DB IN.sam`: the file's text read by pread and handed over as it is "
+                                                   "(slimm_push_sam_bytes), lines found and the four fields parsed on the device "
+                                                   "(sam_decode.hip); bound by PCIe: text bytes / 54 GB/s = "
+                                                   f"{info_s['bytes'] / 54e9:.2f} s; best of 2",
+                                           "same_profile_as_the_bam": bool(prof_s == prof_g), "device_decode": dds,
+                                           "sam_built_in_s": round(info_s["seconds"], 1)}
+                        t1 = time.perf_counter()
+                        rh2 = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, sam],
+                                             capture_output=True, text=True, env=dict(os.environ, SLIMM_CLI_HOST_DECODE="1"))
+                        if rh2.returncode == 0:
+                            sec_h = time.perf_counter() - t1
+                            cli["sam_text"]["host_decoder"] = {"value": round(nb / sec_h / 1e6, 3), "seconds": round(sec_h, 3),
+                                                               "what": "SLIMM_CLI_HOST_DECODE=1 (rounds 1 - 4's SAM path), one run"}
+                    else:
+                        cli["sam_text"] = {"error": rs.stderr[-400:]}
+                    os.unlink(sam)
+                except Exception as e:
+                    cli["sam_text"] = {"error": repr(e)[:300]}
                 # rounds 1 - 4's file beside it: every sequence byte 0x11, every quality 0x28 -- 17.7-fold
                 try:
                     bam_e = os.path.join(tmp, "easy.bam")
@@ -1057,6 +1086,7 @@ def main():
             "cli_host_inflate_M_records_s": ((cli or {}).get("host_inflate") or {}).get("value"),
             "cli_unsorted_M_records_s": ((cli or {}).get("unsorted_file") or {}).get("value"),
             "cli_easy_file_M_records_s": ((cli or {}).get("easy_file") or {}).get("value"),
+            "cli_sam_text_M_records_s": ((cli or {}).get("sam_text") or {}).get("value"),
             "cpu_baseline": (cpu or {}).get("value"), "cpu_baseline_mt": (cpu_mt or {}).get("value"),
         }
         print(json.dumps(line))

@@ -479,7 +479,10 @@ bool bgzf_parse_blocks(const uint8_t* bytes, uint64_t n_bytes, uint64_t dst0, st
         d.csize = bsize - 12u - xlen - 8u;
         d.isize = isize;
         d.dst = dst;
-        if (isize) {  // (the empty block at the end of a file, and any other, has nothing to inflate)
+        // (the empty block at the end of a file -- a fixed-code block that holds its end-of-block code only -- has nothing to
+        // inflate; any other payload that claims ISIZE 0 is inflated all the same: it must give no byte and the CRC of none)
+        const bool eof_block = isize == 0 && d.csize == 2 && h[12u + xlen] == 0x03 && h[13u + xlen] == 0x00 && d.crc == 0;
+        if (!eof_block) {
             out.push_back(d);
             tok += bgzf_token_room(isize);
         }

@@ -250,3 +250,20 @@ def test_the_two_phase_kernels_take_every_huffman_block_themselves():
     mixed = bgzf_block(records[:60000], 0) + bgzf_block(records[:60000], 6) + bgzf_block(bytes(rng.integers(0, 256, 60000, dtype=np.uint8)), 6)
     rc, got, lanes = _inflate_with(mixed, 0)
     assert rc == 0 and lanes == 2 and got[:120000] == records[:60000] * 2
+
+
+def test_a_block_that_claims_no_bytes_is_inflated_all_the_same():
+    """ISIZE = 0 is the end-of-file block (a fixed-code block with its end-of-block code only), which nothing inflates; any other
+    payload under an ISIZE of 0 -- a flipped length field -- must still give no byte and the CRC of none, through either path
+    (found by scripts/stress_inflate.py: the parser used to drop every block of ISIZE 0)."""
+    good = bgzf_block(b"hello world")
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw = c.compress(b"a") + c.flush()
+    lying = bgzf_block(b"a", raw=raw)[:-4] + struct.pack("<I", 0)
+    eof = bgzf_block(b"", raw=b"\x03\x00")
+    empty_stored = bgzf_block(b"", raw=b"\x01\x00\x00\xff\xff")
+    for how in (0, 1):
+        rc, got, _ = _inflate_with(good + eof + good + empty_stored + good + eof, how)
+        assert rc == 0 and got == b"hello world" * 3
+        rc, got, _ = _inflate_with(good + lying + good, how)
+        assert rc != 0

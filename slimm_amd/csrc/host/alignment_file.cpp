@@ -262,7 +262,11 @@ struct ThreadDecompressor {  // one per worker thread, freed with the thread
 };
 
 bool inflate_one(const uint8_t* src, size_t clen, uint8_t* dst, uint32_t isize, uint32_t crc) {
-    if (isize == 0) return true;
+    // (the end-of-file block -- a fixed-code block with its end-of-block code only -- has nothing to inflate; any other payload
+    // under an ISIZE of 0 must give no byte and the CRC of none, like on the device: bgzf_parse_blocks)
+    if (isize == 0 && clen == 2 && src[0] == 0x03 && src[1] == 0x00 && crc == 0) return true;
+    uint8_t none[8];
+    if (isize == 0) dst = none;
     const Deflate& L = deflate_lib();
     if (L.ok) {
         static thread_local ThreadDecompressor td;

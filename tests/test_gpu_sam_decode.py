@@ -105,3 +105,21 @@ def test_unknown_reference_names_and_bad_lines(tmp_path):
     with pytest.raises(capi.SlimmError):
         s2.push_sam_bytes(data)
     s.close(); s2.close()
+
+
+def test_lines_longer_than_a_piece_and_windows_shorter_than_a_line(tmp_path):
+    """Sequences of tens of kilobases: a line runs over several 8 KB pieces (no line starts in them), and windows smaller than
+    a line (several pushes without a complete one); CR LF line ends (the carriage return stays in the last field, which nobody
+    reads)."""
+    w = _named(make_workload(SynthConfig("few", 300, 12, 2.0, bin_width=100, len_lo=5_000, len_hi=50_000, present_frac=0.8), seed=34))
+    o = run_workload(w, use_qnames=True)
+    p = str(tmp_path / "long.sam")
+    write_sam(p, w.ref_names, w.ref_len, w.records, read_len=20_000)
+    body = b"\n".join(ln for ln in open(p, "rb").read().split(b"\n") if ln and not ln.startswith(b"@")) + b"\n"
+    for data, window in ((body, 50_021), (body, 9_973), (body.replace(b"\n", b"\r\n"), 33_333)):
+        s = Slimm.for_workload(w, device=0, grouped=True)
+        s.set_reference_names(w.ref_names)
+        assert s.push_sam_bytes(data, window=window) == len(w.records)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+        s.close()

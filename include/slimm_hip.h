@@ -203,19 +203,20 @@ int slimm_staging_wait(slimm_ctx* ctx, uint32_t which);
  * over and runs beside the device's work on the window BEFORE it: the buffer must stay unchanged until the NEXT call on
  * this context returns (a call with last != 0 finishes everything), so hand over three or more buffers in rotation.
  * *n_records (may be NULL): records appended by this call -- those of the windows it finished: a window is found, counted and
- * decoded once 14 later ones have been handed over (they are copied, or inflated, meanwhile), all of them with last != 0.  last != 0: nothing follows (n_bytes may be 0) -- bytes of an incomplete record are then
+ * decoded once two later ones have been handed over or more than 4 GB of windows are in flight (they are copied, or inflated, meanwhile), all of them with last != 0.  last != 0: nothing follows (n_bytes may be 0) -- bytes of an incomplete record are then
  * an error (SLIMM_E_INVALID, "truncated BAM record"), as is a malformed record in any window.  A record longer than
  * 16 MiB is not supported in this form (SLIMM_E_INVALID: decode such a file on the host).  The forms do not mix within
  * a file.  Replaces: seqan::readRecord in src/slimm.hpp:194-208 / src/misc.hpp:509-522. */
 int slimm_push_bam_bytes(slimm_ctx* ctx, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records);
 /* The same with the inflate on the device as well: `blocks` = n_bytes of whole BGZF blocks of the file (compressed, as they
  * lie in it, one behind the other, in file order across calls), of whose inflated bytes the first `skip` are not alignment
- * records (the end of the BAM header in the file's first record-bearing block; 0 in every later call).  The compressed bytes
- * cross the bus, a lane per block inflates them (slimm_amd/csrc/bgzf_inflate.hip; ISIZE, the DEFLATE blocks' form and
- * the CRC32 are checked), and the records are found and decoded as above.  Windows of this form and of
- * slimm_push_bam_bytes may alternate within a file (a host that inflates some windows itself and leaves the others to the
- * device keeps both busy: up to 14 windows are in flight; a lane inflates a block, so give this form windows of tens of
- * thousands of blocks); buffer lifetime, `last`, *n_records and the errors are those of slimm_push_bam_bytes, plus
+ * records (the BAM header, of any size, up to its end in the file's first record-bearing block; 0 in every later call).  The
+ * compressed bytes cross the bus and are inflated on the device (slimm_amd/csrc/bgzf_tokens.hip: Huffman decode a lane per
+ * block, matches filled a workgroup per block; bgzf_inflate.hip behind it; ISIZE, the DEFLATE blocks' form and the CRC32 are
+ * checked), and the records are found and decoded as above.  Calls of any size: the library gathers them into device windows
+ * of 1.4 - 1.9 GB of inflated bytes (tens of thousands of blocks) and inflates those on two streams in turn.  Windows of this
+ * form and of slimm_push_bam_bytes may alternate within a file; buffer lifetime, `last`, *n_records and the errors are those of
+ * slimm_push_bam_bytes, plus
  * SLIMM_E_INVALID for anything that is not a BGZF block or does not inflate to its ISIZE. */
 int slimm_push_bgzf_blocks(slimm_ctx* ctx, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records);
 /* SAM TEXT decoded on the device (slimm_amd/csrc/sam_decode.hip): the reference takes .sam and .bam alike

@@ -1054,6 +1054,11 @@ def main():
             "roofline": roofline,
             "step_split": step_split,
             "exchange_bins": exchange_bins,
+            "scaling_note": (None if world == 1 else
+                             "strong scaling of ONE 1 B-record stream: a rank's kernels take (11.7 ms / N) per step, while two collectives, "
+                             "two host synchronisations and the host's cut-offs between the phases (0.13 ms + the collectives' latency) stay: "
+                             "above N = 4 the step is mostly the latter (step_split says how much), so the curve flattens by "
+                             "construction -- the work per step is 12 ms of one GPU"),
             "value_resident": round(value, 3),
             "value_with_push": with_push,
             "run_marked_records": marked,

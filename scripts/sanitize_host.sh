@@ -35,6 +35,10 @@ for i, w in enumerate(cases):
     p = f"{d}/c{i}.sldb"
     write_sldb(p, w.taxonomy)
     files.append(p)
+# (a BAM that hardly compresses: more than the reader's own first windows hold, so that read_raw reaches the part of the file it
+# reads in place and read_blocks takes over)
+write_bam(f"{d}/c4.bam", cases[3].ref_names, cases[3].ref_len, cases[3].records, read_len=cases[3].avg_read_len, irregular_seed=5)
+files.append(f"{d}/c4.bam")
 data = open(f"{d}/c2.bam", "rb").read()
 open(f"{d}/trunc.bam", "wb").write(data[:len(data) // 3])
 bad = bytearray(data); bad[200] ^= 0xff
@@ -49,7 +53,7 @@ for thr in ("1", "8"):
     print(r.stdout)
     if r.returncode or r.stderr.strip():
         bad += 1; print("SANITIZER OUTPUT:\n" + r.stderr)
-r = subprocess.run([f"{d}/tsan_readers", f"{d}/c3.bam", f"{d}/c2.bam", f"{d}/trunc.bam"], capture_output=True, text=True,
+r = subprocess.run([f"{d}/tsan_readers", f"{d}/c3.bam", f"{d}/c4.bam", f"{d}/c2.bam", f"{d}/trunc.bam"], capture_output=True, text=True,
                    env=dict(os.environ, SLIMM_DECODE_THREADS="8"))
 print(r.stdout)
 if r.returncode or r.stderr.strip():
@@ -90,10 +94,11 @@ print("slimm_build under sanitizers: done")
 emu = os.path.join(os.getcwd(), "tests", "native", "libslimm_emu.so")
 if os.path.exists(emu) and os.path.exists(f"{d}/tsan_slimm"):
     for extra in ({"SLIMM_CLI_WINDOW_MB": "1"}, {"SLIMM_CLI_WINDOW_MB": "3", "SLIMM_NO_MMAP": "1"}, {"SLIMM_CLI_HOST_DECODE": "1"}):
-        r = subprocess.run([f"{d}/tsan_slimm", "-w", "1000", "-o", f"{d}/cli_", f"{d}/c3.sldb", f"{d}/c3.bam"], capture_output=True,
-                           text=True, errors="replace", env=dict(os.environ, SLIMM_HIP_LIB=emu, **extra))
-        if r.returncode or "ThreadSanitizer" in r.stderr:
-            bad += 1; print("SANITIZER OUTPUT (slimm under TSan):\n" + r.stderr[-4000:])
+        for inp in ("c3.bam", "c2.sam"):
+            r = subprocess.run([f"{d}/tsan_slimm", "-w", "1000", "-o", f"{d}/cli_", f"{d}/{inp[:2]}.sldb", f"{d}/{inp}"], capture_output=True,
+                               text=True, errors="replace", env=dict(os.environ, SLIMM_HIP_LIB=emu, **extra))
+            if r.returncode or "ThreadSanitizer" in r.stderr:
+                bad += 1; print("SANITIZER OUTPUT (slimm under TSan):\n" + r.stderr[-4000:])
     print("slimm (command, emulated device) under ThreadSanitizer: done")
 print("sanitizer findings:", bad)
 sys.exit(1 if bad else 0)

@@ -40,6 +40,45 @@ int main(int argc, char** argv) {
                        windows, sum, k, g.error().c_str());
             }
             unsetenv("SLIMM_NO_MMAP");
+            // read_blocks (the windows `slimm` hands to slimm_push_bgzf_blocks: whole BGZF blocks by pread), alternating with
+            // read_raw, small and large buffers, an inflated-size limit that ends windows early
+            for (int mode = 0; mode < 3; ++mode) {
+                const size_t cap = mode == 0 ? (1u << 20) : mode == 1 ? (2u << 20) + 777u : (32u << 20);
+                const size_t lim = mode == 1 ? (3u << 20) : (1900u << 20);
+                AlignmentFile g;
+                if (!g.open(p)) continue;
+                std::vector<uint8_t> buf(cap);
+                long k = 1; unsigned long long cbytes = 0, ibytes = 0; int windows = 0;
+                while (k > 0) {
+                    if (g.can_read_blocks() && (windows % 3) != 2) {
+                        size_t inf = 0;
+                        k = g.read_blocks(buf.data(), cap, lim, &inf);
+                        if (k > 0) { cbytes += static_cast<unsigned long long>(k); ibytes += inf; }
+                    } else {
+                        k = g.read_raw(buf.data(), cap);
+                        if (k > 0) ibytes += static_cast<unsigned long long>(k);
+                        if (k > 0 && g.raw_exhausted()) break;
+                    }
+                    ++windows;
+                }
+                printf("%s: read_blocks mode %d: %llu compressed + inflated to %llu bytes in %d windows rc=%ld %s\n", p.c_str(), mode, cbytes,
+                       ibytes, windows, k, g.error().c_str());
+            }
+        }
+        if (p.size() > 4 && p.substr(p.size() - 4) == ".sam") {   // read_text (slimm_push_sam_bytes): the text behind the header
+            for (size_t cap : {size_t(1) << 16, (size_t(1) << 20) + 13u, size_t(64) << 20}) {
+                AlignmentFile g;
+                if (!g.open(p)) continue;
+                std::vector<uint8_t> buf(cap);
+                long k; unsigned long long bytes = 0, lines = 0; int first = -1;
+                while ((k = g.read_text(buf.data(), cap)) > 0) {
+                    if (first < 0) first = buf[0];
+                    bytes += static_cast<unsigned long long>(k);
+                    for (long i = 0; i < k; ++i) lines += buf[static_cast<size_t>(i)] == 10;
+                }
+                printf("%s: read_text cap %zu: %llu bytes, %llu lines, first byte %d, rc=%ld %s\n", p.c_str(), cap, bytes, lines, first, k,
+                       g.error().c_str());
+            }
         }
     }
 }

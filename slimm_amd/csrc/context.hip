@@ -663,8 +663,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 // direct rounds: with hundreds of thousands of values per tile, appending at ONE frontier per tile keeps
                 // the bucket's open cache lines in L2, while 256 private frontiers per tile -- 2.5 M partially written
                 // lines at config 3 -- turn every 2-byte store into a partial-line write: measured 834 vs 362 us.)
+                // Since round 5 only beyond kBigRoundTiles tiles: up to there the rounds ordered by tile in LDS
+                // (k_tile_scatter_big) are faster for both phases (config 3, phase B: count 28 -> 17 us, scatter 52 -> 42).
                 const char* mx = getenv("SLIMM_MATRIX");
-                cc->matrix = !cc->fused_scan && !(mx && mx[0] == '0');
+                cc->matrix = !cc->fused_scan && !(mx && mx[0] == '0') && (c->ntiles2 > kBigRoundTiles || (mx && mx[0] == '2'));
                 if (cc->matrix &&
                     cc->tile_matrix.ensure(static_cast<size_t>(TILES(c->tile_shift, tile_count_grid(512))) * cc->tstride) != hipSuccess)
                     return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");

@@ -242,6 +242,8 @@ struct BitsLayout {
     uint32_t tps = 1;           // tiles per slice
     uint64_t slice_w64 = 0;     // 64-bit words of one array in one slice = tps * (bins per tile / 64)
 };
+constexpr uint32_t kBigRoundTiles = 6144;   // tiles up to which the one-level scatter orders its rounds by tile in LDS
+                                            // (k_tile_scatter_big; the direct rounds beyond)
 constexpr uint32_t kFusedScanTiles = 4064;  // (4096 table entries less the room three small arrays take: tile_hist.hip)
 namespace tiles13 {
 #include "tile_api.inc"

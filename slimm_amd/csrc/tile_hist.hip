@@ -87,6 +87,8 @@ struct SlotWalk {  // all wave-uniform
     uint32_t base, left;      // entries of the current slot not yet handed out: [base, base + left)
     uint32_t sum_f, sum_h, sum_v;  // targets, reads and mapped records of the slots taken so far
     bool per_read;
+    uint4 nd;                 // slots[s], asked for when the slot before it was taken up (a scalar load per slot with
+                              // its wait right behind it is a round trip per ~600 values in every kernel that walks)
 };
 
 constexpr uint32_t kPiece = 256;
@@ -102,6 +104,7 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslot
     w.d_end = 0;
     w.d_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.d_first = true;
+    w.nd = make_uint4(0u, 0u, 0u, 0u);
     if (!slots) {  // dense: nslots VALUES; every unit of the bucketing grid a stretch of whole pieces
         const uint32_t units = gridDim.x * fold;
         const uint32_t per_unit = ((nslots + units - 1u) / units + kPieceMax - 1u) & ~(kPieceMax - 1u);
@@ -119,6 +122,7 @@ __device__ __forceinline__ SlotWalk slot_walk(const uint4* slots, uint32_t nslot
     const uint32_t lo = min(wg * per_wg, nslots);
     w.s = lo + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     w.s_end = min(lo + per_wg, nslots);
+    w.nd = w.s < w.s_end ? slots[w.s] : make_uint4(0u, 0u, 0u, 0u);
     w.base = 0;
     w.left = 0;
     w.sum_f = w.sum_h = w.sum_v = 0;
@@ -156,8 +160,9 @@ __device__ __forceinline__ uint32_t slot_next(SlotWalk& w, uint32_t* base, uint3
     }
     while (w.left == 0u) {
         if (w.s >= w.s_end) return 0u;
-        const uint4 d = w.slots[w.s];  // (a scalar load: one address for the wave)
+        const uint4 d = w.nd;
         w.s += w.step;
+        if (w.s < w.s_end) w.nd = w.slots[w.s];  // (a scalar load: one address for the wave)
         w.base = d.x;
         w.left = w.per_read ? d.z : d.y;
         w.sum_f += d.y;
@@ -560,7 +565,10 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
         const uint32_t i = j * kTBlock + tid;
         const uint32_t h = s_cnt[i];
         s_loff[i] = h;
-        got[j] = (h && i < ntiles) ? atomicAdd(&tile_cursor[i], h) + s_mine[i] : 0u;
+        // (nothing but the atomic inside the condition, its result not used before the scan is done: with "+ s_mine[i]"
+        // in here every reservation was a branch with a wait at its end -- eight round trips in a row per round)
+        got[j] = 0u;
+        if (h && i < ntiles) got[j] = atomicAdd(&tile_cursor[i], h);
     }
     __syncthreads();
     TPROF_T(p3);
@@ -569,7 +577,7 @@ __device__ __forceinline__ void scatter_round_ordered(const uint32_t (&v)[kRound
 #pragma unroll
     for (uint32_t j = 0; j < kTileSlots / kTBlock; ++j) {
         const uint32_t i = j * kTBlock + tid;
-        s_cnt[i] = got[j] - s_loff[i];
+        s_cnt[i] = got[j] + s_mine[i] - s_loff[i];  // (entries behind the last tile: never read)
     }
     TPROF_T(p4);
     TPROF_ADD(4, p3, p4);
@@ -611,12 +619,14 @@ __device__ __forceinline__ void scatter_round_direct(const uint32_t (&v)[kPieces
         for (int j = 0; j < kMaxTilesPerThread; ++j) {
             const uint32_t i = i0 + j * kTBlock + threadIdx.x;
             const uint32_t h = i < ntiles ? s_hist[i] : 0u;
-            got[j] = h ? atomicAdd(&tile_cursor[i], h) + tile_base[i] : 0u;  // tiles this round does not touch: no atomic
+            got[j] = 0u;
+            if (h) got[j] = atomicAdd(&tile_cursor[i], h);  // tiles this round does not touch: no atomic.  (Nothing but
+                                                            // the atomic in here: a use of its result is a wait per tile)
         }
 #pragma unroll
         for (int j = 0; j < kMaxTilesPerThread; ++j) {
             const uint32_t i = i0 + j * kTBlock + threadIdx.x;
-            if (i < ntiles) s_hist[i] = got[j];
+            if (i < ntiles) s_hist[i] = got[j] + tile_base[i];
         }
     }
     __syncthreads();
@@ -682,6 +692,185 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
         scatter_round_direct(v, ntiles, rep_base, tile_cursor, bucket, s_hist);
     });
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// One-level bucketing above kFusedScanTiles tiles with the values ORDERED BY TILE in LDS before they leave.
+// The direct rounds (k_tile_scatter) store every 2-byte entry from a register: one L2 write request per value, 617 M at
+// 1 B records -- about what the L2's channels take in the kernel's 2.4 ms -- beside one returning atomic per touched
+// tile and round of 16 K values.  Here a workgroup of kBigBlock threads (the ONE of its CU: the LDS is its own) takes
+// rounds of kBigBlock x kBigPieces values, and ONE table of a word per tile serves in turn as the round's histogram
+// of the round, as the tiles' cursors inside the stage (placement: a returning add), and as "global position of the tile's
+// run minus its offset in the stage" (write-out: consecutive lanes store consecutive bucket positions of one
+// tile -- a request per run, not per value).  Thread t owns tiles t, t + kBigBlock, ...: their counts, their reservations
+// (in registers between the steps) and their runs' places in the stage -- thread-major, so that the scan is over threads.
+// Same slot ranges and counter copies as k_tile_count (same grid, same fold): copy = blockIdx.x % reps, and the
+// workgroups of a copy share an XCD (blockIdx.x % 8) like the frontiers they append to.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef SLIMM_BIG_PIECES
+#define SLIMM_BIG_PIECES 24
+#endif
+constexpr int kBigBlock = kTBlock * kCountFold;                  // 1024 threads
+constexpr int kBigPieces = SLIMM_BIG_PIECES;                     // values per thread and round (four to a 16-byte load)
+constexpr uint32_t kBigRound = kBigBlock * kBigPieces;           // 24 576 values per round
+static_assert(kBigPieces % 8 == 0, "values come four to a lane; the rounds' LDS operations in batches of eight");
+template <int kE>  // tiles per thread: ntiles <= kE * kBigBlock
+__global__ __launch_bounds__(kBigBlock) void k_tile_scatter_big(const uint32_t* __restrict__ vals, const uint4* __restrict__ slots,
+                                                                uint32_t nslots, int per_read, uint32_t ntiles,
+                                                                const uint32_t* __restrict__ tile_base,
+                                                                uint32_t* __restrict__ tile_cursor_all,
+                                                                uint16_t* __restrict__ bucket, uint32_t* __restrict__ cov,
+                                                                uint32_t* __restrict__ ucov,
+                                                                const uint32_t* __restrict__ rep_base_all, uint32_t reps,
+                                                                uint32_t rep_stride, uint32_t tile_sub) {
+    // s_tab[kE * kBigBlock] | 64 more entries, nobody's tiles: where a lane's "no value" counts | s_stage[kBigRound] | 64
+    // more words, where a lane's "no value" is put -- the rounds' LDS operations are issued unconditionally, batch after
+    // batch (a value behind `if (there is one)` is a branch, and a returning LDS atomic inside a branch is waited for
+    // inside it).  An entry per LANE: a slot's last piece is short, every round has a fifth of its lanes without a value,
+    // and one shared entry would take them one after the other.
+    HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
+    __shared__ uint32_t s_more[kBigBlock / 64], s_wtot[kBigBlock / 64];
+    constexpr uint32_t kNoTile = kE * kBigBlock;
+    uint32_t* const s_tab = s_dyn;
+    uint32_t* const s_stage = s_dyn + kNoTile + 64;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid < 64u) s_tab[kNoTile + tid] = 0u;
+    const uint32_t no_tile = kNoTile + lane;
+    const size_t rep_off = static_cast<size_t>(blockIdx.x % reps) * rep_stride;
+    uint32_t* __restrict__ tile_cursor = tile_cursor_all + rep_off;
+    const uint32_t* __restrict__ rep_base = rep_base_all + rep_off;
+    TPROF_T(q0);
+    if (tid < kTBlock) zero_split_tiles(tile_base, ntiles, cov, ucov, tile_sub);
+    SlotWalk walk = slot_walk(slots, nslots, per_read != 0, kCountFold);
+    // (a round's values are asked for while the round before it leaves: step 3 is the last to read them)
+    uint32_t v[kBigPieces];
+    bool mine = round_load<kBigPieces, true>(walk, vals, lane, v);
+    TPROF_T(q1);
+    if (wave < 8u) TPROF_ADD(0, q0, q1);
+    while (true) {
+        TPROF_T(p0);
+        if (lane == 0u) s_more[wave] = mine ? 1u : 0u;
+#pragma unroll
+        for (int u = 0; u < kE; ++u) s_tab[u * kBigBlock + tid] = 0u;
+        __syncthreads();
+        uint32_t any = 0;
+#pragma unroll
+        for (int w = 0; w < kBigBlock / 64; ++w) any |= s_more[w];
+        if (!any) break;
+        TPROF_T(p1);
+        if (wave < 8u) TPROF_ADD(1, p0, p1);
+        // 1. the round's histogram
+#pragma unroll
+        for (int k = 0; k < kBigPieces; ++k) atomicAdd(&s_tab[v[k] != 0xffffffffu ? tile_of(v[k]) : no_tile], 1u);
+        __syncthreads();
+        TPROF_T(p2);
+        if (wave < 8u) TPROF_ADD(2, p1, p2);
+        // 2. my tiles: their stretch of the bucket for this round (one returning atomic per touched tile, all of a
+        // thread's under way during the scan), their offsets in the stage
+        // (Nothing but the atomic inside its condition, and no use of the result before step 4: "h ? atomicAdd() + base : 0"
+        // is a branch with a wait at its end per tile -- the thread's reservations one round trip after the other.)
+        uint32_t got[kE], at[kE], sum = 0;
+        {
+            uint32_t h[kE];
+#pragma unroll
+            for (int u = 0; u < kE; ++u) {
+                const uint32_t i = u * kBigBlock + tid;
+                at[u] = rep_base[i < ntiles ? i : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < kE; ++u) {
+                const uint32_t i = u * kBigBlock + tid;
+                h[u] = s_tab[i];
+                got[u] = 0u;
+                if (h[u] && i < ntiles) got[u] = atomicAdd(&tile_cursor[i], h[u]);
+                sum += h[u];
+            }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t a = __shfl_up(inc, o, 64);
+                if (lane >= static_cast<uint32_t>(o)) inc += a;
+            }
+            if (lane == 63u) s_wtot[wave] = inc;
+            sum = inc - sum;  // (what the wave's lanes before mine hold)
+            __syncthreads();
+            uint32_t run = sum;
+#pragma unroll
+            for (int w = 0; w < kBigBlock / 64; ++w)
+                if (w < static_cast<int>(wave)) run += s_wtot[w];
+            sum = run;  // my first tile's offset in the stage
+#pragma unroll
+            for (int u = 0; u < kE; ++u) {
+                s_tab[u * kBigBlock + tid] = run;
+                run += h[u];
+            }
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kBigBlock / 64; ++w) total += s_wtot[w];
+        __syncthreads();
+        TPROF_T(p3);
+        if (wave < 8u) TPROF_ADD(3, p2, p3);
+        // 3. the values into the stage, tile after tile: a value's place is what its tile's offset was when it came by
+        // (the order inside a tile's run is of no consequence to a histogram)
+#pragma unroll
+        for (int k0 = 0; k0 < kBigPieces; k0 += 8) {
+            uint32_t at_[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) at_[k] = atomicAdd(&s_tab[v[k0 + k] != 0xffffffffu ? tile_of(v[k0 + k]) : no_tile], 1u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = tile_of(v[k0 + k]);
+                s_stage[v[k0 + k] != 0xffffffffu ? at_[k] : kBigRound + lane] = (t << kEntryBits) | entry_of(v[k0 + k]);
+            }
+        }
+        __syncthreads();
+        TPROF_T(p4);
+        if (wave < 8u) TPROF_ADD(4, p3, p4);
+        // 4. the table turns into "where the tile's run goes, minus where it lies in the stage" (an entry holds the END
+        // of its run now = the start of my next tile's)
+        {
+            uint32_t off = sum;
+#pragma unroll
+            for (int u = 0; u < kE; ++u) {
+                const uint32_t end = s_tab[u * kBigBlock + tid];
+                s_tab[u * kBigBlock + tid] = got[u] + at[u] - off;
+                off = end;
+            }
+        }
+        mine = round_load<kBigPieces, true>(walk, vals, lane, v);  // (behind step 4: a wait for the reservations would
+                                                                    // be a wait for these loads too)
+        __syncthreads();
+        TPROF_T(p5);
+        if (wave < 8u) TPROF_ADD(5, p4, p5);
+        // 5. out: consecutive lanes, consecutive entries
+#pragma unroll
+        for (int k0 = 0; k0 < kBigPieces; k0 += 4) {  // (four stage reads, then four table reads, then the stores)
+            if (static_cast<uint32_t>(k0) * kBigBlock >= total) break;
+            uint32_t e[4], d[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = s_stage[(k0 + k) * kBigBlock + tid];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = s_tab[min(e[k] >> kEntryBits, kNoTile)];  // (behind `total`: whatever the stage holds)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = (k0 + k) * kBigBlock + tid;
+                if (j < total) bucket[d[k] + j] = static_cast<uint16_t>(e[k] & ((1u << kEntryBits) - 1u));
+            }
+        }
+        __syncthreads();  // (the next round clears the table and refills the stage)
+        TPROF_T(p6);
+        if (wave < 8u) TPROF_ADD(6, p5, p6);
+    }
+    TPROF_T(q2);
+    if (wave < 8u) TPROF_ADD(7, q0, q2);
+}
+constexpr size_t big_lds_bytes(int e) { return (static_cast<size_t>(e) * kBigBlock + kBigRound + 128u) * 4u; }
+// (kBigE = 12, for the 12 183 tiles of config 5 -- two values per tile and round --, measured slower than the direct
+// rounds there: 236 against 201 us)
+constexpr int kBigE = 6;
+static_assert(big_lds_bytes(kBigE) <= 160u * 1024u - 256u, "the table and the stage share a CU's LDS");
+static_assert(kBigE * kBigBlock == kBigRoundTiles, "kernels.h tells the context which layouts take these rounds");
+static_assert(kTileShift + 1 + 14 <= 32, "a stage entry holds the tile and the bucket entry");
 
 // Matrix bucketing, the scatter: the workgroup that counted these slots (same grid, same slot ranges as k_tile_count)
 // writes them out.  s_cur[tile] = tile_base[tile] + this row's prefix; a value's place is the returned LDS count.  One
@@ -1300,6 +1489,9 @@ int tile_hist_setup(uint32_t ntiles) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter_matrix), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(bytes)) != hipSuccess)
         return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_scatter_big<kBigE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(big_lds_bytes(kBigE))) != hipSuccess)
+        return -1;
     return 0;
 }
 
@@ -1339,6 +1531,15 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
                          const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
                          const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
                          const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride, uint32_t tile_sub) {
+    const char* const big_env = std::getenv("SLIMM_SCATTER_BIG");  // (tuning aid / tests) 0: the direct rounds
+    const bool big_rounds = !(big_env && big_env[0] == '0');
+    // (the copies' workgroups are the count's: tile_count_grid(grid) of them)
+    if (!two_level && big_rounds && reps > 1 && ntiles <= static_cast<uint32_t>(kBigE) * kBigBlock) {
+        hipLaunchKernelGGL(k_tile_scatter_big<kBigE>, dim3(tile_count_grid(grid)), dim3(kBigBlock), big_lds_bytes(kBigE), st,
+                           in.vals, in.slots, in.nslots, in.per_read ? 1 : 0, ntiles, tile_base, tile_cursor, bucket, cov,
+                           ucov, rep_base, reps, rep_stride, tile_sub);
+        return;
+    }
     if (!two_level) {
         const size_t lds = static_cast<size_t>(ntiles) * 4;
         hipLaunchKernelGGL(k_tile_scatter, dim3(grid), dim3(kTBlock), lds, st, in.vals, in.slots, in.nslots,
@@ -1386,12 +1587,15 @@ void launch_tile_hist(hipStream_t st, uint32_t ntiles, uint32_t n_upper, const u
 }  // namespace SLIMM_TILE_NS
 }  // namespace slimm
 
-#if defined(EXP) && (EXP == 8 || EXP == 9) && SLIMM_TILE_SHIFT == 13  // (the cycle probes read the small-tile build)
+#ifndef TPROF_SHIFT
+#define TPROF_SHIFT 13  // (the cycle probes read the small-tile build unless told otherwise)
+#endif
+#if defined(EXP) && (EXP == 8 || EXP == 9) && SLIMM_TILE_SHIFT == TPROF_SHIFT
 extern "C" int slimm_debug_prof_tiles(unsigned long long* out, int n, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::tiles13::g_prof_t), sizeof(unsigned long long) * n);
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::SLIMM_TILE_NS::g_prof_t), sizeof(unsigned long long) * n);
     if (reset) {
         static unsigned long long z[8 * 4096];
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::tiles13::g_prof_t), z, sizeof(z));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::SLIMM_TILE_NS::g_prof_t), z, sizeof(z));
     }
     return e == hipSuccess ? 0 : -1;
 }

@@ -270,10 +270,13 @@ def test_a_read_with_thousands_of_targets(n_hit, where):
     assert s.stats()["n_targets"] > n_hit
 
 
-def test_one_level_bucketing_with_a_separate_scan(monkeypatch):
-    """SLIMM_FUSED_SCAN=0: k_tile_scan + the direct scatter (what layouts of more than 4064 tiles use) on small layouts,
-    reads of thousands of records included."""
+@pytest.mark.parametrize("big", ["1", "0"])
+def test_one_level_bucketing_with_a_separate_scan(monkeypatch, big):
+    """SLIMM_FUSED_SCAN=0: k_tile_scan + the scatter of layouts of more than 4064 tiles on small layouts, reads of
+    thousands of records included: the rounds ordered by tile in LDS (k_tile_scatter_big, the default) and the direct
+    rounds (SLIMM_SCATTER_BIG=0)."""
     monkeypatch.setenv("SLIMM_FUSED_SCAN", "0")
+    monkeypatch.setenv("SLIMM_SCATTER_BIG", big)
     check(make_workload(CONFIGS["config2"], seed=23, n_records=300_000))
     check(make_workload(CONFIGS["config1"], seed=24))
     check(one_long_read_workload(9_000))

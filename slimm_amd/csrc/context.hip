@@ -660,9 +660,9 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 // Layouts beyond the fused kernel's 4064 tiles, PHASE B only, when a tile gets few selectors (decided per
                 // file from the number of reads): a count matrix instead of counter copies and cursors -- one row of tile
                 // counts per counting workgroup, no global atomics and no rounds in the scatter.  (Phase A stays on the
-                // direct rounds: with hundreds of thousands of values per tile, appending at ONE frontier per tile keeps
-                // the bucket's open cache lines in L2, while 256 private frontiers per tile -- 2.5 M partially written
-                // lines at config 3 -- turn every 2-byte store into a partial-line write: measured 834 vs 362 us.)
+                // rounds: with hundreds of thousands of values per tile, appending at ONE frontier per tile and counter
+                // copy keeps the bucket's open cache lines in L2, while 256 private frontiers per tile -- 2.5 M partially
+                // written lines at config 3 -- turn every 2-byte store into a partial-line write: measured 834 vs 362 us.)
                 // Since round 5 only beyond kBigRoundTiles tiles: up to there the rounds ordered by tile in LDS
                 // (k_tile_scatter_big) are faster for both phases (config 3, phase B: count 28 -> 17 us, scatter 52 -> 42).
                 const char* mx = getenv("SLIMM_MATRIX");

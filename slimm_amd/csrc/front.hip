@@ -436,14 +436,6 @@ __device__ __forceinline__ bool has_run_of(uint64_t D, uint32_t n) {
     return x != 0ull;
 }
 
-// Is there a stretch of at least 32 set bits in N?  Such a stretch covers bit 31 -- or is exactly bits 32..63 --, so it is
-// the stretch around the middle of the word: the leading ones of the low half plus the trailing ones of the high half.
-// Six scalar instructions where the doubling above takes thirteen (the scalar unit is what k_front waits for).
-__device__ __forceinline__ bool has_32_ones(uint64_t N) {  // N != ~0 (a window's lane 0 starts a segment)
-    const uint64_t M = ~((N << 32) | (N >> 32));  // halves swapped: the ones of the middle are the ones at both ends
-    return static_cast<uint32_t>(__builtin_clzll(M)) + static_cast<uint32_t>(__builtin_ctzll(M)) >= 32u;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // fast path: lanes [0, X) of the window hold whole runs whose mates never decrease.  field = the staged reference field,
 // SS = segment starts (run starts and mate changes), V = mapped lanes, both inside [0, X).
@@ -466,8 +458,7 @@ __device__ __forceinline__ WinMasks window_fast(uint32_t field, uint32_t gbin, u
     const uint64_t N0 = ~SS & f_below_nz(X);  // (a window holds a record)
     uint64_t D = N0 & (N0 << 1);
     uint64_t F;
-    // (a segment of more than kHashWalk records = more than kHashWalk - 1 non-start lanes in a row)
-    if (kHashWalk == 32u ? has_32_ones(N0) : has_run_of(D, kHashWalk - 1u)) {
+    if (has_run_of(D, kHashWalk - 1u)) {
         hash_clear(tab, lane);
         bool overflow = false;  // (never: 64 keys at most)
         F = f_ballot(hash_first(tab, T, lane, f_bit(V), overflow));

@@ -23,6 +23,9 @@ ONE JSON line on rank 0.  Beside the contract's fields:
                       launch (hipExtLaunchKernelGGL) on the library's stream inside the timed steps
   roofline_config2 / _config3 / _config5   the same for BASELINE.json configs[1], [2] (the designated roofline run) and
                       [4] (100 M records, 50 k strain-level refs, 40 hits/read), resident, N = 1 only
+  two_files_in_flight two host threads, each taking its files back to back through two contexts of its own: the kernels of
+                      two files share the device (round 5: +5 % at 1 B records, +14 % at 100 M).  Reported beside `value`,
+                      which keeps one file at a time
   value_with_push     the clock starts before the first record leaves page-locked HOST memory
                       (slimm_push_records_packed_async) and stops when the profile file is written -- SURVEY.md 8d (1)
   run_marked_records  the same stream handed over as run-marked 8-byte records (include/slimm_hip.h): resident rate, k_front
@@ -190,6 +193,8 @@ def main():
                     help="configurations measured beside the headline, resident, one context ('' = none)")
     ap.add_argument("--config-steps", type=int, default=5)
     ap.add_argument("--push-files", type=int, default=3, help="files of the pipelined push-inclusive measurement (0 = skip the leg)")
+    ap.add_argument("--in-flight-files", type=int, default=20,
+                    help="files of the two-files-in-flight leg (two host threads, each with two contexts of its own; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-any-order", action="store_true", help="skip the record_order = ANY legs (interleaved streams)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="records the single-threaded CPU restatement is timed on")
@@ -613,6 +618,37 @@ def main():
             print(f"# device kernels {kernel_ms:.3f} ms of {ms_per_step:.3f} ms per step", file=sys.stderr)
             for k, v in phase_times.items():
                 print(f"# host wall {k:28s} {v / args.steps * 1e6:9.1f} us/step", file=sys.stderr)
+
+        # ---- two files in flight: two host threads, each working through its files back to back on two contexts of its own,
+        # so that the kernels of two files share the device (the front end waits for the scalar unit, the bucketing for the
+        # LDS, the histograms for memory).  Reported BESIDE `value`, which keeps one file at a time.
+        in_flight = None
+        if extras and world == 1 and args.in_flight_files >= 4 and args.record_order == "grouped" and args.engines == 2:
+            import threading
+            lanes_ = [FilesBackToBack([new_engine(), new_engine()], res.give, dev, out_path + f".t{i}") for i in range(2)]
+            def work(fb, k):
+                for _ in range(k):
+                    fb.step()
+                fb.flush()
+            for fb in lanes_:
+                work(fb, 3)          # (every context's first file allocates)
+            per = args.in_flight_files // 2
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ts = [threading.Thread(target=work, args=(fb, per)) for fb in lanes_]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / (2 * per)
+            for fb in lanes_:
+                [e.close() for e in fb.engines]
+            in_flight = {"value": round(n_rec / dt / 1e6, 3), "unit": "M records/s", "ms_per_file": round(dt * 1e3, 4),
+                         "files": 2 * per,
+                         "what": "TWO files in flight: two host threads, each taking its files back to back through two contexts "
+                                 "of its own (four contexts, four streams); every file a freshly reset object, every profile "
+                                 "written inside the timed region; not the headline -- `value` keeps one file at a time"}
+            if args.breakdown:
+                print(f"# two files in flight: {dt * 1e3:.3f} ms per file = {n_rec / dt / 1e6:.0f} M records/s", file=sys.stderr)
 
         # ---- push-inclusive rate: the clock starts before the first record leaves host
         # memory and stops when the profile file is written.  PCIe, not the path, bounds it.
@@ -1060,6 +1096,7 @@ def main():
                              "above N = 4 the step is mostly the latter (step_split says how much), so the curve flattens by "
                              "construction -- the work per step is 12 ms of one GPU"),
             "value_resident": round(value, 3),
+            "two_files_in_flight": in_flight,
             "value_with_push": with_push,
             "run_marked_records": marked,
             "record_order_any": any_order or None,
@@ -1086,6 +1123,7 @@ def main():
             "any_order_grouping_frac": {k: v["grouping"]["frac"] for k, v in (any_order or {}).items()},
             "any_order_same_profile": all(v["same_profile_as_the_grouped_stream"] for v in (any_order or {}).values()) if any_order else None,
             "parity_in_run": parity_in_run["ok"] if parity_in_run else None,
+            "two_files_in_flight": (in_flight or {}).get("value"),
             "value_with_push": (with_push or {}).get("value"), "run_marked_with_push": ((marked or {}).get("with_push") or {}).get("value"),
             "cli_M_records_s": (cli or {}).get("value"), "cli_compression_ratio": (cli or {}).get("compression_ratio"),
             "cli_host_inflate_M_records_s": ((cli or {}).get("host_inflate") or {}).get("value"),

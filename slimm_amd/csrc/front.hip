@@ -492,12 +492,13 @@ __device__ __forceinline__ WinMasks window_fast(uint32_t field, uint32_t gbin, u
     // target is a head).  In bit-reversed order "the target in front of g" is "the first target above g".
     const uint64_t Fr = __builtin_bitreverse64(F), Gr = __builtin_bitreverse64(F & ~H);
     const uint64_t U = H & ~__builtin_bitreverse64((~Fr + (Gr << 1)) & Fr);
+    const bool uniq = f_bit(U);
     if (f_bit(F)) {
         // (the index in a vector register: the scalar unit is the kernel's bottleneck, and a scalar base per array costs
         // it two 64-bit adds and a shift per window)
         const uint32_t p = so.base + so.nf + f_rank(F);
         tgt_ref[p] = (field - 1u) | (f_bit(H) ? 0x80000000u : 0u);
-        tgt_gbin[p] = gbin | (f_bit(U) ? 0x80000000u : 0u);
+        tgt_gbin[p] = gbin | (uniq ? 0x80000000u : 0u);
     }
     so.nf += static_cast<uint32_t>(__popcll(F));
     so.nh += static_cast<uint32_t>(__popcll(H));

@@ -41,6 +41,14 @@ namespace slimm {
 
 namespace {
 
+#if defined(EXP) && EXP == 10  // cycle split of k_gb_scatter: wave 0's lane 0 of every workgroup (scripts/tprof_group.py)
+__device__ unsigned long long g_prof_g[8 * 1024];
+#define GPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define GPROF_ADD(slot, a, b) if (threadIdx.x == 0) g_prof_g[(blockIdx.x & 1023u) * 8 + slot] += (b) - (a)
+#else
+#define GPROF_T(x)
+#define GPROF_ADD(slot, a, b)
+#endif
 constexpr int kGBlock = 512;
 constexpr int kGWaves = kGBlock / 64;
 constexpr int kGItems = 8;
@@ -197,9 +205,15 @@ __global__ __launch_bounds__(kGroupMaxGrid) void k_gb_scan(uint32_t* __restrict_
 // ---------------------------------------------------------------------------------------------------------
 // dynamic LDS of k_gb_scatter, in 32-bit words: cursors + per-wave counts (16-bit, a spare per wave), rounded to 8 bytes
 __host__ __device__ constexpr uint32_t gb_lds_tables(uint32_t D) { return (D + (kGWaves * (D + 1u) + 1u) / 2u + 1u) & ~1u; }
-constexpr uint32_t kGMatchBits = 9;  // digits up to this width find their peers through a table of lane masks in LDS
+constexpr uint32_t kGMatchBits = 10;  // digits up to this width find their peers through a table of lane masks in LDS
+                                       // (10 bits, staged: 156 KB with the tables -- the stage alone makes it one workgroup per CU)
+constexpr uint32_t kGLdsWords = (160u * 1024u - 256u) / 4u;  // what a workgroup may ask for (a CU's LDS less the static arrays)
+// the lane-mask tables: up to kGMatchBits, where they fit beside the rest
+__host__ __device__ constexpr bool gb_match(uint32_t D, bool staged) {
+    return D <= (1u << kGMatchBits) && gb_lds_tables(D) + (staged ? 2u * D + 4u * kGRound : 0u) + 2u * kGWaves * D <= kGLdsWords;
+}
 __host__ __device__ constexpr uint32_t gb_lds_words(uint32_t D, bool staged) {
-    return gb_lds_tables(D) + (staged ? 2u * D + 4u * kGRound : 0u) + (D <= (1u << kGMatchBits) ? 2u * kGWaves * D : 0u);
+    return gb_lds_tables(D) + (staged ? 2u * D + 4u * kGRound : 0u) + (gb_match(D, staged) ? 2u * kGWaves * D : 0u);
 }
 
 // kStaged: the round's records go out ORDERED BY DIGIT through LDS -- a digit's records of the round are one run of
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
     // (kStaged) behind the tables: s_dstart[D] = where a digit's records start in the ordered round, s_gdelta[D] = global
     // place minus place in the round, then the round itself: identities, payloads
     // (bits <= kGMatchBits) behind those: s_match[kGWaves][D] 64-bit lane masks
-    const bool match = bits <= kGMatchBits;
+    const bool match = gb_match(D, kStaged);
     unsigned long long* const my_match = reinterpret_cast<unsigned long long*>(s_dyn + gb_lds_tables(D) + (kStaged ? 2u * D + 4u * kGRound : 0u)) + wave * D;
     uint32_t* const s_dstart = s_dyn + gb_lds_tables(D);
     uint32_t* const s_gdelta = s_dstart + D;
@@ -272,12 +286,13 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
     __syncthreads();
     uint32_t lo, hi;
     gb_stretch(src.count(counters), lo, hi);
-    for (uint32_t r0 = lo; r0 < hi; r0 += kGRound) {
-        // ---- the round's records: the wave's 512 consecutive ones in chunks of 64, all loads in flight together
-        uint64_t ident[kGItems];
-        uint2 pay[kGItems];
-        uint32_t chk[kGItems], aux[kGItems];
-        bool live[kGItems];
+    // ---- a round's records: the wave's 512 consecutive ones in chunks of 64, all loads in flight together.  (Asking for
+    // the NEXT round's behind the placement, so that they arrive while the round is written out: measured, no change --
+    // the kernel waits for the LDS pipe, scripts/tprof_group.py: peers + ranks 37 %, placement 30 %, write-out 20 %.)
+    uint64_t ident[kGItems];
+    uint2 pay[kGItems];
+    uint32_t chk[kGItems], aux[kGItems];
+    auto load_round = [&](uint32_t r0) {
         const uint32_t w0 = r0 + wave * kGWaveRecs;
 #pragma unroll
         for (int u = 0; u < kGItems; ++u) {
@@ -296,6 +311,12 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
                 chk[u] = kChk ? src.chk[i] : 0u;
             }
         }
+    };
+    for (uint32_t r0 = lo; r0 < hi; r0 += kGRound) {
+        GPROF_T(g0);
+        load_round(r0);
+        bool live[kGItems];
+        const uint32_t w0 = r0 + wave * kGWaveRecs;
         if constexpr (Src::kRaw) {
             // filter, identity, and the bin: one 8-byte gather of the contig's geometry per record (rows of unmapped
             // records gather row 0), uint32 wrap-around and clamp as src/slimm.hpp:200-201 (Q3)
@@ -317,6 +338,8 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
             for (int u = 0; u < kGItems; ++u) live[u] = w0 + u * 64u + lane < hi;
         }
         // ---- place inside the wave's records of the round, per digit, in file order
+        GPROF_T(g1);
+        GPROF_ADD(0, g0, g1);
         uint32_t dig[kGItems], place[kGItems];
 #pragma unroll
         for (int u = 0; u < kGItems; ++u) {
@@ -354,7 +377,11 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
             dig[u] = d;
             place[u] = before + rank;
         }
+        GPROF_T(g2);
+        GPROF_ADD(1, g1, g2);
         __syncthreads();
+        GPROF_T(g3);
+        GPROF_ADD(2, g2, g3);
         if constexpr (!kStaged) {
             // ---- the waves' counts of every digit -> each wave's offset inside the digit's records of the round
             uint32_t tot[kGMaxDigits / kGBlock > 0 ? kGMaxDigits / kGBlock : 1];
@@ -442,6 +469,8 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
                 run += tot[k];
             }
             __syncthreads();
+            GPROF_T(g4);
+            GPROF_ADD(3, g3, g4);
             // ---- the records into the ordered round
 #pragma unroll
             for (int u = 0; u < kGItems; ++u) {
@@ -452,6 +481,8 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
                 }
             }
             __syncthreads();
+            GPROF_T(g5);
+            GPROF_ADD(4, g4, g5);
             // ---- and out: consecutive lanes take consecutive places (the digit again from the identity)
 #pragma unroll
             for (int u = 0; u < kGItems; ++u) {
@@ -463,6 +494,8 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
                     pay_out[dst] = s_rpay[at];
                 }
             }
+            GPROF_T(g6);
+            GPROF_ADD(5, g5, g6);
 #pragma unroll
             for (uint32_t k = 0; k < kPer; ++k) {
                 const uint32_t d = tid * per + k;
@@ -472,6 +505,9 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
                 }
             }
             __syncthreads();
+            GPROF_T(g7);
+            GPROF_ADD(6, g6, g7);
+            GPROF_ADD(7, g0, g7);
         }
     }
 }
@@ -802,7 +838,7 @@ void launch_group_scan(hipStream_t st, const GroupJob& j, uint32_t pass) {
 static bool gb_staged(uint32_t width, bool has_chk) {
     if (has_chk) return false;
     if (const char* e = getenv("SLIMM_GROUP_STAGED")) return e[0] == '1';
-    return width <= 10u;
+    return width <= 10u && gb_lds_words(1u << width, true) <= kGLdsWords;
 }
 
 void launch_group_scatter(hipStream_t st, const GroupJob& j, uint32_t pass) {
@@ -849,10 +885,20 @@ void launch_group_finish(hipStream_t st, const GroupJob& j) {
 
 int group_init() {
     // dynamic LDS beyond 64 KB needs the attribute
-    const int lds = static_cast<int>(gb_lds_words(kGMaxDigits, true) * 4u);
+    uint32_t words = 0;  // the largest any width asks for (the lane-mask tables stop at kGMatchBits)
+    for (uint32_t w = 1; w <= kGroupMaxBits; ++w) {
+        words = std::max(words, gb_lds_words(1u << w, false));
+        if (w <= 10u && gb_lds_words(1u << w, true) <= kGLdsWords) words = std::max(words, gb_lds_words(1u << w, true));  // (gb_staged)
+    }
+    const int lds = static_cast<int>(words * 4u);
     hipError_t e = hipSuccess;
+    int nth = 0;
     auto set = [&](const void* f) {
-        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return;
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess)
+            fprintf(stderr, "slimm_hip: group_init: %d bytes of dynamic LDS for k_gb_scatter variant %d: %s\n", lds, nth, hipGetErrorString(e));
+        ++nth;
     };
     set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, true, false>));
     set(reinterpret_cast<const void*>(k_gb_scatter<GbRaw<true>, false, false>));
@@ -867,3 +913,14 @@ int group_init() {
 }
 
 }  // namespace slimm
+
+#if defined(EXP) && EXP == 10
+extern "C" int slimm_debug_prof_group(unsigned long long* out, int n, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_g), sizeof(unsigned long long) * n);
+    if (reset) {
+        static unsigned long long z[8 * 1024];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_g), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

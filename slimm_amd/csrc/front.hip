@@ -53,6 +53,15 @@
 
 namespace slimm {
 
+#if defined(EXP) && EXP == 11  // cycle split of k_front: lane 0 of every (one-wave) workgroup (scripts/tprof_front.py)
+__device__ unsigned long long g_prof_f[4 * 8192];
+#define FPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define FPROF_ADD(slot, a, b) if (threadIdx.x == 0) atomicAdd(&g_prof_f[(blockIdx.x & 8191u) * 4 + slot], (b) - (a))
+#else
+#define FPROF_T(x)
+#define FPROF_ADD(slot, a, b)
+#endif
+
 namespace {
 
 constexpr uint32_t kTagShift = 26;                       // a staged record's low 26 bits: reference + 1 (slimm_create
@@ -914,6 +923,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
             }
             cf = f;
         };
+        FPROF_T(f0);
         if (B < N) {
             // ---- 1. stage (the only part that waits for memory; everything a group loads is in flight at once)
             if (N - B >= kStageRecs)
@@ -924,6 +934,8 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
             // landed by now; said aloud, so that the compiler does not make each window wait for the stores of the
             // window before it on behalf of a register some load of the staging loop once wrote.)
             __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+            FPROF_T(f1);
+            FPROF_ADD(0, f0, f1);
             uint32_t off = next_run_start(st1, lane, 0u);
             so.base = B + min(off, kSlotRecs);
             while (off < kSlotRecs && B + off < N) {  // (the stream may end inside the slot)
@@ -984,6 +996,9 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                 }
             }
         }
+        FPROF_T(f2);
+        FPROF_ADD(1, f0, f2);
+        FPROF_ADD(2, f2, f2 + 1ull);  // (slots)
         if (lane == 0u) slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
         // the window list: lanes [0, nw) their windows, lane nw the totals, the last entry the number of windows
         if (lane == nw) {
@@ -1079,3 +1094,14 @@ void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident
 }
 
 }  // namespace slimm
+
+#if defined(EXP) && EXP == 11
+extern "C" int slimm_debug_prof_front(unsigned long long* out, int n, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_f), sizeof(unsigned long long) * n);
+    if (reset) {
+        static unsigned long long z[4 * 8192];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_f), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

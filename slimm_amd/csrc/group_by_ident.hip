@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kGBlock) void k_gb_scatter(const Src src, uint32_t*
 #pragma unroll
         for (int u = 0; u < kGItems; ++u) {
             const uint32_t d = (gb_mix(ident[u]) >> shift) & (D - 1u);
-            // the lanes of this chunk with my digit: up to 9-bit digits through the wave's own table of lane masks in LDS
+            // the lanes of this chunk with my digit: up to 10-bit digits through the wave's own table of lane masks in LDS
             // (everybody ORs its bit into its digit's entry, reads the entry back and clears it again: three LDS
             // operations whatever the digits), wider ones by a ballot per bit (6 vector + 2 scalar instructions each)
             uint64_t peers;

@@ -713,8 +713,8 @@ __global__ __launch_bounds__(kTBlock) void k_tile_scatter(const uint32_t* __rest
 // The direct rounds (k_tile_scatter) store every 2-byte entry from a register: one L2 write request per value, 617 M at
 // 1 B records -- about what the L2's channels take in the kernel's 2.4 ms -- beside one returning atomic per touched
 // tile and round of 16 K values.  Here a workgroup of kBigBlock threads (the ONE of its CU: the LDS is its own) takes
-// rounds of kBigBlock x kBigPieces values, and ONE table of a word per tile serves in turn as the round's histogram
-// of the round, as the tiles' cursors inside the stage (placement: a returning add), and as "global position of the tile's
+// rounds of kBigBlock x kBigPieces values, and ONE table of a word per tile serves in turn as the round's histogram,
+// as the tiles' cursors inside the stage (placement: a returning add), and as "global position of the tile's
 // run minus its offset in the stage" (write-out: consecutive lanes store consecutive bucket positions of one
 // tile -- a request per run, not per value).  Thread t owns tiles t, t + kBigBlock, ...: their counts, their reservations
 // (in registers between the steps) and their runs' places in the stage -- thread-major, so that the scan is over threads.
@@ -740,8 +740,8 @@ __global__ __launch_bounds__(kBigBlock) void k_tile_scatter_big(const uint32_t* 
     // s_tab[kE * kBigBlock] | 64 more entries, nobody's tiles: where a lane's "no value" counts | s_stage[kBigRound] | 64
     // more words, where a lane's "no value" is put -- the rounds' LDS operations are issued unconditionally, batch after
     // batch (a value behind `if (there is one)` is a branch, and a returning LDS atomic inside a branch is waited for
-    // inside it).  An entry per LANE: a slot's last piece is short, every round has a fifth of its lanes without a value,
-    // and one shared entry would take them one after the other.
+    // inside it).  An entry per LANE: lanes without a value (behind a slot's short last piece: up to a fifth of a round's
+    // before piece_load_packed) would meet in one shared entry and take it one after the other -- measured: 3 x slower.
     HIP_DYNAMIC_SHARED(uint32_t, s_dyn)
     __shared__ uint32_t s_more[kBigBlock / 64], s_wtot[kBigBlock / 64];
     constexpr uint32_t kNoTile = kE * kBigBlock;

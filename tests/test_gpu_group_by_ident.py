@@ -22,6 +22,8 @@ PLANS = [  # (SLIMM_GROUP_BITS, SLIMM_GROUP_WIDTH, SLIMM_GROUP_GRID); None = the
     (3, 3, 5),
     (6, 2, 1),       # three passes of two bits in ONE stretch: many rounds per workgroup
     (11, 11, 7),     # the widest digit
+    (20, 10, 512),   # 10-bit digits: the widest with lane-mask tables and an ordered round (156 KB of LDS)
+    (27, 9, 64),     # three passes of nine bits (the plan of 100 M records)
     (12, 4, 512),
     (22, 11, 64),
     (24, 8, 3),

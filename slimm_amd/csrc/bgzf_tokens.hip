@@ -16,12 +16,17 @@
 //                      The input comes through a 128-bit reservoir per lane that takes 8 unaligned bytes per step, asked
 //                      for one step ahead; the stores of a step are issued at the top of the next one, behind the wait for
 //                      that load (on this hardware a wait for a load is a wait for every store issued before it).
-//   k_inflate_resolve  a WORKGROUP per block, the block's 64 KB in LDS: the holes are filled in chunks of <= 4 KB of output
-//                      -- every byte of a match gets a pointer to its source byte, pointer JUMPING (log2 of the longest
-//                      chain of matches copying matches, <= 12 rounds) brings every pointer to a literal or to a byte in
-//                      front of the chunk, one gather finishes the chunk.  No byte waits for another lane's copy loop.
-//                      Then the CRC32 of the gzip trailer (256 segments in parallel, combined with x^(8n) mod P like zlib's
-//                      crc32_combine) and the block written out in 16-byte stores.
+//   k_inflate_resolve  a WORKGROUP of 512 threads per block, the block's 64 KB in LDS: the holes are filled in chunks of <= 4 KB
+//                      of output.  A token leaves two 16-bit MARKERS in a table of the chunk's bytes (where its literals
+//                      begin, where its match begins: the distance); every thread carries the markers forward over 8
+//                      consecutive bytes (registers, a DPP scan over the wave, one word per wave through LDS) and turns them
+//                      into a pointer per byte -- no loop over a token's bytes, whose longest the lanes of a wave would
+//                      wait for.  Pointer JUMPING, two jumps per barrier, brings every pointer to a literal or to a byte in
+//                      front of the chunk (a pointer carries a bit that says so: no round that only confirms; log4 of the
+//                      longest chain of matches copying matches), one gather finishes the chunk.  No byte waits for another
+//                      lane's copy loop.  Then the CRC32 of the gzip trailer (512 segments in parallel; crc32_combine is
+//                      linear: every segment's CRC times x^(8 * the bytes behind it) from a table, XORed up) and the block
+//                      written out in 16-byte stores.
 //
 // What the fast path does not do it hands to bgzf_inflate.hip's kernel block by block (info.flag): stored DEFLATE blocks,
 // and ANY irregularity -- a bad code, a distance beyond the output, a CRC that does not match.  That kernel decides what is
@@ -58,6 +63,9 @@ constexpr uint32_t kLaneBytes = 520;
 typedef uint16_t __attribute__((may_alias)) u16a;
 typedef uint32_t __attribute__((may_alias)) u32a;
 typedef int16_t __attribute__((may_alias)) i16a;
+struct __attribute__((may_alias, aligned(8))) uint2a {
+    uint32_t x, y;
+};
 
 struct Lds {
     uint8_t* p;      // the workgroup's table memory
@@ -505,7 +513,57 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------------------ phase 2: resolve
 namespace {
 
-constexpr uint32_t kChunk = 4096;  // output bytes of a chunk (a 16-bit pointer each)
+#if defined(EXP) && EXP == 11  // cycle split of k_inflate_resolve: thread 0 of every workgroup (scripts/tprof_resolve.py)
+__device__ unsigned long long g_prof_r[16 * 1024];
+#define RPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define RPROF_ADD(slot, a, b) if (threadIdx.x == 0) g_prof_r[(blockIdx.x & 1023u) * 16 + slot] += (b) - (a)
+#define RPROF_INC(slot, n) if (threadIdx.x == 0) g_prof_r[(blockIdx.x & 1023u) * 16 + slot] += (n)
+#else
+#define RPROF_T(x)
+#define RPROF_ADD(slot, a, b)
+#define RPROF_INC(slot, n)
+#endif
+constexpr uint32_t kRThreads = 512;                  // threads of a resolve workgroup = the tokens a chunk can take
+constexpr uint32_t kRWaves = kRThreads / 64;
+constexpr uint32_t kPer = 8;                          // output bytes of a chunk per thread (a multiple of 4)
+constexpr uint32_t kJumps = 2;                        // pointer jumps per round and barrier
+constexpr uint32_t kChunk = kRThreads * kPer;         // output bytes of a chunk (a 16-bit pointer each); 64 KB + 8 KB: two workgroups per CU
+constexpr uint32_t kSegLog2 = 7, kSeg = 1u << kSegLog2;   // CRC segment of a thread: 65536 / kRThreads bytes
+constexpr uint32_t kWinLoads = 65536 / 16 / kRThreads;
+constexpr uint32_t kFinal = 0x4000;   // a pointer inside the chunk that is at a literal (pointers in front of the chunk are negative: bit 15)
+static_assert(kChunk <= kFinal && kPer % 4 == 0 && kSeg * kRThreads >= 65536, "");
+
+// inclusive scans over the 64 lanes of a wave with DPP moves (no LDS round trips as with ds_bpermute shuffles)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// "the nearest non-zero value at or in front of the lane" (0: none).  (The choice as arithmetic, not as `v ? v : u`: the host
+// emulator's compiler clones the next move behind such a branch, and the lanes of a wave no longer meet at one call site.)
+__device__ __forceinline__ uint32_t keep_or(uint32_t v, uint32_t u) { return v | (u & (0u - static_cast<uint32_t>(v == 0u))); }
+__device__ __forceinline__ uint32_t wave_scan_last(uint32_t v) {
+    v = keep_or(v, __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true));
+    v = keep_or(v, __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true));
+    v = keep_or(v, __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true));
+    v = keep_or(v, __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true));
+    v = keep_or(v, __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true));
+    v = keep_or(v, __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_xor(uint32_t v) {   // lane 63: the XOR over the wave
+    v ^= __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);
+    v ^= __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);
+    v ^= __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);
+    v ^= __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);
+    v ^= __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, true);
+    v ^= __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
 constexpr uint32_t kPoly = 0xedb88320u;
 
 // zlib's multmodp: a(x) * b(x) mod P(x), reflected representation (bit 31 = x^0)
@@ -528,6 +586,20 @@ __host__ __device__ constexpr CrcPowers crc_powers() {
     return t;
 }
 __device__ const CrcPowers kX2n = crc_powers();
+struct CrcSegPowers {
+    uint32_t v[512];  // x^(8 * kSeg * m) mod P, m = 0 .. 511
+};
+__host__ __device__ constexpr CrcSegPowers crc_seg_powers(uint32_t log2_bits) {
+    CrcSegPowers t{};
+    uint32_t step = 1u << 30;  // x^1 -> x^(2^log2_bits)
+    for (uint32_t k = 0; k < log2_bits; ++k) step = multmodp(step, step);
+    uint32_t p = 1u << 31;  // x^0
+    for (int m = 0; m < 512; ++m) {
+        t.v[m] = p;
+        p = multmodp(p, step);
+    }
+    return t;
+}
 // x^(8 n) mod P
 __device__ uint32_t x8n(uint32_t n) {
     uint32_t p = 1u << 31;  // x^0
@@ -536,18 +608,22 @@ __device__ uint32_t x8n(uint32_t n) {
     return p;
 }
 
+__device__ const CrcSegPowers kXSeg = crc_seg_powers(kSegLog2 + 3u);
+static_assert(kRThreads <= 512, "kXSeg");
+
 }  // namespace
 
-__global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out,
-                                                         const uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
+__global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* __restrict__ blocks, uint32_t n_blocks, uint8_t* __restrict__ out,
+                                                               const uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
     __shared__ uint4 s_win4[65536 / 16];
-    __shared__ uint32_t s_ptr32[kChunk / 2];  // 16-bit pointers; the CRC tables afterwards
-    __shared__ uint32_t s_scan[16];
+    __shared__ uint4 s_ptr4[kChunk * 2 / 16];  // 16-bit markers, then pointers; the CRC tables afterwards
+    __shared__ uint32_t s_scan[4 * kRWaves + 1];
     __shared__ uint32_t s_flag[4];
     __shared__ uint32_t s_crc[256];
     uint8_t* const win = reinterpret_cast<uint8_t*>(s_win4);
-    i16a* const ptr = reinterpret_cast<i16a*>(s_ptr32);
-    u32a* const ptr32 = reinterpret_cast<u32a*>(s_ptr32);
+    u16a* const mark = reinterpret_cast<u16a*>(s_ptr4);
+    u32a* const ptr32 = reinterpret_cast<u32a*>(s_ptr4);
+    uint2a* const mine8 = reinterpret_cast<uint2a*>(s_ptr4) + threadIdx.x * (kPer / 4u);   // this thread's kPer consecutive pointers
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t b = blockIdx.x;
     if (b >= n_blocks) return;
@@ -557,18 +633,33 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
     const uint32_t isize = d.isize;
     uint8_t* const o_base = out + d.dst;
     const uint32_t* const t_base = tok + d.tok;
-    for (uint32_t i = tid * 16u; i < isize; i += 4096u) {
-        uint4 v;
-        __builtin_memcpy(&v, o_base + i, 16);  // (up to 15 bytes behind the block: the next block's, or the buffer's slack)
-        s_win4[i >> 4] = v;
+    RPROF_T(c_start);
+    {   // the block as phase 1 left it (literals in place, holes where matches go): all of a thread's loads in flight together
+        uint4 w[kWinLoads];
+#pragma unroll
+        for (uint32_t k = 0; k < kWinLoads; ++k) {
+            const uint32_t i = (tid + k * kRThreads) * 16u;
+            w[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < isize) __builtin_memcpy(&w[k], o_base + i, 16);  // (up to 15 bytes behind the block: the next block's, or the buffer's slack)
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kPer / 4u; ++k) mine8[k] = uint2a{0u, 0u};   // no marker anywhere
+#pragma unroll
+        for (uint32_t k = 0; k < kWinLoads; ++k) {
+            const uint32_t i = (tid + k * kRThreads) * 16u;
+            if (i < isize) s_win4[i >> 4] = w[k];
+        }
     }
     if (tid < 4u) s_flag[tid] = 0;   // [0 .. 2]: "some pointer moved" of the jumping rounds, in turn; [3]: something is wrong
     __syncthreads();
     uint32_t base = 0, t0 = 0, rr = 0;
     bool wrong = false;
+    RPROF_T(c_loaded);
+    RPROF_ADD(0, c_start, c_loaded);
     uint32_t tv_next = tid < nf.n_tok ? t_base[tid] : 0x80000000u;   // (the next chunk's token is asked for while this one is filled)
     while (t0 < nf.n_tok) {
         // a token per thread, the spans' running sum
+        RPROF_T(c0);
         const uint32_t t = t0 + tid;
         const uint32_t tv = tv_next;
         const bool skip = (tv >> 31) != 0u;
@@ -576,14 +667,12 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         const uint32_t mlen = skip ? 0u : ((tv >> 15) & 0xffu) + 3u;
         const uint32_t dist = (tv & 0x7fffu) + 1u;
         const uint32_t span = litrun + mlen;
-        uint32_t incl = span;
-        for (uint32_t s = 1; s < 64u; s <<= 1) {
-            const uint32_t up = __shfl_up(incl, s);
-            if (lane >= s) incl += up;
-        }
+        uint32_t incl = wave_scan_add(span);
         if (lane == 63u) s_scan[wv] = incl;
-        if (tid == 0) s_scan[12] = span;
+        if (tid == 0) s_scan[4 * kRWaves] = span;
         __syncthreads();
+        RPROF_T(c1);
+        RPROF_ADD(1, c0, c1);
         uint32_t before = 0;
         for (uint32_t k = 0; k < wv; ++k) before += s_scan[k];
         incl += before;
@@ -593,33 +682,36 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         const uint32_t cnt = static_cast<uint32_t>(__popcll(mine));
         const uint32_t top = __shfl(incl, static_cast<int>(cnt ? cnt - 1u : 0u));
         if (lane == 0) {
-            s_scan[4 + wv] = cnt;
-            s_scan[8 + wv] = cnt ? top : 0u;
+            s_scan[kRWaves + wv] = cnt;
+            s_scan[2 * kRWaves + wv] = cnt ? top : 0u;
         }
-        // every byte of the token's span gets a pointer: a literal to itself, a byte of the match to the byte `dist` in front
-        // of it (relative to the chunk: negative = an earlier chunk's byte)
+        // a token leaves MARKERS where its literals and its match begin: 1 = literals from here on, dist + 1 = bytes copied from
+        // `dist` in front of themselves from here on.  (Every byte of the chunk lies behind a marker: a token that has neither
+        // literals nor a match covers no byte.)  No loop over a token's bytes: the lanes of a wave would wait for its longest.
         if (in_chunk) {
             const uint32_t e0 = incl - span, d0 = incl - mlen;
-            for (uint32_t k = e0; k < d0; ++k) ptr[k] = static_cast<int16_t>(k);
+            if (litrun) mark[e0] = 1u;
             if (mlen) {
-                if (base + d0 < dist) {
-                    s_flag[3] = 1;
-                    for (uint32_t k = 0; k < mlen; ++k) ptr[d0 + k] = static_cast<int16_t>(d0 + k);
-                } else {
-                    const int32_t from = static_cast<int32_t>(d0) - static_cast<int32_t>(dist);
-                    for (uint32_t k = 0; k < mlen; ++k) ptr[d0 + k] = static_cast<int16_t>(from + static_cast<int32_t>(k));
-                }
+                mark[d0] = static_cast<uint16_t>(dist + 1u);
+                if (base + d0 < dist) s_flag[3] = 1;   // a distance beyond the start of the output
             }
         }
         __syncthreads();
-        const uint32_t n_act = s_scan[4] + s_scan[5] + s_scan[6] + s_scan[7];
-        const uint32_t S = max(max(s_scan[8], s_scan[9]), max(s_scan[10], s_scan[11]));
+        RPROF_T(c2);
+        RPROF_ADD(2, c1, c2);
+        RPROF_INC(8, 1);
+        uint32_t n_act = 0, S = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kRWaves; ++k) {
+            n_act += s_scan[kRWaves + k];
+            S = max(S, s_scan[2 * kRWaves + k]);
+        }
         {
             const uint32_t tn = t0 + (n_act ? n_act : 1u) + tid;
             tv_next = tn < nf.n_tok ? t_base[tn] : 0x80000000u;
         }
-        if (n_act == 0) {  // the first token is a run of literals longer than a chunk: nothing to fill
-            const uint32_t first_span = s_scan[12];
+        if (n_act == 0) {  // the first token is a run of literals longer than a chunk: nothing to fill (and no marker was left)
+            const uint32_t first_span = s_scan[4 * kRWaves];
             __syncthreads();
             base += first_span;
             t0 += 1;
@@ -633,66 +725,134 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             wrong = true;
             break;
         }
-        // pointer jumping: until every pointer is at a literal (points at itself) or in front of the chunk.  A thread keeps the
-        // pointers of its 16 bytes (j = tid + 256 k) in registers: a round is one LDS read per byte, all 16 in flight together.
-        // The rounds' "some pointer moved" words take turns (three: the one a round sets was cleared two barriers ago)
-        int32_t pj[16];
+        // the markers carried forward, a thread over its kPer consecutive bytes: the last marker at or in front of each byte.
+        // Inside the thread in registers, across the wave's threads by a scan of "the right one unless it is empty", across the
+        // waves through LDS.  Then every byte's pointer: a literal to itself with the kFinal bit, a byte of a match to the byte
+        // `dist` in front of it (relative to the chunk: negative = an earlier chunk's byte); behind the chunk's end: -1.
+        {
+            uint32_t m[kPer];
 #pragma unroll
-        for (uint32_t k = 0; k < 16u; ++k) {
-            const uint32_t j = tid + 256u * k;
-            pj[k] = j < S ? static_cast<int32_t>(ptr[j]) : -1;
-        }
-        for (;;) {
-            int32_t q[16];
+            for (uint32_t k = 0; k < kPer / 4u; ++k) {
+                const uint2a v = mine8[k];
+                m[4 * k] = v.x & 0xffffu;
+                m[4 * k + 1] = v.x >> 16;
+                m[4 * k + 2] = v.y & 0xffffu;
+                m[4 * k + 3] = v.y >> 16;
+            }
+            uint32_t last = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) q[k] = pj[k] >= 0 ? static_cast<int32_t>(ptr[pj[k]]) : pj[k];
-            bool changed = false;
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) {
-                if (q[k] != pj[k]) {
-                    pj[k] = q[k];
-                    ptr[tid + 256u * k] = static_cast<int16_t>(q[k]);
-                    changed = true;
+            for (uint32_t k = 0; k < kPer; ++k) {
+                last = keep_or(m[k], last);
+                m[k] = last;
+            }
+            const uint32_t carry = wave_scan_last(last);   // inclusive over the wave's threads
+            if (lane == 63u) s_scan[3 * kRWaves + wv] = carry;
+            uint32_t in = __builtin_amdgcn_update_dpp(0u, carry, 0x138, 0xf, 0xf, true);   // wave_shr:1 (lane 0: none)
+            __syncthreads();
+            if (in == 0) {
+                for (uint32_t k = 0; k < wv; ++k) {   // (the nearest earlier wave that saw a marker)
+                    const uint32_t c = s_scan[3 * kRWaves + k];
+                    in = c ? c : in;
                 }
             }
+            uint32_t pw[kPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const uint32_t j = tid * kPer + k;
+                const uint32_t v = m[k] ? m[k] : in;
+                const uint32_t pp = v > 1u ? j - (v - 1u) : j | kFinal;
+                pw[k] = (j < S ? pp : 0xffffffffu) & 0xffffu;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kPer / 4u; ++k)
+                mine8[k] = uint2a{pw[4 * k] | (pw[4 * k + 1] << 16), pw[4 * k + 2] | (pw[4 * k + 3] << 16)};
+        }
+        __syncthreads();
+        // pointer jumping: until every pointer is FINAL -- at a literal (kFinal bit) or in front of the chunk (negative).  A thread
+        // keeps the pointers of its kPer bytes (j = tid + kRThreads k) in registers; a round replaces a pointer by the pointer
+        // found where it points (one LDS read, all of a thread's in flight together) and learns from that word's own bits
+        // whether it is final now: no round that only confirms.  Reads and writes are not ordered against each other: whatever
+        // a pointer's place holds is a pointer to a byte of the same value.  The rounds' "some pointer is not final" words take
+        // turns (three: the one a round sets was cleared two barriers ago)
+        uint32_t pj[kPer];
+        bool moving = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t j = tid + kRThreads * k;
+            pj[k] = j < S ? static_cast<uint32_t>(mark[j]) : 0xffffu;
+            moving = moving | ((pj[k] & 0xc000u) == 0u);
+        }
+        RPROF_T(c3);
+        RPROF_ADD(3, c2, c3);
+        for (;;) {
             const uint32_t slot = rr % 3u;
-            if (changed) s_flag[slot] = 1;
+            if (moving) s_flag[slot] = 1;
             if (tid == 0) s_flag[(rr + 1u) % 3u] = 0;
             __syncthreads();
             ++rr;
             if (!s_flag[slot]) break;
-        }
-        {
-            uint8_t v[16];
+            RPROF_INC(9, 1);
+            // kJumps jumps per round and barrier, every lane the same instructions (a final pointer reads some word and keeps itself)
+            uint32_t q[kPer];
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) {
-                const uint32_t j = tid + 256u * k;
-                v[k] = j < S ? win[static_cast<int32_t>(base) + pj[k]] : 0;
+            for (uint32_t k = 0; k < kPer; ++k) q[k] = mark[pj[k] & (kFinal - 1u)];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) q[k] = (pj[k] & 0xc000u) ? pj[k] : q[k];
+            uint32_t q2[kPer];
+            if (kJumps > 1u) {
+#pragma unroll
+                for (uint32_t k = 0; k < kPer; ++k) q2[k] = mark[q[k] & (kFinal - 1u)];
+            }
+            moving = false;
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const uint32_t r = (kJumps > 1u && (q[k] & 0xc000u) == 0u) ? q2[k] : q[k];
+                if ((pj[k] & 0xc000u) == 0u) mark[tid + kRThreads * k] = static_cast<uint16_t>(r);
+                pj[k] = r;
+                moving = moving | ((r & 0xc000u) == 0u);
+            }
+        }
+        RPROF_T(c4);
+        RPROF_ADD(4, c3, c4);
+        {
+            // (nobody reads a pointer from LDS any more: the next chunk's markers want the table empty)
+#pragma unroll
+            for (uint32_t k = 0; k < kPer / 4u; ++k) mine8[k] = uint2a{0u, 0u};
+            // every byte of the chunk from where its pointer ends (a literal takes its own value again)
+            uint8_t v[kPer];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const int32_t t = static_cast<int32_t>(pj[k] << 16) >> 16;
+                const int32_t off = t & (static_cast<int32_t>(kFinal - 1u) | (t >> 31));   // negative: as it is; else without the kFinal bit
+                v[k] = win[max(static_cast<int32_t>(base) + off, 0)];   // (below 0: a block that is handed over; behind S: not stored)
             }
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) {
-                const uint32_t j = tid + 256u * k;
-                if (j < S && pj[k] != static_cast<int32_t>(j)) win[base + j] = v[k];
+            for (uint32_t k = 0; k < kPer; ++k) {
+                const uint32_t j = tid + kRThreads * k;
+                if (j < S) win[base + j] = v[k];
             }
         }
         __syncthreads();
+        RPROF_T(c5);
+        RPROF_ADD(5, c4, c5);
         base += S;
         t0 += n_act;
     }
     __syncthreads();
+    RPROF_T(c_crc);
     if (wrong || s_flag[3]) {
         if (tid == 0) info[b].flag = 1;
         return;
     }
-    // ---- the gzip trailer's CRC32: segments of 256 bytes, one per thread, combined like zlib's crc32_combine
-    for (uint32_t i = tid; i < 256u; i += 256u) {
-        uint32_t c = i;
+    // ---- the gzip trailer's CRC32: segments of 128 bytes, one per thread, combined like zlib's crc32_combine
+    if (tid < 256u) {
+        uint32_t c = tid;
         for (int k = 0; k < 8; ++k) c = (c & 1u) ? kPoly ^ (c >> 1) : c >> 1;
-        s_crc[i] = c;
+        s_crc[tid] = c;
     }
     __syncthreads();
     u32a* const t4 = ptr32;  // slice-by-4 tables 1 .. 3 (table 0 = s_crc)
-    {
+    if (tid < 256u) {
         uint32_t c = s_crc[tid];
         for (uint32_t k = 0; k < 3u; ++k) {
             c = s_crc[c & 0xffu] ^ (c >> 8);
@@ -700,10 +860,10 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         }
     }
     __syncthreads();
-    const uint32_t n_seg = (isize + 255u) >> 8;
+    const uint32_t n_seg = (isize + kSeg - 1u) / kSeg;
     uint32_t crc = 0;
     if (tid < n_seg) {
-        const uint32_t lo = tid << 8, hi = min(isize, lo + 256u);
+        const uint32_t lo = tid * kSeg, hi = min(isize, lo + kSeg);
         uint32_t c = 0xffffffffu, i = lo;
         const u32a* w32 = reinterpret_cast<const u32a*>(win);
         for (; i + 4u <= hi; i += 4u) {
@@ -714,29 +874,20 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         crc = ~c;
     }
     __syncthreads();
-    // the full segments (all but the last) in a tree, right-aligned among 256 leaves; then the last one behind them
-    u32a* const leaf = ptr32 + 1024;
+    // crc32_combine is linear: the CRC of the full segments (all but the last) = the XOR of every segment's CRC times
+    // x^(8 * the bytes behind it) -- one product per thread, its factor from a table; then the last segment behind them
     const uint32_t n_full = n_seg ? n_seg - 1u : 0u;
-    leaf[tid] = 0;
+    uint32_t part = 0;
+    if (tid < n_full) part = multmodp(kXSeg.v[n_full - 1u - tid], crc);
+    part = wave_xor(part);
+    if (lane == 63u) s_scan[wv] = part;
+    if (tid == n_seg - 1u && n_seg) s_scan[kRWaves] = crc;
     __syncthreads();
-    if (tid < n_full) leaf[tid + (256u - n_full)] = crc;
-    if (tid == n_seg - 1u && n_seg) s_scan[0] = crc;
-    __syncthreads();
-    for (uint32_t lv = 0; lv < 8u; ++lv) {   // the right child covers 256 << lv bytes: shift the left one by x^(8 * 256 << lv)
-        const uint32_t n = 128u >> lv;
-        uint32_t v = 0;
-        if (tid < n) {
-            const uint32_t a = leaf[2u * tid], bb = leaf[2u * tid + 1u];
-            v = (a ? multmodp(kX2n.v[(11u + lv) & 31u], a) : 0u) ^ bb;
-        }
-        __syncthreads();
-        if (tid < n) leaf[tid] = v;
-        __syncthreads();
-    }
     if (tid == 0) {
-        const uint32_t last_len = isize - (n_full << 8);
-        const uint32_t head = leaf[0];
-        const uint32_t all = n_seg ? ((head ? multmodp(x8n(last_len), head) : 0u) ^ s_scan[0]) : 0u;
+        uint32_t head = 0;
+        for (uint32_t k = 0; k < kRWaves; ++k) head ^= s_scan[k];
+        const uint32_t last_len = isize - n_full * kSeg;
+        const uint32_t all = n_seg ? ((head ? multmodp(x8n(last_len), head) : 0u) ^ s_scan[kRWaves]) : 0u;
         s_flag[3] = all == d.crc ? 0u : 1u;
     }
     __syncthreads();
@@ -744,7 +895,9 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
         if (tid == 0) info[b].flag = 1;
         return;
     }
-    for (uint32_t i = tid * 16u; i < isize; i += 4096u) {
+    RPROF_T(c_out);
+    RPROF_ADD(6, c_crc, c_out);
+    for (uint32_t i = tid * 16u; i < isize; i += kRThreads * 16u) {
         if (i + 16u <= isize) {
             const uint4 v = s_win4[i >> 4];
             __builtin_memcpy(o_base + i, &v, 16);
@@ -752,6 +905,9 @@ __global__ __launch_bounds__(256) void k_inflate_resolve(const BgzfBlock* __rest
             for (uint32_t k = i; k < isize; ++k) o_base[k] = win[k];
         }
     }
+    RPROF_T(c_end);
+    RPROF_ADD(7, c_out, c_end);
+    RPROF_ADD(10, c_start, c_end);
 }
 
 size_t bgzf_inflate_scratch_bytes(uint32_t n_blocks, uint64_t token_words) {
@@ -771,8 +927,19 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* b
     s += (static_cast<size_t>(n_blocks) * sizeof(InflateInfo) + 255u) & ~static_cast<size_t>(255u);
     uint32_t* tok = reinterpret_cast<uint32_t*>(s);
     hipLaunchKernelGGL(k_inflate_decode, dim3((n_blocks + 63u) / 64u), dim3(64), 0, st, comp, blocks, n_blocks, out, tok, info);
-    hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(256), 0, st, blocks, n_blocks, out, tok, info);
+    hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(kRThreads), 0, st, blocks, n_blocks, out, tok, info);
     launch_bgzf_inflate_lanes(st, comp, blocks, n_blocks, out, lanes_scratch, bgzf_inflate_grid(n_blocks), status, info);
 }
 
 }  // namespace slimm
+
+#if defined(EXP) && EXP == 11
+extern "C" int slimm_debug_prof_resolve(unsigned long long* out, int n, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_r), sizeof(unsigned long long) * n);
+    if (reset) {
+        static unsigned long long z[16 * 1024];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_r), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif

@@ -57,8 +57,11 @@ def decode(br, h):
 def tokens(payload):
     """[(literal run, match length, distance)] of one raw DEFLATE stream"""
     br, out, run = Bits(payload), [], 0
+    global N_DEFLATE_BLOCKS
+    N_DEFLATE_BLOCKS = 0
     while True:
         last, typ = br.get(1), br.get(2)
+        N_DEFLATE_BLOCKS += 1
         if typ == 0:
             br.pos = (br.pos + 7) & ~7
             n = br.get(16)
@@ -140,6 +143,6 @@ while p + 18 <= len(blob) and k < n_blocks + 2:
             return c
         print(f"block {k}: {isize} B, {lit} literals ({100 * lit / isize:.0f} %), {len(m)} matches, mean length {ml.mean():.1f} (max {ml.max()}), "
               f"median distance {int(np.median(md))}, {over} overlap themselves, longest literal run {runs.max()}, "
-              f"tokens per 4 KB {len(t) * 4096 / isize:.0f}, chunks with 256 tokens {chunks(256)}, with 512 {chunks(512)}, with 1024 {chunks(1024)}")
+              f"{N_DEFLATE_BLOCKS} DEFLATE blocks, tokens per 4 KB {len(t) * 4096 / isize:.0f}, chunks with 256 tokens {chunks(256)}, with 512 {chunks(512)}, with 1024 {chunks(1024)}")
     p += bs
     k += 1

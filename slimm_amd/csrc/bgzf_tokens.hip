@@ -159,6 +159,19 @@ __device__ __forceinline__ uint32_t symbol_at(const Lds& L, uint32_t base_at, ui
 
 enum : uint32_t { kModeHeader = 0, kModeDecode = 1, kModeDone = 2, kModeHandOver = 3 };
 
+#if defined(EXP) && EXP == 12  // cycle split of k_inflate_decode's steps: lane 0 of every wave (scripts/tprof_decode.py)
+__device__ unsigned long long g_prof_d[8 * 1024];
+#define DPROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define DPROF_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define DPROF_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define DPROF_ADD(slot, a, b) if (threadIdx.x == 0) g_prof_d[(blockIdx.x & 1023u) * 8 + slot] += (b) - (a)
+#else
+#define DPROF_T(x)
+#define DPROF_WAIT_VM()
+#define DPROF_WAIT_ALL()
+#define DPROF_ADD(slot, a, b)
+#endif
+
 // One lane's view of its block while headers are read: plain bit taking with the load waited for on the spot (a header is
 // a few hundred bits per ~16 K symbols).
 struct HeaderBits {
@@ -367,14 +380,18 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
     // stores waiting for the top of the next step
     uint32_t p_lit = 0, p_lit_at = 0, p_lit_n = 0, p_tok0 = 0, p_tok1 = 0, p_ntok = 0, p_tok_at = 0;
 
+    DPROF_T(d_start);
     for (;;) {
         const uint64_t want = __ballot(mode == kModeHeader);
         const uint64_t going = __ballot(mode == kModeDecode);
         if (!want && !going) break;
         if (want && (!going || __popcll(want) >= 8)) {
+            DPROF_T(h0);
             if (mode == kModeHeader) {
                 mode = read_header(bits, in, csize, L, LL, DL, last);
             }
+            DPROF_T(h1);
+            DPROF_ADD(5, h0, h1);
             continue;
         }
         // a burst of uniform steps
@@ -382,6 +399,10 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
         if (mode == kModeDecode) ahead = ld64u(in + bits.rp);   // (the first step's refill)
         for (uint32_t it = 0; it < 16u; ++it) {
             const bool run = mode == kModeDecode;
+            DPROF_T(s0);
+            DPROF_WAIT_VM();
+            DPROF_T(s1);
+            DPROF_ADD(0, s0, s1);
             // the input asked for a step ago; the stores of the step before behind it
             if (run) bits.refill(ahead);
             if (run) ahead = ld64u(in + bits.rp);
@@ -409,6 +430,9 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
             const uint32_t sym = L.b8(kLsymLo, idx) | (((L.b32(kLsymHi, idx >> 5) >> (idx & 31u)) & 1u) << 8);
             bool bad = len > 15u;
             uint32_t c = len;
+            DPROF_WAIT_ALL();
+            DPROF_T(s2);
+            DPROF_ADD(1, s1, s2);
             const bool is_lit = sym < 256u, is_eob = sym == 256u, is_len = sym > 256u;
             const uint32_t ls = is_len ? sym - 257u : 0u;
             bad = bad | (ls > 28u);
@@ -425,6 +449,9 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
             const uint32_t i2 = min(symbol_at(L, is_lit ? kLbase : kDbase, y, l2), is_lit ? 287u : 31u);
             const uint32_t s2lo = L.b8(is_lit ? kLsymLo : kDsym, i2);
             const uint32_t s2hi = (L.b32(kLsymHi, (i2 >> 5) & 15u) >> (i2 & 31u)) & 1u;
+            DPROF_WAIT_ALL();
+            DPROF_T(s3);
+            DPROF_ADD(2, s2, s3);
             // behind a literal: a second literal?
             const bool lit2 = is_lit & (l2 <= 15u) & (s2hi == 0u);
             // behind a length: the distance
@@ -484,6 +511,10 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
                     mode = last ? kModeDone : kModeHeader;
                 }
             }
+            DPROF_T(s4);
+            DPROF_ADD(3, s3, s4);
+            DPROF_ADD(4, s4, s4 + 1);
+            DPROF_ADD(7, s4, s4 + ((run & lit2) ? 1u : 0u));   // (lane 0's literal pairs)
         }
         // (what the burst's last step left to be stored)
         if (p_lit_n) {
@@ -500,6 +531,8 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
             p_ntok = 0;
         }
     }
+    DPROF_T(d_end);
+    DPROF_ADD(6, d_start, d_end);
     if (have) {
         // the stream must end exactly at ISIZE bytes and inside the payload
         if (mode == kModeDone && (o != isize || (bits.at_bit() + 7u) / 8u > csize)) mode = kModeHandOver;
@@ -933,6 +966,16 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* b
 
 }  // namespace slimm
 
+#if defined(EXP) && EXP == 12
+extern "C" int slimm_debug_prof_decode(unsigned long long* out, int n, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_d), sizeof(unsigned long long) * n);
+    if (reset) {
+        static unsigned long long z[8 * 1024];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_d), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 #if defined(EXP) && EXP == 11
 extern "C" int slimm_debug_prof_resolve(unsigned long long* out, int n, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_r), sizeof(unsigned long long) * n);

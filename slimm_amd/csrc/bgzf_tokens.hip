@@ -561,10 +561,11 @@ constexpr uint32_t kRWaves = kRThreads / 64;
 constexpr uint32_t kPer = 8;                          // output bytes of a chunk per thread (a multiple of 4)
 constexpr uint32_t kJumps = 2;                        // pointer jumps per round and barrier
 constexpr uint32_t kChunk = kRThreads * kPer;         // output bytes of a chunk (a 16-bit pointer each); 64 KB + 8 KB: two workgroups per CU
-constexpr uint32_t kSegLog2 = 7, kSeg = 1u << kSegLog2;   // CRC segment of a thread: 65536 / kRThreads bytes
+constexpr uint32_t kRLog2 = 9;
+constexpr uint32_t kCrcRow = kRThreads;               // words of the block a CRC row covers: one per thread
 constexpr uint32_t kWinLoads = 65536 / 16 / kRThreads;
 constexpr uint32_t kFinal = 0x4000;   // a pointer inside the chunk that is at a literal (pointers in front of the chunk are negative: bit 15)
-static_assert(kChunk <= kFinal && kPer % 4 == 0 && kSeg * kRThreads >= 65536, "");
+static_assert(kChunk <= kFinal && kPer % 4 == 0 && (1u << kRLog2) == kRThreads, "");
 
 // inclusive scans over the 64 lanes of a wave with DPP moves (no LDS round trips as with ds_bpermute shuffles)
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
@@ -618,31 +619,31 @@ __host__ __device__ constexpr CrcPowers crc_powers() {
     for (int k = 1; k < 32; ++k) t.v[k] = p = multmodp(p, p);
     return t;
 }
-__device__ const CrcPowers kX2n = crc_powers();
-struct CrcSegPowers {
-    uint32_t v[512];  // x^(8 * kSeg * m) mod P, m = 0 .. 511
+struct CrcWordPowers {
+    uint32_t v[kCrcRow + 1];  // x^(32 m) mod P, m = 0 .. kCrcRow
 };
-__host__ __device__ constexpr CrcSegPowers crc_seg_powers(uint32_t log2_bits) {
-    CrcSegPowers t{};
-    uint32_t step = 1u << 30;  // x^1 -> x^(2^log2_bits)
-    for (uint32_t k = 0; k < log2_bits; ++k) step = multmodp(step, step);
+__host__ __device__ constexpr CrcWordPowers crc_word_powers() {
+    CrcWordPowers t{};
+    const uint32_t step = crc_powers().v[5];  // x^32
     uint32_t p = 1u << 31;  // x^0
-    for (int m = 0; m < 512; ++m) {
+    for (uint32_t m = 0; m <= kCrcRow; ++m) {
         t.v[m] = p;
         p = multmodp(p, step);
     }
     return t;
 }
-// x^(8 n) mod P
-__device__ uint32_t x8n(uint32_t n) {
-    uint32_t p = 1u << 31;  // x^0
-    for (uint32_t k = 3; n; n >>= 1, ++k)
-        if (n & 1u) p = multmodp(kX2n.v[k & 31u], p);
-    return p;
+struct CrcStrideTables {
+    uint32_t v[1024];  // [k * 256 + b]: the register with byte k = b and nothing else, times x^(32 * kCrcRow)
+};
+__host__ __device__ constexpr CrcStrideTables crc_stride_tables(uint32_t log2_bits) {
+    CrcStrideTables t{};
+    const uint32_t shift = crc_powers().v[log2_bits];
+    for (uint32_t k = 0; k < 4u; ++k)
+        for (uint32_t b = 0; b < 256u; ++b) t.v[k * 256u + b] = multmodp(shift, b << (8u * k));
+    return t;
 }
-
-__device__ const CrcSegPowers kXSeg = crc_seg_powers(kSegLog2 + 3u);
-static_assert(kRThreads <= 512, "kXSeg");
+__device__ const CrcWordPowers kX32 = crc_word_powers();
+__device__ const CrcStrideTables kStride = crc_stride_tables(kRLog2 + 5u);   // a row of kRThreads words = 2^(kRLog2 + 5) bits
 
 }  // namespace
 
@@ -652,7 +653,6 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
     __shared__ uint4 s_ptr4[kChunk * 2 / 16];  // 16-bit markers, then pointers; the CRC tables afterwards
     __shared__ uint32_t s_scan[4 * kRWaves + 1];
     __shared__ uint32_t s_flag[4];
-    __shared__ uint32_t s_crc[256];
     uint8_t* const win = reinterpret_cast<uint8_t*>(s_win4);
     u16a* const mark = reinterpret_cast<u16a*>(s_ptr4);
     u32a* const ptr32 = reinterpret_cast<u32a*>(s_ptr4);
@@ -826,23 +826,23 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             if (!s_flag[slot]) break;
             RPROF_INC(9, 1);
             // kJumps jumps per round and barrier, every lane the same instructions (a final pointer reads some word and keeps itself)
-            uint32_t q[kPer];
+            uint32_t cur[kPer];
 #pragma unroll
-            for (uint32_t k = 0; k < kPer; ++k) q[k] = mark[pj[k] & (kFinal - 1u)];
+            for (uint32_t k = 0; k < kPer; ++k) cur[k] = pj[k];
 #pragma unroll
-            for (uint32_t k = 0; k < kPer; ++k) q[k] = (pj[k] & 0xc000u) ? pj[k] : q[k];
-            uint32_t q2[kPer];
-            if (kJumps > 1u) {
+            for (uint32_t jump = 0; jump < kJumps; ++jump) {
+                uint32_t q[kPer];
 #pragma unroll
-                for (uint32_t k = 0; k < kPer; ++k) q2[k] = mark[q[k] & (kFinal - 1u)];
+                for (uint32_t k = 0; k < kPer; ++k) q[k] = mark[cur[k] & (kFinal - 1u)];
+#pragma unroll
+                for (uint32_t k = 0; k < kPer; ++k) cur[k] = (cur[k] & 0xc000u) ? cur[k] : q[k];
             }
             moving = false;
 #pragma unroll
             for (uint32_t k = 0; k < kPer; ++k) {
-                const uint32_t r = (kJumps > 1u && (q[k] & 0xc000u) == 0u) ? q2[k] : q[k];
-                if ((pj[k] & 0xc000u) == 0u) mark[tid + kRThreads * k] = static_cast<uint16_t>(r);
-                pj[k] = r;
-                moving = moving | ((r & 0xc000u) == 0u);
+                if ((pj[k] & 0xc000u) == 0u) mark[tid + kRThreads * k] = static_cast<uint16_t>(cur[k]);
+                pj[k] = cur[k];
+                moving = moving | ((cur[k] & 0xc000u) == 0u);
             }
         }
         RPROF_T(c4);
@@ -877,51 +877,38 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         if (tid == 0) info[b].flag = 1;
         return;
     }
-    // ---- the gzip trailer's CRC32: segments of 128 bytes, one per thread, combined like zlib's crc32_combine
-    if (tid < 256u) {
-        uint32_t c = tid;
-        for (int k = 0; k < 8; ++k) c = (c & 1u) ? kPoly ^ (c >> 1) : c >> 1;
-        s_crc[tid] = c;
-    }
+    // ---- the gzip trailer's CRC32.  A thread takes the words t, t + 512, t + 1024 ... of the block (the threads of a wave read
+    // consecutive words: a segment of consecutive bytes per thread puts all 64 lanes on one LDS bank): its register is
+    // c = (c ^ word) * x^(8 * 2048) per row -- four look-ups in tables made for that power, like slice-by-4's for x^32 --,
+    // then times x^(32 * the words from its last one on) from a table, and the threads' registers XORed up (the CRC is
+    // linear; the initial ~0 goes in with word 0).  The bytes behind the last full word and the final complement: thread 0.
+    u32a* const st = ptr32;
+    for (uint32_t i = tid; i < 1024u; i += kRThreads) st[i] = kStride.v[i];
     __syncthreads();
-    u32a* const t4 = ptr32;  // slice-by-4 tables 1 .. 3 (table 0 = s_crc)
-    if (tid < 256u) {
-        uint32_t c = s_crc[tid];
-        for (uint32_t k = 0; k < 3u; ++k) {
-            c = s_crc[c & 0xffu] ^ (c >> 8);
-            t4[k * 256u + tid] = c;
-        }
-    }
-    __syncthreads();
-    const uint32_t n_seg = (isize + kSeg - 1u) / kSeg;
-    uint32_t crc = 0;
-    if (tid < n_seg) {
-        const uint32_t lo = tid * kSeg, hi = min(isize, lo + kSeg);
-        uint32_t c = 0xffffffffu, i = lo;
-        const u32a* w32 = reinterpret_cast<const u32a*>(win);
-        for (; i + 4u <= hi; i += 4u) {
-            c ^= w32[i >> 2];
-            c = t4[512u + (c & 0xffu)] ^ t4[256u + ((c >> 8) & 0xffu)] ^ t4[(c >> 16) & 0xffu] ^ s_crc[c >> 24];
-        }
-        for (; i < hi; ++i) c = s_crc[(c ^ win[i]) & 0xffu] ^ (c >> 8);
-        crc = ~c;
-    }
-    __syncthreads();
-    // crc32_combine is linear: the CRC of the full segments (all but the last) = the XOR of every segment's CRC times
-    // x^(8 * the bytes behind it) -- one product per thread, its factor from a table; then the last segment behind them
-    const uint32_t n_full = n_seg ? n_seg - 1u : 0u;
+    const uint32_t nwords = isize >> 2;
     uint32_t part = 0;
-    if (tid < n_full) part = multmodp(kXSeg.v[n_full - 1u - tid], crc);
+    if (tid < nwords) {
+        const u32a* w32 = reinterpret_cast<const u32a*>(win);
+        uint32_t c = tid == 0 ? 0xffffffffu : 0u, i = tid;
+        for (;;) {
+            c ^= w32[i];
+            i += kRThreads;
+            if (i >= nwords) break;
+            c = st[c & 0xffu] ^ st[256u + ((c >> 8) & 0xffu)] ^ st[512u + ((c >> 16) & 0xffu)] ^ st[768u + (c >> 24)];
+        }
+        part = multmodp(kX32.v[nwords - (i - kRThreads)], c);   // (its last word and the words behind it)
+    }
     part = wave_xor(part);
     if (lane == 63u) s_scan[wv] = part;
-    if (tid == n_seg - 1u && n_seg) s_scan[kRWaves] = crc;
     __syncthreads();
     if (tid == 0) {
-        uint32_t head = 0;
-        for (uint32_t k = 0; k < kRWaves; ++k) head ^= s_scan[k];
-        const uint32_t last_len = isize - n_full * kSeg;
-        const uint32_t all = n_seg ? ((head ? multmodp(x8n(last_len), head) : 0u) ^ s_scan[kRWaves]) : 0u;
-        s_flag[3] = all == d.crc ? 0u : 1u;
+        uint32_t c = nwords ? 0u : 0xffffffffu;
+        for (uint32_t k = 0; k < kRWaves; ++k) c ^= s_scan[k];
+        for (uint32_t i = nwords << 2; i < isize; ++i) {
+            c ^= win[i];
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? kPoly ^ (c >> 1) : c >> 1;
+        }
+        s_flag[3] = ~c == d.crc ? 0u : 1u;
     }
     __syncthreads();
     if (s_flag[3]) {

@@ -564,8 +564,12 @@ constexpr uint32_t kChunk = kRThreads * kPer;         // output bytes of a chunk
 constexpr uint32_t kRLog2 = 9;
 constexpr uint32_t kCrcRow = kRThreads;               // words of the block a CRC row covers: one per thread
 constexpr uint32_t kWinLoads = 65536 / 16 / kRThreads;
-constexpr uint32_t kFinal = 0x4000;   // a pointer inside the chunk that is at a literal (pointers in front of the chunk are negative: bit 15)
-static_assert(kChunk <= kFinal && kPer % 4 == 0 && (1u << kRLog2) == kRThreads, "");
+// A pointer of the chunk as 16 bits, told apart by RANGE (one compare): [0, kChunk) a byte of the chunk that is itself copied
+// from somewhere (the pointer still moves); [kChunk, 2 kChunk) = kChunk + a LITERAL of the chunk (final; where it points the
+// table holds the same value: a literal's own pointer); [0x8000, 0xffff] negative, a byte in front of the chunk (final).
+constexpr uint32_t kLit = kChunk;
+constexpr uint32_t kLitMarker = (1u - kLit) & 0xffffu;   // markers: 0 none, dist + 1 a match from here on, this a run of literals
+static_assert(2u * kChunk <= 0x8000u && (kChunk & (kChunk - 1u)) == 0u && kPer % 4 == 0 && (1u << kRLog2) == kRThreads, "");
 
 // inclusive scans over the 64 lanes of a wave with DPP moves (no LDS round trips as with ds_bpermute shuffles)
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         // literals nor a match covers no byte.)  No loop over a token's bytes: the lanes of a wave would wait for its longest.
         if (in_chunk) {
             const uint32_t e0 = incl - span, d0 = incl - mlen;
-            if (litrun) mark[e0] = 1u;
+            if (litrun) mark[e0] = static_cast<uint16_t>(kLitMarker);
             if (mlen) {
                 mark[d0] = static_cast<uint16_t>(dist + 1u);
                 if (base + d0 < dist) s_flag[3] = 1;   // a distance beyond the start of the output
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         }
         // the markers carried forward, a thread over its kPer consecutive bytes: the last marker at or in front of each byte.
         // Inside the thread in registers, across the wave's threads by a scan of "the right one unless it is empty", across the
-        // waves through LDS.  Then every byte's pointer: a literal to itself with the kFinal bit, a byte of a match to the byte
+        // waves through LDS.  Then every byte's pointer: a literal to itself + kLit, a byte of a match to the byte
         // `dist` in front of it (relative to the chunk: negative = an earlier chunk's byte); behind the chunk's end: -1.
         {
             uint32_t m[kPer];
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             for (uint32_t k = 0; k < kPer; ++k) {
                 const uint32_t j = tid * kPer + k;
                 const uint32_t v = m[k] ? m[k] : in;
-                const uint32_t pp = v > 1u ? j - (v - 1u) : j | kFinal;
+                const uint32_t pp = j + 1u - v;   // (a match: j - dist; literals: j + kLit -- the marker is made for it)
                 pw[k] = (j < S ? pp : 0xffffffffu) & 0xffffu;
             }
 #pragma unroll
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
                 mine8[k] = uint2a{pw[4 * k] | (pw[4 * k + 1] << 16), pw[4 * k + 2] | (pw[4 * k + 3] << 16)};
         }
         __syncthreads();
-        // pointer jumping: until every pointer is FINAL -- at a literal (kFinal bit) or in front of the chunk (negative).  A thread
+        // pointer jumping: until every pointer is FINAL -- at a literal or in front of the chunk (the ranges above).  A thread
         // keeps the pointers of its kPer bytes (j = tid + kRThreads k) in registers; a round replaces a pointer by the pointer
         // found where it points (one LDS read, all of a thread's in flight together) and learns from that word's own bits
         // whether it is final now: no round that only confirms.  Reads and writes are not ordered against each other: whatever
@@ -813,7 +817,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         for (uint32_t k = 0; k < kPer; ++k) {
             const uint32_t j = tid + kRThreads * k;
             pj[k] = j < S ? static_cast<uint32_t>(mark[j]) : 0xffffu;
-            moving = moving | ((pj[k] & 0xc000u) == 0u);
+            moving = moving | (pj[k] < kLit);
         }
         RPROF_T(c3);
         RPROF_ADD(3, c2, c3);
@@ -833,16 +837,16 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             for (uint32_t jump = 0; jump < kJumps; ++jump) {
                 uint32_t q[kPer];
 #pragma unroll
-                for (uint32_t k = 0; k < kPer; ++k) q[k] = mark[cur[k] & (kFinal - 1u)];
+                for (uint32_t k = 0; k < kPer; ++k) q[k] = mark[cur[k] & (kLit - 1u)];
 #pragma unroll
-                for (uint32_t k = 0; k < kPer; ++k) cur[k] = (cur[k] & 0xc000u) ? cur[k] : q[k];
+                for (uint32_t k = 0; k < kPer; ++k) cur[k] = cur[k] < kLit ? q[k] : cur[k];
             }
             moving = false;
 #pragma unroll
             for (uint32_t k = 0; k < kPer; ++k) {
-                if ((pj[k] & 0xc000u) == 0u) mark[tid + kRThreads * k] = static_cast<uint16_t>(cur[k]);
+                if (pj[k] < kLit) mark[tid + kRThreads * k] = static_cast<uint16_t>(cur[k]);
                 pj[k] = cur[k];
-                moving = moving | ((cur[k] & 0xc000u) == 0u);
+                moving = moving | (cur[k] < kLit);
             }
         }
         RPROF_T(c4);
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
 #pragma unroll
             for (uint32_t k = 0; k < kPer; ++k) {
                 const int32_t t = static_cast<int32_t>(pj[k] << 16) >> 16;
-                const int32_t off = t & (static_cast<int32_t>(kFinal - 1u) | (t >> 31));   // negative: as it is; else without the kFinal bit
+                const int32_t off = t & (static_cast<int32_t>(kLit - 1u) | (t >> 31));   // negative: as it is; else the literal's place
                 v[k] = win[max(static_cast<int32_t>(base) + off, 0)];   // (below 0: a block that is handed over; behind S: not stored)
             }
 #pragma unroll

@@ -758,14 +758,14 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             }
             continue;
         }
-        if (base + S > isize) {
+        if (base + S > isize || s_flag[3] != 0u) {   // (a distance beyond the start of the output: the other kernel says what it is)
             wrong = true;
             break;
         }
         // the markers carried forward, a thread over its kPer consecutive bytes: the last marker at or in front of each byte.
         // Inside the thread in registers, across the wave's threads by a scan of "the right one unless it is empty", across the
         // waves through LDS.  Then every byte's pointer: a literal to itself + kLit, a byte of a match to the byte
-        // `dist` in front of it (relative to the chunk: negative = an earlier chunk's byte); behind the chunk's end: -1.
+        // `dist` in front of it (relative to the chunk: negative = an earlier chunk's byte); behind the chunk's end: kLit.
         {
             uint32_t m[kPer];
 #pragma unroll
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
                 const uint32_t j = tid * kPer + k;
                 const uint32_t v = m[k] ? m[k] : in;
                 const uint32_t pp = j + 1u - v;   // (a match: j - dist; literals: j + kLit -- the marker is made for it)
-                pw[k] = (j < S ? pp : 0xffffffffu) & 0xffffu;
+                pw[k] = (j < S ? pp : kLit) & 0xffffu;   // (behind the chunk's end: final, and a place the gather may read)
             }
 #pragma unroll
             for (uint32_t k = 0; k < kPer / 4u; ++k)
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
 #pragma unroll
         for (uint32_t k = 0; k < kPer; ++k) {
             const uint32_t j = tid + kRThreads * k;
-            pj[k] = j < S ? static_cast<uint32_t>(mark[j]) : 0xffffu;
+            pj[k] = mark[j];   // (behind the chunk's end the table holds a final pointer)
             moving = moving | (pj[k] < kLit);
         }
         RPROF_T(c3);
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             for (uint32_t k = 0; k < kPer; ++k) {
                 const int32_t t = static_cast<int32_t>(pj[k] << 16) >> 16;
                 const int32_t off = t & (static_cast<int32_t>(kLit - 1u) | (t >> 31));   // negative: as it is; else the literal's place
-                v[k] = win[max(static_cast<int32_t>(base) + off, 0)];   // (below 0: a block that is handed over; behind S: not stored)
+                v[k] = win[static_cast<int32_t>(base) + off];   // (never below 0: such a block left above; behind S: not stored)
             }
 #pragma unroll
             for (uint32_t k = 0; k < kPer; ++k) {

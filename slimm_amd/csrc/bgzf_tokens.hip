@@ -351,125 +351,191 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
-                                                       uint8_t* __restrict__ out, uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
+// What the decoder wave hands the writer wave per lane and step: one word.
+//   kind (bits 30-31): 0 nothing, 1 literals {bits 0-7, 8-15: the bytes, bit 16: two of them}, 2 a match {bits 0-7: length - 3,
+//   bits 8-22: distance - 1}, 3 the lane's stream ends here or went wrong (the decoder's own verdict travels in s_final).
+constexpr uint32_t kRing = 16;    // steps of records between the two waves (a burst is up to kBurst of them)
+constexpr uint32_t kBurst = 8;
+constexpr int kWriterNap = 16, kDecoderNap = 4;   // s_sleep units of 64 cycles between two looks at the other wave's counter
+
+__device__ __forceinline__ uint32_t lds_now(const uint32_t* p) { return *reinterpret_cast<const volatile uint32_t*>(p); }
+__device__ __forceinline__ void lds_set(uint32_t* p, uint32_t v) { *reinterpret_cast<volatile uint32_t*>(p) = v; }
+
+// TWO waves per 64 blocks.  Wave 0, the DECODER: headers, tables, the symbol steps -- and nothing of what becomes of a symbol.
+// Wave 1, the WRITER: the literals gathered four to a store, the match tokens, the bounds of the output, every store.  A
+// lane's step had been both in one chain of ~410 dependent instructions at one wave per SIMD (what bounds this kernel is
+// the latency of that chain: CHANGELOG, round 5); apart they are ~250 and ~160 on two SIMDs side by side, the decoder
+// never waits for a store and the writer never for a load.  Between them a ring of one word per lane and step in LDS,
+// handed over burst by burst through two counters (wave-uniform: every lane takes a step's slot, "nothing" included).
+__global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restrict__ comp, const BgzfBlock* __restrict__ blocks, uint32_t n_blocks,
+                                                        uint8_t* __restrict__ out, uint32_t* __restrict__ tok, InflateInfo* __restrict__ info) {
     __shared__ uint32_t s_lds[kLaneBytes * 16u];
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint32_t s_ring[kRing * 64u];
+    __shared__ uint32_t s_sync[4];     // [0] steps the decoder has handed over, [1] steps the writer has taken, [2] the decoder is through
+    __shared__ uint32_t s_stop[2];     // lanes the writer found wrong: the decoder stops decoding them
+    __shared__ uint32_t s_final[64];   // the decoder's verdict per lane: 1 = its stream ended where it must
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t b = blockIdx.x * 64u + lane;
     const bool have = b < n_blocks;
-    Lds L{reinterpret_cast<uint8_t*>(s_lds), lane};
     BgzfBlock d;
     d.src = d.dst = 0;
     d.csize = d.isize = 0;
     d.tok = 0;
     if (have) d = blocks[b];
-    const uint8_t* in = comp + d.src;
-    uint8_t* o_base = out + d.dst;
-    uint32_t* t_base = tok + d.tok;
-    const uint32_t tok_room = bgzf_token_room(d.isize);
     const uint32_t csize = d.csize, isize = d.isize;
+    if (threadIdx.x < 4u) s_sync[threadIdx.x] = 0;
+    if (threadIdx.x < 2u) s_stop[threadIdx.x] = 0;
+    __syncthreads();
 
-    Bits bits;
-    bits.start(0);
-    Limits LL, DL;
-    LL.clear();
-    DL.clear();
-    uint32_t mode = have ? kModeHeader : kModeDone;
-    uint32_t last = 0, o = 0, acc_n = 0, litrun = 0, ntok = 0;
-    uint64_t acc = 0;   // literals waiting to be stored: up to 3 from the steps before + 2 of this one
-    // stores waiting for the top of the next step
-    uint32_t p_lit = 0, p_lit_at = 0, p_lit_n = 0, p_tok0 = 0, p_tok1 = 0, p_ntok = 0, p_tok_at = 0;
-
-    DPROF_T(d_start);
-    for (;;) {
-        const uint64_t want = __ballot(mode == kModeHeader);
-        const uint64_t going = __ballot(mode == kModeDecode);
-        if (!want && !going) break;
-        if (want && (!going || __popcll(want) >= 8)) {
-            DPROF_T(h0);
-            if (mode == kModeHeader) {
-                mode = read_header(bits, in, csize, L, LL, DL, last);
-            }
-            DPROF_T(h1);
-            DPROF_ADD(5, h0, h1);
-            continue;
-        }
-        // a burst of uniform steps
-        uint64_t ahead = 0;
-        if (mode == kModeDecode) ahead = ld64u(in + bits.rp);   // (the first step's refill)
-        for (uint32_t it = 0; it < 16u; ++it) {
-            const bool run = mode == kModeDecode;
-            DPROF_T(s0);
-            DPROF_WAIT_VM();
-            DPROF_T(s1);
-            DPROF_ADD(0, s0, s1);
-            // the input asked for a step ago; the stores of the step before behind it
-            if (run) bits.refill(ahead);
-            if (run) ahead = ld64u(in + bits.rp);
-            if (p_lit_n) {
-                if (p_lit_at + 4u <= isize) {
-                    st32u(o_base + p_lit_at, p_lit);
-                } else {
-                    for (uint32_t k = 0; k < p_lit_n; ++k) o_base[p_lit_at + k] = static_cast<uint8_t>(p_lit >> (8u * k));
+    if (wave == 0) {
+        // ------------------------------------------------------------------------------------------------ the decoder
+        Lds L{reinterpret_cast<uint8_t*>(s_lds), lane};
+        const uint8_t* in = comp + d.src;
+        Bits bits;
+        bits.start(0);
+        Limits LL, DL;
+        LL.clear();
+        DL.clear();
+        uint32_t mode = have ? kModeHeader : kModeDone;
+        uint32_t last = 0, st = 0;   // st: steps handed over so far (wave-uniform)
+        DPROF_T(d_start);
+        for (;;) {
+            // lanes the writer has given up: no use decoding them on
+            {
+                const uint64_t stop = static_cast<uint64_t>(lds_now(&s_stop[0])) | (static_cast<uint64_t>(lds_now(&s_stop[1])) << 32);
+                if ((stop >> lane) & 1u) {
+                    if (mode == kModeHeader || mode == kModeDecode) mode = kModeHandOver;
                 }
-                p_lit_n = 0;
             }
-            if (p_ntok) {
-                t_base[p_tok_at] = p_tok0;
-                if (p_ntok > 1u) t_base[p_tok_at + 1u] = p_tok1;
-                p_ntok = 0;
+            const uint64_t want = __ballot(mode == kModeHeader);
+            const uint64_t going = __ballot(mode == kModeDecode);
+            if (!want && !going) break;
+            if (want && (!going || __popcll(want) >= 8)) {
+                DPROF_T(h0);
+                if (mode == kModeHeader) {
+                    mode = read_header(bits, in, csize, L, LL, DL, last);
+                }
+                DPROF_T(h1);
+                DPROF_ADD(5, h0, h1);
+                continue;
             }
-            if (!__any(run)) break;
-            // ---- one literal/length symbol, then ONE more symbol of whichever code comes next: behind a literal the
-            // literal/length code again (a second literal is taken along; anything else waits for the next step), behind a
-            // length the distance code.  The second chain's limits, base table and symbol table are selected per lane.
-            const uint32_t w1 = static_cast<uint32_t>(bits.lo);
-            const uint32_t x = top15(w1);
-            const uint32_t len = LL.length_of(x);
-            const uint32_t idx = min(symbol_at(L, kLbase, x, len), 287u);
-            const uint32_t sym = L.b8(kLsymLo, idx) | (((L.b32(kLsymHi, idx >> 5) >> (idx & 31u)) & 1u) << 8);
-            bool bad = len > 15u;
-            uint32_t c = len;
-            DPROF_WAIT_ALL();
-            DPROF_T(s2);
-            DPROF_ADD(1, s1, s2);
-            const bool is_lit = sym < 256u, is_eob = sym == 256u, is_len = sym > 256u;
-            const uint32_t ls = is_len ? sym - 257u : 0u;
-            bad = bad | (ls > 28u);
-            const uint32_t le = (ls >= 8u && ls < 28u) ? (ls >> 2) - 1u : 0u;
-            const uint32_t lb = ls < 8u ? ls + 3u : (ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << le));
-            const uint32_t mlen = lb + ((w1 >> (len > 15u ? 15u : len)) & ((1u << le) - 1u));
-            // (32 bits behind the first symbol and its extra bits: 15 for the second code + 13 extra bits of a distance)
-            const uint32_t w2 = static_cast<uint32_t>(bits.lo >> ((len > 15u ? 15u : len) + le));   // (le = 0 behind a literal)
-            Limits SL;
+            // room for a burst: the writer has taken all but the last kRing - kBurst steps
+            while (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(lds_now(&s_sync[1]))) + (kRing - kBurst) < st) __builtin_amdgcn_s_sleep(kDecoderNap);
+            // a burst of uniform steps
+            uint64_t ahead = 0;
+            if (mode == kModeDecode) ahead = ld64u(in + bits.rp);   // (the first step's refill)
+            for (uint32_t it = 0; it < kBurst; ++it) {
+                const bool run = mode == kModeDecode;
+                DPROF_T(s0);
+                DPROF_WAIT_VM();
+                DPROF_T(s1);
+                DPROF_ADD(0, s0, s1);
+                // the input asked for a step ago
+                if (run) bits.refill(ahead);
+                if (run) ahead = ld64u(in + bits.rp);
+                if (!__any(run)) break;
+                // ---- one literal/length symbol, then ONE more symbol of whichever code comes next: behind a literal the
+                // literal/length code again (a second literal is taken along; anything else waits for the next step), behind a
+                // length the distance code.  The second chain's limits, base table and symbol table are selected per lane.
+                const uint32_t w1 = static_cast<uint32_t>(bits.lo);
+                const uint32_t x = top15(w1);
+                const uint32_t len = LL.length_of(x);
+                const uint32_t idx = min(symbol_at(L, kLbase, x, len), 287u);
+                const uint32_t sym = L.b8(kLsymLo, idx) | (((L.b32(kLsymHi, idx >> 5) >> (idx & 31u)) & 1u) << 8);
+                bool bad = len > 15u;
+                uint32_t c = len;
+                DPROF_WAIT_ALL();
+                DPROF_T(s2);
+                DPROF_ADD(1, s1, s2);
+                const bool is_lit = sym < 256u, is_eob = sym == 256u, is_len = sym > 256u;
+                const uint32_t ls = is_len ? sym - 257u : 0u;
+                bad = bad | (ls > 28u);
+                const uint32_t le = (ls >= 8u && ls < 28u) ? (ls >> 2) - 1u : 0u;
+                const uint32_t lb = ls < 8u ? ls + 3u : (ls >= 28u ? 258u : 3u + ((4u + (ls & 3u)) << le));
+                const uint32_t mlen = lb + ((w1 >> (len > 15u ? 15u : len)) & ((1u << le) - 1u));
+                // (32 bits behind the first symbol and its extra bits: 15 for the second code + 13 extra bits of a distance)
+                const uint32_t w2 = static_cast<uint32_t>(bits.lo >> ((len > 15u ? 15u : len) + le));   // (le = 0 behind a literal)
+                Limits SL;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) SL.v[k] = is_lit ? LL.v[k] : DL.v[k];
-            const uint32_t y = top15(w2);
-            const uint32_t l2 = SL.length_of(y);
-            const uint32_t i2 = min(symbol_at(L, is_lit ? kLbase : kDbase, y, l2), is_lit ? 287u : 31u);
-            const uint32_t s2lo = L.b8(is_lit ? kLsymLo : kDsym, i2);
-            const uint32_t s2hi = (L.b32(kLsymHi, (i2 >> 5) & 15u) >> (i2 & 31u)) & 1u;
-            DPROF_WAIT_ALL();
-            DPROF_T(s3);
-            DPROF_ADD(2, s2, s3);
-            // behind a literal: a second literal?
-            const bool lit2 = is_lit & (l2 <= 15u) & (s2hi == 0u);
-            // behind a length: the distance
-            const uint32_t ds = s2lo;
-            const uint32_t de = ds >= 4u ? (ds >> 1) - 1u : 0u;
-            const uint32_t dbv = ds < 4u ? ds + 1u : 1u + ((2u + (ds & 1u)) << de);
-            const uint32_t dist = dbv + ((w2 >> (l2 > 15u ? 15u : l2)) & ((1u << de) - 1u));
-            if (is_len) {
-                bad = bad | (l2 > 15u) | (ds > 29u);
-                c += le + (l2 > 15u ? 0u : l2) + de;
+                for (int k = 0; k < 8; ++k) SL.v[k] = is_lit ? LL.v[k] : DL.v[k];
+                const uint32_t y = top15(w2);
+                const uint32_t l2 = SL.length_of(y);
+                const uint32_t i2 = min(symbol_at(L, is_lit ? kLbase : kDbase, y, l2), is_lit ? 287u : 31u);
+                const uint32_t s2lo = L.b8(is_lit ? kLsymLo : kDsym, i2);
+                const uint32_t s2hi = (L.b32(kLsymHi, (i2 >> 5) & 15u) >> (i2 & 31u)) & 1u;
+                DPROF_WAIT_ALL();
+                DPROF_T(s3);
+                DPROF_ADD(2, s2, s3);
+                // behind a literal: a second literal?
+                const bool lit2 = is_lit & (l2 <= 15u) & (s2hi == 0u);
+                // behind a length: the distance
+                const uint32_t ds = s2lo;
+                const uint32_t de = ds >= 4u ? (ds >> 1) - 1u : 0u;
+                const uint32_t dbv = ds < 4u ? ds + 1u : 1u + ((2u + (ds & 1u)) << de);
+                const uint32_t dist = dbv + ((w2 >> (l2 > 15u ? 15u : l2)) & ((1u << de) - 1u));
+                if (is_len) {
+                    bad = bad | (l2 > 15u) | (ds > 29u);
+                    c += le + (l2 > 15u ? 0u : l2) + de;
+                }
+                if (lit2) c += l2;
+                uint32_t rec = 0;
+                if (run) {
+                    bits.drop(c);
+                    if (bits.at_bit() > static_cast<uint64_t>(csize) * 8u) bad = true;
+                    if (bad) {
+                        mode = kModeHandOver;
+                        rec = 3u << 30;
+                    } else if (is_eob) {
+                        mode = last ? kModeDone : kModeHeader;
+                        rec = last ? 3u << 30 : 0u;   // (between two DEFLATE blocks of a BGZF block nothing happens to the output)
+                    } else if (is_lit) {
+                        rec = (1u << 30) | sym | (lit2 ? (s2lo << 8) | (1u << 16) : 0u);
+                    } else {
+                        rec = (2u << 30) | (mlen - 3u) | ((dist - 1u) << 8);
+                    }
+                }
+                s_ring[(st % kRing) * 64u + lane] = rec;
+                ++st;
+                DPROF_T(s4);
+                DPROF_ADD(3, s3, s4);
+                DPROF_ADD(4, s4, s4 + 1);
+                DPROF_ADD(7, s4, s4 + ((run & lit2) ? 1u : 0u));   // (lane 0's literal pairs)
             }
-            if (lit2) c += l2;
-            if (run) {
+            if (lane == 0) lds_set(&s_sync[0], st);   // (behind the burst's records: LDS takes a wave's operations in order)
+        }
+        DPROF_T(d_end);
+        DPROF_ADD(6, d_start, d_end);
+        // the stream must end inside the payload (that it ends at ISIZE bytes is the writer's to say)
+        s_final[lane] = (mode == kModeDone && (bits.at_bit() + 7u) / 8u <= csize) ? 1u : 0u;
+        if (lane == 0) lds_set(&s_sync[2], 1u);
+    } else {
+        // ------------------------------------------------------------------------------------------------ the writer
+        uint8_t* o_base = out + d.dst;
+        uint32_t* t_base = tok + d.tok;
+        const uint32_t tok_room = bgzf_token_room(isize);
+        uint32_t o = 0, acc_n = 0, litrun = 0, ntok = 0, wst = 0;
+        uint64_t acc = 0;   // literals waiting to be stored: up to 3 from the steps before + 2 of this one
+        bool bad = false, ended = !have;
+        for (;;) {
+            const uint32_t through = __builtin_amdgcn_readfirstlane(lds_now(&s_sync[2]));
+            const uint32_t upto = __builtin_amdgcn_readfirstlane(lds_now(&s_sync[0]));
+            if (upto == wst) {
+                if (through) break;   // (read before the count: nothing more comes)
+                __builtin_amdgcn_s_sleep(kWriterNap);   // (a burst takes the decoder ~10 us: a look every ~0.5 us, not every 30 ns on its SIMD)
+                continue;
+            }
+            uint32_t rec_next = s_ring[(wst % kRing) * 64u + lane];
+            for (; wst != upto; ++wst) {
+                const uint32_t rec = rec_next;
+                rec_next = s_ring[((wst + 1u) % kRing) * 64u + lane];   // (behind the last one: a slot not yet written, not used)
+                const uint32_t kind = rec >> 30;
+                const bool is_lit = kind == 1u, is_len = kind == 2u;
+                if (kind == 0u || ended || bad) continue;
                 bool flush = false;
                 if (is_lit) {
-                    const uint32_t n_lit = lit2 ? 2u : 1u;
+                    const uint32_t n_lit = 1u + ((rec >> 16) & 1u);
                     if (o + n_lit > isize) bad = true;
-                    acc |= static_cast<uint64_t>(sym | (lit2 ? s2lo << 8 : 0u)) << (8u * acc_n);
+                    acc |= static_cast<uint64_t>(rec & 0xffffu) << (8u * acc_n);
                     acc_n += n_lit;
                     o += n_lit;
                     litrun += n_lit;
@@ -479,66 +545,55 @@ __global__ __launch_bounds__(64) void k_inflate_decode(const uint8_t* __restrict
                 }
                 if (flush & !bad) {   // (four bytes when there are four, else what there is: a match or the block's end follows)
                     const uint32_t n_out = acc_n >= 4u ? 4u : acc_n;
-                    p_lit = static_cast<uint32_t>(acc);
-                    p_lit_n = n_out;
-                    p_lit_at = o - acc_n;
+                    const uint32_t at = o - acc_n, v = static_cast<uint32_t>(acc);
+                    if (at + 4u <= isize) {
+                        st32u(o_base + at, v);
+                    } else {
+                        for (uint32_t k = 0; k < n_out; ++k) o_base[at + k] = static_cast<uint8_t>(v >> (8u * k));
+                    }
                     acc = n_out == 4u ? acc >> 32 : 0ull;
                     acc_n -= n_out;
                 }
                 if (is_len & !bad) {
+                    const uint32_t mlen = (rec & 0xffu) + 3u, dist = ((rec >> 8) & 0x7fffu) + 1u;
                     if (dist > o || o + mlen > isize || ntok + 2u > tok_room) {
                         bad = true;
                     } else {
-                        p_tok_at = ntok;
                         if (litrun > 255u) {
-                            p_tok0 = 0x80000000u | litrun;
-                            p_tok1 = ((mlen - 3u) << 15) | (dist - 1u);
-                            p_ntok = 2;
+                            t_base[ntok] = 0x80000000u | litrun;
+                            t_base[ntok + 1u] = ((mlen - 3u) << 15) | (dist - 1u);
+                            ntok += 2u;
                         } else {
-                            p_tok0 = (litrun << 23) | ((mlen - 3u) << 15) | (dist - 1u);
-                            p_ntok = 1;
+                            t_base[ntok] = (litrun << 23) | ((mlen - 3u) << 15) | (dist - 1u);
+                            ntok += 1u;
                         }
-                        ntok += p_ntok;
                         litrun = 0;
                         o += mlen;
                     }
                 }
-                bits.drop(c);
-                if (bits.at_bit() > static_cast<uint64_t>(csize) * 8u) bad = true;
-                if (bad) {
-                    mode = kModeHandOver;
-                } else if (is_eob) {
-                    mode = last ? kModeDone : kModeHeader;
+                if (kind == 3u) ended = true;
+            }
+            if (lane == 0) lds_set(&s_sync[1], wst);
+            {   // the lanes that went wrong here: the decoder need not go on with them
+                const uint64_t wrong = __ballot(bad);
+                if (lane == 0 && wrong) {
+                    atomicOr(&s_stop[0], static_cast<uint32_t>(wrong));
+                    atomicOr(&s_stop[1], static_cast<uint32_t>(wrong >> 32));
                 }
             }
-            DPROF_T(s4);
-            DPROF_ADD(3, s3, s4);
-            DPROF_ADD(4, s4, s4 + 1);
-            DPROF_ADD(7, s4, s4 + ((run & lit2) ? 1u : 0u));   // (lane 0's literal pairs)
         }
-        // (what the burst's last step left to be stored)
-        if (p_lit_n) {
-            if (p_lit_at + 4u <= isize) {
-                st32u(o_base + p_lit_at, p_lit);
-            } else {
-                for (uint32_t k = 0; k < p_lit_n; ++k) o_base[p_lit_at + k] = static_cast<uint8_t>(p_lit >> (8u * k));
-            }
-            p_lit_n = 0;
-        }
-        if (p_ntok) {
-            t_base[p_tok_at] = p_tok0;
-            if (p_ntok > 1u) t_base[p_tok_at + 1u] = p_tok1;
-            p_ntok = 0;
-        }
+        // (between the decoder's verdicts and this wave's reading them: the barrier below)
+        s_ring[lane] = bad ? 1u : 0u;   // (the ring is done with)
+        s_ring[64u + lane] = o;
+        s_ring[128u + lane] = ntok;
     }
-    DPROF_T(d_end);
-    DPROF_ADD(6, d_start, d_end);
-    if (have) {
-        // the stream must end exactly at ISIZE bytes and inside the payload
-        if (mode == kModeDone && (o != isize || (bits.at_bit() + 7u) / 8u > csize)) mode = kModeHandOver;
+    __syncthreads();
+    if (wave == 1 && have) {
+        // the stream must have ended, inside the payload, at exactly ISIZE bytes
+        const bool ok = s_final[lane] != 0u && s_ring[lane] == 0u && s_ring[64u + lane] == isize;
         InflateInfo r;
-        r.n_tok = ntok;
-        r.flag = mode == kModeDone ? 0u : 1u;
+        r.n_tok = s_ring[128u + lane];
+        r.flag = ok ? 0u : 1u;
         info[b] = r;
     }
 }
@@ -950,7 +1005,7 @@ void launch_bgzf_inflate(hipStream_t st, const uint8_t* comp, const BgzfBlock* b
     InflateInfo* info = reinterpret_cast<InflateInfo*>(s);
     s += (static_cast<size_t>(n_blocks) * sizeof(InflateInfo) + 255u) & ~static_cast<size_t>(255u);
     uint32_t* tok = reinterpret_cast<uint32_t*>(s);
-    hipLaunchKernelGGL(k_inflate_decode, dim3((n_blocks + 63u) / 64u), dim3(64), 0, st, comp, blocks, n_blocks, out, tok, info);
+    hipLaunchKernelGGL(k_inflate_decode, dim3((n_blocks + 63u) / 64u), dim3(128), 0, st, comp, blocks, n_blocks, out, tok, info);
     hipLaunchKernelGGL(k_inflate_resolve, dim3(n_blocks), dim3(kRThreads), 0, st, blocks, n_blocks, out, tok, info);
     launch_bgzf_inflate_lanes(st, comp, blocks, n_blocks, out, lanes_scratch, bgzf_inflate_grid(n_blocks), status, info);
 }

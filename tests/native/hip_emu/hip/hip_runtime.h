@@ -110,6 +110,7 @@ extern uint32_t g_lane;  // lane of the running fiber inside its wave
 // exchange) and, through *live, the mask of lanes that took part
 const uint64_t* wave_exchange(uint64_t v, uint64_t* live = nullptr);
 void block_barrier();
+void yield_now();   // the running fiber steps aside and stays runnable: what a spin-wait does between two looks (s_sleep)
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void* dynamic_lds();
 }  // namespace hipemu
@@ -272,6 +273,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     if (s < 0 || !((live >> s) & 1u)) return bound_ctrl ? 0 : old;
     return static_cast<int>(static_cast<uint32_t>(a[s]));
 }
+static inline void __builtin_amdgcn_s_sleep(int) { ::hipemu::yield_now(); }
 static inline uint32_t __builtin_amdgcn_ds_bpermute(int byte_addr, uint32_t v) {
     uint64_t live = 0;
     const uint64_t* a = ::hipemu::wave_exchange(v, &live);

@@ -180,6 +180,8 @@ const uint64_t* wave_exchange(uint64_t v, uint64_t* live) {
     return w.snap_val[sn];
 }
 
+void yield_now() { yield_to_scheduler(); }
+
 void block_barrier() {
     const uint32_t g = g_bar_gen;
     if (++g_bar_arrived == g_block_alive) {

@@ -398,6 +398,8 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
         DL.clear();
         uint32_t mode = have ? kModeHeader : kModeDone;
         uint32_t last = 0, st = 0;   // st: steps handed over so far (wave-uniform)
+        uint64_t ahead = 0;          // the 8 input bytes the lane's next refill takes: asked for a step ahead, ACROSS bursts too
+        bool have_ahead = false;
         DPROF_T(d_start);
         for (;;) {
             // lanes the writer has given up: no use decoding them on
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
                 DPROF_T(h0);
                 if (mode == kModeHeader) {
                     mode = read_header(bits, in, csize, L, LL, DL, last);
+                    have_ahead = false;
                 }
                 DPROF_T(h1);
                 DPROF_ADD(5, h0, h1);
@@ -422,8 +425,7 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
             // room for a burst: the writer has taken all but the last kRing - kBurst steps
             while (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(lds_now(&s_sync[1]))) + (kRing - kBurst) < st) __builtin_amdgcn_s_sleep(kDecoderNap);
             // a burst of uniform steps
-            uint64_t ahead = 0;
-            if (mode == kModeDecode) ahead = ld64u(in + bits.rp);   // (the first step's refill)
+            if (mode == kModeDecode && !have_ahead) ahead = ld64u(in + bits.rp);   // (the first step behind a header)
             for (uint32_t it = 0; it < kBurst; ++it) {
                 const bool run = mode == kModeDecode;
                 DPROF_T(s0);
@@ -431,8 +433,11 @@ __global__ __launch_bounds__(128) void k_inflate_decode(const uint8_t* __restric
                 DPROF_T(s1);
                 DPROF_ADD(0, s0, s1);
                 // the input asked for a step ago
-                if (run) bits.refill(ahead);
-                if (run) ahead = ld64u(in + bits.rp);
+                if (run) {
+                    bits.refill(ahead);
+                    ahead = ld64u(in + bits.rp);
+                    have_ahead = true;
+                }
                 if (!__any(run)) break;
                 // ---- one literal/length symbol, then ONE more symbol of whichever code comes next: behind a literal the
                 // literal/length code again (a second literal is taken along; anything else waits for the next step), behind a

@@ -8,14 +8,18 @@
 //   k_inflate_decode   a LANE per block, Huffman decoding only, in wave-uniform steps (no data-dependent branch inside a
 //                      step: every lane decodes one literal/length symbol and, speculatively, the distance symbol behind
 //                      it).  Canonical decoding without first-level tables: the next 15 stream bits, bit-reversed, are
-//                      compared with the 15 left-justified code-length limits held in REGISTERS (v_cmp + v_addc per
-//                      length), which leaves LDS only the sorted symbols (9 + 5 bits) and one base per length: 520 B per
-//                      lane, 33 KB per wave -> four waves per CU where the table-driven kernel fits two.  Literals go
-//                      straight to their final place in the output (four at a time), matches become 4-byte TOKENS
-//                      {literals since the last token, length, distance}: what is left of the block afterwards are holes.
-//                      The input comes through a 128-bit reservoir per lane that takes 8 unaligned bytes per step, asked
-//                      for one step ahead; the stores of a step are issued at the top of the next one, behind the wait for
-//                      that load (on this hardware a wait for a load is a wait for every store issued before it).
+//                      compared with the 15 left-justified code-length limits held in REGISTERS (a subtraction and an
+//                      and-or per pair of lengths), which leaves LDS only the sorted symbols (9 + 5 bits) and one base per
+//                      length: 520 B per lane, 33 KB per wave -> four of them per CU where the table-driven kernel fits two.
+//                      TWO waves per 64 blocks: the DECODER wave does the above and hands one word per lane and step
+//                      (literals / a match / the end) through a ring in LDS to the WRITER wave, which puts literals
+//                      straight to their final place in the output (four at a time), turns matches into 4-byte TOKENS
+//                      {literals since the last token, length, distance} and keeps the bounds -- what is left of the block
+//                      afterwards are holes.  What bounds this kernel is the latency of a lane's chain of dependent
+//                      instructions at one decoder wave per SIMD (LDS capacity); the writer's share of that chain runs on
+//                      another SIMD now, the decoder never waits for a store and the writer never for a load.  The input
+//                      comes through a 64-bit reservoir per lane that takes 8 unaligned bytes per step, asked for one step
+//                      ahead.
 //   k_inflate_resolve  a WORKGROUP of 512 threads per block, the block's 64 KB in LDS: the holes are filled in chunks of <= 4 KB
 //                      of output.  A token leaves two 16-bit MARKERS in a table of the chunk's bytes (where its literals
 //                      begin, where its match begins: the distance); every thread carries the markers forward over 8

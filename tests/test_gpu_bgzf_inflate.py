@@ -267,3 +267,90 @@ def test_a_block_that_claims_no_bytes_is_inflated_all_the_same():
         assert rc == 0 and got == b"hello world" * 3
         rc, got, _ = _inflate_with(good + lying + good, how)
         assert rc != 0
+
+
+def _hand_made_fixed_block(symbols) -> bytes:
+    """A raw DEFLATE stream of ONE fixed-Huffman block made by hand: symbols = [("lit", byte) | ("match", length, distance)].
+    (zlib never emits a distance beyond the output; the writer wave has to refuse one.)"""
+    bits = []
+    def put(v, n):           # n bits, least significant first (extra bits, header)
+        for k in range(n):
+            bits.append((v >> k) & 1)
+    def code(v, n):          # a Huffman code: most significant bit first
+        for k in range(n - 1, -1, -1):
+            bits.append((v >> k) & 1)
+    def litlen(s):
+        if s < 144:
+            code(0x30 + s, 8)
+        elif s < 256:
+            code(0x190 + (s - 144), 9)
+        elif s < 280:
+            code(s - 256, 7)
+        else:
+            code(0xc0 + (s - 280), 8)
+    lbase = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    lext = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
+    dbase = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+    dext = [0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13]
+    put(1, 1)
+    put(1, 2)                # BFINAL, fixed codes
+    for s in symbols:
+        if s[0] == "lit":
+            litlen(s[1])
+        else:
+            _, length, dist = s
+            li = max(i for i in range(29) if lbase[i] <= length)
+            litlen(257 + li)
+            put(length - lbase[li], lext[li])
+            di = max(i for i in range(30) if dbase[i] <= dist)
+            code(di, 5)
+            put(dist - dbase[di], dext[di])
+    litlen(256)
+    while len(bits) % 8:
+        bits.append(0)
+    return bytes(sum(bits[i + k] << k for k in range(8)) for i in range(0, len(bits), 8))
+
+
+def test_decoder_and_writer_waves_hand_over():
+    """k_inflate_decode is two waves per 64 blocks (bgzf_tokens.hip): a decoder wave and a writer wave with a ring of one word
+    per lane and step between them.  What the hand-over has to survive: headers in the middle of a burst (a BGZF block of a
+    hundred DEFLATE blocks), lanes that end at very different steps, launches whose last workgroup is partly empty, and a
+    stream only the WRITER can refuse -- a distance that reaches in front of the output -- next to streams that go on."""
+    rng = np.random.default_rng(11)
+    text = (b"the quick brown fox jumps over the lazy dog " * 1500)[:60000]
+    # a DEFLATE block every 300 - 900 bytes: 100 headers inside one BGZF block, fixed and dynamic codes in turn
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw, p = b"", 0
+    while p < len(text):
+        n = int(rng.integers(300, 900))
+        raw += c.compress(text[p:p + n]) + c.flush(zlib.Z_BLOCK)
+        p += n
+    raw += c.flush()
+    many_headers = bgzf_block(text, raw=raw)
+    hand = [("lit", b) for b in b"abcdef"] + [("match", 20, 3), ("lit", 0x7a), ("match", 258, 1), ("match", 4, 280)]
+    want_hand = bytearray(b"abcdef")
+    for s in hand[6:]:
+        if s[0] == "lit":
+            want_hand.append(s[1])
+        else:
+            for _ in range(s[1]):
+                want_hand.append(want_hand[-s[2]])
+    hand_block = bgzf_block(bytes(want_hand), raw=_hand_made_fixed_block(hand))
+    sizes = [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 12287, 12288, 12289, 65279, 65280]
+    small = [bytes(rng.integers(0, 7, n, dtype=np.uint8)) for n in sizes]
+    for n_copies in (1, 3):          # 1: one partly empty workgroup; 3: 66 blocks = one full pair of waves and two lanes
+        blocks = [many_headers, hand_block] + [bgzf_block(d, 1 + k % 9) for k, d in enumerate(small)]
+        blocks = blocks * n_copies + [many_headers] * (n_copies * 2)
+        want = (text + bytes(want_hand) + b"".join(small)) * n_copies + text * (n_copies * 2)
+        rc, got, lanes = _inflate_with(b"".join(blocks), 0)
+        assert rc == 0 and got == want and lanes == 0, (rc, lanes)
+    # a distance in front of the output: behind 6 literals nothing lies 7 back.  zlib refuses it; so must the device, whichever
+    # kernel ends up saying so -- and the blocks around it are what they were
+    far = _hand_made_fixed_block([("lit", b) for b in b"abcdef"] + [("match", 5, 7)])
+    with pytest.raises(zlib.error):
+        zlib.decompressobj(-15).decompress(far)
+    bad_block = bgzf_block(b"abcdef" + b"?" * 5, raw=far)
+    rc, got, err, _ = device_inflate(many_headers + bad_block + hand_block)
+    assert rc != 0 and "corrupt BGZF block" in err and "block 1" in err, (rc, err)
+    rc, got, err, _ = device_inflate(many_headers + hand_block)
+    assert rc == 0 and got == text + bytes(want_hand)

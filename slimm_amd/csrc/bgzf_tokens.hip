@@ -744,8 +744,6 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             if (i < isize) __builtin_memcpy(&w[k], o_base + i, 16);  // (up to 15 bytes behind the block: the next block's, or the buffer's slack)
         }
 #pragma unroll
-        for (uint32_t k = 0; k < kPer / 4u; ++k) mine8[k] = uint2a{0u, 0u};   // no marker anywhere
-#pragma unroll
         for (uint32_t k = 0; k < kWinLoads; ++k) {
             const uint32_t i = (tid + k * kRThreads) * 16u;
             if (i < isize) s_win4[i >> 4] = w[k];
@@ -759,6 +757,10 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
     RPROF_ADD(0, c_start, c_loaded);
     uint32_t tv_next = tid < nf.n_tok ? t_base[tid] : 0x80000000u;   // (the next chunk's token is asked for while this one is filled)
     while (t0 < nf.n_tok) {
+        // the table empty for this chunk's markers (the barrier at the end of a chunk stands between every thread's loading
+        // its pointers and this; the markers come behind the next barrier)
+#pragma unroll
+        for (uint32_t k = 0; k < kPer / 4u; ++k) mine8[k] = uint2a{0u, 0u};
         // a token per thread, the spans' running sum
         RPROF_T(c0);
         const uint32_t t = t0 + tid;
@@ -774,14 +776,15 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         __syncthreads();
         RPROF_T(c1);
         RPROF_ADD(1, c0, c1);
-        uint32_t before = 0;
-        for (uint32_t k = 0; k < wv; ++k) before += s_scan[k];
+        uint32_t before = 0;   // (all eight words asked for at once: a loop up to this wave's number waits for each in turn)
+#pragma unroll
+        for (uint32_t k = 0; k + 1u < kRWaves; ++k) before += k < wv ? s_scan[k] : 0u;
         incl += before;
         // the chunk: the tokens whose spans end inside kChunk bytes (a prefix: spans are sums)
         const bool in_chunk = t < nf.n_tok && incl <= kChunk;
         const uint64_t mine = __ballot(in_chunk);
         const uint32_t cnt = static_cast<uint32_t>(__popcll(mine));
-        const uint32_t top = __shfl(incl, static_cast<int>(cnt ? cnt - 1u : 0u));
+        const uint32_t top = __builtin_amdgcn_readlane(incl, cnt ? cnt - 1u : 0u);   // (the count is the wave's: a scalar)
         if (lane == 0) {
             s_scan[kRWaves + wv] = cnt;
             s_scan[2 * kRWaves + wv] = cnt ? top : 0u;
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         // Inside the thread in registers, across the wave's threads by a scan of "the right one unless it is empty", across the
         // waves through LDS.  Then every byte's pointer: a literal to itself + kLit, a byte of a match to the byte
         // `dist` in front of it (relative to the chunk: negative = an earlier chunk's byte); behind the chunk's end: kLit.
+        bool moving = false;
         {
             uint32_t m[kPer];
 #pragma unroll
@@ -850,11 +854,11 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
             if (lane == 63u) s_scan[3 * kRWaves + wv] = carry;
             uint32_t in = __builtin_amdgcn_update_dpp(0u, carry, 0x138, 0xf, 0xf, true);   // wave_shr:1 (lane 0: none)
             __syncthreads();
-            if (in == 0) {
-                for (uint32_t k = 0; k < wv; ++k) {   // (the nearest earlier wave that saw a marker)
-                    const uint32_t c = s_scan[3 * kRWaves + k];
-                    in = c ? c : in;
-                }
+            {
+                uint32_t far = 0;   // (the nearest earlier wave that saw a marker; all words asked for at once)
+#pragma unroll
+                for (uint32_t k = 0; k + 1u < kRWaves; ++k) far = keep_or(k < wv ? s_scan[3 * kRWaves + k] : 0u, far);
+                in = keep_or(in, far);
             }
             uint32_t pw[kPer];
 #pragma unroll
@@ -867,8 +871,19 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
 #pragma unroll
             for (uint32_t k = 0; k < kPer / 4u; ++k)
                 mine8[k] = uint2a{pw[4 * k] | (pw[4 * k + 1] << 16), pw[4 * k + 2] | (pw[4 * k + 3] << 16)};
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k) moving = moving | (pw[k] < kLit);   // (these bytes; all threads' together: the chunk)
         }
-        __syncthreads();
+        // (the barrier behind the pointers is the first round's too: whether any pointer moves at all is known here)
+        bool go;
+        {
+            const uint32_t slot = rr % 3u;
+            if (moving) s_flag[slot] = 1;
+            if (tid == 0) s_flag[(rr + 1u) % 3u] = 0;
+            __syncthreads();
+            ++rr;
+            go = s_flag[slot] != 0u;
+        }
         // pointer jumping: until every pointer is FINAL -- at a literal or in front of the chunk (the ranges above).  A thread
         // keeps the pointers of its kPer bytes (j = tid + kRThreads k) in registers; a round replaces a pointer by the pointer
         // found where it points (one LDS read, all of a thread's in flight together) and learns from that word's own bits
@@ -876,22 +891,11 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
         // a pointer's place holds is a pointer to a byte of the same value.  The rounds' "some pointer is not final" words take
         // turns (three: the one a round sets was cleared two barriers ago)
         uint32_t pj[kPer];
-        bool moving = false;
 #pragma unroll
-        for (uint32_t k = 0; k < kPer; ++k) {
-            const uint32_t j = tid + kRThreads * k;
-            pj[k] = mark[j];   // (behind the chunk's end the table holds a final pointer)
-            moving = moving | (pj[k] < kLit);
-        }
+        for (uint32_t k = 0; k < kPer; ++k) pj[k] = mark[tid + kRThreads * k];   // (behind the chunk's end the table holds a final pointer)
         RPROF_T(c3);
         RPROF_ADD(3, c2, c3);
-        for (;;) {
-            const uint32_t slot = rr % 3u;
-            if (moving) s_flag[slot] = 1;
-            if (tid == 0) s_flag[(rr + 1u) % 3u] = 0;
-            __syncthreads();
-            ++rr;
-            if (!s_flag[slot]) break;
+        while (go) {
             RPROF_INC(9, 1);
             // kJumps jumps per round and barrier, every lane the same instructions (a final pointer reads some word and keeps itself)
             uint32_t cur[kPer];
@@ -912,13 +916,16 @@ __global__ __launch_bounds__(kRThreads) void k_inflate_resolve(const BgzfBlock* 
                 pj[k] = cur[k];
                 moving = moving | (cur[k] < kLit);
             }
+            const uint32_t slot = rr % 3u;
+            if (moving) s_flag[slot] = 1;
+            if (tid == 0) s_flag[(rr + 1u) % 3u] = 0;
+            __syncthreads();
+            ++rr;
+            go = s_flag[slot] != 0u;
         }
         RPROF_T(c4);
         RPROF_ADD(4, c3, c4);
         {
-            // (nobody reads a pointer from LDS any more: the next chunk's markers want the table empty)
-#pragma unroll
-            for (uint32_t k = 0; k < kPer / 4u; ++k) mine8[k] = uint2a{0u, 0u};
             // every byte of the chunk from where its pointer ends (a literal takes its own value again)
             uint8_t v[kPer];
 #pragma unroll

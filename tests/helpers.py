@@ -30,7 +30,17 @@ def partials_from_oracle(o: OracleResult, lineage: np.ndarray, dense_taxid: np.n
 
 def assert_profiles_match(got_text: str, want_text: str, check_lineage: bool = True):
     got, want = parse_profile(got_text), parse_profile(want_text)
-    assert set(got) == set(want), f"profile rows differ: only got {set(got) - set(want)}, only want {set(want) - set(got)}"
+    # Q16: the reference sums a parent's child abundances in float32 in the iteration order of an unordered_map,
+    # and prints an "unclassified" row when parent - sum > abundance_cut_off.  With a cut-off of 0 and every read of the parent
+    # in its children, that difference is 0 or one float32 rounding step (4.8e-7 at abundances of a few per cent) by the ORDER
+    # of the sum alone: a row `<parent>*` with read_count 0 and an abundance inside the tolerance below is there or not
+    # there by that order, on both sides (found by scripts/stress_bgzf.py, seed 6061).  Such rows may be on one side only.
+    def residue(rows, k):
+        return k.endswith("*") and k != "0*" and rows[k][1] == 0 and abs(rows[k][0]) <= 2e-5
+    only_got = {k for k in set(got) - set(want) if not residue(got, k)}
+    only_want = {k for k in set(want) - set(got) if not residue(want, k)}
+    assert not only_got and not only_want, f"profile rows differ: only got {only_got}, only want {only_want}"
+    want = {k: v for k, v in want.items() if k in got}
     for k in want:
         assert got[k][1] == want[k][1], f"read_count of row {k}: {got[k][1]} != {want[k][1]}"
         # both sides print 6 significant digits; allow one unit in the last printed digit for a different float sum order

@@ -118,3 +118,26 @@ def test_random_shuffled_inputs():
             _run(w, False)
         except AssertionError as e:
             raise AssertionError(f"seed {seed}: {e}") from e
+
+
+def test_q16_rounding_residue_row():
+    """Seed 6061 (found by scripts/stress_bgzf.py): every read of genus 3010 lies in its species, so the genus's "unclassified"
+    abundance is parent - sum(children) = 0 -- or ONE float32 rounding step (4.8e-7), by the order in which the children's
+    abundances are added up.  The reference adds them in the iteration order of an unordered_map (src/slimm.hpp:776-813, Q16),
+    the library in ascending taxon order: with abundance_cut_off = 0 the row `3010*` (read_count 0) is printed by one and not
+    by the other.  Every integer of the run is equal; tests/helpers.py lets a starred row of 0 reads whose abundance is inside
+    the abundance tolerance be on one side only, and nothing else."""
+    from oracle.binding import parse_profile
+    w = random_case(6061)
+    o = run_workload(w, use_qnames=False)
+    s = Slimm.for_workload(w, device=0, grouped=True)
+    s.push_records(w.records)
+    s.get_profiles()
+    assert_matches_oracle(s, o)
+    got, want = parse_profile(s.write_abundance()), parse_profile(o.profile_tsv)
+    for k in set(got) ^ set(want):
+        rows = got if k in got else want
+        assert k.endswith("*") and k != "0*" and rows[k][1] == 0 and abs(rows[k][0]) < 1e-6, (k, rows[k])
+    for form in ("marked", "packed"):
+        _run(w, True, form)
+    _run(w, False)

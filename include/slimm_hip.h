@@ -35,6 +35,8 @@ enum {
     SLIMM_E_RUN_LENGTH = -4,/* (not returned any more: a read may have any number of alignment records; the value is
                                kept so that the codes after it do not move) */
     SLIMM_E_KEY_COLLISION = -5, /* records with one read key carry different check words (slimm_push_records_checked) */
+    SLIMM_E_REGROUP = -6,   /* a GROUPED stream holds names ending in ".1" / ".2" without a mate flag whose flagged namesakes
+                               may lie elsewhere in the file (quirk Q18): push the file again to a SLIMM_ORDER_ANY context */
     SLIMM_E_RETRY = 2,      /* not an error: slimm_install_merged_partials asks for slimm_filter_alignments_launch again */
     SLIMM_E_NO_HITS = 1     /* not an error: no mapped record (reference prints a warning and writes nothing, src/slimm.hpp:451-455) */
 };
@@ -110,6 +112,18 @@ int slimm_set_min_reads(slimm_ctx* ctx, uint32_t min_reads);
  * ADJACENT records, so a producer that hashes names can make the promise exact by comparing every name with the
  * one before it (the slimm command's reader does: host/alignment_file.cpp, separate_adjacent_names); for ANY order
  * a 62-bit hash leaves ~n^2 / 2^63 odds of two different names meeting.
+ *
+ * Q18 ON A GROUPED STREAM.  A file grouped by QNAME (mapper output, @HD GO:query / SO:queryname) keeps the records of one
+ * QNAME adjacent -- not the records of one reference KEY STRING: `r` (flag 0x40) and the unflagged `r.1` are one read of
+ * the reference wherever the two names lie in the file (src/slimm.hpp:204-211 merges through a hash map).  Only a record
+ * whose name was SHORTENED (no mate flag, ends in ".1" / ".2") can join records of another QNAME, and a run of adjacent
+ * records with one canonical base is complete iff it holds an un-shortened record (the QNAME = base records are
+ * contiguous, so they are these).  The library's decoders (slimm_push_bam_bytes, _bgzf_blocks, _sam_bytes) therefore count,
+ * per file, the runs that consist of shortened names only; when there is one, slimm_analyze_alignments of the GROUPED
+ * context returns SLIMM_E_REGROUP: the caller pushes the file again to a context created with SLIMM_ORDER_ANY, which is
+ * exact whatever the order (the slimm command does that by itself).  A file without such names pays two register adds per
+ * record.  A producer of decoded GROUPED records (slimm_push_records*, slimm_group_push_records*) applies the same rule with
+ * slimm_host_q18_note / slimm_host_q18_regroup_needed below -- the library never sees its names.
  *
  * DECLARING A STREAM GROUPED IS A PROMISE THE LIBRARY DOES NOT CHECK BY ITSELF.  With record_order = SLIMM_ORDER_GROUPED
  * the front end compares adjacent records only: a read name that comes back after other names have been in between
@@ -219,6 +233,16 @@ int slimm_push_bam_bytes(slimm_ctx* ctx, const uint8_t* bytes, uint64_t n_bytes,
  * slimm_push_bam_bytes, plus
  * SLIMM_E_INVALID for anything that is not a BGZF block or does not inflate to its ISIZE. */
 int slimm_push_bgzf_blocks(slimm_ctx* ctx, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records);
+/* DEVICE MEMORY OF THE WINDOW PIPELINE.  A gathered window holds [16 MiB | up to 1.9 GB inflated] + its compressed bytes
+ * (window / ratio + one push) + 16 B per block + the inflater's scratch (~0.36 B per inflated byte, two sets) + 456 record
+ * offsets per 16 KB; up to four windows are in turn in flight.  slimm_set_input_size_hint(ctx, the file's COMPRESSED size),
+ * called before a file's first window, lets the library reserve exactly what the file will use at its first push (a 70 MB
+ * file: one window of ~0.3 GB; a file of many gigabytes: four windows, ~14 GB at a ratio of 3) -- reserving ahead matters
+ * because an allocation made while inflate kernels run waits for them.  Without a hint nothing is reserved ahead and buffers
+ * appear as windows need them (the same totals, some stalls).  slimm_reset keeps up to 4 GiB of these buffers for the next
+ * file and releases them above that; slimm_window_memory reports what is held.  The hint is per file (cleared by slimm_reset). */
+int slimm_set_input_size_hint(slimm_ctx* ctx, uint64_t compressed_bytes);
+int slimm_window_memory(slimm_ctx* ctx, uint64_t* device_bytes);
 /* SAM TEXT decoded on the device (slimm_amd/csrc/sam_decode.hip): the reference takes .sam and .bam alike
  * (src/file_helper.hpp:73-75; the record loop src/slimm.hpp:194-208 reads QNAME, FLAG, RNAME -> reference index, POS).
  * `text` = the file's alignment lines, everything behind the header, in windows cut ANYWHERE (the incomplete last line of a
@@ -446,6 +470,20 @@ uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t re
  * compares) name[0, base) and hands the library *flag_out: then "equal keys and equal mate <=> equal reference key
  * string" holds.  The library's own readers (host/alignment_file.cpp, bam_decode.hip) do exactly this. */
 uint32_t slimm_host_canonical_read_name(const char* name, uint32_t name_len, uint16_t flag, uint16_t* flag_out);
+/* Q18 for a producer of GROUPED records (see "Q18 ON A GROUPED STREAM" above): one slimm_q18_runs per file, zeroed;
+ * slimm_host_q18_note for EVERY record in file order -- starts_run: its canonical base differs from the base of the record
+ * before it (the file's first record: 1), shortened: slimm_host_canonical_read_name returned less than name_len --;
+ * slimm_host_q18_regroup_needed != 0 at the end of the file: some run holds shortened names only, declare the file
+ * SLIMM_ORDER_ANY.  (What the device decoders count: slimm_amd/csrc/kernels.h, BamCarry.) */
+typedef struct slimm_q18_runs {
+    uint64_t short_starts;    /* runs whose first record has a shortened name */
+    uint64_t short_to_plain;  /* steps from a shortened to an un-shortened name inside a run */
+    int last_short;           /* the record before was shortened */
+} slimm_q18_runs;
+void slimm_host_q18_note(slimm_q18_runs* q, int starts_run, int shortened);
+int slimm_host_q18_regroup_needed(const slimm_q18_runs* q);
+/* The same two counts of the file a context's device decoders have read so far (0, 0 for any other record form). */
+int slimm_get_q18_runs(slimm_ctx* ctx, uint64_t* short_starts, uint64_t* short_to_plain);
 /* hipDeviceReset() of the process's devices: for a host about to leave the process.  Contexts must not be used afterwards. */
 int slimm_shutdown(void);
 /* Library build info. */

@@ -18,6 +18,7 @@ E_HIP = -2
 E_REF_RANGE = -3
 E_RUN_LENGTH = -4
 E_KEY_COLLISION = -5
+E_REGROUP = -6
 E_RETRY = 2
 E_NO_HITS = 1
 
@@ -157,6 +158,8 @@ SYMBOLS = [
     ("slimm_bgzf_inflate_with", C.c_int, [C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_char_p,
                                           C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),
     ("slimm_pin_host_buffer", C.c_int, [_P, _P, C.c_uint64]),
+    ("slimm_set_input_size_hint", C.c_int, [_P, C.c_uint64]),
+    ("slimm_window_memory", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("slimm_group_plan", None, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                 C.POINTER(C.c_uint32)]),
     ("slimm_grouped_records", C.c_int, [_P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -164,6 +167,9 @@ SYMBOLS = [
     ("slimm_host_quantile_cut_off", C.c_float, [_P, C.c_uint32, C.c_float]),
     ("slimm_host_bin_of", C.c_uint32, [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]),
     ("slimm_host_canonical_read_name", C.c_uint32, [C.c_char_p, C.c_uint32, C.c_uint16, C.c_void_p]),
+    ("slimm_host_q18_note", None, [_P, C.c_int, C.c_int]),
+    ("slimm_host_q18_regroup_needed", C.c_int, [_P]),
+    ("slimm_get_q18_runs", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("slimm_shutdown", C.c_int, []),
     ("slimm_version", C.c_char_p, []),
 ]

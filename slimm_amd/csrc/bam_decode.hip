@@ -317,6 +317,7 @@ __global__ __launch_bounds__(64) void k_bam_decode(const uint8_t* __restrict__ b
             }
         }
     }
+    uint32_t n_short_starts = 0, n_short_to_plain = 0;
     for (uint32_t k = threadIdx.x; k < pc.count; k += 64u) {
         const uint8_t* r = b + po[k] + 4;
         const int32_t rid = static_cast<int32_t>(ld_u32(r));
@@ -324,19 +325,27 @@ __global__ __launch_bounds__(64) void k_bam_decode(const uint8_t* __restrict__ b
         const uint32_t l_name = r[8];
         const uint8_t* name = r + 32;
         uint32_t nlen = l_name ? l_name - 1u : 0u;
-        const uint32_t fl = bam_canonical(name, nlen, ld_u16(r + 14));
+        const uint32_t fl0 = ld_u16(r + 14);
+        const uint32_t fl = bam_canonical(name, nlen, fl0);
         const uint64_t at = out_at + pc.base + k;
         if (kMarked) {
-            bool starts;
+            bool starts, prev_short;
             const uint32_t po_prev = k ? po[k - 1] : prev0;
             if (po_prev != 0xffffffffu) {
                 const uint8_t* q = b + po_prev + 4;
                 uint32_t qlen = q[8] ? q[8] - 1u : 0u;
-                bam_canonical(q + 32, qlen, ld_u16(q + 14));
+                const uint32_t qfl0 = ld_u16(q + 14);
+                prev_short = bam_canonical(q + 32, qlen, qfl0) != qfl0;
                 starts = !bam_same_name(name, nlen, q + 32, qlen);
             } else {
                 starts = !(carry->have && bam_same_name(name, nlen, carry->name, carry->len));
+                prev_short = carry->last_short != 0u;
             }
+            // Q18 on a grouped stream (kernels.h: BamCarry): runs that start with a shortened name, shortened -> plain steps
+            // inside a run -- counted per lane, added up per piece behind the loop
+            const bool is_short = fl != fl0;
+            n_short_starts += (is_short & starts) ? 1u : 0u;
+            n_short_to_plain += (!is_short & !starts & prev_short) ? 1u : 0u;
             // slimm_mark_word (context.hip): reference + 1 (0: not mapped) | mate << 29 | starts a qName run << 31
             const uint32_t mate = (fl & 0x40u) ? 1u : ((fl & 0x80u) ? 2u : 0u);
             const bool mapped = !(fl & 0x4u) && rid != -1;
@@ -351,6 +360,16 @@ __global__ __launch_bounds__(64) void k_bam_decode(const uint8_t* __restrict__ b
             check[at] = bam_check_name(name, nlen);
         }
     }
+    if (kMarked && __any(static_cast<int>(n_short_starts | n_short_to_plain))) {   // (a file without such names: one vote per piece)
+        for (uint32_t d = 32u; d; d >>= 1) {
+            n_short_starts += static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_short_starts), static_cast<int>(d)));
+            n_short_to_plain += static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_short_to_plain), static_cast<int>(d)));
+        }
+        if (threadIdx.x == 0) {
+            if (n_short_starts) atomicAdd(&carry->short_starts, n_short_starts);
+            if (n_short_to_plain) atomicAdd(&carry->short_to_plain, n_short_to_plain);
+        }
+    }
 }
 
 // the window's last record's name -> the carry (after k_bam_decode of the same window has read the old one)
@@ -362,11 +381,13 @@ __global__ __launch_bounds__(64) void k_bam_carry(const uint8_t* __restrict__ b,
     const uint32_t o = offs[static_cast<size_t>(c) * kBamSlots + pieces[c].count - 1u];
     const uint8_t* r = b + o + 4;
     uint32_t nlen = r[8] ? r[8] - 1u : 0u;
-    bam_canonical(r + 32, nlen, ld_u16(r + 14));  // the carried name is the canonical base
+    const uint32_t fl0 = ld_u16(r + 14);
+    const uint32_t fl = bam_canonical(r + 32, nlen, fl0);  // the carried name is the canonical base
     for (uint32_t i = threadIdx.x; i < nlen; i += 64u) carry->name[i] = r[32 + i];
     if (threadIdx.x == 0) {
         carry->len = nlen;
         carry->have = 1;
+        carry->last_short = fl != fl0 ? 1u : 0u;
     }
 }
 

@@ -131,6 +131,9 @@ struct slimm_ctx {
     uint32_t taxon_shift = 0;
     uint32_t Tsel = 0;                 // size of the selectors' taxon space: 8 << taxon_shift (16-byte rows) or T
     PinBuf<uint4> h_rows16;
+    DevBuf<uint32_t> d_valid_bits;     // one bit per reference: what k_filter_compact asks before anything else
+    PinBuf<uint32_t> h_valid_bits;
+    std::vector<uint32_t> valid_bits_prev;   // references whose bit is set in h_valid_bits
     bool rows16_base_ready = false;    // h_rows16 holds the static part of every row
     std::vector<uint32_t> rows16_prev; // references whose valid bit is set in h_rows16
     bool use_rows16 = false;
@@ -152,6 +155,7 @@ struct slimm_ctx {
     static constexpr uint64_t kBamInFlight = 4ull << 30;    // finish the oldest window when more than this is in flight
     static constexpr uint64_t kBamGather = 1900ull << 20;   // inflated bytes of a gathered device window (a window is < 2 GiB)
     static constexpr uint64_t kBamGatherGoal = 1400ull << 20;  // ... which is launched once it holds this much
+    static constexpr uint64_t kBamKeepAcrossFiles = 4ull << 30; // slimm_reset gives the pipeline's buffers back above this
     struct BamDecode {
         DevBuf<uint8_t> bytes[kBamRing];
         DevBuf<BamPiece> pieces;
@@ -194,6 +198,17 @@ struct slimm_ctx {
         uint32_t sam_mask = 0;
         uint8_t sam_last_byte = '\n';
         std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
+        // Q18 on a grouped stream (kernels.h: BamCarry): the decoders' two counts of the windows finished so far
+        uint64_t q18_starts = 0, q18_plain = 0;
+        // what the file's gathered windows are sized for: slimm_set_input_size_hint (the file's compressed bytes; 0 = not
+        // told) and, from it and the first push's ratio, the inflated bytes a gathered window's buffer gets (0 = kBamGather)
+        uint64_t size_hint = 0, win_cap = 0;
+        uint64_t held_bytes() const {   // device memory of the window pipeline
+            uint64_t n = pieces.cap * sizeof(BamPiece) + offs.cap * 4ull;
+            for (uint32_t k = 0; k < kBamRing; ++k) n += bytes[k].cap + comp[k].cap + desc[k].cap * sizeof(BgzfBlock);
+            for (auto& sc : inflate_scratch) n += sc.cap;
+            return n;
+        }
     } bam;
     DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
     bool borrowed = false;
@@ -441,6 +456,19 @@ hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStr
     return hipSuccess;
 }
 
+// the Q18 run counts of the device decoders (every window launched so far), from the carry block
+int bam_fetch_q18(slimm_ctx* c) {
+    slimm_ctx::BamDecode& B = c->bam;
+    if (!B.carry.p) return SLIMM_OK;
+    (void)hipSetDevice(c->device);
+    uint32_t w[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(w, &B.carry.p->short_starts, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    B.q18_starts = w[0];
+    B.q18_plain = w[1];
+    return SLIMM_OK;
+}
+
 int check_device_errors(slimm_ctx* c, uint32_t err) {
     if (err & ERR_REF_RANGE) return fail(c, SLIMM_E_REF_RANGE, "a record names a reference id >= n_refs");
     if (err & ERR_KEY_COLLISION)
@@ -583,6 +611,9 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HIP_TRY0(cc->d_bin_off.ensure(c->R + 1));
         HIP_TRY0(cc->d_lin_dense.ensure(static_cast<size_t>(c->R) * 8));
         HIP_TRY0(cc->d_valid.ensure(c->R));
+        HIP_TRY0(cc->d_valid_bits.ensure(c->R / 32 + 2));
+        HIP_TRY0(cc->h_valid_bits.ensure(c->R / 32 + 2));
+        memset(cc->h_valid_bits.p, 0, (c->R / 32 + 2) * 4);
         HIP_TRY0(cc->bins.ensure(3 * c->Bp + kTailWords + c->Tpad));
         HIP_TRY0(cc->counters.ensure(CNT_WORDS));
         HIP_TRY0(cc->ref_stats.ensure(c->statsA_words() + c->statsB_words() + 64));
@@ -781,6 +812,19 @@ int slimm_reset(slimm_ctx* c) {
     c->bam.active = false;
     c->bam.head = 0;
     c->bam.closed = false;
+    c->bam.q18_starts = c->bam.q18_plain = 0;
+    c->bam.size_hint = c->bam.win_cap = 0;
+    if (c->bam.held_bytes() > slimm_ctx::kBamKeepAcrossFiles) {   // (a large file's windows: the next file sizes its own)
+        (void)hipSetDevice(c->device);
+        for (uint32_t k = 0; k < slimm_ctx::kBamRing; ++k) {
+            c->bam.bytes[k].release();
+            c->bam.comp[k].release();
+            c->bam.desc[k].release();
+        }
+        for (auto& sc : c->bam.inflate_scratch) sc.release();
+        c->bam.pieces.release();
+        c->bam.offs.release();
+    }
     c->has_check = false;
     c->packed = false;
     c->marked = false;
@@ -1143,6 +1187,17 @@ namespace {
 enum { kFormatBam = 0, kFormatBgzf = 1, kFormatSam = 2 };
 int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int format, uint32_t skip, int last, uint64_t* n_records);
 }
+int slimm_set_input_size_hint(slimm_ctx* c, uint64_t compressed_bytes) {
+    if (!c) return SLIMM_E_INVALID;
+    if (c->bam.active) return fail(c, SLIMM_E_INVALID, "slimm_set_input_size_hint: before the file's first window");
+    c->bam.size_hint = compressed_bytes;
+    return SLIMM_OK;
+}
+int slimm_window_memory(slimm_ctx* c, uint64_t* device_bytes) {
+    if (!c || !device_bytes) return SLIMM_E_INVALID;
+    *device_bytes = c->bam.held_bytes();
+    return SLIMM_OK;
+}
 int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records) {
     return bam_push_window(c, bytes, n_bytes, kFormatBam, 0u, last, n_records);
 }
@@ -1215,7 +1270,7 @@ int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes, bool gathered = false) {
     const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
     // (a gathered window gets the room of the largest one at once: a buffer that grows is a hipFree, and a hipFree waits for
     // the inflate kernels of the windows before)
-    const uint64_t need = kBamSlack + (gathered ? std::max<uint64_t>(n_bytes, slimm_ctx::kBamGather) : n_bytes) + 64;
+    const uint64_t need = kBamSlack + (gathered ? std::max<uint64_t>(n_bytes, B.win_cap ? B.win_cap : slimm_ctx::kBamGather) : n_bytes) + 64;
     if (B.bytes[b].cap >= need) return SLIMM_OK;
     // (what the buffer held -- the window a ring's length back -- is done with: it was finished before this one was let in.
     // Only the carried bytes in its slack matter, and only when the window before this one is finished already: otherwise
@@ -1369,20 +1424,40 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
             B.acc_skip = skip;
             B.acc_tok = 0;
             B.desc_host[b].clear();
-            // A large file's first window: every buffer the windows will take in turn, now -- an allocation (like a hipFree)
-            // made while inflate kernels are in flight waits for them, and the pushes that should overlap them stand still
-            if (B.windows == 0 && src_bytes >= (64ull << 20)) {
-                const uint32_t blocks_max = static_cast<uint32_t>(slimm_ctx::kBamGather / 49152u);
-                const uint64_t tok_max = slimm_ctx::kBamGather / 3u + slimm_ctx::kBamGather / 256u + 8ull * blocks_max;
-                for (uint32_t k = 0; k < slimm_ctx::kBamRing; ++k) {
-                    HIP_TRY(c, B.bytes[k].ensure_later(kBamSlack + slimm_ctx::kBamGather + 64, B.outgrown));
-                    HIP_TRY(c, B.comp[k].ensure_later(1ull << 30, B.outgrown));
-                    HIP_TRY(c, B.desc[k].ensure_later(blocks_max, B.outgrown));
+            // A file's first window: the buffers its windows will take in turn, now -- an allocation (like a hipFree) made
+            // while inflate kernels are in flight waits for them, and the pushes that should overlap them stand still.  How
+            // many and how large comes from the caller's hint (slimm_set_input_size_hint: the file's compressed bytes) and
+            // this push's own ratios: a 70 MB file gets one window of its size, not four of 1.9 GB (17 GB
+            // per context whatever the file).  Without a hint nothing is reserved ahead: buffers appear as windows need them.
+            if (B.windows == 0) {
+                B.win_cap = 0;
+                if (B.size_hint && src_bytes && inflated) {
+                    const double ratio = static_cast<double>(inflated) / static_cast<double>(src_bytes);
+                    const uint64_t left = B.size_hint > src_bytes ? B.size_hint - src_bytes : 0;
+                    const uint64_t est = inflated + static_cast<uint64_t>(static_cast<double>(left) * ratio * 1.08) + (16ull << 20);
+                    const uint64_t nwin = est <= slimm_ctx::kBamGather ? 1u : (est + slimm_ctx::kBamGatherGoal - 1) / slimm_ctx::kBamGatherGoal;
+                    const uint32_t nbuf = static_cast<uint32_t>(std::min<uint64_t>(slimm_ctx::kBamRing, nwin));
+                    B.win_cap = nwin == 1 ? est : slimm_ctx::kBamGather;
+                    // (a window's compressed bytes: what inflates to the goal, plus the push that crosses it)
+                    const uint64_t comp_cap = (nwin == 1 ? B.size_hint + (B.size_hint >> 4)
+                                                         : static_cast<uint64_t>(static_cast<double>(slimm_ctx::kBamGatherGoal) / ratio * 1.15) + src_bytes) +
+                                              kBgzfTail + (1ull << 20);
+                    const double blocks_per_byte = static_cast<double>(dh.size()) / static_cast<double>(inflated);
+                    const uint32_t blocks_max = static_cast<uint32_t>(static_cast<double>(B.win_cap) * blocks_per_byte * 1.25) + 1024u;
+                    const uint64_t tok_max = B.win_cap / 3u + B.win_cap / 256u + 8ull * blocks_max;
+                    for (uint32_t k = 0; k < nbuf; ++k) {
+                        HIP_TRY(c, B.bytes[k].ensure_later(kBamSlack + B.win_cap + 64, B.outgrown));
+                        HIP_TRY(c, B.comp[k].ensure_later(comp_cap, B.outgrown));
+                        HIP_TRY(c, B.desc[k].ensure_later(blocks_max, B.outgrown));
+                    }
+                    for (uint32_t k = 0; k < std::min<uint32_t>(2u, nbuf); ++k)
+                        HIP_TRY(c, B.inflate_scratch[k].ensure_later(bgzf_inflate_scratch_bytes(blocks_max, tok_max), B.outgrown));
+                    const size_t np_max = bam_pieces(B.win_cap + kBamSlack) + 64;
+                    HIP_TRY(c, B.pieces.ensure_later(np_max, B.outgrown));
+                    HIP_TRY(c, B.offs.ensure_later(np_max * kBamSlots, B.outgrown));
+                    push_trace("planned %llu window(s) of <= %.0f MB in %u buffer(s), %.0f MB of compressed bytes each: %.2f GB held",
+                               (unsigned long long)nwin, B.win_cap / 1e6, nbuf, comp_cap / 1e6, B.held_bytes() / 1e9);
                 }
-                for (auto& sc : B.inflate_scratch) HIP_TRY(c, sc.ensure_later(bgzf_inflate_scratch_bytes(blocks_max, tok_max), B.outgrown));
-                const size_t np_max = bam_pieces(slimm_ctx::kBamGather + kBamSlack) + 64;
-                HIP_TRY(c, B.pieces.ensure_later(np_max, B.outgrown));
-                HIP_TRY(c, B.offs.ensure_later(np_max * kBamSlots, B.outgrown));
                 HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
                 HIP_TRY(c, B.h_inflate_status.ensure(4));
             }
@@ -1390,7 +1465,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
         const uint64_t need = B.acc_src + src_bytes + kBgzfTail + 64;
         if (B.comp[b].cap < need) {  // (grown with what earlier pushes of this window have put there)
             DevBuf<uint8_t> nb;
-            HIP_TRY(c, nb.ensure(std::max<uint64_t>(need + (need >> 1), 768ull << 20)));
+            HIP_TRY(c, nb.ensure(need + (need >> 1)));
             if (B.acc_src) HIP_TRY(c, hipMemcpyAsync(nb.p, B.comp[b].p, B.acc_src, hipMemcpyDeviceToDevice, c->copy_stream));
             std::swap(B.comp[b].p, nb.p);
             std::swap(B.comp[b].cap, nb.cap);
@@ -1646,6 +1721,19 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "already analysed; reset first");
     HostTrace tr("analyze_alignments");
     (void)hipSetDevice(c->device);
+    if (c->bam.active) {
+        // (windows pushed so far may still be gathered or in flight: analysing now would profile a truncated record stream)
+        if (!c->bam.closed)
+            return fail(c, SLIMM_E_INVALID, "the file's last window has not been pushed (slimm_push_bam_bytes / _bgzf_blocks / _sam_bytes with last != 0)");
+        if (c->order == SLIMM_ORDER_GROUPED) {  // Q18: a run of shortened names only may have its flagged namesakes elsewhere
+            const int qrc = bam_fetch_q18(c);
+            if (qrc != SLIMM_OK) return qrc;
+            if (c->bam.q18_starts != c->bam.q18_plain)
+                return fail(c, SLIMM_E_REGROUP,
+                            "read names ending in .1 / .2 without a mate flag, apart from the flagged records of the shortened name: "
+                            "push this file to a context created with SLIMM_ORDER_ANY");
+        }
+    }
     const uint32_t n = c->rec.n;
     int rc = ensure_work_buffers(c, n);
     if (rc != SLIMM_OK) return rc;
@@ -2051,6 +2139,11 @@ int filter_prepare(slimm_ctx* c, bool& rows_ride_along) {
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_valid.p, h.valid.data(), R, hipMemcpyHostToDevice, st));
     }
+    // one bit per reference (rides along with the clearing kernel like the rows)
+    for (uint32_t r : c->valid_bits_prev) c->h_valid_bits.p[r >> 5] &= ~(1u << (r & 31u));
+    c->valid_bits_prev = h.valid_list();
+    for (uint32_t r : c->valid_bits_prev) c->h_valid_bits.p[r >> 5] |= 1u << (r & 31u);
+    tr.mark("valid bitmap");
     return SLIMM_OK;
 }
 
@@ -2093,6 +2186,9 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             z.cp_src = reinterpret_cast<const uint32_t*>(c->h_rows16.p);
             z.cp_n = R * 4u;
         }
+        z.cp2_dst = c->d_valid_bits.p;   // (every launch: a retry's too -- 2.5 KB at 20 000 references)
+        z.cp2_src = c->h_valid_bits.p;
+        z.cp2_n = R / 32u + 1u;
         launch_zero(st, z);
     }
     const uint32_t nslots = front_slots(c->rec.n);
@@ -2114,6 +2210,8 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             fa.lin_dense = c->d_lin_dense.p;
             fa.valid = c->d_valid.p;
         }
+        static const bool by_window = getenv("SLIMM_FILTER_BY_WINDOW") != nullptr;   // (round 5's k_filter: A/B runs)
+        fa.valid_bits = by_window ? nullptr : c->d_valid_bits.p;
         fa.sel = c->sel.p;
         fa.slot_rbase = c->slot_rbase.p;
         fa.slot_bbase = c->slot_bbase.p;
@@ -2698,6 +2796,23 @@ uint32_t slimm_host_canonical_read_name(const char* name, uint32_t name_len, uin
     const uint16_t f = slimm::canonical_read(name, n, flag);
     if (flag_out) *flag_out = f;
     return static_cast<uint32_t>(n);
+}
+void slimm_host_q18_note(slimm_q18_runs* q, int starts_run, int shortened) {  // include/slimm_hip.h: "Q18 ON A GROUPED STREAM"
+    if (!q) return;
+    if (shortened && starts_run) ++q->short_starts;
+    if (!shortened && !starts_run && q->last_short) ++q->short_to_plain;
+    q->last_short = shortened != 0;
+}
+int slimm_host_q18_regroup_needed(const slimm_q18_runs* q) { return q && q->short_starts != q->short_to_plain; }
+int slimm_get_q18_runs(slimm_ctx* c, uint64_t* short_starts, uint64_t* short_to_plain) {
+    if (!c || !short_starts || !short_to_plain) return SLIMM_E_INVALID;
+    *short_starts = *short_to_plain = 0;
+    if (c->device < 0 || !c->bam.active || c->order != SLIMM_ORDER_GROUPED) return SLIMM_OK;
+    const int rc = bam_fetch_q18(c);
+    if (rc != SLIMM_OK) return rc;
+    *short_starts = c->bam.q18_starts;
+    *short_to_plain = c->bam.q18_plain;
+    return SLIMM_OK;
 }
 uint32_t slimm_host_bin_of(int32_t begin_pos, uint32_t avg_read_len, uint32_t ref_len, uint32_t bin_width) {
     uint32_t center = std::min(static_cast<uint32_t>(begin_pos) + (avg_read_len / 2), ref_len);  // slimm.hpp:200

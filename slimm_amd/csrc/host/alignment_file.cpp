@@ -181,6 +181,8 @@ bool AlignmentFile::open(const std::string& path) {
     eof_ = false;
     have_pending_ = false;
     have_last_ = false;
+    last_short_ = false;
+    q18_short_starts_ = q18_short_to_plain_ = 0;
     {
         // as many threads as the process may keep busy: the logical CPUs, or the cgroup's CPU quota when that is less (a
         // container on a 256-thread host may be held to 16 cores' worth; twice the quota keeps them fed across the
@@ -769,6 +771,25 @@ void AlignmentFile::separate_adjacent_names(uint64_t* key, const std::vector<siz
             clash.insert(clash.begin() + static_cast<long>(q) + 1, e);
         }
     }
+    // Q18 on a grouped file: runs (equal keys = equal canonical bases by now) that start with a shortened name, and steps
+    // from a shortened to an un-shortened name inside a run
+    {
+        auto shortened = [&](size_t k) {
+            const uint8_t* r = &buf_[offs[k] + 4];
+            size_t len = r[8] ? r[8] - 1u : 0u;
+            const uint16_t f0 = rd_u16(r + 14);
+            return canonical_read(reinterpret_cast<const char*>(r + 32), len, f0) != f0;
+        };
+        bool prev_short = last_short_;
+        for (size_t k = 0; k < cnt; ++k) {
+            const bool starts = k ? key[k] != key[k - 1] : !(have_last_ && key[0] == last_key_);
+            const bool sh = shortened(k);
+            q18_short_starts_ += (sh && starts) ? 1u : 0u;
+            q18_short_to_plain_ += (!sh && !starts && prev_short) ? 1u : 0u;
+            prev_short = sh;
+        }
+        last_short_ = prev_short;
+    }
     size_t ll;
     const char* ln = name_of(cnt - 1, ll);
     last_name_.assign(ln, ll);
@@ -1246,14 +1267,22 @@ long AlignmentFile::read_batch(RecordBatch& out, size_t max_records, bool keep_n
             if (it != index.end()) ref_id = it->second;
         }
         size_t blen = qn.size();
+        const uint16_t flag0 = flag;
         flag = canonical_read(qn.data(), blen, flag);  // Q18: key, adjacent-name compare and mate on the canonical base
         const std::string bn = qn.substr(0, blen);
         uint64_t key = hash_read_name(bn.data(), bn.size());
+        const bool starts = !(have_last_ && bn == last_name_);
         if (have_last_) {  // (separate_adjacent_names, one record at a time)
-            if (bn == last_name_)
+            if (!starts)
                 key = last_key_;
             else if (key == last_key_)
                 key = (key + 1) & ((1ull << 62) - 1);
+        }
+        {   // (Q18 on a grouped file: as in separate_adjacent_names)
+            const bool sh = flag != flag0;
+            q18_short_starts_ += (sh && starts) ? 1u : 0u;
+            q18_short_to_plain_ += (!sh && !starts && last_short_) ? 1u : 0u;
+            last_short_ = sh;
         }
         last_name_ = bn;
         last_key_ = key;

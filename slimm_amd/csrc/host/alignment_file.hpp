@@ -68,6 +68,10 @@ public:
     const std::vector<std::string>& ref_names() const { return ref_names_; }
     const std::vector<uint32_t>& ref_lengths() const { return ref_len_; }
     SortOrder sort_order() const { return order_; }
+    // Q18 on a file grouped by QNAME (include/slimm_hip.h, "Q18 ON A GROUPED STREAM"): among the records read_batch /
+    // read_into have handed out, some run of adjacent records with one canonical base holds SHORTENED names only -- their
+    // flagged namesakes may lie anywhere in the file: the file must go through the any-order path
+    bool q18_regroup_needed() const { return q18_short_starts_ != q18_short_to_plain_; }
 
     // Appends up to max_records records to `out`; returns the number appended (0 at end of file), -1 on a format error.
     long read_batch(RecordBatch& out, size_t max_records, bool keep_names = false);
@@ -112,6 +116,8 @@ private:
     std::string last_name_;   // name and key of the last record handed out (separate_adjacent_names)
     uint64_t last_key_ = 0;
     bool have_last_ = false;
+    uint64_t q18_short_starts_ = 0, q18_short_to_plain_ = 0;   // runs that start shortened; shortened -> plain steps inside a run
+    bool last_short_ = false;                                   // the last record handed out had a shortened name
     // record starts in buf_[pos_, end): appended to offs, at most max_records; returns false on a malformed record
     bool find_records(size_t end, size_t max_records, std::vector<size_t>& offs, size_t& new_pos);
     bool plausible_record(size_t o, size_t end, int depth) const;

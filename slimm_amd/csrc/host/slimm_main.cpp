@@ -85,6 +85,7 @@ void* symbol(const char* name) {
         return f args;                                                               \
     }
 SLIMM_FORWARD(int, slimm_create, (const slimm_config* a, slimm_ctx** b), (a, b))
+SLIMM_FORWARD(int, slimm_set_input_size_hint, (slimm_ctx* a, uint64_t b), (a, b))
 SLIMM_FORWARD(void, slimm_destroy, (slimm_ctx* a), (a))
 SLIMM_FORWARD(const char*, slimm_last_error, (const slimm_ctx* a), (a))
 SLIMM_FORWARD(int, slimm_get_cutoff_cache, (slimm_ctx* a, float* b, float* c), (a, b, c))
@@ -368,6 +369,7 @@ int dump_records(const Options& o) {
         std::cerr << f.error() << "\n";
         return 1;
     }
+    std::cerr << "#q18_regroup_needed\t" << (f.q18_regroup_needed() ? 1 : 0) << "\n";   // (reader tests)
     return 0;
 }
 
@@ -856,13 +858,24 @@ bool write_raw_and_coverage(Session& S, slimm_ctx* ctx, bool global_bins, const 
 }
 
 // slimm::get_profiles() for one file (src/slimm.hpp:395-496)
-bool get_profiles(Session& S, size_t file_index) {
+// regroup: the file was found to need the any-order path while it was read as a grouped one (Q18, below): second reading
+bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
     Options& options = S.options;
     const std::string path = S.input_paths[file_index];
     Lap watch;
     Trace trace;
-    std::cerr << "\nReading " << file_index + 1 << " of " << S.input_paths.size() << " files ... (" << get_file_name(path) << ")\n"
-              << "=================================================================\n";
+    if (!regroup)
+        std::cerr << "\nReading " << file_index + 1 << " of " << S.input_paths.size() << " files ... (" << get_file_name(path) << ")\n"
+                  << "=================================================================\n";
+    // Q18 on a file grouped by QNAME (include/slimm_hip.h, "Q18 ON A GROUPED STREAM"): a read named `r.1` without a mate flag
+    // is the reference's read of the first-in-pair records of `r`, wherever those lie in the file (src/slimm.hpp:204-211).
+    // The readers count the runs of such shortened names that stand apart from their namesakes; a file that has one is read
+    // again, in any order (a fresh context of the same process: the HIP runtime and the page cache are warm).
+    auto read_again_in_any_order = [&]() {
+        std::cerr << "\n(read names ending in .1 / .2 without a mate flag, apart from the flagged records of the shortened name: "
+                     "reading " << get_file_name(path) << " again as a file in no particular order)\n";
+        return get_profiles(S, file_index, true);
+    };
     AlignmentFile bam;
     if (!bam.open(path)) {  // src/misc.hpp:500-504: message, skip the file
         std::cerr << bam.error() << "\n";
@@ -894,7 +907,8 @@ bool get_profiles(Session& S, size_t file_index) {
     bam.close();
     if (!bam.open(path)) return true;
     // only a header that promises name grouping is trusted; anything else is sorted on the device
-    const int record_order = options.order >= 0
+    const int record_order = regroup ? SLIMM_ORDER_ANY
+                             : options.order >= 0
                                  ? options.order
                                  : ((bam.sort_order() == SortOrder::QueryName || bam.sort_order() == SortOrder::QueryGrouped)
                                         ? SLIMM_ORDER_GROUPED
@@ -971,6 +985,10 @@ bool get_profiles(Session& S, size_t file_index) {
             slimm_group_destroy(grp);
             return false;
         }
+        if (record_order == SLIMM_ORDER_GROUPED && bam.q18_regroup_needed()) {
+            slimm_group_destroy(grp);
+            return read_again_in_any_order();
+        }
         const int grc = slimm_group_get_profiles(grp, get_tsv_file_name(options.output_prefix, path, "_profile").c_str());
         if (grc < 0) {
             std::cerr << "slimm: " << slimm_group_last_error(grp) << "\n";
@@ -1013,6 +1031,10 @@ bool get_profiles(Session& S, size_t file_index) {
         return false;
     }
     CHECK(ctx, slimm_set_cutoff_cache(ctx, S.cc_cache, S.ucc_cache));
+    {   // the file's size: what the library sizes its window buffers by (include/slimm_hip.h, slimm_set_input_size_hint)
+        struct stat fst;
+        if (stat(path.c_str(), &fst) == 0 && S_ISREG(fst.st_mode)) (void)slimm_set_input_size_hint(ctx, static_cast<uint64_t>(fst.st_size));
+    }
     slimm_keep_bins(ctx, (S.options.raw_output || S.options.coverage_output) ? 1 : 0);  // (only -ro / -co read the arrays back)
     trace.mark("lineage table + slimm_create");
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;
@@ -1066,7 +1088,19 @@ bool get_profiles(Session& S, size_t file_index) {
             std::cerr << "\n[WARNING] " << split << " read name run(s) repeat a name seen earlier in " << get_file_name(path)
                       << ": the file is NOT grouped by read name although it is declared so; run with --any-order\n";
     }
-    CHECK(ctx, slimm_analyze_alignments(ctx));
+    {
+        // (the device decoders count inside the library: SLIMM_E_REGROUP; the host decoder counts in the reader)
+        const int arc = record_order == SLIMM_ORDER_GROUPED && bam.q18_regroup_needed() ? SLIMM_E_REGROUP : slimm_analyze_alignments(ctx);
+        if (arc == SLIMM_E_REGROUP) {
+            slimm_destroy(ctx);
+            return read_again_in_any_order();
+        }
+        if (arc < 0) {
+            std::cerr << "slimm: slimm_analyze_alignments(ctx): " << slimm_last_error(ctx) << "\n";
+            slimm_destroy(ctx);
+            return false;
+        }
+    }
     int rc = slimm_finish_coverage(ctx);
     if (rc < 0) {
         std::cerr << "slimm: " << slimm_last_error(ctx) << "\n";

@@ -87,6 +87,9 @@ struct ZeroArgs {  // arrays cleared by one k_zero launch; p64 is filled with ~0
     uint32_t* cp_dst = nullptr;        // optional ride-along copy of cp_n words (16-byte aligned), e.g. pinned host -> device
     const uint32_t* cp_src = nullptr;
     uint32_t cp_n = 0;
+    uint32_t* cp2_dst = nullptr;       // ... and a second, small one (word by word)
+    const uint32_t* cp2_src = nullptr;
+    uint32_t cp2_n = 0;
 };
 void launch_zero(hipStream_t st, const ZeroArgs& z);
 // n words from device memory to host-mapped pinned memory (16-byte aligned both) by a kernel instead of the DMA engine
@@ -155,6 +158,7 @@ struct FilterArgs {
     uint32_t taxon_shift = 0;
     const uint32_t* lin_dense = nullptr;
     const uint8_t* valid = nullptr;
+    const uint32_t* valid_bits = nullptr;    // one bit per reference: k_filter_compact (nullptr: k_filter, window by window)
     uint32_t* sel = nullptr;                 // one selector per read, dense: slot s writes at slot_rbase[s] + slot_bbase[s >> 10]
     const uint32_t* slot_rbase = nullptr;    // (launch_slot_read_prefix)
     const uint32_t* slot_bbase = nullptr;
@@ -268,6 +272,13 @@ struct BamWindowResult {
 };
 struct BamCarry {  // the name of the last record of the window before (the next window's first record is compared with it)
     uint32_t have, len;
+    // Q18 on a GROUPED stream (read_identity.h): a record whose name was SHORTENED (no mate flag, the name ends in ".1" / ".2")
+    // is the same read as a flagged record of the shortened name -- which a file grouped by QNAME may hold anywhere.  A run of
+    // adjacent records with one canonical base is complete iff it holds an un-shortened record (the QNAME = base group is
+    // contiguous, so it is THIS one); a run of shortened records only may have its flagged namesakes elsewhere.  Counted per
+    // file: runs that start with a shortened record, and shortened -> plain steps inside a run (at most one per run in a file
+    // grouped by QNAME); they differ iff some run holds shortened records only.  last_short: the carried record was shortened.
+    uint32_t short_starts, short_to_plain, last_short, pad;
     uint8_t name[256];
 };
 uint32_t bam_pieces(uint64_t n_bytes);

@@ -689,6 +689,160 @@ __global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// k_filter_compact (round 6): the same phase B + C(1), COMPACTED FIRST.
+// k_filter above works through every window of <= 64 targets with ~85 scalar + ~85 vector instructions of lane-mask
+// arithmetic -- three rounds at 2.4 ms per 1 B records, bound by instruction issue, while only a fifth of the targets name
+// a valid reference (728 of 20 000 references at 1 B records).  Here a wave streams through its slot's targets in plain
+// chunks of 64 (no window cuts: read boundaries do not matter yet): one bit per reference says "valid" (a 2.5 KB bitmap: an
+// L1 hit instead of the 16-byte row gather), a ballot and two lane counts give every valid target its place in a ring of
+// 128 entries in LDS -- {reference, bin, index of its read in the slot} -- and the number of its read among the slot's.
+// Whenever the ring holds 64 entries (or the slot ends) the oldest ones that are whole reads are worked on as ONE window
+// in which every lane is valid: heads = "my read differs from the lane's before" (one DPP move), a read with one entry is
+// unique (its selector is its bin), a read with several gets the level scan of k_filter's window -- on a quarter of the
+// windows.  Reads that keep no target never show up: the slot's selectors live in LDS, start as "nothing" and leave in one
+// coalesced pass at the slot's end.  A read with 64 valid targets or more does not fit a window: its slot goes through
+// filter_span (the one-window-at-a-time walk that takes any read length) instead -- same selectors, marks set twice.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t kFcRing = 128;                  // (a power of two; at most 63 left over + 64 new entries)
+constexpr uint32_t kFcReads = kSlotRecs + 8;       // reads of a slot: its records' runs START in it; the last run may add two
+
+template <typename Rows>
+__device__ __forceinline__ void compact_window(const Rows& rows, const FilterOut& out, uint32_t lane, uint32_t X, uint64_t Hc,
+                                               uint32_t cref, uint32_t cg, uint32_t cr, const typename Rows::Row& row,
+                                               uint32_t* __restrict__ s_sel) {
+    const uint64_t PR = k_below(X);
+    const uint64_t H = Hc & PR;                                    // (bit 0 is set)
+    const uint64_t stops = (H >> 1) | (1ull << (X - 1u));          // the last entry of every read
+    const uint64_t single = H & stops, OW = H & ~stops;            // reads of one entry; first entries of the others
+    if (k_bit(single)) s_sel[cr] = cg & 0x7fffffffu;
+    if (OW) {
+        const uint64_t le = (2ull << lane) - 1ull;
+        const uint32_t fvl = 63u - static_cast<uint32_t>(__builtin_clzll((H & le) | 1ull));   // the first entry of this lane's read
+        const typename Rows::Row first = Rows::from_lane(row, fvl << 2);
+        bool ne[8];
+        Rows::differ(row, first, ne);
+        const uint64_t fvr = __builtin_bitreverse64(H), nfvr = ~fvr;
+        auto owners_of = [&](uint64_t D) { return __builtin_bitreverse64((nfvr + __builtin_bitreverse64(D)) & fvr); };
+        uint32_t lv = 8u;  // src/slimm.hpp:516-531: the first level (from the leaves) on which all kept targets agree
+#pragma unroll
+        for (int l = 3; l >= 0; --l) {
+            const uint64_t bad = owners_of(k_ballot(ne[l]) & PR);
+            lv = k_bit(bad) ? lv : static_cast<uint32_t>(l);
+        }
+        if (k_ballot(lv == 8u) & OW) {
+            uint32_t up = 8u;
+#pragma unroll
+            for (int l = 7; l >= 4; --l) {
+                const uint64_t bad = owners_of(k_ballot(ne[l]) & PR);
+                up = k_bit(bad) ? up : static_cast<uint32_t>(l);
+            }
+            lv = lv == 8u ? up : lv;
+        }
+        const uint64_t Q4 = k_ballot(lv == 8u) & OW;  // no level agrees (quirk Q4): rare, one read at a time below
+        if (k_bit(OW & ~Q4)) s_sel[cr] = out.taxon_base + rows.taxon_index(lv & 7u, Rows::field(row, lv & 7u));
+        const uint32_t lv_read = __builtin_amdgcn_ds_bpermute(fvl << 2, lv);
+        if (k_bit(PR & ~single) && lv_read < 8u) out.marks[cref * kMarkBytes + lv_read] = 1;  // plain, idempotent byte store
+        if (Q4) {
+            uint32_t f[8];
+            Rows::fields(row, f);
+            uint64_t todo = Q4;
+            while (todo) {
+                const uint32_t o = static_cast<uint32_t>(__builtin_ctzll(todo));
+                todo &= todo - 1ull;
+                const uint64_t later = H & ~k_below(o + 1u);
+                const uint32_t nxt = later ? static_cast<uint32_t>(__builtin_ctzll(later)) : X;
+                const uint64_t Vs = k_below(nxt) & ~k_below(o);
+                ReadAcc acc;
+                read_clear(acc);
+                read_max(acc, Vs, cref, f[7]);
+                const uint32_t index = rows.taxon_index(7u, acc.max_f7);
+                const uint32_t taxon = rows.taxon_at(index);
+                read_children(out, k_bit(Vs), cref, 8u, taxon);
+                const uint32_t rl = static_cast<uint32_t>(__builtin_amdgcn_readlane(cr, o));
+                if (lane == 0u) s_sel[rl] = out.taxon_base + index;
+            }
+        }
+    }
+}
+
+template <typename Rows>
+__global__ __launch_bounds__(64, 8) void k_filter_compact(const uint32_t* __restrict__ tgt_ref, const uint32_t* __restrict__ tgt_gbin,
+                                                          const uint4* __restrict__ slots, uint32_t nslots,
+                                                          const uint32_t* __restrict__ valid_bits, const Rows rows, const FilterOut out) {
+    __shared__ uint32_t s_ref[kFcRing], s_g[kFcRing], s_r[kFcRing];
+    __shared__ uint32_t s_sel[kFcReads];
+    const uint32_t lane = lane_id();
+    for (uint32_t r = lane; r < kFcReads; r += 64u) s_sel[r] = 0xffffffffu;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+        const uint4 d = slots[slot];
+        const uint32_t rb = out.rbase[slot] + out.bbase[slot >> 10];
+        const uint32_t t0 = d.x, tend = d.x + d.y;
+        bool whole_reads_walk = d.z > kFcReads;   // (cannot happen with kSlotRecs records per slot; the walk takes anything)
+        uint32_t rcount = 0, ccount = 0, cdone = 0;
+        uint32_t wn = 0, gn = 0;
+        if (!whole_reads_walk && t0 + lane < tend) {
+            wn = tgt_ref[t0 + lane];
+            gn = tgt_gbin[t0 + lane];
+        }
+        for (uint32_t t = t0; t < tend && !whole_reads_walk; t += 64u) {
+            const uint32_t w = wn, g = gn;
+            const bool live = t + lane < tend;
+            const uint32_t ref = w & 0x7fffffffu;
+            const uint32_t bits = live ? valid_bits[ref >> 5] : 0u;
+            if (t + 64u + lane < tend) {   // the next chunk's words: asked for before this chunk is worked on
+                wn = tgt_ref[t + 64u + lane];
+                gn = tgt_gbin[t + 64u + lane];
+            }
+            const bool valid = ((bits >> (ref & 31u)) & 1u) != 0u;
+            const bool head = live && (w >> 31) != 0u;
+            const uint64_t H = k_ballot(head), VB = k_ballot(valid);
+            if (valid) {
+                const uint32_t p = (ccount + mask_rank(VB)) & (kFcRing - 1u);
+                s_ref[p] = ref;
+                s_g[p] = g;
+                s_r[p] = rcount + mask_rank(H) + (head ? 1u : 0u) - 1u;
+            }
+            rcount += static_cast<uint32_t>(__popcll(H));
+            ccount += static_cast<uint32_t>(__popcll(VB));
+            const bool last = t + 64u >= tend;
+            while (ccount - cdone >= 64u || (last && ccount != cdone)) {
+                __builtin_amdgcn_wave_barrier();   // (the ring's words: written above, read here)
+                const uint32_t n_live = min(64u, ccount - cdone);
+                const uint32_t e = (cdone + lane) & (kFcRing - 1u);
+                const uint32_t cref = lane < n_live ? s_ref[e] : 0u;
+                const uint32_t cg = s_g[e], cr = lane < n_live ? s_r[e] : 0xffffffffu;
+                typename Rows::Row row = rows.load(cref);
+                const uint32_t before = __builtin_amdgcn_update_dpp(0xffffffffu, cr, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0: none)
+                const uint64_t Hc = k_ballot(lane < n_live && (lane == 0u || cr != before));
+                // whole reads only: the last read of a full window may go on in the entries to come
+                const bool final_window = last && ccount - cdone <= 64u;
+                const uint32_t X = final_window ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(Hc));
+                __builtin_amdgcn_wave_barrier();   // (every lane has read its entry before the ring is written again)
+                if (X == 0u) {   // 64 valid targets of one read (or more): the slot goes through the walk that takes any length
+                    whole_reads_walk = true;
+                    break;
+                }
+                compact_window(rows, out, lane, X, Hc, cref, cg, cr, row, s_sel);
+                cdone += X;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (whole_reads_walk) {
+            filter_span(rows, out, tgt_ref, tgt_gbin, lane, t0, tend, rb);
+            for (uint32_t r = lane; r < kFcReads; r += 64u) s_sel[r] = 0xffffffffu;
+        } else {
+            for (uint32_t r = lane; r < d.z; r += 64u) {   // the slot's selectors, reads without a valid target included
+                out.sel[rb + r] = s_sel[r];
+                s_sel[r] = 0xffffffffu;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------
@@ -762,10 +916,11 @@ __global__ __launch_bounds__(256) void k_zero(const ZeroArgs z) {
     const uint32_t n4 = z.cp_n >> 2;
     for (uint32_t i = gid; i < n4; i += gsz) reinterpret_cast<uint4*>(z.cp_dst)[i] = reinterpret_cast<const uint4*>(z.cp_src)[i];
     for (uint32_t i = (n4 << 2) + gid; i < z.cp_n; i += gsz) z.cp_dst[i] = z.cp_src[i];
+    for (uint32_t i = gid; i < z.cp2_n; i += gsz) z.cp2_dst[i] = z.cp2_src[i];
 }
 
 void launch_zero(hipStream_t st, const ZeroArgs& z) {
-    uint32_t most = std::max(z.n64, z.cp_n / 4);
+    uint32_t most = std::max(std::max(z.n64, z.cp_n / 4), z.cp2_n);
     for (int k = 0; k < 5; ++k) most = most > z.n[k] ? most : z.n[k];
     uint32_t blocks = (most + 255) / 256;
     if (blocks > 1024) blocks = 1024;
@@ -902,19 +1057,29 @@ void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_
     out.pair_mask = a.pair_mask;
     out.taxon_base = a.taxon_base;
     out.counters = a.counters;
+    // one wave per workgroup, one slot at a time, however many workgroups that makes (the dispatcher backfills wave by wave)
+    const uint32_t grid = a.nslots;
     if (a.rows16) {
         Rows16 r;
         r.rows = reinterpret_cast<const uint4*>(a.rows16);
         r.taxon_flat = a.taxon_flat;
         r.shift = a.taxon_shift;
-        hipExtLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
-                              a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
+        if (a.valid_bits)
+            hipExtLaunchKernelGGL(k_filter_compact<Rows16>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots,
+                                  a.nslots, a.valid_bits, r, out);
+        else
+            hipExtLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
+                                  a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
     } else {
         Rows32 r;
         r.lin4 = reinterpret_cast<const uint4*>(a.lin_dense);
         r.valid_of = a.valid;
-        hipExtLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
-                              a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
+        if (a.valid_bits)
+            hipExtLaunchKernelGGL(k_filter_compact<Rows32>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots,
+                                  a.nslots, a.valid_bits, r, out);
+        else
+            hipExtLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
+                                  a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
     }
 }
 

@@ -168,7 +168,7 @@ __device__ __forceinline__ int64_t field_number(const uint8_t* s, uint32_t n) {
 }
 // (name, flag) of the line at o: QNAME's canonical base (read_identity.h, Q18) and the flag with the base's mate bit
 __device__ __forceinline__ void line_identity(const uint8_t* b, uint64_t o, uint64_t end, const uint8_t*& name, uint32_t& nlen, uint32_t& fl,
-                                              uint64_t& after_flag) {
+                                              uint64_t& after_flag, bool* shortened = nullptr) {
     name = b + o;
     const uint32_t qn = field_len(b, o, end);
     const uint64_t f0 = o + qn + 1;
@@ -178,6 +178,9 @@ __device__ __forceinline__ void line_identity(const uint8_t* b, uint64_t o, uint
     if (!(fl & 0xC0u) && nlen >= 2u && name[nlen - 2u] == '.' && (name[nlen - 1u] == '1' || name[nlen - 1u] == '2')) {
         fl |= name[nlen - 1u] == '1' ? 0x40u : 0x80u;
         nlen -= 2u;
+        if (shortened) *shortened = true;
+    } else if (shortened) {
+        *shortened = false;
     }
     after_flag = f0 + fn + 1;
 }
@@ -202,12 +205,14 @@ __global__ __launch_bounds__(64) void k_sam_decode(const uint8_t* __restrict__ b
             }
         }
     }
+    uint32_t n_short_starts = 0, n_short_to_plain = 0;
     for (uint32_t k = threadIdx.x; k < pc.count; k += 64u) {
         const uint64_t o = po[k] & 0x7fffffffu;
         const uint8_t* name;
         uint32_t nlen, fl;
         uint64_t p;
-        line_identity(b, o, end, name, nlen, fl, p);
+        bool is_short;
+        line_identity(b, o, end, name, nlen, fl, p, &is_short);
         // RNAME -> the header's index (the host reader: "*" and names the header does not have are -1)
         const uint32_t rn = field_len(b, p, end);
         int32_t rid = -1;
@@ -227,17 +232,21 @@ __global__ __launch_bounds__(64) void k_sam_decode(const uint8_t* __restrict__ b
         const int32_t rpos = static_cast<int32_t>(field_number(b + p, pn) - 1);   // SAM POS is 1-based; 0 ("unavailable") becomes -1
         const uint64_t at = out_at + pc.base + k;
         if (kMarked) {
-            bool starts;
+            bool starts, prev_short;
             const uint32_t po_prev = k ? (po[k - 1] & 0x7fffffffu) : prev0;
             if (po_prev != 0xffffffffu) {
                 const uint8_t* qname;
                 uint32_t qlen, qfl;
                 uint64_t unused;
-                line_identity(b, po_prev, end, qname, qlen, qfl, unused);
+                line_identity(b, po_prev, end, qname, qlen, qfl, unused, &prev_short);
                 starts = !sam_same(name, nlen, qname, qlen);
             } else {
                 starts = !(carry->have && sam_same(name, nlen, carry->name, carry->len));
+                prev_short = carry->last_short != 0u;
             }
+            // Q18 on a grouped stream (kernels.h: BamCarry), as in k_bam_decode
+            n_short_starts += (is_short & starts) ? 1u : 0u;
+            n_short_to_plain += (!is_short & !starts & prev_short) ? 1u : 0u;
             const uint32_t mate = (fl & 0x40u) ? 1u : ((fl & 0x80u) ? 2u : 0u);
             const bool mapped = !(fl & 0x4u) && rid != -1;
             const uint32_t r1 = mapped ? min(static_cast<uint32_t>(rid) + 1u, 0x1fffffffu) : 0u;
@@ -249,6 +258,16 @@ __global__ __launch_bounds__(64) void k_sam_decode(const uint8_t* __restrict__ b
             pos[at] = rpos;
             flag[at] = static_cast<uint16_t>(fl);
             check[at] = sam_check_name(name, nlen);
+        }
+    }
+    if (kMarked && __any(static_cast<int>(n_short_starts | n_short_to_plain))) {
+        for (uint32_t d = 32u; d; d >>= 1) {
+            n_short_starts += static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_short_starts), static_cast<int>(d)));
+            n_short_to_plain += static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_short_to_plain), static_cast<int>(d)));
+        }
+        if (threadIdx.x == 0) {
+            if (n_short_starts) atomicAdd(&carry->short_starts, n_short_starts);
+            if (n_short_to_plain) atomicAdd(&carry->short_to_plain, n_short_to_plain);
         }
     }
 }
@@ -263,12 +282,14 @@ __global__ __launch_bounds__(64) void k_sam_carry(const uint8_t* __restrict__ b,
     const uint8_t* name;
     uint32_t nlen, fl;
     uint64_t unused;
-    line_identity(b, o, end, name, nlen, fl, unused);
+    bool is_short;
+    line_identity(b, o, end, name, nlen, fl, unused, &is_short);
     if (nlen > 255u) nlen = 255u;   // (QNAME is at most 254 characters)
     for (uint32_t i = threadIdx.x; i < nlen; i += 64u) carry->name[i] = name[i];
     if (threadIdx.x == 0) {
         carry->len = nlen;
         carry->have = 1;
+        carry->last_short = is_short ? 1u : 0u;
     }
 }
 

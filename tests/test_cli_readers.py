@@ -9,7 +9,7 @@ import pytest
 
 from slimm_amd.synth import CONFIGS, make_workload
 from tests.bam_io import qnames_of, write_bam, write_sam
-from tests.cases import q18_case, tiny_case
+from tests.cases import q18_apart_case, q18_case, tiny_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "slimm_amd", "slimm")
@@ -63,6 +63,19 @@ def test_reader_hands_out_the_canonical_identity_of_q18(tmp_path, writer):
         mate = 1 if int(r[1]) & 0x40 else 2 if int(r[1]) & 0x80 else 0
         assert ident.setdefault(key_string, (r[5], mate)) == (r[5], mate)
     assert len(set(ident.values())) == len(ident) == 12                   # (the unmapped record shares "U.1" with a mapped one)
+
+
+@pytest.mark.parametrize("writer", [write_sam, write_bam])
+def test_reader_tells_shortened_names_that_stand_apart_from_their_namesakes(tmp_path, writer):
+    """Q18 on a file grouped by QNAME (include/slimm_hip.h): a run of shortened names only -- the unflagged `r.1`, fifty reads
+    behind `r`/0x40 -- means the file must go through the any-order path; q18_case, where every shortened name stands next to
+    its un-shortened namesake, must not."""
+    for mk, want in ((q18_apart_case, "1"), (lambda: q18_apart_case(tail=("r.2",)), "1"), (q18_case, "0"), (tiny_case, "0")):
+        w = mk()
+        p = str(tmp_path / "x")
+        writer(p, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+        err = subprocess.run([CLI, "--dump-records", p], capture_output=True, text=True, check=True).stderr
+        assert f"#q18_regroup_needed\t{want}" in err, (w.name, err)
 
 
 def test_bam_spanning_many_bgzf_blocks(tmp_path):

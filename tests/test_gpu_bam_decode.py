@@ -11,7 +11,7 @@ from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Records, Workload
 from tests.bam_io import bam_record_bytes
-from tests.cases import Q18_EXPECTED, q18_case
+from tests.cases import Q18_APART_EXPECTED, Q18_EXPECTED, q18_apart_case, q18_case
 from tests.helpers import assert_matches_oracle
 from tests.test_gpu_parity import _interleave_mates, one_long_read_workload
 
@@ -64,6 +64,61 @@ def test_q18_name_suffix_and_mate_flag_make_one_key(window):
         o = run_workload(wa, use_qnames=True)
         assert o.scalars["matches"] == Q18_EXPECTED["matches"] and o.scalars["uniq_matches"] == Q18_EXPECTED["uniq_matches"]
         _check(wa, False, window, read_len=50)
+
+
+@pytest.mark.parametrize("window", [0, 97, 4_001])
+def test_q18_shortened_names_apart_from_their_namesakes_ask_for_the_any_order_path(window):
+    """A file grouped by QNAME whose key strings are NOT adjacent (`r`/0x40 ... fifty reads ... the unflagged `r.1`): the
+    reference joins them through its hash map (src/slimm.hpp:204-211).  The grouped context counts the runs of shortened names
+    that stand apart from an un-shortened namesake and refuses to analyse (SLIMM_E_REGROUP) instead of profiling 54 reads; the
+    same bytes through an any-order context equal the oracle (52 reads).  q18_case (every shortened name NEXT to its namesake)
+    stays on the grouped path: test_q18_name_suffix_and_mate_flag_make_one_key above."""
+    w = q18_apart_case()
+    o = run_workload(w, use_qnames=True)
+    assert (o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"]) == (
+        Q18_APART_EXPECTED["hits"], Q18_APART_EXPECTED["matches"], Q18_APART_EXPECTED["uniq_matches"])
+    data = bam_record_bytes(w.records, read_len=50)
+    s = Slimm.for_workload(w, device=0, grouped=True)
+    assert s.push_bam_bytes(data, window=window) == len(w.records)
+    assert s.q18_runs() == (1, 0)      # `r.1` and `r.2` share the base `r`: one run of shortened names only
+    with pytest.raises(capi.SlimmError) as e:
+        s.get_profiles()
+    assert e.value.code == capi.E_REGROUP and "SLIMM_ORDER_ANY" in str(e.value)
+    s.close()
+    _check(w, False, window, read_len=50)
+    # only `r.2` apart, `r.1` next to `r`: still one run of shortened names only
+    w1 = q18_apart_case(tail=("r.2",))
+    s = Slimm.for_workload(w1, device=0, grouped=True)
+    s.push_bam_bytes(bam_record_bytes(w1.records, read_len=50), window=window)
+    with pytest.raises(capi.SlimmError) as e:
+        s.get_profiles()
+    assert e.value.code == capi.E_REGROUP
+    # ... and the next file of the same context starts from zero
+    s.reset(); s.reset_cutoffs()
+    wq = q18_case()
+    s2 = Slimm.for_workload(wq, device=0, grouped=True)
+    s2.push_bam_bytes(bam_record_bytes(wq.records, read_len=50), window=window)
+    assert s2.q18_runs() == (3, 3)      # K.1 | K, W.2 | W, U.1 | U: each run holds its un-shortened namesake
+    assert s2.get_profiles() is not None
+    s.close(); s2.close()
+
+
+def test_analysing_before_the_last_window_is_an_error():
+    """A caller that forgets last != 0 would get the profile of a truncated record stream (windows are gathered and in
+    flight inside the library): slimm_analyze_alignments refuses."""
+    w = _named(make_workload(CONFIGS["config1"], seed=36, n_records=3_000))
+    data = bam_record_bytes(w.records)
+    s = Slimm.for_workload(w, device=0)
+    got = capi.C.c_uint64(0)
+    buf = (capi.C.c_uint8 * len(data)).from_buffer_copy(data)
+    s._check(s.L.slimm_push_bam_bytes(s.ctx, buf, len(data), 0, capi.C.byref(got)))
+    with pytest.raises(capi.SlimmError) as e:
+        s.get_profiles()
+    assert "last window" in str(e.value)
+    s._check(s.L.slimm_push_bam_bytes(s.ctx, None, 0, 1, capi.C.byref(got)))
+    assert s.get_profiles() is not None
+    assert_matches_oracle(s, run_workload(w, use_qnames=True))
+    s.close()
 
 
 @pytest.mark.parametrize("window", [0, 250_007])

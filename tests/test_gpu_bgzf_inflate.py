@@ -174,6 +174,41 @@ def test_records_from_compressed_blocks_equal_the_oracle(tmp_path, grouped):
     s.close()
 
 
+def test_window_buffers_are_sized_by_the_file(tmp_path):
+    """the first push of a large file used to reserve every buffer for the largest possible window (17 GB per
+    context).  With slimm_set_input_size_hint the library reserves what the file will use; without it nothing ahead.  Same
+    records either way; slimm_window_memory says what is held."""
+    from oracle.binding import run_workload
+    from slimm_amd.profiler import Slimm
+    from slimm_amd.synth import CONFIGS, make_workload
+    from slimm_amd.workload import Workload
+    from tests.helpers import assert_matches_oracle
+    w = make_workload(CONFIGS["config2"], seed=73, n_records=40_000)
+    names = ["s%x" % k for k in w.records.read_key.tolist()]
+    blocks, skip, want, rec = _bam_file(tmp_path, w, names, seed=13)
+    wq = Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, "bam", grouped=True)
+    o = run_workload(wq, use_qnames=True)
+    held = []
+    for hint in (0, len(blocks), 40 * len(blocks)):       # not told / the truth / a caller that overstates
+        s = Slimm.for_workload(wq, device=0, grouped=True)
+        if hint:
+            s._check(s.L.slimm_set_input_size_hint(s.ctx, hint))
+        assert s.push_bgzf_blocks(blocks, skip=skip, window=300_000) == len(rec)
+        m = capi.C.c_uint64(0)
+        s._check(s.L.slimm_window_memory(s.ctx, capi.C.byref(m)))
+        held.append(m.value)
+        assert s.get_profiles() is not None
+        assert_matches_oracle(s, o)
+        with pytest.raises(capi.SlimmError):
+            s._check(s.L.slimm_set_input_size_hint(s.ctx, 1))     # (only before a file's first window)
+        s.reset(); s.reset_cutoffs()
+        s._check(s.L.slimm_set_input_size_hint(s.ctx, len(blocks)))
+        assert s.push_bgzf_blocks(blocks, skip=skip, window=0) == len(rec)
+        assert_matches_oracle(s, o) if s.get_profiles() is not None else None
+        s.close()
+    assert all(h < (1 << 30) for h in held), held          # a file of a few megabytes holds far less than a gigabyte
+
+
 def test_a_skip_larger_than_the_window_slack(tmp_path):
     """A caller may hand over a file's blocks from its very first one and name the whole BAM header as `skip` -- 17 MiB here
     (hundreds of thousands of contigs), more than the 16 MiB of slack in front of a window buffer: the blocks that lie wholly

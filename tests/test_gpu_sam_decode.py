@@ -11,7 +11,7 @@ from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Records, Workload
 from tests.bam_io import write_sam
-from tests.cases import Q18_EXPECTED, q18_case
+from tests.cases import Q18_APART_EXPECTED, Q18_EXPECTED, q18_apart_case, q18_case
 from tests.helpers import assert_matches_oracle
 from tests.test_gpu_bam_decode import _named
 from tests.test_gpu_parity import _interleave_mates
@@ -66,6 +66,29 @@ def test_long_names_interleaved_mates_and_q18(tmp_path):
     for seed in (1, 2):
         wa = q18_case(list(np.random.default_rng(seed).permutation(18)))
         _check(tmp_path, wa, False, 211)
+
+
+@pytest.mark.parametrize("window", [0, 61, 1_003])
+def test_q18_shortened_names_apart_from_their_namesakes_ask_for_the_any_order_path(tmp_path, window):
+    """tests/test_gpu_bam_decode.py, the test of the same name, through SAM text."""
+    w = q18_apart_case()
+    o = run_workload(w, use_qnames=True)
+    assert o.scalars["matches"] == Q18_APART_EXPECTED["matches"] and o.scalars["uniq_matches"] == Q18_APART_EXPECTED["uniq_matches"]
+    s = Slimm.for_workload(w, device=0, grouped=True)
+    s.set_reference_names(w.ref_names)
+    assert s.push_sam_bytes(sam_body(tmp_path, w), window=window) == len(w.records)
+    assert s.q18_runs() == (1, 0)      # `r.1` and `r.2` share the base `r`: one run of shortened names only
+    with pytest.raises(capi.SlimmError) as e:
+        s.get_profiles()
+    assert e.value.code == capi.E_REGROUP
+    s.close()
+    _check(tmp_path, w, False, window)
+    wq = q18_case()
+    s = Slimm.for_workload(wq, device=0, grouped=True)
+    s.set_reference_names(wq.ref_names)
+    s.push_sam_bytes(sam_body(tmp_path, wq), window=window)
+    assert s.q18_runs() == (3, 3)
+    s.close()
 
 
 def test_unknown_reference_names_and_bad_lines(tmp_path):

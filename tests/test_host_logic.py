@@ -239,3 +239,35 @@ def test_collect_profiles_merges_samples(tmp_path):
     assert rows[("species", "10")] == ["60.5", "10", "605", "1"]
     assert rows[("species", "11")] == ["0", "80", "0", "8"]
     assert lines[1].split("\t")[1] == "10"          # sorted by the first sample's abundance, descending
+
+
+def test_q18_run_counts_for_producers_of_grouped_records():
+    """slimm_host_q18_note / _regroup_needed (include/slimm_hip.h, "Q18 ON A GROUPED STREAM"): fed every record's (starts a
+    run of one canonical base, name was shortened), they tell whether some run holds shortened names only -- the rule the
+    device decoders and the command's reader apply.  Driven here the way a C-ABI producer would, from names and flags."""
+    import ctypes as C
+
+    from slimm_amd import capi
+    from tests.cases import q18_apart_case, q18_case, tiny_case
+
+    class Runs(C.Structure):
+        _fields_ = [("short_starts", C.c_uint64), ("short_to_plain", C.c_uint64), ("last_short", C.c_int)]
+
+    L = capi.lib()
+
+    def needed(w):
+        q = Runs()
+        prev = None
+        for name, flag in zip(w.records.qname, w.records.flags_in_file().tolist()):
+            b = name.encode()
+            out = C.c_uint16(0)
+            n = L.slimm_host_canonical_read_name(b, len(b), int(flag), C.byref(out))
+            base = b[:n]
+            L.slimm_host_q18_note(C.byref(q), int(base != prev), int(n != len(b)))
+            prev = base
+        return bool(L.slimm_host_q18_regroup_needed(C.byref(q))), (q.short_starts, q.short_to_plain)
+
+    assert needed(q18_apart_case()) == (True, (1, 0))
+    assert needed(q18_apart_case(tail=("r.1",))) == (True, (1, 0))
+    assert needed(q18_case()) == (False, (3, 3))
+    assert needed(tiny_case()) == (False, (0, 0))

@@ -243,6 +243,8 @@ int slimm_push_bgzf_blocks(slimm_ctx* ctx, const uint8_t* blocks, uint64_t n_byt
  * file and releases them above that; slimm_window_memory reports what is held.  The hint is per file (cleared by slimm_reset). */
 int slimm_set_input_size_hint(slimm_ctx* ctx, uint64_t compressed_bytes);
 int slimm_window_memory(slimm_ctx* ctx, uint64_t* device_bytes);
+/* hipMemGetInfo of the context's device: bytes in use (by every process and context on it) and the device's total. */
+int slimm_device_memory(slimm_ctx* ctx, uint64_t* used_bytes, uint64_t* total_bytes);
 /* SAM TEXT decoded on the device (slimm_amd/csrc/sam_decode.hip): the reference takes .sam and .bam alike
  * (src/file_helper.hpp:73-75; the record loop src/slimm.hpp:194-208 reads QNAME, FLAG, RNAME -> reference index, POS).
  * `text` = the file's alignment lines, everything behind the header, in windows cut ANYWHERE (the incomplete last line of a

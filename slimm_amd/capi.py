@@ -160,6 +160,7 @@ SYMBOLS = [
     ("slimm_pin_host_buffer", C.c_int, [_P, _P, C.c_uint64]),
     ("slimm_set_input_size_hint", C.c_int, [_P, C.c_uint64]),
     ("slimm_window_memory", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("slimm_device_memory", C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("slimm_group_plan", None, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                 C.POINTER(C.c_uint32)]),
     ("slimm_grouped_records", C.c_int, [_P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -6,333 +6,16 @@
 //   filter          : lineage rows with the valid bit up (16 bytes per reference); uniq2 / LCA counts / child marks down
 // both through pinned host memory that a copy kernel reads / writes (no DMA-engine start-up latency).
 // Multi-GPU entry points (coverage summary in all-gather or all-to-all form, device-side partials merge) are further down.
-#include <cerrno>
-#include <fcntl.h>
-#include <hip/hip_runtime.h>
-#include <unistd.h>
+#include "context.h"
 
-#include <algorithm>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <chrono>
-#include <cstring>
-#include <memory>
-#include <string>
-#include <vector>
-
-#include "../../include/slimm_hip.h"
-#include "host_profile.hpp"
-#include "kernels.h"
-#include "read_identity.h"
-
-namespace {
-
-using namespace slimm;
+namespace slimm {
 
 std::string g_create_error;
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t cap = 0;  // elements
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        release();
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
-        if (e == hipSuccess) cap = n;
-        return e;
-    }
-    // the same without hipFree (which waits for every kernel in flight on the device): what the buffer was goes to `old`,
-    // whose owner frees it when the device has nothing to do anyway
-    hipError_t ensure_later(size_t n, std::vector<void*>& old) {
-        if (n <= cap) return hipSuccess;
-        if (p) old.push_back(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
-        if (e == hipSuccess) cap = n;
-        return e;
-    }
-};
-
-template <typename T>
-struct PinBuf {
-    T* p = nullptr;
-    size_t cap = 0;
-    ~PinBuf() {
-        if (p) (void)hipHostFree(p);
-    }
-    hipError_t ensure(size_t n) {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = n;
-        return e;
-    }
-};
-
-enum KernelId {
-    K_MEMSET = 0, K_GROUP_COUNT, K_GROUP_SCAN, K_GROUP_SCATTER, K_GROUP_FINISH, K_FRONT, K_HIST, K_REF_STATS, K_FILTER,
-    K_REF_STATS2, K_TILE_COUNT, K_TILE_SCAN, K_TILE_SCATTER, K_TILE_HIST, K_TILE_COUNT2, K_TILE_SCAN2, K_TILE_SCATTER2,
-    K_TILE_HIST2, K_PACK, K_PACK2, K_COUNT
-};
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_group_count", "k_group_scan", "k_group_scatter", "k_group_finish",
                                      "k_front", "k_hist", "k_ref_stats", "k_filter", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",
                                      "k_tile_count2", "k_tile_scan2", "k_tile_scatter2", "k_tile_hist2",
                                      "k_pack", "k_pack2"};
-
-constexpr uint32_t kTailWords = 64;
-
-}  // namespace
-
-struct slimm_ctx {
-    std::unique_ptr<HostProfile> host;
-    std::string err;
-    int device = -1;  // -1: host-only context
-    int order = SLIMM_ORDER_GROUPED;
-    hipStream_t stream = nullptr;
-    // streamed ingest (slimm_push_records_async): host -> device copies on a stream of their own, ordered before phase A
-    // by an event (never by the host); two page-locked staging sets for callers that produce records piecemeal
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copy_done = nullptr;
-    bool copy_pending = false;
-    bool filter_pending = false;  // slimm_filter_alignments_launch ran; slimm_install_merged_partials completes it
-    bool stream_ordered = false;  // slimm_set_stream_ordered: the caller enqueues its collectives on `stream`
-    struct Staging {
-        PinBuf<uint64_t> key;
-        PinBuf<int32_t> ref, pos;
-        PinBuf<uint16_t> flag;
-        hipEvent_t done = nullptr;
-        bool pending = false;
-    } staging[2];
-
-    uint32_t R = 0, T = 0;
-    uint64_t Bp = 0;                   // padded bins per coverage array (multiple of 64)
-    std::vector<uint32_t> bin_off_h;   // [R+1] padded offsets
-
-    // static tables
-    DevBuf<uint32_t> d_ref_len, d_bin_off, d_lin_dense;
-    DevBuf<uint32_t> d_tile_ref0;     // per bin tile: first reference overlapping it (fused statistics)
-    DevBuf<uint2> d_geo;              // {contig length, first bin} per reference: one gather in k_emit
-    DevBuf<uint8_t> d_valid;
-    DevBuf<uint4> d_rows16;           // per run: 16-byte lineage rows with the valid bit
-    DevBuf<uint32_t> d_level_taxon;    // [(index << 3) | level] -> dense taxon (8 << taxon_shift entries)
-    DevBuf<uint32_t> d_taxon_off, d_taxon_idx;  // ... and back: the (level, index) entries of dense taxon t (CSR)
-    uint32_t taxon_shift = 0;
-    uint32_t Tsel = 0;                 // size of the selectors' taxon space: 8 << taxon_shift (16-byte rows) or T
-    PinBuf<uint4> h_rows16;
-    DevBuf<uint32_t> d_valid_bits;     // one bit per reference: what k_filter_compact asks before anything else
-    PinBuf<uint32_t> h_valid_bits;
-    std::vector<uint32_t> valid_bits_prev;   // references whose bit is set in h_valid_bits
-    bool rows16_base_ready = false;    // h_rows16 holds the static part of every row
-    std::vector<uint32_t> rows16_prev; // references whose valid bit is set in h_rows16
-    bool use_rows16 = false;
-    // records
-    DevBuf<uint64_t> in_key;
-    DevBuf<int32_t> in_ref, in_pos;
-    DevBuf<uint16_t> in_flag;
-    DevBuf<uint32_t> in_check;     // slimm_push_records_checked: a second hash of every record's read name
-    bool has_check = false;        // ... all pushed batches carry one (checked and unchecked pushes do not mix)
-    bool packed = false;           // slimm_push_records_packed: 16 bytes per record, no flag array (forms do not mix)
-    bool marked = false;           // slimm_push_records_marked: 8 bytes per record, no key array (grouped input only)
-    // slimm_push_bam_bytes: BAM records decoded on the device (bam_decode.hip).  Two byte buffers [slack | window] take the
-    // windows in turn; the incomplete record at a window's end is copied in front of the next window
-    // (the ring of window buffers: a window is copied -- or inflated -- into one while older ones are still on their way or
-    // being decoded: at most kBamLag of them, and at most kBamInFlight bytes -- windows that arrive as BGZF blocks are
-    // gathered into device windows of up to kBamGather inflated bytes, three of which keep both inflate streams busy; a ring
-    // of 16 buffers of that size was 20 - 25 GB of HBM per context)
-    static constexpr uint32_t kBamRing = 4, kBamLag = kBamRing - 2;
-    static constexpr uint64_t kBamInFlight = 4ull << 30;    // finish the oldest window when more than this is in flight
-    static constexpr uint64_t kBamGather = 1900ull << 20;   // inflated bytes of a gathered device window (a window is < 2 GiB)
-    static constexpr uint64_t kBamGatherGoal = 1400ull << 20;  // ... which is launched once it holds this much
-    static constexpr uint64_t kBamKeepAcrossFiles = 4ull << 30; // slimm_reset gives the pipeline's buffers back above this
-    struct BamDecode {
-        DevBuf<uint8_t> bytes[kBamRing];
-        DevBuf<BamPiece> pieces;
-        DevBuf<uint32_t> offs;
-        DevBuf<BamCarry> carry;
-        PinBuf<BamWindowResult> result;     // written by k_bam_scan straight into page-locked host memory
-        std::vector<std::pair<const uint8_t*, size_t>> registered;  // caller buffers page-locked by hipHostRegister
-        uint64_t windows = 0;               // of this file, handed over so far
-        uint64_t head = 0;                  // ... of which [head, windows) are not finished yet (copied / inflating / waiting)
-        uint64_t win_bytes[kBamRing] = {};  // record bytes of the windows in flight
-        uint64_t carry_bytes = 0;
-        bool active = false;                // this file's records come from slimm_push_bam_bytes / slimm_push_bgzf_blocks
-        bool closed = false;                // the file's last window went in
-        hipEvent_t copied[kBamRing] = {};   // the window's bytes are in its buffer (behind the copy, or behind the inflate)
-        hipEvent_t h2d_done[4] = {};        // the caller's buffer of a push has been read (the pushes' events, in turn)
-        uint64_t pushes = 0;                // pushes of this file that started a copy
-        // windows that arrive as BGZF blocks (slimm_push_bgzf_blocks): compressed bytes + block descriptors per buffer, the
-        // inflater's scratch and {error code, first bad block} per buffer; inflated[b]: that window was inflated here
-        DevBuf<uint8_t> comp[kBamRing];
-        DevBuf<BgzfBlock> desc[kBamRing];
-        DevBuf<uint8_t> inflate_scratch[2];
-        DevBuf<uint32_t> inflate_status;       // 4 words per buffer
-        PinBuf<uint32_t> h_inflate_status;     // ... fetched with the window's other results
-        bool inflated[kBamRing] = {};
-        // the inflate kernels' own streams, taken in turn by the device windows: the copies of other windows go on beside
-        // them, and the Huffman phase of one window (a lane per block: 30 K blocks are half the lanes) beside the other's
-        hipStream_t inflate_stream[2] = {nullptr, nullptr};
-        hipEvent_t comp_copied = nullptr;
-        // BGZF pushes gathered for the next device window (buffer windows % kBamRing): compressed bytes so far, inflated
-        // bytes so far, the inflated bytes in front of the file's first record
-        bool acc_open = false;
-        uint64_t acc_src = 0, acc_dst = 0;
-        uint32_t acc_skip = 0, acc_tok = 0;   // (acc_tok: words of token room of the gathered blocks)
-        std::vector<void*> outgrown;   // device buffers replaced by larger ones while kernels were in flight: freed at the file's end
-        // SAM text (slimm_push_sam_bytes, sam_decode.hip): this file's windows are text; the header's reference names as a
-        // hash table on the device (slimm_set_reference_names); the last byte pushed (a last line without its newline gets one)
-        bool sam = false;
-        DevBuf<SamRefEntry> sam_table;
-        DevBuf<uint8_t> sam_names;
-        uint32_t sam_mask = 0;
-        uint8_t sam_last_byte = '\n';
-        std::vector<BgzfBlock> desc_host[kBamRing];   // (a buffer's descriptors stay until the buffer's turn comes again: the copy reads them)
-        // Q18 on a grouped stream (kernels.h: BamCarry): the decoders' two counts of the windows finished so far
-        uint64_t q18_starts = 0, q18_plain = 0;
-        // what the file's gathered windows are sized for: slimm_set_input_size_hint (the file's compressed bytes; 0 = not
-        // told) and, from it and the first push's ratio, the inflated bytes a gathered window's buffer gets (0 = kBamGather)
-        uint64_t size_hint = 0, win_cap = 0;
-        uint64_t held_bytes() const {   // device memory of the window pipeline
-            uint64_t n = pieces.cap * sizeof(BamPiece) + offs.cap * 4ull;
-            for (uint32_t k = 0; k < kBamRing; ++k) n += bytes[k].cap + comp[k].cap + desc[k].cap * sizeof(BgzfBlock);
-            for (auto& sc : inflate_scratch) n += sc.cap;
-            return n;
-        }
-    } bam;
-    DeviceRecords rec;      // what analyze reads (owned buffers or borrowed pointers)
-    bool borrowed = false;
-    uint64_t n_pushed = 0;
-    // work arrays
-    // record_order = ANY (group_by_ident.hip): the grouped stream {identity, {reference, bin}, check word} + scratch
-    DevBuf<uint64_t> c_ident, s_ident;
-    DevBuf<uint2> c_pay, s_pay;
-    DevBuf<uint32_t> group_hist, c_chk, s_chk;
-    DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
-    DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
-    DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
-    DevBuf<uint4> tot_part;              // per workgroup of k_tile_count: totals of its slots (kernels.h: Totals)
-    DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
-    DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;
-    bool keep_bins = true;       // materialise cov / uniq_cov / uniq_cov2 in HBM (slimm_keep_bins)
-    bool binsA_stored = false, binsB_stored = false;
-    DevBuf<uint4> tile_items, part_items;
-    DevBuf<uint32_t> mid, sup_cursor;                   // level-1 buckets (by super tile) and their cursors
-    DevBuf<uint32_t> sel;                               // per read, dense: its uniq_cov2 bin, Bp + LCA taxon, or 0xffffffff
-    DevBuf<uint32_t> slot_rbase, slot_bbase;            // reads in front of a slot = rbase[s] + bbase[s >> 10] (side stream)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t front_done = nullptr, prefix_done = nullptr;
-    bool prefix_pending = false;  // prefix_done has been recorded and not been waited for by the main stream yet
-    uint32_t tile_shift = kTileShiftSmall;              // log2 of the bins per tile: which build of tile_hist.hip runs (kernels.h)
-    uint32_t tile_bins() const { return 1u << tile_shift; }
-    uint32_t ntiles = 0;
-    uint32_t Tpad = 0, ntiles2 = 0;                     // taxa padded to whole tiles; tiles of [uniq_cov2 | taxa]
-    bool fused_scan = false;                            // k_tile_scan runs inside the one-level bucketing kernel
-    uint32_t treps = 1, tstride = 0;                    // copies of the tile counters / cursors and their stride
-    bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
-    bool matrix = false;      // phase B may bucket through a count matrix (one row per counting workgroup, no atomics)
-    bool matrix_always = false;
-    int wide_tiles = -1;      // SLIMM_WIDE_TILES: -1 = by the file's size, 0 / 1 = never / always (tests)
-    // far more entries per tile than a packed work item holds (1 B records on 20 k references): work items of up to
-    // kTileSubWide entries with 32-bit counts, so that a tile is one item again (kernels.h)
-    bool wide_for(uint32_t n_records) const {
-        return wide_tiles >= 0 ? wide_tiles != 0 : (ntiles && n_records / ntiles > 32768u);
-    }
-    DevBuf<uint32_t> tile_matrix;
-    // multi-GPU coverage summary [4R sums | 16 scalars | bitmaps]: n_slices = 0: not announced (bitmaps by extra kernels),
-    // 1: bitmaps written by k_tile_hist as [cov | uniq_cov], n > 1: in n slices of tiles for the all-to-all exchange
-    uint32_t summary_slices = 0;
-    bool summary_has_bits = false;   // the bitmaps of this analysis are in `summary` already
-    uint32_t summary_layout = 0xffffffffu;  // n_slices the buffer was last zeroed for
-    DevBuf<uint32_t> d_sum_vec;      // all-to-all form: [4R | 16] additive vector, all-reduced in place
-    uint32_t slice_tiles() const { return summary_slices > 1 ? (ntiles + summary_slices - 1) / summary_slices : ntiles; }
-    uint64_t slice_words() const { return static_cast<uint64_t>(slice_tiles()) * (tile_bins() / 32); }  // per array
-    uint64_t summary_words() const { return 4ull * R + 16 + 2ull * std::max<uint32_t>(summary_slices, 1u) * slice_words(); }
-    BitsLayout bits_layout() {
-        BitsLayout b;
-        if (summary_has_bits) {
-            b.base = reinterpret_cast<uint64_t*>(summary.p + 4ull * R + 16);
-            b.tps = slice_tiles();
-            b.slice_w64 = slice_words() / 2;
-        }
-        return b;
-    }
-    bool statsA_final = false;  // k_pack has added the non-zero counts of the split tiles to the fused statistics
-    bool bins_exposed = false;  // the caller holds the coverage buffer (may have merged other ranks' bins into it)
-    bool use_tiles = false;   // LDS-privatised histograms (default) vs direct global atomics (too many tiles for LDS)
-    DevBuf<uint32_t> bins;       // cov | uniq_cov | tail | uniq_cov2
-    DevBuf<uint32_t> counters;   // CNT_WORDS
-    DevBuf<uint32_t> ref_stats;  // [R*4] then [R*4]
-    DevBuf<uint32_t> summary;    // multi-GPU: [4R sums | 16 scalars | cov bits | uniq_cov bits]
-    DevBuf<uint32_t> lca_count, marks;
-    DevBuf<uint32_t> d_partials;  // multi-GPU: the additive partial results, summed across ranks in place
-    PinBuf<uint32_t> h_partials;
-    DevBuf<uint64_t> pair_tab, pair_list;
-    uint32_t pair_cap = 0;  // power of two
-    // pinned staging
-    PinBuf<uint32_t> h_stats, h_small, h_lca, h_marks;
-    PinBuf<uint64_t> h_pairs;
-
-    // per-run state
-    bool analyzed = false, covered = false, filtered = false, counted = false, no_hits = false;
-    uint32_t local_V = 0, local_M = 0, local_P = 0;
-    uint32_t n_pairs = 0;
-    std::vector<uint32_t> nz_ucov2;
-    // partials handed out / installed
-    std::vector<uint32_t> part_u2, part_lca, part_marks;
-    std::vector<uint64_t> part_pairs;
-
-    // kernel timing
-    bool timing = false;
-    int timing_only = -1;  // >= 0: bracket only this kernel id (keeps the event overhead out of the other launches)
-    struct Ev {
-        hipEvent_t a, b;
-        int id;
-    };
-    std::vector<Ev> ev_used, ev_free;
-    double k_ms[K_COUNT] = {0};
-    uint32_t k_n[K_COUNT] = {0};
-
-    // packed result blocks: A = [4R stats | 32 counters | 16 tail], B = [4R stats2 | 32 counters | R marks | T lca]
-    size_t statsA_words() const { return 4ull * R + 64; }
-    size_t statsB_words() const { return 5ull * R + 32 + T; }
-    bool pair_clean = false;  // the (taxon, ref) hash set holds only empty slots
-    uint32_t* cov() { return bins.p; }
-    uint32_t* ucov() { return bins.p + Bp; }
-    uint32_t* tail() { return bins.p + 2 * Bp; }
-    uint32_t* ucov2() { return bins.p + 2 * Bp + kTailWords; }
-    uint32_t* lca_tiles() { return bins.p + 3 * Bp + kTailWords; }  // [Tpad] right behind uniq_cov2: one index space
-};
-
-namespace {
-
-// SLIMM_HOST_TRACE=1: wall-clock marks of the host steps between the two device phases, on stderr
-struct HostTrace {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    const char* what;
-    explicit HostTrace(const char* w) : on(false), what(w) {
-        static const bool enabled = getenv("SLIMM_HOST_TRACE") != nullptr;
-        on = enabled;
-        if (on) t0 = std::chrono::steady_clock::now();
-    }
-    void mark(const char* step) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[host] %s: %s %.1f us\n", what, step, std::chrono::duration<double, std::micro>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 
 int fail(slimm_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -347,38 +30,7 @@ int fail(slimm_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(c, expr)                                                                              \
-    do {                                                                                              \
-        hipError_t e_ = (expr);                                                                       \
-        if (e_ != hipSuccess) return fail((c), SLIMM_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
-struct KernelTimer {  // brackets one launch (or a group) with events when timing is on
-    slimm_ctx* c;
-    slimm_ctx::Ev ev{};
-    bool on;
-    bool dispatch;  // the events are handed to the launch itself (hipExtLaunchKernelGGL: the dispatch's own time stamps)
-    KernelTimer(slimm_ctx* ctx, int id, bool of_dispatch = false)
-        : c(ctx), on(ctx->timing && (ctx->timing_only < 0 || ctx->timing_only == id)), dispatch(of_dispatch) {
-        if (!on) return;
-        if (!c->ev_free.empty()) {
-            ev = c->ev_free.back();
-            c->ev_free.pop_back();
-        } else {
-            (void)hipEventCreate(&ev.a);
-            (void)hipEventCreate(&ev.b);
-        }
-        ev.id = id;
-        if (!dispatch) (void)hipEventRecord(ev.a, c->stream);
-    }
-    hipEvent_t t0() const { return on ? ev.a : nullptr; }
-    hipEvent_t t1() const { return on ? ev.b : nullptr; }
-    ~KernelTimer() {
-        if (!on) return;
-        if (!dispatch) (void)hipEventRecord(ev.b, c->stream);
-        c->ev_used.push_back(ev);
-    }
-};
 
 void drain_events(slimm_ctx* c) {
     for (auto& e : c->ev_used) {
@@ -401,6 +53,7 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->sel.ensure(n + 8));
     HIP_TRY(c, c->slot_rbase.ensure(front_slots(n) + 8));
     HIP_TRY(c, c->slot_bbase.ensure(front_slots(n) / 1024 + 8));
+    HIP_TRY(c, c->filter_redo.ensure(front_slots(n) + 1));
     if (c->use_tiles) {
         HIP_TRY(c, c->bucket.ensure(n + 1));
         HIP_TRY(c, c->tile_items.ensure(TILES(c->tile_shift, tile_items_upper(c->ntiles2, n)) + 1));
@@ -431,43 +84,7 @@ int ensure_pair_table(slimm_ctx* c, uint32_t cap) {
     return SLIMM_OK;
 }
 
-// Grows one record array to `cap` elements, keeping the `used` elements pushed so far (when the array holds them at all:
-// an array the file's record form does not use is neither allocated nor copied).
-// later != nullptr: no hipFree now (it waits for every kernel in flight -- the inflate of the windows behind this one):
-// what the array was goes there and is freed when the file has ended
-template <typename T>
-hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStream_t st, std::vector<void*>* later = nullptr) {
-    if (cap <= buf.cap) return hipSuccess;
-    if (used == 0 || buf.cap < used) return later ? buf.ensure_later(cap, *later) : buf.ensure(cap);  // nothing of this file in it
-    DevBuf<T> nb;
-    hipError_t e = nb.ensure(cap);
-    if (e != hipSuccess) return e;
-    e = hipMemcpyAsync(nb.p, buf.p, used * sizeof(T), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return e;
-    std::swap(buf.p, nb.p);
-    std::swap(buf.cap, nb.cap);
-    if (later && nb.p) {
-        later->push_back(nb.p);
-        nb.p = nullptr;
-        nb.cap = 0;
-    }
-    return hipSuccess;
-}
 
-// the Q18 run counts of the device decoders (every window launched so far), from the carry block
-int bam_fetch_q18(slimm_ctx* c) {
-    slimm_ctx::BamDecode& B = c->bam;
-    if (!B.carry.p) return SLIMM_OK;
-    (void)hipSetDevice(c->device);
-    uint32_t w[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(w, &B.carry.p->short_starts, sizeof(w), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    B.q18_starts = w[0];
-    B.q18_plain = w[1];
-    return SLIMM_OK;
-}
 
 int check_device_errors(slimm_ctx* c, uint32_t err) {
     if (err & ERR_REF_RANGE) return fail(c, SLIMM_E_REF_RANGE, "a record names a reference id >= n_refs");
@@ -476,7 +93,7 @@ int check_device_errors(slimm_ctx* c, uint32_t err) {
     return SLIMM_OK;
 }
 
-}  // namespace
+}  // namespace slimm
 
 extern "C" {
 
@@ -856,834 +473,6 @@ int slimm_set_cutoff_cache(slimm_ctx* c, float cc, float ucc) {
 int slimm_set_min_reads(slimm_ctx* c, uint32_t min_reads) {
     if (!c) return SLIMM_E_INVALID;
     c->host->min_reads = min_reads;
-    return SLIMM_OK;
-}
-
-// Room for n records of the file's form: the four-array form holds key | ref | pos | flag (| check), the packed form
-// key | ref | pos, the run-marked form ref (the words) | pos.  Before the first push the form is not known yet: key, ref
-// and pos are reserved and the push itself adds what its form needs beyond them.
-int slimm_reserve(slimm_ctx* c, uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
-    if (c->borrowed) return fail(c, SLIMM_E_INVALID, "records are borrowed device arrays; reset first");
-    (void)hipSetDevice(c->device);
-    const bool need_key = !c->marked;
-    const bool need_flag = !c->packed && !c->marked && (c->n_pushed != 0 || c->in_flag.cap != 0);
-    const bool need_check = c->has_check;
-    const bool fits = n <= c->in_ref.cap && n <= c->in_pos.cap && (!need_key || n <= c->in_key.cap) &&
-                      (!need_flag || n <= c->in_flag.cap) && (!need_check || n <= c->in_check.cap);
-    if (fits) return SLIMM_OK;
-    // grow, keeping what was pushed (copies on their way included)
-    if (c->copy_pending) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-    uint64_t cap = n <= c->in_ref.cap ? c->in_ref.cap : std::max<uint64_t>(n, c->in_ref.cap * 2);  // (double only to grow)
-    if (cap >= 0x7fffffffull) cap = 0x7ffffffeull;
-    const uint64_t used = c->n_pushed;
-    std::vector<void*>* later = c->bam.active ? &c->bam.outgrown : nullptr;  // (windows of a BAM file may be inflating)
-    HIP_TRY(c, grow_record_array(c->in_ref, cap, used, c->stream, later));
-    HIP_TRY(c, grow_record_array(c->in_pos, cap, used, c->stream, later));
-    if (need_key) HIP_TRY(c, grow_record_array(c->in_key, cap, used, c->stream, later));
-    if (need_flag) HIP_TRY(c, grow_record_array(c->in_flag, cap, used, c->stream, later));
-    if (need_check) HIP_TRY(c, grow_record_array(c->in_check, cap, used, c->stream, later));
-    return SLIMM_OK;
-}
-
-int slimm_push_records(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
-                       uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (n == 0) return SLIMM_OK;
-    if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
-    if (c->packed || c->marked)
-        return fail(c, SLIMM_E_INVALID, "earlier batches were packed or run-marked records: the forms do not mix within a file");
-    int rc = slimm_reserve(c, c->n_pushed + n);
-    if (rc != SLIMM_OK) return rc;
-    if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));  // (only ever at a file's first push)
-    const uint64_t o = c->n_pushed;
-    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_flag.p + o, flag, n * 2, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may reuse its buffers on return
-    c->n_pushed += n;
-    c->rec.key = c->in_key.p;
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.flag = c->in_flag.p;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    return SLIMM_OK;
-}
-
-// slimm_push_records with a check word per record: a second, independent hash of the read name.  The library compares
-// keys, never names; with check words it can at least SEE when two different names share a key -- records with one key
-// and two check words next to each other (grouped input) or after the sort (any order) make the run fail with
-// SLIMM_E_KEY_COLLISION instead of silently becoming one read.
-int slimm_push_records_checked(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
-                               const uint32_t* check, uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (n == 0) return SLIMM_OK;
-    if (!key || !ref || !pos || !flag || !check) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->n_pushed && !c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried no check words");
-    if (c->packed || c->marked)
-        return fail(c, SLIMM_E_INVALID, "earlier batches were packed or run-marked records: the forms do not mix within a file");
-    c->has_check = true;
-    int rc = slimm_reserve(c, c->n_pushed + n);
-    if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, c->in_check.ensure(c->in_key.cap));
-    if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));
-    const uint64_t o = c->n_pushed;
-    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_flag.p + o, flag, n * 2, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_check.p + o, check, n * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->n_pushed += n;
-    c->rec.key = c->in_key.p;
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.flag = c->in_flag.p;
-    c->rec.check = c->in_check.p;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    return SLIMM_OK;
-}
-
-// Streamed ingest: the copies go to a stream of their own and the call returns at once; phase A is ordered behind them
-// by an event on the device, never by the host.  With page-locked arrays (the staging sets below, or the caller's own)
-// the DMA engine reads them directly while the host decodes the next batch and the compute stream works on the file
-// before.
-int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, const uint16_t* flag,
-                             uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (n == 0) return SLIMM_OK;
-    if (!key || !ref || !pos || !flag) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->has_check) return fail(c, SLIMM_E_INVALID, "earlier batches carried check words: push this one with slimm_push_records_checked");
-    if (c->packed || c->marked)
-        return fail(c, SLIMM_E_INVALID, "earlier batches were packed or run-marked records: the forms do not mix within a file");
-    int rc = slimm_reserve(c, c->n_pushed + n);
-    if (rc != SLIMM_OK) return rc;
-    if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));
-    const uint64_t o = c->n_pushed;
-    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_flag.p + o, flag, n * 2, hipMemcpyHostToDevice, c->copy_stream));
-    HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
-    c->copy_pending = true;
-    c->n_pushed += n;
-    c->rec.key = c->in_key.p;
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.flag = c->in_flag.p;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    return SLIMM_OK;
-}
-
-// 16 bytes per record: the three flag bits the record loop reads ride in the key (slimm_pack_key); no flag array crosses
-// the bus or is read by the front end.  on_copy_stream: the asynchronous form (slimm_push_records_packed_async).
-static int push_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n, bool on_copy_stream) {
-    if (!c) return SLIMM_E_INVALID;
-    if (n == 0) return SLIMM_OK;
-    if (!key || !ref || !pos) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->has_check || c->marked || (c->n_pushed && !c->packed))
-        return fail(c, SLIMM_E_INVALID, "earlier batches were not packed records: the forms do not mix within a file");
-    c->packed = true;
-    int rc = slimm_reserve(c, c->n_pushed + n);
-    if (rc != SLIMM_OK) return rc;
-    const uint64_t o = c->n_pushed;
-    hipStream_t st = on_copy_stream ? c->copy_stream : c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, st));
-    if (on_copy_stream) {
-        HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
-        c->copy_pending = true;
-    } else {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may reuse its buffers on return
-    }
-    c->n_pushed += n;
-    c->rec.key = c->in_key.p;
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.flag = nullptr;
-    c->rec.packed = true;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    return SLIMM_OK;
-}
-int slimm_push_records_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
-    return push_packed(c, key, ref, pos, n, false);
-}
-int slimm_push_records_packed_async(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
-    return push_packed(c, key, ref, pos, n, true);
-}
-uint64_t slimm_pack_key(uint64_t read_key, uint16_t flag) {  // src/slimm.hpp:197 (unmapped), :205-208 (mate number)
-    const uint64_t mate = (flag & 0x40u) ? 1u : ((flag & 0x80u) ? 2u : 0u);
-    return (read_key & ((1ull << 61) - 1ull)) | (mate << 61) | (static_cast<uint64_t>((flag & 0x4u) != 0u) << 63);
-}
-void slimm_pack_keys(const uint64_t* read_key, const uint16_t* flag, uint64_t n, uint64_t* packed) {
-    for (uint64_t i = 0; i < n; ++i) packed[i] = slimm_pack_key(read_key[i], flag[i]);
-}
-
-// 8 bytes per record: for input grouped by read name the device never needs the names, only where a run of equal names
-// starts -- the producer compares adjacent names instead of hashing them, and no key array crosses the bus or is read by
-// the front end (front.hip: FrontMarked).
-static int push_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n, bool on_copy_stream) {
-    if (!c) return SLIMM_E_INVALID;
-    if (n == 0) return SLIMM_OK;
-    if (!word || !pos) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->order != SLIMM_ORDER_GROUPED)
-        return fail(c, SLIMM_E_INVALID, "run-marked records carry no read identity: the context must be created for input grouped by name");
-    if (c->has_check || c->packed || (c->n_pushed && !c->marked))
-        return fail(c, SLIMM_E_INVALID, "earlier batches were not run-marked records: the forms do not mix within a file");
-    c->marked = true;
-    int rc = slimm_reserve(c, c->n_pushed + n);
-    if (rc != SLIMM_OK) return rc;
-    const uint64_t o = c->n_pushed;
-    hipStream_t st = on_copy_stream ? c->copy_stream : c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, word, n * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, st));
-    if (on_copy_stream) {
-        HIP_TRY(c, hipEventRecord(c->copy_done, c->copy_stream));
-        c->copy_pending = true;
-    } else {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may reuse its buffers on return
-    }
-    c->n_pushed += n;
-    c->rec = DeviceRecords();
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.marked = true;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    return SLIMM_OK;
-}
-int slimm_push_records_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n) {
-    return push_marked(c, word, pos, n, false);
-}
-int slimm_push_records_marked_async(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n) {
-    return push_marked(c, word, pos, n, true);
-}
-uint32_t slimm_mark_word(int32_t ref_id, uint16_t flag, int starts_run) {  // src/slimm.hpp:197 (mapped), :205-208 (mate number)
-    const uint32_t mate = (flag & 0x40u) ? 1u : ((flag & 0x80u) ? 2u : 0u);
-    const bool mapped = !(flag & 0x4u) && ref_id != -1;
-    // (a reference that is neither -1 nor an index of the table keeps its out-of-range value: the front end reports it)
-    const uint32_t r1 = mapped ? std::min<uint32_t>(static_cast<uint32_t>(ref_id) + 1u, 0x1fffffffu) : 0u;
-    return r1 | (mate << 29) | (starts_run ? 0x80000000u : 0u);
-}
-void slimm_mark_words(const uint64_t* read_key, const uint16_t* flag, const int32_t* ref_id, uint64_t n, const uint64_t* prev_key,
-                      uint32_t* word) {
-    for (uint64_t i = 0; i < n; ++i) {
-        const bool starts = i ? read_key[i] != read_key[i - 1] : (!prev_key || read_key[0] != *prev_key);
-        word[i] = slimm_mark_word(ref_id[i], flag[i], starts ? 1 : 0);
-    }
-}
-
-// A caller's host buffer page-locked for the life of the context: the DMA engine then reads it directly (slimm_push_bam_bytes
-// and the *_async pushes take any host memory, at the speed of the runtime's own staging when it is pageable)
-int slimm_pin_host_buffer(slimm_ctx* c, const void* p, uint64_t n_bytes) {
-    if (!c || !p || !n_bytes) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context");
-    (void)hipSetDevice(c->device);
-    const uint8_t* b = static_cast<const uint8_t*>(p);
-    for (auto& r : c->bam.registered)
-        if (b >= r.first && b + n_bytes <= r.first + r.second) return SLIMM_OK;
-    if (hipHostRegister(const_cast<uint8_t*>(b), n_bytes, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(c, SLIMM_E_HIP, "hipHostRegister failed");
-    }
-    c->bam.registered.emplace_back(b, static_cast<size_t>(n_bytes));
-    return SLIMM_OK;
-}
-
-// BAM alignment records decoded on the device (include/slimm_hip.h; kernels: bam_decode.hip).
-// A window is copied when it is pushed and WORKED ON when the next one is pushed (or at once, when it is the last): its
-// host-to-device copy then runs beside the kernels and the host's bookkeeping of the window before it -- the copies are
-// what bounds this path (192 MB at 54 GB/s: 3.6 ms; kernels + one synchronisation per window: 0.8 ms).
-namespace {
-// window j (n bytes, in buffer j % kBamRing) -> records appended; the incomplete record at its end goes in front of window j + 1
-int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, uint64_t& n_rec_out) {
-    slimm_ctx::BamDecode& B = c->bam;
-    hipStream_t st = c->stream;
-    const bool marked = c->order == SLIMM_ORDER_GROUPED;
-    const uint32_t b = static_cast<uint32_t>(j % slimm_ctx::kBamRing), nb = static_cast<uint32_t>((j + 1u) % slimm_ctx::kBamRing);
-    const uint64_t lo = kBamSlack - B.carry_bytes, end = kBamSlack + n_bytes;
-    const uint32_t np = B.sam ? sam_pieces(end - lo) : bam_pieces(end - lo);
-    // (with room to spare and without a hipFree: windows differ by a few pieces, and a hipFree waits for the inflate kernels
-    // of the windows behind this one)
-    if (B.pieces.cap < static_cast<size_t>(np) + 1) HIP_TRY(c, B.pieces.ensure_later(static_cast<size_t>(np) + (np >> 2) + 64, B.outgrown));
-    if (B.offs.cap < static_cast<size_t>(np + 1) * kBamSlots)
-        HIP_TRY(c, B.offs.ensure_later((static_cast<size_t>(np) + (np >> 2) + 64) * kBamSlots, B.outgrown));
-    if (n_bytes) HIP_TRY(c, hipStreamWaitEvent(st, B.copied[b], 0));
-    const bool inflated_here = n_bytes && B.inflated[b];
-    if (inflated_here)
-        HIP_TRY(c, hipMemcpyAsync(B.h_inflate_status.p, B.inflate_status.p + 4u * b, 16, hipMemcpyDeviceToHost, st));
-    if (B.sam)
-        launch_sam_find(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.result.p);
-    else
-        launch_bam_find(st, B.bytes[b].p, lo, end, c->R, B.pieces.p, B.offs.p, B.result.p);
-    HIP_TRY(c, hipStreamSynchronize(st));  // the window is on the device and counted
-    if (inflated_here && B.h_inflate_status.p[0])
-        return fail(c, SLIMM_E_INVALID, "corrupt BGZF block (device inflate: error %u in block %u of the window)", B.h_inflate_status.p[0],
-                    B.h_inflate_status.p[1]);
-    const BamWindowResult res = *B.result.p;
-    if (res.bad && B.sam)
-        return fail(c, SLIMM_E_INVALID, (res.bad & kBamPieceBad) ? "SAM line with fewer than 10 fields"
-                                                                : "a header line or an empty line among the alignment lines: decode this file on the host");
-    if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
-    const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
-    const uint64_t tail = end - stop;
-    if (tail > kBamSlack)
-        return fail(c, SLIMM_E_INVALID, B.sam ? "a SAM line longer than 16 MiB: decode this file on the host"
-                                              : "a BAM record longer than 16 MiB: decode this file on the host");
-    if (is_last && tail) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
-    if (c->n_pushed + n_rec >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
-    int rc = slimm_reserve(c, c->n_pushed + n_rec);
-    if (rc != SLIMM_OK) return rc;
-    if (!marked) {  // (the four-array form's flag and check arrays appear at a file's first window)
-        const uint64_t want = c->n_pushed + n_rec;
-        if (c->in_flag.cap < want) {
-            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
-            HIP_TRY(c, c->in_flag.ensure_later(std::max<uint64_t>(want, c->in_ref.cap), B.outgrown));
-        }
-        if (c->in_check.cap < want) {
-            if (c->n_pushed) return fail(c, SLIMM_E_HIP, "record arrays out of step");
-            HIP_TRY(c, c->in_check.ensure_later(std::max<uint64_t>(want, c->in_ref.cap), B.outgrown));
-        }
-    }
-    if (B.sam)
-        launch_sam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
-                          c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p, B.sam_table.p, B.sam_mask, B.sam_names.p);
-    else
-        launch_bam_decode(st, B.bytes[b].p, lo, end, B.pieces.p, B.offs.p, B.carry.p, B.result.p, marked, c->n_pushed, c->in_key.p,
-                          c->in_ref.p, c->in_pos.p, c->in_flag.p, c->in_check.p);
-    if (tail) {  // the incomplete record goes in front of the next window (whose own bytes may be on their way already)
-        if (B.bytes[nb].cap < kBamSlack + 64) HIP_TRY(c, B.bytes[nb].ensure(kBamSlack + 64));
-        HIP_TRY(c, hipMemcpyAsync(B.bytes[nb].p + kBamSlack - tail, B.bytes[b].p + stop, tail, hipMemcpyDeviceToDevice, st));
-    }
-    HIP_TRY(c, hipGetLastError());
-    B.carry_bytes = tail;
-    c->n_pushed += n_rec;
-    c->rec = DeviceRecords();
-    c->rec.ref = c->in_ref.p;
-    c->rec.pos = c->in_pos.p;
-    c->rec.n = static_cast<uint32_t>(c->n_pushed);
-    if (marked) {
-        c->rec.marked = true;
-    } else {
-        c->rec.key = c->in_key.p;
-        c->rec.flag = c->in_flag.p;
-        c->rec.check = c->in_check.p;
-    }
-    n_rec_out = n_rec;
-    return SLIMM_OK;
-}
-}  // namespace
-
-namespace {
-enum { kFormatBam = 0, kFormatBgzf = 1, kFormatSam = 2 };
-int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int format, uint32_t skip, int last, uint64_t* n_records);
-}
-int slimm_set_input_size_hint(slimm_ctx* c, uint64_t compressed_bytes) {
-    if (!c) return SLIMM_E_INVALID;
-    if (c->bam.active) return fail(c, SLIMM_E_INVALID, "slimm_set_input_size_hint: before the file's first window");
-    c->bam.size_hint = compressed_bytes;
-    return SLIMM_OK;
-}
-int slimm_window_memory(slimm_ctx* c, uint64_t* device_bytes) {
-    if (!c || !device_bytes) return SLIMM_E_INVALID;
-    *device_bytes = c->bam.held_bytes();
-    return SLIMM_OK;
-}
-int slimm_push_bam_bytes(slimm_ctx* c, const uint8_t* bytes, uint64_t n_bytes, int last, uint64_t* n_records) {
-    return bam_push_window(c, bytes, n_bytes, kFormatBam, 0u, last, n_records);
-}
-int slimm_push_bgzf_blocks(slimm_ctx* c, const uint8_t* blocks, uint64_t n_bytes, uint32_t skip, int last, uint64_t* n_records) {
-    return bam_push_window(c, blocks, n_bytes, kFormatBgzf, skip, last, n_records);
-}
-int slimm_push_sam_bytes(slimm_ctx* c, const uint8_t* text, uint64_t n_bytes, int last, uint64_t* n_records) {
-    return bam_push_window(c, text, n_bytes, kFormatSam, 0u, last, n_records);
-}
-// The header's reference names (@SQ SN, index = the reference id) for slimm_push_sam_bytes: a hash table on the device.
-int slimm_set_reference_names(slimm_ctx* c, const char* const* names) {
-    if (!c || !names) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    (void)hipSetDevice(c->device);
-    slimm_ctx::BamDecode& B = c->bam;
-    uint32_t cap = 16;
-    while (cap < 2u * c->R + 2u) cap <<= 1;
-    std::vector<SamRefEntry> tab(cap);
-    for (auto& e : tab) {
-        e.hash = 0;
-        e.ref = -1;
-        e.name_off = e.name_len = e.pad = 0;
-    }
-    std::vector<uint8_t> blob;
-    for (uint32_t r = 0; r < c->R; ++r) {
-        const char* nm = names[r] ? names[r] : "";
-        const size_t n = strlen(nm);
-        const uint64_t h = sam_name_hash(nm, n);
-        bool dup = false;
-        uint32_t slot = static_cast<uint32_t>(h) & (cap - 1u);
-        for (;; slot = (slot + 1u) & (cap - 1u)) {
-            if (tab[slot].ref < 0) break;
-            if (tab[slot].hash == h && tab[slot].name_len == n && memcmp(blob.data() + tab[slot].name_off, nm, n) == 0) {
-                dup = true;   // (two header lines with one name: the first one's index, like the host reader's map)
-                break;
-            }
-        }
-        if (dup) continue;
-        tab[slot].hash = h;
-        tab[slot].ref = static_cast<int32_t>(r);
-        tab[slot].name_off = static_cast<uint32_t>(blob.size());
-        tab[slot].name_len = static_cast<uint32_t>(n);
-        blob.insert(blob.end(), nm, nm + n);
-    }
-    blob.resize(blob.size() + 16, 0);
-    HIP_TRY(c, B.sam_table.ensure(cap));
-    HIP_TRY(c, B.sam_names.ensure(blob.size()));
-    HIP_TRY(c, hipMemcpy(B.sam_table.p, tab.data(), cap * sizeof(SamRefEntry), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(B.sam_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    B.sam_mask = cap - 1u;
-    return SLIMM_OK;
-}
-namespace {
-// SLIMM_PUSH_TRACE=1: what the window pipeline does and when (stderr; milliseconds since the first line)
-void push_trace(const char* fmt, ...) {
-    static const bool on = getenv("SLIMM_PUSH_TRACE") != nullptr;
-    if (!on) return;
-    static const auto t0 = std::chrono::steady_clock::now();
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    va_list ap;
-    va_start(ap, fmt);
-    fprintf(stderr, "[push %9.3f] ", ms);
-    vfprintf(stderr, fmt, ap);
-    fputc('\n', stderr);
-    va_end(ap);
-}
-// the window buffer of window `windows`, large enough for n_bytes behind its slack; what the slack holds is kept
-int bam_window_buffer(slimm_ctx* c, uint64_t n_bytes, bool gathered = false) {
-    slimm_ctx::BamDecode& B = c->bam;
-    const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
-    // (a gathered window gets the room of the largest one at once: a buffer that grows is a hipFree, and a hipFree waits for
-    // the inflate kernels of the windows before)
-    const uint64_t need = kBamSlack + (gathered ? std::max<uint64_t>(n_bytes, B.win_cap ? B.win_cap : slimm_ctx::kBamGather) : n_bytes) + 64;
-    if (B.bytes[b].cap >= need) return SLIMM_OK;
-    // (what the buffer held -- the window a ring's length back -- is done with: it was finished before this one was let in.
-    // Only the carried bytes in its slack matter, and only when the window before this one is finished already: otherwise
-    // its end will put them there later)
-    if (B.head == B.windows && B.carry_bytes) {
-        DevBuf<uint8_t> nb;
-        HIP_TRY(c, nb.ensure(need + (need >> 3)));
-        HIP_TRY(c, hipMemcpyAsync(nb.p + kBamSlack - B.carry_bytes, B.bytes[b].p + kBamSlack - B.carry_bytes, B.carry_bytes,
-                                  hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        std::swap(B.bytes[b].p, nb.p);
-        std::swap(B.bytes[b].cap, nb.cap);
-        if (nb.p) B.outgrown.push_back(nb.p);
-        nb.p = nullptr;
-        nb.cap = 0;
-    } else {
-        HIP_TRY(c, B.bytes[b].ensure_later(need + (gathered ? 0u : need >> 3), B.outgrown));
-    }
-    return SLIMM_OK;
-}
-
-void bam_free_outgrown(slimm_ctx* c) {
-    for (void* p : c->bam.outgrown) (void)hipFree(p);
-    c->bam.outgrown.clear();
-}
-
-// The BGZF blocks gathered so far become window `windows`: descriptors over, the inflate launched behind the copies on the
-// inflate stream whose turn it is.
-int bam_launch_gathered(slimm_ctx* c) {
-    slimm_ctx::BamDecode& B = c->bam;
-    if (!B.acc_open) return SLIMM_OK;
-    const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing), si = static_cast<uint32_t>(B.windows & 1u);
-    const uint32_t nblk = static_cast<uint32_t>(B.desc_host[b].size());
-    const uint64_t n_bytes = B.acc_dst - B.acc_skip;
-    B.acc_open = false;
-    if (!nblk || !n_bytes) return SLIMM_OK;
-    const int rc = bam_window_buffer(c, n_bytes, true);
-    if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, B.desc[b].ensure_later(static_cast<size_t>(nblk) + (nblk >> 1) + 1, B.outgrown));
-    HIP_TRY(c, B.inflate_scratch[si].ensure_later(bgzf_inflate_scratch_bytes(nblk + (nblk >> 2), B.acc_tok + (B.acc_tok >> 2)), B.outgrown));
-    HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
-    HIP_TRY(c, B.h_inflate_status.ensure(4));
-    HIP_TRY(c, hipMemsetAsync(B.comp[b].p + B.acc_src, 0, kBgzfTail, c->copy_stream));
-    HIP_TRY(c, hipMemcpyAsync(B.desc[b].p, B.desc_host[b].data(), static_cast<size_t>(nblk) * sizeof(BgzfBlock), hipMemcpyHostToDevice,
-                              c->copy_stream));
-    HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b, 0, 16, c->copy_stream));
-    HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b + 1u, 0xff, 4, c->copy_stream));
-    if (!B.inflate_stream[si]) HIP_TRY(c, hipStreamCreateWithFlags(&B.inflate_stream[si], hipStreamNonBlocking));
-    if (!B.comp_copied) HIP_TRY(c, hipEventCreateWithFlags(&B.comp_copied, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(B.comp_copied, c->copy_stream));
-    HIP_TRY(c, hipStreamWaitEvent(B.inflate_stream[si], B.comp_copied, 0));
-    launch_bgzf_inflate(B.inflate_stream[si], B.comp[b].p, B.desc[b].p, nblk, B.bytes[b].p + kBamSlack - B.acc_skip, B.inflate_scratch[si].p,
-                        B.inflate_status.p + 4u * b);
-    HIP_TRY(c, hipEventRecord(B.copied[b], B.inflate_stream[si]));
-    B.inflated[b] = true;
-    B.win_bytes[b] = n_bytes;
-    ++B.windows;
-    push_trace("window %llu launched: %u blocks, %.0f MB -> %.0f MB, inflate stream %u", (unsigned long long)(B.windows - 1), nblk,
-               B.acc_src / 1e6, n_bytes / 1e6, si);
-    return SLIMM_OK;
-}
-
-// A window of a BAM file's alignment-record bytes: inflated already (`bytes` are the records' bytes) or as whole BGZF blocks
-// (`bytes` are compressed; the first `skip` inflated bytes are not records).  src_bytes = what crosses the bus.
-// BGZF pushes are GATHERED: their compressed bytes are copied behind each other into the next window's buffer, and the window
-// is launched -- inflate, then the record kernels -- once it holds kBamGatherGoal inflated bytes (or the file ends, or a
-// push of the other kind comes): the inflate's first phase is a lane per block and wants tens of thousands of them, whatever
-// size the caller's buffers have.
-int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int format, uint32_t skip, int last, uint64_t* n_records) {
-    if (!c) return SLIMM_E_INVALID;
-    if (n_records) *n_records = 0;
-    bool compressed = format == kFormatBgzf;
-    const bool sam = format == kFormatSam;
-    if (sam && !c->bam.sam_mask) return fail(c, SLIMM_E_INVALID, "slimm_set_reference_names first: SAM text names its references");
-    if (c->bam.active && c->bam.sam != sam) return fail(c, SLIMM_E_INVALID, "SAM text and BAM bytes do not mix within a file");
-    uint64_t n_bytes = src_bytes;  // the push's record bytes
-    std::vector<BgzfBlock> dh;
-    uint64_t inflated = 0;
-    if (compressed && src_bytes) {
-        if (!bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
-        std::string why;
-        if (!bgzf_parse_blocks(bytes, src_bytes, 0, dh, inflated, why)) return fail(c, SLIMM_E_INVALID, "%s", why.c_str());
-        if (skip > inflated || (skip && c->bam.active && (c->bam.windows > 0 || c->bam.acc_open)))
-            return fail(c, SLIMM_E_INVALID, "skip: only in front of a file's first records");
-        if (dh.size() >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "too many blocks in one window");
-        n_bytes = inflated - skip;
-        // blocks that lie wholly inside the skipped bytes (a BAM header of any size) are not inflated at all; what is left to
-        // skip is less than one block, so the inflater's first byte stays inside the window buffer's slack
-        size_t drop = 0;
-        while (drop < dh.size() && dh[drop].dst + dh[drop].isize <= skip) ++drop;
-        if (drop) {
-            const uint64_t d0 = drop < dh.size() ? dh[drop].dst : inflated;
-            dh.erase(dh.begin(), dh.begin() + static_cast<long>(drop));
-            for (BgzfBlock& d : dh) d.dst -= d0;
-            skip -= static_cast<uint32_t>(d0);
-            inflated -= d0;
-        }
-        if (skip >= 65536u) return fail(c, SLIMM_E_INVALID, "skip: past the first block that holds a record byte");
-        if (n_bytes == 0) {  // (blocks without a record byte: nothing to inflate, nothing to decode)
-            compressed = false;
-            src_bytes = 0;
-        }
-    } else if (compressed) {
-        compressed = false;
-    }
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    if (n_bytes && !bytes) return fail(c, SLIMM_E_INVALID, "null byte buffer");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->borrowed) return fail(c, SLIMM_E_INVALID, "records are borrowed device arrays; reset first");
-    if (n_bytes >= (1ull << 31)) return fail(c, SLIMM_E_INVALID, "a window of BAM bytes is less than 2 GiB");
-    const bool marked = c->order == SLIMM_ORDER_GROUPED;
-    if (c->n_pushed && !c->bam.active)
-        return fail(c, SLIMM_E_INVALID, "earlier batches were decoded records: the forms do not mix within a file");
-    (void)hipSetDevice(c->device);
-    slimm_ctx::BamDecode& B = c->bam;
-    hipStream_t st = c->stream;
-    if (!B.active) {  // a file's first window
-        B.active = true;
-        B.windows = 0;
-        B.head = 0;
-        B.carry_bytes = 0;
-        B.pushes = 0;
-        B.acc_open = false;
-        B.sam = sam;
-        B.sam_last_byte = '\n';
-        c->marked = marked;
-        c->has_check = !marked;
-        c->packed = false;
-        HIP_TRY(c, B.carry.ensure(1));
-        HIP_TRY(c, B.result.ensure(1));
-        for (auto& e : B.copied)
-            if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : B.h2d_done)
-            if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIP_TRY(c, hipMemsetAsync(B.carry.p, 0, sizeof(BamCarry), st));
-    }
-    if (B.closed) return fail(c, SLIMM_E_INVALID, "the file's last window has been pushed; reset first");
-    uint64_t total = 0;
-    bool copy_started = false;
-    push_trace("push: %.0f MB %s -> %.0f MB%s", src_bytes / 1e6, compressed ? "of blocks" : "inflated", n_bytes / 1e6, last ? " (last)" : "");
-    if (n_bytes && compressed) {
-        // behind what is gathered already -- unless the window would grow past its size: that one goes first
-        if (B.acc_open && B.acc_dst + inflated > slimm_ctx::kBamGather) {
-            const int rc = bam_launch_gathered(c);
-            if (rc != SLIMM_OK) return rc;
-        }
-        const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
-        if (!B.acc_open) {
-            B.acc_open = true;
-            B.acc_src = B.acc_dst = 0;
-            B.acc_skip = skip;
-            B.acc_tok = 0;
-            B.desc_host[b].clear();
-            // A file's first window: the buffers its windows will take in turn, now -- an allocation (like a hipFree) made
-            // while inflate kernels are in flight waits for them, and the pushes that should overlap them stand still.  How
-            // many and how large comes from the caller's hint (slimm_set_input_size_hint: the file's compressed bytes) and
-            // this push's own ratios: a 70 MB file gets one window of its size, not four of 1.9 GB (17 GB
-            // per context whatever the file).  Without a hint nothing is reserved ahead: buffers appear as windows need them.
-            if (B.windows == 0) {
-                B.win_cap = 0;
-                if (B.size_hint && src_bytes && inflated) {
-                    const double ratio = static_cast<double>(inflated) / static_cast<double>(src_bytes);
-                    const uint64_t left = B.size_hint > src_bytes ? B.size_hint - src_bytes : 0;
-                    const uint64_t est = inflated + static_cast<uint64_t>(static_cast<double>(left) * ratio * 1.08) + (16ull << 20);
-                    const uint64_t nwin = est <= slimm_ctx::kBamGather ? 1u : (est + slimm_ctx::kBamGatherGoal - 1) / slimm_ctx::kBamGatherGoal;
-                    const uint32_t nbuf = static_cast<uint32_t>(std::min<uint64_t>(slimm_ctx::kBamRing, nwin));
-                    B.win_cap = nwin == 1 ? est : slimm_ctx::kBamGather;
-                    // (a window's compressed bytes: what inflates to the goal, plus the push that crosses it)
-                    const uint64_t comp_cap = (nwin == 1 ? B.size_hint + (B.size_hint >> 4)
-                                                         : static_cast<uint64_t>(static_cast<double>(slimm_ctx::kBamGatherGoal) / ratio * 1.15) + src_bytes) +
-                                              kBgzfTail + (1ull << 20);
-                    const double blocks_per_byte = static_cast<double>(dh.size()) / static_cast<double>(inflated);
-                    const uint32_t blocks_max = static_cast<uint32_t>(static_cast<double>(B.win_cap) * blocks_per_byte * 1.25) + 1024u;
-                    const uint64_t tok_max = B.win_cap / 3u + B.win_cap / 256u + 8ull * blocks_max;
-                    for (uint32_t k = 0; k < nbuf; ++k) {
-                        HIP_TRY(c, B.bytes[k].ensure_later(kBamSlack + B.win_cap + 64, B.outgrown));
-                        HIP_TRY(c, B.comp[k].ensure_later(comp_cap, B.outgrown));
-                        HIP_TRY(c, B.desc[k].ensure_later(blocks_max, B.outgrown));
-                    }
-                    for (uint32_t k = 0; k < std::min<uint32_t>(2u, nbuf); ++k)
-                        HIP_TRY(c, B.inflate_scratch[k].ensure_later(bgzf_inflate_scratch_bytes(blocks_max, tok_max), B.outgrown));
-                    const size_t np_max = bam_pieces(B.win_cap + kBamSlack) + 64;
-                    HIP_TRY(c, B.pieces.ensure_later(np_max, B.outgrown));
-                    HIP_TRY(c, B.offs.ensure_later(np_max * kBamSlots, B.outgrown));
-                    push_trace("planned %llu window(s) of <= %.0f MB in %u buffer(s), %.0f MB of compressed bytes each: %.2f GB held",
-                               (unsigned long long)nwin, B.win_cap / 1e6, nbuf, comp_cap / 1e6, B.held_bytes() / 1e9);
-                }
-                HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
-                HIP_TRY(c, B.h_inflate_status.ensure(4));
-            }
-        }
-        const uint64_t need = B.acc_src + src_bytes + kBgzfTail + 64;
-        if (B.comp[b].cap < need) {  // (grown with what earlier pushes of this window have put there)
-            DevBuf<uint8_t> nb;
-            HIP_TRY(c, nb.ensure(need + (need >> 1)));
-            if (B.acc_src) HIP_TRY(c, hipMemcpyAsync(nb.p, B.comp[b].p, B.acc_src, hipMemcpyDeviceToDevice, c->copy_stream));
-            std::swap(B.comp[b].p, nb.p);
-            std::swap(B.comp[b].cap, nb.cap);
-            if (nb.p) B.outgrown.push_back(nb.p);   // (no hipFree here: it would wait for the inflate kernels in flight)
-            nb.p = nullptr;
-            nb.cap = 0;
-        }
-        HIP_TRY(c, hipMemcpyAsync(B.comp[b].p + B.acc_src, bytes, src_bytes, hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
-        ++B.pushes;
-        copy_started = true;
-        const uint32_t tok0 = dh.empty() ? 0u : dh.front().tok;   // (blocks dropped in front of a file's first record)
-        for (BgzfBlock& d : dh) {
-            d.src += B.acc_src;
-            d.dst += B.acc_dst;
-            d.tok = d.tok - tok0 + B.acc_tok;
-        }
-        if (!dh.empty()) B.acc_tok = dh.back().tok + bgzf_token_room(dh.back().isize);
-        B.desc_host[b].insert(B.desc_host[b].end(), dh.begin(), dh.end());
-        B.acc_src += src_bytes;
-        B.acc_dst += inflated;
-        if (B.acc_dst >= slimm_ctx::kBamGatherGoal) {
-            const int rc = bam_launch_gathered(c);
-            if (rc != SLIMM_OK) return rc;
-        }
-    } else if (n_bytes || (sam && last && B.sam_last_byte != '\n')) {  // inflated bytes / text: a window of their own, behind what was gathered
-        int rc = bam_launch_gathered(c);
-        if (rc != SLIMM_OK) return rc;
-        // (SAM text whose last line has no newline gets one: a line ends where its newline is)
-        if (sam && n_bytes) B.sam_last_byte = bytes[n_bytes - 1];
-        const bool add_newline = sam && last && B.sam_last_byte != '\n';
-        rc = bam_window_buffer(c, n_bytes + (add_newline ? 1u : 0u));
-        if (rc != SLIMM_OK) return rc;
-        const uint32_t b = static_cast<uint32_t>(B.windows % slimm_ctx::kBamRing);
-        B.inflated[b] = false;
-        if (n_bytes) HIP_TRY(c, hipMemcpyAsync(B.bytes[b].p + kBamSlack, bytes, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
-        if (add_newline) {
-            HIP_TRY(c, hipMemsetAsync(B.bytes[b].p + kBamSlack + n_bytes, '\n', 1, c->copy_stream));
-            n_bytes += 1;
-            B.sam_last_byte = '\n';
-        }
-        HIP_TRY(c, hipEventRecord(B.copied[b], c->copy_stream));
-        HIP_TRY(c, hipEventRecord(B.h2d_done[B.pushes % 4u], c->copy_stream));
-        ++B.pushes;
-        copy_started = true;
-        B.win_bytes[b] = n_bytes;
-        ++B.windows;
-    }
-    if (last) {
-        const int rc = bam_launch_gathered(c);
-        if (rc != SLIMM_OK) return rc;
-    }
-    // ... while the windows before are worked on: the oldest are finished (found, counted, decoded) once more than kBamLag
-    // windows or kBamInFlight bytes are in flight -- all of them when this is the file's end
-    const bool had_any = B.head < B.windows;
-    for (;;) {
-        if (B.head >= B.windows) break;
-        uint64_t in_flight = 0;
-        for (uint64_t j = B.head; j < B.windows; ++j) in_flight += B.win_bytes[j % slimm_ctx::kBamRing];
-        if (!last && B.windows - B.head <= slimm_ctx::kBamLag && in_flight <= slimm_ctx::kBamInFlight) break;
-        uint64_t got = 0;
-        const uint64_t j = B.head;
-        push_trace("finishing window %llu (%llu .. %llu in flight, %.0f MB)", (unsigned long long)j, (unsigned long long)B.head,
-                   (unsigned long long)B.windows, in_flight / 1e6);
-        const int rc = bam_finish_window(c, j, B.win_bytes[j % slimm_ctx::kBamRing], last && j + 1 == B.windows, got);
-        push_trace("finished window %llu: %llu records", (unsigned long long)j, (unsigned long long)got);
-        ++B.head;
-        if (rc != SLIMM_OK) return rc;
-        total += got;
-    }
-    if (last) {
-        if (!had_any && B.carry_bytes) return fail(c, SLIMM_E_INVALID, "truncated BAM record");
-        B.closed = true;
-        bam_free_outgrown(c);
-    } else {
-        // the caller's buffer of the call BEFORE this one has been read (it may be reused once this call returns): the most
-        // recent push whose copy this call did not start itself (a call without record bytes starts none)
-        const uint64_t mine = copy_started ? 1u : 0u;
-        if (B.pushes > mine) HIP_TRY(c, hipEventSynchronize(B.h2d_done[(B.pushes - 1u - mine) % 4u]));
-        push_trace("push returns");
-    }
-    if (n_records) *n_records = total;
-    return SLIMM_OK;
-}
-}  // namespace
-
-int slimm_push_wait(slimm_ctx* c) {
-    if (!c) return SLIMM_E_INVALID;
-    if (!c->copy_pending) return SLIMM_OK;
-    (void)hipSetDevice(c->device);
-    HIP_TRY(c, hipEventSynchronize(c->copy_done));
-    c->copy_pending = false;
-    for (auto& sg : c->staging) sg.pending = false;
-    return SLIMM_OK;
-}
-
-int slimm_staging_buffers(slimm_ctx* c, uint32_t which, uint64_t capacity, uint64_t** key, int32_t** ref, int32_t** pos,
-                          uint16_t** flag) {
-    if (!c || which > 1 || !key || !ref || !pos || !flag) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    (void)hipSetDevice(c->device);
-    slimm_ctx::Staging& sg = c->staging[which];
-    if (sg.pending) {  // the set is being read by a copy: it is the caller's again when that has finished
-        HIP_TRY(c, hipEventSynchronize(sg.done));
-        sg.pending = false;
-    }
-    HIP_TRY(c, sg.key.ensure(capacity));
-    HIP_TRY(c, sg.ref.ensure(capacity));
-    HIP_TRY(c, sg.pos.ensure(capacity));
-    HIP_TRY(c, sg.flag.ensure(capacity));
-    *key = sg.key.p;
-    *ref = sg.ref.p;
-    *pos = sg.pos.p;
-    *flag = sg.flag.p;
-    return SLIMM_OK;
-}
-
-int slimm_push_staged_async(slimm_ctx* c, uint32_t which, uint64_t n) {
-    if (!c || which > 1) return SLIMM_E_INVALID;
-    slimm_ctx::Staging& sg = c->staging[which];
-    if (n > sg.key.cap) return fail(c, SLIMM_E_INVALID, "more records than the staging set holds");
-    if (n == 0) return SLIMM_OK;
-    int rc = slimm_push_records_async(c, sg.key.p, sg.ref.p, sg.pos.p, sg.flag.p, n);
-    if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, hipEventRecord(sg.done, c->copy_stream));
-    sg.pending = true;
-    return SLIMM_OK;
-}
-
-int slimm_push_staged_packed_async(slimm_ctx* c, uint32_t which, uint64_t n) {  // the set's key array holds packed keys
-    if (!c || which > 1) return SLIMM_E_INVALID;
-    slimm_ctx::Staging& sg = c->staging[which];
-    if (n > sg.key.cap) return fail(c, SLIMM_E_INVALID, "more records than the staging set holds");
-    if (n == 0) return SLIMM_OK;
-    int rc = push_packed(c, sg.key.p, sg.ref.p, sg.pos.p, n, true);
-    if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, hipEventRecord(sg.done, c->copy_stream));
-    sg.pending = true;
-    return SLIMM_OK;
-}
-
-int slimm_push_staged_marked_async(slimm_ctx* c, uint32_t which, uint64_t n) {  // the set's ref array holds the words
-    if (!c || which > 1) return SLIMM_E_INVALID;
-    slimm_ctx::Staging& sg = c->staging[which];
-    if (n > sg.key.cap) return fail(c, SLIMM_E_INVALID, "more records than the staging set holds");
-    if (n == 0) return SLIMM_OK;
-    int rc = push_marked(c, reinterpret_cast<const uint32_t*>(sg.ref.p), sg.pos.p, n, true);
-    if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, hipEventRecord(sg.done, c->copy_stream));
-    sg.pending = true;
-    return SLIMM_OK;
-}
-
-int slimm_staging_wait(slimm_ctx* c, uint32_t which) {
-    if (!c || which > 1) return SLIMM_E_INVALID;
-    slimm_ctx::Staging& sg = c->staging[which];
-    if (!sg.pending) return SLIMM_OK;
-    (void)hipSetDevice(c->device);
-    HIP_TRY(c, hipEventSynchronize(sg.done));
-    sg.pending = false;
-    return SLIMM_OK;
-}
-
-int slimm_set_records_device(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos,
-                             const uint16_t* flag, uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
-    if (n && (!key || !ref || !pos || !flag)) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    c->rec = DeviceRecords();  // replaces whatever was pushed or set before, in whatever form
-    c->packed = c->marked = c->has_check = false;
-    c->rec.key = key;
-    c->rec.ref = ref;
-    c->rec.pos = pos;
-    c->rec.flag = flag;
-    c->rec.n = static_cast<uint32_t>(n);
-    c->n_pushed = n;
-    c->borrowed = true;
-    return SLIMM_OK;
-}
-
-int slimm_set_records_device_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
-    if (n && (!key || !ref || !pos)) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    c->rec = DeviceRecords();
-    c->rec.key = key;
-    c->rec.ref = ref;
-    c->rec.pos = pos;
-    c->rec.packed = true;
-    c->rec.n = static_cast<uint32_t>(n);
-    c->n_pushed = n;
-    c->packed = true;
-    c->marked = c->has_check = false;
-    c->borrowed = true;
-    return SLIMM_OK;
-}
-
-int slimm_set_records_device_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, uint64_t n) {
-    if (!c) return SLIMM_E_INVALID;
-    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
-    if (n >= 0x7fffffffull) return fail(c, SLIMM_E_INVALID, "a context handles fewer than 2^31 records; shard the stream");
-    if (n && (!word || !pos)) return fail(c, SLIMM_E_INVALID, "null record array");
-    if (c->analyzed) return fail(c, SLIMM_E_INVALID, "records already analysed; reset first");
-    if (c->order != SLIMM_ORDER_GROUPED)
-        return fail(c, SLIMM_E_INVALID, "run-marked records carry no read identity: the context must be created for input grouped by name");
-    c->rec = DeviceRecords();
-    c->rec.ref = reinterpret_cast<const int32_t*>(word);
-    c->rec.pos = pos;
-    c->rec.marked = true;
-    c->rec.n = static_cast<uint32_t>(n);
-    c->n_pushed = n;
-    c->marked = true;
-    c->packed = c->has_check = false;
-    c->borrowed = true;
     return SLIMM_OK;
 }
 
@@ -2162,8 +951,8 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         ZeroArgs z;
         z.p[0] = c->marks.p;
         z.n[0] = R * (kMarkBytes / 4);  // one byte per (reference, level)
-        z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS
-        z.n[1] = 2;
+        z.p[1] = c->counters.p + CNT_ERR;  // ERR, PAIRS, REDO
+        z.n[1] = 3;
         if (c->use_tiles) {
             z.p[2] = c->tile_count.p;
             z.n[2] = c->treps * c->tstride;
@@ -2212,6 +1001,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         }
         static const bool by_window = getenv("SLIMM_FILTER_BY_WINDOW") != nullptr;   // (round 5's k_filter: A/B runs)
         fa.valid_bits = by_window ? nullptr : c->d_valid_bits.p;
+        fa.redo = c->filter_redo.p;
         fa.sel = c->sel.p;
         fa.slot_rbase = c->slot_rbase.p;
         fa.slot_bbase = c->slot_bbase.p;

@@ -86,6 +86,8 @@ void* symbol(const char* name) {
     }
 SLIMM_FORWARD(int, slimm_create, (const slimm_config* a, slimm_ctx** b), (a, b))
 SLIMM_FORWARD(int, slimm_set_input_size_hint, (slimm_ctx* a, uint64_t b), (a, b))
+SLIMM_FORWARD(int, slimm_device_memory, (slimm_ctx* a, uint64_t* b, uint64_t* c), (a, b, c))
+SLIMM_FORWARD(int, slimm_window_memory, (slimm_ctx* a, uint64_t* b), (a, b))
 SLIMM_FORWARD(void, slimm_destroy, (slimm_ctx* a), (a))
 SLIMM_FORWARD(const char*, slimm_last_error, (const slimm_ctx* a), (a))
 SLIMM_FORWARD(int, slimm_get_cutoff_cache, (slimm_ctx* a, float* b, float* c), (a, b, c))
@@ -419,6 +421,23 @@ struct Trace {
         t = now;
     }
 };
+
+// SLIMM_CLI_TRACE=1: what the file's end holds -- device memory in use (hipMemGetInfo: everything on the device), the window
+// pipeline's share of it, and the process's peak resident set
+void trace_memory(slimm_ctx* ctx) {
+    uint64_t used = 0, total = 0, win = 0;
+    (void)slimm_device_memory(ctx, &used, &total);
+    (void)slimm_window_memory(ctx, &win);
+    long hwm_kb = 0;
+    if (FILE* f = fopen("/proc/self/status", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "VmHWM: %ld kB", &hwm_kb) == 1) break;
+        fclose(f);
+    }
+    fprintf(stderr, "[trace] device memory in use %.2f GB of %.0f GB (window pipeline %.2f GB); host peak resident set %.2f GB\n", used / 1e9,
+            total / 1e9, win / 1e9, hwm_kb / 1e6);
+}
 
 // The record stream of one file, decoded on a thread of its own from the moment the file is open: while the main thread
 // builds the lineage table and creates the context (the HIP runtime's start-up included), batches pile up in host
@@ -996,6 +1015,7 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
             return false;
         }
         trace.mark("phases + exchanges + profile");
+        if (trace.on) trace_memory(c0);
         std::cerr << "[" << watch.lap() << " secs]" << std::endl;
         slimm_stats st;
         slimm_get_stats(c0, &st);
@@ -1159,6 +1179,7 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
     }
     std::cerr << "[" << watch.lap() << " secs]" << std::endl;
     trace.mark("filter + LCA + outputs");
+    if (trace.on) trace_memory(ctx);
     std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
     CHECK(ctx, slimm_get_cutoff_cache(ctx, &S.cc_cache, &S.ucc_cache));
     if (file_index + 1 == S.input_paths.size() && S.finale) {

@@ -24,7 +24,8 @@ enum {
     CNT_P = 2,      // distinct (read, ref) pairs = targets
     CNT_ERR = 3,    // ERR_* bits
     CNT_PAIRS = 4,  // entries of the no-level-agrees (taxon, ref) set
-    CNT_ITEMS = 5,  // work items of k_tile_hist
+    CNT_REDO = 5,   // slots k_filter_compact left to k_filter_walk (a read with 64 valid targets or more)
+    CNT_ITEMS = 10, // work items of k_tile_hist
     CNT_ITEMS2 = 6, // work items of k_part_tile
     CNT_ANYGB = 8,  // some record follows a record of the same qName run with a larger mate number (mates interleave)
     CNT_MODE = 7,   // classification picked on the device: 0 = look-back walk, 2 = tagged-word walk (both k_runs), 1 = hash table (k_runs_hash)
@@ -159,6 +160,7 @@ struct FilterArgs {
     const uint32_t* lin_dense = nullptr;
     const uint8_t* valid = nullptr;
     const uint32_t* valid_bits = nullptr;    // one bit per reference: k_filter_compact (nullptr: k_filter, window by window)
+    uint32_t* redo = nullptr;                // ... and the slots it leaves to k_filter_walk (nslots words; their number: counters[CNT_REDO])
     uint32_t* sel = nullptr;                 // one selector per read, dense: slot s writes at slot_rbase[s] + slot_bbase[s >> 10]
     const uint32_t* slot_rbase = nullptr;    // (launch_slot_read_prefix)
     const uint32_t* slot_bbase = nullptr;

@@ -158,3 +158,67 @@ def test_files_back_to_back_through_two_engines_per_rank():
     port = 29500 + (os.getpid() % 2000) + 33
     with tempfile.TemporaryDirectory() as tmp:
         mp.spawn(_worker_back_to_back, args=(2, port, tmp), nprocs=2, join=True)
+
+
+def _unequal_split(w, world):
+    """Shards of very unequal size with one EMPTY rank: reads go to rank (key mod 61) mod world', where world' skips rank
+    world - 3 altogether and ranks get 1, 2, 3 ... shares -- the shapes an 8-GPU run meets when a file's reads are few."""
+    from slimm_amd.workload import Workload
+
+    empty = world - 3
+    live = [r for r in range(world) if r != empty]
+    shares = np.repeat(np.arange(len(live)), np.arange(1, len(live) + 1))      # rank k of `live` owns k + 1 shares
+    owner = np.array(live, dtype=np.int64)[shares[(w.records.read_key % np.uint64(len(shares))).astype(np.int64)]]
+    out = []
+    for r in range(world):
+        idx = np.nonzero(owner == r)[0]
+        out.append(Workload(w.ref_names, w.ref_len, w.taxonomy, w.records.take(idx), w.avg_read_len, w.options, f"{w.name}-u{r}"))
+    assert len(out[empty].records) == 0 and len({len(s.records) for s in out}) == world
+    return out
+
+
+def _worker_eight(rank, world, port, tmp, exchange, cuts):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.binding import run_workload
+        from slimm_amd.distributed import sharded_profile
+        from slimm_amd.partition import chunk_owner, shard_records
+        from slimm_amd.synth import CONFIGS, make_workload
+        from slimm_amd.workload import Workload
+        from tests.helpers import assert_matches_oracle
+        from tests.shard_engine import OracleShardEngine
+
+        w = make_workload(CONFIGS["config2"], seed=29, n_records=120_000)
+        if cuts == "contiguous":
+            rec, still_grouped = shard_records(w.records, rank, world, grouped=True)
+            assert still_grouped
+            shard = Workload(w.ref_names, w.ref_len, w.taxonomy, rec, w.avg_read_len, w.options, f"{w.name}-cut{rank}")
+        else:
+            shard = _unequal_split(w, world)[rank]
+        eng = OracleShardEngine(shard)
+        text = sharded_profile(eng, None, os.path.join(tmp, "profile.tsv"), exchange=exchange)
+        whole = run_workload(w, use_qnames=False, collect_bins=False)
+        assert text is not None
+        assert_matches_oracle(eng.host, whole, bins=False)
+        if rank == 0:
+            assert open(os.path.join(tmp, "profile.tsv")).read() == text
+            # bench.py's chunk ownership at this world size: 100 chunks over 8 ranks = 12 or 13 each, all of them, in order
+            own = chunk_owner(100, world)
+            assert [len(o) for o in own] == [12, 13, 12, 13, 12, 13, 12, 13] and [c for o in own for c in o] == list(range(100))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,cuts", [("auto", "unequal"), ("sliced", "contiguous"), ("summary", "unequal"), ("bins", "unequal")])
+def test_eight_ranks_unequal_shards_and_an_empty_rank(exchange, cuts):
+    """The world size the driver's node has: eight ranks through the real driver code over gloo -- the
+    all-to-all of EIGHT bitmap slices ("auto" above two ranks), the all-gather and the bins all-reduce --, with shards of
+    eight different sizes of which one is EMPTY (a rank without a single record still takes part in every collective), and
+    on the partitioner's contiguous cuts."""
+    port = 29500 + (os.getpid() % 2000) + 40 + {"auto": 0, "sliced": 1, "summary": 2, "bins": 3}[exchange]
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker_eight, args=(8, port, tmp, exchange, cuts), nprocs=8, join=True)

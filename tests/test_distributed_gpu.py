@@ -159,3 +159,26 @@ def test_bench_launches_its_own_ranks():
     assert sp["kernels_ms"] > 0 and sp["collectives_ms"] > 0 and set(sp["collectives"]) == {"all_gather", "all_reduce"}
     xb = many["exchange_bins"]
     assert xb["same_profile"] is True and xb["value"] > 0 and xb["all_reduce_bytes"] > 0
+
+
+def test_eight_processes_with_real_engines_on_one_gpu():
+    """The world size of the driver's node: eight OS processes with real engines on cuda:0, "auto" = the all-to-all of eight
+    bitmap slices + the small all-reduce, on contiguous cuts of the grouped file."""
+    _spawn(8, "config2", "auto", "contiguous")
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 8 --backend gloo --quick --records 40000000`: what the driver's
+    8-GPU node runs, rehearsed with every rank on cuda:0 -- chunk ownership 16 chunks / 8 ranks, `sliced` with eight
+    slices, `step_split`, `exchange_bins` -- and the same job as the N = 1 line."""
+    common = ["--records", "40000000", "--chunk-records", "2500000", "--steps", "2", "--warmup", "1", "--quick"]
+    one = _bench(common)
+    many = _bench(["--gpus", "8", "--backend", "gloo"] + common)       # (bench.py starts its own ranks)
+    assert many["n_gpus"] == 8 and many["config"]["process_group_ranks"] == 8 and many["config"]["exchange"] == "sliced"
+    assert many["config"]["total_records"] == one["config"]["total_records"] == 40_000_000
+    for k in ("reads", "targets", "bins", "profile_rows", "profile_sha1"):
+        assert many["config"][k] == one["config"][k], k
+    sp = many["step_split"]
+    assert sp["kernels_ms"] > 0 and sp["collectives_ms"] > 0
+    assert many["exchange_bins"]["same_profile"] is True
+    print("N=8 rehearsal step_split:", json.dumps(sp))

@@ -206,7 +206,8 @@ def test_window_buffers_are_sized_by_the_file(tmp_path):
         assert s.push_bgzf_blocks(blocks, skip=skip, window=0) == len(rec)
         assert_matches_oracle(s, o) if s.get_profiles() is not None else None
         s.close()
-    assert all(h < (1 << 30) for h in held), held          # a file of a few megabytes holds far less than a gigabyte
+    # a file of a few megabytes holds far less than a gigabyte, told or not; a caller that overstates gets what it asked for
+    assert held[0] < (1 << 29) and held[1] < (1 << 29) and held[2] >= held[1], held
 
 
 def test_a_skip_larger_than_the_window_slack(tmp_path):

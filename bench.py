@@ -940,12 +940,12 @@ def main():
             db = os.path.join(tmp, "db.sldb")
             write_sldb(db, w_cli.taxonomy)
             os.makedirs(os.path.join(tmp, "out"))
-            def run_cli(path, stem, env=None):
+            def run_cli(path, stem, flags=()):
                 runs, r = [], None
                 for _ in range(2):
                     t1 = time.perf_counter()
-                    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/",
-                                        db, path], capture_output=True, text=True, env=dict(os.environ, SLIMM_CLI_TRACE="1", **(env or {})))
+                    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), *flags, "-w", "1000", "-o", os.path.join(tmp, "out") + "/",
+                                        db, path], capture_output=True, text=True, env=dict(os.environ, SLIMM_TRACE="cli"))
                     runs.append(time.perf_counter() - t1)
                     if r.returncode != 0:
                         return None, r, None
@@ -974,11 +974,11 @@ def main():
                                   "(0.1 - 0.3 s, in `start_up`) runs beside the first reads"},
                        "reader": tr, "device_decode": dd, "start_up": su, "bam_built_in_s": round(info["seconds"], 1)}
                 # the same file with every window inflated by the host cores (rounds 1 - 4's path)
-                best_h, rh, prof_h = run_cli(bam, "sample", env={"SLIMM_CLI_DEVICE_INFLATE": "0"})
+                best_h, rh, prof_h = run_cli(bam, "sample", flags=("--device-inflate", "0"))
                 if best_h is not None:
                     _, ddh, _ = traces(rh)
                     cli["host_inflate"] = {"value": round(nb / best_h / 1e6, 3), "unit": "M records/s", "seconds": round(best_h, 3),
-                                           "what": "SLIMM_CLI_DEVICE_INFLATE=0: BGZF inflate by libdeflate on the host cores, inflated "
+                                           "what": "--device-inflate 0: BGZF inflate by libdeflate on the host cores, inflated "
                                                    "windows over PCIe", "same_profile": bool(prof_h == prof_g), "device_decode": ddh}
                 # the same records in NO particular order (header without GO:query): name hash + check word on the device,
                 # then the device-side grouping of record_order = ANY
@@ -1028,12 +1028,12 @@ def main():
                                            "same_profile_as_the_bam": bool(prof_s == prof_g), "device_decode": dds,
                                            "sam_built_in_s": round(info_s["seconds"], 1)}
                         t1 = time.perf_counter()
-                        rh2 = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, sam],
-                                             capture_output=True, text=True, env=dict(os.environ, SLIMM_CLI_HOST_DECODE="1"))
+                        rh2 = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "--host-decode", "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, sam],
+                                             capture_output=True, text=True)
                         if rh2.returncode == 0:
                             sec_h = time.perf_counter() - t1
                             cli["sam_text"]["host_decoder"] = {"value": round(nb / sec_h / 1e6, 3), "seconds": round(sec_h, 3),
-                                                               "what": "SLIMM_CLI_HOST_DECODE=1 (rounds 1 - 4's SAM path), one run"}
+                                                               "what": "--host-decode (rounds 1 - 4's SAM path), one run"}
                     else:
                         cli["sam_text"] = {"error": rs.stderr[-400:]}
                     os.unlink(sam)

@@ -134,7 +134,7 @@ int slimm_set_min_reads(slimm_ctx* ctx, uint32_t min_reads);
  * records are pushed it counts, on the device, the qName runs whose identity started an earlier run as well (0 = the
  * stream is grouped).  It costs a hash-set insert per run -- the set is a power of two of 8-byte entries at or above
  * twice the number of records: 16 to 32 bytes of device memory per record, up to 32 GiB near 2^31 records -- and is
- * therefore never run unasked; the slimm command runs it with SLIMM_VERIFY_GROUPING=1 and warns.  Packed records are
+ * therefore never run unasked; the slimm command runs it with --verify-grouping and warns.  Packed records are
  * compared by the 61 identity bits they carry (the four-array form: 62). */
 int slimm_check_grouping(slimm_ctx* ctx, uint64_t* n_split_names);
 int slimm_reserve(slimm_ctx* ctx, uint64_t n_records);

@@ -84,7 +84,7 @@ try:
         for rep in range(2):
             t0 = time.time()
             r = subprocess.run([cli] + extra + ["-w", "1000", "-o", out + "/", db, bam], capture_output=True, text=True,
-                               env=dict(os.environ, SLIMM_CLI_TRACE="1"))
+                               env=dict(os.environ, SLIMM_TRACE="cli"))
             dt_ = time.time() - t0
             if r.returncode != 0:
                 print(f"   {label}: FAILED rc {r.returncode}: {r.stderr[-600:]}", flush=True)

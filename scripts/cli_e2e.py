@@ -20,11 +20,10 @@ db = os.path.join(tmp, "db.sldb"); write_sldb(db, w.taxonomy)
 cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "slimm_amd", "slimm")
 os.makedirs(os.path.join(tmp, "out"))
 for threads in (0, 16, 32, 64):   # 0 = the command's own choice (logical CPUs or twice the cgroup quota, at most 64)
-    env = dict(os.environ, SLIMM_CLI_TRACE="1")
-    if threads:
-        env["SLIMM_DECODE_THREADS"] = str(threads)
+    env = dict(os.environ, SLIMM_TRACE="cli")
+    flags = ["--decode-threads", str(threads)] if threads else []
     t0 = time.time()
-    r = subprocess.run([cli, "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True, env=env)
+    r = subprocess.run([cli] + flags + ["-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True, env=env)
     dt_ = time.time() - t0
     assert r.returncode == 0, r.stderr[-1000:]
     print("\n".join(l[l.index("[trace]"):] for l in r.stderr.splitlines() if "[trace]" in l))

@@ -19,5 +19,5 @@ print(write_synthetic_bam("/tmp/slimm_prof/realistic.bam", w.ref_names, w.ref_le
 PY
 ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats -d "$OUT" -o cli -- ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam > "$OUT.log" 2>&1 || true
-SLIMM_CLI_TRACE=1 ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam 2>&1 | grep trace | cut -c1-300
+SLIMM_TRACE=cli ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam 2>&1 | grep trace | cut -c1-300
 rm -rf /tmp/slimm_prof

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SLIMM_PUSH_TRACE of `slimm DB realistic.bam`: the window pipeline's events with their times
+# SLIMM_TRACE=push of `slimm DB realistic.bam`: the window pipeline's events with their times
 set -e
 N=${1:-100000000}
 cd "$GRAFT_REPO_ROOT"
@@ -16,5 +16,5 @@ write_sldb("/tmp/slimm_prof/db.sldb", w.taxonomy)
 write_synthetic_bam("/tmp/slimm_prof/realistic.bam", w.ref_names, w.ref_len, w.records, read_len=100, realistic=True)
 PY
 ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam > /dev/null 2>&1
-SLIMM_PUSH_TRACE=1 SLIMM_CLI_TRACE=1 ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam 2>&1 | grep -E "\[push|trace\] device|reached" | cut -c1-200
+SLIMM_TRACE=cli,push ./slimm_amd/slimm -w 1000 -o /tmp/slimm_prof/out/ /tmp/slimm_prof/db.sldb /tmp/slimm_prof/realistic.bam 2>&1 | grep -E "\[push|trace\] device|reached" | cut -c1-200
 rm -rf /tmp/slimm_prof

@@ -16,7 +16,7 @@ for rep in 1 2 3 4; do
 for v in "$@"; do
   lib=$PWD/slimm_amd/libslimm_hip.so; [ "$v" != base ] && lib=$PWD/build/var/$v/libslimm_hip.so
   s=$(date +%s%N)
-  SLIMM_HIP_LIB=$lib SLIMM_CLI_TRACE=1 ./slimm_amd/slimm -w 1000 -o /tmp/slimm_var/out/ /tmp/slimm_var/db.sldb /tmp/slimm_var/realistic.bam 2> /tmp/slimm_var/err.txt > /dev/null
+  SLIMM_HIP_LIB=$lib SLIMM_TRACE=cli ./slimm_amd/slimm -w 1000 -o /tmp/slimm_var/out/ /tmp/slimm_var/db.sldb /tmp/slimm_var/realistic.bam 2> /tmp/slimm_var/err.txt > /dev/null
   e=$(date +%s%N)
   echo "$v: $(( (e - s) / 1000000 )) ms; $(grep -o 'slimm_push_bam_bytes [0-9.]* ms' /tmp/slimm_var/err.txt | head -1); $(grep -o 'slimm_create *[0-9.]* ms' /tmp/slimm_var/err.txt)"
 done; done

@@ -3,8 +3,8 @@
 #   scripts/group_bits.sh TAG config2 "24:8 18:9 20:10 16:8 22:11"
 TAG=${1:-bits}; C=${2:-config2}; PLANS=${3:-"24:8 18:9 20:10"}
 O=gpurun_out/$TAG; mkdir -p $O
-for p in $PLANS; do b=${p%%:*}; rest=${p#*:}; w=${rest%%:*}; export SLIMM_GROUP_PASSES=0; case $rest in *:*) export SLIMM_GROUP_PASSES=${rest##*:};; esac
-  SLIMM_GROUP_BITS=$b SLIMM_GROUP_WIDTH=$w python3 bench.py --quick --engines 1 --config $C --record-order any --breakdown --steps 10 --warmup 3 \
+for p in $PLANS; do b=${p%%:*}; rest=${p#*:}; w=${rest%%:*}; P=0; case $rest in *:*) P=${rest##*:};; esac
+  SLIMM_FORCE=group_bits=$b,group_width=$w,group_passes=$P python3 bench.py --quick --engines 1 --config $C --record-order any --breakdown --steps 10 --warmup 3 \
       > $O/${C}_b${b}_w${w}.json 2> $O/${C}_b${b}_w${w}.txt
   python3 - <<PY
 import json

@@ -4,7 +4,7 @@
 TAG=${1:-group}; CONFIGS=${2:-config2}; WIDTHS=${3:-"8 11"}; GRIDS=${4:-"512"}
 O=gpurun_out/$TAG; mkdir -p $O
 for c in $CONFIGS; do for w in $WIDTHS; do for g in $GRIDS; do
-  SLIMM_GROUP_WIDTH=$w SLIMM_GROUP_GRID=$g python3 bench.py --quick --config $c --record-order any --breakdown --steps 10 --warmup 3 \
+  SLIMM_FORCE=group_width=$w,group_grid=$g python3 bench.py --quick --config $c --record-order any --breakdown --steps 10 --warmup 3 \
       > $O/${c}_w${w}_g${g}.json 2> $O/${c}_w${w}_g${g}.txt
   python3 - <<PY
 import json

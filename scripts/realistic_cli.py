@@ -2,7 +2,7 @@
 random bases, binned qualities with runs, instrument-style names; libdeflate level 6) beside the easy 17-fold file.
     python scripts/realistic_cli.py [records] [easy|realistic|both] [inflate_blocks]
 Prints: the file's compression ratio, `slimm DB IN.bam` process start to profile written with its stage trace (default
-settings, and with every window inflated on the host: SLIMM_CLI_DEVICE_INFLATE=0), the device inflate's rate on the file's
+settings, and with every window inflated on the host: --device-inflate 0), the device inflate's rate on the file's
 first `inflate_blocks` BGZF blocks (slimm_bgzf_inflate: kernel time from HIP events), and the host's inflate rate on the same
 blocks with the cores this process may use (zlib in threads)."""
 import ctypes as C, os, subprocess, sys, tempfile, time, zlib
@@ -30,12 +30,12 @@ for kind in (("easy", "realistic") if which == "both" else (which,)):
     info = write_synthetic_bam(bam, w.ref_names, w.ref_len, w.records, read_len=100, realistic=(kind == "realistic"))
     print(f"== {kind}: {n} records, {info['raw_bytes'] / 1e9:.2f} GB of BAM in {info['compressed_bytes'] / 1e9:.2f} GB = "
           f"{info['raw_bytes'] / info['compressed_bytes']:.2f} x ({info['deflate']}), built in {info['seconds']:.0f} s", flush=True)
-    for label, env in (("default", {}), ("host inflate only", {"SLIMM_CLI_DEVICE_INFLATE": "0"}), ("device inflate only", {"SLIMM_CLI_DEVICE_INFLATE": "1"})):
+    for label, flags in (("default", []), ("host inflate only", ["--device-inflate", "0"])):
         best, tr = None, ""
         for _ in range(2):
             t0 = time.time()
-            r = subprocess.run([cli, "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
-                               env=dict(os.environ, SLIMM_CLI_TRACE="1", **env))
+            r = subprocess.run([cli] + flags + ["-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
+                               env=dict(os.environ, SLIMM_TRACE="cli"))
             dt_ = time.time() - t0
             if r.returncode != 0:
                 print(f"   {label}: FAILED {r.stderr[-300:]}")

@@ -1,5 +1,5 @@
 """`slimm DB IN.sam` on a synthetic SAM file (slimm_amd/synth_bam.py: write_synthetic_sam), the lines found and parsed on the
-device (slimm_push_sam_bytes) against the host decoder (SLIMM_CLI_HOST_DECODE=1).  python scripts/sam_cli.py [records]"""
+device (slimm_push_sam_bytes) against the host decoder (--host-decode).  python scripts/sam_cli.py [records]"""
 import os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,13 +16,13 @@ info = write_synthetic_sam(sam, w.ref_names, w.ref_len, w.records)
 print(f"SAM: {n} records, {info['bytes'] / 1e9:.2f} GB, built in {info['seconds']:.0f} s", flush=True)
 cli = os.path.join(ROOT, "slimm_amd", "slimm")
 outs = {}
-for label, env in (("device decode", {}), ("host decode", {"SLIMM_CLI_HOST_DECODE": "1"})):
+for label, flags in (("device decode", []), ("host decode", ["--host-decode"])):
     os.makedirs(os.path.join(tmp, label.split()[0]), exist_ok=True)
     best, tr = None, ""
     for _ in range(2 if label.startswith("device") else 1):
         t0 = time.time()
-        r = subprocess.run([cli, "-w", "1000", "-o", os.path.join(tmp, label.split()[0]) + "/", db, sam], capture_output=True, text=True,
-                           env=dict(os.environ, SLIMM_CLI_TRACE="1", **env))
+        r = subprocess.run([cli] + flags + ["-w", "1000", "-o", os.path.join(tmp, label.split()[0]) + "/", db, sam], capture_output=True, text=True,
+                           env=dict(os.environ, SLIMM_TRACE="cli"))
         dt_ = time.time() - t0
         assert r.returncode == 0, r.stderr[-1500:]
         if best is None or dt_ < best:

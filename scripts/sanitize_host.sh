@@ -49,12 +49,12 @@ files += [f"{d}/trunc.bam", f"{d}/flip.bam", f"{d}/short.sldb", f"{d}/garbage.sa
 bad = 0
 for thr in ("1", "8"):
     r = subprocess.run([f"{d}/san_readers"] + files, capture_output=True, text=True,
-                       env=dict(os.environ, SLIMM_DECODE_THREADS=thr))
+                       env=dict(os.environ, SAN_READER_THREADS=thr))
     print(r.stdout)
     if r.returncode or r.stderr.strip():
         bad += 1; print("SANITIZER OUTPUT:\n" + r.stderr)
 r = subprocess.run([f"{d}/tsan_readers", f"{d}/c3.bam", f"{d}/c4.bam", f"{d}/c2.bam", f"{d}/trunc.bam"], capture_output=True, text=True,
-                   env=dict(os.environ, SLIMM_DECODE_THREADS="8"))
+                   env=dict(os.environ, SAN_READER_THREADS="8"))
 print(r.stdout)
 if r.returncode or r.stderr.strip():
     bad += 1; print("THREAD SANITIZER OUTPUT:\n" + r.stderr)
@@ -93,10 +93,10 @@ print("slimm_build under sanitizers: done")
 # command dlopen()s what SLIMM_HIP_LIB names).  Skipped when that library has not been built (make -C tests/native).
 emu = os.path.join(os.getcwd(), "tests", "native", "libslimm_emu.so")
 if os.path.exists(emu) and os.path.exists(f"{d}/tsan_slimm"):
-    for extra in ({"SLIMM_CLI_WINDOW_MB": "1"}, {"SLIMM_CLI_WINDOW_MB": "3", "SLIMM_NO_MMAP": "1"}, {"SLIMM_CLI_HOST_DECODE": "1"}):
+    for extra in (["--window-mb", "1"], ["--window-mb", "3", "--no-mmap"], ["--host-decode"]):
         for inp in ("c3.bam", "c2.sam"):
-            r = subprocess.run([f"{d}/tsan_slimm", "-w", "1000", "-o", f"{d}/cli_", f"{d}/{inp[:2]}.sldb", f"{d}/{inp}"], capture_output=True,
-                               text=True, errors="replace", env=dict(os.environ, SLIMM_HIP_LIB=emu, **extra))
+            r = subprocess.run([f"{d}/tsan_slimm"] + extra + ["-w", "1000", "-o", f"{d}/cli_", f"{d}/{inp[:2]}.sldb", f"{d}/{inp}"], capture_output=True,
+                               text=True, errors="replace", env=dict(os.environ, SLIMM_HIP_LIB=emu))
             if r.returncode or "ThreadSanitizer" in r.stderr:
                 bad += 1; print("SANITIZER OUTPUT (slimm under TSan):\n" + r.stderr[-4000:])
     print("slimm (command, emulated device) under ThreadSanitizer: done")

@@ -8,6 +8,6 @@ for v in base "$@"; do
   python bench.py --config config3 --quick --breakdown --steps 10 2>&1 >/dev/null | grep -E "^# (k_tile_scat|device)"
 done
 unset SLIMM_HIP_LIB
-echo "== config 3, SLIMM_MATRIX=0 (phase B through the rounds)"
-SLIMM_MATRIX=0 python bench.py --config config3 --quick --breakdown --steps 10 2>&1 >/dev/null | grep -E "^# (k_tile_(scat|count2)|k_matrix|device)"
+echo "== config 3, SLIMM_FORCE=matrix=0 (phase B through the rounds)"
+SLIMM_FORCE=matrix=0 python bench.py --config config3 --quick --breakdown --steps 10 2>&1 >/dev/null | grep -E "^# (k_tile_(scat|count2)|k_matrix|device)"
 python bench.py --config config5 --quick --breakdown --steps 10 2>&1 >/dev/null | grep -E "^# (k_tile_scat|device)"

@@ -31,9 +31,9 @@ for seed in range(first, first + rounds):
     newpos[by_file] = place[by_place]
     order = np.argsort(newpos)
     sh = Records(r.read_key[order], r.flag[order], r.ref_id[order], r.begin_pos[order])
-    knobs = {"SLIMM_GROUP_BITS": int(rng.integers(14, 27)), "SLIMM_GROUP_WIDTH": int(rng.integers(5, 12)),
-             "SLIMM_GROUP_GRID": int(rng.choice([64, 509, 512])), "SLIMM_GROUP_STAGED": int(rng.integers(0, 2))} if seed % 4 else {}
-    for k, v in knobs.items(): os.environ[k] = str(v)
+    knobs = {"group_bits": int(rng.integers(14, 27)), "group_width": int(rng.integers(5, 12)),
+             "group_grid": int(rng.choice([64, 509, 512])), "group_staged": int(rng.integers(0, 2))} if seed % 4 else {}
+    os.environ["SLIMM_FORCE"] = ",".join(f"{k}={v}" for k, v in knobs.items())   # (slimm_amd/csrc/force.h)
     t0 = time.time()
     try:
         wa = Workload(w.ref_names, w.ref_len, w.taxonomy, sh, w.avg_read_len, w.options, "any", grouped=False)
@@ -50,7 +50,7 @@ for seed in range(first, first + rounds):
     except Exception as e:
         fails += 1
         print("FAIL any seed", seed, cfg, n, knobs, str(e)[:300].replace("\n", " | "), flush=True)
-    for k in knobs: del os.environ[k]
+    os.environ.pop("SLIMM_FORCE", None)
     # the device BAM decoder on the grouped file (names compared on the device), windows of a random size
     try:
         names = ["r%x" % k for k in r.read_key.tolist()]

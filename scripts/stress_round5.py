@@ -1,7 +1,7 @@
 """Stress of round 5's bucket scatter (k_tile_scatter_big: rounds ordered by tile in LDS, one table word per tile) against the
 all-core dense restatement, randomised: files of 3 - 40 M records over random layouts -- reference counts, lengths and bin
 widths chosen so that the tile count falls on either side of the 4064 / 6144 limits --, random hits per read, grouped or in any
-order, under random bucketing switches (SLIMM_FUSED_SCAN, SLIMM_SCATTER_BIG, SLIMM_MATRIX, SLIMM_TILE_SHIFT, SLIMM_WIDE_TILES).
+order, under random bucketing switches (SLIMM_FORCE: fused_scan, scatter_big, matrix, tile_shift, wide_tiles).
 Files of this size give a workgroup several rounds, partial last rounds and slots of every fill.
     python scripts/stress_round5.py [seeds] [first seed]         (GPU box)
 Prints the failures and their count."""
@@ -25,16 +25,15 @@ for seed in range(first, first + n_seeds):
     cfg = SynthConfig(f"s{seed}", n, refs, float(rng.choice([1.5, 4.0, 9.0, 25.0])), bin_width=width, len_lo=lo, len_hi=hi,
                       present_frac=float(rng.choice([0.02, 0.2, 0.8])), strain_level=bool(rng.integers(0, 2)))
     knobs = {}
-    if rng.integers(0, 2): knobs["SLIMM_FUSED_SCAN"] = "0"
-    if rng.integers(0, 3) == 0: knobs["SLIMM_SCATTER_BIG"] = "0"
-    if rng.integers(0, 2): knobs["SLIMM_MATRIX"] = str(rng.choice(["0", "2"]))
-    if rng.integers(0, 2): knobs["SLIMM_TILE_SHIFT"] = str(rng.choice(["13", "14"]))
-    if rng.integers(0, 4) == 0: knobs["SLIMM_WIDE_TILES"] = "1"
+    if rng.integers(0, 2): knobs["fused_scan"] = "0"
+    if rng.integers(0, 3) == 0: knobs["scatter_big"] = "0"
+    if rng.integers(0, 2): knobs["matrix"] = str(rng.choice(["0", "2"]))
+    if rng.integers(0, 2): knobs["tile_shift"] = str(rng.choice(["13", "14"]))
+    if rng.integers(0, 4) == 0: knobs["wide_tiles"] = "1"
     grouped = bool(rng.integers(0, 4))
     t0 = time.time()
     w = make_workload(cfg, seed=seed)
-    for k, v in knobs.items():
-        os.environ[k] = v
+    os.environ["SLIMM_FORCE"] = ",".join(f"{k}={v}" for k, v in knobs.items())   # (slimm_amd/csrc/force.h)
     try:
         d = dense_mt_run(w, want_bins=True)
         s = Slimm.for_workload(w, device=0, grouped=grouped)
@@ -48,7 +47,6 @@ for seed in range(first, first + n_seeds):
     except Exception as e:
         fails += 1
         print("FAIL seed", seed, cfg, knobs, "grouped", grouped, str(e)[:300].replace("\n", " | "), flush=True)
-    for k in knobs:
-        del os.environ[k]
+    os.environ.pop("SLIMM_FORCE", None)
     del w
 print("fails", fails, "of", n_seeds)

@@ -11,7 +11,7 @@ from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, make_workload
 w = make_workload(CONFIGS["config3"], seed=1, n_records=100_000)
 import os
-os.environ["SLIMM_HOST_TRACE"] = "1"
+os.environ["SLIMM_TRACE"] = "host"
 for i in range(3):
     t3 = time.time()
     s = Slimm.for_workload(w, device=0)

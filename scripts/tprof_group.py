@@ -1,6 +1,6 @@
 """Cycle split of the any-order grouping's scatter passes (k_gb_scatter, staged form), from a build with the counters compiled in:
     scripts/build_variant.sh gprof '1s/^/#define EXP 10\\n/'
-    SLIMM_HIP_LIB=build/var/gprof/libslimm_hip.so [SLIMM_GROUP_WIDTH=10] python scripts/tprof_group.py [config]
+    SLIMM_HIP_LIB=build/var/gprof/libslimm_hip.so [SLIMM_FORCE=group_width=10] python scripts/tprof_group.py [config]
 Prints the mean cycles thread 0 of a workgroup spent per phase of a round, summed over the rounds of the three passes."""
 import ctypes, os, sys
 import numpy as np

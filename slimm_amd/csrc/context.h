@@ -19,6 +19,7 @@
 
 #include "../../include/slimm_hip.h"
 #include "host_profile.hpp"
+#include "force.h"
 #include "kernels.h"
 #include "read_identity.h"
 
@@ -237,7 +238,7 @@ struct slimm_ctx {
     bool two_level = false;   // bucket through super tiles first (many tiles: one-level scatter stores are too scattered)
     bool matrix = false;      // phase B may bucket through a count matrix (one row per counting workgroup, no atomics)
     bool matrix_always = false;
-    int wide_tiles = -1;      // SLIMM_WIDE_TILES: -1 = by the file's size, 0 / 1 = never / always (tests)
+    int wide_tiles = -1;      // SLIMM_FORCE wide_tiles: -1 = by the file's size, 0 / 1 = never / always (tests)
     // far more entries per tile than a packed work item holds (1 B records on 20 k references): work items of up to
     // kTileSubWide entries with 32-bit counts, so that a tile is one item again (kernels.h)
     bool wide_for(uint32_t n_records) const {
@@ -311,13 +312,13 @@ struct slimm_ctx {
 
 namespace slimm {
 
-// SLIMM_HOST_TRACE=1: wall-clock marks of the host steps between the two device phases, on stderr
+// SLIMM_TRACE=host: wall-clock marks of the host steps between the two device phases, on stderr
 struct HostTrace {
     bool on;
     std::chrono::steady_clock::time_point t0;
     const char* what;
     explicit HostTrace(const char* w) : on(false), what(w) {
-        static const bool enabled = getenv("SLIMM_HOST_TRACE") != nullptr;
+        static const bool enabled = traced("host");
         on = enabled;
         if (on) t0 = std::chrono::steady_clock::now();
     }

@@ -170,8 +170,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
     // into per-taxon ones (kernels.h: PackArgs::sum_k).  No taxon look-up, one dependent round trip less, on k_filter's
     // path.  With the 32-byte rows the selector is the dense taxon itself.
     {
-        const char* wide_rows = getenv("SLIMM_WIDE_ROWS");
-        c->use_rows16 = c->host->rows16_ok() && !(wide_rows && wide_rows[0] == '1');
+        c->use_rows16 = c->host->rows16_ok() && !forced("wide_rows");
         c->Tsel = c->T;
         if (c->use_rows16) {
             const uint32_t* loff = c->host->level_offset();
@@ -190,9 +189,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         const uint64_t small = (off + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall;
         const uint64_t small2 = small + ((static_cast<uint64_t>(c->Tsel) + (1ull << kTileShiftSmall) - 1) >> kTileShiftSmall);
         c->tile_shift = small2 > kFusedScanTiles ? kTileShiftLarge : kTileShiftSmall;
-        if (const char* ts = getenv("SLIMM_TILE_SHIFT")) {
-            if (atoi(ts) == static_cast<int>(kTileShiftSmall)) c->tile_shift = kTileShiftSmall;
-            if (atoi(ts) == static_cast<int>(kTileShiftLarge)) c->tile_shift = kTileShiftLarge;
+        long ts = 0;
+        if (forced("tile_shift", &ts)) {
+            if (ts == static_cast<long>(kTileShiftSmall)) c->tile_shift = kTileShiftSmall;
+            if (ts == static_cast<long>(kTileShiftLarge)) c->tile_shift = kTileShiftLarge;
         }
     }
     const uint32_t tile_bins = c->tile_bins();
@@ -284,8 +284,7 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 return fail(nullptr, SLIMM_E_HIP, "out of device memory for lineage rows");
         }
         trc.mark("tables to the device");
-        const char* force_direct = getenv("SLIMM_DIRECT_ATOMICS");
-        cc->use_tiles = !(force_direct && force_direct[0] == '1') && TILES(c->tile_shift, tile_hist_setup(c->ntiles2)) == 0;
+        cc->use_tiles = !forced("direct_atomics") && TILES(c->tile_shift, tile_hist_setup(c->ntiles2)) == 0;
         if (cc->order == SLIMM_ORDER_ANY && group_init() != 0) {
             *out = nullptr;
             return fail(nullptr, SLIMM_E_HIP, "group_init: hipFuncSetAttribute failed");
@@ -294,15 +293,16 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         {
             // default by size: with the register-resident scatter chunks one level wins up to ~10 K tiles (config 3:
             // 494 vs 601 us) and is level with two at 24 K (config 5: 430 vs 396 us)
-            const char* tl = getenv("SLIMM_TWO_LEVEL");
-            cc->two_level = tl ? (tl[0] == '1') : (c->ntiles2 > 16384);
+            long tl = 0;
+            cc->two_level = forced("two_level", &tl) ? tl == 1 : (c->ntiles2 > 16384);
         }
         if (cc->use_tiles) {
             cc->treps = (cc->two_level || c->ntiles2 > 16384) ? 1u : kTileReps;  // (k_tile_scan stages the copies of <= 16 K tiles)
             cc->tstride = c->ntiles2 + 1;
             {
-                const char* fs = getenv("SLIMM_FUSED_SCAN");
-                cc->fused_scan = !cc->two_level && cc->treps == kTileReps && c->ntiles2 <= kFusedScanTiles && !(fs && fs[0] == '0');
+                long fs = 1;
+                (void)forced("fused_scan", &fs);
+                cc->fused_scan = !cc->two_level && cc->treps == kTileReps && c->ntiles2 <= kFusedScanTiles && fs != 0;
             }
             {
                 // Layouts beyond the fused kernel's 4064 tiles, PHASE B only, when a tile gets few selectors (decided per
@@ -313,13 +313,15 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
                 // written lines at config 3 -- turn every 2-byte store into a partial-line write: measured 834 vs 362 us.)
                 // Since round 5 only beyond kBigRoundTiles tiles: up to there the rounds ordered by tile in LDS
                 // (k_tile_scatter_big) are faster for both phases (config 3, phase B: count 28 -> 17 us, scatter 52 -> 42).
-                const char* mx = getenv("SLIMM_MATRIX");
-                cc->matrix = !cc->fused_scan && !(mx && mx[0] == '0') && (c->ntiles2 > kBigRoundTiles || (mx && mx[0] == '2'));
+                long mx = 1;
+                (void)forced("matrix", &mx);
+                cc->matrix = !cc->fused_scan && mx != 0 && (c->ntiles2 > kBigRoundTiles || mx == 2);
                 if (cc->matrix &&
                     cc->tile_matrix.ensure(static_cast<size_t>(TILES(c->tile_shift, tile_count_grid(512))) * cc->tstride) != hipSuccess)
                     return fail(nullptr, SLIMM_E_HIP, "out of device memory for the tile count matrix");
-                if (mx && mx[0] == '2') cc->matrix_always = true;  // (tests: small layouts, whatever the number of reads)
-                if (const char* wt = getenv("SLIMM_WIDE_TILES")) cc->wide_tiles = wt[0] == '1' ? 1 : 0;
+                if (mx == 2) cc->matrix_always = true;  // (tests: small layouts, whatever the number of reads)
+                long wt = 0;
+                if (forced("wide_tiles", &wt)) cc->wide_tiles = wt == 1 ? 1 : 0;
             }
             const size_t rep_words = static_cast<size_t>(cc->treps) * cc->tstride;
             if (cc->tile_count.ensure(rep_words) != hipSuccess || cc->tile_base.ensure(c->ntiles2 + 1) != hipSuccess ||
@@ -339,9 +341,10 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         }
         uint32_t cap = 1u << 16;
         while (cap < 8ull * c->R && cap < (1u << 30)) cap <<= 1;
-        if (const char* e = getenv("SLIMM_PAIR_CAP")) {  // tests: start small, so that the overflow -> grow -> retry path runs
+        long pc = 0;
+        if (forced("pair_cap", &pc)) {  // tests: start small, so that the overflow -> grow -> retry path runs
             cap = 16;
-            while (cap < static_cast<uint32_t>(atol(e)) && cap < (1u << 30)) cap <<= 1;
+            while (cap < static_cast<uint32_t>(pc) && cap < (1u << 30)) cap <<= 1;
         }
         int rc = ensure_pair_table(cc, cap);
         if (rc != SLIMM_OK) {
@@ -999,7 +1002,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             fa.lin_dense = c->d_lin_dense.p;
             fa.valid = c->d_valid.p;
         }
-        static const bool by_window = getenv("SLIMM_FILTER_BY_WINDOW") != nullptr;   // (round 5's k_filter: A/B runs)
+        const bool by_window = forced("filter_by_window");   // (round 5's k_filter, window by window: A/B runs)
         fa.valid_bits = by_window ? nullptr : c->d_valid_bits.p;
         fa.redo = c->filter_redo.p;
         fa.sel = c->sel.p;

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/slimm_hip.h"
+#include "force.h"
 
 namespace {
 
@@ -454,9 +455,11 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
         g->ready.push_back(a);
         g->copied.push_back(b);
     }
-    // collectives: RCCL over xGMI for distinct devices (SLIMM_GROUP_COLLECTIVES=copy|rccl overrides the choice)
-    const char* how = getenv("SLIMM_GROUP_COLLECTIVES");
-    const bool want_rccl = how ? strcmp(how, "rccl") == 0 : (distinct && n_devices > 1);
+    // collectives: RCCL over xGMI for distinct devices (SLIMM_FORCE="group_collectives=copy|rccl" overrides the choice: force.h)
+    const char* how = nullptr;
+    (void)slimm::forced_text("group_collectives", &how);
+    const bool how_rccl = how && strncmp(how, "rccl", 4) == 0;
+    const bool want_rccl = how ? how_rccl : (distinct && n_devices > 1);
     if (want_rccl && (distinct || n_devices == 1) && g->rccl.load()) {
         g->comm.assign(n_devices, nullptr);
         if (g->rccl.CommInitAll(g->comm.data(), static_cast<int>(n_devices), g->device.data()) == 0) {
@@ -465,16 +468,10 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
             g->comm.clear();
         }
     }
-    if (how && strcmp(how, "rccl") == 0 && !g->use_rccl) {
-        g_group_create_error = "SLIMM_GROUP_COLLECTIVES=rccl, but librccl could not be loaded or initialised for these devices";
+    if (how_rccl && !g->use_rccl) {
+        g_group_create_error = "SLIMM_FORCE group_collectives=rccl, but librccl could not be loaded or initialised for these devices";
         slimm_group_destroy(g);
         return SLIMM_E_HIP;
-    }
-    if (const char* ex = getenv("SLIMM_GROUP_EXCHANGE")) {  // summary | sliced | bins (tests, experiments)
-        g->exchange = strcmp(ex, "summary") == 0 ? SLIMM_EXCHANGE_SUMMARY
-                      : strcmp(ex, "sliced") == 0 ? SLIMM_EXCHANGE_SLICED
-                      : strcmp(ex, "bins") == 0   ? SLIMM_EXCHANGE_BINS
-                                                  : SLIMM_EXCHANGE_AUTO;
     }
     if (n_devices > 1 || g->use_rccl)  // the collectives run on the members' streams: no host fences around them
         for (slimm_ctx* c : g->ctx) (void)slimm_set_stream_ordered(c, 1);

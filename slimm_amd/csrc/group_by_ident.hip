@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "force.h"
 #include "kernels.h"
 
 namespace slimm {
@@ -734,14 +735,13 @@ __global__ __launch_bounds__(64) void k_gb_finish(uint64_t* __restrict__ ident, 
     }
 }
 
-// test / tuning knobs, read at every call (a test varies them inside one process): SLIMM_GROUP_BITS = hash bits of a
-// bucket, SLIMM_GROUP_WIDTH = widest digit of a pass, SLIMM_GROUP_PASSES = number of passes (with the other two),
-// SLIMM_GROUP_GRID = persistent workgroups of a pass.  (Two passes instead of three, measured at 10 M records, scripts/
-// group_bits.sh: 2 x 11 bits 255 us per scatter pass + 107 us of finish, 2 x 10 bits 156 + 211, against 3 x 8 bits 96 + 30.)
-uint32_t g_env_u32(const char* name) {
-    const char* e = getenv(name);
-    const long v = e ? atol(e) : 0;
-    return v > 0 ? static_cast<uint32_t>(v) : 0u;
+// test / tuning knobs (SLIMM_FORCE, force.h; read at every call: a test varies them inside one process): group_bits = hash
+// bits of a bucket, group_width = widest digit of a pass, group_passes = number of passes (with the other two), group_grid =
+// persistent workgroups of a pass.  (Two passes instead of three, measured at 10 M records, scripts/group_bits.sh: 2 x 11 bits
+// 255 us per scatter pass + 107 us of finish, 2 x 10 bits 156 + 211, against 3 x 8 bits 96 + 30.)
+uint32_t g_env_u32(const char* key) {
+    long v = 0;
+    return forced(key, &v) && v > 0 ? static_cast<uint32_t>(v) : 0u;
 }
 
 }  // namespace
@@ -753,8 +753,8 @@ GroupPlan group_plan(uint32_t n_records) {
     // moves half the stream once more: 9.6 ms against 2.0 ms with 2^30 buckets, for 1.9 ms more in the passes.
     uint32_t b = 8;
     while (b < 32u && (1ull << b) < n_records) ++b;
-    const uint32_t forced_bits = g_env_u32("SLIMM_GROUP_BITS");
-    const uint32_t forced_width = g_env_u32("SLIMM_GROUP_WIDTH");
+    const uint32_t forced_bits = g_env_u32("group_bits");
+    const uint32_t forced_width = g_env_u32("group_width");
     // A pass costs the same up to 8 bits per digit and more beyond (a round's records of one digit get fewer, the open
     // write frontiers more): measured per pass at 100 M / 1 B records with the reads interleaved at random, relative to
     // 8 bits: 9 bits 1.12 - 1.17, 10 bits 1.23 (inside the long bench process) - 1.41 (a fresh one), 11 bits ~1.9; the
@@ -768,7 +768,7 @@ GroupPlan group_plan(uint32_t n_records) {
     for (uint32_t bits = (forced_bits ? std::min(forced_bits, 32u) : b); bits <= (forced_bits ? std::min(forced_bits, 32u) : std::min(b + 1u, 32u));
          ++bits) {
         const uint32_t wcap = forced_width ? std::min(forced_width, kGroupMaxBits) : kGroupMaxBits;
-        const uint32_t forced_passes = g_env_u32("SLIMM_GROUP_PASSES");
+        const uint32_t forced_passes = g_env_u32("group_passes");
         for (uint32_t P = (bits + wcap - 1u) / wcap; P <= kGroupMaxPasses; ++P) {
             const uint32_t lo = bits / P, hi = lo + (bits % P ? 1u : 0u);
             if (hi > wcap) continue;
@@ -789,7 +789,7 @@ GroupPlan group_plan(uint32_t n_records) {
         }
     }
     g.grid = kGroupMaxGrid;
-    if (const uint32_t o = g_env_u32("SLIMM_GROUP_GRID")) g.grid = std::min(o, kGroupMaxGrid);
+    if (const uint32_t o = g_env_u32("group_grid")) g.grid = std::min(o, kGroupMaxGrid);
     return g;
 }
 
@@ -834,10 +834,11 @@ void launch_group_scan(hipStream_t st, const GroupJob& j, uint32_t pass) {
 }
 
 // ordered rounds through LDS (k_gb_scatter<.., kStaged>): up to 10-bit digits without check words (same box, 8-bit digits:
-// 10 M records 94.5 -> 91.7 us per pass, 100 M records 886 -> 818); SLIMM_GROUP_STAGED=0 / 1 forces
+// 10 M records 94.5 -> 91.7 us per pass, 100 M records 886 -> 818); SLIMM_FORCE group_staged=0 / 1 forces
 static bool gb_staged(uint32_t width, bool has_chk) {
     if (has_chk) return false;
-    if (const char* e = getenv("SLIMM_GROUP_STAGED")) return e[0] == '1';
+    long st = 0;
+    if (forced("group_staged", &st)) return st == 1;
     return width <= 10u && gb_lds_words(1u << width, true) <= kGLdsWords;
 }
 

@@ -140,7 +140,7 @@ uint32_t check_read_name(const char* s, size_t n) {
 AlignmentFile::AlignmentFile() = default;
 
 namespace {
-struct StageClock {  // SLIMM_CLI_TRACE=1: where the reader's time goes, printed when the file is closed
+struct StageClock {  // SLIMM_TRACE=cli: where the reader's time goes, printed when the file is closed
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     double& into;
     explicit StageClock(double& acc) : into(acc) {}
@@ -148,9 +148,13 @@ struct StageClock {  // SLIMM_CLI_TRACE=1: where the reader's time goes, printed
 };
 }  // namespace
 AlignmentFile::~AlignmentFile() { close(); }
+AlignmentFile::Settings& AlignmentFile::settings() {
+    static Settings s;
+    return s;
+}
 
 void AlignmentFile::close() {
-    if (fp_ && getenv("SLIMM_CLI_TRACE") && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0 && n_windows_ > 1)
+    if (fp_ && settings().trace && (ms_read_ + ms_inflate_ + ms_find_ + ms_decode_) > 0 && n_windows_ > 1)
         fprintf(stderr, "[trace] reader: read + parse blocks %.1f ms, inflate %.1f ms, record starts %.1f ms, decode + hash %.1f ms, "
                         "name check %.1f ms; %u windows, waited %.1f ms for the prefetch thread (%u threads, inflate by %s)\n", ms_read_, ms_inflate_, ms_find_,
                 ms_decode_, ms_names_, n_windows_, ms_wait_, threads_, inflate_backend());
@@ -187,7 +191,7 @@ bool AlignmentFile::open(const std::string& path) {
         // as many threads as the process may keep busy: the logical CPUs, or the cgroup's CPU quota when that is less (a
         // container on a 256-thread host may be held to 16 cores' worth; twice the quota keeps them fed across the
         // stages' short waits)
-        const char* e = getenv("SLIMM_DECODE_THREADS");
+        const unsigned asked = settings().threads;
         unsigned hw = std::thread::hardware_concurrency();
         hw = hw ? hw : 1u;
         if (FILE* q = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -199,7 +203,7 @@ bool AlignmentFile::open(const std::string& path) {
             }
             fclose(q);
         }
-        threads_ = e ? static_cast<unsigned>(std::max(1, atoi(e))) : std::max(1u, std::min(hw, 64u));
+        threads_ = asked ? asked : std::max(1u, std::min(hw, 64u));
     }
     workers_.reset(new Workers(threads_));
     inflaters_.reset(new Workers(threads_));  // (the prefetch thread's own: its jobs run beside the decode jobs)
@@ -231,7 +235,7 @@ namespace {
 // libdeflate (2 - 3x zlib's inflate rate on BGZF blocks) when the box has the library: there are no headers for it in
 // the image, so the four entry points used are declared here (libdeflate.h: libdeflate_alloc_decompressor,
 // libdeflate_deflate_decompress -- 0 = LIBDEFLATE_SUCCESS --, libdeflate_free_decompressor, libdeflate_crc32) and bound
-// with dlopen("libdeflate.so.0").  SLIMM_INFLATE=zlib keeps zlib; zlib is also the fallback when the library is absent.
+// with dlopen("libdeflate.so.0").  zlib is the fallback when the library is absent.
 struct Deflate {
     void* (*alloc)() = nullptr;
     int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
@@ -239,8 +243,6 @@ struct Deflate {
     uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
     bool ok = false;
     Deflate() {
-        const char* e = getenv("SLIMM_INFLATE");
-        if (e && strcmp(e, "zlib") == 0) return;
         void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return;
@@ -978,7 +980,7 @@ long AlignmentFile::read_raw(uint8_t* dst, size_t cap) {
         // through fread was a quarter of this thread's time.  Regular files only; anything else keeps the buffered reads.
         struct stat sb;
         const long at = ftell(fp_);
-        if (at >= 0 && fstat(fileno(fp_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("SLIMM_NO_MMAP")) {
+        if (at >= 0 && fstat(fileno(fp_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !settings().no_mmap) {
             void* m = mmap(nullptr, static_cast<size_t>(sb.st_size), PROT_READ, MAP_PRIVATE, fileno(fp_), 0);
             if (m != MAP_FAILED) {
                 map_ = static_cast<const uint8_t*>(m);

@@ -57,6 +57,14 @@ public:
     AlignmentFile(const AlignmentFile&) = delete;
     AlignmentFile& operator=(const AlignmentFile&) = delete;
 
+    // How the reader works, for every AlignmentFile opened afterwards (the command's --decode-threads / --no-mmap options and
+    // SLIMM_TRACE=cli): threads = 0 -- as many as the process may keep busy; no_mmap -- buffered reads instead of the mapping;
+    // trace -- the stage clocks on stderr when a file is closed.
+    struct Settings {
+        unsigned threads = 0;
+        bool no_mmap = false, trace = false;
+    };
+    static Settings& settings();
     // false + error() on failure (reference: "Could not open <path>!", src/misc.hpp:500-504)
     bool open(const std::string& path);
     void close();
@@ -173,7 +181,7 @@ private:
     };
     std::vector<Block> blocks_;
     unsigned threads_ = 1;
-    double ms_read_ = 0, ms_inflate_ = 0, ms_find_ = 0, ms_decode_ = 0, ms_names_ = 0, ms_wait_ = 0;  // SLIMM_CLI_TRACE
+    double ms_read_ = 0, ms_inflate_ = 0, ms_find_ = 0, ms_decode_ = 0, ms_names_ = 0, ms_wait_ = 0;  // SLIMM_TRACE=cli
     unsigned n_windows_ = 0;
     class Workers;  // the decode threads, started once per file
     std::unique_ptr<Workers> workers_, inflaters_;

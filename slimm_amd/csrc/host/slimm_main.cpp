@@ -158,7 +158,14 @@ struct Options {  // arg_options, reference src/slimm.hpp:49-87
     int order = -1;  // -1: from the @HD line
     bool dump_records = false;
     bool dump_raw = false;   // --dump-raw: the inflated record bytes (AlignmentFile::read_raw), for reader tests without a GPU
+    // how the records reach the device (defaults: the device inflates, finds and decodes; run-marked records for grouped files)
+    bool host_decode = false;      // --host-decode: the host reader decodes the records (rounds 1 - 3's path)
+    bool packed_records = false;   // --packed-records: 16-byte packed records instead of run-marked ones (host decoder)
+    bool verify_grouping = false;  // --verify-grouping: count the read names that come back (slimm_check_grouping) and warn
+    unsigned device_inflate = 1;   // --device-inflate K: every K-th window read in place is inflated on the device (0: none)
+    unsigned window_mb = 0;        // --window-mb N: bytes per window buffer (tests make windows smaller than a record)
 };
+bool g_trace = false;              // SLIMM_TRACE=cli (or all): millisecond marks of the stages on stderr
 
 const char* kRankList[] = {"strains", "species", "genus", "family", "order", "class", "phylum", "superkingdom"};
 
@@ -221,7 +228,9 @@ void usage() {
                  "  -ro, --raw-output             write raw reference statistics\n"
                  "  -co, --coverage-output        write raw coverage statistics\n"
                  "  -v,  --verbose\n"
-                 "       --device N | --devices N,M,... | --query-grouped | --any-order | --dump-records | --dump-raw\n";
+                 "       --device N | --devices N,M,... | --query-grouped | --any-order | --dump-records | --dump-raw\n"
+                 "       --host-decode | --packed-records | --verify-grouping | --device-inflate K | --window-mb N |\n"
+                 "       --decode-threads N | --no-mmap     (SLIMM_TRACE=cli: stage marks on stderr)\n";
 }
 
 // 0 ok, 1 error, 2 help
@@ -298,6 +307,23 @@ int parse(int argc, char** argv, Options& o) {
             o.order = SLIMM_ORDER_GROUPED;
         } else if (a == "--any-order") {
             o.order = SLIMM_ORDER_ANY;
+        } else if (a == "--host-decode") {
+            o.host_decode = true;
+        } else if (a == "--packed-records") {
+            o.packed_records = true;
+        } else if (a == "--verify-grouping") {
+            o.verify_grouping = true;
+        } else if (a == "--device-inflate") {
+            if (!value(v)) return 1;
+            o.device_inflate = static_cast<unsigned>(std::max(0l, atol(v.c_str())));
+        } else if (a == "--window-mb") {
+            if (!value(v)) return 1;
+            o.window_mb = static_cast<unsigned>(std::max(0l, atol(v.c_str())));
+        } else if (a == "--decode-threads") {
+            if (!value(v)) return 1;
+            AlignmentFile::settings().threads = static_cast<unsigned>(std::max(1l, atol(v.c_str())));
+        } else if (a == "--no-mmap") {
+            AlignmentFile::settings().no_mmap = true;
         } else if (a == "--dump-records") {
             o.dump_records = true;
         } else if (a == "--dump-raw") {
@@ -328,15 +354,14 @@ int parse(int argc, char** argv, Options& o) {
 }
 
 // --dump-raw: what the device decoder is fed -- the inflated bytes behind the BAM header, in windows of
-// SLIMM_CLI_WINDOW_MB (default 1) MiB -- to stdout, the window sizes to stderr
+// --window-mb (default 1) MiB -- to stdout, the window sizes to stderr
 int dump_raw(const Options& o) {
     AlignmentFile f;
     if (!f.open(o.input_path)) {
         std::cerr << f.error() << "\n";
         return 1;
     }
-    const char* e = getenv("SLIMM_CLI_WINDOW_MB");
-    const size_t cap = static_cast<size_t>(std::max(1L, e ? atol(e) : 1L)) << 20;
+    const size_t cap = static_cast<size_t>(std::max(1u, o.window_mb)) << 20;
     std::vector<uint8_t> buf(cap);
     long n;
     while ((n = f.read_raw(buf.data(), cap)) > 0) {
@@ -381,7 +406,6 @@ struct Session {  // what the one `slimm` object of the reference keeps across f
     std::vector<std::string> input_paths;
     float cc_cache = 0.0f, ucc_cache = 0.0f;  // src/slimm.hpp:155-156: never cleared by reset() (Q8)
     uint32_t total_hits = 0;
-    std::function<void()> finale;  // the run's closing lines + exit, callable from inside the last file's get_profiles
 };
 
 #define CHECK(ctx, call)                                                            \
@@ -410,9 +434,9 @@ float depth_of(const uint32_t* bins, uint32_t n, uint32_t nz) {  // reference_co
     return s / n;
 }
 
-// SLIMM_CLI_TRACE=1: millisecond marks of the per-file stages on stderr (the reference's own timer prints whole seconds)
+// SLIMM_TRACE=cli: millisecond marks of the per-file stages on stderr (the reference's own timer prints whole seconds)
 struct Trace {
-    bool on = getenv("SLIMM_CLI_TRACE") != nullptr;
+    bool on = g_trace;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void mark(const char* what) {
         if (!on) return;
@@ -422,7 +446,7 @@ struct Trace {
     }
 };
 
-// SLIMM_CLI_TRACE=1: what the file's end holds -- device memory in use (hipMemGetInfo: everything on the device), the window
+// SLIMM_TRACE=cli: what the file's end holds -- device memory in use (hipMemGetInfo: everything on the device), the window
 // pipeline's share of it, and the process's peak resident set
 void trace_memory(slimm_ctx* ctx) {
     uint64_t used = 0, total = 0, win = 0;
@@ -459,8 +483,8 @@ struct RecordPump {
     const bool want_check;
     // Name-grouped input (no check words) goes over the bus as RUN-MARKED 8-byte records: the reader has made the keys of
     // adjacent records equal exactly when their names are, so "this record starts a qName run" is a key comparison on the
-    // host and the device never sees a key (include/slimm_hip.h, slimm_mark_word).  SLIMM_VERIFY_GROUPING needs the keys
-    // on the device and keeps the packed 16-byte form; so does SLIMM_CLI_PACKED=1.
+    // host and the device never sees a key (include/slimm_hip.h, slimm_mark_word).  --verify-grouping needs the keys
+    // on the device and keeps the packed 16-byte form; so does --packed-records.
     const bool marked;
     uint64_t last_key = 0;   // the key of the last record marked so far (batches are pushed in file order)
     bool have_last = false;
@@ -477,17 +501,14 @@ struct RecordPump {
     // DEVICE DECODE (BAM files, one context): the decoder thread only inflates -- windows of BGZF-inflated record bytes
     // go into a few large host buffers, a second thread hands them to slimm_push_bam_bytes, and the device finds the
     // record boundaries, reads the fields and compares / hashes the names (slimm_amd/csrc/bam_decode.hip).  The host
-    // walked every inflated byte three times for that.  SLIMM_CLI_HOST_DECODE=1 keeps the host decoder.
+    // walked every inflated byte three times for that.  --host-decode keeps the host decoder.
     const bool raw;
-    // bytes per window buffer (SLIMM_CLI_WINDOW_MB: tests make windows smaller than a record)
-    static size_t raw_cap() {
-        static const size_t cap = [] {
-            const char* e = getenv("SLIMM_CLI_WINDOW_MB");
-            const long mb = e ? atol(e) : 0;
-            return (mb > 0 ? static_cast<size_t>(mb) : 192u) << 20;
-        }();
+    // bytes per window buffer (--window-mb: tests make windows smaller than a record)
+    static size_t& raw_cap_setting() {
+        static size_t cap = 192u << 20;
         return cap;
     }
+    static size_t raw_cap() { return raw_cap_setting(); }
     static constexpr unsigned kRawBuffers = 4;
     struct RawWindow {
         unsigned which = 0;
@@ -499,7 +520,7 @@ struct RecordPump {
     // BGZF blocks at a time, read by pread on several threads; the library gathers them into device windows of 1.4 - 1.9 GB
     // of inflated bytes (its inflater's first phase is a lane per block and wants tens of thousands of blocks) and inflates
     // them in two phases on two streams in turn (slimm_amd/csrc/bgzf_tokens.hip) while the next windows cross the bus.
-    // SLIMM_CLI_DEVICE_INFLATE = k: every k-th of those windows only, the others inflated by the host cores (0 = all on
+    // --device-inflate k: every k-th of those windows only, the others inflated by the host cores (0 = all on
     // the host: rounds 1 - 3; 6 = round 4's default, when the device inflated 19 - 38 GB/s and 16 host cores 14 - 55).
     // Measured on 100 M records that compress 3-fold (scripts/realistic_cli.py): host inflate 2.1 - 2.3 s, this 0.7 s.
     unsigned device_period = 1;
@@ -525,16 +546,12 @@ struct RecordPump {
     uint64_t raw_records = 0;
     double raw_push_ms = 0;
 
-    RecordPump(AlignmentFile& f, bool check_words, bool device_decode)
+    RecordPump(AlignmentFile& f, bool check_words, bool device_decode, const Options& o)
         : bam(f), want_check(check_words),
-          marked(!check_words && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED")),
-          raw(device_decode && !getenv("SLIMM_VERIFY_GROUPING") && !getenv("SLIMM_CLI_PACKED") && !getenv("SLIMM_CLI_HOST_DECODE")) {
-        if (const char* e = getenv("SLIMM_CLI_DEVICE_INFLATE")) {
-            device_period = static_cast<unsigned>(std::max(0l, atol(e)));
-        }
+          marked(!check_words && !o.verify_grouping && !o.packed_records),
+          raw(device_decode && !o.verify_grouping && !o.packed_records && !o.host_decode) {
+        device_period = o.device_inflate;
         device_window = std::min<size_t>(10 * raw_cap(), 1900u << 20);
-        if (const char* e = getenv("SLIMM_CLI_DEVICE_WINDOW_MB"))
-            if (atol(e) > 0) device_window = std::min<size_t>(static_cast<size_t>(atol(e)) << 20, 1900u << 20);
         th = std::thread([this] { raw ? run_raw() : run(); });  // (in the body: every member is initialised by now)
     }
     ~RecordPump() {
@@ -935,7 +952,7 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
     // (grouped streams are exact already: the reader compares the names of adjacent records)
     const bool check_words = record_order == SLIMM_ORDER_ANY;
     // decoding starts now; the records are claimed further down, when the context exists (one context: the device decodes)
-    RecordPump pump(bam, check_words, options.devices.size() <= 1);
+    RecordPump pump(bam, check_words, options.devices.size() <= 1, options);
 
     std::cerr << "Intializing coverages for all reference genome ... ";
     const uint32_t R = static_cast<uint32_t>(bam.ref_names().size());
@@ -1084,7 +1101,7 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
                 slimm_destroy(ctx);
                 return false;
             }
-            RecordPump again(bam, check_words, false);
+            RecordPump again(bam, check_words, false, options);
             ok = again.attach(ctx) && again.finish();
             n = again.read_rc;
         }
@@ -1099,7 +1116,7 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
             return false;
         }
     }
-    if (record_order == SLIMM_ORDER_GROUPED && getenv("SLIMM_VERIFY_GROUPING")) {
+    if (record_order == SLIMM_ORDER_GROUPED && options.verify_grouping) {
         // the header (or --query-grouped) promises that the records of a read name are adjacent; nothing checks the promise
         // unless asked: a name that comes back later would be counted as two reads (include/slimm_hip.h, slimm_check_grouping)
         uint64_t split = 0;
@@ -1182,12 +1199,6 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
     if (trace.on) trace_memory(ctx);
     std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
     CHECK(ctx, slimm_get_cutoff_cache(ctx, &S.cc_cache, &S.ucc_cache));
-    if (file_index + 1 == S.input_paths.size() && S.finale) {
-        // the last file's outputs are written and closed: the summary, then out -- without returning a gigabyte of buffers
-        // page by page, un-pinning the window buffers and unloading the HIP runtime first (0.1 - 0.2 s that buy nothing)
-        bam.close();
-        S.finale();
-    }
     slimm_destroy(ctx);
     return true;
 }
@@ -1195,7 +1206,18 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (getenv("SLIMM_CLI_TRACE")) {
+    {   // SLIMM_TRACE=cli | all | 1 (a comma list; host / push are the library's: slimm_amd/csrc/force.h)
+        const char* e = getenv("SLIMM_TRACE");
+        for (const char* p = e; p && *p;) {
+            const char* end = strchr(p, ',');
+            const size_t len = end ? static_cast<size_t>(end - p) : strlen(p);
+            if ((len == 3 && (!memcmp(p, "cli", 3) || !memcmp(p, "all", 3))) || (len == 1 && *p == '1')) g_trace = true;
+            if (!end) break;
+            p = end + 1;
+        }
+        AlignmentFile::settings().trace = g_trace;
+    }
+    if (g_trace) {
         struct timespec now;
         clock_gettime(CLOCK_REALTIME, &now);
         fprintf(stderr, "[trace] main() entered at %.6f (epoch seconds)\n", now.tv_sec + now.tv_nsec * 1e-9);
@@ -1204,6 +1226,7 @@ int main(int argc, char** argv) {
     int pr = parse(argc, argv, S.options);
     if (pr == 2) return 0;
     if (pr != 0) return 1;
+    if (S.options.window_mb && !S.options.dump_records) RecordPump::raw_cap_setting() = static_cast<size_t>(S.options.window_mb) << 20;
     if (S.options.dump_records) return dump_records(S.options);
     // the HIP runtime starts (0.1 - 0.3 s) while the database is loaded and the first file opened and sampled
     struct WarmUp {
@@ -1261,16 +1284,13 @@ int main(int argc, char** argv) {
             clock_gettime(CLOCK_REALTIME, &now);
             fprintf(stderr, "[trace] leaving at %.6f (epoch seconds)\n", now.tv_sec + now.tv_nsec * 1e-9);
         }
-        // Every output file is written and closed.  Leaving through _exit here (SLIMM_FAST_EXIT=1) skips the teardown in
-        // this process -- and measured SLOWER end to end since the window buffers are page-locked: the kernel driver then
-        // takes the process's queues, pinned pages and device memory back on its own, 0.20 - 0.23 s from _exit to the
-        // parent's wait() returning against 0.07 s of orderly teardown + 0.09 s (100 M-record BAM: 0.97 - 0.99 s against
-        // 0.90 - 0.92 s).  The orderly way is the default.
+        // (Every output file is written and closed.  Leaving through _exit here, without the teardown in this process, measured
+        // SLOWER end to end since the window buffers are page-locked: the kernel driver then takes the process's queues, pinned
+        // pages and device memory back on its own -- 0.20 - 0.23 s from _exit to the parent's wait() returning against 0.07 s of
+        // orderly teardown + 0.09 s; round 4.)
         std::cerr.flush();
         fflush(nullptr);
-        if (getenv("SLIMM_FAST_EXIT")) _exit(0);
     };
-    if (getenv("SLIMM_FAST_EXIT")) S.finale = closing_lines;   // (ends in _exit: called from the last file's get_profiles)
     for (size_t n = 0; n < S.input_paths.size(); ++n)
         if (!get_profiles(S, n)) return 1;
     closing_lines();

@@ -29,6 +29,7 @@
 
 #include <algorithm>
 
+#include "force.h"
 #include "kernels.h"
 
 // compiled once per tile size (Makefile: -DSLIMM_TILE_SHIFT=13 -> namespace tiles13, =14 -> tiles14; kernels.h)
@@ -1546,8 +1547,9 @@ void launch_tile_scatter(hipStream_t st, uint32_t grid, uint32_t ntiles, uint32_
                          const uint32_t* counters, const uint32_t* tile_base, uint32_t* tile_cursor, uint32_t* sup_cursor,
                          const uint4* items2, uint32_t* mid, uint16_t* bucket, uint32_t* cov, uint32_t* ucov, bool two_level,
                          const uint32_t* rep_base, uint32_t reps, uint32_t rep_stride, uint32_t tile_sub) {
-    const char* const big_env = std::getenv("SLIMM_SCATTER_BIG");  // (tuning aid / tests) 0: the direct rounds
-    const bool big_rounds = !(big_env && big_env[0] == '0');
+    long big = 1;
+    (void)forced("scatter_big", &big);  // (SLIMM_FORCE, force.h: tests) 0: the direct rounds
+    const bool big_rounds = big != 0;
     // (the copies' workgroups are the count's: tile_count_grid(grid) of them)
     if (!two_level && big_rounds && reps > 1 && ntiles <= static_cast<uint32_t>(kBigE) * kBigBlock) {
         hipLaunchKernelGGL(k_tile_scatter_big<kBigE>, dim3(tile_count_grid(grid)), dim3(kBigBlock), big_lds_bytes(kBigE), st,

@@ -200,9 +200,9 @@ int slimm_set_reference_names(slimm_ctx* c, const char* const* names) {
     return SLIMM_OK;
 }
 namespace {
-// SLIMM_PUSH_TRACE=1: what the window pipeline does and when (stderr; milliseconds since the first line)
+// SLIMM_TRACE=push: what the window pipeline does and when (stderr; milliseconds since the first line)
 void push_trace(const char* fmt, ...) {
-    static const bool on = getenv("SLIMM_PUSH_TRACE") != nullptr;
+    static const bool on = traced("push");
     if (!on) return;
     static const auto t0 = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -84,3 +84,12 @@ def assert_matches_oracle(s, o: OracleResult, bins: bool = True, check_lineage: 
     assert_profiles_match(s.write_abundance(), o.profile_tsv, check_lineage)
     st = s.stats()
     assert st["profile_count"] == o.scalars["profile_count"] and st["profile_failed"] == o.scalars["profile_failed"]
+
+
+def force(monkeypatch, **knobs):
+    """SLIMM_FORCE (slimm_amd/csrc/force.h): the ONE environment variable the library's test knobs are read from --
+    force(monkeypatch, two_level=1, tile_shift=14) adds `two_level=1,tile_shift=14` to it for the rest of the test."""
+    import os
+    cur = dict(p.split("=", 1) if "=" in p else (p, "1") for p in os.environ.get("SLIMM_FORCE", "").split(",") if p)
+    cur.update({k: str(v) for k, v in knobs.items()})
+    monkeypatch.setenv("SLIMM_FORCE", ",".join(f"{k}={v}" for k, v in cur.items()))

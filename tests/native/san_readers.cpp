@@ -6,6 +6,7 @@
 #include <vector>
 using namespace slimm;
 int main(int argc, char** argv) {
+    if (const char* t = getenv("SAN_READER_THREADS")) AlignmentFile::settings().threads = static_cast<unsigned>(atoi(t));   // (this driver's own knob)
     for (int i = 1; i < argc; ++i) {
         std::string p = argv[i];
         if (p.size() > 5 && p.substr(p.size() - 5) == ".sldb") {

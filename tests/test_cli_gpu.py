@@ -73,8 +73,7 @@ def test_cli_q18_name_suffix_and_mate_flag_make_one_key(tmp_path, fmt, order, ho
     (write_sam if fmt == "sam" else write_bam)(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, hd=hd)
     out = str(tmp_path / "out") + "/"
     os.makedirs(out)
-    env = dict(os.environ, SLIMM_CLI_HOST_DECODE="1") if host_decode else None
-    err = run_cli(["-w", "100", "-o", out, "-ro", "-co", "-v", db, inp], env=env)
+    err = run_cli((["--host-decode"] if host_decode else []) + ["-w", "100", "-o", out, "-ro", "-co", "-v", db, inp])
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
     assert (o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"]) == (
         Q18_EXPECTED["hits"], Q18_EXPECTED["matches"], Q18_EXPECTED["uniq_matches"])
@@ -97,9 +96,8 @@ def test_cli_q18_grouped_file_whose_key_strings_are_apart(tmp_path, fmt, hd, mod
     (write_sam if fmt == "sam" else write_bam)(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, hd=hd)
     out = str(tmp_path / "out") + "/"
     os.makedirs(out)
-    env = dict(os.environ, SLIMM_CLI_HOST_DECODE="1") if mode == "host" else None
-    extra = ["--devices", "0,0"] if mode == "group" else []
-    err = run_cli(extra + ["-w", "100", "-o", out, "-ro", "-co", "-v", db, inp], env=env)
+    extra = ["--devices", "0,0"] if mode == "group" else ["--host-decode"] if mode == "host" else []
+    err = run_cli(extra + ["-w", "100", "-o", out, "-ro", "-co", "-v", db, inp])
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
     assert (o.scalars["hits"], o.scalars["matches"], o.scalars["uniq_matches"]) == (
         Q18_APART_EXPECTED["hits"], Q18_APART_EXPECTED["matches"], Q18_APART_EXPECTED["uniq_matches"])
@@ -111,7 +109,7 @@ def test_cli_q18_grouped_file_whose_key_strings_are_apart(tmp_path, fmt, hd, mod
 
 def test_cli_packed_and_run_marked_pushes_write_the_same_files(tmp_path, monkeypatch):
     """Name-grouped input goes over the bus as run-marked 8-byte records (the reader's keys of adjacent records are equal
-    exactly when their names are); SLIMM_CLI_PACKED=1 keeps the 16-byte packed form.  A file of 2.5 M records (three
+    exactly when their names are); --packed-records keeps the 16-byte packed form.  A file of 2.5 M records (three
     batches of the pump: the run a batch ends in continues in the next one) through both: byte-equal outputs."""
     w = with_names(make_workload(CONFIGS["config2"], seed=44, n_records=2_500_000))
     db = str(tmp_path / "db.sldb")
@@ -120,11 +118,9 @@ def test_cli_packed_and_run_marked_pushes_write_the_same_files(tmp_path, monkeyp
     write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
     outs = []
     for k, packed in enumerate((False, True)):
-        if packed:
-            monkeypatch.setenv("SLIMM_CLI_PACKED", "1")
         out = str(tmp_path / f"out{k}") + "/"
         os.makedirs(out)
-        run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp])
+        run_cli((["--packed-records"] if packed else []) + ["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp])
         outs.append({f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))})
     assert outs[0] == outs[1] and len(outs[0]) == 5
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
@@ -294,7 +290,7 @@ def test_cli_unordered_file_with_two_names_under_one_key_fails_loudly(tmp_path):
 
 
 def test_cli_warns_about_a_false_grouping_promise_when_asked(tmp_path):
-    """A header that says GO:query over records that are not grouped: SLIMM_VERIFY_GROUPING=1 makes the command count the
+    """A header that says GO:query over records that are not grouped: --verify-grouping makes the command count the
     names that come back (slimm_check_grouping) and warn; --any-order gives the oracle's outputs for the same file."""
     w = with_names(make_workload(CONFIGS["config1"], seed=47))
     r = w.records
@@ -316,7 +312,7 @@ def test_cli_warns_about_a_false_grouping_promise_when_asked(tmp_path):
     args = [CLI, "-w", str(w.options.bin_width), "-o", out, "-ro", db, inp]
     quiet = subprocess.run(args, capture_output=True, text=True)
     assert quiet.returncode == 0 and "NOT grouped" not in quiet.stderr
-    loud = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, SLIMM_VERIFY_GROUPING="1"))
+    loud = subprocess.run(args[:1] + ["--verify-grouping"] + args[1:], capture_output=True, text=True)
     assert loud.returncode == 0 and "[WARNING] 1 read name run(s) repeat a name seen earlier" in loud.stderr
     run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "--any-order", db, inp])
     o = Oracle(wb.taxonomy, wb.options).run(wb.ref_names, wb.ref_len, wb.records, wb.avg_read_len, want_raw=True)
@@ -347,10 +343,9 @@ def test_cli_devices_writes_raw_and_coverage_outputs_from_all_reduced_bins(tmp_p
 def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, monkeypatch, fmt):
     """BAM input on one GPU: the DEVICE inflates the blocks, finds and decodes the records (slimm_push_bgzf_blocks /
     slimm_push_bam_bytes); SAM text likewise (slimm_push_sam_bytes: lines found and parsed on the device, small windows so
-    that lines are cut everywhere); with SLIMM_CLI_HOST_DECODE=1 the host decoder of rounds 1 - 3 does.  Same files either way,
+    that lines are cut everywhere); with --host-decode the host decoder of rounds 1 - 3 does.  Same files either way,
     for a name-grouped file and for the same records in no particular order (key + check word hashed on the device)."""
-    if fmt == "sam":
-        monkeypatch.setenv("SLIMM_CLI_WINDOW_MB", "1")
+    small = ["--window-mb", "1"] if fmt == "sam" else []
     w = with_names(make_workload(CONFIGS["config2"], seed=47, n_records=300_000))
     db = str(tmp_path / "db.sldb")
     write_sldb(db, w.taxonomy)
@@ -365,13 +360,10 @@ def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, m
         (write_bam if fmt == "bam" else write_sam)(inp, w.ref_names, w.ref_len, rec, read_len=w.avg_read_len, hd=hd)
         outs = []
         for host in (False, True):
-            if host:
-                monkeypatch.setenv("SLIMM_CLI_HOST_DECODE", "1")
-            else:
-                monkeypatch.delenv("SLIMM_CLI_HOST_DECODE", raising=False)
             out = str(tmp_path / f"{stem}_{int(host)}") + "/"
             os.makedirs(out)
-            err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp], env=dict(os.environ, SLIMM_CLI_TRACE="1"))
+            err = run_cli(small + (["--host-decode"] if host else []) + ["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp],
+                          env=dict(os.environ, SLIMM_TRACE="cli"))
             assert ("device decode" in err) == (not host)
             assert "decoding on the host" not in err
             outs.append({f: open(os.path.join(out, f)).read() for f in sorted(os.listdir(out))})
@@ -391,7 +383,7 @@ def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_
     out = str(tmp_path / "out") + "/"
     os.makedirs(out)
     # (windows of 4 MiB, so that the record spans several: the command's own are 192 MiB)
-    err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp], env=dict(os.environ, SLIMM_CLI_WINDOW_MB="4"))
+    err = run_cli(["--window-mb", "4", "-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, inp])
     assert "decoding on the host" in err
     # (the command samples its average read length from the file, src/misc.hpp:509-522: the long record is in the sample)
     avg = (w.avg_read_len * (len(w.records) - 1) + 16_000_000) // len(w.records)
@@ -404,7 +396,7 @@ def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_
     write_bam(inp2, big.ref_names, big.ref_len, big.records, read_len=big.avg_read_len)
     out2 = str(tmp_path / "out2") + "/"
     os.makedirs(out2)
-    err = run_cli(["-w", str(big.options.bin_width), "-o", out2, "-ro", db2, inp2], env=dict(os.environ, SLIMM_CLI_WINDOW_MB="1", SLIMM_CLI_TRACE="1"))
+    err = run_cli(["--window-mb", "1", "-w", str(big.options.bin_width), "-o", out2, "-ro", db2, inp2], env=dict(os.environ, SLIMM_TRACE="cli"))
     assert "device decode" in err and "decoding on the host" not in err
     o2 = Oracle(big.taxonomy, big.options).run(big.ref_names, big.ref_len, big.records, big.avg_read_len, want_raw=True, want_cov=False)
     check_outputs(out2, "many", o2, coverage=False)
@@ -414,7 +406,7 @@ def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_
 def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
     """BAM input on one GPU: of the windows the reader takes straight from the mapped file, a share goes to the device
     COMPRESSED (slimm_push_bgzf_blocks: inflate, CRC, record boundaries, fields, names all there) and alternates with windows
-    the host cores inflated (slimm_push_bam_bytes) -- when asked to (SLIMM_CLI_DEVICE_INFLATE = one window in so many; 1 = every
+    the host cores inflated (slimm_push_bam_bytes) -- when asked to (--device-inflate K = one window in so many; 1 = every
     window, the default since the two-phase inflate of round 5; 0 = none).  Whatever the period -- none, one in six, every window
     -- the same files, equal to the oracle's."""
     import re
@@ -445,11 +437,8 @@ def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
     for tenths in ("0", "6", None):
         out = str(tmp_path / f"out_{tenths}") + "/"
         os.makedirs(out)
-        env = dict(os.environ, SLIMM_CLI_TRACE="1", SLIMM_CLI_WINDOW_MB="2")
-        env.pop("SLIMM_CLI_DEVICE_INFLATE", None)
-        if tenths is not None:
-            env["SLIMM_CLI_DEVICE_INFLATE"] = tenths
-        err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", db, inp], env=env)
+        flags = ["--window-mb", "2"] + (["--device-inflate", tenths] if tenths is not None else [])
+        err = run_cli(flags + ["-w", str(w.options.bin_width), "-o", out, "-ro", db, inp], env=dict(os.environ, SLIMM_TRACE="cli"))
         m = re.search(r"(\d+) were inflated on the host, (\d+) on the device", err)
         assert m, err[-1500:]
         shares.append((int(m.group(1)), int(m.group(2))))
@@ -468,6 +457,6 @@ def test_cli_inflates_some_windows_on_the_device(tmp_path, order):
     bad = str(tmp_path / "bad.bam")
     open(bad, "wb").write(bytes(blob))
     for tenths in ("0", "1"):
-        r = subprocess.run([CLI, "-w", "1000", "-o", str(tmp_path / "bad_") , db, bad], capture_output=True, text=True,
-                           env=dict(os.environ, SLIMM_CLI_WINDOW_MB="2", SLIMM_CLI_DEVICE_INFLATE=tenths))
+        r = subprocess.run([CLI, "--window-mb", "2", "--device-inflate", tenths, "-w", "1000", "-o", str(tmp_path / "bad_") , db, bad],
+                           capture_output=True, text=True)
         assert r.returncode != 0 and "BGZF" in r.stderr, r.stderr[-800:]

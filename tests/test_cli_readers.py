@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "slimm_amd", "slimm")
 
 
-def dump(path):
-    out = subprocess.run([CLI, "--dump-records", path], capture_output=True, text=True, check=True).stdout.split("\n")
+def dump(path, extra=()):
+    out = subprocess.run([CLI, "--dump-records", *extra, path], capture_output=True, text=True, check=True).stdout.split("\n")
     head = out[0].split("\t")
     refs = [ln.split("\t")[1:] for ln in out if ln.startswith("@\t")]
     recs = [ln.split("\t") for ln in out[1:] if ln and not ln.startswith("@\t")]
@@ -122,8 +122,7 @@ def test_bam_with_irregular_records_is_split_correctly_by_the_parallel_reader(tm
             f.write(_bgzf_block(bytes(out[s0:s0 + 0xff00])))
         f.write(_bgzf_block(b""))
     for threads in ("1", "8"):
-        monkeypatch.setenv("SLIMM_DECODE_THREADS", threads)
-        _, refs, recs = dump(p)
+        _, refs, recs = dump(p, ("--decode-threads", threads))
         assert len(recs) == n
         got = [(r[0], int(r[1]), int(r[2]), int(r[3]), int(r[4])) for r in recs]
         assert got == expect
@@ -221,10 +220,8 @@ def test_raw_windows_are_the_inflated_record_bytes(tmp_path, window_mb, mmap):
     p = str(tmp_path / "x.bam")
     write_bam(p, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len, irregular_seed=4)
     want = bam_record_bytes(w.records, read_len=w.avg_read_len, irregular_seed=4)
-    env = dict(os.environ, SLIMM_CLI_WINDOW_MB=str(window_mb))
-    if not mmap:
-        env["SLIMM_NO_MMAP"] = "1"
-    r = subprocess.run([CLI, "--dump-raw", p], capture_output=True, env=env)
+    flags = ["--window-mb", str(window_mb)] + ([] if mmap else ["--no-mmap"])
+    r = subprocess.run([CLI, "--dump-raw"] + flags + [p], capture_output=True)
     assert r.returncode == 0, r.stderr[-500:]
     assert r.stdout == want
     sizes = [int(ln.split("\t")[1]) for ln in r.stderr.decode().splitlines() if ln.startswith("window")]
@@ -234,5 +231,5 @@ def test_raw_windows_are_the_inflated_record_bytes(tmp_path, window_mb, mmap):
     blob = open(p, "rb").read()
     bad = str(tmp_path / "cut.bam")
     open(bad, "wb").write(blob[:len(blob) * 2 // 3])
-    r = subprocess.run([CLI, "--dump-raw", bad], capture_output=True, env=env)
+    r = subprocess.run([CLI, "--dump-raw"] + flags + [bad], capture_output=True)
     assert r.returncode != 0 and b"truncated" in r.stderr

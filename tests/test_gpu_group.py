@@ -10,7 +10,7 @@ import pytest
 from oracle.binding import run_workload
 from slimm_amd.profiler import SlimmGroup
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
-from tests.helpers import assert_matches_oracle, assert_profiles_match
+from tests.helpers import assert_matches_oracle, assert_profiles_match, force
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def test_group_any_order_goes_by_key(tmp_path):
 def test_group_pair_set_overflow_goes_round_again(monkeypatch):
     """Reads whose references agree at no level (Q4) with a 64-entry pair set: slimm_install_merged_partials answers
     SLIMM_E_RETRY on every member, every member grows its table, and the phase is launched again."""
-    monkeypatch.setenv("SLIMM_PAIR_CAP", "64")
+    force(monkeypatch, pair_cap="64")
     cfg = SynthConfig("q4group", 120_000, 10_000, 6.0, present_frac=0.5, len_lo=200_000, len_hi=600_000)
     w = make_workload(cfg, seed=53)
     rng = np.random.default_rng(2)
@@ -100,7 +100,7 @@ def test_group_one_run_longer_than_a_batch_stays_on_one_member():
 def test_group_of_one_through_rccl(monkeypatch):
     """The RCCL form with a communicator of one: the calls (ncclCommInitAll, grouped ncclAllGather / ncclAllReduce on the
     member's stream) are the ones a group of eight makes."""
-    monkeypatch.setenv("SLIMM_GROUP_COLLECTIVES", "rccl")
+    force(monkeypatch, group_collectives="rccl")
     w = make_workload(CONFIGS["config1"], seed=56)
     o = run_workload(w, use_qnames=False, collect_bins=False)
     g = SlimmGroup(w, [0])
@@ -141,8 +141,8 @@ def test_group_exchange_forms_equal_the_oracle(members, form):
 @pytest.mark.parametrize("form", ["summary", "sliced"])
 def test_group_bitmaps_with_both_tile_sizes(monkeypatch, shift, form):
     """The 'bin != 0' bitmaps k_tile_hist / k_pack write for the exchange are laid out in slices of tiles: both tile
-    sizes (SLIMM_TILE_SHIFT) through the all-gather and the all-to-all form, split tiles included."""
-    monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
+    sizes (SLIMM_FORCE tile_shift) through the all-gather and the all-to-all form, split tiles included."""
+    force(monkeypatch, tile_shift=shift)
     w = make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000, len_hi=900_000, present_frac=0.3),
                       seed=62)
     o = run_workload(w, use_qnames=False, collect_bins=False)
@@ -173,7 +173,7 @@ def test_group_exchange_forms_on_a_larger_stream_and_a_second_file(form):
 def test_group_of_one_through_rccl_in_every_form(monkeypatch, form):
     """Each form through the RCCL entry points with a communicator of one: ncclAllGather; ncclSend / ncclRecv in a group +
     ncclAllReduce; ncclAllReduce over the bins (and over uniq_cov2)."""
-    monkeypatch.setenv("SLIMM_GROUP_COLLECTIVES", "rccl")
+    force(monkeypatch, group_collectives="rccl")
     w = make_workload(CONFIGS["config1"], seed=59)
     o = run_workload(w, use_qnames=False)
     g = SlimmGroup(w, [0])

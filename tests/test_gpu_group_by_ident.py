@@ -11,12 +11,12 @@ from oracle.binding import run_workload
 from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Records, Workload
-from tests.helpers import assert_matches_oracle
+from tests.helpers import assert_matches_oracle, force
 from tests.test_gpu_parity import _interleave_mates, _order_preserving_interleave, one_long_read_workload
 
 pytestmark = pytest.mark.gpu
 
-PLANS = [  # (SLIMM_GROUP_BITS, SLIMM_GROUP_WIDTH, SLIMM_GROUP_GRID); None = the library's own choice
+PLANS = [  # SLIMM_FORCE (group_bits, group_width, group_grid); None = the library's own choice
     (None, None, None),
     (1, 1, 2),       # two buckets: the finish's selection sweeps over half the stream each
     (3, 3, 5),
@@ -32,11 +32,11 @@ PLANS = [  # (SLIMM_GROUP_BITS, SLIMM_GROUP_WIDTH, SLIMM_GROUP_GRID); None = the
 
 
 def _plan(monkeypatch, plan):
-    for name, v in zip(("SLIMM_GROUP_BITS", "SLIMM_GROUP_WIDTH", "SLIMM_GROUP_GRID"), plan):
-        if v is None:
-            monkeypatch.delenv(name, raising=False)
-        else:
-            monkeypatch.setenv(name, str(v))
+    pairs = [f"{name}={v}" for name, v in zip(("group_bits", "group_width", "group_grid"), plan) if v is not None]
+    if pairs:
+        monkeypatch.setenv("SLIMM_FORCE", ",".join(pairs))
+    else:
+        monkeypatch.delenv("SLIMM_FORCE", raising=False)
 
 
 def _shuffled(w: Workload, seed: int, keep_read_order: bool = False) -> Workload:

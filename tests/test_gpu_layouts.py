@@ -8,7 +8,7 @@ import pytest
 from oracle.binding import run_workload
 from slimm_amd.profiler import Slimm
 from slimm_amd.synth import SynthConfig, make_workload
-from tests.helpers import assert_matches_oracle
+from tests.helpers import assert_matches_oracle, force
 
 pytestmark = pytest.mark.gpu
 
@@ -39,12 +39,11 @@ def test_layout_default_path(cfg):
 
 
 @pytest.mark.parametrize("cfg", [TINY_REFS, HOT_TILE], ids=lambda c: c.name)
-@pytest.mark.parametrize("env", [{"SLIMM_DIRECT_ATOMICS": "1"}, {"SLIMM_TWO_LEVEL": "1"}, {"SLIMM_WIDE_ROWS": "1"},
-                                 {"SLIMM_FUSED_SCAN": "0"}],
+@pytest.mark.parametrize("knob", [{"direct_atomics": 1}, {"two_level": 1}, {"wide_rows": 1}, {"fused_scan": 0}],
                          ids=lambda e: next(iter(e)))
-def test_layout_fallback_paths(monkeypatch, cfg, env):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+def test_layout_fallback_paths(monkeypatch, cfg, knob):
+    """SLIMM_FORCE direct_atomics / two_level=1 / wide_rows / fused_scan=0 (slimm_amd/csrc/force.h) on these layouts."""
+    force(monkeypatch, **knob)
     _check(cfg, seed=6)
 
 

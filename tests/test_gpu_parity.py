@@ -14,7 +14,7 @@ from slimm_amd.profiler import Slimm
 from slimm_amd.synth import CONFIGS, SynthConfig, make_workload
 from slimm_amd.workload import Options, Records, Workload
 from tests.cases import Q18_EXPECTED, holes_case, load_golden, q18_case, records_from_sam, taxonomy_from_lineages, tiny_case
-from tests.helpers import assert_matches_oracle, assert_profiles_match
+from tests.helpers import assert_matches_oracle, assert_profiles_match, force
 
 pytestmark = pytest.mark.gpu
 
@@ -189,7 +189,7 @@ def test_many_cross_superkingdom_reads_use_the_pair_set():
 
 def test_direct_atomic_fallback_path(monkeypatch):
     """The global-atomic histogram (used when there are too many bin tiles for LDS) must agree too."""
-    monkeypatch.setenv("SLIMM_DIRECT_ATOMICS", "1")
+    force(monkeypatch, direct_atomics="1")
     check(make_workload(CONFIGS["config2"], seed=15, n_records=200_000))
     check(make_workload(CONFIGS["config1"], seed=16))
 
@@ -242,7 +242,7 @@ def test_runs_of_hundreds_of_records():
 
 @pytest.mark.parametrize("two", ["0", "1"])
 def test_both_bucketing_variants(monkeypatch, two):
-    monkeypatch.setenv("SLIMM_TWO_LEVEL", two)
+    force(monkeypatch, two_level=two)
     check(make_workload(CONFIGS["config2"], seed=20, n_records=300_000))
     check(make_workload(CONFIGS["config1"], seed=21))
 
@@ -272,11 +272,11 @@ def test_a_read_with_thousands_of_targets(n_hit, where):
 
 @pytest.mark.parametrize("big", ["1", "0"])
 def test_one_level_bucketing_with_a_separate_scan(monkeypatch, big):
-    """SLIMM_FUSED_SCAN=0: k_tile_scan + the scatter of layouts of more than 4064 tiles on small layouts, reads of
+    """SLIMM_FORCE fused_scan=0: k_tile_scan + the scatter of layouts of more than 4064 tiles on small layouts, reads of
     thousands of records included: the rounds ordered by tile in LDS (k_tile_scatter_big, the default) and the direct
-    rounds (SLIMM_SCATTER_BIG=0)."""
-    monkeypatch.setenv("SLIMM_FUSED_SCAN", "0")
-    monkeypatch.setenv("SLIMM_SCATTER_BIG", big)
+    rounds (SLIMM_FORCE scatter_big=0)."""
+    force(monkeypatch, fused_scan="0")
+    force(monkeypatch, scatter_big=big)
     check(make_workload(CONFIGS["config2"], seed=23, n_records=300_000))
     check(make_workload(CONFIGS["config1"], seed=24))
     check(one_long_read_workload(9_000))
@@ -285,11 +285,11 @@ def test_one_level_bucketing_with_a_separate_scan(monkeypatch, big):
 @pytest.mark.parametrize("matrix", ["2", "0"])
 def test_matrix_bucketing_and_the_direct_rounds(monkeypatch, matrix):
     """Phase B of layouts beyond the fused kernel's 4064 tiles buckets its selectors through a count matrix (one row per
-    counting workgroup, no global atomics in the scatter) when a tile gets few of them; SLIMM_MATRIX=0 keeps the direct
-    rounds, 2 = always.  Forced onto small layouts here (SLIMM_FUSED_SCAN=0), a tile cut into several work items
+    counting workgroup, no global atomics in the scatter) when a tile gets few of them; SLIMM_FORCE matrix=0 keeps the direct
+    rounds, 2 = always.  Forced onto small layouts here (SLIMM_FORCE fused_scan=0), a tile cut into several work items
     included; the big layouts run it at their real sizes (the prefix and full-size tests of configs 3 and 5)."""
-    monkeypatch.setenv("SLIMM_FUSED_SCAN", "0")
-    monkeypatch.setenv("SLIMM_MATRIX", matrix)
+    force(monkeypatch, fused_scan="0")
+    force(monkeypatch, matrix=matrix)
     check(make_workload(CONFIGS["config2"], seed=26, n_records=300_000))
     check(make_workload(CONFIGS["config1"], seed=27))
     check(make_workload(CONFIGS["config1"], seed=28), grouped=False)
@@ -300,11 +300,11 @@ def test_matrix_bucketing_and_the_direct_rounds(monkeypatch, matrix):
 
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_wide_tile_work_items(monkeypatch, fused):
-    """SLIMM_WIDE_TILES=1: the form k_tile_hist takes by itself when a file brings far more entries per tile than a
+    """SLIMM_FORCE wide_tiles=1: the form k_tile_hist takes by itself when a file brings far more entries per tile than a
     packed work item holds (1 B records on 20 k references) -- 32-bit counts, work items of up to 262 144 entries --
     on small layouts: tiles that were cut into pieces become one item, a tile of 300 000 entries still is cut."""
-    monkeypatch.setenv("SLIMM_WIDE_TILES", "1")
-    monkeypatch.setenv("SLIMM_FUSED_SCAN", fused)
+    force(monkeypatch, wide_tiles="1")
+    force(monkeypatch, fused_scan=fused)
     check(make_workload(CONFIGS["config1"], seed=30))
     check(make_workload(CONFIGS["config2"], seed=31, n_records=300_000))
     check(make_workload(SynthConfig("hot", 200_000, 12, 6.0, bin_width=50, len_lo=400_000, len_hi=900_000, present_frac=0.3),
@@ -317,12 +317,12 @@ def test_wide_tile_work_items(monkeypatch, fused):
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_both_tile_sizes(monkeypatch, shift, fused):
     """tile_hist.hip is built once per tile size (8192 / 16384 bins: namespaces tiles13 / tiles14) and a context picks one
-    by its layout -- the small tiles up to the fused kernel's 4064, the large ones beyond.  SLIMM_TILE_SHIFT forces either
+    by its layout -- the small tiles up to the fused kernel's 4064, the large ones beyond.  SLIMM_FORCE tile_shift forces either
     onto any layout: small layouts through the large tiles (and, with their full reference sets, big ones through the
     small: test_prefix_of_the_big_configs_on_small_tiles), ordered and direct rounds, packed, wide and cut work items,
     without materialised arrays."""
-    monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
-    monkeypatch.setenv("SLIMM_FUSED_SCAN", fused)
+    force(monkeypatch, tile_shift=shift)
+    force(monkeypatch, fused_scan=fused)
     check(make_workload(CONFIGS["config1"], seed=34))
     check(make_workload(CONFIGS["config1"], seed=35), grouped=False)
     check(make_workload(CONFIGS["config2"], seed=36, n_records=300_000))
@@ -331,7 +331,7 @@ def test_both_tile_sizes(monkeypatch, shift, fused):
                         seed=37)
     check(hot)
     check(hot, keep_bins=False)
-    monkeypatch.setenv("SLIMM_WIDE_TILES", "1")
+    force(monkeypatch, wide_tiles="1")
     check(hot)
     check(make_workload(SynthConfig("hotter", 600_000, 6, 1.5, bin_width=200, len_lo=300_000, len_hi=400_000, present_frac=1.0),
                         seed=38))
@@ -341,13 +341,13 @@ def test_both_tile_sizes(monkeypatch, shift, fused):
 def test_prefix_of_the_big_configs_on_small_tiles(monkeypatch, name, n):
     """The layouts that take the 16384-bin tiles by themselves through the 8192-bin ones (9 776 / 45 000 tiles: the scan in
     stretches of 16 K tiles, two-level bucketing)."""
-    monkeypatch.setenv("SLIMM_TILE_SHIFT", "13")
+    force(monkeypatch, tile_shift="13")
     check(make_workload(CONFIGS[name], seed=3, n_records=n))
 
 
 def test_wide_lineage_rows_fallback_path(monkeypatch):
     """32-byte lineage rows (used when a level has more than 65535 distinct taxids) must agree with the oracle too."""
-    monkeypatch.setenv("SLIMM_WIDE_ROWS", "1")
+    force(monkeypatch, wide_rows="1")
     check(make_workload(CONFIGS["config2"], seed=17, n_records=200_000))
     w, _, _ = load_golden("holes")
     check(w)
@@ -418,7 +418,7 @@ def test_two_shards_on_one_gpu_device_side_partials_merge(with_pairs, launched, 
     installed); with pairs the pair set starts tiny, so that install asks every rank to go round again."""
     import torch
     if launched and with_pairs:
-        monkeypatch.setenv("SLIMM_PAIR_CAP", "64")
+        force(monkeypatch, pair_cap="64")
     if with_pairs:   # reads straddling superkingdoms agree at no level (Q4): (taxon, ref) pairs
         cfg = SynthConfig("q4shards", 150_000, 10_000, 6.0, present_frac=0.5, len_lo=200_000, len_hi=600_000)
         w = make_workload(cfg, seed=23)
@@ -479,7 +479,7 @@ def test_shards_on_one_gpu_through_the_sliced_exchange(monkeypatch, world, shift
     size the layout picks (8192 bins here) and with the 16384-bin tiles the 20 k-reference layouts pick."""
     import torch
     if shift:
-        monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
+        force(monkeypatch, tile_shift=shift)
     w = make_workload(CONFIGS["config2"], seed=27, n_records=300_000)
     o = run_workload(w, use_qnames=False)
     owner = (w.records.read_key % np.uint64(world)).astype(np.int64)
@@ -521,7 +521,7 @@ def test_shards_on_one_gpu_through_the_sliced_exchange(monkeypatch, world, shift
 def test_single_rank_through_the_exchange_code_path(monkeypatch, shift):
     from slimm_amd.distributed import sharded_profile
     if shift:
-        monkeypatch.setenv("SLIMM_TILE_SHIFT", shift)
+        force(monkeypatch, tile_shift=shift)
     w = make_workload(CONFIGS["config1"], seed=19)
     o = run_workload(w)
     for mode in ("summary", "sliced", "bins"):
@@ -537,7 +537,7 @@ def test_sliced_exchange_on_the_direct_atomics_fallback(monkeypatch):
     (bitmaps from the separate kernels) is its own single slice.  More ranks: slimm_prepare_summary(n > 1) refuses and
     the driver takes the all-gather form (the same decision on every rank: it depends on the configuration only)."""
     from slimm_amd.distributed import sharded_profile
-    monkeypatch.setenv("SLIMM_DIRECT_ATOMICS", "1")
+    force(monkeypatch, direct_atomics="1")
     w = make_workload(CONFIGS["config1"], seed=29)
     o = run_workload(w)
     s = Slimm.for_workload(w, device=0)
@@ -572,14 +572,6 @@ def test_contexts_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) < 64 << 20, (free0, free1)   # (allocator granularity, not a per-context leak)
-
-
-def test_chunked_tile_scan(monkeypatch):
-    """Above 16 K record tiles the tile scan of the compaction (record_order = ANY) runs on several workgroups; forced here
-    on a small input with chunks of 16 tiles (the last chunk ragged)."""
-    monkeypatch.setenv("SLIMM_SCAN_CHUNK", "16")
-    w = make_workload(CONFIGS["config2"], seed=35, n_records=250_000)   # 123 tiles -> 8 chunks
-    check(w, grouped=False)
 
 
 @pytest.mark.parametrize("n_records", [768 * 64, 768 * 64 + 1, 768 * 129 - 5, 1024 * 64, 1024 * 64 + 1, 1_500_000])

@@ -1200,6 +1200,7 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
     std::cerr << "[Done!] File took " << watch.elapsed() << " secs to process.\n";
     CHECK(ctx, slimm_get_cutoff_cache(ctx, &S.cc_cache, &S.ucc_cache));
     slimm_destroy(ctx);
+    trace.mark("slimm_destroy");
     return true;
 }
 
@@ -1291,8 +1292,10 @@ int main(int argc, char** argv) {
         std::cerr.flush();
         fflush(nullptr);
     };
-    for (size_t n = 0; n < S.input_paths.size(); ++n)
+    for (size_t n = 0; n < S.input_paths.size(); ++n) {
         if (!get_profiles(S, n)) return 1;
+        trace.mark("get_profiles + its buffers released");
+    }
     closing_lines();
     return 0;
 }

@@ -778,100 +778,88 @@ __global__ __launch_bounds__(64, 8) void k_filter_compact(const uint32_t* __rest
     const uint32_t lane = lane_id();
     for (uint32_t r = lane; r < kFcReads; r += 64u) s_sel[r] = 0xffffffffu;
     __builtin_amdgcn_wave_barrier();
-    // The wave's slots (blockIdx.x, + gridDim.x, ...) are ONE stream of batches of kFcBatch chunks of 64 targets: the words of
-    // the batch after this one -- the same slot's, or the first of the next slot, whose descriptor was asked for a slot ahead --
-    // are on their way while this one is worked on, and a batch's bitmap words are asked for together.  (One chunk per trip:
-    // 2.15 ms at 1 B records; four: 1.77 ms; with the next slot's first batch asked for ahead as well: below.)
-    const uint4 none = make_uint4(0u, 0u, 0u, 0u);
-    uint32_t slot = blockIdx.x;
-    uint4 d = slot < nslots ? slots[slot] : none;                                   // this slot
-    uint4 dn = slot + gridDim.x < nslots ? slots[slot + gridDim.x] : none;          // the next one
-    uint32_t rb = slot < nslots ? out.rbase[slot] + out.bbase[slot >> 10] : 0u;
-    uint32_t rbn = slot + gridDim.x < nslots ? out.rbase[slot + gridDim.x] + out.bbase[(slot + gridDim.x) >> 10] : 0u;
-    uint32_t t = d.x, tend = d.x + d.y;
-    uint32_t wn[kFcBatch], gn[kFcBatch];
-    auto ask = [&](uint32_t from, uint32_t end) {   // (end > from)
+    for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {
+        const uint4 d = slots[slot];
+        const uint32_t rb = out.rbase[slot] + out.bbase[slot >> 10];
+        const uint32_t t0 = d.x, tend = d.x + d.y;
+        bool whole_reads_walk = d.z > kFcReads;   // (cannot happen with kSlotRecs records per slot; the walk takes anything)
+        uint32_t rcount = 0, ccount = 0, cdone = 0;
+        // kFcBatch chunks of 64 targets per trip: their words were asked for a trip ahead, their bitmap words are asked for
+        // together -- one dependent round trip per 256 targets (with one chunk per trip the kernel waited for that gather:
+        // 2.15 ms at 1 B records, 12 % under the window-by-window kernel)
+        uint32_t wn[kFcBatch], gn[kFcBatch];
+        auto ask = [&](uint32_t t) {
 #pragma unroll
-        for (uint32_t u = 0; u < kFcBatch; ++u) {
-            const uint32_t i = min(from + 64u * u + lane, end - 1u);   // (lanes behind the slot's end: its last target, not used)
-            wn[u] = tgt_ref[i];
-            gn[u] = tgt_gbin[i];
-        }
-    };
+            for (uint32_t u = 0; u < kFcBatch; ++u) {
+                const uint32_t i = min(t + 64u * u + lane, tend - 1u);   // (lanes behind the slot's end: its last target, not used)
+                wn[u] = tgt_ref[i];
+                gn[u] = tgt_gbin[i];
+            }
+        };
+        if (!whole_reads_walk && t0 < tend) ask(t0);
+        for (uint32_t t = t0; t < tend && !whole_reads_walk; t += 64u * kFcBatch) {
+            uint32_t w[kFcBatch], g[kFcBatch], bits[kFcBatch];
 #pragma unroll
-    for (uint32_t u = 0; u < kFcBatch; ++u) wn[u] = gn[u] = 0u;
-    if (t < tend) ask(t, tend);
-    uint32_t rcount = 0, ccount = 0, cdone = 0;
-    bool whole_reads_walk = d.z > kFcReads;   // (cannot happen with kSlotRecs records per slot; the walk takes anything)
-    while (slot < nslots) {
-        uint32_t w[kFcBatch], g[kFcBatch], bits[kFcBatch];
+            for (uint32_t u = 0; u < kFcBatch; ++u) {
+                w[u] = wn[u];
+                g[u] = gn[u];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (uint32_t u = 0; u < kFcBatch; ++u) {
-            w[u] = wn[u];
-            g[u] = gn[u];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (uint32_t u = 0; u < kFcBatch; ++u) bits[u] = valid_bits[(w[u] & 0x7fffffffu) >> 5];
-        __builtin_amdgcn_sched_barrier(0);
-        // the batch after this one
-        const bool slot_ends = t + 64u * kFcBatch >= tend;
-        const uint32_t nt = slot_ends ? dn.x : t + 64u * kFcBatch, ntend = slot_ends ? dn.x + dn.y : tend;
-        if (nt < ntend) ask(nt, ntend);
-        __builtin_amdgcn_sched_barrier(0);
-        // (one chunk after the other through ONE copy of the code below: the chunk's words picked out of the batch's
-        // registers by a few selects -- unrolled, the window code would stand in the kernel kFcBatch times)
+            for (uint32_t u = 0; u < kFcBatch; ++u) bits[u] = valid_bits[(w[u] & 0x7fffffffu) >> 5];
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 64u * kFcBatch < tend) ask(t + 64u * kFcBatch);
+            __builtin_amdgcn_sched_barrier(0);
+            // (one chunk after the other through ONE copy of the code below: the chunk's words picked out of the batch's
+            // registers by a few selects -- unrolled, the window code would stand in the kernel kFcBatch times)
 #pragma unroll 1
-        for (uint32_t u = 0; u < kFcBatch; ++u) {
-            const uint32_t tu = t + 64u * u;
-            if (tu >= tend || whole_reads_walk) break;
-            uint32_t wu = w[0], gu = g[0], bu = bits[0];
+            for (uint32_t u = 0; u < kFcBatch; ++u) {
+                const uint32_t tu = t + 64u * u;
+                if (tu >= tend) break;
+                uint32_t wu = w[0], gu = g[0], bu = bits[0];
 #pragma unroll
-            for (uint32_t k = 1; k < kFcBatch; ++k) {
-                wu = u == k ? w[k] : wu;
-                gu = u == k ? g[k] : gu;
-                bu = u == k ? bits[k] : bu;
-            }
-            const bool live = tu + lane < tend;
-            const uint32_t ref = wu & 0x7fffffffu;
-            const bool valid = live && ((bu >> (ref & 31u)) & 1u) != 0u;
-            const bool head = live && (wu >> 31) != 0u;
-            const uint64_t H = k_ballot(head), VB = k_ballot(valid);
-            if (valid) {
-                const uint32_t p = (ccount + mask_rank(VB)) & (kFcRing - 1u);
-                s_ref[p] = ref;
-                s_g[p] = gu;
-                s_r[p] = rcount + mask_rank(H) + (head ? 1u : 0u) - 1u;
-            }
-            rcount += static_cast<uint32_t>(__popcll(H));
-            ccount += static_cast<uint32_t>(__popcll(VB));
-            const bool last = tu + 64u >= tend;
-            while (ccount - cdone >= 64u || (last && ccount != cdone)) {
-                __builtin_amdgcn_wave_barrier();   // (the ring's words: written above, read here)
-                const uint32_t n_live = min(64u, ccount - cdone);
-                const uint32_t e = (cdone + lane) & (kFcRing - 1u);
-                const uint32_t cref = lane < n_live ? s_ref[e] : 0u;
-                const uint32_t cg = s_g[e], cr = lane < n_live ? s_r[e] : 0xffffffffu;
-                typename Rows::Row row = rows.load(cref);
-                const uint32_t before = __builtin_amdgcn_update_dpp(0xffffffffu, cr, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0: none)
-                const uint64_t Hc = k_ballot(lane < n_live && (lane == 0u || cr != before));
-                // whole reads only: the last read of a full window may go on in the entries to come
-                const bool final_window = last && ccount - cdone <= 64u;
-                const uint32_t X = final_window ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(Hc));
-                __builtin_amdgcn_wave_barrier();   // (every lane has read its entry before the ring is written again)
-                if (X == 0u) {   // 64 valid targets of one read (or more): the slot goes through the walk that takes any length
-                    whole_reads_walk = true;
-                    break;
+                for (uint32_t k = 1; k < kFcBatch; ++k) {
+                    wu = u == k ? w[k] : wu;
+                    gu = u == k ? g[k] : gu;
+                    bu = u == k ? bits[k] : bu;
                 }
-                compact_window(rows, out, lane, X, Hc, cref, cg, cr, row, s_sel);
-                cdone += X;
+                const bool live = tu + lane < tend;
+                const uint32_t ref = wu & 0x7fffffffu;
+                const bool valid = live && ((bu >> (ref & 31u)) & 1u) != 0u;
+                const bool head = live && (wu >> 31) != 0u;
+                const uint64_t H = k_ballot(head), VB = k_ballot(valid);
+                if (valid) {
+                    const uint32_t p = (ccount + mask_rank(VB)) & (kFcRing - 1u);
+                    s_ref[p] = ref;
+                    s_g[p] = gu;
+                    s_r[p] = rcount + mask_rank(H) + (head ? 1u : 0u) - 1u;
+                }
+                rcount += static_cast<uint32_t>(__popcll(H));
+                ccount += static_cast<uint32_t>(__popcll(VB));
+                const bool last = tu + 64u >= tend;
+                while (ccount - cdone >= 64u || (last && ccount != cdone)) {
+                    __builtin_amdgcn_wave_barrier();   // (the ring's words: written above, read here)
+                    const uint32_t n_live = min(64u, ccount - cdone);
+                    const uint32_t e = (cdone + lane) & (kFcRing - 1u);
+                    const uint32_t cref = lane < n_live ? s_ref[e] : 0u;
+                    const uint32_t cg = s_g[e], cr = lane < n_live ? s_r[e] : 0xffffffffu;
+                    typename Rows::Row row = rows.load(cref);
+                    const uint32_t before = __builtin_amdgcn_update_dpp(0xffffffffu, cr, 0x138, 0xf, 0xf, false);   // wave_shr:1 (lane 0: none)
+                    const uint64_t Hc = k_ballot(lane < n_live && (lane == 0u || cr != before));
+                    // whole reads only: the last read of a full window may go on in the entries to come
+                    const bool final_window = last && ccount - cdone <= 64u;
+                    const uint32_t X = final_window ? n_live : 63u - static_cast<uint32_t>(__builtin_clzll(Hc));
+                    __builtin_amdgcn_wave_barrier();   // (every lane has read its entry before the ring is written again)
+                    if (X == 0u) {   // 64 valid targets of one read (or more): the slot goes through the walk that takes any length
+                        whole_reads_walk = true;
+                        break;
+                    }
+                    compact_window(rows, out, lane, X, Hc, cref, cg, cr, row, s_sel);
+                    cdone += X;
+                }
+                if (whole_reads_walk) break;
             }
         }
-        if (!slot_ends) {
-            t += 64u * kFcBatch;
-            continue;
-        }
-        // ---- the slot's end
         __builtin_amdgcn_wave_barrier();
         if (whole_reads_walk) {   // (rare: left to k_filter_walk, a kernel of its own -- inlined, its registers would be this kernel's)
             if (lane == 0u) redo[atomicAdd(&out.counters[CNT_REDO], 1u)] = slot;
@@ -883,16 +871,6 @@ __global__ __launch_bounds__(64, 8) void k_filter_compact(const uint32_t* __rest
             }
         }
         __builtin_amdgcn_wave_barrier();
-        slot += gridDim.x;
-        d = dn;
-        rb = rbn;
-        t = d.x;
-        tend = d.x + d.y;
-        rcount = ccount = cdone = 0;
-        whole_reads_walk = d.z > kFcReads;
-        const uint32_t ahead = slot + gridDim.x;
-        dn = ahead < nslots ? slots[ahead] : none;
-        rbn = ahead < nslots ? out.rbase[ahead] + out.bbase[ahead >> 10] : 0u;
     }
 }
 
@@ -1124,7 +1102,10 @@ void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_
     out.pair_mask = a.pair_mask;
     out.taxon_base = a.taxon_base;
     out.counters = a.counters;
-    // one wave per workgroup, one slot at a time, however many workgroups that makes (the dispatcher backfills wave by wave)
+    // one wave per workgroup, one slot at a time, however many workgroups that makes: the dispatcher backfills wave by wave.
+    // (Measured and dropped in round 6, profiles/round6/03_filter_variants.txt: persistent waves walking their slots as one
+    // stream of batches with the next slot's first batch asked for ahead -- 3 to 4 % slower, and with the descriptors two slots
+    // ahead the registers spill; 2 / 8 chunks per trip: the same; row gathers or the target words past the L1: slower.)
     const uint32_t grid = a.nslots;
     if (a.rows16) {
         Rows16 r;
@@ -1134,7 +1115,7 @@ void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_
         if (a.valid_bits) {
             hipExtLaunchKernelGGL(k_filter_compact<Rows16>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots,
                                   a.nslots, a.valid_bits, a.redo, r, out);
-            hipLaunchKernelGGL(k_filter_walk<Rows16>, dim3(std::min(grid, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
+            hipLaunchKernelGGL(k_filter_walk<Rows16>, dim3(std::min(a.nslots, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
         } else
             hipExtLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
                                   a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
@@ -1145,7 +1126,7 @@ void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_
         if (a.valid_bits) {
             hipExtLaunchKernelGGL(k_filter_compact<Rows32>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots,
                                   a.nslots, a.valid_bits, a.redo, r, out);
-            hipLaunchKernelGGL(k_filter_walk<Rows32>, dim3(std::min(grid, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
+            hipLaunchKernelGGL(k_filter_walk<Rows32>, dim3(std::min(a.nslots, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
         } else
             hipExtLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
                                   a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
@@ -1288,13 +1269,3 @@ void launch_merge_summary(hipStream_t st, const uint32_t* gathered, uint64_t ran
 
 }  // namespace slimm
 
-#if defined(EXP) && EXP == 7
-extern "C" int slimm_debug_prof_filter(unsigned long long* out, int reset) {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(slimm::g_prof_f), sizeof(unsigned long long) * 8);
-    if (reset) {
-        unsigned long long z[8] = {0};
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(slimm::g_prof_f), z, sizeof(z));
-    }
-    return e == hipSuccess ? 0 : -1;
-}
-#endif

@@ -62,6 +62,11 @@ const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+    *v = 3;   // (a few persistent workgroups: grid-stride loops get their second trip)
+    return hipSuccess;
+}
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamDestroy(hipStream_t s);

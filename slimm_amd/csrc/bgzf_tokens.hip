@@ -362,8 +362,15 @@ constexpr uint32_t kRing = 16;    // steps of records between the two waves (a b
 constexpr uint32_t kBurst = 8;
 constexpr int kWriterNap = 16, kDecoderNap = 4;   // s_sleep units of 64 cycles between two looks at the other wave's counter
 
-__device__ __forceinline__ uint32_t lds_now(const uint32_t* p) { return *reinterpret_cast<const volatile uint32_t*>(p); }
-__device__ __forceinline__ void lds_set(uint32_t* p, uint32_t v) { *reinterpret_cast<volatile uint32_t*>(p) = v; }
+// The hand-over words between the two waves: an ACQUIRE load / a RELEASE store at workgroup scope, so that the ring's plain
+// stores stay in front of the counter that announces them and its plain loads behind the counter that admits them (ADVICE
+// round 5: `volatile` orders only against other volatile accesses; on gfx950 the fences cost an s_waitcnt lgkmcnt).
+__device__ __forceinline__ uint32_t lds_now(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_set(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // TWO waves per 64 blocks.  Wave 0, the DECODER: headers, tables, the symbol steps -- and nothing of what becomes of a symbol.
 // Wave 1, the WRITER: the literals gathered four to a store, the match tokens, the bounds of the output, every store.  A

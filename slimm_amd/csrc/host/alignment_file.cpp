@@ -148,6 +148,10 @@ struct StageClock {  // SLIMM_TRACE=cli: where the reader's time goes, printed w
 };
 }  // namespace
 AlignmentFile::~AlignmentFile() { close(); }
+bool AlignmentFile::regular_file() const {
+    struct stat sb;
+    return fp_ && fstat(fileno(fp_), &sb) == 0 && S_ISREG(sb.st_mode);
+}
 AlignmentFile::Settings& AlignmentFile::settings() {
     static Settings s;
     return s;

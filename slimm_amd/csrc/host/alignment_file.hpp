@@ -105,6 +105,7 @@ public:
     // read_batch / read_into afterwards.
     long read_text(uint8_t* dst, size_t cap);
     bool can_read_text() const { return !bam_ && fp_ != nullptr; }
+    bool regular_file() const;   // (read_text and the mapped reads want one; a pipe or a device goes through the buffered reads)
     // after a read_raw that returned bytes: nothing will follow them (false may also mean "not known yet")
     bool raw_exhausted() const { return raw_stage_ == 2 ? eof_ : (raw_stage_ == 1 && eof_ && raw_off_ >= spare_.size()); }
 

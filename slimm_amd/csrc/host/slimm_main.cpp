@@ -549,7 +549,8 @@ struct RecordPump {
     RecordPump(AlignmentFile& f, bool check_words, bool device_decode, const Options& o)
         : bam(f), want_check(check_words),
           marked(!check_words && !o.verify_grouping && !o.packed_records),
-          raw(device_decode && !o.verify_grouping && !o.packed_records && !o.host_decode) {
+          // (SAM text from anything but a regular file -- a pipe -- goes through the host decoder's buffered reads)
+          raw(device_decode && !o.verify_grouping && !o.packed_records && !o.host_decode && (f.is_bam() || f.regular_file())) {
         device_period = o.device_inflate;
         device_window = std::min<size_t>(10 * raw_cap(), 1900u << 20);
         th = std::thread([this] { raw ? run_raw() : run(); });  // (in the body: every member is initialised by now)

@@ -85,9 +85,12 @@ __global__ __launch_bounds__(64) void k_sam_pieces(const uint8_t* __restrict__ b
             } else if (ch == '\n') {
                 if (in_line) {
                     const uint32_t first = b[start];
-                    const bool record = at > start && first != '@' && tabs >= 9u;   // (the host reader: < 10 fields is an error)
+                    // (a line that ends in CR LF: the host reader strips the CR -- such a file is the host decoder's, like a
+                    // header line or an empty line among the alignment lines)
+                    const bool crlf = at > start && b[at - 1] == '\r';
+                    const bool record = at > start && first != '@' && tabs >= 9u && !crlf;   // (the host reader: < 10 fields is an error)
                     if (n < kBamSlots) po[n] = start | (record ? 0u : 0x80000000u);
-                    if (!record) pc.flags |= (at > start && first != '@') ? kBamPieceBad : kSamPieceSkip;
+                    if (!record) pc.flags |= (at > start && first != '@' && !crlf) ? kBamPieceBad : kSamPieceSkip;
                     ++n;
                     pc.stop = static_cast<uint32_t>(at + 1);
                 }
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(64) void k_sam_pieces(const uint8_t* __restrict__ b
         if (p != end) p += nb;
     }
     pc.count = n < kBamSlots ? n : kBamSlots;
-    if (n > kBamSlots) pc.flags = kBamPieceBad;
+    if (n > kBamSlots) pc.flags = kSamPieceSkip;   // (more lines than a piece of records can hold: lines of < 18 bytes, the host reader's to judge)
     pieces[c] = pc;
 }
 

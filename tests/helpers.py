@@ -36,7 +36,7 @@ def assert_profiles_match(got_text: str, want_text: str, check_lineage: bool = T
     # of the sum alone: a row `<parent>*` with read_count 0 and an abundance inside the tolerance below is there or not
     # there by that order, on both sides (found by scripts/stress_bgzf.py, seed 6061).  Such rows may be on one side only.
     def residue(rows, k):
-        return k.endswith("*") and k != "0*" and rows[k][1] == 0 and abs(rows[k][0]) <= 2e-5
+        return k.endswith("*") and k != "0*" and rows[k][1] == 0 and abs(rows[k][0]) <= 2e-6   # (a few float32 steps at a few per cent)
     only_got = {k for k in set(got) - set(want) if not residue(got, k)}
     only_want = {k for k in set(want) - set(got) if not residue(want, k)}
     assert not only_got and not only_want, f"profile rows differ: only got {only_got}, only want {only_want}"

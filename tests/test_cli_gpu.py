@@ -371,6 +371,24 @@ def test_cli_decodes_bam_records_on_the_device_and_on_the_host_alike(tmp_path, m
         check_outputs(str(tmp_path / f"{stem}_0") + "/", stem, want)
 
 
+def test_cli_sam_text_with_cr_lf_line_ends_goes_to_the_host_decoder(tmp_path):
+    """the host reader strips a CR in front of the newline; on the device such a line was "fewer than 10
+    fields".  The device now hands such a file to the host decoder like a header line among the alignments: same outputs."""
+    w = with_names(make_workload(CONFIGS["config1"], seed=52, n_records=4_000))
+    db = str(tmp_path / "db.sldb")
+    write_sldb(db, w.taxonomy)
+    unix = str(tmp_path / "unix.sam")
+    write_sam(unix, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
+    dos = str(tmp_path / "sample.sam")
+    open(dos, "wb").write(open(unix, "rb").read().replace(b"\n", b"\r\n"))
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-ro", "-co", db, dos])
+    assert "decoding on the host" in err
+    o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=True, want_cov=True)
+    check_outputs(out, "sample", o)
+
+
 def test_cli_falls_back_to_the_host_decoder_for_a_record_longer_than_16_mib(tmp_path):
     """The device decoder carries an incomplete record of up to 16 MiB from one window to the next; a file with a longer
     one across windows (a sequence of 16 M bases: 24 MB) is decoded on the host after all -- same outputs as the oracle's.  With

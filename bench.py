@@ -45,6 +45,7 @@ ONE JSON line on rank 0.  Beside the contract's fields:
 import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -142,6 +143,51 @@ def pmc_traffic_bytes(kernel_name, workload):
     return None
 
 
+def cli_one_billion(records: int) -> dict:
+    """`slimm DB IN.bam` on the 1 B-record realistic BAM (scripts/cli_1B.py, a process of its own): M records/s of the runs,
+    the stage trace of the best one, device memory in use and the host's peak resident set."""
+    import re
+    need = records * 80
+    room = max((shutil.disk_usage(d).free for d in ("/dev/shm", "/tmp") if os.path.isdir(d)), default=0)
+    mem_free = None
+    try:
+        mx = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read())
+        mem_free = (int(mx) - cur) if mx != "max" else None
+    except (OSError, ValueError):
+        pass
+    if room < need * 1.05:
+        return {"skipped": f"no scratch room for the file: {need / 1e9:.0f} GB needed, {room / 1e9:.0f} GB free in /dev/shm and /tmp"}
+    if mem_free is not None and mem_free < need + (40 << 30):
+        return {"skipped": f"the memory cgroup has {mem_free / 1e9:.0f} GB left; the file in /dev/shm needs {need / 1e9:.0f} GB + 40"}
+    t0 = time.time()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cli_1B.py"), str(records), "-", "one"], capture_output=True,
+                           text=True, timeout=1200)
+    except subprocess.TimeoutExpired:
+        return {"error": "scripts/cli_1B.py did not finish in 1200 s"}
+    out = r.stdout
+    runs = [(float(a), float(b)) for a, b in re.findall(r"run \d+\]: ([0-9.]+) s = ([0-9.]+) M records/s", out)]
+    if r.returncode != 0 or not runs:
+        return {"error": (out[-300:] + r.stderr[-300:])}
+    built = re.search(r"== (\d+) records, ([0-9.]+) GB of BAM in ([0-9.]+) GB = ([0-9.]+) x .* built in (\d+) s in (\S+)", out)
+    mem = re.search(r"device memory in use ([0-9.]+) GB of (\d+) GB \(window pipeline ([0-9.]+) GB\); host peak resident set ([0-9.]+) GB", out)
+    best = min(runs)
+    trace_lines = [ln.strip() for ln in out.split("run %d]" % (runs.index(best) + 1))[-1].splitlines() if "[trace]" in ln][:16]
+    o = {"value": best[1], "unit": "M records/s", "seconds": best[0], "runs_M_records_s": [b for _, b in runs],
+         "what": "`slimm -w 1000 DB IN.bam`, process start to profile written, on the headline stream as ONE realistic BAM "
+                 "(scripts/cli_1B.py); the first run reads a file that was just written, the second the same file again",
+         "took_s": round(time.time() - t0, 1),
+         "trace": [t for t in trace_lines if any(k in t for k in ("slimm_create", "device decode", "reader:", "rest of read", "slimm_destroy"))]}
+    if built:
+        o.update({"records": int(built.group(1)), "bam_GB": float(built.group(3)), "compression_ratio": float(built.group(4)),
+                  "built_in_s": int(built.group(5)), "where": built.group(6)})
+    if mem:
+        o.update({"device_memory_in_use_GB": float(mem.group(1)), "window_pipeline_GB": float(mem.group(3)),
+                  "host_peak_rss_GB": float(mem.group(4))})
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +247,8 @@ def main():
     ap.add_argument("--cpu-mt-sample", type=int, default=100_000_000, help="records the all-core CPU restatement is timed on")
     ap.add_argument("--no-cli", action="store_true", help="skip the `slimm DB IN.bam` end-to-end leg")
     ap.add_argument("--cli-records", type=int, default=100_000_000)
+    ap.add_argument("--no-cli-1b", action="store_true", help="skip the command on the 1 B-record BAM (cli_end_to_end.one_billion)")
+    ap.add_argument("--cli-1b-records", type=int, default=1_000_000_000)
     args = ap.parse_args()
 
     # `python bench.py --gpus N` with N > 1 and no launcher around it: this process -- which has not touched a GPU and never
@@ -1060,6 +1108,12 @@ def main():
                 os.unlink(bam)
             except OSError:
                 pass
+            shutil.rmtree(tmp, ignore_errors=True)
+            # the command on the 1 B-record BAM north_star names (BASELINE.json configs[3]; ~78 GB, built once per run in
+            # /dev/shm or /tmp: ~5 min): scripts/cli_1B.py in a process of its own, skipped -- with the reason -- when there is no
+            # room for the file or the memory for it
+            if isinstance(cli, dict) and "error" not in cli and not args.no_cli_1b:
+                cli["one_billion"] = cli_one_billion(args.cli_1b_records)
 
         line = {
             "metric": "M alignment-records/sec -> final profile",

@@ -1,7 +1,7 @@
 """`slimm DB IN.bam` on the 1 B-record BAM north_star names (BASELINE.json configs[3]: 1 B records, 20 k references, mean 8
 hits per read) -- VERDICT round 5, item 3; replaces seqan::BamFileIn + the record loop of the reference
 (src/slimm.hpp:946-968, src/misc.hpp:498-522).
-    python scripts/cli_1B.py [records] [dir]
+    python scripts/cli_1B.py [records] [dir | -] [one]          (`one`: the single-device runs only -- bench.py's leg)
 Builds the file once with realistic content (slimm_amd/synth_bam.py, realistic=True: ~78 bytes per record compressed, 3.0 x),
 the stream of bench.py's headline (chunk c = stream_chunk(config4, seed 1, c)), generated chunk by chunk so that the records
 never stand in memory together; runs the command on one device and with `--devices 0,0` (the dealing path), and prints M
@@ -20,7 +20,8 @@ want = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 CHUNK = 10_000_000
 BYTES_PER_RECORD = 79.5        # measured on the 100 M-record file: 7.80 GB
 
-dirs = [sys.argv[2]] if len(sys.argv) > 2 else [d for d in ("/tmp", "/dev/shm", os.environ.get("TMPDIR", "")) if d and os.path.isdir(d)]
+only_one = len(sys.argv) > 3 and sys.argv[3] == "one"
+dirs = [sys.argv[2]] if len(sys.argv) > 2 and sys.argv[2] != "-" else [d for d in ("/tmp", "/dev/shm", os.environ.get("TMPDIR", "")) if d and os.path.isdir(d)]
 free = {d: shutil.disk_usage(d).free for d in dirs}
 print("free space:", {d: f"{v / 1e9:.1f} GB" for d, v in free.items()}, flush=True)
 where = max(free, key=free.get)
@@ -80,7 +81,7 @@ try:
     cli = os.path.join(ROOT, "slimm_amd", "slimm")
     out = os.path.join(tmp, "out"); os.makedirs(out)
     profiles = []
-    for label, extra in (("one device", []), ("--devices 0,0", ["--devices", "0,0"])):
+    for label, extra in ((("one device", []),) if only_one else (("one device", []), ("--devices 0,0", ["--devices", "0,0"]))):
         for rep in range(2):
             t0 = time.time()
             r = subprocess.run([cli] + extra + ["-w", "1000", "-o", out + "/", db, bam], capture_output=True, text=True,

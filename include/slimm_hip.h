@@ -264,6 +264,13 @@ int slimm_pin_host_buffer(slimm_ctx* ctx, const void* buffer, uint64_t n_bytes);
  * until slimm_reset().  Replaces anything pushed before. */
 int slimm_set_records_device(slimm_ctx* ctx, const uint64_t* d_read_key, const int32_t* d_ref_id,
                              const int32_t* d_begin_pos, const uint16_t* d_flag, uint64_t n);
+/* The device arrays of the records a context holds after its pushes, whatever brought them there (decoded records, or the
+ * window pipeline's decoders): for a caller that hands stretches of them to other contexts (slimm_set_records_device*) -- a
+ * group that lets ONE member read and decode a file does (slimm_group_get_profiles).  *form: 0 four arrays, 1 packed
+ * (d_flag NULL), 2 run-marked (d_read_key and d_flag NULL, d_ref_id holds the words).  Waits for the context's copies and
+ * decode kernels; the pointers stay valid until slimm_reset / slimm_destroy. */
+int slimm_records_device(slimm_ctx* ctx, const uint64_t** d_read_key, const int32_t** d_ref_id, const int32_t** d_begin_pos,
+                         const uint16_t** d_flag, uint64_t* n, int* form);
 
 /* ---- phase A: slimm::analyze_alignments() (src/slimm.hpp:191-303) on this context's records:
  * grouping by read, first-bin per (read, ref), cov / uniq_cov histograms.  Local to this GPU. */
@@ -528,6 +535,11 @@ enum { SLIMM_EXCHANGE_AUTO = 0, SLIMM_EXCHANGE_SUMMARY = 1, SLIMM_EXCHANGE_SLICE
 int slimm_group_set_exchange(slimm_group* g, int mode);
 int slimm_group_exchange(const slimm_group* g); /* the form in effect (what AUTO resolves to) */
 int slimm_group_get_profiles(slimm_group* g, const char* path); /* path may be NULL; SLIMM_E_NO_HITS like slimm_get_profiles */
+/* A GROUPED file may also reach a group through ONE member: push its windows to slimm_group_context(g, 0) (slimm_push_bam_bytes /
+ * _bgzf_blocks / _sam_bytes: the device inflates and decodes at the single-context rate) and nothing through
+ * slimm_group_push_records*; slimm_group_get_profiles then deals member 0's run-marked records to the members in contiguous
+ * stretches cut at qName-run starts, device to device (8 bytes per record), before phase A.  SLIMM_E_REGROUP from member 0
+ * (Q18) comes back as the group's return code: such a file goes through slimm_group_push_records* in any order. */
 
 /* Starts the HIP runtime on `device` (what the first slimm_create of a process would otherwise pay, 0.1 - 0.3 s): for
  * hosts that call it from a thread of their own while they load their database and open their input. */

@@ -157,6 +157,7 @@ SYMBOLS = [
     ("slimm_bgzf_inflate", C.c_int, [C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_char_p, C.c_uint64]),
     ("slimm_bgzf_inflate_with", C.c_int, [C.c_int, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_char_p,
                                           C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("slimm_records_device", C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     ("slimm_pin_host_buffer", C.c_int, [_P, _P, C.c_uint64]),
     ("slimm_set_input_size_hint", C.c_int, [_P, C.c_uint64]),
     ("slimm_window_memory", C.c_int, [_P, C.POINTER(C.c_uint64)]),

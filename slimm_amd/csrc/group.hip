@@ -86,6 +86,16 @@ __global__ __launch_bounds__(256) void k_group_sum(const uint32_t* __restrict__ 
     }
 }
 
+// cuts[i] = the first qName-run start at or behind record i * n / G of run-marked records (n when there is none): the
+// members' stretches of a file that member 0 decoded (partition.py: contiguous_cuts, on the device)
+__global__ __launch_bounds__(64) void k_group_cuts(const uint32_t* __restrict__ word, uint64_t n, uint32_t G, uint64_t* __restrict__ cuts) {
+    for (uint32_t i = threadIdx.x; i <= G; i += 64u) {
+        uint64_t c = i == G ? n : (static_cast<uint64_t>(i) * n) / G;
+        while (c != 0 && c < n && (word[c] >> 31) == 0u) ++c;
+        cuts[i] = c;
+    }
+}
+
 }  // namespace
 
 struct slimm_group {
@@ -93,6 +103,9 @@ struct slimm_group {
     std::vector<int> device;
     std::vector<hipStream_t> stream;
     std::vector<hipEvent_t> ready, copied;   // per member: "my buffer is written" / "I have read everybody's buffer"
+    std::vector<uint32_t*> dealt_word;       // per member: its stretch of a file member 0 decoded (deal_from_member0)
+    std::vector<int32_t*> dealt_pos;
+    std::vector<size_t> dealt_cap;
     std::vector<uint32_t*> scratch;          // per member: n x words receive buffer
     std::vector<size_t> scratch_words;
     std::vector<Rccl::comm_t> comm;
@@ -444,6 +457,9 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
         g->stream.push_back(static_cast<hipStream_t>(s));
         g->scratch.push_back(nullptr);
         g->scratch_words.push_back(0);
+        g->dealt_word.push_back(nullptr);
+        g->dealt_pos.push_back(nullptr);
+        g->dealt_cap.push_back(0);
         hipEvent_t a = nullptr, b = nullptr;
         (void)hipSetDevice(devices[i]);
         if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
@@ -491,6 +507,8 @@ void slimm_group_destroy(slimm_group* g) {
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         (void)hipSetDevice(g->device[i]);
         if (i < g->scratch.size() && g->scratch[i]) (void)hipFree(g->scratch[i]);
+        if (i < g->dealt_word.size() && g->dealt_word[i]) (void)hipFree(g->dealt_word[i]);
+        if (i < g->dealt_pos.size() && g->dealt_pos[i]) (void)hipFree(g->dealt_pos[i]);
         if (i < g->ready.size() && g->ready[i]) (void)hipEventDestroy(g->ready[i]);
         if (i < g->copied.size() && g->copied[i]) (void)hipEventDestroy(g->copied[i]);
         slimm_destroy(g->ctx[i]);
@@ -546,6 +564,67 @@ int slimm_group_exchange(const slimm_group* g) {  // what AUTO means for this gr
     return (g->ctx.size() > 2 && can_slice) ? SLIMM_EXCHANGE_SLICED : SLIMM_EXCHANGE_SUMMARY;
 }
 
+// Member 0 holds a GROUPED file it decoded itself (its windows were pushed to slimm_group_context(g, 0)) and nothing was
+// dealt through slimm_group_push_records*: the members' stretches are cut at qName-run starts on the device and copied device to
+// device -- 8 bytes per record; member 0 keeps the first one where it lies.
+static int deal_from_member0(slimm_group* g) {
+    const uint32_t G = static_cast<uint32_t>(g->ctx.size());
+    const uint64_t* key = nullptr;
+    const int32_t *ref = nullptr, *pos = nullptr;
+    const uint16_t* flag = nullptr;
+    uint64_t n = 0;
+    int form = 0;
+    GTRY(g, 0, slimm_records_device(g->ctx[0], &key, &ref, &pos, &flag, &n, &form));
+    if (n == 0 || form != 2) return SLIMM_OK;   // (nothing there, or not run-marked records: as pushed)
+    for (uint32_t i = 1; i < G; ++i) {
+        uint64_t ni = 0;
+        int fi = 0;
+        const uint64_t* k2;
+        const int32_t *r2, *p2;
+        const uint16_t* f2;
+        GTRY(g, i, slimm_records_device(g->ctx[i], &k2, &r2, &p2, &f2, &ni, &fi));
+        if (ni) return SLIMM_OK;                // (the caller dealt records itself)
+    }
+    GHIP(g, hipSetDevice(g->device[0]));
+    uint64_t* d_cuts = nullptr;
+    GHIP(g, hipMalloc(reinterpret_cast<void**>(&d_cuts), (G + 1) * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_group_cuts, dim3(1), dim3(64), 0, g->stream[0], reinterpret_cast<const uint32_t*>(ref), n, G, d_cuts);
+    std::vector<uint64_t> cuts(G + 1);
+    hipError_t e = hipMemcpyAsync(cuts.data(), d_cuts, (G + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream[0]);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream[0]);
+    (void)hipFree(d_cuts);
+    if (e != hipSuccess) return gfail(g, SLIMM_E_HIP, "deal_from_member0: %s", hipGetErrorString(e));
+    for (uint32_t i = 1; i <= G; ++i) cuts[i] = std::max(cuts[i], cuts[i - 1]);
+    for (uint32_t i = 1; i < G; ++i) {
+        const uint64_t lo = cuts[i], ni = cuts[i + 1] - cuts[i];
+        GHIP(g, hipSetDevice(g->device[i]));
+        if (g->dealt_cap[i] < ni) {
+            if (g->dealt_word[i]) (void)hipFree(g->dealt_word[i]);
+            if (g->dealt_pos[i]) (void)hipFree(g->dealt_pos[i]);
+            g->dealt_word[i] = nullptr;
+            g->dealt_pos[i] = nullptr;
+            g->dealt_cap[i] = 0;
+            GHIP(g, hipMalloc(reinterpret_cast<void**>(&g->dealt_word[i]), (ni + 16) * 4));
+            GHIP(g, hipMalloc(reinterpret_cast<void**>(&g->dealt_pos[i]), (ni + 16) * 4));
+            g->dealt_cap[i] = ni;
+        }
+        if (ni) {
+            GHIP(g, hipMemcpyPeerAsync(g->dealt_word[i], g->device[i], ref + lo, g->device[0], ni * 4, g->stream[i]));
+            GHIP(g, hipMemcpyPeerAsync(g->dealt_pos[i], g->device[i], pos + lo, g->device[0], ni * 4, g->stream[i]));
+        }
+        GTRY(g, i, slimm_set_records_device_marked(g->ctx[i], g->dealt_word[i], g->dealt_pos[i], ni));
+    }
+    // (member 0 goes on only when its peers have read their stretches: its arrays are its own again after the file)
+    for (uint32_t i = 1; i < G; ++i) {
+        GHIP(g, hipSetDevice(g->device[i]));
+        GHIP(g, hipEventRecord(g->copied[i], g->stream[i]));
+    }
+    GHIP(g, hipSetDevice(g->device[0]));
+    for (uint32_t i = 1; i < G; ++i) GHIP(g, hipStreamWaitEvent(g->stream[0], g->copied[i], 0));
+    GTRY(g, 0, slimm_set_records_device_marked(g->ctx[0], reinterpret_cast<const uint32_t*>(ref), pos, cuts[1]));
+    return SLIMM_OK;
+}
+
 // slimm::get_profiles() (src/slimm.hpp:447-489) over the members' reads: phases A, B, C(1) on every member with the two
 // exchanges in between, propagation and the profile on member 0 (every member holds the same merged results).
 int slimm_group_get_profiles(slimm_group* g, const char* path) {
@@ -553,6 +632,10 @@ int slimm_group_get_profiles(slimm_group* g, const char* path) {
     const uint32_t n = static_cast<uint32_t>(g->ctx.size());
     int rc = flush_carry(g, g->cur);
     if (rc != SLIMM_OK) return rc;
+    if (n > 1 && g->order == SLIMM_ORDER_GROUPED) {
+        rc = deal_from_member0(g);
+        if (rc != SLIMM_OK) return rc;
+    }
     if (n == 1 && !g->use_rccl) {  // (a group of one with RCCL forced goes the long way: the test of the RCCL calls)
         rc = slimm_get_profiles(g->ctx[0], path);
         if (rc < 0) return member_failed(g, 0, rc, "slimm_get_profiles");

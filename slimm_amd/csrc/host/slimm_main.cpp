@@ -139,6 +139,7 @@ SLIMM_FORWARD(int, slimm_group_push_records_packed,
 SLIMM_FORWARD(int, slimm_group_push_records,
               (slimm_group* a, const uint64_t* b, const int32_t* c, const int32_t* d, const uint16_t* e, uint64_t f_), (a, b, c, d, e, f_))
 SLIMM_FORWARD(int, slimm_group_get_profiles, (slimm_group* a, const char* b), (a, b))
+SLIMM_FORWARD(int, slimm_group_reset, (slimm_group* a), (a))
 #include "accession.hpp"
 #include "alignment_file.hpp"
 #include "sldb.hpp"
@@ -953,7 +954,9 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
     // (grouped streams are exact already: the reader compares the names of adjacent records)
     const bool check_words = record_order == SLIMM_ORDER_ANY;
     // decoding starts now; the records are claimed further down, when the context exists (one context: the device decodes)
-    RecordPump pump(bam, check_words, options.devices.size() <= 1, options);
+    // (a group takes a GROUPED file through member 0's device decoders and deals the records device to device afterwards:
+    // slimm_group_get_profiles; any other order: the host reader deals them by key)
+    RecordPump pump(bam, check_words, options.devices.size() <= 1 || record_order == SLIMM_ORDER_GROUPED, options);
 
     std::cerr << "Intializing coverages for all reference genome ... ";
     const uint32_t R = static_cast<uint32_t>(bam.ref_names().size());
@@ -1015,10 +1018,37 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
         std::cerr << "[" << watch.lap() << " secs]" << std::endl;
         std::cerr << "Analysing alignments on " << options.devices.size() << " devices ("
                   << (slimm_group_uses_rccl(grp) ? "RCCL" : "copy") << " collectives) ... ";
-        const bool pushed = pump.attach_group(grp) && pump.finish();
+        if (pump.raw) {   // the file's size: what member 0 sizes its window buffers by
+            struct stat fst;
+            if (stat(path.c_str(), &fst) == 0 && S_ISREG(fst.st_mode)) (void)slimm_set_input_size_hint(c0, static_cast<uint64_t>(fst.st_size));
+        }
+        bool pushed = (pump.raw ? pump.attach(c0) : pump.attach_group(grp)) && pump.finish();
+        long read_rc = pump.read_rc;
+        if (trace.on && pump.raw)
+            fprintf(stderr, "[trace] device decode on member 0: slimm_push_bam_bytes %.2f ms for %llu records, pusher waited %.2f ms for windows\n",
+                    pump.raw_push_ms, static_cast<unsigned long long>(pump.raw_records), pump.wait_ms);
+        if (!pushed && pump.raw && read_rc >= 0 &&
+            (strstr(slimm_last_error(c0), "decode this file on the host") || strstr(slimm_last_error(c0), "fewer than 2^31 records"))) {
+            // a record longer than the device decoder's carry, or more records than ONE context takes: the host reader deals them
+            std::cerr << "(" << slimm_last_error(c0) << ": decoding on the host) ";
+            if (slimm_group_reset(grp) != SLIMM_OK) {
+                std::cerr << "slimm: " << slimm_group_last_error(grp) << "\n";
+                slimm_group_destroy(grp);
+                return false;
+            }
+            bam.close();
+            if (!bam.open(path)) {
+                std::cerr << bam.error() << "\n";
+                slimm_group_destroy(grp);
+                return false;
+            }
+            RecordPump again(bam, check_words, false, options);
+            pushed = again.attach_group(grp) && again.finish();
+            read_rc = again.read_rc;
+        }
         trace.mark("rest of read + decode + push");
-        if (!pushed || pump.read_rc < 0) {
-            std::cerr << (pushed ? bam.error() : std::string("pushing records: ") + slimm_group_last_error(grp)) << "\n";
+        if (!pushed || read_rc < 0) {
+            std::cerr << (pushed ? bam.error() : std::string("pushing records: ") + (pump.raw ? slimm_last_error(c0) : slimm_group_last_error(grp))) << "\n";
             slimm_group_destroy(grp);
             return false;
         }
@@ -1027,6 +1057,10 @@ bool get_profiles(Session& S, size_t file_index, bool regroup = false) {
             return read_again_in_any_order();
         }
         const int grc = slimm_group_get_profiles(grp, get_tsv_file_name(options.output_prefix, path, "_profile").c_str());
+        if (grc == SLIMM_E_REGROUP) {   // (member 0's decoders counted a run of shortened names only: Q18)
+            slimm_group_destroy(grp);
+            return read_again_in_any_order();
+        }
         if (grc < 0) {
             std::cerr << "slimm: " << slimm_group_last_error(grp) << "\n";
             slimm_group_destroy(grp);

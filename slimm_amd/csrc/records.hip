@@ -324,6 +324,22 @@ int slimm_set_records_device(slimm_ctx* c, const uint64_t* key, const int32_t* r
     return SLIMM_OK;
 }
 
+int slimm_records_device(slimm_ctx* c, const uint64_t** key, const int32_t** ref, const int32_t** pos, const uint16_t** flag, uint64_t* n,
+                         int* form) {
+    if (!c || !key || !ref || !pos || !flag || !n || !form) return SLIMM_E_INVALID;
+    if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");
+    (void)hipSetDevice(c->device);
+    if (c->copy_pending) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *key = c->rec.key;
+    *ref = c->rec.ref;
+    *pos = c->rec.pos;
+    *flag = c->rec.flag;
+    *n = c->rec.n;
+    *form = c->rec.marked ? 2 : (c->rec.packed ? 1 : 0);
+    return SLIMM_OK;
+}
+
 int slimm_set_records_device_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, const int32_t* pos, uint64_t n) {
     if (!c) return SLIMM_E_INVALID;
     if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context has no record stream");

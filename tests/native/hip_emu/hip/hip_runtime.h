@@ -88,6 +88,9 @@ static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 #define hipHostRegisterDefault 0
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+static inline hipError_t hipMemcpyPeerAsync(void* dst, int, const void* src, int, size_t n, hipStream_t s) {
+    return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
+}
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipGetLastError();

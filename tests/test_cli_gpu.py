@@ -237,22 +237,26 @@ def test_cli_two_names_with_one_hash_are_two_reads(tmp_path):
 
 def test_cli_devices_runs_a_group(tmp_path):
     """--devices 0,0,0: three contexts in one process behind slimm_group_* (on the one GPU of the test box the collectives
-    run in their copy form); the profile must be the single-device one."""
+    run in their copy form); the profile must be the single-device one.  A GROUPED file goes through member 0's device decoders
+    and is dealt to the members device to device at qName-run starts (round 6; windows of 1 MiB here, so that the dealt
+    stretches come out of many windows); with --host-decode the host reader deals the records as in rounds 2 - 5."""
     w = with_names(make_workload(CONFIGS["config1"], seed=44))
     db = str(tmp_path / "db.sldb")
     write_sldb(db, w.taxonomy)
     inp = str(tmp_path / "sample.bam")
     write_bam(inp, w.ref_names, w.ref_len, w.records, read_len=w.avg_read_len)
-    outs = []
-    for tag, extra in (("one", []), ("group", ["--devices", "0,0,0"])):
+    outs, errs = [], []
+    for tag, extra in (("one", []), ("group", ["--devices", "0,0,0", "--window-mb", "1"]), ("group_host", ["--devices", "0,0,0", "--host-decode"])):
         out = str(tmp_path / tag) + "/"
         os.makedirs(out)
-        err = run_cli(["-w", str(w.options.bin_width), "-o", out, "-v"] + extra + [db, inp])
+        errs.append(run_cli(["-w", str(w.options.bin_width), "-o", out, "-v"] + extra + [db, inp], env=dict(os.environ, SLIMM_TRACE="cli")))
         outs.append(open(os.path.join(out, "sample_profile.tsv")).read())
     o = Oracle(w.taxonomy, w.options).run(w.ref_names, w.ref_len, w.records, w.avg_read_len, want_raw=False)
-    assert_profiles_match(outs[0], o.profile_tsv)
-    assert_profiles_match(outs[1], o.profile_tsv)
-    assert "3 devices (copy collectives)" in err and f"{o.scalars['matches']} matching reads" in err
+    for got in outs:
+        assert_profiles_match(got, o.profile_tsv)
+    assert "device decode on member 0" in errs[1] and "device decode on member 0" not in errs[2]
+    for err in errs[1:]:
+        assert "3 devices (copy collectives)" in err and f"{o.scalars['matches']} matching reads" in err
 
 
 def test_cli_unordered_file_with_two_names_under_one_key_fails_loudly(tmp_path):

@@ -124,7 +124,7 @@ def cpu_quota_cores():
     return float(os.cpu_count() or 1)
 
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round5", "pmc_traffic_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round6", "pmc_traffic_summary.json")
 
 
 def pmc_traffic_bytes(kernel_name, workload):
@@ -588,7 +588,7 @@ def main():
         achieved = d["bytes_per_launch"] / (d["ms_per_launch"] * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(dom, workload),
-                "traffic_source": "profiles/round5/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE + "
+                "traffic_source": "profiles/round6/pmc_traffic_summary.json (rocprofv3 --pmc, separate passes; 2 x FETCH_SIZE + "
                                   "WRITE_SIZE)",
                 "bytes_per_launch": int(d["bytes_per_launch"]), "ms_per_launch": round(d["ms_per_launch"], 4)}
         if dom == "k_front":

@@ -215,7 +215,6 @@ struct slimm_ctx {
     DevBuf<uint32_t> group_hist, c_chk, s_chk;
     DevBuf<uint32_t> tgt_ref, tgt_gbin;  // targets (bit 31: first of its read / the read has one target), in slots
     DevBuf<uint4> slots;                 // per kSlotRecs records: {first target, targets, reads, mapped records}
-    DevBuf<uint2> wcut;                  // per slot: {targets, reads} in front of each of its windows (kernels.h)
     DevBuf<uint4> tot_part;              // per workgroup of k_tile_count: totals of its slots (kernels.h: Totals)
     DevBuf<uint16_t> bucket;                            // targets bucketed by bin tile (13-bit bin | unique bit)
     DevBuf<uint32_t> tile_count, tile_base, tile_cursor, split_tiles;

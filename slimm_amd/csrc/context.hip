@@ -48,7 +48,6 @@ int ensure_work_buffers(slimm_ctx* c, uint32_t n) {
     HIP_TRY(c, c->tgt_ref.ensure(n + 1));
     HIP_TRY(c, c->tgt_gbin.ensure(n + 8));  // (+ the reach of the bucketing kernels' 16-byte loads, tile_hist.hip: piece_load)
     HIP_TRY(c, c->slots.ensure(front_slots(n) + 1));
-    HIP_TRY(c, c->wcut.ensure(static_cast<size_t>(front_slots(n) + 1) * kSlotWindows));
     HIP_TRY(c, c->tot_part.ensure(512));
     HIP_TRY(c, c->sel.ensure(n + 8));
     HIP_TRY(c, c->slot_rbase.ensure(front_slots(n) + 8));
@@ -597,14 +596,14 @@ int slimm_analyze_alignments(slimm_ctx* c) {
         }
         {
             KernelTimer t(c, K_FRONT);
-            launch_front_sorted(st, n, c->c_ident.p, c->c_pay.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p, c->slots.p, c->wcut.p,
+            launch_front_sorted(st, n, c->c_ident.p, c->c_pay.p, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p, c->slots.p,
                                 c->rec.check ? c->c_chk.p : nullptr);
         }
     } else {
         // grouped input: one pass straight over the caller's record arrays
         KernelTimer t(c, K_FRONT, true);
         launch_front_raw(st, c->rec, c->R, c->d_geo.p, half_read, hc.bin_width, c->counters.p, c->tgt_ref.p, c->tgt_gbin.p,
-                         c->slots.p, c->wcut.p, t.t0(), t.t1());
+                         c->slots.p, t.t0(), t.t1());
     }
     // Where every slot's reads start among all reads (for k_filter's dense selectors): two small launches on a side
     // stream -- beside k_tile_hist, NOT beside the count and the scatter: those run one persistent workgroup per CU
@@ -992,7 +991,6 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
         fa.tgt_ref = c->tgt_ref.p;
         fa.tgt_gbin = c->tgt_gbin.p;
         fa.slots = c->slots.p;
-        fa.wcut = c->wcut.p;
         fa.nslots = nslots;
         if (c->use_rows16) {
             fa.rows16 = c->d_rows16.p;
@@ -1002,8 +1000,7 @@ int filter_launch(slimm_ctx* c, bool copy_rows) {
             fa.lin_dense = c->d_lin_dense.p;
             fa.valid = c->d_valid.p;
         }
-        const bool by_window = forced("filter_by_window");   // (round 5's k_filter, window by window: A/B runs)
-        fa.valid_bits = by_window ? nullptr : c->d_valid_bits.p;
+        fa.valid_bits = c->d_valid_bits.p;
         fa.redo = c->filter_redo.p;
         fa.sel = c->sel.p;
         fa.slot_rbase = c->slot_rbase.p;

@@ -24,8 +24,7 @@
 //                             bit-reversed masks finds the target in front of every non-head target
 //      and the targets are written compacted behind the slot's first run start (rank = popcount of the lanes below).
 // A slot's targets therefore sit at [start, start + nf) with start = index of its first run start and nf <= the records
-// the slot is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.  The windows'
-// first targets / reads are listed per slot (wcut) so that k_filter can take them up independently of each other.
+// the slot is responsible for: the consumers walk slots, no prefix sum over the stream is ever needed.
 //
 // Three paths per window, chosen by wave-uniform tests:
 //   fast     the mate numbers of every run are non-decreasing (mapper output "all of mate 1, then all of mate 2",
@@ -40,8 +39,6 @@
 //   tgt_ref [p]  reference id | bit 31: first target of its read
 //   tgt_gbin[p]  global bin (bin_off[ref] + bin) | bit 31: the read has exactly one target (src/slimm.hpp:224)
 //   slots   [s]  {start, targets, reads, mapped records} of slot s
-//   wcut    [s * kSlotWindows + i]  {targets, reads} of slot s in front of its window i; the last entry of a slot's row
-//                holds the number of windows, the entry behind the last window the slot's totals
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
@@ -891,7 +888,7 @@ __device__ __forceinline__ void stage_slot(const Acc& acc, uint32_t B, uint32_t 
 template <typename Acc, bool kChk>
 __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_t nslots, uint32_t* __restrict__ counters,
                                                        uint32_t* __restrict__ tgt_ref, uint32_t* __restrict__ tgt_gbin,
-                                                       uint4* __restrict__ slots, uint2* __restrict__ wcut) {
+                                                       uint4* __restrict__ slots) {
     __shared__ uint32_t s_stage[kFrontBlock / 64][2][kStageRecs];
     __shared__ __attribute__((aligned(16))) uint32_t s_tab[kFrontBlock / 64][2 * kHashSlots];  // hash_first's table, one per wave
     const uint32_t N = acc.count(counters);
@@ -904,25 +901,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
     bool bad = false, collide = false;
     for (uint32_t slot = blockIdx.x * (kFrontBlock / 64) + wave; slot < nslots; slot += n_waves) {
         const uint32_t B = slot * kSlotRecs;
-        uint2* const cuts = wcut + static_cast<size_t>(slot) * kSlotWindows;
         WinOut so{B, 0u, 0u, 0u};
-        // The window list for k_filter (wcut): ITS windows are cut here, every <= 64 TARGETS at a read's head -- not one
-        // per window of 64 records: at 0.6 targets per record (config 4) the record windows leave 37 of the filter's 64
-        // lanes busy, and the filter is bound by its vector instructions per window.  A cut is {targets, reads} of the
-        // slot in front of it; lane i keeps cut i (one store of the whole list at the end).  cf = targets in front of the last cut.
-        uint32_t nw = 0;
-        uint32_t cut_f = 0, cut_h = 0;
-        uint32_t cf = 0;
-        bool must_cut = true;  // the next window starts a filter window whatever came before (the slot's first; behind a
-                               // window that stands alone)
-        auto emit = [&](uint32_t f, uint32_t h) {
-            if (nw < kSlotWindows - 2u) {  // (never more than 2 * kSlotRecs / 64 + 2 windows of records: two in a row
-                cut_f = lane == nw ? f : cut_f;  // cover 64 records; a list that is full lets its last window take the
-                cut_h = lane == nw ? h : cut_h;  // rest of the slot, which the filter works through in pieces)
-                ++nw;
-            }
-            cf = f;
-        };
         FPROF_T(f0);
         if (B < N) {
             // ---- 1. stage (the only part that waits for memory; everything a group loads is in flight at once)
@@ -955,36 +934,15 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                     const uint32_t mprev = f_shr1z(mate);
                     const uint64_t V = f_ballot(field != kRefField) & PR;
                     if ((f_ballot(mate < mprev) & ~RS & PR) == 0ull) {
-                        const uint32_t f0 = so.nf, h0 = so.nh;
-                        if (must_cut) {
-                            emit(f0, h0);
-                            must_cut = false;
-                        }
-                        const WinMasks m =
-                            window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin, tab);
-                        if (so.nf - cf > 64u) {
-                            // the filter window under construction ends inside this one: at the LAST read head that
-                            // leaves it at most 64 targets.  f0 - cf <= 64 (the invariant this keeps), the window's
-                            // first target is a head of rank 0, so there is one.
-                            const uint32_t room = 64u - (f0 - cf);  // targets of this window that still fit
-                            const uint64_t ok = m.H & f_ballot(f_rank(m.F) <= room);
-                            const uint32_t at = 63u - static_cast<uint32_t>(__builtin_clzll(ok));
-                            const uint64_t below = (1ull << at) - 1ull;
-                            emit(f0 + static_cast<uint32_t>(__popcll(m.F & below)), h0 + static_cast<uint32_t>(__popcll(m.H & below)));
-                        }
-                    } else {  // (mates interleave: the window's targets are not in lane order -- it stands alone)
-                        if (must_cut || so.nf != cf) emit(so.nf, so.nh);
+                        (void)window_fast(field, w2, lane, (RS | f_ballot(mate != mprev)) & PR, V, X, so, tgt_ref, tgt_gbin, tab);
+                    } else {  // (mates interleave: the window's targets are not in lane order)
                         window_general(Staged{mate, field - 1u, w2, f_bit(V)}, lane, RS, V, X, so, tgt_ref, tgt_gbin);
-                        must_cut = true;
                     }
                     off += X;
                 } else {
-                    // a run of 64 records or more (it stands alone in the filter's list: it may hold any number of
-                    // targets).  Inside the staged stretch (its end is the next staged run start): from
+                    // a run of 64 records or more.  Inside the staged stretch (its end is the next staged run start): from
                     // the staged words; running on beyond it, or with more distinct references than the hash table
                     // holds: from global memory, at its own pace
-                    if (must_cut || so.nf != cf) emit(so.nf, so.nh);
-                    must_cut = true;
                     const uint32_t end_off = next_run_start(st1, lane, off + 64u);
                     if (end_off < kStageRecs && long_run_staged(st1, st2, off, end_off, lane, so, tgt_ref, tgt_gbin, tab)) {
                         off = end_off;
@@ -1000,16 +958,6 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
         FPROF_ADD(1, f0, f2);
         FPROF_ADD(2, f2, f2 + 1ull);  // (slots)
         if (lane == 0u) slots[slot] = make_uint4(so.base, so.nf, so.nh, so.nv);
-        // the window list: lanes [0, nw) their windows, lane nw the totals, the last entry the number of windows
-        if (lane == nw) {
-            cut_f = so.nf;
-            cut_h = so.nh;
-        }
-        if (lane == kSlotWindows - 1u) {
-            cut_f = nw;
-            cut_h = 0u;
-        }
-        if (lane <= nw || lane == kSlotWindows - 1u) cuts[lane] = make_uint2(cut_f, cut_h);
     }
     // (No totals here: thousands of waves adding to the same three counters are as many memory-side atomics in a row,
     // ~40 ns each -- 0.3 ms at the end of a 0.1 ms kernel.  The first consumer of the slots sums their counts.)
@@ -1032,7 +980,7 @@ static uint32_t front_grid(uint32_t nslots) {
 
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint2* wcut, hipEvent_t t0, hipEvent_t t1) {
+                      hipEvent_t t0, hipEvent_t t1) {
     const uint32_t ns = front_slots(in.n);
     if (!ns) return;
     FrontRawT<false> a;
@@ -1060,37 +1008,37 @@ void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, 
         m.bin_width = bin_width;
         m.bw_magic = a.bw_magic;
         hipExtLaunchKernelGGL((k_front<FrontMarked, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, m, ns,
-                              counters, tgt_ref, tgt_gbin, slots, wcut);
+                              counters, tgt_ref, tgt_gbin, slots);
     } else if (in.packed) {  // (same members, other accessors)
         FrontPacked b;
         b.key = a.key, b.ref = a.ref, b.pos = a.pos, b.flag = nullptr, b.check = a.check, b.geo = a.geo, b.n = a.n;
         b.n_refs = a.n_refs, b.half_read = a.half_read, b.bin_width = a.bin_width, b.bw_magic = a.bw_magic;
         if (in.check)
             hipExtLaunchKernelGGL((k_front<FrontPacked, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, b, ns,
-                                  counters, tgt_ref, tgt_gbin, slots, wcut);
+                                  counters, tgt_ref, tgt_gbin, slots);
         else
             hipExtLaunchKernelGGL((k_front<FrontPacked, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, b, ns,
-                                  counters, tgt_ref, tgt_gbin, slots, wcut);
+                                  counters, tgt_ref, tgt_gbin, slots);
     } else if (in.check)
         hipExtLaunchKernelGGL((k_front<FrontRaw, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, a, ns,
-                              counters, tgt_ref, tgt_gbin, slots, wcut);
+                              counters, tgt_ref, tgt_gbin, slots);
     else
         hipExtLaunchKernelGGL((k_front<FrontRaw, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, t0, t1, 0, a, ns,
-                              counters, tgt_ref, tgt_gbin, slots, wcut);
+                              counters, tgt_ref, tgt_gbin, slots);
 }
 
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint2* pay,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
                          const uint32_t* cchk) {
     const uint32_t ns = front_slots(n_upper);
     if (!ns) return;
     FrontSorted a{ident, pay, cchk};
     if (cchk)
         hipLaunchKernelGGL((k_front<FrontSorted, true>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters, tgt_ref,
-                           tgt_gbin, slots, wcut);
+                           tgt_gbin, slots);
     else
         hipLaunchKernelGGL((k_front<FrontSorted, false>), dim3(front_grid(ns)), dim3(kFrontBlock), 0, st, a, ns, counters,
-                           tgt_ref, tgt_gbin, slots, wcut);
+                           tgt_ref, tgt_gbin, slots);
 }
 
 }  // namespace slimm

@@ -118,20 +118,15 @@ struct DeviceRecords {
 // of the slots likes them large (1 B records, 1024 -> 768 -> 640 -> 512: k_tile_count 453 -> 460 -> 543 -> 619 us, k_filter
 // 2 571 -> 2 588-2 660 -> 2 616 -> 2 843, scatter 2 314 -> 2 393 -> 2 458 -> 2 503).
 constexpr uint32_t kSlotRecs = 768;
-// The front end works through a slot in windows of whole qName runs (<= 64 records, or one run of 64 records or more);
-// wcut[s * kSlotWindows + i] = {targets, reads} of slot s in front of its window i, the entry behind the last window
-// holds the slot's totals and wcut[s * kSlotWindows + kSlotWindows - 1].x the number of windows.  The targets of a
-// window are whole reads: k_filter takes the windows up independently of each other.
-constexpr uint32_t kSlotWindows = 2 * (kSlotRecs / 64) + 6;
 constexpr int kFrontBlock = 64;   // one slot, one wave, one workgroup: the dispatcher backfills wave by wave (config 3: 594 -> 549 us)
 constexpr uint32_t kMaxRefs = (1u << 26) - 2u;      // reference id + 1 fits 26 bits and is not all ones (front.hip)
 constexpr uint32_t kMaxBins = 0x7ffffff0u;          // global bin indices fit 31 bits (bit 31 of tgt_gbin: unique read)
 uint32_t front_slots(uint32_t n_records);
 void launch_front_raw(hipStream_t st, const DeviceRecords& in, uint32_t n_refs, const uint2* geo, uint32_t half_read,
                       uint32_t bin_width, uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
-                      uint2* wcut, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // t0 / t1: the dispatch's time stamps
+                      hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);  // t0 / t1: the dispatch's time stamps
 void launch_front_sorted(hipStream_t st, uint32_t n_upper, const uint64_t* ident, const uint2* pay,
-                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots, uint2* wcut,
+                         uint32_t* counters, uint32_t* tgt_ref, uint32_t* tgt_gbin, uint4* slots,
                          const uint32_t* cchk = nullptr);  // pay: {reference, global bin}; cchk: check words (equal keys must carry equal ones)
 
 // diagnostic: run starts whose identity (key & id_mask) started an earlier run too; tab: (tab_mask + 1) words of ~0
@@ -152,14 +147,13 @@ struct FilterArgs {
     const uint32_t* tgt_ref = nullptr;
     const uint32_t* tgt_gbin = nullptr;
     const uint4* slots = nullptr;
-    const uint2* wcut = nullptr;
     uint32_t nslots = 0;
     const void* rows16 = nullptr;
     const uint32_t* taxon_flat = nullptr;  // rows16: dense taxon of (level, index) at [(index << 3) | level]
     uint32_t taxon_shift = 0;
     const uint32_t* lin_dense = nullptr;
     const uint8_t* valid = nullptr;
-    const uint32_t* valid_bits = nullptr;    // one bit per reference: k_filter_compact (nullptr: k_filter, window by window)
+    const uint32_t* valid_bits = nullptr;    // one bit per reference: what k_filter_compact asks before anything else
     uint32_t* redo = nullptr;                // ... and the slots it leaves to k_filter_walk (nslots words; their number: counters[CNT_REDO])
     uint32_t* sel = nullptr;                 // one selector per read, dense: slot s writes at slot_rbase[s] + slot_bbase[s >> 10]
     const uint32_t* slot_rbase = nullptr;    // (launch_slot_read_prefix)

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_filter: phase B + C(1) per read, ONE LANE PER TARGET.
+// Phase B + C(1) per read (k_filter_compact + k_filter_walk, further down), ONE LANE PER TARGET:
 //   * keep the targets whose reference is valid (read_stat::update, read_stat.hpp:98-114)
 //   * exactly one left  -> the read's selector is that target's bin: uniq_cov2[g]++   (src/slimm.hpp:383-390)
 //   * more than one     -> level-scan LCA over the lineage rows (src/slimm.hpp:516-531): the first level at which all
@@ -136,13 +136,10 @@ __global__ __launch_bounds__(kBlock) void k_ref_stats(const uint32_t* __restrict
 //     histogram: lca_count[t]++), and children[t] gets every kept reference (src/slimm.hpp:552-555): as a (reference,
 //     level) mark when a level agrees (t is lineage[ref][level] for each of them), as a (t, ref) pair in a hash set
 //     otherwise.
-// A wave walks the slots of the front end (front.hip) in windows of 64 targets that start at a read's first target and
-// are cut behind the window's last complete read, like the front end's windows over runs: the target words arrive by
-// two coalesced loads, the lineage rows by ONE 16-byte gather per target -- two dependent levels instead of the three
-// of a thread per read (offsets, targets, rows).  Per read the work is lane-mask arithmetic on the ballots of "head"
-// and "valid": first / second valid lane of every read by carry chains (f_first_after, below), the reads they belong
-// to by the same chains on the bit-reversed masks.  Only reads that keep several targets (8 % at config 2) get more:
-// a scalar loop over them compares the rows of their valid lanes with the first one's, level by level.
+// What follows first are the pieces both kernels use: the pair set, the two row forms, the lane-mask helpers, and the
+// window-by-window walk (filter_window / filter_q4 / filter_span: windows of up to 64 targets that are whole reads, first /
+// second valid lane of every read by carry chains, reads of 64 targets and more in chunks) that k_filter_walk runs on the few
+// slots k_filter_compact leaves to it.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
@@ -549,147 +546,6 @@ __device__ __forceinline__ void filter_span(const Rows& rows, const FilterOut& o
 
 }  // namespace
 
-constexpr int kFilterBlock = 64;  // one wave per workgroup (backfilled wave by wave: -2 %)
-
-// A wave takes a slot of the front end and works through its windows (wcut): every window's targets are whole reads,
-// at most 64 of them unless a run of 64 records or more left them, so the windows are independent of each other.  A few
-// at a time (kFilterBatch): the target words of all are loaded together, then their lineage rows gathered together, then they
-// are worked on, then the taxa of their reads with several targets looked up together -- three memory round trips per
-// batch of windows.  (Round 2, slots of 1024 records:) four windows per batch at eight waves per SIMD (64 VGPRs): the kernel waits for these round trips
-// two thirds of its time (SQ_WAIT_ANY), and an eighth wave covers more of them than two more windows in flight do --
-// config 3: 436 - 460 us with six windows at seven waves, 394 - 412 us like this; config 2 the same either way.
-// (No branch around the loads:
-// with memory operations on some paths only, the compiler can no longer count the operations younger than the one it
-// waits for and waits for all of them.)
-constexpr int kFilterBatch = 4;
-constexpr uint32_t kFilterSlots = 1;  // consecutive slots per unit of work (their windows: at most 64 together)
-constexpr uint32_t kFilterSplit = 1;  // waves per unit (a power of two dividing the waves of a workgroup)
-static_assert(kFilterSlots * (kSlotWindows - 2u) <= 64u, "a wave keeps one window per lane");
-template <typename Rows>
-__global__ __launch_bounds__(kFilterBlock, 8) void k_filter(const uint32_t* __restrict__ tgt_ref,
-                                                         const uint32_t* __restrict__ tgt_gbin,
-                                                         const uint4* __restrict__ slots, const uint2* __restrict__ wcut,
-                                                         uint32_t nslots, const Rows rows, const FilterOut out) {
-    const uint32_t lane = lane_id();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * (kFilterBlock / 64);
-    // kFilterSplit waves share a unit of kFilterSlots slots: each takes an equal stretch of the unit's windows
-    for (uint32_t unit = (blockIdx.x * (kFilterBlock / 64) + wave) / kFilterSplit; unit * kFilterSlots < nslots;
-         unit += n_waves / kFilterSplit) {
-        const uint32_t first = unit * kFilterSlots;
-        const uint32_t part = (blockIdx.x * (kFilterBlock / 64) + wave) % kFilterSplit;
-        // The windows of this wave's kFilterSlots consecutive slots, one per lane: where the window's targets start, how
-        // many there are, where its reads' selectors start, the last target of its slot (loads are clamped to it).
-        // (A slot's list is loaded whole -- entries behind its last window are never used -- so the number of windows
-        // comes out of the same load instead of a load of its own in front.)
-        uint32_t w_start = 0, w_cnt = 0, w_sel = 0, w_last = 0, nw = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kFilterSlots; ++k) {
-            const uint32_t slot = min(first + k, nslots - 1u);
-            const uint4 d = slots[slot];
-            const uint2 ce = wcut[static_cast<size_t>(slot) * kSlotWindows + min(lane, kSlotWindows - 1u)];
-            const uint32_t n = first + k < nslots ? static_cast<uint32_t>(__builtin_amdgcn_readlane(ce.x, kSlotWindows - 1u)) : 0u;
-            const uint32_t nxt = __shfl_down(ce.x, 1, 64);  // (lane n holds the slot's totals)
-            const uint32_t rb = out.rbase[slot] + out.bbase[slot >> 10];  // (two scalar loads beside the descriptor's)
-            const uint32_t a_start = d.x + ce.x, a_cnt = lane < n ? nxt - ce.x : 0u, a_sel = rb + ce.y;
-            if (kFilterSlots == 1) {
-                w_start = a_start;
-                w_cnt = a_cnt;
-                w_sel = a_sel;
-                w_last = d.x + d.y - 1u;
-            } else {  // behind the windows of the slots before
-                const int src = static_cast<int>((lane - nw) & 63u);
-                const uint32_t b_start = __shfl(a_start, src, 64), b_cnt = __shfl(a_cnt, src, 64), b_sel = __shfl(a_sel, src, 64);
-                const bool here = lane >= nw && lane < nw + n;
-                w_start = here ? b_start : w_start;
-                w_cnt = here ? b_cnt : w_cnt;
-                w_sel = here ? b_sel : w_sel;
-                w_last = here ? d.x + d.y - 1u : w_last;
-            }
-            nw += n;
-        }
-        bool spans = false;  // some window holds more than 64 targets
-        const uint32_t share = (nw + kFilterSplit - 1u) / kFilterSplit;
-        const uint32_t w_lo = min(part * share, nw), w_hi = min(w_lo + share, nw);
-        // the target words of a batch are asked for one batch ahead: of the three round trips per batch (target words ->
-        // lineage rows -> taxa) the first then runs beside the batch before
-        uint32_t wn[kFilterBatch], gn[kFilterBatch], cntn[kFilterBatch], selbn[kFilterBatch];
-        auto ask = [&](uint32_t i0) {
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) {
-                const uint32_t i = (i0 + u) & 63u;  // (lanes behind the last window: windows of no targets)
-                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
-                const uint32_t tl = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_last, i));
-                cntn[u] = i0 + u < w_hi ? static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i)) : 0u;
-                selbn[u] = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i));
-                if (cntn[u] > 64u) {
-                    spans = true;
-                    cntn[u] = 0;
-                }
-                const uint32_t t = cntn[u] ? min(t0 + lane, tl) : 0u;
-                wn[u] = tgt_ref[t];
-                gn[u] = tgt_gbin[t];
-            }
-        };
-        ask(w_lo);
-        for (uint32_t i0 = w_lo; i0 < w_hi; i0 += kFilterBatch) {
-            uint32_t w[kFilterBatch], g[kFilterBatch], cnt[kFilterBatch], selb[kFilterBatch];
-            typename Rows::Row row[kFilterBatch];
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) {
-                w[u] = wn[u];
-                g[u] = gn[u];
-                cnt[u] = cntn[u];
-                selb[u] = selbn[u];
-            }
-            __builtin_amdgcn_sched_barrier(0);  // (every load of the stage before the first use of one)
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) row[u] = rows.load(lane < cnt[u] ? (w[u] & 0x7fffffffu) : 0u);
-            __builtin_amdgcn_sched_barrier(0);
-            ask(i0 + kFilterBatch);  // (behind the last batch: windows of no targets, loads of element 0)
-            __builtin_amdgcn_sched_barrier(0);
-            // Every loaded value gets a use HERE, in the straight-line code behind its stage: a (restrict, read-only) load
-            // whose only uses sit in a conditional block further down is sunk into that block by the compiler -- which
-            // turns "three round trips per eight windows" back into three per window.
-            uint64_t vb[kFilterBatch];
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) {
-                SLIMM_PIN_VGPR(g[u]);
-                vb[u] = k_ballot(Rows::valid(row[u]));
-            }
-            Lookup lk[kFilterBatch];
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) {
-                lk[u] = Lookup{0ull};
-                if (cnt[u]) lk[u] = filter_window(rows, out, lane, cnt[u], w[u], g[u], row[u], vb[u], selb[u]);
-            }
-            uint64_t any_q4 = 0;
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) any_q4 |= lk[u].q4;
-            if (any_q4) {  // (rare; behind everything else of the batch, and said aloud that nothing of it is left under way)
-#pragma unroll
-                for (int u = 0; u < kFilterBatch; ++u)
-                    if (lk[u].q4) filter_q4(rows, out, lane, cnt[u], w[u], row[u], vb[u], selb[u], lk[u].q4);
-                __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
-            }
-#pragma unroll
-            for (int u = 0; u < kFilterBatch; ++u) {  // (the next batch's words stay where they were asked for)
-                SLIMM_PIN_VGPR(wn[u]);
-                SLIMM_PIN_VGPR(gn[u]);
-            }
-        }
-        if (spans) {
-            for (uint32_t i = w_lo; i < w_hi; ++i) {
-                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_start, i));
-                const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(w_cnt, i));
-                if (c > 64u)
-                    filter_span(rows, out, tgt_ref, tgt_gbin, lane, t0, t0 + c, static_cast<uint32_t>(__builtin_amdgcn_readlane(w_sel, i)));
-            }
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
 // k_filter_compact (round 6): the same phase B + C(1), COMPACTED FIRST.
 // k_filter above works through every window of <= 64 targets with ~85 scalar + ~85 vector instructions of lane-mask
@@ -1083,13 +939,6 @@ void launch_sel_atomics(hipStream_t st, const uint32_t* sel, uint32_t n_reads, u
     hipLaunchKernelGGL(k_sel_atomics, dim3(blocks), dim3(kBlock), 0, st, sel, n_reads, taxon_base, ucov2, lca_count);
 }
 
-static uint32_t filter_grid(uint32_t nslots) {
-    // kFilterSlots slots per wave, however many workgroups that makes (front.hip: front_grid)
-    const uint32_t units = (nslots + kFilterSlots - 1u) / kFilterSlots;
-    const uint32_t per = (kFilterBlock / 64) / kFilterSplit;  // units per workgroup
-    return std::max(1u, (units + per - 1u) / per);
-}
-
 void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_t t1) {
     if (!a.nslots) return;
     FilterOut out;
@@ -1112,24 +961,16 @@ void launch_filter(hipStream_t st, const FilterArgs& a, hipEvent_t t0, hipEvent_
         r.rows = reinterpret_cast<const uint4*>(a.rows16);
         r.taxon_flat = a.taxon_flat;
         r.shift = a.taxon_shift;
-        if (a.valid_bits) {
-            hipExtLaunchKernelGGL(k_filter_compact<Rows16>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots,
-                                  a.nslots, a.valid_bits, a.redo, r, out);
-            hipLaunchKernelGGL(k_filter_walk<Rows16>, dim3(std::min(a.nslots, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
-        } else
-            hipExtLaunchKernelGGL(k_filter<Rows16>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
-                                  a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
+        hipExtLaunchKernelGGL(k_filter_compact<Rows16>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots, a.nslots,
+                              a.valid_bits, a.redo, r, out);
+        hipLaunchKernelGGL(k_filter_walk<Rows16>, dim3(std::min(a.nslots, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
     } else {
         Rows32 r;
         r.lin4 = reinterpret_cast<const uint4*>(a.lin_dense);
         r.valid_of = a.valid;
-        if (a.valid_bits) {
-            hipExtLaunchKernelGGL(k_filter_compact<Rows32>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots,
-                                  a.nslots, a.valid_bits, a.redo, r, out);
-            hipLaunchKernelGGL(k_filter_walk<Rows32>, dim3(std::min(a.nslots, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
-        } else
-            hipExtLaunchKernelGGL(k_filter<Rows32>, dim3(filter_grid(a.nslots)), dim3(kFilterBlock), 0, st, t0, t1, 0, a.tgt_ref,
-                                  a.tgt_gbin, a.slots, a.wcut, a.nslots, r, out);
+        hipExtLaunchKernelGGL(k_filter_compact<Rows32>, dim3(grid), dim3(64), 0, st, t0, t1, 0, a.tgt_ref, a.tgt_gbin, a.slots, a.nslots,
+                              a.valid_bits, a.redo, r, out);
+        hipLaunchKernelGGL(k_filter_walk<Rows32>, dim3(std::min(a.nslots, 256u)), dim3(64), 0, st, a.tgt_ref, a.tgt_gbin, a.slots, a.redo, r, out);
     }
 }
 

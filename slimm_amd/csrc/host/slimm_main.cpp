@@ -1323,7 +1323,8 @@ int main(int argc, char** argv) {
         // (Every output file is written and closed.  Leaving through _exit here, without the teardown in this process, measured
         // SLOWER end to end since the window buffers are page-locked: the kernel driver then takes the process's queues, pinned
         // pages and device memory back on its own -- 0.20 - 0.23 s from _exit to the parent's wait() returning against 0.07 s of
-        // orderly teardown + 0.09 s; round 4.)
+        // orderly teardown + 0.09 s; round 4.  Round 6: _exit behind our own release of everything -- only the runtime's
+        // atexit teardown skipped -- is inside the run-to-run noise of 0.64 - 0.84 s, profiles/round6/05_exit_experiment.txt.)
         std::cerr.flush();
         fflush(nullptr);
     };
@@ -1332,8 +1333,5 @@ int main(int argc, char** argv) {
         trace.mark("get_profiles + its buffers released");
     }
     closing_lines();
-#ifdef SLIMM_EXPERIMENT_QUICK_EXIT   // (timing experiment: leave without the HIP runtime's own teardown, everything of ours released)
-    _exit(0);
-#endif
     return 0;
 }

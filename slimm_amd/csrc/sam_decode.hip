@@ -85,12 +85,13 @@ __global__ __launch_bounds__(64) void k_sam_pieces(const uint8_t* __restrict__ b
             } else if (ch == '\n') {
                 if (in_line) {
                     const uint32_t first = b[start];
-                    // (a line that ends in CR LF: the host reader strips the CR -- such a file is the host decoder's, like a
-                    // header line or an empty line among the alignment lines)
-                    const bool crlf = at > start && b[at - 1] == '\r';
-                    const bool record = at > start && first != '@' && tabs >= 9u && !crlf;   // (the host reader: < 10 fields is an error)
+                    // (a line that is empty but for a CR -- a blank line of a CR LF file: the host reader strips the CR and skips
+                    // the line, so it is the host decoder's like any empty line; a CR behind a record stays in its last field, which
+                    // nobody reads.  ADVICE round 5)
+                    const bool blank = at == start || (at == start + 1u && first == '\r');
+                    const bool record = !blank && first != '@' && tabs >= 9u;   // (the host reader: < 10 fields is an error)
                     if (n < kBamSlots) po[n] = start | (record ? 0u : 0x80000000u);
-                    if (!record) pc.flags |= (at > start && first != '@' && !crlf) ? kBamPieceBad : kSamPieceSkip;
+                    if (!record) pc.flags |= (!blank && first != '@') ? kBamPieceBad : kSamPieceSkip;
                     ++n;
                     pc.stop = static_cast<uint32_t>(at + 1);
                 }

@@ -71,7 +71,7 @@ int bam_finish_window(slimm_ctx* c, uint64_t j, uint64_t n_bytes, bool is_last, 
     const BamWindowResult res = *B.result.p;
     if (res.bad && B.sam)
         return fail(c, SLIMM_E_INVALID, (res.bad & kBamPieceBad) ? "SAM line with fewer than 10 fields"
-                                                                : "a header line, an empty line or a line ending in CR among the alignment lines: decode this file on the host");
+                                                                : "a header line or an empty line among the alignment lines: decode this file on the host");
     if (res.bad) return fail(c, SLIMM_E_INVALID, "bad BAM record");
     const uint64_t n_rec = res.n_records, stop = np ? res.stop : end;
     const uint64_t tail = end - stop;

@@ -821,7 +821,11 @@ long AlignmentFile::read_blocks(uint8_t* dst, size_t cap, size_t max_inflated, s
     if (blk_hint_) want = std::min(want, std::max<size_t>(blk_hint_, 1u << 20));
     {
         const int fd = fileno(fp_);
-        const unsigned nt = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(inflaters_->size(), 12u), want >> 22)));
+        // (as many threads as the process has cores to run them on -- the pool holds twice that --, 12 at least: on the 16-core
+        // quota of the GPU box 12 / 16 / 24 / 32 threads read a 7.8 GB file in 200-460 / 180-200 / 150-200 / 160-180 ms,
+        // profiles/round6/06_pread_threads.txt)
+        const unsigned pread_threads = std::max(12u, inflaters_->size() / 2u);
+        const unsigned nt = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(inflaters_->size(), pread_threads), want >> 22)));
         const size_t per = (want + nt - 1) / nt;
         std::atomic<bool> ok{true};
         inflaters_->run(nt, [&](unsigned t) {
@@ -916,7 +920,7 @@ long AlignmentFile::read_text(uint8_t* dst, size_t cap) {
     StageClock clk(ms_read_);
     const size_t want = std::min(cap, sam_size_ - sam_text_pos_);
     const int fd = fileno(fp_);
-    const unsigned nt = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(inflaters_->size(), 12u), want >> 22)));
+    const unsigned nt = static_cast<unsigned>(std::max<size_t>(1, std::min<size_t>(std::min<unsigned>(inflaters_->size(), std::max(12u, inflaters_->size() / 2u)), want >> 22)));   // (as read_blocks)
     const size_t per = (want + nt - 1) / nt;
     std::atomic<bool> ok{true};
     inflaters_->run(nt, [&](unsigned t) {

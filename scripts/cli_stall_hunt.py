@@ -1,0 +1,35 @@
+"""Back-to-back runs of `slimm DB IN.bam` with the pipeline's event trace: where an occasional run of 2 s instead of 0.7 s loses its time."""
+import os, subprocess, sys, tempfile, time, shutil
+ROOT = os.getcwd()
+sys.path.insert(0, ROOT)
+from slimm_amd.synth import CONFIGS, make_workload
+from slimm_amd.synth_bam import write_synthetic_bam
+from tests.bam_io import write_sldb
+n = 100_000_000
+w = make_workload(CONFIGS["config3"], seed=1, n_records=n)
+tmp = tempfile.mkdtemp(prefix="slimm_stall_", dir="/dev/shm")
+db = os.path.join(tmp, "db.sldb"); write_sldb(db, w.taxonomy)
+bam = os.path.join(tmp, "r.bam")
+write_synthetic_bam(bam, w.ref_names, w.ref_len, w.records, read_len=100, realistic=True)
+os.makedirs(os.path.join(tmp, "out"))
+for rep in range(14):
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
+                       env=dict(os.environ, SLIMM_TRACE="cli,push,host"))
+    dt = time.time() - t0
+    print(f"run {rep}: wall {dt:.3f} s", flush=True)
+    if dt > 1.2 or rep == 0:
+        # the events with the gaps in front of them
+        last = None
+        for ln in r.stderr.splitlines():
+            if "[push" in ln:
+                try:
+                    t = float(ln.split("[push")[1].split("]")[0])
+                except ValueError:
+                    continue
+                if last is not None and t - last > 40:
+                    print(f"    GAP {t - last:.0f} ms before: {ln.strip()[:160]}")
+                last = t
+            elif "[trace]" in ln or "[host]" in ln:
+                print("   ", ln.strip()[:200])
+shutil.rmtree(tmp)

@@ -23,6 +23,9 @@ extern "C" {
 
 // A caller's host buffer page-locked for the life of the context: the DMA engine then reads it directly (slimm_push_bam_bytes
 // and the *_async pushes take any host memory, at the speed of the runtime's own staging when it is pageable)
+namespace {
+void push_trace(const char* fmt, ...);
+}
 int slimm_pin_host_buffer(slimm_ctx* c, const void* p, uint64_t n_bytes) {
     if (!c || !p || !n_bytes) return SLIMM_E_INVALID;
     if (c->device < 0) return fail(c, SLIMM_E_INVALID, "host-only context");
@@ -30,10 +33,12 @@ int slimm_pin_host_buffer(slimm_ctx* c, const void* p, uint64_t n_bytes) {
     const uint8_t* b = static_cast<const uint8_t*>(p);
     for (auto& r : c->bam.registered)
         if (b >= r.first && b + n_bytes <= r.first + r.second) return SLIMM_OK;
+    const auto t0 = std::chrono::steady_clock::now();
     if (hipHostRegister(const_cast<uint8_t*>(b), n_bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();
         return fail(c, SLIMM_E_HIP, "hipHostRegister failed");
     }
+    push_trace("page-locked %.0f MB in %.2f ms", n_bytes / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     c->bam.registered.emplace_back(b, static_cast<size_t>(n_bytes));
     return SLIMM_OK;
 }
@@ -262,8 +267,16 @@ int bam_launch_gathered(slimm_ctx* c) {
     if (!nblk || !n_bytes) return SLIMM_OK;
     const int rc = bam_window_buffer(c, n_bytes, true);
     if (rc != SLIMM_OK) return rc;
-    HIP_TRY(c, B.desc[b].ensure_later(static_cast<size_t>(nblk) + (nblk >> 1) + 1, B.outgrown));
-    HIP_TRY(c, B.inflate_scratch[si].ensure_later(bgzf_inflate_scratch_bytes(nblk + (nblk >> 2), B.acc_tok + (B.acc_tok >> 2)), B.outgrown));
+    // (room to spare only when a buffer has to GROW: a request "with a quarter more" that exceeded a buffer reserved for exactly
+    // this kind of window re-allocated 3 GB of scratch in the middle of a file -- a hipMalloc that waits for the kernels in
+    // flight and, now and then, 1.4 s for the memory itself: profiles/round6/06_cli_stall_hunt.txt)
+    if (B.desc[b].cap < static_cast<size_t>(nblk) + 1)
+        HIP_TRY(c, B.desc[b].ensure_later(static_cast<size_t>(nblk) + (nblk >> 1) + 1, B.outgrown));
+    if (B.inflate_scratch[si].cap < bgzf_inflate_scratch_bytes(nblk, B.acc_tok)) {
+        push_trace("inflate scratch %u grows: %.0f MB held, %.0f MB needed", si, B.inflate_scratch[si].cap / 1e6,
+                   bgzf_inflate_scratch_bytes(nblk, B.acc_tok) / 1e6);
+        HIP_TRY(c, B.inflate_scratch[si].ensure_later(bgzf_inflate_scratch_bytes(nblk + (nblk >> 2), B.acc_tok + (B.acc_tok >> 2)), B.outgrown));
+    }
     HIP_TRY(c, B.inflate_status.ensure(4u * slimm_ctx::kBamRing));
     HIP_TRY(c, B.h_inflate_status.ensure(4));
     HIP_TRY(c, hipMemsetAsync(B.comp[b].p + B.acc_src, 0, kBgzfTail, c->copy_stream));
@@ -408,6 +421,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
                     const size_t np_max = bam_pieces(B.win_cap + kBamSlack) + 64;
                     HIP_TRY(c, B.pieces.ensure_later(np_max, B.outgrown));
                     HIP_TRY(c, B.offs.ensure_later(np_max * kBamSlots, B.outgrown));
+                    push_trace("buffers reserved");
                     push_trace("planned %llu window(s) of <= %.0f MB in %u buffer(s), %.0f MB of compressed bytes each: %.2f GB held",
                                (unsigned long long)nwin, B.win_cap / 1e6, nbuf, comp_cap / 1e6, B.held_bytes() / 1e9);
                 }

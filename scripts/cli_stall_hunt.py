@@ -12,12 +12,18 @@ db = os.path.join(tmp, "db.sldb"); write_sldb(db, w.taxonomy)
 bam = os.path.join(tmp, "r.bam")
 write_synthetic_bam(bam, w.ref_names, w.ref_len, w.records, read_len=100, realistic=True)
 os.makedirs(os.path.join(tmp, "out"))
-for rep in range(14):
+first_prof = None
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
     t0 = time.time()
     r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
                        env=dict(os.environ, SLIMM_TRACE="cli,push,host"))
     dt = time.time() - t0
-    print(f"run {rep}: wall {dt:.3f} s", flush=True)
+    prof = open(os.path.join(tmp, "out", "r_profile.tsv")).read() if r.returncode == 0 else None
+    first_prof = prof if rep == 0 else first_prof
+    print(f"run {rep}: wall {dt:.3f} s = {n / dt / 1e6:.0f} M records/s, rc {r.returncode}, profile {'the same' if prof == first_prof and prof else 'DIFFERS / MISSING'}"
+          + ("" if r.returncode == 0 else " -- " + r.stderr[-300:].replace("\n", " | ")), flush=True)
+    if rep == 0:
+        print("\n".join("    " + l.strip()[:200] for l in r.stderr.splitlines() if "page-locked" in l or "reserved" in l or "planned" in l or "grows" in l))
     if dt > 1.2 or rep == 0:
         # the events with the gaps in front of them
         last = None

@@ -198,6 +198,7 @@ struct slimm_ctx {
         // what the file's gathered windows are sized for: slimm_set_input_size_hint (the file's compressed bytes; 0 = not
         // told) and, from it and the first push's ratio, the inflated bytes a gathered window's buffer gets (0 = kBamGather)
         uint64_t size_hint = 0, win_cap = 0;
+        bool planned = false;                // the file's first COMPRESSED push has reserved its buffers (or found no hint)
         uint64_t held_bytes() const {   // device memory of the window pipeline
             uint64_t n = pieces.cap * sizeof(BamPiece) + offs.cap * 4ull;
             for (uint32_t k = 0; k < kBamRing; ++k) n += bytes[k].cap + comp[k].cap + desc[k].cap * sizeof(BgzfBlock);

@@ -433,6 +433,7 @@ int slimm_reset(slimm_ctx* c) {
     c->bam.closed = false;
     c->bam.q18_starts = c->bam.q18_plain = 0;
     c->bam.size_hint = c->bam.win_cap = 0;
+    c->bam.planned = false;
     if (c->bam.held_bytes() > slimm_ctx::kBamKeepAcrossFiles) {   // (a large file's windows: the next file sizes its own)
         (void)hipSetDevice(c->device);
         for (uint32_t k = 0; k < slimm_ctx::kBamRing; ++k) {

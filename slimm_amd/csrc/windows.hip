@@ -361,6 +361,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
         B.pushes = 0;
         B.acc_open = false;
         B.sam = sam;
+        B.planned = false;
         B.sam_last_byte = '\n';
         c->marked = marked;
         c->has_check = !marked;
@@ -395,9 +396,20 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
             // many and how large comes from the caller's hint (slimm_set_input_size_hint: the file's compressed bytes) and
             // this push's own ratios: a 70 MB file gets one window of its size, not four of 1.9 GB (17 GB
             // per context whatever the file).  Without a hint nothing is reserved ahead: buffers appear as windows need them.
-            if (B.windows == 0) {
+            if (!B.planned) {   // (the file's first compressed push: windows the host inflated may have gone before it)
+                B.planned = true;
                 B.win_cap = 0;
                 if (B.size_hint && src_bytes && inflated) {
+                    // (those windows are finished first -- their buffers are about to be replaced; the bytes they carry over
+                    // move with the buffer of the window that is next)
+                    while (B.head < B.windows) {
+                        uint64_t got = 0;
+                        const uint64_t j = B.head;
+                        const int frc = bam_finish_window(c, j, B.win_bytes[j % slimm_ctx::kBamRing], false, got);
+                        ++B.head;
+                        if (frc != SLIMM_OK) return frc;
+                        total += got;
+                    }
                     const double ratio = static_cast<double>(inflated) / static_cast<double>(src_bytes);
                     const uint64_t left = B.size_hint > src_bytes ? B.size_hint - src_bytes : 0;
                     const uint64_t est = inflated + static_cast<uint64_t>(static_cast<double>(left) * ratio * 1.08) + (16ull << 20);
@@ -412,7 +424,12 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
                     const uint32_t blocks_max = static_cast<uint32_t>(static_cast<double>(B.win_cap) * blocks_per_byte * 1.25) + 1024u;
                     const uint64_t tok_max = B.win_cap / 3u + B.win_cap / 256u + 8ull * blocks_max;
                     for (uint32_t k = 0; k < nbuf; ++k) {
-                        HIP_TRY(c, B.bytes[k].ensure_later(kBamSlack + B.win_cap + 64, B.outgrown));
+                        if (k == b && B.carry_bytes) {   // (the carried bytes lie in this buffer's slack: bam_window_buffer keeps them)
+                            const int wrc = bam_window_buffer(c, B.win_cap, true);
+                            if (wrc != SLIMM_OK) return wrc;
+                        } else {
+                            HIP_TRY(c, B.bytes[k].ensure_later(kBamSlack + B.win_cap + 64, B.outgrown));
+                        }
                         HIP_TRY(c, B.comp[k].ensure_later(comp_cap, B.outgrown));
                         HIP_TRY(c, B.desc[k].ensure_later(blocks_max, B.outgrown));
                     }

@@ -1,4 +1,5 @@
-"""Back-to-back runs of `slimm DB IN.bam` with the pipeline's event trace: where an occasional run of 2 s instead of 0.7 s loses its time."""
+"""Back-to-back runs of `slimm DB IN.bam` with the pipeline's event trace: where an occasional run of 2 s instead of 0.7 s loses its time.
+    python scripts/cli_stall_hunt.py [runs] [flags of the command ...]        (SLIMM_STALL_FULL=file: run 0's whole stderr goes there)"""
 import os, subprocess, sys, tempfile, time, shutil
 ROOT = os.getcwd()
 sys.path.insert(0, ROOT)
@@ -15,13 +16,15 @@ os.makedirs(os.path.join(tmp, "out"))
 first_prof = None
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
     t0 = time.time()
-    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
+    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm")] + sys.argv[2:] + ["-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
                        env=dict(os.environ, SLIMM_TRACE="cli,push,host"))
     dt = time.time() - t0
     prof = open(os.path.join(tmp, "out", "r_profile.tsv")).read() if r.returncode == 0 else None
     first_prof = prof if rep == 0 else first_prof
     print(f"run {rep}: wall {dt:.3f} s = {n / dt / 1e6:.0f} M records/s, rc {r.returncode}, profile {'the same' if prof == first_prof and prof else 'DIFFERS / MISSING'}"
           + ("" if r.returncode == 0 else " -- " + r.stderr[-300:].replace("\n", " | ")), flush=True)
+    if rep == 0 and os.environ.get("SLIMM_STALL_FULL"):
+        open(os.environ["SLIMM_STALL_FULL"], "w").write(r.stderr)
     if rep == 0:
         print("\n".join("    " + l.strip()[:200] for l in r.stderr.splitlines() if "page-locked" in l or "reserved" in l or "planned" in l or "grows" in l))
     if dt > 1.2 or rep == 0:

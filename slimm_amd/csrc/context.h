@@ -98,6 +98,10 @@ struct slimm_ctx {
     hipStream_t stream = nullptr;
     // streamed ingest (slimm_push_records_async): host -> device copies on a stream of their own, ordered before phase A
     // by an event (never by the host); two page-locked staging sets for callers that produce records piecemeal
+    // the copy stream, the side stream and the inflaters' streams are made when first used (need_stream below): a process has
+    // few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise), streams beyond them share one and wait for each
+    // other, and the members of a group on one device count together -- `slimm --devices 0,0` on 100 M records had every
+    // second window's inflate wait 26-30 ms behind another stream's work with three streams made at slimm_create
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
     bool copy_pending = false;
@@ -375,6 +379,8 @@ int bam_fetch_q18(slimm_ctx* c);   // windows.hip: the Q18 run counts of the dev
 // an array the file's record form does not use is neither allocated nor copied).
 // later != nullptr: no hipFree now (it waits for every kernel in flight -- the inflate of the windows behind this one):
 // what the array was goes there and is freed when the file has ended
+inline hipError_t need_stream(hipStream_t& s) { return s ? hipSuccess : hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+
 template <typename T>
 hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStream_t st, std::vector<void*>* later = nullptr) {
     if (cap <= buf.cap) return hipSuccess;

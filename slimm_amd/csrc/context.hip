@@ -216,8 +216,6 @@ int slimm_create(const slimm_config* cfg, slimm_ctx** out) {
         HostTrace trc("slimm_create");
         HIP_TRY0(hipSetDevice(c->device));
         HIP_TRY0(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
-        HIP_TRY0(hipStreamCreateWithFlags(&cc->copy_stream, hipStreamNonBlocking));
-        HIP_TRY0(hipStreamCreateWithFlags(&cc->side_stream, hipStreamNonBlocking));
         HIP_TRY0(hipEventCreateWithFlags(&cc->front_done, hipEventDisableTiming));
         HIP_TRY0(hipEventCreateWithFlags(&cc->prefix_done, hipEventDisableTiming));
         HIP_TRY0(hipEventCreateWithFlags(&cc->copy_done, hipEventDisableTiming));
@@ -408,14 +406,14 @@ int slimm_reset(slimm_ctx* c) {
     }
     if (c->bam.active && c->bam.head < c->bam.windows) {  // a file abandoned with windows in flight (an error, a caller's
         (void)hipSetDevice(c->device);                    // change of mind): their copies and inflates must not land in the
-        HIP_TRY(c, hipStreamSynchronize(c->copy_stream)); // next file's buffers
+        if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));  // next file's buffers
         for (auto& is : c->bam.inflate_stream)
             if (is) HIP_TRY(c, hipStreamSynchronize(is));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     if (c->bam.acc_open) {  // (a gathered window that was never launched: its copies)
         (void)hipSetDevice(c->device);
-        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        if (c->copy_stream) HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     }
     c->bam.acc_open = false;
     c->bam.acc_src = c->bam.acc_dst = 0;
@@ -611,6 +609,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     // (half CU), and a CU that is busy with a prefix workgroup when they are placed makes another CU take two of them
     // (k_tile_count 456 -> 610-630 us at 1 B records in five runs of six).  The histogram's workgroups are many and short.
     auto slot_prefix_beside_what_follows = [&]() -> int {
+        HIP_TRY(c, need_stream(c->side_stream));
         HIP_TRY(c, hipEventRecord(c->front_done, st));
         HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->front_done, 0));
         launch_slot_read_prefix(c->side_stream, c->slots.p, nslots, c->slot_rbase.p, c->slot_bbase.p);

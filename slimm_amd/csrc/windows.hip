@@ -351,6 +351,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
     if (c->n_pushed && !c->bam.active)
         return fail(c, SLIMM_E_INVALID, "earlier batches were decoded records: the forms do not mix within a file");
     (void)hipSetDevice(c->device);
+    HIP_TRY(c, need_stream(c->copy_stream));
     slimm_ctx::BamDecode& B = c->bam;
     hipStream_t st = c->stream;
     if (!B.active) {  // a file's first window

@@ -108,6 +108,53 @@ def test_random_small_inputs(lo):
             raise AssertionError(f"seed {seed}: {e}") from e
 
 
+def long_run_case(seed: int) -> Workload:
+    """random_case's database with reads of 6 .. 80 hits on average over several slots of the front end: windows that are
+    cut inside a run (front.hip, window_cut) -- the cut segment's duplicates, its head and its "one target" bit cross the
+    cut; mates in file order (all of mate 1, then all of mate 2: the fast path) or mixed (the general path: never cut)."""
+    w = random_case(seed)
+    rng = np.random.default_rng(seed + 77_000)
+    R = len(w.ref_names)
+    mean_hits = float(rng.choice([6, 15, 30, 45, 80]))
+    target = int(rng.integers(1500, 5000))
+    few_refs = rng.random() < 0.5            # many duplicates of (read, reference)
+    key, flag, ref, pos = [], [], [], []
+    q = 0
+    while len(key) < target:
+        h = int(rng.geometric(1.0 / mean_hits))
+        style = rng.random()
+        if style < 0.25:
+            mates = np.zeros(h, dtype=np.int64)                                  # unpaired
+        elif style < 0.85:
+            mates = np.sort(rng.integers(1, 3, size=h))                          # mate 1, then mate 2
+        else:
+            mates = rng.integers(1, 3, size=h)                                   # interleaved
+        pool = rng.integers(0, R, size=max(1, int(rng.integers(1, 4 if few_refs else 30))))
+        for m in mates.tolist():
+            f = {0: 0, 1: 0x40, 2: 0x80}[m] | (0x100 if rng.random() < 0.5 else 0)
+            r = int(rng.choice(pool)) if rng.random() > 0.04 else -1
+            if rng.random() < 0.03:
+                f |= 0x4
+            key.append(q); flag.append(f); ref.append(r)
+            pos.append(int(rng.integers(-1, int(w.ref_len[max(r, 0)]) + 5)))
+        q += 1
+    k = (np.array(key, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & np.uint64((1 << 62) - 1)
+    w.records = Records(k, np.array(flag, dtype=np.uint16), np.array(ref, dtype=np.int32), np.array(pos, dtype=np.int32))
+    w.name = f"longrun{seed}"
+    return w
+
+
+def test_long_runs_cut_windows():
+    for seed in range(40):
+        w = long_run_case(seed)
+        try:
+            _run(w, True)
+            _run(w, True, "marked")
+            _run(w, bool(seed & 1), "packed")
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed}: {e}") from e
+
+
 def test_random_shuffled_inputs():
     """Arbitrary record order (file order decides first bins, so the oracle sees the same shuffled stream)."""
     for seed in range(200, 260):

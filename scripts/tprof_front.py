@@ -28,4 +28,4 @@ for it in range(3):
     a = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).astype(np.float64)
     a = a[a[:, 2] > 0]
     slots = a[:, 2].sum()
-    print(f"run {it}: {int(slots)} slots; staging {a[:, 0].sum() / slots:.0f} cycles per slot, whole slot {a[:, 1].sum() / slots:.0f}", flush=True)
+    print(f"run {it}: {int(slots)} slots; staging {a[:, 0].sum() / slots:.0f} cycles per slot, whole slot {a[:, 1].sum() / slots:.0f}, of it runs of 64 records or more {a[:, 3].sum() / slots:.0f}", flush=True)

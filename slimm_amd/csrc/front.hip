@@ -717,21 +717,77 @@ __device__ __forceinline__ uint32_t next_run_start(const uint32_t* st1, uint32_t
 __device__ __forceinline__ bool long_run_staged(const uint32_t* st1, const uint32_t* st2, uint32_t off, uint32_t end_off,
                                                 uint32_t lane, WinOut& so, uint32_t* __restrict__ tgt_ref,
                                                 uint32_t* __restrict__ tgt_gbin, uint32_t* tab) {
-    // 1. do the run's mates ever decrease?  (then one pass per mate number, so that a read's targets stay contiguous)
-    bool decreasing = false;
-    {
-        uint32_t last_mate = 0;
-        for (uint32_t o = off; o < end_off; o += 64u) {
-            const uint32_t n_in = min(64u, end_off - o);
-            const uint32_t mate = (st1[min(o + lane, end_off - 1u)] >> kStMateShift) & 3u;
-            const uint32_t mprev = f_shr1(mate, last_mate);
-            decreasing = decreasing | ((f_ballot(mate < mprev) & f_below(n_in)) != 0ull);
-            last_mate = __builtin_amdgcn_readlane(mate, n_in - 1u);
-        }
-    }
+    // 1. mapper output: the run's mates never decrease (all of mate 1, then all of mate 2), a read is a stretch of the run.
+    // ONE pass that says so on the way; heads and the targets per mate by mask arithmetic on two ballots.
     const WinOut so_at_run = so;
+    {
+        uint32_t head_seen = 0, last_mate = 0, nv = 0;
+        uint32_t n_first[3] = {0u, 0u, 0u}, head_p[3] = {0u, 0u, 0u}, head_g[3] = {0u, 0u, 0u};
+        bool falls = false;
+        hash_clear(tab, lane);
+        for (uint32_t o = off; o < end_off; o += 64u) {
+            const uint32_t i = o + lane;
+            const uint32_t n_in = min(64u, end_off - o);
+            const uint32_t at = min(i, end_off - 1u);
+            const uint32_t w1 = st1[at], g = st2[at];
+            const uint32_t field = w1 & kRefField, mate = (w1 >> kStMateShift) & 3u;
+            const uint64_t IN = f_below_nz(n_in);
+            if ((f_ballot(mate < f_shr1(mate, last_mate)) & IN) != 0ull) {
+                falls = true;
+                break;
+            }
+            last_mate = __builtin_amdgcn_readlane(mate, n_in - 1u);
+            const uint64_t V = f_ballot(field != kRefField) & IN;
+            bool overflow = false;
+            const bool first = hash_first(tab, (mate << 28) | field, i - off, f_bit(V), overflow);
+            if (f_ballot(overflow) != 0ull) {
+                so = so_at_run;
+                return false;
+            }
+            const uint64_t F = f_ballot(first);
+            const uint64_t M1 = f_ballot(mate == 1u), M2 = f_ballot(mate == 2u);
+            const uint64_t Mm[3] = {~(M1 | M2), M1, M2};
+            uint64_t H = 0;
+#pragma unroll
+            for (uint32_t m = 0; m < 3u; ++m) {
+                const uint64_t Vm = V & Mm[m];
+                if (Vm && !((head_seen >> m) & 1u)) {
+                    H |= Vm & (0ull - Vm);
+                    head_seen |= 1u << m;
+                }
+                n_first[m] += static_cast<uint32_t>(__popcll(F & Mm[m]));
+            }
+            const bool head = f_bit(H);
+            const uint32_t p = so.base + so.nf + f_rank(F);
+            if (first) {
+                tgt_ref[p] = (field - 1u) | (head ? 0x80000000u : 0u);
+                if (!head) tgt_gbin[p] = g;  // a head's bin word waits for the end of the run (unique or not)
+            }
+            uint64_t Hm = H;
+            while (Hm) {
+                const uint32_t hl = static_cast<uint32_t>(__builtin_ctzll(Hm));
+                Hm &= Hm - 1ull;
+                const uint32_t m = __builtin_amdgcn_readlane(mate, hl);
+                head_p[m] = __builtin_amdgcn_readlane(p, hl);
+                head_g[m] = __builtin_amdgcn_readlane(g, hl);
+            }
+            nv += static_cast<uint32_t>(__popcll(V));
+            so.nf += static_cast<uint32_t>(__popcll(F));
+            so.nh += static_cast<uint32_t>(__popcll(H));
+        }
+        if (!falls) {
+#pragma unroll
+            for (uint32_t m = 0; m < 3u; ++m)
+                if (((head_seen >> m) & 1u) && lane == 0u) tgt_gbin[head_p[m]] = head_g[m] | (n_first[m] == 1u ? 0x80000000u : 0u);
+            so.nv += nv;
+            return true;
+        }
+        so = so_at_run;
+    }
+    // 2. the mates interleave: one pass per mate number, so that a read's targets stay contiguous
+    const bool decreasing = true;
     uint32_t nv_run = 0;
-    for (uint32_t pass = 0; pass < (decreasing ? 3u : 1u); ++pass) {
+    for (uint32_t pass = 0; pass < 3u; ++pass) {
         uint32_t head_seen = 0;                        // bit m: a mapped record with mate m came by
         uint32_t n_first[3] = {0u, 0u, 0u};            // targets per mate
         uint32_t head_p[3] = {0u, 0u, 0u}, head_g[3] = {0u, 0u, 0u};  // where each mate's head went, its bin word
@@ -943,6 +999,7 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                     // a run of 64 records or more.  Inside the staged stretch (its end is the next staged run start): from
                     // the staged words; running on beyond it, or with more distinct references than the hash table
                     // holds: from global memory, at its own pace
+                    FPROF_T(l0);
                     const uint32_t end_off = next_run_start(st1, lane, off + 64u);
                     if (end_off < kStageRecs && long_run_staged(st1, st2, off, end_off, lane, so, tgt_ref, tgt_gbin, tab)) {
                         off = end_off;
@@ -951,6 +1008,8 @@ __global__ __launch_bounds__(kFrontBlock, 4) void k_front(const Acc acc, uint32_
                         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this path's loads stay out of the other windows' waits
                         off = end - B < kStageRecs ? next_run_start(st1, lane, end - B) : kStageRecs;
                     }
+                    FPROF_T(l1);
+                    FPROF_ADD(3, l0, l1);  // (runs of 64 records or more)
                 }
             }
         }

@@ -82,7 +82,7 @@ typedef struct {
 /* slimm::slimm(options) + the per-file reference initialisation of get_profiles() (src/slimm.hpp:96-101, 420-445). */
 int slimm_create(const slimm_config* cfg, slimm_ctx** out);
 void slimm_destroy(slimm_ctx* ctx);
-const char* slimm_last_error(const slimm_ctx* ctx); /* ctx may be NULL: error of the last failed slimm_create */
+const char* slimm_last_error(const slimm_ctx* ctx); /* ctx may be NULL: error of the calling thread's last failed slimm_create */
 
 /* slimm::reset() (src/slimm.hpp:167-188): forget records and results, keep configuration, allocations and --
  * like the reference -- the cached cut-offs (quirk Q8: they survive reset in -d mode). */

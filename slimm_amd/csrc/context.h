@@ -27,7 +27,7 @@ namespace slimm {
 
 
 
-extern std::string g_create_error;
+extern thread_local std::string g_create_error;
 
 template <typename T>
 struct DevBuf {

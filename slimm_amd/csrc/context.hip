@@ -10,7 +10,7 @@
 
 namespace slimm {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // (of the calling thread: a group creates its members side by side)
 const char* kKernelNames[K_COUNT] = {"memset_bins", "k_group_count", "k_group_scan", "k_group_scatter", "k_group_finish",
                                      "k_front", "k_hist", "k_ref_stats", "k_filter", "k_ref_stats2",
                                      "k_tile_count", "k_tile_scan", "k_tile_scatter", "k_tile_hist",

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/slimm_hip.h"
@@ -440,16 +441,32 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
     bool distinct = true;
     for (uint32_t i = 0; i < n_devices; ++i)
         for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
-    for (uint32_t i = 0; i < n_devices; ++i) {
-        slimm_config c = *cfg;
-        c.device = devices[i];
-        slimm_ctx* ctx = nullptr;
-        int rc = slimm_create(&c, &ctx);
-        if (rc != SLIMM_OK) {
-            g_group_create_error = std::string("member ") + std::to_string(i) + ": " + slimm_last_error(nullptr);
+    // the members' contexts side by side, a thread each: a device's part of the HIP runtime starts with its first context,
+    // and the tables of eight members one after the other are eight times one member's
+    std::vector<slimm_ctx*> made(n_devices, nullptr);
+    std::vector<int> made_rc(n_devices, SLIMM_OK);
+    std::vector<std::string> made_err(n_devices);
+    {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < n_devices; ++i)
+            th.emplace_back([&, i] {
+                slimm_config c = *cfg;
+                c.device = devices[i];
+                made_rc[i] = slimm_create(&c, &made[i]);
+                if (made_rc[i] != SLIMM_OK) made_err[i] = slimm_last_error(nullptr);
+            });
+        for (auto& t : th) t.join();
+    }
+    for (uint32_t i = 0; i < n_devices; ++i)
+        if (made_rc[i] != SLIMM_OK) {
+            g_group_create_error = std::string("member ") + std::to_string(i) + ": " + made_err[i];
+            for (slimm_ctx* c : made)
+                if (c) slimm_destroy(c);
             slimm_group_destroy(g);
-            return rc;
+            return made_rc[i];
         }
+    for (uint32_t i = 0; i < n_devices; ++i) {
+        slimm_ctx* ctx = made[i];
         g->ctx.push_back(ctx);
         g->device.push_back(devices[i]);
         void* s = nullptr;
@@ -465,6 +482,7 @@ int slimm_group_create(const slimm_config* cfg, const int* devices, uint32_t n_d
         if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
             g_group_create_error = "hipEventCreate failed";
+            for (uint32_t j = i + 1; j < n_devices; ++j) slimm_destroy(made[j]);  // (the group does not hold them yet)
             slimm_group_destroy(g);
             return SLIMM_E_HIP;
         }

@@ -54,12 +54,17 @@ std::string library_path() {
     if (const char* e = getenv("SLIMM_HIP_LIB")) return e;
     return dir + "libslimm_hip.so";
 }
-void load(int device) {
+void load(const std::vector<int>& devices) {  // (the devices of --devices start side by side: a thread each)
     void* h = dlopen(library_path().c_str(), RTLD_NOW | RTLD_LOCAL);
     std::string err = h ? "" : dlerror();
     if (h) {
         auto warm = reinterpret_cast<int (*)(int)>(dlsym(h, "slimm_warm_up"));
-        if (warm) (void)warm(device);
+        std::vector<std::thread> others;
+        for (size_t i = 1; warm && i < devices.size(); ++i)
+            if (std::find(devices.begin(), devices.begin() + static_cast<long>(i), devices[i]) == devices.begin() + static_cast<long>(i))
+                others.emplace_back([warm, d = devices[i]] { (void)warm(d); });
+        if (warm && !devices.empty()) (void)warm(devices[0]);
+        for (auto& t : others) t.join();
     }
     std::lock_guard<std::mutex> g(mu);
     handle = h;
@@ -1270,7 +1275,7 @@ int main(int argc, char** argv) {
         ~WarmUp() {
             if (t.joinable()) t.join();
         }
-    } warm_up{std::thread([device = S.options.device] { lazy::load(device); })};
+    } warm_up{std::thread([devices = S.options.devices.size() > 1 ? S.options.devices : std::vector<int>{S.options.device}] { lazy::load(devices); })};
     Lap watch;
     // slimm::slimm(): collect_bam_files + load_slimm_database (src/slimm.hpp:96-101, 306-326)
     if (S.options.is_directory) {

@@ -98,10 +98,15 @@ struct slimm_ctx {
     hipStream_t stream = nullptr;
     // streamed ingest (slimm_push_records_async): host -> device copies on a stream of their own, ordered before phase A
     // by an event (never by the host); two page-locked staging sets for callers that produce records piecemeal
-    // the copy stream, the side stream and the inflaters' streams are made when first used (need_stream below): a process has
-    // few hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise), streams beyond them share one and wait for each
-    // other, and the members of a group on one device count together -- `slimm --devices 0,0` on 100 M records had every
-    // second window's inflate wait 26-30 ms behind another stream's work with three streams made at slimm_create
+    // Streams and HARDWARE QUEUES.  A process has few hardware queues per device (four of each priority class unless
+    // GPU_MAX_HW_QUEUES says otherwise); the runtime deals streams to them as they are made, and streams that share one wait
+    // for each other.  Which of the window pipeline's streams shared decided whether `slimm DB 100M.bam` spent 110-210 or
+    // 320-360 ms in slimm_push_bgzf_blocks (every odd window's inflate 18 ms late), and differently for one context and for a
+    // group's two members on one device (profiles/round6/11_*).  So the streams are told apart by PRIORITY CLASS, which the
+    // runtime keeps in separate queue pools: the copy stream high (its work is the DMA engine's; what it needs is to be
+    // seen at once), the two inflate streams low (long kernels that fill what is free), the main stream and the side stream
+    // normal -- no class holds more than four streams even with two members on one device.  The copy stream, the side
+    // stream and the inflaters' streams are made when first used (need_stream below).
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_done = nullptr;
     bool copy_pending = false;
@@ -379,7 +384,14 @@ int bam_fetch_q18(slimm_ctx* c);   // windows.hip: the Q18 run counts of the dev
 // an array the file's record form does not use is neither allocated nor copied).
 // later != nullptr: no hipFree now (it waits for every kernel in flight -- the inflate of the windows behind this one):
 // what the array was goes there and is freed when the file has ended
-inline hipError_t need_stream(hipStream_t& s) { return s ? hipSuccess : hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+enum StreamClass { kStreamHigh = 0, kStreamNormal = 1, kStreamLow = 2 };
+inline hipError_t need_stream(hipStream_t& s, StreamClass cls = kStreamNormal) {
+    if (s) return hipSuccess;
+    int least = 0, greatest = 0;  // (numerically: greatest priority = the smallest number)
+    if (cls == kStreamNormal || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
+        return hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(&s, hipStreamNonBlocking, cls == kStreamHigh ? greatest : least);
+}
 
 template <typename T>
 hipError_t grow_record_array(DevBuf<T>& buf, uint64_t cap, uint64_t used, hipStream_t st, std::vector<void*>* later = nullptr) {

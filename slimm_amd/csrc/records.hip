@@ -112,7 +112,7 @@ int slimm_push_records_async(slimm_ctx* c, const uint64_t* key, const int32_t* r
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     if (c->in_flag.cap < c->in_key.cap) HIP_TRY(c, c->in_flag.ensure(c->in_key.cap));
-    HIP_TRY(c, need_stream(c->copy_stream));
+    HIP_TRY(c, need_stream(c->copy_stream, kStreamHigh));
     const uint64_t o = c->n_pushed;
     HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, c->copy_stream));
@@ -142,7 +142,7 @@ static int push_packed(slimm_ctx* c, const uint64_t* key, const int32_t* ref, co
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     const uint64_t o = c->n_pushed;
-    if (on_copy_stream) HIP_TRY(c, need_stream(c->copy_stream));
+    if (on_copy_stream) HIP_TRY(c, need_stream(c->copy_stream, kStreamHigh));
     hipStream_t st = on_copy_stream ? c->copy_stream : c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->in_key.p + o, key, n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, ref, n * 4, hipMemcpyHostToDevice, st));
@@ -192,7 +192,7 @@ static int push_marked(slimm_ctx* c, const uint32_t* word, const int32_t* pos, u
     int rc = slimm_reserve(c, c->n_pushed + n);
     if (rc != SLIMM_OK) return rc;
     const uint64_t o = c->n_pushed;
-    if (on_copy_stream) HIP_TRY(c, need_stream(c->copy_stream));
+    if (on_copy_stream) HIP_TRY(c, need_stream(c->copy_stream, kStreamHigh));
     hipStream_t st = on_copy_stream ? c->copy_stream : c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->in_ref.p + o, word, n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(c->in_pos.p + o, pos, n * 4, hipMemcpyHostToDevice, st));

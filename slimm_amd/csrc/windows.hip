@@ -284,7 +284,7 @@ int bam_launch_gathered(slimm_ctx* c) {
                               c->copy_stream));
     HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b, 0, 16, c->copy_stream));
     HIP_TRY(c, hipMemsetAsync(B.inflate_status.p + 4u * b + 1u, 0xff, 4, c->copy_stream));
-    if (!B.inflate_stream[si]) HIP_TRY(c, hipStreamCreateWithFlags(&B.inflate_stream[si], hipStreamNonBlocking));
+    HIP_TRY(c, need_stream(B.inflate_stream[si], kStreamLow));
     if (!B.comp_copied) HIP_TRY(c, hipEventCreateWithFlags(&B.comp_copied, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(B.comp_copied, c->copy_stream));
     HIP_TRY(c, hipStreamWaitEvent(B.inflate_stream[si], B.comp_copied, 0));
@@ -351,7 +351,7 @@ int bam_push_window(slimm_ctx* c, const uint8_t* bytes, uint64_t src_bytes, int 
     if (c->n_pushed && !c->bam.active)
         return fail(c, SLIMM_E_INVALID, "earlier batches were decoded records: the forms do not mix within a file");
     (void)hipSetDevice(c->device);
-    HIP_TRY(c, need_stream(c->copy_stream));
+    HIP_TRY(c, need_stream(c->copy_stream, kStreamHigh));
     slimm_ctx::BamDecode& B = c->bam;
     hipStream_t st = c->stream;
     if (!B.active) {  // a file's first window

@@ -68,6 +68,8 @@ static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int
     return hipSuccess;
 }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int priority);
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);

@@ -305,6 +305,12 @@ hipError_t hipGetDevice(int* d) {
     *d = 0;
     return hipSuccess;
 }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) {
+    if (least) *least = 1;
+    if (greatest) *greatest = -1;
+    return hipSuccess;
+}
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
     *s = &g_the_stream;
     return hipSuccess;

@@ -391,6 +391,20 @@ class Slimm:
             cache[name] = t
         return t
 
+    def _after_torch(self):
+        """Before a call that reads device memory the caller has written with torch (a gathered summary, a buffer reduced in
+        place): torch's work on ITS current stream must be done -- the library's kernels run on the context's own stream,
+        which waits for no other.  Nothing to do when the caller works under `torch.cuda.stream(engine.torch_stream())`."""
+        import sys
+
+        torch = sys.modules.get("torch")
+        if self.device is None or self.device < 0 or torch is None or not torch.cuda.is_initialized():
+            return  # (no torch in this process, or none that has touched the device: nothing of its is under way)
+        cur = torch.cuda.current_stream(self.device)
+        ext = getattr(self, "_ext_stream", None)
+        if ext is None or cur.cuda_stream != ext.cuda_stream:
+            cur.synchronize()
+
     def torch_stream(self):
         """The HIP stream the context's kernels run on, as a torch.cuda.ExternalStream.  Asking for it switches the
         context to stream-ordered buffers (slimm_set_stream_ordered): collectives issued under
@@ -431,6 +445,7 @@ class Slimm:
         import torch
 
         self._slices_keepalive = received
+        self._after_torch()
         ptr = C.c_void_p()
         n = C.c_uint64()
         self._check(self.L.slimm_merge_summary_slices(self.ctx, C.c_void_p(received.data_ptr()), int(n_ranks), int(rank),
@@ -438,6 +453,7 @@ class Slimm:
         return self._alias("sum_vec", ptr.value, n.value)
 
     def finish_coverage_reduced(self) -> bool:
+        self._after_torch()
         return self._check(self.L.slimm_finish_coverage_reduced(self.ctx)) != capi.E_NO_HITS
 
     def coverage_summary_tensor(self):
@@ -452,11 +468,13 @@ class Slimm:
     def finish_coverage_merged(self, gathered, n_ranks: int) -> bool:
         """`gathered`: int32 device tensor holding the summaries of all ranks back to back (all_gather output)."""
         self._merged_keepalive = gathered
+        self._after_torch()
         rc = self._check(self.L.slimm_finish_coverage_merged(self.ctx, C.c_void_p(gathered.data_ptr()), int(n_ranks)))
         return rc != capi.E_NO_HITS
 
     def finish_coverage(self) -> bool:
         """True when there are mapped records (False = the reference's 'No mapped reads' early return)."""
+        self._after_torch()
         return self._check(self.L.slimm_finish_coverage(self.ctx)) != capi.E_NO_HITS
 
     def set_coverage_columns(self, reads_count, uniq_reads_count, nz_cov, nz_uniq_cov, hits, matches) -> bool:
@@ -500,6 +518,7 @@ class Slimm:
         """Installs the (summed) partials buffer; returns the number of (taxon, reference) pairs over all ranks -- or None
         after filter_alignments_launch when some rank's pair set overflowed (every rank then launches again)."""
         total = C.c_uint32()
+        self._after_torch()
         if self._check(self.L.slimm_install_merged_partials(self.ctx, C.byref(total))) == capi.E_RETRY:
             return None
         return int(total.value)

@@ -312,7 +312,10 @@ int slimm_keep_bins(slimm_ctx* ctx, int on);
  * "bin != 0" bitmap).  slimm_coverage_summary() builds [sums | 16 scalars | cov bits | uniq_cov bits] for this rank in
  * device memory (*n_words uint32, about 1/16 of the bins); the caller all-gathers the summaries of all ranks into one
  * device buffer (rank-major, contiguous) and hands it to slimm_finish_coverage_merged(), which replaces
- * slimm_finish_coverage().  cov / uniq_cov then stay per-rank partial sums (slimm_get_bins returns this rank's share). */
+ * slimm_finish_coverage().  cov / uniq_cov then stay per-rank partial sums (slimm_get_bins returns this rank's share).
+ * Device memory the caller hands in (here and in the calls below) is read by kernels on the CONTEXT'S stream
+ * (slimm_get_stream), which waits for no other stream: whatever wrote it -- a collective, a copy -- must be complete, or have
+ * been enqueued on that stream. */
 int slimm_coverage_summary(slimm_ctx* ctx, void** d_ptr, uint64_t* n_words);
 int slimm_finish_coverage_merged(slimm_ctx* ctx, const void* d_gathered, uint32_t n_ranks);
 /* All-to-all form of the same exchange for many ranks (each rank receives 1/n of every other rank's bitmaps instead of

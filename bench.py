@@ -247,6 +247,8 @@ def main():
     ap.add_argument("--cpu-mt-sample", type=int, default=100_000_000, help="records the all-core CPU restatement is timed on")
     ap.add_argument("--no-cli", action="store_true", help="skip the `slimm DB IN.bam` end-to-end leg")
     ap.add_argument("--cli-records", type=int, default=100_000_000)
+    ap.add_argument("--cli-history", action="store_true",
+                    help="also: the SAM file through --host-decode and the 17.7-fold file of rounds 1 - 4 (a minute more)")
     ap.add_argument("--no-cli-1b", action="store_true", help="skip the command on the 1 B-record BAM (cli_end_to_end.one_billion)")
     ap.add_argument("--cli-1b-records", type=int, default=1_000_000_000)
     args = ap.parse_args()
@@ -1077,8 +1079,8 @@ def main():
                                            "sam_built_in_s": round(info_s["seconds"], 1)}
                         t1 = time.perf_counter()
                         rh2 = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm"), "--host-decode", "-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, sam],
-                                             capture_output=True, text=True)
-                        if rh2.returncode == 0:
+                                             capture_output=True, text=True) if args.cli_history else None
+                        if rh2 is not None and rh2.returncode == 0:
                             sec_h = time.perf_counter() - t1
                             cli["sam_text"]["host_decoder"] = {"value": round(nb / sec_h / 1e6, 3), "seconds": round(sec_h, 3),
                                                                "what": "--host-decode (rounds 1 - 4's SAM path), one run"}
@@ -1089,6 +1091,8 @@ def main():
                     cli["sam_text"] = {"error": repr(e)[:300]}
                 # rounds 1 - 4's file beside it: every sequence byte 0x11, every quality 0x28 -- 17.7-fold
                 try:
+                    if not args.cli_history:
+                        raise StopIteration
                     bam_e = os.path.join(tmp, "easy.bam")
                     info_e = write_synthetic_bam(bam_e, w_cli.ref_names, w_cli.ref_len, recb, read_len=w_cli.avg_read_len)
                     best_e, re_, prof_e = run_cli(bam_e, "easy")
@@ -1100,6 +1104,8 @@ def main():
                                             "same_profile": bool(prof_e == prof_g), "device_decode": dde,
                                             "bam_built_in_s": round(info_e["seconds"], 1)}
                     os.unlink(bam_e)
+                except StopIteration:
+                    pass
                 except Exception as e:
                     cli["easy_file"] = {"error": repr(e)[:300]}
             else:

@@ -10,7 +10,9 @@
 //                      it).  Canonical decoding without first-level tables: the next 15 stream bits, bit-reversed, are
 //                      compared with the 15 left-justified code-length limits held in REGISTERS (a subtraction and an
 //                      and-or per pair of lengths), which leaves LDS only the sorted symbols (9 + 5 bits) and one base per
-//                      length: 520 B per lane, 33 KB per wave -> four of them per CU where the table-driven kernel fits two.
+//                      length: 420 B per lane, 27 KB per wave -> five of them per CU where the table-driven kernel fits two
+//                      (what construction needs per length lives in the bases' bytes while a header is read; the
+//                      code-length code stays in registers).
 //                      TWO waves per 64 blocks: the DECODER wave does the above and hands one word per lane and step
 //                      (literals / a match / the end) through a ring in LDS to the WRITER wave, which puts literals
 //                      straight to their final place in the output (four at a time), turns matches into 4-byte TOKENS
@@ -57,11 +59,13 @@ constexpr uint32_t kLsymHi = 288;    //  36 B: their bit 8 (9 words)
 constexpr uint32_t kDsym = 324;      //  32 B: the 30 distance symbols in canonical order
 constexpr uint32_t kLbase = 356;     //  32 B: per code length, (symbols with shorter codes) - (first code of the length), 16 bits
 constexpr uint32_t kDbase = 388;     //  32 B: the same for the distance code
-constexpr uint32_t kTmpA = 420;      //  32 B: counts per length (construction)
-constexpr uint32_t kTmpB = 452;      //  32 B: next free place per length (construction)
-constexpr uint32_t kClSym = 484;     //  20 B: the code-length code's 19 symbols in canonical order (while a header is read)
-constexpr uint32_t kClBase = 504;    //  16 B: its bases (lengths 1 .. 7)
-constexpr uint32_t kLaneBytes = 520;
+// While a header is read the two base tables are not in use, and what construction needs per length -- counts, then the next
+// free place -- lives in THEIR bytes; the bases follow from where the places have got to when every symbol is in
+// (bases_from_ends).  The code-length code's 19 symbols and 7 bases stay in registers (ClCode).  420 B per lane instead of
+// 520: 26.9 KB of tables + 4 KB of ring per workgroup, FIVE decoder waves per CU instead of four.
+constexpr uint32_t kTmpB = kLbase;   //  counts of the distance code, then the literal/length code's next free places
+constexpr uint32_t kTmpA = kDbase;   //  counts of the literal/length code, then the distance code's next free places
+constexpr uint32_t kLaneBytes = 420;
 
 // (the same LDS bytes are read and written as bytes, halves and words: types that may alias)
 typedef uint16_t __attribute__((may_alias)) u16a;
@@ -137,29 +141,64 @@ __device__ __forceinline__ uint32_t top15(uint32_t w) { return __builtin_bitreve
 
 // From the counts per code length (LDS, 16 bits each, tmp A): the limits, the base per length (-> `base_at`), the first
 // free place per length (-> tmp B).  Returns the code's slack: 0 complete, > 0 incomplete, < 0 over-subscribed.
+// `bases8`: the bases of a code of at most 7 bits (the code-length code: 19 symbols, codes below 128), one signed byte per length.
 template <uint32_t kMaxLen>
-__device__ int code_from_counts(const Lds& L, uint32_t base_at, Limits& lim) {
+__device__ int code_from_counts(const Lds& L, Limits& lim, uint64_t* bases8) {
     uint32_t code = 0, offs = 0;
     int left = 1;
+    uint64_t b8 = 0;
 #pragma unroll
     for (uint32_t l = 1; l <= 15u; ++l) {
         const uint32_t c = l <= kMaxLen ? L.b16(kTmpA, l) : 0u;
         left = (left << 1) - static_cast<int>(c);
         lim.set(l - 1, (code + c) << (15u - l));
         if (l <= kMaxLen) {
-            L.b16(base_at, l) = static_cast<uint16_t>(offs - code);
+            if (kMaxLen <= 7u) b8 |= static_cast<uint64_t>((offs - code) & 0xffu) << (8u * l);
             L.b16(kTmpB, l) = static_cast<uint16_t>(offs);
         }
         offs += c;
         code = (code + c) << 1;
     }
+    if (bases8) *bases8 = b8;
     return left;
+}
+
+// Every symbol of a code is in its place: slot l of `at` holds where the symbols of length l END (= where those of length
+// l + 1 begin).  It becomes the length's base, (symbols with shorter codes) - (first code of the length).
+__device__ __forceinline__ void bases_from_ends(const Lds& L, uint32_t at) {
+    uint32_t code = 0, offs = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        const uint32_t end = L.b16(at, l);
+        const uint32_t c = end - offs;
+        L.b16(at, l) = static_cast<uint16_t>(offs - code);
+        offs = end;
+        code = (code + c) << 1;
+    }
 }
 
 __device__ __forceinline__ uint32_t symbol_at(const Lds& L, uint32_t base_at, uint32_t x, uint32_t len) {
     const uint32_t l = len > 15u ? 15u : len;
     return (L.b16(base_at, l) + (x >> (15u - l))) & 0xffffu;
 }
+
+// The code-length code of a dynamic block, in registers: limits, a signed byte of base per length (1 .. 7), the 19 symbols in
+// canonical order at 5 bits each (twelve to a word).
+struct ClCode {
+    Limits lim;
+    uint64_t bases8, sym_a, sym_b;
+    __device__ __forceinline__ void put(uint32_t place, uint32_t s) {   // place < 19
+        if (place < 12u) sym_a |= static_cast<uint64_t>(s) << (5u * place);
+        else sym_b |= static_cast<uint64_t>(s) << (5u * (place - 12u));
+    }
+    __device__ __forceinline__ uint32_t index_of(uint32_t x, uint32_t len) const {   // len = 1 .. 7
+        const uint32_t base = static_cast<uint32_t>(static_cast<int32_t>(static_cast<int8_t>(bases8 >> (8u * len))));
+        return (base + (x >> (15u - len))) & 0xffffu;
+    }
+    __device__ __forceinline__ uint32_t symbol(uint32_t idx) const {   // idx < 19
+        return static_cast<uint32_t>(idx < 12u ? sym_a >> (5u * idx) : sym_b >> (5u * (idx - 12u))) & 31u;
+    }
+};
 
 enum : uint32_t { kModeHeader = 0, kModeDecode = 1, kModeDone = 2, kModeHandOver = 3 };
 
@@ -194,15 +233,14 @@ struct HeaderBits {
 };
 
 // The code lengths of a dynamic block as runs {length value, repeat}: decoded from the stream with the code-length code
-// (limits `cl`, symbols at kClSym, bases at kClBase).  prev = the length before (for symbol 16).  Returns false for a bad code.
-__device__ __forceinline__ bool next_run(HeaderBits& hb, const Lds& L, const Limits& cl, uint32_t& prev, uint32_t& val, uint32_t& rep,
-                                         bool first) {
+// (`cl`: ClCode).  prev = the length before (for symbol 16).  Returns false for a bad code.
+__device__ __forceinline__ bool next_run(HeaderBits& hb, const ClCode& cl, uint32_t& prev, uint32_t& val, uint32_t& rep, bool first) {
     const uint32_t x = hb.peek15();
-    const uint32_t len = cl.length_of(x);
+    const uint32_t len = cl.lim.length_of(x);
     if (len > 7u) return false;
-    const uint32_t idx = symbol_at(L, kClBase, x, len);
+    const uint32_t idx = cl.index_of(x, len);
     if (idx >= 19u) return false;
-    const uint32_t sym = L.b8(kClSym, idx);
+    const uint32_t sym = cl.symbol(idx);
     hb.b.drop(len);
     if (sym < 16u) {
         val = sym;
@@ -236,8 +274,9 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
     const uint32_t type = hb.take(2);
     if (type != 1u && type != 2u) return kModeHandOver;  // stored blocks (and type 3) are the other kernel's
     uint32_t nlen = 288, ndist = 30;
-    Limits cl;
-    cl.clear();
+    ClCode cl;
+    cl.lim.clear();
+    cl.bases8 = cl.sym_a = cl.sym_b = 0;
     for (uint32_t l = 0; l < 16u; ++l) L.b16(kTmpA, l) = 0;   // (a table is only ever used through ONE element size: the lanes' elements interleave by it)
     if (type == 2u) {
         nlen = hb.take(5) + 257u;
@@ -254,11 +293,11 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
         }
         uint32_t n_cl = 0;
         for (uint32_t l = 1; l <= 7u; ++l) n_cl += L.b16(kTmpA, l);
-        const int slack = code_from_counts<7>(L, kClBase, cl);
+        const int slack = code_from_counts<7>(L, cl.lim, &cl.bases8);
         if (slack < 0 || (slack > 0 && n_cl != 1u) || n_cl == 0u) return kModeHandOver;
         for (uint32_t s = 0; s < 19u; ++s) {
             const uint32_t v = (cll[s >> 3] >> (3u * (s & 7u))) & 7u;
-            if (v) L.b8(kClSym, L.b16(kTmpB, v)++) = static_cast<uint8_t>(s);
+            if (v) cl.put(L.b16(kTmpB, v)++, s);
         }
     }
     // pass 1: how many codes of each length -- literal/length code in tmp A, distance code in tmp B
@@ -274,7 +313,7 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
         uint32_t index = 0, prev = 0;
         while (index < nlen + ndist) {
             uint32_t val, rep;
-            if (!next_run(hb, L, cl, prev, val, rep, index == 0u)) return kModeHandOver;
+            if (!next_run(hb, cl, prev, val, rep, index == 0u)) return kModeHandOver;
             if (index + rep > nlen + ndist) return kModeHandOver;
             if (val) {
                 const uint32_t in_l = index < nlen ? min(rep, nlen - index) : 0u;
@@ -292,7 +331,7 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
     for (uint32_t l = 0; l < 16u; ++l) dcnt[l] = L.b16(kTmpB, l);
     uint32_t n_l = 0;
     for (uint32_t l = 1; l <= 15u; ++l) n_l += L.b16(kTmpA, l);
-    const int lslack = code_from_counts<15>(L, kLbase, LL);
+    const int lslack = code_from_counts<15>(L, LL, nullptr);
     if (lslack < 0 || (lslack > 0 && n_l != 1u) || n_l == 0u) return kModeHandOver;
 #pragma unroll
     for (uint32_t l = 0; l < 16u; ++l) L.b16(kTmpA, l) = static_cast<uint16_t>(dcnt[l]);
@@ -306,7 +345,6 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
             n_d += c;
             left = (left << 1) - static_cast<int>(c);
             DL.set(l - 1, (code + c) << (15u - l));
-            L.b16(kDbase, l) = static_cast<uint16_t>(offs - code);
             places[l] = offs;
             offs += c;
             code = (code + c) << 1;
@@ -326,14 +364,14 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
             L.b8(kLsymLo, at) = static_cast<uint8_t>(s);
             if (s >= 256u) L.b32(kLsymHi, at >> 5) |= 1u << (at & 31u);
         }
-        for (uint32_t s = 0; s < 30u; ++s) L.b8(kDsym, s) = static_cast<uint8_t>(s);
+        for (uint32_t s = 0; s < 30u; ++s) L.b8(kDsym, L.b16(kTmpA, 5)++) = static_cast<uint8_t>(s);
     } else {
         const Bits end1 = bits;
         bits = saved;
         uint32_t index = 0, prev = 0;
         while (index < nlen + ndist) {
             uint32_t val = 0, rep = 1;
-            if (!next_run(hb, L, cl, prev, val, rep, index == 0u)) return kModeHandOver;  // (cannot happen: pass 1 took these runs)
+            if (!next_run(hb, cl, prev, val, rep, index == 0u)) return kModeHandOver;  // (cannot happen: pass 1 took these runs)
             if (val) {
                 for (uint32_t k = 0; k < rep; ++k) {
                     const uint32_t s = index + k;
@@ -350,6 +388,9 @@ __device__ uint32_t read_header(Bits& bits, const uint8_t* in, uint32_t csize, c
         }
         (void)end1;
     }
+    // the places have run to the ends of their lengths: the bases take their bytes
+    bases_from_ends(L, kLbase);
+    bases_from_ends(L, kDbase);
     return kModeDecode;
 }
 

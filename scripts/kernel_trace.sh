@@ -1,7 +1,8 @@
-# rocprofv3 kernel trace + stats of the default bench; summary goes to gpurun_out/<tag>/
+# rocprofv3 kernel trace + stats of the default bench (its own steps and warm-up: the first launch of a kernel in a process is
+# 20-40 % slower than the rest, and an average over eight launches carries it); summary goes to gpurun_out/<tag>/
 TAG=${1:-trace}
 export TMPDIR=/tmp; R=$PWD; mkdir -p $R/gpurun_out/$TAG; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -o t -- python3 $R/bench.py --steps 5 --warmup 2 --quick > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -o t -- python3 $R/bench.py --steps 20 --warmup 5 --quick > $R/gpurun_out/$TAG/bench.json 2> $R/gpurun_out/$TAG/bench.err
 python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("$R/gpurun_out/$TAG/t_kernel_trace.csv")))

@@ -33,15 +33,22 @@ int fail(slimm_ctx* c, int code, const char* fmt, ...) {
 
 
 void drain_events(slimm_ctx* c) {
+    bool unrecorded = false;
     for (auto& e : c->ev_used) {
         float ms = 0.f;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             c->k_ms[e.id] += ms;
             c->k_n[e.id] += 1;
+        } else {
+            unrecorded = true;
         }
         c->ev_free.push_back(e);
     }
     c->ev_used.clear();
+    // A pair that was never recorded (a launcher that had nothing to launch: a rank without records) makes
+    // hipEventElapsedTime fail with "invalid resource handle" -- and leaves that as the thread's last error, which the next
+    // slimm_analyze_alignments would report as its own (bench.py --gpus 2 with one chunk: the empty rank's second step).
+    if (unrecorded) (void)hipGetLastError();
 }
 
 int ensure_work_buffers(slimm_ctx* c, uint32_t n) {

@@ -182,3 +182,15 @@ def test_bench_eight_ranks_rehearsal_on_one_gpu():
     assert sp["kernels_ms"] > 0 and sp["collectives_ms"] > 0
     assert many["exchange_bins"]["same_profile"] is True
     print("N=8 rehearsal step_split:", json.dumps(sp))
+
+
+def test_bench_with_a_rank_that_holds_no_records():
+    """One chunk, two ranks: rank 0 owns nothing (partition.chunk_owner(1, 2) = [[], [0]]).  Its launchers have nothing to launch,
+    the kernel timers' event pairs stay unrecorded -- and reading them left "invalid resource handle" as the thread's last HIP
+    error, which the empty rank's SECOND step reported as its own (found with `bench.py --gpus 8 --records 40000000`: four chunks)."""
+    common = ["--records", "10000000", "--chunk-records", "10000000", "--steps", "2", "--warmup", "1", "--quick"]
+    one = _bench(common)
+    many = _bench(["--gpus", "2", "--backend", "gloo"] + common)
+    assert many["n_gpus"] == 2 and many["config"]["total_records"] == one["config"]["total_records"] == 10_000_000
+    for k in ("reads", "targets", "bins", "profile_rows", "profile_sha1"):
+        assert many["config"][k] == one["config"][k], k

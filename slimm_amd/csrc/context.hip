@@ -518,6 +518,7 @@ int slimm_analyze_alignments(slimm_ctx* c) {
     if (c->analyzed) return fail(c, SLIMM_E_INVALID, "already analysed; reset first");
     HostTrace tr("analyze_alignments");
     (void)hipSetDevice(c->device);
+    (void)hipGetLastError();  // (the launches below answer for themselves: what another user of the runtime left in this thread is not theirs)
     if (c->bam.active) {
         // (windows pushed so far may still be gathered or in flight: analysing now would profile a truncated record stream)
         if (!c->bam.closed)

@@ -17,6 +17,8 @@ first_prof = None
 # SLIMM_STALL_LIBS=a.so,b.so: the runs alternate between these builds of the library (one file, one box: a fair comparison);
 # SLIMM_STALL_PARENT_GPU=1: this process holds a GPU context of its own meanwhile (as bench.py does around its command legs)
 libs = [l for l in os.environ.get("SLIMM_STALL_LIBS", "").split(",") if l]
+# SLIMM_STALL_FLAGS="--read-buffers 4|--read-buffers 8": the runs alternate between these sets of flags of the command
+flag_sets = [f.split() for f in os.environ.get("SLIMM_STALL_FLAGS", "").split("|") if f.strip()]
 if os.environ.get("SLIMM_STALL_PARENT_GPU") == "1":
     import torch
     hold = torch.zeros(1 << 28, device="cuda:0")
@@ -26,7 +28,8 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
     if libs:
         env["SLIMM_HIP_LIB"] = os.path.abspath(libs[rep % len(libs)])
     t0 = time.time()
-    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm")] + sys.argv[2:] + ["-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
+    extra = flag_sets[rep % len(flag_sets)] if flag_sets else []
+    r = subprocess.run([os.path.join(ROOT, "slimm_amd", "slimm")] + sys.argv[2:] + extra + ["-w", "1000", "-o", os.path.join(tmp, "out") + "/", db, bam], capture_output=True, text=True,
                        env=env)
     dt = time.time() - t0
     prof = open(os.path.join(tmp, "out", "r_profile.tsv")).read() if r.returncode == 0 else None
@@ -41,7 +44,7 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 14):
             w = int(ln.split("finished window")[1].split(":")[0])
             waits[w & 1] += float(ln.split("[push")[1].split("]")[0]) - t_fin
     print(f"finishing even/odd windows {waits[0]:.0f}/{waits[1]:.0f} ms ", end="")
-    print((os.path.basename(os.path.dirname(env["SLIMM_HIP_LIB"])) + " " if libs else "") + f"push {push[0] if push else '?'} ms ", end="")
+    print((os.path.basename(os.path.dirname(env["SLIMM_HIP_LIB"])) + " " if libs else "") + (" ".join(extra) + " " if extra else "") + f"push {push[0] if push else '?'} ms ", end="")
     print(f"run {rep}: wall {dt:.3f} s = {n / dt / 1e6:.0f} M records/s, rc {r.returncode}, profile {'the same' if prof == first_prof and prof else 'DIFFERS / MISSING'}"
           + ("" if r.returncode == 0 else " -- " + r.stderr[-300:].replace("\n", " | ")), flush=True)
     if rep == 0 and os.environ.get("SLIMM_STALL_FULL"):
